@@ -1,0 +1,251 @@
+/*
+ * pmcx.h -- C-ABI of the MI355X-native PartMC microphysics path.
+ *
+ * Drop-in boundary for the per-grid-cell loop body of
+ *     partmc_timestep          /root/reference/interface/wrf_pmc_driver.F90:46-290
+ * i.e. the calls WRF-PartMC makes per owned cell every chemistry step:
+ *     mc_coag(COAG_KERNEL_TYPE_BROWN, env_state, aero_data, aero_state,
+ *             del_t, n_samp, n_coag)                        driver:192-194
+ *     aero_state_rebalance(aero_state, aero_data, allow_doubling,
+ *             allow_halving, ...)                           driver:248-250
+ *     aero_info_array_zero                                  driver:251
+ * and the partmc_process observables                        driver:783,838-857.
+ *
+ * The reference has no FFI: Fortran owns aero_state_t (allocatable components,
+ * not C-interoperable), so the binding a maintainer adds is the
+ * ISO_C_BINDING module wrf-partmc_amd/fortran/pmcx_shim.F90 (see
+ * INTEGRATION.md), which gathers aero_state_t into the flat arrays below.
+ *
+ * Conventions: plain pointers and sizes, host pointers unless a name ends in
+ * _dev; every function returns 0 on success or a PMCX_E* code and
+ * pmcx_last_error() gives the message (the reference aborts on error,
+ * wrf_pmc_trans.F90:713; the Fortran shim maps non-zero to wrf_error_fatal).
+ * All cells of a context are batched: one call advances every cell.
+ * Indices are 0-based here; the shim converts Fortran's 1-based classes.
+ */
+#ifndef PMCX_H
+#define PMCX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMCX_VERSION 1
+
+/* Coagulation kernel ids, numbered as PartMC's COAG_KERNEL_TYPE_*
+ * (selected at wrf_pmc_driver.F90:192; objects interface/Makefile:24-30). */
+enum {
+    PMCX_COAG_KERNEL_TYPE_SEDI = 1,
+    PMCX_COAG_KERNEL_TYPE_ADDITIVE = 2,
+    PMCX_COAG_KERNEL_TYPE_CONSTANT = 3,
+    PMCX_COAG_KERNEL_TYPE_BROWN = 4,
+    PMCX_COAG_KERNEL_TYPE_ZERO = 5,
+    PMCX_COAG_KERNEL_TYPE_BROWN_SEDI = 101
+};
+
+/* error codes */
+enum {
+    PMCX_OK = 0,
+    PMCX_EINVAL = 1,   /* bad argument                                    */
+    PMCX_ENOMEM = 2,   /* device or host allocation failed                */
+    PMCX_EDEVICE = 3,  /* HIP runtime error / no usable gfx950 device     */
+    PMCX_ESTATE = 4,   /* call sequence error (e.g. bounds not computed)  */
+    PMCX_ECELL = 5     /* some cell raised a status bit that stops a step */
+};
+
+/* per-cell status bits (pmcx_get_coag_counters) */
+enum {
+    PMCX_ST_EVENT_OVERFLOW = 1,
+    PMCX_ST_APPEND_OVERFLOW = 2,
+    PMCX_ST_KMAX_EXCEEDED = 4,
+    PMCX_ST_OUT_OF_GRID = 8,
+    PMCX_ST_CAP_OVERFLOW = 16
+};
+
+typedef struct pmcx_ctx pmcx_ctx;
+
+typedef struct {
+    int32_t struct_size;  /* sizeof(pmcx_config), for ABI checking            */
+    int32_t device;       /* HIP device ordinal                               */
+    int32_t n_cells;      /* cells owned by this context (this GPU's block)   */
+    int32_t cap;          /* particle capacity per cell (<= 65280)            */
+    int32_t n_spec;       /* aero_data_n_spec                                 */
+    int32_t n_class;      /* weight classes (n_group is 1, driver:1706)       */
+    int32_t n_source;     /* width of the per-particle source histogram       */
+    int32_t n_bin;        /* aero_sorted bin grid: bins (<= 128)              */
+    double r_min, r_max;  /*   radius range, m                                */
+    int32_t max_events;   /* coagulation events per cell per mc_coag call     */
+    int32_t max_appends;  /* list appends per cell per call (<= 4096)         */
+    int32_t n_dbin;       /* diagnostics diameter grid (100, driver:783)      */
+    int32_t i_water;      /* 0-based index of H2O in aero_data, -1 if none    */
+    double d_min, d_max;  /*   1e-9, 1e-3 m (driver:783)                      */
+    uint32_t cell_id_base;/* global id of local cell 0: RNG key, so results
+                             do not depend on how cells are split over GPUs   */
+    uint32_t reserved;
+    double const_k;       /* constant-kernel value, m^3/s                     */
+    double additive_beta; /* additive-kernel coefficient, 1/s                 */
+} pmcx_config;
+
+/* Fills cfg with the reference's defaults (registry.partmc:1-38, driver:783). */
+void pmcx_config_default(pmcx_config *cfg);
+
+int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out);
+int pmcx_destroy(pmcx_ctx *ctx);
+const char *pmcx_last_error(const pmcx_ctx *ctx); /* ctx may be NULL: create errors */
+int pmcx_synchronize(pmcx_ctx *ctx);
+
+/* aero_data_t: density(:) [kg/m^3], kappa(:), molec_weight(:)
+ * (aero_data.dat columns; wrf_pmc_driver.F90:1420). kappa/molec_weight may be NULL. */
+int pmcx_set_aero_data(pmcx_ctx *ctx, const double *density, const double *kappa,
+                       const double *molec_weight);
+
+/* env_state_t fields the path reads (producer wrf_pmc_driver.F90:611-637),
+ * one value per cell.  rel_humid may be NULL. */
+int pmcx_set_env(pmcx_ctx *ctx, const double *temp, const double *pressure,
+                 const double *rel_humid);
+
+/* awa%weight(1,class)%magnitude, flat weights
+ * (AERO_STATE_WEIGHT_FLAT_SPECIFIED, wrf_pmc_init.F90:252-253): [n_cells][n_class] */
+int pmcx_set_weights(pmcx_ctx *ctx, const double *magnitude);
+int pmcx_get_weights(pmcx_ctx *ctx, double *magnitude);
+
+/* aero_state_set_n_part_ideal (wrf_pmc_init.F90:254): [n_cells][n_class] */
+int pmcx_set_n_part_ideal(pmcx_ctx *ctx, const double *n_ideal);
+
+/* next_id counters (module variable next_id, wrf_pmc_driver.F90:1652): [n_cells] */
+int pmcx_set_next_id(pmcx_ctx *ctx, const int64_t *next_id);
+int pmcx_get_next_id(pmcx_ctx *ctx, int64_t *next_id);
+
+/*
+ * Upload cells [cell_first, cell_first+n_up).  Particles of cell k occupy
+ * [part_offset[k], part_offset[k+1]) of the packed arrays (n_total =
+ * part_offset[n_up]):
+ *   vol      [n_spec][n_total]    particle%vol(:)           driver:1419-1420
+ *   wclass   [n_total]            particle%weight_class-1   driver:1447
+ *   id       [n_total]            particle%id               driver:1451
+ *   least_ct, greatest_ct [n_total]                         driver:1453-1456
+ *   n_orig   [n_source][n_total]  source histogram (replaces component(:),
+ *                                 driver:1421-1437); may be NULL
+ */
+int pmcx_upload_cells(pmcx_ctx *ctx, int32_t cell_first, int32_t n_up,
+                      const int64_t *part_offset, const double *vol,
+                      const int32_t *wclass, const int64_t *id,
+                      const double *least_ct, const double *greatest_ct,
+                      const int32_t *n_orig);
+
+/* aero_state_total_particles per cell (driver:143,174): [n_cells] */
+int pmcx_get_n_part(pmcx_ctx *ctx, int32_t *n_part);
+
+/* Mirror of upload; part_offset must be the exclusive prefix sum of the
+ * counts pmcx_get_n_part returned.  Any output pointer may be NULL. */
+int pmcx_download_cells(pmcx_ctx *ctx, int32_t cell_first, int32_t n_dn,
+                        const int64_t *part_offset, double *vol, int32_t *wclass,
+                        int64_t *id, double *least_ct, double *greatest_ct,
+                        int32_t *n_orig);
+
+/* est_k_minmax_binned_unweighted: (re)compute every cell's kernel upper
+ * bounds for kernel_type from the current env (PartMC caches this per
+ * aero_state, coag_kernel_bounds_valid). */
+int pmcx_update_kernel_bounds(pmcx_ctx *ctx, int32_t kernel_type);
+
+/*
+ * mc_coag on every cell (wrf_pmc_driver.F90:192-194).  Asynchronous on the
+ * context's stream.  seed = grid%random_seed (wrf_pmc_init.F90:131); step =
+ * chemistry-step index; together with the global cell id they key the
+ * counter-based RNG.
+ */
+int pmcx_mc_coag(pmcx_ctx *ctx, int32_t kernel_type, double del_t, uint64_t seed,
+                 uint32_t step);
+
+/* tot_n_samp, tot_n_coag of the last pmcx_mc_coag and the status bits,
+ * each [n_cells]; any pointer may be NULL.  Synchronises. */
+int pmcx_get_coag_counters(pmcx_ctx *ctx, int32_t *n_samp, int32_t *n_coag,
+                           int32_t *status);
+
+/* Sums over cells of the last call's counters (device-side reduction). */
+int pmcx_get_coag_totals(pmcx_ctx *ctx, int64_t *n_samp, int64_t *n_coag,
+                         int64_t *n_part, int32_t *status_or);
+
+/* aero_state_rebalance on every cell (wrf_pmc_driver.F90:248-250). */
+int pmcx_rebalance(pmcx_ctx *ctx, int32_t allow_doubling, int32_t allow_halving,
+                   uint64_t seed, uint32_t step);
+
+/* partmc_process observables (wrf_pmc_driver.F90:838-857):
+ * tot_num_conc[n_cells], tot_mass_conc[n_cells],
+ * num_dist[n_cells][n_dbin], mass_dist[n_cells][n_dbin]. */
+int pmcx_diagnostics(pmcx_ctx *ctx, double *tot_num_conc, double *tot_mass_conc,
+                     double *num_dist, double *mass_dist);
+
+/*
+ * Synthetic populations generated on the device (shape of
+ * aero_state_add_aero_dist_sample for log-normal modes,
+ * wrf_pmc_init.F90:1063,1764-1777): every cell gets n_part particles from
+ * the mode mixture.  mode_frac = number fractions; gm_radius in m;
+ * gsd_log10 = log10 of the geometric std dev; vol_frac[n_mode][n_spec];
+ * ids are cell_global_id*2^32 + slot.
+ */
+int pmcx_generate_lognormal(pmcx_ctx *ctx, int32_t n_part, int32_t n_mode,
+                            const double *mode_frac, const double *gm_radius,
+                            const double *gsd_log10, const double *vol_frac,
+                            const int32_t *mode_class, const int32_t *mode_source,
+                            uint64_t seed, double create_time);
+
+/* One partmc_timestep loop body over all cells (wrf_pmc_driver.F90:169-254):
+ * coagulation when do_coagulation and the chemistry-step gate holds
+ * (driver:189-198), then rebalance (driver:248-250).  Emission, sea salt
+ * and MOSAIC are outside this library. */
+typedef struct {
+    int32_t do_coagulation;  /* grid%do_coagulation                       */
+    int32_t allow_doubling;  /* grid%allow_doubling                       */
+    int32_t allow_halving;   /* grid%allow_halving                        */
+    int32_t kernel_type;     /* COAG_KERNEL_TYPE_BROWN in the reference   */
+    double dt;               /* grid%dt (WRF step)                        */
+    double partmc_chem_dt;   /* grid%partmc_chem_dt                       */
+    double elapsed_time;     /* env_state%elapsed_time at this call       */
+    uint64_t random_seed;    /* grid%random_seed                          */
+} pmcx_step_flags;
+
+int pmcx_timestep(pmcx_ctx *ctx, const pmcx_step_flags *flags);
+
+/* ---- introspection used by tests and by the roofline accounting ---- */
+
+int pmcx_get_bin_tables(pmcx_ctx *ctx, double *v_edge /*[n_bin+1]*/,
+                        double *v_samp /*[n_bin*3]*/);
+int pmcx_get_diag_grid(pmcx_ctx *ctx, double *d_edge /*[n_dbin+1]*/,
+                       double *d_width /*[n_dbin]*/);
+int pmcx_get_kmax(pmcx_ctx *ctx, int32_t cell, double *kmax /*[n_bin*n_bin]*/);
+/* cached per-particle totals: vtot, mass [cap] of one cell */
+int pmcx_get_caches(pmcx_ctx *ctx, int32_t cell, double *vtot, double *mass);
+/* sorted index lists of the last mc_coag's bin sort: perm[cap], group counts
+ * and offsets [n_class*n_bin] of one cell (valid after pmcx_sort_only) */
+int pmcx_sort_only(pmcx_ctx *ctx);
+int pmcx_get_sort(pmcx_ctx *ctx, int32_t cell, uint32_t *perm, int32_t *gcnt,
+                  int32_t *goff);
+
+/* Evaluate a device math routine elementwise (bitwise parity tests):
+ * op 0 exp, 1 log, 2 cbrt, 3 norminv, 4 sqrt, 5 a/b (in2 = b),
+ * 6 poisson(mean=in, u=in2), 7 kernel K(v1=in, m1=in2, v2=in3, m2=in4)
+ * at (temp, pressure) with kernel id ktype. */
+int pmcx_test_math(pmcx_ctx *ctx, int32_t op, int64_t n, const double *in,
+                   const double *in2, const double *in3, const double *in4,
+                   int32_t ktype, double temp, double pressure, double *out);
+int pmcx_test_philox(pmcx_ctx *ctx, const uint32_t ctr[4], const uint32_t key[2],
+                     uint32_t out[4]);
+
+/* Per-kernel device timing with HIP events on the context's stream.
+ * names: "bin_sort", "coag_sample", "coag_apply", "rebalance", "diagnostics",
+ * "kernel_bounds", "generate".  Returns the accumulated milliseconds and
+ * launch count since the last reset for one name. */
+int pmcx_profile_enable(pmcx_ctx *ctx, int32_t on);
+int pmcx_profile_reset(pmcx_ctx *ctx);
+int pmcx_profile_get(pmcx_ctx *ctx, const char *name, double *ms, int64_t *launches);
+
+/* device memory held by the context, bytes (replaces memtrack, interface/mem.c) */
+int pmcx_memory_bytes(pmcx_ctx *ctx, int64_t *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PMCX_H */

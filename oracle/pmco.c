@@ -1,0 +1,555 @@
+/*
+ * pmco.c -- ORACLE (test infrastructure, not product code).  See pmco.h.
+ *
+ * Serial restatement of mc_coag and its neighbours on the WRF-PartMC
+ * timestep.  Straight loops over explicit per-(class,bin) lists; no attempt
+ * at speed beyond what the cpu_baseline timing needs.
+ */
+#include "pmco.h"
+#include "pmco_math.h"
+
+#include <stdlib.h>
+
+/* ------------------------------------------------------------------------
+ * Physical constants (PartMC constants.F90 values; upstream, uncited).
+ * ---------------------------------------------------------------------- */
+#define PMCO_PI 3.14159265358979323846
+#define PMCO_BOLTZMANN 1.3806505e-23
+#define PMCO_AVOGADRO 6.02214179e23
+#define PMCO_UNIV_GAS 8.314472
+#define PMCO_AIR_MW 2.89644e-2
+#define PMCO_GRAV 9.80665
+
+/* exported wrappers of the inline building blocks (for the tests) */
+void pmco_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    out[0] = ctr[0]; out[1] = ctr[1]; out[2] = ctr[2]; out[3] = ctr[3];
+    pmco_philox4x32_10(out, key[0], key[1]);
+}
+double pmco_exp_(double x) { return pmco_exp(x); }
+double pmco_log_(double x) { return pmco_log(x); }
+double pmco_cbrt_(double x) { return pmco_cbrt(x); }
+double pmco_norminv_(double p) { return pmco_norminv(p); }
+int32_t pmco_poisson_(double mean, double u) { return pmco_poisson(mean, u); }
+
+/* ------------------------------------------------------------------------
+ * Coagulation kernels.
+ *
+ * Brownian: Fuchs interpolation between free-molecular and continuum
+ * regimes in the form of Jacobson (2005) eq. 15.33, which is the form
+ * PartMC's kernel_brown uses [upstream, uncited] and, up to the Cunningham
+ * slip constants, the form of WRFV3/chem/module_mosaic_coag.F:898-936
+ * (1.257/0.42/1.1 there; 1.249/0.42/0.87 here, Jacobson's values).
+ * ---------------------------------------------------------------------- */
+
+typedef struct {
+    double kT;          /* k_B T                              */
+    double viscosd;     /* dynamic viscosity of air, kg/m/s   */
+    double gasfreepath; /* mean free path of air, m           */
+    double rhoair;      /* dry-air density, kg/m^3            */
+} env_derived;
+
+typedef struct {
+    double rad, diffus, speedsq, deltasq, wfall;
+} part_props;
+
+static void env_derive(double temp, double pressure, env_derived *e)
+{
+    e->kT = PMCO_BOLTZMANN * temp;
+    e->rhoair = PMCO_AIR_MW * pressure / (PMCO_UNIV_GAS * temp);
+    double tr = temp / 296.16;
+    e->viscosd = (1.8325e-5 * (296.16 + 120.0) / (temp + 120.0)) * (tr * sqrt(tr));
+    double viscosk = e->viscosd / e->rhoair;
+    double gasspeed = sqrt(8.0 * PMCO_BOLTZMANN * temp * PMCO_AVOGADRO /
+                           (PMCO_PI * PMCO_AIR_MW));
+    e->gasfreepath = 2.0 * viscosk / gasspeed;
+}
+
+/* per-particle quantities of the Fuchs form, from volume v and mass m */
+static void particle_props(double v, double m, const env_derived *e, part_props *q)
+{
+    double rad = pmco_cbrt(v * (0.75 / PMCO_PI));
+    double knud = e->gasfreepath / rad;
+    double cunning = 1.0 + knud * (1.249 + 0.42 * pmco_exp(-0.87 / knud));
+    double diffus = e->kT * cunning / (6.0 * PMCO_PI * rad * e->viscosd);
+    double speedsq = (8.0 * e->kT / PMCO_PI) / m;
+    double freepath = 8.0 * diffus / (PMCO_PI * sqrt(speedsq));
+    double t1 = 2.0 * rad + freepath;
+    double tmp1 = t1 * t1 * t1;
+    double t2 = 4.0 * rad * rad + freepath * freepath;
+    double tmp2 = t2 * sqrt(t2);
+    double d = (tmp1 - tmp2) / (6.0 * rad * freepath) - 2.0 * rad;
+    q->rad = rad;
+    q->diffus = diffus;
+    q->speedsq = speedsq;
+    q->deltasq = d * d;
+    /* Stokes-Cunningham terminal velocity (sedimentation kernel) */
+    double rho = m / v;
+    q->wfall = (2.0 * rad * rad * (rho - e->rhoair) * PMCO_GRAV * cunning) /
+               (9.0 * e->viscosd);
+}
+
+static double brown_pair(const part_props *a, const part_props *b)
+{
+    double rad_sum = a->rad + b->rad;
+    double diffus_sum = a->diffus + b->diffus;
+    double tmp1 = rad_sum / (rad_sum + sqrt(a->deltasq + b->deltasq));
+    double tmp2 = 4.0 * diffus_sum / (rad_sum * sqrt(a->speedsq + b->speedsq));
+    return 4.0 * PMCO_PI * rad_sum * diffus_sum / (tmp1 + tmp2);
+}
+
+/* Gravitational collection: E * pi (r1+r2)^2 |w1-w2| with the Long (1974)
+ * polynomial collection efficiency (as tabulated in Bott 1998, eq. 12).
+ * The upstream coag_kernel_sedi uses a Hall (1980) efficiency table that is
+ * not available here; this closed form is the documented substitute. */
+static double sedi_pair(const part_props *a, const part_props *b)
+{
+    double r_big = a->rad > b->rad ? a->rad : b->rad;
+    double r_small = a->rad > b->rad ? b->rad : a->rad;
+    double eff;
+    if (r_big <= 50.0e-6) {
+        double rb_cm = r_big * 100.0, rs_cm = r_small * 100.0;
+        eff = 4.5e4 * rb_cm * rb_cm * (1.0 - 3.0e-4 / rs_cm);
+        if (eff < 1.0e-3) eff = 1.0e-3;
+    } else {
+        eff = 1.0;
+    }
+    double rs = a->rad + b->rad;
+    double dw = a->wfall - b->wfall;
+    if (dw < 0.0) dw = -dw;
+    return eff * PMCO_PI * rs * rs * dw;
+}
+
+static int kernel_needs_props(int type)
+{
+    return type == PMCO_KERNEL_BROWN || type == PMCO_KERNEL_SEDI ||
+           type == PMCO_KERNEL_BROWN_SEDI;
+}
+
+static double kernel_pair(int type, double v1, double v2, const part_props *a,
+                          const part_props *b, const pmco_kernel_params *kp)
+{
+    switch (type) {
+    case PMCO_KERNEL_BROWN: return brown_pair(a, b);
+    case PMCO_KERNEL_SEDI: return sedi_pair(a, b);
+    case PMCO_KERNEL_BROWN_SEDI: return brown_pair(a, b) + sedi_pair(a, b);
+    case PMCO_KERNEL_CONSTANT: return kp->const_k;
+    case PMCO_KERNEL_ADDITIVE: return kp->additive_beta * (v1 + v2);
+    default: return 0.0;
+    }
+}
+
+double pmco_kernel(int type, double v1, double m1, double v2, double m2,
+                   double temp, double pressure, const pmco_kernel_params *kp)
+{
+    env_derived e;
+    part_props a = {0}, b = {0};
+    env_derive(temp, pressure, &e);
+    if (kernel_needs_props(type)) {
+        particle_props(v1, m1, &e, &a);
+        particle_props(v2, m2, &e, &b);
+    }
+    return kernel_pair(type, v1, v2, &a, &b, kp);
+}
+
+/* ------------------------------------------------------------------------
+ * Sort grid (aero_sorted's bin_grid) and kernel bounds
+ * (est_k_minmax_binned_unweighted) [upstream, uncited].
+ * ---------------------------------------------------------------------- */
+
+void pmco_make_bin_tables(int n_bin, double r_min, double r_max, double *v_edge,
+                          double *v_samp)
+{
+    double l0 = log(r_min), l1 = log(r_max);
+    for (int k = 0; k <= n_bin; k++) {
+        double r = exp(l0 + (l1 - l0) * (double)k / (double)n_bin);
+        v_edge[k] = (4.0 / 3.0) * PMCO_PI * r * r * r;
+    }
+    for (int b = 0; b < n_bin; b++) {
+        v_samp[3 * b + 0] = v_edge[b];
+        v_samp[3 * b + 1] = sqrt(v_edge[b] * v_edge[b + 1]);
+        v_samp[3 * b + 2] = v_edge[b + 1];
+    }
+}
+
+/* bin b has v_edge[b] <= v < v_edge[b+1]; out-of-range volumes clamp */
+int pmco_bin_of(const double *v_edge, int n_bin, double v)
+{
+    int lo = 0, hi = n_bin; /* invariant: v_edge[lo] <= v < v_edge[hi] (clamped) */
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (v >= v_edge[mid]) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+void pmco_kmax_table(int type, int n_bin, const double *v_samp, double rho_min,
+                     double rho_max, double temp, double pressure,
+                     const pmco_kernel_params *kp, double *kmax)
+{
+    env_derived e;
+    env_derive(temp, pressure, &e);
+    int np = n_bin * 6; /* (bin, sample, density) */
+    part_props *pp = (part_props *)calloc((size_t)np, sizeof(part_props));
+    if (kernel_needs_props(type)) {
+        for (int b = 0; b < n_bin; b++)
+            for (int s = 0; s < 3; s++)
+                for (int d = 0; d < 2; d++) {
+                    double v = v_samp[3 * b + s];
+                    double rho = d ? rho_max : rho_min;
+                    particle_props(v, v * rho, &e, &pp[(b * 3 + s) * 2 + d]);
+                }
+    }
+    for (int b1 = 0; b1 < n_bin; b1++)
+        for (int b2 = 0; b2 < n_bin; b2++) {
+            double km = 0.0;
+            for (int s1 = 0; s1 < 3; s1++)
+                for (int s2 = 0; s2 < 3; s2++)
+                    for (int d1 = 0; d1 < 2; d1++)
+                        for (int d2 = 0; d2 < 2; d2++) {
+                            double k = kernel_pair(
+                                type, v_samp[3 * b1 + s1], v_samp[3 * b2 + s2],
+                                &pp[(b1 * 3 + s1) * 2 + d1],
+                                &pp[(b2 * 3 + s2) * 2 + d2], kp);
+                            if (k > km) km = k;
+                        }
+            kmax[b1 * n_bin + b2] = km;
+        }
+    free(pp);
+}
+
+/* ------------------------------------------------------------------------
+ * Caches.
+ * ---------------------------------------------------------------------- */
+
+static void refresh_one(pmco_cell *c, int i)
+{
+    double vt = 0.0, ms = 0.0;
+    for (int s = 0; s < c->n_spec; s++) {
+        double v = c->vol[(size_t)s * c->cap + i];
+        vt = vt + v;
+        ms = ms + c->density[s] * v;
+    }
+    c->vtot[i] = vt;
+    c->mass[i] = ms;
+}
+
+void pmco_refresh_caches(pmco_cell *c)
+{
+    for (int i = 0; i < *c->n_part; i++) refresh_one(c, i);
+}
+
+/* ------------------------------------------------------------------------
+ * mc_coag.
+ *
+ * Spec (DESIGN.md "mc_coag semantics"): particles are sorted into groups
+ * g = class*n_bin + bin, lists in ascending slot order.  Slots (pairs of
+ * groups) are visited in the order c1, c2<=c1, b1, b2 (b2>=b1 when c1==c2)
+ * [loop nest of PartMC mc_coag].  Per slot: n_samp ~ Poisson(k_max dt
+ * n_pairs) [compute_n_samp]; per sample: uniform pair [find_rand_pair],
+ * accept with K f / (k_max f_max) [maybe_coag_pair, num_conc_weighted_kernel],
+ * weighted removal [coagulate_weighting]; flat weights only
+ * (AERO_STATE_WEIGHT_FLAT_SPECIFIED, wrf_pmc_init.F90:252-253).
+ * ---------------------------------------------------------------------- */
+
+typedef struct { int32_t *e; int32_t n, cap; } ilist;
+
+static void il_push(ilist *l, int32_t x)
+{
+    if (l->n == l->cap) {
+        l->cap = l->cap ? 2 * l->cap : 8;
+        l->e = (int32_t *)realloc(l->e, sizeof(int32_t) * (size_t)l->cap);
+    }
+    l->e[l->n++] = x;
+}
+
+typedef struct { int32_t pn, po, rem_o, cc; } coag_event;
+
+static void compact_tail_fill(pmco_cell *c, const unsigned char *dead, int n_old,
+                              int n_dead);
+
+int pmco_mc_coag(pmco_cell *c, int kernel_type, const pmco_kernel_params *kp,
+                 double del_t, uint64_t seed, uint32_t cell_id, uint32_t step,
+                 int32_t *n_samp_out, int32_t *n_coag_out)
+{
+    const int B = c->n_bin, C = c->n_class, G = B * C;
+    const int n0 = *c->n_part;
+    int status = 0;
+    int64_t tot_samp = 0;
+    int32_t tot_coag = 0;
+    env_derived env;
+    env_derive(c->temp, c->pressure, &env);
+    const int use_props = kernel_needs_props(kernel_type);
+
+    ilist *L = (ilist *)calloc((size_t)G, sizeof(ilist));
+    coag_event *ev = (coag_event *)malloc(sizeof(coag_event) * (size_t)(c->max_events > 0 ? c->max_events : 1));
+    int n_ev = 0, n_app = 0;
+
+    /* aero_state_sort: ascending slot order inside every group */
+    for (int i = 0; i < n0; i++) {
+        double v = c->vtot[i];
+        if (v < c->v_edge[0] || v >= c->v_edge[B]) status |= PMCO_ST_OUT_OF_GRID;
+        int g = c->wclass[i] * B + pmco_bin_of(c->v_edge, B, v);
+        il_push(&L[g], i);
+    }
+
+    int stop = 0;
+    for (int c1 = 0; c1 < C && !stop; c1++)
+    for (int c2 = 0; c2 <= c1 && !stop; c2++)
+    for (int b1 = 0; b1 < B && !stop; b1++)
+    for (int b2 = (c1 == c2 ? b1 : 0); b2 < B && !stop; b2++) {
+        const int gA = c1 * B + b1, gB = c2 * B + b2;
+        const int same = (gA == gB);
+        ilist *A = &L[gA], *Bl = &L[gB];
+        if (A->n == 0 || Bl->n == 0 || (same && A->n < 2)) continue;
+        const double n1 = c->mag[c1], n2 = c->mag[c2];
+        const int cc = (n1 < n2) ? c1 : c2;       /* coag_dest_class, flat */
+        const double nmin = (n1 < n2) ? n1 : n2;
+        const double fmax = (n1 < n2) ? n2 : n1;  /* max_coag_num_conc_factor */
+        const double k_max = c->kmax[b1 * B + b2] * fmax;
+        const double n_possible = same ? (double)A->n * ((double)A->n - 1.0) / 2.0
+                                       : (double)A->n * (double)Bl->n;
+        const double mean = k_max * del_t * n_possible;
+        const uint32_t slot = ((uint32_t)gA << 16) | (uint32_t)gB;
+        uint32_t w[4];
+        pmco_rng_block(seed, cell_id, step, slot, PMCO_SITE_POISSON, 0, w);
+        const int32_t ns = pmco_poisson(mean, pmco_u53(w[0], w[1]));
+        tot_samp += ns;
+        const double accept_factor = 1.0 / k_max;
+        const double factor = n1 * n2 / nmin;     /* coag_num_conc_factor, flat */
+
+        for (int32_t s = 0; s < ns; s++) {
+            const int nA = A->n, nB = Bl->n;
+            if (nA < 1 || nB < 1 || (same && nA < 2)) break;
+            pmco_rng_block(seed, cell_id, step, slot, PMCO_SITE_CAND, (uint32_t)s, w);
+            int i1 = (int)pmco_index(w[0], (uint32_t)nA), i2;
+            if (same) {
+                i2 = (int)pmco_index(w[1], (uint32_t)(nA - 1));
+                if (i2 >= i1) i2++;
+            } else {
+                i2 = (int)pmco_index(w[1], (uint32_t)nB);
+            }
+            const int p1 = A->e[i1], p2 = Bl->e[i2];
+            const double v1 = c->vtot[p1], v2 = c->vtot[p2];
+            const double m1 = c->mass[p1], m2 = c->mass[p2];
+            part_props q1 = {0}, q2 = {0};
+            if (use_props) {
+                particle_props(v1, m1, &env, &q1);
+                particle_props(v2, m2, &env, &q2);
+            }
+            const double k = kernel_pair(kernel_type, v1, v2, &q1, &q2, kp);
+            const double p = (k * factor) * accept_factor;
+            if (p > 1.0) status |= PMCO_ST_KMAX_EXCEEDED;
+            if (!(pmco_u53(w[2], w[3]) < p)) continue;
+
+            /* ---- coagulate ---- */
+            if (n_ev >= c->max_events) { status |= PMCO_ST_EVENT_OVERFLOW; stop = 1; break; }
+            pmco_rng_block(seed, cell_id, step, slot, PMCO_SITE_COAG, (uint32_t)s, w);
+            const int rem1 = pmco_u53(w[0], w[1]) < nmin / n1;
+            const int rem2 = pmco_u53(w[2], w[3]) < nmin / n2;
+            const double vn = v1 + v2, mn = m1 + m2;
+            const int big1 = (v1 >= v2);
+            int pn_is_1;
+            if (rem1 && rem2) pn_is_1 = big1; else pn_is_1 = rem1;
+            const int pn = pn_is_1 ? p1 : p2, po = pn_is_1 ? p2 : p1;
+            const int rem_o = pn_is_1 ? rem2 : rem1;
+            ilist *Ln = pn_is_1 ? A : Bl, *Lo = pn_is_1 ? Bl : A;
+            int in = pn_is_1 ? i1 : i2, io = pn_is_1 ? i2 : i1;
+            const int g_old = pn_is_1 ? gA : gB;
+            if (vn < c->v_edge[0] || vn >= c->v_edge[B]) status |= PMCO_ST_OUT_OF_GRID;
+            const int g_new = cc * B + pmco_bin_of(c->v_edge, B, vn);
+            if (g_new != g_old && n_app >= c->max_appends) {
+                status |= PMCO_ST_APPEND_OVERFLOW; stop = 1; break;
+            }
+            ev[n_ev].pn = pn; ev[n_ev].po = po; ev[n_ev].rem_o = rem_o; ev[n_ev].cc = cc;
+            n_ev++;
+            if (rem_o) {                       /* swap-with-last removal */
+                const int last = Lo->n - 1;
+                Lo->e[io] = Lo->e[last];
+                Lo->n = last;
+                if (same && in == last) in = io;
+            }
+            if (g_new != g_old) {
+                const int last = Ln->n - 1;
+                Ln->e[in] = Ln->e[last];
+                Ln->n = last;
+                il_push(&L[g_new], pn);
+                n_app++;
+            }
+            c->vtot[pn] = vn;
+            c->mass[pn] = mn;
+            tot_coag++;
+        }
+    }
+
+    /* ---- apply the event log to the particle data, in order ---- */
+    unsigned char *dead = (unsigned char *)calloc((size_t)(n0 > 0 ? n0 : 1), 1);
+    int n_dead = 0;
+    for (int e = 0; e < n_ev; e++) {
+        const int pn = ev[e].pn, po = ev[e].po;
+        for (int s = 0; s < c->n_spec; s++)
+            c->vol[(size_t)s * c->cap + pn] += c->vol[(size_t)s * c->cap + po];
+        for (int s = 0; s < c->n_source; s++)
+            c->n_orig[(size_t)s * c->cap + pn] += c->n_orig[(size_t)s * c->cap + po];
+        if (c->lct[po] < c->lct[pn]) c->lct[pn] = c->lct[po];
+        if (c->gct[po] > c->gct[pn]) c->gct[pn] = c->gct[po];
+        c->wclass[pn] = ev[e].cc;
+        if (ev[e].rem_o) { dead[po] = 1; n_dead++; }
+    }
+    for (int e = 0; e < n_ev; e++)
+        if (!dead[ev[e].pn]) refresh_one(c, ev[e].pn);
+    compact_tail_fill(c, dead, n0, n_dead);
+
+    for (int g = 0; g < G; g++) free(L[g].e);
+    free(L); free(ev); free(dead);
+    *n_samp_out = tot_samp > 0x7FFFFFFF ? 0x7FFFFFFF : (int32_t)tot_samp;
+    *n_coag_out = tot_coag;
+    return status;
+}
+
+static void move_particle(pmco_cell *c, int dst, int src)
+{
+    for (int s = 0; s < c->n_spec; s++)
+        c->vol[(size_t)s * c->cap + dst] = c->vol[(size_t)s * c->cap + src];
+    for (int s = 0; s < c->n_source; s++)
+        c->n_orig[(size_t)s * c->cap + dst] = c->n_orig[(size_t)s * c->cap + src];
+    c->vtot[dst] = c->vtot[src];
+    c->mass[dst] = c->mass[src];
+    c->wclass[dst] = c->wclass[src];
+    c->id[dst] = c->id[src];
+    c->lct[dst] = c->lct[src];
+    c->gct[dst] = c->gct[src];
+}
+
+/* Close the holes left by removed particles: the k-th dead slot below the
+ * new count (ascending) receives the k-th live slot at or above it
+ * (ascending).  [aero_particle_array removal moves the last particle into
+ * the hole one at a time; this is the batched equivalent.] */
+static void compact_tail_fill(pmco_cell *c, const unsigned char *dead, int n_old,
+                              int n_dead)
+{
+    const int n_new = n_old - n_dead;
+    int src = n_new;
+    for (int h = 0; h < n_new; h++) {
+        if (!dead[h]) continue;
+        while (dead[src]) src++;
+        move_particle(c, h, src);
+        src++;
+    }
+    *c->n_part = n_new;
+}
+
+/* ------------------------------------------------------------------------
+ * aero_state_rebalance (call: wrf_pmc_driver.F90:248-250).
+ * [upstream, uncited: aero_state_double / aero_state_halve]
+ * ---------------------------------------------------------------------- */
+int pmco_rebalance(pmco_cell *c, const double *n_ideal, int allow_doubling,
+                   int allow_halving, uint64_t seed, uint32_t cell_id,
+                   uint32_t step, int64_t *next_id)
+{
+    int status = 0;
+    for (int cl = 0; cl < c->n_class; cl++) {
+        for (uint32_t iter = 0; iter < 32; iter++) {
+            int n = *c->n_part, ncl = 0;
+            for (int i = 0; i < n; i++) ncl += (c->wclass[i] == cl);
+            if (allow_doubling && ncl > 0 && (double)ncl < n_ideal[cl] / 2.0) {
+                if (n + ncl > c->cap) { status |= PMCO_ST_CAP_OVERFLOW; break; }
+                int k = 0;
+                for (int i = 0; i < n; i++) {
+                    if (c->wclass[i] != cl) continue;
+                    move_particle(c, n + k, i);
+                    c->id[n + k] = *next_id + k;
+                    k++;
+                }
+                *next_id += k;
+                *c->n_part = n + k;
+                c->mag[cl] = c->mag[cl] / 2.0;
+            } else if (allow_halving && (double)ncl > n_ideal[cl] * 2.0) {
+                unsigned char *dead = (unsigned char *)calloc((size_t)n, 1);
+                int n_dead = 0;
+                for (int i = 0; i < n; i++) {
+                    if (c->wclass[i] != cl) continue;
+                    uint32_t w[4];
+                    pmco_rng_block(seed, cell_id, step, (uint32_t)i, PMCO_SITE_HALVE,
+                                   (uint32_t)cl * 32u + iter, w);
+                    if (pmco_u53(w[0], w[1]) < 0.5) { dead[i] = 1; n_dead++; }
+                }
+                compact_tail_fill(c, dead, n, n_dead);
+                free(dead);
+                c->mag[cl] = c->mag[cl] * 2.0;
+            } else {
+                break;
+            }
+        }
+    }
+    return status;
+}
+
+/* ------------------------------------------------------------------------
+ * partmc_process observables (wrf_pmc_driver.F90:783,838-857):
+ *   dry_diameters = aero_state_dry_diameters   (water excluded)
+ *   num_concs     = aero_state_num_concs       (= class magnitude, flat)
+ *   masses        = aero_state_masses          (all species)
+ *   tot_num_conc  = sum(num_concs); tot_mass_conc = sum(masses*num_concs)
+ *   num_dist  = bin_grid_histogram_1d(diam_grid, dry_diameters, num_concs)
+ *   mass_dist = bin_grid_histogram_1d(diam_grid, dry_diameters, num_concs*masses)
+ * with diam_grid = 100 log bins on [1e-9,1e-3] m and histogram entries
+ * divided by the bin's log-width (widths = log(e(i+1)) - log(e(i)),
+ * same file :795-797).
+ * ---------------------------------------------------------------------- */
+void pmco_diagnostics(const pmco_cell *c, int i_water, int n_dbin,
+                      const double *d_edge, const double *d_width,
+                      double *tot_num, double *tot_mass, double *num_dist,
+                      double *mass_dist)
+{
+    double tn = 0.0, tm = 0.0;
+    for (int b = 0; b < n_dbin; b++) { num_dist[b] = 0.0; mass_dist[b] = 0.0; }
+    for (int i = 0; i < *c->n_part; i++) {
+        double vdry = 0.0, ms = 0.0;
+        for (int s = 0; s < c->n_spec; s++) {
+            double v = c->vol[(size_t)s * c->cap + i];
+            if (s != i_water) vdry = vdry + v;
+            ms = ms + c->density[s] * v;
+        }
+        double diam = 2.0 * pmco_cbrt(vdry * (0.75 / PMCO_PI));
+        double nc = c->mag[c->wclass[i]];
+        tn = tn + nc;
+        tm = tm + ms * nc;
+        if (diam >= d_edge[0] && diam < d_edge[n_dbin]) {
+            int b = pmco_bin_of(d_edge, n_dbin, diam);
+            num_dist[b] = num_dist[b] + nc / d_width[b];
+            mass_dist[b] = mass_dist[b] + nc * ms / d_width[b];
+        }
+    }
+    *tot_num = tn;
+    *tot_mass = tm;
+}
+
+/* ------------------------------------------------------------------------
+ * Synthetic population (shape of aero_state_add_aero_dist_sample for
+ * log-normal modes, wrf_pmc_init.F90:951,1063,1764-1777).
+ * ---------------------------------------------------------------------- */
+void pmco_generate(pmco_cell *c, const pmco_gen_spec *g, int32_t n, uint64_t seed,
+                   uint32_t cell_id, int64_t first_id, double create_time)
+{
+    for (int i = 0; i < n; i++) {
+        uint32_t w[4];
+        pmco_rng_block(seed, cell_id, 0u, (uint32_t)i, PMCO_SITE_GEN, 0, w);
+        double um = (double)w[0] * 0x1.0p-32;
+        int mode = 0;
+        while (mode < g->n_mode - 1 && um >= g->mode_frac[mode]) mode++;
+        double z = pmco_norminv(pmco_u53(w[2], w[3]));
+        double r = pmco_exp(g->ln_gm_radius[mode] + g->ln_gsd[mode] * z);
+        double v = (4.0 / 3.0) * PMCO_PI * r * r * r;
+        for (int s = 0; s < c->n_spec; s++)
+            c->vol[(size_t)s * c->cap + i] = g->vol_frac[mode * c->n_spec + s] * v;
+        for (int s = 0; s < c->n_source; s++)
+            c->n_orig[(size_t)s * c->cap + i] = (s == g->mode_source[mode]) ? 1 : 0;
+        c->wclass[i] = g->mode_class[mode];
+        c->id[i] = first_id + i;
+        c->lct[i] = create_time;
+        c->gct[i] = create_time;
+        refresh_one(c, i);
+    }
+    *c->n_part = n;
+}

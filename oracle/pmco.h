@@ -1,0 +1,151 @@
+/*
+ * pmco.h -- ORACLE (test infrastructure, not product code).
+ *
+ * Plain-C, serial, CPU restatement of the per-grid-cell microphysics path
+ * that WRF-PartMC runs in partmc_timestep
+ * (/root/reference/interface/wrf_pmc_driver.F90:46-290):
+ *
+ *     mc_coag(COAG_KERNEL_TYPE_BROWN, env_state, aero_data, aero_state,
+ *             del_t, n_samp, n_coag)                 wrf_pmc_driver.F90:192-194
+ *     aero_state_rebalance(...)                      wrf_pmc_driver.F90:248-250
+ *     partmc_process observables                     wrf_pmc_driver.F90:783,838-857
+ *
+ * PARITY UNPINNED: the arithmetic of mc_coag lives in the git submodule
+ * compdyn/partmc (.gitmodules:1-3), which is not vendored in /root/reference
+ * (partmc/ is empty, pinned commit unknown), and the reference holds no test,
+ * golden vector or fixture for this path.  This file
+ * therefore restates the *published* PartMC algorithm (Riemer et al. 2009,
+ * J. Geophys. Res. 114 D09202; DeVille et al. 2011, J. Comput. Phys. 230
+ * 8427; Jacobson 2005 eq. 15.33 for the Brownian kernel) behind the call
+ * signature and data fields the interface uses, and is pinned by analytic
+ * Smoluchowski solutions, conservation laws, Random123 known-answer vectors
+ * and an independent transcription of the in-tree Fuchs-form kernel
+ * (WRFV3/chem/module_mosaic_coag.F:746-757,898-936); see tests/.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * include, link or call anything under oracle/.
+ */
+#ifndef PMCO_H
+#define PMCO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Coagulation kernel ids.  1..7 follow PartMC's COAG_KERNEL_TYPE_* numbering
+ * (the interface selects COAG_KERNEL_TYPE_BROWN, wrf_pmc_driver.F90:192; the
+ * objects of the others are linked, interface/Makefile:24-30). */
+enum {
+    PMCO_KERNEL_SEDI = 1,
+    PMCO_KERNEL_ADDITIVE = 2,
+    PMCO_KERNEL_CONSTANT = 3,
+    PMCO_KERNEL_BROWN = 4,
+    PMCO_KERNEL_ZERO = 5,
+    PMCO_KERNEL_BROWN_SEDI = 101 /* Brownian + sedimentation (BASELINE config 2) */
+};
+
+/* cell status bits */
+enum {
+    PMCO_OK = 0,
+    PMCO_ST_EVENT_OVERFLOW = 1,  /* event log full: step stopped early        */
+    PMCO_ST_APPEND_OVERFLOW = 2, /* list-append log full: step stopped early  */
+    PMCO_ST_KMAX_EXCEEDED = 4,   /* some K/K_max > 1 (bound too tight)        */
+    PMCO_ST_OUT_OF_GRID = 8,     /* a particle volume fell outside the bins   */
+    PMCO_ST_CAP_OVERFLOW = 16    /* rebalance doubling exceeded capacity      */
+};
+
+typedef struct {
+    double const_k;       /* constant kernel value, m^3/s                   */
+    double additive_beta; /* additive kernel K = beta*(v1+v2), 1/s          */
+} pmco_kernel_params;
+
+/* One cell's aero_state_t / env_state_t, as flat arrays (the fields the
+ * interface touches, wrf_pmc_driver.F90:1419-1466,1617-1630,611-637). */
+typedef struct {
+    int32_t n_spec, n_class, n_source, cap, n_bin;
+    int32_t max_events, max_appends; /* log capacities shared with the GPU spec */
+    const double *density; /* [n_spec] aero_data%density                     */
+    const double *v_edge;  /* [n_bin+1] sort-grid volume edges               */
+    const double *kmax;    /* [n_bin*n_bin] unweighted kernel upper bounds   */
+    double temp, pressure; /* env_state%temp, %pressure                      */
+    double *mag;           /* [n_class] awa%weight(1,c)%magnitude (flat)     */
+    int32_t *n_part;       /* apa%n_part                                     */
+    double *vol;           /* [n_spec][cap] particle%vol                     */
+    double *vtot, *mass;   /* [cap] cached sum_s vol, sum_s density*vol      */
+    int32_t *wclass;       /* [cap] particle%weight_class (0-based)          */
+    int64_t *id;           /* [cap] particle%id                              */
+    double *lct, *gct;     /* [cap] least/greatest_create_time               */
+    int32_t *n_orig;       /* [n_source][cap] per-source constituent counts  */
+} pmco_cell;
+
+void pmco_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+double pmco_exp_(double x);
+double pmco_log_(double x);
+double pmco_cbrt_(double x);
+double pmco_norminv_(double p);
+int32_t pmco_poisson_(double mean, double u);
+
+/* K(v1,m1; v2,m2) [m^3/s] for particle volumes v [m^3] and masses m [kg]. */
+double pmco_kernel(int type, double v1, double m1, double v2, double m2,
+                   double temp, double pressure, const pmco_kernel_params *kp);
+
+/* Sort-grid tables: n_bin log-spaced radius bins on [r_min, r_max].
+ * v_edge[n_bin+1]; v_samp[n_bin*3] = lower edge, geometric centre, upper edge
+ * (in volume) of each bin -- the sample points of the K_max estimate. */
+void pmco_make_bin_tables(int n_bin, double r_min, double r_max,
+                          double *v_edge, double *v_samp);
+
+int pmco_bin_of(const double *v_edge, int n_bin, double v);
+
+/* kmax[b1*n_bin+b2] = max of K over the 3x3 sample volumes of the two bins
+ * and the four (rho_min|rho_max)^2 density combinations. */
+void pmco_kmax_table(int type, int n_bin, const double *v_samp, double rho_min,
+                     double rho_max, double temp, double pressure,
+                     const pmco_kernel_params *kp, double *kmax);
+
+/* vtot/mass caches from the species volumes, particles [0, n_part). */
+void pmco_refresh_caches(pmco_cell *c);
+
+/* One mc_coag call on one cell.  Returns the status bits. */
+int pmco_mc_coag(pmco_cell *c, int kernel_type, const pmco_kernel_params *kp,
+                 double del_t, uint64_t seed, uint32_t cell_id, uint32_t step,
+                 int32_t *n_samp, int32_t *n_coag);
+
+/* aero_state_rebalance: per class, double while n < n_ideal/2, halve while
+ * n > 2*n_ideal.  next_id is the id counter (module variable next_id,
+ * wrf_pmc_driver.F90:1652). */
+int pmco_rebalance(pmco_cell *c, const double *n_ideal /*[n_class]*/,
+                   int allow_doubling, int allow_halving, uint64_t seed,
+                   uint32_t cell_id, uint32_t step, int64_t *next_id);
+
+/* partmc_process observables: tot_num_conc, tot_mass_conc and the two
+ * n_dbin histograms over dry diameter (wrf_pmc_driver.F90:783,838-857).
+ * i_water < 0 means no water species. */
+void pmco_diagnostics(const pmco_cell *c, int i_water, int n_dbin,
+                      const double *d_edge /*[n_dbin+1]*/,
+                      const double *d_width /*[n_dbin]*/, double *tot_num,
+                      double *tot_mass, double *num_dist, double *mass_dist);
+
+/* Synthetic populations: n particles of one cell drawn from a mixture of
+ * log-normal modes with fixed volume fractions (the shape of the idealised
+ * IC, wrf_pmc_init.F90:1764-1777, and of aero_init_dist.dat). */
+typedef struct {
+    int32_t n_mode;
+    const double *mode_frac;     /* [n_mode] cumulative number fraction     */
+    const double *ln_gm_radius;  /* [n_mode] ln of geometric-mean radius    */
+    const double *ln_gsd;        /* [n_mode] ln of geometric std deviation  */
+    const double *vol_frac;      /* [n_mode][n_spec] species volume fractions */
+    const int32_t *mode_class;   /* [n_mode] weight class of the mode       */
+    const int32_t *mode_source;  /* [n_mode] source index of the mode       */
+} pmco_gen_spec;
+
+void pmco_generate(pmco_cell *c, const pmco_gen_spec *g, int32_t n,
+                   uint64_t seed, uint32_t cell_id, int64_t first_id,
+                   double create_time);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PMCO_H */

@@ -1,0 +1,199 @@
+"""ctypes binding of the CPU oracle (oracle/libpmco.so).
+
+ORACLE -- test infrastructure, not product code.  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+KERNEL_SEDI, KERNEL_ADDITIVE, KERNEL_CONSTANT, KERNEL_BROWN, KERNEL_ZERO = 1, 2, 3, 4, 5
+KERNEL_BROWN_SEDI = 101
+
+ST_EVENT_OVERFLOW, ST_APPEND_OVERFLOW, ST_KMAX_EXCEEDED, ST_OUT_OF_GRID, ST_CAP_OVERFLOW = 1, 2, 4, 8, 16
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lp = C.POINTER(C.c_int64)
+
+
+class KernelParams(C.Structure):
+    _fields_ = [("const_k", C.c_double), ("additive_beta", C.c_double)]
+
+
+class CellStruct(C.Structure):
+    _fields_ = [
+        ("n_spec", C.c_int32), ("n_class", C.c_int32), ("n_source", C.c_int32),
+        ("cap", C.c_int32), ("n_bin", C.c_int32),
+        ("max_events", C.c_int32), ("max_appends", C.c_int32),
+        ("density", _dp), ("v_edge", _dp), ("kmax", _dp),
+        ("temp", C.c_double), ("pressure", C.c_double),
+        ("mag", _dp), ("n_part", _ip), ("vol", _dp), ("vtot", _dp), ("mass", _dp),
+        ("wclass", _ip), ("id", _lp), ("lct", _dp), ("gct", _dp), ("n_orig", _ip),
+    ]
+
+
+class GenSpec(C.Structure):
+    _fields_ = [
+        ("n_mode", C.c_int32), ("mode_frac", _dp), ("ln_gm_radius", _dp),
+        ("ln_gsd", _dp), ("vol_frac", _dp), ("mode_class", _ip), ("mode_source", _ip),
+    ]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libpmco.so")
+    srcs = [os.path.join(_HERE, f) for f in ("pmco.c", "pmco.h", "pmco_math.h")]
+    if force or not os.path.exists(so) or any(
+            os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.pmco_exp_.restype = C.c_double; L.pmco_exp_.argtypes = [C.c_double]
+        L.pmco_log_.restype = C.c_double; L.pmco_log_.argtypes = [C.c_double]
+        L.pmco_cbrt_.restype = C.c_double; L.pmco_cbrt_.argtypes = [C.c_double]
+        L.pmco_norminv_.restype = C.c_double; L.pmco_norminv_.argtypes = [C.c_double]
+        L.pmco_poisson_.restype = C.c_int32; L.pmco_poisson_.argtypes = [C.c_double, C.c_double]
+        L.pmco_kernel.restype = C.c_double
+        L.pmco_kernel.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                                  C.c_double, C.c_double, C.POINTER(KernelParams)]
+        L.pmco_bin_of.restype = C.c_int
+        L.pmco_bin_of.argtypes = [_dp, C.c_int, C.c_double]
+        L.pmco_mc_coag.restype = C.c_int
+        L.pmco_mc_coag.argtypes = [C.POINTER(CellStruct), C.c_int, C.POINTER(KernelParams),
+                                   C.c_double, C.c_uint64, C.c_uint32, C.c_uint32, _ip, _ip]
+        L.pmco_rebalance.restype = C.c_int
+        L.pmco_rebalance.argtypes = [C.POINTER(CellStruct), _dp, C.c_int, C.c_int, C.c_uint64,
+                                     C.c_uint32, C.c_uint32, _lp]
+        L.pmco_generate.restype = None
+        L.pmco_generate.argtypes = [C.POINTER(CellStruct), C.POINTER(GenSpec), C.c_int32,
+                                    C.c_uint64, C.c_uint32, C.c_int64, C.c_double]
+        L.pmco_refresh_caches.restype = None
+        L.pmco_refresh_caches.argtypes = [C.POINTER(CellStruct)]
+        _LIB = L
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def philox(ctr, key):
+    c = np.asarray(ctr, dtype=np.uint32)
+    k = np.asarray(key, dtype=np.uint32)
+    o = np.zeros(4, dtype=np.uint32)
+    u32p = C.POINTER(C.c_uint32)
+    lib().pmco_philox(_p(c, u32p), _p(k, u32p), _p(o, u32p))
+    return o
+
+
+def kernel(ktype, v1, m1, v2, m2, temp, pressure, const_k=0.0, additive_beta=0.0):
+    kp = KernelParams(const_k, additive_beta)
+    return lib().pmco_kernel(ktype, v1, m1, v2, m2, temp, pressure, C.byref(kp))
+
+
+def make_bin_tables(n_bin, r_min, r_max):
+    v_edge = np.zeros(n_bin + 1)
+    v_samp = np.zeros(n_bin * 3)
+    lib().pmco_make_bin_tables(C.c_int(n_bin), C.c_double(r_min), C.c_double(r_max),
+                               _p(v_edge, _dp), _p(v_samp, _dp))
+    return v_edge, v_samp
+
+
+def kmax_table(ktype, v_samp, rho_min, rho_max, temp, pressure, const_k=0.0, additive_beta=0.0):
+    n_bin = len(v_samp) // 3
+    out = np.zeros(n_bin * n_bin)
+    kp = KernelParams(const_k, additive_beta)
+    lib().pmco_kmax_table(C.c_int(ktype), C.c_int(n_bin), _p(np.ascontiguousarray(v_samp), _dp),
+                          C.c_double(rho_min), C.c_double(rho_max), C.c_double(temp),
+                          C.c_double(pressure), C.byref(kp), _p(out, _dp))
+    return out.reshape(n_bin, n_bin)
+
+
+class Cell:
+    """One cell's state as numpy arrays + the C view over them."""
+
+    def __init__(self, n_spec, n_class, n_source, cap, density, v_edge, temp=288.15,
+                 pressure=101325.0, max_events=1 << 20, max_appends=1 << 20):
+        self.n_spec, self.n_class, self.n_source, self.cap = n_spec, n_class, n_source, cap
+        self.density = np.ascontiguousarray(density, dtype=np.float64)
+        self.v_edge = np.ascontiguousarray(v_edge, dtype=np.float64)
+        self.n_bin = len(self.v_edge) - 1
+        self.kmax = np.zeros((self.n_bin, self.n_bin))
+        self.temp, self.pressure = float(temp), float(pressure)
+        self.max_events, self.max_appends = max_events, max_appends
+        self.mag = np.zeros(n_class)
+        self.n_part = np.zeros(1, dtype=np.int32)
+        self.vol = np.zeros((n_spec, cap))
+        self.vtot = np.zeros(cap)
+        self.mass = np.zeros(cap)
+        self.wclass = np.zeros(cap, dtype=np.int32)
+        self.id = np.zeros(cap, dtype=np.int64)
+        self.lct = np.zeros(cap)
+        self.gct = np.zeros(cap)
+        self.n_orig = np.zeros((max(n_source, 1), cap), dtype=np.int32)
+
+    def view(self):
+        s = CellStruct()
+        s.n_spec, s.n_class, s.n_source = self.n_spec, self.n_class, self.n_source
+        s.cap, s.n_bin = self.cap, self.n_bin
+        s.max_events, s.max_appends = self.max_events, self.max_appends
+        s.density = _p(self.density, _dp); s.v_edge = _p(self.v_edge, _dp)
+        s.kmax = _p(self.kmax, _dp)
+        s.temp, s.pressure = self.temp, self.pressure
+        s.mag = _p(self.mag, _dp); s.n_part = _p(self.n_part, _ip)
+        s.vol = _p(self.vol, _dp); s.vtot = _p(self.vtot, _dp); s.mass = _p(self.mass, _dp)
+        s.wclass = _p(self.wclass, _ip); s.id = _p(self.id, _lp)
+        s.lct = _p(self.lct, _dp); s.gct = _p(self.gct, _dp); s.n_orig = _p(self.n_orig, _ip)
+        return s
+
+    def refresh_caches(self):
+        lib().pmco_refresh_caches(C.byref(self.view()))
+
+    def mc_coag(self, ktype, del_t, seed, cell_id, step, const_k=0.0, additive_beta=0.0):
+        kp = KernelParams(const_k, additive_beta)
+        ns, nc = C.c_int32(0), C.c_int32(0)
+        st = lib().pmco_mc_coag(C.byref(self.view()), ktype, C.byref(kp), del_t, seed, cell_id,
+                                step, C.byref(ns), C.byref(nc))
+        return st, ns.value, nc.value
+
+    def rebalance(self, n_ideal, allow_doubling, allow_halving, seed, cell_id, step, next_id):
+        ni = np.ascontiguousarray(n_ideal, dtype=np.float64)
+        nid = C.c_int64(next_id)
+        st = lib().pmco_rebalance(C.byref(self.view()), _p(ni, _dp), int(allow_doubling),
+                                  int(allow_halving), seed, cell_id, step, C.byref(nid))
+        return st, nid.value
+
+    def diagnostics(self, i_water, d_edge, d_width):
+        n = len(d_width)
+        tn, tm = C.c_double(0), C.c_double(0)
+        nd, md = np.zeros(n), np.zeros(n)
+        de = np.ascontiguousarray(d_edge, dtype=np.float64)
+        dw = np.ascontiguousarray(d_width, dtype=np.float64)
+        lib().pmco_diagnostics(C.byref(self.view()), C.c_int(i_water), C.c_int(n), _p(de, _dp),
+                               _p(dw, _dp), C.byref(tn), C.byref(tm), _p(nd, _dp), _p(md, _dp))
+        return tn.value, tm.value, nd, md
+
+    def generate(self, modes, n, seed, cell_id, first_id=0, create_time=0.0):
+        """modes: list of dict(frac, gm_radius, gsd_log10, vol_frac[n_spec], wclass, source)."""
+        fr = np.cumsum([m["frac"] for m in modes], dtype=np.float64)
+        fr = fr / fr[-1]
+        lg = np.array([np.log(m["gm_radius"]) for m in modes], dtype=np.float64)
+        ls = np.array([m["gsd_log10"] * np.log(10.0) for m in modes], dtype=np.float64)
+        vf = np.ascontiguousarray([m["vol_frac"] for m in modes], dtype=np.float64)
+        mc = np.array([m.get("wclass", 0) for m in modes], dtype=np.int32)
+        msrc = np.array([m.get("source", 0) for m in modes], dtype=np.int32)
+        g = GenSpec(len(modes), _p(fr, _dp), _p(lg, _dp), _p(ls, _dp), _p(vf, _dp),
+                    _p(mc, _ip), _p(msrc, _ip))
+        lib().pmco_generate(C.byref(self.view()), C.byref(g), n, seed, cell_id, first_id,
+                            create_time)
+        return fr, lg, ls, vf, mc, msrc

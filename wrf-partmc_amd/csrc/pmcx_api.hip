@@ -1,0 +1,881 @@
+// pmcx_api.hip -- C-ABI (include/pmcx.h) over the gfx950 kernels.
+//
+// Host side of the drop-in boundary for partmc_timestep's per-cell loop body
+// (interface/wrf_pmc_driver.F90:169-254).  Owns device memory for a block of
+// cells, moves packed host arrays in and out, launches the kernels on one HIP
+// stream.  No CPU fallback: without a usable gfx950 device pmcx_create fails.
+#include "../../include/pmcx.h"
+#include "pmcx_kernels.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace pmcx;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct ProfEntry {
+    double ms = 0.0;
+    int64_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+} // namespace
+
+struct pmcx_ctx {
+    pmcx_config cfg{};
+    hipStream_t stream = nullptr;
+    DeviceState st{};
+    std::string err;
+    int64_t bytes = 0;
+    std::vector<void *> allocs;
+    // model tables, host copies
+    std::vector<double> v_edge, v_samp, d_edge, d_width, density;
+    double *d_density = nullptr, *d_v_edge = nullptr, *d_v_samp = nullptr, *d_d_edge = nullptr,
+           *d_d_width = nullptr;
+    double *d_temp = nullptr, *d_pressure = nullptr, *d_rh = nullptr, *d_n_ideal = nullptr;
+    // staging
+    void *stage = nullptr;
+    size_t stage_bytes = 0;
+    int64_t *d_offsets = nullptr;
+    size_t offsets_cap = 0;
+    int64_t *d_totals = nullptr;
+    double *d_diag = nullptr; // [n_cells*(2+2*n_dbin)]
+    bool aero_data_set = false, env_set = false;
+    int bounds_kernel = 0; // kernel type the kmax tables are valid for (0 = none)
+    bool sorted_valid = false;
+    // profiling
+    bool prof = false;
+    std::map<std::string, ProfEntry> profile;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace {
+
+int fail(pmcx_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                  \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? PMCX_ENOMEM : PMCX_EDEVICE,        \
+                        "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T>
+int dev_alloc(pmcx_ctx *ctx, T **p, size_t count, bool zero = true)
+{
+    const size_t bytes = sizeof(T) * (count ? count : 1);
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess)
+        return fail(ctx, PMCX_ENOMEM, "hipMalloc of %zu bytes failed: %s", bytes,
+                    hipGetErrorString(e));
+    if (zero) {
+        e = hipMemsetAsync(q, 0, bytes, ctx->stream);
+        if (e != hipSuccess) return fail(ctx, PMCX_EDEVICE, "hipMemset: %s", hipGetErrorString(e));
+    }
+    ctx->allocs.push_back(q);
+    ctx->bytes += (int64_t)bytes;
+    *p = (T *)q;
+    return PMCX_OK;
+}
+
+int ensure_stage(pmcx_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->stage_bytes) return PMCX_OK;
+    if (ctx->stage) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(ctx->stage));
+        ctx->bytes -= (int64_t)ctx->stage_bytes;
+        ctx->stage = nullptr;
+        ctx->stage_bytes = 0;
+    }
+    HIP_TRY(ctx, hipMalloc(&ctx->stage, bytes));
+    ctx->stage_bytes = bytes;
+    ctx->bytes += (int64_t)bytes;
+    return PMCX_OK;
+}
+
+int ensure_offsets(pmcx_ctx *ctx, size_t n)
+{
+    if (n <= ctx->offsets_cap) return PMCX_OK;
+    if (ctx->d_offsets) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(ctx->d_offsets));
+    }
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_offsets, sizeof(int64_t) * n));
+    ctx->offsets_cap = n;
+    return PMCX_OK;
+}
+
+struct ProfScope {
+    pmcx_ctx *ctx;
+    hipEvent_t a = nullptr, b = nullptr;
+    const char *name;
+    ProfScope(pmcx_ctx *c, const char *n) : ctx(c), name(n)
+    {
+        if (!ctx->prof) return;
+        auto get = [&]() {
+            hipEvent_t e = nullptr;
+            if (!ctx->event_pool.empty()) { e = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
+            else (void)hipEventCreate(&e);
+            return e;
+        };
+        a = get(); b = get();
+        (void)hipEventRecord(a, ctx->stream);
+    }
+    ~ProfScope()
+    {
+        if (!ctx->prof || !a) return;
+        (void)hipEventRecord(b, ctx->stream);
+        ctx->profile[name].pending.emplace_back(a, b);
+        ctx->profile[name].launches++;
+    }
+};
+
+void prof_drain(pmcx_ctx *ctx)
+{
+    for (auto &kv : ctx->profile) {
+        for (auto &pr : kv.second.pending) {
+            float ms = 0.f;
+            (void)hipEventSynchronize(pr.second);
+            (void)hipEventElapsedTime(&ms, pr.first, pr.second);
+            kv.second.ms += ms;
+            ctx->event_pool.push_back(pr.first);
+            ctx->event_pool.push_back(pr.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+void pmcx_config_default(pmcx_config *cfg)
+{
+    memset(cfg, 0, sizeof *cfg);
+    cfg->struct_size = (int32_t)sizeof(pmcx_config);
+    cfg->device = 0;
+    cfg->n_cells = 1;
+    cfg->cap = 2048;    /* num_particles default 1000 (registry.partmc:1), doubled */
+    cfg->n_spec = 20;   /* aero_data.dat */
+    cfg->n_class = 1;
+    cfg->n_source = 0;
+    cfg->n_bin = 80;    /* 10 bins per decade of radius */
+    cfg->r_min = 1e-10;
+    cfg->r_max = 1e-2;
+    cfg->max_events = 1024;
+    cfg->max_appends = 512;
+    cfg->n_dbin = 100;  /* driver:783 */
+    cfg->i_water = -1;
+    cfg->d_min = 1e-9;
+    cfg->d_max = 1e-3;
+    cfg->cell_id_base = 0;
+    cfg->const_k = 0.25 / (60.0 * 2.0e8); /* PartMC constant-kernel beta_0 [upstream] */
+    cfg->additive_beta = 1000.0;          /* PartMC additive-kernel beta_1 [upstream] */
+}
+
+const char *pmcx_last_error(const pmcx_ctx *ctx)
+{
+    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
+{
+    if (!cfg || !out) return fail(nullptr, PMCX_EINVAL, "pmcx_create: null argument");
+    *out = nullptr;
+    if (cfg->struct_size != (int32_t)sizeof(pmcx_config))
+        return fail(nullptr, PMCX_EINVAL, "pmcx_config size mismatch (%d vs %zu)",
+                    cfg->struct_size, sizeof(pmcx_config));
+    if (cfg->n_cells < 1 || cfg->cap < 2 || cfg->cap > 65280 || cfg->n_spec < 1 ||
+        cfg->n_class < 1 || cfg->n_class > 255 || cfg->n_source < 0 || cfg->n_bin < 1 ||
+        cfg->n_bin > 128 || !(cfg->r_min > 0) || !(cfg->r_max > cfg->r_min) ||
+        cfg->max_events < 1 || cfg->max_appends < 1 || cfg->max_appends > 4096 ||
+        cfg->n_dbin < 1 || !(cfg->d_min > 0) || !(cfg->d_max > cfg->d_min) ||
+        cfg->n_class * cfg->n_bin > 65535 || cfg->i_water >= cfg->n_spec)
+        return fail(nullptr, PMCX_EINVAL, "pmcx_create: configuration out of range");
+
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1 || cfg->device >= n_dev)
+        return fail(nullptr, PMCX_EDEVICE, "no HIP device %d (found %d): this library has no CPU path",
+                    cfg->device, n_dev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess)
+        return fail(nullptr, PMCX_EDEVICE, "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, PMCX_EDEVICE, "device %d is %s; this library is built for gfx950 only",
+                    cfg->device, prop.gcnArchName);
+    if (hipSetDevice(cfg->device) != hipSuccess)
+        return fail(nullptr, PMCX_EDEVICE, "hipSetDevice(%d) failed", cfg->device);
+
+    pmcx_ctx *ctx = new pmcx_ctx();
+    ctx->cfg = *cfg;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, PMCX_EDEVICE, "hipStreamCreate failed");
+    }
+    DeviceState &st = ctx->st;
+    st.n_cells = cfg->n_cells; st.cap = cfg->cap; st.n_spec = cfg->n_spec;
+    st.n_class = cfg->n_class; st.n_source = cfg->n_source; st.n_bin = cfg->n_bin;
+    st.n_dbin = cfg->n_dbin; st.i_water = cfg->i_water;
+    st.max_events = cfg->max_events; st.max_appends = cfg->max_appends;
+    st.cell_id_base = cfg->cell_id_base;
+    st.const_k = cfg->const_k; st.additive_beta = cfg->additive_beta;
+    st.rho_min = 0; st.rho_max = 0;
+
+    // sort grid (aero_sorted bin_grid) and diagnostics grid (driver:783)
+    const int B = cfg->n_bin;
+    ctx->v_edge.resize(B + 1); ctx->v_samp.resize(3 * B);
+    const double l0 = std::log(cfg->r_min), l1 = std::log(cfg->r_max);
+    const double pi = 3.14159265358979323846;
+    for (int k = 0; k <= B; k++) {
+        const double r = std::exp(l0 + (l1 - l0) * (double)k / (double)B);
+        ctx->v_edge[k] = (4.0 / 3.0) * pi * r * r * r;
+    }
+    for (int b = 0; b < B; b++) {
+        ctx->v_samp[3 * b + 0] = ctx->v_edge[b];
+        ctx->v_samp[3 * b + 1] = std::sqrt(ctx->v_edge[b] * ctx->v_edge[b + 1]);
+        ctx->v_samp[3 * b + 2] = ctx->v_edge[b + 1];
+    }
+    st.log2_v0 = std::log2(ctx->v_edge[0]);
+    st.inv_dlog2 = (double)B / (std::log2(ctx->v_edge[B]) - std::log2(ctx->v_edge[0]));
+    const int nd = cfg->n_dbin;
+    ctx->d_edge.resize(nd + 1); ctx->d_width.resize(nd);
+    const double m0 = std::log(cfg->d_min), m1 = std::log(cfg->d_max);
+    for (int k = 0; k <= nd; k++)
+        ctx->d_edge[k] = std::exp(m0 + (m1 - m0) * (double)k / (double)nd);
+    for (int k = 0; k < nd; k++)
+        ctx->d_width[k] = std::log(ctx->d_edge[k + 1]) - std::log(ctx->d_edge[k]);
+
+    const size_t nc = (size_t)cfg->n_cells, cap = (size_t)cfg->cap;
+    const size_t G = (size_t)cfg->n_class * B;
+    int rc = PMCX_OK;
+#define A_(ptr, count) if (rc == PMCX_OK) rc = dev_alloc(ctx, &(ptr), (count))
+    A_(ctx->d_density, (size_t)cfg->n_spec);
+    A_(ctx->d_v_edge, (size_t)B + 1);
+    A_(ctx->d_v_samp, (size_t)3 * B);
+    A_(ctx->d_d_edge, (size_t)nd + 1);
+    A_(ctx->d_d_width, (size_t)nd);
+    A_(ctx->d_temp, nc); A_(ctx->d_pressure, nc); A_(ctx->d_rh, nc);
+    A_(st.mag, nc * cfg->n_class);
+    A_(ctx->d_n_ideal, nc * cfg->n_class);
+    A_(st.kmax, nc * B * B);
+    A_(st.n_part, nc); A_(st.next_id, nc);
+    A_(st.vol, nc * cfg->n_spec * cap);
+    A_(st.vtot, nc * cap); A_(st.mass, nc * cap);
+    A_(st.wclass, nc * cap); A_(st.id, nc * cap);
+    A_(st.lct, nc * cap); A_(st.gct, nc * cap);
+    A_(st.n_orig, nc * (size_t)cfg->n_source * cap);
+    A_(st.perm, nc * cap);
+    A_(st.gcnt, nc * G); A_(st.goff, nc * G);
+    A_(st.events, nc * (size_t)cfg->max_events);
+    A_(st.n_events, nc); A_(st.n_samp, nc); A_(st.n_coag, nc); A_(st.status, nc);
+    A_(ctx->d_totals, (size_t)4);
+    A_(ctx->d_diag, nc * (size_t)(2 + 2 * nd));
+#undef A_
+    if (rc != PMCX_OK) {
+        g_create_error = ctx->err;
+        pmcx_destroy(ctx);
+        return rc;
+    }
+    st.density = ctx->d_density; st.v_edge = ctx->d_v_edge; st.v_samp = ctx->d_v_samp;
+    st.d_edge = ctx->d_d_edge; st.d_width = ctx->d_d_width;
+    st.temp = ctx->d_temp; st.pressure = ctx->d_pressure; st.n_ideal = ctx->d_n_ideal;
+
+    hipError_t e = hipSuccess;
+    auto up = [&](double *d, const std::vector<double> &h) {
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(d, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice,
+                               ctx->stream);
+    };
+    up(ctx->d_v_edge, ctx->v_edge); up(ctx->d_v_samp, ctx->v_samp);
+    up(ctx->d_d_edge, ctx->d_edge); up(ctx->d_d_width, ctx->d_width);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        fail(nullptr, PMCX_EDEVICE, "table upload failed: %s", hipGetErrorString(e));
+        pmcx_destroy(ctx);
+        return PMCX_EDEVICE;
+    }
+
+    // shared-memory footprints must fit the CU's 160 KiB LDS
+    const size_t lds_sort = bin_sort_lds_bytes(st), lds_samp = sampler_lds_bytes_per_cell(st);
+    if (lds_sort > 160 * 1024 || lds_samp > 160 * 1024) {
+        fail(nullptr, PMCX_EINVAL,
+             "configuration needs %zu B (sort) / %zu B (sampler) of LDS per workgroup; limit 163840",
+             lds_sort, lds_samp);
+        pmcx_destroy(ctx);
+        return PMCX_EINVAL;
+    }
+    *out = ctx;
+    return PMCX_OK;
+}
+
+int pmcx_destroy(pmcx_ctx *ctx)
+{
+    if (!ctx) return PMCX_OK;
+    (void)hipSetDevice(ctx->cfg.device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    prof_drain(ctx);
+    for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+    for (void *p : ctx->allocs) (void)hipFree(p);
+    if (ctx->stage) (void)hipFree(ctx->stage);
+    if (ctx->d_offsets) (void)hipFree(ctx->d_offsets);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PMCX_OK;
+}
+
+int pmcx_synchronize(pmcx_ctx *ctx)
+{
+    if (!ctx) return PMCX_EINVAL;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PMCX_OK;
+}
+
+int pmcx_memory_bytes(pmcx_ctx *ctx, int64_t *bytes)
+{
+    if (!ctx || !bytes) return PMCX_EINVAL;
+    *bytes = ctx->bytes;
+    return PMCX_OK;
+}
+
+int pmcx_set_aero_data(pmcx_ctx *ctx, const double *density, const double *kappa,
+                       const double *molec_weight)
+{
+    (void)kappa; (void)molec_weight;
+    if (!ctx || !density) return fail(ctx, PMCX_EINVAL, "pmcx_set_aero_data: null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    ctx->density.assign(density, density + ctx->cfg.n_spec);
+    double lo = density[0], hi = density[0];
+    for (int s = 0; s < ctx->cfg.n_spec; s++) {
+        if (!(density[s] > 0)) return fail(ctx, PMCX_EINVAL, "density[%d] must be positive", s);
+        lo = density[s] < lo ? density[s] : lo;
+        hi = density[s] > hi ? density[s] : hi;
+    }
+    ctx->st.rho_min = lo; ctx->st.rho_max = hi;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_density, density, sizeof(double) * ctx->cfg.n_spec,
+                                hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->aero_data_set = true;
+    ctx->bounds_kernel = 0;
+    return PMCX_OK;
+}
+
+int pmcx_set_env(pmcx_ctx *ctx, const double *temp, const double *pressure,
+                 const double *rel_humid)
+{
+    if (!ctx || !temp || !pressure) return fail(ctx, PMCX_EINVAL, "pmcx_set_env: null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t b = sizeof(double) * (size_t)ctx->cfg.n_cells;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_temp, temp, b, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pressure, pressure, b, hipMemcpyHostToDevice, ctx->stream));
+    if (rel_humid)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_rh, rel_humid, b, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->env_set = true;
+    return PMCX_OK;
+}
+
+static int copy_cells_h2d(pmcx_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PMCX_OK;
+}
+static int copy_cells_d2h(pmcx_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PMCX_OK;
+}
+
+int pmcx_set_weights(pmcx_ctx *ctx, const double *magnitude)
+{
+    if (!ctx || !magnitude) return fail(ctx, PMCX_EINVAL, "pmcx_set_weights: null argument");
+    return copy_cells_h2d(ctx, ctx->st.mag, magnitude,
+                          sizeof(double) * (size_t)ctx->cfg.n_cells * ctx->cfg.n_class);
+}
+int pmcx_get_weights(pmcx_ctx *ctx, double *magnitude)
+{
+    if (!ctx || !magnitude) return fail(ctx, PMCX_EINVAL, "pmcx_get_weights: null argument");
+    return copy_cells_d2h(ctx, magnitude, ctx->st.mag,
+                          sizeof(double) * (size_t)ctx->cfg.n_cells * ctx->cfg.n_class);
+}
+int pmcx_set_n_part_ideal(pmcx_ctx *ctx, const double *n_ideal)
+{
+    if (!ctx || !n_ideal) return fail(ctx, PMCX_EINVAL, "pmcx_set_n_part_ideal: null argument");
+    return copy_cells_h2d(ctx, ctx->d_n_ideal, n_ideal,
+                          sizeof(double) * (size_t)ctx->cfg.n_cells * ctx->cfg.n_class);
+}
+int pmcx_set_next_id(pmcx_ctx *ctx, const int64_t *next_id)
+{
+    if (!ctx || !next_id) return fail(ctx, PMCX_EINVAL, "pmcx_set_next_id: null argument");
+    return copy_cells_h2d(ctx, ctx->st.next_id, next_id, sizeof(int64_t) * (size_t)ctx->cfg.n_cells);
+}
+int pmcx_get_next_id(pmcx_ctx *ctx, int64_t *next_id)
+{
+    if (!ctx || !next_id) return fail(ctx, PMCX_EINVAL, "pmcx_get_next_id: null argument");
+    return copy_cells_d2h(ctx, next_id, ctx->st.next_id, sizeof(int64_t) * (size_t)ctx->cfg.n_cells);
+}
+int pmcx_get_n_part(pmcx_ctx *ctx, int32_t *n_part)
+{
+    if (!ctx || !n_part) return fail(ctx, PMCX_EINVAL, "pmcx_get_n_part: null argument");
+    return copy_cells_d2h(ctx, n_part, ctx->st.n_part, sizeof(int32_t) * (size_t)ctx->cfg.n_cells);
+}
+
+int pmcx_upload_cells(pmcx_ctx *ctx, int32_t cell_first, int32_t n_up, const int64_t *part_offset,
+                      const double *vol, const int32_t *wclass, const int64_t *id,
+                      const double *least_ct, const double *greatest_ct, const int32_t *n_orig)
+{
+    if (!ctx || !part_offset || !vol)
+        return fail(ctx, PMCX_EINVAL, "pmcx_upload_cells: null argument");
+    const pmcx_config &cf = ctx->cfg;
+    if (!ctx->aero_data_set) return fail(ctx, PMCX_ESTATE, "pmcx_set_aero_data must come first");
+    if (cell_first < 0 || n_up < 1 || cell_first + n_up > cf.n_cells)
+        return fail(ctx, PMCX_EINVAL, "cell range [%d,%d) outside [0,%d)", cell_first,
+                    cell_first + n_up, cf.n_cells);
+    if (part_offset[0] != 0) return fail(ctx, PMCX_EINVAL, "part_offset[0] must be 0");
+    for (int k = 0; k < n_up; k++) {
+        const int64_t n = part_offset[k + 1] - part_offset[k];
+        if (n < 0 || n > cf.cap)
+            return fail(ctx, PMCX_EINVAL, "cell %d holds %lld particles, capacity %d",
+                        cell_first + k, (long long)n, cf.cap);
+    }
+    HIP_TRY(ctx, hipSetDevice(cf.device));
+    const int64_t nt = part_offset[n_up];
+    const size_t cap = (size_t)cf.cap;
+    DeviceState &st = ctx->st;
+    int rc = ensure_offsets(ctx, (size_t)n_up + 1);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_offsets, part_offset, sizeof(int64_t) * ((size_t)n_up + 1),
+                                hipMemcpyHostToDevice, ctx->stream));
+    const size_t per_part = sizeof(double) * (size_t)cf.n_spec + 4 + 8 + 8 + 8 +
+                            sizeof(int32_t) * (size_t)cf.n_source;
+    unsigned char *sp = nullptr;
+    auto h2d = [&](const void *src, size_t bytes) -> void * {
+        void *d = sp;
+        (void)hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+        sp += (bytes + 15) & ~(size_t)15;
+        return d;
+    };
+    // staging offsets are 16-byte aligned; enlarge the buffer estimate accordingly
+    rc = ensure_stage(ctx, per_part * (size_t)(nt > 0 ? nt : 1) + 16 * 8);
+    if (rc) return rc;
+    sp = (unsigned char *)ctx->stage;
+    const int64_t c0 = cell_first;
+    if (nt > 0) {
+        const double *s_vol = (const double *)h2d(vol, sizeof(double) * cf.n_spec * (size_t)nt);
+        HIP_TRY(ctx, launch_scatter_f64(s_vol, st.vol + c0 * cf.n_spec * cap, ctx->d_offsets, n_up,
+                                        cf.cap, (int64_t)cf.n_spec * cap, nt, cf.n_spec,
+                                        (int64_t)cap, ctx->stream));
+        if (wclass) {
+            const int32_t *s = (const int32_t *)h2d(wclass, sizeof(int32_t) * (size_t)nt);
+            HIP_TRY(ctx, launch_scatter_i32(s, st.wclass + c0 * cap, ctx->d_offsets, n_up, cf.cap,
+                                            (int64_t)cap, nt, 1, (int64_t)cap, ctx->stream));
+        } else {
+            HIP_TRY(ctx, hipMemsetAsync(st.wclass + c0 * cap, 0, sizeof(int32_t) * cap * n_up,
+                                        ctx->stream));
+        }
+        if (id) {
+            const double *s = (const double *)h2d(id, sizeof(int64_t) * (size_t)nt);
+            HIP_TRY(ctx, launch_scatter_f64(s, (double *)st.id + c0 * cap, ctx->d_offsets, n_up,
+                                            cf.cap, (int64_t)cap, nt, 1, (int64_t)cap, ctx->stream));
+        }
+        if (least_ct) {
+            const double *s = (const double *)h2d(least_ct, sizeof(double) * (size_t)nt);
+            HIP_TRY(ctx, launch_scatter_f64(s, st.lct + c0 * cap, ctx->d_offsets, n_up, cf.cap,
+                                            (int64_t)cap, nt, 1, (int64_t)cap, ctx->stream));
+        }
+        if (greatest_ct) {
+            const double *s = (const double *)h2d(greatest_ct, sizeof(double) * (size_t)nt);
+            HIP_TRY(ctx, launch_scatter_f64(s, st.gct + c0 * cap, ctx->d_offsets, n_up, cf.cap,
+                                            (int64_t)cap, nt, 1, (int64_t)cap, ctx->stream));
+        }
+        if (n_orig && cf.n_source > 0) {
+            const int32_t *s =
+                (const int32_t *)h2d(n_orig, sizeof(int32_t) * cf.n_source * (size_t)nt);
+            HIP_TRY(ctx, launch_scatter_i32(s, st.n_orig + c0 * cf.n_source * cap, ctx->d_offsets,
+                                            n_up, cf.cap, (int64_t)cf.n_source * cap, nt,
+                                            cf.n_source, (int64_t)cap, ctx->stream));
+        }
+    }
+    HIP_TRY(ctx, launch_set_n_part(st.n_part + c0, ctx->d_offsets, n_up, ctx->stream));
+    HIP_TRY(ctx, launch_refresh_caches(st, cell_first, n_up, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->sorted_valid = false;
+    return PMCX_OK;
+}
+
+int pmcx_download_cells(pmcx_ctx *ctx, int32_t cell_first, int32_t n_dn, const int64_t *part_offset,
+                        double *vol, int32_t *wclass, int64_t *id, double *least_ct,
+                        double *greatest_ct, int32_t *n_orig)
+{
+    if (!ctx || !part_offset) return fail(ctx, PMCX_EINVAL, "pmcx_download_cells: null argument");
+    const pmcx_config &cf = ctx->cfg;
+    if (cell_first < 0 || n_dn < 1 || cell_first + n_dn > cf.n_cells)
+        return fail(ctx, PMCX_EINVAL, "cell range outside the context");
+    HIP_TRY(ctx, hipSetDevice(cf.device));
+    std::vector<int32_t> np((size_t)n_dn);
+    HIP_TRY(ctx, hipMemcpyAsync(np.data(), ctx->st.n_part + cell_first, sizeof(int32_t) * n_dn,
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < n_dn; k++)
+        if (part_offset[k + 1] - part_offset[k] != np[k])
+            return fail(ctx, PMCX_EINVAL, "part_offset does not match n_part at cell %d",
+                        cell_first + k);
+    const int64_t nt = part_offset[n_dn];
+    if (nt == 0) return PMCX_OK;
+    const size_t cap = (size_t)cf.cap;
+    DeviceState &st = ctx->st;
+    int rc = ensure_offsets(ctx, (size_t)n_dn + 1);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_offsets, part_offset, sizeof(int64_t) * ((size_t)n_dn + 1),
+                                hipMemcpyHostToDevice, ctx->stream));
+    const size_t biggest = sizeof(double) * (size_t)(cf.n_spec > 1 ? cf.n_spec : 1) * (size_t)nt;
+    const size_t big2 = sizeof(int32_t) * (size_t)cf.n_source * (size_t)nt;
+    rc = ensure_stage(ctx, biggest > big2 ? biggest : big2);
+    if (rc) return rc;
+    const int64_t c0 = cell_first;
+    if (vol) {
+        HIP_TRY(ctx, launch_gather_f64((double *)ctx->stage, st.vol + c0 * cf.n_spec * cap,
+                                       ctx->d_offsets, n_dn, (int64_t)cf.n_spec * cap, nt,
+                                       cf.n_spec, (int64_t)cap, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(vol, ctx->stage, sizeof(double) * cf.n_spec * (size_t)nt,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    auto one_f64 = [&](double *host, const double *dev) -> int {
+        HIP_TRY(ctx, launch_gather_f64((double *)ctx->stage, dev + c0 * cap, ctx->d_offsets, n_dn,
+                                       (int64_t)cap, nt, 1, (int64_t)cap, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(host, ctx->stage, sizeof(double) * (size_t)nt,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return PMCX_OK;
+    };
+    if (id && (rc = one_f64((double *)id, (const double *)st.id))) return rc;
+    if (least_ct && (rc = one_f64(least_ct, st.lct))) return rc;
+    if (greatest_ct && (rc = one_f64(greatest_ct, st.gct))) return rc;
+    if (wclass) {
+        HIP_TRY(ctx, launch_gather_i32((int32_t *)ctx->stage, st.wclass + c0 * cap, ctx->d_offsets,
+                                       n_dn, (int64_t)cap, nt, 1, (int64_t)cap, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(wclass, ctx->stage, sizeof(int32_t) * (size_t)nt,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (n_orig && cf.n_source > 0) {
+        HIP_TRY(ctx, launch_gather_i32((int32_t *)ctx->stage, st.n_orig + c0 * cf.n_source * cap,
+                                       ctx->d_offsets, n_dn, (int64_t)cf.n_source * cap, nt,
+                                       cf.n_source, (int64_t)cap, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(n_orig, ctx->stage, sizeof(int32_t) * cf.n_source * (size_t)nt,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return PMCX_OK;
+}
+
+int pmcx_update_kernel_bounds(pmcx_ctx *ctx, int32_t kernel_type)
+{
+    if (!ctx) return PMCX_EINVAL;
+    if (!ctx->aero_data_set || !ctx->env_set)
+        return fail(ctx, PMCX_ESTATE, "pmcx_set_aero_data and pmcx_set_env must come first");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    {
+        ProfScope ps(ctx, "kernel_bounds");
+        HIP_TRY(ctx, launch_kernel_bounds(ctx->st, kernel_type, ctx->stream));
+    }
+    ctx->bounds_kernel = kernel_type;
+    return PMCX_OK;
+}
+
+static int check_kernel_type(pmcx_ctx *ctx, int32_t k)
+{
+    switch (k) {
+    case PMCX_COAG_KERNEL_TYPE_SEDI: case PMCX_COAG_KERNEL_TYPE_ADDITIVE:
+    case PMCX_COAG_KERNEL_TYPE_CONSTANT: case PMCX_COAG_KERNEL_TYPE_BROWN:
+    case PMCX_COAG_KERNEL_TYPE_ZERO: case PMCX_COAG_KERNEL_TYPE_BROWN_SEDI:
+        return PMCX_OK;
+    default:
+        return fail(ctx, PMCX_EINVAL, "unknown coag_kernel_type %d", k);
+    }
+}
+
+int pmcx_sort_only(pmcx_ctx *ctx)
+{
+    if (!ctx) return PMCX_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    ProfScope ps(ctx, "bin_sort");
+    HIP_TRY(ctx, launch_bin_sort(ctx->st, ctx->stream));
+    ctx->sorted_valid = true;
+    return PMCX_OK;
+}
+
+int pmcx_mc_coag(pmcx_ctx *ctx, int32_t kernel_type, double del_t, uint64_t seed, uint32_t step)
+{
+    if (!ctx) return PMCX_EINVAL;
+    int rc = check_kernel_type(ctx, kernel_type);
+    if (rc) return rc;
+    if (!(del_t >= 0)) return fail(ctx, PMCX_EINVAL, "del_t must be non-negative");
+    if (ctx->bounds_kernel != kernel_type) {
+        rc = pmcx_update_kernel_bounds(ctx, kernel_type);
+        if (rc) return rc;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->st.status, 0, sizeof(int32_t) * (size_t)ctx->cfg.n_cells,
+                                ctx->stream));
+    {
+        ProfScope ps(ctx, "bin_sort");
+        HIP_TRY(ctx, launch_bin_sort(ctx->st, ctx->stream));
+    }
+    {
+        ProfScope ps(ctx, "coag_sample");
+        HIP_TRY(ctx, launch_coag_sample(ctx->st, kernel_type, del_t, seed, step, ctx->stream));
+    }
+    {
+        ProfScope ps(ctx, "coag_apply");
+        HIP_TRY(ctx, launch_coag_apply(ctx->st, ctx->stream));
+    }
+    ctx->sorted_valid = false;
+    return PMCX_OK;
+}
+
+int pmcx_get_coag_counters(pmcx_ctx *ctx, int32_t *n_samp, int32_t *n_coag, int32_t *status)
+{
+    if (!ctx) return PMCX_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t b = sizeof(int32_t) * (size_t)ctx->cfg.n_cells;
+    if (n_samp) HIP_TRY(ctx, hipMemcpyAsync(n_samp, ctx->st.n_samp, b, hipMemcpyDeviceToHost, ctx->stream));
+    if (n_coag) HIP_TRY(ctx, hipMemcpyAsync(n_coag, ctx->st.n_coag, b, hipMemcpyDeviceToHost, ctx->stream));
+    if (status) HIP_TRY(ctx, hipMemcpyAsync(status, ctx->st.status, b, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PMCX_OK;
+}
+
+int pmcx_get_coag_totals(pmcx_ctx *ctx, int64_t *n_samp, int64_t *n_coag, int64_t *n_part,
+                         int32_t *status_or)
+{
+    if (!ctx) return PMCX_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_totals, 0, sizeof(int64_t) * 4, ctx->stream));
+    HIP_TRY(ctx, launch_totals(ctx->st, ctx->d_totals, ctx->stream));
+    int64_t h[4];
+    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_totals, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_samp) *n_samp = h[0];
+    if (n_coag) *n_coag = h[1];
+    if (n_part) *n_part = h[2];
+    if (status_or) *status_or = (int32_t)h[3];
+    return PMCX_OK;
+}
+
+int pmcx_rebalance(pmcx_ctx *ctx, int32_t allow_doubling, int32_t allow_halving, uint64_t seed,
+                   uint32_t step)
+{
+    if (!ctx) return PMCX_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    ProfScope ps(ctx, "rebalance");
+    HIP_TRY(ctx, launch_rebalance(ctx->st, allow_doubling, allow_halving, seed, step, ctx->stream));
+    ctx->sorted_valid = false;
+    return PMCX_OK;
+}
+
+int pmcx_diagnostics(pmcx_ctx *ctx, double *tot_num_conc, double *tot_mass_conc, double *num_dist,
+                     double *mass_dist)
+{
+    if (!ctx) return PMCX_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t nc = (size_t)ctx->cfg.n_cells, nd = (size_t)ctx->cfg.n_dbin;
+    double *d_tn = ctx->d_diag, *d_tm = d_tn + nc, *d_nd = d_tm + nc, *d_md = d_nd + nc * nd;
+    {
+        ProfScope ps(ctx, "diagnostics");
+        HIP_TRY(ctx, launch_diagnostics(ctx->st, d_tn, d_tm, d_nd, d_md, ctx->stream));
+    }
+    if (tot_num_conc) HIP_TRY(ctx, hipMemcpyAsync(tot_num_conc, d_tn, sizeof(double) * nc, hipMemcpyDeviceToHost, ctx->stream));
+    if (tot_mass_conc) HIP_TRY(ctx, hipMemcpyAsync(tot_mass_conc, d_tm, sizeof(double) * nc, hipMemcpyDeviceToHost, ctx->stream));
+    if (num_dist) HIP_TRY(ctx, hipMemcpyAsync(num_dist, d_nd, sizeof(double) * nc * nd, hipMemcpyDeviceToHost, ctx->stream));
+    if (mass_dist) HIP_TRY(ctx, hipMemcpyAsync(mass_dist, d_md, sizeof(double) * nc * nd, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PMCX_OK;
+}
+
+int pmcx_generate_lognormal(pmcx_ctx *ctx, int32_t n_part, int32_t n_mode, const double *mode_frac,
+                            const double *gm_radius, const double *gsd_log10,
+                            const double *vol_frac, const int32_t *mode_class,
+                            const int32_t *mode_source, uint64_t seed, double create_time)
+{
+    if (!ctx || !mode_frac || !gm_radius || !gsd_log10 || !vol_frac)
+        return fail(ctx, PMCX_EINVAL, "pmcx_generate_lognormal: null argument");
+    if (!ctx->aero_data_set) return fail(ctx, PMCX_ESTATE, "pmcx_set_aero_data must come first");
+    if (n_part < 0 || n_part > ctx->cfg.cap || n_mode < 1 || n_mode > 64)
+        return fail(ctx, PMCX_EINVAL, "n_part or n_mode out of range");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const int S = ctx->cfg.n_spec;
+    std::vector<double> h(3 * (size_t)n_mode + (size_t)n_mode * S);
+    double acc = 0, tot = 0;
+    for (int m = 0; m < n_mode; m++) tot += mode_frac[m];
+    for (int m = 0; m < n_mode; m++) {
+        acc += mode_frac[m];
+        h[m] = acc / tot;
+        h[n_mode + m] = std::log(gm_radius[m]);
+        h[2 * n_mode + m] = gsd_log10[m] * std::log(10.0);
+        for (int s = 0; s < S; s++) h[3 * n_mode + (size_t)m * S + s] = vol_frac[(size_t)m * S + s];
+    }
+    std::vector<int32_t> hi(2 * (size_t)n_mode);
+    for (int m = 0; m < n_mode; m++) {
+        hi[m] = mode_class ? mode_class[m] : 0;
+        hi[n_mode + m] = mode_source ? mode_source[m] : 0;
+        if (hi[m] < 0 || hi[m] >= ctx->cfg.n_class)
+            return fail(ctx, PMCX_EINVAL, "mode_class[%d] out of range", m);
+    }
+    int rc = ensure_stage(ctx, sizeof(double) * h.size() + sizeof(int32_t) * hi.size() + 64);
+    if (rc) return rc;
+    double *dd = (double *)ctx->stage;
+    int32_t *di = (int32_t *)(dd + h.size());
+    HIP_TRY(ctx, hipMemcpyAsync(dd, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(di, hi.data(), sizeof(int32_t) * hi.size(), hipMemcpyHostToDevice, ctx->stream));
+    GenSpecDev g;
+    g.n_mode = n_mode;
+    g.mode_frac = dd; g.ln_gm_radius = dd + n_mode; g.ln_gsd = dd + 2 * n_mode;
+    g.vol_frac = dd + 3 * n_mode;
+    g.mode_class = di; g.mode_source = di + n_mode;
+    {
+        ProfScope ps(ctx, "generate");
+        HIP_TRY(ctx, launch_generate(ctx->st, g, n_part, seed, create_time, ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->sorted_valid = false;
+    return PMCX_OK;
+}
+
+int pmcx_timestep(pmcx_ctx *ctx, const pmcx_step_flags *f)
+{
+    if (!ctx || !f) return fail(ctx, PMCX_EINVAL, "pmcx_timestep: null argument");
+    // chemistry-step gate, interface/wrf_pmc_driver.F90:189
+    const bool chem_step = std::fmod(f->elapsed_time, f->partmc_chem_dt) == 0.0;
+    const uint32_t step = (uint32_t)(f->elapsed_time / f->partmc_chem_dt);
+    const uint32_t wrf_step = (uint32_t)(f->elapsed_time / f->dt);
+    if (chem_step && f->do_coagulation) {
+        int rc = pmcx_mc_coag(ctx, f->kernel_type, f->partmc_chem_dt, f->random_seed, step);
+        if (rc) return rc;
+    }
+    return pmcx_rebalance(ctx, f->allow_doubling, f->allow_halving, f->random_seed, wrf_step);
+}
+
+int pmcx_get_bin_tables(pmcx_ctx *ctx, double *v_edge, double *v_samp)
+{
+    if (!ctx) return PMCX_EINVAL;
+    if (v_edge) memcpy(v_edge, ctx->v_edge.data(), sizeof(double) * ctx->v_edge.size());
+    if (v_samp) memcpy(v_samp, ctx->v_samp.data(), sizeof(double) * ctx->v_samp.size());
+    return PMCX_OK;
+}
+int pmcx_get_diag_grid(pmcx_ctx *ctx, double *d_edge, double *d_width)
+{
+    if (!ctx) return PMCX_EINVAL;
+    if (d_edge) memcpy(d_edge, ctx->d_edge.data(), sizeof(double) * ctx->d_edge.size());
+    if (d_width) memcpy(d_width, ctx->d_width.data(), sizeof(double) * ctx->d_width.size());
+    return PMCX_OK;
+}
+int pmcx_get_kmax(pmcx_ctx *ctx, int32_t cell, double *kmax)
+{
+    if (!ctx || !kmax || cell < 0 || cell >= ctx->cfg.n_cells) return fail(ctx, PMCX_EINVAL, "pmcx_get_kmax: bad argument");
+    if (!ctx->bounds_kernel) return fail(ctx, PMCX_ESTATE, "kernel bounds not computed yet");
+    const size_t bb = (size_t)ctx->cfg.n_bin * ctx->cfg.n_bin;
+    return copy_cells_d2h(ctx, kmax, ctx->st.kmax + (size_t)cell * bb, sizeof(double) * bb);
+}
+int pmcx_get_caches(pmcx_ctx *ctx, int32_t cell, double *vtot, double *mass)
+{
+    if (!ctx || cell < 0 || cell >= ctx->cfg.n_cells) return fail(ctx, PMCX_EINVAL, "pmcx_get_caches: bad argument");
+    const size_t cap = (size_t)ctx->cfg.cap;
+    int rc = PMCX_OK;
+    if (vtot) rc = copy_cells_d2h(ctx, vtot, ctx->st.vtot + cell * cap, sizeof(double) * cap);
+    if (!rc && mass) rc = copy_cells_d2h(ctx, mass, ctx->st.mass + cell * cap, sizeof(double) * cap);
+    return rc;
+}
+int pmcx_get_sort(pmcx_ctx *ctx, int32_t cell, uint32_t *perm, int32_t *gcnt, int32_t *goff)
+{
+    if (!ctx || cell < 0 || cell >= ctx->cfg.n_cells) return fail(ctx, PMCX_EINVAL, "pmcx_get_sort: bad argument");
+    if (!ctx->sorted_valid) return fail(ctx, PMCX_ESTATE, "call pmcx_sort_only first");
+    const size_t cap = (size_t)ctx->cfg.cap, G = (size_t)ctx->cfg.n_class * ctx->cfg.n_bin;
+    int rc = PMCX_OK;
+    if (perm) rc = copy_cells_d2h(ctx, perm, ctx->st.perm + cell * cap, sizeof(uint32_t) * cap);
+    if (!rc && gcnt) rc = copy_cells_d2h(ctx, gcnt, ctx->st.gcnt + cell * G, sizeof(int32_t) * G);
+    if (!rc && goff) rc = copy_cells_d2h(ctx, goff, ctx->st.goff + cell * G, sizeof(int32_t) * G);
+    return rc;
+}
+
+int pmcx_test_math(pmcx_ctx *ctx, int32_t op, int64_t n, const double *in, const double *in2,
+                   const double *in3, const double *in4, int32_t ktype, double temp,
+                   double pressure, double *out)
+{
+    if (!ctx || !in || !out || n < 1) return fail(ctx, PMCX_EINVAL, "pmcx_test_math: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    int rc = ensure_stage(ctx, sizeof(double) * 5 * (size_t)n);
+    if (rc) return rc;
+    double *d = (double *)ctx->stage;
+    const double *src[4] = {in, in2, in3, in4};
+    for (int k = 0; k < 4; k++)
+        if (src[k])
+            HIP_TRY(ctx, hipMemcpyAsync(d + k * n, src[k], sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, launch_test_math(op, n, d, d + n, d + 2 * n, d + 3 * n, ktype, temp, pressure,
+                                  ctx->cfg.const_k, ctx->cfg.additive_beta, d + 4 * n, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(out, d + 4 * n, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PMCX_OK;
+}
+
+int pmcx_test_philox(pmcx_ctx *ctx, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    if (!ctx || !ctr || !key || !out) return fail(ctx, PMCX_EINVAL, "pmcx_test_philox: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    int rc = ensure_stage(ctx, 64);
+    if (rc) return rc;
+    HIP_TRY(ctx, launch_test_philox(ctr, key, (uint32_t *)ctx->stage, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->stage, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PMCX_OK;
+}
+
+int pmcx_profile_enable(pmcx_ctx *ctx, int32_t on)
+{
+    if (!ctx) return PMCX_EINVAL;
+    ctx->prof = on != 0;
+    return PMCX_OK;
+}
+int pmcx_profile_reset(pmcx_ctx *ctx)
+{
+    if (!ctx) return PMCX_EINVAL;
+    (void)hipStreamSynchronize(ctx->stream);
+    prof_drain(ctx);
+    ctx->profile.clear();
+    return PMCX_OK;
+}
+int pmcx_profile_get(pmcx_ctx *ctx, const char *name, double *ms, int64_t *launches)
+{
+    if (!ctx || !name) return PMCX_EINVAL;
+    prof_drain(ctx);
+    auto it = ctx->profile.find(name);
+    if (ms) *ms = it == ctx->profile.end() ? 0.0 : it->second.ms;
+    if (launches) *launches = it == ctx->profile.end() ? 0 : it->second.launches;
+    return PMCX_OK;
+}
+
+} // extern "C"

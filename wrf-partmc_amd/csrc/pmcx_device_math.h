@@ -1,0 +1,333 @@
+// pmcx_device_math.h -- gfx950 device-side scalar building blocks.
+//
+// Counter-based RNG (Philox4x32-10) and exp/log/cbrt/inverse-normal built from
+// IEEE-754 +,-,*,/,sqrt and integer ops only, so results are reproducible
+// bit for bit across launch geometries and against a host restatement.
+// Built with -ffp-contract=off: no fused multiply-add may be formed here.
+//
+// Replaces on the reference path: pmc_srand/pmc_random/pmc_rand_int/
+// rand_poisson (interface/wrf_pmc_init.F90:131,
+// interface/wrf_pmc_trans_aero.F90:2107-2143), which draw from one sequential
+// GSL stream per MPI rank; here every draw is addressed by
+// (seed, global cell, step, site) so cells are independent.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pmcx {
+
+// ------------------------------------------------------------------ Philox
+
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]);
+        const uint32_t lo0 = 0xD2511F53u * c[0];
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]);
+        const uint32_t lo1 = 0xCD9E8D57u * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0;
+        const uint32_t n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+enum : uint32_t {
+    SITE_POISSON = 1,
+    SITE_CAND = 2,
+    SITE_COAG = 3,
+    SITE_HALVE = 4,
+    SITE_GEN = 5,
+    SITE_GENCLS = 6
+};
+
+// counter = (cell, step, a, site<<28 | b); key = seed
+__device__ __forceinline__ void rng_block(uint64_t seed, uint32_t cell, uint32_t step,
+                                          uint32_t a, uint32_t site, uint32_t b,
+                                          uint32_t (&w)[4])
+{
+    w[0] = cell; w[1] = step; w[2] = a;
+    w[3] = (site << 28) | (b & 0x0FFFFFFFu);
+    philox4x32_10(w, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+__device__ __forceinline__ double u53(uint32_t hi, uint32_t lo)
+{
+    const uint64_t x = ((uint64_t)hi << 32) | lo;
+    return (double)(x >> 11) * 0x1.0p-53;
+}
+
+__device__ __forceinline__ uint32_t index_of(uint32_t w, uint32_t n)
+{
+    return __umulhi(w, n);
+}
+
+// -------------------------------------------------------------- exp / log
+
+__device__ __forceinline__ double u2d(uint64_t u) { return __longlong_as_double((long long)u); }
+__device__ __forceinline__ uint64_t d2u(double x) { return (uint64_t)__double_as_longlong(x); }
+
+__device__ inline double det_exp(double x)
+{
+    if (x < -745.0) return 0.0;
+    if (x > 709.0) return __builtin_inf();
+    const double inv_ln2 = 1.4426950408889634;
+    const double ln2_hi = 6.93147180369123816490e-01;
+    const double ln2_lo = 1.90821492927058770002e-10;
+    const double t = x * inv_ln2;
+    const int k = (int)(t + (t < 0.0 ? -0.5 : 0.5));
+    const double kd = (double)k;
+    const double r = (x - kd * ln2_hi) - kd * ln2_lo;
+    double p = 1.0 / 6227020800.0;
+    p = p * r + 1.0 / 479001600.0;
+    p = p * r + 1.0 / 39916800.0;
+    p = p * r + 1.0 / 3628800.0;
+    p = p * r + 1.0 / 362880.0;
+    p = p * r + 1.0 / 40320.0;
+    p = p * r + 1.0 / 5040.0;
+    p = p * r + 1.0 / 720.0;
+    p = p * r + 1.0 / 120.0;
+    p = p * r + 1.0 / 24.0;
+    p = p * r + 1.0 / 6.0;
+    p = p * r + 0.5;
+    p = p * r + 1.0;
+    p = p * r + 1.0;
+    if (k >= -1021) return p * u2d((uint64_t)(k + 1023) << 52);
+    return (p * u2d((uint64_t)(k + 1000 + 1023) << 52)) * 0x1.0p-1000;
+}
+
+__device__ inline double det_log(double x)
+{
+    const double ln2_hi = 6.93147180369123816490e-01;
+    const double ln2_lo = 1.90821492927058770002e-10;
+    const uint64_t u = d2u(x);
+    int e = (int)((u >> 52) & 0x7FF) - 1023;
+    double m = u2d((u & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull);
+    if (m > 1.4142135623730951) { m = m * 0.5; e = e + 1; }
+    const double s = (m - 1.0) / (m + 1.0);
+    const double s2 = s * s;
+    double q = 2.0 / 23.0;
+    q = q * s2 + 2.0 / 21.0;
+    q = q * s2 + 2.0 / 19.0;
+    q = q * s2 + 2.0 / 17.0;
+    q = q * s2 + 2.0 / 15.0;
+    q = q * s2 + 2.0 / 13.0;
+    q = q * s2 + 2.0 / 11.0;
+    q = q * s2 + 2.0 / 9.0;
+    q = q * s2 + 2.0 / 7.0;
+    q = q * s2 + 2.0 / 5.0;
+    q = q * s2 + 2.0 / 3.0;
+    q = q * s2 + 2.0;
+    const double ed = (double)e;
+    return ed * ln2_hi + (s * q + ed * ln2_lo);
+}
+
+__device__ inline double det_cbrt(double x)
+{
+    if (x <= 0.0) return 0.0;
+    uint64_t u = d2u(x);
+    u = u / 3 + 0x2A9F789300000000ull;
+    double y = u2d(u);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const double y3 = y * y * y;
+        y = y * ((y3 + 2.0 * x) / (2.0 * y3 + x));
+    }
+    y = y - (y * y * y - x) / (3.0 * y * y);
+    return y;
+}
+
+__device__ inline double det_norminv(double p)
+{
+    const double a0 = -3.969683028665376e+01, a1 = 2.209460984245205e+02,
+                 a2 = -2.759285104469687e+02, a3 = 1.383577518672690e+02,
+                 a4 = -3.066479806614716e+01, a5 = 2.506628277459239e+00;
+    const double b0 = -5.447609879822406e+01, b1 = 1.615858368580409e+02,
+                 b2 = -1.556989798598866e+02, b3 = 6.680131188771972e+01,
+                 b4 = -1.328068155288572e+01;
+    const double c0 = -7.784894002430293e-03, c1 = -3.223964580411365e-01,
+                 c2 = -2.400758277161838e+00, c3 = -2.549732539343734e+00,
+                 c4 = 4.374664141464968e+00, c5 = 2.938163982698783e+00;
+    const double d0 = 7.784695709041462e-03, d1 = 3.224671290700398e-01,
+                 d2 = 2.445134137142996e+00, d3 = 3.754408661907416e+00;
+    const double p_low = 0.02425;
+    if (p < 0x1.0p-53) p = 0x1.0p-53;
+    if (p < p_low) {
+        const double q = __builtin_sqrt(-2.0 * det_log(p));
+        return (((((c0 * q + c1) * q + c2) * q + c3) * q + c4) * q + c5) /
+               ((((d0 * q + d1) * q + d2) * q + d3) * q + 1.0);
+    }
+    if (p <= 1.0 - p_low) {
+        const double q = p - 0.5;
+        const double r = q * q;
+        return (((((a0 * r + a1) * r + a2) * r + a3) * r + a4) * r + a5) * q /
+               (((((b0 * r + b1) * r + b2) * r + b3) * r + b4) * r + 1.0);
+    }
+    {
+        const double q = __builtin_sqrt(-2.0 * det_log(1.0 - p));
+        return -(((((c0 * q + c1) * q + c2) * q + c3) * q + c4) * q + c5) /
+               ((((d0 * q + d1) * q + d2) * q + d3) * q + 1.0);
+    }
+}
+
+// ---------------------------------------------------------------- Poisson
+
+constexpr double POISSON_WALK_MAX = 200.0;
+constexpr int32_t NSAMP_MAX = 0x0FFFFFFF;
+
+__device__ inline int32_t poisson(double mean, double u)
+{
+    if (!(mean > 0.0)) return 0;
+    if (mean < POISSON_WALK_MAX) {
+        double p = det_exp(-mean);
+        double F = p;
+        int32_t n = 0;
+        while (u > F && n < 1000) {
+            n = n + 1;
+            p = p * (mean / (double)n);
+            F = F + p;
+        }
+        return n;
+    }
+    const double z = det_norminv(u);
+    const double x = mean + __builtin_sqrt(mean) * z + 0.5;
+    if (x < 0.0) return 0;
+    if (x > (double)NSAMP_MAX) return NSAMP_MAX;
+    return (int32_t)x;
+}
+
+// ------------------------------------------------------ coagulation kernels
+//
+// Brownian kernel: Fuchs form, Jacobson (2005) eq. 15.33 -- the form of
+// PartMC's kernel_brown [upstream] and of the in-tree
+// WRFV3/chem/module_mosaic_coag.F:898-936 (slip constants 1.257/0.42/1.1
+// there, Jacobson's 1.249/0.42/0.87 here).  Selected by
+// COAG_KERNEL_TYPE_BROWN at interface/wrf_pmc_driver.F90:192.
+
+constexpr double PI = 3.14159265358979323846;
+constexpr double BOLTZMANN = 1.3806505e-23;
+constexpr double AVOGADRO = 6.02214179e23;
+constexpr double UNIV_GAS = 8.314472;
+constexpr double AIR_MW = 2.89644e-2;
+constexpr double GRAV = 9.80665;
+
+enum : int {
+    KERNEL_SEDI = 1,
+    KERNEL_ADDITIVE = 2,
+    KERNEL_CONSTANT = 3,
+    KERNEL_BROWN = 4,
+    KERNEL_ZERO = 5,
+    KERNEL_BROWN_SEDI = 101
+};
+
+struct EnvDerived {
+    double kT, viscosd, gasfreepath, rhoair;
+};
+
+struct PartProps {
+    double rad, diffus, speedsq, deltasq, wfall;
+};
+
+struct KernelParams {
+    double const_k, additive_beta;
+};
+
+__device__ inline EnvDerived env_derive(double temp, double pressure)
+{
+    EnvDerived e;
+    e.kT = BOLTZMANN * temp;
+    e.rhoair = AIR_MW * pressure / (UNIV_GAS * temp);
+    const double tr = temp / 296.16;
+    e.viscosd = (1.8325e-5 * (296.16 + 120.0) / (temp + 120.0)) * (tr * __builtin_sqrt(tr));
+    const double viscosk = e.viscosd / e.rhoair;
+    const double gasspeed =
+        __builtin_sqrt(8.0 * BOLTZMANN * temp * AVOGADRO / (PI * AIR_MW));
+    e.gasfreepath = 2.0 * viscosk / gasspeed;
+    return e;
+}
+
+__device__ inline PartProps particle_props(double v, double m, const EnvDerived &e)
+{
+    PartProps q;
+    const double rad = det_cbrt(v * (0.75 / PI));
+    const double knud = e.gasfreepath / rad;
+    const double cunning = 1.0 + knud * (1.249 + 0.42 * det_exp(-0.87 / knud));
+    const double diffus = e.kT * cunning / (6.0 * PI * rad * e.viscosd);
+    const double speedsq = (8.0 * e.kT / PI) / m;
+    const double freepath = 8.0 * diffus / (PI * __builtin_sqrt(speedsq));
+    const double t1 = 2.0 * rad + freepath;
+    const double tmp1 = t1 * t1 * t1;
+    const double t2 = 4.0 * rad * rad + freepath * freepath;
+    const double tmp2 = t2 * __builtin_sqrt(t2);
+    const double d = (tmp1 - tmp2) / (6.0 * rad * freepath) - 2.0 * rad;
+    q.rad = rad;
+    q.diffus = diffus;
+    q.speedsq = speedsq;
+    q.deltasq = d * d;
+    const double rho = m / v;
+    q.wfall = (2.0 * rad * rad * (rho - e.rhoair) * GRAV * cunning) / (9.0 * e.viscosd);
+    return q;
+}
+
+__device__ inline double brown_pair(const PartProps &a, const PartProps &b)
+{
+    const double rad_sum = a.rad + b.rad;
+    const double diffus_sum = a.diffus + b.diffus;
+    const double tmp1 = rad_sum / (rad_sum + __builtin_sqrt(a.deltasq + b.deltasq));
+    const double tmp2 = 4.0 * diffus_sum / (rad_sum * __builtin_sqrt(a.speedsq + b.speedsq));
+    return 4.0 * PI * rad_sum * diffus_sum / (tmp1 + tmp2);
+}
+
+// E pi (r1+r2)^2 |w1-w2|, Long (1974) efficiency, Stokes-Cunningham fall speed
+__device__ inline double sedi_pair(const PartProps &a, const PartProps &b)
+{
+    const double r_big = a.rad > b.rad ? a.rad : b.rad;
+    const double r_small = a.rad > b.rad ? b.rad : a.rad;
+    double eff;
+    if (r_big <= 50.0e-6) {
+        const double rb_cm = r_big * 100.0, rs_cm = r_small * 100.0;
+        eff = 4.5e4 * rb_cm * rb_cm * (1.0 - 3.0e-4 / rs_cm);
+        if (eff < 1.0e-3) eff = 1.0e-3;
+    } else {
+        eff = 1.0;
+    }
+    const double rs = a.rad + b.rad;
+    double dw = a.wfall - b.wfall;
+    if (dw < 0.0) dw = -dw;
+    return eff * PI * rs * rs * dw;
+}
+
+__device__ __forceinline__ bool kernel_needs_props(int type)
+{
+    return type == KERNEL_BROWN || type == KERNEL_SEDI || type == KERNEL_BROWN_SEDI;
+}
+
+__device__ inline double kernel_pair(int type, double v1, double v2, const PartProps &a,
+                                     const PartProps &b, const KernelParams &kp)
+{
+    switch (type) {
+    case KERNEL_BROWN: return brown_pair(a, b);
+    case KERNEL_SEDI: return sedi_pair(a, b);
+    case KERNEL_BROWN_SEDI: return brown_pair(a, b) + sedi_pair(a, b);
+    case KERNEL_CONSTANT: return kp.const_k;
+    case KERNEL_ADDITIVE: return kp.additive_beta * (v1 + v2);
+    default: return 0.0;
+    }
+}
+
+// bin b has v_edge[b] <= v < v_edge[b+1]; out-of-range clamps to the end bins
+template <typename EdgePtr>
+__device__ __forceinline__ int bin_of(EdgePtr v_edge, int n_bin, double v)
+{
+    int lo = 0, hi = n_bin;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (v >= v_edge[mid]) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+} // namespace pmcx

@@ -1,0 +1,98 @@
+// pmcx_kernels.h -- device state view and kernel launchers (internal).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pmcx {
+
+enum : int {
+    ST_EVENT_OVERFLOW = 1,
+    ST_APPEND_OVERFLOW = 2,
+    ST_KMAX_EXCEEDED = 4,
+    ST_OUT_OF_GRID = 8,
+    ST_CAP_OVERFLOW = 16
+};
+
+// Plain view of everything a kernel needs; passed by value.
+struct DeviceState {
+    int32_t n_cells, cap, n_spec, n_class, n_source, n_bin, n_dbin, i_water;
+    int32_t max_events, max_appends;
+    uint32_t cell_id_base;
+    double const_k, additive_beta;
+    double rho_min, rho_max;
+    double log2_v0, inv_dlog2; // bit-level bin estimate of the sort grid
+    // model tables
+    const double *density; // [n_spec]
+    const double *v_edge;  // [n_bin+1]
+    const double *v_samp;  // [n_bin*3]
+    const double *d_edge;  // [n_dbin+1]
+    const double *d_width; // [n_dbin]
+    // per cell
+    const double *temp, *pressure; // [n_cells]
+    double *mag;                   // [n_cells][n_class]
+    const double *n_ideal;         // [n_cells][n_class]
+    double *kmax;                  // [n_cells][n_bin*n_bin]
+    int32_t *n_part;               // [n_cells]
+    int64_t *next_id;              // [n_cells]
+    // particles
+    double *vol;     // [n_cells][n_spec][cap]
+    double *vtot;    // [n_cells][cap]
+    double *mass;    // [n_cells][cap]
+    int32_t *wclass; // [n_cells][cap]
+    int64_t *id;     // [n_cells][cap]
+    double *lct, *gct;
+    int32_t *n_orig; // [n_cells][n_source][cap]
+    // scratch / outputs of the coagulation step
+    uint32_t *perm;  // [n_cells][cap]
+    int32_t *gcnt;   // [n_cells][n_class*n_bin]
+    int32_t *goff;   // [n_cells][n_class*n_bin]
+    int4 *events;    // [n_cells][max_events]
+    int32_t *n_events, *n_samp, *n_coag, *status; // [n_cells]
+};
+
+struct GenSpecDev {
+    int32_t n_mode;
+    const double *mode_frac, *ln_gm_radius, *ln_gsd, *vol_frac;
+    const int32_t *mode_class, *mode_source;
+};
+
+// shared-memory footprints (host side needs them to size launches)
+size_t bin_sort_lds_bytes(const DeviceState &st);
+size_t sampler_lds_bytes_per_cell(const DeviceState &st);
+size_t diagnostics_lds_bytes(const DeviceState &st);
+
+hipError_t launch_scatter_f64(const double *src, double *dst, const int64_t *part_offset, int n_up,
+                              int cap, int64_t dst_cell_stride, int64_t src_row_stride, int n_rows,
+                              int64_t dst_row_stride, hipStream_t s);
+hipError_t launch_scatter_i32(const int32_t *src, int32_t *dst, const int64_t *part_offset,
+                              int n_up, int cap, int64_t dst_cell_stride, int64_t src_row_stride,
+                              int n_rows, int64_t dst_row_stride, hipStream_t s);
+hipError_t launch_gather_f64(double *dst, const double *src, const int64_t *part_offset, int n_dn,
+                             int64_t src_cell_stride, int64_t dst_row_stride, int n_rows,
+                             int64_t src_row_stride, hipStream_t s);
+hipError_t launch_gather_i32(int32_t *dst, const int32_t *src, const int64_t *part_offset,
+                             int n_dn, int64_t src_cell_stride, int64_t dst_row_stride, int n_rows,
+                             int64_t src_row_stride, hipStream_t s);
+hipError_t launch_set_n_part(int32_t *n_part, const int64_t *part_offset, int n_up, hipStream_t s);
+hipError_t launch_refresh_caches(const DeviceState &st, int cell_first, int n_cells_do,
+                                 hipStream_t s);
+hipError_t launch_kernel_bounds(const DeviceState &st, int ktype, hipStream_t s);
+hipError_t launch_bin_sort(const DeviceState &st, hipStream_t s);
+hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, uint64_t seed,
+                              uint32_t step, hipStream_t s);
+hipError_t launch_coag_apply(const DeviceState &st, hipStream_t s);
+hipError_t launch_rebalance(const DeviceState &st, int allow_doubling, int allow_halving,
+                            uint64_t seed, uint32_t step, hipStream_t s);
+hipError_t launch_diagnostics(const DeviceState &st, double *tot_num, double *tot_mass,
+                              double *num_dist, double *mass_dist, hipStream_t s);
+hipError_t launch_generate(const DeviceState &st, const GenSpecDev &g, int n, uint64_t seed,
+                           double create_time, hipStream_t s);
+hipError_t launch_totals(const DeviceState &st, int64_t *out4, hipStream_t s);
+hipError_t launch_test_math(int op, int64_t n, const double *a, const double *b, const double *c3,
+                            const double *c4, int ktype, double temp, double pressure,
+                            double const_k, double additive_beta, double *out, hipStream_t s);
+hipError_t launch_test_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t *out_dev,
+                              hipStream_t s);
+
+} // namespace pmcx

@@ -1,0 +1,60 @@
+"""Input tables of the reference's shipped cases (data, transcribed as values).
+
+Sources in /root/reference:
+  WRFV3/test/em_scm_xy/aero_data.dat:2-21     species table
+  WRFV3/test/em_scm_xy/aero_init_dist.dat:2-14  bimodal initial distribution
+  WRFV3/test/em_scm_xy/aero_init_comp.dat:2-4   its composition (mass fractions)
+  interface/wrf_pmc_init.F90:1764-1777          idealised log-normal IC
+"""
+import numpy as np
+
+# name, density kg/m^3, ions in solution, molecular weight kg/mol, kappa
+AERO_DATA_SCM = [
+    ("SO4", 1770.0, 0, 96e-3, 0.65), ("NO3", 1770.0, 0, 62e-3, 0.65),
+    ("Cl", 1900.0, 0, 35.5e-3, 1.28), ("NH4", 1770.0, 0, 18e-3, 0.65),
+    ("MSA", 1800.0, 0, 95e-3, 0.53), ("ARO1", 1400.0, 0, 150e-3, 0.1),
+    ("ARO2", 1400.0, 0, 150e-3, 0.1), ("ALK1", 1400.0, 0, 140e-3, 0.1),
+    ("OLE1", 1400.0, 0, 140e-3, 0.1), ("API1", 1000.0, 0, 184e-3, 0.1),
+    ("API2", 1400.0, 0, 184e-3, 0.1), ("LIM1", 1400.0, 0, 200e-3, 0.1),
+    ("LIM2", 1400.0, 0, 200e-3, 0.1), ("CO3", 2600.0, 0, 60e-3, 0.53),
+    ("Na", 1900.0, 0, 23e-3, 1.28), ("Ca", 2600.0, 0, 40e-3, 0.53),
+    ("OIN", 2600.0, 0, 1e-3, 0.1), ("OC", 1000.0, 0, 1e-3, 0.001),
+    ("BC", 1700.0, 0, 1e-3, 0.0), ("H2O", 1000.0, 0, 18e-3, 0.0),
+]
+
+
+def aero_data_arrays(names=None):
+    rows = AERO_DATA_SCM if names is None else [r for n in names for r in AERO_DATA_SCM if r[0] == n]
+    return (np.array([r[1] for r in rows]), np.array([r[4] for r in rows]),
+            np.array([r[3] for r in rows]), [r[0] for r in rows])
+
+
+def _vol_frac_from_mass_frac(mass_frac, names):
+    """PartMC converts mass fractions to volume fractions with the densities."""
+    dens, _, _, all_names = aero_data_arrays(names)
+    vf = np.zeros(len(all_names))
+    for sp, mf in mass_frac.items():
+        i = all_names.index(sp)
+        vf[i] = mf / dens[i]
+    return vf / vf.sum()
+
+
+def scm_init_modes(names=None):
+    """em_scm_xy bimodal IC (aero_init_dist.dat) with composition aero_init_comp.dat.
+    Returns (modes, total number concentration m^-3)."""
+    vf = _vol_frac_from_mass_frac({"OC": 1.375, "SO4": 1.0, "NH4": 0.375}, names)
+    n_small, n_large = 3.2e9, 2.9e9
+    modes = [
+        dict(frac=n_small, gm_radius=2e-8 / 2, gsd_log10=0.161, vol_frac=vf, wclass=0, source=0),
+        dict(frac=n_large, gm_radius=1.16e-7 / 2, gsd_log10=0.217, vol_frac=vf, wclass=0, source=0),
+    ]
+    return modes, n_small + n_large
+
+
+def idealised_modes(n_spec, n_modes=1):
+    """Idealised IC of init_wrf_partmc_idealized: log-normal, char_radius 2e-8 m,
+    log10_std_dev_radius 0.25, species 1 only; one weight class per mode."""
+    vf = np.zeros(n_spec)
+    vf[0] = 1.0
+    return [dict(frac=1.0, gm_radius=2e-8, gsd_log10=0.25, vol_frac=vf, wclass=m, source=m)
+            for m in range(n_modes)]

@@ -1,0 +1,374 @@
+"""ctypes host over libpmcx.so (include/pmcx.h).
+
+Names follow the reference's call surface on the path
+(interface/wrf_pmc_driver.F90:143,174,192-194,248-251): ``mc_coag``,
+``aero_state_rebalance``, ``aero_state_total_particles``, ``partmc_timestep``.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+
+COAG_KERNEL_TYPE_SEDI = 1
+COAG_KERNEL_TYPE_ADDITIVE = 2
+COAG_KERNEL_TYPE_CONSTANT = 3
+COAG_KERNEL_TYPE_BROWN = 4
+COAG_KERNEL_TYPE_ZERO = 5
+COAG_KERNEL_TYPE_BROWN_SEDI = 101
+
+# every symbol include/pmcx.h declares
+EXPORTED_SYMBOLS = [
+    "pmcx_config_default", "pmcx_create", "pmcx_destroy", "pmcx_last_error", "pmcx_synchronize",
+    "pmcx_set_aero_data", "pmcx_set_env", "pmcx_set_weights", "pmcx_get_weights",
+    "pmcx_set_n_part_ideal", "pmcx_set_next_id", "pmcx_get_next_id", "pmcx_upload_cells",
+    "pmcx_get_n_part", "pmcx_download_cells", "pmcx_update_kernel_bounds", "pmcx_mc_coag",
+    "pmcx_get_coag_counters", "pmcx_get_coag_totals", "pmcx_rebalance", "pmcx_diagnostics",
+    "pmcx_generate_lognormal", "pmcx_timestep", "pmcx_get_bin_tables", "pmcx_get_diag_grid",
+    "pmcx_get_kmax", "pmcx_get_caches", "pmcx_sort_only", "pmcx_get_sort", "pmcx_test_math",
+    "pmcx_test_philox", "pmcx_profile_enable", "pmcx_profile_reset", "pmcx_profile_get",
+    "pmcx_memory_bytes",
+]
+
+
+class PmcxError(RuntimeError):
+    pass
+
+
+class PmcxConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("device", C.c_int32), ("n_cells", C.c_int32),
+        ("cap", C.c_int32), ("n_spec", C.c_int32), ("n_class", C.c_int32),
+        ("n_source", C.c_int32), ("n_bin", C.c_int32), ("r_min", C.c_double),
+        ("r_max", C.c_double), ("max_events", C.c_int32), ("max_appends", C.c_int32),
+        ("n_dbin", C.c_int32), ("i_water", C.c_int32), ("d_min", C.c_double),
+        ("d_max", C.c_double), ("cell_id_base", C.c_uint32), ("reserved", C.c_uint32),
+        ("const_k", C.c_double), ("additive_beta", C.c_double),
+    ]
+
+
+class PmcxStepFlags(C.Structure):
+    _fields_ = [
+        ("do_coagulation", C.c_int32), ("allow_doubling", C.c_int32),
+        ("allow_halving", C.c_int32), ("kernel_type", C.c_int32), ("dt", C.c_double),
+        ("partmc_chem_dt", C.c_double), ("elapsed_time", C.c_double),
+        ("random_seed", C.c_uint64),
+    ]
+
+
+def library_path():
+    return os.path.join(_HERE, "libpmcx.so")
+
+
+def build_library(force=False):
+    """Compile the HIP sources for gfx950 (hipcc cross-compiles without a GPU)."""
+    so = library_path()
+    src_dir = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(src_dir, f) for f in os.listdir(src_dir)
+            if f.endswith((".hip", ".h"))] + [os.path.join(_ROOT, "include", "pmcx.h")]
+    stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", src_dir, "-s"])
+    return so
+
+
+_LIB = None
+
+
+def load_library():
+    """dlopen libpmcx.so.  Raises if it has not been built -- there is no fallback."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    so = library_path()
+    if not os.path.exists(so):
+        raise PmcxError(
+            f"{so} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(the HIP extension is required; there is no CPU path)")
+    L = C.CDLL(so)
+    L.pmcx_last_error.restype = C.c_char_p
+    L.pmcx_last_error.argtypes = [C.c_void_p]
+    L.pmcx_config_default.restype = None
+    L.pmcx_config_default.argtypes = [C.POINTER(PmcxConfig)]
+    L.pmcx_create.argtypes = [C.POINTER(PmcxConfig), C.POINTER(C.c_void_p)]
+    L.pmcx_mc_coag.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_uint64, C.c_uint32]
+    L.pmcx_rebalance.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_uint32]
+    L.pmcx_generate_lognormal.argtypes = [
+        C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+        C.c_void_p, C.c_void_p, C.c_uint64, C.c_double]
+    L.pmcx_test_math.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_double,
+                                 C.c_void_p]
+    L.pmcx_profile_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double),
+                                   C.POINTER(C.c_int64)]
+    L.pmcx_timestep.argtypes = [C.c_void_p, C.POINTER(PmcxStepFlags)]
+    for name in ("pmcx_upload_cells", "pmcx_download_cells"):
+        getattr(L, name).argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 7
+    _LIB = L
+    return L
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+class CellBlock:
+    """A block of grid cells resident on one MI355X: the batched counterpart of
+    the reference's ``aero_states(i,k,j)`` / ``env_states(i,k,j)`` arrays
+    (WRFV3/main/module_wrf_top.F:522-525)."""
+
+    def __init__(self, n_cells, cap, n_spec, n_class=1, n_source=0, device=0, cell_id_base=0,
+                 **overrides):
+        self._lib = load_library()
+        cfg = PmcxConfig()
+        self._lib.pmcx_config_default(C.byref(cfg))
+        cfg.device, cfg.n_cells, cfg.cap, cfg.n_spec = device, n_cells, cap, n_spec
+        cfg.n_class, cfg.n_source, cfg.cell_id_base = n_class, n_source, cell_id_base
+        for k, v in overrides.items():
+            if not hasattr(cfg, k):
+                raise TypeError(f"unknown pmcx_config field {k!r}")
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        rc = self._lib.pmcx_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            raise PmcxError(f"pmcx_create failed ({rc}): "
+                            f"{self._lib.pmcx_last_error(None).decode()}")
+
+    # -- plumbing ---------------------------------------------------------
+    def _ck(self, rc):
+        if rc != 0:
+            raise PmcxError(f"pmcx error {rc}: {self._lib.pmcx_last_error(self._h).decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.pmcx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def synchronize(self):
+        self._ck(self._lib.pmcx_synchronize(self._h))
+
+    # -- model / environment ---------------------------------------------
+    def set_aero_data(self, density, kappa=None, molec_weight=None):
+        d = _f64(density)
+        assert d.shape == (self.cfg.n_spec,)
+        self._ck(self._lib.pmcx_set_aero_data(self._h, _ptr(d), _ptr(_f64(kappa)),
+                                              _ptr(_f64(molec_weight))))
+
+    def set_env(self, temp, pressure, rel_humid=None):
+        n = self.cfg.n_cells
+        t = np.broadcast_to(_f64(temp), (n,)).copy()
+        p = np.broadcast_to(_f64(pressure), (n,)).copy()
+        r = None if rel_humid is None else np.broadcast_to(_f64(rel_humid), (n,)).copy()
+        self._ck(self._lib.pmcx_set_env(self._h, _ptr(t), _ptr(p), _ptr(r)))
+
+    def set_weights(self, magnitude):
+        m = np.broadcast_to(_f64(magnitude), (self.cfg.n_cells, self.cfg.n_class)).copy()
+        self._ck(self._lib.pmcx_set_weights(self._h, _ptr(m)))
+
+    def get_weights(self):
+        m = np.zeros((self.cfg.n_cells, self.cfg.n_class))
+        self._ck(self._lib.pmcx_get_weights(self._h, _ptr(m)))
+        return m
+
+    def set_n_part_ideal(self, n_ideal):
+        m = np.broadcast_to(_f64(n_ideal), (self.cfg.n_cells, self.cfg.n_class)).copy()
+        self._ck(self._lib.pmcx_set_n_part_ideal(self._h, _ptr(m)))
+
+    def set_next_id(self, next_id):
+        a = np.broadcast_to(np.asarray(next_id, dtype=np.int64), (self.cfg.n_cells,)).copy()
+        self._ck(self._lib.pmcx_set_next_id(self._h, _ptr(a)))
+
+    def get_next_id(self):
+        a = np.zeros(self.cfg.n_cells, dtype=np.int64)
+        self._ck(self._lib.pmcx_get_next_id(self._h, _ptr(a)))
+        return a
+
+    # -- particle data ----------------------------------------------------
+    def upload_cells(self, cell_first, part_offset, vol, wclass=None, id=None, least_ct=None,
+                     greatest_ct=None, n_orig=None):
+        po = np.ascontiguousarray(part_offset, dtype=np.int64)
+        n_up, nt = len(po) - 1, int(po[-1])
+        v = _f64(vol)
+        assert v.shape == (self.cfg.n_spec, nt), (v.shape, nt)
+        wc = None if wclass is None else np.ascontiguousarray(wclass, dtype=np.int32)
+        ii = None if id is None else np.ascontiguousarray(id, dtype=np.int64)
+        no = None if n_orig is None else np.ascontiguousarray(n_orig, dtype=np.int32)
+        self._ck(self._lib.pmcx_upload_cells(self._h, cell_first, n_up, _ptr(po), _ptr(v),
+                                             _ptr(wc), _ptr(ii), _ptr(_f64(least_ct)),
+                                             _ptr(_f64(greatest_ct)), _ptr(no)))
+
+    def aero_state_total_particles(self):
+        """n_part of every cell (reference: aero_state_total_particles, driver:143,174)."""
+        a = np.zeros(self.cfg.n_cells, dtype=np.int32)
+        self._ck(self._lib.pmcx_get_n_part(self._h, _ptr(a)))
+        return a
+
+    def download_cells(self, cell_first=0, n_cells=None):
+        n_cells = self.cfg.n_cells - cell_first if n_cells is None else n_cells
+        npart = self.aero_state_total_particles()[cell_first:cell_first + n_cells]
+        po = np.zeros(n_cells + 1, dtype=np.int64)
+        po[1:] = np.cumsum(npart)
+        nt = int(po[-1])
+        out = dict(
+            part_offset=po,
+            vol=np.zeros((self.cfg.n_spec, nt)),
+            wclass=np.zeros(nt, dtype=np.int32),
+            id=np.zeros(nt, dtype=np.int64),
+            least_ct=np.zeros(nt), greatest_ct=np.zeros(nt),
+            n_orig=np.zeros((max(self.cfg.n_source, 1), nt), dtype=np.int32),
+        )
+        self._ck(self._lib.pmcx_download_cells(
+            self._h, cell_first, n_cells, _ptr(po), _ptr(out["vol"]), _ptr(out["wclass"]),
+            _ptr(out["id"]), _ptr(out["least_ct"]), _ptr(out["greatest_ct"]),
+            _ptr(out["n_orig"]) if self.cfg.n_source > 0 else None))
+        return out
+
+    def generate_lognormal(self, n_part, modes, seed, create_time=0.0):
+        """modes: list of dict(frac, gm_radius, gsd_log10, vol_frac, wclass, source)."""
+        fr = _f64([m["frac"] for m in modes])
+        gm = _f64([m["gm_radius"] for m in modes])
+        gs = _f64([m["gsd_log10"] for m in modes])
+        vf = _f64([m["vol_frac"] for m in modes])
+        mc = np.array([m.get("wclass", 0) for m in modes], dtype=np.int32)
+        ms = np.array([m.get("source", 0) for m in modes], dtype=np.int32)
+        assert vf.shape == (len(modes), self.cfg.n_spec)
+        self._ck(self._lib.pmcx_generate_lognormal(self._h, n_part, len(modes), _ptr(fr), _ptr(gm),
+                                                   _ptr(gs), _ptr(vf), _ptr(mc), _ptr(ms), seed,
+                                                   create_time))
+
+    # -- the path ---------------------------------------------------------
+    def update_kernel_bounds(self, kernel_type):
+        self._ck(self._lib.pmcx_update_kernel_bounds(self._h, kernel_type))
+
+    def mc_coag(self, coag_kernel_type, del_t, seed=0, step=0, counters=True):
+        """mc_coag on every cell (driver:192-194).  Returns (n_samp, n_coag, status)
+        arrays when counters is True (synchronises)."""
+        self._ck(self._lib.pmcx_mc_coag(self._h, coag_kernel_type, del_t, seed, step))
+        if counters:
+            return self.coag_counters()
+        return None
+
+    def coag_counters(self):
+        n = self.cfg.n_cells
+        a, b, s = (np.zeros(n, dtype=np.int32) for _ in range(3))
+        self._ck(self._lib.pmcx_get_coag_counters(self._h, _ptr(a), _ptr(b), _ptr(s)))
+        return a, b, s
+
+    def coag_totals(self):
+        a, b, p, s = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
+        self._ck(self._lib.pmcx_get_coag_totals(self._h, C.byref(a), C.byref(b), C.byref(p),
+                                                C.byref(s)))
+        return a.value, b.value, p.value, s.value
+
+    def aero_state_rebalance(self, allow_doubling=True, allow_halving=True, seed=0, step=0):
+        self._ck(self._lib.pmcx_rebalance(self._h, int(allow_doubling), int(allow_halving), seed,
+                                          step))
+
+    def partmc_timestep(self, elapsed_time, dt, partmc_chem_dt, do_coagulation=True,
+                        allow_doubling=True, allow_halving=True,
+                        kernel_type=COAG_KERNEL_TYPE_BROWN, random_seed=0):
+        f = PmcxStepFlags(int(do_coagulation), int(allow_doubling), int(allow_halving),
+                          kernel_type, dt, partmc_chem_dt, elapsed_time, random_seed)
+        self._ck(self._lib.pmcx_timestep(self._h, C.byref(f)))
+
+    def diagnostics(self):
+        """tot_num_conc, tot_mass_conc, num_dist, mass_dist (driver:838-857)."""
+        n, nd = self.cfg.n_cells, self.cfg.n_dbin
+        tn, tm = np.zeros(n), np.zeros(n)
+        d1, d2 = np.zeros((n, nd)), np.zeros((n, nd))
+        self._ck(self._lib.pmcx_diagnostics(self._h, _ptr(tn), _ptr(tm), _ptr(d1), _ptr(d2)))
+        return tn, tm, d1, d2
+
+    def run_part(self, kernel_type, del_t, n_steps, seed=0, rebalance=True, t_output=1):
+        """Single-block time loop in the shape of PartMC's run_part (BASELINE config 1):
+        per step mc_coag + rebalance; diagnostics every t_output steps."""
+        hist = []
+        for step in range(n_steps):
+            self.mc_coag(kernel_type, del_t, seed, step, counters=False)
+            if rebalance:
+                self.aero_state_rebalance(True, True, seed, step)
+            if (step + 1) % t_output == 0:
+                hist.append(((step + 1) * del_t,) + self.diagnostics())
+        return hist
+
+    # -- introspection ----------------------------------------------------
+    def bin_tables(self):
+        ve, vs = np.zeros(self.cfg.n_bin + 1), np.zeros(self.cfg.n_bin * 3)
+        self._ck(self._lib.pmcx_get_bin_tables(self._h, _ptr(ve), _ptr(vs)))
+        return ve, vs
+
+    def diag_grid(self):
+        de, dw = np.zeros(self.cfg.n_dbin + 1), np.zeros(self.cfg.n_dbin)
+        self._ck(self._lib.pmcx_get_diag_grid(self._h, _ptr(de), _ptr(dw)))
+        return de, dw
+
+    def kmax(self, cell):
+        k = np.zeros((self.cfg.n_bin, self.cfg.n_bin))
+        self._ck(self._lib.pmcx_get_kmax(self._h, cell, _ptr(k)))
+        return k
+
+    def caches(self, cell):
+        v, m = np.zeros(self.cfg.cap), np.zeros(self.cfg.cap)
+        self._ck(self._lib.pmcx_get_caches(self._h, cell, _ptr(v), _ptr(m)))
+        return v, m
+
+    def sort_only(self):
+        self._ck(self._lib.pmcx_sort_only(self._h))
+
+    def get_sort(self, cell):
+        G = self.cfg.n_class * self.cfg.n_bin
+        perm = np.zeros(self.cfg.cap, dtype=np.uint32)
+        gcnt, goff = np.zeros(G, dtype=np.int32), np.zeros(G, dtype=np.int32)
+        self._ck(self._lib.pmcx_get_sort(self._h, cell, _ptr(perm), _ptr(gcnt), _ptr(goff)))
+        return perm, gcnt, goff
+
+    def test_math(self, op, a, b=None, c=None, d=None, ktype=0, temp=288.15, pressure=101325.0):
+        a = _f64(a)
+        out = np.zeros_like(a)
+        self._ck(self._lib.pmcx_test_math(self._h, op, a.size, _ptr(a), _ptr(_f64(b)),
+                                          _ptr(_f64(c)), _ptr(_f64(d)), ktype, temp, pressure,
+                                          _ptr(out)))
+        return out
+
+    def test_philox(self, ctr, key):
+        c = np.asarray(ctr, dtype=np.uint32)
+        k = np.asarray(key, dtype=np.uint32)
+        o = np.zeros(4, dtype=np.uint32)
+        self._ck(self._lib.pmcx_test_philox(self._h, _ptr(c), _ptr(k), _ptr(o)))
+        return o
+
+    def profile_enable(self, on=True):
+        self._ck(self._lib.pmcx_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        self._ck(self._lib.pmcx_profile_reset(self._h))
+
+    def profile_get(self, name):
+        ms, n = C.c_double(), C.c_int64()
+        self._ck(self._lib.pmcx_profile_get(self._h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def memory_bytes(self):
+        b = C.c_int64()
+        self._ck(self._lib.pmcx_memory_bytes(self._h, C.byref(b)))
+        return b.value
