@@ -1,0 +1,338 @@
+#!/usr/bin/env python3
+"""Throughput of the PartMC per-cell microphysics step on MI355X.
+
+Workload (BASELINE.json configs[4], the configuration the metric is quoted
+on): synthetic 100 x 100 x 30 domain, 10^4 computational particles per cell,
+Brownian coagulation (the kernel the reference selects,
+interface/wrf_pmc_driver.F90:192) with del_t = 300 s (partmc_chem_dt of the
+reference's only coagulation-enabled namelist), followed by
+aero_state_rebalance (driver:248-250).  One "step" = one pass of that loop
+body over every cell.  Cells are partitioned by contiguous blocks of (i,j)
+columns over the ranks (one process per GPU, no data-path collective);
+total work is fixed as N grows ("strong").
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+KERNELS = ("bin_sort", "coag_sample", "coag_apply", "rebalance")
+
+
+def partition_columns(n_cols, world, rank):
+    """Contiguous block of (i,j) columns owned by `rank` (all levels of a column
+    stay together, as in WRF's horizontal decomposition,
+    WRFV3/main/module_wrf_top.F:505-510)."""
+    return rank * n_cols // world, (rank + 1) * n_cols // world
+
+
+def level_profile(levels):
+    """Standard-atmosphere T/p by model level (synthetic env_state)."""
+    z = np.linspace(50.0, 12000.0, levels)
+    temp = 288.15 - 6.5e-3 * z
+    pres = 101325.0 * (temp / 288.15) ** 5.2559
+    return temp, pres
+
+
+def algorithmic_bytes(name, n_spec, n_class, n_source, particles, candidates, events):
+    """Algorithmic HBM bytes of one launch (DESIGN.md 'Kernels and rooflines',
+    per-unit figures from SURVEY.md 8(d))."""
+    meta = 28  # id 8 + create times 16 + class 4
+    if name == "bin_sort":
+        return particles * (8 + 4 + (4 if n_class > 1 else 0))
+    if name == "coag_sample":
+        return candidates * 32 + events * (2 * 16 + 16 + 16)  # caches read x2, written, log entry
+    if name == "coag_apply":
+        per_ev = 3 * 8 * n_spec + 3 * 4 * n_source + 3 * meta + 16
+        return events * per_ev
+    if name == "rebalance":
+        return particles * 4
+    return 0
+
+
+def aggregate(local, dist=None):
+    """Sum counters, max time over ranks (the contract's max-over-ranks timing)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return dict(local)
+    import torch
+    keys_sum = [k for k in local if k != "elapsed"]
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([float(local[k]) for k in keys_sum], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    e = torch.tensor([float(local["elapsed"])], dtype=torch.float64, device=dev)
+    dist.all_reduce(e, op=dist.ReduceOp.MAX)
+    out = {k: float(v) for k, v in zip(keys_sum, t.tolist())}
+    out["elapsed"] = float(e.item())
+    return out
+
+
+def cpu_baseline(args, n_cells_total):
+    """Times the CPU oracle (a restatement: the reference's PartMC submodule is
+    not vendored) on a bounded sample of the same
+    workload: the first cells of the domain, same seeds, one mc_coag step."""
+    import multiprocessing as mp
+    from oracle import pmco_py
+    pmco_py.build()
+    cores = min(os.cpu_count() or 1, args.cpu_cores)
+    budget = args.cpu_seconds
+    # calibrate on a few cells, single thread
+    t0 = time.perf_counter()
+    r = _oracle_cells((args, list(range(0, 4))))
+    per_cell = (time.perf_counter() - t0) / 4          # setup + step, bounds the wall time
+    single = dict(cells=4, events=r["events"], seconds=r["step_s"])
+    n_sample = int(max(cores, min(n_cells_total, budget * cores / max(per_cell, 1e-6))))
+    n_sample -= n_sample % cores
+    chunks = [list(range(k, n_sample, cores)) for k in range(cores)]
+    with mp.get_context("fork").Pool(cores) as pool:
+        t0 = time.perf_counter()
+        res = pool.map(_oracle_cells, [(args, ch) for ch in chunks])
+        wall = time.perf_counter() - t0
+    # workers overlap setup and stepping; charge only the stepping share of the wall time
+    step_frac = sum(x["step_s"] for x in res) / max(sum(x["step_s"] + x["setup_s"] for x in res), 1e-9)
+    step_wall = wall * step_frac
+    events = sum(x["events"] for x in res)
+    parts = sum(x["particles"] for x in res)
+    out = {
+        "value": events / step_wall, "unit": "events/s", "cores": cores, "kind": "port",
+        "sample": f"{n_sample} cells x {args.particles} particles x 1 step "
+                  f"(oracle/libpmco.so, gcc -O2, {cores} processes; setup excluded)",
+        "particle_steps_per_sec": parts / step_wall,
+        "single_thread_events_per_sec": single["events"] / max(single["seconds"], 1e-9),
+        "events": events, "seconds": step_wall,
+    }
+    chk = {}
+    for x in res:
+        chk.update(x["n_coag"])
+    return out, chk
+
+
+def _oracle_cells(job):
+    args, cell_ids = job
+    from oracle import pmco_py as o
+    import wrf_partmc_amd as wp
+    t_setup = time.perf_counter()
+    dens = bench_density(args.n_spec)
+    ve, vs = o.make_bin_tables(80, 1e-10, 1e-2)
+    temp, pres = level_profile(args.levels)
+    modes = bench_modes(args.n_spec)
+    cells, kcache = [], {}
+    for gid in cell_ids:
+        k = gid % args.levels
+        c = o.Cell(args.n_spec, 1, 0, args.cap, dens, ve, temp[k], pres[k],
+                   max_events=args.max_events, max_appends=args.max_appends)
+        c.mag[:] = args.num_conc / args.particles
+        c.generate(modes, args.particles, args.seed, gid, first_id=gid << 32)
+        if k not in kcache:
+            kcache[k] = o.kmax_table(o.KERNEL_BROWN, vs, dens.min(), dens.max(), temp[k], pres[k])
+        c.kmax[:] = kcache[k]
+        cells.append((gid, c))
+    t_setup = time.perf_counter() - t_setup
+    ev, n_coag = 0, {}
+    t0 = time.perf_counter()
+    for gid, c in cells:
+        st, ns, nc = c.mc_coag(o.KERNEL_BROWN, args.del_t, args.seed, gid, 0)
+        ev += nc
+        n_coag[gid] = nc
+    return dict(events=ev, particles=len(cells) * args.particles, n_coag=n_coag,
+                step_s=time.perf_counter() - t0, setup_s=t_setup)
+
+
+def bench_density(n_spec):
+    from wrf_partmc_amd.data import AERO_DATA_SCM
+    return np.array([r[1] for r in AERO_DATA_SCM][:n_spec])
+
+
+def bench_modes(n_spec):
+    """Idealised reference IC (interface/wrf_pmc_init.F90:1764-1777): log-normal,
+    char_radius 2e-8 m, log10 sigma 0.25, species 1 only."""
+    from wrf_partmc_amd.data import idealised_modes
+    return idealised_modes(n_spec, 1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nx", type=int, default=100)
+    ap.add_argument("--ny", type=int, default=100)
+    ap.add_argument("--levels", type=int, default=30)
+    ap.add_argument("--particles", type=int, default=10000)
+    ap.add_argument("--n-spec", type=int, default=1)
+    ap.add_argument("--num-conc", type=float, default=1e10)   # wrf_pmc_init.F90:1835-1836
+    ap.add_argument("--del-t", type=float, default=300.0)
+    ap.add_argument("--seed", type=int, default=0)            # registry.partmc:13
+    ap.add_argument("--max-events", type=int, default=1024)
+    ap.add_argument("--max-appends", type=int, default=512)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-cores", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    args.cap = (args.particles + 63) // 64 * 64
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         "with torch.distributed.run")
+    # CPU baseline first, on rank 0 at N=1 only, before this process touches the GPU
+    # (the worker pool forks; a forked child must not inherit a live HIP runtime)
+    cpu_line, cpu_counts = None, None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_line, cpu_counts = cpu_baseline(args, args.nx * args.ny * args.levels)
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU is visible and there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import wrf_partmc_amd as wp
+    n_cols = args.nx * args.ny
+    c0, c1 = partition_columns(n_cols, world, rank)
+    first_cell, n_cells = c0 * args.levels, (c1 - c0) * args.levels
+    n_cells_total = n_cols * args.levels
+
+    blk = wp.CellBlock(n_cells, args.cap, args.n_spec, n_class=1, n_source=0, device=local_rank,
+                       cell_id_base=first_cell, max_events=args.max_events,
+                       max_appends=args.max_appends)
+    blk.set_aero_data(bench_density(args.n_spec))
+    temp, pres = level_profile(args.levels)
+    lev = (first_cell + np.arange(n_cells)) % args.levels
+    blk.set_env(temp[lev], pres[lev], np.full(n_cells, 0.5))
+    blk.set_weights(np.full((n_cells, 1), args.num_conc / args.particles))
+    blk.set_n_part_ideal(np.full((n_cells, 1), float(args.particles)))
+    blk.set_next_id((first_cell + np.arange(n_cells, dtype=np.int64) << 32) + (1 << 24))
+    blk.generate_lognormal(args.particles, bench_modes(args.n_spec), seed=args.seed)
+    blk.update_kernel_bounds(wp.COAG_KERNEL_TYPE_BROWN)
+    blk.synchronize()
+
+    def barrier():
+        blk.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_step(step):
+        blk.mc_coag(wp.COAG_KERNEL_TYPE_BROWN, args.del_t, args.seed, step, counters=False)
+        tot = blk.coag_totals()      # n_samp, n_coag, n_part (before rebalance), status
+        blk.aero_state_rebalance(True, True, args.seed, step)
+        return tot
+
+    # the first step's per-cell event counts, for the oracle cross-check
+    first_counts = None
+    step = 0
+    for _ in range(args.warmup):
+        tot = one_step(step)
+        if step == 0 and rank == 0:
+            ns, nc, st = blk.coag_counters()
+            first_counts = {first_cell + i: int(v) for i, v in enumerate(nc[:4096])}
+        step += 1
+    blk.profile_enable(True)
+    blk.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    samp = coag = parts = 0
+    status = 0
+    for _ in range(args.steps):
+        tot = one_step(step)
+        if step == 0 and rank == 0:
+            ns, nc, st = blk.coag_counters()
+            first_counts = {first_cell + i: int(v) for i, v in enumerate(nc[:4096])}
+        samp += tot[0]; coag += tot[1]; parts += tot[2] + tot[1]; status |= tot[3]
+        step += 1
+    barrier()
+    elapsed = time.perf_counter() - t0
+    blk.profile_enable(False)
+
+    local = dict(elapsed=elapsed, n_samp=samp, n_coag=coag, particle_steps=parts)
+    for k in KERNELS:
+        ms, n = blk.profile_get(k)
+        local["ms_" + k] = ms
+        local["n_" + k] = n
+    agg = aggregate(local, dist if world > 1 else None)
+    mem = blk.memory_bytes()
+
+    if rank == 0:
+        el = agg["elapsed"]
+        kern_ms = {k: agg["ms_" + k] / world for k in KERNELS}          # mean over ranks
+        dom = max(kern_ms, key=kern_ms.get)
+        launches = max(1.0, agg["n_" + dom] / world)
+        # units one launch of the dominant kernel processes on one GPU, averaged
+        per_launch = dict(particles=agg["particle_steps"] / world / args.steps,
+                          candidates=agg["n_samp"] / world / args.steps,
+                          events=agg["n_coag"] / world / args.steps)
+        alg = algorithmic_bytes(dom, args.n_spec, 1, 0, **per_launch)
+        avg_ms = kern_ms[dom] / launches
+        achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom, {}).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "coagulation_events_per_sec", "value": agg["n_coag"] / el,
+            "unit": "events/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.nx}x{args.ny}x{args.levels} cells x {args.particles} "
+                                   f"particles/cell, Brownian mc_coag del_t={args.del_t:g}s + rebalance, "
+                                   f"n_spec={args.n_spec}, cell-column blocks over {world} GPU(s)",
+                       "cells": n_cells_total, "particles_per_cell": args.particles,
+                       "n_spec": args.n_spec, "kernel": "COAG_KERNEL_TYPE_BROWN"},
+            "particle_steps_per_sec": agg["particle_steps"] / el,
+            "candidate_pairs_per_sec": agg["n_samp"] / el,
+            "events_per_step": agg["n_coag"] / args.steps,
+            "status_or": status,
+            "device_memory_gb_rank0": mem / 1e9,
+            "kernel_ms_per_step": {k: kern_ms[k] / args.steps for k in KERNELS},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms},
+        }
+        # secondary rooflines of the other kernels (same accounting)
+        others = {}
+        for k in KERNELS:
+            if k == dom or agg["n_" + k] == 0:
+                continue
+            a = algorithmic_bytes(k, args.n_spec, 1, 0, **per_launch)
+            ms = kern_ms[k] / max(1.0, agg["n_" + k] / world)
+            others[k] = {"achieved": a / (ms * 1e-3) / 1e9 if ms > 0 else 0.0, "avg_launch_ms": ms}
+        line["roofline_other_kernels"] = others
+        if cpu_line is not None:
+            both = [c for c in cpu_counts if c in (first_counts or {})]
+            cpu_line["cells_compared_with_gpu"] = len(both)
+            cpu_line["gpu_matches_oracle_on_sample"] = bool(
+                both and all(cpu_counts[c] == first_counts[c] for c in both))
+            line["cpu_baseline"] = cpu_line
+            line["gpu_vs_cpu_events_per_sec"] = line["value"] / cpu_line["value"]
+        print(json.dumps(line), flush=True)
+    blk.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,355 @@
+"""CPU tests (-m "not gpu"): pin the oracle.
+
+The reference holds no golden vectors for this path, so the
+oracle is pinned by: Random123 known-answer vectors; libm/scipy for the
+deterministic math; an independent numpy transcription of the in-tree Fuchs
+Brownian form (WRFV3/chem/module_mosaic_coag.F:746-757,898-936) and textbook
+values; analytic Smoluchowski solutions (constant and additive kernels);
+exact conservation laws; and the committed fixtures in tests/golden/."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from tests import parity
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+K_BROWN, K_SEDI, K_ADD, K_CONST, K_ZERO, K_BS = 4, 1, 2, 3, 5, 101
+
+
+# ------------------------------------------------------------------ RNG + math
+
+def test_philox_known_answers(oracle):
+    # Random123 kat_vectors, philox4x32-10
+    assert [hex(x) for x in oracle.philox([0] * 4, [0] * 2)] == \
+        ['0x6627e8d5', '0xe169c58d', '0xbc57ac4c', '0x9b00dbd8']
+    assert [hex(x) for x in oracle.philox([0xffffffff] * 4, [0xffffffff] * 2)] == \
+        ['0x408f276d', '0x41c83b0e', '0xa20bc7c6', '0x6d5451fd']
+    assert [hex(x) for x in oracle.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344],
+                                          [0xa4093822, 0x299f31d0])] == \
+        ['0xd16cfe09', '0x94fdcceb', '0x5001e420', '0x24126ea1']
+
+
+def test_deterministic_math_accuracy(oracle):
+    from scipy.stats import norm
+    L = oracle.lib()
+    for x in np.concatenate([-np.logspace(-8, 2.85, 400), np.logspace(-8, 2.8, 100)]):
+        assert abs(L.pmco_exp_(x) - math.exp(x)) <= 4e-16 * math.exp(x)
+    for x in np.logspace(-300, 300, 900):
+        assert abs(L.pmco_log_(x) - math.log(x)) <= 4e-16 * max(1.0, abs(math.log(x)))
+    for x in np.logspace(-40, 5, 900):
+        y = L.pmco_cbrt_(x)
+        assert abs(y * y * y - x) <= 1e-15 * x
+    for p in np.concatenate([np.logspace(-15, -2, 60), np.linspace(0.01, 0.99, 99)]):
+        assert abs(L.pmco_norminv_(p) - norm.ppf(p)) <= 2e-9 * max(1.0, abs(norm.ppf(p)))
+
+
+def test_poisson_moments(oracle):
+    L = oracle.lib()
+    rng = np.random.RandomState(3)
+    for mean in (0.05, 0.7, 3.0, 25.0, 180.0, 450.0, 5000.0):
+        x = np.array([L.pmco_poisson_(mean, u) for u in rng.uniform(0, 1, 40000)])
+        assert abs(x.mean() - mean) < 5 * math.sqrt(mean / x.size) + 0.01 * (mean >= 200)
+        assert abs(x.var() - mean) < 0.06 * mean + 0.01
+    assert L.pmco_poisson_(0.0, 0.5) == 0 and L.pmco_poisson_(-1.0, 0.5) == 0
+
+
+# ----------------------------------------------------------------- kernels
+
+def fuchs_cgs(r1_cm, r2_cm, rho1, rho2, tk, patm, slip=(1.257, 0.42, 1.1)):
+    """Independent transcription of the functional form of
+    WRFV3/chem/module_mosaic_coag.F:746-757 (air properties) and :898-936
+    (Fuchs Brownian coefficient), CGS units, returns cm^3/s."""
+    boltg, wtair, avg, rgas2 = 1.38054e-16, 28.966, 6.02252e23, 0.08206
+    amu = 1.8325e-4 * (296.16 + 120.0) / (tk + 120.0) * (tk / 296.16) ** 1.5
+    rho3 = patm * wtair * 0.001 / (rgas2 * tk)
+    vthermg = math.sqrt(8.0 * boltg * tk * avg / (math.pi * wtair))
+    gmfp = 2.0 * (amu / rho3) / vthermg
+    out = []
+    for r, rho in ((r1_cm, rho1), (r2_cm, rho2)):
+        kn = gmfp / r
+        bpm = 1.0 + kn * (slip[0] + slip[1] * math.exp(-slip[2] / kn))
+        dif = boltg * tk * bpm / (6.0 * math.pi * r * amu)
+        vol = 4.0 / 3.0 * math.pi * r ** 3
+        vth = math.sqrt(8.0 * boltg * tk / (math.pi * rho * vol))
+        pmfp = 8.0 * dif / (math.pi * vth)
+        delt = ((2 * r + pmfp) ** 3 - (4 * r * r + pmfp * pmfp) ** 1.5) / (6.0 * r * pmfp) - 2 * r
+        out.append((dif, vth * vth, delt * delt))
+    rs = r1_cm + r2_cm
+    sd = out[0][0] + out[1][0]
+    ggr = math.sqrt(out[0][1] + out[1][1])
+    deltr = math.sqrt(out[0][2] + out[1][2])
+    return 4.0 * math.pi * rs * sd / (rs / (rs + deltr) + 4.0 * sd / (rs * ggr))
+
+
+def test_brownian_kernel_matches_in_tree_form(oracle):
+    rng = np.random.RandomState(1)
+    for T, p in ((288.15, 101325.0), (220.0, 25000.0)):
+        for _ in range(200):
+            d1, d2 = 10 ** rng.uniform(-9, -5, 2)
+            rho1, rho2 = rng.uniform(900, 2700, 2)
+            v1, v2 = math.pi / 6 * d1 ** 3, math.pi / 6 * d2 ** 3
+            k = oracle.kernel(K_BROWN, v1, v1 * rho1, v2, v2 * rho2, T, p)
+            same = fuchs_cgs(d1 * 50, d2 * 50, rho1 * 1e-3, rho2 * 1e-3, T, p / 101325.0,
+                             slip=(1.249, 0.42, 0.87)) * 1e-6
+            mosaic = fuchs_cgs(d1 * 50, d2 * 50, rho1 * 1e-3, rho2 * 1e-3, T, p / 101325.0) * 1e-6
+            assert abs(k - same) <= 2e-4 * same      # constants differ in the 5th digit
+            assert abs(k - mosaic) <= 0.05 * mosaic  # slip constants 1.257/0.42/1.1 in-tree
+
+
+def test_brownian_kernel_textbook_values(oracle):
+    # Seinfeld & Pandis, Table 13.3 (25 C, 1 atm, rho = 1 g/cm^3), cm^3/s
+    table = {(0.01, 0.01): 18e-10, (0.1, 0.1): 14.4e-10, (1.0, 1.0): 6.9e-10,
+             (0.01, 1.0): 3.4e-7}
+    for (d1, d2), k_cgs in table.items():
+        v1, v2 = math.pi / 6 * (d1 * 1e-6) ** 3, math.pi / 6 * (d2 * 1e-6) ** 3
+        k = oracle.kernel(K_BROWN, v1, v1 * 1000, v2, v2 * 1000, 298.15, 101325.0)
+        assert abs(k - k_cgs * 1e-6) <= 0.10 * k_cgs * 1e-6  # table rounding + slip constants
+
+
+def test_kernel_limits_and_symmetry(oracle):
+    # symmetric; free-molecular limit ~ sqrt(T); continuum limit of equal spheres 8kT/3mu
+    v = lambda d: math.pi / 6 * d ** 3
+    a = oracle.kernel(K_BROWN, v(3e-8), v(3e-8) * 1800, v(4e-7), v(4e-7) * 1200, 280.0, 9e4)
+    b = oracle.kernel(K_BROWN, v(4e-7), v(4e-7) * 1200, v(3e-8), v(3e-8) * 1800, 280.0, 9e4)
+    assert a == b
+    T = 293.15
+    mu = 1.8325e-5 * (296.16 + 120) / (T + 120) * (T / 296.16) ** 1.5
+    k = oracle.kernel(K_BROWN, v(2e-5), v(2e-5) * 1000, v(2e-5), v(2e-5) * 1000, T, 101325.0)
+    assert abs(k - 8 * 1.3806505e-23 * T / (3 * mu)) < 0.02 * k
+    assert oracle.kernel(K_ZERO, 1e-21, 1e-18, 1e-21, 1e-18, T, 1e5) == 0.0
+    assert oracle.kernel(K_ADD, 1e-21, 1e-18, 3e-21, 1e-18, T, 1e5, additive_beta=1000.0) == 1000.0 * 4e-21
+    # sedimentation: zero between equal particles, positive and growing with size contrast
+    assert oracle.kernel(K_SEDI, v(2e-6), v(2e-6) * 1000, v(2e-6), v(2e-6) * 1000, T, 1e5) == 0.0
+    s1 = oracle.kernel(K_SEDI, v(2e-6), v(2e-6) * 1000, v(2e-5), v(2e-5) * 1000, T, 1e5)
+    s2 = oracle.kernel(K_SEDI, v(2e-6), v(2e-6) * 1000, v(4e-5), v(4e-5) * 1000, T, 1e5)
+    assert 0 < s1 < s2
+    bs = oracle.kernel(K_BS, v(2e-6), v(2e-6) * 1000, v(2e-5), v(2e-5) * 1000, T, 1e5)
+    br = oracle.kernel(K_BROWN, v(2e-6), v(2e-6) * 1000, v(2e-5), v(2e-5) * 1000, T, 1e5)
+    assert bs == br + s1
+
+
+def test_kmax_bounds_random_pairs(oracle):
+    ve, vs = oracle.make_bin_tables(80, 1e-10, 1e-2)
+    rng = np.random.RandomState(2)
+    for ktype in (K_BROWN, K_BS):
+        km = oracle.kmax_table(ktype, vs, 1000.0, 2600.0, 275.0, 8e4)
+        assert np.array_equal(km, km.T)
+        worst = 0.0
+        for _ in range(4000):
+            b1, b2 = rng.randint(5, 60, 2)
+            v1 = ve[b1] * (ve[b1 + 1] / ve[b1]) ** rng.uniform()
+            v2 = ve[b2] * (ve[b2 + 1] / ve[b2]) ** rng.uniform()
+            k = oracle.kernel(ktype, v1, v1 * rng.uniform(1000, 2600), v2,
+                              v2 * rng.uniform(1000, 2600), 275.0, 8e4)
+            worst = max(worst, k / km[b1, b2])
+        # 3x3-point bound [PartMC est_k_minmax]: tight, may be exceeded by a few percent
+        assert worst < 1.1
+
+
+def test_bin_of(oracle):
+    ve, _ = oracle.make_bin_tables(80, 1e-10, 1e-2)
+    L = oracle.lib()
+    p = ve.ctypes.data_as(oracle._dp)
+    for b in range(80):
+        assert L.pmco_bin_of(p, 80, ve[b]) == b
+        assert L.pmco_bin_of(p, 80, np.nextafter(ve[b + 1], 0)) == b
+    assert L.pmco_bin_of(p, 80, ve[0] / 10) == 0 and L.pmco_bin_of(p, 80, ve[80] * 10) == 79
+
+
+# ------------------------------------------------------- mc_coag: exact laws
+
+def _cell(oracle, n_part, n_spec, n_class, kernel, seed, cell_id=0, coarse=False, T=288.15,
+          p=101325.0, conc_scale=1.0, const_k=0.25 / (60 * 2e8), beta=1000.0):
+    names, dens = parity.default_species(n_spec)
+    ve, vs = oracle.make_bin_tables(80, 1e-10, 1e-2)
+    modes, nc = parity.make_modes(n_spec, n_class, coarse)
+    c = oracle.Cell(n_spec, n_class, 3, int(2.2 * n_part), dens, ve, T, p)
+    c.mag[:] = nc * conc_scale / n_part * (1 + 0.5 * np.arange(n_class))
+    c.generate(modes, n_part, seed, cell_id, first_id=cell_id << 32)
+    c.kmax[:] = oracle.kmax_table(kernel, vs, dens.min(), dens.max(), T, p, const_k, beta)
+    return c
+
+
+def test_single_class_conservation(oracle):
+    c = _cell(oracle, 3000, 3, 1, K_BROWN, seed=4)
+    n0 = 3000
+    v0 = c.vol[:, :n0].copy()
+    src0 = c.n_orig[:, :n0].sum(1)
+    tot = 0
+    for step in range(5):
+        st, ns, nc = c.mc_coag(K_BROWN, 3000.0, 4, 0, step)
+        assert st == 0 and ns >= nc > 0
+        tot += nc
+    n = int(c.n_part[0])
+    assert n == n0 - tot                                    # one particle lost per event
+    np.testing.assert_allclose(c.vol[:, :n].sum(1), v0.sum(1), rtol=1e-13)   # species volume
+    assert np.array_equal(c.n_orig[:, :n].sum(1), src0)      # constituents
+    assert len(np.unique(c.id[:n])) == n                     # ids unique
+    # caches are the sequential species sums
+    vt = np.zeros(n); ms = np.zeros(n)
+    for s in range(3):
+        vt = vt + c.vol[s, :n]; ms = ms + c.density[s] * c.vol[s, :n]
+    assert np.array_equal(vt, c.vtot[:n]) and np.array_equal(ms, c.mass[:n])
+    # the survivor keeps the id of the larger particle: the largest particle's id is original
+    assert (c.id[:n] >> 32 == 0).all()
+
+
+def test_deterministic_and_seed_sensitive(oracle):
+    runs = []
+    for seed, cid in ((4, 0), (4, 0), (5, 0), (4, 1)):
+        c = _cell(oracle, 1500, 2, 1, K_BROWN, seed=4)
+        r = [c.mc_coag(K_BROWN, 2000.0, seed, cid, s) for s in range(2)]
+        runs.append((r, c.vol[:, :int(c.n_part[0])].copy()))
+    assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1])
+    assert runs[0][0] != runs[2][0] and runs[0][0] != runs[3][0]
+
+
+def test_weighted_classes_statistics(oracle):
+    """Two weight classes with different magnitudes: physical (number-weighted)
+    species volume is conserved in expectation [DeVille et al. 2011]."""
+    ratios = []
+    for seed in range(24):
+        c = _cell(oracle, 1500, 2, 2, K_BROWN, seed=seed, cell_id=seed)
+        n0 = 1500
+        phys0 = (c.vol[:, :n0] * c.mag[c.wclass[:n0]]).sum()
+        for step in range(3):
+            c.mc_coag(K_BROWN, 6000.0, seed, seed, step)
+        n = int(c.n_part[0])
+        ratios.append((c.vol[:, :n] * c.mag[c.wclass[:n]]).sum() / phys0)
+    r = np.array(ratios)
+    assert abs(r.mean() - 1.0) < 4 * r.std() / math.sqrt(len(r)) + 1e-3
+
+
+def test_overflow_flags(oracle):
+    c = _cell(oracle, 800, 1, 1, K_BROWN, seed=1)
+    c.max_events = 5
+    st, ns, nc = c.mc_coag(K_BROWN, 30000.0, 1, 0, 0)
+    assert st & oracle.ST_EVENT_OVERFLOW and nc == 5
+    c = _cell(oracle, 800, 1, 1, K_BROWN, seed=1)
+    c.max_appends = 3
+    st, ns, nc = c.mc_coag(K_BROWN, 30000.0, 1, 0, 0)
+    assert st & oracle.ST_APPEND_OVERFLOW
+
+
+# ----------------------------------------------- analytic Smoluchowski tests
+
+def test_constant_kernel_analytic(oracle):
+    """N(t)/N0 = 1/(1 + K N0 t/2) for the constant kernel; ensemble of cells."""
+    K = 0.25 / (60 * 2e8)
+    n_part, reps = 2000, 12
+    t_end, steps = 600.0, 30
+    finals, N0 = [], None
+    for r in range(reps):
+        c = _cell(oracle, n_part, 1, 1, K_CONST, seed=100 + r, cell_id=r, conc_scale=1e-2)
+        N0 = c.mag[0] * n_part
+        for s in range(steps):
+            c.mc_coag(K_CONST, t_end / steps, 100 + r, r, s, const_k=K)
+        finals.append(c.mag[0] * c.n_part[0])
+    exact = N0 / (1 + K * N0 * t_end / 2)
+    m, sd = np.mean(finals), np.std(finals) / math.sqrt(reps)
+    assert exact < 0.75 * N0                       # the test exercises real depletion
+    assert abs(m - exact) < 4 * sd + 0.01 * exact  # dt-splitting bias is O(1%)
+
+
+def test_additive_kernel_analytic(oracle):
+    """dN/dt = -beta*phi*N for K = beta (v1+v2) (Golovin): N(t) = N0 exp(-beta phi t)."""
+    beta = 1000.0
+    n_part, reps, steps = 2000, 12, 40
+    finals, exact = [], None
+    for r in range(reps):
+        c = _cell(oracle, n_part, 1, 1, K_ADD, seed=300 + r, cell_id=r, beta=beta)
+        N0 = c.mag[0] * n_part
+        phi = c.mag[0] * c.vtot[:n_part].sum()
+        t_end = 0.5 / (beta * phi)
+        for s in range(steps):
+            c.mc_coag(K_ADD, t_end / steps, 300 + r, r, s, additive_beta=beta)
+        finals.append(c.mag[0] * c.n_part[0] / N0)
+        exact = math.exp(-0.5)
+    m, sd = np.mean(finals), np.std(finals) / math.sqrt(reps)
+    assert abs(m - exact) < 4 * sd + 0.015
+
+
+# --------------------------------------------------------- rebalance, diags
+
+def test_rebalance_doubling_and_halving(oracle):
+    c = _cell(oracle, 1000, 2, 2, K_BROWN, seed=8)
+    n_cls0 = np.bincount(c.wclass[:1000], minlength=2)
+    mag0 = c.mag.copy()
+    physical0 = (c.vol[:, :1000] * c.mag[c.wclass[:1000]]).sum()
+    # ideal far above: both classes double (maybe twice) until >= ideal/2
+    ideal = n_cls0 * 3.0
+    st, nid = c.rebalance(ideal, True, True, 8, 0, 0, next_id=1 << 40)
+    n = int(c.n_part[0])
+    n_cls = np.bincount(c.wclass[:n], minlength=2)
+    assert st == 0 and (n_cls >= ideal / 2).all() and (n_cls == 2 * n_cls0).all()
+    assert np.allclose(c.mag, mag0 / 2) and nid == (1 << 40) + n_cls0.sum()
+    assert len(np.unique(c.id[:n])) == n
+    np.testing.assert_allclose((c.vol[:, :n] * c.mag[c.wclass[:n]]).sum(), physical0, rtol=1e-12)
+    # ideal far below: halve until <= 2*ideal; physical volume conserved in expectation
+    st, _ = c.rebalance(n_cls0 / 4.0, True, True, 8, 0, 1, next_id=nid)
+    n2 = int(c.n_part[0])
+    n_cls2 = np.bincount(c.wclass[:n2], minlength=2)
+    assert (n_cls2 <= 2 * (n_cls0 / 4.0) + 1).all() and n2 < n
+    phys = (c.vol[:, :n2] * c.mag[c.wclass[:n2]]).sum()
+    assert abs(phys / physical0 - 1) < 0.2
+    # disabled switches leave the state alone
+    before = c.vol.copy()
+    c.rebalance(n_cls0 * 100.0, False, False, 8, 0, 2, next_id=0)
+    assert np.array_equal(before, c.vol)
+
+
+def test_diagnostics_against_numpy(oracle):
+    c = _cell(oracle, 4000, 3, 2, K_BROWN, seed=9)
+    de = np.exp(np.linspace(np.log(1e-9), np.log(1e-3), 101))
+    dw = np.log(de[1:]) - np.log(de[:-1])
+    i_water = 2
+    tn, tm, nd, md = c.diagnostics(i_water, de, dw)
+    n = 4000
+    dry = c.vol[[0, 1], :n].sum(0)
+    diam = 2 * np.cbrt(dry * 0.75 / np.pi)
+    mass = (c.density[:, None] * c.vol[:, :n]).sum(0)
+    nc = c.mag[c.wclass[:n]]
+    assert abs(tn - nc.sum()) <= 1e-12 * tn and abs(tm - (mass * nc).sum()) <= 1e-12 * tm
+    b = np.searchsorted(de, diam, side="right") - 1
+    ref_n = np.bincount(b, weights=nc, minlength=100) / dw
+    ref_m = np.bincount(b, weights=nc * mass, minlength=100) / dw
+    np.testing.assert_allclose(nd, ref_n, rtol=1e-11)
+    np.testing.assert_allclose(md, ref_m, rtol=1e-11)
+    assert abs((nd * dw).sum() - tn) <= 1e-12 * tn   # histogram integrates to the total
+
+
+def test_generator_statistics(oracle):
+    c = _cell(oracle, 20000, 2, 1, K_BROWN, seed=2)
+    r = np.cbrt(c.vtot[:20000] * 0.75 / np.pi)
+    lr = np.log10(r)
+    small = lr < np.log10(2.4e-8)
+    # mode 1: gm radius 1e-8, log10 sigma 0.161; number fraction 3.2/(3.2+2.9)
+    assert abs(small.mean() - 3.2 / 6.1) < 0.03
+    assert abs(np.median(lr[small]) - np.log10(1e-8)) < 0.03
+
+
+# ------------------------------------------------------------ golden fixtures
+
+def test_golden_kernel_table(oracle):
+    g = np.load(os.path.join(GOLDEN, "brownian_kernel_16x16.npz"))
+    d = g["diam"]
+    for key, (T, p) in (("k_288", (288.15, 101325.0)), ("k_220", (220.0, 25000.0))):
+        got = np.array([[oracle.kernel(K_BROWN, math.pi / 6 * a ** 3, math.pi / 6 * a ** 3 * 1770.0,
+                                       math.pi / 6 * b ** 3, math.pi / 6 * b ** 3 * 1000.0, T, p)
+                         for b in d] for a in d])
+        assert np.array_equal(got, g[key])
+
+
+def test_golden_event_log(oracle):
+    """1000-particle single cell, seed 0, 10 steps of 60 s (BASELINE config 1 shape)."""
+    with open(os.path.join(GOLDEN, "single_cell_1000_seed0.json")) as f:
+        gold = json.load(f)
+    from tests.golden.make_golden import run_config1
+    got = run_config1(oracle)
+    assert got["counters"] == gold["counters"]
+    assert got["n_part"] == gold["n_part"]
+    assert got["vol_checksum"] == gold["vol_checksum"]
+    assert got["id_checksum"] == gold["id_checksum"]
