@@ -47,6 +47,8 @@ typedef struct {
     double viscosd;     /* dynamic viscosity of air, kg/m/s   */
     double gasfreepath; /* mean free path of air, m           */
     double rhoair;      /* dry-air density, kg/m^3            */
+    /* per-cell constants that keep divisions out of the per-particle code */
+    double inv_gfp, c_diff, c_speed, c_inv_speed, c_fall;
 } env_derived;
 
 typedef struct {
@@ -63,17 +65,34 @@ static void env_derive(double temp, double pressure, env_derived *e)
     double gasspeed = sqrt(8.0 * PMCO_BOLTZMANN * temp * PMCO_AVOGADRO /
                            (PMCO_PI * PMCO_AIR_MW));
     e->gasfreepath = 2.0 * viscosk / gasspeed;
+    e->inv_gfp = 1.0 / e->gasfreepath;
+    e->c_diff = e->kT / (6.0 * PMCO_PI * e->viscosd);
+    e->c_speed = 8.0 * e->kT / PMCO_PI;
+    e->c_inv_speed = PMCO_PI / (8.0 * e->kT);
+    e->c_fall = 2.0 * PMCO_GRAV / (9.0 * e->viscosd);
 }
 
-/* per-particle quantities of the Fuchs form, from volume v and mass m */
-static void particle_props(double v, double m, const env_derived *e, part_props *q)
+/* Per-particle quantities of the Fuchs form, from volume v and mass m.
+ * Jacobson eq. 15.33 term by term:
+ *   rad      = (3v/4pi)^(1/3)                 Kn = lambda/rad
+ *   cunning  = 1 + Kn (1.249 + 0.42 exp(-0.87/Kn))
+ *   diffus   = kT cunning / (6 pi rad mu)     speedsq = 8kT/(pi m)
+ *   freepath = 8 diffus / (pi sqrt(speedsq))
+ *   delta    = ((2rad+fp)^3 - (4rad^2+fp^2)^1.5)/(6 rad fp) - 2rad
+ * written with 1/rad from the reciprocal cube root and 1/speed from a square
+ * root, so one particle costs two divisions. */
+static void particle_props(double v, double m, const env_derived *e, int sedi,
+                           part_props *q)
 {
-    double rad = pmco_cbrt(v * (0.75 / PMCO_PI));
-    double knud = e->gasfreepath / rad;
-    double cunning = 1.0 + knud * (1.249 + 0.42 * pmco_exp(-0.87 / knud));
-    double diffus = e->kT * cunning / (6.0 * PMCO_PI * rad * e->viscosd);
-    double speedsq = (8.0 * e->kT / PMCO_PI) / m;
-    double freepath = 8.0 * diffus / (PMCO_PI * sqrt(speedsq));
+    double x = v * (0.75 / PMCO_PI);
+    double inv_rad = pmco_rcbrt(x);
+    double rad = x * inv_rad * inv_rad;
+    double knud = e->gasfreepath * inv_rad;
+    double cunning = 1.0 + knud * (1.249 + 0.42 * pmco_exp(-0.87 * (rad * e->inv_gfp)));
+    double diffus = e->c_diff * cunning * inv_rad;
+    double speedsq = e->c_speed / m;
+    double inv_speed = sqrt(m * e->c_inv_speed);
+    double freepath = (8.0 / PMCO_PI) * diffus * inv_speed;
     double t1 = 2.0 * rad + freepath;
     double tmp1 = t1 * t1 * t1;
     double t2 = 4.0 * rad * rad + freepath * freepath;
@@ -83,19 +102,19 @@ static void particle_props(double v, double m, const env_derived *e, part_props 
     q->diffus = diffus;
     q->speedsq = speedsq;
     q->deltasq = d * d;
-    /* Stokes-Cunningham terminal velocity (sedimentation kernel) */
-    double rho = m / v;
-    q->wfall = (2.0 * rad * rad * (rho - e->rhoair) * PMCO_GRAV * cunning) /
-               (9.0 * e->viscosd);
+    q->wfall = 0.0;
+    /* Stokes-Cunningham terminal velocity (sedimentation kernels only) */
+    if (sedi) q->wfall = e->c_fall * (rad * rad) * (m / v - e->rhoair) * cunning;
 }
 
+/* K = 4 pi R D / (R/(R+delta) + 4D/(R c)), inner quotients cleared */
 static double brown_pair(const part_props *a, const part_props *b)
 {
-    double rad_sum = a->rad + b->rad;
-    double diffus_sum = a->diffus + b->diffus;
-    double tmp1 = rad_sum / (rad_sum + sqrt(a->deltasq + b->deltasq));
-    double tmp2 = 4.0 * diffus_sum / (rad_sum * sqrt(a->speedsq + b->speedsq));
-    return 4.0 * PMCO_PI * rad_sum * diffus_sum / (tmp1 + tmp2);
+    double R = a->rad + b->rad;
+    double D = a->diffus + b->diffus;
+    double Rd = R + sqrt(a->deltasq + b->deltasq);
+    double Rc = R * sqrt(a->speedsq + b->speedsq);
+    return (4.0 * PMCO_PI) * (R * D) * (Rd * Rc) / (R * Rc + 4.0 * D * Rd);
 }
 
 /* Gravitational collection: E * pi (r1+r2)^2 |w1-w2| with the Long (1974)
@@ -125,6 +144,10 @@ static int kernel_needs_props(int type)
     return type == PMCO_KERNEL_BROWN || type == PMCO_KERNEL_SEDI ||
            type == PMCO_KERNEL_BROWN_SEDI;
 }
+static int kernel_needs_fall(int type)
+{
+    return type == PMCO_KERNEL_SEDI || type == PMCO_KERNEL_BROWN_SEDI;
+}
 
 static double kernel_pair(int type, double v1, double v2, const part_props *a,
                           const part_props *b, const pmco_kernel_params *kp)
@@ -146,8 +169,8 @@ double pmco_kernel(int type, double v1, double m1, double v2, double m2,
     part_props a = {0}, b = {0};
     env_derive(temp, pressure, &e);
     if (kernel_needs_props(type)) {
-        particle_props(v1, m1, &e, &a);
-        particle_props(v2, m2, &e, &b);
+        particle_props(v1, m1, &e, kernel_needs_fall(type), &a);
+        particle_props(v2, m2, &e, kernel_needs_fall(type), &b);
     }
     return kernel_pair(type, v1, v2, &a, &b, kp);
 }
@@ -197,7 +220,8 @@ void pmco_kmax_table(int type, int n_bin, const double *v_samp, double rho_min,
                 for (int d = 0; d < 2; d++) {
                     double v = v_samp[3 * b + s];
                     double rho = d ? rho_max : rho_min;
-                    particle_props(v, v * rho, &e, &pp[(b * 3 + s) * 2 + d]);
+                    particle_props(v, v * rho, &e, kernel_needs_fall(type),
+                                   &pp[(b * 3 + s) * 2 + d]);
                 }
     }
     for (int b1 = 0; b1 < n_bin; b1++)
@@ -280,6 +304,7 @@ int pmco_mc_coag(pmco_cell *c, int kernel_type, const pmco_kernel_params *kp,
     env_derived env;
     env_derive(c->temp, c->pressure, &env);
     const int use_props = kernel_needs_props(kernel_type);
+    const int use_fall = kernel_needs_fall(kernel_type);
 
     ilist *L = (ilist *)calloc((size_t)G, sizeof(ilist));
     coag_event *ev = (coag_event *)malloc(sizeof(coag_event) * (size_t)(c->max_events > 0 ? c->max_events : 1));
@@ -315,7 +340,6 @@ int pmco_mc_coag(pmco_cell *c, int kernel_type, const pmco_kernel_params *kp,
         pmco_rng_block(seed, cell_id, step, slot, PMCO_SITE_POISSON, 0, w);
         const int32_t ns = pmco_poisson(mean, pmco_u53(w[0], w[1]));
         tot_samp += ns;
-        const double accept_factor = 1.0 / k_max;
         const double factor = n1 * n2 / nmin;     /* coag_num_conc_factor, flat */
 
         for (int32_t s = 0; s < ns; s++) {
@@ -334,13 +358,14 @@ int pmco_mc_coag(pmco_cell *c, int kernel_type, const pmco_kernel_params *kp,
             const double m1 = c->mass[p1], m2 = c->mass[p2];
             part_props q1 = {0}, q2 = {0};
             if (use_props) {
-                particle_props(v1, m1, &env, &q1);
-                particle_props(v2, m2, &env, &q2);
+                particle_props(v1, m1, &env, use_fall, &q1);
+                particle_props(v2, m2, &env, use_fall, &q2);
             }
             const double k = kernel_pair(kernel_type, v1, v2, &q1, &q2, kp);
-            const double p = (k * factor) * accept_factor;
-            if (p > 1.0) status |= PMCO_ST_KMAX_EXCEEDED;
-            if (!(pmco_u53(w[2], w[3]) < p)) continue;
+            /* accept with probability K f / k_max, without forming the quotient */
+            const double kf = k * factor;
+            if (kf > k_max) status |= PMCO_ST_KMAX_EXCEEDED;
+            if (!(pmco_u53(w[2], w[3]) * k_max < kf)) continue;
 
             /* ---- coagulate ---- */
             if (n_ev >= c->max_events) { status |= PMCO_ST_EVENT_OVERFLOW; stop = 1; break; }

@@ -125,19 +125,24 @@ __device__ inline double det_log(double x)
     return ed * ln2_hi + (s * q + ed * ln2_lo);
 }
 
-__device__ inline double det_cbrt(double x)
+// x^(-1/3): bit-level first guess, three division-free third-order steps
+__device__ __forceinline__ double det_rcbrt(double x)
 {
-    if (x <= 0.0) return 0.0;
-    uint64_t u = d2u(x);
-    u = u / 3 + 0x2A9F789300000000ull;
+    const uint64_t u = 0x553EEEAD3BAB5000ull - d2u(x) / 3;
     double y = u2d(u);
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const double y3 = y * y * y;
-        y = y * ((y3 + 2.0 * x) / (2.0 * y3 + x));
+    for (int i = 0; i < 3; i++) {
+        const double h = 1.0 - x * (y * y * y);
+        y = y + y * h * (1.0 / 3.0 + h * (2.0 / 9.0));
     }
-    y = y - (y * y * y - x) / (3.0 * y * y);
     return y;
+}
+
+__device__ __forceinline__ double det_cbrt(double x)
+{
+    if (x <= 0.0) return 0.0;
+    const double y = det_rcbrt(x);
+    return x * y * y;
 }
 
 __device__ inline double det_norminv(double p)
@@ -225,6 +230,12 @@ enum : int {
 
 struct EnvDerived {
     double kT, viscosd, gasfreepath, rhoair;
+    // per-cell constants that keep divisions out of the per-particle code
+    double inv_gfp;     // 1 / gasfreepath
+    double c_diff;      // kT / (6 pi mu)
+    double c_speed;     // 8 kT / pi
+    double c_inv_speed; // pi / (8 kT)
+    double c_fall;      // 2 g / (9 mu)
 };
 
 struct PartProps {
@@ -246,18 +257,30 @@ __device__ inline EnvDerived env_derive(double temp, double pressure)
     const double gasspeed =
         __builtin_sqrt(8.0 * BOLTZMANN * temp * AVOGADRO / (PI * AIR_MW));
     e.gasfreepath = 2.0 * viscosk / gasspeed;
+    e.inv_gfp = 1.0 / e.gasfreepath;
+    e.c_diff = e.kT / (6.0 * PI * e.viscosd);
+    e.c_speed = 8.0 * e.kT / PI;
+    e.c_inv_speed = PI / (8.0 * e.kT);
+    e.c_fall = 2.0 * GRAV / (9.0 * e.viscosd);
     return e;
 }
 
+// Per-particle quantities of the Fuchs form.  Same formulas as Jacobson
+// eq. 15.33, arranged so that one particle costs two divisions: 1/rad comes
+// from the reciprocal cube root, 1/speed from a square root.
+template <bool SEDI>
 __device__ inline PartProps particle_props(double v, double m, const EnvDerived &e)
 {
     PartProps q;
-    const double rad = det_cbrt(v * (0.75 / PI));
-    const double knud = e.gasfreepath / rad;
-    const double cunning = 1.0 + knud * (1.249 + 0.42 * det_exp(-0.87 / knud));
-    const double diffus = e.kT * cunning / (6.0 * PI * rad * e.viscosd);
-    const double speedsq = (8.0 * e.kT / PI) / m;
-    const double freepath = 8.0 * diffus / (PI * __builtin_sqrt(speedsq));
+    const double x = v * (0.75 / PI);
+    const double inv_rad = det_rcbrt(x);
+    const double rad = x * inv_rad * inv_rad;
+    const double knud = e.gasfreepath * inv_rad;
+    const double cunning = 1.0 + knud * (1.249 + 0.42 * det_exp(-0.87 * (rad * e.inv_gfp)));
+    const double diffus = e.c_diff * cunning * inv_rad;
+    const double speedsq = e.c_speed / m;
+    const double inv_speed = __builtin_sqrt(m * e.c_inv_speed);
+    const double freepath = (8.0 / PI) * diffus * inv_speed;
     const double t1 = 2.0 * rad + freepath;
     const double tmp1 = t1 * t1 * t1;
     const double t2 = 4.0 * rad * rad + freepath * freepath;
@@ -267,18 +290,20 @@ __device__ inline PartProps particle_props(double v, double m, const EnvDerived 
     q.diffus = diffus;
     q.speedsq = speedsq;
     q.deltasq = d * d;
-    const double rho = m / v;
-    q.wfall = (2.0 * rad * rad * (rho - e.rhoair) * GRAV * cunning) / (9.0 * e.viscosd);
+    q.wfall = 0.0;
+    if (SEDI) q.wfall = e.c_fall * (rad * rad) * (m / v - e.rhoair) * cunning;
     return q;
 }
 
+// K = 4 pi R D / (R/(R+delta) + 4D/(R c)) with the two inner quotients
+// cleared: one division.
 __device__ inline double brown_pair(const PartProps &a, const PartProps &b)
 {
-    const double rad_sum = a.rad + b.rad;
-    const double diffus_sum = a.diffus + b.diffus;
-    const double tmp1 = rad_sum / (rad_sum + __builtin_sqrt(a.deltasq + b.deltasq));
-    const double tmp2 = 4.0 * diffus_sum / (rad_sum * __builtin_sqrt(a.speedsq + b.speedsq));
-    return 4.0 * PI * rad_sum * diffus_sum / (tmp1 + tmp2);
+    const double R = a.rad + b.rad;
+    const double D = a.diffus + b.diffus;
+    const double Rd = R + __builtin_sqrt(a.deltasq + b.deltasq);
+    const double Rc = R * __builtin_sqrt(a.speedsq + b.speedsq);
+    return (4.0 * PI) * (R * D) * (Rd * Rc) / (R * Rc + 4.0 * D * Rd);
 }
 
 // E pi (r1+r2)^2 |w1-w2|, Long (1974) efficiency, Stokes-Cunningham fall speed
@@ -303,6 +328,18 @@ __device__ inline double sedi_pair(const PartProps &a, const PartProps &b)
 __device__ __forceinline__ bool kernel_needs_props(int type)
 {
     return type == KERNEL_BROWN || type == KERNEL_SEDI || type == KERNEL_BROWN_SEDI;
+}
+__device__ __forceinline__ bool kernel_needs_fall(int type)
+{
+    return type == KERNEL_SEDI || type == KERNEL_BROWN_SEDI;
+}
+
+// props of one particle for kernel `type` (zeros for the size-only kernels)
+__device__ __forceinline__ PartProps props_for(int type, double v, double m, const EnvDerived &e)
+{
+    if (type == KERNEL_BROWN) return particle_props<false>(v, m, e);
+    if (kernel_needs_fall(type)) return particle_props<true>(v, m, e);
+    return PartProps{0, 0, 0, 0, 0};
 }
 
 __device__ inline double kernel_pair(int type, double v1, double v2, const PartProps &a,

@@ -28,6 +28,8 @@
 #include "pmcx_kernels.h"
 #include "pmcx_device_math.h"
 
+#include <cstdlib>
+
 namespace pmcx {
 
 // ---------------------------------------------------------------- helpers
@@ -188,14 +190,11 @@ __global__ __launch_bounds__(256) void k_kernel_bounds(DeviceState st, int ktype
     const int B = st.n_bin;
     const EnvDerived env = env_derive(st.temp[c], st.pressure[c]);
     const KernelParams kp{st.const_k, st.additive_beta};
-    const bool props = kernel_needs_props(ktype);
     for (int j = threadIdx.x; j < B * 6; j += blockDim.x) {
         const int d = j & 1, bs = j >> 1; // bs = b*3+s
         const double v = st.v_samp[bs];
         const double rho = d ? st.rho_max : st.rho_min;
-        PartProps q{0, 0, 0, 0, 0};
-        if (props) q = particle_props(v, v * rho, env);
-        pp[j] = q;
+        pp[j] = props_for(ktype, v, v * rho, env);
     }
     __syncthreads();
     double *km = st.kmax + (int64_t)c * B * B;
@@ -219,51 +218,14 @@ __global__ __launch_bounds__(256) void k_kernel_bounds(DeviceState st, int ktype
 //
 // aero_state_sort [upstream; called at wrf_pmc_init.F90:1279 and inside
 // mc_coag]: groups g = class*n_bin + bin, ascending slot order inside a
-// group.  Stable counting sort with per-thread contiguous ownership of
-// positions, so the order never depends on atomics or scheduling.  With more
-// than one class it runs as two stable passes (bin, then class).
+// group.  One 256-thread workgroup per cell.  Each wavefront owns a
+// contiguous quarter of the slots; per 64-slot chunk the lanes that share a
+// group are found with ballots (rank = popcount of lower matching lanes), so
+// the order is the slot order by construction and never depends on atomics
+// or scheduling.  vtot is streamed once (8 B per particle), perm written
+// once (4 B per particle).
 
-struct SortLds {
-    uint16_t *tab;   // [D][256] per-digit per-thread counts -> write cursors
-    uint32_t *dtot;  // [D] digit totals, then exclusive bases
-    uint8_t *key;    // [n] bin of slot
-    uint8_t *cls;    // [n] class of slot (n_class > 1)
-    uint16_t *ord;   // [n] order after the bin pass (n_class > 1)
-    uint32_t *gcnt;  // [G] (n_class > 1)
-    double *edge;    // [n_bin+1]
-};
-
-// tab[d][t] += 1 for every position owned by thread t; then per-digit
-// exclusive scan over t, digit totals, exclusive scan over digits.
-template <typename DigitOf>
-__device__ __forceinline__ void count_and_scan(const SortLds &L, int D, int n, int chunk,
-                                               DigitOf digit_of)
-{
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    for (int j = t; j < D * 256; j += 256) L.tab[j] = 0;
-    __syncthreads();
-    {
-        const int j0 = t * chunk, j1 = min(n, j0 + chunk);
-        for (int j = j0; j < j1; j++) L.tab[digit_of(j) * 256 + t] += 1;
-    }
-    __syncthreads();
-    for (int d = wave; d < D; d += 4) {
-        uint16_t *row = L.tab + d * 256;
-        const uint32_t a0 = row[4 * lane], a1 = row[4 * lane + 1], a2 = row[4 * lane + 2],
-                       a3 = row[4 * lane + 3];
-        const uint32_t s = a0 + a1 + a2 + a3;
-        const uint32_t inc = wave_incl_scan_u32(s, lane);
-        const uint32_t ex = inc - s;
-        row[4 * lane] = (uint16_t)ex;
-        row[4 * lane + 1] = (uint16_t)(ex + a0);
-        row[4 * lane + 2] = (uint16_t)(ex + a0 + a1);
-        row[4 * lane + 3] = (uint16_t)(ex + a0 + a1 + a2);
-        if (lane == 63) L.dtot[d] = inc;
-    }
-    __syncthreads();
-}
-
-// exclusive scan in place over an LDS u32 array of length n (n <= 256*K)
+// exclusive scan in place over an LDS u32 array of length n
 __device__ __forceinline__ void block_excl_scan_u32(uint32_t *a, int n, uint32_t *wsum)
 {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -289,112 +251,109 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st)
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint32_t wsum[4];
     const int c = blockIdx.x;
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int B = st.n_bin, C = st.n_class, G = B * C;
     const int n = st.n_part[c];
-    const int cap = st.cap;
-    const int64_t cb = (int64_t)c * cap;
-    const int D = B > C ? B : C;
+    const int64_t cb = (int64_t)c * st.cap;
 
-    SortLds L;
-    size_t o = 0;
-    L.edge = (double *)(smem + o); o += sizeof(double) * (size_t)(B + 1);
-    L.dtot = (uint32_t *)(smem + o); o += sizeof(uint32_t) * (size_t)D;
-    L.gcnt = (uint32_t *)(smem + o); o += (C > 1) ? sizeof(uint32_t) * (size_t)G : 0;
-    L.tab = (uint16_t *)(smem + o); o += sizeof(uint16_t) * 256 * (size_t)D;
-    L.ord = (uint16_t *)(smem + o); o += (C > 1) ? sizeof(uint16_t) * (size_t)cap : 0;
-    L.key = (uint8_t *)(smem + o); o += (size_t)cap;
-    L.cls = (uint8_t *)(smem + o);
+    double *edge = (double *)smem;                    // [B+1]
+    uint32_t *hist = (uint32_t *)(edge + (B + 1));    // [4][G] per-wave counts -> cursors
+    uint32_t *tot = hist + 4 * (size_t)G;             // [G] totals -> offsets
+    uint16_t *key = (uint16_t *)(tot + G);            // [cap] group of slot
 
-    for (int j = t; j <= B; j += 256) L.edge[j] = st.v_edge[j];
-    if (C > 1) for (int j = t; j < G; j += 256) L.gcnt[j] = 0;
+    for (int j = t; j <= B; j += 256) edge[j] = st.v_edge[j];
+    for (int j = t; j < 4 * G; j += 256) hist[j] = 0;
     __syncthreads();
 
-    // keys: one coalesced streaming read of vtot (8 B per particle)
+    // this wave's slots: a contiguous range whose length is a multiple of 64
+    const int per = (((n + 3) >> 2) + 63) & ~63;
+    const int lo = min(n, wave * per), hi = min(n, lo + per);
     const double *vt = st.vtot + cb;
     const int32_t *wc = st.wclass + cb;
-    const double v_lo = L.edge[0], v_hi = L.edge[B];
+    const double v_lo = edge[0], v_hi = edge[B];
+    uint32_t *myhist = hist + (size_t)wave * G;
+
     int oog = 0;
-    for (int i = t; i < n; i += 256) {
+    for (int i = lo + lane; i < hi; i += 64) {
         const double v = vt[i];
         oog |= (v < v_lo) | (v >= v_hi);
-        const int b = bin_of_fast(L.edge, B, v, st.log2_v0, st.inv_dlog2);
-        L.key[i] = (uint8_t)b;
-        if (C > 1) {
-            const int cl = wc[i];
-            L.cls[i] = (uint8_t)cl;
-            atomicAdd(&L.gcnt[cl * B + b], 1u);
-        }
+        int g = bin_of_fast(edge, B, v, st.log2_v0, st.inv_dlog2);
+        if (C > 1) g += wc[i] * B;
+        key[i] = (uint16_t)g;
+        atomicAdd(&myhist[g], 1u); // counting only: order-independent
     }
     if (oog) atomicOr(&st.status[c], ST_OUT_OF_GRID);
     __syncthreads();
 
-    const int chunk = (n + 255) / 256;
-    uint32_t *perm = st.perm + cb;
     int32_t *gcnt_g = st.gcnt + (int64_t)c * G;
     int32_t *goff_g = st.goff + (int64_t)c * G;
-
-    // pass 1: by bin
-    count_and_scan(L, B, n, chunk, [&](int j) { return (int)L.key[j]; });
-    if (C == 1) {
-        for (int j = t; j < B; j += 256) gcnt_g[j] = (int32_t)L.dtot[j];
+    for (int g = t; g < G; g += 256) {
+        const uint32_t h0 = hist[g], h1 = hist[G + g], h2 = hist[2 * G + g], h3 = hist[3 * G + g];
+        hist[g] = 0; hist[G + g] = h0; hist[2 * G + g] = h0 + h1; hist[3 * G + g] = h0 + h1 + h2;
+        const uint32_t s = h0 + h1 + h2 + h3;
+        tot[g] = s;
+        gcnt_g[g] = (int32_t)s;
     }
-    block_excl_scan_u32(L.dtot, B, wsum);
-    if (C == 1) {
-        for (int j = t; j < B; j += 256) goff_g[j] = (int32_t)L.dtot[j];
+    __syncthreads();
+    block_excl_scan_u32(tot, G, wsum);
+    for (int g = t; g < G; g += 256) {
+        const uint32_t o = tot[g];
+        goff_g[g] = (int32_t)o;
+        hist[g] += o; hist[G + g] += o; hist[2 * G + g] += o; hist[3 * G + g] += o;
     }
-    {
-        const int j0 = t * chunk, j1 = min(n, j0 + chunk);
-        for (int j = j0; j < j1; j++) {
-            const int d = L.key[j];
-            const uint32_t pos = L.dtot[d] + L.tab[d * 256 + t];
-            L.tab[d * 256 + t] += 1;
-            if (C == 1) perm[pos] = (uint32_t)j; else L.ord[pos] = (uint16_t)j;
-        }
-    }
-    if (C == 1) return;
     __syncthreads();
 
-    // pass 2: by class, over the bin-sorted order
-    count_and_scan(L, C, n, chunk, [&](int j) { return (int)L.cls[L.ord[j]]; });
-    block_excl_scan_u32(L.dtot, C, wsum);
-    {
-        const int j0 = t * chunk, j1 = min(n, j0 + chunk);
-        for (int j = j0; j < j1; j++) {
-            const int slot = L.ord[j];
-            const int d = L.cls[slot];
-            const uint32_t pos = L.dtot[d] + L.tab[d * 256 + t];
-            L.tab[d * 256 + t] += 1;
-            perm[pos] = (uint32_t)slot;
+    // scatter: position = cursor of (wave, group) + rank among matching lanes
+    uint32_t *perm = st.perm + cb;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    for (int i0 = lo; i0 < hi; i0 += 64) {
+        const int i = i0 + lane;
+        const bool valid = i < hi;
+        const uint32_t g = valid ? key[i] : 0xFFFFFFFFu;
+        uint64_t remaining = __ballot(valid);
+        uint32_t rank = 0, count = 0;
+        while (remaining) {
+            const int leader = __builtin_ctzll(remaining);
+            const uint32_t gl = __shfl(g, leader, 64);
+            const uint64_t m = __ballot(g == gl);
+            if (g == gl) { rank = (uint32_t)__popcll(m & lt); count = (uint32_t)__popcll(m); }
+            remaining &= ~m;
         }
+        if (valid) {
+            const uint32_t base = myhist[g];
+            perm[base + rank] = (uint32_t)i;
+        }
+        wave_sync();
+        if (valid && rank == 0) myhist[g] += count;
+        wave_sync();
     }
-    for (int j = t; j < G; j += 256) gcnt_g[j] = (int32_t)L.gcnt[j];
-    __syncthreads();
-    block_excl_scan_u32(L.gcnt, G, wsum);
-    for (int j = t; j < G; j += 256) goff_g[j] = (int32_t)L.gcnt[j];
 }
 
 // ------------------------------------------------------------- coag sampler
 //
-// mc_coag sweep of one cell by one wavefront.  Sequential semantics of the
-// reference loop nest (classes, bins, samples in order; every accepted pair
-// changes the lists the next sample draws from) are kept exactly: the wave
-// evaluates up to 64 upcoming candidates of the current row against the
-// current lists, the first accepted one (ballot + ctz) is applied, and the
-// Poisson counts of the row's later slots are redrawn from the new counts.
-// Draws are addressed by (seed, cell, step, slot, sample), so a redraw with
-// unchanged counts reproduces the same number.
+// mc_coag sweep.  One group of L lanes (L = 16: four cells per wavefront;
+// L = 64: one) owns a cell.  The reference's sequential semantics (classes,
+// bins, samples in order; every accepted pair changes the lists the next
+// sample draws from) are kept exactly: the group evaluates up to L upcoming
+// candidates of the current row against the current lists, the first accepted
+// one (ballot + ctz) is applied, and the Poisson counts of the row's later
+// slots are redrawn from the new counts.  Draws are addressed by
+// (seed, cell, step, slot, sample), so a redraw with unchanged counts
+// reproduces the same number.  All groups of a wavefront run one flattened
+// loop (advance row | draw counts | prefix | evaluate | coagulate) so they
+// stay convergent whatever row each one is on.
 
 struct CellLds {
+    uint64_t *P;        // [n_bin] inclusive prefix of remaining samples (active slots)
+    uint64_t *mask;     // [n_class][2] non-empty bins bitmask
+    uint32_t *ns;       // [n_bin] Poisson counts of the active slots of the row
     uint16_t *cnt;      // [G] current list length
     uint16_t *nb;       // [G] entries still in the sorted base segment
     uint16_t *off;      // [G] base segment offset in perm
     uint16_t *last_app; // [G] newest appended entry of the group (0xFFFF none)
     uint16_t *app_slot; // [max_appends]
     uint16_t *app_prev; // [max_appends]
-    uint32_t *ns;       // [n_bin] Poisson counts of the current row
-    uint64_t *P;        // [n_bin] inclusive prefix of remaining samples
-    uint64_t *mask;     // [n_class][2] non-empty bins bitmask
+    uint8_t *act;       // [n_bin] partner bins of the row's active slots
 };
 
 __host__ __device__ inline size_t sampler_lds_bytes(int G, int B, int C, int max_appends)
@@ -405,6 +364,7 @@ __host__ __device__ inline size_t sampler_lds_bytes(int G, int B, int C, int max
     o += sizeof(uint32_t) * (size_t)B;      // ns
     o += sizeof(uint16_t) * 4 * (size_t)G;  // cnt nb off last_app
     o += sizeof(uint16_t) * 2 * (size_t)max_appends;
+    o += (size_t)B;                         // act
     return (o + 15) & ~(size_t)15;
 }
 
@@ -423,12 +383,12 @@ __device__ __forceinline__ uint32_t list_get(const CellCtx &X, int g, int i)
     return X.L.app_slot[e];
 }
 
-// uniform across the wave: every lane performs the same LDS writes
-__device__ __forceinline__ void list_set(const CellCtx &X, int g, int i, uint32_t val, int lane)
+// group-uniform: every lane of the group performs the same LDS writes
+__device__ __forceinline__ void list_set(const CellCtx &X, int g, int i, uint32_t val, bool lead)
 {
     const int nb = X.L.nb[g];
     if (i < nb) {
-        if (lane == 0) st_u32(&X.perm[X.L.off[g] + i], val);
+        if (lead) st_u32(&X.perm[X.L.off[g] + i], val);
     } else {
         int e = X.L.last_app[g];
         for (int k = X.L.cnt[g] - 1 - i; k > 0; k--) e = X.L.app_prev[e];
@@ -437,10 +397,10 @@ __device__ __forceinline__ void list_set(const CellCtx &X, int g, int i, uint32_
 }
 
 // swap-with-last removal of logical position i; returns the old last index
-__device__ __forceinline__ int list_remove(const CellCtx &X, int g, int i, int B, int lane)
+__device__ __forceinline__ int list_remove(const CellCtx &X, int g, int i, int B, bool lead)
 {
     const int last = (int)X.L.cnt[g] - 1;
-    if (i != last) list_set(X, g, i, list_get(X, g, last), lane);
+    if (i != last) list_set(X, g, i, list_get(X, g, last), lead);
     if (last >= (int)X.L.nb[g]) X.L.last_app[g] = X.L.app_prev[X.L.last_app[g]];
     else X.L.nb[g] = (uint16_t)last;
     X.L.cnt[g] = (uint16_t)last;
@@ -478,22 +438,60 @@ __device__ __forceinline__ int next_bit(const uint64_t *m2, int from)
     return -1;
 }
 
+template <int L>
+struct Grp {
+    // ballot restricted to this lane's group, as the low L bits
+    static __device__ __forceinline__ uint64_t ballot(bool p, int sub)
+    {
+        const uint64_t m = __ballot(p);
+        if (L == 64) return m;
+        return (m >> (sub * L)) & ((1ull << (L & 63)) - 1ull);
+    }
+    static __device__ __forceinline__ uint64_t incl_scan(uint64_t x, int gl)
+    {
+#pragma unroll
+        for (int d = 1; d < L; d <<= 1) {
+            const uint64_t y = __shfl_up(x, d, L);
+            if (gl >= d) x += y;
+        }
+        return x;
+    }
+    static __device__ __forceinline__ uint64_t sum(uint64_t x)
+    {
+#pragma unroll
+        for (int d = L / 2; d >= 1; d >>= 1) x += __shfl_xor(x, d, L);
+        return x;
+    }
+};
+
+template <int L>
 __global__ __launch_bounds__(256) void k_coag_sample(DeviceState st, int ktype, double del_t,
                                                      uint64_t seed, uint32_t step,
-                                                     size_t lds_per_cell)
+                                                     uint32_t lds_per_cell)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int GPW = 64 / L; // cells per wavefront
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wpb = blockDim.x >> 6;
-    const int c = blockIdx.x * wpb + wave;
-    if (c >= st.n_cells) return; // no workgroup barrier is used below
+    const int sub = lane / L, gl = lane % L;
+    const bool lead = gl == 0;
+    const int cpb = (blockDim.x >> 6) * GPW;
+    const int cidx = blockIdx.x * cpb + wave * GPW + sub;
+    const bool live = cidx < st.n_cells;
+    const int c = live ? cidx : st.n_cells - 1;
     const int B = st.n_bin, C = st.n_class, G = B * C;
     const int64_t cb = (int64_t)c * st.cap;
     const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
+    const uint64_t lt = (1ull << gl) - 1ull;
+
+    // sort-grid edges, shared by the workgroup
+    double *edge = (double *)smem;
+    for (int j = threadIdx.x; j <= B; j += blockDim.x) edge[j] = st.v_edge[j];
+    __syncthreads(); // the only workgroup barrier: groups finish at different times
 
     CellCtx X;
     {
-        unsigned char *base = smem + lds_per_cell * wave;
+        unsigned char *base = smem + (((size_t)(B + 1) * sizeof(double) + 15) & ~(size_t)15) +
+                              (size_t)lds_per_cell * (size_t)(wave * GPW + sub);
         size_t o = 0;
         X.L.P = (uint64_t *)(base + o); o += sizeof(uint64_t) * (size_t)B;
         X.L.mask = (uint64_t *)(base + o); o += sizeof(uint64_t) * 2 * (size_t)C;
@@ -503,7 +501,8 @@ __global__ __launch_bounds__(256) void k_coag_sample(DeviceState st, int ktype, 
         X.L.off = (uint16_t *)(base + o); o += sizeof(uint16_t) * (size_t)G;
         X.L.last_app = (uint16_t *)(base + o); o += sizeof(uint16_t) * (size_t)G;
         X.L.app_slot = (uint16_t *)(base + o); o += sizeof(uint16_t) * (size_t)st.max_appends;
-        X.L.app_prev = (uint16_t *)(base + o);
+        X.L.app_prev = (uint16_t *)(base + o); o += sizeof(uint16_t) * (size_t)st.max_appends;
+        X.L.act = (uint8_t *)(base + o);
     }
     X.perm = st.perm + cb;
     X.vtot = st.vtot + cb;
@@ -511,227 +510,251 @@ __global__ __launch_bounds__(256) void k_coag_sample(DeviceState st, int ktype, 
 
     const int32_t *gcnt_g = st.gcnt + (int64_t)c * G;
     const int32_t *goff_g = st.goff + (int64_t)c * G;
-    for (int g = lane; g < G; g += 64) {
+    for (int g = gl; g < G; g += L) {
         const int n = gcnt_g[g];
         X.L.cnt[g] = (uint16_t)n;
         X.L.nb[g] = (uint16_t)n;
         X.L.off[g] = (uint16_t)goff_g[g];
         X.L.last_app[g] = 0xFFFF;
     }
-    for (int cl = 0; cl < C; cl++) {
-        const uint64_t m0 = __ballot(lane < B && gcnt_g[cl * B + lane] > 0);
-        const uint64_t m1 = __ballot(64 + lane < B && gcnt_g[cl * B + (64 + lane < B ? 64 + lane : 0)] > 0);
-        X.L.mask[cl * 2] = m0;
-        X.L.mask[cl * 2 + 1] = m1;
-    }
+    for (int j = gl; j < 2 * C; j += L) X.L.mask[j] = 0;
     wave_sync();
+    for (int cl = 0; cl < C; cl++)
+        for (int b0 = 0; b0 < B; b0 += L) {
+            const int b = b0 + gl;
+            const uint64_t m = Grp<L>::ballot(b < B && gcnt_g[cl * B + (b < B ? b : 0)] > 0, sub);
+            // bins b0..b0+L-1 never straddle a 64-bit word (L divides 64)
+            X.L.mask[cl * 2 + (b0 >> 6)] |= m << (b0 & 63);
+            wave_sync();
+        }
 
     const EnvDerived env = env_derive(st.temp[c], st.pressure[c]);
     const KernelParams kp{st.const_k, st.additive_beta};
-    const bool use_props = kernel_needs_props(ktype);
     const double *kmax = st.kmax + (int64_t)c * B * B;
     const double *mag = st.mag + (int64_t)c * C;
     int4 *evlog = st.events + (int64_t)c * st.max_events;
 
     int n_ev = 0, n_app = 0, tot_coag = 0, status = 0;
     uint64_t tot_samp = 0;
-    bool stop = false;
 
-    for (int c1 = 0; c1 < C && !stop; c1++)
-    for (int c2 = 0; c2 <= c1 && !stop; c2++) {
-        const double n1 = mag[c1], n2 = mag[c2];
-        const int cc = (n1 < n2) ? c1 : c2;
-        const double nmin = (n1 < n2) ? n1 : n2;
-        const double fmax = (n1 < n2) ? n2 : n1;
-        const double factor = n1 * n2 / nmin;
-        int b1 = -1;
-        while (!stop) {
-            b1 = next_bit(&X.L.mask[c1 * 2], b1 + 1);
-            if (b1 < 0 || b1 >= B) break;
-            const int gA = c1 * B + b1;
-            const int b2s = (c1 == c2) ? b1 : 0;
+    // row state (uniform inside the group)
+    int c1 = 0, c2 = 0, b1 = -1;
+    int gA = 0, cc = 0, na = 0, cur = 0, counted = 0, ns_from = 0;
+    uint32_t cur_s0 = 0;
+    double n1 = 0, n2 = 0, nmin = 0, fmax = 0, factor = 0;
+    uint64_t T = 0, q0 = 0;
+    bool need_row = true, need_ns = false, need_prefix = false;
+    bool done = !live;
 
-            // Poisson counts of slots (gA, (c2,b2)), b2 >= from
-            auto compute_ns = [&](int from) {
-                const int nA = X.L.cnt[gA];
-                for (int k = 0; k < 2; k++) {
-                    const int b2 = k * 64 + lane;
-                    if (b2 < from || b2 >= B) continue;
-                    const int gB = c2 * B + b2;
-                    const int nB = X.L.cnt[gB];
-                    const bool same = (gA == gB);
-                    uint32_t ns = 0;
-                    if (nA > 0 && nB > 0 && !(same && nA < 2)) {
-                        const double k_max = kmax[b1 * B + b2] * fmax;
-                        const double n_possible =
-                            same ? (double)nA * ((double)nA - 1.0) / 2.0
-                                 : (double)nA * (double)nB;
-                        const double mean = k_max * del_t * n_possible;
-                        uint32_t w[4];
-                        rng_block(seed, cell_id, step, ((uint32_t)gA << 16) | (uint32_t)gB,
-                                  SITE_POISSON, 0, w);
-                        ns = (uint32_t)poisson(mean, u53(w[0], w[1]));
-                    }
-                    X.L.ns[b2] = ns;
-                }
-                wave_sync();
-            };
-            auto sum_ns = [&](int from, int to) { // sum ns[from..to)
-                uint64_t s = 0;
-                for (int k = 0; k < 2; k++) {
-                    const int b2 = k * 64 + lane;
-                    if (b2 >= from && b2 < to) s += X.L.ns[b2];
-                }
-                return wave_sum_u64(s);
-            };
+    // append the non-empty partner bins >= from_bin of class c2 at act[at...]
+    auto build_act = [&](int from_bin, int at) {
+        int n = at;
+        for (int b0 = (from_bin / L) * L; b0 < B; b0 += L) {
+            const int b = b0 + gl;
+            const bool bit = b < B && b >= from_bin &&
+                             ((X.L.mask[c2 * 2 + (b >> 6)] >> (b & 63)) & 1ull);
+            const uint64_t m = Grp<L>::ballot(bit, sub);
+            if (bit) X.L.act[n + __popcll(m & lt)] = (uint8_t)b;
+            n += __popcll(m);
+        }
+        wave_sync();
+        return n;
+    };
+    auto sum_ns = [&](int from, int to) { // sum of ns[from..to)
+        uint64_t s = 0;
+        for (int j = from + gl; j < to; j += L) s += X.L.ns[j];
+        return Grp<L>::sum(s);
+    };
 
-            compute_ns(b2s);
-            int counted = b2s, cur_b2 = b2s;
-            uint32_t cur_s0 = 0;
+    while (true) {
+        // ---- advance to the next non-empty row (c1, c2, b1) ----
+        if (!done && need_row) {
+            while (true) {
+                b1 = next_bit(&X.L.mask[c1 * 2], b1 + 1);
+                if (b1 >= 0 && b1 < B) break;
+                b1 = -1;
+                if (++c2 > c1) { c2 = 0; ++c1; }
+                if (c1 >= C) { done = true; break; }
+            }
+            if (!done) {
+                n1 = mag[c1]; n2 = mag[c2];
+                cc = (n1 < n2) ? c1 : c2;
+                nmin = (n1 < n2) ? n1 : n2;
+                fmax = (n1 < n2) ? n2 : n1;
+                factor = n1 * n2 / nmin;
+                gA = c1 * B + b1;
+                na = build_act((c1 == c2) ? b1 : 0, 0);
+                cur = 0; cur_s0 = 0; counted = 0;
+                ns_from = 0; need_ns = true; need_row = false;
+            }
+        }
+        if (__ballot(!done) == 0) break;
+        if (done) continue;
 
-            while (!stop) {
-                // inclusive prefix of remaining samples over b2 in [cur_b2, B)
-                uint64_t T;
-                {
-                    uint64_t r0 = 0, r1 = 0;
-                    if (lane >= cur_b2 && lane < B)
-                        r0 = X.L.ns[lane] - (lane == cur_b2 ? cur_s0 : 0u);
-                    if (64 + lane >= cur_b2 && 64 + lane < B)
-                        r1 = X.L.ns[64 + lane] - (64 + lane == cur_b2 ? cur_s0 : 0u);
-                    const uint64_t i0 = wave_incl_scan_u64(r0, lane);
-                    const uint64_t t0 = __shfl(i0, 63, 64);
-                    const uint64_t i1 = wave_incl_scan_u64(r1, lane) + t0;
-                    if (lane < B) X.L.P[lane] = i0;
-                    if (64 + lane < B) X.L.P[64 + lane] = i1;
-                    T = __shfl(i1, 63, 64);
-                    wave_sync();
-                }
-                if (T == 0) break;
-
-                bool had_event = false;
-                for (uint64_t q0 = 0; q0 < T && !had_event && !stop; q0 += 64) {
-                    const uint64_t q = q0 + (uint64_t)lane;
-                    const bool act = q < T;
-                    int b2 = cur_b2;
-                    uint32_t s = 0;
-                    int i1 = 0, i2 = 0;
-                    uint32_t p1 = 0, p2 = 0;
-                    double v1 = 0, v2 = 0, m1 = 0, m2 = 0;
-                    bool acc = false, over = false;
-                    if (act) {
-                        int lo = cur_b2, hi = B - 1; // smallest b2 with P[b2] > q
-                        while (lo < hi) {
-                            const int mid = (lo + hi) >> 1;
-                            if (X.L.P[mid] > q) hi = mid; else lo = mid + 1;
-                        }
-                        b2 = lo;
-                        const uint32_t first = (b2 == cur_b2) ? cur_s0 : 0u;
-                        const uint64_t rem = (uint64_t)X.L.ns[b2] - first;
-                        s = (uint32_t)(q - (X.L.P[b2] - rem)) + first;
-                        const int gB = c2 * B + b2;
-                        const bool same = (gA == gB);
-                        const int nA = X.L.cnt[gA], nB = X.L.cnt[gB];
-                        uint32_t w[4];
-                        rng_block(seed, cell_id, step, ((uint32_t)gA << 16) | (uint32_t)gB,
-                                  SITE_CAND, s, w);
-                        i1 = (int)index_of(w[0], (uint32_t)nA);
-                        if (same) {
-                            i2 = (int)index_of(w[1], (uint32_t)(nA - 1));
-                            if (i2 >= i1) i2++;
-                        } else {
-                            i2 = (int)index_of(w[1], (uint32_t)nB);
-                        }
-                        p1 = list_get(X, gA, i1);
-                        p2 = list_get(X, gB, i2);
-                        v1 = ld_f64(&X.vtot[p1]); v2 = ld_f64(&X.vtot[p2]);
-                        m1 = ld_f64(&X.mass[p1]); m2 = ld_f64(&X.mass[p2]);
-                        PartProps qa{0, 0, 0, 0, 0}, qb{0, 0, 0, 0, 0};
-                        if (use_props) {
-                            qa = particle_props(v1, m1, env);
-                            qb = particle_props(v2, m2, env);
-                        }
-                        const double k = kernel_pair(ktype, v1, v2, qa, qb, kp);
-                        const double k_max = kmax[b1 * B + b2] * fmax;
-                        const double accept_factor = 1.0 / k_max;
-                        const double p = (k * factor) * accept_factor;
-                        over = p > 1.0;
-                        acc = u53(w[2], w[3]) < p;
-                    }
-                    const uint64_t m = __ballot(act && acc);
-                    const int f = m ? __builtin_ctzll(m) : 64;
-                    // status of candidates actually reached in sequential order
-                    if (__ballot(act && over && lane <= f)) status |= ST_KMAX_EXCEEDED;
-                    if (!m) continue;
-
-                    // ---- coagulate the pair held by lane f (uniform from here) ----
-                    const int b2f = __shfl(b2, f, 64);
-                    const uint32_t sf = __shfl(s, f, 64);
-                    int i1f = __shfl(i1, f, 64), i2f = __shfl(i2, f, 64);
-                    const uint32_t p1f = __shfl(p1, f, 64), p2f = __shfl(p2, f, 64);
-                    const double v1f = __shfl(v1, f, 64), v2f = __shfl(v2, f, 64);
-                    const double m1f = __shfl(m1, f, 64), m2f = __shfl(m2, f, 64);
-                    const int gB = c2 * B + b2f;
-                    const bool same = (gA == gB);
-
-                    // slots up to and including this one have started
-                    tot_samp += sum_ns(counted, b2f + 1);
-                    counted = b2f + 1;
-
-                    if (n_ev >= st.max_events) { status |= ST_EVENT_OVERFLOW; stop = true; break; }
+        // ---- Poisson counts of the active slots j >= ns_from ----
+        if (need_ns) {
+            const int nA = X.L.cnt[gA];
+            for (int j = ns_from + gl; j < na; j += L) {
+                const int b2 = X.L.act[j];
+                const int gB = c2 * B + b2;
+                const int nB = X.L.cnt[gB];
+                const bool same = (gA == gB);
+                uint32_t ns = 0;
+                if (nA > 0 && nB > 0 && !(same && nA < 2)) {
+                    const double k_max = kmax[b1 * B + b2] * fmax;
+                    const double n_possible = same ? (double)nA * ((double)nA - 1.0) / 2.0
+                                                   : (double)nA * (double)nB;
+                    const double mean = k_max * del_t * n_possible;
                     uint32_t w[4];
                     rng_block(seed, cell_id, step, ((uint32_t)gA << 16) | (uint32_t)gB,
-                              SITE_COAG, sf, w);
-                    const bool rem1 = u53(w[0], w[1]) < nmin / n1;
-                    const bool rem2 = u53(w[2], w[3]) < nmin / n2;
-                    const double vn = v1f + v2f, mn = m1f + m2f;
-                    const bool big1 = (v1f >= v2f);
-                    const bool pn_is_1 = (rem1 && rem2) ? big1 : rem1;
-                    const uint32_t pn = pn_is_1 ? p1f : p2f, po = pn_is_1 ? p2f : p1f;
-                    const bool rem_o = pn_is_1 ? rem2 : rem1;
-                    int in = pn_is_1 ? i1f : i2f;
-                    const int io = pn_is_1 ? i2f : i1f;
-                    const int g_old = pn_is_1 ? gA : gB, g_o = pn_is_1 ? gB : gA;
-                    if (vn < st.v_edge[0] || vn >= st.v_edge[B]) status |= ST_OUT_OF_GRID;
-                    const int g_new = cc * B + bin_of(st.v_edge, B, vn);
-                    if (g_new != g_old && n_app >= st.max_appends) {
-                        status |= ST_APPEND_OVERFLOW; stop = true; break;
-                    }
-                    if (lane == 0)
-                        evlog[n_ev] = make_int4((int)pn, (int)po, rem_o ? 1 : 0, cc);
-                    n_ev++;
-                    if (rem_o) {
-                        const int last = list_remove(X, g_o, io, B, lane);
-                        if (same && in == last) in = io;
-                        wave_sync();
-                    }
-                    if (g_new != g_old) {
-                        list_remove(X, g_old, in, B, lane);
-                        wave_sync();
-                        list_append(X, g_new, pn, n_app, B);
-                        n_app++;
-                    }
-                    if (lane == 0) { st_f64(&X.vtot[pn], vn); st_f64(&X.mass[pn], mn); }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    wave_sync();
-                    tot_coag++;
-
-                    // continue the row after this sample
-                    cur_b2 = b2f;
-                    cur_s0 = sf + 1;
-                    {
-                        const int nA = X.L.cnt[gA], nB = X.L.cnt[gB];
-                        if (nA < 1 || nB < 1 || (same && nA < 2)) cur_s0 = X.L.ns[cur_b2];
-                    }
-                    compute_ns(cur_b2 + 1);
-                    had_event = true;
+                              SITE_POISSON, 0, w);
+                    ns = (uint32_t)poisson(mean, u53(w[0], w[1]));
                 }
-                if (!had_event) break;
+                X.L.ns[j] = ns;
             }
-            if (!stop) tot_samp += sum_ns(counted, B);
+            wave_sync();
+            need_ns = false;
+            need_prefix = true;
         }
+
+        // ---- inclusive prefix of the remaining samples over slots j >= cur ----
+        if (need_prefix) {
+            uint64_t carry = 0;
+            for (int j0 = cur; j0 < na; j0 += L) {
+                const int j = j0 + gl;
+                uint64_t r = 0;
+                if (j < na) r = (uint64_t)X.L.ns[j] - (j == cur ? cur_s0 : 0u);
+                const uint64_t inc = Grp<L>::incl_scan(r, gl) + carry;
+                if (j < na) X.L.P[j] = inc;
+                carry = __shfl(inc, L - 1, L);
+            }
+            wave_sync();
+            T = carry;
+            q0 = 0;
+            need_prefix = false;
+        }
+
+        // ---- row exhausted ----
+        if (q0 >= T) {
+            tot_samp += sum_ns(counted, na);
+            need_row = true;
+            continue;
+        }
+
+        // ---- evaluate up to L candidates against the current lists ----
+        const uint64_t q = q0 + (uint64_t)gl;
+        const bool act = q < T;
+        int j = cur;
+        uint32_t s = 0;
+        int i1 = 0, i2 = 0;
+        uint32_t p1 = 0, p2 = 0;
+        double v1 = 0, v2 = 0, m1 = 0, m2 = 0;
+        bool acc = false, over = false;
+        if (act) {
+            int lo = cur, hi = na - 1; // smallest j with P[j] > q
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (X.L.P[mid] > q) hi = mid; else lo = mid + 1;
+            }
+            j = lo;
+            const int b2 = X.L.act[j];
+            const uint32_t first = (j == cur) ? cur_s0 : 0u;
+            const uint64_t rem = (uint64_t)X.L.ns[j] - first;
+            s = (uint32_t)(q - (X.L.P[j] - rem)) + first;
+            const int gB = c2 * B + b2;
+            const bool same = (gA == gB);
+            const int nA = X.L.cnt[gA], nB = X.L.cnt[gB];
+            uint32_t w[4];
+            rng_block(seed, cell_id, step, ((uint32_t)gA << 16) | (uint32_t)gB, SITE_CAND, s, w);
+            i1 = (int)index_of(w[0], (uint32_t)nA);
+            if (same) {
+                i2 = (int)index_of(w[1], (uint32_t)(nA - 1));
+                if (i2 >= i1) i2++;
+            } else {
+                i2 = (int)index_of(w[1], (uint32_t)nB);
+            }
+            p1 = list_get(X, gA, i1);
+            p2 = list_get(X, gB, i2);
+            v1 = ld_f64(&X.vtot[p1]); v2 = ld_f64(&X.vtot[p2]);
+            m1 = ld_f64(&X.mass[p1]); m2 = ld_f64(&X.mass[p2]);
+            const double k_max = kmax[b1 * B + b2] * fmax;
+            const PartProps qa = props_for(ktype, v1, m1, env);
+            const PartProps qb = props_for(ktype, v2, m2, env);
+            const double k = kernel_pair(ktype, v1, v2, qa, qb, kp);
+            const double kf = k * factor;
+            over = kf > k_max;
+            acc = u53(w[2], w[3]) * k_max < kf; // accept with probability K f / k_max
+        }
+        const uint64_t m = Grp<L>::ballot(act && acc, sub);
+        const int f = m ? __builtin_ctzll(m) : L;
+        // status of the candidates actually reached in sequential order
+        if (Grp<L>::ballot(act && over && gl <= f, sub)) status |= ST_KMAX_EXCEEDED;
+        if (!m) { q0 += L; continue; }
+
+        // ---- coagulate the pair held by lane f (uniform in the group from here) ----
+        const int jf = __shfl(j, f, L);
+        const uint32_t sf = __shfl(s, f, L);
+        const int i1f = __shfl(i1, f, L), i2f = __shfl(i2, f, L);
+        const uint32_t p1f = __shfl(p1, f, L), p2f = __shfl(p2, f, L);
+        const double v1f = __shfl(v1, f, L), v2f = __shfl(v2, f, L);
+        const double m1f = __shfl(m1, f, L), m2f = __shfl(m2, f, L);
+        const int b2f = X.L.act[jf];
+        const int gB = c2 * B + b2f;
+        const bool same = (gA == gB);
+
+        // slots up to and including this one have started
+        tot_samp += sum_ns(counted, jf + 1);
+        counted = jf + 1;
+
+        if (n_ev >= st.max_events) { status |= ST_EVENT_OVERFLOW; done = true; continue; }
+        uint32_t w[4];
+        rng_block(seed, cell_id, step, ((uint32_t)gA << 16) | (uint32_t)gB, SITE_COAG, sf, w);
+        const bool rem1 = u53(w[0], w[1]) < nmin / n1;
+        const bool rem2 = u53(w[2], w[3]) < nmin / n2;
+        const double vn = v1f + v2f, mn = m1f + m2f;
+        const bool big1 = (v1f >= v2f);
+        const bool pn_is_1 = (rem1 && rem2) ? big1 : rem1;
+        const uint32_t pn = pn_is_1 ? p1f : p2f, po = pn_is_1 ? p2f : p1f;
+        const bool rem_o = pn_is_1 ? rem2 : rem1;
+        int in = pn_is_1 ? i1f : i2f;
+        const int io = pn_is_1 ? i2f : i1f;
+        const int g_old = pn_is_1 ? gA : gB, g_o = pn_is_1 ? gB : gA;
+        if (vn < edge[0] || vn >= edge[B]) status |= ST_OUT_OF_GRID;
+        const int g_new = cc * B + bin_of_fast(edge, B, vn, st.log2_v0, st.inv_dlog2);
+        if (g_new != g_old && n_app >= st.max_appends) {
+            status |= ST_APPEND_OVERFLOW; done = true; continue;
+        }
+        if (lead) evlog[n_ev] = make_int4((int)pn, (int)po, rem_o ? 1 : 0, cc);
+        n_ev++;
+        if (rem_o) {
+            const int last = list_remove(X, g_o, io, B, lead);
+            if (same && in == last) in = io;
+            wave_sync();
+        }
+        if (g_new != g_old) {
+            list_remove(X, g_old, in, B, lead);
+            wave_sync();
+            list_append(X, g_new, pn, n_app, B);
+            n_app++;
+        }
+        if (lead) { st_f64(&X.vtot[pn], vn); st_f64(&X.mass[pn], mn); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_sync();
+        tot_coag++;
+
+        // continue the row after this sample: later slots are rebuilt and redrawn
+        cur = jf;
+        cur_s0 = sf + 1;
+        {
+            const int nA = X.L.cnt[gA], nB = X.L.cnt[gB];
+            if (nA < 1 || nB < 1 || (same && nA < 2)) cur_s0 = X.L.ns[cur]; // exit this slot
+        }
+        na = build_act(b2f + 1, cur + 1);
+        ns_from = cur + 1;
+        need_ns = true;
     }
 
-    if (lane == 0) {
+    if (live && lead) {
         st.n_events[c] = n_ev;
         st.n_samp[c] = tot_samp > 0x7FFFFFFFull ? 0x7FFFFFFF : (int32_t)tot_samp;
         st.n_coag[c] = tot_coag;
@@ -1102,11 +1125,8 @@ __global__ void k_test_math(int op, int64_t n, const double *a, const double *b,
     case 7: {
         const EnvDerived env = env_derive(temp, pressure);
         const KernelParams kp{const_k, additive_beta};
-        PartProps qa{0, 0, 0, 0, 0}, qb{0, 0, 0, 0, 0};
-        if (kernel_needs_props(ktype)) {
-            qa = particle_props(a[i], b[i], env);
-            qb = particle_props(c3[i], c4[i], env);
-        }
+        const PartProps qa = props_for(ktype, a[i], b[i], env);
+        const PartProps qb = props_for(ktype, c3[i], c4[i], env);
         r = kernel_pair(ktype, a[i], c3[i], qa, qb, kp);
         break;
     }
@@ -1127,18 +1147,22 @@ __global__ void k_test_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
 
 size_t bin_sort_lds_bytes(const DeviceState &st)
 {
-    const int B = st.n_bin, C = st.n_class, G = B * C, D = B > C ? B : C;
-    size_t o = sizeof(double) * (size_t)(B + 1) + sizeof(uint32_t) * (size_t)D;
-    if (C > 1) o += sizeof(uint32_t) * (size_t)G;
-    o += sizeof(uint16_t) * 256 * (size_t)D;
-    if (C > 1) o += sizeof(uint16_t) * (size_t)st.cap;
-    o += (size_t)st.cap;
-    if (C > 1) o += (size_t)st.cap;
+    const size_t B = st.n_bin, G = (size_t)st.n_bin * st.n_class;
+    const size_t o = sizeof(double) * (B + 1) + sizeof(uint32_t) * 5 * G +
+                     sizeof(uint16_t) * (size_t)st.cap;
     return (o + 15) & ~(size_t)15;
 }
 size_t sampler_lds_bytes_per_cell(const DeviceState &st)
 {
     return sampler_lds_bytes(st.n_bin * st.n_class, st.n_bin, st.n_class, st.max_appends);
+}
+// lanes per cell of the sampler: 16 (four cells per wavefront) while a cell's
+// list state is small, 64 otherwise.  PMCX_SAMPLER_LANES overrides (tuning).
+int sampler_lanes(const DeviceState &st)
+{
+    const char *e = getenv("PMCX_SAMPLER_LANES");
+    if (e && (atoi(e) == 16 || atoi(e) == 64)) return atoi(e);
+    return sampler_lds_bytes_per_cell(st) <= 6 * 1024 ? 16 : 64;
 }
 size_t diagnostics_lds_bytes(const DeviceState &st)
 {
@@ -1231,10 +1255,23 @@ hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, ui
                               uint32_t step, hipStream_t s)
 {
     const size_t per = sampler_lds_bytes_per_cell(st);
-    const int wpb = waves_per_block(per);
-    allow_lds(k_coag_sample, per * wpb);
-    hipLaunchKernelGGL(k_coag_sample, dim3((st.n_cells + wpb - 1) / wpb), dim3(64 * wpb),
-                       per * wpb, s, st, ktype, del_t, seed, step, per);
+    const size_t shared = (sizeof(double) * (size_t)(st.n_bin + 1) + 15) & ~(size_t)15;
+    const int L = sampler_lanes(st);
+    const int gpw = 64 / L;
+    int wpb = 4; // wavefronts per workgroup, shrunk until the cells' LDS fits 64 KiB
+    while (wpb > 1 && shared + per * wpb * gpw > 64 * 1024) wpb >>= 1;
+    const int cpb = wpb * gpw;
+    const size_t lds = shared + per * cpb;
+    const dim3 grid((st.n_cells + cpb - 1) / cpb), block(64 * wpb);
+    if (L == 16) {
+        allow_lds(k_coag_sample<16>, lds);
+        hipLaunchKernelGGL(k_coag_sample<16>, grid, block, lds, s, st, ktype, del_t, seed, step,
+                           (uint32_t)per);
+    } else {
+        allow_lds(k_coag_sample<64>, lds);
+        hipLaunchKernelGGL(k_coag_sample<64>, grid, block, lds, s, st, ktype, del_t, seed, step,
+                           (uint32_t)per);
+    }
     return hipGetLastError();
 }
 hipError_t launch_coag_apply(const DeviceState &st, hipStream_t s)
