@@ -215,7 +215,7 @@ static inline double pmco_norminv(double p)
 /* -------------------------------------------------------------- Poisson */
 
 #define PMCO_POISSON_WALK_MAX 200.0
-#define PMCO_NSAMP_MAX 0x0FFFFFFF
+#define PMCO_NSAMP_MAX 0x00FFFFFF
 
 /* Poisson variate from one 53-bit uniform: CDF walk below
  * PMCO_POISSON_WALK_MAX, rounded normal approximation above it (the

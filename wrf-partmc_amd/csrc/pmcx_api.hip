@@ -240,6 +240,8 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
     st.cell_id_base = cfg->cell_id_base;
     st.const_k = cfg->const_k; st.additive_beta = cfg->additive_beta;
     st.rho_min = 0; st.rho_max = 0;
+    st.key_bits = 1;
+    while ((1 << st.key_bits) < cfg->n_class * cfg->n_bin) st.key_bits++;
 
     // sort grid (aero_sorted bin_grid) and diagnostics grid (driver:783)
     const int B = cfg->n_bin;
@@ -255,8 +257,10 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
         ctx->v_samp[3 * b + 1] = std::sqrt(ctx->v_edge[b] * ctx->v_edge[b + 1]);
         ctx->v_samp[3 * b + 2] = ctx->v_edge[b + 1];
     }
-    st.log2_v0 = std::log2(ctx->v_edge[0]);
-    st.inv_dlog2 = (double)B / (std::log2(ctx->v_edge[B]) - std::log2(ctx->v_edge[0]));
+    st.log2_v0 = (float)std::log2(ctx->v_edge[0]);
+    st.inv_dlog2 = (float)((double)B / (std::log2(ctx->v_edge[B]) - std::log2(ctx->v_edge[0])));
+    // piecewise-linear log2 is off by at most 0.0861: keep the estimate within one bin
+    st.bin_fast = (st.inv_dlog2 * 0.09f < 0.9f) ? 1 : 0;
     const int nd = cfg->n_dbin;
     ctx->d_edge.resize(nd + 1); ctx->d_width.resize(nd);
     const double m0 = std::log(cfg->d_min), m1 = std::log(cfg->d_max);

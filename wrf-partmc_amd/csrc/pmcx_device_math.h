@@ -23,13 +23,13 @@ __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uin
 {
 #pragma unroll
     for (int r = 0; r < 10; r++) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]);
-        const uint32_t lo0 = 0xD2511F53u * c[0];
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]);
-        const uint32_t lo1 = 0xCD9E8D57u * c[2];
-        const uint32_t n0 = hi1 ^ c[1] ^ k0;
-        const uint32_t n2 = hi0 ^ c[3] ^ k1;
-        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        // one 32x32->64 multiply (v_mad_u64_u32) per product: integer multiplies
+        // are quarter-rate, so hi and lo must not be separate instructions
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        c[0] = n0; c[1] = (uint32_t)p1; c[2] = n2; c[3] = (uint32_t)p0;
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }
@@ -181,7 +181,7 @@ __device__ inline double det_norminv(double p)
 // ---------------------------------------------------------------- Poisson
 
 constexpr double POISSON_WALK_MAX = 200.0;
-constexpr int32_t NSAMP_MAX = 0x0FFFFFFF;
+constexpr int32_t NSAMP_MAX = 0x00FFFFFF; // per-slot cap: a row's total fits 32 bits
 
 __device__ inline int32_t poisson(double mean, double u)
 {

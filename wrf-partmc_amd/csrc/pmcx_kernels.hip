@@ -84,20 +84,21 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t x)
     return x;
 }
 
-// Exact bin of a volume on the log-spaced grid: a bit-level estimate of
-// log2(v) lands within one bin of the answer and two edge compares settle it.
-__device__ __forceinline__ int bin_of_fast(const double *v_edge, int n_bin, double v,
-                                           double log2_v0, double inv_dlog2)
+// Exact bin of a volume on the log-spaced grid.  A float estimate of log2(v)
+// from the exponent and the top mantissa bits lands within one bin of the
+// answer (host checks the grid is coarse enough: st.bin_fast); one compare
+// against each edge of that bin settles it.  Falls back to binary search.
+__device__ __forceinline__ int bin_index(const double *v_edge, int n_bin, double v,
+                                         const DeviceState &st)
 {
-    const uint64_t u = d2u(v);
-    const double l2 = (double)((int)((u >> 52) & 0x7FF) - 1023) +
-                      (double)(u & 0x000FFFFFFFFFFFFFull) * 0x1.0p-52;
-    int b = (int)((l2 - log2_v0) * inv_dlog2);
+    if (!st.bin_fast) return bin_of(v_edge, n_bin, v);
+    const uint32_t hi = (uint32_t)(d2u(v) >> 32);
+    const float l2 = (float)((int)((hi >> 20) & 0x7FF) - 1023) + (float)(hi & 0xFFFFFu) * 0x1.0p-20f;
+    int b = (int)((l2 - st.log2_v0) * st.inv_dlog2);
     b = b < 0 ? 0 : (b > n_bin - 1 ? n_bin - 1 : b);
-    // settle (at most a couple of steps; loops only guard pathological input)
-    while (b > 0 && v < v_edge[b]) b--;
-    while (b < n_bin - 1 && v >= v_edge[b + 1]) b++;
-    return b;
+    const double e_lo = v_edge[b], e_hi = v_edge[b + 1];
+    b += (int)(v >= e_hi) - (int)(v < e_lo);
+    return b < 0 ? 0 : (b > n_bin - 1 ? n_bin - 1 : b);
 }
 
 // ------------------------------------------------------------ upload/download
@@ -273,14 +274,40 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st)
     const double v_lo = edge[0], v_hi = edge[B];
     uint32_t *myhist = hist + (size_t)wave * G;
 
+    // lanes of a 64-slot chunk that hold the same group, from one ballot per key bit
+    const int key_bits = st.key_bits;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    auto peers_of = [&](uint32_t g, bool valid) {
+        uint64_t peers = __ballot(valid);
+        for (int k = 0; k < key_bits; k++) {
+            const bool bit = (g >> k) & 1u;
+            const uint64_t m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        return peers;
+    };
+
+    // pass 1: keys + per-wave histogram (LDS atomics: counting is order-independent).
+    // Four loads are issued before the first use so a wave keeps 2 KiB in flight.
     int oog = 0;
-    for (int i = lo + lane; i < hi; i += 64) {
-        const double v = vt[i];
-        oog |= (v < v_lo) | (v >= v_hi);
-        int g = bin_of_fast(edge, B, v, st.log2_v0, st.inv_dlog2);
-        if (C > 1) g += wc[i] * B;
-        key[i] = (uint16_t)g;
-        atomicAdd(&myhist[g], 1u); // counting only: order-independent
+    for (int i0 = lo; i0 < hi; i0 += 256) {
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * 64 + lane;
+            v[u] = i < hi ? vt[i] : v_lo;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * 64 + lane;
+            if (i < hi) {
+                oog |= (v[u] < v_lo) | (v[u] >= v_hi);
+                uint32_t g = (uint32_t)bin_index(edge, B, v[u], st);
+                if (C > 1) g += (uint32_t)wc[i] * (uint32_t)B;
+                key[i] = (uint16_t)g;
+                atomicAdd(&myhist[g], 1u);
+            }
+        }
     }
     if (oog) atomicOr(&st.status[c], ST_OUT_OF_GRID);
     __syncthreads();
@@ -305,26 +332,15 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st)
 
     // scatter: position = cursor of (wave, group) + rank among matching lanes
     uint32_t *perm = st.perm + cb;
-    const uint64_t lt = (1ull << lane) - 1ull;
     for (int i0 = lo; i0 < hi; i0 += 64) {
         const int i = i0 + lane;
         const bool valid = i < hi;
-        const uint32_t g = valid ? key[i] : 0xFFFFFFFFu;
-        uint64_t remaining = __ballot(valid);
-        uint32_t rank = 0, count = 0;
-        while (remaining) {
-            const int leader = __builtin_ctzll(remaining);
-            const uint32_t gl = __shfl(g, leader, 64);
-            const uint64_t m = __ballot(g == gl);
-            if (g == gl) { rank = (uint32_t)__popcll(m & lt); count = (uint32_t)__popcll(m); }
-            remaining &= ~m;
-        }
-        if (valid) {
-            const uint32_t base = myhist[g];
-            perm[base + rank] = (uint32_t)i;
-        }
+        const uint32_t g = valid ? key[i] : 0u;
+        const uint64_t peers = peers_of(g, valid);
+        const uint32_t rank = (uint32_t)__popcll(peers & lt);
+        if (valid) perm[myhist[g] + rank] = (uint32_t)i;
         wave_sync();
-        if (valid && rank == 0) myhist[g] += count;
+        if (valid && rank == 0) myhist[g] += (uint32_t)__popcll(peers);
         wave_sync();
     }
 }
@@ -344,8 +360,10 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st)
 // stay convergent whatever row each one is on.
 
 struct CellLds {
-    uint64_t *P;        // [n_bin] inclusive prefix of remaining samples (active slots)
+    EnvDerived *env;    // per-cell air properties (kept out of registers)
+    double *ub;         // [n_bin] cached Poisson uniform of slot (row, partner bin); <0 = none
     uint64_t *mask;     // [n_class][2] non-empty bins bitmask
+    uint32_t *P;        // [n_bin] inclusive prefix of remaining samples (active slots)
     uint32_t *ns;       // [n_bin] Poisson counts of the active slots of the row
     uint16_t *cnt;      // [G] current list length
     uint16_t *nb;       // [G] entries still in the sorted base segment
@@ -359,9 +377,10 @@ struct CellLds {
 __host__ __device__ inline size_t sampler_lds_bytes(int G, int B, int C, int max_appends)
 {
     size_t o = 0;
-    o += sizeof(uint64_t) * (size_t)B;      // P
+    o += sizeof(EnvDerived);                // env
+    o += sizeof(double) * (size_t)B;        // ub
     o += sizeof(uint64_t) * 2 * (size_t)C;  // mask
-    o += sizeof(uint32_t) * (size_t)B;      // ns
+    o += sizeof(uint32_t) * 2 * (size_t)B;  // P, ns
     o += sizeof(uint16_t) * 4 * (size_t)G;  // cnt nb off last_app
     o += sizeof(uint16_t) * 2 * (size_t)max_appends;
     o += (size_t)B;                         // act
@@ -447,16 +466,16 @@ struct Grp {
         if (L == 64) return m;
         return (m >> (sub * L)) & ((1ull << (L & 63)) - 1ull);
     }
-    static __device__ __forceinline__ uint64_t incl_scan(uint64_t x, int gl)
+    static __device__ __forceinline__ uint32_t incl_scan(uint32_t x, int gl)
     {
 #pragma unroll
         for (int d = 1; d < L; d <<= 1) {
-            const uint64_t y = __shfl_up(x, d, L);
+            const uint32_t y = __shfl_up(x, d, L);
             if (gl >= d) x += y;
         }
         return x;
     }
-    static __device__ __forceinline__ uint64_t sum(uint64_t x)
+    static __device__ __forceinline__ uint32_t sum(uint32_t x)
     {
 #pragma unroll
         for (int d = L / 2; d >= 1; d >>= 1) x += __shfl_xor(x, d, L);
@@ -464,8 +483,8 @@ struct Grp {
     }
 };
 
-template <int L>
-__global__ __launch_bounds__(256) void k_coag_sample(DeviceState st, int ktype, double del_t,
+template <int L, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_coag_sample(DeviceState st, int ktype, double del_t,
                                                      uint64_t seed, uint32_t step,
                                                      uint32_t lds_per_cell)
 {
@@ -493,8 +512,10 @@ __global__ __launch_bounds__(256) void k_coag_sample(DeviceState st, int ktype, 
         unsigned char *base = smem + (((size_t)(B + 1) * sizeof(double) + 15) & ~(size_t)15) +
                               (size_t)lds_per_cell * (size_t)(wave * GPW + sub);
         size_t o = 0;
-        X.L.P = (uint64_t *)(base + o); o += sizeof(uint64_t) * (size_t)B;
+        X.L.env = (EnvDerived *)(base + o); o += sizeof(EnvDerived);
+        X.L.ub = (double *)(base + o); o += sizeof(double) * (size_t)B;
         X.L.mask = (uint64_t *)(base + o); o += sizeof(uint64_t) * 2 * (size_t)C;
+        X.L.P = (uint32_t *)(base + o); o += sizeof(uint32_t) * (size_t)B;
         X.L.ns = (uint32_t *)(base + o); o += sizeof(uint32_t) * (size_t)B;
         X.L.cnt = (uint16_t *)(base + o); o += sizeof(uint16_t) * (size_t)G;
         X.L.nb = (uint16_t *)(base + o); o += sizeof(uint16_t) * (size_t)G;
@@ -528,7 +549,9 @@ __global__ __launch_bounds__(256) void k_coag_sample(DeviceState st, int ktype, 
             wave_sync();
         }
 
-    const EnvDerived env = env_derive(st.temp[c], st.pressure[c]);
+    *X.L.env = env_derive(st.temp[c], st.pressure[c]); // same value from every lane of the group
+    wave_sync();
+    const EnvDerived &env = *X.L.env;
     const KernelParams kp{st.const_k, st.additive_beta};
     const double *kmax = st.kmax + (int64_t)c * B * B;
     const double *mag = st.mag + (int64_t)c * C;
@@ -542,8 +565,8 @@ __global__ __launch_bounds__(256) void k_coag_sample(DeviceState st, int ktype, 
     int gA = 0, cc = 0, na = 0, cur = 0, counted = 0, ns_from = 0;
     uint32_t cur_s0 = 0;
     double n1 = 0, n2 = 0, nmin = 0, fmax = 0, factor = 0;
-    uint64_t T = 0, q0 = 0;
-    bool need_row = true, need_ns = false, need_prefix = false;
+    uint32_t T = 0, q0 = 0; // a row holds < 2^31 samples (NSAMP_MAX per slot, <= 128 slots)
+    bool need_row = true, need_ns = false, need_prefix = false, fresh = false;
     bool done = !live;
 
     // append the non-empty partner bins >= from_bin of class c2 at act[at...]
@@ -561,9 +584,9 @@ __global__ __launch_bounds__(256) void k_coag_sample(DeviceState st, int ktype, 
         return n;
     };
     auto sum_ns = [&](int from, int to) { // sum of ns[from..to)
-        uint64_t s = 0;
+        uint32_t s = 0;
         for (int j = from + gl; j < to; j += L) s += X.L.ns[j];
-        return Grp<L>::sum(s);
+        return (uint64_t)Grp<L>::sum(s);
     };
 
     while (true) {
@@ -585,7 +608,7 @@ __global__ __launch_bounds__(256) void k_coag_sample(DeviceState st, int ktype, 
                 gA = c1 * B + b1;
                 na = build_act((c1 == c2) ? b1 : 0, 0);
                 cur = 0; cur_s0 = 0; counted = 0;
-                ns_from = 0; need_ns = true; need_row = false;
+                ns_from = 0; need_ns = true; need_row = false; fresh = true;
             }
         }
         if (__ballot(!done) == 0) break;
@@ -605,26 +628,35 @@ __global__ __launch_bounds__(256) void k_coag_sample(DeviceState st, int ktype, 
                     const double n_possible = same ? (double)nA * ((double)nA - 1.0) / 2.0
                                                    : (double)nA * (double)nB;
                     const double mean = k_max * del_t * n_possible;
-                    uint32_t w[4];
-                    rng_block(seed, cell_id, step, ((uint32_t)gA << 16) | (uint32_t)gB,
-                              SITE_POISSON, 0, w);
-                    ns = (uint32_t)poisson(mean, u53(w[0], w[1]));
+                    // the slot's uniform is fixed for the row: draw it once, reuse on redraws
+                    double u = X.L.ub[b2];
+                    if (fresh || u < 0.0) {
+                        uint32_t w[4];
+                        rng_block(seed, cell_id, step, ((uint32_t)gA << 16) | (uint32_t)gB,
+                                  SITE_POISSON, 0, w);
+                        u = u53(w[0], w[1]);
+                        X.L.ub[b2] = u;
+                    }
+                    ns = (uint32_t)poisson(mean, u);
+                } else if (fresh) {
+                    X.L.ub[b2] = -1.0;
                 }
                 X.L.ns[j] = ns;
             }
             wave_sync();
             need_ns = false;
+            fresh = false;
             need_prefix = true;
         }
 
         // ---- inclusive prefix of the remaining samples over slots j >= cur ----
         if (need_prefix) {
-            uint64_t carry = 0;
+            uint32_t carry = 0;
             for (int j0 = cur; j0 < na; j0 += L) {
                 const int j = j0 + gl;
-                uint64_t r = 0;
-                if (j < na) r = (uint64_t)X.L.ns[j] - (j == cur ? cur_s0 : 0u);
-                const uint64_t inc = Grp<L>::incl_scan(r, gl) + carry;
+                uint32_t r = 0;
+                if (j < na) r = X.L.ns[j] - (j == cur ? cur_s0 : 0u);
+                const uint32_t inc = Grp<L>::incl_scan(r, gl) + carry;
                 if (j < na) X.L.P[j] = inc;
                 carry = __shfl(inc, L - 1, L);
             }
@@ -642,7 +674,7 @@ __global__ __launch_bounds__(256) void k_coag_sample(DeviceState st, int ktype, 
         }
 
         // ---- evaluate up to L candidates against the current lists ----
-        const uint64_t q = q0 + (uint64_t)gl;
+        const uint32_t q = q0 + (uint32_t)gl;
         const bool act = q < T;
         int j = cur;
         uint32_t s = 0;
@@ -659,8 +691,8 @@ __global__ __launch_bounds__(256) void k_coag_sample(DeviceState st, int ktype, 
             j = lo;
             const int b2 = X.L.act[j];
             const uint32_t first = (j == cur) ? cur_s0 : 0u;
-            const uint64_t rem = (uint64_t)X.L.ns[j] - first;
-            s = (uint32_t)(q - (X.L.P[j] - rem)) + first;
+            const uint32_t rem = X.L.ns[j] - first;
+            s = (q - (X.L.P[j] - rem)) + first;
             const int gB = c2 * B + b2;
             const bool same = (gA == gB);
             const int nA = X.L.cnt[gA], nB = X.L.cnt[gB];
@@ -707,10 +739,15 @@ __global__ __launch_bounds__(256) void k_coag_sample(DeviceState st, int ktype, 
         counted = jf + 1;
 
         if (n_ev >= st.max_events) { status |= ST_EVENT_OVERFLOW; done = true; continue; }
-        uint32_t w[4];
-        rng_block(seed, cell_id, step, ((uint32_t)gA << 16) | (uint32_t)gB, SITE_COAG, sf, w);
-        const bool rem1 = u53(w[0], w[1]) < nmin / n1;
-        const bool rem2 = u53(w[2], w[3]) < nmin / n2;
+        // weighted removal [coagulate_weighting]: with equal weights both quotients are
+        // exactly 1 and every uniform in [0,1) passes, so the draw is not needed
+        bool rem1 = true, rem2 = true;
+        if (n1 != n2) {
+            uint32_t w[4];
+            rng_block(seed, cell_id, step, ((uint32_t)gA << 16) | (uint32_t)gB, SITE_COAG, sf, w);
+            rem1 = u53(w[0], w[1]) < nmin / n1;
+            rem2 = u53(w[2], w[3]) < nmin / n2;
+        }
         const double vn = v1f + v2f, mn = m1f + m2f;
         const bool big1 = (v1f >= v2f);
         const bool pn_is_1 = (rem1 && rem2) ? big1 : rem1;
@@ -720,7 +757,7 @@ __global__ __launch_bounds__(256) void k_coag_sample(DeviceState st, int ktype, 
         const int io = pn_is_1 ? i2f : i1f;
         const int g_old = pn_is_1 ? gA : gB, g_o = pn_is_1 ? gB : gA;
         if (vn < edge[0] || vn >= edge[B]) status |= ST_OUT_OF_GRID;
-        const int g_new = cc * B + bin_of_fast(edge, B, vn, st.log2_v0, st.inv_dlog2);
+        const int g_new = cc * B + bin_index(edge, B, vn, st);
         if (g_new != g_old && n_app >= st.max_appends) {
             status |= ST_APPEND_OVERFLOW; done = true; continue;
         }
@@ -734,6 +771,7 @@ __global__ __launch_bounds__(256) void k_coag_sample(DeviceState st, int ktype, 
         if (g_new != g_old) {
             list_remove(X, g_old, in, B, lead);
             wave_sync();
+            if (cc == c2 && X.L.cnt[g_new] == 0) X.L.ub[g_new - cc * B] = -1.0; // new slot: no draw yet
             list_append(X, g_new, pn, n_app, B);
             n_app++;
         }
@@ -849,34 +887,54 @@ __global__ __launch_bounds__(256) void k_coag_apply(DeviceState st)
     for (int w = lane; w < ((n_old + 63) >> 6); w += 64) dead[w] = 0;
     wave_sync();
 
-    // merge along the log, in order; lanes over species / sources / scalars
+    // Merge along the log.  Results must equal the in-order merge, so an event
+    // waits for the latest earlier event that touched either of its two slots;
+    // events with disjoint slots run side by side, one per lane, 64 per chunk.
     int n_dead = 0;
     const int S = st.n_spec, NS = st.n_source;
-    for (int e = 0; e < n_ev; e++) {
-        const int4 ev = evlog[e];
-        const int pn = ev.x, po = ev.y;
-        for (int s = lane; s < S; s += 64) {
-            double *a = &st.vol[cb * S + (int64_t)s * st.cap + pn];
-            const double b = st.vol[cb * S + (int64_t)s * st.cap + po];
-            *a = *a + b;
+    for (int e0 = 0; e0 < n_ev; e0 += 64) {
+        const int e = e0 + lane;
+        const bool mine = e < n_ev;
+        int4 ev = make_int4(-1, -2, 0, 0);
+        if (mine) ev = evlog[e];
+        int dA = -1, dB = -1; // chunk-local index of the latest earlier event on pn / po
+        const int n_here = min(64, n_ev - e0);
+        for (int k = 0; k < n_here; k++) {
+            const int pnk = __shfl(ev.x, k, 64), pok = __shfl(ev.y, k, 64);
+            if (k < lane) {
+                if (pnk == ev.x || pok == ev.x) dA = k;
+                if (pnk == ev.y || pok == ev.y) dB = k;
+            }
         }
-        for (int s = lane; s < NS; s += 64) {
-            int32_t *a = &st.n_orig[cb * NS + (int64_t)s * st.cap + pn];
-            *a = *a + st.n_orig[cb * NS + (int64_t)s * st.cap + po];
+        bool fin = !mine;
+        uint64_t donemask = __ballot(fin);
+        while (donemask != ~0ull) {
+            const bool ready = !fin && (dA < 0 || ((donemask >> dA) & 1ull)) &&
+                               (dB < 0 || ((donemask >> dB) & 1ull));
+            if (ready) {
+                const int pn = ev.x, po = ev.y;
+                for (int s = 0; s < S; s++) {
+                    double *a = &st.vol[cb * S + (int64_t)s * st.cap + pn];
+                    st_f64(a, ld_f64(a) + ld_f64(&st.vol[cb * S + (int64_t)s * st.cap + po]));
+                }
+                for (int s = 0; s < NS; s++) {
+                    uint32_t *a = (uint32_t *)&st.n_orig[cb * NS + (int64_t)s * st.cap + pn];
+                    st_u32(a, ld_u32(a) + ld_u32((uint32_t *)&st.n_orig[cb * NS + (int64_t)s * st.cap + po]));
+                }
+                const double lo = ld_f64(&st.lct[cb + po]), go = ld_f64(&st.gct[cb + po]);
+                if (lo < ld_f64(&st.lct[cb + pn])) st_f64(&st.lct[cb + pn], lo);
+                if (go > ld_f64(&st.gct[cb + pn])) st_f64(&st.gct[cb + pn], go);
+                st_u32((uint32_t *)&st.wclass[cb + pn], (uint32_t)ev.w);
+                if (ev.z) atomicOr((unsigned long long *)&dead[po >> 6], 1ull << (po & 63));
+                fin = true;
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            wave_sync();
+            donemask = __ballot(fin);
         }
-        if (lane == 0) {
-            const double lo = st.lct[cb + po], go = st.gct[cb + po];
-            if (lo < st.lct[cb + pn]) st.lct[cb + pn] = lo;
-            if (go > st.gct[cb + pn]) st.gct[cb + pn] = go;
-            st.wclass[cb + pn] = ev.w;
-        }
-        if (ev.z) {
-            dead[po >> 6] |= (1ull << (po & 63)); // uniform: same value from every lane
-            n_dead++;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wave_sync();
+        n_dead += __popcll(__ballot(mine && ev.z));
     }
+    wave_sync();
     // caches of surviving merged particles from the species
     for (int e = lane; e < n_ev; e += 64) {
         const int pn = evlog[e].x;
@@ -917,9 +975,12 @@ __global__ __launch_bounds__(64) void k_rebalance(DeviceState st, int allow_doub
     for (int cl = 0; cl < st.n_class; cl++) {
         for (uint32_t iter = 0; iter < 32; iter++) {
             const int n = st.n_part[c];
-            uint32_t cnt = 0;
-            for (int i = lane; i < n; i += 64) cnt += (st.wclass[cb + i] == cl);
-            const int ncl = (int)wave_sum_u64(cnt);
+            int ncl = n; // one class: every particle belongs to it
+            if (st.n_class > 1) {
+                uint32_t cnt = 0;
+                for (int i = lane; i < n; i += 64) cnt += (st.wclass[cb + i] == cl);
+                ncl = (int)wave_sum_u64(cnt);
+            }
             const double ideal = n_ideal[cl];
             if (allow_doubling && ncl > 0 && (double)ncl < ideal / 2.0) {
                 if (n + ncl > st.cap) { status |= ST_CAP_OVERFLOW; break; }
@@ -1161,7 +1222,7 @@ size_t sampler_lds_bytes_per_cell(const DeviceState &st)
 int sampler_lanes(const DeviceState &st)
 {
     const char *e = getenv("PMCX_SAMPLER_LANES");
-    if (e && (atoi(e) == 16 || atoi(e) == 64)) return atoi(e);
+    if (e && (atoi(e) == 8 || atoi(e) == 16 || atoi(e) == 64)) return atoi(e);
     return sampler_lds_bytes_per_cell(st) <= 6 * 1024 ? 16 : 64;
 }
 size_t diagnostics_lds_bytes(const DeviceState &st)
@@ -1258,20 +1319,29 @@ hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, ui
     const size_t shared = (sizeof(double) * (size_t)(st.n_bin + 1) + 15) & ~(size_t)15;
     const int L = sampler_lanes(st);
     const int gpw = 64 / L;
-    int wpb = 4; // wavefronts per workgroup, shrunk until the cells' LDS fits 64 KiB
+    // tuning knobs (defaults chosen from measurements)
+    const char *e_wpb = getenv("PMCX_SAMPLER_WPB"), *e_occ = getenv("PMCX_SAMPLER_OCC");
+    int wpb = e_wpb ? atoi(e_wpb) : 2; // wavefronts per workgroup
+    if (wpb != 1 && wpb != 2 && wpb != 4) wpb = 2;
     while (wpb > 1 && shared + per * wpb * gpw > 64 * 1024) wpb >>= 1;
+    const int occ = e_occ ? atoi(e_occ) : 3;
     const int cpb = wpb * gpw;
     const size_t lds = shared + per * cpb;
     const dim3 grid((st.n_cells + cpb - 1) / cpb), block(64 * wpb);
-    if (L == 16) {
-        allow_lds(k_coag_sample<16>, lds);
-        hipLaunchKernelGGL(k_coag_sample<16>, grid, block, lds, s, st, ktype, del_t, seed, step,
-                           (uint32_t)per);
+#define PMCX_LAUNCH_SAMPLER(LL, OO)                                                              \
+    do {                                                                                         \
+        allow_lds(k_coag_sample<LL, OO>, lds);                                                   \
+        hipLaunchKernelGGL((k_coag_sample<LL, OO>), grid, block, lds, s, st, ktype, del_t, seed, \
+                           step, (uint32_t)per);                                                 \
+    } while (0)
+    if (L == 8) {
+        if (occ >= 4) PMCX_LAUNCH_SAMPLER(8, 4); else if (occ == 3) PMCX_LAUNCH_SAMPLER(8, 3); else PMCX_LAUNCH_SAMPLER(8, 2);
+    } else if (L == 16) {
+        if (occ >= 4) PMCX_LAUNCH_SAMPLER(16, 4); else if (occ == 3) PMCX_LAUNCH_SAMPLER(16, 3); else PMCX_LAUNCH_SAMPLER(16, 2);
     } else {
-        allow_lds(k_coag_sample<64>, lds);
-        hipLaunchKernelGGL(k_coag_sample<64>, grid, block, lds, s, st, ktype, del_t, seed, step,
-                           (uint32_t)per);
+        if (occ >= 4) PMCX_LAUNCH_SAMPLER(64, 4); else if (occ == 3) PMCX_LAUNCH_SAMPLER(64, 3); else PMCX_LAUNCH_SAMPLER(64, 2);
     }
+#undef PMCX_LAUNCH_SAMPLER
     return hipGetLastError();
 }
 hipError_t launch_coag_apply(const DeviceState &st, hipStream_t s)
