@@ -1,0 +1,369 @@
+! pmcx_shim.F90 -- ISO_C_BINDING shim between the WRF-PartMC Fortran host and
+! libpmcx.so (include/pmcx.h).
+!
+! Keeps the call surface of the reference's per-cell loop body
+! (interface/wrf_pmc_driver.F90:169-254):
+!
+!   call mc_coag(COAG_KERNEL_TYPE_BROWN, env_states(i,k,j), aero_data, &
+!        aero_states(i,k,j), chemistry_call, n_samp, n_coag)      driver:192-194
+!
+! becomes, per cell (drop-in, same argument list)
+!
+!   call mc_coag_pmcx(COAG_KERNEL_TYPE_BROWN, env_states(i,k,j), aero_data, &
+!        aero_states(i,k,j), chemistry_call, n_samp, n_coag)
+!
+! or, batched over every owned cell in one call (the fast path: one upload,
+! one launch set, one download for the whole rank)
+!
+!   call partmc_coag_cells_pmcx(COAG_KERNEL_TYPE_BROWN, env_states, aero_data, &
+!        aero_states, chemistry_call, n_samp(:), n_coag(:))
+!
+! aero_state_t holds allocatable components and is not C-interoperable, so
+! the shim gathers the particle fields into flat arrays (the layout
+! pmcx_upload_cells documents) and scatters them back.  Errors follow the
+! reference's abort convention: a non-zero status stops the run (replace
+! pmcx_die by wrf_error_fatal when building inside WRF).
+!
+! `use pmc_mock` is the stand-in for `use pmc_aero_state; use pmc_env_state;
+! use pmc_aero_data` when built outside WRF.
+module pmcx_shim
+  use iso_c_binding
+  use pmc_mock
+  implicit none
+  private
+  public :: pmcx_shim_init, pmcx_shim_finalize, pmcx_set_rng, mc_coag_pmcx, &
+       partmc_coag_cells_pmcx, aero_state_rebalance_cells_pmcx, pmcx_config
+
+  type, bind(c) :: pmcx_config
+     integer(c_int32_t) :: struct_size, device, n_cells, cap, n_spec, n_class, n_source, n_bin
+     real(c_double) :: r_min, r_max
+     integer(c_int32_t) :: max_events, max_appends, n_dbin, i_water
+     real(c_double) :: d_min, d_max
+     integer(c_int32_t) :: cell_id_base, reserved
+     real(c_double) :: const_k, additive_beta
+  end type pmcx_config
+
+  interface
+     subroutine pmcx_config_default(cfg) bind(c, name="pmcx_config_default")
+       import :: pmcx_config
+       type(pmcx_config), intent(out) :: cfg
+     end subroutine pmcx_config_default
+     integer(c_int) function pmcx_create(cfg, ctx) bind(c, name="pmcx_create")
+       import :: pmcx_config, c_ptr, c_int
+       type(pmcx_config), intent(in) :: cfg
+       type(c_ptr), intent(out) :: ctx
+     end function pmcx_create
+     integer(c_int) function pmcx_destroy(ctx) bind(c, name="pmcx_destroy")
+       import :: c_ptr, c_int
+       type(c_ptr), value :: ctx
+     end function pmcx_destroy
+     function pmcx_last_error(ctx) bind(c, name="pmcx_last_error") result(msg)
+       import :: c_ptr
+       type(c_ptr), value :: ctx
+       type(c_ptr) :: msg
+     end function pmcx_last_error
+     integer(c_int) function pmcx_set_aero_data(ctx, density, kappa, molec_weight) &
+          bind(c, name="pmcx_set_aero_data")
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: density(*)
+       type(c_ptr), value :: kappa, molec_weight
+     end function pmcx_set_aero_data
+     integer(c_int) function pmcx_set_env(ctx, temp, pressure, rel_humid) bind(c, name="pmcx_set_env")
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: temp(*), pressure(*), rel_humid(*)
+     end function pmcx_set_env
+     integer(c_int) function pmcx_set_weights(ctx, magnitude) bind(c, name="pmcx_set_weights")
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: magnitude(*)
+     end function pmcx_set_weights
+     integer(c_int) function pmcx_get_weights(ctx, magnitude) bind(c, name="pmcx_get_weights")
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(out) :: magnitude(*)
+     end function pmcx_get_weights
+     integer(c_int) function pmcx_set_n_part_ideal(ctx, n_ideal) bind(c, name="pmcx_set_n_part_ideal")
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: n_ideal(*)
+     end function pmcx_set_n_part_ideal
+     integer(c_int) function pmcx_set_next_id(ctx, next_id) bind(c, name="pmcx_set_next_id")
+       import :: c_ptr, c_int, c_int64_t
+       type(c_ptr), value :: ctx
+       integer(c_int64_t), intent(in) :: next_id(*)
+     end function pmcx_set_next_id
+     integer(c_int) function pmcx_upload_cells(ctx, cell_first, n_up, part_offset, vol, wclass, &
+          id, least_ct, greatest_ct, n_orig) bind(c, name="pmcx_upload_cells")
+       import :: c_ptr, c_int, c_int32_t, c_int64_t, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: cell_first, n_up
+       integer(c_int64_t), intent(in) :: part_offset(*), id(*)
+       real(c_double), intent(in) :: vol(*), least_ct(*), greatest_ct(*)
+       integer(c_int32_t), intent(in) :: wclass(*)
+       type(c_ptr), value :: n_orig
+     end function pmcx_upload_cells
+     integer(c_int) function pmcx_get_n_part(ctx, n_part) bind(c, name="pmcx_get_n_part")
+       import :: c_ptr, c_int, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), intent(out) :: n_part(*)
+     end function pmcx_get_n_part
+     integer(c_int) function pmcx_download_cells(ctx, cell_first, n_dn, part_offset, vol, wclass, &
+          id, least_ct, greatest_ct, n_orig) bind(c, name="pmcx_download_cells")
+       import :: c_ptr, c_int, c_int32_t, c_int64_t, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: cell_first, n_dn
+       integer(c_int64_t), intent(in) :: part_offset(*)
+       integer(c_int64_t), intent(out) :: id(*)
+       real(c_double), intent(out) :: vol(*), least_ct(*), greatest_ct(*)
+       integer(c_int32_t), intent(out) :: wclass(*)
+       type(c_ptr), value :: n_orig
+     end function pmcx_download_cells
+     integer(c_int) function pmcx_mc_coag(ctx, kernel_type, del_t, seed, step) bind(c, name="pmcx_mc_coag")
+       import :: c_ptr, c_int, c_int32_t, c_int64_t, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: kernel_type
+       real(c_double), value :: del_t
+       integer(c_int64_t), value :: seed
+       integer(c_int32_t), value :: step
+     end function pmcx_mc_coag
+     integer(c_int) function pmcx_get_coag_counters(ctx, n_samp, n_coag, status) &
+          bind(c, name="pmcx_get_coag_counters")
+       import :: c_ptr, c_int, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), intent(out) :: n_samp(*), n_coag(*), status(*)
+     end function pmcx_get_coag_counters
+     integer(c_int) function pmcx_rebalance(ctx, allow_doubling, allow_halving, seed, step) &
+          bind(c, name="pmcx_rebalance")
+       import :: c_ptr, c_int, c_int32_t, c_int64_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: allow_doubling, allow_halving
+       integer(c_int64_t), value :: seed
+       integer(c_int32_t), value :: step
+     end function pmcx_rebalance
+  end interface
+
+  ! one context per (rank, cell count); rebuilt when the shape changes
+  type(c_ptr), save :: ctx = c_null_ptr
+  type(pmcx_config), save :: cfg
+  logical, save :: have_ctx = .false.
+  integer(c_int64_t), save :: rng_seed = 0     ! grid%random_seed (wrf_pmc_init.F90:131)
+  integer(c_int32_t), save :: rng_step = 0     ! chemistry-step index
+  integer(c_int32_t), save :: cell_id_base = 0 ! global id of this rank's first cell
+
+contains
+
+  subroutine pmcx_die(code, where)
+    integer(c_int), intent(in) :: code
+    character(len=*), intent(in) :: where
+    type(c_ptr) :: cmsg
+    character(kind=c_char), pointer :: s(:)
+    integer :: n
+    if (code == 0) return
+    cmsg = pmcx_last_error(ctx)
+    write(0,'(a,a,a,i0)') 'pmcx_shim: ', where, ' failed with status ', code
+    if (c_associated(cmsg)) then
+       call c_f_pointer(cmsg, s, [512])
+       n = 1
+       do while (n < 512 .and. s(n) /= c_null_char)
+          n = n + 1
+       end do
+       write(0,'(512a1)') s(1:n-1)
+    end if
+    error stop 1   ! inside WRF: call wrf_error_fatal(...)
+  end subroutine pmcx_die
+
+  !> Seed / step of the counter-based RNG and the global id of the first owned
+  !> cell (replaces pmc_srand(seed, rank), wrf_pmc_init.F90:131).
+  subroutine pmcx_set_rng(seed, step, first_cell_id)
+    integer(kind=8), intent(in) :: seed
+    integer, intent(in) :: step
+    integer, intent(in), optional :: first_cell_id
+    rng_seed = seed
+    rng_step = step
+    if (present(first_cell_id)) cell_id_base = first_cell_id
+  end subroutine pmcx_set_rng
+
+  subroutine pmcx_shim_init(n_cells, cap, aero_data, n_class, n_source, device)
+    integer, intent(in) :: n_cells, cap, n_class, n_source, device
+    type(aero_data_t), intent(in) :: aero_data
+    if (have_ctx) call pmcx_shim_finalize()
+    call pmcx_config_default(cfg)
+    cfg%device = device
+    cfg%n_cells = n_cells
+    cfg%cap = cap
+    cfg%n_spec = size(aero_data%density)
+    cfg%n_class = n_class
+    cfg%n_source = n_source
+    cfg%i_water = aero_data%i_water - 1
+    cfg%cell_id_base = cell_id_base
+    call pmcx_die(pmcx_create(cfg, ctx), 'pmcx_create')
+    have_ctx = .true.
+    call pmcx_die(pmcx_set_aero_data(ctx, aero_data%density, c_null_ptr, c_null_ptr), &
+         'pmcx_set_aero_data')
+  end subroutine pmcx_shim_init
+
+  subroutine pmcx_shim_finalize()
+    integer(c_int) :: rc
+    if (have_ctx) rc = pmcx_destroy(ctx)
+    have_ctx = .false.
+    ctx = c_null_ptr
+  end subroutine pmcx_shim_finalize
+
+  !> mc_coag on a flat array of cells: gather, upload, step, download, scatter.
+  subroutine partmc_coag_cells_pmcx(coag_kernel_type, env_states, aero_data, aero_states, &
+       del_t, tot_n_samp, tot_n_coag)
+    integer, intent(in) :: coag_kernel_type
+    type(env_state_t), intent(in) :: env_states(:)
+    type(aero_data_t), intent(in) :: aero_data
+    type(aero_state_t), intent(inout) :: aero_states(:)
+    real(kind=dp), intent(in) :: del_t
+    integer, intent(out) :: tot_n_samp(:), tot_n_coag(:)
+
+    integer :: n_cells, n_spec, n_class, n_source, c, i, s, cap_needed
+    integer(c_int64_t) :: nt, o
+    integer(c_int64_t), allocatable :: part_offset(:), id(:)
+    real(c_double), allocatable :: vol(:,:), lct(:), gct(:), temp(:), pres(:), rh(:), mag(:,:)
+    integer(c_int32_t), allocatable, target :: n_orig(:,:)
+    integer(c_int32_t), allocatable :: wclass(:), n_part(:), ns(:), nc(:), st(:)
+    type(c_ptr) :: p_norig
+
+    n_cells = size(aero_states)
+    n_spec = size(aero_data%density)
+    n_class = size(aero_states(1)%awa%weight, 2)
+    n_source = 0
+    if (aero_states(1)%apa%n_part > 0) then
+       if (allocated(aero_states(1)%apa%particle(1)%n_orig_part)) &
+            n_source = size(aero_states(1)%apa%particle(1)%n_orig_part)
+    end if
+    cap_needed = 64
+    do c = 1, n_cells
+       cap_needed = max(cap_needed, aero_states(c)%apa%n_part)
+    end do
+    cap_needed = ((cap_needed + 63) / 64) * 64
+    if (.not. have_ctx .or. cfg%n_cells /= n_cells .or. cfg%cap < cap_needed &
+         .or. cfg%n_spec /= n_spec .or. cfg%n_class /= n_class .or. cfg%n_source /= n_source) then
+       call pmcx_shim_init(n_cells, cap_needed, aero_data, n_class, n_source, 0)
+    end if
+
+    ! ---- gather aero_state_t -> flat arrays (pmcx_upload_cells layout) ----
+    allocate(part_offset(n_cells + 1))
+    part_offset(1) = 0
+    do c = 1, n_cells
+       part_offset(c + 1) = part_offset(c) + aero_states(c)%apa%n_part
+    end do
+    nt = part_offset(n_cells + 1)
+    allocate(vol(max(nt, 1_c_int64_t), n_spec), wclass(max(nt, 1_c_int64_t)), &
+         id(max(nt, 1_c_int64_t)), lct(max(nt, 1_c_int64_t)), gct(max(nt, 1_c_int64_t)))
+    allocate(n_orig(max(nt, 1_c_int64_t), max(n_source, 1)))
+    allocate(temp(n_cells), pres(n_cells), rh(n_cells), mag(n_class, n_cells))
+    do c = 1, n_cells
+       o = part_offset(c)
+       do i = 1, aero_states(c)%apa%n_part
+          do s = 1, n_spec
+             vol(o + i, s) = aero_states(c)%apa%particle(i)%vol(s)
+          end do
+          do s = 1, n_source
+             n_orig(o + i, s) = aero_states(c)%apa%particle(i)%n_orig_part(s)
+          end do
+          wclass(o + i) = aero_states(c)%apa%particle(i)%weight_class - 1
+          id(o + i) = aero_states(c)%apa%particle(i)%id
+          lct(o + i) = aero_states(c)%apa%particle(i)%least_create_time
+          gct(o + i) = aero_states(c)%apa%particle(i)%greatest_create_time
+       end do
+       temp(c) = env_states(c)%temp
+       pres(c) = env_states(c)%pressure
+       rh(c) = env_states(c)%rel_humid
+       do s = 1, n_class
+          mag(s, c) = aero_states(c)%awa%weight(1, s)%magnitude
+       end do
+    end do
+    p_norig = c_null_ptr
+    if (n_source > 0) p_norig = c_loc(n_orig)
+
+    call pmcx_die(pmcx_set_env(ctx, temp, pres, rh), 'pmcx_set_env')
+    call pmcx_die(pmcx_set_weights(ctx, mag), 'pmcx_set_weights')
+    call pmcx_die(pmcx_upload_cells(ctx, 0, n_cells, part_offset, vol, wclass, id, lct, gct, &
+         p_norig), 'pmcx_upload_cells')
+
+    ! ---- the step ----
+    call pmcx_die(pmcx_mc_coag(ctx, coag_kernel_type, del_t, rng_seed, rng_step), 'pmcx_mc_coag')
+    allocate(ns(n_cells), nc(n_cells), st(n_cells), n_part(n_cells))
+    call pmcx_die(pmcx_get_coag_counters(ctx, ns, nc, st), 'pmcx_get_coag_counters')
+    if (any(iand(st, 3) /= 0)) call pmcx_die(5, 'mc_coag (event/append log overflow)')
+    tot_n_samp = ns
+    tot_n_coag = nc
+
+    ! ---- download and scatter back into aero_state_t ----
+    call pmcx_die(pmcx_get_n_part(ctx, n_part), 'pmcx_get_n_part')
+    do c = 1, n_cells
+       part_offset(c + 1) = part_offset(c) + n_part(c)
+    end do
+    nt = part_offset(n_cells + 1)
+    ! packed arrays are [n_spec][n_total]: the leading dimension must be the new total
+    deallocate(vol, wclass, id, lct, gct, n_orig)
+    allocate(vol(max(nt, 1_c_int64_t), n_spec), wclass(max(nt, 1_c_int64_t)), &
+         id(max(nt, 1_c_int64_t)), lct(max(nt, 1_c_int64_t)), gct(max(nt, 1_c_int64_t)))
+    allocate(n_orig(max(nt, 1_c_int64_t), max(n_source, 1)))
+    if (n_source > 0) p_norig = c_loc(n_orig)
+    call pmcx_die(pmcx_download_cells(ctx, 0, n_cells, part_offset, vol, wclass, id, lct, gct, &
+         p_norig), 'pmcx_download_cells')
+    do c = 1, n_cells
+       o = part_offset(c)
+       aero_states(c)%apa%n_part = n_part(c)
+       do i = 1, n_part(c)
+          do s = 1, n_spec
+             aero_states(c)%apa%particle(i)%vol(s) = vol(o + i, s)
+          end do
+          do s = 1, n_source
+             aero_states(c)%apa%particle(i)%n_orig_part(s) = n_orig(o + i, s)
+          end do
+          aero_states(c)%apa%particle(i)%weight_class = wclass(o + i) + 1
+          aero_states(c)%apa%particle(i)%id = id(o + i)
+          aero_states(c)%apa%particle(i)%least_create_time = lct(o + i)
+          aero_states(c)%apa%particle(i)%greatest_create_time = gct(o + i)
+       end do
+       aero_states(c)%valid_sort = .false.
+    end do
+  end subroutine partmc_coag_cells_pmcx
+
+  !> Drop-in for mc_coag (same argument list, one cell).
+  subroutine mc_coag_pmcx(coag_kernel_type, env_state, aero_data, aero_state, del_t, &
+       tot_n_samp, tot_n_coag)
+    integer, intent(in) :: coag_kernel_type
+    type(env_state_t), intent(in) :: env_state
+    type(aero_data_t), intent(in) :: aero_data
+    type(aero_state_t), intent(inout) :: aero_state
+    real(kind=dp), intent(in) :: del_t
+    integer, intent(out) :: tot_n_samp, tot_n_coag
+    type(env_state_t) :: envs(1)
+    type(aero_state_t) :: states(1)
+    integer :: ns(1), nc(1)
+    envs(1) = env_state
+    call move_alloc_state(aero_state, states(1))
+    call partmc_coag_cells_pmcx(coag_kernel_type, envs, aero_data, states, del_t, ns, nc)
+    call move_alloc_state(states(1), aero_state)
+    tot_n_samp = ns(1)
+    tot_n_coag = nc(1)
+  end subroutine mc_coag_pmcx
+
+  subroutine move_alloc_state(from, to)
+    type(aero_state_t), intent(inout) :: from, to
+    to%apa%n_part = from%apa%n_part
+    call move_alloc(from%apa%particle, to%apa%particle)
+    call move_alloc(from%awa%weight, to%awa%weight)
+    if (allocated(from%n_part_ideal)) call move_alloc(from%n_part_ideal, to%n_part_ideal)
+    to%valid_sort = from%valid_sort
+  end subroutine move_alloc_state
+
+  !> aero_state_rebalance on the cells last uploaded (state stays on the device).
+  subroutine aero_state_rebalance_cells_pmcx(allow_doubling, allow_halving)
+    logical, intent(in) :: allow_doubling, allow_halving
+    integer(c_int32_t) :: d, h
+    d = merge(1, 0, allow_doubling)
+    h = merge(1, 0, allow_halving)
+    call pmcx_die(pmcx_rebalance(ctx, d, h, rng_seed, rng_step), 'pmcx_rebalance')
+  end subroutine aero_state_rebalance_cells_pmcx
+
+end module pmcx_shim
