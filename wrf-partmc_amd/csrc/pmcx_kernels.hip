@@ -361,29 +361,27 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st)
 
 struct CellLds {
     EnvDerived *env;    // per-cell air properties (kept out of registers)
-    double *ub;         // [n_bin] cached Poisson uniform of slot (row, partner bin); <0 = none
     uint64_t *mask;     // [n_class][2] non-empty bins bitmask
-    uint32_t *P;        // [n_bin] inclusive prefix of remaining samples (active slots)
-    uint32_t *ns;       // [n_bin] Poisson counts of the active slots of the row
+    uint32_t *P;        // [WN] inclusive prefix of remaining samples of the window's slots
+    uint32_t *ns;       // [WN] Poisson counts of the window's slots
     uint16_t *cnt;      // [G] current list length
     uint16_t *nb;       // [G] entries still in the sorted base segment
     uint16_t *off;      // [G] base segment offset in perm
     uint16_t *last_app; // [G] newest appended entry of the group (0xFFFF none)
     uint16_t *app_slot; // [max_appends]
     uint16_t *app_prev; // [max_appends]
-    uint8_t *act;       // [n_bin] partner bins of the row's active slots
+    uint8_t *act;       // [WN] partner bins of the window's slots
 };
 
-__host__ __device__ inline size_t sampler_lds_bytes(int G, int B, int C, int max_appends)
+__host__ __device__ inline size_t sampler_lds_bytes(int G, int C, int max_appends, int wn)
 {
     size_t o = 0;
     o += sizeof(EnvDerived);                // env
-    o += sizeof(double) * (size_t)B;        // ub
     o += sizeof(uint64_t) * 2 * (size_t)C;  // mask
-    o += sizeof(uint32_t) * 2 * (size_t)B;  // P, ns
+    o += sizeof(uint32_t) * 2 * (size_t)wn; // P, ns
     o += sizeof(uint16_t) * 4 * (size_t)G;  // cnt nb off last_app
     o += sizeof(uint16_t) * 2 * (size_t)max_appends;
-    o += (size_t)B;                         // act
+    o += (size_t)wn;                        // act
     return (o + 15) & ~(size_t)15;
 }
 
@@ -512,11 +510,11 @@ __global__ __launch_bounds__(256, OCC) void k_coag_sample(DeviceState st, int kt
         unsigned char *base = smem + (((size_t)(B + 1) * sizeof(double) + 15) & ~(size_t)15) +
                               (size_t)lds_per_cell * (size_t)(wave * GPW + sub);
         size_t o = 0;
+        constexpr int WNL = (L == 64) ? 64 : 16;
         X.L.env = (EnvDerived *)(base + o); o += sizeof(EnvDerived);
-        X.L.ub = (double *)(base + o); o += sizeof(double) * (size_t)B;
         X.L.mask = (uint64_t *)(base + o); o += sizeof(uint64_t) * 2 * (size_t)C;
-        X.L.P = (uint32_t *)(base + o); o += sizeof(uint32_t) * (size_t)B;
-        X.L.ns = (uint32_t *)(base + o); o += sizeof(uint32_t) * (size_t)B;
+        X.L.P = (uint32_t *)(base + o); o += sizeof(uint32_t) * (size_t)WNL;
+        X.L.ns = (uint32_t *)(base + o); o += sizeof(uint32_t) * (size_t)WNL;
         X.L.cnt = (uint16_t *)(base + o); o += sizeof(uint16_t) * (size_t)G;
         X.L.nb = (uint16_t *)(base + o); o += sizeof(uint16_t) * (size_t)G;
         X.L.off = (uint16_t *)(base + o); o += sizeof(uint16_t) * (size_t)G;
@@ -560,29 +558,19 @@ __global__ __launch_bounds__(256, OCC) void k_coag_sample(DeviceState st, int kt
     int n_ev = 0, n_app = 0, tot_coag = 0, status = 0;
     uint64_t tot_samp = 0;
 
-    // row state (uniform inside the group)
+    // Row state (uniform inside the group).  The partner slots of a row are
+    // visited through a window of up to WN non-empty partner bins: counts are
+    // drawn for the window only, and the window is rebuilt from the slot of an
+    // event (whose own count and progress are kept) or moved on when exhausted.
+    constexpr int WN = (L == 64) ? 64 : 16;
     int c1 = 0, c2 = 0, b1 = -1;
-    int gA = 0, cc = 0, na = 0, cur = 0, counted = 0, ns_from = 0;
-    uint32_t cur_s0 = 0;
+    int gA = 0, cc = 0, wn = 0, counted = 0, wfrom = 0;
+    uint32_t cur_s0 = 0, ns0 = 0;
     double n1 = 0, n2 = 0, nmin = 0, fmax = 0, factor = 0;
-    uint32_t T = 0, q0 = 0; // a row holds < 2^31 samples (NSAMP_MAX per slot, <= 128 slots)
-    bool need_row = true, need_ns = false, need_prefix = false, fresh = false;
+    uint32_t T = 0, q0 = 0; // a window holds < 2^31 samples (NSAMP_MAX per slot)
+    bool need_row = true, need_win = false, keep_first = false;
     bool done = !live;
 
-    // append the non-empty partner bins >= from_bin of class c2 at act[at...]
-    auto build_act = [&](int from_bin, int at) {
-        int n = at;
-        for (int b0 = (from_bin / L) * L; b0 < B; b0 += L) {
-            const int b = b0 + gl;
-            const bool bit = b < B && b >= from_bin &&
-                             ((X.L.mask[c2 * 2 + (b >> 6)] >> (b & 63)) & 1ull);
-            const uint64_t m = Grp<L>::ballot(bit, sub);
-            if (bit) X.L.act[n + __popcll(m & lt)] = (uint8_t)b;
-            n += __popcll(m);
-        }
-        wave_sync();
-        return n;
-    };
     auto sum_ns = [&](int from, int to) { // sum of ns[from..to)
         uint32_t s = 0;
         for (int j = from + gl; j < to; j += L) s += X.L.ns[j];
@@ -606,91 +594,100 @@ __global__ __launch_bounds__(256, OCC) void k_coag_sample(DeviceState st, int kt
                 fmax = (n1 < n2) ? n2 : n1;
                 factor = n1 * n2 / nmin;
                 gA = c1 * B + b1;
-                na = build_act((c1 == c2) ? b1 : 0, 0);
-                cur = 0; cur_s0 = 0; counted = 0;
-                ns_from = 0; need_ns = true; need_row = false; fresh = true;
+                wfrom = (c1 == c2) ? b1 : 0;
+                keep_first = false; cur_s0 = 0; counted = 0;
+                need_win = true; need_row = false;
             }
         }
         if (__ballot(!done) == 0) break;
         if (done) continue;
 
-        // ---- Poisson counts of the active slots j >= ns_from ----
-        if (need_ns) {
-            const int nA = X.L.cnt[gA];
-            for (int j = ns_from + gl; j < na; j += L) {
-                const int b2 = X.L.act[j];
-                const int gB = c2 * B + b2;
-                const int nB = X.L.cnt[gB];
-                const bool same = (gA == gB);
-                uint32_t ns = 0;
-                if (nA > 0 && nB > 0 && !(same && nA < 2)) {
-                    const double k_max = kmax[b1 * B + b2] * fmax;
-                    const double n_possible = same ? (double)nA * ((double)nA - 1.0) / 2.0
-                                                   : (double)nA * (double)nB;
-                    const double mean = k_max * del_t * n_possible;
-                    // the slot's uniform is fixed for the row: draw it once, reuse on redraws
-                    double u = X.L.ub[b2];
-                    if (fresh || u < 0.0) {
-                        uint32_t w[4];
-                        rng_block(seed, cell_id, step, ((uint32_t)gA << 16) | (uint32_t)gB,
-                                  SITE_POISSON, 0, w);
-                        u = u53(w[0], w[1]);
-                        X.L.ub[b2] = u;
-                    }
-                    ns = (uint32_t)poisson(mean, u);
-                } else if (fresh) {
-                    X.L.ub[b2] = -1.0;
-                }
-                X.L.ns[j] = ns;
+        // ---- (re)build the window: bins, Poisson counts, prefix ----
+        if (need_win) {
+            // slot 0 is the slot of the last event when keep_first (its bin is wfrom - 1)
+            int n = 0;
+            if (keep_first) { X.L.act[0] = (uint8_t)(wfrom - 1); n = 1; }
+            for (int b0 = (wfrom / L) * L; b0 < B && n < WN; b0 += L) {
+                const int b = b0 + gl;
+                const bool bit = b < B && b >= wfrom &&
+                                 ((X.L.mask[c2 * 2 + (b >> 6)] >> (b & 63)) & 1ull);
+                const uint64_t m = Grp<L>::ballot(bit, sub);
+                const int pos = n + __popcll(m & lt);
+                if (bit && pos < WN) X.L.act[pos] = (uint8_t)b;
+                n += __popcll(m);
             }
+            wn = n < WN ? n : WN;
             wave_sync();
-            need_ns = false;
-            fresh = false;
-            need_prefix = true;
-        }
+            if (wn == 0) { need_row = true; need_win = false; continue; }
 
-        // ---- inclusive prefix of the remaining samples over slots j >= cur ----
-        if (need_prefix) {
+            const int nA = X.L.cnt[gA];
             uint32_t carry = 0;
-            for (int j0 = cur; j0 < na; j0 += L) {
+            for (int j0 = 0; j0 < wn; j0 += L) {
                 const int j = j0 + gl;
-                uint32_t r = 0;
-                if (j < na) r = X.L.ns[j] - (j == cur ? cur_s0 : 0u);
+                uint32_t ns = 0, r = 0;
+                if (j < wn) {
+                    if (keep_first && j == 0) {
+                        ns = ns0;
+                        r = ns0 - cur_s0;
+                    } else {
+                        const int b2 = X.L.act[j];
+                        const int gB = c2 * B + b2;
+                        const int nB = X.L.cnt[gB];
+                        const bool same = (gA == gB);
+                        if (nA > 0 && nB > 0 && !(same && nA < 2)) {
+                            const double k_max = kmax[b1 * B + b2] * fmax;
+                            const double n_possible =
+                                same ? (double)nA * ((double)nA - 1.0) / 2.0
+                                     : (double)nA * (double)nB;
+                            const double mean = k_max * del_t * n_possible;
+                            uint32_t w[4];
+                            rng_block(seed, cell_id, step, ((uint32_t)gA << 16) | (uint32_t)gB,
+                                      SITE_POISSON, 0, w);
+                            ns = (uint32_t)poisson(mean, u53(w[0], w[1]));
+                        }
+                        r = ns;
+                    }
+                    X.L.ns[j] = ns;
+                }
                 const uint32_t inc = Grp<L>::incl_scan(r, gl) + carry;
-                if (j < na) X.L.P[j] = inc;
+                if (j < wn) X.L.P[j] = inc;
                 carry = __shfl(inc, L - 1, L);
             }
             wave_sync();
             T = carry;
             q0 = 0;
-            need_prefix = false;
+            counted = keep_first ? 1 : 0;
+            need_win = false;
         }
 
-        // ---- row exhausted ----
+        // ---- window exhausted: its slots have all started; move on ----
         if (q0 >= T) {
-            tot_samp += sum_ns(counted, na);
-            need_row = true;
+            tot_samp += sum_ns(counted, wn);
+            wfrom = (int)X.L.act[wn - 1] + 1;
+            keep_first = false; cur_s0 = 0;
+            // a window that was not filled held every remaining bin of the row
+            if (wfrom >= B || wn < WN) need_row = true; else need_win = true;
             continue;
         }
 
         // ---- evaluate up to L candidates against the current lists ----
         const uint32_t q = q0 + (uint32_t)gl;
         const bool act = q < T;
-        int j = cur;
+        int j = 0;
         uint32_t s = 0;
         int i1 = 0, i2 = 0;
         uint32_t p1 = 0, p2 = 0;
         double v1 = 0, v2 = 0, m1 = 0, m2 = 0;
         bool acc = false, over = false;
         if (act) {
-            int lo = cur, hi = na - 1; // smallest j with P[j] > q
+            int lo = 0, hi = wn - 1; // smallest j with P[j] > q
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
                 if (X.L.P[mid] > q) hi = mid; else lo = mid + 1;
             }
             j = lo;
             const int b2 = X.L.act[j];
-            const uint32_t first = (j == cur) ? cur_s0 : 0u;
+            const uint32_t first = (keep_first && j == 0) ? cur_s0 : 0u;
             const uint32_t rem = X.L.ns[j] - first;
             s = (q - (X.L.P[j] - rem)) + first;
             const int gB = c2 * B + b2;
@@ -731,12 +728,12 @@ __global__ __launch_bounds__(256, OCC) void k_coag_sample(DeviceState st, int kt
         const double v1f = __shfl(v1, f, L), v2f = __shfl(v2, f, L);
         const double m1f = __shfl(m1, f, L), m2f = __shfl(m2, f, L);
         const int b2f = X.L.act[jf];
+        const uint32_t nsf = X.L.ns[jf];
         const int gB = c2 * B + b2f;
         const bool same = (gA == gB);
 
         // slots up to and including this one have started
         tot_samp += sum_ns(counted, jf + 1);
-        counted = jf + 1;
 
         if (n_ev >= st.max_events) { status |= ST_EVENT_OVERFLOW; done = true; continue; }
         // weighted removal [coagulate_weighting]: with equal weights both quotients are
@@ -771,7 +768,6 @@ __global__ __launch_bounds__(256, OCC) void k_coag_sample(DeviceState st, int kt
         if (g_new != g_old) {
             list_remove(X, g_old, in, B, lead);
             wave_sync();
-            if (cc == c2 && X.L.cnt[g_new] == 0) X.L.ub[g_new - cc * B] = -1.0; // new slot: no draw yet
             list_append(X, g_new, pn, n_app, B);
             n_app++;
         }
@@ -780,16 +776,17 @@ __global__ __launch_bounds__(256, OCC) void k_coag_sample(DeviceState st, int kt
         wave_sync();
         tot_coag++;
 
-        // continue the row after this sample: later slots are rebuilt and redrawn
-        cur = jf;
+        // continue the row after this sample: the window restarts at this slot,
+        // later slots are redrawn from the new counts
+        ns0 = nsf;
         cur_s0 = sf + 1;
         {
             const int nA = X.L.cnt[gA], nB = X.L.cnt[gB];
-            if (nA < 1 || nB < 1 || (same && nA < 2)) cur_s0 = X.L.ns[cur]; // exit this slot
+            if (nA < 1 || nB < 1 || (same && nA < 2)) cur_s0 = ns0; // exit this slot
         }
-        na = build_act(b2f + 1, cur + 1);
-        ns_from = cur + 1;
-        need_ns = true;
+        wfrom = b2f + 1;
+        keep_first = true;
+        need_win = true;
     }
 
     if (live && lead) {
@@ -1213,17 +1210,22 @@ size_t bin_sort_lds_bytes(const DeviceState &st)
                      sizeof(uint16_t) * (size_t)st.cap;
     return (o + 15) & ~(size_t)15;
 }
+static size_t sampler_lds_for(const DeviceState &st, int lanes)
+{
+    return sampler_lds_bytes(st.n_bin * st.n_class, st.n_class, st.max_appends,
+                             lanes == 64 ? 64 : 16);
+}
 size_t sampler_lds_bytes_per_cell(const DeviceState &st)
 {
-    return sampler_lds_bytes(st.n_bin * st.n_class, st.n_bin, st.n_class, st.max_appends);
+    return sampler_lds_for(st, 64); // upper bound over the lane variants
 }
 // lanes per cell of the sampler: 16 (four cells per wavefront) while a cell's
 // list state is small, 64 otherwise.  PMCX_SAMPLER_LANES overrides (tuning).
 int sampler_lanes(const DeviceState &st)
 {
     const char *e = getenv("PMCX_SAMPLER_LANES");
-    if (e && (atoi(e) == 8 || atoi(e) == 16 || atoi(e) == 64)) return atoi(e);
-    return sampler_lds_bytes_per_cell(st) <= 6 * 1024 ? 16 : 64;
+    if (e && (atoi(e) == 4 || atoi(e) == 8 || atoi(e) == 16 || atoi(e) == 64)) return atoi(e);
+    return sampler_lds_for(st, 16) <= 4 * 1024 ? 8 : 64;
 }
 size_t diagnostics_lds_bytes(const DeviceState &st)
 {
@@ -1315,9 +1317,9 @@ hipError_t launch_bin_sort(const DeviceState &st, hipStream_t s)
 hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, uint64_t seed,
                               uint32_t step, hipStream_t s)
 {
-    const size_t per = sampler_lds_bytes_per_cell(st);
     const size_t shared = (sizeof(double) * (size_t)(st.n_bin + 1) + 15) & ~(size_t)15;
     const int L = sampler_lanes(st);
+    const size_t per = sampler_lds_for(st, L);
     const int gpw = 64 / L;
     // tuning knobs (defaults chosen from measurements)
     const char *e_wpb = getenv("PMCX_SAMPLER_WPB"), *e_occ = getenv("PMCX_SAMPLER_OCC");
@@ -1334,7 +1336,9 @@ hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, ui
         hipLaunchKernelGGL((k_coag_sample<LL, OO>), grid, block, lds, s, st, ktype, del_t, seed, \
                            step, (uint32_t)per);                                                 \
     } while (0)
-    if (L == 8) {
+    if (L == 4) {
+        if (occ >= 4) PMCX_LAUNCH_SAMPLER(4, 4); else if (occ == 3) PMCX_LAUNCH_SAMPLER(4, 3); else PMCX_LAUNCH_SAMPLER(4, 2);
+    } else if (L == 8) {
         if (occ >= 4) PMCX_LAUNCH_SAMPLER(8, 4); else if (occ == 3) PMCX_LAUNCH_SAMPLER(8, 3); else PMCX_LAUNCH_SAMPLER(8, 2);
     } else if (L == 16) {
         if (occ >= 4) PMCX_LAUNCH_SAMPLER(16, 4); else if (occ == 3) PMCX_LAUNCH_SAMPLER(16, 3); else PMCX_LAUNCH_SAMPLER(16, 2);
