@@ -30,7 +30,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
-KERNELS = ("bin_sort", "coag_sample", "coag_apply", "rebalance")
+KERNELS = ("bin_sort", "coag_sample", "compact", "rebalance")
 
 
 def partition_columns(n_cols, world, rank):
@@ -55,12 +55,13 @@ def algorithmic_bytes(name, n_spec, n_class, n_source, particles, candidates, ev
     if name == "bin_sort":
         return particles * (8 + 4 + (4 if n_class > 1 else 0))
     if name == "coag_sample":
-        return candidates * 32 + events * (2 * 16 + 16 + 16)  # caches read x2, written, log entry
-    if name == "coag_apply":
-        per_ev = 3 * 8 * n_spec + 3 * 4 * n_source + 3 * meta + 16
-        return events * per_ev
+        # per candidate: 2 x (vtot + mass); per event: species 2R+1W, sources, metadata, caches
+        per_ev = 3 * 8 * n_spec + 3 * 4 * n_source + 3 * meta + 2 * 16
+        return candidates * 32 + events * per_ev
+    if name == "compact":
+        return 0  # only cells past the tombstone threshold move data
     if name == "rebalance":
-        return particles * 4
+        return particles * 4 if n_class > 1 else 0
     return 0
 
 

@@ -235,7 +235,7 @@ int pmcx_test_philox(pmcx_ctx *ctx, const uint32_t ctr[4], const uint32_t key[2]
                      uint32_t out[4]);
 
 /* Per-kernel device timing with HIP events on the context's stream.
- * names: "bin_sort", "coag_sample", "coag_apply", "rebalance", "diagnostics",
+ * names: "bin_sort", "coag_sample", "compact", "rebalance", "diagnostics",
  * "kernel_bounds", "generate".  Returns the accumulated milliseconds and
  * launch count since the last reset for one name. */
 int pmcx_profile_enable(pmcx_ctx *ctx, int32_t on);

@@ -289,7 +289,7 @@ static void il_push(ilist *l, int32_t x)
 
 typedef struct { int32_t pn, po, rem_o, cc; } coag_event;
 
-static void compact_tail_fill(pmco_cell *c, const unsigned char *dead, int n_old,
+static void compact_stable(pmco_cell *c, const unsigned char *dead, int n_old,
                               int n_dead);
 
 int pmco_mc_coag(pmco_cell *c, int kernel_type, const pmco_kernel_params *kp,
@@ -421,9 +421,10 @@ int pmco_mc_coag(pmco_cell *c, int kernel_type, const pmco_kernel_params *kp,
         c->wclass[pn] = ev[e].cc;
         if (ev[e].rem_o) { dead[po] = 1; n_dead++; }
     }
-    for (int e = 0; e < n_ev; e++)
-        if (!dead[ev[e].pn]) refresh_one(c, ev[e].pn);
-    compact_tail_fill(c, dead, n0, n_dead);
+    /* vtot/mass of merged particles stay the sums of their parents' caches
+     * (set at event time); they are recomputed from the species only by
+     * pmco_refresh_caches (upload, condensation). */
+    compact_stable(c, dead, n0, n_dead);
 
     for (int g = 0; g < G; g++) free(L[g].e);
     free(L); free(ev); free(dead);
@@ -446,22 +447,22 @@ static void move_particle(pmco_cell *c, int dst, int src)
     c->gct[dst] = c->gct[src];
 }
 
-/* Close the holes left by removed particles: the k-th dead slot below the
- * new count (ascending) receives the k-th live slot at or above it
- * (ascending).  [aero_particle_array removal moves the last particle into
- * the hole one at a time; this is the batched equivalent.] */
-static void compact_tail_fill(pmco_cell *c, const unsigned char *dead, int n_old,
+/* Close the holes left by removed particles, keeping the survivors' relative
+ * order (stable).  [aero_particle_array removal moves the last particle into
+ * the hole; the order of particles carries no physical meaning.  A stable
+ * order is specified here so that WHEN holes are closed cannot change any
+ * later result: the GPU side leaves tombstones and compacts lazily.] */
+static void compact_stable(pmco_cell *c, const unsigned char *dead, int n_old,
                               int n_dead)
 {
-    const int n_new = n_old - n_dead;
-    int src = n_new;
-    for (int h = 0; h < n_new; h++) {
-        if (!dead[h]) continue;
-        while (dead[src]) src++;
-        move_particle(c, h, src);
-        src++;
+    int dst = 0;
+    for (int i = 0; i < n_old; i++) {
+        if (dead[i]) continue;
+        if (dst != i) move_particle(c, dst, i);
+        dst++;
     }
-    *c->n_part = n_new;
+    (void)n_dead;
+    *c->n_part = dst;
 }
 
 /* ------------------------------------------------------------------------
@@ -499,7 +500,7 @@ int pmco_rebalance(pmco_cell *c, const double *n_ideal, int allow_doubling,
                                    (uint32_t)cl * 32u + iter, w);
                     if (pmco_u53(w[0], w[1]) < 0.5) { dead[i] = 1; n_dead++; }
                 }
-                compact_tail_fill(c, dead, n, n_dead);
+                compact_stable(c, dead, n, n_dead);
                 free(dead);
                 c->mag[cl] = c->mag[cl] * 2.0;
             } else {

@@ -282,7 +282,7 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
     A_(st.mag, nc * cfg->n_class);
     A_(ctx->d_n_ideal, nc * cfg->n_class);
     A_(st.kmax, nc * B * B);
-    A_(st.n_part, nc); A_(st.next_id, nc);
+    A_(st.n_part, nc); A_(st.n_hi, nc); A_(st.next_id, nc);
     A_(st.vol, nc * cfg->n_spec * cap);
     A_(st.vtot, nc * cap); A_(st.mass, nc * cap);
     A_(st.wclass, nc * cap); A_(st.id, nc * cap);
@@ -290,7 +290,6 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
     A_(st.n_orig, nc * (size_t)cfg->n_source * cap);
     A_(st.perm, nc * cap);
     A_(st.gcnt, nc * G); A_(st.goff, nc * G);
-    A_(st.events, nc * (size_t)cfg->max_events);
     A_(st.n_events, nc); A_(st.n_samp, nc); A_(st.n_coag, nc); A_(st.status, nc);
     A_(ctx->d_totals, (size_t)4);
     A_(ctx->d_diag, nc * (size_t)(2 + 2 * nd));
@@ -523,7 +522,7 @@ int pmcx_upload_cells(pmcx_ctx *ctx, int32_t cell_first, int32_t n_up, const int
                                             cf.n_source, (int64_t)cap, ctx->stream));
         }
     }
-    HIP_TRY(ctx, launch_set_n_part(st.n_part + c0, ctx->d_offsets, n_up, ctx->stream));
+    HIP_TRY(ctx, launch_set_n_part(st.n_part + c0, st.n_hi + c0, ctx->d_offsets, n_up, ctx->stream));
     HIP_TRY(ctx, launch_refresh_caches(st, cell_first, n_up, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->sorted_valid = false;
@@ -539,6 +538,8 @@ int pmcx_download_cells(pmcx_ctx *ctx, int32_t cell_first, int32_t n_dn, const i
     if (cell_first < 0 || n_dn < 1 || cell_first + n_dn > cf.n_cells)
         return fail(ctx, PMCX_EINVAL, "cell range outside the context");
     HIP_TRY(ctx, hipSetDevice(cf.device));
+    // the host view is dense: close any holes left by removals first
+    HIP_TRY(ctx, launch_compact(ctx->st, cell_first, n_dn, 0, 1, ctx->stream));
     std::vector<int32_t> np((size_t)n_dn);
     HIP_TRY(ctx, hipMemcpyAsync(np.data(), ctx->st.n_part + cell_first, sizeof(int32_t) * n_dn,
                                 hipMemcpyDeviceToHost, ctx->stream));
@@ -655,8 +656,9 @@ int pmcx_mc_coag(pmcx_ctx *ctx, int32_t kernel_type, double del_t, uint64_t seed
         HIP_TRY(ctx, launch_coag_sample(ctx->st, kernel_type, del_t, seed, step, ctx->stream));
     }
     {
-        ProfScope ps(ctx, "coag_apply");
-        HIP_TRY(ctx, launch_coag_apply(ctx->st, ctx->stream));
+        // close holes in the cells where more than 1/8 of the slots are tombstones
+        ProfScope ps(ctx, "compact");
+        HIP_TRY(ctx, launch_compact(ctx->st, 0, ctx->cfg.n_cells, 1, 8, ctx->stream));
     }
     ctx->sorted_valid = false;
     return PMCX_OK;
@@ -810,6 +812,8 @@ int pmcx_get_caches(pmcx_ctx *ctx, int32_t cell, double *vtot, double *mass)
     if (!ctx || cell < 0 || cell >= ctx->cfg.n_cells) return fail(ctx, PMCX_EINVAL, "pmcx_get_caches: bad argument");
     const size_t cap = (size_t)ctx->cfg.cap;
     int rc = PMCX_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, launch_compact(ctx->st, cell, 1, 0, 1, ctx->stream));
     if (vtot) rc = copy_cells_d2h(ctx, vtot, ctx->st.vtot + cell * cap, sizeof(double) * cap);
     if (!rc && mass) rc = copy_cells_d2h(ctx, mass, ctx->st.mass + cell * cap, sizeof(double) * cap);
     return rc;

@@ -35,7 +35,8 @@ struct DeviceState {
     double *mag;                   // [n_cells][n_class]
     const double *n_ideal;         // [n_cells][n_class]
     double *kmax;                  // [n_cells][n_bin*n_bin]
-    int32_t *n_part;               // [n_cells]
+    int32_t *n_part;               // [n_cells] live particles
+    int32_t *n_hi;                 // [n_cells] slots in use (live + tombstones)
     int64_t *next_id;              // [n_cells]
     // particles
     double *vol;     // [n_cells][n_spec][cap]
@@ -49,7 +50,6 @@ struct DeviceState {
     uint32_t *perm;  // [n_cells][cap]
     int32_t *gcnt;   // [n_cells][n_class*n_bin]
     int32_t *goff;   // [n_cells][n_class*n_bin]
-    int4 *events;    // [n_cells][max_events]
     int32_t *n_events, *n_samp, *n_coag, *status; // [n_cells]
 };
 
@@ -76,14 +76,16 @@ hipError_t launch_gather_f64(double *dst, const double *src, const int64_t *part
 hipError_t launch_gather_i32(int32_t *dst, const int32_t *src, const int64_t *part_offset,
                              int n_dn, int64_t src_cell_stride, int64_t dst_row_stride, int n_rows,
                              int64_t src_row_stride, hipStream_t s);
-hipError_t launch_set_n_part(int32_t *n_part, const int64_t *part_offset, int n_up, hipStream_t s);
+hipError_t launch_set_n_part(int32_t *n_part, int32_t *n_hi, const int64_t *part_offset, int n_up,
+                             hipStream_t s);
+hipError_t launch_compact(const DeviceState &st, int cell_first, int n_cells_do, int num, int den,
+                          hipStream_t s);
 hipError_t launch_refresh_caches(const DeviceState &st, int cell_first, int n_cells_do,
                                  hipStream_t s);
 hipError_t launch_kernel_bounds(const DeviceState &st, int ktype, hipStream_t s);
 hipError_t launch_bin_sort(const DeviceState &st, hipStream_t s);
 hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, uint64_t seed,
                               uint32_t step, hipStream_t s);
-hipError_t launch_coag_apply(const DeviceState &st, hipStream_t s);
 hipError_t launch_rebalance(const DeviceState &st, int allow_doubling, int allow_halving,
                             uint64_t seed, uint32_t step, hipStream_t s);
 hipError_t launch_diagnostics(const DeviceState &st, double *tot_num, double *tot_mass,

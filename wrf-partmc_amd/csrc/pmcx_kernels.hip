@@ -19,9 +19,8 @@
 //   k_coag_sample  one 64-lane wavefront per cell; candidate pairs of the
 //                  sequential PartMC sweep evaluated 64 at a time, first
 //                  accepted pair found by ballot, applied, later slots redrawn.
-//   k_coag_apply   one wavefront per cell; merges species volumes along the
-//                  event log, refreshes caches, closes holes (bitmap +
-//                  wave prefix sums).
+//   k_compact      one wavefront per cell; stable compaction of cells whose
+//                  tombstone fraction exceeds a threshold.
 //   k_rebalance, k_diagnostics, k_kernel_bounds, k_generate: full-population
 //                  or per-cell table passes around the above.
 // All arithmetic that feeds a decision is fp64 with contraction off.
@@ -57,6 +56,13 @@ __device__ __forceinline__ uint32_t ld_u32(const uint32_t *p)
 __device__ __forceinline__ void st_u32(uint32_t *p, uint32_t v)
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// tombstone: the slot stays allocated, every consumer skips it
+__device__ __forceinline__ void mark_dead(const DeviceState &st, int64_t cb, int i)
+{
+    st_f64(&st.vtot[cb + i], -1.0);
+    st_u32((uint32_t *)&st.wclass[cb + i], 0xFFFFFFFFu);
 }
 
 __device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t x, int lane)
@@ -154,10 +160,13 @@ __global__ void k_gather_i32(int32_t *__restrict__ dst, const int32_t *__restric
             dst[r * dst_row_stride + o0 + i] =
                 src[(int64_t)k * src_cell_stride + r * src_row_stride + i];
 }
-__global__ void k_set_n_part(int32_t *n_part, const int64_t *part_offset, int n_up)
+__global__ void k_set_n_part(int32_t *n_part, int32_t *n_hi, const int64_t *part_offset, int n_up)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n_up) n_part[k] = (int32_t)(part_offset[k + 1] - part_offset[k]);
+    if (k < n_up) {
+        n_part[k] = (int32_t)(part_offset[k + 1] - part_offset[k]);
+        n_hi[k] = n_part[k];
+    }
 }
 
 // vtot/mass from the species volumes (sequential sum over species)
@@ -254,7 +263,7 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st)
     const int c = blockIdx.x;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int B = st.n_bin, C = st.n_class, G = B * C;
-    const int n = st.n_part[c];
+    const int n = st.n_hi[c]; // slots in use; dead ones (vtot < 0) are skipped
     const int64_t cb = (int64_t)c * st.cap;
 
     double *edge = (double *)smem;                    // [B+1]
@@ -301,11 +310,15 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st)
         for (int u = 0; u < 4; u++) {
             const int i = i0 + u * 64 + lane;
             if (i < hi) {
-                oog |= (v[u] < v_lo) | (v[u] >= v_hi);
-                uint32_t g = (uint32_t)bin_index(edge, B, v[u], st);
-                if (C > 1) g += (uint32_t)wc[i] * (uint32_t)B;
-                key[i] = (uint16_t)g;
-                atomicAdd(&myhist[g], 1u);
+                if (v[u] >= 0.0) {
+                    oog |= (v[u] < v_lo) | (v[u] >= v_hi);
+                    uint32_t g = (uint32_t)bin_index(edge, B, v[u], st);
+                    if (C > 1) g += (uint32_t)wc[i] * (uint32_t)B;
+                    key[i] = (uint16_t)g;
+                    atomicAdd(&myhist[g], 1u);
+                } else {
+                    key[i] = 0xFFFFu; // tombstone
+                }
             }
         }
     }
@@ -334,8 +347,9 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st)
     uint32_t *perm = st.perm + cb;
     for (int i0 = lo; i0 < hi; i0 += 64) {
         const int i = i0 + lane;
-        const bool valid = i < hi;
-        const uint32_t g = valid ? key[i] : 0u;
+        const uint32_t gk = i < hi ? key[i] : 0xFFFFu;
+        const bool valid = gk != 0xFFFFu;
+        const uint32_t g = valid ? gk : 0u;
         const uint64_t peers = peers_of(g, valid);
         const uint32_t rank = (uint32_t)__popcll(peers & lt);
         if (valid) perm[myhist[g] + rank] = (uint32_t)i;
@@ -553,9 +567,7 @@ __global__ __launch_bounds__(256, OCC) void k_coag_sample(DeviceState st, int kt
     const KernelParams kp{st.const_k, st.additive_beta};
     const double *kmax = st.kmax + (int64_t)c * B * B;
     const double *mag = st.mag + (int64_t)c * C;
-    int4 *evlog = st.events + (int64_t)c * st.max_events;
-
-    int n_ev = 0, n_app = 0, tot_coag = 0, status = 0;
+    int n_ev = 0, n_app = 0, n_dead = 0, tot_coag = 0, status = 0;
     uint64_t tot_samp = 0;
 
     // Row state (uniform inside the group).  The partner slots of a row are
@@ -758,8 +770,25 @@ __global__ __launch_bounds__(256, OCC) void k_coag_sample(DeviceState st, int kt
         if (g_new != g_old && n_app >= st.max_appends) {
             status |= ST_APPEND_OVERFLOW; done = true; continue;
         }
-        if (lead) evlog[n_ev] = make_int4((int)pn, (int)po, rem_o ? 1 : 0, cc);
         n_ev++;
+        // Species volumes, source histogram, create times and class of the merged
+        // particle [aero_particle_coagulate]: loads go out now and are consumed after
+        // the list updates below; lanes of the group split the species.
+        const int S = st.n_spec, NS = st.n_source;
+        double mv_a[3] = {0, 0, 0}, mv_b[3] = {0, 0, 0}; // up to 3 species per lane at L = 8
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int sp = gl + k * L;
+            if (sp < S) {
+                mv_a[k] = ld_f64(&st.vol[cb * S + (int64_t)sp * st.cap + pn]);
+                mv_b[k] = ld_f64(&st.vol[cb * S + (int64_t)sp * st.cap + po]);
+            }
+        }
+        double lo_n = 0, lo_o = 0, go_n = 0, go_o = 0;
+        if (lead) {
+            lo_n = ld_f64(&st.lct[cb + pn]); lo_o = ld_f64(&st.lct[cb + po]);
+            go_n = ld_f64(&st.gct[cb + pn]); go_o = ld_f64(&st.gct[cb + po]);
+        }
         if (rem_o) {
             const int last = list_remove(X, g_o, io, B, lead);
             if (same && in == last) in = io;
@@ -771,7 +800,31 @@ __global__ __launch_bounds__(256, OCC) void k_coag_sample(DeviceState st, int kt
             list_append(X, g_new, pn, n_app, B);
             n_app++;
         }
-        if (lead) { st_f64(&X.vtot[pn], vn); st_f64(&X.mass[pn], mn); }
+        if (lead) {
+            st_f64(&X.vtot[pn], vn); st_f64(&X.mass[pn], mn);
+            if (lo_o < lo_n) st_f64(&st.lct[cb + pn], lo_o);
+            if (go_o > go_n) st_f64(&st.gct[cb + pn], go_o);
+            if (C > 1) st_u32((uint32_t *)&st.wclass[cb + pn], (uint32_t)cc);
+        }
+        {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int sp = gl + k * L;
+                if (sp < S) st_f64(&st.vol[cb * S + (int64_t)sp * st.cap + pn], mv_a[k] + mv_b[k]);
+            }
+            for (int sp = gl + 3 * L; sp < S; sp += L) { // more than 3*L species: plain loop
+                double *a = &st.vol[cb * S + (int64_t)sp * st.cap + pn];
+                st_f64(a, ld_f64(a) + ld_f64(&st.vol[cb * S + (int64_t)sp * st.cap + po]));
+            }
+            for (int sp = gl; sp < NS; sp += L) {
+                uint32_t *a = (uint32_t *)&st.n_orig[cb * NS + (int64_t)sp * st.cap + pn];
+                st_u32(a, ld_u32(a) + ld_u32((uint32_t *)&st.n_orig[cb * NS + (int64_t)sp * st.cap + po]));
+            }
+        }
+        if (rem_o) {
+            if (lead) mark_dead(st, cb, (int)po); // tombstone
+            n_dead++;
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
         tot_coag++;
@@ -791,18 +844,20 @@ __global__ __launch_bounds__(256, OCC) void k_coag_sample(DeviceState st, int kt
 
     if (live && lead) {
         st.n_events[c] = n_ev;
+        st.n_part[c] = st.n_part[c] - n_dead;
         st.n_samp[c] = tot_samp > 0x7FFFFFFFull ? 0x7FFFFFFF : (int32_t)tot_samp;
         st.n_coag[c] = tot_coag;
         if (status) atomicOr(&st.status[c], status);
     }
 }
 
-// --------------------------------------------------------------- coag apply
+// ---------------------------------------------------------------- compaction
 //
-// Deferred part of `coagulate` [upstream]: merged particle = species-wise sum
-// (aero_particle_coagulate), create times min/max, source histogram summed,
-// class set; then caches refreshed from the species and holes closed by
-// tail fill (batched form of aero_particle_array's swap-with-last removal).
+// Removed particles become tombstones (vtot = -1, wclass = -1): slots [0, n_hi) hold
+// n_part live particles in a fixed relative order, and holes are closed by a
+// stable compaction only when more than 1/8 of the slots are dead (or when a
+// caller needs a dense cell).  Because the order of the survivors never
+// changes, when compaction happens cannot change any later result.
 
 __device__ __forceinline__ void move_particle(const DeviceState &st, int64_t cb, int c, int dst,
                                               int src)
@@ -821,133 +876,76 @@ __device__ __forceinline__ void move_particle(const DeviceState &st, int64_t cb,
     st.gct[cb + dst] = st.gct[cb + src];
 }
 
-// Close holes: dead[] bitmap (LDS, one bit per slot) -> the k-th dead slot
-// below n_new receives the k-th live slot at or above n_new.  `scratch` is a
-// global u32 area of `cap` entries: holes in [0, cap/2), fillers in
-// [cap/2, cap) (at most min(n_dead, n_new) <= cap/2 moves).
-__device__ void compact_tail_fill(const DeviceState &st, int c, uint64_t *dead, int n_old,
-                                  int n_dead, uint32_t *scratch, int lane)
+// Stable compaction of one cell by one wavefront: 64 slots at a time, every
+// row read into registers before any is written (dst <= src, chunks ascend).
+__device__ void compact_wave(const DeviceState &st, int c, int lane)
 {
     const int64_t cb = (int64_t)c * st.cap;
-    const int n_new = n_old - n_dead;
-    const int fill_off = st.cap >> 1;
-    if (n_dead > 0) {
-        const int n_words = (n_old + 63) >> 6;
-        uint32_t hole_base = 0, fill_base = 0;
-        for (int w0 = 0; w0 < n_words; w0 += 64) {
-            const int w = w0 + lane;
-            uint64_t hw = 0, fw = 0;
-            if (w < n_words) {
-                const uint64_t d = dead[w];
-                // bits of this word that lie below / at-or-above n_new, below n_old
-                const int lo = w << 6;
-                uint64_t valid = ~0ull;
-                if (n_old - lo < 64) valid = (n_old - lo <= 0) ? 0ull : ((1ull << (n_old - lo)) - 1ull);
-                uint64_t below = 0ull;
-                if (n_new - lo >= 64) below = ~0ull;
-                else if (n_new - lo > 0) below = (1ull << (n_new - lo)) - 1ull;
-                hw = d & below & valid;
-                fw = ~d & ~below & valid;
-            }
-            const uint32_t hc = (uint32_t)__popcll(hw), fc = (uint32_t)__popcll(fw);
-            const uint32_t hi = wave_incl_scan_u32(hc, lane), fi = wave_incl_scan_u32(fc, lane);
-            uint32_t hp = hole_base + hi - hc, fp = fill_base + fi - fc;
-            while (hw) { const int b = __builtin_ctzll(hw); hw &= hw - 1; scratch[hp++] = (uint32_t)((w << 6) + b); }
-            while (fw) { const int b = __builtin_ctzll(fw); fw &= fw - 1; scratch[fill_off + fp++] = (uint32_t)((w << 6) + b); }
-            hole_base += __shfl(hi, 63, 64);
-            fill_base += __shfl(fi, 63, 64);
+    const int n_hi = st.n_hi[c];
+    const int S = st.n_spec, NS = st.n_source;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    int base = 0;
+    for (int i0 = 0; i0 < n_hi; i0 += 64) {
+        const int i = i0 + lane;
+        const bool live = i < n_hi && (int32_t)ld_u32((const uint32_t *)&st.wclass[cb + i]) >= 0;
+        const uint64_t m = __ballot(live);
+        const int dst = base + __popcll(m & lt);
+        const bool mv = live && dst != i;
+        base += __popcll(m);
+        if (__ballot(mv) == 0) continue;
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        int64_t idv = 0;
+        int32_t wc = 0;
+        if (mv) {
+            a0 = ld_f64(&st.vtot[cb + i]); a1 = ld_f64(&st.mass[cb + i]);
+            a2 = ld_f64(&st.lct[cb + i]); a3 = ld_f64(&st.gct[cb + i]);
+            idv = (int64_t)d2u(ld_f64((const double *)&st.id[cb + i]));
+            wc = (int32_t)ld_u32((const uint32_t *)&st.wclass[cb + i]);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
-        const int n_move = (int)hole_base; // == fill_base
-        for (int k = lane; k < n_move; k += 64)
-            move_particle(st, cb, c, (int)ld_u32(&scratch[k]), (int)ld_u32(&scratch[fill_off + k]));
-    }
-    if (lane == 0) st.n_part[c] = n_new;
-}
-
-__global__ __launch_bounds__(256) void k_coag_apply(DeviceState st)
-{
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wpb = blockDim.x >> 6;
-    const int c = blockIdx.x * wpb + wave;
-    if (c >= st.n_cells) return;
-    const int64_t cb = (int64_t)c * st.cap;
-    const int n_old = st.n_part[c];
-    const int n_ev = st.n_events[c];
-    const int n_words_cap = (st.cap + 63) >> 6;
-    uint64_t *dead = (uint64_t *)smem + (size_t)wave * n_words_cap;
-    const int4 *evlog = st.events + (int64_t)c * st.max_events;
-    if (n_ev == 0) return;
-    for (int w = lane; w < ((n_old + 63) >> 6); w += 64) dead[w] = 0;
-    wave_sync();
-
-    // Merge along the log.  Results must equal the in-order merge, so an event
-    // waits for the latest earlier event that touched either of its two slots;
-    // events with disjoint slots run side by side, one per lane, 64 per chunk.
-    int n_dead = 0;
-    const int S = st.n_spec, NS = st.n_source;
-    for (int e0 = 0; e0 < n_ev; e0 += 64) {
-        const int e = e0 + lane;
-        const bool mine = e < n_ev;
-        int4 ev = make_int4(-1, -2, 0, 0);
-        if (mine) ev = evlog[e];
-        int dA = -1, dB = -1; // chunk-local index of the latest earlier event on pn / po
-        const int n_here = min(64, n_ev - e0);
-        for (int k = 0; k < n_here; k++) {
-            const int pnk = __shfl(ev.x, k, 64), pok = __shfl(ev.y, k, 64);
-            if (k < lane) {
-                if (pnk == ev.x || pok == ev.x) dA = k;
-                if (pnk == ev.y || pok == ev.y) dB = k;
-            }
+        if (mv) {
+            st_f64(&st.vtot[cb + dst], a0); st_f64(&st.mass[cb + dst], a1);
+            st_f64(&st.lct[cb + dst], a2); st_f64(&st.gct[cb + dst], a3);
+            st_f64((double *)&st.id[cb + dst], u2d((uint64_t)idv));
+            st_u32((uint32_t *)&st.wclass[cb + dst], (uint32_t)wc);
         }
-        bool fin = !mine;
-        uint64_t donemask = __ballot(fin);
-        while (donemask != ~0ull) {
-            const bool ready = !fin && (dA < 0 || ((donemask >> dA) & 1ull)) &&
-                               (dB < 0 || ((donemask >> dB) & 1ull));
-            if (ready) {
-                const int pn = ev.x, po = ev.y;
-                for (int s = 0; s < S; s++) {
-                    double *a = &st.vol[cb * S + (int64_t)s * st.cap + pn];
-                    st_f64(a, ld_f64(a) + ld_f64(&st.vol[cb * S + (int64_t)s * st.cap + po]));
-                }
-                for (int s = 0; s < NS; s++) {
-                    uint32_t *a = (uint32_t *)&st.n_orig[cb * NS + (int64_t)s * st.cap + pn];
-                    st_u32(a, ld_u32(a) + ld_u32((uint32_t *)&st.n_orig[cb * NS + (int64_t)s * st.cap + po]));
-                }
-                const double lo = ld_f64(&st.lct[cb + po]), go = ld_f64(&st.gct[cb + po]);
-                if (lo < ld_f64(&st.lct[cb + pn])) st_f64(&st.lct[cb + pn], lo);
-                if (go > ld_f64(&st.gct[cb + pn])) st_f64(&st.gct[cb + pn], go);
-                st_u32((uint32_t *)&st.wclass[cb + pn], (uint32_t)ev.w);
-                if (ev.z) atomicOr((unsigned long long *)&dead[po >> 6], 1ull << (po & 63));
-                fin = true;
-            }
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        for (int s0 = 0; s0 < S; s0 += 4) {
+            double v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                v[k] = (mv && s0 + k < S) ? ld_f64(&st.vol[cb * S + (int64_t)(s0 + k) * st.cap + i]) : 0.0;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             wave_sync();
-            donemask = __ballot(fin);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (mv && s0 + k < S) st_f64(&st.vol[cb * S + (int64_t)(s0 + k) * st.cap + dst], v[k]);
         }
-        n_dead += __popcll(__ballot(mine && ev.z));
-    }
-    wave_sync();
-    // caches of surviving merged particles from the species
-    for (int e = lane; e < n_ev; e += 64) {
-        const int pn = evlog[e].x;
-        if ((dead[pn >> 6] >> (pn & 63)) & 1ull) continue;
-        double vt = 0.0, ms = 0.0;
-        for (int s = 0; s < S; s++) {
-            const double v = ld_f64(&st.vol[cb * S + (int64_t)s * st.cap + pn]);
-            vt = vt + v;
-            ms = ms + st.density[s] * v;
+        for (int s = 0; s < NS; s++) {
+            uint32_t x = 0;
+            if (mv) x = ld_u32((const uint32_t *)&st.n_orig[cb * NS + (int64_t)s * st.cap + i]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wave_sync();
+            if (mv) st_u32((uint32_t *)&st.n_orig[cb * NS + (int64_t)s * st.cap + dst], x);
         }
-        st.vtot[cb + pn] = vt;
-        st.mass[cb + pn] = ms;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_sync();
     }
+    if (lane == 0) st.n_hi[c] = base;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wave_sync();
-    compact_tail_fill(st, c, dead, n_old, n_dead, st.perm + cb, lane);
+}
+
+// compacts the cells whose dead fraction exceeds num/den (num = 0: any dead slot)
+__global__ __launch_bounds__(256) void k_compact(DeviceState st, int cell_first, int n_cells_do,
+                                                 int num, int den)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (k >= n_cells_do) return;
+    const int c = cell_first + k;
+    const int n_hi = st.n_hi[c], n_live = st.n_part[c];
+    if ((int64_t)(n_hi - n_live) * den > (int64_t)n_hi * num) compact_wave(st, c, lane);
 }
 
 // ---------------------------------------------------------------- rebalance
@@ -955,42 +953,48 @@ __global__ __launch_bounds__(256) void k_coag_apply(DeviceState st)
 // aero_state_rebalance (interface/wrf_pmc_driver.F90:248-250): per class,
 // double (copy every particle, new ids, halve the weight) while the class
 // holds fewer than n_ideal/2 particles, halve (drop each with probability
-// 1/2, double the weight) while it holds more than 2 n_ideal.
+// 1/2, double the weight) while it holds more than 2 n_ideal.  Dropped
+// particles become tombstones; the halving draw of a particle is keyed by its
+// rank among the live particles, which does not depend on where holes are.
 
 __global__ __launch_bounds__(64) void k_rebalance(DeviceState st, int allow_doubling,
                                                   int allow_halving, uint64_t seed, uint32_t step)
 {
-    extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
     const int c = blockIdx.x;
     const int64_t cb = (int64_t)c * st.cap;
     const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
-    uint64_t *dead = (uint64_t *)smem;
+    const uint64_t lt = (1ull << lane) - 1ull;
     double *mag = st.mag + (int64_t)c * st.n_class;
     const double *n_ideal = st.n_ideal + (int64_t)c * st.n_class;
     int status = 0;
     for (int cl = 0; cl < st.n_class; cl++) {
         for (uint32_t iter = 0; iter < 32; iter++) {
-            const int n = st.n_part[c];
-            int ncl = n; // one class: every particle belongs to it
+            int n_hi = st.n_hi[c];
+            const int n_live = st.n_part[c];
+            int ncl = n_live; // one class: every live particle belongs to it
             if (st.n_class > 1) {
                 uint32_t cnt = 0;
-                for (int i = lane; i < n; i += 64) cnt += (st.wclass[cb + i] == cl);
+                for (int i = lane; i < n_hi; i += 64) cnt += ((int32_t)ld_u32((const uint32_t *)&st.wclass[cb + i]) == cl);
                 ncl = (int)wave_sum_u64(cnt);
             }
             const double ideal = n_ideal[cl];
             if (allow_doubling && ncl > 0 && (double)ncl < ideal / 2.0) {
-                if (n + ncl > st.cap) { status |= ST_CAP_OVERFLOW; break; }
+                if (n_hi + ncl > st.cap && n_hi > n_live) { // make room: close the holes first
+                    compact_wave(st, c, lane);
+                    n_hi = n_live;
+                }
+                if (n_hi + ncl > st.cap) { status |= ST_CAP_OVERFLOW; break; }
                 const int64_t nid = st.next_id[c];
                 uint32_t base = 0;
-                for (int i0 = 0; i0 < n; i0 += 64) {
+                for (int i0 = 0; i0 < n_hi; i0 += 64) {
                     const int i = i0 + lane;
-                    const bool is = (i < n) && (st.wclass[cb + i] == cl);
+                    const bool is = (i < n_hi) && ((int32_t)ld_u32((const uint32_t *)&st.wclass[cb + i]) == cl);
                     const uint64_t m = __ballot(is);
-                    const uint32_t k = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    const uint32_t k = base + (uint32_t)__popcll(m & lt);
                     if (is) {
-                        move_particle(st, cb, c, n + (int)k, i);
-                        st.id[cb + n + k] = nid + (int64_t)k;
+                        move_particle(st, cb, c, n_hi + (int)k, i);
+                        st.id[cb + n_hi + k] = nid + (int64_t)k;
                     }
                     base += (uint32_t)__popcll(m);
                 }
@@ -998,32 +1002,40 @@ __global__ __launch_bounds__(64) void k_rebalance(DeviceState st, int allow_doub
                 wave_sync();
                 if (lane == 0) {
                     st.next_id[c] = nid + ncl;
-                    st.n_part[c] = n + ncl;
+                    st.n_hi[c] = n_hi + ncl;
+                    st.n_part[c] = n_live + ncl;
                     mag[cl] = mag[cl] / 2.0;
                 }
-                __threadfence_block();
-                wave_sync();
-            } else if (allow_halving && (double)ncl > ideal * 2.0) {
-                uint32_t nd = 0;
-                for (int w0 = 0; w0 < ((n + 63) >> 6); w0++) {
-                    const int i = (w0 << 6) + lane;
-                    bool drop = false;
-                    if (i < n && st.wclass[cb + i] == cl) {
-                        uint32_t w[4];
-                        rng_block(seed, cell_id, step, (uint32_t)i, SITE_HALVE,
-                                  (uint32_t)cl * 32u + iter, w);
-                        drop = u53(w[0], w[1]) < 0.5;
-                    }
-                    const uint64_t m = __ballot(drop);
-                    dead[w0] = m; // uniform store
-                    nd += (uint32_t)__popcll(m);
-                }
-                wave_sync();
-                compact_tail_fill(st, c, dead, n, (int)nd, st.perm + cb, lane);
-                if (lane == 0) mag[cl] = mag[cl] * 2.0;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __threadfence_block();
                 wave_sync();
+            } else if (allow_halving && (double)ncl > ideal * 2.0) {
+                uint32_t nd = 0, rank0 = 0;
+                for (int i0 = 0; i0 < n_hi; i0 += 64) {
+                    const int i = i0 + lane;
+                    const int wc = i < n_hi ? (int32_t)ld_u32((const uint32_t *)&st.wclass[cb + i]) : -1;
+                    const uint64_t mlive = __ballot(wc >= 0);
+                    const uint32_t rank = rank0 + (uint32_t)__popcll(mlive & lt);
+                    bool drop = false;
+                    if (wc == cl) {
+                        uint32_t w[4];
+                        rng_block(seed, cell_id, step, rank, SITE_HALVE, (uint32_t)cl * 32u + iter, w);
+                        drop = u53(w[0], w[1]) < 0.5;
+                    }
+                    if (drop) mark_dead(st, cb, i);
+                    nd += (uint32_t)__popcll(__ballot(drop));
+                    rank0 += (uint32_t)__popcll(mlive);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                wave_sync();
+                if (lane == 0) {
+                    st.n_part[c] = n_live - (int)nd;
+                    mag[cl] = mag[cl] * 2.0;
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __threadfence_block();
+                wave_sync();
+                if (((int)nd + n_hi - n_live) * 8 > n_hi) compact_wave(st, c, lane);
             } else {
                 break;
             }
@@ -1057,18 +1069,19 @@ __global__ __launch_bounds__(256) void k_diagnostics(DeviceState st, double *tot
     for (int j = t; j < C * nd; j += 256) ccnt[j] = 0;
     for (int j = t; j < C; j += 256) clcnt[j] = 0;
     __syncthreads();
-    const int n = st.n_part[c];
+    const int n = st.n_hi[c];
     const int64_t cb = (int64_t)c * st.cap;
     const double *mag = st.mag + (int64_t)c * C;
     double tm = 0.0;
     for (int i = t; i < n; i += 256) {
+        const int cl = st.wclass[cb + i];
+        if (cl < 0) continue; // tombstone
         double vdry = 0.0, ms = 0.0;
         for (int s = 0; s < S; s++) {
             const double v = st.vol[cb * S + (int64_t)s * st.cap + i];
             if (s != st.i_water) vdry = vdry + v;
             ms = ms + st.density[s] * v;
         }
-        const int cl = st.wclass[cb + i];
         const double nc = mag[cl];
         const double diam = 2.0 * det_cbrt(vdry * (0.75 / PI));
         atomicAdd(&clcnt[cl], 1u);
@@ -1134,7 +1147,7 @@ __global__ void k_generate(DeviceState st, GenSpecDev g, int n, uint64_t seed, d
         st.lct[cb + i] = create_time;
         st.gct[cb + i] = create_time;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) st.n_part[c] = n;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st.n_part[c] = n; st.n_hi[c] = n; }
 }
 
 // ------------------------------------------------------------------- totals
@@ -1289,10 +1302,18 @@ hipError_t launch_gather_i32(int32_t *dst, const int32_t *src, const int64_t *pa
                        part_offset, src_cell_stride, dst_row_stride, n_rows, src_row_stride);
     return hipGetLastError();
 }
-hipError_t launch_set_n_part(int32_t *n_part, const int64_t *part_offset, int n_up, hipStream_t s)
+hipError_t launch_set_n_part(int32_t *n_part, int32_t *n_hi, const int64_t *part_offset, int n_up,
+                             hipStream_t s)
 {
-    hipLaunchKernelGGL(k_set_n_part, dim3((n_up + 255) / 256), dim3(256), 0, s, n_part,
+    hipLaunchKernelGGL(k_set_n_part, dim3((n_up + 255) / 256), dim3(256), 0, s, n_part, n_hi,
                        part_offset, n_up);
+    return hipGetLastError();
+}
+hipError_t launch_compact(const DeviceState &st, int cell_first, int n_cells_do, int num, int den,
+                          hipStream_t s)
+{
+    hipLaunchKernelGGL(k_compact, dim3((n_cells_do + 3) / 4), dim3(256), 0, s, st, cell_first,
+                       n_cells_do, num, den);
     return hipGetLastError();
 }
 hipError_t launch_refresh_caches(const DeviceState &st, int cell_first, int n_cells_do,
@@ -1348,19 +1369,10 @@ hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, ui
 #undef PMCX_LAUNCH_SAMPLER
     return hipGetLastError();
 }
-hipError_t launch_coag_apply(const DeviceState &st, hipStream_t s)
-{
-    const size_t per = sizeof(uint64_t) * (size_t)((st.cap + 63) >> 6);
-    const int wpb = waves_per_block(per);
-    hipLaunchKernelGGL(k_coag_apply, dim3((st.n_cells + wpb - 1) / wpb), dim3(64 * wpb), per * wpb,
-                       s, st);
-    return hipGetLastError();
-}
 hipError_t launch_rebalance(const DeviceState &st, int allow_doubling, int allow_halving,
                             uint64_t seed, uint32_t step, hipStream_t s)
 {
-    const size_t lds = sizeof(uint64_t) * (size_t)((st.cap + 63) >> 6);
-    hipLaunchKernelGGL(k_rebalance, dim3(st.n_cells), dim3(64), lds, s, st, allow_doubling,
+    hipLaunchKernelGGL(k_rebalance, dim3(st.n_cells), dim3(64), 0, s, st, allow_doubling,
                        allow_halving, seed, step);
     return hipGetLastError();
 }
