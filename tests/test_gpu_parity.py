@@ -236,3 +236,107 @@ def test_conservation_full_size(wp):
         assert len(np.unique(after["id"][sa])) == sa.stop - sa.start
     assert tot_coag.sum() > n_cells
     blk.close()
+
+
+# ------------------------------------------------------------------ edge cases
+
+def _ragged_pair(wp, oracle, counts, n_spec=2, n_class=1, kernel=K_BROWN, cap=None, seed=4,
+                 conc=6.1e9, **over):
+    """Cells with different particle counts (including 0 and 1)."""
+    n_cells = len(counts)
+    cap = cap or max(64, int(np.ceil(max(counts) / 64) * 64))
+    blk = wp.CellBlock(n_cells, cap, n_spec, n_class=n_class, n_source=2, **over)
+    names, dens = parity.default_species(n_spec)
+    blk.set_aero_data(dens)
+    temp = np.linspace(290, 230, n_cells); pres = np.linspace(101325, 30000, n_cells)
+    blk.set_env(temp, pres)
+    ve, vs = blk.bin_tables()
+    modes, _ = parity.make_modes(n_spec, n_class)
+    for m in modes:
+        m["source"] = m["source"] % 2
+    mag = np.zeros((n_cells, n_class))
+    cells, po = [], np.zeros(n_cells + 1, np.int64)
+    for c, n in enumerate(counts):
+        oc = oracle.Cell(n_spec, n_class, 2, cap, dens, ve, temp[c], pres[c],
+                         max_events=blk.cfg.max_events, max_appends=blk.cfg.max_appends)
+        mag[c] = conc / max(n, 1) * (1 + 0.5 * np.arange(n_class))
+        oc.mag[:] = mag[c]
+        oc.generate(modes, n, seed, c, first_id=c << 32)
+        oc.cell_id = c
+        oc.kmax[:] = oracle.kmax_table(kernel, vs, dens.min(), dens.max(), temp[c], pres[c],
+                                       blk.cfg.const_k, blk.cfg.additive_beta)
+        cells.append(oc)
+        po[c + 1] = po[c] + n
+    nt = int(po[-1])
+    vol = np.zeros((n_spec, nt)); wc = np.zeros(nt, np.int32); ids = np.zeros(nt, np.int64)
+    lct = np.zeros(nt); gct = np.zeros(nt); no = np.zeros((2, nt), np.int32)
+    for c, oc in enumerate(cells):
+        s = slice(po[c], po[c + 1]); n = counts[c]
+        vol[:, s] = oc.vol[:, :n]; wc[s] = oc.wclass[:n]; ids[s] = oc.id[:n]
+        lct[s] = oc.lct[:n]; gct[s] = oc.gct[:n]; no[:, s] = oc.n_orig[:, :n]
+    blk.set_weights(mag)
+    blk.upload_cells(0, po, vol, wc, ids, lct, gct, no)
+    return blk, cells
+
+
+def test_empty_ragged_and_tiny_cells(wp, oracle):
+    counts = [0, 1, 2, 3, 64, 65, 1000, 0, 777, 5]
+    blk, cells = _ragged_pair(wp, oracle, counts)
+    assert list(blk.aero_state_total_particles()) == counts
+    for step in range(3):
+        ns, nc, st = blk.mc_coag(K_BROWN, 5000.0, 4, step)
+        for c, oc in enumerate(cells):
+            ost, ons, onc = oc.mc_coag(K_BROWN, 5000.0, 4, c, step)
+            assert (ons, onc, ost) == (int(ns[c]), int(nc[c]), int(st[c])), (step, c)
+        ok, msg = parity.compare_state(blk, cells)
+        assert ok, msg
+    assert ns[0] == 0 and nc[0] == 0 and ns[1] == 0      # empty and single-particle cells
+    tn, tm, nd, md = blk.diagnostics()
+    assert tn[0] == 0 and tm[0] == 0 and not nd[0].any()
+    blk.close()
+
+
+def test_maximum_capacity_cell(wp, oracle):
+    """cap = 65280, the largest a cell may hold (16-bit slot indices in the sampler)."""
+    blk, cells = _ragged_pair(wp, oracle, [65280, 40000], n_spec=1, cap=65280, conc=2e10,
+                              max_events=8192, max_appends=4096)
+    ns, nc, st = blk.mc_coag(K_BROWN, 300.0, 4, 0)
+    for c, oc in enumerate(cells):
+        ost, ons, onc = oc.mc_coag(K_BROWN, 300.0, 4, c, 0)
+        assert (ons, onc, ost) == (int(ns[c]), int(nc[c]), int(st[c]))
+    assert nc.min() > 100
+    ok, msg = parity.compare_state(blk, cells)
+    assert ok, msg
+    blk.close()
+
+
+def test_tombstones_and_lazy_compaction(wp, oracle):
+    """Many steps with heavy depletion: cells cross the 1/8 tombstone threshold and are
+    compacted in between; results must not depend on when that happens."""
+    blk, cells = _ragged_pair(wp, oracle, [1500, 900, 1200], n_spec=2, n_class=2,
+                              max_events=4096, max_appends=4096)
+    for step in range(8):
+        ns, nc, st = blk.mc_coag(K_BROWN, 15000.0, 4, step)
+        for c, oc in enumerate(cells):
+            ost, ons, onc = oc.mc_coag(K_BROWN, 15000.0, 4, c, step)
+            assert (ons, onc, ost) == (int(ns[c]), int(nc[c]), int(st[c])), (step, c)
+        assert list(blk.aero_state_total_particles()) == [int(oc.n_part[0]) for oc in cells]
+    ok, msg = parity.compare_state(blk, cells)
+    assert ok, msg
+    assert int(cells[0].n_part[0]) < 1500 * 0.7      # far past the compaction threshold
+    blk.close()
+
+
+def test_api_error_paths(wp):
+    blk = wp.CellBlock(2, 128, 1)
+    with pytest.raises(wp.PmcxError):          # aero_data must come before particles
+        blk.upload_cells(0, [0, 1, 2], np.ones((1, 2)))
+    blk.set_aero_data([1000.0])
+    with pytest.raises(wp.PmcxError):          # more particles than capacity
+        blk.upload_cells(0, [0, 200, 201], np.ones((1, 201)))
+    with pytest.raises(wp.PmcxError):          # env not set: bounds cannot be computed
+        blk.mc_coag(K_BROWN, 60.0)
+    blk.set_env(288.0, 101325.0)
+    with pytest.raises(wp.PmcxError):          # unknown kernel id
+        blk.mc_coag(42, 60.0)
+    blk.close()
