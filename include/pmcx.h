@@ -172,6 +172,18 @@ int pmcx_get_coag_totals(pmcx_ctx *ctx, int64_t *n_samp, int64_t *n_coag,
 int pmcx_rebalance(pmcx_ctx *ctx, int32_t allow_doubling, int32_t allow_halving,
                    uint64_t seed, uint32_t step);
 
+/*
+ * EXTENSION -- water condensation as a per-particle growth-ODE sub-step over
+ * del_t at each cell's (temp, pressure, rel_humid): kappa-Koehler equilibrium,
+ * Seinfeld & Pandis eq. 17.70 growth law, n_sub sub-steps.  The reference
+ * links condense.o but its timestep never calls the growth ODE
+ * (condense_equilib_particles only, inside optics, wrf_pmc_driver.F90:1181,1201);
+ * the BASELINE north_star names it, so it is provided as a labelled extension
+ * with its own oracle (parity unpinned).  Needs kappa (pmcx_set_aero_data),
+ * rel_humid (pmcx_set_env) and cfg.i_water >= 0.
+ */
+int pmcx_condense(pmcx_ctx *ctx, double del_t, int32_t n_sub);
+
 /* partmc_process observables (wrf_pmc_driver.F90:838-857):
  * tot_num_conc[n_cells], tot_mass_conc[n_cells],
  * num_dist[n_cells][n_dbin], mass_dist[n_cells][n_dbin]. */

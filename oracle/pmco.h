@@ -145,6 +145,11 @@ void pmco_generate(pmco_cell *c, const pmco_gen_spec *g, int32_t n,
                    uint64_t seed, uint32_t cell_id, int64_t first_id,
                    double create_time);
 
+/* EXTENSION (no call site on the reference's timestep): water condensation,
+ * kappa-Koehler growth ODE per particle, environment fixed over del_t. */
+void pmco_condense(pmco_cell *c, const double *kappa /*[n_spec]*/, int i_water,
+                   double rel_humid, double del_t, int n_sub);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,9 @@ def lib():
         L.pmco_generate.restype = None
         L.pmco_generate.argtypes = [C.POINTER(CellStruct), C.POINTER(GenSpec), C.c_int32,
                                     C.c_uint64, C.c_uint32, C.c_int64, C.c_double]
+        L.pmco_condense.restype = None
+        L.pmco_condense.argtypes = [C.POINTER(CellStruct), _dp, C.c_int, C.c_double, C.c_double,
+                                    C.c_int]
         L.pmco_refresh_caches.restype = None
         L.pmco_refresh_caches.argtypes = [C.POINTER(CellStruct)]
         _LIB = L
@@ -172,6 +175,11 @@ class Cell:
         st = lib().pmco_rebalance(C.byref(self.view()), _p(ni, _dp), int(allow_doubling),
                                   int(allow_halving), seed, cell_id, step, C.byref(nid))
         return st, nid.value
+
+    def condense(self, kappa, i_water, rel_humid, del_t, n_sub=4):
+        k = np.ascontiguousarray(kappa, dtype=np.float64)
+        lib().pmco_condense(C.byref(self.view()), _p(k, _dp), int(i_water), float(rel_humid),
+                            float(del_t), int(n_sub))
 
     def diagnostics(self, i_water, d_edge, d_width):
         n = len(d_width)

@@ -340,3 +340,44 @@ def test_api_error_paths(wp):
     with pytest.raises(wp.PmcxError):          # unknown kernel id
         blk.mc_coag(42, 60.0)
     blk.close()
+
+
+def test_condensation_extension_parity(wp, oracle):
+    """EXTENSION (no reference call site): water uptake, GPU vs oracle bit for bit, then
+    coagulation of the wet population."""
+    n_cells, n_part, n_spec = 4, 2000, 3
+    dens = np.array([1770.0, 1700.0, 1000.0]); kappa = np.array([0.65, 0.0, 0.0])
+    blk = wp.CellBlock(n_cells, 2048, n_spec, i_water=2)
+    blk.set_aero_data(dens, kappa=kappa)
+    temp = np.array([290.0, 280.0, 265.0, 240.0]); pres = np.array([101325.0, 9e4, 7e4, 4e4])
+    rh = np.array([0.3, 0.7, 0.9, 0.95])
+    blk.set_env(temp, pres, rh)
+    blk.set_weights(np.full((n_cells, 1), 5e9 / n_part))
+    ve, vs = blk.bin_tables()
+    modes = [dict(frac=1, gm_radius=4e-8, gsd_log10=0.35, vol_frac=[0.6, 0.4, 0.0])]
+    blk.generate_lognormal(n_part, modes, seed=5)
+    cells = []
+    for c in range(n_cells):
+        oc = oracle.Cell(n_spec, 1, 0, 2048, dens, ve, temp[c], pres[c],
+                         max_events=blk.cfg.max_events, max_appends=blk.cfg.max_appends)
+        oc.mag[:] = 5e9 / n_part
+        oc.generate(modes, n_part, 5, c, first_id=c << 32)
+        oc.kmax[:] = oracle.kmax_table(K_BROWN, vs, dens.min(), dens.max(), temp[c], pres[c])
+        cells.append(oc)
+    for step, dt in enumerate([0.05, 60.0]):
+        blk.condense(dt, 4)
+        for c, oc in enumerate(cells):
+            oc.condense(kappa, 2, rh[c], dt, 4)
+        ok, msg = parity.compare_state(blk, cells)
+        assert ok, f"after condense {step}: {msg}"
+        ns, nc, st = blk.mc_coag(K_BROWN, 1200.0, 5, step)
+        for c, oc in enumerate(cells):
+            assert oc.mc_coag(K_BROWN, 1200.0, 5, c, step) == (int(st[c]), int(ns[c]), int(nc[c]))
+        ok, msg = parity.compare_state(blk, cells)
+        assert ok, f"after coag {step}: {msg}"
+    # physics: water present, more of it at higher RH; dry species untouched by condensation
+    dn = blk.download_cells()
+    wet_frac = [dn["vol"][2, dn["part_offset"][c]:dn["part_offset"][c + 1]].sum() /
+                dn["vol"][:2, dn["part_offset"][c]:dn["part_offset"][c + 1]].sum() for c in range(4)]
+    assert wet_frac[0] < wet_frac[1] < wet_frac[2] < wet_frac[3]
+    blk.close()

@@ -357,3 +357,34 @@ def test_golden_event_log(oracle):
     assert got["n_part"] == gold["n_part"]
     assert got["vol_checksum"] == gold["vol_checksum"]
     assert got["id_checksum"] == gold["id_checksum"]
+
+
+# ------------------------------------------------ condensation (extension)
+
+def test_condensation_reaches_koehler_equilibrium(oracle):
+    dens = np.array([1770.0, 1700.0, 1000.0]); kappa = np.array([0.65, 0.0, 0.0])
+    ve, _ = oracle.make_bin_tables(80, 1e-10, 1e-2)
+    T = 288.15
+    c = oracle.Cell(3, 1, 0, 1024, dens, ve, T, 101325.0)
+    c.generate([dict(frac=1, gm_radius=5e-8, gsd_log10=0.4, vol_frac=[0.7, 0.3, 0.0])], 1000, 1, 0)
+    dry = c.vol[:2, :1000].copy()
+    A = 4 * 0.073 * 18e-3 / (8.314472 * T * 1000.0)
+    for RH in (0.5, 0.9, 0.3):
+        c.condense(kappa, 2, RH, 600.0, 4)
+        assert np.array_equal(c.vol[:2, :1000], dry)              # dry species untouched
+        vd = dry.sum(0); d3 = (vd + c.vol[2, :1000]) * 6 / np.pi; dd3 = vd * 6 / np.pi
+        D = np.cbrt(d3); keff = 0.65 * dry[0] / vd
+        s_eq = (d3 - dd3) / (d3 - dd3 * (1 - keff)) * np.exp(A / D)
+        np.testing.assert_allclose(s_eq, RH, rtol=2e-6)            # kappa-Koehler equilibrium
+    # kinetic limitation: a very short step leaves large particles short of equilibrium
+    c.condense(kappa, 2, 0.95, 600.0, 4)
+    w_eq = c.vol[2, :1000].copy()
+    c.condense(kappa, 2, 0.3, 600.0, 4)
+    c.condense(kappa, 2, 0.95, 1e-4, 4)
+    big = np.argsort(dry.sum(0))[-20:]
+    assert (c.vol[2, big] < 0.9 * w_eq[big]).all() and (c.vol[2, big] > 0).all()
+    # kappa = 0 particles take no water
+    c2 = oracle.Cell(3, 1, 0, 64, dens, ve, T, 101325.0)
+    c2.generate([dict(frac=1, gm_radius=5e-8, gsd_log10=0.2, vol_frac=[0.0, 1.0, 0.0])], 50, 1, 0)
+    c2.condense(kappa, 2, 0.9, 600.0, 4)
+    assert not c2.vol[2, :50].any()

@@ -38,6 +38,8 @@ struct pmcx_ctx {
     std::vector<void *> allocs;
     // model tables, host copies
     std::vector<double> v_edge, v_samp, d_edge, d_width, density;
+    double *d_kappa = nullptr;
+    bool kappa_set = false;
     double *d_density = nullptr, *d_v_edge = nullptr, *d_v_samp = nullptr, *d_d_edge = nullptr,
            *d_d_width = nullptr;
     double *d_temp = nullptr, *d_pressure = nullptr, *d_rh = nullptr, *d_n_ideal = nullptr;
@@ -274,6 +276,7 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
     int rc = PMCX_OK;
 #define A_(ptr, count) if (rc == PMCX_OK) rc = dev_alloc(ctx, &(ptr), (count))
     A_(ctx->d_density, (size_t)cfg->n_spec);
+    A_(ctx->d_kappa, (size_t)cfg->n_spec);
     A_(ctx->d_v_edge, (size_t)B + 1);
     A_(ctx->d_v_samp, (size_t)3 * B);
     A_(ctx->d_d_edge, (size_t)nd + 1);
@@ -363,7 +366,7 @@ int pmcx_memory_bytes(pmcx_ctx *ctx, int64_t *bytes)
 int pmcx_set_aero_data(pmcx_ctx *ctx, const double *density, const double *kappa,
                        const double *molec_weight)
 {
-    (void)kappa; (void)molec_weight;
+    (void)molec_weight;
     if (!ctx || !density) return fail(ctx, PMCX_EINVAL, "pmcx_set_aero_data: null argument");
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     ctx->density.assign(density, density + ctx->cfg.n_spec);
@@ -376,6 +379,11 @@ int pmcx_set_aero_data(pmcx_ctx *ctx, const double *density, const double *kappa
     ctx->st.rho_min = lo; ctx->st.rho_max = hi;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_density, density, sizeof(double) * ctx->cfg.n_spec,
                                 hipMemcpyHostToDevice, ctx->stream));
+    if (kappa) {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_kappa, kappa, sizeof(double) * ctx->cfg.n_spec,
+                                    hipMemcpyHostToDevice, ctx->stream));
+        ctx->kappa_set = true;
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->aero_data_set = true;
     ctx->bounds_kernel = 0;
@@ -700,6 +708,20 @@ int pmcx_rebalance(pmcx_ctx *ctx, int32_t allow_doubling, int32_t allow_halving,
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     ProfScope ps(ctx, "rebalance");
     HIP_TRY(ctx, launch_rebalance(ctx->st, allow_doubling, allow_halving, seed, step, ctx->stream));
+    ctx->sorted_valid = false;
+    return PMCX_OK;
+}
+
+int pmcx_condense(pmcx_ctx *ctx, double del_t, int32_t n_sub)
+{
+    if (!ctx) return PMCX_EINVAL;
+    if (ctx->cfg.i_water < 0) return fail(ctx, PMCX_ESTATE, "pmcx_condense: config has no water species (i_water < 0)");
+    if (!ctx->kappa_set || !ctx->env_set)
+        return fail(ctx, PMCX_ESTATE, "pmcx_condense: kappa (pmcx_set_aero_data) and env (pmcx_set_env) must be set");
+    if (!(del_t >= 0) || n_sub < 1) return fail(ctx, PMCX_EINVAL, "pmcx_condense: bad del_t or n_sub");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    ProfScope ps(ctx, "condense");
+    HIP_TRY(ctx, launch_condense(ctx->st, ctx->d_kappa, ctx->d_rh, del_t, n_sub, ctx->stream));
     ctx->sorted_valid = false;
     return PMCX_OK;
 }

@@ -367,4 +367,72 @@ __device__ __forceinline__ int bin_of(EdgePtr v_edge, int n_bin, double v)
     return lo;
 }
 
+// ------------------------------------------------------------ condensation
+//
+// EXTENSION: the growth ODE has no call site on the reference's timestep
+// (condense_equilib_particles is called only inside the optional optics
+// diagnostics, interface/wrf_pmc_driver.F90:1181,1201).  Seinfeld & Pandis
+// eq. 17.70 with kappa-Koehler equilibrium:
+//   D dD/dt = 4 (RH - a_w exp(A/D)) / (F_d + F_k),
+//   a_w = (D^3 - Dd^3)/(D^3 - Dd^3 (1 - kappa)).
+
+constexpr double WATER_MW = 18e-3;
+constexpr double WATER_DENSITY = 1000.0;
+constexpr double WATER_SURF_ENG = 0.073;
+constexpr double WATER_LATENT = 2.272e6;
+constexpr double AIR_CP = 1005.0;
+
+struct CondEnv {
+    double rh, kelvin_a, fd_coef, fk, dv, ka, c_dv, c_ka;
+};
+
+__device__ inline CondEnv cond_env_derive(double temp, double pressure, double rh)
+{
+    CondEnv e;
+    const double R = UNIV_GAS;
+    const double p_sat =
+        611.0 * det_exp(2.302585092994046 * (7.45 * (temp - 273.15) / (temp - 38.0)));
+    const double dv = 0.211e-4 / (pressure / 101325.0) * det_exp(1.94 * det_log(temp / 273.0));
+    const double ka = 1e-3 * (4.39 + 0.071 * temp);
+    const double rho_air = AIR_MW * pressure / (R * temp);
+    e.rh = rh;
+    e.kelvin_a = 4.0 * WATER_SURF_ENG * WATER_MW / (R * temp * WATER_DENSITY);
+    e.fd_coef = WATER_DENSITY * R * temp / (p_sat * WATER_MW);
+    e.fk = WATER_LATENT * WATER_DENSITY / temp * (WATER_LATENT * WATER_MW / (R * temp) - 1.0);
+    e.dv = dv;
+    e.ka = ka;
+    e.c_dv = 2.0 * dv * __builtin_sqrt(2.0 * PI * WATER_MW / (R * temp));
+    e.c_ka = 2.0 * ka / (rho_air * AIR_CP) * __builtin_sqrt(2.0 * PI * AIR_MW / (R * temp));
+    return e;
+}
+
+// D * dD/dt / D, i.e. dD/dt, at wet diameter d
+__device__ inline double cond_rate(double d, double dd3, double kappa, const CondEnv &e)
+{
+    const double d3 = d * d * d;
+    const double aw = (d3 - dd3) / (d3 - dd3 * (1.0 - kappa));
+    const double seq = aw * det_exp(e.kelvin_a / d);
+    const double dvp = e.dv / (1.0 + e.c_dv / d);
+    const double kap = e.ka / (1.0 + e.c_ka / d);
+    return 4.0 * (e.rh - seq) / (e.fd_coef / dvp + e.fk / kap) / d;
+}
+
+__device__ inline double cond_equilibrium(double dd, double dd3, double kappa, double d_min,
+                                          const CondEnv &e)
+{
+    const double gf3 = 1.0 + kappa * e.rh / (1.0 - e.rh);
+    double b = dd * det_cbrt(gf3);
+    if (b < d_min) b = d_min;
+    double a = d_min;
+    double fa = cond_rate(a, dd3, kappa, e), fb = cond_rate(b, dd3, kappa, e);
+    if (!(fa > 0.0) || !(fb < 0.0)) return fb >= 0.0 ? b : a;
+    for (int it = 0; it < 12; it++) {
+        const double x = (a * fb - b * fa) / (fb - fa);
+        const double fx = cond_rate(x, dd3, kappa, e);
+        if ((fx > 0.0) == (fb > 0.0)) { b = x; fb = fx; fa = fa * 0.5; }
+        else { a = b; fa = fb; b = x; fb = fx; }
+    }
+    return b;
+}
+
 } // namespace pmcx

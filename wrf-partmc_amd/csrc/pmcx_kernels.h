@@ -92,6 +92,8 @@ hipError_t launch_diagnostics(const DeviceState &st, double *tot_num, double *to
                               double *num_dist, double *mass_dist, hipStream_t s);
 hipError_t launch_generate(const DeviceState &st, const GenSpecDev &g, int n, uint64_t seed,
                            double create_time, hipStream_t s);
+hipError_t launch_condense(const DeviceState &st, const double *kappa, const double *rel_humid,
+                           double del_t, int n_sub, hipStream_t s);
 hipError_t launch_totals(const DeviceState &st, int64_t *out4, hipStream_t s);
 hipError_t launch_test_math(int op, int64_t n, const double *a, const double *b, const double *c3,
                             const double *c4, int ktype, double temp, double pressure,

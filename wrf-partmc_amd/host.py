@@ -26,7 +26,8 @@ EXPORTED_SYMBOLS = [
     "pmcx_set_aero_data", "pmcx_set_env", "pmcx_set_weights", "pmcx_get_weights",
     "pmcx_set_n_part_ideal", "pmcx_set_next_id", "pmcx_get_next_id", "pmcx_upload_cells",
     "pmcx_get_n_part", "pmcx_download_cells", "pmcx_update_kernel_bounds", "pmcx_mc_coag",
-    "pmcx_get_coag_counters", "pmcx_get_coag_totals", "pmcx_rebalance", "pmcx_diagnostics",
+    "pmcx_get_coag_counters", "pmcx_get_coag_totals", "pmcx_rebalance", "pmcx_condense",
+    "pmcx_diagnostics",
     "pmcx_generate_lognormal", "pmcx_timestep", "pmcx_get_bin_tables", "pmcx_get_diag_grid",
     "pmcx_get_kmax", "pmcx_get_caches", "pmcx_sort_only", "pmcx_get_sort", "pmcx_test_math",
     "pmcx_test_philox", "pmcx_profile_enable", "pmcx_profile_reset", "pmcx_profile_get",
@@ -96,6 +97,7 @@ def load_library():
     L.pmcx_create.argtypes = [C.POINTER(PmcxConfig), C.POINTER(C.c_void_p)]
     L.pmcx_mc_coag.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_uint64, C.c_uint32]
     L.pmcx_rebalance.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_uint32]
+    L.pmcx_condense.argtypes = [C.c_void_p, C.c_double, C.c_int32]
     L.pmcx_generate_lognormal.argtypes = [
         C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
         C.c_void_p, C.c_void_p, C.c_uint64, C.c_double]
@@ -283,6 +285,10 @@ class CellBlock:
     def aero_state_rebalance(self, allow_doubling=True, allow_halving=True, seed=0, step=0):
         self._ck(self._lib.pmcx_rebalance(self._h, int(allow_doubling), int(allow_halving), seed,
                                           step))
+
+    def condense(self, del_t, n_sub=4):
+        """EXTENSION: water condensation sub-step (see include/pmcx.h)."""
+        self._ck(self._lib.pmcx_condense(self._h, del_t, n_sub))
 
     def partmc_timestep(self, elapsed_time, dt, partmc_chem_dt, do_coagulation=True,
                         allow_doubling=True, allow_halving=True,
