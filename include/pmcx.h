@@ -173,6 +173,33 @@ int pmcx_rebalance(pmcx_ctx *ctx, int32_t allow_doubling, int32_t allow_halving,
                    uint64_t seed, uint32_t step);
 
 /*
+ * scenario_update_aero_state on every cell (wrf_pmc_driver.F90:207-210):
+ * emission of new particles from log-normal modes, loss by dilution, gain
+ * from the background.  An aero_dist is n_mode log-normal modes
+ * (gm_radius [m], gsd_log10, vol_frac[n_mode][n_spec], weight class, source)
+ * with a number concentration per cell and mode: emission rate [#/m^3/s] or
+ * background concentration [#/m^3], both [n_cells][n_mode].  dilution_rate
+ * [1/s] is [n_cells] (NULL: no dilution).  New particles get create_time =
+ * elapsed_time and ids from the cell's next_id.  Counters are [n_cells], any
+ * may be NULL.  Either dist may be NULL.  Synchronises.
+ */
+typedef struct {
+    int32_t n_mode;
+    const double *num_conc;    /* [n_cells][n_mode] */
+    const double *gm_radius;   /* [n_mode] */
+    const double *gsd_log10;   /* [n_mode] */
+    const double *vol_frac;    /* [n_mode][n_spec] */
+    const int32_t *mode_class; /* [n_mode] */
+    const int32_t *mode_source;/* [n_mode] */
+} pmcx_aero_dist;
+
+int pmcx_scenario_update_aero_state(pmcx_ctx *ctx, double dt, double elapsed_time, uint64_t seed,
+                                    uint32_t step, const pmcx_aero_dist *emission,
+                                    const double *dilution_rate,
+                                    const pmcx_aero_dist *background, int32_t *n_emit,
+                                    int32_t *n_dil_in, int32_t *n_dil_out);
+
+/*
  * EXTENSION -- water condensation as a per-particle growth-ODE sub-step over
  * del_t at each cell's (temp, pressure, rel_humid): kappa-Koehler equilibrium,
  * Seinfeld & Pandis eq. 17.70 growth law, n_sub sub-steps.  The reference

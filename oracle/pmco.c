@@ -698,3 +698,81 @@ void pmco_condense(pmco_cell *c, const double *kappa, int i_water, double rel_hu
         refresh_one(c, i);
     }
 }
+
+/* ------------------------------------------------------------------------
+ * scenario_update_aero_state (interface/wrf_pmc_driver.F90:207-210)
+ * [upstream, uncited: aero_state_add_aero_dist_sample for the emissions and
+ * the background, aero_state_sample_particles for the dilution loss].
+ *   emission   : per mode, Poisson(rate dt / magnitude(class)) new particles
+ *   dilution   : every particle is lost with probability 1 - exp(-rate dt)
+ *   background : per mode, Poisson((1 - exp(-rate dt)) N_bg / magnitude) new particles
+ * New particles are appended in order; ids come from next_id.
+ * ---------------------------------------------------------------------- */
+static int add_dist_sample(pmco_cell *c, const pmco_aero_dist *d, double factor, int kind,
+                           double create_time, uint64_t seed, uint32_t cell_id, uint32_t step,
+                           int64_t *next_id, int *status)
+{
+    int added = 0;
+    for (int m = 0; m < d->n_mode; m++) {
+        uint32_t w[4];
+        const int cl = d->mode_class[m];
+        const double mean = d->num_conc[m] * factor / c->mag[cl];
+        pmco_rng_block(seed, cell_id, step, ((uint32_t)kind << 8) | (uint32_t)m, PMCO_SITE_EMIT_N, 0, w);
+        int n = pmco_poisson(mean, pmco_u53(w[0], w[1]));
+        const int n0 = *c->n_part;
+        if (n0 + n > c->cap) { *status |= PMCO_ST_CAP_OVERFLOW; n = c->cap - n0; }
+        for (int k = 0; k < n; k++) {
+            const int i = n0 + k;
+            pmco_rng_block(seed, cell_id, step, ((uint32_t)kind << 28) | ((uint32_t)m << 20) | (uint32_t)k,
+                           PMCO_SITE_EMIT_P, 0, w);
+            double z = pmco_norminv(pmco_u53(w[2], w[3]));
+            double r = pmco_exp(d->ln_gm_radius[m] + d->ln_gsd[m] * z);
+            double v = (4.0 / 3.0) * PMCO_PI * r * r * r;
+            for (int s = 0; s < c->n_spec; s++)
+                c->vol[(size_t)s * c->cap + i] = d->vol_frac[m * c->n_spec + s] * v;
+            for (int s = 0; s < c->n_source; s++)
+                c->n_orig[(size_t)s * c->cap + i] = (s == d->mode_source[m]) ? 1 : 0;
+            c->wclass[i] = cl;
+            c->id[i] = *next_id + k;
+            c->lct[i] = create_time;
+            c->gct[i] = create_time;
+            refresh_one(c, i);
+        }
+        *next_id += n;
+        *c->n_part = n0 + n;
+        added += n;
+    }
+    return added;
+}
+
+int pmco_scenario_update(pmco_cell *c, double dt, double create_time, uint64_t seed,
+                         uint32_t cell_id, uint32_t step, const pmco_aero_dist *emission,
+                         double dilution_rate, const pmco_aero_dist *background,
+                         int64_t *next_id, int32_t *n_emit, int32_t *n_dil_in,
+                         int32_t *n_dil_out)
+{
+    int status = 0;
+    *n_emit = *n_dil_in = *n_dil_out = 0;
+    if (emission && emission->n_mode > 0)
+        *n_emit = add_dist_sample(c, emission, dt, 0, create_time, seed, cell_id, step, next_id,
+                                  &status);
+    if (dilution_rate > 0.0) {
+        const double p_loss = 1.0 - pmco_exp(-dilution_rate * dt);
+        const int n = *c->n_part;
+        unsigned char *dead = (unsigned char *)calloc((size_t)(n > 0 ? n : 1), 1);
+        int nd = 0;
+        for (int i = 0; i < n; i++) {
+            uint32_t w[4];
+            pmco_rng_block(seed, cell_id, step, (uint32_t)i, PMCO_SITE_DILUTE, 0, w);
+            if (pmco_u53(w[0], w[1]) < p_loss) { dead[i] = 1; nd++; }
+        }
+        compact_stable(c, dead, n, nd);
+        free(dead);
+        *n_dil_out = nd;
+        if (background && background->n_mode > 0)
+            *n_dil_in = add_dist_sample(c, background, p_loss, 1, create_time, seed, cell_id, step,
+                                        next_id, &status);
+    }
+    return status;
+}
+

@@ -145,6 +145,26 @@ void pmco_generate(pmco_cell *c, const pmco_gen_spec *g, int32_t n,
                    uint64_t seed, uint32_t cell_id, int64_t first_id,
                    double create_time);
 
+/* scenario_update_aero_state (call: wrf_pmc_driver.F90:207-210): emission of
+ * new particles from log-normal modes, loss by dilution, gain from the
+ * background.  Rates are number concentrations: emission [#/m^3/s],
+ * background [#/m^3]; dilution_rate [1/s]. */
+typedef struct {
+    int32_t n_mode;
+    const double *num_conc;      /* [n_mode] rate (emission) or concentration (background) */
+    const double *ln_gm_radius;  /* [n_mode] */
+    const double *ln_gsd;        /* [n_mode] */
+    const double *vol_frac;      /* [n_mode][n_spec] */
+    const int32_t *mode_class;   /* [n_mode] */
+    const int32_t *mode_source;  /* [n_mode] */
+} pmco_aero_dist;
+
+int pmco_scenario_update(pmco_cell *c, double dt, double create_time, uint64_t seed,
+                         uint32_t cell_id, uint32_t step, const pmco_aero_dist *emission,
+                         double dilution_rate, const pmco_aero_dist *background,
+                         int64_t *next_id, int32_t *n_emit, int32_t *n_dil_in,
+                         int32_t *n_dil_out);
+
 /* EXTENSION (no call site on the reference's timestep): water condensation,
  * kappa-Koehler growth ODE per particle, environment fixed over del_t. */
 void pmco_condense(pmco_cell *c, const double *kappa /*[n_spec]*/, int i_water,

@@ -57,7 +57,10 @@ enum {
     PMCO_SITE_COAG    = 3,  /* weighted removal draws of an accepted pair */
     PMCO_SITE_HALVE   = 4,  /* rebalance: keep/drop one particle          */
     PMCO_SITE_GEN     = 5,  /* synthetic generator: one particle          */
-    PMCO_SITE_GENCLS  = 6   /* synthetic generator: weight class draw     */
+    PMCO_SITE_GENCLS  = 6,  /* synthetic generator: weight class draw     */
+    PMCO_SITE_EMIT_N  = 7,  /* scenario: number of new particles of a mode */
+    PMCO_SITE_EMIT_P  = 8,  /* scenario: one new particle                  */
+    PMCO_SITE_DILUTE  = 9   /* scenario: keep/drop one particle (dilution) */
 };
 
 /* One 128-bit block of the stream: counter = (cell, step, a, site<<28 | b),

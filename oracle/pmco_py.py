@@ -38,6 +38,13 @@ class CellStruct(C.Structure):
     ]
 
 
+class AeroDist(C.Structure):
+    _fields_ = [
+        ("n_mode", C.c_int32), ("num_conc", _dp), ("ln_gm_radius", _dp), ("ln_gsd", _dp),
+        ("vol_frac", _dp), ("mode_class", _ip), ("mode_source", _ip),
+    ]
+
+
 class GenSpec(C.Structure):
     _fields_ = [
         ("n_mode", C.c_int32), ("mode_frac", _dp), ("ln_gm_radius", _dp),
@@ -77,6 +84,10 @@ def lib():
         L.pmco_generate.restype = None
         L.pmco_generate.argtypes = [C.POINTER(CellStruct), C.POINTER(GenSpec), C.c_int32,
                                     C.c_uint64, C.c_uint32, C.c_int64, C.c_double]
+        L.pmco_scenario_update.restype = C.c_int
+        L.pmco_scenario_update.argtypes = [
+            C.POINTER(CellStruct), C.c_double, C.c_double, C.c_uint64, C.c_uint32, C.c_uint32,
+            C.POINTER(AeroDist), C.c_double, C.POINTER(AeroDist), _lp, _ip, _ip, _ip]
         L.pmco_condense.restype = None
         L.pmco_condense.argtypes = [C.POINTER(CellStruct), _dp, C.c_int, C.c_double, C.c_double,
                                     C.c_int]
@@ -175,6 +186,34 @@ class Cell:
         st = lib().pmco_rebalance(C.byref(self.view()), _p(ni, _dp), int(allow_doubling),
                                   int(allow_halving), seed, cell_id, step, C.byref(nid))
         return st, nid.value
+
+    @staticmethod
+    def _dist(modes):
+        if not modes:
+            return None, None
+        keep = dict(
+            nc=np.array([m["num_conc"] for m in modes], dtype=np.float64),
+            lg=np.array([np.log(m["gm_radius"]) for m in modes], dtype=np.float64),
+            ls=np.array([m["gsd_log10"] * np.log(10.0) for m in modes], dtype=np.float64),
+            vf=np.ascontiguousarray([m["vol_frac"] for m in modes], dtype=np.float64),
+            mc=np.array([m.get("wclass", 0) for m in modes], dtype=np.int32),
+            ms=np.array([m.get("source", 0) for m in modes], dtype=np.int32))
+        d = AeroDist(len(modes), _p(keep["nc"], _dp), _p(keep["lg"], _dp), _p(keep["ls"], _dp),
+                     _p(keep["vf"], _dp), _p(keep["mc"], _ip), _p(keep["ms"], _ip))
+        return d, keep
+
+    def scenario_update(self, dt, create_time, seed, cell_id, step, emission, dilution_rate,
+                        background, next_id):
+        """emission/background: lists of dict(num_conc, gm_radius, gsd_log10, vol_frac, wclass, source)."""
+        e, ke = self._dist(emission)
+        b, kb = self._dist(background)
+        nid = C.c_int64(next_id)
+        ne, ni, no = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        st = lib().pmco_scenario_update(C.byref(self.view()), dt, create_time, seed, cell_id, step,
+                                        C.byref(e) if e else None, dilution_rate,
+                                        C.byref(b) if b else None, C.byref(nid), C.byref(ne),
+                                        C.byref(ni), C.byref(no))
+        return st, nid.value, ne.value, ni.value, no.value
 
     def condense(self, kappa, i_water, rel_humid, del_t, n_sub=4):
         k = np.ascontiguousarray(kappa, dtype=np.float64)

@@ -381,3 +381,36 @@ def test_condensation_extension_parity(wp, oracle):
                 dn["vol"][:2, dn["part_offset"][c]:dn["part_offset"][c + 1]].sum() for c in range(4)]
     assert wet_frac[0] < wet_frac[1] < wet_frac[2] < wet_frac[3]
     blk.close()
+
+
+def test_scenario_update_parity(wp, oracle):
+    """scenario_update_aero_state (driver:207-210): emission, dilution, background."""
+    n_cells, n_part, n_spec, n_class = 3, 800, 2, 2
+    blk, cells, info = parity.setup_pair(wp, oracle, n_cells, n_part, n_spec, n_class, 8, K_BROWN,
+                                         cap=4096, n_source=3)
+    mag = info["mag"]
+    em = [dict(gm_radius=2e-8, gsd_log10=0.2, vol_frac=[0.5, 0.5], wclass=0, source=1),
+          dict(gm_radius=1e-7, gsd_log10=0.1, vol_frac=[0.0, 1.0], wclass=1, source=2)]
+    bg = [dict(gm_radius=5e-8, gsd_log10=0.3, vol_frac=[1.0, 0.0], wclass=0, source=0)]
+    em_rate = np.array([[mag[c, 0] * 2.5, mag[c, 1] * 0.4] for c in range(n_cells)])   # per second
+    bg_conc = np.array([[mag[c, 0] * 900.0] for c in range(n_cells)])
+    dil = np.array([1e-3, 0.0, 4e-3])
+    for step in range(3):
+        ne, ni, no = blk.scenario_update_aero_state(60.0, 60.0 * step, 8, step, em, em_rate, dil,
+                                                    bg, bg_conc)
+        for c, oc in enumerate(cells):
+            oe = [dict(m, num_conc=em_rate[c, k]) for k, m in enumerate(em)]
+            ob = [dict(m, num_conc=bg_conc[c, k]) for k, m in enumerate(bg)]
+            st, oc.next_id, one, oni, ono = oc.scenario_update(60.0, 60.0 * step, 8, oc.cell_id, step,
+                                                               oe, dil[c], ob, oc.next_id)
+            assert (one, oni, ono) == (int(ne[c]), int(ni[c]), int(no[c])), (step, c)
+        ok, msg = parity.compare_state(blk, cells)
+        assert ok, f"step {step}: {msg}"
+        assert np.array_equal(blk.get_next_id(), [oc.next_id for oc in cells])
+        ns, nc, st = blk.mc_coag(K_BROWN, 600.0, 8, step)       # and the sort copes with the new tail
+        for c, oc in enumerate(cells):
+            assert oc.mc_coag(K_BROWN, 600.0, 8, oc.cell_id, step) == (int(st[c]), int(ns[c]), int(nc[c]))
+    assert ne.min() > 50 and no[1] == 0 and ni[1] == 0 and no[0] > 0
+    ok, msg = parity.compare_state(blk, cells)
+    assert ok, msg
+    blk.close()

@@ -19,6 +19,7 @@ from .host import (  # noqa: F401
     CellBlock,
     PmcxConfig,
     PmcxError,
+    PmcxAeroDist,
     PmcxStepFlags,
     build_library,
     library_path,

@@ -712,6 +712,83 @@ int pmcx_rebalance(pmcx_ctx *ctx, int32_t allow_doubling, int32_t allow_halving,
     return PMCX_OK;
 }
 
+namespace {
+// uploads one aero_dist into a fresh device block; returns the device view
+int upload_dist(pmcx_ctx *ctx, const pmcx_aero_dist *d, std::vector<void *> &tmp, GenSpecDev &g,
+                double *&conc_dev)
+{
+    const int S = ctx->cfg.n_spec, M = d->n_mode;
+    const size_t nc = (size_t)ctx->cfg.n_cells;
+    if (M < 1 || M > 64 || !d->num_conc || !d->gm_radius || !d->gsd_log10 || !d->vol_frac)
+        return fail(ctx, PMCX_EINVAL, "aero_dist: bad n_mode or null array");
+    std::vector<double> h(2 * (size_t)M + (size_t)M * S);
+    std::vector<int32_t> hi(2 * (size_t)M);
+    for (int m = 0; m < M; m++) {
+        h[m] = std::log(d->gm_radius[m]);
+        h[M + m] = d->gsd_log10[m] * std::log(10.0);
+        for (int s = 0; s < S; s++) h[2 * M + (size_t)m * S + s] = d->vol_frac[(size_t)m * S + s];
+        hi[m] = d->mode_class ? d->mode_class[m] : 0;
+        hi[M + m] = d->mode_source ? d->mode_source[m] : 0;
+        if (hi[m] < 0 || hi[m] >= ctx->cfg.n_class)
+            return fail(ctx, PMCX_EINVAL, "aero_dist: mode_class[%d] out of range", m);
+    }
+    double *dd = nullptr; int32_t *di = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&dd, sizeof(double) * h.size())); tmp.push_back(dd);
+    HIP_TRY(ctx, hipMalloc((void **)&di, sizeof(int32_t) * hi.size())); tmp.push_back(di);
+    HIP_TRY(ctx, hipMalloc((void **)&conc_dev, sizeof(double) * nc * M)); tmp.push_back(conc_dev);
+    HIP_TRY(ctx, hipMemcpyAsync(dd, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(di, hi.data(), sizeof(int32_t) * hi.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(conc_dev, d->num_conc, sizeof(double) * nc * M, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    g.n_mode = M; g.mode_frac = nullptr;
+    g.ln_gm_radius = dd; g.ln_gsd = dd + M; g.vol_frac = dd + 2 * M;
+    g.mode_class = di; g.mode_source = di + M;
+    return PMCX_OK;
+}
+} // namespace
+
+int pmcx_scenario_update_aero_state(pmcx_ctx *ctx, double dt, double elapsed_time, uint64_t seed,
+                                    uint32_t step, const pmcx_aero_dist *emission,
+                                    const double *dilution_rate, const pmcx_aero_dist *background,
+                                    int32_t *n_emit, int32_t *n_dil_in, int32_t *n_dil_out)
+{
+    if (!ctx) return PMCX_EINVAL;
+    if (!ctx->aero_data_set) return fail(ctx, PMCX_ESTATE, "pmcx_set_aero_data must come first");
+    if (!(dt >= 0)) return fail(ctx, PMCX_EINVAL, "dt must be non-negative");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t nc = (size_t)ctx->cfg.n_cells;
+    std::vector<void *> tmp;
+    auto cleanup = [&]() { for (void *p : tmp) (void)hipFree(p); };
+    GenSpecDev ge{}, gb{};
+    double *ce = nullptr, *cbg = nullptr, *d_dil = nullptr;
+    int32_t *d_cnt = nullptr;
+    int rc = PMCX_OK;
+    if (emission) rc = upload_dist(ctx, emission, tmp, ge, ce);
+    if (!rc && background) rc = upload_dist(ctx, background, tmp, gb, cbg);
+    if (rc) { cleanup(); return rc; }
+    hipError_t e = hipSuccess;
+    if (dilution_rate) {
+        e = hipMalloc((void **)&d_dil, sizeof(double) * nc);
+        if (e == hipSuccess) { tmp.push_back(d_dil); e = hipMemcpyAsync(d_dil, dilution_rate, sizeof(double) * nc, hipMemcpyHostToDevice, ctx->stream); }
+    }
+    if (e == hipSuccess) { e = hipMalloc((void **)&d_cnt, sizeof(int32_t) * 3 * nc); if (e == hipSuccess) tmp.push_back(d_cnt); }
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->st.status, 0, sizeof(int32_t) * nc, ctx->stream);
+    if (e == hipSuccess) {
+        ProfScope ps(ctx, "scenario");
+        e = launch_scenario_update(ctx->st, dt, elapsed_time, seed, step, emission ? &ge : nullptr, ce,
+                                   d_dil, background ? &gb : nullptr, cbg, d_cnt, d_cnt + nc,
+                                   d_cnt + 2 * nc, ctx->stream);
+    }
+    if (e == hipSuccess && n_emit) e = hipMemcpyAsync(n_emit, d_cnt, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && n_dil_in) e = hipMemcpyAsync(n_dil_in, d_cnt + nc, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && n_dil_out) e = hipMemcpyAsync(n_dil_out, d_cnt + 2 * nc, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    cleanup();
+    ctx->sorted_valid = false;
+    if (e != hipSuccess) return fail(ctx, PMCX_EDEVICE, "pmcx_scenario_update_aero_state: %s", hipGetErrorString(e));
+    return PMCX_OK;
+}
+
 int pmcx_condense(pmcx_ctx *ctx, double del_t, int32_t n_sub)
 {
     if (!ctx) return PMCX_EINVAL;

@@ -41,7 +41,10 @@ enum : uint32_t {
     SITE_COAG = 3,
     SITE_HALVE = 4,
     SITE_GEN = 5,
-    SITE_GENCLS = 6
+    SITE_GENCLS = 6,
+    SITE_EMIT_N = 7,
+    SITE_EMIT_P = 8,
+    SITE_DILUTE = 9
 };
 
 // counter = (cell, step, a, site<<28 | b); key = seed

@@ -92,6 +92,11 @@ hipError_t launch_diagnostics(const DeviceState &st, double *tot_num, double *to
                               double *num_dist, double *mass_dist, hipStream_t s);
 hipError_t launch_generate(const DeviceState &st, const GenSpecDev &g, int n, uint64_t seed,
                            double create_time, hipStream_t s);
+hipError_t launch_scenario_update(const DeviceState &st, double dt, double create_time, uint64_t seed,
+                                  uint32_t step, const GenSpecDev *em, const double *em_conc,
+                                  const double *dilution_rate, const GenSpecDev *bg,
+                                  const double *bg_conc, int32_t *n_emit, int32_t *n_dil_in,
+                                  int32_t *n_dil_out, hipStream_t s);
 hipError_t launch_condense(const DeviceState &st, const double *kappa, const double *rel_humid,
                            double del_t, int n_sub, hipStream_t s);
 hipError_t launch_totals(const DeviceState &st, int64_t *out4, hipStream_t s);

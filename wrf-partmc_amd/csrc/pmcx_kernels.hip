@@ -1112,6 +1112,129 @@ __global__ __launch_bounds__(256) void k_diagnostics(DeviceState st, double *tot
     }
 }
 
+// ----------------------------------------------------------------- scenario
+//
+// scenario_update_aero_state (interface/wrf_pmc_driver.F90:207-210)
+// [upstream: aero_state_add_aero_dist_sample, aero_state_sample_particles]:
+// emission of new particles from log-normal modes, loss by dilution, gain
+// from the background.  One wavefront per cell; new particles are appended in
+// order at n_hi, lost ones become tombstones.
+
+struct AeroDistDev {
+    int32_t n_mode;
+    const double *num_conc;     // [n_cells][n_mode]
+    const double *ln_gm_radius, *ln_gsd, *vol_frac;
+    const int32_t *mode_class, *mode_source;
+};
+
+// appends Poisson(num_conc*factor/magnitude) particles per mode; returns how many
+__device__ int add_dist_sample(const DeviceState &st, int c, const AeroDistDev &d, double factor,
+                               uint32_t kind, double create_time, uint64_t seed, uint32_t step,
+                               int &status, int lane)
+{
+    const int64_t cb = (int64_t)c * st.cap;
+    const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
+    const double *mag = st.mag + (int64_t)c * st.n_class;
+    int added = 0;
+    for (int m = 0; m < d.n_mode; m++) {
+        uint32_t w[4];
+        const int cl = d.mode_class[m];
+        const double mean = d.num_conc[(int64_t)c * d.n_mode + m] * factor / mag[cl];
+        rng_block(seed, cell_id, step, (kind << 8) | (uint32_t)m, SITE_EMIT_N, 0, w);
+        int n = poisson(mean, u53(w[0], w[1]));
+        int n_hi = st.n_hi[c];
+        if (n_hi + n > st.cap && n_hi > st.n_part[c]) { compact_wave(st, c, lane); n_hi = st.n_hi[c]; }
+        if (n_hi + n > st.cap) { status |= ST_CAP_OVERFLOW; n = st.cap - n_hi; }
+        const int64_t nid = st.next_id[c];
+        for (int k = lane; k < n; k += 64) {
+            const int i = n_hi + k;
+            rng_block(seed, cell_id, step, (kind << 28) | ((uint32_t)m << 20) | (uint32_t)k, SITE_EMIT_P, 0, w);
+            const double z = det_norminv(u53(w[2], w[3]));
+            const double r = det_exp(d.ln_gm_radius[m] + d.ln_gsd[m] * z);
+            const double v = (4.0 / 3.0) * PI * r * r * r;
+            double vt = 0.0, ms = 0.0;
+            for (int s = 0; s < st.n_spec; s++) {
+                const double vs = d.vol_frac[m * st.n_spec + s] * v;
+                st.vol[cb * st.n_spec + (int64_t)s * st.cap + i] = vs;
+                vt = vt + vs;
+                ms = ms + st.density[s] * vs;
+            }
+            for (int s = 0; s < st.n_source; s++)
+                st.n_orig[cb * st.n_source + (int64_t)s * st.cap + i] = (s == d.mode_source[m]) ? 1 : 0;
+            st.vtot[cb + i] = vt;
+            st.mass[cb + i] = ms;
+            st.wclass[cb + i] = cl;
+            st.id[cb + i] = nid + k;
+            st.lct[cb + i] = create_time;
+            st.gct[cb + i] = create_time;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_sync();
+        if (lane == 0) {
+            st.next_id[c] = nid + n;
+            st.n_hi[c] = n_hi + n;
+            st.n_part[c] = st.n_part[c] + n;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __threadfence_block();
+        wave_sync();
+        added += n;
+    }
+    return added;
+}
+
+__global__ __launch_bounds__(64) void k_scenario_update(DeviceState st, double dt, double create_time,
+                                                        uint64_t seed, uint32_t step,
+                                                        AeroDistDev emission, const double *dilution_rate,
+                                                        AeroDistDev background, int32_t *n_emit,
+                                                        int32_t *n_dil_in, int32_t *n_dil_out)
+{
+    const int lane = threadIdx.x;
+    const int c = blockIdx.x;
+    const int64_t cb = (int64_t)c * st.cap;
+    const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    int status = 0, ne = 0, ni = 0, no = 0;
+    if (emission.n_mode > 0)
+        ne = add_dist_sample(st, c, emission, dt, 0u, create_time, seed, step, status, lane);
+    const double rate = dilution_rate ? dilution_rate[c] : 0.0;
+    if (rate > 0.0) {
+        const double p_loss = 1.0 - det_exp(-rate * dt);
+        const int n_hi = st.n_hi[c];
+        uint32_t rank0 = 0;
+        for (int i0 = 0; i0 < n_hi; i0 += 64) {
+            const int i = i0 + lane;
+            const int wc = i < n_hi ? (int32_t)ld_u32((const uint32_t *)&st.wclass[cb + i]) : -1;
+            const uint64_t mlive = __ballot(wc >= 0);
+            bool drop = false;
+            if (wc >= 0) {
+                uint32_t w[4];
+                rng_block(seed, cell_id, step, rank0 + (uint32_t)__popcll(mlive & lt), SITE_DILUTE, 0, w);
+                drop = u53(w[0], w[1]) < p_loss;
+            }
+            if (drop) mark_dead(st, cb, i);
+            no += __popcll(__ballot(drop));
+            rank0 += (uint32_t)__popcll(mlive);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_sync();
+        if (lane == 0) st.n_part[c] = st.n_part[c] - no;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __threadfence_block();
+        wave_sync();
+        if (background.n_mode > 0)
+            ni = add_dist_sample(st, c, background, p_loss, 1u, create_time, seed, step, status, lane);
+        const int hi = st.n_hi[c], live = st.n_part[c];
+        if ((hi - live) * 8 > hi) compact_wave(st, c, lane);
+    }
+    if (lane == 0) {
+        if (n_emit) n_emit[c] = ne;
+        if (n_dil_in) n_dil_in[c] = ni;
+        if (n_dil_out) n_dil_out[c] = no;
+        if (status) atomicOr(&st.status[c], status);
+    }
+}
+
 // ------------------------------------------------------------- condensation
 //
 // EXTENSION (see pmcx_device_math.h): water uptake of every live particle over
@@ -1446,6 +1569,21 @@ hipError_t launch_generate(const DeviceState &st, const GenSpecDev &g, int n, ui
 {
     hipLaunchKernelGGL(k_generate, grid2(n, st.n_cells), dim3(256), 0, s, st, g, n, seed,
                        create_time);
+    return hipGetLastError();
+}
+hipError_t launch_scenario_update(const DeviceState &st, double dt, double create_time, uint64_t seed,
+                                  uint32_t step, const GenSpecDev *em, const double *em_conc,
+                                  const double *dilution_rate, const GenSpecDev *bg,
+                                  const double *bg_conc, int32_t *n_emit, int32_t *n_dil_in,
+                                  int32_t *n_dil_out, hipStream_t s)
+{
+    AeroDistDev e{0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, b = e;
+    if (em) e = AeroDistDev{em->n_mode, em_conc, em->ln_gm_radius, em->ln_gsd, em->vol_frac,
+                            em->mode_class, em->mode_source};
+    if (bg) b = AeroDistDev{bg->n_mode, bg_conc, bg->ln_gm_radius, bg->ln_gsd, bg->vol_frac,
+                            bg->mode_class, bg->mode_source};
+    hipLaunchKernelGGL(k_scenario_update, dim3(st.n_cells), dim3(64), 0, s, st, dt, create_time,
+                       seed, step, e, dilution_rate, b, n_emit, n_dil_in, n_dil_out);
     return hipGetLastError();
 }
 hipError_t launch_condense(const DeviceState &st, const double *kappa, const double *rel_humid,

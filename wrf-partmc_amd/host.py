@@ -27,6 +27,7 @@ EXPORTED_SYMBOLS = [
     "pmcx_set_n_part_ideal", "pmcx_set_next_id", "pmcx_get_next_id", "pmcx_upload_cells",
     "pmcx_get_n_part", "pmcx_download_cells", "pmcx_update_kernel_bounds", "pmcx_mc_coag",
     "pmcx_get_coag_counters", "pmcx_get_coag_totals", "pmcx_rebalance", "pmcx_condense",
+    "pmcx_scenario_update_aero_state",
     "pmcx_diagnostics",
     "pmcx_generate_lognormal", "pmcx_timestep", "pmcx_get_bin_tables", "pmcx_get_diag_grid",
     "pmcx_get_kmax", "pmcx_get_caches", "pmcx_sort_only", "pmcx_get_sort", "pmcx_test_math",
@@ -48,6 +49,14 @@ class PmcxConfig(C.Structure):
         ("n_dbin", C.c_int32), ("i_water", C.c_int32), ("d_min", C.c_double),
         ("d_max", C.c_double), ("cell_id_base", C.c_uint32), ("reserved", C.c_uint32),
         ("const_k", C.c_double), ("additive_beta", C.c_double),
+    ]
+
+
+class PmcxAeroDist(C.Structure):
+    _fields_ = [
+        ("n_mode", C.c_int32), ("num_conc", C.c_void_p), ("gm_radius", C.c_void_p),
+        ("gsd_log10", C.c_void_p), ("vol_frac", C.c_void_p), ("mode_class", C.c_void_p),
+        ("mode_source", C.c_void_p),
     ]
 
 
@@ -98,6 +107,9 @@ def load_library():
     L.pmcx_mc_coag.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_uint64, C.c_uint32]
     L.pmcx_rebalance.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_uint32]
     L.pmcx_condense.argtypes = [C.c_void_p, C.c_double, C.c_int32]
+    L.pmcx_scenario_update_aero_state.argtypes = [
+        C.c_void_p, C.c_double, C.c_double, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pmcx_generate_lognormal.argtypes = [
         C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
         C.c_void_p, C.c_void_p, C.c_uint64, C.c_double]
@@ -285,6 +297,37 @@ class CellBlock:
     def aero_state_rebalance(self, allow_doubling=True, allow_halving=True, seed=0, step=0):
         self._ck(self._lib.pmcx_rebalance(self._h, int(allow_doubling), int(allow_halving), seed,
                                           step))
+
+    def _aero_dist(self, modes, num_conc):
+        """modes: list of dict(gm_radius, gsd_log10, vol_frac, wclass, source);
+        num_conc: [n_cells][n_mode] (or broadcastable)."""
+        if not modes:
+            return None, None
+        keep = dict(
+            nc=np.broadcast_to(_f64(num_conc), (self.cfg.n_cells, len(modes))).copy(),
+            gm=_f64([m["gm_radius"] for m in modes]), gs=_f64([m["gsd_log10"] for m in modes]),
+            vf=_f64([m["vol_frac"] for m in modes]),
+            mc=np.array([m.get("wclass", 0) for m in modes], dtype=np.int32),
+            ms=np.array([m.get("source", 0) for m in modes], dtype=np.int32))
+        d = PmcxAeroDist(len(modes), keep["nc"].ctypes.data, keep["gm"].ctypes.data,
+                         keep["gs"].ctypes.data, keep["vf"].ctypes.data, keep["mc"].ctypes.data,
+                         keep["ms"].ctypes.data)
+        return d, keep
+
+    def scenario_update_aero_state(self, dt, elapsed_time, seed=0, step=0, emission=None,
+                                   emission_rate=None, dilution_rate=None, background=None,
+                                   background_conc=None):
+        """scenario_update_aero_state on every cell (driver:207-210).
+        Returns (n_emit, n_dil_in, n_dil_out) per cell."""
+        n = self.cfg.n_cells
+        e, ke = self._aero_dist(emission, emission_rate)
+        b, kb = self._aero_dist(background, background_conc)
+        dil = None if dilution_rate is None else np.broadcast_to(_f64(dilution_rate), (n,)).copy()
+        ne, ni, no = (np.zeros(n, dtype=np.int32) for _ in range(3))
+        self._ck(self._lib.pmcx_scenario_update_aero_state(
+            self._h, dt, elapsed_time, seed, step, C.addressof(e) if e else None, _ptr(dil),
+            C.addressof(b) if b else None, _ptr(ne), _ptr(ni), _ptr(no)))
+        return ne, ni, no
 
     def condense(self, del_t, n_sub=4):
         """EXTENSION: water condensation sub-step (see include/pmcx.h)."""
