@@ -29,6 +29,10 @@
 
 #include <cstdlib>
 
+#ifndef PMCX_WIN
+#define PMCX_WIN 8 // partner slots per sampler window (lanes-per-cell < 64)
+#endif
+
 namespace pmcx {
 
 // ---------------------------------------------------------------- helpers
@@ -476,6 +480,7 @@ struct Grp {
     {
         const uint64_t m = __ballot(p);
         if (L == 64) return m;
+        if (L == 1) return p ? 1ull : 0ull;
         return (m >> (sub * L)) & ((1ull << (L & 63)) - 1ull);
     }
     static __device__ __forceinline__ uint32_t incl_scan(uint32_t x, int gl)
@@ -524,7 +529,7 @@ __global__ __launch_bounds__(256, OCC) void k_coag_sample(DeviceState st, int kt
         unsigned char *base = smem + (((size_t)(B + 1) * sizeof(double) + 15) & ~(size_t)15) +
                               (size_t)lds_per_cell * (size_t)(wave * GPW + sub);
         size_t o = 0;
-        constexpr int WNL = (L == 64) ? 64 : 16;
+        constexpr int WNL = (L == 64) ? 64 : (L == 1 ? 1 : PMCX_WIN);
         X.L.env = (EnvDerived *)(base + o); o += sizeof(EnvDerived);
         X.L.mask = (uint64_t *)(base + o); o += sizeof(uint64_t) * 2 * (size_t)C;
         X.L.P = (uint32_t *)(base + o); o += sizeof(uint32_t) * (size_t)WNL;
@@ -574,7 +579,7 @@ __global__ __launch_bounds__(256, OCC) void k_coag_sample(DeviceState st, int kt
     // visited through a window of up to WN non-empty partner bins: counts are
     // drawn for the window only, and the window is rebuilt from the slot of an
     // event (whose own count and progress are kept) or moved on when exhausted.
-    constexpr int WN = (L == 64) ? 64 : 16;
+    constexpr int WN = (L == 64) ? 64 : (L == 1 ? 1 : PMCX_WIN);
     int c1 = 0, c2 = 0, b1 = -1;
     int gA = 0, cc = 0, wn = 0, counted = 0, wfrom = 0;
     uint32_t cur_s0 = 0, ns0 = 0;
@@ -1407,7 +1412,7 @@ size_t bin_sort_lds_bytes(const DeviceState &st)
 static size_t sampler_lds_for(const DeviceState &st, int lanes)
 {
     return sampler_lds_bytes(st.n_bin * st.n_class, st.n_class, st.max_appends,
-                             lanes == 64 ? 64 : 16);
+                             lanes == 64 ? 64 : (lanes == 1 ? 1 : PMCX_WIN));
 }
 size_t sampler_lds_bytes_per_cell(const DeviceState &st)
 {
@@ -1418,7 +1423,7 @@ size_t sampler_lds_bytes_per_cell(const DeviceState &st)
 int sampler_lanes(const DeviceState &st)
 {
     const char *e = getenv("PMCX_SAMPLER_LANES");
-    if (e && (atoi(e) == 4 || atoi(e) == 8 || atoi(e) == 16 || atoi(e) == 64)) return atoi(e);
+    if (e && (atoi(e) == 1 || atoi(e) == 4 || atoi(e) == 8 || atoi(e) == 16 || atoi(e) == 64)) return atoi(e);
     return sampler_lds_for(st, 16) <= 4 * 1024 ? 8 : 64;
 }
 size_t diagnostics_lds_bytes(const DeviceState &st)
@@ -1528,6 +1533,7 @@ hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, ui
     int wpb = e_wpb ? atoi(e_wpb) : 2; // wavefronts per workgroup
     if (wpb != 1 && wpb != 2 && wpb != 4) wpb = 2;
     while (wpb > 1 && shared + per * wpb * gpw > 64 * 1024) wpb >>= 1;
+    if (shared + per * wpb * gpw > 160 * 1024) return hipErrorInvalidConfiguration;
     const int occ = e_occ ? atoi(e_occ) : 3;
     const int cpb = wpb * gpw;
     const size_t lds = shared + per * cpb;
@@ -1538,7 +1544,9 @@ hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, ui
         hipLaunchKernelGGL((k_coag_sample<LL, OO>), grid, block, lds, s, st, ktype, del_t, seed, \
                            step, (uint32_t)per);                                                 \
     } while (0)
-    if (L == 4) {
+    if (L == 1) {
+        if (occ >= 4) PMCX_LAUNCH_SAMPLER(1, 4); else if (occ == 3) PMCX_LAUNCH_SAMPLER(1, 3); else PMCX_LAUNCH_SAMPLER(1, 2);
+    } else if (L == 4) {
         if (occ >= 4) PMCX_LAUNCH_SAMPLER(4, 4); else if (occ == 3) PMCX_LAUNCH_SAMPLER(4, 3); else PMCX_LAUNCH_SAMPLER(4, 2);
     } else if (L == 8) {
         if (occ >= 4) PMCX_LAUNCH_SAMPLER(8, 4); else if (occ == 3) PMCX_LAUNCH_SAMPLER(8, 3); else PMCX_LAUNCH_SAMPLER(8, 2);
