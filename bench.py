@@ -178,7 +178,7 @@ def main():
     ap.add_argument("--del-t", type=float, default=300.0)
     ap.add_argument("--seed", type=int, default=0)            # registry.partmc:13
     ap.add_argument("--max-events", type=int, default=1024)
-    ap.add_argument("--max-appends", type=int, default=512)
+    ap.add_argument("--max-appends", type=int, default=128)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-cores", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")

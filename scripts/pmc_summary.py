@@ -14,3 +14,20 @@ json.dump(out, open(os.path.join(root, f"pmc_{tag}_summary.json"), "w"), indent=
 for k in sorted(out):
     if "pmcx" in k:
         print(k, {c: (f"{v:.4g}") for c, v in out[k].items()})
+
+# HBM traffic per launch for bench.py's roofline.traffic (profiles/pmc_traffic.json).
+# FETCH_SIZE/WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE reports half the bytes of a
+# coalesced streaming read (MI355X_MICROARCH.md, HBM): k_bin_sort's read side is such a
+# stream and is calibrated here (algorithmic 8 B/particle read once == 2 x FETCH_SIZE);
+# the sampler's 8-byte gathers are an uncalibrated access width, so its figure uses the
+# raw counter and is a lower bound.
+traffic = {}
+names = {"pmcx::k_bin_sort": ("bin_sort", 2.0), "pmcx::k_coag_sample<8, 3>": ("coag_sample", 1.0),
+         "pmcx::k_rebalance": ("rebalance", 1.0), "pmcx::k_compact": ("compact", 1.0)}
+for k, (short, f) in names.items():
+    if k in out and "FETCH_SIZE" in out[k] and "WRITE_SIZE" in out[k]:
+        traffic[short] = {"bytes_per_launch": (out[k]["FETCH_SIZE"] * f + out[k]["WRITE_SIZE"]) * 1024.0,
+                          "fetch_size_kib": out[k]["FETCH_SIZE"], "write_size_kib": out[k]["WRITE_SIZE"],
+                          "fetch_factor": f}
+if traffic:
+    json.dump(traffic, open(os.path.join(root, f"pmc_{tag}_traffic.json"), "w"), indent=1)

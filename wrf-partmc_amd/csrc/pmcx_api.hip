@@ -185,7 +185,7 @@ void pmcx_config_default(pmcx_config *cfg)
     cfg->r_min = 1e-10;
     cfg->r_max = 1e-2;
     cfg->max_events = 1024;
-    cfg->max_appends = 512;
+    cfg->max_appends = 256; /* 4 B of LDS per entry and cell in the sampler */
     cfg->n_dbin = 100;  /* driver:783 */
     cfg->i_water = -1;
     cfg->d_min = 1e-9;
