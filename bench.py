@@ -201,10 +201,17 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU is visible and there is no CPU path")
-    torch.cuda.set_device(local_rank)
+    # PMCX_BENCH_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N>1
+    # path on a one-GPU box); the driver's multi-GPU runs use the default, RCCL.
+    backend = os.environ.get("PMCX_BENCH_BACKEND", "nccl")
+    device = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
 
     import wrf_partmc_amd as wp
     n_cols = args.nx * args.ny
@@ -212,7 +219,7 @@ def main():
     first_cell, n_cells = c0 * args.levels, (c1 - c0) * args.levels
     n_cells_total = n_cols * args.levels
 
-    blk = wp.CellBlock(n_cells, args.cap, args.n_spec, n_class=1, n_source=0, device=local_rank,
+    blk = wp.CellBlock(n_cells, args.cap, args.n_spec, n_class=1, n_source=0, device=device,
                        cell_id_base=first_cell, max_events=args.max_events,
                        max_appends=args.max_appends)
     blk.set_aero_data(bench_density(args.n_spec))
