@@ -287,18 +287,7 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st)
     const double v_lo = edge[0], v_hi = edge[B];
     uint32_t *myhist = hist + (size_t)wave * G;
 
-    // lanes of a 64-slot chunk that hold the same group, from one ballot per key bit
-    const int key_bits = st.key_bits;
     const uint64_t lt = (1ull << lane) - 1ull;
-    auto peers_of = [&](uint32_t g, bool valid) {
-        uint64_t peers = __ballot(valid);
-        for (int k = 0; k < key_bits; k++) {
-            const bool bit = (g >> k) & 1u;
-            const uint64_t m = __ballot(bit);
-            peers &= bit ? m : ~m;
-        }
-        return peers;
-    };
 
     // pass 1: keys + per-wave histogram (LDS atomics: counting is order-independent).
     // Four loads are issued before the first use so a wave keeps 2 KiB in flight.
@@ -331,14 +320,32 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st)
 
     int32_t *gcnt_g = st.gcnt + (int64_t)c * G;
     int32_t *goff_g = st.goff + (int64_t)c * G;
+    __shared__ uint32_t g_lo, g_hi; // occupied key range of this cell
+    if (t == 0) { g_lo = 0xFFFFFFFFu; g_hi = 0u; }
+    __syncthreads();
     for (int g = t; g < G; g += 256) {
         const uint32_t h0 = hist[g], h1 = hist[G + g], h2 = hist[2 * G + g], h3 = hist[3 * G + g];
         hist[g] = 0; hist[G + g] = h0; hist[2 * G + g] = h0 + h1; hist[3 * G + g] = h0 + h1 + h2;
         const uint32_t s = h0 + h1 + h2 + h3;
         tot[g] = s;
         gcnt_g[g] = (int32_t)s;
+        if (s) { atomicMin(&g_lo, (uint32_t)g); atomicMax(&g_hi, (uint32_t)g); }
     }
     __syncthreads();
+    // keys relative to the lowest occupied group need fewer bits (typically 5 of 7)
+    const uint32_t key_lo = g_lo <= g_hi ? g_lo : 0u;
+    const int key_bits = g_lo < g_hi ? 32 - __builtin_clz(g_hi - g_lo) : 0;
+    // lanes of a 64-slot chunk that hold the same group: one ballot per key bit
+    auto peers_of = [&](uint32_t g, bool valid) {
+        uint64_t peers = __ballot(valid);
+        const uint32_t r = g - key_lo;
+        for (int k = 0; k < key_bits; k++) {
+            const uint32_t x = (uint32_t)(-(int32_t)((r >> k) & 1u)); // all ones when the bit is set
+            const uint64_t m = __ballot(x != 0u);
+            peers &= ~(m ^ (((uint64_t)x << 32) | x));
+        }
+        return peers;
+    };
     block_excl_scan_u32(tot, G, wsum);
     for (int g = t; g < G; g += 256) {
         const uint32_t o = tot[g];
