@@ -199,32 +199,43 @@ __global__ void k_refresh_caches(DeviceState st, int cell_first, int n_cells_do)
 __global__ __launch_bounds__(256) void k_kernel_bounds(DeviceState st, int ktype)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    PartProps *pp = (PartProps *)smem; // [n_bin*6]
     const int c = blockIdx.x;
-    const int B = st.n_bin;
+    const int B = st.n_bin, NP = B * 6;
+    // per-(bin, sample, density) particle properties, structure of arrays in LDS
+    double *p_rad = (double *)smem, *p_dif = p_rad + NP, *p_spd = p_dif + NP,
+           *p_del = p_spd + NP, *p_fal = p_del + NP;
     const EnvDerived env = env_derive(st.temp[c], st.pressure[c]);
     const KernelParams kp{st.const_k, st.additive_beta};
-    for (int j = threadIdx.x; j < B * 6; j += blockDim.x) {
+    for (int j = threadIdx.x; j < NP; j += blockDim.x) {
         const int d = j & 1, bs = j >> 1; // bs = b*3+s
         const double v = st.v_samp[bs];
         const double rho = d ? st.rho_max : st.rho_min;
-        pp[j] = props_for(ktype, v, v * rho, env);
+        const PartProps q = props_for(ktype, v, v * rho, env);
+        p_rad[j] = q.rad; p_dif[j] = q.diffus; p_spd[j] = q.speedsq; p_del[j] = q.deltasq;
+        p_fal[j] = q.wfall;
     }
     __syncthreads();
     double *km = st.kmax + (int64_t)c * B * B;
-    for (int j = threadIdx.x; j < B * B; j += blockDim.x) {
-        const int b1 = j / B, b2 = j - b1 * B;
+    // K is symmetric: one thread per unordered bin pair, both entries written
+    const int n_pair = B * (B + 1) / 2;
+    for (int j = threadIdx.x; j < n_pair; j += blockDim.x) {
+        // row b1 of the upper triangle holds B - b1 entries
+        int b1 = 0, rem = j;
+        while (rem >= B - b1) { rem -= B - b1; b1++; }
+        const int b2 = b1 + rem;
         double m = 0.0;
-        for (int s1 = 0; s1 < 3; s1++)
-            for (int s2 = 0; s2 < 3; s2++)
-                for (int d1 = 0; d1 < 2; d1++)
-                    for (int d2 = 0; d2 < 2; d2++) {
-                        const double k = kernel_pair(
-                            ktype, st.v_samp[3 * b1 + s1], st.v_samp[3 * b2 + s2],
-                            pp[(b1 * 3 + s1) * 2 + d1], pp[(b2 * 3 + s2) * 2 + d2], kp);
-                        if (k > m) m = k;
-                    }
-        km[j] = m;
+        for (int i1 = 0; i1 < 6; i1++) {
+            const int ja = b1 * 6 + i1;
+            const PartProps qa{p_rad[ja], p_dif[ja], p_spd[ja], p_del[ja], p_fal[ja]};
+            for (int i2 = 0; i2 < 6; i2++) {
+                const int jb = b2 * 6 + i2;
+                const PartProps qb{p_rad[jb], p_dif[jb], p_spd[jb], p_del[jb], p_fal[jb]};
+                const double k = kernel_pair(ktype, st.v_samp[ja >> 1], st.v_samp[jb >> 1], qa, qb, kp);
+                if (k > m) m = k;
+            }
+        }
+        km[b1 * B + b2] = m;
+        km[b2 * B + b1] = m;
     }
 }
 
@@ -1518,7 +1529,7 @@ hipError_t launch_refresh_caches(const DeviceState &st, int cell_first, int n_ce
 }
 hipError_t launch_kernel_bounds(const DeviceState &st, int ktype, hipStream_t s)
 {
-    const size_t lds = sizeof(PartProps) * (size_t)st.n_bin * 6;
+    const size_t lds = sizeof(double) * 5 * (size_t)st.n_bin * 6;
     hipLaunchKernelGGL(k_kernel_bounds, dim3(st.n_cells), dim3(256), lds, s, st, ktype);
     return hipGetLastError();
 }
