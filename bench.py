@@ -30,7 +30,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
-KERNELS = ("bin_sort", "coag_sample", "compact", "rebalance")
+KERNELS = ("bin_sort", "coag_sample", "compact", "rebalance", "condense")
 
 
 def partition_columns(n_cols, world, rank):
@@ -62,6 +62,9 @@ def algorithmic_bytes(name, n_spec, n_class, n_source, particles, candidates, ev
         return 0  # only cells past the tombstone threshold move data
     if name == "rebalance":
         return particles * 4 if n_class > 1 else 0
+    if name == "condense":
+        # read the species (+ class), write water volume and the two caches
+        return particles * (8 * n_spec + 4 + 8 + 16)
     return 0
 
 
@@ -182,8 +185,15 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-cores", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["domain", "config3"], default="domain",
+                    help="domain: BASELINE configs[4] (default). config3: 1000 cells x 10^4, "
+                         "20 species, condensation sub-step + coagulation (BASELINE configs[2])")
     args = ap.parse_args()
     args.cap = (args.particles + 63) // 64 * 64
+    config3 = args.workload == "config3"
+    if config3:
+        args.nx, args.ny, args.levels, args.n_spec = 10, 10, 10, 20
+        args.no_cpu_baseline = True
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -221,15 +231,27 @@ def main():
 
     blk = wp.CellBlock(n_cells, args.cap, args.n_spec, n_class=1, n_source=0, device=device,
                        cell_id_base=first_cell, max_events=args.max_events,
-                       max_appends=args.max_appends)
-    blk.set_aero_data(bench_density(args.n_spec))
+                       max_appends=args.max_appends, i_water=(19 if config3 else -1))
     temp, pres = level_profile(args.levels)
     lev = (first_cell + np.arange(n_cells)) % args.levels
-    blk.set_env(temp[lev], pres[lev], np.full(n_cells, 0.5))
+    if config3:
+        from wrf_partmc_amd.data import aero_data_arrays
+        dens20, kappa20, _, _ = aero_data_arrays()
+        blk.set_aero_data(dens20, kappa=kappa20)
+        rh = np.random.RandomState(args.seed).uniform(0.3, 0.95, n_cells_total)
+        blk.set_env(temp[lev], pres[lev], rh[first_cell:first_cell + n_cells])
+    else:
+        blk.set_aero_data(bench_density(args.n_spec))
+        blk.set_env(temp[lev], pres[lev], np.full(n_cells, 0.5))
     blk.set_weights(np.full((n_cells, 1), args.num_conc / args.particles))
     blk.set_n_part_ideal(np.full((n_cells, 1), float(args.particles)))
     blk.set_next_id((first_cell + np.arange(n_cells, dtype=np.int64) << 32) + (1 << 24))
-    blk.generate_lognormal(args.particles, bench_modes(args.n_spec), seed=args.seed)
+    if config3:
+        from wrf_partmc_amd.data import scm_init_modes
+        modes3, _ = scm_init_modes()      # em_scm_xy bimodal IC, OC:SO4:NH4 composition
+        blk.generate_lognormal(args.particles, modes3, seed=args.seed)
+    else:
+        blk.generate_lognormal(args.particles, bench_modes(args.n_spec), seed=args.seed)
     blk.update_kernel_bounds(wp.COAG_KERNEL_TYPE_BROWN)
     blk.synchronize()
 
@@ -241,6 +263,8 @@ def main():
         torch.cuda.synchronize()
 
     def one_step(step):
+        if config3:
+            blk.condense(args.del_t, 4)   # extension: water uptake sub-step before coagulation
         blk.mc_coag(wp.COAG_KERNEL_TYPE_BROWN, args.del_t, args.seed, step, counters=False)
         tot = blk.coag_totals()      # n_samp, n_coag, n_part (before rebalance), status
         blk.aero_state_rebalance(True, True, args.seed, step)
@@ -294,7 +318,10 @@ def main():
         achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        # the committed PMC passes were taken on the default full-size workload only
+        full_default = (args.workload == "domain" and (args.nx, args.ny, args.levels) == (100, 100, 30)
+                        and args.particles == 10000 and args.n_spec == 1 and world == 1)
+        if full_default and os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get(dom, {}).get("bytes_per_launch")
             except Exception:
@@ -304,9 +331,11 @@ def main():
             "unit": "events/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.nx}x{args.ny}x{args.levels} cells x {args.particles} "
-                                   f"particles/cell, Brownian mc_coag del_t={args.del_t:g}s + rebalance, "
-                                   f"n_spec={args.n_spec}, cell-column blocks over {world} GPU(s)",
+            "config": {"workload": (f"{args.nx}x{args.ny}x{args.levels} cells x {args.particles} "
+                                    f"particles/cell, Brownian mc_coag del_t={args.del_t:g}s + rebalance, "
+                                    f"n_spec={args.n_spec}, cell-column blocks over {world} GPU(s)"
+                                    + (", condensation sub-step (extension) before coagulation, "
+                                       "em_scm_xy species table and bimodal IC" if config3 else "")),
                        "cells": n_cells_total, "particles_per_cell": args.particles,
                        "n_spec": args.n_spec, "kernel": "COAG_KERNEL_TYPE_BROWN"},
             "particle_steps_per_sec": agg["particle_steps"] / el,

@@ -1442,7 +1442,14 @@ int sampler_lanes(const DeviceState &st)
 {
     const char *e = getenv("PMCX_SAMPLER_LANES");
     if (e && (atoi(e) == 1 || atoi(e) == 4 || atoi(e) == 8 || atoi(e) == 16 || atoi(e) == 64)) return atoi(e);
-    return sampler_lds_for(st, 16) <= 4 * 1024 ? 8 : 64;
+    if (sampler_lds_for(st, 16) > 4 * 1024) return 64;
+    // 8 lanes per cell (8 cells per wavefront) is the throughput optimum; with few
+    // cells the kernel is one wavefront's latency, which is shortest with more lanes
+    // per cell: widen while every wavefront still finds a slot (256 CUs x 12).
+    const long slots = 256L * 12L;
+    if ((long)st.n_cells <= slots) return 64;
+    if ((long)st.n_cells <= slots * 4) return 16;
+    return 8;
 }
 size_t diagnostics_lds_bytes(const DeviceState &st)
 {
