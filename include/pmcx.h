@@ -217,6 +217,15 @@ int pmcx_condense(pmcx_ctx *ctx, double del_t, int32_t n_sub);
 int pmcx_diagnostics(pmcx_ctx *ctx, double *tot_num_conc, double *tot_mass_conc,
                      double *num_dist, double *mass_dist);
 
+/* More partmc_process observables:
+ *   species_mass_conc [n_cells][n_spec]   sum(masses(include=species) * num_concs), driver:864-932
+ *   num_conc_by_source [n_cells][n_source] aero_state_num_concs_by_source, driver:858-861
+ *   pm_mass_conc [n_cells][3]             PM1, PM2.5, PM10 dry mass, driver:1153-1157
+ *   n_parts [n_cells]                     aero_state_n_part, driver:1137
+ * any pointer may be NULL. */
+int pmcx_diagnostics_ext(pmcx_ctx *ctx, double *species_mass_conc, double *num_conc_by_source,
+                         double *pm_mass_conc, int32_t *n_parts);
+
 /*
  * Synthetic populations generated on the device (shape of
  * aero_state_add_aero_dist_sample for log-normal modes,

@@ -776,3 +776,32 @@ int pmco_scenario_update(pmco_cell *c, double dt, double create_time, uint64_t s
     return status;
 }
 
+/* ------------------------------------------------------------------------
+ * More partmc_process observables (interface/wrf_pmc_driver.F90):
+ *   species_mass[s] = sum(aero_state_masses(include=species s) * num_concs)   :864-932
+ *   source_num[k]   = aero_state_num_concs_by_source                          :858-861
+ *   pm[0..2]        = PM1 / PM2.5 / PM10 dry mass concentration               :1153-1157
+ * ---------------------------------------------------------------------- */
+void pmco_diagnostics_ext(const pmco_cell *c, int i_water, double *species_mass,
+                          double *source_num, double *pm)
+{
+    for (int s = 0; s < c->n_spec; s++) species_mass[s] = 0.0;
+    for (int k = 0; k < c->n_source; k++) source_num[k] = 0.0;
+    pm[0] = pm[1] = pm[2] = 0.0;
+    for (int i = 0; i < *c->n_part; i++) {
+        const double nc = c->mag[c->wclass[i]];
+        double vdry = 0.0, mdry = 0.0;
+        for (int s = 0; s < c->n_spec; s++) {
+            const double v = c->vol[(size_t)s * c->cap + i];
+            species_mass[s] = species_mass[s] + c->density[s] * v * nc;
+            if (s != i_water) { vdry = vdry + v; mdry = mdry + c->density[s] * v; }
+        }
+        for (int k = 0; k < c->n_source; k++)
+            if (c->n_orig[(size_t)k * c->cap + i] > 0) source_num[k] = source_num[k] + nc;
+        const double diam = 2.0 * pmco_cbrt(vdry * (0.75 / PMCO_PI));
+        if (diam < 1e-6) pm[0] = pm[0] + nc * mdry;
+        if (diam < 2.5e-6) pm[1] = pm[1] + nc * mdry;
+        if (diam < 10e-6) pm[2] = pm[2] + nc * mdry;
+    }
+}
+

@@ -145,6 +145,11 @@ void pmco_generate(pmco_cell *c, const pmco_gen_spec *g, int32_t n,
                    uint64_t seed, uint32_t cell_id, int64_t first_id,
                    double create_time);
 
+/* species mass concentrations, number concentration by source, PM1/2.5/10
+ * (wrf_pmc_driver.F90:858-932,1153-1157) */
+void pmco_diagnostics_ext(const pmco_cell *c, int i_water, double *species_mass /*[n_spec]*/,
+                          double *source_num /*[n_source]*/, double *pm /*[3]*/);
+
 /* scenario_update_aero_state (call: wrf_pmc_driver.F90:207-210): emission of
  * new particles from log-normal modes, loss by dilution, gain from the
  * background.  Rates are number concentrations: emission [#/m^3/s],

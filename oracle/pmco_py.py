@@ -215,6 +215,14 @@ class Cell:
                                         C.byref(ni), C.byref(no))
         return st, nid.value, ne.value, ni.value, no.value
 
+    def diagnostics_ext(self, i_water):
+        sm, sn, pm = np.zeros(self.n_spec), np.zeros(max(self.n_source, 1)), np.zeros(3)
+        f = lib().pmco_diagnostics_ext
+        f.restype = None
+        f.argtypes = [C.POINTER(CellStruct), C.c_int, _dp, _dp, _dp]
+        f(C.byref(self.view()), int(i_water), _p(sm, _dp), _p(sn, _dp), _p(pm, _dp))
+        return sm, sn[:self.n_source], pm
+
     def condense(self, kappa, i_water, rel_humid, del_t, n_sub=4):
         k = np.ascontiguousarray(kappa, dtype=np.float64)
         lib().pmco_condense(C.byref(self.view()), _p(k, _dp), int(i_water), float(rel_humid),

@@ -183,6 +183,14 @@ def test_diagnostics_parity(wp, oracle):
         # north_star gate: relative L2 of the size distributions below 1e-6
         assert np.linalg.norm(nd[c] - ond) <= 1e-6 * np.linalg.norm(ond)
         assert np.linalg.norm(md[c] - omd) <= 1e-6 * np.linalg.norm(omd)
+    sm, sn, pm, npart = blk.diagnostics_ext()
+    for c, oc in enumerate(cells):
+        osm, osn, opm = oc.diagnostics_ext(2)
+        np.testing.assert_allclose(sm[c], osm, rtol=parity.DIAM_TOL)
+        np.testing.assert_allclose(sn[c], osn, rtol=parity.DIAM_TOL)
+        np.testing.assert_allclose(pm[c], opm, rtol=parity.DIAM_TOL)
+        assert npart[c] == oc.n_part[0]
+        assert abs(sm[c].sum() - tm[c]) <= 1e-12 * tm[c]       # species masses add up to the total
     blk.close()
 
 

@@ -822,6 +822,28 @@ int pmcx_diagnostics(pmcx_ctx *ctx, double *tot_num_conc, double *tot_mass_conc,
     return PMCX_OK;
 }
 
+int pmcx_diagnostics_ext(pmcx_ctx *ctx, double *species_mass_conc, double *num_conc_by_source,
+                         double *pm_mass_conc, int32_t *n_parts)
+{
+    if (!ctx) return PMCX_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t nc = (size_t)ctx->cfg.n_cells, S = (size_t)ctx->cfg.n_spec,
+                 NS = (size_t)ctx->cfg.n_source;
+    int rc = ensure_stage(ctx, sizeof(double) * nc * (S + NS + 3) + 64);
+    if (rc) return rc;
+    double *d_sm = (double *)ctx->stage, *d_sn = d_sm + nc * S, *d_pm = d_sn + nc * NS;
+    {
+        ProfScope ps(ctx, "diagnostics");
+        HIP_TRY(ctx, launch_diagnostics_ext(ctx->st, d_sm, d_sn, d_pm, ctx->stream));
+    }
+    if (species_mass_conc) HIP_TRY(ctx, hipMemcpyAsync(species_mass_conc, d_sm, sizeof(double) * nc * S, hipMemcpyDeviceToHost, ctx->stream));
+    if (num_conc_by_source && NS) HIP_TRY(ctx, hipMemcpyAsync(num_conc_by_source, d_sn, sizeof(double) * nc * NS, hipMemcpyDeviceToHost, ctx->stream));
+    if (pm_mass_conc) HIP_TRY(ctx, hipMemcpyAsync(pm_mass_conc, d_pm, sizeof(double) * nc * 3, hipMemcpyDeviceToHost, ctx->stream));
+    if (n_parts) HIP_TRY(ctx, hipMemcpyAsync(n_parts, ctx->st.n_part, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PMCX_OK;
+}
+
 int pmcx_generate_lognormal(pmcx_ctx *ctx, int32_t n_part, int32_t n_mode, const double *mode_frac,
                             const double *gm_radius, const double *gsd_log10,
                             const double *vol_frac, const int32_t *mode_class,

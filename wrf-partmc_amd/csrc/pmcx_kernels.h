@@ -90,6 +90,8 @@ hipError_t launch_rebalance(const DeviceState &st, int allow_doubling, int allow
                             uint64_t seed, uint32_t step, hipStream_t s);
 hipError_t launch_diagnostics(const DeviceState &st, double *tot_num, double *tot_mass,
                               double *num_dist, double *mass_dist, hipStream_t s);
+hipError_t launch_diagnostics_ext(const DeviceState &st, double *species_mass, double *source_num,
+                                  double *pm, hipStream_t s);
 hipError_t launch_generate(const DeviceState &st, const GenSpecDev &g, int n, uint64_t seed,
                            double create_time, hipStream_t s);
 hipError_t launch_scenario_update(const DeviceState &st, double dt, double create_time, uint64_t seed,

@@ -1135,6 +1135,43 @@ __global__ __launch_bounds__(256) void k_diagnostics(DeviceState st, double *tot
     }
 }
 
+// extended observables: species mass concentrations (driver:864-932), number
+// concentration by source (driver:858-861), PM1/PM2.5/PM10 (driver:1153-1157)
+__global__ __launch_bounds__(256) void k_diagnostics_ext(DeviceState st, double *species_mass,
+                                                         double *source_num, double *pm)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int c = blockIdx.x, t = threadIdx.x;
+    const int S = st.n_spec, NS = st.n_source;
+    double *acc = (double *)smem; // [S] species, [NS] sources, [3] pm
+    for (int j = t; j < S + NS + 3; j += 256) acc[j] = 0.0;
+    __syncthreads();
+    const int n = st.n_hi[c];
+    const int64_t cb = (int64_t)c * st.cap;
+    const double *mag = st.mag + (int64_t)c * st.n_class;
+    for (int i = t; i < n; i += 256) {
+        const int cl = st.wclass[cb + i];
+        if (cl < 0) continue;
+        const double nc = mag[cl];
+        double vdry = 0.0, mdry = 0.0;
+        for (int s = 0; s < S; s++) {
+            const double v = st.vol[cb * S + (int64_t)s * st.cap + i];
+            atomicAdd(&acc[s], st.density[s] * v * nc);
+            if (s != st.i_water) { vdry = vdry + v; mdry = mdry + st.density[s] * v; }
+        }
+        for (int k = 0; k < NS; k++)
+            if (st.n_orig[cb * NS + (int64_t)k * st.cap + i] > 0) atomicAdd(&acc[S + k], nc);
+        const double diam = 2.0 * det_cbrt(vdry * (0.75 / PI));
+        if (diam < 1e-6) atomicAdd(&acc[S + NS], nc * mdry);
+        if (diam < 2.5e-6) atomicAdd(&acc[S + NS + 1], nc * mdry);
+        if (diam < 10e-6) atomicAdd(&acc[S + NS + 2], nc * mdry);
+    }
+    __syncthreads();
+    for (int j = t; j < S; j += 256) species_mass[(int64_t)c * S + j] = acc[j];
+    for (int j = t; j < NS; j += 256) source_num[(int64_t)c * NS + j] = acc[S + j];
+    for (int j = t; j < 3; j += 256) pm[(int64_t)c * 3 + j] = acc[S + NS + j];
+}
+
 // ----------------------------------------------------------------- scenario
 //
 // scenario_update_aero_state (interface/wrf_pmc_driver.F90:207-210)
@@ -1595,6 +1632,14 @@ hipError_t launch_diagnostics(const DeviceState &st, double *tot_num, double *to
 {
     hipLaunchKernelGGL(k_diagnostics, dim3(st.n_cells), dim3(256), diagnostics_lds_bytes(st), s, st,
                        tot_num, tot_mass, num_dist, mass_dist);
+    return hipGetLastError();
+}
+hipError_t launch_diagnostics_ext(const DeviceState &st, double *species_mass, double *source_num,
+                                  double *pm, hipStream_t s)
+{
+    const size_t lds = sizeof(double) * (size_t)(st.n_spec + st.n_source + 3);
+    hipLaunchKernelGGL(k_diagnostics_ext, dim3(st.n_cells), dim3(256), lds, s, st, species_mass,
+                       source_num, pm);
     return hipGetLastError();
 }
 hipError_t launch_generate(const DeviceState &st, const GenSpecDev &g, int n, uint64_t seed,

@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "pmcx_get_n_part", "pmcx_download_cells", "pmcx_update_kernel_bounds", "pmcx_mc_coag",
     "pmcx_get_coag_counters", "pmcx_get_coag_totals", "pmcx_rebalance", "pmcx_condense",
     "pmcx_scenario_update_aero_state",
-    "pmcx_diagnostics",
+    "pmcx_diagnostics", "pmcx_diagnostics_ext",
     "pmcx_generate_lognormal", "pmcx_timestep", "pmcx_get_bin_tables", "pmcx_get_diag_grid",
     "pmcx_get_kmax", "pmcx_get_caches", "pmcx_sort_only", "pmcx_get_sort", "pmcx_test_math",
     "pmcx_test_philox", "pmcx_profile_enable", "pmcx_profile_reset", "pmcx_profile_get",
@@ -347,6 +347,14 @@ class CellBlock:
         d1, d2 = np.zeros((n, nd)), np.zeros((n, nd))
         self._ck(self._lib.pmcx_diagnostics(self._h, _ptr(tn), _ptr(tm), _ptr(d1), _ptr(d2)))
         return tn, tm, d1, d2
+
+    def diagnostics_ext(self):
+        """species mass conc [n_cells][n_spec], number conc by source, PM1/2.5/10, n_parts."""
+        n, S, NS = self.cfg.n_cells, self.cfg.n_spec, max(self.cfg.n_source, 1)
+        sm, sn, pm = np.zeros((n, S)), np.zeros((n, NS)), np.zeros((n, 3))
+        npart = np.zeros(n, dtype=np.int32)
+        self._ck(self._lib.pmcx_diagnostics_ext(self._h, _ptr(sm), _ptr(sn), _ptr(pm), _ptr(npart)))
+        return sm, sn[:, :self.cfg.n_source], pm, npart
 
     def run_part(self, kernel_type, del_t, n_steps, seed=0, rebalance=True, t_output=1):
         """Single-block time loop in the shape of PartMC's run_part (BASELINE config 1):
