@@ -471,3 +471,33 @@ def test_run_part_driver(wp):
         np.testing.assert_allclose(h[2], tm0, rtol=1e-12)
         np.testing.assert_allclose((h[3] * blk.diag_grid()[1]).sum(1), h[1], rtol=1e-12)
     blk.close()
+
+
+def test_results_independent_of_launch_geometry(wp, oracle, monkeypatch):
+    """Same cells through the sampler with 8, 16 and 64 lanes per cell and different
+    workgroup sizes: identical particle data, counters and status."""
+    outs = []
+    for lanes, wpb in (("8", "2"), ("16", "4"), ("64", "1"), ("4", "2")):
+        monkeypatch.setenv("PMCX_SAMPLER_LANES", lanes)
+        monkeypatch.setenv("PMCX_SAMPLER_WPB", wpb)
+        blk = wp.CellBlock(5, 1536, 2, n_class=2, n_source=2, max_appends=128)
+        names, dens = parity.default_species(2)
+        blk.set_aero_data(dens)
+        blk.set_env(np.linspace(290, 240, 5), np.linspace(1e5, 4e4, 5))
+        blk.set_weights(np.tile([4e6, 7e6], (5, 1)))
+        modes, _ = parity.make_modes(2, 2)
+        for m in modes:
+            m["source"] = m["source"] % 2
+        blk.generate_lognormal(1500, modes, seed=2)
+        log = []
+        for step in range(3):
+            ns, nc, st = blk.mc_coag(K_BROWN, 4000.0, 2, step)
+            log.append((ns.tolist(), nc.tolist(), st.tolist()))
+        dn = blk.download_cells()
+        outs.append((log, dn))
+        blk.close()
+    for log, dn in outs[1:]:
+        assert log == outs[0][0]
+        for k in ("part_offset", "vol", "wclass", "id", "least_ct", "greatest_ct", "n_orig"):
+            assert np.array_equal(dn[k], outs[0][1][k]), k
+    assert sum(outs[0][0][0][1]) > 50
