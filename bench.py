@@ -266,35 +266,34 @@ def main():
         if config3:
             blk.condense(args.del_t, 4)   # extension: water uptake sub-step before coagulation
         blk.mc_coag(wp.COAG_KERNEL_TYPE_BROWN, args.del_t, args.seed, step, counters=False)
-        tot = blk.coag_totals()      # n_samp, n_coag, n_part (before rebalance), status
-        blk.aero_state_rebalance(True, True, args.seed, step)
-        return tot
+        blk.accumulate_totals()      # n_samp, n_coag, n_part, status: summed on the device,
+        blk.aero_state_rebalance(True, True, args.seed, step)   # no host sync inside the step
 
     # the first step's per-cell event counts, for the oracle cross-check
     first_counts = None
     step = 0
     for _ in range(args.warmup):
-        tot = one_step(step)
+        one_step(step)
         if step == 0 and rank == 0:
             ns, nc, st = blk.coag_counters()
             first_counts = {first_cell + i: int(v) for i, v in enumerate(nc[:4096])}
         step += 1
+    blk.read_accumulated(reset=True)      # drop the warm-up steps' sums
     blk.profile_enable(True)
     blk.profile_reset()
     barrier()
     t0 = time.perf_counter()
-    samp = coag = parts = 0
-    status = 0
     for _ in range(args.steps):
-        tot = one_step(step)
+        one_step(step)
         if step == 0 and rank == 0:
             ns, nc, st = blk.coag_counters()
             first_counts = {first_cell + i: int(v) for i, v in enumerate(nc[:4096])}
-        samp += tot[0]; coag += tot[1]; parts += tot[2] + tot[1]; status |= tot[3]
         step += 1
     barrier()
     elapsed = time.perf_counter() - t0
     blk.profile_enable(False)
+    samp, coag, parts_after, status = blk.read_accumulated(reset=True)
+    parts = parts_after + coag    # one class: particles entering a step = survivors + events
 
     local = dict(elapsed=elapsed, n_samp=samp, n_coag=coag, particle_steps=parts)
     for k in KERNELS:

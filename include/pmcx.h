@@ -168,6 +168,12 @@ int pmcx_get_coag_counters(pmcx_ctx *ctx, int32_t *n_samp, int32_t *n_coag,
 int pmcx_get_coag_totals(pmcx_ctx *ctx, int64_t *n_samp, int64_t *n_coag,
                          int64_t *n_part, int32_t *status_or);
 
+/* Asynchronous form: add the last call's sums to running totals kept on the
+ * device (no host synchronisation per step); read (and optionally reset) them later. */
+int pmcx_accumulate_totals(pmcx_ctx *ctx);
+int pmcx_read_accumulated(pmcx_ctx *ctx, int64_t *n_samp, int64_t *n_coag, int64_t *n_part,
+                          int32_t *status_or, int32_t reset);
+
 /* aero_state_rebalance on every cell (wrf_pmc_driver.F90:248-250). */
 int pmcx_rebalance(pmcx_ctx *ctx, int32_t allow_doubling, int32_t allow_halving,
                    uint64_t seed, uint32_t step);

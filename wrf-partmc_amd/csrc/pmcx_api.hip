@@ -49,6 +49,7 @@ struct pmcx_ctx {
     int64_t *d_offsets = nullptr;
     size_t offsets_cap = 0;
     int64_t *d_totals = nullptr;
+    int64_t *d_acc = nullptr;   // running sums over calls: n_samp, n_coag, n_part, status
     double *d_diag = nullptr; // [n_cells*(2+2*n_dbin)]
     bool aero_data_set = false, env_set = false;
     int bounds_kernel = 0; // kernel type the kmax tables are valid for (0 = none)
@@ -295,6 +296,7 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
     A_(st.gcnt, nc * G); A_(st.goff, nc * G);
     A_(st.n_events, nc); A_(st.n_samp, nc); A_(st.n_coag, nc); A_(st.status, nc);
     A_(ctx->d_totals, (size_t)4);
+    A_(ctx->d_acc, (size_t)4);
     A_(ctx->d_diag, nc * (size_t)(2 + 2 * nd));
 #undef A_
     if (rc != PMCX_OK) {
@@ -693,6 +695,30 @@ int pmcx_get_coag_totals(pmcx_ctx *ctx, int64_t *n_samp, int64_t *n_coag, int64_
     HIP_TRY(ctx, launch_totals(ctx->st, ctx->d_totals, ctx->stream));
     int64_t h[4];
     HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_totals, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_samp) *n_samp = h[0];
+    if (n_coag) *n_coag = h[1];
+    if (n_part) *n_part = h[2];
+    if (status_or) *status_or = (int32_t)h[3];
+    return PMCX_OK;
+}
+
+int pmcx_accumulate_totals(pmcx_ctx *ctx)
+{
+    if (!ctx) return PMCX_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, launch_totals(ctx->st, ctx->d_acc, ctx->stream)); // adds, no host round trip
+    return PMCX_OK;
+}
+
+int pmcx_read_accumulated(pmcx_ctx *ctx, int64_t *n_samp, int64_t *n_coag, int64_t *n_part,
+                          int32_t *status_or, int32_t reset)
+{
+    if (!ctx) return PMCX_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    int64_t h[4];
+    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_acc, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    if (reset) HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0, sizeof h, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (n_samp) *n_samp = h[0];
     if (n_coag) *n_coag = h[1];

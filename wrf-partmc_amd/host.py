@@ -26,7 +26,8 @@ EXPORTED_SYMBOLS = [
     "pmcx_set_aero_data", "pmcx_set_env", "pmcx_set_weights", "pmcx_get_weights",
     "pmcx_set_n_part_ideal", "pmcx_set_next_id", "pmcx_get_next_id", "pmcx_upload_cells",
     "pmcx_get_n_part", "pmcx_download_cells", "pmcx_update_kernel_bounds", "pmcx_mc_coag",
-    "pmcx_get_coag_counters", "pmcx_get_coag_totals", "pmcx_rebalance", "pmcx_condense",
+    "pmcx_get_coag_counters", "pmcx_get_coag_totals", "pmcx_accumulate_totals",
+    "pmcx_read_accumulated", "pmcx_rebalance", "pmcx_condense",
     "pmcx_scenario_update_aero_state",
     "pmcx_diagnostics", "pmcx_diagnostics_ext",
     "pmcx_generate_lognormal", "pmcx_timestep", "pmcx_get_bin_tables", "pmcx_get_diag_grid",
@@ -292,6 +293,16 @@ class CellBlock:
         a, b, p, s = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
         self._ck(self._lib.pmcx_get_coag_totals(self._h, C.byref(a), C.byref(b), C.byref(p),
                                                 C.byref(s)))
+        return a.value, b.value, p.value, s.value
+
+    def accumulate_totals(self):
+        """Add the last mc_coag's sums to the device-side running totals (asynchronous)."""
+        self._ck(self._lib.pmcx_accumulate_totals(self._h))
+
+    def read_accumulated(self, reset=True):
+        a, b, p, s = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
+        self._ck(self._lib.pmcx_read_accumulated(self._h, C.byref(a), C.byref(b), C.byref(p),
+                                                 C.byref(s), int(reset)))
         return a.value, b.value, p.value, s.value
 
     def aero_state_rebalance(self, allow_doubling=True, allow_halving=True, seed=0, step=0):
