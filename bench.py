@@ -185,6 +185,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-cores", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel", type=int, default=4,
+                    help="coag_kernel_type (4 = COAG_KERNEL_TYPE_BROWN, the reference's; others for tuning)")
     ap.add_argument("--workload", choices=["domain", "config3"], default="domain",
                     help="domain: BASELINE configs[4] (default). config3: 1000 cells x 10^4, "
                          "20 species, condensation sub-step + coagulation (BASELINE configs[2])")
@@ -252,7 +254,7 @@ def main():
         blk.generate_lognormal(args.particles, modes3, seed=args.seed)
     else:
         blk.generate_lognormal(args.particles, bench_modes(args.n_spec), seed=args.seed)
-    blk.update_kernel_bounds(wp.COAG_KERNEL_TYPE_BROWN)
+    blk.update_kernel_bounds(args.kernel)
     blk.synchronize()
 
     def barrier():
@@ -265,7 +267,7 @@ def main():
     def one_step(step):
         if config3:
             blk.condense(args.del_t, 4)   # extension: water uptake sub-step before coagulation
-        blk.mc_coag(wp.COAG_KERNEL_TYPE_BROWN, args.del_t, args.seed, step, counters=False)
+        blk.mc_coag(args.kernel, args.del_t, args.seed, step, counters=False)
         blk.accumulate_totals()      # n_samp, n_coag, n_part, status: summed on the device,
         blk.aero_state_rebalance(True, True, args.seed, step)   # no host sync inside the step
 
