@@ -243,8 +243,6 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
     st.cell_id_base = cfg->cell_id_base;
     st.const_k = cfg->const_k; st.additive_beta = cfg->additive_beta;
     st.rho_min = 0; st.rho_max = 0;
-    st.key_bits = 1;
-    while ((1 << st.key_bits) < cfg->n_class * cfg->n_bin) st.key_bits++;
 
     // sort grid (aero_sorted bin_grid) and diagnostics grid (driver:783)
     const int B = cfg->n_bin;

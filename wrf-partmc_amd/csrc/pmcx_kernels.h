@@ -23,7 +23,6 @@ struct DeviceState {
     double rho_min, rho_max;
     float log2_v0, inv_dlog2;  // float estimate of the sort-grid bin from the bits of v
     int32_t bin_fast;          // estimate is within one bin (grid coarse enough)
-    int32_t key_bits;          // bits of a (class,bin) group id
     // model tables
     const double *density; // [n_spec]
     const double *v_edge;  // [n_bin+1]

@@ -69,15 +69,6 @@ __device__ __forceinline__ void mark_dead(const DeviceState &st, int64_t cb, int
     st_u32((uint32_t *)&st.wclass[cb + i], 0xFFFFFFFFu);
 }
 
-__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t x, int lane)
-{
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint64_t y = __shfl_up(x, d, 64);
-        if (lane >= d) x += y;
-    }
-    return x;
-}
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x, int lane)
 {
 #pragma unroll
@@ -498,7 +489,6 @@ struct Grp {
     {
         const uint64_t m = __ballot(p);
         if (L == 64) return m;
-        if (L == 1) return p ? 1ull : 0ull;
         return (m >> (sub * L)) & ((1ull << (L & 63)) - 1ull);
     }
     static __device__ __forceinline__ uint32_t incl_scan(uint32_t x, int gl)
@@ -518,8 +508,9 @@ struct Grp {
     }
 };
 
-template <int L, int OCC>
-__global__ __launch_bounds__(256, OCC) void k_coag_sample(DeviceState st, int ktype, double del_t,
+// launch bounds: 3 wavefronts per SIMD (<= 168 VGPRs) measured fastest; 4 spills, 2 idles
+template <int L>
+__global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktype, double del_t,
                                                      uint64_t seed, uint32_t step,
                                                      uint32_t lds_per_cell)
 {
@@ -547,7 +538,7 @@ __global__ __launch_bounds__(256, OCC) void k_coag_sample(DeviceState st, int kt
         unsigned char *base = smem + (((size_t)(B + 1) * sizeof(double) + 15) & ~(size_t)15) +
                               (size_t)lds_per_cell * (size_t)(wave * GPW + sub);
         size_t o = 0;
-        constexpr int WNL = (L == 64) ? 64 : (L == 1 ? 1 : PMCX_WIN);
+        constexpr int WNL = (L == 64) ? 64 : PMCX_WIN;
         X.L.env = (EnvDerived *)(base + o); o += sizeof(EnvDerived);
         X.L.mask = (uint64_t *)(base + o); o += sizeof(uint64_t) * 2 * (size_t)C;
         X.L.P = (uint32_t *)(base + o); o += sizeof(uint32_t) * (size_t)WNL;
@@ -597,7 +588,7 @@ __global__ __launch_bounds__(256, OCC) void k_coag_sample(DeviceState st, int kt
     // visited through a window of up to WN non-empty partner bins: counts are
     // drawn for the window only, and the window is rebuilt from the slot of an
     // event (whose own count and progress are kept) or moved on when exhausted.
-    constexpr int WN = (L == 64) ? 64 : (L == 1 ? 1 : PMCX_WIN);
+    constexpr int WN = (L == 64) ? 64 : PMCX_WIN;
     int c1 = 0, c2 = 0, b1 = -1;
     int gA = 0, cc = 0, wn = 0, counted = 0, wfrom = 0;
     uint32_t cur_s0 = 0, ns0 = 0;
@@ -1467,7 +1458,7 @@ size_t bin_sort_lds_bytes(const DeviceState &st)
 static size_t sampler_lds_for(const DeviceState &st, int lanes)
 {
     return sampler_lds_bytes(st.n_bin * st.n_class, st.n_class, st.max_appends,
-                             lanes == 64 ? 64 : (lanes == 1 ? 1 : PMCX_WIN));
+                             lanes == 64 ? 64 : PMCX_WIN);
 }
 size_t sampler_lds_bytes_per_cell(const DeviceState &st)
 {
@@ -1478,7 +1469,7 @@ size_t sampler_lds_bytes_per_cell(const DeviceState &st)
 int sampler_lanes(const DeviceState &st)
 {
     const char *e = getenv("PMCX_SAMPLER_LANES");
-    if (e && (atoi(e) == 1 || atoi(e) == 4 || atoi(e) == 8 || atoi(e) == 16 || atoi(e) == 64)) return atoi(e);
+    if (e && (atoi(e) == 8 || atoi(e) == 16 || atoi(e) == 64)) return atoi(e);
     if (sampler_lds_for(st, 16) > 4 * 1024) return 64;
     // 8 lanes per cell (8 cells per wavefront) is the throughput optimum; with few
     // cells the kernel is one wavefront's latency, which is shortest with more lanes
@@ -1590,33 +1581,24 @@ hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, ui
     const int L = sampler_lanes(st);
     const size_t per = sampler_lds_for(st, L);
     const int gpw = 64 / L;
-    // tuning knobs (defaults chosen from measurements)
-    const char *e_wpb = getenv("PMCX_SAMPLER_WPB"), *e_occ = getenv("PMCX_SAMPLER_OCC");
-    int wpb = e_wpb ? atoi(e_wpb) : 2; // wavefronts per workgroup
+    // PMCX_SAMPLER_WPB: wavefronts per workgroup (tuning; 2 measured best)
+    const char *e_wpb = getenv("PMCX_SAMPLER_WPB");
+    int wpb = e_wpb ? atoi(e_wpb) : 2;
     if (wpb != 1 && wpb != 2 && wpb != 4) wpb = 2;
     while (wpb > 1 && shared + per * wpb * gpw > 64 * 1024) wpb >>= 1;
     if (shared + per * wpb * gpw > 160 * 1024) return hipErrorInvalidConfiguration;
-    const int occ = e_occ ? atoi(e_occ) : 3;
     const int cpb = wpb * gpw;
     const size_t lds = shared + per * cpb;
     const dim3 grid((st.n_cells + cpb - 1) / cpb), block(64 * wpb);
-#define PMCX_LAUNCH_SAMPLER(LL, OO)                                                              \
+#define PMCX_LAUNCH_SAMPLER(LL)                                                                  \
     do {                                                                                         \
-        allow_lds(k_coag_sample<LL, OO>, lds);                                                   \
-        hipLaunchKernelGGL((k_coag_sample<LL, OO>), grid, block, lds, s, st, ktype, del_t, seed, \
+        allow_lds(k_coag_sample<LL>, lds);                                                       \
+        hipLaunchKernelGGL((k_coag_sample<LL>), grid, block, lds, s, st, ktype, del_t, seed,     \
                            step, (uint32_t)per);                                                 \
     } while (0)
-    if (L == 1) {
-        if (occ >= 4) PMCX_LAUNCH_SAMPLER(1, 4); else if (occ == 3) PMCX_LAUNCH_SAMPLER(1, 3); else PMCX_LAUNCH_SAMPLER(1, 2);
-    } else if (L == 4) {
-        if (occ >= 4) PMCX_LAUNCH_SAMPLER(4, 4); else if (occ == 3) PMCX_LAUNCH_SAMPLER(4, 3); else PMCX_LAUNCH_SAMPLER(4, 2);
-    } else if (L == 8) {
-        if (occ >= 4) PMCX_LAUNCH_SAMPLER(8, 4); else if (occ == 3) PMCX_LAUNCH_SAMPLER(8, 3); else PMCX_LAUNCH_SAMPLER(8, 2);
-    } else if (L == 16) {
-        if (occ >= 4) PMCX_LAUNCH_SAMPLER(16, 4); else if (occ == 3) PMCX_LAUNCH_SAMPLER(16, 3); else PMCX_LAUNCH_SAMPLER(16, 2);
-    } else {
-        if (occ >= 4) PMCX_LAUNCH_SAMPLER(64, 4); else if (occ == 3) PMCX_LAUNCH_SAMPLER(64, 3); else PMCX_LAUNCH_SAMPLER(64, 2);
-    }
+    if (L == 8) PMCX_LAUNCH_SAMPLER(8);
+    else if (L == 16) PMCX_LAUNCH_SAMPLER(16);
+    else PMCX_LAUNCH_SAMPLER(64);
 #undef PMCX_LAUNCH_SAMPLER
     return hipGetLastError();
 }
