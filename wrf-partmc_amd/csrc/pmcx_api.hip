@@ -269,6 +269,9 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
         ctx->d_edge[k] = std::exp(m0 + (m1 - m0) * (double)k / (double)nd);
     for (int k = 0; k < nd; k++)
         ctx->d_width[k] = std::log(ctx->d_edge[k + 1]) - std::log(ctx->d_edge[k]);
+    st.dlog2_d0 = (float)std::log2(cfg->d_min);
+    st.dinv_dlog2 = (float)((double)nd / (std::log2(cfg->d_max) - std::log2(cfg->d_min)));
+    st.dbin_fast = (st.dinv_dlog2 * 0.09f < 0.9f) ? 1 : 0;
 
     const size_t nc = (size_t)cfg->n_cells, cap = (size_t)cfg->cap;
     const size_t G = (size_t)cfg->n_class * B;

@@ -23,6 +23,8 @@ struct DeviceState {
     double rho_min, rho_max;
     float log2_v0, inv_dlog2;  // float estimate of the sort-grid bin from the bits of v
     int32_t bin_fast;          // estimate is within one bin (grid coarse enough)
+    float dlog2_d0, dinv_dlog2; // same for the diagnostics diameter grid
+    int32_t dbin_fast;
     // model tables
     const double *density; // [n_spec]
     const double *v_edge;  // [n_bin+1]

@@ -1071,22 +1071,26 @@ __global__ __launch_bounds__(256) void k_diagnostics(DeviceState st, double *tot
                                                      double *mass_dist)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int c = blockIdx.x, t = threadIdx.x;
+    const int c = blockIdx.x, t = threadIdx.x, wave = t >> 6;
     const int nd = st.n_dbin, C = st.n_class, S = st.n_spec;
+    // histograms are private to each of the 4 wavefronts (fewer atomic collisions)
     double *edge = (double *)smem;                       // [nd+1]
-    double *msum = edge + (nd + 1);                      // [nd]
-    double *red = msum + nd;                             // [256]
-    uint32_t *ccnt = (uint32_t *)(red + 256);            // [C][nd]
-    uint32_t *clcnt = ccnt + (size_t)C * nd;             // [C]
+    double *msum = edge + (nd + 1);                      // [4][nd]
+    double *red = msum + 4 * nd;                         // [256]
+    uint32_t *ccnt = (uint32_t *)(red + 256);            // [4][C][nd]
+    uint32_t *clcnt = ccnt + 4 * (size_t)C * nd;         // [C]
     for (int j = t; j <= nd; j += 256) edge[j] = st.d_edge[j];
-    for (int j = t; j < nd; j += 256) msum[j] = 0.0;
-    for (int j = t; j < C * nd; j += 256) ccnt[j] = 0;
+    for (int j = t; j < 4 * nd; j += 256) msum[j] = 0.0;
+    for (int j = t; j < 4 * C * nd; j += 256) ccnt[j] = 0;
     for (int j = t; j < C; j += 256) clcnt[j] = 0;
     __syncthreads();
     const int n = st.n_hi[c];
     const int64_t cb = (int64_t)c * st.cap;
     const double *mag = st.mag + (int64_t)c * C;
+    double *my_msum = msum + wave * nd;
+    uint32_t *my_ccnt = ccnt + (size_t)wave * C * nd;
     double tm = 0.0;
+    uint32_t n_live = 0;
     for (int i = t; i < n; i += 256) {
         const int cl = st.wclass[cb + i];
         if (cl < 0) continue; // tombstone
@@ -1098,14 +1102,26 @@ __global__ __launch_bounds__(256) void k_diagnostics(DeviceState st, double *tot
         }
         const double nc = mag[cl];
         const double diam = 2.0 * det_cbrt(vdry * (0.75 / PI));
-        atomicAdd(&clcnt[cl], 1u);
+        if (C == 1) n_live++; else atomicAdd(&clcnt[cl], 1u);
         tm += ms * nc;
         if (diam >= edge[0] && diam < edge[nd]) {
-            const int b = bin_of(edge, nd, diam);
-            atomicAdd(&ccnt[cl * nd + b], 1u);
-            atomicAdd(&msum[b], nc * ms);
+            int b;
+            if (st.dbin_fast) { // float estimate of log2(diam), settled against the two edges
+                const uint32_t hi = (uint32_t)(d2u(diam) >> 32);
+                const float l2 = (float)((int)((hi >> 20) & 0x7FF) - 1023) +
+                                 (float)(hi & 0xFFFFFu) * 0x1.0p-20f;
+                b = (int)((l2 - st.dlog2_d0) * st.dinv_dlog2);
+                b = b < 0 ? 0 : (b > nd - 1 ? nd - 1 : b);
+                b += (int)(diam >= edge[b + 1]) - (int)(diam < edge[b]);
+                b = b < 0 ? 0 : (b > nd - 1 ? nd - 1 : b);
+            } else {
+                b = bin_of(edge, nd, diam);
+            }
+            atomicAdd(&my_ccnt[cl * nd + b], 1u);
+            atomicAdd(&my_msum[b], nc * ms);
         }
     }
+    if (C == 1 && n_live) atomicAdd(&clcnt[0], n_live);
     red[t] = tm;
     __syncthreads();
     for (int d = 128; d >= 1; d >>= 1) {
@@ -1120,9 +1136,14 @@ __global__ __launch_bounds__(256) void k_diagnostics(DeviceState st, double *tot
     }
     for (int b = t; b < nd; b += 256) {
         double x = 0.0;
-        for (int cl = 0; cl < C; cl++) x = x + (double)ccnt[cl * nd + b] * mag[cl];
+        for (int cl = 0; cl < C; cl++) {
+            const uint32_t k = ccnt[cl * nd + b] + ccnt[(C + cl) * nd + b] +
+                               ccnt[(2 * C + cl) * nd + b] + ccnt[(3 * C + cl) * nd + b];
+            x = x + (double)k * mag[cl];
+        }
         num_dist[(int64_t)c * nd + b] = x / st.d_width[b];
-        mass_dist[(int64_t)c * nd + b] = msum[b] / st.d_width[b];
+        mass_dist[(int64_t)c * nd + b] =
+            (((msum[b] + msum[nd + b]) + msum[2 * nd + b]) + msum[3 * nd + b]) / st.d_width[b];
     }
 }
 
@@ -1481,8 +1502,8 @@ int sampler_lanes(const DeviceState &st)
 }
 size_t diagnostics_lds_bytes(const DeviceState &st)
 {
-    return sizeof(double) * (size_t)(2 * st.n_dbin + 1 + 256) +
-           sizeof(uint32_t) * (size_t)(st.n_class * st.n_dbin + st.n_class);
+    return sizeof(double) * (size_t)(5 * st.n_dbin + 1 + 256) +
+           sizeof(uint32_t) * (size_t)(4 * st.n_class * st.n_dbin + st.n_class);
 }
 
 // dynamic LDS above 64 KiB needs the per-function opt-in
