@@ -206,6 +206,24 @@ int pmcx_scenario_update_aero_state(pmcx_ctx *ctx, double dt, double elapsed_tim
                                     int32_t *n_dil_in, int32_t *n_dil_out);
 
 /*
+ * Stochastic particle transport between the cells of this context (SURVEY
+ * section 8, row f2): aero_state_multisample + aero_state_sample_particles_by_class
+ * (interface/wrf_pmc_trans_aero.F90:2351-2482, 2181-2322) in per-particle form.
+ * The context's cells form an nx x nz x ny block in WRF's (i,k,j) order,
+ * cell = (j*nz + k)*nx + i.  prob_h [n_cells][n_class][4]: probability to move to
+ * i-1, i+1, j-1, j+1 (prob_advection + prob_diffusion, :2419-2445); prob_v
+ * [n_cells][n_class][nz]: to level k' of the column (prob_vert_diffusion,
+ * :2446-2460; the own level is ignored); cell_volume [n_cells] (the
+ * dz_source/dz_dest weight factor, :2214-2218).  Lateral boundaries are periodic
+ * or closed; exchange with other contexts (other GPUs) is not part of this call.
+ * n_moved / n_arrived: [n_cells], may be NULL.  Synchronises.
+ */
+int pmcx_transport(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int32_t periodic_x,
+                   int32_t periodic_y, const double *prob_h, const double *prob_v,
+                   const double *cell_volume, uint64_t seed, uint32_t step, int32_t *n_moved,
+                   int32_t *n_arrived);
+
+/*
  * EXTENSION -- water condensation as a per-particle growth-ODE sub-step over
  * del_t at each cell's (temp, pressure, rel_humid): kappa-Koehler equilibrium,
  * Seinfeld & Pandis eq. 17.70 growth law, n_sub sub-steps.  The reference

@@ -805,3 +805,183 @@ void pmco_diagnostics_ext(const pmco_cell *c, int i_water, double *species_mass,
     }
 }
 
+/* ------------------------------------------------------------------------
+ * Stochastic transport, per-particle form of
+ *   aero_state_multisample                  wrf_pmc_trans_aero.F90:2351-2482
+ *   aero_state_sample_particles_by_class    wrf_pmc_trans_aero.F90:2181-2322
+ *
+ * Reference, per source cell and weight class: destinations with prob > 0
+ * (W, E, S, N with prob_advection + prob_diffusion, :2419-2445; every other
+ * level of the column with prob_vert_diffusion, :2446-2460) are sorted by
+ * probability (:2462-2465) and visited with adjusted probabilities
+ * min(prob/remainder, 1) while remainder >= 1e-8 (:2466-2479); each visit
+ * draws a Binomial/Poisson number of particles and moves them one by one,
+ * adding/removing according to the ratio of the destination weight (scaled
+ * by dz_source/dz_dest, :2214-2218) to the source weight (:2236-2262).
+ *
+ * Here the same law is applied particle by particle, which is what makes it
+ * data-parallel: one uniform places a particle in [thr_lo, thr_hi) of one
+ * destination (cumulative probabilities in the sorted order = the sequence of
+ * adjusted Bernoulli trials) or leaves it where it is.  A selected particle
+ * leaves its cell.  With r = weight_to' / weight_from:
+ *   r == 1: one copy arrives                                   (:2254-2257)
+ *   r  > 1: it arrives with probability 1/r                    (:2267-2273)
+ *   r  < 1: G >= 1 copies arrive, P(G = g) = r (1-r)^(g-1), capped at 16;
+ *           the last keeps the id, the others get new ids      (:2258-2266,2279-2283)
+ *           [the reference reaches the same mean 1/r with repeated picks]
+ * Arrivals are appended to the destination in a fixed order: from the east,
+ * west, north, south neighbour, then from levels 0..nz-1 of the column; inside
+ * one source in the order of the particles' rank.
+ * ---------------------------------------------------------------------- */
+
+#define PMCO_TRANS_MAX_COPIES 16
+
+typedef struct { int dest; double lo, hi, ratio; } trans_dest;
+
+/* destination table of (cell c, class cl): returns the number of entries */
+static int trans_table(const pmco_cell *cells, int c, int cl, int nx, int nz, int ny, int px, int py,
+                       const double *prob_h, const double *prob_v, const double *vol, int n_class,
+                       trans_dest *out)
+{
+    const int i = c % nx, k = (c / nx) % nz, j = c / (nx * nz);
+    double p[4 + 128];
+    int dcell[4 + 128], n = 0;
+    const int di[4] = {-1, 1, 0, 0}, dj[4] = {0, 0, -1, 1};
+    for (int d = 0; d < 4; d++) {
+        int ii = i + di[d], jj = j + dj[d];
+        if (ii < 0 || ii >= nx) { if (!px) continue; ii = (ii + nx) % nx; }
+        if (jj < 0 || jj >= ny) { if (!py) continue; jj = (jj + ny) % ny; }
+        const double pr = prob_h[((size_t)c * n_class + cl) * 4 + d];
+        if (pr > 0.0) { p[n] = pr; dcell[n] = (jj * nz + k) * nx + ii; n++; }
+    }
+    for (int kk = 0; kk < nz; kk++) {
+        if (kk == k) continue;
+        const double pr = prob_v[((size_t)c * n_class + cl) * nz + kk];
+        if (pr > 0.0) { p[n] = pr; dcell[n] = (j * nz + kk) * nx + i; n++; }
+    }
+    /* stable ascending sort by probability (:2462-2465) */
+    int ord[4 + 128];
+    for (int a = 0; a < n; a++) {
+        int r = 0;
+        for (int b = 0; b < n; b++) r += (p[b] < p[a]) || (p[b] == p[a] && b < a);
+        ord[r] = a;
+    }
+    double rem = 1.0, cum = 0.0;
+    for (int r = 0; r < n; r++) {
+        const int a = ord[r];
+        out[r].dest = dcell[a];
+        out[r].lo = cum;
+        if (rem >= 1e-8) {               /* remainder_eps, :2400 */
+            cum = cum + p[a];
+            if (cum > 1.0) cum = 1.0;
+            rem = rem - p[a];
+        }
+        out[r].hi = cum;
+        /* weight of the class in the destination scaled by dz_source/dz_dest (:2214-2218) */
+        const double factor = vol[c] / vol[dcell[a]];
+        out[r].ratio = (cells[dcell[a]].mag[cl] / factor) / cells[c].mag[cl];
+    }
+    return n;
+}
+
+int pmco_transport(pmco_cell *cells, int n_cells, int nx, int nz, int ny, int periodic_x,
+                   int periodic_y, const double *prob_h, const double *prob_v,
+                   const double *cell_volume, uint64_t seed, uint32_t cell_id_base,
+                   uint32_t step, int64_t *next_id, int32_t *n_moved, int32_t *n_arrived)
+{
+    const int C = cells[0].n_class;
+    int status = 0;
+    /* phase 1: every particle decides; outbox entries (slot, dest, copies) in rank order */
+    typedef struct { int32_t slot, dest, copies; } entry;
+    entry **box = (entry **)calloc((size_t)n_cells, sizeof(entry *));
+    int *nbox = (int *)calloc((size_t)n_cells, sizeof(int));
+    trans_dest *tab = (trans_dest *)malloc(sizeof(trans_dest) * (size_t)C * (4 + 128));
+    int *ntab = (int *)malloc(sizeof(int) * (size_t)C);
+    for (int c = 0; c < n_cells; c++) {
+        pmco_cell *s = &cells[c];
+        const int n = *s->n_part;
+        box[c] = (entry *)malloc(sizeof(entry) * (size_t)(n > 0 ? n : 1));
+        for (int cl = 0; cl < C; cl++)
+            ntab[cl] = trans_table(cells, c, cl, nx, nz, ny, periodic_x, periodic_y, prob_h, prob_v,
+                                   cell_volume, C, tab + (size_t)cl * (4 + 128));
+        for (int i = 0; i < n; i++) {
+            const int cl = s->wclass[i];
+            const trans_dest *t = tab + (size_t)cl * (4 + 128);
+            if (ntab[cl] == 0) continue;
+            uint32_t w[4];
+            pmco_rng_block(seed, cell_id_base + (uint32_t)c, step, (uint32_t)i, PMCO_SITE_TRANS, 0, w);
+            const double u = pmco_u53(w[0], w[1]);
+            if (!(u < t[ntab[cl] - 1].hi)) continue;      /* stays */
+            int d = 0;
+            while (!(u < t[d].hi)) d++;
+            const double r = t[d].ratio, u2 = pmco_u53(w[2], w[3]);
+            int copies = 1;
+            if (r > 1.0) copies = (u2 < 1.0 / r) ? 1 : 0;
+            else if (r < 1.0) {
+                copies = 1 + (int)(pmco_log(1.0 - u2) / pmco_log(1.0 - r));
+                if (copies > PMCO_TRANS_MAX_COPIES) copies = PMCO_TRANS_MAX_COPIES;
+            }
+            box[c][nbox[c]].slot = i; box[c][nbox[c]].dest = t[d].dest; box[c][nbox[c]].copies = copies;
+            nbox[c]++;
+        }
+        n_moved[c] = nbox[c];
+    }
+    /* phase 2: arrivals appended in the fixed source order; sources still hold their data */
+    int *n_old = (int *)malloc(sizeof(int) * (size_t)n_cells);
+    for (int c = 0; c < n_cells; c++) n_old[c] = *cells[c].n_part;
+    for (int c = 0; c < n_cells; c++) {
+        pmco_cell *dst = &cells[c];
+        const int i = c % nx, k = (c / nx) % nz, j = c / (nx * nz);
+        int src[4 + 128], ns = 0;
+        const int di[4] = {1, -1, 0, 0}, dj[4] = {0, 0, 1, -1}; /* east, west, north, south neighbour */
+        for (int d = 0; d < 4; d++) {
+            int ii = i + di[d], jj = j + dj[d];
+            if (ii < 0 || ii >= nx) { if (!periodic_x) continue; ii = (ii + nx) % nx; }
+            if (jj < 0 || jj >= ny) { if (!periodic_y) continue; jj = (jj + ny) % ny; }
+            src[ns++] = (jj * nz + k) * nx + ii;
+        }
+        for (int kk = 0; kk < nz; kk++) if (kk != k) src[ns++] = (j * nz + kk) * nx + i;
+        int arrived = 0;
+        for (int q = 0; q < ns; q++) {
+            const int sc = src[q];
+            /* a neighbour can appear twice under periodic wrap with nx or ny <= 2: take it once */
+            int dup = 0;
+            for (int q2 = 0; q2 < q; q2++) dup |= (src[q2] == sc);
+            if (dup || sc == c) continue;
+            const pmco_cell *s = &cells[sc];
+            for (int e = 0; e < nbox[sc]; e++) {
+                if (box[sc][e].dest != c) continue;
+                for (int g = 0; g < box[sc][e].copies; g++) {
+                    const int at = *dst->n_part;
+                    if (at >= dst->cap) { status |= PMCO_ST_CAP_OVERFLOW; continue; }
+                    const int from = box[sc][e].slot;
+                    for (int sp = 0; sp < dst->n_spec; sp++)
+                        dst->vol[(size_t)sp * dst->cap + at] = s->vol[(size_t)sp * s->cap + from];
+                    for (int sp = 0; sp < dst->n_source; sp++)
+                        dst->n_orig[(size_t)sp * dst->cap + at] = s->n_orig[(size_t)sp * s->cap + from];
+                    dst->vtot[at] = s->vtot[from]; dst->mass[at] = s->mass[from];
+                    dst->wclass[at] = s->wclass[from];
+                    dst->lct[at] = s->lct[from]; dst->gct[at] = s->gct[from];
+                    if (g == box[sc][e].copies - 1) dst->id[at] = s->id[from];
+                    else { dst->id[at] = next_id[c]; next_id[c]++; }
+                    *dst->n_part = at + 1;
+                    arrived++;
+                }
+            }
+        }
+        n_arrived[c] = arrived;
+    }
+    /* phase 3: the movers leave (stable compaction keeps arrivals behind the survivors) */
+    for (int c = 0; c < n_cells; c++) {
+        const int n = *cells[c].n_part;
+        unsigned char *dead = (unsigned char *)calloc((size_t)(n > 0 ? n : 1), 1);
+        for (int e = 0; e < nbox[c]; e++) dead[box[c][e].slot] = 1;
+        compact_stable(&cells[c], dead, n, nbox[c]);
+        free(dead);
+        free(box[c]);
+    }
+    (void)n_old;
+    free(n_old); free(box); free(nbox); free(tab); free(ntab);
+    return status;
+}
+

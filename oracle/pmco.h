@@ -170,6 +170,20 @@ int pmco_scenario_update(pmco_cell *c, double dt, double create_time, uint64_t s
                          int64_t *next_id, int32_t *n_emit, int32_t *n_dil_in,
                          int32_t *n_dil_out);
 
+/* Stochastic particle transport between the cells of a block:
+ * aero_state_multisample + aero_state_sample_particles_by_class
+ * (interface/wrf_pmc_trans_aero.F90:2351-2482, 2181-2322), per-particle form.
+ * cells[] in WRF order: cell = (j*nz + k)*nx + i.
+ *   prob_h [n_cells][n_class][4]  to i-1, i+1, j-1, j+1 (prob_advection + prob_diffusion)
+ *   prob_v [n_cells][n_class][nz] to level k' of the same column (prob_vert_diffusion)
+ *   cell_volume [n_cells]
+ * Lateral boundaries are periodic or closed (a destination outside the block
+ * is dropped from the list).  n_moved[c] = particles that left cell c. */
+int pmco_transport(pmco_cell *cells, int n_cells, int nx, int nz, int ny, int periodic_x,
+                   int periodic_y, const double *prob_h, const double *prob_v,
+                   const double *cell_volume, uint64_t seed, uint32_t cell_id_base,
+                   uint32_t step, int64_t *next_id, int32_t *n_moved, int32_t *n_arrived);
+
 /* EXTENSION (no call site on the reference's timestep): water condensation,
  * kappa-Koehler growth ODE per particle, environment fixed over del_t. */
 void pmco_condense(pmco_cell *c, const double *kappa /*[n_spec]*/, int i_water,

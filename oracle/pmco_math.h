@@ -60,7 +60,8 @@ enum {
     PMCO_SITE_GENCLS  = 6,  /* synthetic generator: weight class draw     */
     PMCO_SITE_EMIT_N  = 7,  /* scenario: number of new particles of a mode */
     PMCO_SITE_EMIT_P  = 8,  /* scenario: one new particle                  */
-    PMCO_SITE_DILUTE  = 9   /* scenario: keep/drop one particle (dilution) */
+    PMCO_SITE_DILUTE  = 9,  /* scenario: keep/drop one particle (dilution) */
+    PMCO_SITE_TRANS   = 10  /* transport: destination and copies of one particle */
 };
 
 /* One 128-bit block of the stream: counter = (cell, step, a, site<<28 | b),

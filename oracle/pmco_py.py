@@ -252,3 +252,21 @@ class Cell:
         lib().pmco_generate(C.byref(self.view()), C.byref(g), n, seed, cell_id, first_id,
                             create_time)
         return fr, lg, ls, vf, mc, msrc
+
+
+def transport(cells, nx, nz, ny, prob_h, prob_v, cell_volume, seed, cell_id_base, step, next_id,
+              periodic_x=True, periodic_y=True):
+    """pmco_transport over a list of Cell objects (WRF order).  next_id: int64 array, updated."""
+    n = len(cells)
+    arr = (CellStruct * n)(*[c.view() for c in cells])
+    ph = np.ascontiguousarray(prob_h, dtype=np.float64)
+    pv = np.ascontiguousarray(prob_v, dtype=np.float64)
+    cv = np.ascontiguousarray(cell_volume, dtype=np.float64)
+    nm, na = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+    f = lib().pmco_transport
+    f.restype = C.c_int
+    f.argtypes = [C.POINTER(CellStruct), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp,
+                  _dp, _dp, C.c_uint64, C.c_uint32, C.c_uint32, _lp, _ip, _ip]
+    st = f(arr, n, nx, nz, ny, int(periodic_x), int(periodic_y), _p(ph, _dp), _p(pv, _dp),
+           _p(cv, _dp), seed, cell_id_base, step, _p(next_id, _lp), _p(nm, _ip), _p(na, _ip))
+    return st, nm, na

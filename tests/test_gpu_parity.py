@@ -501,3 +501,65 @@ def test_results_independent_of_launch_geometry(wp, oracle, monkeypatch):
         for k in ("part_offset", "vol", "wclass", "id", "least_ct", "greatest_ct", "n_orig"):
             assert np.array_equal(dn[k], outs[0][1][k]), k
     assert sum(outs[0][0][0][1]) > 50
+
+
+def _transport_probs(n_cells, n_class, nz, seed, scale=0.08):
+    rng = np.random.RandomState(seed)
+    ph = rng.uniform(0, scale, (n_cells, n_class, 4))
+    ph[rng.uniform(size=ph.shape) < 0.2] = 0.0                       # some directions closed
+    pv = rng.uniform(0, scale / 2, (n_cells, n_class, nz)) * (rng.uniform(size=(n_cells, n_class, nz)) < 0.5)
+    cv = rng.uniform(0.8e9, 1.3e9, n_cells)
+    return ph, pv, cv
+
+
+@pytest.mark.parametrize("nx,nz,ny,px,py", [(3, 4, 2, True, True), (2, 3, 2, True, True),
+                                            (4, 5, 1, False, False)])
+def test_transport_parity(wp, oracle, nx, nz, ny, px, py):
+    """stochastic transport between cells, GPU vs oracle bit for bit, followed by
+    a coagulation step on the mixed populations."""
+    n_cells, n_part, n_spec, n_class = nx * nz * ny, 700, 2, 2
+    blk, cells, info = parity.setup_pair(wp, oracle, n_cells, n_part, n_spec, n_class, 13, K_BROWN,
+                                         cap=2048, n_source=2)
+    ph, pv, cv = _transport_probs(n_cells, n_class, nz, 5)
+    next_id = np.array([oc.next_id for oc in cells], dtype=np.int64)
+    total0 = sum(int(oc.n_part[0]) for oc in cells)
+    for step in range(3):
+        nm, na = blk.transport(nx, nz, ny, ph, pv, cv, 13, step, px, py)
+        st, onm, ona = oracle.transport(cells, nx, nz, ny, ph, pv, cv, 13, 0, step, next_id, px, py)
+        assert st == 0
+        assert np.array_equal(nm, onm) and np.array_equal(na, ona), step
+        ok, msg = parity.compare_state(blk, cells)
+        assert ok, f"step {step}: {msg}"
+        assert np.array_equal(blk.get_next_id(), next_id)
+        ns, nc, s2 = blk.mc_coag(K_BROWN, 600.0, 13, step)
+        for c, oc in enumerate(cells):
+            assert oc.mc_coag(K_BROWN, 600.0, 13, oc.cell_id, step) == (int(s2[c]), int(ns[c]), int(nc[c]))
+    assert nm.sum() > n_cells * 10
+    ok, msg = parity.compare_state(blk, cells)
+    assert ok, msg
+    blk.close()
+
+
+def test_transport_conserves_with_equal_weights(wp):
+    """Equal weights and volumes everywhere: every mover arrives exactly once, so the total
+    particle count and the multiset of ids are conserved; a closed box keeps everything in."""
+    nx, nz, ny = 4, 3, 3
+    n_cells, n_part = nx * nz * ny, 900
+    blk = wp.CellBlock(n_cells, 2048, 1)
+    blk.set_aero_data([1500.0])
+    blk.set_env(280.0, 9e4)
+    blk.set_weights(np.full((n_cells, 1), 1e7))
+    blk.set_next_id((np.arange(n_cells, dtype=np.int64) << 32) + (1 << 24))
+    from wrf_partmc_amd.data import idealised_modes
+    blk.generate_lognormal(n_part, idealised_modes(1), seed=1)
+    ids0 = np.sort(blk.download_cells()["id"])
+    ph = np.full((n_cells, 1, 4), 0.06); pv = np.full((n_cells, 1, nz), 0.02)
+    moved = 0
+    for step in range(4):
+        nm, na = blk.transport(nx, nz, ny, ph, pv, np.ones(n_cells), 1, step, False, False)
+        assert nm.sum() == na.sum()
+        moved += int(nm.sum())
+    dn = blk.download_cells()
+    assert np.array_equal(np.sort(dn["id"]), ids0)
+    assert moved > 0.15 * n_cells * n_part
+    blk.close()

@@ -49,6 +49,8 @@ struct pmcx_ctx {
     int64_t *d_offsets = nullptr;
     size_t offsets_cap = 0;
     int64_t *d_totals = nullptr;
+    void *d_outbox = nullptr;   // transport outboxes, allocated on first use
+    int32_t *d_n_out = nullptr, *d_n_arr = nullptr;
     int64_t *d_acc = nullptr;   // running sums over calls: n_samp, n_coag, n_part, status
     double *d_diag = nullptr; // [n_cells*(2+2*n_dbin)]
     bool aero_data_set = false, env_set = false;
@@ -813,6 +815,48 @@ int pmcx_scenario_update_aero_state(pmcx_ctx *ctx, double dt, double elapsed_tim
     cleanup();
     ctx->sorted_valid = false;
     if (e != hipSuccess) return fail(ctx, PMCX_EDEVICE, "pmcx_scenario_update_aero_state: %s", hipGetErrorString(e));
+    return PMCX_OK;
+}
+
+int pmcx_transport(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int32_t periodic_x,
+                   int32_t periodic_y, const double *prob_h, const double *prob_v,
+                   const double *cell_volume, uint64_t seed, uint32_t step, int32_t *n_moved,
+                   int32_t *n_arrived)
+{
+    if (!ctx || !prob_h || !prob_v || !cell_volume)
+        return fail(ctx, PMCX_EINVAL, "pmcx_transport: null argument");
+    const pmcx_config &cf = ctx->cfg;
+    if (nx < 1 || nz < 1 || ny < 1 || nz > 128 || (int64_t)nx * nz * ny != cf.n_cells)
+        return fail(ctx, PMCX_EINVAL, "pmcx_transport: nx*nz*ny must equal n_cells (nz <= 128)");
+    if (transport_lds_bytes(ctx->st, nz) > 160 * 1024)
+        return fail(ctx, PMCX_EINVAL, "pmcx_transport: n_class x (4+nz) destination tables exceed LDS");
+    HIP_TRY(ctx, hipSetDevice(cf.device));
+    const size_t nc = (size_t)cf.n_cells, C = (size_t)cf.n_class;
+    if (!ctx->d_outbox) {
+        int rc = dev_alloc(ctx, (int64_t **)&ctx->d_outbox, nc * (size_t)cf.cap, false);
+        if (!rc) rc = dev_alloc(ctx, &ctx->d_n_out, nc);
+        if (!rc) rc = dev_alloc(ctx, &ctx->d_n_arr, nc);
+        if (rc) return rc;
+    }
+    const size_t bh = sizeof(double) * nc * C * 4, bv = sizeof(double) * nc * C * (size_t)nz,
+                 bc = sizeof(double) * nc;
+    int rc = ensure_stage(ctx, bh + bv + bc + 64);
+    if (rc) return rc;
+    double *d_ph = (double *)ctx->stage, *d_pv = d_ph + nc * C * 4, *d_cv = d_pv + nc * C * (size_t)nz;
+    HIP_TRY(ctx, hipMemcpyAsync(d_ph, prob_h, bh, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_pv, prob_v, bv, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_cv, cell_volume, bc, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->st.status, 0, sizeof(int32_t) * nc, ctx->stream));
+    {
+        ProfScope ps(ctx, "transport");
+        HIP_TRY(ctx, launch_transport(ctx->st, nx, nz, ny, periodic_x, periodic_y, d_ph, d_pv, d_cv,
+                                      ctx->d_outbox, ctx->d_n_out, ctx->d_n_arr, seed, step,
+                                      ctx->stream));
+    }
+    if (n_moved) HIP_TRY(ctx, hipMemcpyAsync(n_moved, ctx->d_n_out, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));
+    if (n_arrived) HIP_TRY(ctx, hipMemcpyAsync(n_arrived, ctx->d_n_arr, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->sorted_valid = false;
     return PMCX_OK;
 }
 

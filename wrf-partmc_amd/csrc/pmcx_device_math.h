@@ -44,7 +44,8 @@ enum : uint32_t {
     SITE_GENCLS = 6,
     SITE_EMIT_N = 7,
     SITE_EMIT_P = 8,
-    SITE_DILUTE = 9
+    SITE_DILUTE = 9,
+    SITE_TRANS = 10
 };
 
 // counter = (cell, step, a, site<<28 | b); key = seed

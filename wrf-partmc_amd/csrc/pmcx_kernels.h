@@ -100,6 +100,11 @@ hipError_t launch_scenario_update(const DeviceState &st, double dt, double creat
                                   const double *dilution_rate, const GenSpecDev *bg,
                                   const double *bg_conc, int32_t *n_emit, int32_t *n_dil_in,
                                   int32_t *n_dil_out, hipStream_t s);
+size_t transport_lds_bytes(const DeviceState &st, int nz);
+hipError_t launch_transport(const DeviceState &st, int nx, int nz, int ny, int periodic_x,
+                            int periodic_y, const double *prob_h, const double *prob_v,
+                            const double *cell_volume, void *outbox, int32_t *n_out, int32_t *n_arr,
+                            uint64_t seed, uint32_t step, hipStream_t s);
 hipError_t launch_condense(const DeviceState &st, const double *kappa, const double *rel_humid,
                            double del_t, int n_sub, hipStream_t s);
 hipError_t launch_totals(const DeviceState &st, int64_t *out4, hipStream_t s);

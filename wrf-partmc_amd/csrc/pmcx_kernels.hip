@@ -1307,6 +1307,228 @@ __global__ __launch_bounds__(64) void k_scenario_update(DeviceState st, double d
     }
 }
 
+// ---------------------------------------------------------------- transport
+//
+// Stochastic particle transport between the cells of a block:
+// aero_state_multisample + aero_state_sample_particles_by_class
+// (interface/wrf_pmc_trans_aero.F90:2351-2482, 2181-2322) in per-particle form
+// (every particle draws its own destination; see oracle/pmco.c for the law).
+//   k_trans_decide  one wavefront per source cell: destination tables of each
+//                   class in LDS (sorted by probability, cumulative thresholds,
+//                   weight ratios), one Philox block per live particle, movers
+//                   compacted into the cell's outbox in rank order
+//   k_trans_gather  one wavefront per destination cell: scans the outboxes of
+//                   its sources in a fixed order and appends the arrivals
+//   k_trans_remove  one wavefront per source cell: movers become tombstones
+
+constexpr int TRANS_MAX_COPIES = 16;
+
+struct TransGrid {
+    int32_t nx, nz, ny, periodic_x, periodic_y;
+    const double *prob_h, *prob_v, *cell_volume;
+    int2 *outbox;     // [n_cells][cap]  {slot | copies << 16, destination cell}
+    int32_t *n_out;   // [n_cells]
+    int32_t *n_arr;   // [n_cells]
+};
+
+__global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid tg, uint64_t seed,
+                                                     uint32_t step)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x, c = blockIdx.x;
+    const int C = st.n_class, nx = tg.nx, nz = tg.nz, ny = tg.ny;
+    const int ND = 4 + nz;
+    double *t_lo = (double *)smem;           // [C][ND]
+    double *t_hi = t_lo + C * ND;
+    double *t_ratio = t_hi + C * ND;
+    double *t_p = t_ratio + C * ND;          // scratch: probabilities before sorting
+    int *t_dest = (int *)(t_p + C * ND);     // [C][ND]
+    int *t_tmpd = t_dest + C * ND;           // scratch: destinations before sorting
+    int *t_n = t_tmpd + C * ND;              // [C]
+    const int i = c % nx, k = (c / nx) % nz, j = c / (nx * nz);
+    const int64_t cb = (int64_t)c * st.cap;
+    const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
+    const uint64_t lt = (1ull << lane) - 1ull;
+
+    // destination tables (serial per class: the cumulative sums are order dependent)
+    if (lane < C) {
+        const int cl = lane;
+        double *p = t_p + cl * ND;
+        int *dc = t_tmpd + cl * ND, n = 0;
+        const int di[4] = {-1, 1, 0, 0}, dj[4] = {0, 0, -1, 1};
+        for (int d = 0; d < 4; d++) {
+            int ii = i + di[d], jj = j + dj[d];
+            if (ii < 0 || ii >= nx) { if (!tg.periodic_x) continue; ii = (ii + nx) % nx; }
+            if (jj < 0 || jj >= ny) { if (!tg.periodic_y) continue; jj = (jj + ny) % ny; }
+            const double pr = tg.prob_h[((int64_t)c * C + cl) * 4 + d];
+            if (pr > 0.0) { p[n] = pr; dc[n] = (jj * nz + k) * nx + ii; n++; }
+        }
+        for (int kk = 0; kk < nz; kk++) {
+            if (kk == k) continue;
+            const double pr = tg.prob_v[((int64_t)c * C + cl) * nz + kk];
+            if (pr > 0.0) { p[n] = pr; dc[n] = (j * nz + kk) * nx + i; n++; }
+        }
+        // stable ascending order by probability, then thresholds in that order
+        double rem = 1.0, cum = 0.0;
+        const double mag_from = st.mag[(int64_t)c * C + cl];
+        int *ord = t_dest + cl * ND; // rank -> element, overwritten by the destinations below
+        for (int x = 0; x < n; x++) {
+            int rk = 0;
+            for (int y = 0; y < n; y++) rk += (p[y] < p[x]) || (p[y] == p[x] && y < x);
+            ord[rk] = x;
+        }
+        for (int r = 0; r < n; r++) {
+            const int a = ord[r];
+            t_dest[cl * ND + r] = dc[a];
+            t_lo[cl * ND + r] = cum;
+            if (rem >= 1e-8) {
+                cum = cum + p[a];
+                if (cum > 1.0) cum = 1.0;
+                rem = rem - p[a];
+            }
+            t_hi[cl * ND + r] = cum;
+            const double factor = tg.cell_volume[c] / tg.cell_volume[dc[a]];
+            t_ratio[cl * ND + r] = (st.mag[(int64_t)dc[a] * C + cl] / factor) / mag_from;
+        }
+        t_n[cl] = n;
+    }
+    wave_sync();
+
+    const int n_hi = st.n_hi[c];
+    int2 *box = tg.outbox + cb;
+    uint32_t rank0 = 0, n_out = 0;
+    for (int i0 = 0; i0 < n_hi; i0 += 64) {
+        const int s = i0 + lane;
+        const int cl = s < n_hi ? st.wclass[cb + s] : -1;
+        const uint64_t mlive = __ballot(cl >= 0);
+        const uint32_t rank = rank0 + (uint32_t)__popcll(mlive & lt);
+        bool moves = false;
+        int dest = 0, copies = 0;
+        if (cl >= 0 && t_n[cl] > 0) {
+            uint32_t w[4];
+            rng_block(seed, cell_id, step, rank, SITE_TRANS, 0, w);
+            const double u = u53(w[0], w[1]);
+            const int nt = t_n[cl];
+            if (u < t_hi[cl * ND + nt - 1]) {
+                int d = 0;
+                while (!(u < t_hi[cl * ND + d])) d++;
+                const double r = t_ratio[cl * ND + d], u2 = u53(w[2], w[3]);
+                copies = 1;
+                if (r > 1.0) copies = (u2 < 1.0 / r) ? 1 : 0;
+                else if (r < 1.0) {
+                    copies = 1 + (int)(det_log(1.0 - u2) / det_log(1.0 - r));
+                    if (copies > TRANS_MAX_COPIES) copies = TRANS_MAX_COPIES;
+                }
+                dest = t_dest[cl * ND + d];
+                moves = true;
+            }
+        }
+        const uint64_t mm = __ballot(moves);
+        if (moves) box[n_out + (uint32_t)__popcll(mm & lt)] = make_int2(s | (copies << 16), dest);
+        n_out += (uint32_t)__popcll(mm);
+        rank0 += (uint32_t)__popcll(mlive);
+    }
+    if (lane == 0) tg.n_out[c] = (int32_t)n_out;
+}
+
+__global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid tg)
+{
+    const int lane = threadIdx.x, c = blockIdx.x;
+    const int nx = tg.nx, nz = tg.nz, ny = tg.ny;
+    const int i = c % nx, k = (c / nx) % nz, j = c / (nx * nz);
+    const int64_t cb = (int64_t)c * st.cap;
+    const int S = st.n_spec, NS = st.n_source;
+    const int n_hi0 = st.n_hi[c];
+    int at = n_hi0;                 // next free slot of this cell
+    int64_t nid = st.next_id[c];
+    int status = 0;
+    // sources in the fixed order: east, west, north, south neighbour, then the column
+    for (int q = 0; q < 4 + nz; q++) {
+        int sc = -1;
+        if (q < 4) {
+            const int di[4] = {1, -1, 0, 0}, dj[4] = {0, 0, 1, -1};
+            int ii = i + di[q], jj = j + dj[q];
+            bool ok = true;
+            if (ii < 0 || ii >= nx) { if (!tg.periodic_x) ok = false; else ii = (ii + nx) % nx; }
+            if (jj < 0 || jj >= ny) { if (!tg.periodic_y) ok = false; else jj = (jj + ny) % ny; }
+            if (ok) sc = (jj * nz + k) * nx + ii;
+            // under periodic wrap with nx or ny <= 2 a neighbour repeats (or is the cell itself)
+            for (int q2 = 0; q2 < q && sc >= 0; q2++) {
+                int i2 = i + di[q2], j2 = j + dj[q2];
+                bool ok2 = true;
+                if (i2 < 0 || i2 >= nx) { if (!tg.periodic_x) ok2 = false; else i2 = (i2 + nx) % nx; }
+                if (j2 < 0 || j2 >= ny) { if (!tg.periodic_y) ok2 = false; else j2 = (j2 + ny) % ny; }
+                if (ok2 && (j2 * nz + k) * nx + i2 == sc) sc = -1;
+            }
+            if (sc == c) sc = -1;
+        } else {
+            const int kk = q - 4;
+            if (kk != k) sc = (j * nz + kk) * nx + i;
+        }
+        if (sc < 0) continue;
+        const int64_t sb = (int64_t)sc * st.cap;
+        const int2 *box = tg.outbox + sb;
+        const int n_out = tg.n_out[sc];
+        for (int e0 = 0; e0 < n_out; e0 += 64) {
+            const int e = e0 + lane;
+            int2 en = make_int2(0, -1);
+            if (e < n_out) en = box[e];
+            const bool mine = en.y == c;
+            const int copies = mine ? (en.x >> 16) : 0;
+            const int from = en.x & 0xFFFF;
+            // slots and new ids of this entry's copies: prefix sums over the chunk
+            const uint32_t inc = wave_incl_scan_u32((uint32_t)copies, lane);
+            const uint32_t first = (uint32_t)at + inc - (uint32_t)copies;
+            const uint32_t n_new = copies > 0 ? (uint32_t)(copies - 1) : 0u;
+            const uint32_t inc_new = wave_incl_scan_u32(n_new, lane);
+            const int64_t id0 = nid + (int64_t)(inc_new - n_new);
+            for (int g = 0; g < copies; g++) {
+                const int dst = (int)first + g;
+                if (dst >= st.cap) { status |= ST_CAP_OVERFLOW; break; }
+                for (int sp = 0; sp < S; sp++)
+                    st.vol[cb * S + (int64_t)sp * st.cap + dst] = st.vol[sb * S + (int64_t)sp * st.cap + from];
+                for (int sp = 0; sp < NS; sp++)
+                    st.n_orig[cb * NS + (int64_t)sp * st.cap + dst] = st.n_orig[sb * NS + (int64_t)sp * st.cap + from];
+                st.vtot[cb + dst] = st.vtot[sb + from];
+                st.mass[cb + dst] = st.mass[sb + from];
+                st.wclass[cb + dst] = st.wclass[sb + from];
+                st.lct[cb + dst] = st.lct[sb + from];
+                st.gct[cb + dst] = st.gct[sb + from];
+                st.id[cb + dst] = (g == copies - 1) ? st.id[sb + from] : id0 + g;
+            }
+            at += (int)__shfl(inc, 63, 64);
+            nid += (int64_t)__shfl(inc_new, 63, 64);
+        }
+    }
+    if (__ballot(status != 0)) status = ST_CAP_OVERFLOW;
+    if (at > st.cap) at = st.cap;
+    if (lane == 0) {
+        st.n_hi[c] = at;
+        st.n_part[c] = st.n_part[c] + (at - n_hi0);
+        st.next_id[c] = nid;
+        tg.n_arr[c] = at - n_hi0;
+        if (status) atomicOr(&st.status[c], status);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_trans_remove(DeviceState st, TransGrid tg)
+{
+    const int lane = threadIdx.x, c = blockIdx.x;
+    const int64_t cb = (int64_t)c * st.cap;
+    const int n_out = tg.n_out[c];
+    const int2 *box = tg.outbox + cb;
+    for (int e = lane; e < n_out; e += 64) mark_dead(st, cb, box[e].x & 0xFFFF);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wave_sync();
+    const int n_live = st.n_part[c] - n_out;
+    if (lane == 0) st.n_part[c] = n_live;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __threadfence_block();
+    wave_sync();
+    const int n_hi = st.n_hi[c];
+    if ((n_hi - n_live) * 8 > n_hi) compact_wave(st, c, lane);
+}
+
 // ------------------------------------------------------------- condensation
 //
 // EXTENSION (see pmcx_device_math.h): water uptake of every live particle over
@@ -1665,6 +1887,25 @@ hipError_t launch_scenario_update(const DeviceState &st, double dt, double creat
                             bg->mode_class, bg->mode_source};
     hipLaunchKernelGGL(k_scenario_update, dim3(st.n_cells), dim3(64), 0, s, st, dt, create_time,
                        seed, step, e, dilution_rate, b, n_emit, n_dil_in, n_dil_out);
+    return hipGetLastError();
+}
+size_t transport_lds_bytes(const DeviceState &st, int nz)
+{
+    const size_t nd = (size_t)(4 + nz), C = (size_t)st.n_class;
+    return (sizeof(double) * 4 + sizeof(int) * 2) * C * nd + sizeof(int) * C + 16;
+}
+hipError_t launch_transport(const DeviceState &st, int nx, int nz, int ny, int periodic_x,
+                            int periodic_y, const double *prob_h, const double *prob_v,
+                            const double *cell_volume, void *outbox, int32_t *n_out, int32_t *n_arr,
+                            uint64_t seed, uint32_t step, hipStream_t s)
+{
+    TransGrid tg{nx, nz, ny, periodic_x, periodic_y, prob_h, prob_v, cell_volume, (int2 *)outbox,
+                 n_out, n_arr};
+    const size_t lds = transport_lds_bytes(st, nz);
+    allow_lds(k_trans_decide, lds);
+    hipLaunchKernelGGL(k_trans_decide, dim3(st.n_cells), dim3(64), lds, s, st, tg, seed, step);
+    hipLaunchKernelGGL(k_trans_gather, dim3(st.n_cells), dim3(64), 0, s, st, tg);
+    hipLaunchKernelGGL(k_trans_remove, dim3(st.n_cells), dim3(64), 0, s, st, tg);
     return hipGetLastError();
 }
 hipError_t launch_condense(const DeviceState &st, const double *kappa, const double *rel_humid,

@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "pmcx_get_n_part", "pmcx_download_cells", "pmcx_update_kernel_bounds", "pmcx_mc_coag",
     "pmcx_get_coag_counters", "pmcx_get_coag_totals", "pmcx_accumulate_totals",
     "pmcx_read_accumulated", "pmcx_rebalance", "pmcx_condense",
-    "pmcx_scenario_update_aero_state",
+    "pmcx_scenario_update_aero_state", "pmcx_transport",
     "pmcx_diagnostics", "pmcx_diagnostics_ext",
     "pmcx_generate_lognormal", "pmcx_timestep", "pmcx_get_bin_tables", "pmcx_get_diag_grid",
     "pmcx_get_kmax", "pmcx_get_caches", "pmcx_sort_only", "pmcx_get_sort", "pmcx_test_math",
@@ -108,6 +108,9 @@ def load_library():
     L.pmcx_mc_coag.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_uint64, C.c_uint32]
     L.pmcx_rebalance.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_uint32]
     L.pmcx_condense.argtypes = [C.c_void_p, C.c_double, C.c_int32]
+    L.pmcx_transport.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
+                                 C.c_void_p, C.c_void_p]
     L.pmcx_scenario_update_aero_state.argtypes = [
         C.c_void_p, C.c_double, C.c_double, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -339,6 +342,19 @@ class CellBlock:
             self._h, dt, elapsed_time, seed, step, C.addressof(e) if e else None, _ptr(dil),
             C.addressof(b) if b else None, _ptr(ne), _ptr(ni), _ptr(no)))
         return ne, ni, no
+
+    def transport(self, nx, nz, ny, prob_h, prob_v, cell_volume, seed=0, step=0, periodic_x=True,
+                  periodic_y=True):
+        """Stochastic transport between the block's cells (wrf_pmc_trans_aero.F90:2351-2482).
+        Returns (n_moved, n_arrived) per cell."""
+        n, Cn = self.cfg.n_cells, self.cfg.n_class
+        ph = np.ascontiguousarray(np.broadcast_to(_f64(prob_h), (n, Cn, 4)))
+        pv = np.ascontiguousarray(np.broadcast_to(_f64(prob_v), (n, Cn, nz)))
+        cv = np.ascontiguousarray(np.broadcast_to(_f64(cell_volume), (n,)))
+        nm, na = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+        self._ck(self._lib.pmcx_transport(self._h, nx, nz, ny, int(periodic_x), int(periodic_y),
+                                          _ptr(ph), _ptr(pv), _ptr(cv), seed, step, _ptr(nm), _ptr(na)))
+        return nm, na
 
     def condense(self, del_t, n_sub=4):
         """EXTENSION: water condensation sub-step (see include/pmcx.h)."""
