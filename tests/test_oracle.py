@@ -388,3 +388,65 @@ def test_condensation_reaches_koehler_equilibrium(oracle):
     c2.generate([dict(frac=1, gm_radius=5e-8, gsd_log10=0.2, vol_frac=[0.0, 1.0, 0.0])], 50, 1, 0)
     c2.condense(kappa, 2, 0.9, 600.0, 4)
     assert not c2.vol[2, :50].any()
+
+
+# ------------------------------------------------------------- transport (f2)
+
+def _reference_sequential_sample(rng, n_from, prob, ratio):
+    """Transcription of the pick loop of aero_state_sample_particles_by_class
+    (interface/wrf_pmc_trans_aero.F90:2236-2300), counting adds and removes:
+    n_transfer is Binomial(n, p) when ratio >= 1, Poisson(n p / ratio) otherwise (:2236-2241);
+    each pick is uniform over the current list (:2249-2252); equal mixing ratios add and
+    remove, a smaller destination weight always adds and removes with probability
+    to/from, a larger one always removes and adds with probability from/to (:2254-2273)."""
+    n_transfer = rng.binomial(n_from, prob) if ratio >= 1.0 else rng.poisson(n_from * prob / ratio)
+    n_list, added, removed = n_from, 0, 0
+    for _ in range(n_transfer):
+        if n_list <= 0:
+            break
+        if ratio == 1.0:
+            add, rem = True, True
+        elif ratio < 1.0:
+            add, rem = True, rng.uniform() < ratio
+        else:
+            add, rem = rng.uniform() < 1.0 / ratio, True
+        added += add
+        if rem:
+            removed += 1
+            n_list -= 1
+    return added, removed
+
+
+@pytest.mark.parametrize("ratio", [1.0, 2.5, 0.4])
+def test_transport_matches_reference_sampling_law(oracle, ratio):
+    """The per-particle form used here against a transcription of the reference's sequential
+    sampler: same mean number of removals and arrivals (they are equal in distribution for
+    ratio >= 1; for ratio < 1 the means agree and the reference's list shrinkage is O(p))."""
+    n_part, p, trials = 4000, 0.05, 40
+    dens = np.array([1500.0]); ve, _ = oracle.make_bin_tables(80, 1e-10, 1e-2)
+    rng = np.random.RandomState(7)
+    ref = np.array([_reference_sequential_sample(rng, n_part, p, ratio) for _ in range(400)])
+    got = []
+    for t in range(trials):
+        cells = []
+        for c in range(2):                      # two cells side by side, closed box: 0 <-> 1
+            oc = oracle.Cell(1, 1, 0, 3 * n_part, dens, ve)
+            oc.mag[:] = 1e6 if c == 0 else 1e6 * ratio   # equal volumes: ratio = mag_to / mag_from
+            oc.generate([dict(frac=1, gm_radius=3e-8, gsd_log10=0.2, vol_frac=[1.0])], n_part, t, c,
+                        first_id=c << 32)
+            cells.append(oc)
+        ph = np.zeros((2, 1, 4)); ph[0, 0, 1] = p   # only cell 0 sends, eastwards
+        next_id = np.array([1 << 40, 2 << 40], dtype=np.int64)
+        st, nm, na = oracle.transport(cells, 2, 1, 1, ph, np.zeros((2, 1, 1)), np.ones(2), t, 0, 0,
+                                      next_id, False, False)
+        assert st == 0 and nm[1] == 0 and na[0] == 0
+        assert int(cells[0].n_part[0]) == n_part - nm[0] and int(cells[1].n_part[0]) == n_part + na[1]
+        ids = np.concatenate([cells[0].id[:int(cells[0].n_part[0])], cells[1].id[:int(cells[1].n_part[0])]])
+        assert len(np.unique(ids)) == len(ids)
+        got.append((na[1], nm[0]))
+    got = np.array(got)
+    for col, name in ((0, "added"), (1, "removed")):
+        se = math.sqrt(ref[:, col].var() / len(ref) + got[:, col].var() / trials)
+        assert abs(ref[:, col].mean() - got[:, col].mean()) < 4 * se + 0.02 * ref[:, col].mean(), name
+    assert abs(got[:, 1].mean() - n_part * p) < 4 * math.sqrt(n_part * p / trials)   # removals = n p
+    assert abs(got[:, 0].mean() - n_part * p / ratio) < 0.06 * n_part * p / ratio     # arrivals = n p / r
