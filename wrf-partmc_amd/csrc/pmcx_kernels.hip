@@ -273,12 +273,13 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st)
     const int64_t cb = (int64_t)c * st.cap;
 
     double *edge = (double *)smem;                    // [B+1]
-    uint32_t *hist = (uint32_t *)(edge + (B + 1));    // [4][G] per-wave counts -> cursors
+    uint64_t *pmask = (uint64_t *)(edge + (B + 1));   // [4][G] lanes of the chunk holding group g
+    uint32_t *hist = (uint32_t *)(pmask + 4 * (size_t)G); // [4][G] per-wave counts -> cursors
     uint32_t *tot = hist + 4 * (size_t)G;             // [G] totals -> offsets
     uint16_t *key = (uint16_t *)(tot + G);            // [cap] group of slot
 
     for (int j = t; j <= B; j += 256) edge[j] = st.v_edge[j];
-    for (int j = t; j < 4 * G; j += 256) hist[j] = 0;
+    for (int j = t; j < 4 * G; j += 256) { hist[j] = 0; pmask[j] = 0; }
     __syncthreads();
 
     // this wave's slots: a contiguous range whose length is a multiple of 64
@@ -322,32 +323,14 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st)
 
     int32_t *gcnt_g = st.gcnt + (int64_t)c * G;
     int32_t *goff_g = st.goff + (int64_t)c * G;
-    __shared__ uint32_t g_lo, g_hi; // occupied key range of this cell
-    if (t == 0) { g_lo = 0xFFFFFFFFu; g_hi = 0u; }
-    __syncthreads();
     for (int g = t; g < G; g += 256) {
         const uint32_t h0 = hist[g], h1 = hist[G + g], h2 = hist[2 * G + g], h3 = hist[3 * G + g];
         hist[g] = 0; hist[G + g] = h0; hist[2 * G + g] = h0 + h1; hist[3 * G + g] = h0 + h1 + h2;
         const uint32_t s = h0 + h1 + h2 + h3;
         tot[g] = s;
         gcnt_g[g] = (int32_t)s;
-        if (s) { atomicMin(&g_lo, (uint32_t)g); atomicMax(&g_hi, (uint32_t)g); }
     }
     __syncthreads();
-    // keys relative to the lowest occupied group need fewer bits (typically 5 of 7)
-    const uint32_t key_lo = g_lo <= g_hi ? g_lo : 0u;
-    const int key_bits = g_lo < g_hi ? 32 - __builtin_clz(g_hi - g_lo) : 0;
-    // lanes of a 64-slot chunk that hold the same group: one ballot per key bit
-    auto peers_of = [&](uint32_t g, bool valid) {
-        uint64_t peers = __ballot(valid);
-        const uint32_t r = g - key_lo;
-        for (int k = 0; k < key_bits; k++) {
-            const uint32_t x = (uint32_t)(-(int32_t)((r >> k) & 1u)); // all ones when the bit is set
-            const uint64_t m = __ballot(x != 0u);
-            peers &= ~(m ^ (((uint64_t)x << 32) | x));
-        }
-        return peers;
-    };
     block_excl_scan_u32(tot, G, wsum);
     for (int g = t; g < G; g += 256) {
         const uint32_t o = tot[g];
@@ -356,18 +339,27 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st)
     }
     __syncthreads();
 
-    // scatter: position = cursor of (wave, group) + rank among matching lanes
+    // scatter: position = cursor of (wave, group) + rank among the chunk's lanes of the
+    // same group.  The lanes of a group are collected by OR-ing their lane bit into the
+    // group's 64-bit word in LDS (commutative, so the result does not depend on the order
+    // the hardware serves the atomics); rank = popcount of the lower lanes in that word.
     uint32_t *perm = st.perm + cb;
+    uint64_t *mymask = pmask + (size_t)wave * G;
     for (int i0 = lo; i0 < hi; i0 += 64) {
         const int i = i0 + lane;
         const uint32_t gk = i < hi ? key[i] : 0xFFFFu;
         const bool valid = gk != 0xFFFFu;
-        const uint32_t g = valid ? gk : 0u;
-        const uint64_t peers = peers_of(g, valid);
-        const uint32_t rank = (uint32_t)__popcll(peers & lt);
-        if (valid) perm[myhist[g] + rank] = (uint32_t)i;
+        if (valid) atomicOr((unsigned long long *)&mymask[gk], 1ull << lane);
         wave_sync();
-        if (valid && rank == 0) myhist[g] += (uint32_t)__popcll(peers);
+        uint64_t peers = 0;
+        if (valid) peers = mymask[gk];
+        const uint32_t rank = (uint32_t)__popcll(peers & lt);
+        if (valid) perm[myhist[gk] + rank] = (uint32_t)i;
+        wave_sync();
+        if (valid && rank == 0) { // the group's first lane advances the cursor, clears the word
+            myhist[gk] += (uint32_t)__popcll(peers);
+            mymask[gk] = 0;
+        }
         wave_sync();
     }
 }
@@ -1694,7 +1686,7 @@ __global__ void k_test_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
 size_t bin_sort_lds_bytes(const DeviceState &st)
 {
     const size_t B = st.n_bin, G = (size_t)st.n_bin * st.n_class;
-    const size_t o = sizeof(double) * (B + 1) + sizeof(uint32_t) * 5 * G +
+    const size_t o = sizeof(double) * (B + 1) + sizeof(uint64_t) * 4 * G + sizeof(uint32_t) * 5 * G +
                      sizeof(uint16_t) * (size_t)st.cap;
     return (o + 15) & ~(size_t)15;
 }
