@@ -689,6 +689,11 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
         }
 
         // ---- evaluate up to L candidates against the current lists ----
+        // Stores of the previous event (lists, caches, merged species) must have reached
+        // L2 before the gathers below; waiting here instead of right after the event lets
+        // the window rebuild above run under their latency.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_sync();
         const uint32_t q = q0 + (uint32_t)gl;
         const bool act = q < T;
         int j = 0;
@@ -831,7 +836,7 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
             if (lead) mark_dead(st, cb, (int)po); // tombstone
             n_dead++;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (the stores above are waited for just before the next gathers, see "evaluate")
         wave_sync();
         tot_coag++;
 
