@@ -93,11 +93,12 @@ def cpu_baseline(args, n_cells_total):
     pmco_py.build()
     cores = min(os.cpu_count() or 1, args.cpu_cores)
     budget = args.cpu_seconds
-    # calibrate on a few cells, single thread
+    # calibrate on a few cells, single thread (after one warm call: library load, tables)
+    _oracle_cells((args, [0]))
     t0 = time.perf_counter()
-    r = _oracle_cells((args, list(range(0, 4))))
-    per_cell = (time.perf_counter() - t0) / 4          # setup + step, bounds the wall time
-    single = dict(cells=4, events=r["events"], seconds=r["step_s"])
+    r = _oracle_cells((args, list(range(0, 8))))
+    per_cell = (time.perf_counter() - t0) / 8          # setup + step, bounds the wall time
+    single = dict(cells=8, events=r["events"], seconds=r["step_s"])
     n_sample = int(max(cores, min(n_cells_total, budget * cores / max(per_cell, 1e-6))))
     n_sample -= n_sample % cores
     chunks = [list(range(k, n_sample, cores)) for k in range(cores)]

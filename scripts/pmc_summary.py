@@ -22,7 +22,7 @@ for k in sorted(out):
 # the sampler's 8-byte gathers are an uncalibrated access width, so its figure uses the
 # raw counter and is a lower bound.
 traffic = {}
-names = {"pmcx::k_bin_sort": ("bin_sort", 2.0), "pmcx::k_coag_sample<8, 3>": ("coag_sample", 1.0),
+names = {"pmcx::k_bin_sort": ("bin_sort", 2.0), "pmcx::k_coag_sample<8>": ("coag_sample", 1.0),
          "pmcx::k_rebalance": ("rebalance", 1.0), "pmcx::k_compact": ("compact", 1.0)}
 for k, (short, f) in names.items():
     if k in out and "FETCH_SIZE" in out[k] and "WRITE_SIZE" in out[k]:
