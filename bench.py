@@ -97,7 +97,7 @@ def cpu_baseline(args, n_cells_total):
     _oracle_cells((args, [0]))
     t0 = time.perf_counter()
     r = _oracle_cells((args, list(range(0, 8))))
-    per_cell = (time.perf_counter() - t0) / 8          # setup + step, bounds the wall time
+    per_cell = (time.perf_counter() - t0) / 8          # setup + steps, bounds the wall time
     single = dict(cells=8, events=r["events"], seconds=r["step_s"])
     n_sample = int(max(cores, min(n_cells_total, budget * cores / max(per_cell, 1e-6))))
     n_sample -= n_sample % cores
@@ -113,8 +113,9 @@ def cpu_baseline(args, n_cells_total):
     parts = sum(x["particles"] for x in res)
     out = {
         "value": events / step_wall, "unit": "events/s", "cores": cores, "kind": "port",
-        "sample": f"{n_sample} cells x {args.particles} particles x 1 step "
-                  f"(oracle/libpmco.so, gcc -O2, {cores} processes; setup excluded)",
+        "sample": f"{n_sample} cells x {args.particles} particles x {args.cpu_steps} steps after "
+                  f"one warm-up step (oracle/libpmco.so, gcc -O2, {cores} processes; "
+                  "setup and warm-up excluded)",
         "particle_steps_per_sec": parts / step_wall,
         "single_thread_events_per_sec": single["events"] / max(single["seconds"], 1e-9),
         "events": events, "seconds": step_wall,
@@ -146,14 +147,23 @@ def _oracle_cells(job):
         c.kmax[:] = kcache[k]
         cells.append((gid, c))
     t_setup = time.perf_counter() - t_setup
-    ev, n_coag = 0, {}
-    t0 = time.perf_counter()
+    # step 0 (which sorts every cell) is the warm-up, as in the GPU loop; steps 1..cpu_steps
+    # run on the lists the previous call left (aero_state%valid_sort) and are the timed ones
+    n_coag = {}
+    t_warm = time.perf_counter()
     for gid, c in cells:
         st, ns, nc = c.mc_coag(o.KERNEL_BROWN, args.del_t, args.seed, gid, 0)
-        ev += nc
         n_coag[gid] = nc
-    return dict(events=ev, particles=len(cells) * args.particles, n_coag=n_coag,
-                step_s=time.perf_counter() - t0, setup_s=t_setup)
+    t_warm = time.perf_counter() - t_warm
+    ev, parts = 0, 0
+    t0 = time.perf_counter()
+    for step in range(1, 1 + args.cpu_steps):
+        for gid, c in cells:
+            parts += int(c.n_part[0])
+            st, ns, nc = c.mc_coag(o.KERNEL_BROWN, args.del_t, args.seed, gid, step)
+            ev += nc
+    return dict(events=ev, particles=parts, n_coag=n_coag,
+                step_s=time.perf_counter() - t0, setup_s=t_setup + t_warm)
 
 
 def bench_density(n_spec):
@@ -185,6 +195,10 @@ def main():
     ap.add_argument("--max-appends", type=int, default=128)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-cores", type=int, default=16)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--resort-steps", type=int, default=3,
+                    help="extra steps after the timed region with the sort invalidated before "
+                         "each (reported as resort_every_step; 0 to skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel", type=int, default=4,
                     help="coag_kernel_type (4 = COAG_KERNEL_TYPE_BROWN, the reference's; others for tuning)")
@@ -272,6 +286,7 @@ def main():
         blk.accumulate_totals()      # n_samp, n_coag, n_part, status: summed on the device,
         blk.aero_state_rebalance(True, True, args.seed, step)   # no host sync inside the step
 
+    prof_main = {}
     # the first step's per-cell event counts, for the oracle cross-check
     first_counts = None
     step = 0
@@ -297,13 +312,42 @@ def main():
     blk.profile_enable(False)
     samp, coag, parts_after, status = blk.read_accumulated(reset=True)
     parts = parts_after + coag    # one class: particles entering a step = survivors + events
+    for k in KERNELS:
+        prof_main[k] = blk.profile_get(k)
+
+    # Side measurement, outside the timed region: the same step when something other than
+    # mc_coag touched every cell in between (transport, emission: aero_state%valid_sort
+    # false), so that every cell is sorted again on every step.
+    resort = None
+    if args.resort_steps > 0:
+        blk.profile_enable(True)
+        blk.profile_reset()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.resort_steps):
+            blk.invalidate_sort()
+            one_step(step)
+            step += 1
+        barrier()
+        el_r = time.perf_counter() - t1
+        blk.profile_enable(False)
+        _, coag_r, _, _ = blk.read_accumulated(reset=True)
+        resort = dict(elapsed=el_r, n_coag=coag_r, ms_sort=blk.profile_get("bin_sort")[0])
 
     local = dict(elapsed=elapsed, n_samp=samp, n_coag=coag, particle_steps=parts)
     for k in KERNELS:
-        ms, n = blk.profile_get(k)
+        ms, n = prof_main[k]
         local["ms_" + k] = ms
         local["n_" + k] = n
+    if resort:
+        local.update(r_n_coag=resort["n_coag"], r_ms_sort=resort["ms_sort"])
     agg = aggregate(local, dist if world > 1 else None)
+    if resort and world > 1:
+        import torch as _t
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        e = _t.tensor([resort["elapsed"]], dtype=_t.float64, device=dev)
+        dist.all_reduce(e, op=dist.ReduceOp.MAX)
+        resort["elapsed"] = float(e.item())
     mem = blk.memory_bytes()
 
     if rank == 0:
@@ -359,6 +403,17 @@ def main():
             ms = kern_ms[k] / max(1.0, agg["n_" + k] / world)
             others[k] = {"achieved": a / (ms * 1e-3) / 1e9 if ms > 0 else 0.0, "avg_launch_ms": ms}
         line["roofline_other_kernels"] = others
+        line["sort"] = ("lists persist between mc_coag calls (aero_state%valid_sort, "
+                        "wrf_pmc_trans_aero.F90:2094): bin_sort only runs for cells whose "
+                        "population something else changed")
+        if resort:
+            line["resort_every_step"] = {
+                "ms_per_step": resort["elapsed"] / args.resort_steps * 1e3,
+                "value": agg["r_n_coag"] / resort["elapsed"], "unit": "events/s",
+                "steps": args.resort_steps,
+                "bin_sort_ms_per_step": agg["r_ms_sort"] / world / args.resort_steps,
+                "bin_sort_gbs": (algorithmic_bytes("bin_sort", args.n_spec, 1, 0, **per_launch)
+                                 / max(agg["r_ms_sort"] / world / args.resort_steps * 1e-3, 1e-12) / 1e9)}
         if cpu_line is not None:
             both = [c for c in cpu_counts if c in (first_counts or {})]
             cpu_line["cells_compared_with_gpu"] = len(both)

@@ -70,7 +70,8 @@ typedef struct {
     int32_t struct_size;  /* sizeof(pmcx_config), for ABI checking            */
     int32_t device;       /* HIP device ordinal                               */
     int32_t n_cells;      /* cells owned by this context (this GPU's block)   */
-    int32_t cap;          /* particle capacity per cell (<= 65280)            */
+    int32_t cap;          /* particle capacity per cell; cap + cap/8 +
+                           * 16 n_class n_bin <= 65535 (16-bit list offsets)   */
     int32_t n_spec;       /* aero_data_n_spec                                 */
     int32_t n_class;      /* weight classes (n_group is 1, driver:1706)       */
     int32_t n_source;     /* width of the per-particle source histogram       */
@@ -290,9 +291,16 @@ int pmcx_get_diag_grid(pmcx_ctx *ctx, double *d_edge /*[n_dbin+1]*/,
 int pmcx_get_kmax(pmcx_ctx *ctx, int32_t cell, double *kmax /*[n_bin*n_bin]*/);
 /* cached per-particle totals: vtot, mass [cap] of one cell */
 int pmcx_get_caches(pmcx_ctx *ctx, int32_t cell, double *vtot, double *mass);
-/* sorted index lists of the last mc_coag's bin sort: perm[cap], group counts
- * and offsets [n_class*n_bin] of one cell (valid after pmcx_sort_only) */
+/* aero_sorted of one cell: the slot lists perm[pcap], pcap = cap + cap/8 +
+ * 16 n_class n_bin; list lengths gcnt[n_class*n_bin]; list starts
+ * goff[n_class*n_bin + 1] (each list has free entries behind it).  The lists
+ * persist between mc_coag calls like aero_state%valid_sort
+ * (wrf_pmc_trans_aero.F90:2094): pmcx_sort_only sorts only the cells whose
+ * population was changed by anything other than mc_coag since their last sort. */
 int pmcx_sort_only(pmcx_ctx *ctx);
+/* aero_state%valid_sort = .false. for every cell (what a host-side edit of the
+ * particles implies; also used to time the sort on every step) */
+int pmcx_invalidate_sort(pmcx_ctx *ctx);
 int pmcx_get_sort(pmcx_ctx *ctx, int32_t cell, uint32_t *perm, int32_t *gcnt,
                   int32_t *goff);
 

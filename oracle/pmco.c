@@ -261,6 +261,7 @@ static void refresh_one(pmco_cell *c, int i)
 void pmco_refresh_caches(pmco_cell *c)
 {
     for (int i = 0; i < *c->n_part; i++) refresh_one(c, i);
+    *c->sort_valid = 0;
 }
 
 /* ------------------------------------------------------------------------
@@ -292,6 +293,60 @@ typedef struct { int32_t pn, po, rem_o, cc; } coag_event;
 static void compact_stable(pmco_cell *c, const unsigned char *dead, int n_old,
                               int n_dead);
 
+/* room left behind a group of n entries when the lists are laid out */
+int pmco_sort_slack(int n) { return 16 + (n >> 3); }
+
+/* aero_state_sort [upstream; wrf_pmc_init.F90:1279, trans_aero:801]: groups
+ * g = class*n_bin + bin, every list in ascending slot order, laid out one
+ * after the other in perm with pmco_sort_slack() free entries behind each. */
+void pmco_sort(pmco_cell *c, int *status)
+{
+    const int B = c->n_bin, G = B * c->n_class, n = *c->n_part;
+    int32_t *key = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    for (int g = 0; g < G; g++) c->gcnt[g] = 0;
+    for (int i = 0; i < n; i++) {
+        const double v = c->vtot[i];
+        if (v < c->v_edge[0] || v >= c->v_edge[B]) *status |= PMCO_ST_OUT_OF_GRID;
+        key[i] = c->wclass[i] * B + pmco_bin_of(c->v_edge, B, v);
+        c->gcnt[key[i]]++;
+    }
+    int32_t o = 0;
+    for (int g = 0; g < G; g++) {
+        c->goff[g] = o;
+        o += c->gcnt[g] + pmco_sort_slack(c->gcnt[g]);
+        c->gcnt[g] = 0;
+    }
+    c->goff[G] = o; /* <= n + n/8 + 16 G <= pcap */
+    for (int i = 0; i < n; i++) c->perm[c->goff[key[i]] + c->gcnt[key[i]]++] = i;
+    free(key);
+    *c->sort_valid = 1;
+}
+
+/* One group's list during a call: the first nb entries live in perm, later
+ * ones (appended after the group's room ran out) in ovf. */
+typedef struct { int32_t *base; int32_t n, nb, room; ilist ovf; } glist;
+
+static int32_t gl_get(const glist *l, int i) { return i < l->nb ? l->base[i] : l->ovf.e[i - l->nb]; }
+static void gl_set(glist *l, int i, int32_t x)
+{
+    if (i < l->nb) l->base[i] = x; else l->ovf.e[i - l->nb] = x;
+}
+static void gl_remove(glist *l, int i) /* swap-with-last */
+{
+    const int last = l->n - 1;
+    if (i != last) gl_set(l, i, gl_get(l, last));
+    if (last >= l->nb) l->ovf.n--; else l->nb = last;
+    l->n = last;
+}
+/* returns 1 when the entry went to the overflow list */
+static int gl_append(glist *l, int32_t x)
+{
+    if (l->ovf.n == 0 && l->n < l->room) { l->base[l->n] = x; l->nb = ++l->n; return 0; }
+    il_push(&l->ovf, x);
+    l->n++;
+    return 1;
+}
+
 int pmco_mc_coag(pmco_cell *c, int kernel_type, const pmco_kernel_params *kp,
                  double del_t, uint64_t seed, uint32_t cell_id, uint32_t step,
                  int32_t *n_samp_out, int32_t *n_coag_out)
@@ -306,16 +361,17 @@ int pmco_mc_coag(pmco_cell *c, int kernel_type, const pmco_kernel_params *kp,
     const int use_props = kernel_needs_props(kernel_type);
     const int use_fall = kernel_needs_fall(kernel_type);
 
-    ilist *L = (ilist *)calloc((size_t)G, sizeof(ilist));
     coag_event *ev = (coag_event *)malloc(sizeof(coag_event) * (size_t)(c->max_events > 0 ? c->max_events : 1));
     int n_ev = 0, n_app = 0;
 
-    /* aero_state_sort: ascending slot order inside every group */
-    for (int i = 0; i < n0; i++) {
-        double v = c->vtot[i];
-        if (v < c->v_edge[0] || v >= c->v_edge[B]) status |= PMCO_ST_OUT_OF_GRID;
-        int g = c->wclass[i] * B + pmco_bin_of(c->v_edge, B, v);
-        il_push(&L[g], i);
+    /* the sort persists between calls while aero_state%valid_sort holds
+     * (consulted by the reference at wrf_pmc_trans_aero.F90:2094,2237) */
+    if (!*c->sort_valid) pmco_sort(c, &status);
+    glist *L = (glist *)calloc((size_t)G, sizeof(glist));
+    for (int g = 0; g < G; g++) {
+        L[g].base = c->perm + c->goff[g];
+        L[g].n = L[g].nb = c->gcnt[g];
+        L[g].room = c->goff[g + 1] - c->goff[g];
     }
 
     int stop = 0;
@@ -325,7 +381,7 @@ int pmco_mc_coag(pmco_cell *c, int kernel_type, const pmco_kernel_params *kp,
     for (int b2 = (c1 == c2 ? b1 : 0); b2 < B && !stop; b2++) {
         const int gA = c1 * B + b1, gB = c2 * B + b2;
         const int same = (gA == gB);
-        ilist *A = &L[gA], *Bl = &L[gB];
+        glist *A = &L[gA], *Bl = &L[gB];
         if (A->n == 0 || Bl->n == 0 || (same && A->n < 2)) continue;
         const double n1 = c->mag[c1], n2 = c->mag[c2];
         const int cc = (n1 < n2) ? c1 : c2;       /* coag_dest_class, flat */
@@ -353,7 +409,7 @@ int pmco_mc_coag(pmco_cell *c, int kernel_type, const pmco_kernel_params *kp,
             } else {
                 i2 = (int)pmco_index(w[1], (uint32_t)nB);
             }
-            const int p1 = A->e[i1], p2 = Bl->e[i2];
+            const int p1 = gl_get(A, i1), p2 = gl_get(Bl, i2);
             const double v1 = c->vtot[p1], v2 = c->vtot[p2];
             const double m1 = c->mass[p1], m2 = c->mass[p2];
             part_props q1 = {0}, q2 = {0};
@@ -378,11 +434,14 @@ int pmco_mc_coag(pmco_cell *c, int kernel_type, const pmco_kernel_params *kp,
             if (rem1 && rem2) pn_is_1 = big1; else pn_is_1 = rem1;
             const int pn = pn_is_1 ? p1 : p2, po = pn_is_1 ? p2 : p1;
             const int rem_o = pn_is_1 ? rem2 : rem1;
-            ilist *Ln = pn_is_1 ? A : Bl, *Lo = pn_is_1 ? Bl : A;
+            glist *Ln = pn_is_1 ? A : Bl, *Lo = pn_is_1 ? Bl : A;
             int in = pn_is_1 ? i1 : i2, io = pn_is_1 ? i2 : i1;
             const int g_old = pn_is_1 ? gA : gB;
             if (vn < c->v_edge[0] || vn >= c->v_edge[B]) status |= PMCO_ST_OUT_OF_GRID;
             const int g_new = cc * B + pmco_bin_of(c->v_edge, B, vn);
+            /* n_app counts the appends that did not fit behind their group;
+             * once that budget is spent any further move between groups stops
+             * the step */
             if (g_new != g_old && n_app >= c->max_appends) {
                 status |= PMCO_ST_APPEND_OVERFLOW; stop = 1; break;
             }
@@ -390,16 +449,12 @@ int pmco_mc_coag(pmco_cell *c, int kernel_type, const pmco_kernel_params *kp,
             n_ev++;
             if (rem_o) {                       /* swap-with-last removal */
                 const int last = Lo->n - 1;
-                Lo->e[io] = Lo->e[last];
-                Lo->n = last;
+                gl_remove(Lo, io);
                 if (same && in == last) in = io;
             }
             if (g_new != g_old) {
-                const int last = Ln->n - 1;
-                Ln->e[in] = Ln->e[last];
-                Ln->n = last;
-                il_push(&L[g_new], pn);
-                n_app++;
+                gl_remove(Ln, in);
+                n_app += gl_append(&L[g_new], pn);
             }
             c->vtot[pn] = vn;
             c->mass[pn] = mn;
@@ -424,9 +479,28 @@ int pmco_mc_coag(pmco_cell *c, int kernel_type, const pmco_kernel_params *kp,
     /* vtot/mass of merged particles stay the sums of their parents' caches
      * (set at event time); they are recomputed from the species only by
      * pmco_refresh_caches (upload, condensation). */
+
+    /* the lists stay valid for the next call unless some entry is held outside
+     * perm; closing the holes renames the slots (monotone map), which the
+     * entries follow */
+    for (int g = 0; g < G; g++) {
+        c->gcnt[g] = L[g].n;
+        if (L[g].ovf.n > 0) *c->sort_valid = 0;
+        free(L[g].ovf.e);
+    }
+    if (*c->sort_valid && n_dead > 0) {
+        int32_t *below = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n0 + 1));
+        below[0] = 0;
+        for (int i = 0; i < n0; i++) below[i + 1] = below[i] + dead[i];
+        for (int g = 0; g < G; g++)
+            for (int j = 0; j < c->gcnt[g]; j++) {
+                int32_t *e = &c->perm[c->goff[g] + j];
+                *e -= below[*e];
+            }
+        free(below);
+    }
     compact_stable(c, dead, n0, n_dead);
 
-    for (int g = 0; g < G; g++) free(L[g].e);
     free(L); free(ev); free(dead);
     *n_samp_out = tot_samp > 0x7FFFFFFF ? 0x7FFFFFFF : (int32_t)tot_samp;
     *n_coag_out = tot_coag;
@@ -490,6 +564,7 @@ int pmco_rebalance(pmco_cell *c, const double *n_ideal, int allow_doubling,
                 *next_id += k;
                 *c->n_part = n + k;
                 c->mag[cl] = c->mag[cl] / 2.0;
+                *c->sort_valid = 0;
             } else if (allow_halving && (double)ncl > n_ideal[cl] * 2.0) {
                 unsigned char *dead = (unsigned char *)calloc((size_t)n, 1);
                 int n_dead = 0;
@@ -503,6 +578,7 @@ int pmco_rebalance(pmco_cell *c, const double *n_ideal, int allow_doubling,
                 compact_stable(c, dead, n, n_dead);
                 free(dead);
                 c->mag[cl] = c->mag[cl] * 2.0;
+                *c->sort_valid = 0;
             } else {
                 break;
             }
@@ -578,6 +654,7 @@ void pmco_generate(pmco_cell *c, const pmco_gen_spec *g, int32_t n, uint64_t see
         refresh_one(c, i);
     }
     *c->n_part = n;
+    *c->sort_valid = 0;
 }
 
 /* ------------------------------------------------------------------------
@@ -697,6 +774,7 @@ void pmco_condense(pmco_cell *c, const double *kappa, int i_water, double rel_hu
         c->vol[(size_t)i_water * c->cap + i] = vw;
         refresh_one(c, i);
     }
+    *c->sort_valid = 0;
 }
 
 /* ------------------------------------------------------------------------
@@ -753,6 +831,7 @@ int pmco_scenario_update(pmco_cell *c, double dt, double create_time, uint64_t s
 {
     int status = 0;
     *n_emit = *n_dil_in = *n_dil_out = 0;
+    *c->sort_valid = 0;
     if (emission && emission->n_mode > 0)
         *n_emit = add_dist_sample(c, emission, dt, 0, create_time, seed, cell_id, step, next_id,
                                   &status);
@@ -891,6 +970,7 @@ int pmco_transport(pmco_cell *cells, int n_cells, int nx, int nz, int ny, int pe
 {
     const int C = cells[0].n_class;
     int status = 0;
+    for (int k = 0; k < n_cells; k++) *cells[k].sort_valid = 0;
     /* phase 1: every particle decides; outbox entries (slot, dest, copies) in rank order */
     typedef struct { int32_t slot, dest, copies; } entry;
     entry **box = (entry **)calloc((size_t)n_cells, sizeof(entry *));

@@ -78,6 +78,14 @@ typedef struct {
     int64_t *id;           /* [cap] particle%id                              */
     double *lct, *gct;     /* [cap] least/greatest_create_time               */
     int32_t *n_orig;       /* [n_source][cap] per-source constituent counts  */
+    /* aero_state%aero_sorted + %valid_sort (wrf_pmc_trans_aero.F90:2094-2122):
+     * kept between calls; every routine that adds, removes or resizes
+     * particles other than mc_coag clears sort_valid */
+    int32_t pcap;          /* entries of perm: >= cap + cap/8 + 16 n_class n_bin */
+    int32_t *sort_valid;   /* [1]                                            */
+    int32_t *perm;         /* [pcap] slot lists, group after group           */
+    int32_t *gcnt;         /* [n_class*n_bin] list lengths                   */
+    int32_t *goff;         /* [n_class*n_bin + 1] list starts in perm        */
 } pmco_cell;
 
 void pmco_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
@@ -108,7 +116,14 @@ void pmco_kmax_table(int type, int n_bin, const double *v_samp, double rho_min,
 /* vtot/mass caches from the species volumes, particles [0, n_part). */
 void pmco_refresh_caches(pmco_cell *c);
 
-/* One mc_coag call on one cell.  Returns the status bits. */
+/* aero_state_sort: lists in ascending slot order, pmco_sort_slack(n) free
+ * entries behind a list of n.  Sets sort_valid. */
+int pmco_sort_slack(int n);
+void pmco_sort(pmco_cell *c, int *status);
+
+/* One mc_coag call on one cell.  Returns the status bits.  Sorts first unless
+ * sort_valid; the lists it leaves are valid for the next call unless an
+ * appended entry did not fit behind its group (then sort_valid is cleared). */
 int pmco_mc_coag(pmco_cell *c, int kernel_type, const pmco_kernel_params *kp,
                  double del_t, uint64_t seed, uint32_t cell_id, uint32_t step,
                  int32_t *n_samp, int32_t *n_coag);

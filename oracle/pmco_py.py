@@ -35,6 +35,7 @@ class CellStruct(C.Structure):
         ("temp", C.c_double), ("pressure", C.c_double),
         ("mag", _dp), ("n_part", _ip), ("vol", _dp), ("vtot", _dp), ("mass", _dp),
         ("wclass", _ip), ("id", _lp), ("lct", _dp), ("gct", _dp), ("n_orig", _ip),
+        ("pcap", C.c_int32), ("sort_valid", _ip), ("perm", _ip), ("gcnt", _ip), ("goff", _ip),
     ]
 
 
@@ -155,6 +156,14 @@ class Cell:
         self.lct = np.zeros(cap)
         self.gct = np.zeros(cap)
         self.n_orig = np.zeros((max(n_source, 1), cap), dtype=np.int32)
+        # aero_sorted: kept between calls while sort_valid (set it to 0 after
+        # editing the particle arrays by hand)
+        G = n_class * self.n_bin
+        self.pcap = cap + cap // 8 + 16 * G
+        self.sort_valid = np.zeros(1, dtype=np.int32)
+        self.perm = np.zeros(self.pcap, dtype=np.int32)
+        self.gcnt = np.zeros(G, dtype=np.int32)
+        self.goff = np.zeros(G + 1, dtype=np.int32)
 
     def view(self):
         s = CellStruct()
@@ -168,6 +177,8 @@ class Cell:
         s.vol = _p(self.vol, _dp); s.vtot = _p(self.vtot, _dp); s.mass = _p(self.mass, _dp)
         s.wclass = _p(self.wclass, _ip); s.id = _p(self.id, _lp)
         s.lct = _p(self.lct, _dp); s.gct = _p(self.gct, _dp); s.n_orig = _p(self.n_orig, _ip)
+        s.pcap = self.pcap; s.sort_valid = _p(self.sort_valid, _ip)
+        s.perm = _p(self.perm, _ip); s.gcnt = _p(self.gcnt, _ip); s.goff = _p(self.goff, _ip)
         return s
 
     def refresh_caches(self):
@@ -252,6 +263,16 @@ class Cell:
         lib().pmco_generate(C.byref(self.view()), C.byref(g), n, seed, cell_id, first_id,
                             create_time)
         return fr, lg, ls, vf, mc, msrc
+
+
+def sort(cell):
+    """aero_state_sort of one Cell; returns the status bits."""
+    st = C.c_int(0)
+    f = lib().pmco_sort
+    f.restype = None
+    f.argtypes = [C.POINTER(CellStruct), C.POINTER(C.c_int)]
+    f(C.byref(cell.view()), C.byref(st))
+    return st.value
 
 
 def transport(cells, nx, nz, ny, prob_h, prob_v, cell_volume, seed, cell_id_base, step, next_id,

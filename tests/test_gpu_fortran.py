@@ -63,6 +63,9 @@ def test_fortran_shim_matches_oracle(tmp_path, wp, oracle, mode):
         ns = np.frombuffer(out, "<i4", n_cells, off); off += 4 * n_cells
         nc = np.frombuffer(out, "<i4", n_cells, off); off += 4 * n_cells
         for c, oc in enumerate(cells):
+            # the shim uploads the Fortran aero_state before every call: caches are
+            # recomputed from the species and the sort is not valid (a host-side edit)
+            oc.refresh_caches()
             st, ons, onc = oc.mc_coag(kernel, del_t, seed, c, step, const_k, beta)
             assert (int(ns[c]), int(nc[c])) == (ons, onc), (step, c)
     rec = 8 * n_spec + 4 * n_source + 4 + 8 + 16

@@ -86,11 +86,20 @@ def test_bin_sort_matches_definition(wp, oracle, n_class, n_part):
         perm, gcnt, goff = blk.get_sort(c)
         bins = np.searchsorted(info["v_edge"], oc.vtot[:n_part], side="right") - 1
         g = oc.wclass[:n_part] * B + np.clip(bins, 0, B - 1)
-        order = np.lexsort((np.arange(n_part), g))     # by group, ascending slot inside
-        assert np.array_equal(perm[:n_part], order.astype(np.uint32))
         cnt = np.bincount(g, minlength=n_class * B)
         assert np.array_equal(gcnt, cnt)
-        assert np.array_equal(goff, np.concatenate([[0], np.cumsum(cnt)[:-1]]))
+        # every list is followed by 16 + n/8 free entries (appends of later events)
+        room = cnt + 16 + cnt // 8
+        assert np.array_equal(goff, np.concatenate([[0], np.cumsum(room)]))
+        assert goff[-1] <= len(perm)
+        for k in np.nonzero(cnt)[0]:                   # ascending slot order inside a group
+            assert np.array_equal(perm[goff[k]:goff[k] + cnt[k]], np.nonzero(g == k)[0])
+        # the oracle's own sort lays the lists out the same way
+        st = np.zeros(1, dtype=np.int32)
+        oracle.sort(oc)
+        assert np.array_equal(oc.gcnt, gcnt) and np.array_equal(oc.goff, goff)
+        for k in np.nonzero(cnt)[0]:
+            assert np.array_equal(oc.perm[goff[k]:goff[k] + cnt[k]], perm[goff[k]:goff[k] + cnt[k]])
     blk.close()
 
 
@@ -140,7 +149,13 @@ def test_overflow_status_matches():
     res = parity.run_pair(n_cells=3, n_part=800, n_spec=1, n_class=1, steps=1, seed=3,
                           kernel=K_BROWN, del_t=20000.0, max_events=16, max_appends=8)
     assert res["bitwise_equal"], res["first_mismatch"]
-    assert res["status_or"] & 3
+    assert res["status_or"] & 1
+    res["blk"].close()
+    # appends that do not fit behind their list: the overflow list fills up
+    res = parity.run_pair(n_cells=3, n_part=800, n_spec=1, n_class=1, steps=2, seed=3,
+                          kernel=K_BROWN, del_t=300000.0, max_events=4096, max_appends=3)
+    assert res["bitwise_equal"], res["first_mismatch"]
+    assert res["status_or"] & 2
     res["blk"].close()
 
 
@@ -305,8 +320,10 @@ def test_empty_ragged_and_tiny_cells(wp, oracle):
 
 
 def test_maximum_capacity_cell(wp, oracle):
-    """cap = 65280, the largest a cell may hold (16-bit slot indices in the sampler)."""
-    blk, cells = _ragged_pair(wp, oracle, [65280, 40000], n_spec=1, cap=65280, conc=2e10,
+    """The largest cell the sampler's 16-bit list offsets allow: cap + cap/8 + 16 G <= 65535."""
+    with pytest.raises(wp.PmcxError):
+        wp.CellBlock(1, 57152, 1)
+    blk, cells = _ragged_pair(wp, oracle, [57088, 40000], n_spec=1, cap=57088, conc=2e10,
                               max_events=8192, max_appends=4096)
     ns, nc, st = blk.mc_coag(K_BROWN, 300.0, 4, 0)
     for c, oc in enumerate(cells):
@@ -332,6 +349,33 @@ def test_tombstones_and_lazy_compaction(wp, oracle):
     ok, msg = parity.compare_state(blk, cells)
     assert ok, msg
     assert int(cells[0].n_part[0]) < 1500 * 0.7      # far past the compaction threshold
+    blk.close()
+
+
+def test_sort_persists_between_calls(wp, oracle):
+    """aero_state%valid_sort semantics: the lists left by one mc_coag call are the next
+    call's lists (no re-sort), appended entries sit behind their group, holes are closed
+    without disturbing them, and an explicit invalidation re-sorts.  No download in between:
+    the device state is compared once at the end."""
+    blk, cells = _ragged_pair(wp, oracle, [2000, 1300, 64, 1700], n_spec=2, n_class=2,
+                              max_events=4096, max_appends=64)
+    for step in range(14):
+        if step == 9:                      # a host-side edit of the population
+            blk.invalidate_sort()
+            for oc in cells:
+                oc.sort_valid[0] = 0
+        ns, nc, st = blk.mc_coag(K_BROWN, 4000.0, 9, step)
+        for c, oc in enumerate(cells):
+            ost, ons, onc = oc.mc_coag(K_BROWN, 4000.0, 9, c, step)
+            assert (ons, onc, ost) == (int(ns[c]), int(nc[c]), int(st[c])), (step, c)
+    # the lists themselves agree entry for entry wherever both sides kept them
+    for c, oc in enumerate(cells):
+        if oc.sort_valid[0]:
+            perm, gcnt, goff = blk.get_sort(c)
+            assert np.array_equal(gcnt, oc.gcnt) and np.array_equal(goff, oc.goff)
+    ok, msg = parity.compare_state(blk, cells)
+    assert ok, msg
+    assert int(cells[0].n_part[0]) < 2000 * 0.8
     blk.close()
 
 

@@ -233,9 +233,15 @@ def test_overflow_flags(oracle):
     st, ns, nc = c.mc_coag(K_BROWN, 30000.0, 1, 0, 0)
     assert st & oracle.ST_EVENT_OVERFLOW and nc == 5
     c = _cell(oracle, 800, 1, 1, K_BROWN, seed=1)
+    # appends go behind their list in perm while there is room (16 + n/8 entries);
+    # max_appends bounds the ones that do not fit
     c.max_appends = 3
     st, ns, nc = c.mc_coag(K_BROWN, 30000.0, 1, 0, 0)
-    assert st & oracle.ST_APPEND_OVERFLOW
+    assert st == 0 and c.sort_valid[0] == 1
+    c = _cell(oracle, 800, 1, 1, K_BROWN, seed=1)
+    c.max_appends = 3
+    st, ns, nc = c.mc_coag(K_BROWN, 300000.0, 1, 0, 0)
+    assert st & oracle.ST_APPEND_OVERFLOW and c.sort_valid[0] == 0
 
 
 # ----------------------------------------------- analytic Smoluchowski tests

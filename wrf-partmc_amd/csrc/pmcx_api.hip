@@ -55,7 +55,6 @@ struct pmcx_ctx {
     double *d_diag = nullptr; // [n_cells*(2+2*n_dbin)]
     bool aero_data_set = false, env_set = false;
     int bounds_kernel = 0; // kernel type the kmax tables are valid for (0 = none)
-    bool sorted_valid = false;
     // profiling
     bool prof = false;
     std::map<std::string, ProfEntry> profile;
@@ -217,6 +216,11 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
         cfg->n_dbin < 1 || !(cfg->d_min > 0) || !(cfg->d_max > cfg->d_min) ||
         cfg->n_class * cfg->n_bin > 65535 || cfg->i_water >= cfg->n_spec)
         return fail(nullptr, PMCX_EINVAL, "pmcx_create: configuration out of range");
+    // list offsets are 16-bit in the sampler's LDS: lists + the room behind them must fit
+    if ((int64_t)cfg->cap + cfg->cap / 8 + 16 * (int64_t)cfg->n_class * cfg->n_bin > 65535)
+        return fail(nullptr, PMCX_EINVAL,
+                    "pmcx_create: cap + cap/8 + 16 n_class n_bin = %lld exceeds 65535",
+                    (long long)((int64_t)cfg->cap + cfg->cap / 8 + 16 * (int64_t)cfg->n_class * cfg->n_bin));
 
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1 || cfg->device >= n_dev)
@@ -242,6 +246,7 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
     st.n_class = cfg->n_class; st.n_source = cfg->n_source; st.n_bin = cfg->n_bin;
     st.n_dbin = cfg->n_dbin; st.i_water = cfg->i_water;
     st.max_events = cfg->max_events; st.max_appends = cfg->max_appends;
+    st.pcap = cfg->cap + cfg->cap / 8 + 16 * cfg->n_class * cfg->n_bin;
     st.cell_id_base = cfg->cell_id_base;
     st.const_k = cfg->const_k; st.additive_beta = cfg->additive_beta;
     st.rho_min = 0; st.rho_max = 0;
@@ -295,8 +300,8 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
     A_(st.wclass, nc * cap); A_(st.id, nc * cap);
     A_(st.lct, nc * cap); A_(st.gct, nc * cap);
     A_(st.n_orig, nc * (size_t)cfg->n_source * cap);
-    A_(st.perm, nc * cap);
-    A_(st.gcnt, nc * G); A_(st.goff, nc * G);
+    A_(st.perm, nc * (size_t)st.pcap);
+    A_(st.gcnt, nc * G); A_(st.goff, nc * (G + 1)); A_(st.sort_valid, nc);
     A_(st.n_events, nc); A_(st.n_samp, nc); A_(st.n_coag, nc); A_(st.status, nc);
     A_(ctx->d_totals, (size_t)4);
     A_(ctx->d_acc, (size_t)4);
@@ -408,6 +413,12 @@ int pmcx_set_env(pmcx_ctx *ctx, const double *temp, const double *pressure,
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->env_set = true;
     return PMCX_OK;
+}
+
+// the lists of these cells no longer describe their particles (aero_state%valid_sort = .false.)
+static hipError_t invalidate_sort(pmcx_ctx *ctx, int cell_first, int n)
+{
+    return hipMemsetAsync(ctx->st.sort_valid + cell_first, 0, sizeof(int32_t) * (size_t)n, ctx->stream);
 }
 
 static int copy_cells_h2d(pmcx_ctx *ctx, void *dst, const void *src, size_t bytes)
@@ -538,7 +549,7 @@ int pmcx_upload_cells(pmcx_ctx *ctx, int32_t cell_first, int32_t n_up, const int
     HIP_TRY(ctx, launch_set_n_part(st.n_part + c0, st.n_hi + c0, ctx->d_offsets, n_up, ctx->stream));
     HIP_TRY(ctx, launch_refresh_caches(st, cell_first, n_up, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->sorted_valid = false;
+    HIP_TRY(ctx, invalidate_sort(ctx, cell_first, n_up));
     return PMCX_OK;
 }
 
@@ -643,7 +654,14 @@ int pmcx_sort_only(pmcx_ctx *ctx)
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     ProfScope ps(ctx, "bin_sort");
     HIP_TRY(ctx, launch_bin_sort(ctx->st, ctx->stream));
-    ctx->sorted_valid = true;
+    return PMCX_OK;
+}
+
+int pmcx_invalidate_sort(pmcx_ctx *ctx)
+{
+    if (!ctx) return PMCX_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, invalidate_sort(ctx, 0, ctx->cfg.n_cells));
     return PMCX_OK;
 }
 
@@ -673,7 +691,6 @@ int pmcx_mc_coag(pmcx_ctx *ctx, int32_t kernel_type, double del_t, uint64_t seed
         ProfScope ps(ctx, "compact");
         HIP_TRY(ctx, launch_compact(ctx->st, 0, ctx->cfg.n_cells, 1, 8, ctx->stream));
     }
-    ctx->sorted_valid = false;
     return PMCX_OK;
 }
 
@@ -737,7 +754,6 @@ int pmcx_rebalance(pmcx_ctx *ctx, int32_t allow_doubling, int32_t allow_halving,
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     ProfScope ps(ctx, "rebalance");
     HIP_TRY(ctx, launch_rebalance(ctx->st, allow_doubling, allow_halving, seed, step, ctx->stream));
-    ctx->sorted_valid = false;
     return PMCX_OK;
 }
 
@@ -813,7 +829,7 @@ int pmcx_scenario_update_aero_state(pmcx_ctx *ctx, double dt, double elapsed_tim
     if (e == hipSuccess && n_dil_out) e = hipMemcpyAsync(n_dil_out, d_cnt + 2 * nc, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     cleanup();
-    ctx->sorted_valid = false;
+    HIP_TRY(ctx, invalidate_sort(ctx, 0, ctx->cfg.n_cells));
     if (e != hipSuccess) return fail(ctx, PMCX_EDEVICE, "pmcx_scenario_update_aero_state: %s", hipGetErrorString(e));
     return PMCX_OK;
 }
@@ -856,7 +872,7 @@ int pmcx_transport(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int32_t pe
     if (n_moved) HIP_TRY(ctx, hipMemcpyAsync(n_moved, ctx->d_n_out, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));
     if (n_arrived) HIP_TRY(ctx, hipMemcpyAsync(n_arrived, ctx->d_n_arr, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->sorted_valid = false;
+    HIP_TRY(ctx, invalidate_sort(ctx, 0, ctx->cfg.n_cells));
     return PMCX_OK;
 }
 
@@ -870,7 +886,7 @@ int pmcx_condense(pmcx_ctx *ctx, double del_t, int32_t n_sub)
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     ProfScope ps(ctx, "condense");
     HIP_TRY(ctx, launch_condense(ctx->st, ctx->d_kappa, ctx->d_rh, del_t, n_sub, ctx->stream));
-    ctx->sorted_valid = false;
+    HIP_TRY(ctx, invalidate_sort(ctx, 0, ctx->cfg.n_cells));
     return PMCX_OK;
 }
 
@@ -960,7 +976,7 @@ int pmcx_generate_lognormal(pmcx_ctx *ctx, int32_t n_part, int32_t n_mode, const
         HIP_TRY(ctx, launch_generate(ctx->st, g, n_part, seed, create_time, ctx->stream));
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->sorted_valid = false;
+    HIP_TRY(ctx, invalidate_sort(ctx, 0, ctx->cfg.n_cells));
     return PMCX_OK;
 }
 
@@ -1013,12 +1029,11 @@ int pmcx_get_caches(pmcx_ctx *ctx, int32_t cell, double *vtot, double *mass)
 int pmcx_get_sort(pmcx_ctx *ctx, int32_t cell, uint32_t *perm, int32_t *gcnt, int32_t *goff)
 {
     if (!ctx || cell < 0 || cell >= ctx->cfg.n_cells) return fail(ctx, PMCX_EINVAL, "pmcx_get_sort: bad argument");
-    if (!ctx->sorted_valid) return fail(ctx, PMCX_ESTATE, "call pmcx_sort_only first");
-    const size_t cap = (size_t)ctx->cfg.cap, G = (size_t)ctx->cfg.n_class * ctx->cfg.n_bin;
+    const size_t pcap = (size_t)ctx->st.pcap, G = (size_t)ctx->cfg.n_class * ctx->cfg.n_bin;
     int rc = PMCX_OK;
-    if (perm) rc = copy_cells_d2h(ctx, perm, ctx->st.perm + cell * cap, sizeof(uint32_t) * cap);
+    if (perm) rc = copy_cells_d2h(ctx, perm, ctx->st.perm + cell * pcap, sizeof(uint32_t) * pcap);
     if (!rc && gcnt) rc = copy_cells_d2h(ctx, gcnt, ctx->st.gcnt + cell * G, sizeof(int32_t) * G);
-    if (!rc && goff) rc = copy_cells_d2h(ctx, goff, ctx->st.goff + cell * G, sizeof(int32_t) * G);
+    if (!rc && goff) rc = copy_cells_d2h(ctx, goff, ctx->st.goff + cell * (G + 1), sizeof(int32_t) * (G + 1));
     return rc;
 }
 

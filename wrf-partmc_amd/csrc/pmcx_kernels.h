@@ -18,6 +18,7 @@ enum : int {
 struct DeviceState {
     int32_t n_cells, cap, n_spec, n_class, n_source, n_bin, n_dbin, i_water;
     int32_t max_events, max_appends;
+    int32_t pcap; // entries of perm per cell: cap + cap/8 + 16 n_class n_bin
     uint32_t cell_id_base;
     double const_k, additive_beta;
     double rho_min, rho_max;
@@ -48,9 +49,11 @@ struct DeviceState {
     double *lct, *gct;
     int32_t *n_orig; // [n_cells][n_source][cap]
     // scratch / outputs of the coagulation step
-    uint32_t *perm;  // [n_cells][cap]
-    int32_t *gcnt;   // [n_cells][n_class*n_bin]
-    int32_t *goff;   // [n_cells][n_class*n_bin]
+    // aero_sorted, kept between calls while sort_valid (aero_state%valid_sort)
+    uint32_t *perm;  // [n_cells][pcap] slot lists, group after group, room behind each
+    int32_t *gcnt;   // [n_cells][n_class*n_bin] list lengths
+    int32_t *goff;   // [n_cells][n_class*n_bin + 1] list starts
+    int32_t *sort_valid; // [n_cells]
     int32_t *n_events, *n_samp, *n_coag, *status; // [n_cells]
 };
 
@@ -64,6 +67,7 @@ struct GenSpecDev {
 size_t bin_sort_lds_bytes(const DeviceState &st);
 size_t sampler_lds_bytes_per_cell(const DeviceState &st);
 size_t diagnostics_lds_bytes(const DeviceState &st);
+size_t compact_lds_bytes(const DeviceState &st);
 
 hipError_t launch_scatter_f64(const double *src, double *dst, const int64_t *part_offset, int n_up,
                               int cap, int64_t dst_cell_stride, int64_t src_row_stride, int n_rows,

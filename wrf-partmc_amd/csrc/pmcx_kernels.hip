@@ -239,7 +239,13 @@ __global__ __launch_bounds__(256) void k_kernel_bounds(DeviceState st, int ktype
 // group are found with ballots (rank = popcount of lower matching lanes), so
 // the order is the slot order by construction and never depends on atomics
 // or scheduling.  vtot is streamed once (8 B per particle), perm written
-// once (4 B per particle).
+// once (4 B per particle).  The lists are laid out one after the other in
+// perm with sort_slack() free entries behind each, so that the sampler can
+// append in place; a cell whose lists still hold (sort_valid, the reference's
+// aero_state%valid_sort, wrf_pmc_trans_aero.F90:2094) is skipped.
+
+// free entries left behind a list of n when the lists are laid out (oracle: pmco_sort_slack)
+__device__ __forceinline__ uint32_t sort_slack(uint32_t n) { return 16u + (n >> 3); }
 
 // exclusive scan in place over an LDS u32 array of length n
 __device__ __forceinline__ void block_excl_scan_u32(uint32_t *a, int n, uint32_t *wsum)
@@ -269,6 +275,7 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st)
     const int c = blockIdx.x;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int B = st.n_bin, C = st.n_class, G = B * C;
+    if (st.sort_valid[c]) return; // the lists of the last call still hold (whole workgroup)
     const int n = st.n_hi[c]; // slots in use; dead ones (vtot < 0) are skipped
     const int64_t cb = (int64_t)c * st.cap;
 
@@ -322,12 +329,12 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st)
     __syncthreads();
 
     int32_t *gcnt_g = st.gcnt + (int64_t)c * G;
-    int32_t *goff_g = st.goff + (int64_t)c * G;
+    int32_t *goff_g = st.goff + (int64_t)c * (G + 1);
     for (int g = t; g < G; g += 256) {
         const uint32_t h0 = hist[g], h1 = hist[G + g], h2 = hist[2 * G + g], h3 = hist[3 * G + g];
         hist[g] = 0; hist[G + g] = h0; hist[2 * G + g] = h0 + h1; hist[3 * G + g] = h0 + h1 + h2;
         const uint32_t s = h0 + h1 + h2 + h3;
-        tot[g] = s;
+        tot[g] = s + sort_slack(s); // the list and the room behind it
         gcnt_g[g] = (int32_t)s;
     }
     __syncthreads();
@@ -335,6 +342,10 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st)
     for (int g = t; g < G; g += 256) {
         const uint32_t o = tot[g];
         goff_g[g] = (int32_t)o;
+        if (g == G - 1) {
+            const uint32_t s = (uint32_t)gcnt_g[g];
+            goff_g[G] = (int32_t)(o + s + sort_slack(s));
+        }
         hist[g] += o; hist[G + g] += o; hist[2 * G + g] += o; hist[3 * G + g] += o;
     }
     __syncthreads();
@@ -343,8 +354,9 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st)
     // same group.  The lanes of a group are collected by OR-ing their lane bit into the
     // group's 64-bit word in LDS (commutative, so the result does not depend on the order
     // the hardware serves the atomics); rank = popcount of the lower lanes in that word.
-    uint32_t *perm = st.perm + cb;
+    uint32_t *perm = st.perm + (int64_t)c * st.pcap;
     uint64_t *mymask = pmask + (size_t)wave * G;
+    if (t == 0) st.sort_valid[c] = 1;
     for (int i0 = lo; i0 < hi; i0 += 64) {
         const int i = i0 + lane;
         const uint32_t gk = i < hi ? key[i] : 0xFFFFu;
@@ -386,8 +398,9 @@ struct CellLds {
     uint16_t *cnt;      // [G] current list length
     uint16_t *nb;       // [G] entries still in the sorted base segment
     uint16_t *off;      // [G] base segment offset in perm
-    uint16_t *last_app; // [G] newest appended entry of the group (0xFFFF none)
-    uint16_t *app_slot; // [max_appends]
+    uint16_t *room;     // [G] entries the base segment can hold
+    uint16_t *last_app; // [G] newest overflow entry of the group (0xFFFF none)
+    uint16_t *app_slot; // [max_appends] overflow entries: appended when the room was used up
     uint16_t *app_prev; // [max_appends]
     uint8_t *act;       // [WN] partner bins of the window's slots
 };
@@ -398,7 +411,7 @@ __host__ __device__ inline size_t sampler_lds_bytes(int G, int C, int max_append
     o += sizeof(EnvDerived);                // env
     o += sizeof(uint64_t) * 2 * (size_t)C;  // mask
     o += sizeof(uint32_t) * 2 * (size_t)wn; // P, ns
-    o += sizeof(uint16_t) * 4 * (size_t)G;  // cnt nb off last_app
+    o += sizeof(uint16_t) * 5 * (size_t)G;  // cnt nb off room last_app
     o += sizeof(uint16_t) * 2 * (size_t)max_appends;
     o += (size_t)wn;                        // act
     return (o + 15) & ~(size_t)15;
@@ -447,17 +460,28 @@ __device__ __forceinline__ int list_remove(const CellCtx &X, int g, int i, int B
     return last;
 }
 
-__device__ __forceinline__ void list_append(const CellCtx &X, int g, uint32_t slot, int e, int B)
+// Appends behind the list in perm while there is room (and nothing of the group sits in
+// the overflow list already), else to overflow entry e.  Returns 1 when e was used.
+__device__ __forceinline__ int list_append(const CellCtx &X, int g, uint32_t slot, int e, int B,
+                                           bool lead)
 {
-    X.L.app_slot[e] = (uint16_t)slot;
-    X.L.app_prev[e] = X.L.last_app[g];
-    X.L.last_app[g] = (uint16_t)e;
     const int n = X.L.cnt[g];
+    int used = 0;
+    if (X.L.last_app[g] == 0xFFFF && n < (int)X.L.room[g]) {
+        if (lead) st_u32(&X.perm[X.L.off[g] + n], slot);
+        X.L.nb[g] = (uint16_t)(n + 1);
+    } else {
+        X.L.app_slot[e] = (uint16_t)slot;
+        X.L.app_prev[e] = X.L.last_app[g];
+        X.L.last_app[g] = (uint16_t)e;
+        used = 1;
+    }
     X.L.cnt[g] = (uint16_t)(n + 1);
     if (n == 0) {
         const int cl = g / B, b = g - cl * B;
         X.L.mask[cl * 2 + (b >> 6)] |= (1ull << (b & 63));
     }
+    return used;
 }
 
 __device__ __forceinline__ int next_bit(const uint64_t *m2, int from)
@@ -538,22 +562,24 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
         X.L.cnt = (uint16_t *)(base + o); o += sizeof(uint16_t) * (size_t)G;
         X.L.nb = (uint16_t *)(base + o); o += sizeof(uint16_t) * (size_t)G;
         X.L.off = (uint16_t *)(base + o); o += sizeof(uint16_t) * (size_t)G;
+        X.L.room = (uint16_t *)(base + o); o += sizeof(uint16_t) * (size_t)G;
         X.L.last_app = (uint16_t *)(base + o); o += sizeof(uint16_t) * (size_t)G;
         X.L.app_slot = (uint16_t *)(base + o); o += sizeof(uint16_t) * (size_t)st.max_appends;
         X.L.app_prev = (uint16_t *)(base + o); o += sizeof(uint16_t) * (size_t)st.max_appends;
         X.L.act = (uint8_t *)(base + o);
     }
-    X.perm = st.perm + cb;
+    X.perm = st.perm + (int64_t)c * st.pcap;
     X.vtot = st.vtot + cb;
     X.mass = st.mass + cb;
 
-    const int32_t *gcnt_g = st.gcnt + (int64_t)c * G;
-    const int32_t *goff_g = st.goff + (int64_t)c * G;
+    int32_t *gcnt_g = st.gcnt + (int64_t)c * G;
+    const int32_t *goff_g = st.goff + (int64_t)c * (G + 1);
     for (int g = gl; g < G; g += L) {
         const int n = gcnt_g[g];
         X.L.cnt[g] = (uint16_t)n;
         X.L.nb[g] = (uint16_t)n;
         X.L.off[g] = (uint16_t)goff_g[g];
+        X.L.room[g] = (uint16_t)(goff_g[g + 1] - goff_g[g]);
         X.L.last_app[g] = 0xFFFF;
     }
     for (int j = gl; j < 2 * C; j += L) X.L.mask[j] = 0;
@@ -808,8 +834,7 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
         if (g_new != g_old) {
             list_remove(X, g_old, in, B, lead);
             wave_sync();
-            list_append(X, g_new, pn, n_app, B);
-            n_app++;
+            n_app += list_append(X, g_new, pn, n_app, B, lead);
         }
         if (lead) {
             st_f64(&X.vtot[pn], vn); st_f64(&X.mass[pn], mn);
@@ -853,6 +878,17 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
         need_win = true;
     }
 
+    // The lists are left for the next call (aero_state%valid_sort): lengths go back to HBM;
+    // a cell with entries in the overflow list is sorted again next time.
+    if (live) {
+        wave_sync();
+        bool ovf = false;
+        for (int g = gl; g < G; g += L) {
+            gcnt_g[g] = (int32_t)X.L.cnt[g];
+            ovf |= X.L.last_app[g] != 0xFFFF;
+        }
+        if (ovf) st.sort_valid[c] = 0;
+    }
     if (live && lead) {
         st.n_events[c] = n_ev;
         st.n_part[c] = st.n_part[c] - n_dead;
@@ -889,12 +925,19 @@ __device__ __forceinline__ void move_particle(const DeviceState &st, int64_t cb,
 
 // Stable compaction of one cell by one wavefront: 64 slots at a time, every
 // row read into registers before any is written (dst <= src, chunks ascend).
-__device__ void compact_wave(const DeviceState &st, int c, int lane)
+// The slots are renamed by a monotone map; when the caller passes a chunk
+// table (LDS, n_hi/64 + 1 entries each) and the cell's lists hold, their
+// entries follow the particles, so that closing holes is invisible to the
+// sampler.  Callers that change the population pass nullptr and clear
+// sort_valid themselves.
+__device__ void compact_wave(const DeviceState &st, int c, int lane, uint32_t *cbase = nullptr,
+                             uint64_t *cmask = nullptr)
 {
     const int64_t cb = (int64_t)c * st.cap;
     const int n_hi = st.n_hi[c];
     const int S = st.n_spec, NS = st.n_source;
     const uint64_t lt = (1ull << lane) - 1ull;
+    const bool remap = cbase != nullptr && st.sort_valid[c] != 0;
     int base = 0;
     for (int i0 = 0; i0 < n_hi; i0 += 64) {
         const int i = i0 + lane;
@@ -902,6 +945,7 @@ __device__ void compact_wave(const DeviceState &st, int c, int lane)
         const uint64_t m = __ballot(live);
         const int dst = base + __popcll(m & lt);
         const bool mv = live && dst != i;
+        if (remap && lane == 0) { cbase[i0 >> 6] = (uint32_t)base; cmask[i0 >> 6] = m; }
         base += __popcll(m);
         if (__ballot(mv) == 0) continue;
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
@@ -945,18 +989,40 @@ __device__ void compact_wave(const DeviceState &st, int c, int lane)
     if (lane == 0) st.n_hi[c] = base;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wave_sync();
+    if (remap && base != n_hi) {
+        // every position of perm up to the end of the last list; room behind a list holds
+        // stale entries, renaming them is harmless
+        uint32_t *perm = st.perm + (int64_t)c * st.pcap;
+        const int G = st.n_bin * st.n_class;
+        const int used = st.goff[(int64_t)c * (G + 1) + G];
+        for (int j = lane; j < used; j += 64) {
+            const uint32_t e = perm[j];
+            if (e < (uint32_t)n_hi) {
+                const uint32_t k = e >> 6;
+                perm[j] = cbase[k] + (uint32_t)__popcll(cmask[k] & ((1ull << (e & 63)) - 1ull));
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_sync();
+    }
 }
 
 // compacts the cells whose dead fraction exceeds num/den (num = 0: any dead slot)
 __global__ __launch_bounds__(256) void k_compact(DeviceState st, int cell_first, int n_cells_do,
                                                  int num, int den)
 {
+    extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k = blockIdx.x * (blockDim.x >> 6) + wave;
     if (k >= n_cells_do) return;
     const int c = cell_first + k;
     const int n_hi = st.n_hi[c], n_live = st.n_part[c];
-    if ((int64_t)(n_hi - n_live) * den > (int64_t)n_hi * num) compact_wave(st, c, lane);
+    const int n_chunk = (st.cap + 63) / 64 + 1;
+    uint64_t *cmask = (uint64_t *)smem + (size_t)wave * n_chunk;
+    uint32_t *cbase = (uint32_t *)((uint64_t *)smem + (size_t)(blockDim.x >> 6) * n_chunk) +
+                      (size_t)wave * n_chunk;
+    if ((int64_t)(n_hi - n_live) * den > (int64_t)n_hi * num)
+        compact_wave(st, c, lane, cbase, cmask);
 }
 
 // ---------------------------------------------------------------- rebalance
@@ -1016,6 +1082,7 @@ __global__ __launch_bounds__(64) void k_rebalance(DeviceState st, int allow_doub
                     st.n_hi[c] = n_hi + ncl;
                     st.n_part[c] = n_live + ncl;
                     mag[cl] = mag[cl] / 2.0;
+                    st.sort_valid[c] = 0;
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __threadfence_block();
@@ -1042,6 +1109,7 @@ __global__ __launch_bounds__(64) void k_rebalance(DeviceState st, int allow_doub
                 if (lane == 0) {
                     st.n_part[c] = n_live - (int)nd;
                     mag[cl] = mag[cl] * 2.0;
+                    st.sort_valid[c] = 0;
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __threadfence_block();
@@ -1719,6 +1787,11 @@ int sampler_lanes(const DeviceState &st)
     if ((long)st.n_cells <= slots * 4) return 16;
     return 8;
 }
+size_t compact_lds_bytes(const DeviceState &st)
+{
+    return (size_t)4 * ((size_t)(st.cap + 63) / 64 + 1) * (sizeof(uint64_t) + sizeof(uint32_t));
+}
+
 size_t diagnostics_lds_bytes(const DeviceState &st)
 {
     return sizeof(double) * (size_t)(5 * st.n_dbin + 1 + 256) +
@@ -1791,8 +1864,9 @@ hipError_t launch_set_n_part(int32_t *n_part, int32_t *n_hi, const int64_t *part
 hipError_t launch_compact(const DeviceState &st, int cell_first, int n_cells_do, int num, int den,
                           hipStream_t s)
 {
-    hipLaunchKernelGGL(k_compact, dim3((n_cells_do + 3) / 4), dim3(256), 0, s, st, cell_first,
-                       n_cells_do, num, den);
+    allow_lds(k_compact, compact_lds_bytes(st));
+    hipLaunchKernelGGL(k_compact, dim3((n_cells_do + 3) / 4), dim3(256), compact_lds_bytes(st), s, st,
+                       cell_first, n_cells_do, num, den);
     return hipGetLastError();
 }
 hipError_t launch_refresh_caches(const DeviceState &st, int cell_first, int n_cells_do,

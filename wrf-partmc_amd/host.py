@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "pmcx_scenario_update_aero_state", "pmcx_transport",
     "pmcx_diagnostics", "pmcx_diagnostics_ext",
     "pmcx_generate_lognormal", "pmcx_timestep", "pmcx_get_bin_tables", "pmcx_get_diag_grid",
-    "pmcx_get_kmax", "pmcx_get_caches", "pmcx_sort_only", "pmcx_get_sort", "pmcx_test_math",
+    "pmcx_get_kmax", "pmcx_get_caches", "pmcx_sort_only", "pmcx_invalidate_sort", "pmcx_get_sort", "pmcx_test_math",
     "pmcx_test_philox", "pmcx_profile_enable", "pmcx_profile_reset", "pmcx_profile_get",
     "pmcx_memory_bytes",
 ]
@@ -419,10 +419,15 @@ class CellBlock:
     def sort_only(self):
         self._ck(self._lib.pmcx_sort_only(self._h))
 
+    def invalidate_sort(self):
+        """aero_state%valid_sort = .false. for every cell: the next mc_coag sorts them again."""
+        self._ck(self._lib.pmcx_invalidate_sort(self._h))
+
     def get_sort(self, cell):
         G = self.cfg.n_class * self.cfg.n_bin
-        perm = np.zeros(self.cfg.cap, dtype=np.uint32)
-        gcnt, goff = np.zeros(G, dtype=np.int32), np.zeros(G, dtype=np.int32)
+        pcap = self.cfg.cap + self.cfg.cap // 8 + 16 * G
+        perm = np.zeros(pcap, dtype=np.uint32)
+        gcnt, goff = np.zeros(G, dtype=np.int32), np.zeros(G + 1, dtype=np.int32)
         self._ck(self._lib.pmcx_get_sort(self._h, cell, _ptr(perm), _ptr(gcnt), _ptr(goff)))
         return perm, gcnt, goff
 
