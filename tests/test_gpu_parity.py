@@ -518,10 +518,10 @@ def test_run_part_driver(wp):
 
 
 def test_results_independent_of_launch_geometry(wp, oracle, monkeypatch):
-    """Same cells through the sampler with 8, 16 and 64 lanes per cell and different
+    """Same cells through the sampler with 1, 8, 16 and 64 lanes per cell and different
     workgroup sizes: identical particle data, counters and status."""
     outs = []
-    for lanes, wpb in (("8", "2"), ("16", "4"), ("64", "1"), ("8", "1")):
+    for lanes, wpb in (("8", "2"), ("16", "4"), ("64", "1"), ("8", "1"), ("1", "1")):
         monkeypatch.setenv("PMCX_SAMPLER_LANES", lanes)
         monkeypatch.setenv("PMCX_SAMPLER_WPB", wpb)
         blk = wp.CellBlock(5, 1536, 2, n_class=2, n_source=2, max_appends=128)

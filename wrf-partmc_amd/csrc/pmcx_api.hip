@@ -302,6 +302,7 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
     A_(st.n_orig, nc * (size_t)cfg->n_source * cap);
     A_(st.perm, nc * (size_t)st.pcap);
     A_(st.gcnt, nc * G); A_(st.goff, nc * (G + 1)); A_(st.sort_valid, nc);
+    A_(st.seq_ovf, nc * (2 * G + 2 * (size_t)cfg->max_appends));
     A_(st.n_events, nc); A_(st.n_samp, nc); A_(st.n_coag, nc); A_(st.status, nc);
     A_(ctx->d_totals, (size_t)4);
     A_(ctx->d_acc, (size_t)4);

@@ -54,6 +54,7 @@ struct DeviceState {
     int32_t *gcnt;   // [n_cells][n_class*n_bin] list lengths
     int32_t *goff;   // [n_cells][n_class*n_bin + 1] list starts
     int32_t *sort_valid; // [n_cells]
+    uint16_t *seq_ovf;   // [n_cells][2 G + 2 max_appends] lane-per-cell sampler: entries past a group's room
     int32_t *n_events, *n_samp, *n_coag, *status; // [n_cells]
 };
 

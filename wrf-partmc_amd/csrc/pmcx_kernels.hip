@@ -898,6 +898,348 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
     }
 }
 
+// ------------------------------------------------ coag sampler, lane per cell
+//
+// The same sweep with one LANE per cell (64 cells per wavefront): every lane runs the
+// reference's sequential loop nest for its own cell, so nothing is evaluated
+// speculatively and no count is drawn twice.  The wavefront alternates two phases so
+// that its lanes stay dense: (draw) lanes without a pending sample advance to their
+// next non-empty slot and draw its Poisson count, repeated until at most DRAW_SLACK
+// lanes still look for work; (evaluate) every lane that holds a sample evaluates it
+// and, when accepted, coagulates the pair.  A cell's list lengths and offsets live in
+// LDS, one 128-byte row per group with the lanes side by side (2 bytes each), so the
+// 64 cells never meet on an LDS bank; entries appended after a group's room ran out
+// (rare) go to a per-cell table in HBM.  Chosen for large cell counts, where cells --
+// not lanes inside a cell -- are the parallelism (launch_coag_sample).
+
+struct SeqOverflow {      // per cell, in HBM; touched only after a group's room ran out
+    uint16_t *ovf_n;      // [G] entries of the group held in the table
+    uint16_t *last_app;   // [G] newest table entry of the group
+    uint16_t *app_slot;   // [max_appends]
+    uint16_t *app_prev;   // [max_appends]
+};
+
+__host__ __device__ inline size_t seq_lds_bytes(int B, int C)
+{
+    const size_t G = (size_t)B * C;
+    size_t o = ((size_t)(B + 1) * sizeof(double) + 15) & ~(size_t)15; // sort-grid edges
+    o += sizeof(double) * 7 * 64;                                    // air properties
+    o += sizeof(uint64_t) * 2 * (size_t)C * 64;                      // non-empty bins
+    o += sizeof(uint16_t) * 64 * (2 * G + 1);                        // cnt, off
+    return (o + 15) & ~(size_t)15;
+}
+
+constexpr int DRAW_SLACK = 16;
+
+__global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, double del_t,
+                                                 uint64_t seed, uint32_t step, uint16_t *ovf_mem)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int cidx = blockIdx.x * 64 + lane;
+    const bool live = cidx < st.n_cells;
+    const int c = live ? cidx : st.n_cells - 1;
+    const int B = st.n_bin, C = st.n_class, G = B * C;
+    const int S = st.n_spec, NS = st.n_source;
+    const int64_t cb = (int64_t)c * st.cap;
+    const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
+
+    double *edge = (double *)smem;
+    double *envs = (double *)(smem + (((size_t)(B + 1) * sizeof(double) + 15) & ~(size_t)15));
+    uint64_t *mask = (uint64_t *)(envs + 7 * 64);      // [C*2][64]
+    uint16_t *cnt = (uint16_t *)(mask + 2 * (size_t)C * 64); // [G][64]
+    uint16_t *off = cnt + (size_t)G * 64;               // [G+1][64]
+#define CNT(g) cnt[(g) * 64 + lane]
+#define OFF(g) off[(g) * 64 + lane]
+#define MASK(j) mask[(j) * 64 + lane]
+
+    for (int j = lane; j <= B; j += 64) edge[j] = st.v_edge[j];
+
+    uint32_t *perm = st.perm + (int64_t)c * st.pcap;
+    double *vtot = st.vtot + cb, *mass = st.mass + cb;
+    int32_t *gcnt_g = st.gcnt + (int64_t)c * G;
+    const int32_t *goff_g = st.goff + (int64_t)c * (G + 1);
+    SeqOverflow O;
+    {
+        uint16_t *ob = ovf_mem + (size_t)c * (2 * (size_t)G + 2 * (size_t)st.max_appends);
+        O.ovf_n = ob; O.last_app = ob + G; O.app_slot = ob + 2 * G;
+        O.app_prev = O.app_slot + st.max_appends;
+    }
+
+    for (int j = 0; j < 2 * C; j++) MASK(j) = 0;
+    for (int g = 0; g < G; g++) {
+        const int n = gcnt_g[g];
+        CNT(g) = (uint16_t)n;
+        OFF(g) = (uint16_t)goff_g[g];
+        if (n > 0) {
+            const int cl = g / B, b = g - cl * B;
+            MASK(cl * 2 + (b >> 6)) |= 1ull << (b & 63);
+        }
+    }
+    OFF(G) = (uint16_t)goff_g[G];
+    {
+        const EnvDerived e = env_derive(st.temp[c], st.pressure[c]);
+        envs[0 * 64 + lane] = e.gasfreepath; envs[1 * 64 + lane] = e.inv_gfp;
+        envs[2 * 64 + lane] = e.c_diff; envs[3 * 64 + lane] = e.c_speed;
+        envs[4 * 64 + lane] = e.c_inv_speed; envs[5 * 64 + lane] = e.c_fall;
+        envs[6 * 64 + lane] = e.rhoair;
+    }
+    __syncthreads(); // one wavefront: orders the edge table
+
+    const KernelParams kp{st.const_k, st.additive_beta};
+    const double *kmax = st.kmax + (int64_t)c * B * B;
+    const double *mag = st.mag + (int64_t)c * C;
+
+    // list access: the first nb = cnt - ovf_n entries of a group sit in perm behind off
+    auto ovf_of = [&](int g, int n_app) -> int { return n_app ? (int)O.ovf_n[g] : 0; };
+    auto list_get = [&](int g, int i, int n_app) -> uint32_t {
+        const int nb = (int)CNT(g) - ovf_of(g, n_app);
+        if (i < nb) return ld_u32(&perm[OFF(g) + i]);
+        int e = O.last_app[g];
+        for (int k = (int)CNT(g) - 1 - i; k > 0; k--) e = O.app_prev[e];
+        return O.app_slot[e];
+    };
+    auto list_set = [&](int g, int i, uint32_t val, int n_app) {
+        const int nb = (int)CNT(g) - ovf_of(g, n_app);
+        if (i < nb) {
+            st_u32(&perm[OFF(g) + i], val);
+        } else {
+            int e = O.last_app[g];
+            for (int k = (int)CNT(g) - 1 - i; k > 0; k--) e = O.app_prev[e];
+            O.app_slot[e] = (uint16_t)val;
+        }
+    };
+    auto list_remove = [&](int g, int i, int n_app) -> int { // swap-with-last; returns old last
+        const int last = (int)CNT(g) - 1;
+        if (i != last) list_set(g, i, list_get(g, last, n_app), n_app);
+        if (ovf_of(g, n_app) > 0) {
+            O.last_app[g] = O.app_prev[O.last_app[g]];
+            O.ovf_n[g] = (uint16_t)(O.ovf_n[g] - 1);
+        }
+        CNT(g) = (uint16_t)last;
+        if (last == 0) {
+            const int cl = g / B, b = g - cl * B;
+            MASK(cl * 2 + (b >> 6)) &= ~(1ull << (b & 63));
+        }
+        return last;
+    };
+    auto list_append = [&](int g, uint32_t slot, int &n_app) {
+        const int n = CNT(g);
+        if (ovf_of(g, n_app) == 0 && n < (int)OFF(g + 1) - (int)OFF(g)) {
+            st_u32(&perm[OFF(g) + n], slot);
+        } else {
+            if (n_app == 0) // first use of the table in this call
+                for (int k = 0; k < G; k++) { O.ovf_n[k] = 0; O.last_app[k] = 0xFFFF; }
+            O.app_slot[n_app] = (uint16_t)slot;
+            O.app_prev[n_app] = O.last_app[g];
+            O.last_app[g] = (uint16_t)n_app;
+            O.ovf_n[g] = (uint16_t)(O.ovf_n[g] + 1);
+            n_app++;
+        }
+        CNT(g) = (uint16_t)(n + 1);
+        if (n == 0) {
+            const int cl = g / B, b = g - cl * B;
+            MASK(cl * 2 + (b >> 6)) |= 1ull << (b & 63);
+        }
+    };
+    auto next_bin = [&](int cl, int from) -> int { // next non-empty bin >= from, or -1
+        if (from < 64) {
+            const uint64_t w = MASK(cl * 2) & (~0ull << from);
+            if (w) return __builtin_ctzll(w);
+            from = 64;
+        }
+        if (from < 128) {
+            const uint64_t w = MASK(cl * 2 + 1) & (~0ull << (from - 64));
+            if (w) return 64 + __builtin_ctzll(w);
+        }
+        return -1;
+    };
+
+    int n_ev = 0, n_app = 0, n_dead = 0, tot_coag = 0, status = 0;
+    uint64_t tot_samp = 0;
+    int c1 = 0, c2 = 0, b1 = -1, b2 = -1, gA = 0, gB = 0, cc = 0;
+    double n1 = 0, n2 = 0, nmin = 0, fmax = 0, factor = 0, k_max = 0;
+    uint32_t ns_rem = 0, s = 0;
+    bool done = !live;
+
+    while (true) {
+        // ---- draw: lanes without a sample move to their next slot ----
+        while (true) {
+            const bool need = !done && ns_rem == 0;
+            if (need) {
+                // next slot of the sweep c1, c2 <= c1, b1, b2 (>= b1 within a class) whose
+                // lists can give a pair now
+                bool found = false;
+                while (!found && !done) {
+                    if (b1 >= 0 && CNT(gA) > 0) {
+                        const int nb2 = next_bin(c2, b2 + 1);
+                        if (nb2 >= 0 && nb2 < B) {
+                            b2 = nb2;
+                            gB = c2 * B + b2;
+                            found = !(gA == gB && CNT(gA) < 2);
+                            continue;
+                        }
+                    }
+                    b1 = next_bin(c1, b1 + 1);
+                    if (b1 < 0 || b1 >= B) {
+                        b1 = -1;
+                        if (++c2 > c1) { c2 = 0; ++c1; }
+                        if (c1 >= C) done = true;
+                        continue;
+                    }
+                    gA = c1 * B + b1;
+                    b2 = ((c1 == c2) ? b1 : 0) - 1;
+                    n1 = mag[c1]; n2 = mag[c2];
+                    cc = (n1 < n2) ? c1 : c2;
+                    nmin = (n1 < n2) ? n1 : n2;
+                    fmax = (n1 < n2) ? n2 : n1;
+                    factor = n1 * n2 / nmin;
+                }
+                if (found) {
+                    const double km = kmax[b1 * B + b2];
+                    uint32_t w[4];
+                    rng_block(seed, cell_id, step, ((uint32_t)gA << 16) | (uint32_t)gB,
+                              SITE_POISSON, 0, w);
+                    const double nA = (double)CNT(gA), nB = (double)CNT(gB);
+                    k_max = km * fmax;
+                    const double n_possible = (gA == gB) ? nA * (nA - 1.0) / 2.0 : nA * nB;
+                    const double mean = k_max * del_t * n_possible;
+                    ns_rem = (uint32_t)poisson(mean, u53(w[0], w[1]));
+                    tot_samp += ns_rem;
+                    s = 0;
+                }
+            }
+            const int waiting = __popcll(__ballot(!done && ns_rem == 0));
+            if (waiting <= DRAW_SLACK) break;
+        }
+        if (__ballot(!done) == 0) break;
+
+        // ---- evaluate one sample per lane ----
+        bool acc = false;
+        int i1 = 0, i2 = 0;
+        uint32_t p1 = 0, p2 = 0, s_ev = 0;
+        double v1 = 0, v2 = 0, m1 = 0, m2 = 0;
+        const bool same = (gA == gB);
+        if (!done && ns_rem > 0) {
+            const int nA = CNT(gA), nB = CNT(gB);
+            if (nA < 1 || nB < 1 || (same && nA < 2)) {
+                ns_rem = 0; // a list ran out: the slot ends
+            } else {
+                uint32_t w[4];
+                rng_block(seed, cell_id, step, ((uint32_t)gA << 16) | (uint32_t)gB, SITE_CAND, s, w);
+                i1 = (int)index_of(w[0], (uint32_t)nA);
+                if (same) {
+                    i2 = (int)index_of(w[1], (uint32_t)(nA - 1));
+                    if (i2 >= i1) i2++;
+                } else {
+                    i2 = (int)index_of(w[1], (uint32_t)nB);
+                }
+                p1 = list_get(gA, i1, n_app);
+                p2 = list_get(gB, i2, n_app);
+                v1 = ld_f64(&vtot[p1]); v2 = ld_f64(&vtot[p2]);
+                m1 = ld_f64(&mass[p1]); m2 = ld_f64(&mass[p2]);
+                EnvDerived env;
+                env.gasfreepath = envs[0 * 64 + lane]; env.inv_gfp = envs[1 * 64 + lane];
+                env.c_diff = envs[2 * 64 + lane]; env.c_speed = envs[3 * 64 + lane];
+                env.c_inv_speed = envs[4 * 64 + lane]; env.c_fall = envs[5 * 64 + lane];
+                env.rhoair = envs[6 * 64 + lane];
+                const PartProps qa = props_for(ktype, v1, m1, env);
+                const PartProps qb = props_for(ktype, v2, m2, env);
+                const double k = kernel_pair(ktype, v1, v2, qa, qb, kp);
+                const double kf = k * factor;
+                if (kf > k_max) status |= ST_KMAX_EXCEEDED;
+                acc = u53(w[2], w[3]) * k_max < kf;
+                s_ev = s;
+                s++;
+                ns_rem--;
+            }
+        }
+
+        // ---- coagulate ----
+        if (acc) {
+            do {
+                if (n_ev >= st.max_events) { status |= ST_EVENT_OVERFLOW; done = true; break; }
+                bool rem1 = true, rem2 = true;
+                if (n1 != n2) {
+                    uint32_t w[4];
+                    rng_block(seed, cell_id, step, ((uint32_t)gA << 16) | (uint32_t)gB, SITE_COAG,
+                              s_ev, w);
+                    rem1 = u53(w[0], w[1]) < nmin / n1;
+                    rem2 = u53(w[2], w[3]) < nmin / n2;
+                }
+                const double vn = v1 + v2, mn = m1 + m2;
+                const bool big1 = (v1 >= v2);
+                const bool pn_is_1 = (rem1 && rem2) ? big1 : rem1;
+                const uint32_t pn = pn_is_1 ? p1 : p2, po = pn_is_1 ? p2 : p1;
+                const bool rem_o = pn_is_1 ? rem2 : rem1;
+                int in = pn_is_1 ? i1 : i2;
+                const int io = pn_is_1 ? i2 : i1;
+                const int g_old = pn_is_1 ? gA : gB, g_o = pn_is_1 ? gB : gA;
+                if (vn < edge[0] || vn >= edge[B]) status |= ST_OUT_OF_GRID;
+                const int g_new = cc * B + bin_index(edge, B, vn, st);
+                if (g_new != g_old && n_app >= st.max_appends) {
+                    status |= ST_APPEND_OVERFLOW; done = true; break;
+                }
+                n_ev++;
+                if (rem_o) {
+                    const int last = list_remove(g_o, io, n_app);
+                    if (same && in == last) in = io;
+                }
+                if (g_new != g_old) {
+                    list_remove(g_old, in, n_app);
+                    list_append(g_new, pn, n_app);
+                }
+                st_f64(&vtot[pn], vn); st_f64(&mass[pn], mn);
+                // species volumes, source histogram, create times, class [aero_particle_coagulate]
+                for (int s0 = 0; s0 < S; s0 += 4) { // four species' loads in flight
+                    double a[4], b[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (s0 + k < S) {
+                            a[k] = ld_f64(&st.vol[cb * S + (int64_t)(s0 + k) * st.cap + pn]);
+                            b[k] = ld_f64(&st.vol[cb * S + (int64_t)(s0 + k) * st.cap + po]);
+                        }
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (s0 + k < S)
+                            st_f64(&st.vol[cb * S + (int64_t)(s0 + k) * st.cap + pn], a[k] + b[k]);
+                }
+                for (int sp = 0; sp < NS; sp++) {
+                    uint32_t *a = (uint32_t *)&st.n_orig[cb * NS + (int64_t)sp * st.cap + pn];
+                    st_u32(a, ld_u32(a) + ld_u32((uint32_t *)&st.n_orig[cb * NS + (int64_t)sp * st.cap + po]));
+                }
+                {
+                    const double lo_n = ld_f64(&st.lct[cb + pn]), lo_o = ld_f64(&st.lct[cb + po]);
+                    const double go_n = ld_f64(&st.gct[cb + pn]), go_o = ld_f64(&st.gct[cb + po]);
+                    if (lo_o < lo_n) st_f64(&st.lct[cb + pn], lo_o);
+                    if (go_o > go_n) st_f64(&st.gct[cb + pn], go_o);
+                }
+                if (C > 1) st_u32((uint32_t *)&st.wclass[cb + pn], (uint32_t)cc);
+                if (rem_o) { mark_dead(st, cb, (int)po); n_dead++; }
+                tot_coag++;
+            } while (false);
+        }
+        if (done) ns_rem = 0;
+    }
+
+    if (live) {
+        bool ovf = false;
+        for (int g = 0; g < G; g++) {
+            gcnt_g[g] = (int32_t)CNT(g);
+            if (n_app) ovf |= O.ovf_n[g] != 0;
+        }
+        if (ovf) st.sort_valid[c] = 0;
+        st.n_events[c] = n_ev;
+        st.n_part[c] = st.n_part[c] - n_dead;
+        st.n_samp[c] = tot_samp > 0x7FFFFFFFull ? 0x7FFFFFFF : (int32_t)tot_samp;
+        st.n_coag[c] = tot_coag;
+        if (status) atomicOr(&st.status[c], status);
+    }
+#undef CNT
+#undef OFF
+#undef MASK
+}
+
 // ---------------------------------------------------------------- compaction
 //
 // Removed particles become tombstones (vtot = -1, wclass = -1): slots [0, n_hi) hold
@@ -1777,7 +2119,11 @@ size_t sampler_lds_bytes_per_cell(const DeviceState &st)
 int sampler_lanes(const DeviceState &st)
 {
     const char *e = getenv("PMCX_SAMPLER_LANES");
+    const bool seq_fits = seq_lds_bytes(st.n_bin, st.n_class) <= 64 * 1024;
+    if (e && atoi(e) == 1 && seq_fits) return 1;
     if (e && (atoi(e) == 8 || atoi(e) == 16 || atoi(e) == 64)) return atoi(e);
+    // one lane per cell once the cells alone fill the chip (256 CUs x 4 SIMDs x 64 lanes x 2)
+    if (seq_fits && (long)st.n_cells >= 256L * 4L * 64L / 2L) return 1;
     if (sampler_lds_for(st, 16) > 4 * 1024) return 64;
     // 8 lanes per cell (8 cells per wavefront) is the throughput optimum; with few
     // cells the kernel is one wavefront's latency, which is shortest with more lanes
@@ -1893,6 +2239,12 @@ hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, ui
 {
     const size_t shared = (sizeof(double) * (size_t)(st.n_bin + 1) + 15) & ~(size_t)15;
     const int L = sampler_lanes(st);
+    if (L == 1) {
+        hipLaunchKernelGGL(k_coag_seq, dim3((st.n_cells + 63) / 64), dim3(64),
+                           seq_lds_bytes(st.n_bin, st.n_class), s, st, ktype, del_t, seed, step,
+                           st.seq_ovf);
+        return hipGetLastError();
+    }
     const size_t per = sampler_lds_for(st, L);
     const int gpw = 64 / L;
     // PMCX_SAMPLER_WPB: wavefronts per workgroup (tuning; 2 measured best)
