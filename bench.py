@@ -314,6 +314,14 @@ def main():
     parts = parts_after + coag    # one class: particles entering a step = survivors + events
     for k in KERNELS:
         prof_main[k] = blk.profile_get(k)
+    if os.environ.get("PMCX_SEQ_STAMPS") == "1" and rank == 0:   # diagnostic build of the sampler
+        ph = blk.profile_phase_cycles()
+        w = max(ph[7], 1)
+        print("seq sampler, mean shader cycles per wavefront: " + json.dumps(dict(
+            setup=ph[0] / w, draw=ph[1] / w, evaluate=ph[2] / w, coagulate=ph[3] / w,
+            write_back=ph[4] / w, draw_iterations=ph[5] / w, evaluate_iterations=ph[6] / w,
+            wavefronts=ph[7], draw_search=ph[8] / w, draw_wait_bound=ph[9] / w,
+            draw_philox=ph[10] / w, draw_poisson=ph[11] / w)), file=sys.stderr)
 
     # Side measurement, outside the timed region: the same step when something other than
     # mc_coag touched every cell in between (transport, emission: aero_state%valid_sort

@@ -322,6 +322,13 @@ int pmcx_profile_enable(pmcx_ctx *ctx, int32_t on);
 int pmcx_profile_reset(pmcx_ctx *ctx);
 int pmcx_profile_get(pmcx_ctx *ctx, const char *name, double *ms, int64_t *launches);
 
+/* Diagnostic: shader cycles per phase of the lane-per-cell sampler, summed over
+ * wavefronts, when the library runs with PMCX_SEQ_STAMPS=1 (a separate, slower
+ * instantiation of the kernel; zeros otherwise).  out: setup, draw, evaluate,
+ * coagulate, write-back cycles; draw iterations; evaluate iterations; wavefronts;
+ * inside draw: slot search, wait for the bound, Philox, Poisson. */
+int pmcx_profile_phase_cycles(pmcx_ctx *ctx, uint64_t out[12], int32_t reset);
+
 /* device memory held by the context, bytes (replaces memtrack, interface/mem.c) */
 int pmcx_memory_bytes(pmcx_ctx *ctx, int64_t *bytes);
 

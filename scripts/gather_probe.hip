@@ -25,13 +25,16 @@ __global__ __launch_bounds__(256) void k_gather(const uint64_t *buf, uint64_t n_
                                                 int iters, uint64_t *out)
 {
     const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    uint64_t acc = 0, h = mix(tid + 1);
+    uint64_t acc = 0, h = mix(tid + 1) | 1;
     for (int it = 0; it < iters; it++) {
         uint64_t v[ILP][W / 8];
 #pragma unroll
         for (int k = 0; k < ILP; k++) {
-            h = mix(h + k + (DEP ? acc : 0));
-            const uint64_t line = h % n_lines;
+            // cheap address arithmetic (the probe must not be ALU-bound): xorshift32, n_lines = 2^k
+            uint32_t x = (uint32_t)h + (DEP ? (uint32_t)acc : 0u);
+            x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+            h = x;
+            const uint64_t line = ((uint64_t)x * 2654435761ull >> 8) & (n_lines - 1);
             const uint64_t *p = buf + line * (uint64_t)(line_b / 8);
 #pragma unroll
             for (int j = 0; j < W / 8; j++) v[k][j] = __builtin_nontemporal_load(p + j);
@@ -50,10 +53,12 @@ static void run(const char *name, const uint64_t *buf, uint64_t bytes, int line_
     const int blocks = 256 * 8, threads = 256;
     hipEvent_t a, b;
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    k_gather<W, ILP, DEP><<<blocks, threads>>>(buf, bytes / line_b, line_b, 2, out);
+    uint64_t n_lines = 1;
+    while (n_lines * 2 * line_b <= bytes) n_lines *= 2; // largest power of two that fits
+    k_gather<W, ILP, DEP><<<blocks, threads>>>(buf, n_lines, line_b, 2, out);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(a));
-    k_gather<W, ILP, DEP><<<blocks, threads>>>(buf, bytes / line_b, line_b, iters, out);
+    k_gather<W, ILP, DEP><<<blocks, threads>>>(buf, n_lines, line_b, iters, out);
     CK(hipEventRecord(b));
     CK(hipEventSynchronize(b));
     float ms = 0;

@@ -1070,6 +1070,15 @@ int pmcx_test_philox(pmcx_ctx *ctx, const uint32_t ctr[4], const uint32_t key[2]
     return PMCX_OK;
 }
 
+int pmcx_profile_phase_cycles(pmcx_ctx *ctx, uint64_t out[12], int32_t reset)
+{
+    if (!ctx || !out) return fail(ctx, PMCX_EINVAL, "pmcx_profile_phase_cycles: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, seq_stamps_read(out, reset != 0));
+    return PMCX_OK;
+}
+
 int pmcx_profile_enable(pmcx_ctx *ctx, int32_t on)
 {
     if (!ctx) return PMCX_EINVAL;

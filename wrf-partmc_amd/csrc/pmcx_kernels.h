@@ -92,6 +92,7 @@ hipError_t launch_kernel_bounds(const DeviceState &st, int ktype, hipStream_t s)
 hipError_t launch_bin_sort(const DeviceState &st, hipStream_t s);
 hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, uint64_t seed,
                               uint32_t step, hipStream_t s);
+hipError_t seq_stamps_read(uint64_t out[12], bool reset); // diagnostic (PMCX_SEQ_STAMPS=1)
 hipError_t launch_rebalance(const DeviceState &st, int allow_doubling, int allow_halving,
                             uint64_t seed, uint32_t step, hipStream_t s);
 hipError_t launch_diagnostics(const DeviceState &st, double *tot_num, double *tot_mass,

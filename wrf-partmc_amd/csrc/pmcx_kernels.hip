@@ -906,11 +906,15 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
 // that its lanes stay dense: (draw) lanes without a pending sample advance to their
 // next non-empty slot and draw its Poisson count, repeated until at most DRAW_SLACK
 // lanes still look for work; (evaluate) every lane that holds a sample evaluates it
-// and, when accepted, coagulates the pair.  A cell's list lengths and offsets live in
-// LDS, one 128-byte row per group with the lanes side by side (2 bytes each), so the
-// 64 cells never meet on an LDS bank; entries appended after a group's room ran out
-// (rare) go to a per-cell table in HBM.  Chosen for large cell counts, where cells --
-// not lanes inside a cell -- are the parallelism (launch_coag_sample).
+// and, when accepted, coagulates the pair.  Everything an accepted pair will need
+// (the list ends that fill the holes, species volumes, create times, source counts) is
+// requested together with the pair's cached volume and mass, so the coagulation itself
+// waits for nothing.  A cell's list lengths and offsets live in LDS as one packed
+// 32-bit word per group for a window of SEQ_W bins above the cell's first non-empty
+// bin (groups beyond it, and entries appended after a group's room ran out, are rare
+// and served from HBM); rows of 64 lanes side by side, so the 64 cells never meet on
+// an LDS bank.  Chosen for large cell counts, where cells -- not lanes inside a cell --
+// are the parallelism (launch_coag_sample).
 
 struct SeqOverflow {      // per cell, in HBM; touched only after a group's room ran out
     uint16_t *ovf_n;      // [G] entries of the group held in the table
@@ -919,21 +923,37 @@ struct SeqOverflow {      // per cell, in HBM; touched only after a group's room
     uint16_t *app_prev;   // [max_appends]
 };
 
+constexpr int SEQ_W = 40;      // bins per class with list state in LDS
+constexpr int SEQ_ENV = 7;     // air properties kept per cell
+constexpr int DRAW_SLACK = 16;
+
 __host__ __device__ inline size_t seq_lds_bytes(int B, int C)
 {
-    const size_t G = (size_t)B * C;
     size_t o = ((size_t)(B + 1) * sizeof(double) + 15) & ~(size_t)15; // sort-grid edges
-    o += sizeof(double) * 7 * 64;                                    // air properties
-    o += sizeof(uint64_t) * 2 * (size_t)C * 64;                      // non-empty bins
-    o += sizeof(uint16_t) * 64 * (2 * G + 1);                        // cnt, off
+    o += sizeof(double) * (SEQ_ENV + (size_t)C) * 64;                 // air properties, weights
+    o += sizeof(uint64_t) * 2 * (size_t)C * 64;                       // non-empty bins
+    o += sizeof(uint32_t) * (size_t)C * SEQ_W * 64;                   // count | offset << 16
     return (o + 15) & ~(size_t)15;
 }
 
-constexpr int DRAW_SLACK = 16;
+// diagnostic build only (STAMPS = true, PMCX_SEQ_STAMPS=1): shader cycles per phase, summed
+// over wavefronts: [0] setup, [1] draw, [2] evaluate, [3] coagulate, [4] write-back,
+// [5] draw iterations, [6] evaluate iterations, [7] wavefronts; inside draw: [8] slot search,
+// [9] wait for the bound, [10] Philox, [11] Poisson
+__device__ unsigned long long g_seq_stamps[12];
 
+template <bool STAMPS>
 __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, double del_t,
                                                  uint64_t seed, uint32_t step, uint16_t *ovf_mem)
 {
+    uint64_t t_last = 0, t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (STAMPS) t_last = __builtin_amdgcn_s_memtime();
+#define STAMP(k)                                                                                  \
+    if (STAMPS) {                                                                                 \
+        const uint64_t t_now = __builtin_amdgcn_s_memtime();                                      \
+        t_acc[k] += t_now - t_last;                                                               \
+        t_last = t_now;                                                                           \
+    }
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
     const int cidx = blockIdx.x * 64 + lane;
@@ -946,11 +966,9 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
 
     double *edge = (double *)smem;
     double *envs = (double *)(smem + (((size_t)(B + 1) * sizeof(double) + 15) & ~(size_t)15));
-    uint64_t *mask = (uint64_t *)(envs + 7 * 64);      // [C*2][64]
-    uint16_t *cnt = (uint16_t *)(mask + 2 * (size_t)C * 64); // [G][64]
-    uint16_t *off = cnt + (size_t)G * 64;               // [G+1][64]
-#define CNT(g) cnt[(g) * 64 + lane]
-#define OFF(g) off[(g) * 64 + lane]
+    double *magl = envs + SEQ_ENV * 64;                   // [C][64] weight magnitudes
+    uint64_t *mask = (uint64_t *)(magl + (size_t)C * 64); // [C*2][64]
+    uint32_t *ent = (uint32_t *)(mask + 2 * (size_t)C * 64); // [C*SEQ_W][64]
 #define MASK(j) mask[(j) * 64 + lane]
 
     for (int j = lane; j <= B; j += 64) edge[j] = st.v_edge[j];
@@ -966,17 +984,26 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
         O.app_prev = O.app_slot + st.max_appends;
     }
 
-    for (int j = 0; j < 2 * C; j++) MASK(j) = 0;
-    for (int g = 0; g < G; g++) {
-        const int n = gcnt_g[g];
-        CNT(g) = (uint16_t)n;
-        OFF(g) = (uint16_t)goff_g[g];
-        if (n > 0) {
-            const int cl = g / B, b = g - cl * B;
-            MASK(cl * 2 + (b >> 6)) |= 1ull << (b & 63);
-        }
+    // non-empty bins of every class; the window starts at the cell's first one
+    int blo = B;
+    for (int cl = 0; cl < C; cl++) {
+        uint64_t m0 = 0, m1 = 0;
+        for (int b = 0; b < B; b++)
+            if (gcnt_g[cl * B + b] > 0) {
+                if (b < 64) m0 |= 1ull << b; else m1 |= 1ull << (b - 64);
+                if (b < blo) blo = b;
+            }
+        MASK(cl * 2) = m0; MASK(cl * 2 + 1) = m1;
     }
-    OFF(G) = (uint16_t)goff_g[G];
+    if (blo > B - SEQ_W) blo = (B - SEQ_W > 0) ? B - SEQ_W : 0;
+    for (int cl = 0; cl < C; cl++)
+        for (int k = 0; k < SEQ_W; k++) {
+            const int b = blo + k;
+            uint32_t e = 0;
+            if (b < B) e = (uint32_t)gcnt_g[cl * B + b] | ((uint32_t)goff_g[cl * B + b] << 16);
+            ent[(cl * SEQ_W + k) * 64 + lane] = e;
+        }
+    for (int cl = 0; cl < C; cl++) magl[cl * 64 + lane] = st.mag[(int64_t)c * C + cl];
     {
         const EnvDerived e = env_derive(st.temp[c], st.pressure[c]);
         envs[0 * 64 + lane] = e.gasfreepath; envs[1 * 64 + lane] = e.inv_gfp;
@@ -988,58 +1015,41 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
 
     const KernelParams kp{st.const_k, st.additive_beta};
     const double *kmax = st.kmax + (int64_t)c * B * B;
-    const double *mag = st.mag + (int64_t)c * C;
 
-    // list access: the first nb = cnt - ovf_n entries of a group sit in perm behind off
+    // ---- list state: packed entry = count | offset << 16 ----
+    auto in_win = [&](int b) -> bool { return (unsigned)(b - blo) < (unsigned)SEQ_W; };
+    auto ent_get = [&](int cl, int b) -> uint32_t {
+        if (in_win(b)) return ent[(cl * SEQ_W + (b - blo)) * 64 + lane];
+        const int g = cl * B + b;
+        return (uint32_t)gcnt_g[g] | ((uint32_t)goff_g[g] << 16);
+    };
+    auto cnt_set = [&](int cl, int b, uint32_t e, int n) { // new length n of the group with entry e
+        if (in_win(b)) ent[(cl * SEQ_W + (b - blo)) * 64 + lane] = (e & 0xFFFF0000u) | (uint32_t)n;
+        else gcnt_g[cl * B + b] = n;
+        if (n == 0) MASK(cl * 2 + (b >> 6)) &= ~(1ull << (b & 63));
+        else if (n == 1) MASK(cl * 2 + (b >> 6)) |= 1ull << (b & 63);
+    };
+    auto room_end = [&](int cl, int b) -> int { // offset where the room behind the group ends
+        if (b + 1 < B && in_win(b + 1)) return (int)(ent[(cl * SEQ_W + (b + 1 - blo)) * 64 + lane] >> 16);
+        return goff_g[cl * B + b + 1];
+    };
+    // entries beyond a group's room (rare): linked through the per-cell table
     auto ovf_of = [&](int g, int n_app) -> int { return n_app ? (int)O.ovf_n[g] : 0; };
-    auto list_get = [&](int g, int i, int n_app) -> uint32_t {
-        const int nb = (int)CNT(g) - ovf_of(g, n_app);
-        if (i < nb) return ld_u32(&perm[OFF(g) + i]);
-        int e = O.last_app[g];
-        for (int k = (int)CNT(g) - 1 - i; k > 0; k--) e = O.app_prev[e];
-        return O.app_slot[e];
+    auto list_get = [&](int g, uint32_t e, int i, int n_app) -> uint32_t {
+        const int n = (int)(e & 0xFFFFu), nb = n - ovf_of(g, n_app);
+        if (i < nb) return perm[(e >> 16) + i];
+        int x = O.last_app[g];
+        for (int k = n - 1 - i; k > 0; k--) x = O.app_prev[x];
+        return O.app_slot[x];
     };
-    auto list_set = [&](int g, int i, uint32_t val, int n_app) {
-        const int nb = (int)CNT(g) - ovf_of(g, n_app);
+    auto list_set = [&](int g, uint32_t e, int i, uint32_t val, int n_app) {
+        const int n = (int)(e & 0xFFFFu), nb = n - ovf_of(g, n_app);
         if (i < nb) {
-            st_u32(&perm[OFF(g) + i], val);
+            perm[(e >> 16) + i] = val;
         } else {
-            int e = O.last_app[g];
-            for (int k = (int)CNT(g) - 1 - i; k > 0; k--) e = O.app_prev[e];
-            O.app_slot[e] = (uint16_t)val;
-        }
-    };
-    auto list_remove = [&](int g, int i, int n_app) -> int { // swap-with-last; returns old last
-        const int last = (int)CNT(g) - 1;
-        if (i != last) list_set(g, i, list_get(g, last, n_app), n_app);
-        if (ovf_of(g, n_app) > 0) {
-            O.last_app[g] = O.app_prev[O.last_app[g]];
-            O.ovf_n[g] = (uint16_t)(O.ovf_n[g] - 1);
-        }
-        CNT(g) = (uint16_t)last;
-        if (last == 0) {
-            const int cl = g / B, b = g - cl * B;
-            MASK(cl * 2 + (b >> 6)) &= ~(1ull << (b & 63));
-        }
-        return last;
-    };
-    auto list_append = [&](int g, uint32_t slot, int &n_app) {
-        const int n = CNT(g);
-        if (ovf_of(g, n_app) == 0 && n < (int)OFF(g + 1) - (int)OFF(g)) {
-            st_u32(&perm[OFF(g) + n], slot);
-        } else {
-            if (n_app == 0) // first use of the table in this call
-                for (int k = 0; k < G; k++) { O.ovf_n[k] = 0; O.last_app[k] = 0xFFFF; }
-            O.app_slot[n_app] = (uint16_t)slot;
-            O.app_prev[n_app] = O.last_app[g];
-            O.last_app[g] = (uint16_t)n_app;
-            O.ovf_n[g] = (uint16_t)(O.ovf_n[g] + 1);
-            n_app++;
-        }
-        CNT(g) = (uint16_t)(n + 1);
-        if (n == 0) {
-            const int cl = g / B, b = g - cl * B;
-            MASK(cl * 2 + (b >> 6)) |= 1ull << (b & 63);
+            int x = O.last_app[g];
+            for (int k = n - 1 - i; k > 0; k--) x = O.app_prev[x];
+            O.app_slot[x] = (uint16_t)val;
         }
     };
     auto next_bin = [&](int cl, int from) -> int { // next non-empty bin >= from, or -1
@@ -1057,27 +1067,44 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
 
     int n_ev = 0, n_app = 0, n_dead = 0, tot_coag = 0, status = 0;
     uint64_t tot_samp = 0;
-    int c1 = 0, c2 = 0, b1 = -1, b2 = -1, gA = 0, gB = 0, cc = 0;
+    int c1 = 0, c2 = 0, b1 = -1, b2 = -1, cc = 0;
     double n1 = 0, n2 = 0, nmin = 0, fmax = 0, factor = 0, k_max = 0;
     uint32_t ns_rem = 0, s = 0;
+    double km_pref = 0;
+    int km_tag = -1;
     bool done = !live;
+    STAMP(0)
 
     while (true) {
         // ---- draw: lanes without a sample move to their next slot ----
         while (true) {
+            uint64_t t_sub = 0;
+            if (STAMPS) { t_acc[5]++; t_sub = __builtin_amdgcn_s_memtime(); }
+#define SUBSTAMP(k)                                                                               \
+    if (STAMPS) {                                                                                 \
+        const uint64_t t_now = __builtin_amdgcn_s_memtime();                                      \
+        t_acc[k] += t_now - t_sub;                                                                \
+        t_sub = t_now;                                                                            \
+    }
             const bool need = !done && ns_rem == 0;
+            bool found = false;
+            double km = 0;
+            uint32_t eA = 0, eB = 0;
             if (need) {
                 // next slot of the sweep c1, c2 <= c1, b1, b2 (>= b1 within a class) whose
                 // lists can give a pair now
-                bool found = false;
                 while (!found && !done) {
-                    if (b1 >= 0 && CNT(gA) > 0) {
-                        const int nb2 = next_bin(c2, b2 + 1);
-                        if (nb2 >= 0 && nb2 < B) {
-                            b2 = nb2;
-                            gB = c2 * B + b2;
-                            found = !(gA == gB && CNT(gA) < 2);
-                            continue;
+                    if (b1 >= 0) {
+                        eA = ent_get(c1, b1);
+                        if ((eA & 0xFFFFu) > 0) {
+                            const int nb2 = next_bin(c2, b2 + 1);
+                            if (nb2 >= 0 && nb2 < B) {
+                                b2 = nb2;
+                                const bool same = (c1 == c2 && b1 == b2);
+                                eB = same ? eA : ent_get(c2, b2);
+                                found = !(same && (eA & 0xFFFFu) < 2);
+                                continue;
+                            }
                         }
                     }
                     b1 = next_bin(c1, b1 + 1);
@@ -1087,41 +1114,76 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
                         if (c1 >= C) done = true;
                         continue;
                     }
-                    gA = c1 * B + b1;
                     b2 = ((c1 == c2) ? b1 : 0) - 1;
-                    n1 = mag[c1]; n2 = mag[c2];
+                    n1 = magl[c1 * 64 + lane]; n2 = magl[c2 * 64 + lane];
                     cc = (n1 < n2) ? c1 : c2;
                     nmin = (n1 < n2) ? n1 : n2;
                     fmax = (n1 < n2) ? n2 : n1;
                     factor = n1 * n2 / nmin;
                 }
                 if (found) {
-                    const double km = kmax[b1 * B + b2];
-                    uint32_t w[4];
-                    rng_block(seed, cell_id, step, ((uint32_t)gA << 16) | (uint32_t)gB,
-                              SITE_POISSON, 0, w);
-                    const double nA = (double)CNT(gA), nB = (double)CNT(gB);
-                    k_max = km * fmax;
-                    const double n_possible = (gA == gB) ? nA * (nA - 1.0) / 2.0 : nA * nB;
-                    const double mean = k_max * del_t * n_possible;
-                    ns_rem = (uint32_t)poisson(mean, u53(w[0], w[1]));
-                    tot_samp += ns_rem;
-                    s = 0;
+                    // the bound of this slot was requested while the previous one was drawn
+                    const int kidx = b1 * B + b2;
+                    km = (km_tag == kidx) ? km_pref : kmax[kidx];
+                    {   // request the next slot's bound: next partner bin, else the next row's first
+                        int pb1 = b1, pb2 = next_bin(c2, b2 + 1);
+                        if (pb2 < 0 || pb2 >= B) {
+                            pb1 = next_bin(c1, b1 + 1);
+                            pb2 = (c1 == c2) ? pb1 : next_bin(c2, 0);
+                        }
+                        km_tag = -1;
+                        if (pb1 >= 0 && pb1 < B && pb2 >= 0 && pb2 < B) {
+                            km_tag = pb1 * B + pb2;
+                            km_pref = kmax[km_tag];
+                        }
+                    }
                 }
             }
+            SUBSTAMP(8)
+            if (STAMPS) { // diagnostic: expose the wait for the bound
+                if (found && km == -1.0) status |= 64;
+                asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            }
+            SUBSTAMP(9)
+            uint32_t w[4] = {0, 0, 0, 0};
+            if (found)
+                rng_block(seed, cell_id, step,
+                          ((uint32_t)(c1 * B + b1) << 16) | (uint32_t)(c2 * B + b2), SITE_POISSON, 0, w);
+            if (STAMPS && w[0] == 0x12345u && w[1] == 0x54321u) status |= 64;
+            SUBSTAMP(10)
+            if (found) {
+                const double nA = (double)(eA & 0xFFFFu), nB = (double)(eB & 0xFFFFu);
+                k_max = km * fmax;
+                const double n_possible =
+                    (c1 == c2 && b1 == b2) ? nA * (nA - 1.0) / 2.0 : nA * nB;
+                const double mean = k_max * del_t * n_possible;
+                ns_rem = (uint32_t)poisson(mean, u53(w[0], w[1]));
+                tot_samp += ns_rem;
+                s = 0;
+            }
+            SUBSTAMP(11)
+#undef SUBSTAMP
             const int waiting = __popcll(__ballot(!done && ns_rem == 0));
             if (waiting <= DRAW_SLACK) break;
         }
+        STAMP(1)
         if (__ballot(!done) == 0) break;
+        if (STAMPS) t_acc[6]++;
 
         // ---- evaluate one sample per lane ----
         bool acc = false;
         int i1 = 0, i2 = 0;
-        uint32_t p1 = 0, p2 = 0, s_ev = 0;
+        uint32_t p1 = 0, p2 = 0, s_ev = 0, eA = 0, eB = 0;
+        uint32_t last1 = 0, last2 = 0;          // entries at the ends of the two lists
         double v1 = 0, v2 = 0, m1 = 0, m2 = 0;
+        double vol1 = 0, vol2 = 0, lct1 = 0, lct2 = 0, gct1 = 0, gct2 = 0; // first species, times
+        int32_t no1 = 0, no2 = 0;               // first source
+        const int gA = c1 * B + b1, gB = c2 * B + b2;
         const bool same = (gA == gB);
         if (!done && ns_rem > 0) {
-            const int nA = CNT(gA), nB = CNT(gB);
+            eA = ent_get(c1, b1);
+            eB = same ? eA : ent_get(c2, b2);
+            const int nA = (int)(eA & 0xFFFFu), nB = (int)(eB & 0xFFFFu);
             if (nA < 1 || nB < 1 || (same && nA < 2)) {
                 ns_rem = 0; // a list ran out: the slot ends
             } else {
@@ -1134,10 +1196,24 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
                 } else {
                     i2 = (int)index_of(w[1], (uint32_t)nB);
                 }
-                p1 = list_get(gA, i1, n_app);
-                p2 = list_get(gB, i2, n_app);
-                v1 = ld_f64(&vtot[p1]); v2 = ld_f64(&vtot[p2]);
-                m1 = ld_f64(&mass[p1]); m2 = ld_f64(&mass[p2]);
+                if (n_app == 0) { // every entry sits in perm
+                    p1 = perm[(eA >> 16) + i1];
+                    p2 = perm[(eB >> 16) + i2];
+                    last1 = perm[(eA >> 16) + nA - 1];
+                    last2 = perm[(eB >> 16) + nB - 1];
+                } else {
+                    p1 = list_get(gA, eA, i1, n_app);
+                    p2 = list_get(gB, eB, i2, n_app);
+                    last1 = list_get(gA, eA, nA - 1, n_app);
+                    last2 = list_get(gB, eB, nB - 1, n_app);
+                }
+                v1 = vtot[p1]; v2 = vtot[p2];
+                m1 = mass[p1]; m2 = mass[p2];
+                // what a coagulation of this pair will need, requested now
+                vol1 = st.vol[cb * S + p1]; vol2 = st.vol[cb * S + p2];
+                lct1 = st.lct[cb + p1]; lct2 = st.lct[cb + p2];
+                gct1 = st.gct[cb + p1]; gct2 = st.gct[cb + p2];
+                if (NS > 0) { no1 = st.n_orig[cb * NS + p1]; no2 = st.n_orig[cb * NS + p2]; }
                 EnvDerived env;
                 env.gasfreepath = envs[0 * 64 + lane]; env.inv_gfp = envs[1 * 64 + lane];
                 env.c_diff = envs[2 * 64 + lane]; env.c_speed = envs[3 * 64 + lane];
@@ -1155,6 +1231,7 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
             }
         }
 
+        STAMP(2)
         // ---- coagulate ----
         if (acc) {
             do {
@@ -1174,70 +1251,130 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
                 const bool rem_o = pn_is_1 ? rem2 : rem1;
                 int in = pn_is_1 ? i1 : i2;
                 const int io = pn_is_1 ? i2 : i1;
-                const int g_old = pn_is_1 ? gA : gB, g_o = pn_is_1 ? gB : gA;
+                // the merged particle's list (old) and the other particle's list (o)
+                const int cl_old = pn_is_1 ? c1 : c2, b_old = pn_is_1 ? b1 : b2;
+                const int cl_o = pn_is_1 ? c2 : c1, b_o = pn_is_1 ? b2 : b1;
+                const int g_old = cl_old * B + b_old, g_o = cl_o * B + b_o;
                 if (vn < edge[0] || vn >= edge[B]) status |= ST_OUT_OF_GRID;
-                const int g_new = cc * B + bin_index(edge, B, vn, st);
+                const int b_new = bin_index(edge, B, vn, st);
+                const int g_new = cc * B + b_new;
                 if (g_new != g_old && n_app >= st.max_appends) {
                     status |= ST_APPEND_OVERFLOW; done = true; break;
                 }
                 n_ev++;
-                if (rem_o) {
-                    const int last = list_remove(g_o, io, n_app);
+                if (rem_o) { // swap-with-last removal of the other particle
+                    const uint32_t e = pn_is_1 ? eB : eA;
+                    const int last = (int)(e & 0xFFFFu) - 1;
+                    if (io != last) list_set(g_o, e, io, pn_is_1 ? last2 : last1, n_app);
+                    if (ovf_of(g_o, n_app) > 0) {
+                        O.last_app[g_o] = O.app_prev[O.last_app[g_o]];
+                        O.ovf_n[g_o] = (uint16_t)(O.ovf_n[g_o] - 1);
+                    }
+                    cnt_set(cl_o, b_o, e, last);
                     if (same && in == last) in = io;
                 }
                 if (g_new != g_old) {
-                    list_remove(g_old, in, n_app);
-                    list_append(g_new, pn, n_app);
+                    // the merged particle leaves its list ...
+                    uint32_t e = pn_is_1 ? eA : eB;
+                    uint32_t lastv = pn_is_1 ? last1 : last2;
+                    if (same && rem_o) { // the list just changed: look again
+                        e = ent_get(cl_old, b_old);
+                        lastv = list_get(g_old, e, (int)(e & 0xFFFFu) - 1, n_app);
+                    }
+                    const int last = (int)(e & 0xFFFFu) - 1;
+                    if (in != last) list_set(g_old, e, in, lastv, n_app);
+                    if (ovf_of(g_old, n_app) > 0) {
+                        O.last_app[g_old] = O.app_prev[O.last_app[g_old]];
+                        O.ovf_n[g_old] = (uint16_t)(O.ovf_n[g_old] - 1);
+                    }
+                    cnt_set(cl_old, b_old, e, last);
+                    // ... and joins the list of its new bin: behind it in perm while there is
+                    // room (and nothing of the group sits in the table already), else the table
+                    const uint32_t en = ent_get(cc, b_new);
+                    const int n = (int)(en & 0xFFFFu), o = (int)(en >> 16);
+                    if (ovf_of(g_new, n_app) == 0 && o + n < room_end(cc, b_new)) {
+                        perm[o + n] = pn;
+                    } else {
+                        if (n_app == 0) // first use of the table in this call
+                            for (int k = 0; k < G; k++) { O.ovf_n[k] = 0; O.last_app[k] = 0xFFFF; }
+                        O.app_slot[n_app] = (uint16_t)pn;
+                        O.app_prev[n_app] = O.last_app[g_new];
+                        O.last_app[g_new] = (uint16_t)n_app;
+                        O.ovf_n[g_new] = (uint16_t)(O.ovf_n[g_new] + 1);
+                        n_app++;
+                    }
+                    cnt_set(cc, b_new, en, n + 1);
                 }
-                st_f64(&vtot[pn], vn); st_f64(&mass[pn], mn);
+                vtot[pn] = vn; mass[pn] = mn;
                 // species volumes, source histogram, create times, class [aero_particle_coagulate]
-                for (int s0 = 0; s0 < S; s0 += 4) { // four species' loads in flight
+                st.vol[cb * S + pn] = (pn_is_1 ? vol1 : vol2) + (pn_is_1 ? vol2 : vol1);
+                for (int s0 = 1; s0 < S; s0 += 4) { // four species' loads in flight
                     double a[4], b[4];
 #pragma unroll
                     for (int k = 0; k < 4; k++)
                         if (s0 + k < S) {
-                            a[k] = ld_f64(&st.vol[cb * S + (int64_t)(s0 + k) * st.cap + pn]);
-                            b[k] = ld_f64(&st.vol[cb * S + (int64_t)(s0 + k) * st.cap + po]);
+                            a[k] = st.vol[cb * S + (int64_t)(s0 + k) * st.cap + pn];
+                            b[k] = st.vol[cb * S + (int64_t)(s0 + k) * st.cap + po];
                         }
 #pragma unroll
                     for (int k = 0; k < 4; k++)
                         if (s0 + k < S)
-                            st_f64(&st.vol[cb * S + (int64_t)(s0 + k) * st.cap + pn], a[k] + b[k]);
+                            st.vol[cb * S + (int64_t)(s0 + k) * st.cap + pn] = a[k] + b[k];
                 }
-                for (int sp = 0; sp < NS; sp++) {
-                    uint32_t *a = (uint32_t *)&st.n_orig[cb * NS + (int64_t)sp * st.cap + pn];
-                    st_u32(a, ld_u32(a) + ld_u32((uint32_t *)&st.n_orig[cb * NS + (int64_t)sp * st.cap + po]));
+                if (NS > 0)
+                    st.n_orig[cb * NS + pn] = (int32_t)((uint32_t)no1 + (uint32_t)no2);
+                for (int sp = 1; sp < NS; sp++) {
+                    int32_t *a = &st.n_orig[cb * NS + (int64_t)sp * st.cap + pn];
+                    *a = (int32_t)((uint32_t)*a + (uint32_t)st.n_orig[cb * NS + (int64_t)sp * st.cap + po]);
                 }
                 {
-                    const double lo_n = ld_f64(&st.lct[cb + pn]), lo_o = ld_f64(&st.lct[cb + po]);
-                    const double go_n = ld_f64(&st.gct[cb + pn]), go_o = ld_f64(&st.gct[cb + po]);
-                    if (lo_o < lo_n) st_f64(&st.lct[cb + pn], lo_o);
-                    if (go_o > go_n) st_f64(&st.gct[cb + pn], go_o);
+                    const double lo_n = pn_is_1 ? lct1 : lct2, lo_o = pn_is_1 ? lct2 : lct1;
+                    const double go_n = pn_is_1 ? gct1 : gct2, go_o = pn_is_1 ? gct2 : gct1;
+                    if (lo_o < lo_n) st.lct[cb + pn] = lo_o;
+                    if (go_o > go_n) st.gct[cb + pn] = go_o;
                 }
-                if (C > 1) st_u32((uint32_t *)&st.wclass[cb + pn], (uint32_t)cc);
-                if (rem_o) { mark_dead(st, cb, (int)po); n_dead++; }
+                if (C > 1) st.wclass[cb + pn] = cc;
+                if (rem_o) { vtot[po] = -1.0; st.wclass[cb + po] = -1; n_dead++; } // tombstone
                 tot_coag++;
             } while (false);
         }
         if (done) ns_rem = 0;
+        STAMP(3)
     }
 
     if (live) {
-        bool ovf = false;
-        for (int g = 0; g < G; g++) {
-            gcnt_g[g] = (int32_t)CNT(g);
-            if (n_app) ovf |= O.ovf_n[g] != 0;
+        for (int cl = 0; cl < C; cl++)
+            for (int k = 0; k < SEQ_W && blo + k < B; k++)
+                gcnt_g[cl * B + blo + k] = (int32_t)(ent[(cl * SEQ_W + k) * 64 + lane] & 0xFFFFu);
+        if (n_app) {
+            bool ovf = false;
+            for (int g = 0; g < G; g++) ovf |= O.ovf_n[g] != 0;
+            if (ovf) st.sort_valid[c] = 0;
         }
-        if (ovf) st.sort_valid[c] = 0;
         st.n_events[c] = n_ev;
         st.n_part[c] = st.n_part[c] - n_dead;
         st.n_samp[c] = tot_samp > 0x7FFFFFFFull ? 0x7FFFFFFF : (int32_t)tot_samp;
         st.n_coag[c] = tot_coag;
         if (status) atomicOr(&st.status[c], status);
     }
-#undef CNT
-#undef OFF
+    STAMP(4)
+    if (STAMPS && lane == 0) {
+        for (int k = 0; k < 12; k++)
+            if (k != 7) atomicAdd(&g_seq_stamps[k], (unsigned long long)t_acc[k]);
+        atomicAdd(&g_seq_stamps[7], 1ull);
+    }
+#undef STAMP
 #undef MASK
+}
+
+hipError_t seq_stamps_read(uint64_t out[12], bool reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_seq_stamps), 12 * sizeof(uint64_t));
+    if (e == hipSuccess && reset) {
+        const uint64_t z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_seq_stamps), z, sizeof(z));
+    }
+    return e;
 }
 
 // ---------------------------------------------------------------- compaction
@@ -2240,9 +2377,15 @@ hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, ui
     const size_t shared = (sizeof(double) * (size_t)(st.n_bin + 1) + 15) & ~(size_t)15;
     const int L = sampler_lanes(st);
     if (L == 1) {
-        hipLaunchKernelGGL(k_coag_seq, dim3((st.n_cells + 63) / 64), dim3(64),
-                           seq_lds_bytes(st.n_bin, st.n_class), s, st, ktype, del_t, seed, step,
-                           st.seq_ovf);
+        const char *e_st = getenv("PMCX_SEQ_STAMPS");
+        const dim3 grid((st.n_cells + 63) / 64), block(64);
+        const size_t lds = seq_lds_bytes(st.n_bin, st.n_class);
+        if (e_st && atoi(e_st) == 1)
+            hipLaunchKernelGGL(k_coag_seq<true>, grid, block, lds, s, st, ktype, del_t, seed, step,
+                               st.seq_ovf);
+        else
+            hipLaunchKernelGGL(k_coag_seq<false>, grid, block, lds, s, st, ktype, del_t, seed, step,
+                               st.seq_ovf);
         return hipGetLastError();
     }
     const size_t per = sampler_lds_for(st, L);

@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = [
     "pmcx_diagnostics", "pmcx_diagnostics_ext",
     "pmcx_generate_lognormal", "pmcx_timestep", "pmcx_get_bin_tables", "pmcx_get_diag_grid",
     "pmcx_get_kmax", "pmcx_get_caches", "pmcx_sort_only", "pmcx_invalidate_sort", "pmcx_get_sort", "pmcx_test_math",
-    "pmcx_test_philox", "pmcx_profile_enable", "pmcx_profile_reset", "pmcx_profile_get",
+    "pmcx_test_philox", "pmcx_profile_enable", "pmcx_profile_reset", "pmcx_profile_get", "pmcx_profile_phase_cycles",
     "pmcx_memory_bytes",
 ]
 
@@ -122,6 +122,7 @@ def load_library():
                                  C.c_void_p]
     L.pmcx_profile_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double),
                                    C.POINTER(C.c_int64)]
+    L.pmcx_profile_phase_cycles.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     L.pmcx_timestep.argtypes = [C.c_void_p, C.POINTER(PmcxStepFlags)]
     for name in ("pmcx_upload_cells", "pmcx_download_cells"):
         getattr(L, name).argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 7
@@ -451,6 +452,12 @@ class CellBlock:
 
     def profile_reset(self):
         self._ck(self._lib.pmcx_profile_reset(self._h))
+
+    def profile_phase_cycles(self, reset=True):
+        """Diagnostic (PMCX_SEQ_STAMPS=1): cycles per phase of the lane-per-cell sampler."""
+        out = (C.c_uint64 * 12)()
+        self._ck(self._lib.pmcx_profile_phase_cycles(self._h, out, 1 if reset else 0))
+        return list(out)
 
     def profile_get(self, name):
         ms, n = C.c_double(), C.c_int64()
