@@ -296,9 +296,9 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
     A_(st.kmax, nc * B * B);
     A_(st.n_part, nc); A_(st.n_hi, nc); A_(st.next_id, nc);
     A_(st.vol, nc * cfg->n_spec * cap);
-    A_(st.vtot, nc * cap); A_(st.mass, nc * cap);
+    A_(st.vm, nc * cap);
     A_(st.wclass, nc * cap); A_(st.id, nc * cap);
-    A_(st.lct, nc * cap); A_(st.gct, nc * cap);
+    A_(st.ct, nc * cap);
     A_(st.n_orig, nc * (size_t)cfg->n_source * cap);
     A_(st.perm, nc * (size_t)st.pcap);
     A_(st.gcnt, nc * G); A_(st.goff, nc * (G + 1)); A_(st.sort_valid, nc);
@@ -531,13 +531,13 @@ int pmcx_upload_cells(pmcx_ctx *ctx, int32_t cell_first, int32_t n_up, const int
         }
         if (least_ct) {
             const double *s = (const double *)h2d(least_ct, sizeof(double) * (size_t)nt);
-            HIP_TRY(ctx, launch_scatter_f64(s, st.lct + c0 * cap, ctx->d_offsets, n_up, cf.cap,
-                                            (int64_t)cap, nt, 1, (int64_t)cap, ctx->stream));
+            HIP_TRY(ctx, launch_scatter_f64(s, &st.ct[c0 * cap].x, ctx->d_offsets, n_up, cf.cap,
+                                            (int64_t)cap, nt, 1, (int64_t)cap, ctx->stream, 2));
         }
         if (greatest_ct) {
             const double *s = (const double *)h2d(greatest_ct, sizeof(double) * (size_t)nt);
-            HIP_TRY(ctx, launch_scatter_f64(s, st.gct + c0 * cap, ctx->d_offsets, n_up, cf.cap,
-                                            (int64_t)cap, nt, 1, (int64_t)cap, ctx->stream));
+            HIP_TRY(ctx, launch_scatter_f64(s, &st.ct[c0 * cap].y, ctx->d_offsets, n_up, cf.cap,
+                                            (int64_t)cap, nt, 1, (int64_t)cap, ctx->stream, 2));
         }
         if (n_orig && cf.n_source > 0) {
             const int32_t *s =
@@ -594,17 +594,18 @@ int pmcx_download_cells(pmcx_ctx *ctx, int32_t cell_first, int32_t n_dn, const i
                                     hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
-    auto one_f64 = [&](double *host, const double *dev) -> int {
-        HIP_TRY(ctx, launch_gather_f64((double *)ctx->stage, dev + c0 * cap, ctx->d_offsets, n_dn,
-                                       (int64_t)cap, nt, 1, (int64_t)cap, ctx->stream));
+    // dev: first element of cell 0; es: element stride (2 for half of an interleaved pair)
+    auto one_f64 = [&](double *host, const double *dev, int es = 1) -> int {
+        HIP_TRY(ctx, launch_gather_f64((double *)ctx->stage, dev + c0 * cap * es, ctx->d_offsets, n_dn,
+                                       (int64_t)cap, nt, 1, (int64_t)cap, ctx->stream, es));
         HIP_TRY(ctx, hipMemcpyAsync(host, ctx->stage, sizeof(double) * (size_t)nt,
                                     hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         return PMCX_OK;
     };
     if (id && (rc = one_f64((double *)id, (const double *)st.id))) return rc;
-    if (least_ct && (rc = one_f64(least_ct, st.lct))) return rc;
-    if (greatest_ct && (rc = one_f64(greatest_ct, st.gct))) return rc;
+    if (least_ct && (rc = one_f64(least_ct, &st.ct[0].x, 2))) return rc;
+    if (greatest_ct && (rc = one_f64(greatest_ct, &st.ct[0].y, 2))) return rc;
     if (wclass) {
         HIP_TRY(ctx, launch_gather_i32((int32_t *)ctx->stage, st.wclass + c0 * cap, ctx->d_offsets,
                                        n_dn, (int64_t)cap, nt, 1, (int64_t)cap, ctx->stream));
@@ -1023,8 +1024,13 @@ int pmcx_get_caches(pmcx_ctx *ctx, int32_t cell, double *vtot, double *mass)
     int rc = PMCX_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     HIP_TRY(ctx, launch_compact(ctx->st, cell, 1, 0, 1, ctx->stream));
-    if (vtot) rc = copy_cells_d2h(ctx, vtot, ctx->st.vtot + cell * cap, sizeof(double) * cap);
-    if (!rc && mass) rc = copy_cells_d2h(ctx, mass, ctx->st.mass + cell * cap, sizeof(double) * cap);
+    // the two caches are interleaved on the device: strided copies
+    const double2 *src = ctx->st.vm + (size_t)cell * cap;
+    if (vtot) HIP_TRY(ctx, hipMemcpy2DAsync(vtot, sizeof(double), &src->x, sizeof(double2), sizeof(double),
+                                            cap, hipMemcpyDeviceToHost, ctx->stream));
+    if (mass) HIP_TRY(ctx, hipMemcpy2DAsync(mass, sizeof(double), &src->y, sizeof(double2), sizeof(double),
+                                            cap, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return rc;
 }
 int pmcx_get_sort(pmcx_ctx *ctx, int32_t cell, uint32_t *perm, int32_t *gcnt, int32_t *goff)

@@ -42,11 +42,10 @@ struct DeviceState {
     int64_t *next_id;              // [n_cells]
     // particles
     double *vol;     // [n_cells][n_spec][cap]
-    double *vtot;    // [n_cells][cap]
-    double *mass;    // [n_cells][cap]
+    double2 *vm;     // [n_cells][cap] (cached total volume, cached mass): one request per particle
     int32_t *wclass; // [n_cells][cap]
     int64_t *id;     // [n_cells][cap]
-    double *lct, *gct;
+    double2 *ct;     // [n_cells][cap] (least, greatest create time)
     int32_t *n_orig; // [n_cells][n_source][cap]
     // scratch / outputs of the coagulation step
     // aero_sorted, kept between calls while sort_valid (aero_state%valid_sort)
@@ -72,13 +71,13 @@ size_t compact_lds_bytes(const DeviceState &st);
 
 hipError_t launch_scatter_f64(const double *src, double *dst, const int64_t *part_offset, int n_up,
                               int cap, int64_t dst_cell_stride, int64_t src_row_stride, int n_rows,
-                              int64_t dst_row_stride, hipStream_t s);
+                              int64_t dst_row_stride, hipStream_t s, int elem_stride = 1);
 hipError_t launch_scatter_i32(const int32_t *src, int32_t *dst, const int64_t *part_offset,
                               int n_up, int cap, int64_t dst_cell_stride, int64_t src_row_stride,
                               int n_rows, int64_t dst_row_stride, hipStream_t s);
 hipError_t launch_gather_f64(double *dst, const double *src, const int64_t *part_offset, int n_dn,
                              int64_t src_cell_stride, int64_t dst_row_stride, int n_rows,
-                             int64_t src_row_stride, hipStream_t s);
+                             int64_t src_row_stride, hipStream_t s, int elem_stride = 1);
 hipError_t launch_gather_i32(int32_t *dst, const int32_t *src, const int64_t *part_offset,
                              int n_dn, int64_t src_cell_stride, int64_t dst_row_stride, int n_rows,
                              int64_t src_row_stride, hipStream_t s);

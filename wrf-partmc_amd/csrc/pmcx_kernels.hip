@@ -8,9 +8,9 @@
 //
 // Layout in HBM (structure of arrays, one slab of `cap` slots per cell):
 //   vol   [n_cells][n_spec][cap] f64   particle%vol(:)
-//   vtot  [n_cells][cap] f64           cached sum_s vol
-//   mass  [n_cells][cap] f64           cached sum_s density_s*vol
-//   wclass[n_cells][cap] i32, id [..] i64, lct/gct [..] f64,
+//   vm    [n_cells][cap] 2 x f64       (cached sum_s vol, cached sum_s density_s*vol):
+//                                      interleaved, a pair evaluation is one request per particle
+//   wclass[n_cells][cap] i32, id [..] i64, ct [..] 2 x f64 (least, greatest create time),
 //   n_orig[n_cells][n_source][cap] i32
 // Kernels:
 //   k_bin_sort     one 256-thread workgroup per cell; stable counting sort of
@@ -65,7 +65,7 @@ __device__ __forceinline__ void st_u32(uint32_t *p, uint32_t v)
 // tombstone: the slot stays allocated, every consumer skips it
 __device__ __forceinline__ void mark_dead(const DeviceState &st, int64_t cb, int i)
 {
-    st_f64(&st.vtot[cb + i], -1.0);
+    st_f64(&st.vm[cb + i].x, -1.0);
     st_u32((uint32_t *)&st.wclass[cb + i], 0xFFFFFFFFu);
 }
 
@@ -105,17 +105,18 @@ __device__ __forceinline__ int bin_index(const double *v_edge, int n_bin, double
 // ------------------------------------------------------------ upload/download
 
 // packed [n_total] (cell-major) -> slab [n_cells][cap]
+// (es = element stride of the slab: 2 for one half of an interleaved pair array)
 __global__ void k_scatter_f64(const double *__restrict__ src, double *__restrict__ dst,
                               const int64_t *__restrict__ part_offset, int n_up, int cap,
                               int64_t dst_cell_stride, int64_t src_row_stride, int n_rows,
-                              int64_t dst_row_stride)
+                              int64_t dst_row_stride, int es)
 {
     const int k = blockIdx.y;
     const int64_t o0 = part_offset[k], n = part_offset[k + 1] - o0;
     for (int r = 0; r < n_rows; r++)
         for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
              i += (int64_t)gridDim.x * blockDim.x)
-            dst[(int64_t)k * dst_cell_stride + r * dst_row_stride + i] =
+            dst[((int64_t)k * dst_cell_stride + r * dst_row_stride + i) * es] =
                 src[r * src_row_stride + o0 + i];
 }
 __global__ void k_scatter_i32(const int32_t *__restrict__ src, int32_t *__restrict__ dst,
@@ -133,7 +134,7 @@ __global__ void k_scatter_i32(const int32_t *__restrict__ src, int32_t *__restri
 }
 __global__ void k_gather_f64(double *__restrict__ dst, const double *__restrict__ src,
                              const int64_t *__restrict__ part_offset, int64_t src_cell_stride,
-                             int64_t dst_row_stride, int n_rows, int64_t src_row_stride)
+                             int64_t dst_row_stride, int n_rows, int64_t src_row_stride, int es)
 {
     const int k = blockIdx.y;
     const int64_t o0 = part_offset[k], n = part_offset[k + 1] - o0;
@@ -141,7 +142,7 @@ __global__ void k_gather_f64(double *__restrict__ dst, const double *__restrict_
         for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
              i += (int64_t)gridDim.x * blockDim.x)
             dst[r * dst_row_stride + o0 + i] =
-                src[(int64_t)k * src_cell_stride + r * src_row_stride + i];
+                src[((int64_t)k * src_cell_stride + r * src_row_stride + i) * es];
 }
 __global__ void k_gather_i32(int32_t *__restrict__ dst, const int32_t *__restrict__ src,
                              const int64_t *__restrict__ part_offset, int64_t src_cell_stride,
@@ -177,8 +178,8 @@ __global__ void k_refresh_caches(DeviceState st, int cell_first, int n_cells_do)
             vt = vt + v;
             ms = ms + st.density[s] * v;
         }
-        st.vtot[cb + i] = vt;
-        st.mass[cb + i] = ms;
+        st.vm[cb + i].x = vt;
+        st.vm[cb + i].y = ms;
     }
 }
 
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st)
     // this wave's slots: a contiguous range whose length is a multiple of 64
     const int per = (((n + 3) >> 2) + 63) & ~63;
     const int lo = min(n, wave * per), hi = min(n, lo + per);
-    const double *vt = st.vtot + cb;
+    const double2 *vt = st.vm + cb; // .x = cached total volume
     const int32_t *wc = st.wclass + cb;
     const double v_lo = edge[0], v_hi = edge[B];
     uint32_t *myhist = hist + (size_t)wave * G;
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st)
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int i = i0 + u * 64 + lane;
-            v[u] = i < hi ? vt[i] : v_lo;
+            v[u] = i < hi ? vt[i].x : v_lo;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -420,7 +421,7 @@ __host__ __device__ inline size_t sampler_lds_bytes(int G, int C, int max_append
 struct CellCtx {
     CellLds L;
     uint32_t *perm;
-    double *vtot, *mass;
+    double2 *vm; // (cached total volume, cached mass) per slot
 };
 
 __device__ __forceinline__ uint32_t list_get(const CellCtx &X, int g, int i)
@@ -569,8 +570,7 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
         X.L.act = (uint8_t *)(base + o);
     }
     X.perm = st.perm + (int64_t)c * st.pcap;
-    X.vtot = st.vtot + cb;
-    X.mass = st.mass + cb;
+    X.vm = st.vm + cb;
 
     int32_t *gcnt_g = st.gcnt + (int64_t)c * G;
     const int32_t *goff_g = st.goff + (int64_t)c * (G + 1);
@@ -753,8 +753,8 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
             }
             p1 = list_get(X, gA, i1);
             p2 = list_get(X, gB, i2);
-            v1 = ld_f64(&X.vtot[p1]); v2 = ld_f64(&X.vtot[p2]);
-            m1 = ld_f64(&X.mass[p1]); m2 = ld_f64(&X.mass[p2]);
+            v1 = ld_f64(&X.vm[p1].x); v2 = ld_f64(&X.vm[p2].x);
+            m1 = ld_f64(&X.vm[p1].y); m2 = ld_f64(&X.vm[p2].y);
             const double k_max = kmax[b1 * B + b2] * fmax;
             const PartProps qa = props_for(ktype, v1, m1, env);
             const PartProps qb = props_for(ktype, v2, m2, env);
@@ -823,8 +823,8 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
         }
         double lo_n = 0, lo_o = 0, go_n = 0, go_o = 0;
         if (lead) {
-            lo_n = ld_f64(&st.lct[cb + pn]); lo_o = ld_f64(&st.lct[cb + po]);
-            go_n = ld_f64(&st.gct[cb + pn]); go_o = ld_f64(&st.gct[cb + po]);
+            lo_n = ld_f64(&st.ct[cb + pn].x); lo_o = ld_f64(&st.ct[cb + po].x);
+            go_n = ld_f64(&st.ct[cb + pn].y); go_o = ld_f64(&st.ct[cb + po].y);
         }
         if (rem_o) {
             const int last = list_remove(X, g_o, io, B, lead);
@@ -837,9 +837,9 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
             n_app += list_append(X, g_new, pn, n_app, B, lead);
         }
         if (lead) {
-            st_f64(&X.vtot[pn], vn); st_f64(&X.mass[pn], mn);
-            if (lo_o < lo_n) st_f64(&st.lct[cb + pn], lo_o);
-            if (go_o > go_n) st_f64(&st.gct[cb + pn], go_o);
+            st_f64(&X.vm[pn].x, vn); st_f64(&X.vm[pn].y, mn);
+            if (lo_o < lo_n) st_f64(&st.ct[cb + pn].x, lo_o);
+            if (go_o > go_n) st_f64(&st.ct[cb + pn].y, go_o);
             if (C > 1) st_u32((uint32_t *)&st.wclass[cb + pn], (uint32_t)cc);
         }
         {
@@ -974,7 +974,8 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
     for (int j = lane; j <= B; j += 64) edge[j] = st.v_edge[j];
 
     uint32_t *perm = st.perm + (int64_t)c * st.pcap;
-    double *vtot = st.vtot + cb, *mass = st.mass + cb;
+    double2 *vm = st.vm + cb;  // (cached total volume, cached mass)
+    double2 *ct = st.ct + cb;  // (least, greatest create time)
     int32_t *gcnt_g = st.gcnt + (int64_t)c * G;
     const int32_t *goff_g = st.goff + (int64_t)c * (G + 1);
     SeqOverflow O;
@@ -1207,12 +1208,13 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
                     last1 = list_get(gA, eA, nA - 1, n_app);
                     last2 = list_get(gB, eB, nB - 1, n_app);
                 }
-                v1 = vtot[p1]; v2 = vtot[p2];
-                m1 = mass[p1]; m2 = mass[p2];
-                // what a coagulation of this pair will need, requested now
-                vol1 = st.vol[cb * S + p1]; vol2 = st.vol[cb * S + p2];
-                lct1 = st.lct[cb + p1]; lct2 = st.lct[cb + p2];
-                gct1 = st.gct[cb + p1]; gct2 = st.gct[cb + p2];
+                const double2 a1 = vm[p1], a2 = vm[p2];
+                v1 = a1.x; m1 = a1.y; v2 = a2.x; m2 = a2.y;
+                // what a coagulation of this pair will need, requested now (with one species
+                // the volume of that species IS the cached total: both are sums of the same terms)
+                if (S > 1) { vol1 = st.vol[cb * S + p1]; vol2 = st.vol[cb * S + p2]; }
+                const double2 t1 = ct[p1], t2 = ct[p2];
+                lct1 = t1.x; gct1 = t1.y; lct2 = t2.x; gct2 = t2.y;
                 if (NS > 0) { no1 = st.n_orig[cb * NS + p1]; no2 = st.n_orig[cb * NS + p2]; }
                 EnvDerived env;
                 env.gasfreepath = envs[0 * 64 + lane]; env.inv_gfp = envs[1 * 64 + lane];
@@ -1305,9 +1307,9 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
                     }
                     cnt_set(cc, b_new, en, n + 1);
                 }
-                vtot[pn] = vn; mass[pn] = mn;
+                vm[pn] = make_double2(vn, mn);
                 // species volumes, source histogram, create times, class [aero_particle_coagulate]
-                st.vol[cb * S + pn] = (pn_is_1 ? vol1 : vol2) + (pn_is_1 ? vol2 : vol1);
+                st.vol[cb * S + pn] = (S > 1) ? (pn_is_1 ? vol1 : vol2) + (pn_is_1 ? vol2 : vol1) : vn;
                 for (int s0 = 1; s0 < S; s0 += 4) { // four species' loads in flight
                     double a[4], b[4];
 #pragma unroll
@@ -1330,11 +1332,11 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
                 {
                     const double lo_n = pn_is_1 ? lct1 : lct2, lo_o = pn_is_1 ? lct2 : lct1;
                     const double go_n = pn_is_1 ? gct1 : gct2, go_o = pn_is_1 ? gct2 : gct1;
-                    if (lo_o < lo_n) st.lct[cb + pn] = lo_o;
-                    if (go_o > go_n) st.gct[cb + pn] = go_o;
+                    if (lo_o < lo_n || go_o > go_n)
+                        ct[pn] = make_double2(lo_o < lo_n ? lo_o : lo_n, go_o > go_n ? go_o : go_n);
                 }
                 if (C > 1) st.wclass[cb + pn] = cc;
-                if (rem_o) { vtot[po] = -1.0; st.wclass[cb + po] = -1; n_dead++; } // tombstone
+                if (rem_o) { vm[po].x = -1.0; st.wclass[cb + po] = -1; n_dead++; } // tombstone
                 tot_coag++;
             } while (false);
         }
@@ -1394,12 +1396,12 @@ __device__ __forceinline__ void move_particle(const DeviceState &st, int64_t cb,
     for (int s = 0; s < st.n_source; s++)
         st.n_orig[cb * st.n_source + (int64_t)s * st.cap + dst] =
             st.n_orig[cb * st.n_source + (int64_t)s * st.cap + src];
-    st.vtot[cb + dst] = st.vtot[cb + src];
-    st.mass[cb + dst] = st.mass[cb + src];
+    st.vm[cb + dst].x = st.vm[cb + src].x;
+    st.vm[cb + dst].y = st.vm[cb + src].y;
     st.wclass[cb + dst] = st.wclass[cb + src];
     st.id[cb + dst] = st.id[cb + src];
-    st.lct[cb + dst] = st.lct[cb + src];
-    st.gct[cb + dst] = st.gct[cb + src];
+    st.ct[cb + dst].x = st.ct[cb + src].x;
+    st.ct[cb + dst].y = st.ct[cb + src].y;
 }
 
 // Stable compaction of one cell by one wavefront: 64 slots at a time, every
@@ -1431,16 +1433,16 @@ __device__ void compact_wave(const DeviceState &st, int c, int lane, uint32_t *c
         int64_t idv = 0;
         int32_t wc = 0;
         if (mv) {
-            a0 = ld_f64(&st.vtot[cb + i]); a1 = ld_f64(&st.mass[cb + i]);
-            a2 = ld_f64(&st.lct[cb + i]); a3 = ld_f64(&st.gct[cb + i]);
+            a0 = ld_f64(&st.vm[cb + i].x); a1 = ld_f64(&st.vm[cb + i].y);
+            a2 = ld_f64(&st.ct[cb + i].x); a3 = ld_f64(&st.ct[cb + i].y);
             idv = (int64_t)d2u(ld_f64((const double *)&st.id[cb + i]));
             wc = (int32_t)ld_u32((const uint32_t *)&st.wclass[cb + i]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
         if (mv) {
-            st_f64(&st.vtot[cb + dst], a0); st_f64(&st.mass[cb + dst], a1);
-            st_f64(&st.lct[cb + dst], a2); st_f64(&st.gct[cb + dst], a3);
+            st_f64(&st.vm[cb + dst].x, a0); st_f64(&st.vm[cb + dst].y, a1);
+            st_f64(&st.ct[cb + dst].x, a2); st_f64(&st.ct[cb + dst].y, a3);
             st_f64((double *)&st.id[cb + dst], u2d((uint64_t)idv));
             st_u32((uint32_t *)&st.wclass[cb + dst], (uint32_t)wc);
         }
@@ -1777,12 +1779,12 @@ __device__ int add_dist_sample(const DeviceState &st, int c, const AeroDistDev &
             }
             for (int s = 0; s < st.n_source; s++)
                 st.n_orig[cb * st.n_source + (int64_t)s * st.cap + i] = (s == d.mode_source[m]) ? 1 : 0;
-            st.vtot[cb + i] = vt;
-            st.mass[cb + i] = ms;
+            st.vm[cb + i].x = vt;
+            st.vm[cb + i].y = ms;
             st.wclass[cb + i] = cl;
             st.id[cb + i] = nid + k;
-            st.lct[cb + i] = create_time;
-            st.gct[cb + i] = create_time;
+            st.ct[cb + i].x = create_time;
+            st.ct[cb + i].y = create_time;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
@@ -2033,11 +2035,11 @@ __global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid t
                     st.vol[cb * S + (int64_t)sp * st.cap + dst] = st.vol[sb * S + (int64_t)sp * st.cap + from];
                 for (int sp = 0; sp < NS; sp++)
                     st.n_orig[cb * NS + (int64_t)sp * st.cap + dst] = st.n_orig[sb * NS + (int64_t)sp * st.cap + from];
-                st.vtot[cb + dst] = st.vtot[sb + from];
-                st.mass[cb + dst] = st.mass[sb + from];
+                st.vm[cb + dst].x = st.vm[sb + from].x;
+                st.vm[cb + dst].y = st.vm[sb + from].y;
                 st.wclass[cb + dst] = st.wclass[sb + from];
-                st.lct[cb + dst] = st.lct[sb + from];
-                st.gct[cb + dst] = st.gct[sb + from];
+                st.ct[cb + dst].x = st.ct[sb + from].x;
+                st.ct[cb + dst].y = st.ct[sb + from].y;
                 st.id[cb + dst] = (g == copies - 1) ? st.id[sb + from] : id0 + g;
             }
             at += (int)__shfl(inc, 63, 64);
@@ -2126,8 +2128,8 @@ __global__ __launch_bounds__(256) void k_condense(DeviceState st, const double *
             vt = vt + v;
             ms = ms + st.density[s] * v;
         }
-        st.vtot[cb + i] = vt;
-        st.mass[cb + i] = ms;
+        st.vm[cb + i].x = vt;
+        st.vm[cb + i].y = ms;
     }
 }
 
@@ -2159,12 +2161,12 @@ __global__ void k_generate(DeviceState st, GenSpecDev g, int n, uint64_t seed, d
         }
         for (int s = 0; s < st.n_source; s++)
             st.n_orig[cb * st.n_source + (int64_t)s * st.cap + i] = (s == g.mode_source[mode]) ? 1 : 0;
-        st.vtot[cb + i] = vt;
-        st.mass[cb + i] = ms;
+        st.vm[cb + i].x = vt;
+        st.vm[cb + i].y = ms;
         st.wclass[cb + i] = g.mode_class[mode];
         st.id[cb + i] = ((int64_t)cell_id << 32) + i;
-        st.lct[cb + i] = create_time;
-        st.gct[cb + i] = create_time;
+        st.ct[cb + i].x = create_time;
+        st.ct[cb + i].y = create_time;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { st.n_part[c] = n; st.n_hi[c] = n; }
 }
@@ -2307,10 +2309,11 @@ static inline dim3 grid2(int64_t n_max, int n_y)
 
 hipError_t launch_scatter_f64(const double *src, double *dst, const int64_t *part_offset, int n_up,
                               int cap, int64_t dst_cell_stride, int64_t src_row_stride, int n_rows,
-                              int64_t dst_row_stride, hipStream_t s)
+                              int64_t dst_row_stride, hipStream_t s, int elem_stride)
 {
     hipLaunchKernelGGL(k_scatter_f64, grid2(cap, n_up), dim3(256), 0, s, src, dst, part_offset,
-                       n_up, cap, dst_cell_stride, src_row_stride, n_rows, dst_row_stride);
+                       n_up, cap, dst_cell_stride, src_row_stride, n_rows, dst_row_stride,
+                       elem_stride);
     return hipGetLastError();
 }
 hipError_t launch_scatter_i32(const int32_t *src, int32_t *dst, const int64_t *part_offset,
@@ -2323,10 +2326,11 @@ hipError_t launch_scatter_i32(const int32_t *src, int32_t *dst, const int64_t *p
 }
 hipError_t launch_gather_f64(double *dst, const double *src, const int64_t *part_offset, int n_dn,
                              int64_t src_cell_stride, int64_t dst_row_stride, int n_rows,
-                             int64_t src_row_stride, hipStream_t s)
+                             int64_t src_row_stride, hipStream_t s, int elem_stride)
 {
     hipLaunchKernelGGL(k_gather_f64, grid2(src_cell_stride, n_dn), dim3(256), 0, s, dst, src,
-                       part_offset, src_cell_stride, dst_row_stride, n_rows, src_row_stride);
+                       part_offset, src_cell_stride, dst_row_stride, n_rows, src_row_stride,
+                       elem_stride);
     return hipGetLastError();
 }
 hipError_t launch_gather_i32(int32_t *dst, const int32_t *src, const int64_t *part_offset,
