@@ -1071,8 +1071,6 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
     int c1 = 0, c2 = 0, b1 = -1, b2 = -1, cc = 0;
     double n1 = 0, n2 = 0, nmin = 0, fmax = 0, factor = 0, k_max = 0;
     uint32_t ns_rem = 0, s = 0;
-    double km_pref = 0;
-    int km_tag = -1;
     bool done = !live;
     STAMP(0)
 
@@ -1122,23 +1120,7 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
                     fmax = (n1 < n2) ? n2 : n1;
                     factor = n1 * n2 / nmin;
                 }
-                if (found) {
-                    // the bound of this slot was requested while the previous one was drawn
-                    const int kidx = b1 * B + b2;
-                    km = (km_tag == kidx) ? km_pref : kmax[kidx];
-                    {   // request the next slot's bound: next partner bin, else the next row's first
-                        int pb1 = b1, pb2 = next_bin(c2, b2 + 1);
-                        if (pb2 < 0 || pb2 >= B) {
-                            pb1 = next_bin(c1, b1 + 1);
-                            pb2 = (c1 == c2) ? pb1 : next_bin(c2, 0);
-                        }
-                        km_tag = -1;
-                        if (pb1 >= 0 && pb1 < B && pb2 >= 0 && pb2 < B) {
-                            km_tag = pb1 * B + pb2;
-                            km_pref = kmax[km_tag];
-                        }
-                    }
-                }
+                if (found) km = kmax[b1 * B + b2]; // arrives while the Philox rounds run
             }
             SUBSTAMP(8)
             if (STAMPS) { // diagnostic: expose the wait for the bound
