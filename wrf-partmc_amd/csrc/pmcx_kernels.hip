@@ -923,9 +923,8 @@ struct SeqOverflow {      // per cell, in HBM; touched only after a group's room
     uint16_t *app_prev;   // [max_appends]
 };
 
-constexpr int SEQ_W = 40;      // bins per class with list state in LDS
+constexpr int SEQ_W = 32;      // bins per class with list state in LDS
 constexpr int SEQ_ENV = 7;     // air properties kept per cell
-constexpr int DRAW_SLACK = 16;
 
 __host__ __device__ inline size_t seq_lds_bytes(int B, int C)
 {
@@ -943,7 +942,7 @@ __host__ __device__ inline size_t seq_lds_bytes(int B, int C)
 __device__ unsigned long long g_seq_stamps[12];
 
 template <bool STAMPS>
-__global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, double del_t,
+__global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype, double del_t,
                                                  uint64_t seed, uint32_t step, uint16_t *ovf_mem)
 {
     uint64_t t_last = 0, t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1074,93 +1073,69 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
     bool done = !live;
     STAMP(0)
 
-    while (true) {
-        // ---- draw: lanes without a sample move to their next slot ----
-        while (true) {
-            uint64_t t_sub = 0;
-            if (STAMPS) { t_acc[5]++; t_sub = __builtin_amdgcn_s_memtime(); }
-#define SUBSTAMP(k)                                                                               \
-    if (STAMPS) {                                                                                 \
-        const uint64_t t_now = __builtin_amdgcn_s_memtime();                                      \
-        t_acc[k] += t_now - t_sub;                                                                \
-        t_sub = t_now;                                                                            \
-    }
-            const bool need = !done && ns_rem == 0;
-            bool found = false;
-            double km = 0;
-            uint32_t eA = 0, eB = 0;
-            if (need) {
-                // next slot of the sweep c1, c2 <= c1, b1, b2 (>= b1 within a class) whose
-                // lists can give a pair now
-                while (!found && !done) {
-                    if (b1 >= 0) {
-                        eA = ent_get(c1, b1);
-                        if ((eA & 0xFFFFu) > 0) {
-                            const int nb2 = next_bin(c2, b2 + 1);
-                            if (nb2 >= 0 && nb2 < B) {
-                                b2 = nb2;
-                                const bool same = (c1 == c2 && b1 == b2);
-                                eB = same ? eA : ent_get(c2, b2);
-                                found = !(same && (eA & 0xFFFFu) < 2);
-                                continue;
-                            }
-                        }
-                    }
-                    b1 = next_bin(c1, b1 + 1);
-                    if (b1 < 0 || b1 >= B) {
-                        b1 = -1;
-                        if (++c2 > c1) { c2 = 0; ++c1; }
-                        if (c1 >= C) done = true;
+    // One draw step of a lane that holds no sample: move to the next slot of the sweep
+    // c1, c2 <= c1, b1, b2 (>= b1 within a class) whose lists can give a pair now, and
+    // request its bound.  Returns false when there is none left (done is set).
+    auto draw_find = [&](uint32_t &eA, uint32_t &eB, double &km) -> bool {
+        bool found = false;
+        while (!found && !done) {
+            if (b1 >= 0) {
+                eA = ent_get(c1, b1);
+                if ((eA & 0xFFFFu) > 0) {
+                    const int nb2 = next_bin(c2, b2 + 1);
+                    if (nb2 >= 0 && nb2 < B) {
+                        b2 = nb2;
+                        const bool same = (c1 == c2 && b1 == b2);
+                        eB = same ? eA : ent_get(c2, b2);
+                        found = !(same && (eA & 0xFFFFu) < 2);
                         continue;
                     }
-                    b2 = ((c1 == c2) ? b1 : 0) - 1;
-                    n1 = magl[c1 * 64 + lane]; n2 = magl[c2 * 64 + lane];
-                    cc = (n1 < n2) ? c1 : c2;
-                    nmin = (n1 < n2) ? n1 : n2;
-                    fmax = (n1 < n2) ? n2 : n1;
-                    factor = n1 * n2 / nmin;
                 }
-                if (found) km = kmax[b1 * B + b2]; // arrives while the Philox rounds run
             }
-            SUBSTAMP(8)
-            if (STAMPS) { // diagnostic: expose the wait for the bound
-                if (found && km == -1.0) status |= 64;
-                asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            b1 = next_bin(c1, b1 + 1);
+            if (b1 < 0 || b1 >= B) {
+                b1 = -1;
+                if (++c2 > c1) { c2 = 0; ++c1; }
+                if (c1 >= C) done = true;
+                continue;
             }
-            SUBSTAMP(9)
-            uint32_t w[4] = {0, 0, 0, 0};
-            if (found)
-                rng_block(seed, cell_id, step,
-                          ((uint32_t)(c1 * B + b1) << 16) | (uint32_t)(c2 * B + b2), SITE_POISSON, 0, w);
-            if (STAMPS && w[0] == 0x12345u && w[1] == 0x54321u) status |= 64;
-            SUBSTAMP(10)
-            if (found) {
-                const double nA = (double)(eA & 0xFFFFu), nB = (double)(eB & 0xFFFFu);
-                k_max = km * fmax;
-                const double n_possible =
-                    (c1 == c2 && b1 == b2) ? nA * (nA - 1.0) / 2.0 : nA * nB;
-                const double mean = k_max * del_t * n_possible;
-                ns_rem = (uint32_t)poisson(mean, u53(w[0], w[1]));
-                tot_samp += ns_rem;
-                s = 0;
-            }
-            SUBSTAMP(11)
-#undef SUBSTAMP
-            const int waiting = __popcll(__ballot(!done && ns_rem == 0));
-            if (waiting <= DRAW_SLACK) break;
+            b2 = ((c1 == c2) ? b1 : 0) - 1;
+            n1 = magl[c1 * 64 + lane]; n2 = magl[c2 * 64 + lane];
+            cc = (n1 < n2) ? c1 : c2;
+            nmin = (n1 < n2) ? n1 : n2;
+            fmax = (n1 < n2) ? n2 : n1;
+            factor = n1 * n2 / nmin;
         }
-        STAMP(1)
+        if (found) km = kmax[b1 * B + b2];
+        return found;
+    };
+    // the slot's Poisson count from its uniform u
+    auto draw_count = [&](uint32_t eA, uint32_t eB, double km, double u) {
+        const double nA = (double)(eA & 0xFFFFu), nB = (double)(eB & 0xFFFFu);
+        k_max = km * fmax;
+        const double n_possible = (c1 == c2 && b1 == b2) ? nA * (nA - 1.0) / 2.0 : nA * nB;
+        const double mean = k_max * del_t * n_possible;
+        ns_rem = (uint32_t)poisson(mean, u);
+        tot_samp += ns_rem;
+        s = 0;
+    };
+
+    // Every pass of the loop a lane either evaluates one sample (and coagulates the pair when
+    // accepted) or, holding none, draws the counts of up to two slots.  The memory requests
+    // of one kind of lane are issued before the arithmetic of the other kind, so that each
+    // wait of the wavefront is covered by work: list entries | first draw's search and
+    // Philox -> volumes, masses and event data | first Poisson, second search and Philox ->
+    // kernel evaluation, second Poisson, coagulation.
+    while (true) {
         if (__ballot(!done) == 0) break;
         if (STAMPS) t_acc[6]++;
 
-        // ---- evaluate one sample per lane ----
-        bool acc = false;
+        // ---- (1) evaluating lanes: the sample's pair, list entries requested ----
+        bool evalid = false, acc = false;
         int i1 = 0, i2 = 0;
         uint32_t p1 = 0, p2 = 0, s_ev = 0, eA = 0, eB = 0;
         uint32_t last1 = 0, last2 = 0;          // entries at the ends of the two lists
-        double v1 = 0, v2 = 0, m1 = 0, m2 = 0;
-        double vol1 = 0, vol2 = 0, lct1 = 0, lct2 = 0, gct1 = 0, gct2 = 0; // first species, times
-        int32_t no1 = 0, no2 = 0;               // first source
+        double u_acc = 0;
         const int gA = c1 * B + b1, gB = c2 * B + b2;
         const bool same = (gA == gB);
         if (!done && ns_rem > 0) {
@@ -1168,7 +1143,7 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
             eB = same ? eA : ent_get(c2, b2);
             const int nA = (int)(eA & 0xFFFFu), nB = (int)(eB & 0xFFFFu);
             if (nA < 1 || nB < 1 || (same && nA < 2)) {
-                ns_rem = 0; // a list ran out: the slot ends
+                ns_rem = 0; // a list ran out: the slot ends (the lane draws below)
             } else {
                 uint32_t w[4];
                 rng_block(seed, cell_id, step, ((uint32_t)gA << 16) | (uint32_t)gB, SITE_CAND, s, w);
@@ -1179,6 +1154,7 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
                 } else {
                     i2 = (int)index_of(w[1], (uint32_t)nB);
                 }
+                u_acc = u53(w[2], w[3]);
                 if (n_app == 0) { // every entry sits in perm
                     p1 = perm[(eA >> 16) + i1];
                     p2 = perm[(eB >> 16) + i2];
@@ -1190,33 +1166,80 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
                     last1 = list_get(gA, eA, nA - 1, n_app);
                     last2 = list_get(gB, eB, nB - 1, n_app);
                 }
-                const double2 a1 = vm[p1], a2 = vm[p2];
-                v1 = a1.x; m1 = a1.y; v2 = a2.x; m2 = a2.y;
-                // what a coagulation of this pair will need, requested now (with one species
-                // the volume of that species IS the cached total: both are sums of the same terms)
-                if (S > 1) { vol1 = st.vol[cb * S + p1]; vol2 = st.vol[cb * S + p2]; }
-                const double2 t1 = ct[p1], t2 = ct[p2];
-                lct1 = t1.x; gct1 = t1.y; lct2 = t2.x; gct2 = t2.y;
-                if (NS > 0) { no1 = st.n_orig[cb * NS + p1]; no2 = st.n_orig[cb * NS + p2]; }
-                EnvDerived env;
-                env.gasfreepath = envs[0 * 64 + lane]; env.inv_gfp = envs[1 * 64 + lane];
-                env.c_diff = envs[2 * 64 + lane]; env.c_speed = envs[3 * 64 + lane];
-                env.c_inv_speed = envs[4 * 64 + lane]; env.c_fall = envs[5 * 64 + lane];
-                env.rhoair = envs[6 * 64 + lane];
-                const PartProps qa = props_for(ktype, v1, m1, env);
-                const PartProps qb = props_for(ktype, v2, m2, env);
-                const double k = kernel_pair(ktype, v1, v2, qa, qb, kp);
-                const double kf = k * factor;
-                if (kf > k_max) status |= ST_KMAX_EXCEEDED;
-                acc = u53(w[2], w[3]) * k_max < kf;
-                s_ev = s;
-                s++;
-                ns_rem--;
+                evalid = true;
             }
         }
 
+        // ---- (2) drawing lanes: first slot, bound requested, Philox ----
+        const bool drawing = !done && !evalid && ns_rem == 0;
+        uint32_t dA = 0, dB = 0;
+        double km = 0, u_d = 0;
+        bool found = false;
+        if (drawing) {
+            if (STAMPS) t_acc[5]++;
+            found = draw_find(dA, dB, km);
+            if (found) {
+                uint32_t w[4];
+                rng_block(seed, cell_id, step,
+                          ((uint32_t)(c1 * B + b1) << 16) | (uint32_t)(c2 * B + b2), SITE_POISSON, 0, w);
+                u_d = u53(w[0], w[1]);
+            }
+        }
+        STAMP(1)
+
+        // ---- (3) evaluating lanes: volumes, masses and what a coagulation will need ----
+        double v1 = 0, v2 = 0, m1 = 0, m2 = 0;
+        double vol1 = 0, vol2 = 0, lct1 = 0, lct2 = 0, gct1 = 0, gct2 = 0; // first species, times
+        int32_t no1 = 0, no2 = 0;               // first source
+        if (evalid) {
+            const double2 a1 = vm[p1], a2 = vm[p2];
+            v1 = a1.x; m1 = a1.y; v2 = a2.x; m2 = a2.y;
+            // (with one species the volume of that species IS the cached total: both are sums
+            // of the same terms)
+            if (S > 1) { vol1 = st.vol[cb * S + p1]; vol2 = st.vol[cb * S + p2]; }
+            const double2 t1 = ct[p1], t2 = ct[p2];
+            lct1 = t1.x; gct1 = t1.y; lct2 = t2.x; gct2 = t2.y;
+            if (NS > 0) { no1 = st.n_orig[cb * NS + p1]; no2 = st.n_orig[cb * NS + p2]; }
+        }
+
+        // ---- (4) drawing lanes: first count; still empty-handed: second slot ----
+        bool found2 = false;
+        if (drawing) {
+            if (found) draw_count(dA, dB, km, u_d);
+            if (!done && ns_rem == 0) {
+                if (STAMPS) t_acc[5]++;
+                found2 = draw_find(dA, dB, km);
+                if (found2) {
+                    uint32_t w[4];
+                    rng_block(seed, cell_id, step,
+                              ((uint32_t)(c1 * B + b1) << 16) | (uint32_t)(c2 * B + b2), SITE_POISSON, 0, w);
+                    u_d = u53(w[0], w[1]);
+                }
+            }
+        }
         STAMP(2)
-        // ---- coagulate ----
+
+        // ---- (5) evaluating lanes: kernel, accept ----
+        if (evalid) {
+            EnvDerived env;
+            env.gasfreepath = envs[0 * 64 + lane]; env.inv_gfp = envs[1 * 64 + lane];
+            env.c_diff = envs[2 * 64 + lane]; env.c_speed = envs[3 * 64 + lane];
+            env.c_inv_speed = envs[4 * 64 + lane]; env.c_fall = envs[5 * 64 + lane];
+            env.rhoair = envs[6 * 64 + lane];
+            const PartProps qa = props_for(ktype, v1, m1, env);
+            const PartProps qb = props_for(ktype, v2, m2, env);
+            const double k = kernel_pair(ktype, v1, v2, qa, qb, kp);
+            const double kf = k * factor;
+            if (kf > k_max) status |= ST_KMAX_EXCEEDED;
+            acc = u_acc * k_max < kf;
+            s_ev = s;
+            s++;
+            ns_rem--;
+        }
+        // ---- (6) drawing lanes: second count ----
+        if (found2) draw_count(dA, dB, km, u_d);
+
+        // ---- (7) coagulate ----
         if (acc) {
             do {
                 if (n_ev >= st.max_events) { status |= ST_EVENT_OVERFLOW; done = true; break; }
