@@ -187,7 +187,21 @@ __device__ inline double det_norminv(double p)
 constexpr double POISSON_WALK_MAX = 200.0;
 constexpr int32_t NSAMP_MAX = 0x00FFFFFF; // per-slot cap: a row's total fits 32 bits
 
-__device__ inline int32_t poisson(double mean, double u)
+// 1/n for n = 1..POISSON_RCP_N, correctly rounded (the walk multiplies by these instead of
+// dividing: a division is ~35 instructions on gfx950, and the walk is as long as the largest
+// count drawn by any lane of the wavefront).  Kernels that draw often keep a copy in LDS.
+constexpr int POISSON_RCP_N = 64;
+__device__ const double g_poisson_rcp[POISSON_RCP_N + 1] = {
+    0.0, 1.0 / 1, 1.0 / 2, 1.0 / 3, 1.0 / 4, 1.0 / 5, 1.0 / 6, 1.0 / 7, 1.0 / 8, 1.0 / 9, 1.0 / 10,
+    1.0 / 11, 1.0 / 12, 1.0 / 13, 1.0 / 14, 1.0 / 15, 1.0 / 16, 1.0 / 17, 1.0 / 18, 1.0 / 19,
+    1.0 / 20, 1.0 / 21, 1.0 / 22, 1.0 / 23, 1.0 / 24, 1.0 / 25, 1.0 / 26, 1.0 / 27, 1.0 / 28,
+    1.0 / 29, 1.0 / 30, 1.0 / 31, 1.0 / 32, 1.0 / 33, 1.0 / 34, 1.0 / 35, 1.0 / 36, 1.0 / 37,
+    1.0 / 38, 1.0 / 39, 1.0 / 40, 1.0 / 41, 1.0 / 42, 1.0 / 43, 1.0 / 44, 1.0 / 45, 1.0 / 46,
+    1.0 / 47, 1.0 / 48, 1.0 / 49, 1.0 / 50, 1.0 / 51, 1.0 / 52, 1.0 / 53, 1.0 / 54, 1.0 / 55,
+    1.0 / 56, 1.0 / 57, 1.0 / 58, 1.0 / 59, 1.0 / 60, 1.0 / 61, 1.0 / 62, 1.0 / 63, 1.0 / 64};
+
+template <typename RcpPtr>
+__device__ inline int32_t poisson(double mean, double u, RcpPtr rcp)
 {
     if (!(mean > 0.0)) return 0;
     if (mean < POISSON_WALK_MAX) {
@@ -196,7 +210,8 @@ __device__ inline int32_t poisson(double mean, double u)
         int32_t n = 0;
         while (u > F && n < 1000) {
             n = n + 1;
-            p = p * (mean / (double)n);
+            if (n <= POISSON_RCP_N) p = p * (mean * rcp[n]);
+            else p = p * (mean / (double)n);
             F = F + p;
         }
         return n;
@@ -207,6 +222,7 @@ __device__ inline int32_t poisson(double mean, double u)
     if (x > (double)NSAMP_MAX) return NSAMP_MAX;
     return (int32_t)x;
 }
+__device__ inline int32_t poisson(double mean, double u) { return poisson(mean, u, g_poisson_rcp); }
 
 // ------------------------------------------------------ coagulation kernels
 //

@@ -929,6 +929,7 @@ constexpr int SEQ_ENV = 7;     // air properties kept per cell
 __host__ __device__ inline size_t seq_lds_bytes(int B, int C)
 {
     size_t o = ((size_t)(B + 1) * sizeof(double) + 15) & ~(size_t)15; // sort-grid edges
+    o += sizeof(double) * (POISSON_RCP_N + 2);                        // 1/n of the Poisson walk
     o += sizeof(double) * (SEQ_ENV + (size_t)C) * 64;                 // air properties, weights
     o += sizeof(uint64_t) * 2 * (size_t)C * 64;                       // non-empty bins
     o += sizeof(uint32_t) * (size_t)C * SEQ_W * 64;                   // count | offset << 16
@@ -942,7 +943,7 @@ __host__ __device__ inline size_t seq_lds_bytes(int B, int C)
 __device__ unsigned long long g_seq_stamps[12];
 
 template <bool STAMPS>
-__global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype, double del_t,
+__global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, double del_t,
                                                  uint64_t seed, uint32_t step, uint16_t *ovf_mem)
 {
     uint64_t t_last = 0, t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -964,13 +965,15 @@ __global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype, d
     const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
 
     double *edge = (double *)smem;
-    double *envs = (double *)(smem + (((size_t)(B + 1) * sizeof(double) + 15) & ~(size_t)15));
+    double *rcp = (double *)(smem + (((size_t)(B + 1) * sizeof(double) + 15) & ~(size_t)15));
+    double *envs = rcp + (POISSON_RCP_N + 2);
     double *magl = envs + SEQ_ENV * 64;                   // [C][64] weight magnitudes
     uint64_t *mask = (uint64_t *)(magl + (size_t)C * 64); // [C*2][64]
     uint32_t *ent = (uint32_t *)(mask + 2 * (size_t)C * 64); // [C*SEQ_W][64]
 #define MASK(j) mask[(j) * 64 + lane]
 
     for (int j = lane; j <= B; j += 64) edge[j] = st.v_edge[j];
+    for (int j = lane; j <= POISSON_RCP_N; j += 64) rcp[j] = g_poisson_rcp[j];
 
     uint32_t *perm = st.perm + (int64_t)c * st.pcap;
     double2 *vm = st.vm + cb;  // (cached total volume, cached mass)
@@ -1115,7 +1118,7 @@ __global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype, d
         k_max = km * fmax;
         const double n_possible = (c1 == c2 && b1 == b2) ? nA * (nA - 1.0) / 2.0 : nA * nB;
         const double mean = k_max * del_t * n_possible;
-        ns_rem = (uint32_t)poisson(mean, u);
+        ns_rem = (st.dbg & 1) ? (uint32_t)(u * 4.0 * mean > 0.9) : (uint32_t)poisson(mean, u, rcp);
         tot_samp += ns_rem;
         s = 0;
     };
@@ -1180,7 +1183,8 @@ __global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype, d
             found = draw_find(dA, dB, km);
             if (found) {
                 uint32_t w[4];
-                rng_block(seed, cell_id, step,
+                if (st.dbg & 2) { w[0] = (uint32_t)(c1 * B + b1) * 2654435761u ^ step; w[1] = (uint32_t)(c2 * B + b2) * 40503u ^ cell_id; }
+                else rng_block(seed, cell_id, step,
                           ((uint32_t)(c1 * B + b1) << 16) | (uint32_t)(c2 * B + b2), SITE_POISSON, 0, w);
                 u_d = u53(w[0], w[1]);
             }
@@ -1191,7 +1195,9 @@ __global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype, d
         double v1 = 0, v2 = 0, m1 = 0, m2 = 0;
         double vol1 = 0, vol2 = 0, lct1 = 0, lct2 = 0, gct1 = 0, gct2 = 0; // first species, times
         int32_t no1 = 0, no2 = 0;               // first source
-        if (evalid) {
+        if (evalid && (st.dbg & 16)) {
+            v1 = 1e-21 * (double)(p1 + 1); v2 = 2e-21 * (double)(p2 + 1); m1 = v1 * 1770.0; m2 = v2 * 1770.0;
+        } else if (evalid) {
             const double2 a1 = vm[p1], a2 = vm[p2];
             v1 = a1.x; m1 = a1.y; v2 = a2.x; m2 = a2.y;
             // (with one species the volume of that species IS the cached total: both are sums
@@ -1211,7 +1217,8 @@ __global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype, d
                 found2 = draw_find(dA, dB, km);
                 if (found2) {
                     uint32_t w[4];
-                    rng_block(seed, cell_id, step,
+                    if (st.dbg & 2) { w[0] = (uint32_t)(c1 * B + b1) * 2654435761u ^ step; w[1] = (uint32_t)(c2 * B + b2) * 40503u ^ cell_id; }
+                else rng_block(seed, cell_id, step,
                               ((uint32_t)(c1 * B + b1) << 16) | (uint32_t)(c2 * B + b2), SITE_POISSON, 0, w);
                     u_d = u53(w[0], w[1]);
                 }
@@ -1226,9 +1233,14 @@ __global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype, d
             env.c_diff = envs[2 * 64 + lane]; env.c_speed = envs[3 * 64 + lane];
             env.c_inv_speed = envs[4 * 64 + lane]; env.c_fall = envs[5 * 64 + lane];
             env.rhoair = envs[6 * 64 + lane];
-            const PartProps qa = props_for(ktype, v1, m1, env);
-            const PartProps qb = props_for(ktype, v2, m2, env);
-            const double k = kernel_pair(ktype, v1, v2, qa, qb, kp);
+            double k;
+            if (st.dbg & 4) {
+                k = k_max * 0.78 / factor + (v1 + m2) * 1e-300;
+            } else {
+                const PartProps qa = props_for(ktype, v1, m1, env);
+                const PartProps qb = props_for(ktype, v2, m2, env);
+                k = kernel_pair(ktype, v1, v2, qa, qb, kp);
+            }
             const double kf = k * factor;
             if (kf > k_max) status |= ST_KMAX_EXCEEDED;
             acc = u_acc * k_max < kf;
