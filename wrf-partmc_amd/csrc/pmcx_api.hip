@@ -298,9 +298,9 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
     A_(st.n_part, nc); A_(st.n_hi, nc); A_(st.next_id, nc);
     A_(st.vol, nc * cfg->n_spec * cap);
     A_(st.vm, nc * cap);
-    A_(st.wclass, nc * cap); A_(st.id, nc * cap);
-    A_(st.ct, nc * cap);
-    A_(st.n_orig, nc * (size_t)cfg->n_source * cap);
+    A_(st.wclass, nc * cap);
+    A_(st.meta, nc * cap);
+    A_(st.n_orig, nc * (size_t)(cfg->n_source > 1 ? cfg->n_source - 1 : 0) * cap + 1);
     A_(st.perm, nc * (size_t)st.pcap);
     A_(st.gcnt, nc * G); A_(st.goff, nc * (G + 1)); A_(st.sort_valid, nc);
     A_(st.seq_ovf, nc * (2 * G + 2 * (size_t)cfg->max_appends));
@@ -527,25 +527,30 @@ int pmcx_upload_cells(pmcx_ctx *ctx, int32_t cell_first, int32_t n_up, const int
         }
         if (id) {
             const double *s = (const double *)h2d(id, sizeof(int64_t) * (size_t)nt);
-            HIP_TRY(ctx, launch_scatter_f64(s, (double *)st.id + c0 * cap, ctx->d_offsets, n_up,
-                                            cf.cap, (int64_t)cap, nt, 1, (int64_t)cap, ctx->stream));
+            HIP_TRY(ctx, launch_scatter_f64(s, (double *)&st.meta[c0 * cap].id, ctx->d_offsets, n_up,
+                                            cf.cap, (int64_t)cap, nt, 1, (int64_t)cap, ctx->stream, 4));
         }
         if (least_ct) {
             const double *s = (const double *)h2d(least_ct, sizeof(double) * (size_t)nt);
-            HIP_TRY(ctx, launch_scatter_f64(s, &st.ct[c0 * cap].x, ctx->d_offsets, n_up, cf.cap,
-                                            (int64_t)cap, nt, 1, (int64_t)cap, ctx->stream, 2));
+            HIP_TRY(ctx, launch_scatter_f64(s, &st.meta[c0 * cap].lct, ctx->d_offsets, n_up, cf.cap,
+                                            (int64_t)cap, nt, 1, (int64_t)cap, ctx->stream, 4));
         }
         if (greatest_ct) {
             const double *s = (const double *)h2d(greatest_ct, sizeof(double) * (size_t)nt);
-            HIP_TRY(ctx, launch_scatter_f64(s, &st.ct[c0 * cap].y, ctx->d_offsets, n_up, cf.cap,
-                                            (int64_t)cap, nt, 1, (int64_t)cap, ctx->stream, 2));
+            HIP_TRY(ctx, launch_scatter_f64(s, &st.meta[c0 * cap].gct, ctx->d_offsets, n_up, cf.cap,
+                                            (int64_t)cap, nt, 1, (int64_t)cap, ctx->stream, 4));
         }
         if (n_orig && cf.n_source > 0) {
             const int32_t *s =
                 (const int32_t *)h2d(n_orig, sizeof(int32_t) * cf.n_source * (size_t)nt);
-            HIP_TRY(ctx, launch_scatter_i32(s, st.n_orig + c0 * cf.n_source * cap, ctx->d_offsets,
-                                            n_up, cf.cap, (int64_t)cf.n_source * cap, nt,
-                                            cf.n_source, (int64_t)cap, ctx->stream));
+            // source 0 lives in the metadata record (8 int32 per record), the rest in planes
+            HIP_TRY(ctx, launch_scatter_i32(s, &st.meta[c0 * cap].n_orig0, ctx->d_offsets, n_up,
+                                            cf.cap, (int64_t)cap, nt, 1, (int64_t)cap, ctx->stream, 8));
+            if (cf.n_source > 1)
+                HIP_TRY(ctx, launch_scatter_i32(s + nt, st.n_orig + c0 * (cf.n_source - 1) * cap,
+                                                ctx->d_offsets, n_up, cf.cap,
+                                                (int64_t)(cf.n_source - 1) * cap, nt,
+                                                cf.n_source - 1, (int64_t)cap, ctx->stream));
         }
     }
     HIP_TRY(ctx, launch_set_n_part(st.n_part + c0, st.n_hi + c0, ctx->d_offsets, n_up, ctx->stream));
@@ -604,9 +609,9 @@ int pmcx_download_cells(pmcx_ctx *ctx, int32_t cell_first, int32_t n_dn, const i
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         return PMCX_OK;
     };
-    if (id && (rc = one_f64((double *)id, (const double *)st.id))) return rc;
-    if (least_ct && (rc = one_f64(least_ct, &st.ct[0].x, 2))) return rc;
-    if (greatest_ct && (rc = one_f64(greatest_ct, &st.ct[0].y, 2))) return rc;
+    if (id && (rc = one_f64((double *)id, (const double *)&st.meta[0].id, 4))) return rc;
+    if (least_ct && (rc = one_f64(least_ct, &st.meta[0].lct, 4))) return rc;
+    if (greatest_ct && (rc = one_f64(greatest_ct, &st.meta[0].gct, 4))) return rc;
     if (wclass) {
         HIP_TRY(ctx, launch_gather_i32((int32_t *)ctx->stage, st.wclass + c0 * cap, ctx->d_offsets,
                                        n_dn, (int64_t)cap, nt, 1, (int64_t)cap, ctx->stream));
@@ -615,9 +620,14 @@ int pmcx_download_cells(pmcx_ctx *ctx, int32_t cell_first, int32_t n_dn, const i
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     if (n_orig && cf.n_source > 0) {
-        HIP_TRY(ctx, launch_gather_i32((int32_t *)ctx->stage, st.n_orig + c0 * cf.n_source * cap,
-                                       ctx->d_offsets, n_dn, (int64_t)cf.n_source * cap, nt,
-                                       cf.n_source, (int64_t)cap, ctx->stream));
+        HIP_TRY(ctx, launch_gather_i32((int32_t *)ctx->stage, &st.meta[c0 * cap].n_orig0,
+                                       ctx->d_offsets, n_dn, (int64_t)cap, nt, 1, (int64_t)cap,
+                                       ctx->stream, 8));
+        if (cf.n_source > 1)
+            HIP_TRY(ctx, launch_gather_i32((int32_t *)ctx->stage + nt,
+                                           st.n_orig + c0 * (cf.n_source - 1) * cap, ctx->d_offsets,
+                                           n_dn, (int64_t)(cf.n_source - 1) * cap, nt,
+                                           cf.n_source - 1, (int64_t)cap, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(n_orig, ctx->stage, sizeof(int32_t) * cf.n_source * (size_t)nt,
                                     hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

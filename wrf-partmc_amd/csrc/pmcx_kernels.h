@@ -14,6 +14,15 @@ enum : int {
     ST_CAP_OVERFLOW = 16
 };
 
+// Per-particle metadata that only coagulation events and whole-particle moves touch, kept
+// together so that an event costs one memory request per particle for all of it.
+struct __attribute__((aligned(32))) Meta {
+    double lct, gct;   // least / greatest create time
+    int64_t id;
+    int32_t n_orig0;   // constituents from source 0 (the other sources: DeviceState::n_orig)
+    int32_t pad;
+};
+
 // Plain view of everything a kernel needs; passed by value.
 struct DeviceState {
     int32_t n_cells, cap, n_spec, n_class, n_source, n_bin, n_dbin, i_water;
@@ -45,9 +54,8 @@ struct DeviceState {
     double *vol;     // [n_cells][n_spec][cap]
     double2 *vm;     // [n_cells][cap] (cached total volume, cached mass): one request per particle
     int32_t *wclass; // [n_cells][cap]
-    int64_t *id;     // [n_cells][cap]
-    double2 *ct;     // [n_cells][cap] (least, greatest create time)
-    int32_t *n_orig; // [n_cells][n_source][cap]
+    Meta *meta;      // [n_cells][cap] create times, id, source-0 count
+    int32_t *n_orig; // [n_cells][n_source - 1][cap] sources 1.. (source 0 is in meta)
     // scratch / outputs of the coagulation step
     // aero_sorted, kept between calls while sort_valid (aero_state%valid_sort)
     uint32_t *perm;  // [n_cells][pcap] slot lists, group after group, room behind each
@@ -75,13 +83,13 @@ hipError_t launch_scatter_f64(const double *src, double *dst, const int64_t *par
                               int64_t dst_row_stride, hipStream_t s, int elem_stride = 1);
 hipError_t launch_scatter_i32(const int32_t *src, int32_t *dst, const int64_t *part_offset,
                               int n_up, int cap, int64_t dst_cell_stride, int64_t src_row_stride,
-                              int n_rows, int64_t dst_row_stride, hipStream_t s);
+                              int n_rows, int64_t dst_row_stride, hipStream_t s, int elem_stride = 1);
 hipError_t launch_gather_f64(double *dst, const double *src, const int64_t *part_offset, int n_dn,
                              int64_t src_cell_stride, int64_t dst_row_stride, int n_rows,
                              int64_t src_row_stride, hipStream_t s, int elem_stride = 1);
 hipError_t launch_gather_i32(int32_t *dst, const int32_t *src, const int64_t *part_offset,
                              int n_dn, int64_t src_cell_stride, int64_t dst_row_stride, int n_rows,
-                             int64_t src_row_stride, hipStream_t s);
+                             int64_t src_row_stride, hipStream_t s, int elem_stride = 1);
 hipError_t launch_set_n_part(int32_t *n_part, int32_t *n_hi, const int64_t *part_offset, int n_up,
                              hipStream_t s);
 hipError_t launch_compact(const DeviceState &st, int cell_first, int n_cells_do, int num, int den,

@@ -10,8 +10,9 @@
 //   vol   [n_cells][n_spec][cap] f64   particle%vol(:)
 //   vm    [n_cells][cap] 2 x f64       (cached sum_s vol, cached sum_s density_s*vol):
 //                                      interleaved, a pair evaluation is one request per particle
-//   wclass[n_cells][cap] i32, id [..] i64, ct [..] 2 x f64 (least, greatest create time),
-//   n_orig[n_cells][n_source][cap] i32
+//   wclass[n_cells][cap] i32
+//   meta  [n_cells][cap] 32 B          {least, greatest create time, id, source-0 count}
+//   n_orig[n_cells][n_source-1][cap] i32  constituents from sources 1..
 // Kernels:
 //   k_bin_sort     one 256-thread workgroup per cell; stable counting sort of
 //                  the slots by (class, bin) -> perm, gcnt, goff.  Streams
@@ -60,6 +61,15 @@ __device__ __forceinline__ uint32_t ld_u32(const uint32_t *p)
 __device__ __forceinline__ void st_u32(uint32_t *p, uint32_t v)
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// particles of source s among the constituents of slot i: the first source sits in the
+// particle's metadata record (it is read and written with the create times), the others in
+// their own planes
+__device__ __forceinline__ int32_t &norig(const DeviceState &st, int64_t cb, int s, int64_t i)
+{
+    if (s == 0) return st.meta[cb + i].n_orig0;
+    return st.n_orig[cb * (st.n_source - 1) + (int64_t)(s - 1) * st.cap + i];
 }
 
 // tombstone: the slot stays allocated, every consumer skips it
@@ -122,14 +132,14 @@ __global__ void k_scatter_f64(const double *__restrict__ src, double *__restrict
 __global__ void k_scatter_i32(const int32_t *__restrict__ src, int32_t *__restrict__ dst,
                               const int64_t *__restrict__ part_offset, int n_up, int cap,
                               int64_t dst_cell_stride, int64_t src_row_stride, int n_rows,
-                              int64_t dst_row_stride)
+                              int64_t dst_row_stride, int es)
 {
     const int k = blockIdx.y;
     const int64_t o0 = part_offset[k], n = part_offset[k + 1] - o0;
     for (int r = 0; r < n_rows; r++)
         for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
              i += (int64_t)gridDim.x * blockDim.x)
-            dst[(int64_t)k * dst_cell_stride + r * dst_row_stride + i] =
+            dst[((int64_t)k * dst_cell_stride + r * dst_row_stride + i) * es] =
                 src[r * src_row_stride + o0 + i];
 }
 __global__ void k_gather_f64(double *__restrict__ dst, const double *__restrict__ src,
@@ -146,7 +156,7 @@ __global__ void k_gather_f64(double *__restrict__ dst, const double *__restrict_
 }
 __global__ void k_gather_i32(int32_t *__restrict__ dst, const int32_t *__restrict__ src,
                              const int64_t *__restrict__ part_offset, int64_t src_cell_stride,
-                             int64_t dst_row_stride, int n_rows, int64_t src_row_stride)
+                             int64_t dst_row_stride, int n_rows, int64_t src_row_stride, int es)
 {
     const int k = blockIdx.y;
     const int64_t o0 = part_offset[k], n = part_offset[k + 1] - o0;
@@ -154,7 +164,7 @@ __global__ void k_gather_i32(int32_t *__restrict__ dst, const int32_t *__restric
         for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
              i += (int64_t)gridDim.x * blockDim.x)
             dst[r * dst_row_stride + o0 + i] =
-                src[(int64_t)k * src_cell_stride + r * src_row_stride + i];
+                src[((int64_t)k * src_cell_stride + r * src_row_stride + i) * es];
 }
 __global__ void k_set_n_part(int32_t *n_part, int32_t *n_hi, const int64_t *part_offset, int n_up)
 {
@@ -823,8 +833,8 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
         }
         double lo_n = 0, lo_o = 0, go_n = 0, go_o = 0;
         if (lead) {
-            lo_n = ld_f64(&st.ct[cb + pn].x); lo_o = ld_f64(&st.ct[cb + po].x);
-            go_n = ld_f64(&st.ct[cb + pn].y); go_o = ld_f64(&st.ct[cb + po].y);
+            lo_n = ld_f64(&st.meta[cb + pn].lct); lo_o = ld_f64(&st.meta[cb + po].lct);
+            go_n = ld_f64(&st.meta[cb + pn].gct); go_o = ld_f64(&st.meta[cb + po].gct);
         }
         if (rem_o) {
             const int last = list_remove(X, g_o, io, B, lead);
@@ -838,8 +848,8 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
         }
         if (lead) {
             st_f64(&X.vm[pn].x, vn); st_f64(&X.vm[pn].y, mn);
-            if (lo_o < lo_n) st_f64(&st.ct[cb + pn].x, lo_o);
-            if (go_o > go_n) st_f64(&st.ct[cb + pn].y, go_o);
+            if (lo_o < lo_n) st_f64(&st.meta[cb + pn].lct, lo_o);
+            if (go_o > go_n) st_f64(&st.meta[cb + pn].gct, go_o);
             if (C > 1) st_u32((uint32_t *)&st.wclass[cb + pn], (uint32_t)cc);
         }
         {
@@ -853,8 +863,8 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
                 st_f64(a, ld_f64(a) + ld_f64(&st.vol[cb * S + (int64_t)sp * st.cap + po]));
             }
             for (int sp = gl; sp < NS; sp += L) {
-                uint32_t *a = (uint32_t *)&st.n_orig[cb * NS + (int64_t)sp * st.cap + pn];
-                st_u32(a, ld_u32(a) + ld_u32((uint32_t *)&st.n_orig[cb * NS + (int64_t)sp * st.cap + po]));
+                uint32_t *a = (uint32_t *)&norig(st, cb, sp, pn);
+                st_u32(a, ld_u32(a) + ld_u32((uint32_t *)&norig(st, cb, sp, po)));
             }
         }
         if (rem_o) {
@@ -977,7 +987,7 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
 
     uint32_t *perm = st.perm + (int64_t)c * st.pcap;
     double2 *vm = st.vm + cb;  // (cached total volume, cached mass)
-    double2 *ct = st.ct + cb;  // (least, greatest create time)
+    Meta *meta = st.meta + cb; // create times, id, first source count
     int32_t *gcnt_g = st.gcnt + (int64_t)c * G;
     const int32_t *goff_g = st.goff + (int64_t)c * (G + 1);
     SeqOverflow O;
@@ -1203,9 +1213,9 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
             // (with one species the volume of that species IS the cached total: both are sums
             // of the same terms)
             if (S > 1) { vol1 = st.vol[cb * S + p1]; vol2 = st.vol[cb * S + p2]; }
-            const double2 t1 = ct[p1], t2 = ct[p2];
-            lct1 = t1.x; gct1 = t1.y; lct2 = t2.x; gct2 = t2.y;
-            if (NS > 0) { no1 = st.n_orig[cb * NS + p1]; no2 = st.n_orig[cb * NS + p2]; }
+            const Meta t1 = meta[p1], t2 = meta[p2];
+            lct1 = t1.lct; gct1 = t1.gct; lct2 = t2.lct; gct2 = t2.gct;
+            no1 = t1.n_orig0; no2 = t2.n_orig0;
         }
 
         // ---- (4) drawing lanes: first count; still empty-handed: second slot ----
@@ -1340,17 +1350,16 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
                         if (s0 + k < S)
                             st.vol[cb * S + (int64_t)(s0 + k) * st.cap + pn] = a[k] + b[k];
                 }
-                if (NS > 0)
-                    st.n_orig[cb * NS + pn] = (int32_t)((uint32_t)no1 + (uint32_t)no2);
                 for (int sp = 1; sp < NS; sp++) {
-                    int32_t *a = &st.n_orig[cb * NS + (int64_t)sp * st.cap + pn];
-                    *a = (int32_t)((uint32_t)*a + (uint32_t)st.n_orig[cb * NS + (int64_t)sp * st.cap + po]);
+                    int32_t *a = &norig(st, cb, sp, pn);
+                    *a = (int32_t)((uint32_t)*a + (uint32_t)norig(st, cb, sp, po));
                 }
-                {
+                {   // create times and first source count share the particle's metadata record
                     const double lo_n = pn_is_1 ? lct1 : lct2, lo_o = pn_is_1 ? lct2 : lct1;
                     const double go_n = pn_is_1 ? gct1 : gct2, go_o = pn_is_1 ? gct2 : gct1;
-                    if (lo_o < lo_n || go_o > go_n)
-                        ct[pn] = make_double2(lo_o < lo_n ? lo_o : lo_n, go_o > go_n ? go_o : go_n);
+                    if (lo_o < lo_n) meta[pn].lct = lo_o;
+                    if (go_o > go_n) meta[pn].gct = go_o;
+                    if (NS > 0) meta[pn].n_orig0 = (int32_t)((uint32_t)no1 + (uint32_t)no2);
                 }
                 if (C > 1) st.wclass[cb + pn] = cc;
                 if (rem_o) { vm[po].x = -1.0; st.wclass[cb + po] = -1; n_dead++; } // tombstone
@@ -1411,14 +1420,14 @@ __device__ __forceinline__ void move_particle(const DeviceState &st, int64_t cb,
         st.vol[cb * st.n_spec + (int64_t)s * st.cap + dst] =
             st.vol[cb * st.n_spec + (int64_t)s * st.cap + src];
     for (int s = 0; s < st.n_source; s++)
-        st.n_orig[cb * st.n_source + (int64_t)s * st.cap + dst] =
-            st.n_orig[cb * st.n_source + (int64_t)s * st.cap + src];
+        norig(st, cb, s, dst) =
+            norig(st, cb, s, src);
     st.vm[cb + dst].x = st.vm[cb + src].x;
     st.vm[cb + dst].y = st.vm[cb + src].y;
     st.wclass[cb + dst] = st.wclass[cb + src];
-    st.id[cb + dst] = st.id[cb + src];
-    st.ct[cb + dst].x = st.ct[cb + src].x;
-    st.ct[cb + dst].y = st.ct[cb + src].y;
+    st.meta[cb + dst].id = st.meta[cb + src].id;
+    st.meta[cb + dst].lct = st.meta[cb + src].lct;
+    st.meta[cb + dst].gct = st.meta[cb + src].gct;
 }
 
 // Stable compaction of one cell by one wavefront: 64 slots at a time, every
@@ -1451,16 +1460,16 @@ __device__ void compact_wave(const DeviceState &st, int c, int lane, uint32_t *c
         int32_t wc = 0;
         if (mv) {
             a0 = ld_f64(&st.vm[cb + i].x); a1 = ld_f64(&st.vm[cb + i].y);
-            a2 = ld_f64(&st.ct[cb + i].x); a3 = ld_f64(&st.ct[cb + i].y);
-            idv = (int64_t)d2u(ld_f64((const double *)&st.id[cb + i]));
+            a2 = ld_f64(&st.meta[cb + i].lct); a3 = ld_f64(&st.meta[cb + i].gct);
+            idv = (int64_t)d2u(ld_f64((const double *)&st.meta[cb + i].id));
             wc = (int32_t)ld_u32((const uint32_t *)&st.wclass[cb + i]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
         if (mv) {
             st_f64(&st.vm[cb + dst].x, a0); st_f64(&st.vm[cb + dst].y, a1);
-            st_f64(&st.ct[cb + dst].x, a2); st_f64(&st.ct[cb + dst].y, a3);
-            st_f64((double *)&st.id[cb + dst], u2d((uint64_t)idv));
+            st_f64(&st.meta[cb + dst].lct, a2); st_f64(&st.meta[cb + dst].gct, a3);
+            st_f64((double *)&st.meta[cb + dst].id, u2d((uint64_t)idv));
             st_u32((uint32_t *)&st.wclass[cb + dst], (uint32_t)wc);
         }
         for (int s0 = 0; s0 < S; s0 += 4) {
@@ -1476,10 +1485,10 @@ __device__ void compact_wave(const DeviceState &st, int c, int lane, uint32_t *c
         }
         for (int s = 0; s < NS; s++) {
             uint32_t x = 0;
-            if (mv) x = ld_u32((const uint32_t *)&st.n_orig[cb * NS + (int64_t)s * st.cap + i]);
+            if (mv) x = ld_u32((const uint32_t *)&norig(st, cb, s, i));
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             wave_sync();
-            if (mv) st_u32((uint32_t *)&st.n_orig[cb * NS + (int64_t)s * st.cap + dst], x);
+            if (mv) st_u32((uint32_t *)&norig(st, cb, s, dst), x);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
@@ -1569,7 +1578,7 @@ __global__ __launch_bounds__(64) void k_rebalance(DeviceState st, int allow_doub
                     const uint32_t k = base + (uint32_t)__popcll(m & lt);
                     if (is) {
                         move_particle(st, cb, c, n_hi + (int)k, i);
-                        st.id[cb + n_hi + k] = nid + (int64_t)k;
+                        st.meta[cb + n_hi + k].id = nid + (int64_t)k;
                     }
                     base += (uint32_t)__popcll(m);
                 }
@@ -1735,7 +1744,7 @@ __global__ __launch_bounds__(256) void k_diagnostics_ext(DeviceState st, double 
             if (s != st.i_water) { vdry = vdry + v; mdry = mdry + st.density[s] * v; }
         }
         for (int k = 0; k < NS; k++)
-            if (st.n_orig[cb * NS + (int64_t)k * st.cap + i] > 0) atomicAdd(&acc[S + k], nc);
+            if (norig(st, cb, k, i) > 0) atomicAdd(&acc[S + k], nc);
         const double diam = 2.0 * det_cbrt(vdry * (0.75 / PI));
         if (diam < 1e-6) atomicAdd(&acc[S + NS], nc * mdry);
         if (diam < 2.5e-6) atomicAdd(&acc[S + NS + 1], nc * mdry);
@@ -1795,13 +1804,13 @@ __device__ int add_dist_sample(const DeviceState &st, int c, const AeroDistDev &
                 ms = ms + st.density[s] * vs;
             }
             for (int s = 0; s < st.n_source; s++)
-                st.n_orig[cb * st.n_source + (int64_t)s * st.cap + i] = (s == d.mode_source[m]) ? 1 : 0;
+                norig(st, cb, s, i) = (s == d.mode_source[m]) ? 1 : 0;
             st.vm[cb + i].x = vt;
             st.vm[cb + i].y = ms;
             st.wclass[cb + i] = cl;
-            st.id[cb + i] = nid + k;
-            st.ct[cb + i].x = create_time;
-            st.ct[cb + i].y = create_time;
+            st.meta[cb + i].id = nid + k;
+            st.meta[cb + i].lct = create_time;
+            st.meta[cb + i].gct = create_time;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
@@ -2051,13 +2060,13 @@ __global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid t
                 for (int sp = 0; sp < S; sp++)
                     st.vol[cb * S + (int64_t)sp * st.cap + dst] = st.vol[sb * S + (int64_t)sp * st.cap + from];
                 for (int sp = 0; sp < NS; sp++)
-                    st.n_orig[cb * NS + (int64_t)sp * st.cap + dst] = st.n_orig[sb * NS + (int64_t)sp * st.cap + from];
+                    norig(st, cb, sp, dst) = norig(st, sb, sp, from);
                 st.vm[cb + dst].x = st.vm[sb + from].x;
                 st.vm[cb + dst].y = st.vm[sb + from].y;
                 st.wclass[cb + dst] = st.wclass[sb + from];
-                st.ct[cb + dst].x = st.ct[sb + from].x;
-                st.ct[cb + dst].y = st.ct[sb + from].y;
-                st.id[cb + dst] = (g == copies - 1) ? st.id[sb + from] : id0 + g;
+                st.meta[cb + dst].lct = st.meta[sb + from].lct;
+                st.meta[cb + dst].gct = st.meta[sb + from].gct;
+                st.meta[cb + dst].id = (g == copies - 1) ? st.meta[sb + from].id : id0 + g;
             }
             at += (int)__shfl(inc, 63, 64);
             nid += (int64_t)__shfl(inc_new, 63, 64);
@@ -2177,13 +2186,13 @@ __global__ void k_generate(DeviceState st, GenSpecDev g, int n, uint64_t seed, d
             ms = ms + st.density[s] * vs;
         }
         for (int s = 0; s < st.n_source; s++)
-            st.n_orig[cb * st.n_source + (int64_t)s * st.cap + i] = (s == g.mode_source[mode]) ? 1 : 0;
+            norig(st, cb, s, i) = (s == g.mode_source[mode]) ? 1 : 0;
         st.vm[cb + i].x = vt;
         st.vm[cb + i].y = ms;
         st.wclass[cb + i] = g.mode_class[mode];
-        st.id[cb + i] = ((int64_t)cell_id << 32) + i;
-        st.ct[cb + i].x = create_time;
-        st.ct[cb + i].y = create_time;
+        st.meta[cb + i].id = ((int64_t)cell_id << 32) + i;
+        st.meta[cb + i].lct = create_time;
+        st.meta[cb + i].gct = create_time;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { st.n_part[c] = n; st.n_hi[c] = n; }
 }
@@ -2335,10 +2344,11 @@ hipError_t launch_scatter_f64(const double *src, double *dst, const int64_t *par
 }
 hipError_t launch_scatter_i32(const int32_t *src, int32_t *dst, const int64_t *part_offset,
                               int n_up, int cap, int64_t dst_cell_stride, int64_t src_row_stride,
-                              int n_rows, int64_t dst_row_stride, hipStream_t s)
+                              int n_rows, int64_t dst_row_stride, hipStream_t s, int elem_stride)
 {
     hipLaunchKernelGGL(k_scatter_i32, grid2(cap, n_up), dim3(256), 0, s, src, dst, part_offset,
-                       n_up, cap, dst_cell_stride, src_row_stride, n_rows, dst_row_stride);
+                       n_up, cap, dst_cell_stride, src_row_stride, n_rows, dst_row_stride,
+                       elem_stride);
     return hipGetLastError();
 }
 hipError_t launch_gather_f64(double *dst, const double *src, const int64_t *part_offset, int n_dn,
@@ -2352,10 +2362,11 @@ hipError_t launch_gather_f64(double *dst, const double *src, const int64_t *part
 }
 hipError_t launch_gather_i32(int32_t *dst, const int32_t *src, const int64_t *part_offset,
                              int n_dn, int64_t src_cell_stride, int64_t dst_row_stride, int n_rows,
-                             int64_t src_row_stride, hipStream_t s)
+                             int64_t src_row_stride, hipStream_t s, int elem_stride)
 {
     hipLaunchKernelGGL(k_gather_i32, grid2(src_cell_stride, n_dn), dim3(256), 0, s, dst, src,
-                       part_offset, src_cell_stride, dst_row_stride, n_rows, src_row_stride);
+                       part_offset, src_cell_stride, dst_row_stride, n_rows, src_row_stride,
+                       elem_stride);
     return hipGetLastError();
 }
 hipError_t launch_set_n_part(int32_t *n_part, int32_t *n_hi, const int64_t *part_offset, int n_up,
