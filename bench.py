@@ -29,6 +29,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+# Random-gather ceiling of the chip, measured with scripts/gather_probe.hip (profiles/
+# r1f_gather_probe.txt): independent 8..16-byte loads at random addresses of a 1..160 GiB buffer
+# complete at 53e9 per second whatever the footprint or the loads in flight per lane; the
+# memory side moves 64 B for each (FETCH_SIZE), i.e. 3.4 TB/s of its 8 TB/s.
+GATHER_PEAK_PER_S = 53e9
 
 KERNELS = ("bin_sort", "coag_sample", "compact", "rebalance", "condense")
 
@@ -402,6 +407,16 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms},
         }
+        if traffic:
+            # the sampler reads single words of randomly picked particles: what bounds it is
+            # the rate of 64-byte memory requests, not bytes of payload
+            req_s = traffic / 64.0 / (avg_ms * 1e-3)
+            line["gather_roofline"] = {
+                "kernel": dom, "unit": "64-B requests/s", "achieved": req_s,
+                "peak": GATHER_PEAK_PER_S, "frac": req_s / GATHER_PEAK_PER_S,
+                "requests_per_launch": traffic / 64.0,
+                "source": "FETCH_SIZE + WRITE_SIZE of profiles/pmc_traffic.json over 64 B; "
+                          "peak from scripts/gather_probe.hip"}
         # secondary rooflines of the other kernels (same accounting)
         others = {}
         for k in KERNELS:

@@ -19,10 +19,11 @@ for k in sorted(out):
 # FETCH_SIZE/WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE reports half the bytes of a
 # coalesced streaming read (MI355X_MICROARCH.md, HBM): k_bin_sort's read side is such a
 # stream and is calibrated here (algorithmic 8 B/particle read once == 2 x FETCH_SIZE);
-# the sampler's 8-byte gathers are an uncalibrated access width, so its figure uses the
-# raw counter and is a lower bound.
+# the sampler's gathers (4 to 16 bytes per lane at independent addresses) are calibrated by
+# scripts/gather_probe.hip: FETCH_SIZE counts 64 B per such load, used raw.
 traffic = {}
 names = {"pmcx::k_bin_sort": ("bin_sort", 2.0), "pmcx::k_coag_sample<8>": ("coag_sample", 1.0),
+         "pmcx::k_coag_seq<false>": ("coag_sample", 1.0),
          "pmcx::k_rebalance": ("rebalance", 1.0), "pmcx::k_compact": ("compact", 1.0)}
 for k, (short, f) in names.items():
     if k in out and "FETCH_SIZE" in out[k] and "WRITE_SIZE" in out[k]:
