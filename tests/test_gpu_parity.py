@@ -13,6 +13,18 @@ pytestmark = pytest.mark.gpu
 K_BROWN, K_SEDI, K_ADD, K_CONST, K_ZERO, K_BS = 4, 1, 2, 3, 5, 101
 
 
+@pytest.fixture(autouse=True, params=["dispatch", "lane-per-cell"])
+def sampler_variant(request, monkeypatch):
+    """Every test of this module runs twice: with the library's own choice of sampler (the
+    lanes-per-cell kernels at these cell counts) and with the lane-per-cell kernel forced
+    (the one the full-size domain runs), so that both are held to the oracle."""
+    if request.param == "lane-per-cell":
+        monkeypatch.setenv("PMCX_SAMPLER_LANES", "1")
+    else:
+        monkeypatch.delenv("PMCX_SAMPLER_LANES", raising=False)
+    return request.param
+
+
 def test_device_philox_kat(wp, oracle):
     with wp.CellBlock(1, 64, 1) as blk:
         # Random123 known-answer vectors for philox4x32-10
@@ -316,6 +328,48 @@ def test_empty_ragged_and_tiny_cells(wp, oracle):
     assert ns[0] == 0 and nc[0] == 0 and ns[1] == 0      # empty and single-particle cells
     tn, tm, nd, md = blk.diagnostics()
     assert tn[0] == 0 and tm[0] == 0 and not nd[0].any()
+    blk.close()
+
+
+def test_wide_distribution_beyond_lds_window(wp, oracle, sampler_variant):
+    """Populations spanning more bins than the lane-per-cell sampler keeps in LDS (32 above
+    the first non-empty one): groups beyond the window are served from gcnt/goff in HBM."""
+    n_cells, n_part = 5, 3000
+    blk = wp.CellBlock(n_cells, 4096, 1, n_source=1, max_events=4096, max_appends=512)
+    dens = np.array([1800.0])
+    blk.set_aero_data(dens)
+    temp = np.linspace(295, 250, n_cells); pres = np.linspace(1e5, 5e4, n_cells)
+    blk.set_env(temp, pres)
+    ve, vs = blk.bin_tables()
+    modes = [dict(frac=0.5, gm_radius=4e-9, gsd_log10=0.3, vol_frac=[1.0], wclass=0, source=0),
+             dict(frac=0.5, gm_radius=8e-6, gsd_log10=0.25, vol_frac=[1.0], wclass=0, source=0)]
+    mag = np.full((n_cells, 1), 5e8 / n_part)
+    cells, po = [], np.arange(n_cells + 1, dtype=np.int64) * n_part
+    for c in range(n_cells):
+        oc = oracle.Cell(1, 1, 1, 4096, dens, ve, temp[c], pres[c], max_events=4096, max_appends=512)
+        oc.mag[:] = mag[c]
+        oc.generate(modes, n_part, 9, c, first_id=c << 32)
+        oc.cell_id = c
+        oc.kmax[:] = oracle.kmax_table(K_BROWN, vs, 1800.0, 1800.0, temp[c], pres[c],
+                                       blk.cfg.const_k, blk.cfg.additive_beta)
+        cells.append(oc)
+    vol = np.concatenate([oc.vol[:, :n_part] for oc in cells], axis=1)
+    blk.set_weights(mag)
+    blk.upload_cells(0, po, vol, np.zeros(po[-1], np.int32),
+                     np.concatenate([oc.id[:n_part] for oc in cells]),
+                     np.zeros(po[-1]), np.zeros(po[-1]), np.ones((1, po[-1]), np.int32))
+    span = [int(np.ptp(np.nonzero(np.histogram(oc.vtot[:n_part], ve)[0])[0])) for oc in cells]
+    assert min(span) > 34          # wider than the window
+    total = 0
+    for step in range(4):       # the fine mode is scavenged by the coarse one within minutes
+        ns, nc, st = blk.mc_coag(K_BROWN, 60.0, 9, step)
+        for c, oc in enumerate(cells):
+            ost, ons, onc = oc.mc_coag(K_BROWN, 60.0, 9, c, step)
+            assert (ons, onc, ost) == (int(ns[c]), int(nc[c]), int(st[c])), (step, c)
+        total += int(nc.sum())
+    assert total > 1000
+    ok, msg = parity.compare_state(blk, cells)
+    assert ok, msg
     blk.close()
 
 

@@ -1213,9 +1213,9 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
             // (with one species the volume of that species IS the cached total: both are sums
             // of the same terms)
             if (S > 1) { vol1 = st.vol[cb * S + p1]; vol2 = st.vol[cb * S + p2]; }
-            const Meta t1 = meta[p1], t2 = meta[p2];
-            lct1 = t1.lct; gct1 = t1.gct; lct2 = t2.lct; gct2 = t2.gct;
-            no1 = t1.n_orig0; no2 = t2.n_orig0;
+            // (the record's two 16-byte halves are two requests: the second only when sources exist)
+            lct1 = meta[p1].lct; gct1 = meta[p1].gct; lct2 = meta[p2].lct; gct2 = meta[p2].gct;
+            if (NS > 0) { no1 = meta[p1].n_orig0; no2 = meta[p2].n_orig0; }
         }
 
         // ---- (4) drawing lanes: first count; still empty-handed: second slot ----
