@@ -9,6 +9,7 @@
 #include "pmco_math.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 /* ------------------------------------------------------------------------
  * Physical constants (PartMC constants.F90 values; upstream, uncited).
@@ -206,6 +207,19 @@ int pmco_bin_of(const double *v_edge, int n_bin, double v)
     return lo;
 }
 
+/* smallest float >= k (k >= 0, finite) */
+float pmco_up_f32(double k)
+{
+    float f = (float)k;
+    if ((double)f < k) {
+        uint32_t u;
+        memcpy(&u, &f, 4);
+        u += 1u;
+        memcpy(&f, &u, 4);
+    }
+    return f;
+}
+
 void pmco_kmax_table(int type, int n_bin, const double *v_samp, double rho_min,
                      double rho_max, double temp, double pressure,
                      const pmco_kernel_params *kp, double *kmax)
@@ -237,7 +251,9 @@ void pmco_kmax_table(int type, int n_bin, const double *v_samp, double rho_min,
                                 &pp[(b2 * 3 + s2) * 2 + d2], kp);
                             if (k > km) km = k;
                         }
-            kmax[b1 * n_bin + b2] = km;
+            /* stored as the next float at or above the bound (the device keeps the table
+             * in fp32: half the bytes, four bounds per 16-byte load) */
+            kmax[b1 * n_bin + b2] = (double)pmco_up_f32(km);
         }
     free(pp);
 }

@@ -107,8 +107,9 @@ void pmco_make_bin_tables(int n_bin, double r_min, double r_max,
 
 int pmco_bin_of(const double *v_edge, int n_bin, double v);
 
-/* kmax[b1*n_bin+b2] = max of K over the 3x3 sample volumes of the two bins
+/* kmax[b1*n_bin+b2] = (rounded up to a float) max of K over the 3x3 sample volumes of the two bins
  * and the four (rho_min|rho_max)^2 density combinations. */
+float pmco_up_f32(double k);
 void pmco_kmax_table(int type, int n_bin, const double *v_samp, double rho_min,
                      double rho_max, double temp, double pressure,
                      const pmco_kernel_params *kp, double *kmax);

@@ -294,7 +294,8 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
     A_(ctx->d_temp, nc); A_(ctx->d_pressure, nc); A_(ctx->d_rh, nc);
     A_(st.mag, nc * cfg->n_class);
     A_(ctx->d_n_ideal, nc * cfg->n_class);
-    A_(st.kmax, nc * B * B);
+    st.kmax_stride = (B * B + 3) & ~3;
+    A_(st.kmax, nc * (size_t)st.kmax_stride);
     A_(st.n_part, nc); A_(st.n_hi, nc); A_(st.next_id, nc);
     A_(st.vol, nc * cfg->n_spec * cap);
     A_(st.vm, nc * cap);
@@ -1026,7 +1027,13 @@ int pmcx_get_kmax(pmcx_ctx *ctx, int32_t cell, double *kmax)
     if (!ctx || !kmax || cell < 0 || cell >= ctx->cfg.n_cells) return fail(ctx, PMCX_EINVAL, "pmcx_get_kmax: bad argument");
     if (!ctx->bounds_kernel) return fail(ctx, PMCX_ESTATE, "kernel bounds not computed yet");
     const size_t bb = (size_t)ctx->cfg.n_bin * ctx->cfg.n_bin;
-    return copy_cells_d2h(ctx, kmax, ctx->st.kmax + (size_t)cell * bb, sizeof(double) * bb);
+    // the device table is fp32 (bounds rounded up): widen for the caller
+    std::vector<float> f(bb);
+    int rc = copy_cells_d2h(ctx, f.data(), ctx->st.kmax + (size_t)cell * ctx->st.kmax_stride,
+                            sizeof(float) * bb);
+    if (rc) return rc;
+    for (size_t k = 0; k < bb; k++) kmax[k] = (double)f[k];
+    return PMCX_OK;
 }
 int pmcx_get_caches(pmcx_ctx *ctx, int32_t cell, double *vtot, double *mass)
 {

@@ -46,7 +46,8 @@ struct DeviceState {
     const double *temp, *pressure; // [n_cells]
     double *mag;                   // [n_cells][n_class]
     const double *n_ideal;         // [n_cells][n_class]
-    double *kmax;                  // [n_cells][n_bin*n_bin]
+    float *kmax;                   // [n_cells][kmax_stride] bounds rounded up to fp32, row b1 = [b1*n_bin ..)
+    int32_t kmax_stride;           // n_bin*n_bin rounded up to a multiple of 4 (16-byte loads)
     int32_t *n_part;               // [n_cells] live particles
     int32_t *n_hi;                 // [n_cells] slots in use (live + tombstones)
     int64_t *next_id;              // [n_cells]

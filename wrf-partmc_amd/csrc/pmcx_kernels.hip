@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void k_kernel_bounds(DeviceState st, int ktype
         p_fal[j] = q.wfall;
     }
     __syncthreads();
-    double *km = st.kmax + (int64_t)c * B * B;
+    float *km = st.kmax + (int64_t)c * st.kmax_stride;
     // K is symmetric: one thread per unordered bin pair, both entries written
     const int n_pair = B * (B + 1) / 2;
     for (int j = threadIdx.x; j < n_pair; j += blockDim.x) {
@@ -236,8 +236,11 @@ __global__ __launch_bounds__(256) void k_kernel_bounds(DeviceState st, int ktype
                 if (k > m) m = k;
             }
         }
-        km[b1 * B + b2] = m;
-        km[b2 * B + b1] = m;
+        // smallest float >= m: half the table, four bounds per 16-byte load in the sampler
+        float f = (float)m;
+        if ((double)f < m) f = __uint_as_float(__float_as_uint(f) + 1u);
+        km[b1 * B + b2] = f;
+        km[b2 * B + b1] = f;
     }
 }
 
@@ -607,7 +610,7 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
     wave_sync();
     const EnvDerived &env = *X.L.env;
     const KernelParams kp{st.const_k, st.additive_beta};
-    const double *kmax = st.kmax + (int64_t)c * B * B;
+    const float *kmax = st.kmax + (int64_t)c * st.kmax_stride;
     const double *mag = st.mag + (int64_t)c * C;
     int n_ev = 0, n_app = 0, n_dead = 0, tot_coag = 0, status = 0;
     uint64_t tot_samp = 0;
@@ -933,7 +936,7 @@ struct SeqOverflow {      // per cell, in HBM; touched only after a group's room
     uint16_t *app_prev;   // [max_appends]
 };
 
-constexpr int SEQ_W = 32;      // bins per class with list state in LDS
+constexpr int SEQ_W = 24;      // bins per class with list state in LDS
 constexpr int SEQ_ENV = 7;     // air properties kept per cell
 
 __host__ __device__ inline size_t seq_lds_bytes(int B, int C)
@@ -953,7 +956,7 @@ __host__ __device__ inline size_t seq_lds_bytes(int B, int C)
 __device__ unsigned long long g_seq_stamps[12];
 
 template <bool STAMPS>
-__global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, double del_t,
+__global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype, double del_t,
                                                  uint64_t seed, uint32_t step, uint16_t *ovf_mem)
 {
     uint64_t t_last = 0, t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -988,14 +991,13 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
     uint32_t *perm = st.perm + (int64_t)c * st.pcap;
     double2 *vm = st.vm + cb;  // (cached total volume, cached mass)
     Meta *meta = st.meta + cb; // create times, id, first source count
-    int32_t *gcnt_g = st.gcnt + (int64_t)c * G;
-    const int32_t *goff_g = st.goff + (int64_t)c * (G + 1);
-    SeqOverflow O;
-    {
-        uint16_t *ob = ovf_mem + (size_t)c * (2 * (size_t)G + 2 * (size_t)st.max_appends);
-        O.ovf_n = ob; O.last_app = ob + G; O.app_slot = ob + 2 * G;
-        O.app_prev = O.app_slot + st.max_appends;
-    }
+    // (per-lane pointers cost two registers each: the rarely used ones are formed on use)
+#define gcnt_g (st.gcnt + (int64_t)c * G)
+#define goff_g (st.goff + (int64_t)c * (G + 1))
+#define O_ovf_n(g) (ovf_mem[(size_t)c * (2 * (size_t)G + 2 * (size_t)st.max_appends) + (g)])
+#define O_last_app(g) (ovf_mem[(size_t)c * (2 * (size_t)G + 2 * (size_t)st.max_appends) + G + (g)])
+#define O_app_slot(e) (ovf_mem[(size_t)c * (2 * (size_t)G + 2 * (size_t)st.max_appends) + 2 * G + (e)])
+#define O_app_prev(e) (ovf_mem[(size_t)c * (2 * (size_t)G + 2 * (size_t)st.max_appends) + 2 * G + st.max_appends + (e)])
 
     // non-empty bins of every class; the window starts at the cell's first one
     int blo = B;
@@ -1027,7 +1029,6 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
     __syncthreads(); // one wavefront: orders the edge table
 
     const KernelParams kp{st.const_k, st.additive_beta};
-    const double *kmax = st.kmax + (int64_t)c * B * B;
 
     // ---- list state: packed entry = count | offset << 16 ----
     auto in_win = [&](int b) -> bool { return (unsigned)(b - blo) < (unsigned)SEQ_W; };
@@ -1047,22 +1048,22 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
         return goff_g[cl * B + b + 1];
     };
     // entries beyond a group's room (rare): linked through the per-cell table
-    auto ovf_of = [&](int g, int n_app) -> int { return n_app ? (int)O.ovf_n[g] : 0; };
+    auto ovf_of = [&](int g, int n_app) -> int { return n_app ? (int)O_ovf_n(g) : 0; };
     auto list_get = [&](int g, uint32_t e, int i, int n_app) -> uint32_t {
         const int n = (int)(e & 0xFFFFu), nb = n - ovf_of(g, n_app);
         if (i < nb) return perm[(e >> 16) + i];
-        int x = O.last_app[g];
-        for (int k = n - 1 - i; k > 0; k--) x = O.app_prev[x];
-        return O.app_slot[x];
+        int x = O_last_app(g);
+        for (int k = n - 1 - i; k > 0; k--) x = O_app_prev(x);
+        return O_app_slot(x);
     };
     auto list_set = [&](int g, uint32_t e, int i, uint32_t val, int n_app) {
         const int n = (int)(e & 0xFFFFu), nb = n - ovf_of(g, n_app);
         if (i < nb) {
             perm[(e >> 16) + i] = val;
         } else {
-            int x = O.last_app[g];
-            for (int k = n - 1 - i; k > 0; k--) x = O.app_prev[x];
-            O.app_slot[x] = (uint16_t)val;
+            int x = O_last_app(g);
+            for (int k = n - 1 - i; k > 0; k--) x = O_app_prev(x);
+            O_app_slot(x) = (uint16_t)val;
         }
     };
     auto next_bin = [&](int cl, int from) -> int { // next non-empty bin >= from, or -1
@@ -1119,7 +1120,7 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
             fmax = (n1 < n2) ? n2 : n1;
             factor = n1 * n2 / nmin;
         }
-        if (found) km = kmax[b1 * B + b2];
+        if (found) km = (double)st.kmax[(int64_t)c * st.kmax_stride + b1 * B + b2];
         return found;
     };
     // the slot's Poisson count from its uniform u
@@ -1296,8 +1297,8 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
                     const int last = (int)(e & 0xFFFFu) - 1;
                     if (io != last) list_set(g_o, e, io, pn_is_1 ? last2 : last1, n_app);
                     if (ovf_of(g_o, n_app) > 0) {
-                        O.last_app[g_o] = O.app_prev[O.last_app[g_o]];
-                        O.ovf_n[g_o] = (uint16_t)(O.ovf_n[g_o] - 1);
+                        O_last_app(g_o) = O_app_prev(O_last_app(g_o));
+                        O_ovf_n(g_o) = (uint16_t)(O_ovf_n(g_o) - 1);
                     }
                     cnt_set(cl_o, b_o, e, last);
                     if (same && in == last) in = io;
@@ -1313,8 +1314,8 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
                     const int last = (int)(e & 0xFFFFu) - 1;
                     if (in != last) list_set(g_old, e, in, lastv, n_app);
                     if (ovf_of(g_old, n_app) > 0) {
-                        O.last_app[g_old] = O.app_prev[O.last_app[g_old]];
-                        O.ovf_n[g_old] = (uint16_t)(O.ovf_n[g_old] - 1);
+                        O_last_app(g_old) = O_app_prev(O_last_app(g_old));
+                        O_ovf_n(g_old) = (uint16_t)(O_ovf_n(g_old) - 1);
                     }
                     cnt_set(cl_old, b_old, e, last);
                     // ... and joins the list of its new bin: behind it in perm while there is
@@ -1325,11 +1326,11 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
                         perm[o + n] = pn;
                     } else {
                         if (n_app == 0) // first use of the table in this call
-                            for (int k = 0; k < G; k++) { O.ovf_n[k] = 0; O.last_app[k] = 0xFFFF; }
-                        O.app_slot[n_app] = (uint16_t)pn;
-                        O.app_prev[n_app] = O.last_app[g_new];
-                        O.last_app[g_new] = (uint16_t)n_app;
-                        O.ovf_n[g_new] = (uint16_t)(O.ovf_n[g_new] + 1);
+                            for (int k = 0; k < G; k++) { O_ovf_n(k) = 0; O_last_app(k) = 0xFFFF; }
+                        O_app_slot(n_app) = (uint16_t)pn;
+                        O_app_prev(n_app) = O_last_app(g_new);
+                        O_last_app(g_new) = (uint16_t)n_app;
+                        O_ovf_n(g_new) = (uint16_t)(O_ovf_n(g_new) + 1);
                         n_app++;
                     }
                     cnt_set(cc, b_new, en, n + 1);
@@ -1376,7 +1377,7 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
                 gcnt_g[cl * B + blo + k] = (int32_t)(ent[(cl * SEQ_W + k) * 64 + lane] & 0xFFFFu);
         if (n_app) {
             bool ovf = false;
-            for (int g = 0; g < G; g++) ovf |= O.ovf_n[g] != 0;
+            for (int g = 0; g < G; g++) ovf |= O_ovf_n(g) != 0;
             if (ovf) st.sort_valid[c] = 0;
         }
         st.n_events[c] = n_ev;
@@ -1393,6 +1394,12 @@ __global__ __launch_bounds__(64) void k_coag_seq(DeviceState st, int ktype, doub
     }
 #undef STAMP
 #undef MASK
+#undef gcnt_g
+#undef goff_g
+#undef O_ovf_n
+#undef O_last_app
+#undef O_app_slot
+#undef O_app_prev
 }
 
 hipError_t seq_stamps_read(uint64_t out[12], bool reset)
