@@ -594,6 +594,12 @@ int pmcx_download_cells(pmcx_ctx *ctx, int32_t cell_first, int32_t n_dn, const i
     if (rc) return rc;
     const int64_t c0 = cell_first;
     if (vol) {
+        // with one species the volume of that species is the cached total (the lane-per-cell
+        // sampler does not keep the plane current): gathered from the (vtot, mass) records
+        if (cf.n_spec == 1)
+            HIP_TRY(ctx, launch_gather_f64((double *)ctx->stage, &st.vm[c0 * cap].x, ctx->d_offsets,
+                                           n_dn, (int64_t)cap, nt, 1, (int64_t)cap, ctx->stream, 2));
+        else
         HIP_TRY(ctx, launch_gather_f64((double *)ctx->stage, st.vol + c0 * cf.n_spec * cap,
                                        ctx->d_offsets, n_dn, (int64_t)cf.n_spec * cap, nt,
                                        cf.n_spec, (int64_t)cap, ctx->stream));

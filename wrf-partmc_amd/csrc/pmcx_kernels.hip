@@ -79,6 +79,31 @@ __device__ __forceinline__ void mark_dead(const DeviceState &st, int64_t cb, int
     st_u32((uint32_t *)&st.wclass[cb + i], 0xFFFFFFFFu);
 }
 
+// Class of the particle in slot i, or -1 for a tombstone.  A slot is dead when its cached
+// total volume is negative (the lane-per-cell sampler marks a removed particle there, in the
+// record it has just read, and leaves wclass alone: a store to an untouched line per event
+// costs it 5 % of its time); wclass of a dead slot is unspecified.
+__device__ __forceinline__ int live_class(const DeviceState &st, int64_t cb, int i)
+{
+    if (st.vm[cb + i].x < 0.0) return -1;
+    return st.n_class > 1 ? st.wclass[cb + i] : 0;
+}
+// same, for kernels that kill particles themselves before looking again
+__device__ __forceinline__ int live_class_c(const DeviceState &st, int64_t cb, int i)
+{
+    if (ld_f64(&st.vm[cb + i].x) < 0.0) return -1;
+    return st.n_class > 1 ? (int32_t)ld_u32((const uint32_t *)&st.wclass[cb + i]) : 0;
+}
+// volume of species s of slot i.  With ONE species the plane `vol` is not kept current by the
+// lane-per-cell sampler: that volume and the cached total are sums of the same terms in the
+// same order, so the cached total is read instead (and `vol` is written at upload, generation
+// and emission only).
+__device__ __forceinline__ double spec_vol(const DeviceState &st, int64_t cb, int s, int i)
+{
+    if (st.n_spec == 1) return st.vm[cb + i].x;
+    return st.vol[cb * st.n_spec + (int64_t)s * st.cap + i];
+}
+
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x, int lane)
 {
 #pragma unroll
@@ -1337,7 +1362,7 @@ __global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype, d
                 }
                 vm[pn] = make_double2(vn, mn);
                 // species volumes, source histogram, create times, class [aero_particle_coagulate]
-                st.vol[cb * S + pn] = (S > 1) ? (pn_is_1 ? vol1 : vol2) + (pn_is_1 ? vol2 : vol1) : vn;
+                if (S > 1) st.vol[cb * S + pn] = (pn_is_1 ? vol1 : vol2) + (pn_is_1 ? vol2 : vol1);
                 for (int s0 = 1; s0 < S; s0 += 4) { // four species' loads in flight
                     double a[4], b[4];
 #pragma unroll
@@ -1363,7 +1388,7 @@ __global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype, d
                     if (NS > 0) meta[pn].n_orig0 = (int32_t)((uint32_t)no1 + (uint32_t)no2);
                 }
                 if (C > 1) st.wclass[cb + pn] = cc;
-                if (rem_o) { vm[po].x = -1.0; st.wclass[cb + po] = -1; n_dead++; } // tombstone
+                if (rem_o) { vm[po].x = -1.0; n_dead++; } // tombstone: in the record just read
                 tot_coag++;
             } while (false);
         }
@@ -1455,7 +1480,7 @@ __device__ void compact_wave(const DeviceState &st, int c, int lane, uint32_t *c
     int base = 0;
     for (int i0 = 0; i0 < n_hi; i0 += 64) {
         const int i = i0 + lane;
-        const bool live = i < n_hi && (int32_t)ld_u32((const uint32_t *)&st.wclass[cb + i]) >= 0;
+        const bool live = i < n_hi && live_class_c(st, cb, i) >= 0;
         const uint64_t m = __ballot(live);
         const int dst = base + __popcll(m & lt);
         const bool mv = live && dst != i;
@@ -1566,7 +1591,7 @@ __global__ __launch_bounds__(64) void k_rebalance(DeviceState st, int allow_doub
             int ncl = n_live; // one class: every live particle belongs to it
             if (st.n_class > 1) {
                 uint32_t cnt = 0;
-                for (int i = lane; i < n_hi; i += 64) cnt += ((int32_t)ld_u32((const uint32_t *)&st.wclass[cb + i]) == cl);
+                for (int i = lane; i < n_hi; i += 64) cnt += (live_class_c(st, cb, i) == cl);
                 ncl = (int)wave_sum_u64(cnt);
             }
             const double ideal = n_ideal[cl];
@@ -1580,7 +1605,7 @@ __global__ __launch_bounds__(64) void k_rebalance(DeviceState st, int allow_doub
                 uint32_t base = 0;
                 for (int i0 = 0; i0 < n_hi; i0 += 64) {
                     const int i = i0 + lane;
-                    const bool is = (i < n_hi) && ((int32_t)ld_u32((const uint32_t *)&st.wclass[cb + i]) == cl);
+                    const bool is = (i < n_hi) && (live_class_c(st, cb, i) == cl);
                     const uint64_t m = __ballot(is);
                     const uint32_t k = base + (uint32_t)__popcll(m & lt);
                     if (is) {
@@ -1605,7 +1630,7 @@ __global__ __launch_bounds__(64) void k_rebalance(DeviceState st, int allow_doub
                 uint32_t nd = 0, rank0 = 0;
                 for (int i0 = 0; i0 < n_hi; i0 += 64) {
                     const int i = i0 + lane;
-                    const int wc = i < n_hi ? (int32_t)ld_u32((const uint32_t *)&st.wclass[cb + i]) : -1;
+                    const int wc = i < n_hi ? live_class_c(st, cb, i) : -1;
                     const uint64_t mlive = __ballot(wc >= 0);
                     const uint32_t rank = rank0 + (uint32_t)__popcll(mlive & lt);
                     bool drop = false;
@@ -1671,11 +1696,11 @@ __global__ __launch_bounds__(256) void k_diagnostics(DeviceState st, double *tot
     double tm = 0.0;
     uint32_t n_live = 0;
     for (int i = t; i < n; i += 256) {
-        const int cl = st.wclass[cb + i];
+        const int cl = live_class(st, cb, i);
         if (cl < 0) continue; // tombstone
         double vdry = 0.0, ms = 0.0;
         for (int s = 0; s < S; s++) {
-            const double v = st.vol[cb * S + (int64_t)s * st.cap + i];
+            const double v = spec_vol(st, cb, s, i);
             if (s != st.i_water) vdry = vdry + v;
             ms = ms + st.density[s] * v;
         }
@@ -1741,12 +1766,12 @@ __global__ __launch_bounds__(256) void k_diagnostics_ext(DeviceState st, double 
     const int64_t cb = (int64_t)c * st.cap;
     const double *mag = st.mag + (int64_t)c * st.n_class;
     for (int i = t; i < n; i += 256) {
-        const int cl = st.wclass[cb + i];
+        const int cl = live_class(st, cb, i);
         if (cl < 0) continue;
         const double nc = mag[cl];
         double vdry = 0.0, mdry = 0.0;
         for (int s = 0; s < S; s++) {
-            const double v = st.vol[cb * S + (int64_t)s * st.cap + i];
+            const double v = spec_vol(st, cb, s, i);
             atomicAdd(&acc[s], st.density[s] * v * nc);
             if (s != st.i_water) { vdry = vdry + v; mdry = mdry + st.density[s] * v; }
         }
@@ -1855,7 +1880,7 @@ __global__ __launch_bounds__(64) void k_scenario_update(DeviceState st, double d
         uint32_t rank0 = 0;
         for (int i0 = 0; i0 < n_hi; i0 += 64) {
             const int i = i0 + lane;
-            const int wc = i < n_hi ? (int32_t)ld_u32((const uint32_t *)&st.wclass[cb + i]) : -1;
+            const int wc = i < n_hi ? live_class_c(st, cb, i) : -1;
             const uint64_t mlive = __ballot(wc >= 0);
             bool drop = false;
             if (wc >= 0) {
@@ -1978,7 +2003,7 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
     uint32_t rank0 = 0, n_out = 0;
     for (int i0 = 0; i0 < n_hi; i0 += 64) {
         const int s = i0 + lane;
-        const int cl = s < n_hi ? st.wclass[cb + s] : -1;
+        const int cl = s < n_hi ? live_class(st, cb, s) : -1;
         const uint64_t mlive = __ballot(cl >= 0);
         const uint32_t rank = rank0 + (uint32_t)__popcll(mlive & lt);
         bool moves = false;
@@ -2129,7 +2154,7 @@ __global__ __launch_bounds__(256) void k_condense(DeviceState st, const double *
     const CondEnv e = cond_env_derive(st.temp[c], st.pressure[c], rh);
     const double h = del_t / (double)n_sub;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        if (st.wclass[cb + i] < 0) continue; // tombstone
+        if (live_class(st, cb, i) < 0) continue; // tombstone
         double vdry = 0.0, kv = 0.0;
         for (int s = 0; s < S; s++) {
             if (s == iw) continue;
