@@ -17,8 +17,11 @@
 //   k_bin_sort     one 256-thread workgroup per cell; stable counting sort of
 //                  the slots by (class, bin) -> perm, gcnt, goff.  Streams
 //                  vtot once: the HBM-bound pass (12 B per particle).
-//   k_coag_sample  one 64-lane wavefront per cell; candidate pairs of the
-//                  sequential PartMC sweep evaluated 64 at a time, first
+//   k_coag_seq     the pair sampler for large blocks of cells: ONE LANE PER CELL, every
+//                  lane runs the sequential PartMC sweep of its own cell; bound by the
+//                  chip's rate of random 64-byte requests.
+//   k_coag_sample  the pair sampler for small blocks (or many classes): 8, 16 or 64 lanes
+//                  per cell; candidate pairs of the sweep evaluated a window at a time, first
 //                  accepted pair found by ballot, applied, later slots redrawn.
 //   k_compact      one wavefront per cell; stable compaction of cells whose
 //                  tombstone fraction exceeds a threshold.
@@ -953,13 +956,6 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
 // and served from HBM); rows of 64 lanes side by side, so the 64 cells never meet on
 // an LDS bank.  Chosen for large cell counts, where cells -- not lanes inside a cell --
 // are the parallelism (launch_coag_sample).
-
-struct SeqOverflow {      // per cell, in HBM; touched only after a group's room ran out
-    uint16_t *ovf_n;      // [G] entries of the group held in the table
-    uint16_t *last_app;   // [G] newest table entry of the group
-    uint16_t *app_slot;   // [max_appends]
-    uint16_t *app_prev;   // [max_appends]
-};
 
 constexpr int SEQ_W = 24;      // bins per class with list state in LDS
 constexpr int SEQ_ENV = 7;     // air properties kept per cell
