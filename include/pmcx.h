@@ -206,6 +206,25 @@ int pmcx_scenario_update_aero_state(pmcx_ctx *ctx, double dt, double elapsed_tim
                                     const pmcx_aero_dist *background, int32_t *n_emit,
                                     int32_t *n_dil_in, int32_t *n_dil_out);
 
+/* Dry deposition of aerosol particles (dep_aero_dry_driver / dry_dep_aero_state,
+ * interface/wrf_pmc_dep_aero.F90:28-192): on every cell with surface[c] != 0
+ * (NULL: every cell; the reference applies it to the lowest level of interior
+ * columns, :131-151) each particle is removed with probability (dt / height) vd,
+ * vd the Zhang et al. (2001) deposition velocity of the whole particle
+ * (:196-234, :265-420) from the aerodynamic resistance aer_res_a [s/m], the
+ * friction velocity ustar [m/s], the land-use impaction parameter alpha and the
+ * collector radius big_a = A(season, land use) [m] (tables at :94-130; the
+ * land-use gamma is overwritten by the reference, :325, and not an input),
+ * env_state%height [m], env_state%inverse_density [m^3/kg] and the cell's
+ * temperature (pmcx_set_env).  One uniform per particle, keyed by
+ * (seed, global cell, step, rank of the particle among the live ones).
+ * n_removed, unrealistic ("Unrealistic deposition": a probability outside (0,1),
+ * :181-183) are [n_cells] outputs and may be NULL.  Synchronises. */
+int pmcx_dry_deposition(pmcx_ctx *ctx, double dt, uint64_t seed, uint32_t step,
+                        const int32_t *surface, const double *aer_res_a, const double *ustar,
+                        const double *alpha, const double *big_a, const double *height,
+                        const double *inv_density, int32_t *n_removed, int32_t *unrealistic);
+
 /*
  * Stochastic particle transport between the cells of this context (SURVEY
  * section 8, row f2): aero_state_multisample + aero_state_sample_particles_by_class
@@ -307,7 +326,9 @@ int pmcx_get_sort(pmcx_ctx *ctx, int32_t cell, uint32_t *perm, int32_t *gcnt,
 /* Evaluate a device math routine elementwise (bitwise parity tests):
  * op 0 exp, 1 log, 2 cbrt, 3 norminv, 4 sqrt, 5 a/b (in2 = b),
  * 6 poisson(mean=in, u=in2), 7 kernel K(v1=in, m1=in2, v2=in3, m2=in4)
- * at (temp, pressure) with kernel id ktype. */
+ * at (temp, pressure) with kernel id ktype, 8 dry-deposition velocity
+ * (diameter=in, density=in2, ustar=in3, aer_res_a=in4; pressure carries
+ * 1/rho_air; ktype 0: alpha 1.2, A 0.002; 1: alpha 100, A 9.999). */
 int pmcx_test_math(pmcx_ctx *ctx, int32_t op, int64_t n, const double *in,
                    const double *in2, const double *in3, const double *in4,
                    int32_t ktype, double temp, double pressure, double *out);

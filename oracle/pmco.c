@@ -32,6 +32,11 @@ double pmco_log_(double x) { return pmco_log(x); }
 double pmco_cbrt_(double x) { return pmco_cbrt(x); }
 double pmco_norminv_(double p) { return pmco_norminv(p); }
 int32_t pmco_poisson_(double mean, double u) { return pmco_poisson(mean, u); }
+double pmco_dep_velocity_(double diameter, double density, double temp, double rrho, double ustar,
+                          double ra, double alpha, double big_a)
+{
+    return pmco_dep_velocity(diameter, density, temp, rrho, ustar, ra, alpha, big_a);
+}
 
 /* ------------------------------------------------------------------------
  * Coagulation kernels.
@@ -869,6 +874,44 @@ int pmco_scenario_update(pmco_cell *c, double dt, double create_time, uint64_t s
                                         next_id, &status);
     }
     return status;
+}
+
+/* ------------------------------------------------------------------------
+ * Dry deposition of one (surface) cell: dry_dep_aero_state
+ * (interface/wrf_pmc_dep_aero.F90:154-192): deposition velocity of every
+ * particle (compute_dep_vel :196-234, diameter and density of the whole
+ * particle), removal probability (dt / dz) vd (compute_dep_prob :238-256,
+ * option 1 as the reference has it), removal by one uniform per particle
+ * (aero_particles_remove_by_dep :260-272).  The reference draws from its
+ * sequential stream walking the particles backwards; here the draw of a
+ * particle is addressed by its rank among the live particles.  Returns the
+ * number removed; *unrealistic is set when a probability is outside (0, 1)
+ * (the reference prints "Unrealistic deposition", :181-183).
+ * ---------------------------------------------------------------------- */
+int pmco_dry_deposition(pmco_cell *c, double dt, uint64_t seed, uint32_t cell_id, uint32_t step,
+                        double aer_res_a, double ustar, double alpha, double big_a,
+                        double height, double inv_density, int32_t *unrealistic)
+{
+    const int n = *c->n_part;
+    unsigned char *dead = (unsigned char *)calloc((size_t)(n > 0 ? n : 1), 1);
+    int nd = 0;
+    *unrealistic = 0;
+    for (int i = 0; i < n; i++) {
+        const double v = c->vtot[i], m = c->mass[i];
+        const double diam = 2.0 * pmco_cbrt(v * (0.75 / PMCO_DEP_PI));
+        const double dens = m / v;
+        const double vd = pmco_dep_velocity(diam, dens, c->temp, inv_density, ustar, aer_res_a,
+                                            alpha, big_a);
+        const double prob = (dt / height) * vd;
+        if (prob >= 1.0 || prob <= 0.0) *unrealistic = 1;
+        uint32_t w[4];
+        pmco_rng_block(seed, cell_id, step, (uint32_t)i, PMCO_SITE_DEPOSIT, 0, w);
+        if (pmco_u53(w[0], w[1]) < prob) { dead[i] = 1; nd++; }
+    }
+    if (nd > 0) *c->sort_valid = 0;
+    compact_stable(c, dead, n, nd);
+    free(dead);
+    return nd;
 }
 
 /* ------------------------------------------------------------------------

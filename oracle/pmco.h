@@ -109,6 +109,12 @@ int pmco_bin_of(const double *v_edge, int n_bin, double v);
 
 /* kmax[b1*n_bin+b2] = (rounded up to a float) max of K over the 3x3 sample volumes of the two bins
  * and the four (rho_min|rho_max)^2 density combinations. */
+/* dry deposition of one surface cell (interface/wrf_pmc_dep_aero.F90:154-272) */
+int pmco_dry_deposition(pmco_cell *c, double dt, uint64_t seed, uint32_t cell_id, uint32_t step,
+                        double aer_res_a, double ustar, double alpha, double big_a,
+                        double height, double inv_density, int32_t *unrealistic);
+double pmco_dep_velocity_(double diameter, double density, double temp, double rrho, double ustar,
+                          double ra, double alpha, double big_a);
 float pmco_up_f32(double k);
 void pmco_kmax_table(int type, int n_bin, const double *v_samp, double rho_min,
                      double rho_max, double temp, double pressure,

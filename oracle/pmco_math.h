@@ -61,7 +61,8 @@ enum {
     PMCO_SITE_EMIT_N  = 7,  /* scenario: number of new particles of a mode */
     PMCO_SITE_EMIT_P  = 8,  /* scenario: one new particle                  */
     PMCO_SITE_DILUTE  = 9,  /* scenario: keep/drop one particle (dilution) */
-    PMCO_SITE_TRANS   = 10  /* transport: destination and copies of one particle */
+    PMCO_SITE_TRANS   = 10, /* transport: destination and copies of one particle */
+    PMCO_SITE_DEPOSIT = 11  /* dry deposition: keep/drop one particle          */
 };
 
 /* One 128-bit block of the stream: counter = (cell, step, a, site<<28 | b),
@@ -246,6 +247,57 @@ static inline int32_t pmco_poisson(double mean, double u)
     if (x < 0.0) return 0;
     if (x > (double)PMCO_NSAMP_MAX) return PMCO_NSAMP_MAX;
     return (int32_t)x;
+}
+
+/* x^y for x > 0 from the deterministic exp and log */
+static inline double pmco_pow(double x, double y) { return pmco_exp(y * pmco_log(x)); }
+
+/* ------------------------------------------------------------------------
+ * Dry deposition velocity of one particle, Zhang et al. (2001) as written in
+ * interface/wrf_pmc_dep_aero.F90 (updated_version = .true., :313-329):
+ *   slip_correction_factor :377-386   calculate_vs :265-276
+ *   compute_brownian_diff  :409-420   calculate_st :390-404
+ *   calculate_rs           :280-357   calculate_vd :361-372
+ * The reference writes several constants as default-real literals (.2, 0.8,
+ * 0.4, 2.0/3.0, 1.257, .4, 1.1); they are reproduced as the doubles those
+ * single-precision values convert to.  const%air_dyn_visc, const%grav,
+ * const%boltzmann are PartMC's [upstream]: 1.78e-5, 9.80665, 1.3806505e-23.
+ * x**2.0d0 and x**.5 are taken as x*x and sqrt(x); the other powers are
+ * exp(y log x) with the deterministic exp/log.  alpha is the land-use impaction
+ * parameter, big_a the collector radius A(season, land use) (:113-130); the
+ * land-use gamma is overwritten by the reference (:325) and therefore unused.
+ * ---------------------------------------------------------------------- */
+#define PMCO_AIR_DYN_VISC 1.78e-5
+#define PMCO_DEP_GRAV 9.80665
+#define PMCO_DEP_BOLTZMANN 1.3806505e-23
+#define PMCO_DEP_PI 3.14159265358979323846
+
+static inline double pmco_dep_slip(double d_p)
+{
+    const double lambda = .065e-6;
+    return 1.0 + ((2.0 * lambda) / d_p) *
+                     ((double)1.257f + (double).4f * pmco_exp(-((double)1.1f * d_p) / (2.0 * lambda)));
+}
+
+static inline double pmco_dep_velocity(double diameter, double density, double temp, double rrho,
+                                       double ustar, double ra, double alpha, double big_a)
+{
+    const double c_c = pmco_dep_slip(diameter);
+    const double vs = ((diameter * diameter) * density * PMCO_DEP_GRAV * c_c) / (18.0 * PMCO_AIR_DYN_VISC);
+    const double diff = (PMCO_DEP_BOLTZMANN * temp * c_c) / (3.0 * PMCO_DEP_PI * PMCO_AIR_DYN_VISC * diameter);
+    const double sc = 1.45e-5 / diff;
+    const double gamma = (double)(2.0f / 3.0f), c_b = (double).2f, nu = (double)0.8f, c_im = (double)0.4f;
+    double st;
+    if (big_a > 1.0) st = (vs * (ustar * ustar)) / (PMCO_AIR_DYN_VISC * rrho);
+    else st = (vs * ustar) / (PMCO_DEP_GRAV * big_a);
+    const double eb = c_b * pmco_pow(sc, -gamma);
+    const double r = st / (alpha + st);
+    const double eim = c_im * (r * r);
+    const double ein = .5 * pmco_pow(diameter / big_a, nu);
+    const double r1 = pmco_exp(-sqrt(st));
+    const double rs = 1.0 / (3.0 * ustar * (eb + eim + ein) * r1);
+    const double tmp = ra + rs + ra * rs * vs;
+    return (1.0 / tmp) + vs;
 }
 
 #endif /* PMCO_MATH_H */

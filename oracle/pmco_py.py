@@ -124,6 +124,13 @@ def make_bin_tables(n_bin, r_min, r_max):
     return v_edge, v_samp
 
 
+def dep_velocity(diameter, density, temp, rrho, ustar, ra, alpha, big_a):
+    f = lib().pmco_dep_velocity_
+    f.restype = C.c_double
+    f.argtypes = [C.c_double] * 8
+    return f(diameter, density, temp, rrho, ustar, ra, alpha, big_a)
+
+
 def kmax_table(ktype, v_samp, rho_min, rho_max, temp, pressure, const_k=0.0, additive_beta=0.0):
     n_bin = len(v_samp) // 3
     out = np.zeros(n_bin * n_bin)
@@ -225,6 +232,18 @@ class Cell:
                                         C.byref(b) if b else None, C.byref(nid), C.byref(ne),
                                         C.byref(ni), C.byref(no))
         return st, nid.value, ne.value, ni.value, no.value
+
+    def dry_deposition(self, dt, seed, cell_id, step, aer_res_a, ustar, alpha, big_a, height,
+                       inv_density):
+        """dry_dep_aero_state of this cell; returns (n_removed, unrealistic)."""
+        f = lib().pmco_dry_deposition
+        f.restype = C.c_int
+        f.argtypes = [C.POINTER(CellStruct), C.c_double, C.c_uint64, C.c_uint32, C.c_uint32] + \
+                     [C.c_double] * 6 + [C.POINTER(C.c_int32)]
+        bad = C.c_int32(0)
+        nd = f(C.byref(self.view()), dt, seed, cell_id, step, aer_res_a, ustar, alpha, big_a, height,
+               inv_density, C.byref(bad))
+        return nd, bad.value
 
     def diagnostics_ext(self, i_water):
         sm, sn, pm = np.zeros(self.n_spec), np.zeros(max(self.n_source, 1)), np.zeros(3)

@@ -373,6 +373,51 @@ def test_wide_distribution_beyond_lds_window(wp, oracle, sampler_variant):
     blk.close()
 
 
+def test_dry_deposition_parity(wp, oracle):
+    """SURVEY f4, dry_dep_aero_state (wrf_pmc_dep_aero.F90:154-272): deposition velocity bit for
+    bit, then removal on the surface cells of a ragged block, GPU vs oracle, followed by a
+    coagulation step on what is left (the lists are rebuilt)."""
+    rng = np.random.RandomState(8)
+    n = 3000
+    d = 10 ** rng.uniform(-8.7, -4.3, n); rho = rng.uniform(900, 2700, n)
+    us = rng.uniform(0.03, 0.9, n); ra = rng.uniform(3, 400, n)
+    with wp.CellBlock(1, 64, 1) as b0:
+        for kt, (alpha, big_a) in enumerate(((1.2, 0.002), (100.0, 9.999))):
+            got = b0.test_math(8, d, rho, us, ra, ktype=kt, temp=281.0, pressure=1 / 1.15)
+            ref = np.array([oracle.dep_velocity(a, b, 281.0, 1 / 1.15, c, e, alpha, big_a)
+                            for a, b, c, e in zip(d, rho, us, ra)])
+            assert np.array_equal(got, ref)
+    counts = [1500, 0, 900, 1, 2047, 1200]
+    blk, cells = _ragged_pair(wp, oracle, counts, n_spec=2, n_class=2, cap=2048)
+    nc = len(counts)
+    from wrf_partmc_amd.data import zhang_surface_parameters
+    alpha, big_a = zhang_surface_parameters([7, 16, 1, 24, 11, 99])       # grass, water, urban, ice ...
+    surface = np.array([1, 1, 0, 1, 1, 1], np.int32)
+    ra = np.linspace(20, 200, nc); us = np.linspace(0.6, 0.1, nc)
+    height = np.linspace(30, 80, nc); rrho = 1 / np.linspace(1.25, 1.0, nc)
+    for step in range(2):
+        nr, bad = blk.dry_deposition(1500.0, ra, us, alpha, big_a, height, rrho, seed=4, step=step,
+                                     surface=surface)
+        for c, oc in enumerate(cells):
+            if surface[c]:
+                ond, obad = oc.dry_deposition(1500.0, 4, c, step, ra[c], us[c], alpha[c], big_a[c],
+                                              height[c], rrho[c])
+                assert (int(nr[c]), int(bad[c])) == (ond, obad), (step, c)
+            else:
+                assert nr[c] == 0
+        ok, msg = parity.compare_state(blk, cells)
+        assert ok, f"step {step}: {msg}"
+    assert nr.sum() > 20
+    ns, ncg, st = blk.mc_coag(K_BROWN, 3000.0, 4, 7)
+    for c, oc in enumerate(cells):
+        assert oc.mc_coag(K_BROWN, 3000.0, 4, c, 7) == (int(st[c]), int(ns[c]), int(ncg[c]))
+    ok, msg = parity.compare_state(blk, cells)
+    assert ok, msg
+    with pytest.raises(wp.PmcxError):
+        blk.dry_deposition(60.0, ra, us, alpha, big_a, np.zeros(nc), rrho)   # height must be positive
+    blk.close()
+
+
 def test_maximum_capacity_cell(wp, oracle):
     """The largest cell the sampler's 16-bit list offsets allow: cap + cap/8 + 16 G <= 65535."""
     with pytest.raises(wp.PmcxError):

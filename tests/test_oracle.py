@@ -456,3 +456,67 @@ def test_transport_matches_reference_sampling_law(oracle, ratio):
         assert abs(ref[:, col].mean() - got[:, col].mean()) < 4 * se + 0.02 * ref[:, col].mean(), name
     assert abs(got[:, 1].mean() - n_part * p) < 4 * math.sqrt(n_part * p / trials)   # removals = n p
     assert abs(got[:, 0].mean() - n_part * p / ratio) < 0.06 * n_part * p / ratio     # arrivals = n p / r
+
+
+def _dep_velocity_numpy(d, rho, temp, rrho, ustar, ra, alpha, big_a):
+    """Independent transcription of wrf_pmc_dep_aero.F90:265-420 (updated_version branch) in
+    numpy float64, with the reference's default-real literals as float32 values."""
+    f32 = np.float32
+    lam = 0.065e-6
+    mu, g, kb = 1.78e-5, 9.80665, 1.3806505e-23
+    cc = 1.0 + (2.0 * lam / d) * (float(f32(1.257)) + float(f32(.4)) * np.exp(-(float(f32(1.1)) * d) / (2.0 * lam)))
+    vs = d ** 2 * rho * g * cc / (18.0 * mu)
+    diff = kb * temp * cc / (3.0 * np.pi * mu * d)
+    sc = 1.45e-5 / diff
+    st = vs * ustar ** 2 / (mu * rrho) if big_a > 1.0 else vs * ustar / (g * big_a)
+    eb = float(f32(.2)) * sc ** (-float(f32(2.0) / f32(3.0)))
+    eim = float(f32(0.4)) * (st / (alpha + st)) ** 2.0
+    ein = 0.5 * (d / big_a) ** float(f32(0.8))
+    r1 = np.exp(-np.sqrt(st))
+    rs = 1.0 / (3.0 * ustar * (eb + eim + ein) * r1)
+    return 1.0 / (ra + rs + ra * rs * vs) + vs
+
+
+def test_dry_deposition_velocity(oracle):
+    """Zhang (2001) deposition velocity (wrf_pmc_dep_aero.F90:265-420): equal to an independent
+    numpy transcription to rounding, U-shaped in diameter, settling-dominated for coarse
+    particles, bounded by 1/ra + vs."""
+    rng = np.random.RandomState(3)
+    for big_a, alpha in ((0.002, 1.2), (0.010, 1.3), (9.999, 100.0)):
+        for _ in range(200):
+            d = 10 ** rng.uniform(-8.5, -4.5); rho = rng.uniform(900, 2600)
+            T = rng.uniform(230, 305); rrho = 1.0 / rng.uniform(0.9, 1.3)
+            us = rng.uniform(0.05, 0.8); ra = rng.uniform(5, 300)
+            got = oracle.dep_velocity(d, rho, T, rrho, us, ra, alpha, big_a)
+            ref = _dep_velocity_numpy(d, rho, T, rrho, us, ra, alpha, big_a)
+            assert abs(got - ref) <= 1e-12 * ref
+            vs = d ** 2 * rho * 9.80665 / (18 * 1.78e-5)
+            assert vs < got < 1.0 / ra + vs * (1 + 0.3) + 1e-9 or d < 3e-7
+    v = [oracle.dep_velocity(d, 1800.0, 288.0, 1 / 1.2, 0.3, 50.0, 1.2, 0.002) for d in (1e-8, 3e-7, 1e-5)]
+    assert v[0] > 5 * v[1] and v[2] > 5 * v[1]          # minimum in the accumulation mode
+    assert 1e-4 < v[1] < 2e-3 and 2e-3 < v[0] < 2e-2    # m/s, the textbook range
+
+
+def test_dry_deposition_removal_statistics(oracle):
+    """dry_dep_aero_state (wrf_pmc_dep_aero.F90:154-272): every particle goes with probability
+    (dt/dz) vd; the number removed matches the sum of the probabilities, survivors keep their
+    order, the sort is invalidated."""
+    dens = np.array([1800.0])
+    ve, vs = oracle.make_bin_tables(80, 1e-10, 1e-2)
+    modes = [dict(frac=1.0, gm_radius=2e-8, gsd_log10=0.4, vol_frac=[1.0], wclass=0, source=0)]
+    c = oracle.Cell(1, 1, 1, 8192, dens, ve, 285.0, 1e5)
+    c.mag[:] = 1e6
+    c.generate(modes, 8000, 5, 0)
+    v0, ids0 = c.vtot[:8000].copy(), c.id[:8000].copy()
+    dt, dz, ra, us = 60.0, 50.0, 40.0, 0.4
+    diam = 2 * np.cbrt(v0 * 0.75 / np.pi)
+    prob = np.array([dt / dz * oracle.dep_velocity(d, 1800.0, 285.0, 1 / 1.2, us, ra, 1.2, 0.002) for d in diam])
+    nd, bad = c.dry_deposition(dt, 5, 0, 0, ra, us, 1.2, 0.002, dz, 1 / 1.2)
+    assert bad == 0 and int(c.n_part[0]) == 8000 - nd
+    assert abs(nd - prob.sum()) < 4 * np.sqrt((prob * (1 - prob)).sum())
+    keep = np.isin(ids0, c.id[:8000 - nd])
+    assert np.array_equal(ids0[keep], c.id[:8000 - nd])      # stable
+    assert np.array_equal(v0[keep], c.vtot[:8000 - nd])
+    assert int(c.sort_valid[0]) == 0
+    nd2, bad2 = c.dry_deposition(1e6, 5, 0, 1, ra, us, 1.2, 0.002, dz, 1 / 1.2)   # absurd step
+    assert bad2 == 1 and int(c.n_part[0]) == 0

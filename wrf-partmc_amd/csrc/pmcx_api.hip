@@ -854,6 +854,43 @@ int pmcx_scenario_update_aero_state(pmcx_ctx *ctx, double dt, double elapsed_tim
     return PMCX_OK;
 }
 
+int pmcx_dry_deposition(pmcx_ctx *ctx, double dt, uint64_t seed, uint32_t step,
+                        const int32_t *surface, const double *aer_res_a, const double *ustar,
+                        const double *alpha, const double *big_a, const double *height,
+                        const double *inv_density, int32_t *n_removed, int32_t *unrealistic)
+{
+    if (!ctx || !aer_res_a || !ustar || !alpha || !big_a || !height || !inv_density)
+        return fail(ctx, PMCX_EINVAL, "pmcx_dry_deposition: null argument");
+    if (!ctx->aero_data_set) return fail(ctx, PMCX_ESTATE, "pmcx_set_aero_data must come first");
+    if (!(dt >= 0)) return fail(ctx, PMCX_EINVAL, "dt must be non-negative");
+    const size_t nc = (size_t)ctx->cfg.n_cells;
+    for (size_t k = 0; k < nc; k++)
+        if ((!surface || surface[k]) && (!(height[k] > 0) || !(ustar[k] > 0) || !(big_a[k] > 0)))
+            return fail(ctx, PMCX_EINVAL, "pmcx_dry_deposition: height, ustar and big_a must be positive (cell %zu)", k);
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    double *d6 = nullptr;
+    int32_t *d_i = nullptr;
+    hipError_t e = hipMalloc((void **)&d6, sizeof(double) * 6 * nc);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_i, sizeof(int32_t) * 3 * nc);
+    const double *src[6] = {aer_res_a, ustar, alpha, big_a, height, inv_density};
+    for (int k = 0; k < 6 && e == hipSuccess; k++)
+        e = hipMemcpyAsync(d6 + k * nc, src[k], sizeof(double) * nc, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && surface)
+        e = hipMemcpyAsync(d_i + 2 * nc, surface, sizeof(int32_t) * nc, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        ProfScope ps(ctx, "dry_deposition");
+        e = launch_dry_deposition(ctx->st, dt, seed, step, surface ? d_i + 2 * nc : nullptr, d6, d_i,
+                                  d_i + nc, ctx->stream);
+    }
+    if (e == hipSuccess && n_removed) e = hipMemcpyAsync(n_removed, d_i, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && unrealistic) e = hipMemcpyAsync(unrealistic, d_i + nc, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (d6) (void)hipFree(d6);
+    if (d_i) (void)hipFree(d_i);
+    if (e != hipSuccess) return fail(ctx, PMCX_EDEVICE, "pmcx_dry_deposition: %s", hipGetErrorString(e));
+    return PMCX_OK;
+}
+
 int pmcx_transport(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int32_t periodic_x,
                    int32_t periodic_y, const double *prob_h, const double *prob_v,
                    const double *cell_volume, uint64_t seed, uint32_t step, int32_t *n_moved,

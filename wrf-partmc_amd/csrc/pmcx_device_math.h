@@ -45,7 +45,8 @@ enum : uint32_t {
     SITE_EMIT_N = 7,
     SITE_EMIT_P = 8,
     SITE_DILUTE = 9,
-    SITE_TRANS = 10
+    SITE_TRANS = 10,
+    SITE_DEPOSIT = 11
 };
 
 // counter = (cell, step, a, site<<28 | b); key = seed
@@ -453,6 +454,47 @@ __device__ inline double cond_equilibrium(double dd, double dd3, double kappa, d
         else { a = b; fa = fb; b = x; fb = fx; }
     }
     return b;
+}
+
+// ------------------------------------------------------------ dry deposition
+//
+// Deposition velocity of one particle, Zhang et al. (2001) as written in
+// interface/wrf_pmc_dep_aero.F90 (updated_version = .true.): slip_correction_factor
+// :377-386, calculate_vs :265-276, compute_brownian_diff :409-420, calculate_st :390-404,
+// calculate_rs :280-357, calculate_vd :361-372.  Default-real literals of the reference
+// (.2, 0.8, 0.4, 2.0/3.0, 1.257, .4, 1.1) are the doubles those single-precision values
+// convert to; x**2.0d0 and x**.5 are x*x and sqrt(x), the other powers exp(y log x).
+
+constexpr double AIR_DYN_VISC = 1.78e-5; // const%air_dyn_visc [upstream]
+
+__device__ __forceinline__ double det_pow(double x, double y) { return det_exp(y * det_log(x)); }
+
+__device__ inline double dep_slip(double d_p)
+{
+    const double lambda = .065e-6;
+    return 1.0 + ((2.0 * lambda) / d_p) *
+                     ((double)1.257f + (double).4f * det_exp(-((double)1.1f * d_p) / (2.0 * lambda)));
+}
+
+__device__ inline double dep_velocity(double diameter, double density, double temp, double rrho,
+                                      double ustar, double ra, double alpha, double big_a)
+{
+    const double c_c = dep_slip(diameter);
+    const double vs = ((diameter * diameter) * density * GRAV * c_c) / (18.0 * AIR_DYN_VISC);
+    const double diff = (BOLTZMANN * temp * c_c) / (3.0 * PI * AIR_DYN_VISC * diameter);
+    const double sc = 1.45e-5 / diff;
+    const double gamma = (double)(2.0f / 3.0f), c_b = (double).2f, nu = (double)0.8f, c_im = (double)0.4f;
+    double st;
+    if (big_a > 1.0) st = (vs * (ustar * ustar)) / (AIR_DYN_VISC * rrho);
+    else st = (vs * ustar) / (GRAV * big_a);
+    const double eb = c_b * det_pow(sc, -gamma);
+    const double r = st / (alpha + st);
+    const double eim = c_im * (r * r);
+    const double ein = .5 * det_pow(diameter / big_a, nu);
+    const double r1 = det_exp(-__builtin_sqrt(st));
+    const double rs = 1.0 / (3.0 * ustar * (eb + eim + ein) * r1);
+    const double tmp = ra + rs + ra * rs * vs;
+    return (1.0 / tmp) + vs;
 }
 
 } // namespace pmcx

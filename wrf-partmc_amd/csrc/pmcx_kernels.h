@@ -120,6 +120,10 @@ hipError_t launch_transport(const DeviceState &st, int nx, int nz, int ny, int p
                             int periodic_y, const double *prob_h, const double *prob_v,
                             const double *cell_volume, void *outbox, int32_t *n_out, int32_t *n_arr,
                             uint64_t seed, uint32_t step, hipStream_t s);
+// per_cell6: [6][n_cells] aer_res_a, ustar, alpha, big_a, height, inv_density
+hipError_t launch_dry_deposition(const DeviceState &st, double dt, uint64_t seed, uint32_t step,
+                                 const int32_t *surface, const double *per_cell6,
+                                 int32_t *n_removed, int32_t *unrealistic, hipStream_t s);
 hipError_t launch_condense(const DeviceState &st, const double *kappa, const double *rel_humid,
                            double del_t, int n_sub, hipStream_t s);
 hipError_t launch_totals(const DeviceState &st, int64_t *out4, hipStream_t s);

@@ -1907,6 +1907,71 @@ __global__ __launch_bounds__(64) void k_scenario_update(DeviceState st, double d
     }
 }
 
+// ----------------------------------------------------------- dry deposition
+//
+// dry_dep_aero_state (interface/wrf_pmc_dep_aero.F90:154-192) on the cells flagged as
+// surface cells: per particle the Zhang (2001) deposition velocity, removal probability
+// (dt / dz) vd, one uniform keyed by the particle's rank among the live ones.  One
+// wavefront per cell; removed particles become tombstones.
+
+struct DepArgs {
+    const int32_t *surface; // [n_cells] non-zero: the cell touches the ground (NULL: every cell)
+    const double *aer_res_a, *ustar, *alpha, *big_a, *height, *inv_density; // [n_cells]
+    int32_t *n_removed, *unrealistic;                                       // [n_cells]
+};
+
+__global__ __launch_bounds__(64) void k_dry_deposition(DeviceState st, DepArgs a, double dt,
+                                                       uint64_t seed, uint32_t step)
+{
+    const int lane = threadIdx.x;
+    const int c = blockIdx.x;
+    if (a.surface && !a.surface[c]) {
+        if (lane == 0) { a.n_removed[c] = 0; a.unrealistic[c] = 0; }
+        return;
+    }
+    const int64_t cb = (int64_t)c * st.cap;
+    const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const double ra = a.aer_res_a[c], ustar = a.ustar[c], alpha = a.alpha[c], big_a = a.big_a[c];
+    const double rrho = a.inv_density[c], temp = st.temp[c], dt_dz = dt / a.height[c];
+    const int n_hi = st.n_hi[c];
+    uint32_t rank0 = 0;
+    int nd = 0, bad = 0;
+    for (int i0 = 0; i0 < n_hi; i0 += 64) {
+        const int i = i0 + lane;
+        const bool live = i < n_hi && live_class_c(st, cb, i) >= 0;
+        const uint64_t mlive = __ballot(live);
+        bool drop = false;
+        if (live) {
+            const double v = st.vm[cb + i].x, m = st.vm[cb + i].y;
+            const double diam = 2.0 * det_cbrt(v * (0.75 / PI));
+            const double vd = dep_velocity(diam, m / v, temp, rrho, ustar, ra, alpha, big_a);
+            const double prob = dt_dz * vd;
+            bad |= (prob >= 1.0) | (prob <= 0.0);
+            uint32_t w[4];
+            rng_block(seed, cell_id, step, rank0 + (uint32_t)__popcll(mlive & lt), SITE_DEPOSIT, 0, w);
+            drop = u53(w[0], w[1]) < prob;
+        }
+        if (drop) mark_dead(st, cb, i);
+        nd += __popcll(__ballot(drop));
+        rank0 += (uint32_t)__popcll(mlive);
+    }
+    bad = __ballot(bad != 0) != 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wave_sync();
+    if (lane == 0) {
+        st.n_part[c] = st.n_part[c] - nd;
+        if (nd) st.sort_valid[c] = 0;
+        a.n_removed[c] = nd;
+        a.unrealistic[c] = bad;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __threadfence_block();
+    wave_sync();
+    const int hi = st.n_hi[c], live_n = st.n_part[c];
+    if ((hi - live_n) * 8 > hi) compact_wave(st, c, lane);
+}
+
 // ---------------------------------------------------------------- transport
 //
 // Stochastic particle transport between the cells of a block:
@@ -2276,6 +2341,11 @@ __global__ void k_test_math(int op, int64_t n, const double *a, const double *b,
         r = kernel_pair(ktype, a[i], c3[i], qa, qb, kp);
         break;
     }
+    case 8: // dry-deposition velocity: diameter, density, ustar, aer_res_a; pressure = 1/rho_air;
+            // ktype 0: grass (alpha 1.2, A 2 mm), 1: water (alpha 100, A = 9.999: the A > 1 branch)
+        r = dep_velocity(a[i], b[i], temp, pressure, c3[i], c4[i], ktype ? 100.0 : 1.2,
+                         ktype ? 9.999 : 0.002);
+        break;
     default: break;
     }
     out[i] = r;
@@ -2532,6 +2602,16 @@ hipError_t launch_transport(const DeviceState &st, int nx, int nz, int ny, int p
     hipLaunchKernelGGL(k_trans_decide, dim3(st.n_cells), dim3(64), lds, s, st, tg, seed, step);
     hipLaunchKernelGGL(k_trans_gather, dim3(st.n_cells), dim3(64), 0, s, st, tg);
     hipLaunchKernelGGL(k_trans_remove, dim3(st.n_cells), dim3(64), 0, s, st, tg);
+    return hipGetLastError();
+}
+hipError_t launch_dry_deposition(const DeviceState &st, double dt, uint64_t seed, uint32_t step,
+                                 const int32_t *surface, const double *per_cell6,
+                                 int32_t *n_removed, int32_t *unrealistic, hipStream_t s)
+{
+    const size_t nc = (size_t)st.n_cells;
+    DepArgs a{surface, per_cell6, per_cell6 + nc, per_cell6 + 2 * nc, per_cell6 + 3 * nc,
+              per_cell6 + 4 * nc, per_cell6 + 5 * nc, n_removed, unrealistic};
+    hipLaunchKernelGGL(k_dry_deposition, dim3(st.n_cells), dim3(64), 0, s, st, a, dt, seed, step);
     return hipGetLastError();
 }
 hipError_t launch_condense(const DeviceState &st, const double *kappa, const double *rel_humid,

@@ -58,3 +58,28 @@ def idealised_modes(n_spec, n_modes=1):
     vf[0] = 1.0
     return [dict(frac=1.0, gm_radius=2e-8, gsd_log10=0.25, vol_frac=vf, wclass=m, source=m)
             for m in range(n_modes)]
+
+
+# Zhang et al. (2001) land-use parameters of the dry-deposition scheme as tabulated in
+# interface/wrf_pmc_dep_aero.F90: USGS -> Zhang land-use map (:66-92), impaction parameter
+# alpha (:99-102) and collector radius A [m] by (season, land use) (:104-121).  The land-use
+# gamma (:94-97) is overwritten by the reference (:325) and therefore not needed.
+ZHANG_FROM_USGS = (15, 7, 7, 7, 7, 10, 6, 6, 6, 6, 4, 3, 2, 1, 5, 14, 11, 10, 8, 9, 10, 9, 8, 12, 8)
+ZHANG_ALPHA = (1.0, 0.6, 1.1, 0.8, 0.8, 1.2, 1.2, 50.0, 50.0, 1.3, 2.0, 50.0, 100.0, 100.0, 1.5)
+ZHANG_A = (  # [land use][season]
+    (0.002,) * 5, (0.005,) * 5, (0.002, 0.002, 0.005, 0.005, 0.002), (0.005, 0.005, 0.010, 0.010, 0.005),
+    (0.005,) * 5, (0.002, 0.002, 0.005, 0.005, 0.002), (0.002, 0.002, 0.005, 0.005, 0.002),
+    (9.999,) * 5, (9.999,) * 5, (0.010,) * 5, (0.010,) * 5, (9.999,) * 5, (9.999,) * 5, (9.999,) * 5,
+    (0.010,) * 5)
+
+
+def zhang_surface_parameters(ivgtyp, season=1):
+    """(alpha, A) of the dry-deposition scheme for USGS vegetation types `ivgtyp`, as
+    dep_aero_dry_driver selects them (wrf_pmc_dep_aero.F90:131-151: modesurftype = 2,
+    iseason = 1; types outside 1..25 fall back to Zhang type 7)."""
+    import numpy as np
+    iv = np.atleast_1d(np.asarray(ivgtyp, dtype=np.int64))
+    z = np.where((iv >= 1) & (iv <= 25), np.asarray(ZHANG_FROM_USGS)[np.clip(iv, 1, 25) - 1], 7)
+    alpha = np.asarray(ZHANG_ALPHA)[z - 1]
+    big_a = np.asarray([row[season - 1] for row in ZHANG_A])[z - 1]
+    return alpha, big_a

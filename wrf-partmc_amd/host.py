@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = [
     "pmcx_diagnostics", "pmcx_diagnostics_ext",
     "pmcx_generate_lognormal", "pmcx_timestep", "pmcx_get_bin_tables", "pmcx_get_diag_grid",
     "pmcx_get_kmax", "pmcx_get_caches", "pmcx_sort_only", "pmcx_invalidate_sort", "pmcx_get_sort", "pmcx_test_math",
-    "pmcx_test_philox", "pmcx_profile_enable", "pmcx_profile_reset", "pmcx_profile_get", "pmcx_profile_phase_cycles",
+    "pmcx_test_philox", "pmcx_profile_enable", "pmcx_profile_reset", "pmcx_profile_get", "pmcx_profile_phase_cycles", "pmcx_dry_deposition",
     "pmcx_memory_bytes",
 ]
 
@@ -123,6 +123,7 @@ def load_library():
     L.pmcx_profile_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double),
                                    C.POINTER(C.c_int64)]
     L.pmcx_profile_phase_cycles.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    L.pmcx_dry_deposition.argtypes = [C.c_void_p, C.c_double, C.c_uint64, C.c_uint32] + [C.c_void_p] * 9
     L.pmcx_timestep.argtypes = [C.c_void_p, C.POINTER(PmcxStepFlags)]
     for name in ("pmcx_upload_cells", "pmcx_download_cells"):
         getattr(L, name).argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 7
@@ -343,6 +344,20 @@ class CellBlock:
             self._h, dt, elapsed_time, seed, step, C.addressof(e) if e else None, _ptr(dil),
             C.addressof(b) if b else None, _ptr(ne), _ptr(ni), _ptr(no)))
         return ne, ni, no
+
+    def dry_deposition(self, dt, aer_res_a, ustar, alpha, big_a, height, inv_density, seed=0,
+                       step=0, surface=None):
+        """dry_dep_aero_state on the surface cells (wrf_pmc_dep_aero.F90:154-192).
+        Per-cell inputs broadcast to [n_cells]; surface: 0/1 per cell (None: every cell).
+        Returns (n_removed, unrealistic) per cell."""
+        n = self.cfg.n_cells
+        arr = [np.ascontiguousarray(np.broadcast_to(_f64(x), (n,))) for x in
+               (aer_res_a, ustar, alpha, big_a, height, inv_density)]
+        sf = None if surface is None else np.ascontiguousarray(np.broadcast_to(surface, (n,)), dtype=np.int32)
+        nr, bad = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+        self._ck(self._lib.pmcx_dry_deposition(self._h, dt, seed, step, _ptr(sf), *[_ptr(a) for a in arr],
+                                               _ptr(nr), _ptr(bad)))
+        return nr, bad
 
     def transport(self, nx, nz, ny, prob_h, prob_v, cell_volume, seed=0, step=0, periodic_x=True,
                   periodic_y=True):
