@@ -520,3 +520,17 @@ def test_dry_deposition_removal_statistics(oracle):
     assert int(c.sort_valid[0]) == 0
     nd2, bad2 = c.dry_deposition(1e6, 5, 0, 1, ra, us, 1.2, 0.002, dz, 1 / 1.2)   # absurd step
     assert bad2 == 1 and int(c.n_part[0]) == 0
+
+
+def test_aerodynamic_resistance_and_landuse_tables():
+    """Host-side inputs of dry deposition: depvel_partmc (wrf_pmc_dep.F90:188-213) and the
+    Zhang land-use selection (wrf_pmc_dep_aero.F90:66-151)."""
+    from wrf_partmc_amd.data import aerodynamic_resistance, zhang_surface_parameters
+    ra = aerodynamic_resistance([0.0, 0.02, -0.02, 1e-7], 0.1, 0.3)
+    assert abs(ra[0] - 0.74 * np.log(2.0 / 0.1) / (0.4 * 0.3)) < 1e-12
+    assert ra[3] == ra[0]                       # |rmol| < 1e-6 is neutral
+    assert ra[1] > ra[0] > ra[2] > 0            # stable > neutral > unstable
+    assert aerodynamic_resistance(0.0, 0.1, 0.0) == 0.74 * np.log(20.0) / (0.4 * 1e-4)
+    alpha, big_a = zhang_surface_parameters([1, 7, 16, 24, 0, 99])
+    assert list(alpha) == [1.5, 1.2, 100.0, 50.0, 1.2, 1.2]        # urban, grass, water, ice, fallback
+    assert list(big_a) == [0.010, 0.002, 9.999, 9.999, 0.002, 0.002]

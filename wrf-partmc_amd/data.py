@@ -83,3 +83,21 @@ def zhang_surface_parameters(ivgtyp, season=1):
     alpha = np.asarray(ZHANG_ALPHA)[z - 1]
     big_a = np.asarray([row[season - 1] for row in ZHANG_A])[z - 1]
     return alpha, big_a
+
+
+def aerodynamic_resistance(rmol, z0, ustar, zr=2.0):
+    """Aerodynamic resistance [s/m] that dry deposition receives per column: depvel_partmc
+    (interface/wrf_pmc_dep.F90:188-213; called with zr = 2 m, z0 = grid%znt, rmol = 1/L the
+    inverse Monin-Obukhov length, :85-91).  Host-side, one value per column."""
+    import numpy as np
+    rmol = np.where(np.abs(np.asarray(rmol, dtype=np.float64)) < 1.0e-6, 0.0, rmol)
+    z0 = np.asarray(z0, dtype=np.float64)
+    ustar = np.asarray(ustar, dtype=np.float64)
+    neutral = 0.74 * np.log(zr / z0)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ar = ((1.0 - 9.0 * zr * rmol) ** 0.25 + 0.001) ** 2
+        ao = ((1.0 - 9.0 * z0 * rmol) ** 0.25 + 0.001) ** 2
+        unstable = 0.74 * (np.log((ar - 1.0) / (ar + 1.0)) - np.log((ao - 1.0) / (ao + 1.0)))
+    stable = neutral + 4.7 * rmol * (zr - z0)
+    polint = np.where(rmol < 0.0, unstable, np.where(rmol == 0.0, neutral, stable))
+    return polint / (0.40 * np.maximum(ustar, 1.0e-4))
