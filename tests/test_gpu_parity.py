@@ -418,6 +418,34 @@ def test_dry_deposition_parity(wp, oracle):
     blk.close()
 
 
+def test_column_file_output_and_restart(wp, oracle, tmp_path):
+    """device state -> column file (output_column_to_file_new layout) -> a fresh
+    block (init_read_in_restart): ids, classes, create times, source counts, weights, next_id
+    identical; species volumes to one rounding (the file stores mass = vol * density)."""
+    counts = [700, 0, 333, 41]
+    blk, cells = _ragged_pair(wp, oracle, counts, n_spec=2, n_class=2, cap=1024)
+    for step in range(2):
+        blk.mc_coag(K_BROWN, 6000.0, 4, step)
+    blk.set_next_id(np.arange(4, dtype=np.int64) + (7 << 40))
+    path = blk.output_column(str(tmp_path / "col"), 3, 9, 17, 0, 4, ["SO4", "OC"], time=51.0, del_t=3.0)
+    assert path.endswith("col_003_009_00000017.nc")
+    a = blk.download_cells()
+    b2 = wp.CellBlock(4, 1024, 2, n_class=2, n_source=2)
+    b2.set_aero_data(parity.default_species(2)[1])
+    b2.set_env(280.0, 9e4)
+    col = b2.restart_column(path, 0)
+    assert col["time"] == 51.0 and col["index"] == 17 and col["next_id"] == (7 << 40) + 3
+    b = b2.download_cells()
+    for k in ("part_offset", "wclass", "id", "least_ct", "greatest_ct", "n_orig"):
+        assert np.array_equal(a[k], b[k]), k
+    np.testing.assert_allclose(b["vol"], a["vol"], rtol=3e-16, atol=0)
+    assert np.array_equal(b2.get_weights(), blk.get_weights())
+    assert (b2.get_next_id() == (7 << 40) + 3).all()
+    ns, nc, st = b2.mc_coag(K_BROWN, 6000.0, 4, 2)            # the restarted block runs on
+    assert nc.sum() > 0 and not st.any()
+    blk.close(); b2.close()
+
+
 def test_maximum_capacity_cell(wp, oracle):
     """The largest cell the sampler's 16-bit list offsets allow: cap + cap/8 + 16 G <= 65535."""
     with pytest.raises(wp.PmcxError):

@@ -534,3 +534,97 @@ def test_aerodynamic_resistance_and_landuse_tables():
     alpha, big_a = zhang_surface_parameters([1, 7, 16, 24, 0, 99])
     assert list(alpha) == [1.5, 1.2, 100.0, 50.0, 1.2, 1.2]        # urban, grass, water, ice, fallback
     assert list(big_a) == [0.010, 0.002, 9.999, 9.999, 0.002, 0.002]
+
+
+def test_cdf_codec_against_scipy(tmp_path):
+    """The self-contained NetCDF encoder/decoder of ncio.py (no netCDF library in this image):
+    its CDF-2 files are read by scipy.io.netcdf_file, it reads scipy's, and the CDF-5 variant
+    (needed for the reference's 64-bit aero_id / next_id) differs only in 8-byte counts."""
+    from scipy.io import netcdf_file
+    from wrf_partmc_amd import ncio
+    rng = np.random.RandomState(0)
+    a = rng.standard_normal((3, 5)); b = rng.randint(-9, 9, 7).astype(np.int32)
+    w = ncio.CdfWriter(version=2)
+    w.att("title", "t"); w.att("n", np.int32(4))
+    w.dim("x", 3); w.dim("y", 5); w.dim("z", 7)
+    w.var("a", ["x", "y"], a, unit="m", long_name="an array")
+    w.var("b", ["z"], b)
+    p = str(tmp_path / "mine.nc"); w.write(p)
+    f = netcdf_file(p, "r", mmap=False)
+    assert f.dimensions == {"x": 3, "y": 5, "z": 7} and f.title == b"t" and f.n == 4
+    assert np.array_equal(f.variables["a"][:], a) and f.variables["a"].unit == b"m"
+    assert f.variables["a"].dimensions == ("x", "y") and np.array_equal(f.variables["b"][:], b)
+    f.close()
+    q = str(tmp_path / "theirs.nc")
+    g = netcdf_file(q, "w", version=2)
+    g.history = "h"; g.createDimension("p", 4); g.createDimension("s", 2)
+    v = g.createVariable("m", "d", ("s", "p")); v[:] = np.arange(8.0).reshape(2, 4); v.unit = "kg"
+    g.createVariable("k", "i", ("p",))[:] = [1, 2, 3, 4]
+    g.close()
+    dims, gatts, vs = ncio.read_cdf(q)
+    assert dims == {"p": 4, "s": 2} and gatts["history"] == "h"
+    assert np.array_equal(vs["m"][0], np.arange(8.0).reshape(2, 4)) and vs["m"][1]["unit"] == "kg"
+    assert vs["m"][2] == ["s", "p"] and list(vs["k"][0]) == [1, 2, 3, 4]
+    w5 = ncio.CdfWriter(version=5)
+    w5.dim("n", 3)
+    big = np.array([1 << 40, -(1 << 50), 7], dtype=np.int64)
+    w5.var("id", ["n"], big, nc_type=ncio.NC_INT64, long_name="ids")
+    p5 = str(tmp_path / "five.nc"); w5.write(p5)
+    raw = open(p5, "rb").read()
+    assert raw[:4] == b"CDF\x05" and raw[4:12] == b"\x00" * 8          # magic, numrecs (8 bytes)
+    dims, _, vs = ncio.read_cdf(p5)
+    assert dims == {"n": 3} and np.array_equal(vs["id"][0], big) and vs["id"][0].dtype == np.int64
+
+
+def test_column_file_round_trip(oracle, tmp_path):
+    """a column written in the layout of output_column_to_file_new
+    (wrf_pmc_driver.F90:1508-1653) and read back the way init_read_in_restart does
+    (wrf_pmc_init.F90:1084-1286): names, dimensions, 1-based indices, mass = vol * density."""
+    from wrf_partmc_amd import ncio
+    from wrf_partmc_amd.data import aero_data_arrays
+    dens, kappa, mw, names = aero_data_arrays()
+    ve, vs = oracle.make_bin_tables(80, 1e-10, 1e-2)
+    vf = np.zeros(20); vf[[0, 3, 17]] = [0.36, 0.14, 0.5]
+    modes = [dict(frac=0.6, gm_radius=1e-8, gsd_log10=0.161, vol_frac=vf, wclass=0, source=0),
+             dict(frac=0.4, gm_radius=5.8e-8, gsd_log10=0.217, vol_frac=vf, wclass=1, source=2)]
+    counts = [300, 0, 120, 77]
+    cells = []
+    for k, n in enumerate(counts):
+        c = oracle.Cell(20, 2, 3, 512, dens, ve, 280.0, 9e4)
+        c.mag[:] = [1e7 + k, 3e7 + k]
+        c.generate(modes, n, 2, k, first_id=(k << 40) + 5)
+        c.kmax[:] = oracle.kmax_table(4, vs, dens.min(), dens.max(), 280.0, 9e4)
+        for s in range(3):
+            c.mc_coag(4, 4000.0, 2, k, s)           # merged particles: several constituents
+        cells.append(c)
+    n_live = [int(c.n_part[0]) for c in cells]
+    po = np.concatenate([[0], np.cumsum(n_live)])
+    cat = lambda f: np.concatenate([f(c, n) for c, n in zip(cells, n_live)], axis=-1)
+    state = dict(vol=cat(lambda c, n: c.vol[:, :n]), wclass=cat(lambda c, n: c.wclass[:n]),
+                 ids=cat(lambda c, n: c.id[:n]), least_ct=cat(lambda c, n: c.lct[:n]),
+                 greatest_ct=cat(lambda c, n: c.gct[:n]), n_orig=cat(lambda c, n: c.n_orig[:, :n]))
+    wmag = np.array([c.mag for c in cells])
+    path = ncio.column_filename(str(tmp_path / "out"), 12, 7, 42)
+    assert path.endswith("out_012_007_00000042.nc")
+    ncio.write_column(path, species_names=names, density=dens, part_offset=po, weight_magnitude=wmag,
+                      next_id=(9 << 40) + 1, time=126.0, del_t=3.0, index=42, kappa=kappa,
+                      molec_weight=mw, gas_names=["so2", "o3"], gas_mixing_ratio=np.ones((4, 2)), **state)
+    dims, gatts, v = ncio.read_cdf(path)
+    assert dims["number_levels"] == 4 and dims["aero_particle"] == po[-1] and dims["aero_species"] == 20
+    assert dims["aero_weight_class"] == 2 and dims["aero_weight_group"] == 1
+    assert v["aero_particle_mass"][2] == ["aero_species", "aero_particle"] and v["aero_particle_mass"][1]["unit"] == "kg"
+    assert v["weight_magnitude"][2] == ["aero_weight_class", "aero_weight_group", "number_levels"]
+    assert v["gas_mixing_ratio"][2] == ["gas_species", "number_levels"]
+    assert list(v["part_start_index"][0]) == list(po[:-1] + 1) and list(v["n_parts"][0]) == n_live
+    assert v["aero_id"][0].dtype == np.int64 and v["aero_species"][1]["names"].split(",")[:3] == ["SO4", "NO3", "Cl"]
+    clen, cstart = v["aero_component_len"][0], v["aero_component_start_ind"][0]
+    assert np.array_equal(clen, state["n_orig"].sum(0)) and clen.max() > 1
+    assert np.array_equal(cstart, 1 + np.concatenate([[0], np.cumsum(clen)[:-1]]))
+    assert np.array_equal(v["aero_num_conc"][0], wmag[np.repeat(np.arange(4), n_live), state["wclass"]])
+    back = ncio.read_column(path)
+    assert np.array_equal(back["part_offset"], po) and back["next_id"] == (9 << 40) + 1
+    for k in ("wclass", "ids", "least_ct", "greatest_ct", "n_orig"):
+        assert np.array_equal(back[k], state[k]), k
+    assert np.array_equal(back["weight_magnitude"], wmag) and back["time"] == 126.0 and back["index"] == 42
+    # mass = vol * density, vol = mass / density (:1421, init:1232): exact to one rounding each way
+    np.testing.assert_allclose(back["vol"], state["vol"], rtol=3e-16, atol=0)

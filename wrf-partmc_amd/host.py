@@ -191,6 +191,7 @@ class CellBlock:
     def set_aero_data(self, density, kappa=None, molec_weight=None):
         d = _f64(density)
         assert d.shape == (self.cfg.n_spec,)
+        self._density = d.copy()
         self._ck(self._lib.pmcx_set_aero_data(self._h, _ptr(d), _ptr(_f64(kappa)),
                                               _ptr(_f64(molec_weight))))
 
@@ -236,6 +237,43 @@ class CellBlock:
         self._ck(self._lib.pmcx_upload_cells(self._h, cell_first, n_up, _ptr(po), _ptr(v),
                                              _ptr(wc), _ptr(ii), _ptr(_f64(least_ct)),
                                              _ptr(_f64(greatest_ct)), _ptr(no)))
+
+    # -- column files ------------------------------------------
+    def output_column(self, prefix, ix, iy, index, cell_first, nz, species_names, time=0.0,
+                      del_t=0.0, **extra):
+        """Writes cells [cell_first, cell_first + nz) as one column file in the layout of
+        output_column_to_file_new (wrf_pmc_driver.F90:1292-1658); returns the path."""
+        from . import ncio
+        dn = self.download_cells(cell_first, nz)
+        path = ncio.column_filename(prefix, ix, iy, index)
+        ncio.write_column(
+            path, species_names=species_names, density=self._density, part_offset=dn["part_offset"],
+            vol=dn["vol"], wclass=dn["wclass"], ids=dn["id"], least_ct=dn["least_ct"],
+            greatest_ct=dn["greatest_ct"], n_orig=dn["n_orig"] if self.cfg.n_source > 0 else None,
+            weight_magnitude=self.get_weights()[cell_first:cell_first + nz],
+            next_id=int(self.get_next_id()[cell_first:cell_first + nz].max()),
+            time=time, del_t=del_t, index=index, cell_ix=ix, cell_iy=iy, **extra)
+        return path
+
+    def restart_column(self, path, cell_first):
+        """Loads a column file the way init_read_in_restart does (wrf_pmc_init.F90:1084-1286):
+        particles, weights and next_id of cells [cell_first, cell_first + nz)."""
+        from . import ncio
+        col = ncio.read_column(path)
+        nz = len(col["part_offset"]) - 1
+        no = col["n_orig"]
+        if self.cfg.n_source > 0:
+            assert no.shape[0] <= self.cfg.n_source, "file has more sources than the block"
+            no = np.vstack([no, np.zeros((self.cfg.n_source - no.shape[0], no.shape[1]), np.int32)])
+        self.upload_cells(cell_first, col["part_offset"], col["vol"], col["wclass"], col["ids"],
+                          col["least_ct"], col["greatest_ct"], no if self.cfg.n_source > 0 else None)
+        w = self.get_weights()
+        w[cell_first:cell_first + nz] = col["weight_magnitude"]
+        self.set_weights(w)
+        nid = self.get_next_id()
+        nid[cell_first:cell_first + nz] = col["next_id"]
+        self.set_next_id(nid)
+        return col
 
     def aero_state_total_particles(self):
         """n_part of every cell (reference: aero_state_total_particles, driver:143,174)."""
