@@ -515,9 +515,10 @@ int pmcx_upload_cells(pmcx_ctx *ctx, int32_t cell_first, int32_t n_up, const int
     const int64_t c0 = cell_first;
     if (nt > 0) {
         const double *s_vol = (const double *)h2d(vol, sizeof(double) * cf.n_spec * (size_t)nt);
+        // device layout [cap][n_spec]: species s of particle i at i * n_spec + s
         HIP_TRY(ctx, launch_scatter_f64(s_vol, st.vol + c0 * cf.n_spec * cap, ctx->d_offsets, n_up,
                                         cf.cap, (int64_t)cf.n_spec * cap, nt, cf.n_spec,
-                                        (int64_t)cap, ctx->stream));
+                                        (int64_t)1, ctx->stream, cf.n_spec));
         if (wclass) {
             const int32_t *s = (const int32_t *)h2d(wclass, sizeof(int32_t) * (size_t)nt);
             HIP_TRY(ctx, launch_scatter_i32(s, st.wclass + c0 * cap, ctx->d_offsets, n_up, cf.cap,
@@ -529,24 +530,24 @@ int pmcx_upload_cells(pmcx_ctx *ctx, int32_t cell_first, int32_t n_up, const int
         if (id) {
             const double *s = (const double *)h2d(id, sizeof(int64_t) * (size_t)nt);
             HIP_TRY(ctx, launch_scatter_f64(s, (double *)&st.meta[c0 * cap].id, ctx->d_offsets, n_up,
-                                            cf.cap, (int64_t)cap, nt, 1, (int64_t)cap, ctx->stream, 4));
+                                            cf.cap, (int64_t)cap * 4, nt, 1, (int64_t)cap, ctx->stream, 4));
         }
         if (least_ct) {
             const double *s = (const double *)h2d(least_ct, sizeof(double) * (size_t)nt);
             HIP_TRY(ctx, launch_scatter_f64(s, &st.meta[c0 * cap].lct, ctx->d_offsets, n_up, cf.cap,
-                                            (int64_t)cap, nt, 1, (int64_t)cap, ctx->stream, 4));
+                                            (int64_t)cap * 4, nt, 1, (int64_t)cap, ctx->stream, 4));
         }
         if (greatest_ct) {
             const double *s = (const double *)h2d(greatest_ct, sizeof(double) * (size_t)nt);
             HIP_TRY(ctx, launch_scatter_f64(s, &st.meta[c0 * cap].gct, ctx->d_offsets, n_up, cf.cap,
-                                            (int64_t)cap, nt, 1, (int64_t)cap, ctx->stream, 4));
+                                            (int64_t)cap * 4, nt, 1, (int64_t)cap, ctx->stream, 4));
         }
         if (n_orig && cf.n_source > 0) {
             const int32_t *s =
                 (const int32_t *)h2d(n_orig, sizeof(int32_t) * cf.n_source * (size_t)nt);
             // source 0 lives in the metadata record (8 int32 per record), the rest in planes
             HIP_TRY(ctx, launch_scatter_i32(s, &st.meta[c0 * cap].n_orig0, ctx->d_offsets, n_up,
-                                            cf.cap, (int64_t)cap, nt, 1, (int64_t)cap, ctx->stream, 8));
+                                            cf.cap, (int64_t)cap * 8, nt, 1, (int64_t)cap, ctx->stream, 8));
             if (cf.n_source > 1)
                 HIP_TRY(ctx, launch_scatter_i32(s + nt, st.n_orig + c0 * (cf.n_source - 1) * cap,
                                                 ctx->d_offsets, n_up, cf.cap,
@@ -598,11 +599,11 @@ int pmcx_download_cells(pmcx_ctx *ctx, int32_t cell_first, int32_t n_dn, const i
         // sampler does not keep the plane current): gathered from the (vtot, mass) records
         if (cf.n_spec == 1)
             HIP_TRY(ctx, launch_gather_f64((double *)ctx->stage, &st.vm[c0 * cap].x, ctx->d_offsets,
-                                           n_dn, (int64_t)cap, nt, 1, (int64_t)cap, ctx->stream, 2));
+                                           n_dn, (int64_t)cap * 2, nt, 1, (int64_t)cap, ctx->stream, 2));
         else
         HIP_TRY(ctx, launch_gather_f64((double *)ctx->stage, st.vol + c0 * cf.n_spec * cap,
                                        ctx->d_offsets, n_dn, (int64_t)cf.n_spec * cap, nt,
-                                       cf.n_spec, (int64_t)cap, ctx->stream));
+                                       cf.n_spec, (int64_t)1, ctx->stream, cf.n_spec));
         HIP_TRY(ctx, hipMemcpyAsync(vol, ctx->stage, sizeof(double) * cf.n_spec * (size_t)nt,
                                     hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -610,7 +611,7 @@ int pmcx_download_cells(pmcx_ctx *ctx, int32_t cell_first, int32_t n_dn, const i
     // dev: first element of cell 0; es: element stride (2 for half of an interleaved pair)
     auto one_f64 = [&](double *host, const double *dev, int es = 1) -> int {
         HIP_TRY(ctx, launch_gather_f64((double *)ctx->stage, dev + c0 * cap * es, ctx->d_offsets, n_dn,
-                                       (int64_t)cap, nt, 1, (int64_t)cap, ctx->stream, es));
+                                       (int64_t)cap * es, nt, 1, (int64_t)cap, ctx->stream, es));
         HIP_TRY(ctx, hipMemcpyAsync(host, ctx->stage, sizeof(double) * (size_t)nt,
                                     hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -628,7 +629,7 @@ int pmcx_download_cells(pmcx_ctx *ctx, int32_t cell_first, int32_t n_dn, const i
     }
     if (n_orig && cf.n_source > 0) {
         HIP_TRY(ctx, launch_gather_i32((int32_t *)ctx->stage, &st.meta[c0 * cap].n_orig0,
-                                       ctx->d_offsets, n_dn, (int64_t)cap, nt, 1, (int64_t)cap,
+                                       ctx->d_offsets, n_dn, (int64_t)cap * 8, nt, 1, (int64_t)cap,
                                        ctx->stream, 8));
         if (cf.n_source > 1)
             HIP_TRY(ctx, launch_gather_i32((int32_t *)ctx->stage + nt,

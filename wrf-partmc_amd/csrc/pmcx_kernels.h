@@ -52,7 +52,7 @@ struct DeviceState {
     int32_t *n_hi;                 // [n_cells] slots in use (live + tombstones)
     int64_t *next_id;              // [n_cells]
     // particles
-    double *vol;     // [n_cells][n_spec][cap]
+    double *vol;     // [n_cells][cap][n_spec]: a particle's species are contiguous
     double2 *vm;     // [n_cells][cap] (cached total volume, cached mass): one request per particle
     int32_t *wclass; // [n_cells][cap]
     Meta *meta;      // [n_cells][cap] create times, id, source-0 count

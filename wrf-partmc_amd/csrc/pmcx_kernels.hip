@@ -7,7 +7,8 @@
 //   partmc_process observables                           driver:783,838-857
 //
 // Layout in HBM (structure of arrays, one slab of `cap` slots per cell):
-//   vol   [n_cells][n_spec][cap] f64   particle%vol(:)
+//   vol   [n_cells][cap][n_spec] f64   particle%vol(:): a particle's species are contiguous,
+//                                      a coagulation touches 3 lines per particle at 20 species
 //   vm    [n_cells][cap] 2 x f64       (cached sum_s vol, cached sum_s density_s*vol):
 //                                      interleaved, a pair evaluation is one request per particle
 //   wclass[n_cells][cap] i32
@@ -104,7 +105,43 @@ __device__ __forceinline__ int live_class_c(const DeviceState &st, int64_t cb, i
 __device__ __forceinline__ double spec_vol(const DeviceState &st, int64_t cb, int s, int i)
 {
     if (st.n_spec == 1) return st.vm[cb + i].x;
-    return st.vol[cb * st.n_spec + (int64_t)s * st.cap + i];
+    return st.vol[(cb + i) * st.n_spec + s];
+}
+
+// Species s of the particle whose record starts at rec (a particle's species are
+// contiguous).  Full-population passes walk a record with 16-byte loads when the species
+// count is even: species_pair(rec, s) returns species s and s + 1 for even s.
+__device__ __forceinline__ double2 species_pair(const double *rec, int s)
+{
+    return *(const double2 *)(rec + s);
+}
+
+// Species of 64 consecutive particles staged through LDS, for the memory-bound passes over
+// the whole population: the records of consecutive particles are contiguous, so the
+// wavefront loads them coalesced (element j of the block to tile[p * (S + 1) + s]) and each
+// lane then reads its own record tile[lane * (S + 1) + s] (the odd row length keeps the
+// lanes on different banks).  Every lane of the wavefront must call it; i0 is a multiple of 64.
+__host__ __device__ inline size_t species_tile_bytes(int n_spec, int waves)
+{
+    return n_spec > 1 ? sizeof(double) * 64 * (size_t)(n_spec + 1) * (size_t)waves : 0;
+}
+__device__ __forceinline__ void stage_species(const DeviceState &st, int64_t cb, int i0, int n,
+                                              double *tile, int lane)
+{
+    const int S = st.n_spec;
+    int np = n - i0;
+    np = np > 64 ? 64 : (np < 0 ? 0 : np);
+    const int cnt = np * S;
+    const double *src = st.vol + (cb + i0) * S;
+    int p = lane / S, sp = lane - p * S;
+    const int q = 64 / S, r = 64 - q * S;
+    wave_sync(); // the previous tile has been consumed
+    for (int j = lane; j < cnt; j += 64) {
+        tile[p * (S + 1) + sp] = src[j];
+        p += q; sp += r;
+        if (sp >= S) { sp -= S; p++; }
+    }
+    wave_sync();
 }
 
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x, int lane)
@@ -143,18 +180,20 @@ __device__ __forceinline__ int bin_index(const double *v_edge, int n_bin, double
 // ------------------------------------------------------------ upload/download
 
 // packed [n_total] (cell-major) -> slab [n_cells][cap]
-// (es = element stride of the slab: 2 for one half of an interleaved pair array)
+// (es = stride between consecutive particles in the slab, in elements: 1 for a plane,
+// the record length for one field of a record array)
 __global__ void k_scatter_f64(const double *__restrict__ src, double *__restrict__ dst,
                               const int64_t *__restrict__ part_offset, int n_up, int cap,
                               int64_t dst_cell_stride, int64_t src_row_stride, int n_rows,
                               int64_t dst_row_stride, int es)
 {
+    // destination element of (cell k, row r, particle i): k * cell_stride + r * row_stride + i * es
     const int k = blockIdx.y;
     const int64_t o0 = part_offset[k], n = part_offset[k + 1] - o0;
     for (int r = 0; r < n_rows; r++)
         for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
              i += (int64_t)gridDim.x * blockDim.x)
-            dst[((int64_t)k * dst_cell_stride + r * dst_row_stride + i) * es] =
+            dst[(int64_t)k * dst_cell_stride + r * dst_row_stride + i * es] =
                 src[r * src_row_stride + o0 + i];
 }
 __global__ void k_scatter_i32(const int32_t *__restrict__ src, int32_t *__restrict__ dst,
@@ -162,37 +201,40 @@ __global__ void k_scatter_i32(const int32_t *__restrict__ src, int32_t *__restri
                               int64_t dst_cell_stride, int64_t src_row_stride, int n_rows,
                               int64_t dst_row_stride, int es)
 {
+    // destination element of (cell k, row r, particle i): k * cell_stride + r * row_stride + i * es
     const int k = blockIdx.y;
     const int64_t o0 = part_offset[k], n = part_offset[k + 1] - o0;
     for (int r = 0; r < n_rows; r++)
         for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
              i += (int64_t)gridDim.x * blockDim.x)
-            dst[((int64_t)k * dst_cell_stride + r * dst_row_stride + i) * es] =
+            dst[(int64_t)k * dst_cell_stride + r * dst_row_stride + i * es] =
                 src[r * src_row_stride + o0 + i];
 }
 __global__ void k_gather_f64(double *__restrict__ dst, const double *__restrict__ src,
                              const int64_t *__restrict__ part_offset, int64_t src_cell_stride,
                              int64_t dst_row_stride, int n_rows, int64_t src_row_stride, int es)
 {
+    // source element of (cell k, row r, particle i): k * cell_stride + r * row_stride + i * es
     const int k = blockIdx.y;
     const int64_t o0 = part_offset[k], n = part_offset[k + 1] - o0;
     for (int r = 0; r < n_rows; r++)
         for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
              i += (int64_t)gridDim.x * blockDim.x)
             dst[r * dst_row_stride + o0 + i] =
-                src[((int64_t)k * src_cell_stride + r * src_row_stride + i) * es];
+                src[(int64_t)k * src_cell_stride + r * src_row_stride + i * es];
 }
 __global__ void k_gather_i32(int32_t *__restrict__ dst, const int32_t *__restrict__ src,
                              const int64_t *__restrict__ part_offset, int64_t src_cell_stride,
                              int64_t dst_row_stride, int n_rows, int64_t src_row_stride, int es)
 {
+    // source element of (cell k, row r, particle i): k * cell_stride + r * row_stride + i * es
     const int k = blockIdx.y;
     const int64_t o0 = part_offset[k], n = part_offset[k + 1] - o0;
     for (int r = 0; r < n_rows; r++)
         for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
              i += (int64_t)gridDim.x * blockDim.x)
             dst[r * dst_row_stride + o0 + i] =
-                src[((int64_t)k * src_cell_stride + r * src_row_stride + i) * es];
+                src[(int64_t)k * src_cell_stride + r * src_row_stride + i * es];
 }
 __global__ void k_set_n_part(int32_t *n_part, int32_t *n_hi, const int64_t *part_offset, int n_up)
 {
@@ -209,10 +251,19 @@ __global__ void k_refresh_caches(DeviceState st, int cell_first, int n_cells_do)
     const int c = cell_first + blockIdx.y;
     const int n = st.n_part[c];
     const int64_t cb = (int64_t)c * st.cap;
+    const int S = st.n_spec;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double *rec = st.vol + (cb + i) * S;
         double vt = 0.0, ms = 0.0;
-        for (int s = 0; s < st.n_spec; s++) {
-            const double v = st.vol[(cb * st.n_spec) + (int64_t)s * st.cap + i];
+        int s = 0;
+        if ((S & 1) == 0)
+            for (; s < S; s += 2) {
+                const double2 v = species_pair(rec, s);
+                vt = vt + v.x; ms = ms + st.density[s] * v.x;
+                vt = vt + v.y; ms = ms + st.density[s + 1] * v.y;
+            }
+        for (; s < S; s++) {
+            const double v = rec[s];
             vt = vt + v;
             ms = ms + st.density[s] * v;
         }
@@ -858,8 +909,8 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
         for (int k = 0; k < 3; k++) {
             const int sp = gl + k * L;
             if (sp < S) {
-                mv_a[k] = ld_f64(&st.vol[cb * S + (int64_t)sp * st.cap + pn]);
-                mv_b[k] = ld_f64(&st.vol[cb * S + (int64_t)sp * st.cap + po]);
+                mv_a[k] = ld_f64(&st.vol[(cb + pn) * S + sp]);
+                mv_b[k] = ld_f64(&st.vol[(cb + po) * S + sp]);
             }
         }
         double lo_n = 0, lo_o = 0, go_n = 0, go_o = 0;
@@ -887,11 +938,11 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const int sp = gl + k * L;
-                if (sp < S) st_f64(&st.vol[cb * S + (int64_t)sp * st.cap + pn], mv_a[k] + mv_b[k]);
+                if (sp < S) st_f64(&st.vol[(cb + pn) * S + sp], mv_a[k] + mv_b[k]);
             }
             for (int sp = gl + 3 * L; sp < S; sp += L) { // more than 3*L species: plain loop
-                double *a = &st.vol[cb * S + (int64_t)sp * st.cap + pn];
-                st_f64(a, ld_f64(a) + ld_f64(&st.vol[cb * S + (int64_t)sp * st.cap + po]));
+                double *a = &st.vol[(cb + pn) * S + sp];
+                st_f64(a, ld_f64(a) + ld_f64(&st.vol[(cb + po) * S + sp]));
             }
             for (int sp = gl; sp < NS; sp += L) {
                 uint32_t *a = (uint32_t *)&norig(st, cb, sp, pn);
@@ -1234,7 +1285,7 @@ __global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype, d
             v1 = a1.x; m1 = a1.y; v2 = a2.x; m2 = a2.y;
             // (with one species the volume of that species IS the cached total: both are sums
             // of the same terms)
-            if (S > 1) { vol1 = st.vol[cb * S + p1]; vol2 = st.vol[cb * S + p2]; }
+            if (S > 1) { vol1 = st.vol[(cb + p1) * S]; vol2 = st.vol[(cb + p2) * S]; }
             // (the record's two 16-byte halves are two requests: the second only when sources exist)
             lct1 = meta[p1].lct; gct1 = meta[p1].gct; lct2 = meta[p2].lct; gct2 = meta[p2].gct;
             if (NS > 0) { no1 = meta[p1].n_orig0; no2 = meta[p2].n_orig0; }
@@ -1358,19 +1409,19 @@ __global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype, d
                 }
                 vm[pn] = make_double2(vn, mn);
                 // species volumes, source histogram, create times, class [aero_particle_coagulate]
-                if (S > 1) st.vol[cb * S + pn] = (pn_is_1 ? vol1 : vol2) + (pn_is_1 ? vol2 : vol1);
+                if (S > 1) st.vol[(cb + pn) * S] = (pn_is_1 ? vol1 : vol2) + (pn_is_1 ? vol2 : vol1);
                 for (int s0 = 1; s0 < S; s0 += 4) { // four species' loads in flight
                     double a[4], b[4];
 #pragma unroll
                     for (int k = 0; k < 4; k++)
                         if (s0 + k < S) {
-                            a[k] = st.vol[cb * S + (int64_t)(s0 + k) * st.cap + pn];
-                            b[k] = st.vol[cb * S + (int64_t)(s0 + k) * st.cap + po];
+                            a[k] = st.vol[(cb + pn) * S + (s0 + k)];
+                            b[k] = st.vol[(cb + po) * S + (s0 + k)];
                         }
 #pragma unroll
                     for (int k = 0; k < 4; k++)
                         if (s0 + k < S)
-                            st.vol[cb * S + (int64_t)(s0 + k) * st.cap + pn] = a[k] + b[k];
+                            st.vol[(cb + pn) * S + (s0 + k)] = a[k] + b[k];
                 }
                 for (int sp = 1; sp < NS; sp++) {
                     int32_t *a = &norig(st, cb, sp, pn);
@@ -1445,8 +1496,8 @@ __device__ __forceinline__ void move_particle(const DeviceState &st, int64_t cb,
                                               int src)
 {
     for (int s = 0; s < st.n_spec; s++)
-        st.vol[cb * st.n_spec + (int64_t)s * st.cap + dst] =
-            st.vol[cb * st.n_spec + (int64_t)s * st.cap + src];
+        st.vol[(cb + dst) * st.n_spec + s] =
+            st.vol[(cb + src) * st.n_spec + s];
     for (int s = 0; s < st.n_source; s++)
         norig(st, cb, s, dst) =
             norig(st, cb, s, src);
@@ -1504,12 +1555,12 @@ __device__ void compact_wave(const DeviceState &st, int c, int lane, uint32_t *c
             double v[4];
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                v[k] = (mv && s0 + k < S) ? ld_f64(&st.vol[cb * S + (int64_t)(s0 + k) * st.cap + i]) : 0.0;
+                v[k] = (mv && s0 + k < S) ? ld_f64(&st.vol[(cb + i) * S + (s0 + k)]) : 0.0;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             wave_sync();
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                if (mv && s0 + k < S) st_f64(&st.vol[cb * S + (int64_t)(s0 + k) * st.cap + dst], v[k]);
+                if (mv && s0 + k < S) st_f64(&st.vol[(cb + dst) * S + (s0 + k)], v[k]);
         }
         for (int s = 0; s < NS; s++) {
             uint32_t x = 0;
@@ -1679,6 +1730,7 @@ __global__ __launch_bounds__(256) void k_diagnostics(DeviceState st, double *tot
     double *red = msum + 4 * nd;                         // [256]
     uint32_t *ccnt = (uint32_t *)(red + 256);            // [4][C][nd]
     uint32_t *clcnt = ccnt + 4 * (size_t)C * nd;         // [C]
+    const size_t tile_off = ((size_t)((unsigned char *)(clcnt + C) - smem) + 15) & ~(size_t)15;
     for (int j = t; j <= nd; j += 256) edge[j] = st.d_edge[j];
     for (int j = t; j < 4 * nd; j += 256) msum[j] = 0.0;
     for (int j = t; j < 4 * C * nd; j += 256) ccnt[j] = 0;
@@ -1691,12 +1743,17 @@ __global__ __launch_bounds__(256) void k_diagnostics(DeviceState st, double *tot
     uint32_t *my_ccnt = ccnt + (size_t)wave * C * nd;
     double tm = 0.0;
     uint32_t n_live = 0;
-    for (int i = t; i < n; i += 256) {
+    double *tile = (double *)(smem + tile_off) + (size_t)wave * 64 * (S + 1);
+    const int lane = t & 63;
+    for (int i0 = t & ~63; i0 < n; i0 += 256) {
+        const int i = i0 + lane;
+        if (S > 1) stage_species(st, cb, i0, n, tile, lane);
+        if (i >= n) continue;
         const int cl = live_class(st, cb, i);
         if (cl < 0) continue; // tombstone
         double vdry = 0.0, ms = 0.0;
         for (int s = 0; s < S; s++) {
-            const double v = spec_vol(st, cb, s, i);
+            const double v = S > 1 ? tile[lane * (S + 1) + s] : st.vm[cb + i].x;
             if (s != st.i_water) vdry = vdry + v;
             ms = ms + st.density[s] * v;
         }
@@ -1761,13 +1818,19 @@ __global__ __launch_bounds__(256) void k_diagnostics_ext(DeviceState st, double 
     const int n = st.n_hi[c];
     const int64_t cb = (int64_t)c * st.cap;
     const double *mag = st.mag + (int64_t)c * st.n_class;
-    for (int i = t; i < n; i += 256) {
+    double *tile = (double *)(smem + (((size_t)(S + NS + 3) * sizeof(double) + 15) & ~(size_t)15)) +
+                   (size_t)(t >> 6) * 64 * (S + 1);
+    const int lane = t & 63;
+    for (int i0 = t & ~63; i0 < n; i0 += 256) {
+        const int i = i0 + lane;
+        if (S > 1) stage_species(st, cb, i0, n, tile, lane);
+        if (i >= n) continue;
         const int cl = live_class(st, cb, i);
         if (cl < 0) continue;
         const double nc = mag[cl];
         double vdry = 0.0, mdry = 0.0;
         for (int s = 0; s < S; s++) {
-            const double v = spec_vol(st, cb, s, i);
+            const double v = S > 1 ? tile[lane * (S + 1) + s] : st.vm[cb + i].x;
             atomicAdd(&acc[s], st.density[s] * v * nc);
             if (s != st.i_water) { vdry = vdry + v; mdry = mdry + st.density[s] * v; }
         }
@@ -1827,7 +1890,7 @@ __device__ int add_dist_sample(const DeviceState &st, int c, const AeroDistDev &
             double vt = 0.0, ms = 0.0;
             for (int s = 0; s < st.n_spec; s++) {
                 const double vs = d.vol_frac[m * st.n_spec + s] * v;
-                st.vol[cb * st.n_spec + (int64_t)s * st.cap + i] = vs;
+                st.vol[(cb + i) * st.n_spec + s] = vs;
                 vt = vt + vs;
                 ms = ms + st.density[s] * vs;
             }
@@ -2151,7 +2214,7 @@ __global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid t
                 const int dst = (int)first + g;
                 if (dst >= st.cap) { status |= ST_CAP_OVERFLOW; break; }
                 for (int sp = 0; sp < S; sp++)
-                    st.vol[cb * S + (int64_t)sp * st.cap + dst] = st.vol[sb * S + (int64_t)sp * st.cap + from];
+                    st.vol[(cb + dst) * S + sp] = st.vol[(sb + from) * S + sp];
                 for (int sp = 0; sp < NS; sp++)
                     norig(st, cb, sp, dst) = norig(st, sb, sp, from);
                 st.vm[cb + dst].x = st.vm[sb + from].x;
@@ -2214,20 +2277,36 @@ __global__ __launch_bounds__(256) void k_condense(DeviceState st, const double *
     if (rh > 0.999) rh = 0.999;
     const CondEnv e = cond_env_derive(st.temp[c], st.pressure[c], rh);
     const double h = del_t / (double)n_sub;
+    // A particle's species are contiguous: one pass over its record gives the dry volume, the
+    // kappa-weighted volume and the dry mass.  When water is the last species (the reference's
+    // table, aero_data.dat:21) the new cached totals are those sums plus the water term -- the
+    // same additions in the same order as a sum over all species -- so nothing is read twice.
+    const bool water_last = (iw == S - 1);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         if (live_class(st, cb, i) < 0) continue; // tombstone
-        double vdry = 0.0, kv = 0.0;
-        for (int s = 0; s < S; s++) {
-            if (s == iw) continue;
-            const double v = st.vol[cb * S + (int64_t)s * st.cap + i];
-            vdry = vdry + v;
-            kv = kv + kappa[s] * v;
+        const double *rec = st.vol + (cb + i) * S;
+        double vdry = 0.0, kv = 0.0, mdry = 0.0, v_water = 0.0;
+        if ((S & 1) == 0) { // 16-byte loads: two species each
+            const double2 *r2 = (const double2 *)rec;
+            for (int s = 0; s < S; s += 2) {
+                const double2 v = r2[s >> 1];
+                if (s == iw) v_water = v.x;
+                else { vdry = vdry + v.x; kv = kv + kappa[s] * v.x; mdry = mdry + st.density[s] * v.x; }
+                if (s + 1 == iw) v_water = v.y;
+                else { vdry = vdry + v.y; kv = kv + kappa[s + 1] * v.y; mdry = mdry + st.density[s + 1] * v.y; }
+            }
+        } else {
+            for (int s = 0; s < S; s++) {
+                const double v = rec[s];
+                if (s == iw) v_water = v;
+                else { vdry = vdry + v; kv = kv + kappa[s] * v; mdry = mdry + st.density[s] * v; }
+            }
         }
         if (!(vdry > 0.0) || !(kv > 0.0)) continue;
         const double kap = kv / vdry;
         const double dd3 = vdry * (6.0 / PI);
         const double dd = det_cbrt(dd3);
-        const double d3 = (vdry + st.vol[cb * S + (int64_t)iw * st.cap + i]) * (6.0 / PI);
+        const double d3 = (vdry + v_water) * (6.0 / PI);
         double d = det_cbrt(d3);
         const double d_min = dd * (1.0 + 1e-9);
         if (d < d_min) d = d_min;
@@ -2240,12 +2319,18 @@ __global__ __launch_bounds__(256) void k_condense(DeviceState st, const double *
         }
         double vw = d * d * d * (PI / 6.0) - vdry;
         if (vw < 0.0) vw = 0.0;
-        st.vol[cb * S + (int64_t)iw * st.cap + i] = vw;
-        double vt = 0.0, ms = 0.0;
-        for (int s = 0; s < S; s++) {
-            const double v = (s == iw) ? vw : st.vol[cb * S + (int64_t)s * st.cap + i];
-            vt = vt + v;
-            ms = ms + st.density[s] * v;
+        st.vol[(cb + i) * S + iw] = vw;
+        double vt, ms;
+        if (water_last) {
+            vt = vdry + vw;
+            ms = mdry + st.density[iw] * vw;
+        } else {
+            vt = 0.0; ms = 0.0;
+            for (int s = 0; s < S; s++) {
+                const double v = (s == iw) ? vw : rec[s];
+                vt = vt + v;
+                ms = ms + st.density[s] * v;
+            }
         }
         st.vm[cb + i].x = vt;
         st.vm[cb + i].y = ms;
@@ -2274,7 +2359,7 @@ __global__ void k_generate(DeviceState st, GenSpecDev g, int n, uint64_t seed, d
         double vt = 0.0, ms = 0.0;
         for (int s = 0; s < st.n_spec; s++) {
             const double vs = g.vol_frac[mode * st.n_spec + s] * v;
-            st.vol[cb * st.n_spec + (int64_t)s * st.cap + i] = vs;
+            st.vol[(cb + i) * st.n_spec + s] = vs;
             vt = vt + vs;
             ms = ms + st.density[s] * vs;
         }
@@ -2403,8 +2488,9 @@ size_t compact_lds_bytes(const DeviceState &st)
 
 size_t diagnostics_lds_bytes(const DeviceState &st)
 {
-    return sizeof(double) * (size_t)(5 * st.n_dbin + 1 + 256) +
-           sizeof(uint32_t) * (size_t)(4 * st.n_class * st.n_dbin + st.n_class);
+    const size_t base = sizeof(double) * (size_t)(5 * st.n_dbin + 1 + 256) +
+                        sizeof(uint32_t) * (size_t)(4 * st.n_class * st.n_dbin + st.n_class);
+    return ((base + 15) & ~(size_t)15) + species_tile_bytes(st.n_spec, 4);
 }
 
 // dynamic LDS above 64 KiB needs the per-function opt-in
@@ -2551,6 +2637,7 @@ hipError_t launch_rebalance(const DeviceState &st, int allow_doubling, int allow
 hipError_t launch_diagnostics(const DeviceState &st, double *tot_num, double *tot_mass,
                               double *num_dist, double *mass_dist, hipStream_t s)
 {
+    allow_lds(k_diagnostics, diagnostics_lds_bytes(st));
     hipLaunchKernelGGL(k_diagnostics, dim3(st.n_cells), dim3(256), diagnostics_lds_bytes(st), s, st,
                        tot_num, tot_mass, num_dist, mass_dist);
     return hipGetLastError();
@@ -2558,7 +2645,9 @@ hipError_t launch_diagnostics(const DeviceState &st, double *tot_num, double *to
 hipError_t launch_diagnostics_ext(const DeviceState &st, double *species_mass, double *source_num,
                                   double *pm, hipStream_t s)
 {
-    const size_t lds = sizeof(double) * (size_t)(st.n_spec + st.n_source + 3);
+    const size_t lds = ((sizeof(double) * (size_t)(st.n_spec + st.n_source + 3) + 15) & ~(size_t)15) +
+                       species_tile_bytes(st.n_spec, 4);
+    allow_lds(k_diagnostics_ext, lds);
     hipLaunchKernelGGL(k_diagnostics_ext, dim3(st.n_cells), dim3(256), lds, s, st, species_mass,
                        source_num, pm);
     return hipGetLastError();
