@@ -23,7 +23,8 @@ for k in sorted(out):
 # scripts/gather_probe.hip: FETCH_SIZE counts 64 B per such load, used raw.
 traffic = {}
 names = {"pmcx::k_bin_sort": ("bin_sort", 2.0), "pmcx::k_coag_sample<8>": ("coag_sample", 1.0),
-         "pmcx::k_coag_seq<false>": ("coag_sample", 1.0),
+         "pmcx::k_coag_seq<false>": ("coag_sample", 1.0), "pmcx::k_coag_seq<false, true, 4>": ("coag_sample", 1.0),
+         "pmcx::k_coag_seq<false, false, 4>": ("coag_sample", 1.0), "pmcx::k_coag_seq<false, false, 0>": ("coag_sample", 1.0),
          "pmcx::k_rebalance": ("rebalance", 1.0), "pmcx::k_compact": ("compact", 1.0)}
 for k, (short, f) in names.items():
     if k in out and "FETCH_SIZE" in out[k] and "WRITE_SIZE" in out[k]:

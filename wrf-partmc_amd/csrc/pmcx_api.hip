@@ -246,7 +246,6 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
     st.n_class = cfg->n_class; st.n_source = cfg->n_source; st.n_bin = cfg->n_bin;
     st.n_dbin = cfg->n_dbin; st.i_water = cfg->i_water;
     st.max_events = cfg->max_events; st.max_appends = cfg->max_appends;
-    st.dbg = getenv("PMCX_DBG") ? atoi(getenv("PMCX_DBG")) : 0;
     st.pcap = cfg->cap + cfg->cap / 8 + 16 * cfg->n_class * cfg->n_bin;
     st.cell_id_base = cfg->cell_id_base;
     st.const_k = cfg->const_k; st.additive_beta = cfg->additive_beta;

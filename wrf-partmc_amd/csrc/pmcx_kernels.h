@@ -27,7 +27,6 @@ struct __attribute__((aligned(32))) Meta {
 struct DeviceState {
     int32_t n_cells, cap, n_spec, n_class, n_source, n_bin, n_dbin, i_water;
     int32_t max_events, max_appends;
-    int32_t dbg; // PMCX_DBG: timing ablations of the lane-per-cell sampler (results invalid when != 0)
     int32_t pcap; // entries of perm per cell: cap + cap/8 + 16 n_class n_bin
     uint32_t cell_id_base;
     double const_k, additive_beta;

@@ -1027,8 +1027,13 @@ __host__ __device__ inline size_t seq_lds_bytes(int B, int C)
 // [9] wait for the bound, [10] Philox, [11] Poisson
 __device__ unsigned long long g_seq_stamps[12];
 
-template <bool STAMPS>
-__global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype, double del_t,
+// SIMPLE: one species and one weight class known at compile time (the idealised reference
+// initial condition, wrf_pmc_init.F90:1766-1770): the species loop, the weighted-removal
+// draws and the class bookkeeping fold away, which is worth registers in the hot loop.
+// KT: the coagulation kernel when known at compile time (COAG_KERNEL_TYPE_BROWN, the one the
+// reference selects, wrf_pmc_driver.F90:192), 0 = chosen at run time.
+template <bool STAMPS, bool SIMPLE, int KT>
+__global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype_rt, double del_t,
                                                  uint64_t seed, uint32_t step, uint16_t *ovf_mem)
 {
     uint64_t t_last = 0, t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1044,8 +1049,9 @@ __global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype, d
     const int cidx = blockIdx.x * 64 + lane;
     const bool live = cidx < st.n_cells;
     const int c = live ? cidx : st.n_cells - 1;
-    const int B = st.n_bin, C = st.n_class, G = B * C;
-    const int S = st.n_spec, NS = st.n_source;
+    const int ktype = KT ? KT : ktype_rt;
+    const int B = st.n_bin, C = SIMPLE ? 1 : st.n_class, G = B * C;
+    const int S = SIMPLE ? 1 : st.n_spec, NS = st.n_source;
     const int64_t cb = (int64_t)c * st.cap;
     const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
 
@@ -1201,7 +1207,7 @@ __global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype, d
         k_max = km * fmax;
         const double n_possible = (c1 == c2 && b1 == b2) ? nA * (nA - 1.0) / 2.0 : nA * nB;
         const double mean = k_max * del_t * n_possible;
-        ns_rem = (st.dbg & 1) ? (uint32_t)(u * 4.0 * mean > 0.9) : (uint32_t)poisson(mean, u, rcp);
+        ns_rem = (uint32_t)poisson(mean, u, rcp);
         tot_samp += ns_rem;
         s = 0;
     };
@@ -1266,8 +1272,7 @@ __global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype, d
             found = draw_find(dA, dB, km);
             if (found) {
                 uint32_t w[4];
-                if (st.dbg & 2) { w[0] = (uint32_t)(c1 * B + b1) * 2654435761u ^ step; w[1] = (uint32_t)(c2 * B + b2) * 40503u ^ cell_id; }
-                else rng_block(seed, cell_id, step,
+                rng_block(seed, cell_id, step,
                           ((uint32_t)(c1 * B + b1) << 16) | (uint32_t)(c2 * B + b2), SITE_POISSON, 0, w);
                 u_d = u53(w[0], w[1]);
             }
@@ -1278,9 +1283,7 @@ __global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype, d
         double v1 = 0, v2 = 0, m1 = 0, m2 = 0;
         double vol1 = 0, vol2 = 0, lct1 = 0, lct2 = 0, gct1 = 0, gct2 = 0; // first species, times
         int32_t no1 = 0, no2 = 0;               // first source
-        if (evalid && (st.dbg & 16)) {
-            v1 = 1e-21 * (double)(p1 + 1); v2 = 2e-21 * (double)(p2 + 1); m1 = v1 * 1770.0; m2 = v2 * 1770.0;
-        } else if (evalid) {
+        if (evalid) {
             const double2 a1 = vm[p1], a2 = vm[p2];
             v1 = a1.x; m1 = a1.y; v2 = a2.x; m2 = a2.y;
             // (with one species the volume of that species IS the cached total: both are sums
@@ -1300,8 +1303,7 @@ __global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype, d
                 found2 = draw_find(dA, dB, km);
                 if (found2) {
                     uint32_t w[4];
-                    if (st.dbg & 2) { w[0] = (uint32_t)(c1 * B + b1) * 2654435761u ^ step; w[1] = (uint32_t)(c2 * B + b2) * 40503u ^ cell_id; }
-                else rng_block(seed, cell_id, step,
+                    rng_block(seed, cell_id, step,
                               ((uint32_t)(c1 * B + b1) << 16) | (uint32_t)(c2 * B + b2), SITE_POISSON, 0, w);
                     u_d = u53(w[0], w[1]);
                 }
@@ -1316,14 +1318,9 @@ __global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype, d
             env.c_diff = envs[2 * 64 + lane]; env.c_speed = envs[3 * 64 + lane];
             env.c_inv_speed = envs[4 * 64 + lane]; env.c_fall = envs[5 * 64 + lane];
             env.rhoair = envs[6 * 64 + lane];
-            double k;
-            if (st.dbg & 4) {
-                k = k_max * 0.78 / factor + (v1 + m2) * 1e-300;
-            } else {
-                const PartProps qa = props_for(ktype, v1, m1, env);
-                const PartProps qb = props_for(ktype, v2, m2, env);
-                k = kernel_pair(ktype, v1, v2, qa, qb, kp);
-            }
+            const PartProps qa = props_for(ktype, v1, m1, env);
+            const PartProps qb = props_for(ktype, v2, m2, env);
+            const double k = kernel_pair(ktype, v1, v2, qa, qb, kp);
             const double kf = k * factor;
             if (kf > k_max) status |= ST_KMAX_EXCEEDED;
             acc = u_acc * k_max < kf;
@@ -2596,12 +2593,19 @@ hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, ui
         const char *e_st = getenv("PMCX_SEQ_STAMPS");
         const dim3 grid((st.n_cells + 63) / 64), block(64);
         const size_t lds = seq_lds_bytes(st.n_bin, st.n_class);
+        const bool simple = st.n_spec == 1 && st.n_class == 1;
         if (e_st && atoi(e_st) == 1)
-            hipLaunchKernelGGL(k_coag_seq<true>, grid, block, lds, s, st, ktype, del_t, seed, step,
-                               st.seq_ovf);
+            hipLaunchKernelGGL((k_coag_seq<true, false, 0>), grid, block, lds, s, st, ktype, del_t, seed,
+                               step, st.seq_ovf);
+        else if (simple && ktype == KERNEL_BROWN)
+            hipLaunchKernelGGL((k_coag_seq<false, true, KERNEL_BROWN>), grid, block, lds, s, st, ktype,
+                               del_t, seed, step, st.seq_ovf);
+        else if (ktype == KERNEL_BROWN)
+            hipLaunchKernelGGL((k_coag_seq<false, false, KERNEL_BROWN>), grid, block, lds, s, st, ktype,
+                               del_t, seed, step, st.seq_ovf);
         else
-            hipLaunchKernelGGL(k_coag_seq<false>, grid, block, lds, s, st, ktype, del_t, seed, step,
-                               st.seq_ovf);
+            hipLaunchKernelGGL((k_coag_seq<false, false, 0>), grid, block, lds, s, st, ktype, del_t, seed,
+                               step, st.seq_ovf);
         return hipGetLastError();
     }
     const size_t per = sampler_lds_for(st, L);
