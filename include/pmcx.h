@@ -84,7 +84,12 @@ typedef struct {
     double d_min, d_max;  /*   1e-9, 1e-3 m (driver:783)                      */
     uint32_t cell_id_base;/* global id of local cell 0: RNG key, so results
                              do not depend on how cells are split over GPUs   */
-    uint32_t reserved;
+    uint32_t compact_den; /* mc_coag closes a cell's holes (stable compaction) once more
+                             than 1/compact_den of its slots are tombstones; default 2.
+                             Results never depend on it (the survivors' order is fixed);
+                             a full compaction moves every particle, so a small value
+                             costs bandwidth, a large one leaves holes for the
+                             full-population passes to skip                      */
     double const_k;       /* constant-kernel value, m^3/s                     */
     double additive_beta; /* additive-kernel coefficient, 1/s                 */
 } pmcx_config;

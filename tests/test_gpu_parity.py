@@ -463,10 +463,11 @@ def test_maximum_capacity_cell(wp, oracle):
 
 
 def test_tombstones_and_lazy_compaction(wp, oracle):
-    """Many steps with heavy depletion: cells cross the 1/8 tombstone threshold and are
-    compacted in between; results must not depend on when that happens."""
+    """Many steps with heavy depletion: cells cross the tombstone threshold (set to 1/8 here;
+    the default is 1/2) and are compacted in between; results must not depend on when that
+    happens."""
     blk, cells = _ragged_pair(wp, oracle, [1500, 900, 1200], n_spec=2, n_class=2,
-                              max_events=4096, max_appends=4096)
+                              max_events=4096, max_appends=4096, compact_den=8)
     for step in range(8):
         ns, nc, st = blk.mc_coag(K_BROWN, 15000.0, 4, step)
         for c, oc in enumerate(cells):
@@ -485,7 +486,7 @@ def test_sort_persists_between_calls(wp, oracle):
     without disturbing them, and an explicit invalidation re-sorts.  No download in between:
     the device state is compared once at the end."""
     blk, cells = _ragged_pair(wp, oracle, [2000, 1300, 64, 1700], n_spec=2, n_class=2,
-                              max_events=4096, max_appends=64)
+                              max_events=4096, max_appends=64, compact_den=8)
     for step in range(14):
         if step == 9:                      # a host-side edit of the population
             blk.invalidate_sort()

@@ -193,6 +193,7 @@ void pmcx_config_default(pmcx_config *cfg)
     cfg->d_min = 1e-9;
     cfg->d_max = 1e-3;
     cfg->cell_id_base = 0;
+    cfg->compact_den = 2;
     cfg->const_k = 0.25 / (60.0 * 2.0e8); /* PartMC constant-kernel beta_0 [upstream] */
     cfg->additive_beta = 1000.0;          /* PartMC additive-kernel beta_1 [upstream] */
 }
@@ -707,9 +708,10 @@ int pmcx_mc_coag(pmcx_ctx *ctx, int32_t kernel_type, double del_t, uint64_t seed
         HIP_TRY(ctx, launch_coag_sample(ctx->st, kernel_type, del_t, seed, step, ctx->stream));
     }
     {
-        // close holes in the cells where more than 1/8 of the slots are tombstones
+        // close holes in the cells where more than 1/compact_den of the slots are tombstones
         ProfScope ps(ctx, "compact");
-        HIP_TRY(ctx, launch_compact(ctx->st, 0, ctx->cfg.n_cells, 1, 8, ctx->stream));
+        const int den = ctx->cfg.compact_den ? (int)ctx->cfg.compact_den : 2;
+        HIP_TRY(ctx, launch_compact(ctx->st, 0, ctx->cfg.n_cells, 1, den, ctx->stream));
     }
     return PMCX_OK;
 }

@@ -1522,49 +1522,86 @@ __device__ void compact_wave(const DeviceState &st, int c, int lane, uint32_t *c
     const uint64_t lt = (1ull << lane) - 1ull;
     const bool remap = cbase != nullptr && st.sort_valid[c] != 0;
     int base = 0;
-    for (int i0 = 0; i0 < n_hi; i0 += 64) {
-        const int i = i0 + lane;
-        const bool live = i < n_hi && live_class_c(st, cb, i) >= 0;
-        const uint64_t m = __ballot(live);
-        const int dst = base + __popcll(m & lt);
-        const bool mv = live && dst != i;
-        if (remap && lane == 0) { cbase[i0 >> 6] = (uint32_t)base; cmask[i0 >> 6] = m; }
-        base += __popcll(m);
-        if (__ballot(mv) == 0) continue;
-        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        int64_t idv = 0;
-        int32_t wc = 0;
-        if (mv) {
-            a0 = ld_f64(&st.vm[cb + i].x); a1 = ld_f64(&st.vm[cb + i].y);
-            a2 = ld_f64(&st.meta[cb + i].lct); a3 = ld_f64(&st.meta[cb + i].gct);
-            idv = (int64_t)d2u(ld_f64((const double *)&st.meta[cb + i].id));
-            wc = (int32_t)ld_u32((const uint32_t *)&st.wclass[cb + i]);
+    // four 64-slot chunks per trip: their liveness words, then every field of the slots that
+    // move, are requested together (one memory round trip each instead of one per chunk)
+    constexpr int U = 4;
+    for (int i0 = 0; i0 < n_hi; i0 += 64 * U) {
+        double x[U];
+        int dst[U];
+        bool mv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = i0 + u * 64 + lane;
+            x[u] = i < n_hi ? ld_f64(&st.vm[cb + i].x) : -1.0;
+        }
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = i0 + u * 64 + lane;
+            const bool live = x[u] >= 0.0; // tombstones carry a negative cached volume
+            const uint64_t m = __ballot(live);
+            dst[u] = base + __popcll(m & lt);
+            mv[u] = live && dst[u] != i;
+            if (remap && lane == 0 && i0 + u * 64 < n_hi) {
+                cbase[(i0 >> 6) + u] = (uint32_t)base;
+                cmask[(i0 >> 6) + u] = m;
+            }
+            base += __popcll(m);
+            any |= __ballot(mv[u]) != 0;
+        }
+        if (!any) continue;
+        double a1[U], a2[U], a3[U];
+        int64_t idv[U];
+        int32_t wc[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = i0 + u * 64 + lane;
+            a1[u] = a2[u] = a3[u] = 0; idv[u] = 0; wc[u] = 0;
+            if (mv[u]) {
+                a1[u] = ld_f64(&st.vm[cb + i].y);
+                a2[u] = ld_f64(&st.meta[cb + i].lct); a3[u] = ld_f64(&st.meta[cb + i].gct);
+                idv[u] = (int64_t)d2u(ld_f64((const double *)&st.meta[cb + i].id));
+                wc[u] = (int32_t)ld_u32((const uint32_t *)&st.wclass[cb + i]);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
-        if (mv) {
-            st_f64(&st.vm[cb + dst].x, a0); st_f64(&st.vm[cb + dst].y, a1);
-            st_f64(&st.meta[cb + dst].lct, a2); st_f64(&st.meta[cb + dst].gct, a3);
-            st_f64((double *)&st.meta[cb + dst].id, u2d((uint64_t)idv));
-            st_u32((uint32_t *)&st.wclass[cb + dst], (uint32_t)wc);
-        }
-        for (int s0 = 0; s0 < S; s0 += 4) {
-            double v[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                v[k] = (mv && s0 + k < S) ? ld_f64(&st.vol[(cb + i) * S + (s0 + k)]) : 0.0;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            wave_sync();
+        for (int u = 0; u < U; u++)
+            if (mv[u]) {
+                const int d = dst[u];
+                st_f64(&st.vm[cb + d].x, x[u]); st_f64(&st.vm[cb + d].y, a1[u]);
+                st_f64(&st.meta[cb + d].lct, a2[u]); st_f64(&st.meta[cb + d].gct, a3[u]);
+                st_f64((double *)&st.meta[cb + d].id, u2d((uint64_t)idv[u]));
+                st_u32((uint32_t *)&st.wclass[cb + d], (uint32_t)wc[u]);
+            }
+        // species volumes (with one species the plane is not kept current: nothing to move)
+        if (S > 1)
+            for (int u = 0; u < U; u++) {
+                const int i = i0 + u * 64 + lane;
+                if (__ballot(mv[u]) == 0) continue;
+                for (int s0 = 0; s0 < S; s0 += 4) {
+                    double v[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (mv && s0 + k < S) st_f64(&st.vol[(cb + dst) * S + (s0 + k)], v[k]);
-        }
+                    for (int k = 0; k < 4; k++)
+                        v[k] = (mv[u] && s0 + k < S) ? ld_f64(&st.vol[(cb + i) * S + (s0 + k)]) : 0.0;
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    wave_sync();
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (mv[u] && s0 + k < S) st_f64(&st.vol[(cb + dst[u]) * S + (s0 + k)], v[k]);
+                }
+            }
         for (int s = 0; s < NS; s++) {
-            uint32_t x = 0;
-            if (mv) x = ld_u32((const uint32_t *)&norig(st, cb, s, i));
+            uint32_t xo[U];
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                xo[u] = mv[u] ? ld_u32((const uint32_t *)&norig(st, cb, s, i0 + u * 64 + lane)) : 0u;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             wave_sync();
-            if (mv) st_u32((uint32_t *)&norig(st, cb, s, dst), x);
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (mv[u]) st_u32((uint32_t *)&norig(st, cb, s, dst[u]), xo[u]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();

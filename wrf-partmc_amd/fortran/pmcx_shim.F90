@@ -39,7 +39,7 @@ module pmcx_shim
      real(c_double) :: r_min, r_max
      integer(c_int32_t) :: max_events, max_appends, n_dbin, i_water
      real(c_double) :: d_min, d_max
-     integer(c_int32_t) :: cell_id_base, reserved
+     integer(c_int32_t) :: cell_id_base, compact_den
      real(c_double) :: const_k, additive_beta
   end type pmcx_config
 

@@ -48,7 +48,7 @@ class PmcxConfig(C.Structure):
         ("n_source", C.c_int32), ("n_bin", C.c_int32), ("r_min", C.c_double),
         ("r_max", C.c_double), ("max_events", C.c_int32), ("max_appends", C.c_int32),
         ("n_dbin", C.c_int32), ("i_water", C.c_int32), ("d_min", C.c_double),
-        ("d_max", C.c_double), ("cell_id_base", C.c_uint32), ("reserved", C.c_uint32),
+        ("d_max", C.c_double), ("cell_id_base", C.c_uint32), ("compact_den", C.c_uint32),
         ("const_k", C.c_double), ("additive_beta", C.c_double),
     ]
 
