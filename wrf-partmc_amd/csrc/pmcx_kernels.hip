@@ -903,7 +903,8 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
         // Species volumes, source histogram, create times and class of the merged
         // particle [aero_particle_coagulate]: loads go out now and are consumed after
         // the list updates below; lanes of the group split the species.
-        const int S = st.n_spec, NS = st.n_source;
+        // (with one species the plane is not kept current, see spec_vol: nothing to merge)
+        const int S = st.n_spec > 1 ? st.n_spec : 0, NS = st.n_source;
         double mv_a[3] = {0, 0, 0}, mv_b[3] = {0, 0, 0}; // up to 3 species per lane at L = 8
 #pragma unroll
         for (int k = 0; k < 3; k++) {
@@ -950,7 +951,7 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
             }
         }
         if (rem_o) {
-            if (lead) mark_dead(st, cb, (int)po); // tombstone
+            if (lead) st_f64(&X.vm[po].x, -1.0); // tombstone, in the record just read
             n_dead++;
         }
         // (the stores above are waited for just before the next gathers, see "evaluate")
