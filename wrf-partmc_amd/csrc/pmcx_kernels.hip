@@ -995,14 +995,15 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
 //
 // The same sweep with one LANE per cell (64 cells per wavefront): every lane runs the
 // reference's sequential loop nest for its own cell, so nothing is evaluated
-// speculatively and no count is drawn twice.  The wavefront alternates two phases so
-// that its lanes stay dense: (draw) lanes without a pending sample advance to their
-// next non-empty slot and draw its Poisson count, repeated until at most DRAW_SLACK
-// lanes still look for work; (evaluate) every lane that holds a sample evaluates it
-// and, when accepted, coagulates the pair.  Everything an accepted pair will need
-// (the list ends that fill the holes, species volumes, create times, source counts) is
-// requested together with the pair's cached volume and mass, so the coagulation itself
-// waits for nothing.  A cell's list lengths and offsets live in LDS as one packed
+// speculatively and no count is drawn twice.  Every pass of the wavefront's loop a lane
+// either evaluates the sample it holds (and coagulates the pair when accepted) or, holding
+// none, moves to its next non-empty slots and draws the Poisson counts of up to two of them;
+// the memory requests of one kind of lane are issued before the arithmetic of the other
+// kind (see the loop).  Everything an accepted pair will need (the list ends that fill the
+// holes, first species volume, create times, source count) is requested together with the
+// pair's cached volume and mass, so the coagulation itself waits for nothing, and it writes
+// only to lines it has read: requests, and above all stores to untouched lines, are what
+// bounds this kernel.  A cell's list lengths and offsets live in LDS as one packed
 // 32-bit word per group for a window of SEQ_W bins above the cell's first non-empty
 // bin (groups beyond it, and entries appended after a group's room ran out, are rare
 // and served from HBM); rows of 64 lanes side by side, so the 64 cells never meet on
@@ -1023,9 +1024,9 @@ __host__ __device__ inline size_t seq_lds_bytes(int B, int C)
 }
 
 // diagnostic build only (STAMPS = true, PMCX_SEQ_STAMPS=1): shader cycles per phase, summed
-// over wavefronts: [0] setup, [1] draw, [2] evaluate, [3] coagulate, [4] write-back,
-// [5] draw iterations, [6] evaluate iterations, [7] wavefronts; inside draw: [8] slot search,
-// [9] wait for the bound, [10] Philox, [11] Poisson
+// over wavefronts: [0] setup, [1] stage 1-2 (pair picked, first draw), [2] stage 3-4 (particle
+// data requested, first count, second draw), [3] stage 5-7 (kernel, second count, coagulation),
+// [4] write-back, [5] draws, [6] passes, [7] wavefronts; [8..11] unused
 __device__ unsigned long long g_seq_stamps[12];
 
 // SIMPLE: one species and one weight class known at compile time (the idealised reference
