@@ -323,10 +323,9 @@ def main():
         ph = blk.profile_phase_cycles()
         w = max(ph[7], 1)
         print("seq sampler, mean shader cycles per wavefront: " + json.dumps(dict(
-            setup=ph[0] / w, draw=ph[1] / w, evaluate=ph[2] / w, coagulate=ph[3] / w,
-            write_back=ph[4] / w, draw_iterations=ph[5] / w, evaluate_iterations=ph[6] / w,
-            wavefronts=ph[7], draw_search=ph[8] / w, draw_wait_bound=ph[9] / w,
-            draw_philox=ph[10] / w, draw_poisson=ph[11] / w)), file=sys.stderr)
+            setup=ph[0] / w, pair_and_first_draw=ph[1] / w, particle_data_and_second_draw=ph[2] / w,
+            kernel_and_coagulation=ph[3] / w, write_back=ph[4] / w, draws=ph[5] / w,
+            passes=ph[6] / w, wavefronts=ph[7])), file=sys.stderr)
 
     # Side measurement, outside the timed region: the same step when something other than
     # mc_coag touched every cell in between (transport, emission: aero_state%valid_sort

@@ -348,11 +348,12 @@ int pmcx_profile_enable(pmcx_ctx *ctx, int32_t on);
 int pmcx_profile_reset(pmcx_ctx *ctx);
 int pmcx_profile_get(pmcx_ctx *ctx, const char *name, double *ms, int64_t *launches);
 
-/* Diagnostic: shader cycles per phase of the lane-per-cell sampler, summed over
+/* Diagnostic: shader cycles per stage of the lane-per-cell sampler's pass, summed over
  * wavefronts, when the library runs with PMCX_SEQ_STAMPS=1 (a separate, slower
- * instantiation of the kernel; zeros otherwise).  out: setup, draw, evaluate,
- * coagulate, write-back cycles; draw iterations; evaluate iterations; wavefronts;
- * inside draw: slot search, wait for the bound, Philox, Poisson. */
+ * instantiation of the kernel; zeros otherwise).  out[0..7]: setup; pair picked and
+ * first draw; particle data requested, first count, second draw; kernel evaluation,
+ * second count, coagulation; write-back (cycles); draws; passes; wavefronts (counts).
+ * out[8..11] unused. */
 int pmcx_profile_phase_cycles(pmcx_ctx *ctx, uint64_t out[12], int32_t reset);
 
 /* device memory held by the context, bytes (replaces memtrack, interface/mem.c) */
