@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""One WRF-PartMC step (minus MOSAIC) that never leaves HBM: the order of the reference's
+driver -- transport + dry deposition (wrf_pmc_trans_driver, interface/wrf_pmc_trans.F90:37-200,
+deposition at :184), then partmc_timestep (interface/wrf_pmc_driver.F90:169-254: mc_coag at the
+chemistry step, scenario_update_aero_state for emission and dilution, aero_state_rebalance) and
+the partmc_process observables at output time -- on one block of cells, with the per-kernel
+device time of each piece.  Synthetic inputs (probabilities, resistances, emission rates);
+the point is that every piece runs on the resident state and what each costs.
+
+  python scripts/whole_step.py [--nx 64 --ny 64 --levels 30 --particles 10000 --steps 6]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import wrf_partmc_amd as wp  # noqa: E402
+from wrf_partmc_amd.data import (aerodynamic_resistance, idealised_modes,  # noqa: E402
+                                 zhang_surface_parameters)
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--nx", type=int, default=64)
+ap.add_argument("--ny", type=int, default=64)
+ap.add_argument("--levels", type=int, default=30)
+ap.add_argument("--particles", type=int, default=10000)
+ap.add_argument("--steps", type=int, default=6)
+ap.add_argument("--dt", type=float, default=20.0)          # WRF step, s
+ap.add_argument("--chem-dt", type=float, default=60.0)     # registry.partmc:24
+a = ap.parse_args()
+
+nx, ny, nz, N = a.nx, a.ny, a.levels, a.particles
+n = nx * ny * nz
+cap = (int(N * 1.3) + 63) // 64 * 64                       # room for arrivals and emissions
+blk = wp.CellBlock(n, cap, 1, n_class=1, n_source=2, max_events=1024, max_appends=128)
+blk.set_aero_data([1770.0])
+# transport's cell order: c = (j * nz + k) * nx + i
+k = (np.arange(n) // nx) % nz
+z = np.linspace(50.0, 12000.0, nz)
+temp = 288.15 - 6.5e-3 * z
+pres = 101325.0 * (temp / 288.15) ** 5.2559
+blk.set_env(temp[k], pres[k], np.full(n, 0.5))
+blk.set_weights(np.full((n, 1), 1e10 / N))
+blk.set_n_part_ideal(np.full((n, 1), float(N)))
+blk.set_next_id((np.arange(n, dtype=np.int64) << 32) + (1 << 24))
+blk.generate_lognormal(N, idealised_modes(1, 1), seed=0)
+blk.update_kernel_bounds(wp.COAG_KERNEL_TYPE_BROWN)
+blk.synchronize()
+
+rng = np.random.RandomState(1)
+prob_h = np.full((n, 1, 4), 0.01) * rng.uniform(0.9, 1.1, (n, 1, 4))     # Courant-like numbers
+prob_v = np.zeros((n, 1, nz))
+for kk in range(nz):                                                      # to the level above/below
+    m = k == kk
+    if kk + 1 < nz:
+        prob_v[m, 0, kk + 1] = 0.004
+    if kk > 0:
+        prob_v[m, 0, kk - 1] = 0.004
+cell_volume = np.full(n, 1.0e9)
+surface = (k == 0).astype(np.int32)
+ustar = np.full(n, 0.35)
+ra = np.broadcast_to(aerodynamic_resistance(0.0, 0.1, 0.35), (n,))
+alpha, big_a = zhang_surface_parameters(np.full(n, 7))                    # grassland
+height = np.full(n, 50.0)
+rrho = 1.0 / (pres[k] / (287.0 * temp[k]))
+emission = [dict(num_conc=None, gm_radius=3e-8, gsd_log10=0.2, vol_frac=[1.0], wclass=0, source=1)]
+emit_rate = np.where(surface[:, None] == 1, 2.0e5, 0.0)                   # m^-3 s^-1 at the ground
+
+names = ("transport", "dry_deposition", "scenario", "bin_sort", "coag_sample", "compact",
+         "rebalance", "diagnostics")
+blk.profile_enable(True)
+blk.profile_reset()
+t0 = time.perf_counter()
+elapsed = 0.0
+moved = deposited = emitted = events = 0
+for step in range(a.steps):
+    nm, na = blk.transport(nx, nz, ny, prob_h, prob_v, cell_volume, seed=0, step=step)
+    assert nm.sum() == na.sum(), "transport lost particles (capacity)"   # equal weights: 1 copy each
+    nr, bad = blk.dry_deposition(a.dt, ra, ustar, alpha, big_a, height, rrho, seed=0, step=step,
+                                 surface=surface)
+    ne, ni, no = blk.scenario_update_aero_state(a.dt, elapsed, seed=0, step=step, emission=emission,
+                                                emission_rate=emit_rate)
+    if elapsed % a.chem_dt == 0.0:
+        ns, nc, st = blk.mc_coag(wp.COAG_KERNEL_TYPE_BROWN, a.chem_dt, 0, int(elapsed // a.chem_dt))
+        events += int(nc.sum())
+        assert not (st & ~4).any(), "status"
+    blk.aero_state_rebalance(True, True, 0, step)
+    moved += int(nm.sum()); deposited += int(nr.sum()); emitted += int(ne.sum())
+    elapsed += a.dt
+tn, tm, nd, md = blk.diagnostics()
+blk.synchronize()
+wall = time.perf_counter() - t0
+out = {"cells": n, "particles_per_cell": N, "steps": a.steps, "wall_ms_per_step": wall / a.steps * 1e3,
+       "moved_per_step": moved / a.steps, "deposited_per_step": deposited / a.steps,
+       "emitted_per_step": emitted / a.steps, "coag_events": events,
+       "particles_end": int(blk.aero_state_total_particles().sum()),
+       "device_ms": {}}
+for name in names:
+    ms, cnt = blk.profile_get(name)
+    if cnt:
+        out["device_ms"][name] = {"per_launch": ms / cnt, "launches": int(cnt)}
+print(json.dumps(out))
+blk.close()

@@ -712,6 +712,38 @@ def test_transport_parity(wp, oracle, nx, nz, ny, px, py):
     blk.close()
 
 
+def test_transport_makes_room_among_tombstones(wp, oracle):
+    """Arrivals are appended behind the last used slot; with holes closed lazily (compact_den = 2)
+    a cell can be short of room while a third of its slots are dead.  pmcx_transport closes the
+    holes of such cells before the movers' slots are named: same result as the oracle (which
+    compacts after every call), nothing lost to ST_CAP_OVERFLOW."""
+    nx, nz, ny = 3, 2, 2
+    n_cells, n_part, cap = nx * nz * ny, 900, 960
+    blk, cells, info = parity.setup_pair(wp, oracle, n_cells, n_part, 1, 1, 21, K_BROWN, cap=cap,
+                                         n_source=1, max_events=4096, max_appends=4096)
+    for step in range(12):                                    # deplete: about a third becomes tombstones
+        ns, nc, st = blk.mc_coag(K_BROWN, 8000.0, 21, step)
+        for c, oc in enumerate(cells):
+            assert oc.mc_coag(K_BROWN, 8000.0, 21, oc.cell_id, step) == (int(st[c]), int(ns[c]), int(nc[c]))
+        live = blk.aero_state_total_particles()
+        if (live < 0.72 * n_part).all():
+            break
+    assert (live < 0.72 * n_part).all() and (live > 0.5 * n_part).all()   # holes, not yet closed
+    ph = np.full((n_cells, 1, 4), 0.03); pv = np.full((n_cells, 1, nz), 0.03)
+    ph[0] = 0.0; pv[0] = 0.0                                  # cell 0 only receives
+    next_id = np.array([oc.next_id for oc in cells], dtype=np.int64)
+    for step in range(2):
+        nm, na = blk.transport(nx, nz, ny, ph, pv, np.ones(n_cells), 21, step, True, True)
+        st, onm, ona = oracle.transport(cells, nx, nz, ny, ph, pv, np.ones(n_cells), 21, 0, step,
+                                        next_id, True, True)
+        assert st == 0 and np.array_equal(nm, onm) and np.array_equal(na, ona)
+        assert nm.sum() == na.sum()                           # equal weights: nothing lost
+        ok, msg = parity.compare_state(blk, cells)
+        assert ok, f"step {step}: {msg}"
+    assert na[0] > cap - n_part                               # more arrivals than the free tail held
+    blk.close()
+
+
 def test_transport_conserves_with_equal_weights(wp):
     """Equal weights and volumes everywhere: every mover arrives exactly once, so the total
     particle count and the multiset of ids are conserved; a closed box keeps everything in."""

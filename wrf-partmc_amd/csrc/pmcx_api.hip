@@ -51,6 +51,7 @@ struct pmcx_ctx {
     int64_t *d_totals = nullptr;
     void *d_outbox = nullptr;   // transport outboxes, allocated on first use
     int32_t *d_n_out = nullptr, *d_n_arr = nullptr;
+    uint64_t *d_dest_mask = nullptr;
     int64_t *d_acc = nullptr;   // running sums over calls: n_samp, n_coag, n_part, status
     double *d_diag = nullptr; // [n_cells*(2+2*n_dbin)]
     bool aero_data_set = false, env_set = false;
@@ -247,6 +248,7 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
     st.n_class = cfg->n_class; st.n_source = cfg->n_source; st.n_bin = cfg->n_bin;
     st.n_dbin = cfg->n_dbin; st.i_water = cfg->i_water;
     st.max_events = cfg->max_events; st.max_appends = cfg->max_appends;
+    st.compact_den = cfg->compact_den ? (int32_t)cfg->compact_den : 2;
     st.pcap = cfg->cap + cfg->cap / 8 + 16 * cfg->n_class * cfg->n_bin;
     st.cell_id_base = cfg->cell_id_base;
     st.const_k = cfg->const_k; st.additive_beta = cfg->additive_beta;
@@ -911,6 +913,7 @@ int pmcx_transport(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int32_t pe
         int rc = dev_alloc(ctx, (int64_t **)&ctx->d_outbox, nc * (size_t)cf.cap, false);
         if (!rc) rc = dev_alloc(ctx, &ctx->d_n_out, nc);
         if (!rc) rc = dev_alloc(ctx, &ctx->d_n_arr, nc);
+        if (!rc) rc = dev_alloc(ctx, &ctx->d_dest_mask, nc);
         if (rc) return rc;
     }
     const size_t bh = sizeof(double) * nc * C * 4, bv = sizeof(double) * nc * C * (size_t)nz,
@@ -922,11 +925,14 @@ int pmcx_transport(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int32_t pe
     HIP_TRY(ctx, hipMemcpyAsync(d_pv, prob_v, bv, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_cv, cell_volume, bc, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->st.status, 0, sizeof(int32_t) * nc, ctx->stream));
+    // arrivals are appended behind n_hi: close the holes first where room is short (the
+    // movers' slots are named in the outboxes, so this cannot happen once the step has begun)
+    HIP_TRY(ctx, launch_compact(ctx->st, 0, cf.n_cells, 1, -ctx->st.compact_den, ctx->stream));
     {
         ProfScope ps(ctx, "transport");
         HIP_TRY(ctx, launch_transport(ctx->st, nx, nz, ny, periodic_x, periodic_y, d_ph, d_pv, d_cv,
-                                      ctx->d_outbox, ctx->d_n_out, ctx->d_n_arr, seed, step,
-                                      ctx->stream));
+                                      ctx->d_outbox, ctx->d_n_out, ctx->d_n_arr, ctx->d_dest_mask,
+                                      seed, step, ctx->stream));
     }
     if (n_moved) HIP_TRY(ctx, hipMemcpyAsync(n_moved, ctx->d_n_out, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));
     if (n_arrived) HIP_TRY(ctx, hipMemcpyAsync(n_arrived, ctx->d_n_arr, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));

@@ -27,6 +27,7 @@ struct __attribute__((aligned(32))) Meta {
 struct DeviceState {
     int32_t n_cells, cap, n_spec, n_class, n_source, n_bin, n_dbin, i_water;
     int32_t max_events, max_appends;
+    int32_t compact_den; // holes are closed once more than 1/compact_den of a cell's slots are dead
     int32_t pcap; // entries of perm per cell: cap + cap/8 + 16 n_class n_bin
     uint32_t cell_id_base;
     double const_k, additive_beta;
@@ -118,7 +119,7 @@ size_t transport_lds_bytes(const DeviceState &st, int nz);
 hipError_t launch_transport(const DeviceState &st, int nx, int nz, int ny, int periodic_x,
                             int periodic_y, const double *prob_h, const double *prob_v,
                             const double *cell_volume, void *outbox, int32_t *n_out, int32_t *n_arr,
-                            uint64_t seed, uint32_t step, hipStream_t s);
+                            uint64_t *dest_mask, uint64_t seed, uint32_t step, hipStream_t s);
 // per_cell6: [6][n_cells] aer_res_a, ustar, alpha, big_a, height, inv_density
 hipError_t launch_dry_deposition(const DeviceState &st, double dt, uint64_t seed, uint32_t step,
                                  const int32_t *surface, const double *per_cell6,

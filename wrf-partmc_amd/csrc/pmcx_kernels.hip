@@ -1643,8 +1643,12 @@ __global__ __launch_bounds__(256) void k_compact(DeviceState st, int cell_first,
     uint64_t *cmask = (uint64_t *)smem + (size_t)wave * n_chunk;
     uint32_t *cbase = (uint32_t *)((uint64_t *)smem + (size_t)(blockDim.x >> 6) * n_chunk) +
                       (size_t)wave * n_chunk;
-    if ((int64_t)(n_hi - n_live) * den > (int64_t)n_hi * num)
-        compact_wave(st, c, lane, cbase, cmask);
+    // den < 0 (used before arrivals are appended behind n_hi: transport): also when the free
+    // room behind n_hi is smaller than what the holes would give back plus 1/16 of the capacity
+    const int dead = n_hi - n_live;
+    bool go = (int64_t)dead * (den < 0 ? -den : den) > (int64_t)n_hi * num;
+    if (den < 0 && dead > 0 && st.cap - n_hi < dead + st.cap / 16) go = true;
+    if (go) compact_wave(st, c, lane, cbase, cmask);
 }
 
 // ---------------------------------------------------------------- rebalance
@@ -1736,7 +1740,7 @@ __global__ __launch_bounds__(64) void k_rebalance(DeviceState st, int allow_doub
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __threadfence_block();
                 wave_sync();
-                if (((int)nd + n_hi - n_live) * 8 > n_hi) compact_wave(st, c, lane);
+                if (((int)nd + n_hi - n_live) * st.compact_den > n_hi) compact_wave(st, c, lane);
             } else {
                 break;
             }
@@ -1996,7 +2000,7 @@ __global__ __launch_bounds__(64) void k_scenario_update(DeviceState st, double d
         if (background.n_mode > 0)
             ni = add_dist_sample(st, c, background, p_loss, 1u, create_time, seed, step, status, lane);
         const int hi = st.n_hi[c], live = st.n_part[c];
-        if ((hi - live) * 8 > hi) compact_wave(st, c, lane);
+        if ((hi - live) * st.compact_den > hi) compact_wave(st, c, lane);
     }
     if (lane == 0) {
         if (n_emit) n_emit[c] = ne;
@@ -2068,7 +2072,7 @@ __global__ __launch_bounds__(64) void k_dry_deposition(DeviceState st, DepArgs a
     __threadfence_block();
     wave_sync();
     const int hi = st.n_hi[c], live_n = st.n_part[c];
-    if ((hi - live_n) * 8 > hi) compact_wave(st, c, lane);
+    if ((hi - live_n) * st.compact_den > hi) compact_wave(st, c, lane);
 }
 
 // ---------------------------------------------------------------- transport
@@ -2093,6 +2097,9 @@ struct TransGrid {
     int2 *outbox;     // [n_cells][cap]  {slot | copies << 16, destination cell}
     int32_t *n_out;   // [n_cells]
     int32_t *n_arr;   // [n_cells]
+    uint64_t *dest_mask; // [n_cells] which of its neighbours a cell sends to this step: bit 0 east,
+                         // 1 west, 2 north, 3 south, 4 + k level k of its own column (all ones when
+                         // the grid is too small or too tall for the code to be unambiguous)
 };
 
 __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid tg, uint64_t seed,
@@ -2109,7 +2116,9 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
     int *t_dest = (int *)(t_p + C * ND);     // [C][ND]
     int *t_tmpd = t_dest + C * ND;           // scratch: destinations before sorting
     int *t_n = t_tmpd + C * ND;              // [C]
+    uint64_t *t_bit = (uint64_t *)(((uintptr_t)(t_n + C) + 7) & ~(uintptr_t)7); // [C][ND] dest_mask bit
     const int i = c % nx, k = (c / nx) % nz, j = c / (nx * nz);
+    const bool mask_ok = ND <= 64 && (nx >= 3 || !tg.periodic_x) && (ny >= 3 || !tg.periodic_y);
     const int64_t cb = (int64_t)c * st.cap;
     const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
     const uint64_t lt = (1ull << lane) - 1ull;
@@ -2153,6 +2162,16 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
             t_hi[cl * ND + r] = cum;
             const double factor = tg.cell_volume[c] / tg.cell_volume[dc[a]];
             t_ratio[cl * ND + r] = (st.mag[(int64_t)dc[a] * C + cl] / factor) / mag_from;
+            {   // where the destination lies, as the gather of that cell will look for it
+                const int di_ = dc[a] % nx, dk_ = (dc[a] / nx) % nz, dj_ = dc[a] / (nx * nz);
+                uint64_t bit = ~0ull;
+                if (mask_ok) {
+                    if (di_ == i && dj_ == j) bit = 1ull << (4 + dk_);
+                    else if (dj_ == j) bit = (di_ == (i + 1) % nx) ? 1ull : 2ull;
+                    else bit = (dj_ == (j + 1) % ny) ? 4ull : 8ull;
+                }
+                t_bit[cl * ND + r] = bit;
+            }
         }
         t_n[cl] = n;
     }
@@ -2161,6 +2180,7 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
     const int n_hi = st.n_hi[c];
     int2 *box = tg.outbox + cb;
     uint32_t rank0 = 0, n_out = 0;
+    uint64_t bits = 0;
     for (int i0 = 0; i0 < n_hi; i0 += 64) {
         const int s = i0 + lane;
         const int cl = s < n_hi ? live_class(st, cb, s) : -1;
@@ -2184,6 +2204,7 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
                     if (copies > TRANS_MAX_COPIES) copies = TRANS_MAX_COPIES;
                 }
                 dest = t_dest[cl * ND + d];
+                bits |= t_bit[cl * ND + d];
                 moves = true;
             }
         }
@@ -2192,7 +2213,8 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
         n_out += (uint32_t)__popcll(mm);
         rank0 += (uint32_t)__popcll(mlive);
     }
-    if (lane == 0) tg.n_out[c] = (int32_t)n_out;
+    for (int d = 32; d >= 1; d >>= 1) bits |= __shfl_xor(bits, d, 64);
+    if (lane == 0) { tg.n_out[c] = (int32_t)n_out; tg.dest_mask[c] = bits; }
 }
 
 __global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid tg)
@@ -2230,6 +2252,10 @@ __global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid t
             if (kk != k) sc = (j * nz + kk) * nx + i;
         }
         if (sc < 0) continue;
+        {   // does that source send anything this way?  (this cell as seen from the source)
+            const int need = q < 4 ? (q ^ 1) : 4 + k;
+            if (need < 64 && !((tg.dest_mask[sc] >> need) & 1ull)) continue;
+        }
         const int64_t sb = (int64_t)sc * st.cap;
         const int2 *box = tg.outbox + sb;
         const int n_out = tg.n_out[sc];
@@ -2290,7 +2316,7 @@ __global__ __launch_bounds__(64) void k_trans_remove(DeviceState st, TransGrid t
     __threadfence_block();
     wave_sync();
     const int n_hi = st.n_hi[c];
-    if ((n_hi - n_live) * 8 > n_hi) compact_wave(st, c, lane);
+    if ((n_hi - n_live) * st.compact_den > n_hi) compact_wave(st, c, lane);
 }
 
 // ------------------------------------------------------------- condensation
@@ -2720,15 +2746,15 @@ hipError_t launch_scenario_update(const DeviceState &st, double dt, double creat
 size_t transport_lds_bytes(const DeviceState &st, int nz)
 {
     const size_t nd = (size_t)(4 + nz), C = (size_t)st.n_class;
-    return (sizeof(double) * 4 + sizeof(int) * 2) * C * nd + sizeof(int) * C + 16;
+    return (sizeof(double) * 4 + sizeof(int) * 2 + sizeof(uint64_t)) * C * nd + sizeof(int) * C + 24;
 }
 hipError_t launch_transport(const DeviceState &st, int nx, int nz, int ny, int periodic_x,
                             int periodic_y, const double *prob_h, const double *prob_v,
                             const double *cell_volume, void *outbox, int32_t *n_out, int32_t *n_arr,
-                            uint64_t seed, uint32_t step, hipStream_t s)
+                            uint64_t *dest_mask, uint64_t seed, uint32_t step, hipStream_t s)
 {
     TransGrid tg{nx, nz, ny, periodic_x, periodic_y, prob_h, prob_v, cell_volume, (int2 *)outbox,
-                 n_out, n_arr};
+                 n_out, n_arr, dest_mask};
     const size_t lds = transport_lds_bytes(st, nz);
     allow_lds(k_trans_decide, lds);
     hipLaunchKernelGGL(k_trans_decide, dim3(st.n_cells), dim3(64), lds, s, st, tg, seed, step);
