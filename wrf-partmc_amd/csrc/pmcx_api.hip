@@ -52,6 +52,7 @@ struct pmcx_ctx {
     void *d_outbox = nullptr;   // transport outboxes, allocated on first use
     int32_t *d_n_out = nullptr, *d_n_arr = nullptr;
     uint64_t *d_dest_mask = nullptr;
+    int32_t *d_n_exp = nullptr;
     int64_t *d_acc = nullptr;   // running sums over calls: n_samp, n_coag, n_part, status
     double *d_diag = nullptr; // [n_cells*(2+2*n_dbin)]
     bool aero_data_set = false, env_set = false;
@@ -914,6 +915,7 @@ int pmcx_transport(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int32_t pe
         if (!rc) rc = dev_alloc(ctx, &ctx->d_n_out, nc);
         if (!rc) rc = dev_alloc(ctx, &ctx->d_n_arr, nc);
         if (!rc) rc = dev_alloc(ctx, &ctx->d_dest_mask, nc);
+        if (!rc) rc = dev_alloc(ctx, &ctx->d_n_exp, nc);
         if (rc) return rc;
     }
     const size_t bh = sizeof(double) * nc * C * 4, bv = sizeof(double) * nc * C * (size_t)nz,
@@ -925,14 +927,11 @@ int pmcx_transport(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int32_t pe
     HIP_TRY(ctx, hipMemcpyAsync(d_pv, prob_v, bv, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_cv, cell_volume, bc, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->st.status, 0, sizeof(int32_t) * nc, ctx->stream));
-    // arrivals are appended behind n_hi: close the holes first where room is short (the
-    // movers' slots are named in the outboxes, so this cannot happen once the step has begun)
-    HIP_TRY(ctx, launch_compact(ctx->st, 0, cf.n_cells, 1, -ctx->st.compact_den, ctx->stream));
     {
         ProfScope ps(ctx, "transport");
         HIP_TRY(ctx, launch_transport(ctx->st, nx, nz, ny, periodic_x, periodic_y, d_ph, d_pv, d_cv,
-                                      ctx->d_outbox, ctx->d_n_out, ctx->d_n_arr, ctx->d_dest_mask,
-                                      seed, step, ctx->stream));
+                                      ctx->d_outbox, ctx->d_n_out, ctx->d_n_arr, ctx->d_n_exp,
+                                      ctx->d_dest_mask, seed, step, ctx->stream));
     }
     if (n_moved) HIP_TRY(ctx, hipMemcpyAsync(n_moved, ctx->d_n_out, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));
     if (n_arrived) HIP_TRY(ctx, hipMemcpyAsync(n_arrived, ctx->d_n_arr, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));

@@ -119,7 +119,8 @@ size_t transport_lds_bytes(const DeviceState &st, int nz);
 hipError_t launch_transport(const DeviceState &st, int nx, int nz, int ny, int periodic_x,
                             int periodic_y, const double *prob_h, const double *prob_v,
                             const double *cell_volume, void *outbox, int32_t *n_out, int32_t *n_arr,
-                            uint64_t *dest_mask, uint64_t seed, uint32_t step, hipStream_t s);
+                            int32_t *n_exp, uint64_t *dest_mask, uint64_t seed, uint32_t step,
+                            hipStream_t s);
 // per_cell6: [6][n_cells] aer_res_a, ustar, alpha, big_a, height, inv_density
 hipError_t launch_dry_deposition(const DeviceState &st, double dt, uint64_t seed, uint32_t step,
                                  const int32_t *surface, const double *per_cell6,

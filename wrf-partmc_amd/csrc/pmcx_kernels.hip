@@ -1516,13 +1516,16 @@ __device__ __forceinline__ void move_particle(const DeviceState &st, int64_t cb,
 // sampler.  Callers that change the population pass nullptr and clear
 // sort_valid themselves.
 __device__ void compact_wave(const DeviceState &st, int c, int lane, uint32_t *cbase = nullptr,
-                             uint64_t *cmask = nullptr)
+                             uint64_t *cmask = nullptr, bool map_always = false)
 {
     const int64_t cb = (int64_t)c * st.cap;
     const int n_hi = st.n_hi[c];
     const int S = st.n_spec, NS = st.n_source;
     const uint64_t lt = (1ull << lane) - 1ull;
-    const bool remap = cbase != nullptr && st.sort_valid[c] != 0;
+    // the slot map (chunk bases and live masks) is filled for the caller when the cell's lists
+    // hold (they are renamed below) or when the caller renames something itself (map_always)
+    const bool lists = cbase != nullptr && st.sort_valid[c] != 0;
+    const bool remap = lists || (cbase != nullptr && map_always);
     int base = 0;
     // four 64-slot chunks per trip: their liveness words, then every field of the slots that
     // move, are requested together (one memory round trip each instead of one per chunk)
@@ -1611,7 +1614,7 @@ __device__ void compact_wave(const DeviceState &st, int c, int lane, uint32_t *c
     if (lane == 0) st.n_hi[c] = base;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wave_sync();
-    if (remap && base != n_hi) {
+    if (lists && base != n_hi) {
         // every position of perm up to the end of the last list; room behind a list holds
         // stale entries, renaming them is harmless
         uint32_t *perm = st.perm + (int64_t)c * st.pcap;
@@ -1643,12 +1646,8 @@ __global__ __launch_bounds__(256) void k_compact(DeviceState st, int cell_first,
     uint64_t *cmask = (uint64_t *)smem + (size_t)wave * n_chunk;
     uint32_t *cbase = (uint32_t *)((uint64_t *)smem + (size_t)(blockDim.x >> 6) * n_chunk) +
                       (size_t)wave * n_chunk;
-    // den < 0 (used before arrivals are appended behind n_hi: transport): also when the free
-    // room behind n_hi is smaller than what the holes would give back plus 1/16 of the capacity
-    const int dead = n_hi - n_live;
-    bool go = (int64_t)dead * (den < 0 ? -den : den) > (int64_t)n_hi * num;
-    if (den < 0 && dead > 0 && st.cap - n_hi < dead + st.cap / 16) go = true;
-    if (go) compact_wave(st, c, lane, cbase, cmask);
+    if ((int64_t)(n_hi - n_live) * den > (int64_t)n_hi * num)
+        compact_wave(st, c, lane, cbase, cmask);
 }
 
 // ---------------------------------------------------------------- rebalance
@@ -2097,6 +2096,7 @@ struct TransGrid {
     int2 *outbox;     // [n_cells][cap]  {slot | copies << 16, destination cell}
     int32_t *n_out;   // [n_cells]
     int32_t *n_arr;   // [n_cells]
+    int32_t *n_exp;   // [n_cells] arrivals a cell is about to receive (slots), counted by the senders
     uint64_t *dest_mask; // [n_cells] which of its neighbours a cell sends to this step: bit 0 east,
                          // 1 west, 2 north, 3 south, 4 + k level k of its own column (all ones when
                          // the grid is too small or too tall for the code to be unambiguous)
@@ -2210,11 +2210,38 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
         }
         const uint64_t mm = __ballot(moves);
         if (moves) box[n_out + (uint32_t)__popcll(mm & lt)] = make_int2(s | (copies << 16), dest);
+        if (moves && copies > 0) atomicAdd(&tg.n_exp[dest], copies);
         n_out += (uint32_t)__popcll(mm);
         rank0 += (uint32_t)__popcll(mlive);
     }
     for (int d = 32; d >= 1; d >>= 1) bits |= __shfl_xor(bits, d, 64);
     if (lane == 0) { tg.n_out[c] = (int32_t)n_out; tg.dest_mask[c] = bits; }
+}
+
+// Arrivals are appended behind n_hi.  A cell that would run out of slots while it has holes
+// closes them now (stable, as always) and renames the slots its own outbox names; this is the
+// only moment it can: the outboxes exist, nobody has read them yet.
+__global__ __launch_bounds__(256) void k_trans_room(DeviceState st, TransGrid tg)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (c >= st.n_cells) return;
+    const int n_hi = st.n_hi[c], dead = n_hi - st.n_part[c];
+    if (dead <= 0 || n_hi + tg.n_exp[c] <= st.cap) return;
+    const int n_chunk = (st.cap + 63) / 64 + 1;
+    uint64_t *cmask = (uint64_t *)smem + (size_t)wave * n_chunk;
+    uint32_t *cbase = (uint32_t *)((uint64_t *)smem + (size_t)(blockDim.x >> 6) * n_chunk) +
+                      (size_t)wave * n_chunk;
+    compact_wave(st, c, lane, cbase, cmask, true);
+    int2 *box = tg.outbox + (int64_t)c * st.cap;
+    const int n_out = tg.n_out[c];
+    for (int e = lane; e < n_out; e += 64) {
+        const int2 en = box[e];
+        const uint32_t sl = (uint32_t)en.x & 0xFFFFu, k = sl >> 6;
+        const uint32_t nw = cbase[k] + (uint32_t)__popcll(cmask[k] & ((1ull << (sl & 63)) - 1ull));
+        box[e] = make_int2((int)((uint32_t)en.x & 0xFFFF0000u) | (int)nw, en.y);
+    }
 }
 
 __global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid tg)
@@ -2751,13 +2778,17 @@ size_t transport_lds_bytes(const DeviceState &st, int nz)
 hipError_t launch_transport(const DeviceState &st, int nx, int nz, int ny, int periodic_x,
                             int periodic_y, const double *prob_h, const double *prob_v,
                             const double *cell_volume, void *outbox, int32_t *n_out, int32_t *n_arr,
-                            uint64_t *dest_mask, uint64_t seed, uint32_t step, hipStream_t s)
+                            int32_t *n_exp, uint64_t *dest_mask, uint64_t seed, uint32_t step,
+                            hipStream_t s)
 {
     TransGrid tg{nx, nz, ny, periodic_x, periodic_y, prob_h, prob_v, cell_volume, (int2 *)outbox,
-                 n_out, n_arr, dest_mask};
+                 n_out, n_arr, n_exp, dest_mask};
     const size_t lds = transport_lds_bytes(st, nz);
     allow_lds(k_trans_decide, lds);
+    (void)hipMemsetAsync(n_exp, 0, sizeof(int32_t) * (size_t)st.n_cells, s);
     hipLaunchKernelGGL(k_trans_decide, dim3(st.n_cells), dim3(64), lds, s, st, tg, seed, step);
+    allow_lds(k_trans_room, compact_lds_bytes(st));
+    hipLaunchKernelGGL(k_trans_room, dim3((st.n_cells + 3) / 4), dim3(256), compact_lds_bytes(st), s, st, tg);
     hipLaunchKernelGGL(k_trans_gather, dim3(st.n_cells), dim3(64), 0, s, st, tg);
     hipLaunchKernelGGL(k_trans_remove, dim3(st.n_cells), dim3(64), 0, s, st, tg);
     return hipGetLastError();
