@@ -76,11 +76,11 @@ __device__ __forceinline__ int32_t &norig(const DeviceState &st, int64_t cb, int
     return st.n_orig[cb * (st.n_source - 1) + (int64_t)(s - 1) * st.cap + i];
 }
 
-// tombstone: the slot stays allocated, every consumer skips it
+// tombstone: the slot stays allocated, every consumer skips it (live_class: a negative cached
+// total volume is the one mark; wclass of a dead slot is unspecified)
 __device__ __forceinline__ void mark_dead(const DeviceState &st, int64_t cb, int i)
 {
     st_f64(&st.vm[cb + i].x, -1.0);
-    st_u32((uint32_t *)&st.wclass[cb + i], 0xFFFFFFFFu);
 }
 
 // Class of the particle in slot i, or -1 for a tombstone.  A slot is dead when its cached
