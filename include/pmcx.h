@@ -211,6 +211,40 @@ int pmcx_scenario_update_aero_state(pmcx_ctx *ctx, double dt, double elapsed_tim
                                     const pmcx_aero_dist *background, int32_t *n_emit,
                                     int32_t *n_dil_in, int32_t *n_dil_out);
 
+/* The same transport for a SLAB of a domain decomposed in y across ranks (one process per
+ * GPU; wrf_pmc_trans_aero.F90 exchanges the movers between MPI patches).  The block carries
+ * one ghost row below its first real row (j = 0) and one above its last (j = ny - 1); the
+ * ghost cells hold no particles between steps, but their weights (pmcx_set_weights) and
+ * cell volumes must be those of the neighbouring rank's boundary rows, and
+ * cell_id_base must make cell_id_base + local index the global cell id (RNG key).
+ *   pmcx_transport_begin        every cell draws its movers (no periodicity in y: close a side
+ *                               that has no neighbour by zero probabilities towards it)
+ *   pmcx_transport_export_size  bytes of the movers of the boundary row that leave through
+ *                               side 0 (row 1 -> ghost row 0) or side 1 (row ny-2 -> row ny-1)
+ *   pmcx_transport_export       packs them into a DEVICE buffer of that size (a header of
+ *                               per-cell counts, then fixed-size records in source-cell and
+ *                               outbox order); ship it with RCCL / torch.distributed
+ *   pmcx_transport_import       lays a neighbour's buffer out in ghost row 0 (side 0) or ny-1
+ *                               (side 1) exactly as that neighbour's boundary row looks to a
+ *                               destination (NULL / 0 bytes: no neighbour)
+ *   pmcx_transport_finish       arrivals are pulled in the fixed source order (ghost rows
+ *                               included), movers removed, ghost rows emptied
+ * The result on the real rows is bit for bit the one of pmcx_transport on the whole domain
+ * (tests/test_gpu_parity.py::test_transport_slabs_match_whole_domain). */
+/* plain device buffers on the context's GPU for the halo exchange (callers that already hold
+ * device memory, e.g. torch tensors handed to RCCL, pass their own pointers instead) */
+int pmcx_device_alloc(pmcx_ctx *ctx, int64_t n_bytes, void **dev_ptr);
+int pmcx_device_free(pmcx_ctx *ctx, void *dev_ptr);
+/* kind: 0 device -> device, 1 host -> device, 2 device -> host; synchronises */
+int pmcx_device_copy(pmcx_ctx *ctx, void *dst, const void *src, int64_t n_bytes, int32_t kind);
+int pmcx_transport_begin(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int32_t periodic_x,
+                         const double *prob_h, const double *prob_v, const double *cell_volume,
+                         uint64_t seed, uint32_t step);
+int pmcx_transport_export_size(pmcx_ctx *ctx, int32_t side, int64_t *n_bytes);
+int pmcx_transport_export(pmcx_ctx *ctx, int32_t side, void *dev_buf);
+int pmcx_transport_import(pmcx_ctx *ctx, int32_t side, const void *dev_buf, int64_t n_bytes);
+int pmcx_transport_finish(pmcx_ctx *ctx, int32_t *n_moved, int32_t *n_arrived);
+
 /* Dry deposition of aerosol particles (dep_aero_dry_driver / dry_dep_aero_state,
  * interface/wrf_pmc_dep_aero.F90:28-192): on every cell with surface[c] != 0
  * (NULL: every cell; the reference applies it to the lowest level of interior

@@ -1,0 +1,68 @@
+"""Worker of tests/test_gpu_fortran.py-style multi-process test: run under torch.distributed.run
+with 2 ranks sharing one GPU over gloo.  Each rank owns one slab of a 4 x 3 x 6 domain, steps the
+transport with CellBlock.transport_distributed, and checks its real rows against
+pmcx_transport on the whole domain (computed locally by every rank)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(os.environ.get("PMCX_TEST_BACKEND", "gloo"))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    import wrf_partmc_amd as wp
+    from tests import parity
+    nx, nz, ny, n_class, n_spec, cap, n_part = 4, 3, 3 * world, 2, 2, 1024, 400
+    row, n = nx * nz, nx * nz * ny
+    rng = np.random.RandomState(5)
+    names, dens = parity.default_species(n_spec)
+    modes, _ = parity.make_modes(n_spec, n_class)
+    for m in modes:
+        m["source"] = m["source"] % 2
+    mag = rng.uniform(0.5e7, 2e7, (n, n_class)); cv = rng.uniform(0.8e9, 1.3e9, n)
+    ph = rng.uniform(0, 0.08, (n, n_class, 4)); pv = rng.uniform(0, 0.04, (n, n_class, nz))
+    whole = wp.CellBlock(n, cap, n_spec, n_class=n_class, n_source=2)
+    whole.set_aero_data(dens); whole.set_env(280.0, 9e4); whole.set_weights(mag)
+    whole.set_next_id((np.arange(n, dtype=np.int64) << 32) + (1 << 20))
+    whole.generate_lognormal(n_part, modes, seed=3)
+    dn = whole.download_cells()
+    j0 = 3 * rank
+    rows = [(j0 - 1) % ny, j0, j0 + 1, j0 + 2, (j0 + 3) % ny]
+    cells = np.concatenate([np.arange(j * row, (j + 1) * row) for j in rows])
+    real = cells[row:-row]
+    b = wp.CellBlock(len(cells), cap, n_spec, n_class=n_class, n_source=2,
+                     cell_id_base=((j0 - 1) * row) % (1 << 32))
+    b.set_aero_data(dens); b.set_env(280.0, 9e4); b.set_weights(mag[cells])
+    b.set_next_id((cells.astype(np.int64) << 32) + (1 << 20))
+    po = np.concatenate([[0], np.cumsum(np.diff(dn["part_offset"])[real])])
+    sel = np.concatenate([np.arange(dn["part_offset"][c], dn["part_offset"][c + 1]) for c in real])
+    b.upload_cells(row, po, dn["vol"][:, sel], dn["wclass"][sel], dn["id"][sel], dn["least_ct"][sel],
+                   dn["greatest_ct"][sel], dn["n_orig"][:, sel])
+    for g0 in (0, len(cells) - row):
+        b.upload_cells(g0, np.zeros(row + 1, np.int64), np.zeros((n_spec, 0)))
+    for step in range(3):
+        nm_w, na_w = whole.transport(nx, nz, ny, ph, pv, cv, 9, step, True, True)
+        nm, na = b.transport_distributed(dist, nx, nz, 5, ph[cells], pv[cells], cv[cells], 9, step)
+        assert np.array_equal(nm[row:-row], nm_w[real]) and np.array_equal(na[row:-row], na_w[real])
+        ref = whole.download_cells()
+        got = b.download_cells(row, len(real))
+        sel = np.concatenate([np.arange(ref["part_offset"][c], ref["part_offset"][c + 1]) for c in real])
+        for k in ("vol", "wclass", "id", "least_ct", "greatest_ct", "n_orig"):
+            assert np.array_equal(got[k], ref[k][..., sel]), (rank, step, k)
+    dist.barrier()
+    if rank == 0:
+        print(f"distributed transport ok: {world} ranks, {int(nm_w.sum())} movers in the last step")
+    whole.close(); b.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

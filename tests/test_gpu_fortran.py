@@ -80,3 +80,21 @@ def test_fortran_shim_matches_oracle(tmp_path, wp, oracle, mode):
         assert np.array_equal(ids, oc.id[:n])
         assert np.array_equal(cls - 1, oc.wclass[:n])
     assert off == len(out)
+
+
+def test_transport_across_two_ranks():
+    """The N > 1 form of the transport: two processes (one slab each, sharing this GPU, gloo
+    rendezvous on 127.0.0.1) exchange their boundary rows' movers with
+    CellBlock.transport_distributed; every rank checks its rows against the whole-domain
+    transport bit for bit (tests/dist_transport_worker.py)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PMCX_TEST_BACKEND="gloo")
+    env.pop("PMCX_SAMPLER_LANES", None)
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+         "--master-addr", "127.0.0.1", "--master-port", "29533",
+         os.path.join(ROOT, "tests", "dist_transport_worker.py")],
+        capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "distributed transport ok: 2 ranks" in out.stdout

@@ -744,6 +744,74 @@ def test_transport_makes_room_among_tombstones(wp, oracle):
     blk.close()
 
 
+def test_transport_slabs_match_whole_domain(wp):
+    """Multi-GPU form of the transport: the domain cut in two slabs along y, each
+    with a ghost row on either side, movers of the boundary rows exported / imported as device
+    buffers (what RCCL would carry), gives on every real cell exactly the particles -- order,
+    ids of the copies, everything -- of pmcx_transport on the whole domain."""
+    nx, nz, ny, n_class, n_spec, cap, n_part = 4, 3, 6, 2, 2, 1024, 500
+    row = nx * nz
+    n = row * ny
+    rng = np.random.RandomState(5)
+    names, dens = parity.default_species(n_spec)
+    modes, _ = parity.make_modes(n_spec, n_class)
+    for m in modes:
+        m["source"] = m["source"] % 2
+    mag = rng.uniform(0.5e7, 2e7, (n, n_class))
+    cv = rng.uniform(0.8e9, 1.3e9, n)
+    ph = rng.uniform(0, 0.08, (n, n_class, 4)); pv = rng.uniform(0, 0.04, (n, n_class, nz))
+    whole = wp.CellBlock(n, cap, n_spec, n_class=n_class, n_source=2)
+    whole.set_aero_data(dens); whole.set_env(280.0, 9e4); whole.set_weights(mag)
+    whole.set_next_id((np.arange(n, dtype=np.int64) << 32) + (1 << 20))
+    whole.generate_lognormal(n_part, modes, seed=3)
+    dn = whole.download_cells()
+    slabs = []
+    rows_per = ny // 2
+    for a in range(2):
+        j0 = a * rows_per
+        rows = [(j0 - 1) % ny] + list(range(j0, j0 + rows_per)) + [(j0 + rows_per) % ny]   # global rows
+        cells = np.concatenate([np.arange(j * row, (j + 1) * row) for j in rows])
+        nloc = len(cells)
+        b = wp.CellBlock(nloc, cap, n_spec, n_class=n_class, n_source=2,
+                         cell_id_base=((j0 - 1) * row) % (1 << 32))
+        b.set_aero_data(dens); b.set_env(280.0, 9e4)
+        b.set_weights(mag[cells])                       # ghost rows: the neighbour's weights
+        b.set_next_id((cells.astype(np.int64) << 32) + (1 << 20))
+        real = cells[row:-row]
+        po = np.concatenate([[0], np.cumsum(np.diff(dn["part_offset"])[real])])
+        sel = np.concatenate([np.arange(dn["part_offset"][c], dn["part_offset"][c + 1]) for c in real])
+        b.upload_cells(row, po, dn["vol"][:, sel], dn["wclass"][sel], dn["id"][sel], dn["least_ct"][sel],
+                       dn["greatest_ct"][sel], dn["n_orig"][:, sel])
+        for g0 in (0, nloc - row):                      # ghost rows start empty
+            b.upload_cells(g0, np.zeros(row + 1, np.int64), np.zeros((n_spec, 0)))
+        slabs.append((b, cells, real))
+    for step in range(3):
+        nm_w, na_w = whole.transport(nx, nz, ny, ph, pv, cv, 9, step, True, True)
+        for b, cells, real in slabs:
+            b.transport_begin(nx, nz, rows_per + 2, ph[cells], pv[cells], cv[cells], 9, step, True)
+        lo = [b.transport_export(0) for b, _, _ in slabs]     # towards the slab below
+        hi = [b.transport_export(1) for b, _, _ in slabs]     # towards the slab above
+        for a, (b, _, _) in enumerate(slabs):
+            b.transport_import(0, hi[(a - 1) % 2].copy_to(b))  # from below: its top row's movers
+            b.transport_import(1, lo[(a + 1) % 2].copy_to(b))  # from above: its bottom row's movers
+        ref = whole.download_cells()
+        for b, cells, real in slabs:
+            nm, na = b.transport_finish()
+            assert np.array_equal(nm[row:-row], nm_w[real]) and np.array_equal(na[row:-row], na_w[real]), step
+            assert not nm[:row].any() and not nm[-row:].any()
+            got = b.download_cells(row, len(real))
+            assert np.array_equal(np.diff(got["part_offset"]), np.diff(ref["part_offset"])[real]), step
+            sel = np.concatenate([np.arange(ref["part_offset"][c], ref["part_offset"][c + 1]) for c in real])
+            for k in ("vol", "wclass", "id", "least_ct", "greatest_ct", "n_orig"):
+                assert np.array_equal(got[k], ref[k][..., sel]), (step, k)
+            assert np.array_equal(b.get_next_id()[row:-row], whole.get_next_id()[real])
+            assert not b.aero_state_total_particles()[:row].any()      # ghost rows are empty again
+    assert nm_w.sum() > 1000
+    whole.close()
+    for b, _, _ in slabs:
+        b.close()
+
+
 def test_transport_conserves_with_equal_weights(wp):
     """Equal weights and volumes everywhere: every mover arrives exactly once, so the total
     particle count and the multiset of ids are conserved; a closed box keeps everything in."""

@@ -53,6 +53,11 @@ struct pmcx_ctx {
     int32_t *d_n_out = nullptr, *d_n_arr = nullptr;
     uint64_t *d_dest_mask = nullptr;
     int32_t *d_n_exp = nullptr;
+    // slab transport across ranks (pmcx_transport_begin .. _finish)
+    int32_t *d_halo = nullptr;      // [2 sides][counts(row_cells) | offsets(row_cells + 1)] + import scratch
+    int halo_nx = 0, halo_nz = 0, halo_ny = 0, halo_px = 0;
+    int64_t halo_total[2] = {0, 0}; // records to export per side (after _export_size)
+    const double *halo_cv = nullptr;
     int64_t *d_acc = nullptr;   // running sums over calls: n_samp, n_coag, n_part, status
     double *d_diag = nullptr; // [n_cells*(2+2*n_dbin)]
     bool aero_data_set = false, env_set = false;
@@ -937,6 +942,163 @@ int pmcx_transport(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int32_t pe
     if (n_arrived) HIP_TRY(ctx, hipMemcpyAsync(n_arrived, ctx->d_n_arr, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, invalidate_sort(ctx, 0, ctx->cfg.n_cells));
+    return PMCX_OK;
+}
+
+// ---- transport of a slab whose first and last rows are ghosts of the neighbouring ranks ----
+
+static int transport_buffers(pmcx_ctx *ctx)
+{
+    const size_t nc = (size_t)ctx->cfg.n_cells;
+    if (!ctx->d_outbox) {
+        int rc = dev_alloc(ctx, (int64_t **)&ctx->d_outbox, nc * (size_t)ctx->cfg.cap, false);
+        if (!rc) rc = dev_alloc(ctx, &ctx->d_n_out, nc);
+        if (!rc) rc = dev_alloc(ctx, &ctx->d_n_arr, nc);
+        if (!rc) rc = dev_alloc(ctx, &ctx->d_dest_mask, nc);
+        if (!rc) rc = dev_alloc(ctx, &ctx->d_n_exp, nc);
+        if (rc) return rc;
+    }
+    return PMCX_OK;
+}
+
+int pmcx_device_alloc(pmcx_ctx *ctx, int64_t n_bytes, void **dev_ptr)
+{
+    if (!ctx || !dev_ptr || n_bytes < 0) return fail(ctx, PMCX_EINVAL, "pmcx_device_alloc: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    *dev_ptr = nullptr;
+    HIP_TRY(ctx, hipMalloc(dev_ptr, (size_t)(n_bytes > 0 ? n_bytes : 1)));
+    return PMCX_OK;
+}
+int pmcx_device_free(pmcx_ctx *ctx, void *dev_ptr)
+{
+    if (!ctx) return PMCX_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    if (dev_ptr) HIP_TRY(ctx, hipFree(dev_ptr));
+    return PMCX_OK;
+}
+int pmcx_device_copy(pmcx_ctx *ctx, void *dst, const void *src, int64_t n_bytes, int32_t kind)
+{
+    if (!ctx || (n_bytes > 0 && (!dst || !src)) || kind < 0 || kind > 2)
+        return fail(ctx, PMCX_EINVAL, "pmcx_device_copy: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const hipMemcpyKind k = kind == 0 ? hipMemcpyDeviceToDevice : kind == 1 ? hipMemcpyHostToDevice
+                                                                          : hipMemcpyDeviceToHost;
+    if (n_bytes > 0) HIP_TRY(ctx, hipMemcpyAsync(dst, src, (size_t)n_bytes, k, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PMCX_OK;
+}
+
+int pmcx_transport_begin(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int32_t periodic_x,
+                         const double *prob_h, const double *prob_v, const double *cell_volume,
+                         uint64_t seed, uint32_t step)
+{
+    if (!ctx || !prob_h || !prob_v || !cell_volume)
+        return fail(ctx, PMCX_EINVAL, "pmcx_transport_begin: null argument");
+    const pmcx_config &cf = ctx->cfg;
+    if (nx < 1 || nz < 1 || ny < 3 || nz > 128 || (int64_t)nx * nz * ny != cf.n_cells)
+        return fail(ctx, PMCX_EINVAL, "pmcx_transport_begin: nx*nz*ny must equal n_cells, ny >= 3 "
+                                      "(two ghost rows), nz <= 128");
+    if (transport_lds_bytes(ctx->st, nz) > 160 * 1024)
+        return fail(ctx, PMCX_EINVAL, "pmcx_transport_begin: destination tables exceed LDS");
+    HIP_TRY(ctx, hipSetDevice(cf.device));
+    int rc = transport_buffers(ctx);
+    if (rc) return rc;
+    const size_t nc = (size_t)cf.n_cells, C = (size_t)cf.n_class, row = (size_t)nx * nz;
+    if (!ctx->d_halo || ctx->halo_nx * ctx->halo_nz != (int)row) {
+        ctx->d_halo = nullptr;
+        rc = dev_alloc(ctx, &ctx->d_halo, 6 * (row + 1));
+        if (rc) return rc;
+    }
+    const size_t bh = sizeof(double) * nc * C * 4, bv = sizeof(double) * nc * C * (size_t)nz,
+                 bc = sizeof(double) * nc;
+    rc = ensure_stage(ctx, bh + bv + bc + 64);
+    if (rc) return rc;
+    double *d_ph = (double *)ctx->stage, *d_pv = d_ph + nc * C * 4, *d_cv = d_pv + nc * C * (size_t)nz;
+    HIP_TRY(ctx, hipMemcpyAsync(d_ph, prob_h, bh, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_pv, prob_v, bv, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_cv, cell_volume, bc, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->st.status, 0, sizeof(int32_t) * nc, ctx->stream));
+    ctx->halo_nx = nx; ctx->halo_nz = nz; ctx->halo_ny = ny; ctx->halo_px = periodic_x;
+    ctx->halo_cv = d_cv; ctx->halo_total[0] = ctx->halo_total[1] = -1;
+    ProfScope ps(ctx, "transport");
+    HIP_TRY(ctx, launch_transport_begin(ctx->st, nx, nz, ny, periodic_x, 0, d_ph, d_pv, d_cv,
+                                        ctx->d_outbox, ctx->d_n_out, ctx->d_n_arr, ctx->d_n_exp,
+                                        ctx->d_dest_mask, seed, step, ctx->stream));
+    return PMCX_OK;
+}
+
+static inline size_t halo_header_bytes(int row_cells) { return ((size_t)row_cells * 4 + 15) & ~(size_t)15; }
+
+int pmcx_transport_export_size(pmcx_ctx *ctx, int32_t side, int64_t *n_bytes)
+{
+    if (!ctx || !n_bytes || side < 0 || side > 1 || !ctx->halo_nx)
+        return fail(ctx, PMCX_EINVAL, "pmcx_transport_export_size: bad argument or no pmcx_transport_begin");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const int row = ctx->halo_nx * ctx->halo_nz, ny = ctx->halo_ny;
+    const int src_row = side == 0 ? 1 : ny - 2, dst_row = side == 0 ? 0 : ny - 1;
+    int32_t *counts = ctx->d_halo + (size_t)side * 2 * (row + 1), *offsets = counts + row;
+    HIP_TRY(ctx, launch_halo_count(ctx->st, ctx->halo_nx, ctx->halo_nz, ny, ctx->d_outbox, ctx->d_n_out,
+                                   src_row, dst_row, counts, offsets, ctx->stream));
+    int32_t total = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&total, offsets + row, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->halo_total[side] = total;
+    *n_bytes = (int64_t)halo_header_bytes(row) + (int64_t)total * (int64_t)halo_record_bytes(ctx->st);
+    return PMCX_OK;
+}
+
+int pmcx_transport_export(pmcx_ctx *ctx, int32_t side, void *dev_buf)
+{
+    if (!ctx || !dev_buf || side < 0 || side > 1 || !ctx->halo_nx || ctx->halo_total[side] < 0)
+        return fail(ctx, PMCX_EINVAL, "pmcx_transport_export: call pmcx_transport_export_size first");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const int row = ctx->halo_nx * ctx->halo_nz, ny = ctx->halo_ny;
+    const int src_row = side == 0 ? 1 : ny - 2, dst_row = side == 0 ? 0 : ny - 1;
+    const int32_t *counts = ctx->d_halo + (size_t)side * 2 * (row + 1), *offsets = counts + row;
+    HIP_TRY(ctx, hipMemcpyAsync(dev_buf, counts, sizeof(int32_t) * row, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, launch_halo_pack(ctx->st, ctx->halo_nx, ctx->halo_nz, ny, ctx->d_outbox, ctx->d_n_out,
+                                  src_row, dst_row, offsets, (unsigned char *)dev_buf + halo_header_bytes(row),
+                                  ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PMCX_OK;
+}
+
+int pmcx_transport_import(pmcx_ctx *ctx, int32_t side, const void *dev_buf, int64_t n_bytes)
+{
+    if (!ctx || side < 0 || side > 1 || !ctx->halo_nx)
+        return fail(ctx, PMCX_EINVAL, "pmcx_transport_import: bad argument or no pmcx_transport_begin");
+    if (!dev_buf || n_bytes == 0) return PMCX_OK; // no neighbour on that side: the ghost row stays empty
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const int row = ctx->halo_nx * ctx->halo_nz, ny = ctx->halo_ny;
+    if (n_bytes < (int64_t)halo_header_bytes(row))
+        return fail(ctx, PMCX_EINVAL, "pmcx_transport_import: buffer shorter than its header");
+    const int ghost_row = side == 0 ? 0 : ny - 1, real_row = side == 0 ? 1 : ny - 2;
+    int32_t *offsets = ctx->d_halo + 4 * (size_t)(row + 1) + (size_t)side * (row + 1);
+    HIP_TRY(ctx, launch_halo_unpack(ctx->st, ctx->halo_nx, ctx->halo_nz, ny, ctx->d_outbox, ctx->d_n_out,
+                                    ctx->d_n_exp, ctx->d_dest_mask, ghost_row, real_row,
+                                    (const int32_t *)dev_buf, offsets,
+                                    (const unsigned char *)dev_buf + halo_header_bytes(row), ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PMCX_OK;
+}
+
+int pmcx_transport_finish(pmcx_ctx *ctx, int32_t *n_moved, int32_t *n_arrived)
+{
+    if (!ctx || !ctx->halo_nx) return fail(ctx, PMCX_EINVAL, "pmcx_transport_finish: no pmcx_transport_begin");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t nc = (size_t)ctx->cfg.n_cells;
+    {
+        ProfScope ps(ctx, "transport");
+        HIP_TRY(ctx, launch_transport_finish(ctx->st, ctx->halo_nx, ctx->halo_nz, ctx->halo_ny, ctx->halo_px,
+                                             0, ctx->halo_cv, ctx->d_outbox, ctx->d_n_out, ctx->d_n_arr,
+                                             ctx->d_n_exp, ctx->d_dest_mask, 1, ctx->halo_ny - 2,
+                                             ctx->stream));
+    }
+    if (n_moved) HIP_TRY(ctx, hipMemcpyAsync(n_moved, ctx->d_n_out, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));
+    if (n_arrived) HIP_TRY(ctx, hipMemcpyAsync(n_arrived, ctx->d_n_arr, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, invalidate_sort(ctx, 0, ctx->cfg.n_cells));
+    ctx->halo_nx = 0;
     return PMCX_OK;
 }
 

@@ -121,6 +121,26 @@ hipError_t launch_transport(const DeviceState &st, int nx, int nz, int ny, int p
                             const double *cell_volume, void *outbox, int32_t *n_out, int32_t *n_arr,
                             int32_t *n_exp, uint64_t *dest_mask, uint64_t seed, uint32_t step,
                             hipStream_t s);
+hipError_t launch_transport_begin(const DeviceState &st, int nx, int nz, int ny, int periodic_x,
+                                  int periodic_y, const double *prob_h, const double *prob_v,
+                                  const double *cell_volume, void *outbox, int32_t *n_out,
+                                  int32_t *n_arr, int32_t *n_exp, uint64_t *dest_mask, uint64_t seed,
+                                  uint32_t step, hipStream_t s);
+hipError_t launch_transport_finish(const DeviceState &st, int nx, int nz, int ny, int periodic_x,
+                                   int periodic_y, const double *cell_volume, void *outbox,
+                                   int32_t *n_out, int32_t *n_arr, int32_t *n_exp,
+                                   uint64_t *dest_mask, int row_first, int n_rows, hipStream_t s);
+size_t halo_record_bytes(const DeviceState &st);
+hipError_t launch_halo_count(const DeviceState &st, int nx, int nz, int ny, void *outbox,
+                             int32_t *n_out, int src_row, int dst_row, int32_t *counts,
+                             int32_t *offsets, hipStream_t s);
+hipError_t launch_halo_pack(const DeviceState &st, int nx, int nz, int ny, void *outbox,
+                            int32_t *n_out, int src_row, int dst_row, const int32_t *offsets,
+                            void *recs, hipStream_t s);
+hipError_t launch_halo_unpack(const DeviceState &st, int nx, int nz, int ny, void *outbox,
+                              int32_t *n_out, int32_t *n_exp, uint64_t *dest_mask, int ghost_row,
+                              int real_row, const int32_t *counts, int32_t *offsets, const void *recs,
+                              hipStream_t s);
 // per_cell6: [6][n_cells] aer_res_a, ustar, alpha, big_a, height, inv_density
 hipError_t launch_dry_deposition(const DeviceState &st, double dt, uint64_t seed, uint32_t step,
                                  const int32_t *surface, const double *per_cell6,

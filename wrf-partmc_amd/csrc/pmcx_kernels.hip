@@ -2096,6 +2096,8 @@ struct TransGrid {
     int2 *outbox;     // [n_cells][cap]  {slot | copies << 16, destination cell}
     int32_t *n_out;   // [n_cells]
     int32_t *n_arr;   // [n_cells]
+    int32_t c_first;  // gather / remove work on cells [c_first, c_first + gridDim.x): the real rows
+                      // of a slab whose first and last rows are ghosts of the neighbouring ranks
     int32_t *n_exp;   // [n_cells] arrivals a cell is about to receive (slots), counted by the senders
     uint64_t *dest_mask; // [n_cells] which of its neighbours a cell sends to this step: bit 0 east,
                          // 1 west, 2 north, 3 south, 4 + k level k of its own column (all ones when
@@ -2246,7 +2248,7 @@ __global__ __launch_bounds__(256) void k_trans_room(DeviceState st, TransGrid tg
 
 __global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid tg)
 {
-    const int lane = threadIdx.x, c = blockIdx.x;
+    const int lane = threadIdx.x, c = tg.c_first + blockIdx.x;
     const int nx = tg.nx, nz = tg.nz, ny = tg.ny;
     const int i = c % nx, k = (c / nx) % nz, j = c / (nx * nz);
     const int64_t cb = (int64_t)c * st.cap;
@@ -2330,7 +2332,7 @@ __global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid t
 
 __global__ __launch_bounds__(64) void k_trans_remove(DeviceState st, TransGrid tg)
 {
-    const int lane = threadIdx.x, c = blockIdx.x;
+    const int lane = threadIdx.x, c = tg.c_first + blockIdx.x;
     const int64_t cb = (int64_t)c * st.cap;
     const int n_out = tg.n_out[c];
     const int2 *box = tg.outbox + cb;
@@ -2344,6 +2346,146 @@ __global__ __launch_bounds__(64) void k_trans_remove(DeviceState st, TransGrid t
     wave_sync();
     const int n_hi = st.n_hi[c];
     if ((n_hi - n_live) * st.compact_den > n_hi) compact_wave(st, c, lane);
+}
+
+// ------------------------------------------------------- transport across ranks
+//
+// Slab decomposition in y: a rank's block carries one ghost row below its first real row and
+// one above its last.  After k_trans_decide the movers of a boundary row that go to the
+// neighbouring rank are packed (source cell by source cell, in outbox order) and shipped;
+// the receiver lays them out in its ghost row exactly as the sender's boundary row looked to
+// a destination -- particles in slots 0.., an outbox that names them -- so that
+// k_trans_gather, unchanged, pulls them in the same place of its fixed source order as it
+// would inside one block.  Record: header {src, dest (cell index within its row), copies,
+// wclass, index within the source cell, pad} | vtot, mass | lct, gct, id, n_orig0 |
+// vol[n_spec] | n_orig[1..] (padded to 8 bytes).
+
+__host__ __device__ inline size_t halo_rec_bytes(int n_spec, int n_source)
+{
+    const size_t extra = n_source > 1 ? (size_t)(n_source - 1) * 4 : 0;
+    return 24 + 16 + 32 + 8 * (size_t)n_spec + ((extra + 7) & ~(size_t)7);
+}
+
+// entries of the cells of row src_row that go to row dst_row: counts per source cell
+__global__ __launch_bounds__(64) void k_halo_count(DeviceState st, TransGrid tg, int src_row,
+                                                   int dst_row, int32_t *counts)
+{
+    const int lane = threadIdx.x, r = blockIdx.x; // r: cell index within the row
+    const int row_cells = tg.nx * tg.nz;
+    const int c = src_row * row_cells + r;
+    const int2 *box = tg.outbox + (int64_t)c * st.cap;
+    const int n_out = tg.n_out[c];
+    int cnt = 0;
+    for (int e0 = 0; e0 < n_out; e0 += 64) {
+        const int e = e0 + lane;
+        const bool mine = e < n_out && box[e].y / row_cells == dst_row;
+        cnt += __popcll(__ballot(mine));
+    }
+    if (lane == 0) counts[r] = cnt;
+}
+
+// exclusive scan of n counts by one wavefront; offsets[n] = total
+__global__ __launch_bounds__(64) void k_halo_scan(const int32_t *counts, int32_t *offsets, int n)
+{
+    const int lane = threadIdx.x;
+    uint32_t base = 0;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        const int j = j0 + lane;
+        const uint32_t x = j < n ? (uint32_t)counts[j] : 0u;
+        const uint32_t inc = wave_incl_scan_u32(x, lane);
+        if (j < n) offsets[j] = (int32_t)(base + inc - x);
+        base += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) offsets[n] = (int32_t)base;
+}
+
+__global__ __launch_bounds__(64) void k_halo_pack(DeviceState st, TransGrid tg, int src_row,
+                                                  int dst_row, const int32_t *offsets,
+                                                  unsigned char *recs, int rec_bytes)
+{
+    const int lane = threadIdx.x, r = blockIdx.x;
+    const int row_cells = tg.nx * tg.nz;
+    const int c = src_row * row_cells + r;
+    const int64_t cb = (int64_t)c * st.cap;
+    const int2 *box = tg.outbox + cb;
+    const int n_out = tg.n_out[c];
+    const int S = st.n_spec, NS = st.n_source;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    int at = 0;
+    for (int e0 = 0; e0 < n_out; e0 += 64) {
+        const int e = e0 + lane;
+        int2 en = make_int2(0, -1);
+        if (e < n_out) en = box[e];
+        const bool mine = e < n_out && en.y / row_cells == dst_row;
+        const uint64_t m = __ballot(mine);
+        if (mine) {
+            const int idx = at + __popcll(m & lt);
+            unsigned char *rec = recs + (size_t)(offsets[r] + idx) * rec_bytes;
+            const int from = en.x & 0xFFFF;
+            int32_t *h = (int32_t *)rec;
+            h[0] = r; h[1] = en.y - dst_row * row_cells; h[2] = en.x >> 16;
+            h[3] = st.wclass[cb + from]; h[4] = idx; h[5] = 0;
+            double *d = (double *)(rec + 24);
+            d[0] = st.vm[cb + from].x; d[1] = st.vm[cb + from].y;
+            d[2] = st.meta[cb + from].lct; d[3] = st.meta[cb + from].gct;
+            ((int64_t *)d)[4] = st.meta[cb + from].id;
+            ((int32_t *)(d + 5))[0] = st.meta[cb + from].n_orig0; ((int32_t *)(d + 5))[1] = 0;
+            for (int sp = 0; sp < S; sp++) d[6 + sp] = st.vol[(cb + from) * S + sp];
+            int32_t *no = (int32_t *)(d + 6 + S);
+            for (int sp = 1; sp < NS; sp++) no[sp - 1] = norig(st, cb, sp, from);
+        }
+        at += __popcll(m);
+    }
+}
+
+// the receiving side: ghost cell r of row ghost_row gets its records' particles in slots 0..,
+// an outbox naming them with destinations in row real_row, and tells those cells what is coming
+__global__ __launch_bounds__(64) void k_halo_unpack(DeviceState st, TransGrid tg, int ghost_row,
+                                                    int real_row, const int32_t *counts,
+                                                    const int32_t *offsets,
+                                                    const unsigned char *recs, int rec_bytes,
+                                                    uint64_t mask_bit)
+{
+    const int lane = threadIdx.x, r = blockIdx.x;
+    const int row_cells = tg.nx * tg.nz;
+    const int c = ghost_row * row_cells + r;
+    const int64_t cb = (int64_t)c * st.cap;
+    int2 *box = tg.outbox + cb;
+    const int S = st.n_spec, NS = st.n_source;
+    const int cnt = counts[r];
+    for (int e = lane; e < cnt; e += 64) {
+        const unsigned char *rec = recs + (size_t)(offsets[r] + e) * rec_bytes;
+        const int32_t *h = (const int32_t *)rec;
+        const int slot = h[4]; // = e: records of a cell arrive in order
+        const int dest = real_row * row_cells + h[1], copies = h[2];
+        const double *d = (const double *)(rec + 24);
+        st.vm[cb + slot].x = d[0]; st.vm[cb + slot].y = d[1];
+        st.meta[cb + slot].lct = d[2]; st.meta[cb + slot].gct = d[3];
+        st.meta[cb + slot].id = ((const int64_t *)d)[4];
+        st.meta[cb + slot].n_orig0 = ((const int32_t *)(d + 5))[0];
+        st.wclass[cb + slot] = h[3];
+        for (int sp = 0; sp < S; sp++) st.vol[(cb + slot) * S + sp] = d[6 + sp];
+        const int32_t *no = (const int32_t *)(d + 6 + S);
+        for (int sp = 1; sp < NS; sp++) norig(st, cb, sp, slot) = no[sp - 1];
+        box[slot] = make_int2(slot | (copies << 16), dest);
+        if (copies > 0) atomicAdd(&tg.n_exp[dest], copies);
+    }
+    if (lane == 0) {
+        tg.n_out[c] = cnt;
+        tg.dest_mask[c] = cnt ? mask_bit : 0ull;
+        st.n_hi[c] = cnt;
+        st.n_part[c] = cnt;
+    }
+}
+
+// ghost rows are scratch: empty again once the step is over
+__global__ void k_halo_clear(DeviceState st, TransGrid tg, int row_a, int row_b)
+{
+    const int row_cells = tg.nx * tg.nz;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= 2 * row_cells) return;
+    const int c = (j < row_cells ? row_a : row_b) * row_cells + (j % row_cells);
+    st.n_hi[c] = 0; st.n_part[c] = 0; tg.n_out[c] = 0; tg.dest_mask[c] = 0; st.sort_valid[c] = 0;
 }
 
 // ------------------------------------------------------------- condensation
@@ -2775,22 +2917,96 @@ size_t transport_lds_bytes(const DeviceState &st, int nz)
     const size_t nd = (size_t)(4 + nz), C = (size_t)st.n_class;
     return (sizeof(double) * 4 + sizeof(int) * 2 + sizeof(uint64_t)) * C * nd + sizeof(int) * C + 24;
 }
+static TransGrid make_grid(int nx, int nz, int ny, int periodic_x, int periodic_y,
+                           const double *prob_h, const double *prob_v, const double *cell_volume,
+                           void *outbox, int32_t *n_out, int32_t *n_arr, int32_t *n_exp,
+                           uint64_t *dest_mask, int c_first)
+{
+    return TransGrid{nx, nz, ny, periodic_x, periodic_y, prob_h, prob_v, cell_volume, (int2 *)outbox,
+                     n_out, n_arr, c_first, n_exp, dest_mask};
+}
+// decide: every cell draws its movers (outboxes, expected arrivals, destination masks)
+hipError_t launch_transport_begin(const DeviceState &st, int nx, int nz, int ny, int periodic_x,
+                                  int periodic_y, const double *prob_h, const double *prob_v,
+                                  const double *cell_volume, void *outbox, int32_t *n_out,
+                                  int32_t *n_arr, int32_t *n_exp, uint64_t *dest_mask, uint64_t seed,
+                                  uint32_t step, hipStream_t s)
+{
+    const TransGrid tg = make_grid(nx, nz, ny, periodic_x, periodic_y, prob_h, prob_v, cell_volume,
+                                   outbox, n_out, n_arr, n_exp, dest_mask, 0);
+    const size_t lds = transport_lds_bytes(st, nz);
+    allow_lds(k_trans_decide, lds);
+    (void)hipMemsetAsync(n_exp, 0, sizeof(int32_t) * (size_t)st.n_cells, s);
+    hipLaunchKernelGGL(k_trans_decide, dim3(st.n_cells), dim3(64), lds, s, st, tg, seed, step);
+    return hipGetLastError();
+}
+// room, gather, remove on the rows [row_first, row_first + n_rows); ghost rows emptied
+hipError_t launch_transport_finish(const DeviceState &st, int nx, int nz, int ny, int periodic_x,
+                                   int periodic_y, const double *cell_volume, void *outbox,
+                                   int32_t *n_out, int32_t *n_arr, int32_t *n_exp,
+                                   uint64_t *dest_mask, int row_first, int n_rows, hipStream_t s)
+{
+    const int c_first = row_first * nx * nz, n_do = n_rows * nx * nz;
+    const TransGrid tg = make_grid(nx, nz, ny, periodic_x, periodic_y, nullptr, nullptr, cell_volume,
+                                   outbox, n_out, n_arr, n_exp, dest_mask, c_first);
+    allow_lds(k_trans_room, compact_lds_bytes(st));
+    hipLaunchKernelGGL(k_trans_room, dim3((st.n_cells + 3) / 4), dim3(256), compact_lds_bytes(st), s, st, tg);
+    hipLaunchKernelGGL(k_trans_gather, dim3(n_do), dim3(64), 0, s, st, tg);
+    hipLaunchKernelGGL(k_trans_remove, dim3(n_do), dim3(64), 0, s, st, tg);
+    if (n_rows != ny) // a slab: rows 0 and ny - 1 are ghosts
+        hipLaunchKernelGGL(k_halo_clear, dim3((2 * nx * nz + 255) / 256), dim3(256), 0, s, st, tg, 0, ny - 1);
+    return hipGetLastError();
+}
 hipError_t launch_transport(const DeviceState &st, int nx, int nz, int ny, int periodic_x,
                             int periodic_y, const double *prob_h, const double *prob_v,
                             const double *cell_volume, void *outbox, int32_t *n_out, int32_t *n_arr,
                             int32_t *n_exp, uint64_t *dest_mask, uint64_t seed, uint32_t step,
                             hipStream_t s)
 {
-    TransGrid tg{nx, nz, ny, periodic_x, periodic_y, prob_h, prob_v, cell_volume, (int2 *)outbox,
-                 n_out, n_arr, n_exp, dest_mask};
-    const size_t lds = transport_lds_bytes(st, nz);
-    allow_lds(k_trans_decide, lds);
-    (void)hipMemsetAsync(n_exp, 0, sizeof(int32_t) * (size_t)st.n_cells, s);
-    hipLaunchKernelGGL(k_trans_decide, dim3(st.n_cells), dim3(64), lds, s, st, tg, seed, step);
-    allow_lds(k_trans_room, compact_lds_bytes(st));
-    hipLaunchKernelGGL(k_trans_room, dim3((st.n_cells + 3) / 4), dim3(256), compact_lds_bytes(st), s, st, tg);
-    hipLaunchKernelGGL(k_trans_gather, dim3(st.n_cells), dim3(64), 0, s, st, tg);
-    hipLaunchKernelGGL(k_trans_remove, dim3(st.n_cells), dim3(64), 0, s, st, tg);
+    hipError_t e = launch_transport_begin(st, nx, nz, ny, periodic_x, periodic_y, prob_h, prob_v,
+                                          cell_volume, outbox, n_out, n_arr, n_exp, dest_mask, seed,
+                                          step, s);
+    if (e != hipSuccess) return e;
+    return launch_transport_finish(st, nx, nz, ny, periodic_x, periodic_y, cell_volume, outbox, n_out,
+                                   n_arr, n_exp, dest_mask, 0, ny, s);
+}
+size_t halo_record_bytes(const DeviceState &st) { return halo_rec_bytes(st.n_spec, st.n_source); }
+// counts[row_cells] and offsets[row_cells + 1] of the movers of row src_row bound for dst_row
+hipError_t launch_halo_count(const DeviceState &st, int nx, int nz, int ny, void *outbox,
+                             int32_t *n_out, int src_row, int dst_row, int32_t *counts,
+                             int32_t *offsets, hipStream_t s)
+{
+    const TransGrid tg = make_grid(nx, nz, ny, 0, 0, nullptr, nullptr, nullptr, outbox, n_out, nullptr,
+                                   nullptr, nullptr, 0);
+    hipLaunchKernelGGL(k_halo_count, dim3(nx * nz), dim3(64), 0, s, st, tg, src_row, dst_row, counts);
+    hipLaunchKernelGGL(k_halo_scan, dim3(1), dim3(64), 0, s, counts, offsets, nx * nz);
+    return hipGetLastError();
+}
+hipError_t launch_halo_pack(const DeviceState &st, int nx, int nz, int ny, void *outbox,
+                            int32_t *n_out, int src_row, int dst_row, const int32_t *offsets,
+                            void *recs, hipStream_t s)
+{
+    const TransGrid tg = make_grid(nx, nz, ny, 0, 0, nullptr, nullptr, nullptr, outbox, n_out, nullptr,
+                                   nullptr, nullptr, 0);
+    hipLaunchKernelGGL(k_halo_pack, dim3(nx * nz), dim3(64), 0, s, st, tg, src_row, dst_row, offsets,
+                       (unsigned char *)recs, (int)halo_rec_bytes(st.n_spec, st.n_source));
+    return hipGetLastError();
+}
+hipError_t launch_halo_unpack(const DeviceState &st, int nx, int nz, int ny, void *outbox,
+                              int32_t *n_out, int32_t *n_exp, uint64_t *dest_mask, int ghost_row,
+                              int real_row, const int32_t *counts, int32_t *offsets, const void *recs,
+                              hipStream_t s)
+{
+    const TransGrid tg = make_grid(nx, nz, ny, 0, 0, nullptr, nullptr, nullptr, outbox, n_out, nullptr,
+                                   n_exp, dest_mask, 0);
+    // the gather of row real_row looks at the ghost row as its south (ghost below) or north
+    // neighbour: bit 2 = "sends north", bit 3 = "sends south" (k_trans_decide's code)
+    const bool ok = 4 + nz <= 64 && nx >= 3 && ny >= 3;
+    const uint64_t bit = !ok ? ~0ull : (ghost_row < real_row ? 4ull : 8ull);
+    hipLaunchKernelGGL(k_halo_scan, dim3(1), dim3(64), 0, s, counts, offsets, nx * nz);
+    hipLaunchKernelGGL(k_halo_unpack, dim3(nx * nz), dim3(64), 0, s, st, tg, ghost_row, real_row,
+                       counts, offsets, (const unsigned char *)recs,
+                       (int)halo_rec_bytes(st.n_spec, st.n_source), bit);
     return hipGetLastError();
 }
 hipError_t launch_dry_deposition(const DeviceState &st, double dt, uint64_t seed, uint32_t step,

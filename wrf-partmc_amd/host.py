@@ -33,6 +33,9 @@ EXPORTED_SYMBOLS = [
     "pmcx_generate_lognormal", "pmcx_timestep", "pmcx_get_bin_tables", "pmcx_get_diag_grid",
     "pmcx_get_kmax", "pmcx_get_caches", "pmcx_sort_only", "pmcx_invalidate_sort", "pmcx_get_sort", "pmcx_test_math",
     "pmcx_test_philox", "pmcx_profile_enable", "pmcx_profile_reset", "pmcx_profile_get", "pmcx_profile_phase_cycles", "pmcx_dry_deposition",
+    "pmcx_transport_begin", "pmcx_transport_export_size", "pmcx_transport_export",
+    "pmcx_transport_import", "pmcx_transport_finish", "pmcx_device_alloc", "pmcx_device_free",
+    "pmcx_device_copy",
     "pmcx_memory_bytes",
 ]
 
@@ -123,6 +126,15 @@ def load_library():
     L.pmcx_profile_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double),
                                    C.POINTER(C.c_int64)]
     L.pmcx_profile_phase_cycles.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    L.pmcx_transport_begin.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
+    L.pmcx_transport_export_size.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
+    L.pmcx_transport_export.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    L.pmcx_transport_import.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+    L.pmcx_transport_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pmcx_device_alloc.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
+    L.pmcx_device_free.argtypes = [C.c_void_p, C.c_void_p]
+    L.pmcx_device_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
     L.pmcx_dry_deposition.argtypes = [C.c_void_p, C.c_double, C.c_uint64, C.c_uint32] + [C.c_void_p] * 9
     L.pmcx_timestep.argtypes = [C.c_void_p, C.POINTER(PmcxStepFlags)]
     for name in ("pmcx_upload_cells", "pmcx_download_cells"):
@@ -137,6 +149,29 @@ def _ptr(a):
 
 def _f64(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+class DeviceBuffer:
+    """A plain device allocation on a block's GPU (pmcx_device_alloc): what the halo exchange of
+    the transport hands around when no torch tensor is involved."""
+
+    def __init__(self, blk, nbytes):
+        self._blk, self.nbytes = blk, int(nbytes)
+        self.ptr = C.c_void_p()
+        blk._ck(blk._lib.pmcx_device_alloc(blk._h, self.nbytes, C.byref(self.ptr)))
+
+    def copy_to(self, other_blk):
+        """A copy owned by another block (same GPU): the in-process stand-in for a send."""
+        out = DeviceBuffer(other_blk, self.nbytes)
+        other_blk._ck(other_blk._lib.pmcx_device_copy(other_blk._h, out.ptr, self.ptr, self.nbytes, 0))
+        return out
+
+    def __del__(self):
+        try:
+            if self.ptr and self._blk._h and self._blk._h.value:
+                self._blk._lib.pmcx_device_free(self._blk._h, self.ptr)
+        except Exception:
+            pass
 
 
 class CellBlock:
@@ -382,6 +417,96 @@ class CellBlock:
             self._h, dt, elapsed_time, seed, step, C.addressof(e) if e else None, _ptr(dil),
             C.addressof(b) if b else None, _ptr(ne), _ptr(ni), _ptr(no)))
         return ne, ni, no
+
+    # -- transport of a slab across ranks (ghost rows j = 0 and j = ny - 1) -----
+    def transport_begin(self, nx, nz, ny, prob_h, prob_v, cell_volume, seed=0, step=0,
+                        periodic_x=True):
+        n, Cn = self.cfg.n_cells, self.cfg.n_class
+        self._tr = (np.ascontiguousarray(np.broadcast_to(_f64(prob_h), (n, Cn, 4))),
+                    np.ascontiguousarray(np.broadcast_to(_f64(prob_v), (n, Cn, nz))),
+                    np.ascontiguousarray(np.broadcast_to(_f64(cell_volume), (n,))))
+        self._ck(self._lib.pmcx_transport_begin(self._h, nx, nz, ny, int(periodic_x), _ptr(self._tr[0]),
+                                                _ptr(self._tr[1]), _ptr(self._tr[2]), seed, step))
+
+    def transport_export(self, side):
+        """The movers leaving through `side` (0: towards row 0, 1: towards row ny - 1) as a
+        DeviceBuffer on this block's GPU (an empty side still carries its header)."""
+        nb = C.c_int64(0)
+        self._ck(self._lib.pmcx_transport_export_size(self._h, side, C.byref(nb)))
+        buf = DeviceBuffer(self, nb.value)
+        self._ck(self._lib.pmcx_transport_export(self._h, side, buf.ptr))
+        return buf
+
+    def transport_import(self, side, buf):
+        """Fills ghost row 0 (side 0) or ny - 1 (side 1) from a neighbour's export: a
+        DeviceBuffer, a (device pointer, bytes) pair or a CUDA torch tensor; None: no neighbour."""
+        if buf is None:
+            self._ck(self._lib.pmcx_transport_import(self._h, side, None, 0))
+            return
+        if isinstance(buf, DeviceBuffer):
+            ptr, nb = buf.ptr, buf.nbytes
+        elif isinstance(buf, tuple):
+            ptr, nb = C.c_void_p(buf[0]), buf[1]
+        else:
+            ptr, nb = C.c_void_p(buf.data_ptr()), buf.numel() * buf.element_size()
+        self._ck(self._lib.pmcx_transport_import(self._h, side, ptr, nb))
+
+    def transport_finish(self):
+        n = self.cfg.n_cells
+        nm, na = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+        self._ck(self._lib.pmcx_transport_finish(self._h, _ptr(nm), _ptr(na)))
+        return nm, na
+
+    def transport_distributed(self, dist, nx, nz, ny, prob_h, prob_v, cell_volume, seed=0, step=0,
+                              periodic_x=True, periodic_y=True):
+        """One transport step of this rank's slab inside a torch.distributed job (one process
+        per GPU, ranks ordered along y): movers of the two boundary rows go to the ranks
+        below and above as device buffers (RCCL point-to-point on the "nccl" backend; staged
+        through the host on "gloo").  Without periodicity the end ranks have no neighbour on
+        one side (the caller gives zero probabilities towards it).  Returns (n_moved,
+        n_arrived) per local cell."""
+        import torch
+        rank, world = dist.get_rank(), dist.get_world_size()
+        self.transport_begin(nx, nz, ny, prob_h, prob_v, cell_volume, seed, step, periodic_x)
+        bufs = [self.transport_export(0), self.transport_export(1)]      # to below, to above
+        below = (rank - 1) % world if (periodic_y or rank > 0) else None
+        above = (rank + 1) % world if (periodic_y or rank < world - 1) else None
+        on_host = dist.get_backend() != "nccl"
+        dev = "cpu" if on_host else f"cuda:{self.cfg.device}"
+        out = []
+        for bf in bufs:                                   # as tensors torch.distributed can send
+            t = torch.empty(bf.nbytes, dtype=torch.uint8, device=dev)
+            if bf.nbytes:
+                self._ck(self._lib.pmcx_device_copy(self._h, C.c_void_p(t.data_ptr()), bf.ptr, bf.nbytes,
+                                                    2 if on_host else 0))
+            out.append(t)
+        sizes = torch.tensor([out[0].numel(), out[1].numel()], dtype=torch.int64, device=dev)
+        all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+        dist.all_gather(all_sizes, sizes)
+        got = [None, None]                                               # from below, from above
+        # phase 0: everybody sends down and receives from above; phase 1: the other way round
+        for phase, (to, frm, slot) in enumerate(((below, above, 1), (above, below, 0))):
+            ops, rbuf = [], None
+            if to is not None:
+                ops.append(dist.P2POp(dist.isend, out[phase], to))
+            if frm is not None:
+                rbuf = torch.empty(int(all_sizes[frm][phase]), dtype=torch.uint8, device=dev)
+                ops.append(dist.P2POp(dist.irecv, rbuf, frm))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            if rbuf is not None:
+                if on_host:
+                    d = DeviceBuffer(self, rbuf.numel())
+                    if rbuf.numel():
+                        self._ck(self._lib.pmcx_device_copy(self._h, d.ptr, C.c_void_p(rbuf.data_ptr()),
+                                                            rbuf.numel(), 1))
+                    got[slot] = d
+                else:
+                    got[slot] = rbuf
+        self.transport_import(0, got[0])
+        self.transport_import(1, got[1])
+        return self.transport_finish()
 
     def dry_deposition(self, dt, aer_res_a, ustar, alpha, big_a, height, inv_density, seed=0,
                        step=0, surface=None):
