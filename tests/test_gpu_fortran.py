@@ -82,6 +82,91 @@ def test_fortran_shim_matches_oracle(tmp_path, wp, oracle, mode):
     assert off == len(out)
 
 
+def test_fortran_resident_sequence(tmp_path, wp):
+    """The device-resident calls of the shim (pmcx_upload_states once, then per step
+    trans_cells_pmcx, dry_dep_cells_pmcx, mc_coag_resident_pmcx, one pmcx_download_states)
+    against the same sequence through the Python host: the Fortran bindings pass every
+    argument the way the C-ABI means it.  (Each piece has its own oracle parity test.)"""
+    _build()
+    n_cells, n_part, n_spec, n_class, n_source, kernel, n_steps = 8, 600, 2, 2, 2, 4, 3
+    seed, del_t = 2024, 600.0
+    nx, nz, ny = 2, 2, n_cells // 4
+    names, dens = parity.default_species(n_spec)
+    rs = np.random.RandomState(5)
+    cap = (2 * n_part + 63) // 64 * 64
+    T = 288.15 - 3.0 * np.arange(n_cells)
+    P = 101325.0 - 4000.0 * np.arange(n_cells)
+    mag = (1e9 / n_part) * (1 + 0.5 * np.arange(n_class))[None, :] * np.ones((n_cells, 1))
+    r = 10 ** rs.uniform(-8.0, -6.0, (n_cells, n_part))
+    frac = rs.uniform(0.1, 0.9, (n_cells, n_part))
+    vtot = 4.0 / 3.0 * np.pi * r ** 3
+    vol = np.stack([vtot * frac, vtot * (1 - frac)], axis=1)              # [cell][spec][part]
+    wcl = rs.randint(0, n_class, (n_cells, n_part)).astype(np.int32)
+    src = rs.randint(0, n_source, (n_cells, n_part))
+    n_orig = np.zeros((n_cells, n_source, n_part), np.int32)
+    for s in range(n_source):
+        n_orig[:, s, :] = src == s
+    ids = (np.arange(n_cells, dtype=np.int64)[:, None] << 32) + np.arange(1, n_part + 1)
+    lct = np.tile(np.arange(n_part) * 0.5, (n_cells, 1))
+    buf = struct.pack("<7i", n_cells, n_part, n_spec, n_class, n_source, kernel, n_steps)
+    buf += struct.pack("<q", seed) + struct.pack("<d", del_t) + dens.astype("<f8").tobytes()
+    for c in range(n_cells):
+        buf += struct.pack("<2d", T[c], P[c]) + mag[c].astype("<f8").tobytes()
+        for i in range(n_part):
+            buf += vol[c, :, i].astype("<f8").tobytes() + n_orig[c, :, i].astype("<i4").tobytes()
+            buf += struct.pack("<i", int(wcl[c, i]) + 1) + struct.pack("<q", int(ids[c, i]))
+            buf += struct.pack("<2d", lct[c, i], lct[c, i] + 1.0)
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    fin.write_bytes(buf)
+    run = subprocess.run([EXE, str(fin), str(fout), "2"], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    out = fout.read_bytes()
+
+    # the same sequence through the Python host
+    c0 = np.arange(n_cells)
+    lev = (c0 // nx) % nz
+    prob_h = 0.02 + 0.005 * np.arange(4)[None, None, :] + 0.001 * np.arange(n_class)[None, :, None]
+    prob_h = np.broadcast_to(prob_h, (n_cells, n_class, 4))
+    prob_v = np.where(np.arange(nz)[None, None, :] == lev[:, None, None], 0.0, 0.01)
+    prob_v = np.broadcast_to(prob_v, (n_cells, n_class, nz))
+    with wp.CellBlock(n_cells, cap, n_spec, n_class=n_class, n_source=n_source) as blk:
+        blk.set_aero_data(dens)
+        blk.set_env(T, P, np.full(n_cells, 0.5))
+        blk.set_weights(mag)
+        po = np.arange(n_cells + 1, dtype=np.int64) * n_part
+        blk.upload_cells(0, po, vol.transpose(1, 0, 2).reshape(n_spec, -1), wcl.reshape(-1),
+                         ids.reshape(-1), lct.reshape(-1), lct.reshape(-1) + 1.0,
+                         n_orig.transpose(1, 0, 2).reshape(n_source, -1))
+        off = 0
+        for step in range(n_steps):
+            nm, na = blk.transport(nx, nz, ny, prob_h, prob_v, np.ones(n_cells), seed=seed, step=step)
+            nr, bad = blk.dry_deposition(del_t, 30.0 + c0 + 1, 0.3, 1.2, 2e-3, 40.0, 0.8, seed=seed,
+                                         step=step, surface=(lev == 0).astype(np.int32))
+            ns, nc, st = blk.mc_coag(kernel, del_t, seed, step)
+            assert not (st & 3).any()
+            for want in (nm, na, nr, ns, nc):
+                got = np.frombuffer(out, "<i4", n_cells, off); off += 4 * n_cells
+                assert np.array_equal(got, want), step
+            assert nm.sum() > 0 and nr.sum() > 0 and nc.sum() > 0
+        d = blk.download_cells()
+    rec = 8 * n_spec + 4 * n_source + 4 + 8 + 16
+    po = d["part_offset"]
+    for c in range(n_cells):
+        n = int(np.frombuffer(out, "<i4", 1, off)[0]); off += 4
+        assert n == po[c + 1] - po[c]
+        blob = np.frombuffer(out, np.uint8, rec * n, off).reshape(n, rec); off += rec * n
+        sl = slice(po[c], po[c + 1])
+        o = 8 * n_spec
+        assert np.array_equal(blob[:, :o].copy().view("<f8").T, d["vol"][:, sl])
+        assert np.array_equal(blob[:, o:o + 4 * n_source].copy().view("<i4").T, d["n_orig"][:, sl])
+        o += 4 * n_source
+        assert np.array_equal(blob[:, o:o + 4].copy().view("<i4")[:, 0] - 1, d["wclass"][sl])
+        assert np.array_equal(blob[:, o + 4:o + 12].copy().view("<i8")[:, 0], d["id"][sl])
+        assert np.array_equal(blob[:, o + 12:o + 28].copy().view("<f8"),
+                              np.stack([d["least_ct"][sl], d["greatest_ct"][sl]], axis=1))
+    assert off == len(out)
+
+
 def test_transport_across_two_ranks():
     """The N > 1 form of the transport: two processes (one slab each, sharing this GPU, gloo
     rendezvous on 127.0.0.1) exchange their boundary rows' movers with

@@ -33,6 +33,15 @@ module pmcx_shim
   private
   public :: pmcx_shim_init, pmcx_shim_finalize, pmcx_set_rng, mc_coag_pmcx, &
        partmc_coag_cells_pmcx, aero_state_rebalance_cells_pmcx, pmcx_config
+  ! the device-resident sequence (INTEGRATION.md 2c): upload once, step on the device,
+  ! download when the host needs the particles (output, restart)
+  public :: pmcx_upload_states, pmcx_download_states, mc_coag_resident_pmcx, &
+       trans_cells_pmcx, dry_dep_cells_pmcx
+  ! slab transport across MPI ranks: the host moves the packed buffers (GPU-aware MPI on
+  ! the device pointers, or staged through pmcx_device_copy)
+  public :: pmcx_shim_context, pmcx_transport_begin, pmcx_transport_export_size, &
+       pmcx_transport_export, pmcx_transport_import, pmcx_transport_finish, &
+       pmcx_device_alloc, pmcx_device_free, pmcx_device_copy
 
   type, bind(c) :: pmcx_config
      integer(c_int32_t) :: struct_size, device, n_cells, cap, n_spec, n_class, n_source, n_bin
@@ -142,6 +151,77 @@ module pmcx_shim
        integer(c_int64_t), value :: seed
        integer(c_int32_t), value :: step
      end function pmcx_rebalance
+     integer(c_int) function pmcx_transport(ctx, nx, nz, ny, periodic_x, periodic_y, prob_h, prob_v, &
+          cell_volume, seed, step, n_moved, n_arrived) bind(c, name="pmcx_transport")
+       import :: c_ptr, c_int, c_int32_t, c_int64_t, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: nx, nz, ny, periodic_x, periodic_y
+       real(c_double), intent(in) :: prob_h(*), prob_v(*), cell_volume(*)
+       integer(c_int64_t), value :: seed
+       integer(c_int32_t), value :: step
+       integer(c_int32_t), intent(out) :: n_moved(*), n_arrived(*)
+     end function pmcx_transport
+     integer(c_int) function pmcx_transport_begin(ctx, nx, nz, ny, periodic_x, prob_h, prob_v, &
+          cell_volume, seed, step) bind(c, name="pmcx_transport_begin")
+       import :: c_ptr, c_int, c_int32_t, c_int64_t, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: nx, nz, ny, periodic_x
+       real(c_double), intent(in) :: prob_h(*), prob_v(*), cell_volume(*)
+       integer(c_int64_t), value :: seed
+       integer(c_int32_t), value :: step
+     end function pmcx_transport_begin
+     integer(c_int) function pmcx_transport_export_size(ctx, side, n_bytes) &
+          bind(c, name="pmcx_transport_export_size")
+       import :: c_ptr, c_int, c_int32_t, c_int64_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: side
+       integer(c_int64_t), intent(out) :: n_bytes
+     end function pmcx_transport_export_size
+     integer(c_int) function pmcx_transport_export(ctx, side, dev_buf) bind(c, name="pmcx_transport_export")
+       import :: c_ptr, c_int, c_int32_t
+       type(c_ptr), value :: ctx, dev_buf
+       integer(c_int32_t), value :: side
+     end function pmcx_transport_export
+     integer(c_int) function pmcx_transport_import(ctx, side, dev_buf, n_bytes) &
+          bind(c, name="pmcx_transport_import")
+       import :: c_ptr, c_int, c_int32_t, c_int64_t
+       type(c_ptr), value :: ctx, dev_buf
+       integer(c_int32_t), value :: side
+       integer(c_int64_t), value :: n_bytes
+     end function pmcx_transport_import
+     integer(c_int) function pmcx_transport_finish(ctx, n_moved, n_arrived) &
+          bind(c, name="pmcx_transport_finish")
+       import :: c_ptr, c_int, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), intent(out) :: n_moved(*), n_arrived(*)
+     end function pmcx_transport_finish
+     integer(c_int) function pmcx_device_alloc(ctx, n_bytes, dev_ptr) bind(c, name="pmcx_device_alloc")
+       import :: c_ptr, c_int, c_int64_t
+       type(c_ptr), value :: ctx
+       integer(c_int64_t), value :: n_bytes
+       type(c_ptr), intent(out) :: dev_ptr
+     end function pmcx_device_alloc
+     integer(c_int) function pmcx_device_free(ctx, dev_ptr) bind(c, name="pmcx_device_free")
+       import :: c_ptr, c_int
+       type(c_ptr), value :: ctx, dev_ptr
+     end function pmcx_device_free
+     integer(c_int) function pmcx_device_copy(ctx, dst, src, n_bytes, kind) bind(c, name="pmcx_device_copy")
+       import :: c_ptr, c_int, c_int32_t, c_int64_t
+       type(c_ptr), value :: ctx, dst, src
+       integer(c_int64_t), value :: n_bytes
+       integer(c_int32_t), value :: kind
+     end function pmcx_device_copy
+     integer(c_int) function pmcx_dry_deposition(ctx, dt, seed, step, surface, aer_res_a, ustar, alpha, &
+          big_a, height, inv_density, n_removed, unrealistic) bind(c, name="pmcx_dry_deposition")
+       import :: c_ptr, c_int, c_int32_t, c_int64_t, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), value :: dt
+       integer(c_int64_t), value :: seed
+       integer(c_int32_t), value :: step
+       integer(c_int32_t), intent(in) :: surface(*)
+       real(c_double), intent(in) :: aer_res_a(*), ustar(*), alpha(*), big_a(*), height(*), inv_density(*)
+       integer(c_int32_t), intent(out) :: n_removed(*), unrealistic(*)
+     end function pmcx_dry_deposition
   end interface
 
   ! one context per (rank, cell count); rebuilt when the shape changes
@@ -211,22 +291,27 @@ contains
     ctx = c_null_ptr
   end subroutine pmcx_shim_finalize
 
-  !> mc_coag on a flat array of cells: gather, upload, step, download, scatter.
-  subroutine partmc_coag_cells_pmcx(coag_kernel_type, env_states, aero_data, aero_states, &
-       del_t, tot_n_samp, tot_n_coag)
-    integer, intent(in) :: coag_kernel_type
+  !> The context handle, for the C entry points the shim has no wrapper for.
+  function pmcx_shim_context() result(h)
+    type(c_ptr) :: h
+    h = ctx
+  end function pmcx_shim_context
+
+  !> Gather aero_states(:) into flat arrays (the layout pmcx_upload_cells documents) and
+  !> upload them with the cells' environment and weights.  cap_min: room per cell the caller
+  !> wants beyond the present populations (arrivals of the transport, emissions).
+  subroutine pmcx_upload_states(env_states, aero_data, aero_states, cap_min)
     type(env_state_t), intent(in) :: env_states(:)
     type(aero_data_t), intent(in) :: aero_data
-    type(aero_state_t), intent(inout) :: aero_states(:)
-    real(kind=dp), intent(in) :: del_t
-    integer, intent(out) :: tot_n_samp(:), tot_n_coag(:)
+    type(aero_state_t), intent(in) :: aero_states(:)
+    integer, intent(in), optional :: cap_min
 
     integer :: n_cells, n_spec, n_class, n_source, c, i, s, cap_needed
     integer(c_int64_t) :: nt, o
     integer(c_int64_t), allocatable :: part_offset(:), id(:)
     real(c_double), allocatable :: vol(:,:), lct(:), gct(:), temp(:), pres(:), rh(:), mag(:,:)
     integer(c_int32_t), allocatable, target :: n_orig(:,:)
-    integer(c_int32_t), allocatable :: wclass(:), n_part(:), ns(:), nc(:), st(:)
+    integer(c_int32_t), allocatable :: wclass(:)
     type(c_ptr) :: p_norig
 
     n_cells = size(aero_states)
@@ -238,6 +323,7 @@ contains
             n_source = size(aero_states(1)%apa%particle(1)%n_orig_part)
     end if
     cap_needed = 64
+    if (present(cap_min)) cap_needed = max(cap_needed, cap_min)
     do c = 1, n_cells
        cap_needed = max(cap_needed, aero_states(c)%apa%n_part)
     end do
@@ -247,7 +333,6 @@ contains
        call pmcx_shim_init(n_cells, cap_needed, aero_data, n_class, n_source, 0)
     end if
 
-    ! ---- gather aero_state_t -> flat arrays (pmcx_upload_cells layout) ----
     allocate(part_offset(n_cells + 1))
     part_offset(1) = 0
     do c = 1, n_cells
@@ -286,33 +371,56 @@ contains
     call pmcx_die(pmcx_set_weights(ctx, mag), 'pmcx_set_weights')
     call pmcx_die(pmcx_upload_cells(ctx, 0, n_cells, part_offset, vol, wclass, id, lct, gct, &
          p_norig), 'pmcx_upload_cells')
+  end subroutine pmcx_upload_states
 
-    ! ---- the step ----
-    call pmcx_die(pmcx_mc_coag(ctx, coag_kernel_type, del_t, rng_seed, rng_step), 'pmcx_mc_coag')
-    allocate(ns(n_cells), nc(n_cells), st(n_cells), n_part(n_cells))
-    call pmcx_die(pmcx_get_coag_counters(ctx, ns, nc, st), 'pmcx_get_coag_counters')
-    if (any(iand(st, 3) /= 0)) call pmcx_die(5, 'mc_coag (event/append log overflow)')
-    tot_n_samp = ns
-    tot_n_coag = nc
+  !> Download the resident cells and scatter them back into aero_states(:) (populations may
+  !> have grown: transport arrivals, emissions) together with the weights a rebalance changed.
+  subroutine pmcx_download_states(aero_states)
+    type(aero_state_t), intent(inout) :: aero_states(:)
 
-    ! ---- download and scatter back into aero_state_t ----
+    integer :: n_cells, n_spec, n_class, n_source, c, i, s
+    integer(c_int64_t) :: nt, o
+    integer(c_int64_t), allocatable :: part_offset(:), id(:)
+    real(c_double), allocatable :: vol(:,:), lct(:), gct(:), mag(:,:)
+    integer(c_int32_t), allocatable, target :: n_orig(:,:)
+    integer(c_int32_t), allocatable :: wclass(:), n_part(:)
+    type(aero_particle_t), allocatable :: grown(:)
+    type(c_ptr) :: p_norig
+
+    n_cells = cfg%n_cells
+    n_spec = cfg%n_spec
+    n_class = cfg%n_class
+    n_source = cfg%n_source
+    allocate(n_part(n_cells), part_offset(n_cells + 1), mag(n_class, n_cells))
     call pmcx_die(pmcx_get_n_part(ctx, n_part), 'pmcx_get_n_part')
+    call pmcx_die(pmcx_get_weights(ctx, mag), 'pmcx_get_weights')
+    part_offset(1) = 0
     do c = 1, n_cells
        part_offset(c + 1) = part_offset(c) + n_part(c)
     end do
     nt = part_offset(n_cells + 1)
-    ! packed arrays are [n_spec][n_total]: the leading dimension must be the new total
-    deallocate(vol, wclass, id, lct, gct, n_orig)
+    ! packed arrays are [n_spec][n_total]: the leading dimension is the total
     allocate(vol(max(nt, 1_c_int64_t), n_spec), wclass(max(nt, 1_c_int64_t)), &
          id(max(nt, 1_c_int64_t)), lct(max(nt, 1_c_int64_t)), gct(max(nt, 1_c_int64_t)))
     allocate(n_orig(max(nt, 1_c_int64_t), max(n_source, 1)))
+    p_norig = c_null_ptr
     if (n_source > 0) p_norig = c_loc(n_orig)
     call pmcx_die(pmcx_download_cells(ctx, 0, n_cells, part_offset, vol, wclass, id, lct, gct, &
          p_norig), 'pmcx_download_cells')
     do c = 1, n_cells
        o = part_offset(c)
+       if (.not. allocated(aero_states(c)%apa%particle)) allocate(aero_states(c)%apa%particle(n_part(c)))
+       if (size(aero_states(c)%apa%particle) < n_part(c)) then
+          allocate(grown(n_part(c)))
+          grown(1:size(aero_states(c)%apa%particle)) = aero_states(c)%apa%particle
+          call move_alloc(grown, aero_states(c)%apa%particle)
+       end if
        aero_states(c)%apa%n_part = n_part(c)
        do i = 1, n_part(c)
+          if (.not. allocated(aero_states(c)%apa%particle(i)%vol)) &
+               allocate(aero_states(c)%apa%particle(i)%vol(n_spec))
+          if (.not. allocated(aero_states(c)%apa%particle(i)%n_orig_part)) &
+               allocate(aero_states(c)%apa%particle(i)%n_orig_part(n_source))
           do s = 1, n_spec
              aero_states(c)%apa%particle(i)%vol(s) = vol(o + i, s)
           end do
@@ -324,8 +432,72 @@ contains
           aero_states(c)%apa%particle(i)%least_create_time = lct(o + i)
           aero_states(c)%apa%particle(i)%greatest_create_time = gct(o + i)
        end do
+       do s = 1, n_class
+          aero_states(c)%awa%weight(1, s)%magnitude = mag(s, c)
+       end do
        aero_states(c)%valid_sort = .false.
     end do
+  end subroutine pmcx_download_states
+
+  !> mc_coag on the resident cells (interface/wrf_pmc_driver.F90:192-194 for every cell).
+  subroutine mc_coag_resident_pmcx(coag_kernel_type, del_t, tot_n_samp, tot_n_coag)
+    integer, intent(in) :: coag_kernel_type
+    real(kind=dp), intent(in) :: del_t
+    integer, intent(out) :: tot_n_samp(:), tot_n_coag(:)
+    integer(c_int32_t), allocatable :: ns(:), nc(:), st(:)
+    call pmcx_die(pmcx_mc_coag(ctx, coag_kernel_type, del_t, rng_seed, rng_step), 'pmcx_mc_coag')
+    allocate(ns(cfg%n_cells), nc(cfg%n_cells), st(cfg%n_cells))
+    call pmcx_die(pmcx_get_coag_counters(ctx, ns, nc, st), 'pmcx_get_coag_counters')
+    if (any(iand(st, 3) /= 0)) call pmcx_die(5, 'mc_coag (event/append log overflow)')
+    tot_n_samp = ns
+    tot_n_coag = nc
+  end subroutine mc_coag_resident_pmcx
+
+  !> The stochastic transport of wrf_pmc_trans_driver (interface/wrf_pmc_trans.F90:37-200) on
+  !> the resident cells, ordered c = (j * nz + k) * nx + i (0-based).  prob_h(4, n_class, n_cells):
+  !> east, west, north, south; prob_v(nz, n_class, n_cells): to each level of the column.
+  subroutine trans_cells_pmcx(nx, nz, ny, periodic_x, periodic_y, prob_h, prob_v, cell_volume, &
+       n_moved, n_arrived)
+    integer, intent(in) :: nx, nz, ny
+    logical, intent(in) :: periodic_x, periodic_y
+    real(kind=dp), intent(in) :: prob_h(:,:,:), prob_v(:,:,:), cell_volume(:)
+    integer, intent(out) :: n_moved(:), n_arrived(:)
+    integer(c_int32_t), allocatable :: nm(:), na(:)
+    allocate(nm(cfg%n_cells), na(cfg%n_cells))
+    call pmcx_die(pmcx_transport(ctx, nx, nz, ny, merge(1, 0, periodic_x), merge(1, 0, periodic_y), &
+         prob_h, prob_v, cell_volume, rng_seed, rng_step, nm, na), 'pmcx_transport')
+    n_moved = nm
+    n_arrived = na
+  end subroutine trans_cells_pmcx
+
+  !> Dry deposition of wrf_pmc_dep_aero.F90:28-192 on the resident surface cells
+  !> (surface(c) /= 0); the per-cell inputs are the ones the reference reads from grid%.
+  subroutine dry_dep_cells_pmcx(dt, surface, aer_res_a, ustar, alpha, big_a, height, inv_density, &
+       n_removed)
+    real(kind=dp), intent(in) :: dt
+    integer, intent(in) :: surface(:)
+    real(kind=dp), intent(in) :: aer_res_a(:), ustar(:), alpha(:), big_a(:), height(:), inv_density(:)
+    integer, intent(out) :: n_removed(:)
+    integer(c_int32_t), allocatable :: sf(:), nr(:), bad(:)
+    allocate(sf(cfg%n_cells), nr(cfg%n_cells), bad(cfg%n_cells))
+    sf = surface
+    call pmcx_die(pmcx_dry_deposition(ctx, dt, rng_seed, rng_step, sf, aer_res_a, ustar, alpha, &
+         big_a, height, inv_density, nr, bad), 'pmcx_dry_deposition')
+    n_removed = nr
+  end subroutine dry_dep_cells_pmcx
+
+  !> mc_coag on a flat array of cells: gather, upload, step, download, scatter.
+  subroutine partmc_coag_cells_pmcx(coag_kernel_type, env_states, aero_data, aero_states, &
+       del_t, tot_n_samp, tot_n_coag)
+    integer, intent(in) :: coag_kernel_type
+    type(env_state_t), intent(in) :: env_states(:)
+    type(aero_data_t), intent(in) :: aero_data
+    type(aero_state_t), intent(inout) :: aero_states(:)
+    real(kind=dp), intent(in) :: del_t
+    integer, intent(out) :: tot_n_samp(:), tot_n_coag(:)
+    call pmcx_upload_states(env_states, aero_data, aero_states)
+    call mc_coag_resident_pmcx(coag_kernel_type, del_t, tot_n_samp, tot_n_coag)
+    call pmcx_download_states(aero_states)
   end subroutine partmc_coag_cells_pmcx
 
   !> Drop-in for mc_coag (same argument list, one cell).

@@ -4,7 +4,10 @@
 ! (batched).  Input and output are raw binary files so a test can compare the
 ! result bit for bit with the CPU oracle.
 !
-! usage: test_shim <in.bin> <out.bin> <mode: 0 per-cell, 1 batched>
+! usage: test_shim <in.bin> <out.bin> <mode: 0 per-cell, 1 batched, 2 resident>
+! mode 2: the cells are a 2 x 2 x (n_cells / 4) grid (x, level, y), uploaded once; every step
+!         runs transport, dry deposition on level 0 and mc_coag on the device; one download at
+!         the end (the per-step record is then n_moved, n_arrived, n_removed, n_samp, n_coag)
 ! in.bin : int32 n_cells, n_part, n_spec, n_class, n_source, kernel, n_steps;
 !          int64 seed; float64 del_t; float64 density(n_spec);
 !          per cell: float64 temp, pressure, mag(n_class);
@@ -23,7 +26,10 @@ program test_shim
   type(env_state_t), allocatable :: env_states(:)
   type(aero_state_t), allocatable :: aero_states(:)
   integer, allocatable :: n_samp(:), n_coag(:)
-  integer :: c, i, s, step, u
+  integer :: c, i, s, step, u, q, k, nx, nz, ny, lev
+  integer, allocatable :: n_moved(:), n_arrived(:), n_removed(:), surface(:)
+  real(kind=dp), allocatable :: prob_h(:,:,:), prob_v(:,:,:), cell_volume(:), ra(:), ustar(:), &
+       alpha(:), big_a(:), height(:), inv_density(:)
 
   call get_command_argument(1, fin)
   call get_command_argument(2, fout)
@@ -59,7 +65,45 @@ program test_shim
   close(u)
 
   open(newunit=u, file=trim(fout), access='stream', form='unformatted', status='replace')
-  do step = 0, n_steps - 1
+  if (mode == 2) then
+     nx = 2; nz = 2; ny = n_cells / 4
+     allocate(n_moved(n_cells), n_arrived(n_cells), n_removed(n_cells), surface(n_cells))
+     allocate(prob_h(4, n_class, n_cells), prob_v(nz, n_class, n_cells), cell_volume(n_cells))
+     allocate(ra(n_cells), ustar(n_cells), alpha(n_cells), big_a(n_cells), height(n_cells), &
+          inv_density(n_cells))
+     do c = 1, n_cells
+        lev = mod((c - 1) / nx, nz)               ! c - 1 = (j * nz + k) * nx + i
+        surface(c) = merge(1, 0, lev == 0)
+        do s = 1, n_class
+           do q = 1, 4
+              prob_h(q, s, c) = 0.02d0 + 0.005d0 * (q - 1) + 0.001d0 * (s - 1)
+           end do
+           do k = 1, nz
+              prob_v(k, s, c) = merge(0d0, 0.01d0, k - 1 == lev)
+           end do
+        end do
+        cell_volume(c) = 1d0
+        ra(c) = 30d0 + c
+        ustar(c) = 0.3d0
+        alpha(c) = 1.2d0
+        big_a(c) = 2d-3
+        height(c) = 40d0
+        inv_density(c) = 0.8d0
+     end do
+     call pmcx_set_rng(seed, 0, 0)
+     call pmcx_upload_states(env_states, aero_data, aero_states, 2 * n_part)
+     do step = 0, n_steps - 1
+        call pmcx_set_rng(seed, step, 0)
+        call trans_cells_pmcx(nx, nz, ny, .true., .true., prob_h, prob_v, cell_volume, &
+             n_moved, n_arrived)
+        call dry_dep_cells_pmcx(del_t, surface, ra, ustar, alpha, big_a, height, inv_density, &
+             n_removed)
+        call mc_coag_resident_pmcx(kernel, del_t, n_samp, n_coag)
+        write(u) n_moved, n_arrived, n_removed, n_samp, n_coag
+     end do
+     call pmcx_download_states(aero_states)
+  end if
+  do step = 0, merge(-1, n_steps - 1, mode == 2)
      if (mode == 1) then
         call pmcx_set_rng(seed, step, 0)
         call partmc_coag_cells_pmcx(kernel, env_states, aero_data, aero_states, del_t, &
