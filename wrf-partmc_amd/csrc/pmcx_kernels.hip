@@ -2119,6 +2119,8 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
     int *t_tmpd = t_dest + C * ND;           // scratch: destinations before sorting
     int *t_n = t_tmpd + C * ND;              // [C]
     uint64_t *t_bit = (uint64_t *)(((uintptr_t)(t_n + C) + 7) & ~(uintptr_t)7); // [C][ND] dest_mask bit
+    int *t_cnt = (int *)(t_bit + C * ND);    // [C][ND] copies sent to each destination
+    for (int x = lane; x < C * ND; x += 64) t_cnt[x] = 0;
     const int i = c % nx, k = (c / nx) % nz, j = c / (nx * nz);
     const bool mask_ok = ND <= 64 && (nx >= 3 || !tg.periodic_x) && (ny >= 3 || !tg.periodic_y);
     const int64_t cb = (int64_t)c * st.cap;
@@ -2183,13 +2185,12 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
     int2 *box = tg.outbox + cb;
     uint32_t rank0 = 0, n_out = 0;
     uint64_t bits = 0;
-    for (int i0 = 0; i0 < n_hi; i0 += 64) {
-        const int s = i0 + lane;
-        const int cl = s < n_hi ? live_class(st, cb, s) : -1;
+    // two chunks of 64 slots per trip: both liveness loads are in flight before the first draw
+    auto chunk = [&](int s, int cl) {
         const uint64_t mlive = __ballot(cl >= 0);
         const uint32_t rank = rank0 + (uint32_t)__popcll(mlive & lt);
         bool moves = false;
-        int dest = 0, copies = 0;
+        int dest = 0, copies = 0, dslot = 0;
         if (cl >= 0 && t_n[cl] > 0) {
             uint32_t w[4];
             rng_block(seed, cell_id, step, rank, SITE_TRANS, 0, w);
@@ -2205,17 +2206,29 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
                     copies = 1 + (int)(det_log(1.0 - u2) / det_log(1.0 - r));
                     if (copies > TRANS_MAX_COPIES) copies = TRANS_MAX_COPIES;
                 }
-                dest = t_dest[cl * ND + d];
-                bits |= t_bit[cl * ND + d];
+                dslot = cl * ND + d;
+                dest = t_dest[dslot];
+                bits |= t_bit[dslot];
                 moves = true;
             }
         }
         const uint64_t mm = __ballot(moves);
         if (moves) box[n_out + (uint32_t)__popcll(mm & lt)] = make_int2(s | (copies << 16), dest);
-        if (moves && copies > 0) atomicAdd(&tg.n_exp[dest], copies);
+        if (moves && copies > 0) atomicAdd(&t_cnt[dslot], copies);
         n_out += (uint32_t)__popcll(mm);
         rank0 += (uint32_t)__popcll(mlive);
+    };
+    for (int i0 = 0; i0 < n_hi; i0 += 128) {
+        const int sa = i0 + lane, sb = i0 + 64 + lane;
+        const int cla = sa < n_hi ? live_class(st, cb, sa) : -1;
+        const int clb = sb < n_hi ? live_class(st, cb, sb) : -1;
+        chunk(sa, cla);
+        if (i0 + 64 < n_hi) chunk(sb, clb);
     }
+    // the arrivals each destination has to expect: one atomic per destination, not per mover
+    wave_sync();
+    for (int x = lane; x < C * ND; x += 64)
+        if (x % ND < t_n[x / ND] && t_cnt[x] > 0) atomicAdd(&tg.n_exp[t_dest[x]], t_cnt[x]);
     for (int d = 32; d >= 1; d >>= 1) bits |= __shfl_xor(bits, d, 64);
     if (lane == 0) { tg.n_out[c] = (int32_t)n_out; tg.dest_mask[c] = bits; }
 }
@@ -2301,19 +2314,26 @@ __global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid t
             const uint32_t n_new = copies > 0 ? (uint32_t)(copies - 1) : 0u;
             const uint32_t inc_new = wave_incl_scan_u32(n_new, lane);
             const int64_t id0 = nid + (int64_t)(inc_new - n_new);
-            for (int g = 0; g < copies; g++) {
-                const int dst = (int)first + g;
-                if (dst >= st.cap) { status |= ST_CAP_OVERFLOW; break; }
-                for (int sp = 0; sp < S; sp++)
-                    st.vol[(cb + dst) * S + sp] = st.vol[(sb + from) * S + sp];
-                for (int sp = 0; sp < NS; sp++)
-                    norig(st, cb, sp, dst) = norig(st, sb, sp, from);
-                st.vm[cb + dst].x = st.vm[sb + from].x;
-                st.vm[cb + dst].y = st.vm[sb + from].y;
-                st.wclass[cb + dst] = st.wclass[sb + from];
-                st.meta[cb + dst].lct = st.meta[sb + from].lct;
-                st.meta[cb + dst].gct = st.meta[sb + from].gct;
-                st.meta[cb + dst].id = (g == copies - 1) ? st.meta[sb + from].id : id0 + g;
+            if (copies > 0) {
+                // the record is read once (one request per plane), then written per copy; with
+                // one species the species plane is not kept current (see spec_vol): not moved
+                const double2 vmv = st.vm[sb + from];
+                const Meta mt = st.meta[sb + from];
+                const int32_t wc = st.n_class > 1 ? st.wclass[sb + from] : 0; // one class: all zero
+                for (int g = 0; g < copies; g++) {
+                    const int dst = (int)first + g;
+                    if (dst >= st.cap) { status |= ST_CAP_OVERFLOW; break; }
+                    if (S > 1)
+                        for (int sp = 0; sp < S; sp++)
+                            st.vol[(cb + dst) * S + sp] = st.vol[(sb + from) * S + sp];
+                    for (int sp = 1; sp < NS; sp++)
+                        norig(st, cb, sp, dst) = norig(st, sb, sp, from);
+                    st.vm[cb + dst] = vmv;
+                    if (st.n_class > 1) st.wclass[cb + dst] = wc;
+                    Meta m2 = mt;
+                    if (g != copies - 1) m2.id = id0 + g;
+                    st.meta[cb + dst] = m2;
+                }
             }
             at += (int)__shfl(inc, 63, 64);
             nid += (int64_t)__shfl(inc_new, 63, 64);
@@ -2430,7 +2450,7 @@ __global__ __launch_bounds__(64) void k_halo_pack(DeviceState st, TransGrid tg, 
             d[2] = st.meta[cb + from].lct; d[3] = st.meta[cb + from].gct;
             ((int64_t *)d)[4] = st.meta[cb + from].id;
             ((int32_t *)(d + 5))[0] = st.meta[cb + from].n_orig0; ((int32_t *)(d + 5))[1] = 0;
-            for (int sp = 0; sp < S; sp++) d[6 + sp] = st.vol[(cb + from) * S + sp];
+            for (int sp = 0; sp < S; sp++) d[6 + sp] = spec_vol(st, cb, sp, from);
             int32_t *no = (int32_t *)(d + 6 + S);
             for (int sp = 1; sp < NS; sp++) no[sp - 1] = norig(st, cb, sp, from);
         }
@@ -2915,7 +2935,7 @@ hipError_t launch_scenario_update(const DeviceState &st, double dt, double creat
 size_t transport_lds_bytes(const DeviceState &st, int nz)
 {
     const size_t nd = (size_t)(4 + nz), C = (size_t)st.n_class;
-    return (sizeof(double) * 4 + sizeof(int) * 2 + sizeof(uint64_t)) * C * nd + sizeof(int) * C + 24;
+    return (sizeof(double) * 4 + sizeof(int) * 3 + sizeof(uint64_t)) * C * nd + sizeof(int) * C + 24;
 }
 static TransGrid make_grid(int nx, int nz, int ny, int periodic_x, int periodic_y,
                            const double *prob_h, const double *prob_v, const double *cell_volume,
