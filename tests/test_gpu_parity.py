@@ -835,3 +835,69 @@ def test_transport_conserves_with_equal_weights(wp):
     assert np.array_equal(np.sort(dn["id"]), ids0)
     assert moved > 0.15 * n_cells * n_part
     blk.close()
+
+
+# ------------------------------------------------- the HIP path against closed-form solutions
+#
+# Anchors that do not pass through the oracle: the Smoluchowski equation has closed-form
+# solutions for the constant and the additive kernel, and an ensemble of cells must follow
+# them within its own sampling error (plus the O(1 %) bias of splitting time into steps).
+
+def _analytic_block(wp, n_cells, n_part, **cfg):
+    from wrf_partmc_amd.data import idealised_modes
+    blk = wp.CellBlock(n_cells, (n_part + 63) // 64 * 64, 1, **cfg)
+    blk.set_aero_data([1800.0])
+    blk.set_env(np.full(n_cells, 288.15), np.full(n_cells, 101325.0), np.full(n_cells, 0.5))
+    blk.set_n_part_ideal(np.full((n_cells, 1), float(n_part)))
+    blk.set_next_id(np.arange(n_cells, dtype=np.int64) << 32)
+    return blk, idealised_modes(1, 1)
+
+
+def test_constant_kernel_follows_smoluchowski(wp):
+    """N(t) / N0 = 1 / (1 + K N0 t / 2) for K(v1, v2) = K (Smoluchowski 1916), over 4096 cells
+    of 2048 particles each."""
+    # (rates are frozen over a step, an explicit scheme: 120 steps keep that bias near 0.4 %)
+    n_cells, n_part, steps, t_end = 4096, 2048, 120, 600.0
+    K = 0.25 / (60 * 2e8)
+    N0 = 4.0e8                                            # K N0 t / 2 = 2.5: N falls to 0.29 N0
+    blk, modes = _analytic_block(wp, n_cells, n_part, const_k=K)
+    with blk:
+        blk.set_weights(np.full((n_cells, 1), N0 / n_part))
+        blk.generate_lognormal(n_part, modes, seed=11)
+        blk.update_kernel_bounds(K_CONST)
+        for s in range(steps):
+            ns, nc, st = blk.mc_coag(K_CONST, t_end / steps, 11, s)
+            assert not st.any()
+        conc = blk.get_weights()[:, 0] * blk.aero_state_total_particles()
+    exact = N0 / (1 + K * N0 * t_end / 2)
+    m, sd = conc.mean(), conc.std() / np.sqrt(n_cells)
+    assert exact < 0.5 * N0
+    assert abs(m - exact) < 4 * sd + 0.01 * exact, (m, exact, sd)
+    # and the spread between cells is the one of independent realisations, not zero
+    assert 0.005 * exact < conc.std() < 0.1 * exact
+
+
+def test_additive_kernel_follows_golovin(wp):
+    """N(t) = N0 exp(-beta phi t) for K(v1, v2) = beta (v1 + v2) (Golovin 1963), phi the
+    volume concentration, which coagulation conserves."""
+    n_cells, n_part, steps, beta = 2048, 2048, 40, 1000.0
+    blk, modes = _analytic_block(wp, n_cells, n_part, additive_beta=beta)
+    with blk:
+        mag = 1.0e9 / n_part
+        blk.set_weights(np.full((n_cells, 1), mag))
+        blk.generate_lognormal(n_part, modes, seed=12)
+        d = blk.download_cells()
+        po = d["part_offset"]
+        phi = mag * np.add.reduceat(d["vol"][0], po[:-1])                 # per cell
+        t_end = 0.5 / (beta * phi.mean())
+        blk.update_kernel_bounds(K_ADD)
+        for s in range(steps):
+            ns, nc, st = blk.mc_coag(K_ADD, t_end / steps, 12, s)
+            assert not st.any()
+        frac = blk.aero_state_total_particles() / n_part
+        d2 = blk.download_cells()
+        phi2 = mag * np.add.reduceat(d2["vol"][0], d2["part_offset"][:-1])
+    assert np.allclose(phi2, phi, rtol=1e-12)                             # volume is conserved
+    exact = np.exp(-beta * phi * t_end)                                   # each cell's own phi
+    m, sd = (frac - exact).mean(), (frac - exact).std() / np.sqrt(n_cells)
+    assert abs(m) < 4 * sd + 0.015, (m, sd)
