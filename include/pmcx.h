@@ -61,7 +61,9 @@ enum {
     PMCX_ST_APPEND_OVERFLOW = 2,
     PMCX_ST_KMAX_EXCEEDED = 4,
     PMCX_ST_OUT_OF_GRID = 8,
-    PMCX_ST_CAP_OVERFLOW = 16
+    PMCX_ST_CAP_OVERFLOW = 16,
+    PMCX_ST_KMAX_RANGE = 32   /* a particle was created in a bin above the range the cell's
+                                 kernel bounds cover (pmcx_set_kernel_bounds_margin)        */
 };
 
 typedef struct pmcx_ctx pmcx_ctx;
@@ -108,7 +110,9 @@ int pmcx_set_aero_data(pmcx_ctx *ctx, const double *density, const double *kappa
                        const double *molec_weight);
 
 /* env_state_t fields the path reads (producer wrf_pmc_driver.F90:611-637),
- * one value per cell.  rel_humid may be NULL. */
+ * one value per cell.  rel_humid may be NULL.  The kernel bounds belong to the
+ * environment they were computed in: after this call the next pmcx_mc_coag (or an
+ * explicit pmcx_update_kernel_bounds) computes them again. */
 int pmcx_set_env(pmcx_ctx *ctx, const double *temp, const double *pressure,
                  const double *rel_humid);
 
@@ -155,6 +159,17 @@ int pmcx_download_cells(pmcx_ctx *ctx, int32_t cell_first, int32_t n_dn,
  * bounds for kernel_type from the current env (PartMC caches this per
  * aero_state, coag_kernel_bounds_valid). */
 int pmcx_update_kernel_bounds(pmcx_ctx *ctx, int32_t kernel_type);
+
+/* Without that explicit call pmcx_mc_coag keeps the bounds current by itself, after its sort:
+ * a cell gets bounds for its populated bins plus `margin` bins above them (default 8: a
+ * particle 250 times the volume of the cell's largest) whenever the kernel type, its
+ * temperature or pressure (pmcx_set_env), or -- through anything but coagulation -- its
+ * population changed, and every 16th call for the growth coagulation itself causes; the rest
+ * of its table is stale.  Should a call create a particle above the covered range the cell's
+ * status carries PMCX_ST_KMAX_RANGE (the pairs of that bin were sampled with a stale bound).
+ * margin < 0: whole tables, computed when the kernel type or the environment changes
+ * (est_k_minmax_binned_unweighted as upstream runs it; 9 ms per 1.2e5 cells). */
+int pmcx_set_kernel_bounds_margin(pmcx_ctx *ctx, int32_t margin);
 
 /*
  * mc_coag on every cell (wrf_pmc_driver.F90:192-194).  Asynchronous on the

@@ -48,8 +48,7 @@ blk.set_weights(np.full((n, 1), 1e10 / N))
 blk.set_n_part_ideal(np.full((n, 1), float(N)))
 blk.set_next_id((np.arange(n, dtype=np.int64) << 32) + (1 << 24))
 blk.generate_lognormal(N, idealised_modes(1, 1), seed=0)
-blk.update_kernel_bounds(wp.COAG_KERNEL_TYPE_BROWN)
-blk.synchronize()
+blk.synchronize()      # (no pmcx_update_kernel_bounds: mc_coag keeps each cell's bounds current)
 
 rng = np.random.RandomState(1)
 prob_h = np.full((n, 1, 4), 0.01) * rng.uniform(0.9, 1.1, (n, 1, 4))     # Courant-like numbers
@@ -70,7 +69,7 @@ rrho = 1.0 / (pres[k] / (287.0 * temp[k]))
 emission = [dict(num_conc=None, gm_radius=3e-8, gsd_log10=0.2, vol_frac=[1.0], wclass=0, source=1)]
 emit_rate = np.where(surface[:, None] == 1, 2.0e5, 0.0)                   # m^-3 s^-1 at the ground
 
-names = ("transport", "dry_deposition", "scenario", "bin_sort", "coag_sample", "compact",
+names = ("transport", "dry_deposition", "scenario", "kernel_bounds", "bin_sort", "coag_sample", "compact",
          "rebalance", "diagnostics")
 blk.profile_enable(True)
 blk.profile_reset()
@@ -85,6 +84,10 @@ for step in range(a.steps):
     ne, ni, no = blk.scenario_update_aero_state(a.dt, elapsed, seed=0, step=step, emission=emission,
                                                 emission_rate=emit_rate)
     if elapsed % a.chem_dt == 0.0:
+        # WRF hands PartMC new air every step (wrf_to_partmc, driver:611-637): the kernel bounds
+        # of every cell are computed again inside mc_coag
+        drift = 0.02 * np.sin(0.1 * step + 0.001 * np.arange(n))
+        blk.set_env(temp[k] + drift, pres[k], np.full(n, 0.5))
         ns, nc, st = blk.mc_coag(wp.COAG_KERNEL_TYPE_BROWN, a.chem_dt, 0, int(elapsed // a.chem_dt))
         events += int(nc.sum())
         assert not (st & ~4).any(), "status"

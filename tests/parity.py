@@ -32,7 +32,7 @@ def make_modes(n_spec, n_class, coarse=False):
 
 def setup_pair(wp, oracle, n_cells, n_part, n_spec, n_class, seed, kernel, cap=None,
                n_source=3, coarse=False, cell_id_base=0, max_events=None, max_appends=None,
-               num_conc_scale=1.0, device=0, **cfg_over):
+               num_conc_scale=1.0, device=0, explicit_bounds=True, **cfg_over):
     """Build a CellBlock and matching oracle cells with identical contents."""
     cap = cap or int(np.ceil(n_part * 1.0 / 64) * 64)
     over = dict(cfg_over)
@@ -82,7 +82,8 @@ def setup_pair(wp, oracle, n_cells, n_part, n_spec, n_class, seed, kernel, cap=N
         vol[:, s] = oc.vol[:, :n_part]; wc[s] = oc.wclass[:n_part]; ids[s] = oc.id[:n_part]
         lct[s] = oc.lct[:n_part]; gct[s] = oc.gct[:n_part]; norig[:, s] = oc.n_orig[:, :n_part]
     blk.upload_cells(0, po, vol, wc, ids, lct, gct, norig if n_source > 0 else None)
-    blk.update_kernel_bounds(kernel)
+    if explicit_bounds:      # whole tables now; otherwise mc_coag computes what each cell needs
+        blk.update_kernel_bounds(kernel)
     for c, oc in enumerate(cells):
         oc.kmax[:] = oracle.kmax_table(kernel, v_samp, dens.min(), dens.max(), temp[c], pres[c],
                                        blk.cfg.const_k, blk.cfg.additive_beta)

@@ -83,10 +83,20 @@ def test_bin_tables_and_kmax(wp, oracle):
         np.testing.assert_allclose(vs, ovs, rtol=1e-13)
         blk.set_aero_data([1000.0, 2600.0])
         blk.set_env([288.15, 230.0], [101325.0, 30000.0])
-        for k in (K_BROWN, K_BS):
+        for k in (K_BROWN, K_BS, K_SEDI, K_ADD, K_CONST):
             blk.update_kernel_bounds(k)
             for c, (T, p) in enumerate([(288.15, 101325.0), (230.0, 30000.0)]):
-                assert np.array_equal(blk.kmax(c), oracle.kmax_table(k, vs, 1000.0, 2600.0, T, p))
+                assert np.array_equal(blk.kmax(c), oracle.kmax_table(
+                    k, vs, 1000.0, 2600.0, T, p, blk.cfg.const_k, blk.cfg.additive_beta))
+    # one density (the sample lattice is walked once), and another bin grid
+    with wp.CellBlock(2, 64, 1, n_bin=37, r_min=1e-9, r_max=1e-4) as blk:
+        ve, vs = blk.bin_tables()
+        blk.set_aero_data([1770.0])
+        blk.set_env([300.0, 215.0], [95000.0, 20000.0])
+        for k in (K_BROWN, K_BS):
+            blk.update_kernel_bounds(k)
+            for c, (T, p) in enumerate([(300.0, 95000.0), (215.0, 20000.0)]):
+                assert np.array_equal(blk.kmax(c), oracle.kmax_table(k, vs, 1770.0, 1770.0, T, p))
 
 
 @pytest.mark.parametrize("n_class,n_part", [(1, 1000), (1, 4097), (3, 1500)])
@@ -901,3 +911,59 @@ def test_additive_kernel_follows_golovin(wp):
     exact = np.exp(-beta * phi * t_end)                                   # each cell's own phi
     m, sd = (frac - exact).mean(), (frac - exact).std() / np.sqrt(n_cells)
     assert abs(m) < 4 * sd + 0.015, (m, sd)
+
+
+def test_kernel_bounds_kept_current_by_mc_coag(wp, oracle):
+    """Without an explicit pmcx_update_kernel_bounds the library computes, inside mc_coag, each
+    cell's bounds over its populated bins (+ margin) and again when the environment changes
+    (pmcx_set_env) or another kernel is asked for; the oracle is given the whole table of the
+    environment of the moment, and the two stay equal bit for bit."""
+    n_cells = 5
+    blk, cells, info = parity.setup_pair(wp, oracle, n_cells, 1500, 2, 2, seed=3, kernel=K_BROWN,
+                                         explicit_bounds=False)
+    with blk:
+        temp, pres, kernel = info["temp"].copy(), info["pres"].copy(), K_BROWN
+        for step in range(5):
+            if step == 2:                       # the air changes: every table is void
+                temp, pres = temp - 11.0, pres * 0.8
+                blk.set_env(temp, pres, np.full(n_cells, 0.5))
+            if step == 4:                       # and so does the kernel
+                kernel = K_BS
+            for c, oc in enumerate(cells):
+                oc.temp, oc.pressure = float(temp[c]), float(pres[c])
+                oc.kmax[:] = oracle.kmax_table(kernel, info["v_samp"], info["dens"].min(),
+                                               info["dens"].max(), temp[c], pres[c],
+                                               blk.cfg.const_k, blk.cfg.additive_beta)
+            ns, nc, st = blk.mc_coag(kernel, 600.0, 3, step)
+            assert nc.sum() > 0 and not (st & 32).any()
+            for c, oc in enumerate(cells):
+                ost, ons, onc = oc.mc_coag(kernel, 600.0, 3, oc.cell_id, step, blk.cfg.const_k,
+                                           blk.cfg.additive_beta)
+                assert (ons, onc, ost) == (int(ns[c]), int(nc[c]), int(st[c])), (step, c)
+            ok, msg = parity.compare_state(blk, cells)
+            assert ok, (step, msg)
+            # the part of the table the cell can use is the oracle's
+            for c, oc in enumerate(cells):
+                b = np.searchsorted(info["v_edge"], oc.vtot[:int(oc.n_part[0])], side="right") - 1
+                lo, hi = int(b.min()), int(b.max())
+                k = blk.kmax(c)
+                assert np.array_equal(k[lo:hi + 3, lo:hi + 3], oc.kmax.reshape(k.shape)[lo:hi + 3, lo:hi + 3])
+
+
+def test_kernel_bounds_range_is_flagged_when_outgrown(wp):
+    """64 equal particles and a constant kernel strong enough to merge almost all of them in one
+    call: the merged particle ends several bins above anything the bounds were computed for
+    (margin 2), which the cell reports (PMCX_ST_KMAX_RANGE); with whole tables it does not."""
+    for margin, expect in ((2, True), (-1, False)):
+        with wp.CellBlock(2, 64, 1, const_k=1.0e-6) as blk:
+            blk.set_aero_data([1800.0])
+            blk.set_env([288.15] * 2, [101325.0] * 2, [0.5] * 2)
+            blk.set_weights(np.full((2, 1), 1.0e6))
+            blk.set_next_id(np.array([1 << 24, (1 << 32) + (1 << 24)], dtype=np.int64))
+            blk.set_kernel_bounds_margin(margin)
+            v = np.full((1, 128), 4.0 / 3.0 * np.pi * (1e-7) ** 3)
+            blk.upload_cells(0, np.array([0, 64, 128]), v, np.zeros(128, np.int32),
+                             np.arange(128, dtype=np.int64), np.zeros(128), np.zeros(128))
+            ns, nc, st = blk.mc_coag(K_CONST, 10.0, 1, 0)
+            assert (nc > 40).all() and not (st & 3).any()
+            assert bool((st & 32).all()) == expect, (margin, st)

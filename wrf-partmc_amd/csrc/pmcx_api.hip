@@ -62,6 +62,10 @@ struct pmcx_ctx {
     double *d_diag = nullptr; // [n_cells*(2+2*n_dbin)]
     bool aero_data_set = false, env_set = false;
     int bounds_kernel = 0; // kernel type the kmax tables are valid for (0 = none)
+    int32_t *d_bounds_list = nullptr; // k_bounds_check's two counts and lists
+    int bounds_margin = 8;     // bins above a cell's populated range its bounds cover (< 0: whole tables)
+    bool bounds_dirty = true;  // something other than mc_coag changed a population since the last check
+    int bounds_age = 0;        // mc_coag calls since the last check (coagulation moves the range up)
     // profiling
     bool prof = false;
     std::map<std::string, ProfEntry> profile;
@@ -304,6 +308,8 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
     A_(ctx->d_n_ideal, nc * cfg->n_class);
     st.kmax_stride = (B * B + 3) & ~3;
     A_(st.kmax, nc * (size_t)st.kmax_stride);
+    A_(st.kmax_rng, nc * 4); A_(st.kmax_env, nc * 2);
+    A_(ctx->d_bounds_list, 2 * nc + 2);
     A_(st.n_part, nc); A_(st.n_hi, nc); A_(st.next_id, nc);
     A_(st.vol, nc * cfg->n_spec * cap);
     A_(st.vm, nc * cap);
@@ -408,6 +414,9 @@ int pmcx_set_aero_data(pmcx_ctx *ctx, const double *density, const double *kappa
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->aero_data_set = true;
     ctx->bounds_kernel = 0;
+    // the bounds depend on the densities: no cell's table is current any more
+    HIP_TRY(ctx, hipMemsetAsync(ctx->st.kmax_rng, 0, sizeof(int32_t) * 4 * (size_t)ctx->cfg.n_cells,
+                                ctx->stream));
     return PMCX_OK;
 }
 
@@ -423,12 +432,14 @@ int pmcx_set_env(pmcx_ctx *ctx, const double *temp, const double *pressure,
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_rh, rel_humid, b, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->env_set = true;
+    ctx->bounds_kernel = 0; // the bounds are those of the environment they were computed in
     return PMCX_OK;
 }
 
 // the lists of these cells no longer describe their particles (aero_state%valid_sort = .false.)
 static hipError_t invalidate_sort(pmcx_ctx *ctx, int cell_first, int n)
 {
+    ctx->bounds_dirty = true; // whatever changed the populations may have moved their bin ranges
     return hipMemsetAsync(ctx->st.sort_valid + cell_first, 0, sizeof(int32_t) * (size_t)n, ctx->stream);
 }
 
@@ -659,9 +670,20 @@ int pmcx_update_kernel_bounds(pmcx_ctx *ctx, int32_t kernel_type)
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     {
         ProfScope ps(ctx, "kernel_bounds");
-        HIP_TRY(ctx, launch_kernel_bounds(ctx->st, kernel_type, ctx->stream));
+        HIP_TRY(ctx, launch_kernel_bounds(ctx->st, kernel_type, -1, nullptr, ctx->stream));
     }
     ctx->bounds_kernel = kernel_type;
+    ctx->bounds_dirty = false;
+    ctx->bounds_age = 0;
+    return PMCX_OK;
+}
+
+int pmcx_set_kernel_bounds_margin(pmcx_ctx *ctx, int32_t margin)
+{
+    if (!ctx) return PMCX_EINVAL;
+    if (margin > 127) return fail(ctx, PMCX_EINVAL, "pmcx_set_kernel_bounds_margin: at most 127 bins");
+    ctx->bounds_margin = margin < 0 ? -1 : (margin < 2 ? 2 : margin);
+    ctx->bounds_kernel = 0;
     return PMCX_OK;
 }
 
@@ -700,16 +722,29 @@ int pmcx_mc_coag(pmcx_ctx *ctx, int32_t kernel_type, double del_t, uint64_t seed
     int rc = check_kernel_type(ctx, kernel_type);
     if (rc) return rc;
     if (!(del_t >= 0)) return fail(ctx, PMCX_EINVAL, "del_t must be non-negative");
-    if (ctx->bounds_kernel != kernel_type) {
+    if (ctx->bounds_margin < 0 && ctx->bounds_kernel != kernel_type) {
         rc = pmcx_update_kernel_bounds(ctx, kernel_type);
         if (rc) return rc;
     }
+    if (!ctx->aero_data_set || !ctx->env_set)
+        return fail(ctx, PMCX_ESTATE, "pmcx_set_aero_data and pmcx_set_env must come first");
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     HIP_TRY(ctx, hipMemsetAsync(ctx->st.status, 0, sizeof(int32_t) * (size_t)ctx->cfg.n_cells,
                                 ctx->stream));
     {
         ProfScope ps(ctx, "bin_sort");
         HIP_TRY(ctx, launch_bin_sort(ctx->st, ctx->stream));
+    }
+    // Bounds over each cell's populated bins (+ margin), now that the lists say which those are:
+    // when the kernel, the environment or a population changed, and every 16th call for the
+    // range coagulation itself moves up.  A cell whose bounds still hold costs one look.
+    if (ctx->bounds_margin >= 0 &&
+        (ctx->bounds_kernel != kernel_type || ctx->bounds_dirty || ++ctx->bounds_age >= 16)) {
+        ProfScope ps(ctx, "kernel_bounds");
+        HIP_TRY(ctx, launch_kernel_bounds(ctx->st, kernel_type, ctx->bounds_margin, ctx->d_bounds_list, ctx->stream));
+        ctx->bounds_kernel = kernel_type;
+        ctx->bounds_dirty = false;
+        ctx->bounds_age = 0;
     }
     {
         ProfScope ps(ctx, "coag_sample");

@@ -11,7 +11,8 @@ enum : int {
     ST_APPEND_OVERFLOW = 2,
     ST_KMAX_EXCEEDED = 4,
     ST_OUT_OF_GRID = 8,
-    ST_CAP_OVERFLOW = 16
+    ST_CAP_OVERFLOW = 16,
+    ST_KMAX_RANGE = 32
 };
 
 // Per-particle metadata that only coagulation events and whole-particle moves touch, kept
@@ -48,6 +49,9 @@ struct DeviceState {
     const double *n_ideal;         // [n_cells][n_class]
     float *kmax;                   // [n_cells][kmax_stride] bounds rounded up to fp32, row b1 = [b1*n_bin ..)
     int32_t kmax_stride;           // n_bin*n_bin rounded up to a multiple of 4 (16-byte loads)
+    int32_t *kmax_rng;             // [n_cells][4] {first bin, last bin, kernel type} the bounds of a cell
+                                   // were computed for (rows and columns outside are stale)
+    double *kmax_env;              // [n_cells][2] temperature and pressure they were computed at
     int32_t *n_part;               // [n_cells] live particles
     int32_t *n_hi;                 // [n_cells] slots in use (live + tombstones)
     int64_t *next_id;              // [n_cells]
@@ -97,7 +101,8 @@ hipError_t launch_compact(const DeviceState &st, int cell_first, int n_cells_do,
                           hipStream_t s);
 hipError_t launch_refresh_caches(const DeviceState &st, int cell_first, int n_cells_do,
                                  hipStream_t s);
-hipError_t launch_kernel_bounds(const DeviceState &st, int ktype, hipStream_t s);
+hipError_t launch_kernel_bounds(const DeviceState &st, int ktype, int margin, int32_t *scratch,
+                                hipStream_t s);
 hipError_t launch_bin_sort(const DeviceState &st, hipStream_t s);
 hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, uint64_t seed,
                               uint32_t step, hipStream_t s);

@@ -276,51 +276,149 @@ __global__ void k_refresh_caches(DeviceState st, int cell_first, int n_cells_do)
 //
 // est_k_minmax_binned_unweighted [upstream]: per cell, K_max(b1,b2) = max of K
 // over 3x3 sample volumes of the two bins and (rho_min|rho_max)^2.
+//
+// The upper edge of a bin is the lower edge of the next, so the 3 B sample volumes are
+// 2 B + 1 distinct ones (lattice point l = 2 b + s), and K is symmetric bit for bit
+// (brown_pair, sedi_pair: commutative sums and products only): K is evaluated once per
+// unordered pair of lattice points -- over the density pairs, one when every species has the
+// same density -- rounded up to fp32 into a triangular table in LDS, and a bin pair takes the
+// maximum of its 3x3 block (rounding up is monotone: the maximum of the rounded values is the
+// rounded maximum).  About 1/9 of the evaluations of the direct form with one density, 4/9
+// with two.
 
-__global__ __launch_bounds__(256) void k_kernel_bounds(DeviceState st, int ktype)
+__host__ __device__ inline size_t kernel_bounds_lds_bytes(int n_bin)
+{
+    const size_t L = 2 * (size_t)n_bin + 1;
+    return sizeof(double) * (5 * L * 2 + L + 1) + sizeof(float) * (L * (L + 1) / 2);
+}
+
+// Which cells need new bounds (after a sort: the lists are current).  A cell whose bounds were
+// computed for this kernel, at this temperature and pressure, over a range of bins that still
+// covers its populated bins plus the two a merged pair can reach, is left alone; any other is
+// listed, with the range [first populated bin, last + margin] it will get (everything else in
+// its table is stale: the samplers raise ST_KMAX_RANGE should a particle ever be created
+// beyond that range within the call).  One lane per cell.
+constexpr int BOUNDS_SMALL = 40; // ranges up to this many bins go to the small-footprint launch
+
+__global__ __launch_bounds__(256) void k_bounds_check(DeviceState st, int ktype, int margin,
+                                                      int32_t *scratch)
+{
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x; // one lane per cell
+    const int B = st.n_bin, G = B * st.n_class;
+    int need = -1;                                        // -1 none, 0 small range, 1 large
+    if (c < st.n_cells) {
+        int plo = B, phi = -1;
+        for (int g = 0; g < G; g++)
+            if (st.gcnt[(int64_t)c * G + g] > 0) {
+                const int b = g % B;
+                plo = b < plo ? b : plo;
+                phi = b > phi ? b : phi;
+            }
+        int32_t *rng = st.kmax_rng + 4 * (int64_t)c;
+        const double temp = st.temp[c], pres = st.pressure[c];
+        const int reach = phi + 2 < B - 1 ? phi + 2 : B - 1;
+        if (!(rng[2] == ktype && st.kmax_env[2 * (int64_t)c] == temp &&
+              st.kmax_env[2 * (int64_t)c + 1] == pres && plo >= rng[0] && reach <= rng[1])) {
+            rng[2] = 0;                                   // void until the table is written
+            if (phi < 0) { rng[0] = 0; rng[1] = -1; }     // empty cell: nothing to bound
+            else { rng[0] = plo; rng[1] = phi + margin < B - 1 ? phi + margin : B - 1; }
+            need = (rng[1] - rng[0] + 1 > BOUNDS_SMALL) ? 1 : 0;
+        }
+    }
+    // scratch: {n_small, n_large, small list [n_cells], large list [n_cells]}; one atomic per
+    // wavefront and list
+    for (int big = 0; big < 2; big++) {
+        const uint64_t m = __ballot(need == big);
+        if (m == 0) continue;
+        int base = 0;
+        if (lane == __builtin_ctzll(m)) base = atomicAdd(&scratch[big], (int)__popcll(m));
+        base = __shfl(base, __builtin_ctzll(m), 64);
+        if (need == big)
+            scratch[2 + (int64_t)big * st.n_cells + base + (int)__popcll(m & ((1ull << lane) - 1ull))] = c;
+    }
+}
+
+// list == nullptr: the whole table of every cell.  Otherwise the listed cells, each over the
+// range k_bounds_check left in kmax_rng (at most bins_cap bins: the LDS tables are laid out
+// for that many).  The workgroups share the work round-robin.
+__global__ __launch_bounds__(512) void k_kernel_bounds(DeviceState st, int ktype, int bins_cap,
+                                                       const int32_t *list, const int32_t *count)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int c = blockIdx.x;
-    const int B = st.n_bin, NP = B * 6;
-    // per-(bin, sample, density) particle properties, structure of arrays in LDS
-    double *p_rad = (double *)smem, *p_dif = p_rad + NP, *p_spd = p_dif + NP,
-           *p_del = p_spd + NP, *p_fal = p_del + NP;
-    const EnvDerived env = env_derive(st.temp[c], st.pressure[c]);
+    const int B = st.n_bin, L = 2 * bins_cap + 1;
+    const int ND = (st.rho_min == st.rho_max) ? 1 : 2;
+    const int n_work = list ? *count : st.n_cells;
+  for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
+    const int c = list ? list[w] : w;
+    const double temp = st.temp[c], pres = st.pressure[c];
+    int klo = 0, khi = B - 1;
+    if (list) { klo = st.kmax_rng[4 * (int64_t)c]; khi = st.kmax_rng[4 * (int64_t)c + 1]; }
+    const int nb = khi - klo + 1;                 // bins, lattice points 2 klo .. 2 khi + 2
+    const int Ls = nb > 0 ? 2 * nb + 1 : 0, l0 = 2 * klo;
+    const int NP = Ls * ND;
+    // per-(lattice point, density) particle properties, structure of arrays in LDS
+    double *p_rad = (double *)smem, *p_dif = p_rad + 2 * L, *p_spd = p_dif + 2 * L,
+           *p_del = p_spd + 2 * L, *p_fal = p_del + 2 * L;
+    double *p_vol = p_fal + 2 * L;          // [L] the lattice volumes
+    float *M = (float *)(p_vol + L + 1);    // row l1 of the upper triangle: Ls - l1 entries
+    const EnvDerived env = env_derive(temp, pres);
     const KernelParams kp{st.const_k, st.additive_beta};
     for (int j = threadIdx.x; j < NP; j += blockDim.x) {
-        const int d = j & 1, bs = j >> 1; // bs = b*3+s
-        const double v = st.v_samp[bs];
+        const int l = j / ND, d = j - l * ND, lg = l0 + l;
+        const double v = (lg & 1) ? st.v_samp[3 * (lg >> 1) + 1] : st.v_edge[lg >> 1];
+        if (d == 0) p_vol[l] = v;
         const double rho = d ? st.rho_max : st.rho_min;
         const PartProps q = props_for(ktype, v, v * rho, env);
         p_rad[j] = q.rad; p_dif[j] = q.diffus; p_spd[j] = q.speedsq; p_del[j] = q.deltasq;
         p_fal[j] = q.wfall;
     }
     __syncthreads();
-    float *km = st.kmax + (int64_t)c * st.kmax_stride;
-    // K is symmetric: one thread per unordered bin pair, both entries written
-    const int n_pair = B * (B + 1) / 2;
-    for (int j = threadIdx.x; j < n_pair; j += blockDim.x) {
-        // row b1 of the upper triangle holds B - b1 entries
-        int b1 = 0, rem = j;
-        while (rem >= B - b1) { rem -= B - b1; b1++; }
-        const int b2 = b1 + rem;
+    const int n_lat = Ls * (Ls + 1) / 2;
+    // a thread walks the triangle in steps of blockDim.x: (l1, position in row l1) kept incrementally
+    int l1 = 0, pos = threadIdx.x;
+    for (int j = threadIdx.x; j < n_lat; j += blockDim.x, pos += blockDim.x) {
+        while (pos >= Ls - l1) { pos -= Ls - l1; l1++; }
+        const int l2 = l1 + pos;
+        const double v1 = p_vol[l1], v2 = p_vol[l2];
         double m = 0.0;
-        for (int i1 = 0; i1 < 6; i1++) {
-            const int ja = b1 * 6 + i1;
+        for (int d1 = 0; d1 < ND; d1++) {
+            const int ja = l1 * ND + d1;
             const PartProps qa{p_rad[ja], p_dif[ja], p_spd[ja], p_del[ja], p_fal[ja]};
-            for (int i2 = 0; i2 < 6; i2++) {
-                const int jb = b2 * 6 + i2;
+            for (int d2 = 0; d2 < ND; d2++) {
+                const int jb = l2 * ND + d2;
                 const PartProps qb{p_rad[jb], p_dif[jb], p_spd[jb], p_del[jb], p_fal[jb]};
-                const double k = kernel_pair(ktype, st.v_samp[ja >> 1], st.v_samp[jb >> 1], qa, qb, kp);
+                const double k = kernel_pair(ktype, v1, v2, qa, qb, kp);
                 if (k > m) m = k;
             }
         }
         // smallest float >= m: half the table, four bounds per 16-byte load in the sampler
         float f = (float)m;
         if ((double)f < m) f = __uint_as_float(__float_as_uint(f) + 1u);
-        km[b1 * B + b2] = f;
-        km[b2 * B + b1] = f;
+        M[j] = f;
     }
+    __syncthreads();
+    // the entries of the range (both triangles: row segments are written whole, coalesced)
+    float *km = st.kmax + (int64_t)c * st.kmax_stride;
+    for (int j = threadIdx.x; j < nb * nb; j += blockDim.x) {
+        const int r1 = j / nb, r2 = j - r1 * nb;
+        float f = 0.0f;
+        for (int s1 = 0; s1 < 3; s1++)
+            for (int s2 = 0; s2 < 3; s2++) {
+                int la = 2 * r1 + s1, lb = 2 * r2 + s2;
+                if (la > lb) { const int x = la; la = lb; lb = x; }
+                const float k = M[la * (2 * Ls + 1 - la) / 2 + (lb - la)];
+                if (k > f) f = k;
+            }
+        km[(klo + r1) * B + (klo + r2)] = f;
+    }
+    if (threadIdx.x == 0) {
+        int32_t *rng = st.kmax_rng + 4 * (int64_t)c;
+        rng[0] = klo; rng[1] = khi; rng[2] = ktype;
+        st.kmax_env[2 * (int64_t)c] = temp; st.kmax_env[2 * (int64_t)c + 1] = pres;
+    }
+    __syncthreads(); // the LDS tables are reused by the next cell
+  }
 }
 
 // ---------------------------------------------------------------- bin sort
@@ -896,6 +994,7 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
         const int g_old = pn_is_1 ? gA : gB, g_o = pn_is_1 ? gB : gA;
         if (vn < edge[0] || vn >= edge[B]) status |= ST_OUT_OF_GRID;
         const int g_new = cc * B + bin_index(edge, B, vn, st);
+        if (g_new - cc * B > st.kmax_rng[4 * (int64_t)c + 1]) status |= ST_KMAX_RANGE; // no bound computed there
         if (g_new != g_old && n_app >= st.max_appends) {
             status |= ST_APPEND_OVERFLOW; done = true; continue;
         }
@@ -1105,6 +1204,10 @@ __global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype_rt
         envs[2 * 64 + lane] = e.c_diff; envs[3 * 64 + lane] = e.c_speed;
         envs[4 * 64 + lane] = e.c_inv_speed; envs[5 * 64 + lane] = e.c_fall;
         envs[6 * 64 + lane] = e.rhoair;
+        // The last bin the cell's bounds cover, looked at when an event creates a particle.  The
+        // Brownian kernel does not use the air density: its slot carries it (another 512 bytes
+        // of LDS per wavefront would cost the twelfth wavefront of the CU).
+        if (KT == KERNEL_BROWN) envs[6 * 64 + lane] = (double)st.kmax_rng[4 * (int64_t)c + 1];
     }
     __syncthreads(); // one wavefront: orders the edge table
 
@@ -1358,6 +1461,8 @@ __global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype_rt
                 const int g_old = cl_old * B + b_old, g_o = cl_o * B + b_o;
                 if (vn < edge[0] || vn >= edge[B]) status |= ST_OUT_OF_GRID;
                 const int b_new = bin_index(edge, B, vn, st);
+                if (b_new > (KT == KERNEL_BROWN ? (int)envs[6 * 64 + lane] : st.kmax_rng[4 * (int64_t)c + 1]))
+                    status |= ST_KMAX_RANGE; // no bound was computed there
                 const int g_new = cc * B + b_new;
                 if (g_new != g_old && n_app >= st.max_appends) {
                     status |= ST_APPEND_OVERFLOW; done = true; break;
@@ -2826,10 +2931,30 @@ hipError_t launch_refresh_caches(const DeviceState &st, int cell_first, int n_ce
                        cell_first, n_cells_do);
     return hipGetLastError();
 }
-hipError_t launch_kernel_bounds(const DeviceState &st, int ktype, hipStream_t s)
+// margin < 0: whole tables for every cell.  Otherwise scratch (2 n_cells + 2 ints) takes the lists
+// of the cells whose bounds no longer hold, and only those are computed: narrow ranges by
+// small workgroups with a small LDS footprint (many per CU), the others at full size.
+hipError_t launch_kernel_bounds(const DeviceState &st, int ktype, int margin, int32_t *scratch,
+                                hipStream_t s)
 {
-    const size_t lds = sizeof(double) * 5 * (size_t)st.n_bin * 6;
-    hipLaunchKernelGGL(k_kernel_bounds, dim3(st.n_cells), dim3(256), lds, s, st, ktype);
+    const size_t lds = kernel_bounds_lds_bytes(st.n_bin);
+    allow_lds(k_kernel_bounds, lds);
+    const int n_wg = st.n_cells < 8192 ? st.n_cells : 8192;
+    if (margin < 0 || !scratch) {
+        hipLaunchKernelGGL(k_kernel_bounds, dim3(n_wg), dim3(512), lds, s, st, ktype, st.n_bin,
+                           (const int32_t *)nullptr, (const int32_t *)nullptr);
+        return hipGetLastError();
+    }
+    (void)hipMemsetAsync(scratch, 0, 2 * sizeof(int32_t), s);
+    hipLaunchKernelGGL(k_bounds_check, dim3((st.n_cells + 255) / 256), dim3(256), 0, s, st, ktype, margin,
+                       scratch);
+    const int small = BOUNDS_SMALL < st.n_bin ? BOUNDS_SMALL : st.n_bin;
+    hipLaunchKernelGGL(k_kernel_bounds, dim3(st.n_cells < 32768 ? st.n_cells : 32768), dim3(256),
+                       kernel_bounds_lds_bytes(small), s, st, ktype, small,
+                       (const int32_t *)(scratch + 2), (const int32_t *)scratch);
+    if (small < st.n_bin)
+        hipLaunchKernelGGL(k_kernel_bounds, dim3(n_wg), dim3(512), lds, s, st, ktype, st.n_bin,
+                           (const int32_t *)(scratch + 2 + st.n_cells), (const int32_t *)(scratch + 1));
     return hipGetLastError();
 }
 hipError_t launch_bin_sort(const DeviceState &st, hipStream_t s)

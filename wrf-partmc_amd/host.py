@@ -25,7 +25,8 @@ EXPORTED_SYMBOLS = [
     "pmcx_config_default", "pmcx_create", "pmcx_destroy", "pmcx_last_error", "pmcx_synchronize",
     "pmcx_set_aero_data", "pmcx_set_env", "pmcx_set_weights", "pmcx_get_weights",
     "pmcx_set_n_part_ideal", "pmcx_set_next_id", "pmcx_get_next_id", "pmcx_upload_cells",
-    "pmcx_get_n_part", "pmcx_download_cells", "pmcx_update_kernel_bounds", "pmcx_mc_coag",
+    "pmcx_get_n_part", "pmcx_download_cells", "pmcx_update_kernel_bounds",
+    "pmcx_set_kernel_bounds_margin", "pmcx_mc_coag",
     "pmcx_get_coag_counters", "pmcx_get_coag_totals", "pmcx_accumulate_totals",
     "pmcx_read_accumulated", "pmcx_rebalance", "pmcx_condense",
     "pmcx_scenario_update_aero_state", "pmcx_transport",
@@ -110,6 +111,7 @@ def load_library():
     L.pmcx_create.argtypes = [C.POINTER(PmcxConfig), C.POINTER(C.c_void_p)]
     L.pmcx_mc_coag.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_uint64, C.c_uint32]
     L.pmcx_rebalance.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_uint32]
+    L.pmcx_set_kernel_bounds_margin.argtypes = [C.c_void_p, C.c_int32]
     L.pmcx_condense.argtypes = [C.c_void_p, C.c_double, C.c_int32]
     L.pmcx_transport.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
@@ -351,7 +353,13 @@ class CellBlock:
 
     # -- the path ---------------------------------------------------------
     def update_kernel_bounds(self, kernel_type):
+        """Whole tables for every cell, now (est_k_minmax_binned_unweighted).  Without this call
+        mc_coag keeps each cell's bounds current over its populated bins by itself."""
         self._ck(self._lib.pmcx_update_kernel_bounds(self._h, kernel_type))
+
+    def set_kernel_bounds_margin(self, margin):
+        """Bins above a cell's populated range its bounds cover (default 8); < 0: whole tables."""
+        self._ck(self._lib.pmcx_set_kernel_bounds_margin(self._h, int(margin)))
 
     def mc_coag(self, coag_kernel_type, del_t, seed=0, step=0, counters=True):
         """mc_coag on every cell (driver:192-194).  Returns (n_samp, n_coag, status)
