@@ -449,6 +449,7 @@ contains
     allocate(ns(cfg%n_cells), nc(cfg%n_cells), st(cfg%n_cells))
     call pmcx_die(pmcx_get_coag_counters(ctx, ns, nc, st), 'pmcx_get_coag_counters')
     if (any(iand(st, 3) /= 0)) call pmcx_die(5, 'mc_coag (event/append log overflow)')
+    if (any(iand(st, 32) /= 0)) call pmcx_die(5, 'mc_coag (particle created above the kernel-bounds range)')
     tot_n_samp = ns
     tot_n_coag = nc
   end subroutine mc_coag_resident_pmcx
