@@ -62,7 +62,6 @@ struct pmcx_ctx {
     double *d_diag = nullptr; // [n_cells*(2+2*n_dbin)]
     bool aero_data_set = false, env_set = false;
     int bounds_kernel = 0; // kernel type the kmax tables are valid for (0 = none)
-    int32_t *d_bounds_list = nullptr; // k_bounds_check's two counts and lists
     int bounds_margin = 8;     // bins above a cell's populated range its bounds cover (< 0: whole tables)
     bool bounds_dirty = true;  // something other than mc_coag changed a population since the last check
     int bounds_age = 0;        // mc_coag calls since the last check (coagulation moves the range up)
@@ -309,7 +308,7 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
     st.kmax_stride = (B * B + 3) & ~3;
     A_(st.kmax, nc * (size_t)st.kmax_stride);
     A_(st.kmax_rng, nc * 4); A_(st.kmax_env, nc * 2);
-    A_(ctx->d_bounds_list, 2 * nc + 2);
+    A_(st.work_list, 2 * nc + 2);
     A_(st.n_part, nc); A_(st.n_hi, nc); A_(st.next_id, nc);
     A_(st.vol, nc * cfg->n_spec * cap);
     A_(st.vm, nc * cap);
@@ -741,7 +740,7 @@ int pmcx_mc_coag(pmcx_ctx *ctx, int32_t kernel_type, double del_t, uint64_t seed
     if (ctx->bounds_margin >= 0 &&
         (ctx->bounds_kernel != kernel_type || ctx->bounds_dirty || ++ctx->bounds_age >= 16)) {
         ProfScope ps(ctx, "kernel_bounds");
-        HIP_TRY(ctx, launch_kernel_bounds(ctx->st, kernel_type, ctx->bounds_margin, ctx->d_bounds_list, ctx->stream));
+        HIP_TRY(ctx, launch_kernel_bounds(ctx->st, kernel_type, ctx->bounds_margin, ctx->st.work_list, ctx->stream));
         ctx->bounds_kernel = kernel_type;
         ctx->bounds_dirty = false;
         ctx->bounds_age = 0;

@@ -52,6 +52,7 @@ struct DeviceState {
     int32_t *kmax_rng;             // [n_cells][4] {first bin, last bin, kernel type} the bounds of a cell
                                    // were computed for (rows and columns outside are stale)
     double *kmax_env;              // [n_cells][2] temperature and pressure they were computed at
+    int32_t *work_list;            // [2 n_cells + 2] scratch: which cells the next kernel has work for
     int32_t *n_part;               // [n_cells] live particles
     int32_t *n_hi;                 // [n_cells] slots in use (live + tombstones)
     int64_t *next_id;              // [n_cells]

@@ -459,14 +459,50 @@ __device__ __forceinline__ void block_excl_scan_u32(uint32_t *a, int n, uint32_t
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_bin_sort(DeviceState st)
+// Which cells have work to do in the kernel that follows: most calls find most cells idle (the
+// lists of the last call still hold, no cell is past its tombstone threshold, no class is off
+// its ideal count), and a workgroup launched only to find that out costs more than the look.
+// One lane per cell decides; the cells with work are listed (scratch[0] = count, the list
+// behind it; one atomic per wavefront) and the kernel's workgroups share the list round-robin.
+enum : int { LIST_SORT = 0, LIST_COMPACT = 1, LIST_REBALANCE = 2 };
+
+__global__ __launch_bounds__(256) void k_list_cells(DeviceState st, int what, int p0, int p1,
+                                                    int cell_first, int n_do, int32_t *scratch)
+{
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = cell_first + k;
+    bool need = false;
+    if (k < n_do) {
+        if (what == LIST_SORT) {
+            need = st.sort_valid[c] == 0;
+        } else if (what == LIST_COMPACT) { // more than p0 / p1 of the slots are tombstones
+            const int n_hi = st.n_hi[c], n_live = st.n_part[c];
+            need = (int64_t)(n_hi - n_live) * p1 > (int64_t)n_hi * p0;
+        } else { // one class: its count is the cell's; p0 = allow_doubling, p1 = allow_halving
+            const double n = (double)st.n_part[c], ideal = st.n_ideal[c];
+            need = (p0 && n > 0.0 && n < ideal / 2.0) || (p1 && n > ideal * 2.0);
+        }
+    }
+    const uint64_t m = __ballot(need);
+    if (m == 0) return;
+    int base = 0;
+    if (lane == __builtin_ctzll(m)) base = atomicAdd(&scratch[0], (int)__popcll(m));
+    base = __shfl(base, __builtin_ctzll(m), 64);
+    if (need) scratch[1 + base + (int)__popcll(m & ((1ull << lane) - 1ull))] = c;
+}
+
+__global__ __launch_bounds__(256) void k_bin_sort(DeviceState st, const int32_t *list,
+                                                  const int32_t *count)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint32_t wsum[4];
-    const int c = blockIdx.x;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int B = st.n_bin, C = st.n_class, G = B * C;
-    if (st.sort_valid[c]) return; // the lists of the last call still hold (whole workgroup)
+    const int n_work = list ? *count : st.n_cells;
+  for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
+    const int c = list ? list[w] : w;
+    if (st.sort_valid[c]) continue; // the lists of the last call still hold (whole workgroup)
     const int n = st.n_hi[c]; // slots in use; dead ones (vtot < 0) are skipped
     const int64_t cb = (int64_t)c * st.cap;
 
@@ -565,6 +601,8 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st)
         }
         wave_sync();
     }
+    __syncthreads(); // the LDS tables are reused by the next cell
+  }
 }
 
 // ------------------------------------------------------------- coag sampler
@@ -1738,21 +1776,20 @@ __device__ void compact_wave(const DeviceState &st, int c, int lane, uint32_t *c
 }
 
 // compacts the cells whose dead fraction exceeds num/den (num = 0: any dead slot)
-__global__ __launch_bounds__(256) void k_compact(DeviceState st, int cell_first, int n_cells_do,
-                                                 int num, int den)
+__global__ __launch_bounds__(256) void k_compact(DeviceState st, const int32_t *list,
+                                                 const int32_t *count)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int k = blockIdx.x * (blockDim.x >> 6) + wave;
-    if (k >= n_cells_do) return;
-    const int c = cell_first + k;
-    const int n_hi = st.n_hi[c], n_live = st.n_part[c];
     const int n_chunk = (st.cap + 63) / 64 + 1;
     uint64_t *cmask = (uint64_t *)smem + (size_t)wave * n_chunk;
     uint32_t *cbase = (uint32_t *)((uint64_t *)smem + (size_t)(blockDim.x >> 6) * n_chunk) +
                       (size_t)wave * n_chunk;
-    if ((int64_t)(n_hi - n_live) * den > (int64_t)n_hi * num)
-        compact_wave(st, c, lane, cbase, cmask);
+    const int n_work = *count, stride = gridDim.x * (blockDim.x >> 6);
+    for (int w = blockIdx.x * (blockDim.x >> 6) + wave; w < n_work; w += stride) {
+        compact_wave(st, list[w], lane, cbase, cmask);
+        wave_sync();
+    }
 }
 
 // ---------------------------------------------------------------- rebalance
@@ -1765,10 +1802,13 @@ __global__ __launch_bounds__(256) void k_compact(DeviceState st, int cell_first,
 // rank among the live particles, which does not depend on where holes are.
 
 __global__ __launch_bounds__(64) void k_rebalance(DeviceState st, int allow_doubling,
-                                                  int allow_halving, uint64_t seed, uint32_t step)
+                                                  int allow_halving, uint64_t seed, uint32_t step,
+                                                  const int32_t *list, const int32_t *count)
 {
     const int lane = threadIdx.x;
-    const int c = blockIdx.x;
+    const int n_work = list ? *count : st.n_cells;
+  for (int wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+    const int c = list ? list[wi] : wi;
     const int64_t cb = (int64_t)c * st.cap;
     const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
     const uint64_t lt = (1ull << lane) - 1ull;
@@ -1851,6 +1891,8 @@ __global__ __launch_bounds__(64) void k_rebalance(DeviceState st, int allow_doub
         }
     }
     if (lane == 0 && status) atomicOr(&st.status[c], status);
+    wave_sync();
+  }
 }
 
 // -------------------------------------------------------------- diagnostics
@@ -2858,6 +2900,15 @@ static inline void allow_lds(K kernel, size_t bytes)
                                   (int)bytes);
 }
 
+// the cells with work for the kernel that follows, listed in st.work_list (count first)
+static void list_cells(const DeviceState &st, int what, int p0, int p1, int cell_first, int n_do,
+                       hipStream_t s)
+{
+    (void)hipMemsetAsync(st.work_list, 0, sizeof(int32_t), s);
+    hipLaunchKernelGGL(k_list_cells, dim3((n_do + 255) / 256), dim3(256), 0, s, st, what, p0, p1,
+                       cell_first, n_do, st.work_list);
+}
+
 static inline int waves_per_block(size_t lds_per_cell)
 {
     int wpb = 4;
@@ -2920,8 +2971,10 @@ hipError_t launch_compact(const DeviceState &st, int cell_first, int n_cells_do,
                           hipStream_t s)
 {
     allow_lds(k_compact, compact_lds_bytes(st));
-    hipLaunchKernelGGL(k_compact, dim3((n_cells_do + 3) / 4), dim3(256), compact_lds_bytes(st), s, st,
-                       cell_first, n_cells_do, num, den);
+    list_cells(st, LIST_COMPACT, num, den, cell_first, n_cells_do, s);
+    const int n_wg = (n_cells_do + 3) / 4;
+    hipLaunchKernelGGL(k_compact, dim3(n_wg < 8192 ? n_wg : 8192), dim3(256), compact_lds_bytes(st), s,
+                       st, (const int32_t *)(st.work_list + 1), (const int32_t *)st.work_list);
     return hipGetLastError();
 }
 hipError_t launch_refresh_caches(const DeviceState &st, int cell_first, int n_cells_do,
@@ -2960,7 +3013,10 @@ hipError_t launch_kernel_bounds(const DeviceState &st, int ktype, int margin, in
 hipError_t launch_bin_sort(const DeviceState &st, hipStream_t s)
 {
     allow_lds(k_bin_sort, bin_sort_lds_bytes(st));
-    hipLaunchKernelGGL(k_bin_sort, dim3(st.n_cells), dim3(256), bin_sort_lds_bytes(st), s, st);
+    list_cells(st, LIST_SORT, 0, 0, 0, st.n_cells, s);
+    hipLaunchKernelGGL(k_bin_sort, dim3(st.n_cells < 16384 ? st.n_cells : 16384), dim3(256),
+                       bin_sort_lds_bytes(st), s, st, (const int32_t *)(st.work_list + 1),
+                       (const int32_t *)st.work_list);
     return hipGetLastError();
 }
 hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, uint64_t seed,
@@ -3013,8 +3069,15 @@ hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, ui
 hipError_t launch_rebalance(const DeviceState &st, int allow_doubling, int allow_halving,
                             uint64_t seed, uint32_t step, hipStream_t s)
 {
+    if (st.n_class == 1) { // the test is a comparison of two per-cell scalars: list the cells first
+        list_cells(st, LIST_REBALANCE, allow_doubling, allow_halving, 0, st.n_cells, s);
+        hipLaunchKernelGGL(k_rebalance, dim3(st.n_cells < 32768 ? st.n_cells : 32768), dim3(64), 0, s,
+                           st, allow_doubling, allow_halving, seed, step,
+                           (const int32_t *)(st.work_list + 1), (const int32_t *)st.work_list);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_rebalance, dim3(st.n_cells), dim3(64), 0, s, st, allow_doubling,
-                       allow_halving, seed, step);
+                       allow_halving, seed, step, (const int32_t *)nullptr, (const int32_t *)nullptr);
     return hipGetLastError();
 }
 hipError_t launch_diagnostics(const DeviceState &st, double *tot_num, double *tot_mass,

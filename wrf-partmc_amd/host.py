@@ -75,7 +75,8 @@ class PmcxStepFlags(C.Structure):
 
 
 def library_path():
-    return os.path.join(_HERE, "libpmcx.so")
+    # PMCX_LIBRARY: another build of the same library (A/B timing of two builds on one box)
+    return os.environ.get("PMCX_LIBRARY") or os.path.join(_HERE, "libpmcx.so")
 
 
 def build_library(force=False):
@@ -111,7 +112,8 @@ def load_library():
     L.pmcx_create.argtypes = [C.POINTER(PmcxConfig), C.POINTER(C.c_void_p)]
     L.pmcx_mc_coag.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_uint64, C.c_uint32]
     L.pmcx_rebalance.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_uint32]
-    L.pmcx_set_kernel_bounds_margin.argtypes = [C.c_void_p, C.c_int32]
+    if hasattr(L, "pmcx_set_kernel_bounds_margin"):   # (absent from an older build under PMCX_LIBRARY)
+        L.pmcx_set_kernel_bounds_margin.argtypes = [C.c_void_p, C.c_int32]
     L.pmcx_condense.argtypes = [C.c_void_p, C.c_double, C.c_int32]
     L.pmcx_transport.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
