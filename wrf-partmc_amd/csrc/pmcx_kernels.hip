@@ -3237,7 +3237,7 @@ hipError_t launch_condense(const DeviceState &st, const double *kappa, const dou
 hipError_t launch_totals(const DeviceState &st, int64_t *out4, hipStream_t s)
 {
     int g = (st.n_cells + 255) / 256;
-    if (g > 1024) g = 1024;
+    if (g > 128) g = 128; // four same-address atomics per workgroup: few workgroups
     hipLaunchKernelGGL(k_totals, dim3(g), dim3(256), 0, s, st, out4);
     return hipGetLastError();
 }
