@@ -13,13 +13,16 @@ pytestmark = pytest.mark.gpu
 K_BROWN, K_SEDI, K_ADD, K_CONST, K_ZERO, K_BS = 4, 1, 2, 3, 5, 101
 
 
-@pytest.fixture(autouse=True, params=["dispatch", "lane-per-cell"])
+@pytest.fixture(autouse=True, params=["dispatch", "lane-per-cell", "lane-per-cell-split"])
 def sampler_variant(request, monkeypatch):
-    """Every test of this module runs twice: with the library's own choice of sampler (the
-    lanes-per-cell kernels at these cell counts) and with the lane-per-cell kernel forced
-    (the one the full-size domain runs), so that both are held to the oracle."""
+    """Every test of this module runs three times: with the library's own choice of sampler (the
+    lanes-per-cell kernels at these cell counts), with the lane-per-cell kernel forced (the one
+    the full-size domain runs) and with its two-wavefront form (evaluator + drawer, what a
+    rank's share of the domain runs at N = 4, 8), so that all are held to the oracle."""
     if request.param == "lane-per-cell":
         monkeypatch.setenv("PMCX_SAMPLER_LANES", "1")
+    elif request.param == "lane-per-cell-split":
+        monkeypatch.setenv("PMCX_SAMPLER_LANES", "2")
     else:
         monkeypatch.delenv("PMCX_SAMPLER_LANES", raising=False)
     return request.param

@@ -1150,6 +1150,8 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
 constexpr int SEQ_W = 24;      // bins per class with list state in LDS
 constexpr int SEQ_ENV = 7;     // air properties kept per cell
 
+constexpr size_t SEQ_SHARED_BYTES = 64 * (4 * sizeof(uint32_t) + sizeof(double)); // SPLIT: a lane's sweep state
+
 __host__ __device__ inline size_t seq_lds_bytes(int B, int C)
 {
     size_t o = ((size_t)(B + 1) * sizeof(double) + 15) & ~(size_t)15; // sort-grid edges
@@ -1171,9 +1173,17 @@ __device__ unsigned long long g_seq_stamps[12];
 // draws and the class bookkeeping fold away, which is worth registers in the hot loop.
 // KT: the coagulation kernel when known at compile time (COAG_KERNEL_TYPE_BROWN, the one the
 // reference selects, wrf_pmc_driver.F90:192), 0 = chosen at run time.
-template <bool STAMPS, bool SIMPLE, int KT>
-__global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype_rt, double del_t,
-                                                 uint64_t seed, uint32_t step, uint16_t *ovf_mem)
+// SPLIT: two wavefronts share the 64 cells of a workgroup -- the first evaluates the samples
+// (and coagulates), the second draws the counts -- each executing its own half of the pass.
+// A lane's sweep state (slot, samples left, bound, done) lives in LDS between passes and the
+// lane is worked on by exactly one of the two in a pass (the evaluator while it holds samples,
+// else the drawer), so per lane the sequence of operations is the one of the single
+// wavefront, bit for bit.  For blocks of cells too few to fill the chip: a wavefront alone on
+// its SIMD is bound by the instructions of a pass, and this halves them (launch_coag_sample).
+template <bool STAMPS, bool SIMPLE, int KT, bool SPLIT = false>
+__global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 2 : 3)
+void k_coag_seq(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint32_t step,
+                uint16_t *ovf_mem)
 {
     uint64_t t_last = 0, t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (STAMPS) t_last = __builtin_amdgcn_s_memtime();
@@ -1184,7 +1194,9 @@ __global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype_rt
         t_last = t_now;                                                                           \
     }
     extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool role_e = !SPLIT || (threadIdx.x >> 6) == 0; // evaluates and coagulates
+    const bool role_d = !SPLIT || (threadIdx.x >> 6) == 1; // draws the counts
     const int cidx = blockIdx.x * 64 + lane;
     const bool live = cidx < st.n_cells;
     const int c = live ? cidx : st.n_cells - 1;
@@ -1200,6 +1212,10 @@ __global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype_rt
     double *magl = envs + SEQ_ENV * 64;                   // [C][64] weight magnitudes
     uint64_t *mask = (uint64_t *)(magl + (size_t)C * 64); // [C*2][64]
     uint32_t *ent = (uint32_t *)(mask + 2 * (size_t)C * 64); // [C*SEQ_W][64]
+    // SPLIT: the sweep state of each lane, handed from one wavefront to the other
+    uint32_t *sh_pos = ent + (size_t)C * SEQ_W * 64;  // c1 | c2 << 8 | (b1 + 1) << 16 | (b2 + 1) << 24
+    uint32_t *sh_ns = sh_pos + 64, *sh_s = sh_ns + 64, *sh_done = sh_s + 64;
+    double *sh_kmax = (double *)(sh_done + 64);
 #define MASK(j) mask[(j) * 64 + lane]
 
     for (int j = lane; j <= B; j += 64) edge[j] = st.v_edge[j];
@@ -1361,7 +1377,25 @@ __global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype_rt
     // wait of the wavefront is covered by work: list entries | first draw's search and
     // Philox -> volumes, masses and event data | first Poisson, second search and Philox ->
     // kernel evaluation, second Poisson, coagulation.
+    if (SPLIT) { // (both wavefronts write the same values)
+        sh_pos[lane] = 0; sh_ns[lane] = 0; sh_s[lane] = 0; sh_done[lane] = done; sh_kmax[lane] = 0.0;
+        __syncthreads();
+    }
     while (true) {
+        bool own = true; // SPLIT: this wavefront works on the lane in this pass
+        if (SPLIT) {
+            const uint32_t pk = sh_pos[lane];
+            c1 = (int)(pk & 255u); c2 = (int)((pk >> 8) & 255u);
+            b1 = (int)((pk >> 16) & 255u) - 1; b2 = (int)(pk >> 24) - 1;
+            ns_rem = sh_ns[lane]; s = sh_s[lane]; done = sh_done[lane] != 0; k_max = sh_kmax[lane];
+            // what draw_find derives from the classes of the slot
+            n1 = magl[(c1 < C ? c1 : C - 1) * 64 + lane]; n2 = magl[(c2 < C ? c2 : C - 1) * 64 + lane];
+            cc = (n1 < n2) ? c1 : c2;
+            nmin = (n1 < n2) ? n1 : n2;
+            fmax = (n1 < n2) ? n2 : n1;
+            factor = n1 * n2 / nmin;
+            own = !done && (role_e ? ns_rem > 0 : ns_rem == 0);
+        }
         if (__ballot(!done) == 0) break;
         if (STAMPS) t_acc[6]++;
 
@@ -1373,7 +1407,7 @@ __global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype_rt
         double u_acc = 0;
         const int gA = c1 * B + b1, gB = c2 * B + b2;
         const bool same = (gA == gB);
-        if (!done && ns_rem > 0) {
+        if (role_e && own && !done && ns_rem > 0) {
             eA = ent_get(c1, b1);
             eB = same ? eA : ent_get(c2, b2);
             const int nA = (int)(eA & 0xFFFFu), nB = (int)(eB & 0xFFFFu);
@@ -1406,7 +1440,7 @@ __global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype_rt
         }
 
         // ---- (2) drawing lanes: first slot, bound requested, Philox ----
-        const bool drawing = !done && !evalid && ns_rem == 0;
+        const bool drawing = role_d && own && !done && !evalid && ns_rem == 0;
         uint32_t dA = 0, dB = 0;
         double km = 0, u_d = 0;
         bool found = false;
@@ -1582,10 +1616,20 @@ __global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype_rt
             } while (false);
         }
         if (done) ns_rem = 0;
+        if (SPLIT) {
+            if (own) {
+                sh_pos[lane] = (uint32_t)c1 | ((uint32_t)c2 << 8) | ((uint32_t)(b1 + 1) << 16) |
+                               ((uint32_t)(b2 + 1) << 24);
+                sh_ns[lane] = ns_rem; sh_s[lane] = s; sh_done[lane] = done; sh_kmax[lane] = k_max;
+            }
+            __syncthreads(); // the other wavefront's lanes and list updates, before the next pass
+        }
         STAMP(3)
     }
 
-    if (live) {
+    if (live && role_d) // (the drawer counts the samples)
+        st.n_samp[c] = tot_samp > 0x7FFFFFFFull ? 0x7FFFFFFF : (int32_t)tot_samp;
+    if (live && role_e) {
         for (int cl = 0; cl < C; cl++)
             for (int k = 0; k < SEQ_W && blo + k < B; k++)
                 gcnt_g[cl * B + blo + k] = (int32_t)(ent[(cl * SEQ_W + k) * 64 + lane] & 0xFFFFu);
@@ -1596,7 +1640,6 @@ __global__ __launch_bounds__(64, 3) void k_coag_seq(DeviceState st, int ktype_rt
         }
         st.n_events[c] = n_ev;
         st.n_part[c] = st.n_part[c] - n_dead;
-        st.n_samp[c] = tot_samp > 0x7FFFFFFFull ? 0x7FFFFFFF : (int32_t)tot_samp;
         st.n_coag[c] = tot_coag;
         if (status) atomicOr(&st.status[c], status);
     }
@@ -2866,10 +2909,14 @@ int sampler_lanes(const DeviceState &st)
 {
     const char *e = getenv("PMCX_SAMPLER_LANES");
     const bool seq_fits = seq_lds_bytes(st.n_bin, st.n_class) <= 64 * 1024;
-    if (e && atoi(e) == 1 && seq_fits) return 1;
+    if (e && (atoi(e) == 1 || atoi(e) == 2) && seq_fits) return atoi(e);
     if (e && (atoi(e) == 8 || atoi(e) == 16 || atoi(e) == 64)) return atoi(e);
-    // one lane per cell once the cells alone fill the chip (256 CUs x 4 SIMDs x 64 lanes x 2)
-    if (seq_fits && (long)st.n_cells >= 256L * 4L * 64L / 2L) return 1;
+    // one lane per cell once the cells alone fill the chip (256 CUs x 4 SIMDs x 64 lanes); while
+    // its wavefronts would still find a SIMD each even twice as many, the two-wavefront form
+    // (measured, scripts/gpu_split.sh: 1.29 against 1.83 ms at 39 000 cells, 1.57 against 2.12 at
+    // 63 000; at 75 000 a third wavefront lands on some SIMDs and it loses, 2.55 against 2.18)
+    if (seq_fits && (long)st.n_cells > 256L * 4L * 64L) return 1;
+    if (seq_fits && (long)st.n_cells >= 24000L) return 2;
     if (sampler_lds_for(st, 16) > 4 * 1024) return 64;
     // 8 lanes per cell (8 cells per wavefront) is the throughput optimum; with few
     // cells the kernel is one wavefront's latency, which is shortest with more lanes
@@ -3024,6 +3071,21 @@ hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, ui
 {
     const size_t shared = (sizeof(double) * (size_t)(st.n_bin + 1) + 15) & ~(size_t)15;
     const int L = sampler_lanes(st);
+    if (L == 2) { // lane per cell, two wavefronts (evaluator, drawer) per 64 cells
+        const dim3 grid((st.n_cells + 63) / 64), block(128);
+        const size_t lds = seq_lds_bytes(st.n_bin, st.n_class) + SEQ_SHARED_BYTES;
+        const bool simple = st.n_spec == 1 && st.n_class == 1;
+        if (simple && ktype == KERNEL_BROWN)
+            hipLaunchKernelGGL((k_coag_seq<false, true, KERNEL_BROWN, true>), grid, block, lds, s, st,
+                               ktype, del_t, seed, step, st.seq_ovf);
+        else if (ktype == KERNEL_BROWN)
+            hipLaunchKernelGGL((k_coag_seq<false, false, KERNEL_BROWN, true>), grid, block, lds, s, st,
+                               ktype, del_t, seed, step, st.seq_ovf);
+        else
+            hipLaunchKernelGGL((k_coag_seq<false, false, 0, true>), grid, block, lds, s, st, ktype,
+                               del_t, seed, step, st.seq_ovf);
+        return hipGetLastError();
+    }
     if (L == 1) {
         const char *e_st = getenv("PMCX_SEQ_STAMPS");
         const dim3 grid((st.n_cells + 63) / 64), block(64);
