@@ -1671,9 +1671,9 @@ hipError_t seq_stamps_read(uint64_t out[12], bool reset)
 
 // ---------------------------------------------------------------- compaction
 //
-// Removed particles become tombstones (vtot = -1, wclass = -1): slots [0, n_hi) hold
+// Removed particles become tombstones (cached volume -1): slots [0, n_hi) hold
 // n_part live particles in a fixed relative order, and holes are closed by a
-// stable compaction only when more than 1/8 of the slots are dead (or when a
+// stable compaction only when more than 1/compact_den of the slots are dead (or when a
 // caller needs a dense cell).  Because the order of the survivors never
 // changes, when compaction happens cannot change any later result.
 
