@@ -2908,7 +2908,7 @@ size_t sampler_lds_bytes_per_cell(const DeviceState &st)
 int sampler_lanes(const DeviceState &st)
 {
     const char *e = getenv("PMCX_SAMPLER_LANES");
-    const bool seq_fits = seq_lds_bytes(st.n_bin, st.n_class) <= 64 * 1024;
+    const bool seq_fits = seq_lds_bytes(st.n_bin, st.n_class) + SEQ_SHARED_BYTES <= 64 * 1024;
     if (e && (atoi(e) == 1 || atoi(e) == 2) && seq_fits) return atoi(e);
     if (e && (atoi(e) == 8 || atoi(e) == 16 || atoi(e) == 64)) return atoi(e);
     // one lane per cell once the cells alone fill the chip (256 CUs x 4 SIMDs x 64 lanes); while
