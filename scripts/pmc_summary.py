@@ -22,10 +22,13 @@ for k in sorted(out):
 # the sampler's gathers (4 to 16 bytes per lane at independent addresses) are calibrated by
 # scripts/gather_probe.hip: FETCH_SIZE counts 64 B per such load, used raw.
 traffic = {}
-names = {"pmcx::k_bin_sort": ("bin_sort", 2.0), "pmcx::k_coag_sample<8>": ("coag_sample", 1.0),
-         "pmcx::k_coag_seq<false>": ("coag_sample", 1.0), "pmcx::k_coag_seq<false, true, 4>": ("coag_sample", 1.0),
-         "pmcx::k_coag_seq<false, false, 4>": ("coag_sample", 1.0), "pmcx::k_coag_seq<false, false, 0>": ("coag_sample", 1.0),
-         "pmcx::k_rebalance": ("rebalance", 1.0), "pmcx::k_compact": ("compact", 1.0)}
+names = {"pmcx::k_bin_sort": ("bin_sort", 2.0), "pmcx::k_rebalance": ("rebalance", 1.0),
+         "pmcx::k_compact": ("compact", 1.0)}
+# the sampler under whichever template arguments it ran with (the one with the most traffic)
+samplers = [k for k in out if k.startswith("pmcx::k_coag_seq<") or k.startswith("pmcx::k_coag_sample<")]
+samplers = [k for k in samplers if "FETCH_SIZE" in out[k] and "WRITE_SIZE" in out[k]]
+if samplers:
+    names[max(samplers, key=lambda k: out[k]["FETCH_SIZE"])] = ("coag_sample", 1.0)
 for k, (short, f) in names.items():
     if k in out and "FETCH_SIZE" in out[k] and "WRITE_SIZE" in out[k]:
         traffic[short] = {"bytes_per_launch": (out[k]["FETCH_SIZE"] * f + out[k]["WRITE_SIZE"]) * 1024.0,
