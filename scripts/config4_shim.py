@@ -52,6 +52,9 @@ for step in range(n_steps):
     nc = np.frombuffer(out, "<i4", n_cells, off); off += 4 * n_cells
     events += int(nc.sum())
     for c, oc in enumerate(cells):
+        # the shim uploads the Fortran aero_state before every call: caches are recomputed from
+        # the species and the lists are built again (a host-side edit, as in tests/test_gpu_fortran.py)
+        oc.refresh_caches()
         st, ons, onc = oc.mc_coag(kernel, del_t, seed, c, step, const_k, beta)
         ok &= (int(ns[c]), int(nc[c])) == (ons, onc)
 print(json.dumps({"workload": "config 4: 1 column x 30 levels x 10^4 particles, 20 species, Fortran shim (batched)",
