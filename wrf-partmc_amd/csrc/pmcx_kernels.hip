@@ -2204,7 +2204,7 @@ __global__ __launch_bounds__(64) void k_scenario_update(DeviceState st, double d
 // dry_dep_aero_state (interface/wrf_pmc_dep_aero.F90:154-192) on the cells flagged as
 // surface cells: per particle the Zhang (2001) deposition velocity, removal probability
 // (dt / dz) vd, one uniform keyed by the particle's rank among the live ones.  One
-// wavefront per cell; removed particles become tombstones.
+// workgroup of four wavefronts per cell; removed particles become tombstones.
 
 struct DepArgs {
     const int32_t *surface; // [n_cells] non-zero: the cell touches the ground (NULL: every cell)
@@ -2212,13 +2212,15 @@ struct DepArgs {
     int32_t *n_removed, *unrealistic;                                       // [n_cells]
 };
 
-__global__ __launch_bounds__(64) void k_dry_deposition(DeviceState st, DepArgs a, double dt,
-                                                       uint64_t seed, uint32_t step)
+__global__ __launch_bounds__(256) void k_dry_deposition(DeviceState st, DepArgs a, double dt,
+                                                        uint64_t seed, uint32_t step)
 {
-    const int lane = threadIdx.x;
+    __shared__ uint32_t s_live[4];
+    __shared__ int s_nd, s_bad;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int c = blockIdx.x;
-    if (a.surface && !a.surface[c]) {
-        if (lane == 0) { a.n_removed[c] = 0; a.unrealistic[c] = 0; }
+    if (a.surface && !a.surface[c]) { // (the whole workgroup)
+        if (t == 0) { a.n_removed[c] = 0; a.unrealistic[c] = 0; }
         return;
     }
     const int64_t cb = (int64_t)c * st.cap;
@@ -2227,11 +2229,24 @@ __global__ __launch_bounds__(64) void k_dry_deposition(DeviceState st, DepArgs a
     const double ra = a.aer_res_a[c], ustar = a.ustar[c], alpha = a.alpha[c], big_a = a.big_a[c];
     const double rrho = a.inv_density[c], temp = st.temp[c], dt_dz = dt / a.height[c];
     const int n_hi = st.n_hi[c];
-    uint32_t rank0 = 0;
-    int nd = 0, bad = 0;
-    for (int i0 = 0; i0 < n_hi; i0 += 64) {
+    // Each wavefront takes a contiguous quarter of the slots (a multiple of 64).  A particle's
+    // uniform is keyed by its rank among the live ones: the quarters are counted first.
+    const int per = (((n_hi + 3) >> 2) + 63) & ~63;
+    const int lo = min(n_hi, wave * per), hi = min(n_hi, lo + per);
+    uint32_t cnt = 0;
+    for (int i0 = lo; i0 < hi; i0 += 64) {
         const int i = i0 + lane;
-        const bool live = i < n_hi && live_class_c(st, cb, i) >= 0;
+        cnt += (uint32_t)__popcll(__ballot(i < hi && live_class_c(st, cb, i) >= 0));
+    }
+    if (lane == 0) s_live[wave] = cnt;
+    if (t == 0) { s_nd = 0; s_bad = 0; }
+    __syncthreads();
+    uint32_t rank0 = 0;
+    for (int w = 0; w < wave; w++) rank0 += s_live[w];
+    int nd = 0, bad = 0;
+    for (int i0 = lo; i0 < hi; i0 += 64) {
+        const int i = i0 + lane;
+        const bool live = i < hi && live_class_c(st, cb, i) >= 0;
         const uint64_t mlive = __ballot(live);
         bool drop = false;
         if (live) {
@@ -2249,19 +2264,26 @@ __global__ __launch_bounds__(64) void k_dry_deposition(DeviceState st, DepArgs a
         rank0 += (uint32_t)__popcll(mlive);
     }
     bad = __ballot(bad != 0) != 0;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    wave_sync();
     if (lane == 0) {
-        st.n_part[c] = st.n_part[c] - nd;
-        if (nd) st.sort_valid[c] = 0;
-        a.n_removed[c] = nd;
-        a.unrealistic[c] = bad;
+        if (nd) atomicAdd(&s_nd, nd);
+        if (bad) atomicOr(&s_bad, 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __threadfence_block();
-    wave_sync();
-    const int hi = st.n_hi[c], live_n = st.n_part[c];
-    if ((hi - live_n) * st.compact_den > hi) compact_wave(st, c, lane);
+    __syncthreads();
+    if (t == 0) {
+        st.n_part[c] = st.n_part[c] - s_nd;
+        if (s_nd) st.sort_valid[c] = 0;
+        a.n_removed[c] = s_nd;
+        a.unrealistic[c] = s_bad;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __threadfence_block();
+    __syncthreads();
+    if (wave == 0) { // (compaction is one wavefront's work)
+        const int top = st.n_hi[c], live_n = st.n_part[c];
+        if ((top - live_n) * st.compact_den > top) compact_wave(st, c, lane);
+    }
 }
 
 // ---------------------------------------------------------------- transport
@@ -3286,7 +3308,7 @@ hipError_t launch_dry_deposition(const DeviceState &st, double dt, uint64_t seed
     const size_t nc = (size_t)st.n_cells;
     DepArgs a{surface, per_cell6, per_cell6 + nc, per_cell6 + 2 * nc, per_cell6 + 3 * nc,
               per_cell6 + 4 * nc, per_cell6 + 5 * nc, n_removed, unrealistic};
-    hipLaunchKernelGGL(k_dry_deposition, dim3(st.n_cells), dim3(64), 0, s, st, a, dt, seed, step);
+    hipLaunchKernelGGL(k_dry_deposition, dim3(st.n_cells), dim3(256), 0, s, st, a, dt, seed, step);
     return hipGetLastError();
 }
 hipError_t launch_condense(const DeviceState &st, const double *kappa, const double *rel_humid,
