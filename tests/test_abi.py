@@ -65,3 +65,25 @@ def test_code_objects_are_gfx950_only(wp):
     else:
         data = open(so, "rb").read()
         assert b"gfx950" in data and b"gfx942" not in data and b"sm_90" not in data
+
+
+def test_fortran_shim_binds_only_declared_entry_points():
+    """Every bind(c, name=...) of the ISO_C_BINDING shim names a function include/pmcx.h
+    declares, and the bind(c) mirror of pmcx_config lists the header's fields in order."""
+    shim = open(os.path.join(ROOT, "wrf-partmc_amd", "fortran", "pmcx_shim.F90")).read()
+    bound = set(re.findall(r'bind\(c,\s*name="(pmcx_[a-z0-9_]+)"\)', shim))
+    declared = set(_declared_symbols())
+    assert len(bound) >= 20 and bound <= declared, sorted(bound - declared)
+    # the path itself and the rows around it are all reachable from Fortran
+    for name in ("pmcx_mc_coag", "pmcx_rebalance", "pmcx_transport", "pmcx_dry_deposition",
+                 "pmcx_transport_begin", "pmcx_transport_finish", "pmcx_upload_cells",
+                 "pmcx_download_cells"):
+        assert name in bound, name
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "pmcx.h")).read(), flags=re.S)
+    struct = header[header.index("typedef struct {"):header.index("} pmcx_config;")]
+    c_fields = re.findall(r"\b(?:u?int32_t|double)\s+([a-z_0-9, ]+);", struct)
+    c_fields = [f.strip() for grp in c_fields for f in grp.split(",")]
+    f_type = shim[shim.index("type, bind(c) :: pmcx_config"):shim.index("end type pmcx_config")]
+    f_fields = [f.strip() for grp in re.findall(r"::\s*([a-z_0-9, ]+)", f_type.split("\n", 1)[1])
+                for f in grp.split(",")]
+    assert f_fields == c_fields, (f_fields, c_fields)
