@@ -87,3 +87,10 @@ def test_fortran_shim_binds_only_declared_entry_points():
     f_fields = [f.strip() for grp in re.findall(r"::\s*([a-z_0-9, ]+)", f_type.split("\n", 1)[1])
                 for f in grp.split(",")]
     assert f_fields == c_fields, (f_fields, c_fields)
+
+
+def test_integration_notes_cover_every_entry_point():
+    """INTEGRATION.md names the reference interface each C entry point replaces: none is left out."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [s for s in _declared_symbols() if s not in doc]
+    assert not missing, missing
