@@ -970,3 +970,49 @@ def test_kernel_bounds_range_is_flagged_when_outgrown(wp):
             ns, nc, st = blk.mc_coag(K_CONST, 10.0, 1, 0)
             assert (nc > 40).all() and not (st & 3).any()
             assert bool((st & 32).all()) == expect, (margin, st)
+
+
+def test_transport_follows_the_sampling_law(wp):
+    """The stochastic transport on the HIP path against the law of aero_state_multisample +
+    aero_state_sample_particles_by_class (wrf_pmc_trans_aero.F90:2351-2482, 2181-2322), without
+    the oracle in between: a particle leaves towards a neighbour with that neighbour's
+    probability, and arrives there as 1/r copies on average, r = (weight there / (V_from /
+    V_to)) / weight here -- so that the physical number moved is conserved in expectation.
+    A column of two levels with cell volumes 1 and 2, 2048 columns."""
+    nx, nz, ny, n_part = 64, 2, 32, 2000
+    n_cells = nx * nz * ny
+    lev = (np.arange(n_cells) // nx) % nz
+    vol = np.where(lev == 0, 1.0, 2.0)
+    p_up, p_dn, p_h = 0.05, 0.03, 0.01
+    ph = np.full((n_cells, 1, 4), p_h)
+    pv = np.zeros((n_cells, 1, nz))
+    pv[lev == 0, 0, 1] = p_up
+    pv[lev == 1, 0, 0] = p_dn
+    from wrf_partmc_amd.data import idealised_modes
+    with wp.CellBlock(n_cells, 4096, 1) as blk:
+        blk.set_aero_data([1500.0])
+        blk.set_env(280.0, 9e4)
+        blk.set_weights(np.full((n_cells, 1), 1e7))
+        blk.set_next_id((np.arange(n_cells, dtype=np.int64) << 32) + (1 << 24))
+        blk.generate_lognormal(n_part, idealised_modes(1), seed=4)
+        nm, na = blk.transport(nx, nz, ny, ph, pv, vol, seed=4, step=0)
+        n_after = blk.aero_state_total_particles()
+    assert np.array_equal(n_after, n_part - nm + na)
+    n0, n1 = int((lev == 0).sum()), int((lev == 1).sum())
+
+    def close(x, mean, var):
+        assert abs(x - mean) < 5 * np.sqrt(var) + 1e-9, (x, mean, var)
+
+    # movers: binomial, p = the sum of the destination probabilities
+    p0, p1 = 4 * p_h + p_up, 4 * p_h + p_dn
+    close(nm[lev == 0].sum(), n0 * n_part * p0, n0 * n_part * p0 * (1 - p0))
+    close(nm[lev == 1].sum(), n1 * n_part * p1, n1 * n_part * p1 * (1 - p1))
+    # arrivals: same level r = 1 (one copy each); going up r = 2 (a copy with probability 1/2);
+    # coming down r = 1/2 (1 + geometric: two copies on average, variance 2 per mover)
+    up, dn = n0 * n_part * p_up, n1 * n_part * p_dn
+    close(na[lev == 1].sum(), n1 * n_part * 4 * p_h + up / 2, n1 * n_part * 4 * p_h + up * 0.5 * 0.5 + up * 0.25)
+    close(na[lev == 0].sum(), n0 * n_part * 4 * p_h + dn * 2, n0 * n_part * 4 * p_h + dn * 2 + dn * 4)
+    # physical number (count x weight x volume) is conserved in expectation
+    phys0 = n_part * (n0 * 1.0 + n1 * 2.0)
+    phys1 = float((n_after * vol).sum())
+    assert abs(phys1 - phys0) < 5 * np.sqrt(dn * 2 * 1.0 + up * 0.25 * 4.0) + 1e-9
