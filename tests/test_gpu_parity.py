@@ -1016,3 +1016,34 @@ def test_transport_follows_the_sampling_law(wp):
     phys0 = n_part * (n0 * 1.0 + n1 * 2.0)
     phys1 = float((n_after * vol).sum())
     assert abs(phys1 - phys0) < 5 * np.sqrt(dn * 2 * 1.0 + up * 0.25 * 4.0) + 1e-9
+
+
+def test_dry_deposition_follows_zhang_2001(wp):
+    """Dry deposition on the HIP path against an independent numpy transcription of the in-tree
+    scheme (wrf_pmc_dep_aero.F90:265-420; tests/test_oracle.py::_dep_velocity_numpy), without the
+    oracle in between: over 2048 surface cells the number removed is the sum of the particles'
+    probabilities (dt / dz) vd within the binomial error, and nothing leaves the other cells."""
+    from tests.test_oracle import _dep_velocity_numpy
+    from wrf_partmc_amd.data import idealised_modes
+    n_cells, n_part = 4096, 1500
+    surface = (np.arange(n_cells) % 2 == 0).astype(np.int32)
+    dt, dz, ra, us, alpha, big_a, rrho, temp, rho = 60.0, 50.0, 40.0, 0.4, 1.2, 0.002, 1 / 1.2, 285.0, 1800.0
+    with wp.CellBlock(n_cells, 1536, 1) as blk:
+        blk.set_aero_data([rho])
+        blk.set_env(temp, 1e5)
+        blk.set_weights(np.full((n_cells, 1), 1e6))
+        blk.set_next_id(np.arange(n_cells, dtype=np.int64) << 32)
+        blk.generate_lognormal(n_part, idealised_modes(1), seed=6)
+        d0 = blk.download_cells()
+        nr, bad = blk.dry_deposition(dt, ra, us, alpha, big_a, dz, rrho, seed=6, step=0, surface=surface)
+        n_after = blk.aero_state_total_particles()
+    assert not bad.any() and (nr[surface == 0] == 0).all()
+    assert np.array_equal(n_after, n_part - nr)
+    v = d0["vol"][0].reshape(n_cells, n_part)[surface == 1]
+    diam = 2 * np.cbrt(v * 0.75 / np.pi)
+    prob = dt / dz * _dep_velocity_numpy(diam, rho, temp, rrho, us, ra, alpha, big_a)
+    assert 0.0 < prob.min() and prob.max() < 1.0 and prob.sum() > 1000
+    assert abs(nr.sum() - prob.sum()) < 5 * np.sqrt((prob * (1 - prob)).sum())
+    # and cell by cell
+    z = (nr[surface == 1] - prob.sum(axis=1)) / np.sqrt((prob * (1 - prob)).sum(axis=1))
+    assert abs(z.mean()) < 5 / np.sqrt(len(z)) and 0.8 < z.std() < 1.2
