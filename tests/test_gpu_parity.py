@@ -1047,3 +1047,46 @@ def test_dry_deposition_follows_zhang_2001(wp):
     # and cell by cell
     z = (nr[surface == 1] - prob.sum(axis=1)) / np.sqrt((prob * (1 - prob)).sum(axis=1))
     assert abs(z.mean()) < 5 / np.sqrt(len(z)) and 0.8 < z.std() < 1.2
+
+
+def test_emission_and_dilution_follow_their_laws(wp):
+    """scenario_update_aero_state on the HIP path against the laws it samples,
+    without the oracle in between: emitted particles Poisson(rate dt / weight) per cell with
+    log-normal radii, dilution loss binomial with p = 1 - exp(-lambda dt), background gain
+    Poisson(conc p / weight); 4096 cells."""
+    from wrf_partmc_amd.data import idealised_modes
+    n_cells, n_part, mag, dt = 4096, 1000, 2.0e6, 30.0
+    rate, lam, bg = 4.0e6, 2.0e-3, 5.0e8                   # m^-3 s^-1, s^-1, m^-3
+    emis = [dict(gm_radius=5e-8, gsd_log10=0.2, vol_frac=[1.0], wclass=0, source=0)]
+    back = [dict(gm_radius=1e-7, gsd_log10=0.1, vol_frac=[1.0], wclass=0, source=0)]
+    with wp.CellBlock(n_cells, 2048, 1) as blk:
+        blk.set_aero_data([1500.0])
+        blk.set_env(285.0, 1e5)
+        blk.set_weights(np.full((n_cells, 1), mag))
+        blk.set_next_id((np.arange(n_cells, dtype=np.int64) << 32) + (1 << 24))
+        blk.generate_lognormal(n_part, idealised_modes(1), seed=8)
+        ids0 = set(blk.download_cells()["id"].tolist())
+        ne, ni, no = blk.scenario_update_aero_state(dt, 0.0, seed=8, step=0, emission=emis,
+                                                    emission_rate=rate, dilution_rate=lam,
+                                                    background=back, background_conc=bg)
+        d = blk.download_cells()
+        n_after = blk.aero_state_total_particles()
+    assert np.array_equal(n_after, n_part + ne + ni - no)
+    p = 1.0 - np.exp(-lam * dt)
+    n_at_loss = n_part + rate * dt / mag     # the order is emission, loss, gain (DESIGN.md 3.4)
+    for x, mean, var in ((ne, rate * dt / mag, rate * dt / mag), (ni, bg * p / mag, bg * p / mag),
+                         (no, n_at_loss * p, n_at_loss * p * (1 - p) + rate * dt / mag * p * p)):
+        assert abs(x.mean() - mean) < 5 * np.sqrt(var / n_cells), (x.mean(), mean)
+        assert 0.9 * var < x.var() < 1.1 * var, (x.var(), var)
+    # the new particles: radii log-normal about the modes' geometric means
+    new = np.array([i not in ids0 for i in d["id"].tolist()])
+    r = np.cbrt(d["vol"][0][new] * 0.75 / np.pi)
+    # (emitted particles are exposed to the loss of the same call, background ones are not)
+    n_e, n_b = ne.sum() * (1 - p), ni.sum()
+    assert abs(new.sum() - (n_e + n_b)) < 5 * np.sqrt(ne.sum() * p * (1 - p))
+    lr = np.log10(r)
+    mix_mean = (n_e * np.log10(5e-8) + n_b * np.log10(1e-7)) / (n_e + n_b)
+    assert abs(lr.mean() - mix_mean) < 0.005
+    w_e, w_b = n_e / (n_e + n_b), n_b / (n_e + n_b)
+    mix_var = w_e * (0.2 ** 2 + np.log10(5e-8) ** 2) + w_b * (0.1 ** 2 + np.log10(1e-7) ** 2) - mix_mean ** 2
+    assert abs(lr.std() - np.sqrt(mix_var)) < 0.005
