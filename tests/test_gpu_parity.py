@@ -1090,3 +1090,40 @@ def test_emission_and_dilution_follow_their_laws(wp):
     w_e, w_b = n_e / (n_e + n_b), n_b / (n_e + n_b)
     mix_var = w_e * (0.2 ** 2 + np.log10(5e-8) ** 2) + w_b * (0.1 ** 2 + np.log10(1e-7) ** 2) - mix_mean ** 2
     assert abs(lr.std() - np.sqrt(mix_var)) < 0.005
+
+
+def test_rebalance_follows_its_law(wp):
+    """aero_state_rebalance on the HIP path against what it must do (driver:248-250), without the
+    oracle in between: above twice the ideal count every particle is dropped with probability
+    1/2 and the weight doubles (number concentration conserved in expectation, binomial
+    spread); below half the ideal count every particle is copied and the weight halves
+    (conserved exactly, new ids unique)."""
+    from wrf_partmc_amd.data import idealised_modes
+    n_cells, ideal, mag = 2048, 1000.0, 3.0e6
+    with wp.CellBlock(n_cells, 2176, 1) as blk:
+        blk.set_aero_data([1500.0])
+        blk.set_env(285.0, 1e5)
+        blk.set_weights(np.full((n_cells, 1), mag))
+        blk.set_n_part_ideal(np.full((n_cells, 1), ideal))
+        blk.set_next_id((np.arange(n_cells, dtype=np.int64) << 32) + (1 << 24))
+        blk.generate_lognormal(2100, idealised_modes(1), seed=9)
+        blk.aero_state_rebalance(True, True, 9, 0)
+        n = blk.aero_state_total_particles()
+        w = blk.get_weights()[:, 0]
+        assert (w == 2 * mag).all()
+        assert abs(n.mean() - 1050.0) < 5 * np.sqrt(525.0 / n_cells) and 0.9 * 525 < n.var() < 1.1 * 525
+        assert abs((n * w).mean() - 2100 * mag) < 5 * 2 * mag * np.sqrt(525.0 / n_cells)
+    with wp.CellBlock(n_cells, 1024, 1) as blk:
+        blk.set_aero_data([1500.0])
+        blk.set_env(285.0, 1e5)
+        blk.set_weights(np.full((n_cells, 1), mag))
+        blk.set_n_part_ideal(np.full((n_cells, 1), ideal))
+        blk.set_next_id((np.arange(n_cells, dtype=np.int64) << 32) + (1 << 24))
+        blk.generate_lognormal(400, idealised_modes(1), seed=9)
+        v0 = np.sort(blk.download_cells()["vol"][0])
+        blk.aero_state_rebalance(True, True, 9, 0)
+        d = blk.download_cells()
+        assert (blk.aero_state_total_particles() == 800).all()
+        assert (blk.get_weights()[:, 0] == mag / 2).all()
+        assert len(np.unique(d["id"])) == 800 * n_cells
+        assert np.array_equal(np.sort(d["vol"][0]), np.repeat(v0, 2))
