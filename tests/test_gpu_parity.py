@@ -1127,3 +1127,37 @@ def test_rebalance_follows_its_law(wp):
         assert (blk.get_weights()[:, 0] == mag / 2).all()
         assert len(np.unique(d["id"])) == 800 * n_cells
         assert np.array_equal(np.sort(d["vol"][0]), np.repeat(v0, 2))
+
+
+def test_brownian_rate_of_a_monodisperse_population(wp):
+    """mc_coag with the Brownian kernel on the HIP path against the in-tree Fuchs form
+    (WRFV3/chem/module_mosaic_coag.F:746-757,898-936, transcribed independently in
+    tests/test_oracle.py::fuchs_cgs), without the oracle in between: a population of equal
+    particles coagulates at K(d, d) N^2 / 2, i.e. K mag n (n - 1) / 2 dt events per cell
+    while few have merged; 4096 cells, two sizes, two environments."""
+    from tests.test_oracle import fuchs_cgs
+    n_cells, n_part, rho = 2048, 4096, 1500.0
+    for diam, T, p, mag, dt in ((4.0e-8, 288.15, 101325.0, 1.0e7, 120.0),
+                                (1.0e-6, 230.0, 30000.0, 6.0e6, 900.0)):
+        K = fuchs_cgs(diam * 50, diam * 50, rho * 1e-3, rho * 1e-3, T, p / 101325.0,
+                      slip=(1.249, 0.42, 0.87)) * 1e-6
+        expect = K * mag * n_part * (n_part - 1) / 2 * dt
+        assert 5.0 < expect < 0.03 * n_part, expect         # enough events, population still equal
+        with wp.CellBlock(n_cells, n_part, 1) as blk:
+            blk.set_aero_data([rho])
+            blk.set_env(T, p)
+            blk.set_weights(np.full((n_cells, 1), mag))
+            blk.set_next_id(np.arange(n_cells, dtype=np.int64) << 32)
+            v = np.full((1, n_cells * n_part), np.pi / 6 * diam ** 3)
+            blk.upload_cells(0, np.arange(n_cells + 1, dtype=np.int64) * n_part, v,
+                             np.zeros(n_cells * n_part, np.int32),
+                             np.arange(n_cells * n_part, dtype=np.int64),
+                             np.zeros(n_cells * n_part), np.zeros(n_cells * n_part))
+            ns, nc, st = blk.mc_coag(K_BROWN, dt, 13, 0)
+        assert not st.any()
+        # (the sweep reaches the slot of the merged particles after the one that made them, so
+        # they get the step's chance to merge again: a second-order surplus of ~2 expect^2 / n)
+        surplus = 2.0 * expect * expect / n_part
+        assert -5 * np.sqrt(expect / n_cells) - 0.005 * expect < nc.mean() - expect < \
+            5 * np.sqrt(expect / n_cells) + 1.5 * surplus + 0.005 * expect, (nc.mean(), expect, surplus)
+        assert 0.85 * expect < nc.var() < 1.15 * expect
