@@ -1161,3 +1161,36 @@ def test_brownian_rate_of_a_monodisperse_population(wp):
         assert -5 * np.sqrt(expect / n_cells) - 0.005 * expect < nc.mean() - expect < \
             5 * np.sqrt(expect / n_cells) + 1.5 * surplus + 0.005 * expect, (nc.mean(), expect, surplus)
         assert 0.85 * expect < nc.var() < 1.15 * expect
+
+
+def test_condensation_extension_reaches_koehler_equilibrium(wp):
+    """The condensation sub-step (labelled extension) on the HIP path against the kappa-Koehler
+    equation itself, without the oracle in between: after a long step at fixed relative humidity
+    every particle's water satisfies a_w exp(A / D) = RH, the dry species are untouched, and a
+    particle without hygroscopic material takes no water."""
+    n_cells, n_part, T = 512, 2000, 288.15
+    dens, kappa = np.array([1770.0, 1700.0, 1000.0]), np.array([0.65, 0.0, 0.0])
+    modes = [dict(frac=0.9, gm_radius=5e-8, gsd_log10=0.4, vol_frac=[0.7, 0.3, 0.0]),
+             dict(frac=0.1, gm_radius=5e-8, gsd_log10=0.2, vol_frac=[0.0, 1.0, 0.0])]
+    A = 4 * 0.073 * 18e-3 / (8.314472 * T * 1000.0)
+    with wp.CellBlock(n_cells, 2048, 3, i_water=2) as blk:
+        blk.set_aero_data(dens, kappa=kappa)
+        blk.set_weights(np.full((n_cells, 1), 1e6))
+        blk.set_next_id(np.arange(n_cells, dtype=np.int64) << 32)
+        blk.set_env(T, 101325.0, 0.5)
+        blk.generate_lognormal(n_part, modes, seed=14)
+        dry = blk.download_cells()["vol"][:2].copy()
+        for rh in (0.5, 0.9, 0.3):
+            blk.set_env(T, 101325.0, rh)
+            blk.condense(600.0, 4)
+            v = blk.download_cells()["vol"]
+            assert np.array_equal(v[:2], dry)
+            vd = dry.sum(0)
+            hygro = dry[0] > 0
+            assert not v[2][~hygro].any() and (~hygro).sum() > 0.05 * n_cells * n_part
+            d3, dd3 = (vd + v[2])[hygro] * 6 / np.pi, vd[hygro] * 6 / np.pi
+            keff = 0.65 * dry[0][hygro] / vd[hygro]
+            s_eq = (d3 - dd3) / (d3 - dd3 * (1 - keff)) * np.exp(A / np.cbrt(d3))
+            err = np.abs(s_eq / rh - 1.0)
+            # (the very largest of the 10^6 particles are still up to 1e-3 short of equilibrium after 600 s)
+            assert np.quantile(err, 0.999) < 2e-6 and err.max() < 2e-3, (np.quantile(err, 0.999), err.max())
