@@ -1194,3 +1194,50 @@ def test_condensation_extension_reaches_koehler_equilibrium(wp):
             err = np.abs(s_eq / rh - 1.0)
             # (the very largest of the 10^6 particles are still up to 1e-3 short of equilibrium after 600 s)
             assert np.quantile(err, 0.999) < 2e-6 and err.max() < 2e-3, (np.quantile(err, 0.999), err.max())
+
+
+def test_diagnostics_against_numpy(wp):
+    """The partmc_process observables (driver:783,838-857, 858-932, 1153-1157) on the HIP path
+    recomputed with numpy from the downloaded particles, without the oracle in between: number
+    quantities exact, mass quantities to 1e-12, on a log-spaced grid of 100 diameter bins
+    between 1e-9 and 1e-3 m; after a coagulation step that leaves tombstones in the slabs."""
+    from wrf_partmc_amd.data import idealised_modes
+    n_cells, n_part = 64, 3000
+    dens = np.array([1770.0, 1000.0, 2600.0])
+    modes = [dict(frac=0.6, gm_radius=3e-8, gsd_log10=0.3, vol_frac=[0.5, 0.2, 0.3], wclass=0, source=0),
+             dict(frac=0.4, gm_radius=4e-7, gsd_log10=0.2, vol_frac=[0.1, 0.0, 0.9], wclass=1, source=1)]
+    with wp.CellBlock(n_cells, 3072, 3, n_class=2, n_source=2, i_water=1, compact_den=64) as blk:
+        blk.set_aero_data(dens)
+        blk.set_env(285.0, 9e4)
+        mag = np.array([1e6, 3e4])
+        blk.set_weights(np.tile(mag, (n_cells, 1)))
+        blk.set_next_id(np.arange(n_cells, dtype=np.int64) << 32)
+        blk.generate_lognormal(n_part, modes, seed=15)
+        ns, nc, st = blk.mc_coag(K_BROWN, 1800.0, 15, 0)
+        assert nc.sum() > 500 and not (st & 3).any()
+        tn, tm, nd_, md_ = blk.diagnostics()
+        sm, sn, pm, npart = blk.diagnostics_ext()
+        de, dw = blk.diag_grid()
+        d = blk.download_cells()
+    assert np.allclose(de, np.logspace(-9, -3, 101), rtol=1e-12)
+    assert np.allclose(dw, np.log(de[1]) - np.log(de[0]), rtol=1e-9)
+    po = d["part_offset"]
+    for c in range(n_cells):
+        sl = slice(po[c], po[c + 1])
+        v, cl = d["vol"][:, sl], d["wclass"][sl]
+        w = mag[cl]
+        assert npart[c] == po[c + 1] - po[c]
+        assert tn[c] == w.sum() or abs(tn[c] - w.sum()) <= 1e-12 * w.sum()
+        mass = (v * dens[:, None]).sum(0)
+        assert abs(tm[c] - (mass * w).sum()) <= 1e-12 * tm[c]
+        dry = v[0] + v[2]                                          # species 1 is water
+        diam = np.cbrt(dry * 6 / np.pi)
+        b = np.searchsorted(de, diam, side="right") - 1
+        ok = (b >= 0) & (b < 100)
+        num = np.bincount(b[ok], weights=w[ok], minlength=100) / dw
+        ms = np.bincount(b[ok], weights=(w * mass)[ok], minlength=100) / dw
+        assert np.allclose(nd_[c], num, rtol=1e-12, atol=0)
+        assert np.allclose(md_[c], ms, rtol=1e-11, atol=1e-30)
+        assert np.allclose(sm[c], (v * dens[:, None] * w).sum(1), rtol=1e-12)
+        src = d["n_orig"][:, sl]        # a particle counts once for every source it contains
+        assert np.allclose(sn[c], ((src > 0) * w).sum(1), rtol=1e-12)
