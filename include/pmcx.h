@@ -407,6 +407,9 @@ int pmcx_profile_phase_cycles(pmcx_ctx *ctx, uint64_t out[12], int32_t reset);
 
 /* device memory held by the context, bytes (replaces memtrack, interface/mem.c) */
 int pmcx_memory_bytes(pmcx_ctx *ctx, int64_t *bytes);
+/* free and total memory of a HIP device, bytes (no context needed: sizes a block of cells
+ * before pmcx_create; 0 on success, PMCX_EDEVICE otherwise) */
+int pmcx_device_memory_info(int32_t device, int64_t *free_bytes, int64_t *total_bytes);
 
 #ifdef __cplusplus
 }

@@ -22,6 +22,7 @@ from .host import (  # noqa: F401
     PmcxAeroDist,
     PmcxStepFlags,
     build_library,
+    device_memory_info,
     library_path,
     load_library,
     EXPORTED_SYMBOLS,

@@ -389,6 +389,16 @@ int pmcx_memory_bytes(pmcx_ctx *ctx, int64_t *bytes)
     return PMCX_OK;
 }
 
+int pmcx_device_memory_info(int32_t device, int64_t *free_bytes, int64_t *total_bytes)
+{
+    size_t f = 0, t = 0;
+    if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&f, &t) != hipSuccess)
+        return fail(nullptr, PMCX_EDEVICE, "pmcx_device_memory_info: no HIP device %d", device);
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
+    return PMCX_OK;
+}
+
 int pmcx_set_aero_data(pmcx_ctx *ctx, const double *density, const double *kappa,
                        const double *molec_weight)
 {

@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "pmcx_transport_begin", "pmcx_transport_export_size", "pmcx_transport_export",
     "pmcx_transport_import", "pmcx_transport_finish", "pmcx_device_alloc", "pmcx_device_free",
     "pmcx_device_copy",
-    "pmcx_memory_bytes",
+    "pmcx_memory_bytes", "pmcx_device_memory_info",
 ]
 
 
@@ -153,6 +153,15 @@ def _ptr(a):
 
 def _f64(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+def device_memory_info(device=0):
+    """(free, total) bytes of a HIP device, through the library (no torch involved)."""
+    L = load_library()
+    f, t = C.c_int64(), C.c_int64()
+    if L.pmcx_device_memory_info(int(device), C.byref(f), C.byref(t)) != 0:
+        raise PmcxError(L.pmcx_last_error(None).decode())
+    return f.value, t.value
 
 
 class DeviceBuffer:
