@@ -338,10 +338,46 @@ int pmcx_generate_lognormal(pmcx_ctx *ctx, int32_t n_part, int32_t n_mode,
                             const int32_t *mode_class, const int32_t *mode_source,
                             uint64_t seed, double create_time);
 
-/* One partmc_timestep loop body over all cells (wrf_pmc_driver.F90:169-254):
- * coagulation when do_coagulation and the chemistry-step gate holds
- * (driver:189-198), then rebalance (driver:248-250).  Emission, sea salt
- * and MOSAIC are outside this library. */
+/* gas_state_t%mix_rat(:) [ppb] of every cell (wrf_pmc_driver.F90:1698,1726-1762):
+ * [n_cells][n_gas].  The first call fixes n_gas (gas_data_n_spec: 77 in the reference's
+ * gas_data.dat, wrf_pmc_init.F90:1492); later calls must repeat it. */
+int pmcx_set_gas_state(pmcx_ctx *ctx, int32_t n_gas, const double *mix_rat);
+int pmcx_get_gas_state(pmcx_ctx *ctx, double *mix_rat);
+
+/* The gas half of scenario_t as the interface fills it (wrf_pmc_init.F90:646-657, 718-720,
+ * 789-791, 901-919), kept on the device:
+ *   gas_emission_time [n_time_e], gas_emission_rate_scale [n_time_e],
+ *   gas_emission [n_cells][n_time_e][n_gas]            mol m^-2 s^-1
+ *   gas_dilution_time [n_time_d], gas_dilution_rate [n_cells][n_time_d]   1/s
+ *   gas_background [n_cells][n_time_d][n_gas]          ppb
+ * n_time_e = 0: no emissions; n_time_d = 0: no dilution (the arrays of that half may be NULL).
+ * Needs pmcx_set_gas_state first (n_gas). */
+int pmcx_set_gas_scenario(pmcx_ctx *ctx, int32_t n_time_e, const double *emission_time,
+                          const double *emission_rate_scale, const double *emission,
+                          int32_t n_time_d, const double *dilution_time,
+                          const double *dilution_rate, const double *background);
+
+/* scenario_update_gas_state on every cell (wrf_pmc_driver.F90:202-205): the scenario's series
+ * interpolated at elapsed_time (constant outside their range, linear inside); emissions
+ * converted to ppb with the cell's air molar density p / (R T) (pmcx_set_env) and added with
+ * the factor rate_scale dt / height; dilution towards the background with
+ * p = exp(-rate dt), times old_height / height where the layer grew.  height [n_cells] =
+ * env_state%height, old_height = old_env_state%height (NULL: unchanged).  Asynchronous. */
+int pmcx_scenario_update_gas_state(pmcx_ctx *ctx, double dt, double elapsed_time,
+                                   const double *height, const double *old_height);
+
+/* Global id of local cell 0 (the RNG key, pmcx_config.cell_id_base) of an existing context:
+ * what a per-cell caller changes between cells instead of rebuilding the context. */
+int pmcx_set_cell_id_base(pmcx_ctx *ctx, uint32_t cell_id_base);
+
+/* One partmc_timestep loop body over all cells (wrf_pmc_driver.F90:169-254), in the
+ * reference's order:
+ *   mc_coag when do_coagulation and mod(elapsed_time, partmc_chem_dt) == 0     driver:189-198
+ *   scenario_update_gas_state (when a gas scenario is resident and height given) driver:202-205
+ *   scenario_update_aero_state (when any of the three aerosol inputs is given)  driver:207-210
+ *   aero_state_rebalance                                                        driver:248-250
+ * Sea salt (driver:212-223) and MOSAIC (driver:232-245) are outside this library.  RNG step
+ * index: chemistry-step count for mc_coag, WRF-step count (elapsed_time / dt) for the rest. */
 typedef struct {
     int32_t do_coagulation;  /* grid%do_coagulation                       */
     int32_t allow_doubling;  /* grid%allow_doubling                       */
@@ -351,6 +387,12 @@ typedef struct {
     double partmc_chem_dt;   /* grid%partmc_chem_dt                       */
     double elapsed_time;     /* env_state%elapsed_time at this call       */
     uint64_t random_seed;    /* grid%random_seed                          */
+    /* scenario(i,k,j) at this step; NULL = nothing of that kind */
+    const double *height;                  /* env_state%height [n_cells]: enables the gas update */
+    const double *old_height;              /* old_env_state%height [n_cells] or NULL             */
+    const pmcx_aero_dist *aero_emission;   /* as pmcx_scenario_update_aero_state                 */
+    const double *aero_dilution_rate;      /* [n_cells]                                          */
+    const pmcx_aero_dist *aero_background;
 } pmcx_step_flags;
 
 int pmcx_timestep(pmcx_ctx *ctx, const pmcx_step_flags *flags);

@@ -877,6 +877,37 @@ int pmco_scenario_update(pmco_cell *c, double dt, double create_time, uint64_t s
 }
 
 /* ------------------------------------------------------------------------
+ * scenario_update_gas_state of one cell (pmco.h).  [UPSTREAM-UNCITED]
+ * ---------------------------------------------------------------------- */
+double pmco_interp_1d(int n, const double *x, const double *y, int y_stride, double xq)
+{
+    if (n <= 1 || xq <= x[0]) return y[0];
+    if (xq >= x[n - 1]) return y[(size_t)(n - 1) * y_stride];
+    int p = 0;
+    while (p < n - 2 && xq >= x[p + 1]) p++;
+    const double alpha = (xq - x[p]) / (x[p + 1] - x[p]);
+    return (1.0 - alpha) * y[(size_t)p * y_stride] + alpha * y[(size_t)(p + 1) * y_stride];
+}
+
+void pmco_scenario_update_gas(int n_gas, double *mix_rat, double dt, double temp, double pressure,
+                              double height, double old_height, const double *emission,
+                              double emission_rate_scale, const double *background,
+                              double dilution_rate)
+{
+    const double air_molar_den = pressure / (8.314472 * temp); /* env_state_air_molar_den */
+    const double p_emit = emission_rate_scale * dt / height;
+    double p = pmco_exp(-dilution_rate * dt);
+    if (height > old_height) p = p * old_height / height;
+    for (int g = 0; g < n_gas; g++) {
+        double x = mix_rat[g];
+        if (emission) x = x + p_emit * (emission[g] / air_molar_den * 1e9);
+        x = x * p;
+        if (background) x = x + background[g] * (1.0 - p);
+        mix_rat[g] = x < 0.0 ? 0.0 : x;
+    }
+}
+
+/* ------------------------------------------------------------------------
  * Dry deposition of one (surface) cell: dry_dep_aero_state
  * (interface/wrf_pmc_dep_aero.F90:154-192): deposition velocity of every
  * particle (compute_dep_vel :196-234, diameter and density of the whole

@@ -192,6 +192,23 @@ int pmco_scenario_update(pmco_cell *c, double dt, double create_time, uint64_t s
                          int64_t *next_id, int32_t *n_emit, int32_t *n_dil_in,
                          int32_t *n_dil_out);
 
+/* scenario_update_gas_state (call: wrf_pmc_driver.F90:202-205) for one cell: the gas phase
+ * gas_state%mix_rat(:) [ppb] gains the emissions and is diluted towards the background
+ * [UPSTREAM-UNCITED: PartMC scenario.F90; restated from the published model description,
+ * Riemer et al. 2009 eq. 5-6, and the scenario fields the interface fills,
+ * wrf_pmc_init.F90:641-657,718-720,789-791,901-919]:
+ *   emission [mol m^-2 s^-1] -> ppb: / (p / (R T)) * 1e9, added with the factor
+ *       emission_rate_scale * dt / height;
+ *   p = exp(-dilution_rate * dt), times old_height / height when the layer grew;
+ *   mix_rat = mix_rat * p + background * (1 - p), clipped at zero.
+ * The scenario's time series are interpolated first (pmco_interp_1d: constant before the
+ * first and after the last point, linear in between). */
+double pmco_interp_1d(int n, const double *x, const double *y, int y_stride, double xq);
+void pmco_scenario_update_gas(int n_gas, double *mix_rat, double dt, double temp, double pressure,
+                              double height, double old_height, const double *emission,
+                              double emission_rate_scale, const double *background,
+                              double dilution_rate);
+
 /* Stochastic particle transport between the cells of a block:
  * aero_state_multisample + aero_state_sample_particles_by_class
  * (interface/wrf_pmc_trans_aero.F90:2351-2482, 2181-2322), per-particle form.

@@ -284,6 +284,38 @@ class Cell:
         return fr, lg, ls, vf, mc, msrc
 
 
+def interp_1d(x, y, xq):
+    """pmco_interp_1d on a time series y[n] (or y[n][m], every column)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    f = lib().pmco_interp_1d
+    f.restype = C.c_double
+    f.argtypes = [C.c_int, _dp, _dp, C.c_int, C.c_double]
+    if y.ndim == 1:
+        return f(len(x), _p(x, _dp), _p(y, _dp), 1, xq)
+    m = y.shape[1]
+    out = np.zeros(m)
+    for j in range(m):
+        col = y[:, j:].reshape(-1)
+        out[j] = f(len(x), _p(x, _dp), C.cast(C.c_void_p(y.ctypes.data + 8 * j), _dp), m, xq)
+    return out
+
+
+def scenario_update_gas(mix_rat, dt, temp, pressure, height, old_height, emission,
+                        emission_rate_scale, background, dilution_rate):
+    """pmco_scenario_update_gas on one cell's mix_rat [n_gas] (in place; returns it)."""
+    mr = np.ascontiguousarray(mix_rat, dtype=np.float64)
+    em = None if emission is None else np.ascontiguousarray(emission, dtype=np.float64)
+    bg = None if background is None else np.ascontiguousarray(background, dtype=np.float64)
+    f = lib().pmco_scenario_update_gas
+    f.restype = None
+    f.argtypes = [C.c_int, _dp] + [C.c_double] * 5 + [_dp, C.c_double, _dp, C.c_double]
+    f(len(mr), _p(mr, _dp), dt, temp, pressure, height, old_height,
+      None if em is None else _p(em, _dp), emission_rate_scale,
+      None if bg is None else _p(bg, _dp), dilution_rate)
+    return mr
+
+
 def sort(cell):
     """aero_state_sort of one Cell; returns the status bits."""
     st = C.c_int(0)

@@ -37,6 +37,8 @@ def test_fortran_shim_matches_oracle(tmp_path, wp, oracle, mode):
         max_events, max_appends = blk.cfg.max_events, blk.cfg.max_appends
     modes, num_conc = parity.make_modes(n_spec, n_class)
     cells = []
+    # ideal counts that make the first rebalance halve every class (n > 2 n_ideal)
+    n_ideal = np.full(n_class, 0.45 * n_part / n_class)
     buf = struct.pack("<7i", n_cells, n_part, n_spec, n_class, n_source, kernel, n_steps)
     buf += struct.pack("<q", seed) + struct.pack("<d", del_t) + dens.astype("<f8").tobytes()
     for c in range(n_cells):
@@ -47,7 +49,7 @@ def test_fortran_shim_matches_oracle(tmp_path, wp, oracle, mode):
         oc.generate(modes, n_part, seed, c, first_id=c << 32, create_time=float(c))
         oc.kmax[:] = oracle.kmax_table(kernel, vs, dens.min(), dens.max(), T, p, const_k, beta)
         cells.append(oc)
-        buf += struct.pack("<2d", T, p) + oc.mag.astype("<f8").tobytes()
+        buf += struct.pack("<2d", T, p) + oc.mag.astype("<f8").tobytes() + n_ideal.astype("<f8").tobytes()
         for i in range(n_part):
             buf += oc.vol[:, i].astype("<f8").tobytes() + oc.n_orig[:, i].astype("<i4").tobytes()
             buf += struct.pack("<i", int(oc.wclass[i]) + 1) + struct.pack("<q", int(oc.id[i]))
@@ -59,6 +61,8 @@ def test_fortran_shim_matches_oracle(tmp_path, wp, oracle, mode):
     assert r.returncode == 0, r.stdout + r.stderr
     out = fout.read_bytes()
     off = 0
+    merged = [set() for _ in cells]          # ids whose composition a coagulation changed
+    halved = 0
     for step in range(n_steps):
         ns = np.frombuffer(out, "<i4", n_cells, off); off += 4 * n_cells
         nc = np.frombuffer(out, "<i4", n_cells, off); off += 4 * n_cells
@@ -66,19 +70,52 @@ def test_fortran_shim_matches_oracle(tmp_path, wp, oracle, mode):
             # the shim uploads the Fortran aero_state before every call: caches are
             # recomputed from the species and the sort is not valid (a host-side edit)
             oc.refresh_caches()
+            oc.sort_valid[0] = 0
+            n0 = int(oc.n_part[0])
+            before = dict(zip(oc.id[:n0].tolist(), oc.vol[:, :n0].T.tolist()))
             st, ons, onc = oc.mc_coag(kernel, del_t, seed, c, step, const_k, beta)
             assert (int(ns[c]), int(nc[c])) == (ons, onc), (step, c)
-    rec = 8 * n_spec + 4 * n_source + 4 + 8 + 16
+            n1 = int(oc.n_part[0])
+            for pid, v in zip(oc.id[:n1].tolist(), oc.vol[:, :n1].T.tolist()):
+                if before[pid] != v:
+                    merged[c].add(pid)
+            # aero_state_rebalance_pmcx: upload (with n_part_ideal), rebalance, download
+            oc.refresh_caches()
+            oc.sort_valid[0] = 0
+            oc.rebalance(n_ideal, True, True, seed, c, step, 1)
+            halved += n1 - int(oc.n_part[0])
+    assert halved > 0 and all(merged)
+    rec = 8 * n_spec + 4 * n_source + 4 + 8 + 16 + 4 + 8 + 8 + 4 + 16
     for c, oc in enumerate(cells):
         n = int(np.frombuffer(out, "<i4", 1, off)[0]); off += 4
         assert n == int(oc.n_part[0])
         blob = np.frombuffer(out, np.uint8, rec * n, off).reshape(n, rec); off += rec * n
-        vol = blob[:, :8 * n_spec].copy().view("<f8")
-        ids = blob[:, 8 * n_spec + 4 * n_source + 4:8 * n_spec + 4 * n_source + 12].copy().view("<i8")[:, 0]
-        cls = blob[:, 8 * n_spec + 4 * n_source:8 * n_spec + 4 * n_source + 4].copy().view("<i4")[:, 0]
+        o = 8 * n_spec
+        vol = blob[:, :o].copy().view("<f8")
+        cnt = blob[:, o:o + 4 * n_source].copy().view("<i4"); o += 4 * n_source
+        cls = blob[:, o:o + 4].copy().view("<i4")[:, 0]
+        ids = blob[:, o + 4:o + 12].copy().view("<i8")[:, 0]
+        ct = blob[:, o + 12:o + 28].copy().view("<f8"); o += 28
+        hyst = blob[:, o:o + 4].copy().view("<i4")[:, 0]
+        core = blob[:, o + 4:o + 12].copy().view("<f8")[:, 0]
+        absorb = blob[:, o + 12:o + 20].copy().view("<f8")[:, 0]
+        ncomp = blob[:, o + 20:o + 24].copy().view("<i4")[:, 0]
+        tlim = blob[:, o + 24:o + 40].copy().view("<f8")
         assert np.array_equal(vol.T, oc.vol[:, :n])
         assert np.array_equal(ids, oc.id[:n])
         assert np.array_equal(cls - 1, oc.wclass[:n])
+        assert np.array_equal(cnt.T, oc.n_orig[:, :n])          # component(:) <-> source histogram
+        assert np.array_equal(ct[:, 0], oc.lct[:n]) and np.array_equal(ct[:, 1], oc.gct[:n])
+        # what the device does not carry: re-attached to the particle with the same id, reset
+        # where a coagulation changed the particle, never left in a slot that changed hands
+        assert np.array_equal(hyst, ids % 7 + 1)
+        was_merged = np.array([int(i) in merged[c] for i in ids])
+        assert was_merged.any() and not was_merged.all()
+        assert np.array_equal(core, np.where(was_merged, 0.0, ids.astype(float)))
+        assert np.array_equal(absorb, np.where(was_merged, 0.0, ids.astype(float)))
+        assert np.array_equal(ncomp, cnt.sum(1))
+        assert (tlim[:, 0] >= oc.lct[:n]).all() and (tlim[:, 1] <= oc.gct[:n]).all()
+        assert np.array_equal(tlim[~was_merged, 0], oc.lct[:n][~was_merged])
     assert off == len(out)
 
 
@@ -110,8 +147,9 @@ def test_fortran_resident_sequence(tmp_path, wp):
     lct = np.tile(np.arange(n_part) * 0.5, (n_cells, 1))
     buf = struct.pack("<7i", n_cells, n_part, n_spec, n_class, n_source, kernel, n_steps)
     buf += struct.pack("<q", seed) + struct.pack("<d", del_t) + dens.astype("<f8").tobytes()
+    n_ideal = np.full(n_class, 0.45 * n_part / n_class)    # the first rebalance halves
     for c in range(n_cells):
-        buf += struct.pack("<2d", T[c], P[c]) + mag[c].astype("<f8").tobytes()
+        buf += struct.pack("<2d", T[c], P[c]) + mag[c].astype("<f8").tobytes() + n_ideal.astype("<f8").tobytes()
         for i in range(n_part):
             buf += vol[c, :, i].astype("<f8").tobytes() + n_orig[c, :, i].astype("<i4").tobytes()
             buf += struct.pack("<i", int(wcl[c, i]) + 1) + struct.pack("<q", int(ids[c, i]))
@@ -133,6 +171,9 @@ def test_fortran_resident_sequence(tmp_path, wp):
         blk.set_aero_data(dens)
         blk.set_env(T, P, np.full(n_cells, 0.5))
         blk.set_weights(mag)
+        blk.set_n_part_ideal(np.tile(n_ideal, (n_cells, 1)))
+        # the shim gives every cell its own block of PartMC's id counter (pmcx_upload_states)
+        blk.set_next_id(1 + np.arange(n_cells, dtype=np.int64) * 2 * cap)
         po = np.arange(n_cells + 1, dtype=np.int64) * n_part
         blk.upload_cells(0, po, vol.transpose(1, 0, 2).reshape(n_spec, -1), wcl.reshape(-1),
                          ids.reshape(-1), lct.reshape(-1), lct.reshape(-1) + 1.0,
@@ -144,12 +185,18 @@ def test_fortran_resident_sequence(tmp_path, wp):
                                          step=step, surface=(lev == 0).astype(np.int32))
             ns, nc, st = blk.mc_coag(kernel, del_t, seed, step)
             assert not (st & 3).any()
+            n_before = blk.aero_state_total_particles().sum()
+            blk.aero_state_rebalance(True, True, seed, step)
+            if step == 0:
+                assert blk.aero_state_total_particles().sum() < 0.7 * n_before   # it halved
             for want in (nm, na, nr, ns, nc):
                 got = np.frombuffer(out, "<i4", n_cells, off); off += 4 * n_cells
                 assert np.array_equal(got, want), step
             assert nm.sum() > 0 and nr.sum() > 0 and nc.sum() > 0
         d = blk.download_cells()
-    rec = 8 * n_spec + 4 * n_source + 4 + 8 + 16
+        w_dev = blk.get_weights()
+    assert (w_dev > mag * 1.5).all()                       # halving doubled the magnitudes
+    rec = 8 * n_spec + 4 * n_source + 4 + 8 + 16 + 4 + 8 + 8 + 4 + 16
     po = d["part_offset"]
     for c in range(n_cells):
         n = int(np.frombuffer(out, "<i4", 1, off)[0]); off += 4

@@ -55,12 +55,21 @@ struct pmcx_ctx {
     int32_t *d_n_exp = nullptr;
     // slab transport across ranks (pmcx_transport_begin .. _finish)
     int32_t *d_halo = nullptr;      // [2 sides][counts(row_cells) | offsets(row_cells + 1)] + import scratch
-    int halo_nx = 0, halo_nz = 0, halo_ny = 0, halo_px = 0;
+    int halo_nx = 0, halo_nz = 0, halo_ny = 0, halo_px = 0; // halo_nx != 0: a transport is open
+    int halo_row_cells = 0;         // row size d_halo was allocated for (kept across steps)
     int64_t halo_total[2] = {0, 0}; // records to export per side (after _export_size)
-    const double *halo_cv = nullptr;
+    double *d_halo_cv = nullptr;    // [n_cells] cell volumes of the open transport (own buffer: the
+                                    // staging area may be reallocated between _begin and _finish)
+    int32_t *d_halo_bad = nullptr;  // [1] records of an imported buffer that failed validation
     int64_t *d_acc = nullptr;   // running sums over calls: n_samp, n_coag, n_part, status
     double *d_diag = nullptr; // [n_cells*(2+2*n_dbin)]
-    bool aero_data_set = false, env_set = false;
+    bool aero_data_set = false, env_set = false, n_ideal_set = false;
+    // gas phase (pmcx_set_gas_state, pmcx_set_gas_scenario)
+    int32_t n_gas = 0;
+    double *d_gas = nullptr;            // [n_cells][n_gas] mix_rat, ppb
+    GasScenarioDev gas_scn{};
+    std::vector<void *> gas_scn_allocs; // the scenario's device arrays
+    double *d_height = nullptr;         // [2][n_cells] height, old height of the current update
     int bounds_kernel = 0; // kernel type the kmax tables are valid for (0 = none)
     int bounds_margin = 8;     // bins above a cell's populated range its bounds cover (< 0: whole tables)
     bool bounds_dirty = true;  // something other than mc_coag changed a population since the last check
@@ -368,6 +377,7 @@ int pmcx_destroy(pmcx_ctx *ctx)
     prof_drain(ctx);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     for (void *p : ctx->allocs) (void)hipFree(p);
+    for (void *p : ctx->gas_scn_allocs) (void)hipFree(p);
     if (ctx->stage) (void)hipFree(ctx->stage);
     if (ctx->d_offsets) (void)hipFree(ctx->d_offsets);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -482,6 +492,7 @@ int pmcx_get_weights(pmcx_ctx *ctx, double *magnitude)
 int pmcx_set_n_part_ideal(pmcx_ctx *ctx, const double *n_ideal)
 {
     if (!ctx || !n_ideal) return fail(ctx, PMCX_EINVAL, "pmcx_set_n_part_ideal: null argument");
+    ctx->n_ideal_set = true;
     return copy_cells_h2d(ctx, ctx->d_n_ideal, n_ideal,
                           sizeof(double) * (size_t)ctx->cfg.n_cells * ctx->cfg.n_class);
 }
@@ -825,6 +836,9 @@ int pmcx_rebalance(pmcx_ctx *ctx, int32_t allow_doubling, int32_t allow_halving,
                    uint32_t step)
 {
     if (!ctx) return PMCX_EINVAL;
+    // with an ideal count of zero every class would be "too large" and halved away
+    if (!ctx->n_ideal_set)
+        return fail(ctx, PMCX_ESTATE, "pmcx_rebalance: pmcx_set_n_part_ideal must come first");
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     ProfScope ps(ctx, "rebalance");
     HIP_TRY(ctx, launch_rebalance(ctx->st, allow_doubling, allow_halving, seed, step, ctx->stream));
@@ -1000,6 +1014,8 @@ static int transport_buffers(pmcx_ctx *ctx)
         if (!rc) rc = dev_alloc(ctx, &ctx->d_n_arr, nc);
         if (!rc) rc = dev_alloc(ctx, &ctx->d_dest_mask, nc);
         if (!rc) rc = dev_alloc(ctx, &ctx->d_n_exp, nc);
+        if (!rc) rc = dev_alloc(ctx, &ctx->d_halo_cv, nc);
+        if (!rc) rc = dev_alloc(ctx, &ctx->d_halo_bad, (size_t)1);
         if (rc) return rc;
     }
     return PMCX_OK;
@@ -1048,26 +1064,37 @@ int pmcx_transport_begin(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int3
     int rc = transport_buffers(ctx);
     if (rc) return rc;
     const size_t nc = (size_t)cf.n_cells, C = (size_t)cf.n_class, row = (size_t)nx * nz;
-    if (!ctx->d_halo || ctx->halo_nx * ctx->halo_nz != (int)row) {
-        ctx->d_halo = nullptr;
+    if (!ctx->d_halo || ctx->halo_row_cells < (int)row) { // grown only when the rows get longer
+        if (ctx->d_halo) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            for (auto it = ctx->allocs.begin(); it != ctx->allocs.end(); ++it)
+                if (*it == (void *)ctx->d_halo) { ctx->allocs.erase(it); break; }
+            HIP_TRY(ctx, hipFree(ctx->d_halo));
+            ctx->bytes -= (int64_t)sizeof(int32_t) * 6 * ((int64_t)ctx->halo_row_cells + 1);
+            ctx->d_halo = nullptr;
+        }
         rc = dev_alloc(ctx, &ctx->d_halo, 6 * (row + 1));
         if (rc) return rc;
+        ctx->halo_row_cells = (int)row;
     }
     const size_t bh = sizeof(double) * nc * C * 4, bv = sizeof(double) * nc * C * (size_t)nz,
                  bc = sizeof(double) * nc;
     rc = ensure_stage(ctx, bh + bv + bc + 64);
     if (rc) return rc;
-    double *d_ph = (double *)ctx->stage, *d_pv = d_ph + nc * C * 4, *d_cv = d_pv + nc * C * (size_t)nz;
+    double *d_ph = (double *)ctx->stage, *d_pv = d_ph + nc * C * 4, *d_cv = ctx->d_halo_cv;
     HIP_TRY(ctx, hipMemcpyAsync(d_ph, prob_h, bh, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_pv, prob_v, bv, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_cv, cell_volume, bc, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->st.status, 0, sizeof(int32_t) * nc, ctx->stream));
     ctx->halo_nx = nx; ctx->halo_nz = nz; ctx->halo_ny = ny; ctx->halo_px = periodic_x;
-    ctx->halo_cv = d_cv; ctx->halo_total[0] = ctx->halo_total[1] = -1;
+    ctx->halo_total[0] = ctx->halo_total[1] = -1;
     ProfScope ps(ctx, "transport");
     HIP_TRY(ctx, launch_transport_begin(ctx->st, nx, nz, ny, periodic_x, 0, d_ph, d_pv, d_cv,
                                         ctx->d_outbox, ctx->d_n_out, ctx->d_n_arr, ctx->d_n_exp,
                                         ctx->d_dest_mask, seed, step, ctx->stream));
+    // the probabilities live in the staging area, which another call may reallocate: they
+    // have been consumed once the stream is idle
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PMCX_OK;
 }
 
@@ -1118,11 +1145,39 @@ int pmcx_transport_import(pmcx_ctx *ctx, int32_t side, const void *dev_buf, int6
         return fail(ctx, PMCX_EINVAL, "pmcx_transport_import: buffer shorter than its header");
     const int ghost_row = side == 0 ? 0 : ny - 1, real_row = side == 0 ? 1 : ny - 2;
     int32_t *offsets = ctx->d_halo + 4 * (size_t)(row + 1) + (size_t)side * (row + 1);
+    // The buffer comes from another process: its counts index this block's slabs.  Checked on the
+    // host (counts within a cell's capacity, records within the buffer) before anything is
+    // written; destinations, copies and classes are checked record by record in the kernel.
+    {
+        std::vector<int32_t> h_counts((size_t)row);
+        HIP_TRY(ctx, hipMemcpyAsync(h_counts.data(), dev_buf, sizeof(int32_t) * (size_t)row,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        int64_t total = 0;
+        for (int r = 0; r < row; r++) {
+            if (h_counts[r] < 0 || h_counts[r] > ctx->cfg.cap)
+                return fail(ctx, PMCX_EINVAL, "pmcx_transport_import: cell %d of the buffer claims %d "
+                                              "particles (capacity %d)", r, h_counts[r], ctx->cfg.cap);
+            total += h_counts[r];
+        }
+        const int64_t need = (int64_t)halo_header_bytes(row) + total * (int64_t)halo_record_bytes(ctx->st);
+        if (need > n_bytes)
+            return fail(ctx, PMCX_EINVAL, "pmcx_transport_import: %lld records need %lld bytes, the "
+                                          "buffer holds %lld", (long long)total, (long long)need,
+                        (long long)n_bytes);
+    }
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_halo_bad, 0, sizeof(int32_t), ctx->stream));
     HIP_TRY(ctx, launch_halo_unpack(ctx->st, ctx->halo_nx, ctx->halo_nz, ny, ctx->d_outbox, ctx->d_n_out,
                                     ctx->d_n_exp, ctx->d_dest_mask, ghost_row, real_row,
                                     (const int32_t *)dev_buf, offsets,
-                                    (const unsigned char *)dev_buf + halo_header_bytes(row), ctx->stream));
+                                    (const unsigned char *)dev_buf + halo_header_bytes(row),
+                                    ctx->d_halo_bad, ctx->stream));
+    int32_t bad = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&bad, ctx->d_halo_bad, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (bad)
+        return fail(ctx, PMCX_EINVAL, "pmcx_transport_import: %d records name a destination, a class "
+                                      "or a copy count outside this block (they were dropped)", bad);
     return PMCX_OK;
 }
 
@@ -1134,7 +1189,7 @@ int pmcx_transport_finish(pmcx_ctx *ctx, int32_t *n_moved, int32_t *n_arrived)
     {
         ProfScope ps(ctx, "transport");
         HIP_TRY(ctx, launch_transport_finish(ctx->st, ctx->halo_nx, ctx->halo_nz, ctx->halo_ny, ctx->halo_px,
-                                             0, ctx->halo_cv, ctx->d_outbox, ctx->d_n_out, ctx->d_n_arr,
+                                             0, ctx->d_halo_cv, ctx->d_outbox, ctx->d_n_out, ctx->d_n_arr,
                                              ctx->d_n_exp, ctx->d_dest_mask, 1, ctx->halo_ny - 2,
                                              ctx->stream));
     }
@@ -1250,18 +1305,141 @@ int pmcx_generate_lognormal(pmcx_ctx *ctx, int32_t n_part, int32_t n_mode, const
     return PMCX_OK;
 }
 
+int pmcx_set_cell_id_base(pmcx_ctx *ctx, uint32_t cell_id_base)
+{
+    if (!ctx) return PMCX_EINVAL;
+    ctx->cfg.cell_id_base = cell_id_base;
+    ctx->st.cell_id_base = cell_id_base; // (the state view is passed by value with every launch)
+    return PMCX_OK;
+}
+
+int pmcx_set_gas_state(pmcx_ctx *ctx, int32_t n_gas, const double *mix_rat)
+{
+    if (!ctx || !mix_rat || n_gas < 1) return fail(ctx, PMCX_EINVAL, "pmcx_set_gas_state: bad argument");
+    if (ctx->n_gas && ctx->n_gas != n_gas)
+        return fail(ctx, PMCX_EINVAL, "pmcx_set_gas_state: n_gas was %d, now %d", ctx->n_gas, n_gas);
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t nc = (size_t)ctx->cfg.n_cells;
+    if (!ctx->d_gas) {
+        int rc = dev_alloc(ctx, &ctx->d_gas, nc * (size_t)n_gas, false);
+        if (!rc) rc = dev_alloc(ctx, &ctx->d_height, 2 * nc, false);
+        if (rc) return rc;
+        ctx->n_gas = n_gas;
+        ctx->gas_scn.n_gas = n_gas;
+    }
+    return copy_cells_h2d(ctx, ctx->d_gas, mix_rat, sizeof(double) * nc * (size_t)n_gas);
+}
+
+int pmcx_get_gas_state(pmcx_ctx *ctx, double *mix_rat)
+{
+    if (!ctx || !mix_rat) return fail(ctx, PMCX_EINVAL, "pmcx_get_gas_state: null argument");
+    if (!ctx->d_gas) return fail(ctx, PMCX_ESTATE, "pmcx_get_gas_state: no gas state was set");
+    return copy_cells_d2h(ctx, mix_rat, ctx->d_gas,
+                          sizeof(double) * (size_t)ctx->cfg.n_cells * (size_t)ctx->n_gas);
+}
+
+int pmcx_set_gas_scenario(pmcx_ctx *ctx, int32_t n_time_e, const double *emission_time,
+                          const double *emission_rate_scale, const double *emission,
+                          int32_t n_time_d, const double *dilution_time,
+                          const double *dilution_rate, const double *background)
+{
+    if (!ctx) return PMCX_EINVAL;
+    if (!ctx->d_gas) return fail(ctx, PMCX_ESTATE, "pmcx_set_gas_scenario: pmcx_set_gas_state must come first");
+    if (n_time_e < 0 || n_time_d < 0 || n_time_e > 4096 || n_time_d > 4096 ||
+        (n_time_e > 0 && (!emission_time || !emission_rate_scale || !emission)) ||
+        (n_time_d > 0 && (!dilution_time || !dilution_rate || !background)))
+        return fail(ctx, PMCX_EINVAL, "pmcx_set_gas_scenario: bad series length or null array");
+    for (int k = 1; k < n_time_e; k++)
+        if (!(emission_time[k] > emission_time[k - 1]))
+            return fail(ctx, PMCX_EINVAL, "pmcx_set_gas_scenario: emission_time must increase");
+    for (int k = 1; k < n_time_d; k++)
+        if (!(dilution_time[k] > dilution_time[k - 1]))
+            return fail(ctx, PMCX_EINVAL, "pmcx_set_gas_scenario: dilution_time must increase");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (void *p : ctx->gas_scn_allocs) (void)hipFree(p);
+    ctx->gas_scn_allocs.clear();
+    GasScenarioDev g{};
+    g.n_gas = ctx->n_gas;
+    const size_t nc = (size_t)ctx->cfg.n_cells, ng = (size_t)ctx->n_gas;
+    auto up = [&](const double *h, size_t count, const double *&d) -> int {
+        double *q = nullptr;
+        HIP_TRY(ctx, hipMalloc((void **)&q, sizeof(double) * count));
+        ctx->gas_scn_allocs.push_back(q);
+        HIP_TRY(ctx, hipMemcpyAsync(q, h, sizeof(double) * count, hipMemcpyHostToDevice, ctx->stream));
+        d = q;
+        return PMCX_OK;
+    };
+    int rc = PMCX_OK;
+    if (n_time_e > 0) {
+        if (!rc) rc = up(emission_time, (size_t)n_time_e, g.emission_time);
+        if (!rc) rc = up(emission_rate_scale, (size_t)n_time_e, g.emission_rate_scale);
+        if (!rc) rc = up(emission, nc * (size_t)n_time_e * ng, g.emission);
+        g.n_time_e = n_time_e;
+    }
+    if (n_time_d > 0) {
+        if (!rc) rc = up(dilution_time, (size_t)n_time_d, g.dilution_time);
+        if (!rc) rc = up(dilution_rate, nc * (size_t)n_time_d, g.dilution_rate);
+        if (!rc) rc = up(background, nc * (size_t)n_time_d * ng, g.background);
+        g.n_time_d = n_time_d;
+    }
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->gas_scn = g;
+    return PMCX_OK;
+}
+
+int pmcx_scenario_update_gas_state(pmcx_ctx *ctx, double dt, double elapsed_time,
+                                   const double *height, const double *old_height)
+{
+    if (!ctx || !height) return fail(ctx, PMCX_EINVAL, "pmcx_scenario_update_gas_state: null argument");
+    if (!ctx->d_gas) return fail(ctx, PMCX_ESTATE, "pmcx_scenario_update_gas_state: no gas state was set");
+    if (!ctx->env_set) return fail(ctx, PMCX_ESTATE, "pmcx_set_env must come first");
+    if (!(dt >= 0)) return fail(ctx, PMCX_EINVAL, "dt must be non-negative");
+    const size_t nc = (size_t)ctx->cfg.n_cells;
+    for (size_t k = 0; k < nc; k++)
+        if (!(height[k] > 0) || (old_height && !(old_height[k] > 0)))
+            return fail(ctx, PMCX_EINVAL, "pmcx_scenario_update_gas_state: heights must be positive (cell %zu)", k);
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    // (pageable host memory: the copies have left the caller's arrays when these calls return)
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_height, height, sizeof(double) * nc, hipMemcpyHostToDevice, ctx->stream));
+    if (old_height)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_height + nc, old_height, sizeof(double) * nc,
+                                    hipMemcpyHostToDevice, ctx->stream));
+    ProfScope ps(ctx, "gas_scenario");
+    HIP_TRY(ctx, launch_gas_update(ctx->gas_scn, ctx->d_gas, ctx->d_temp, ctx->d_pressure, ctx->d_height,
+                                   old_height ? ctx->d_height + nc : nullptr, ctx->cfg.n_cells, dt,
+                                   elapsed_time, ctx->stream));
+    return PMCX_OK;
+}
+
 int pmcx_timestep(pmcx_ctx *ctx, const pmcx_step_flags *f)
 {
     if (!ctx || !f) return fail(ctx, PMCX_EINVAL, "pmcx_timestep: null argument");
+    if (!(f->dt > 0) || !(f->partmc_chem_dt > 0) || !(f->elapsed_time >= 0))
+        return fail(ctx, PMCX_EINVAL, "pmcx_timestep: dt and partmc_chem_dt must be positive");
+    if (!ctx->n_ideal_set)
+        return fail(ctx, PMCX_ESTATE, "pmcx_timestep: pmcx_set_n_part_ideal must come first");
     // chemistry-step gate, interface/wrf_pmc_driver.F90:189
     const bool chem_step = std::fmod(f->elapsed_time, f->partmc_chem_dt) == 0.0;
     const uint32_t step = (uint32_t)(f->elapsed_time / f->partmc_chem_dt);
     const uint32_t wrf_step = (uint32_t)(f->elapsed_time / f->dt);
-    if (chem_step && f->do_coagulation) {
-        int rc = pmcx_mc_coag(ctx, f->kernel_type, f->partmc_chem_dt, f->random_seed, step);
+    int rc = PMCX_OK;
+    if (chem_step && f->do_coagulation) {                                        // driver:189-198
+        rc = pmcx_mc_coag(ctx, f->kernel_type, f->partmc_chem_dt, f->random_seed, step);
         if (rc) return rc;
     }
-    return pmcx_rebalance(ctx, f->allow_doubling, f->allow_halving, f->random_seed, wrf_step);
+    if (f->height && ctx->d_gas) {                                               // driver:202-205
+        rc = pmcx_scenario_update_gas_state(ctx, f->dt, f->elapsed_time, f->height, f->old_height);
+        if (rc) return rc;
+    }
+    if (f->aero_emission || f->aero_dilution_rate || f->aero_background) {       // driver:207-210
+        rc = pmcx_scenario_update_aero_state(ctx, f->dt, f->elapsed_time, f->random_seed, wrf_step,
+                                             f->aero_emission, f->aero_dilution_rate,
+                                             f->aero_background, nullptr, nullptr, nullptr);
+        if (rc) return rc;
+    }
+    return pmcx_rebalance(ctx, f->allow_doubling, f->allow_halving, f->random_seed, wrf_step); // :248-250
 }
 
 int pmcx_get_bin_tables(pmcx_ctx *ctx, double *v_edge, double *v_samp)

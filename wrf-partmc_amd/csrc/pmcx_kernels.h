@@ -78,6 +78,16 @@ struct GenSpecDev {
     const int32_t *mode_class, *mode_source;
 };
 
+// the gas half of scenario_t, resident (pmcx_set_gas_scenario)
+struct GasScenarioDev {
+    int32_t n_gas, n_time_e, n_time_d;
+    const double *emission_time, *emission_rate_scale; // [n_time_e]
+    const double *emission;                            // [n_cells][n_time_e][n_gas]
+    const double *dilution_time;                       // [n_time_d]
+    const double *dilution_rate;                       // [n_cells][n_time_d]
+    const double *background;                          // [n_cells][n_time_d][n_gas]
+};
+
 // shared-memory footprints (host side needs them to size launches)
 size_t bin_sort_lds_bytes(const DeviceState &st);
 size_t sampler_lds_bytes_per_cell(const DeviceState &st);
@@ -121,6 +131,9 @@ hipError_t launch_scenario_update(const DeviceState &st, double dt, double creat
                                   const double *dilution_rate, const GenSpecDev *bg,
                                   const double *bg_conc, int32_t *n_emit, int32_t *n_dil_in,
                                   int32_t *n_dil_out, hipStream_t s);
+hipError_t launch_gas_update(const GasScenarioDev &g, double *mix_rat, const double *temp,
+                             const double *pressure, const double *height, const double *old_height,
+                             int n_cells, double dt, double elapsed_time, hipStream_t s);
 size_t transport_lds_bytes(const DeviceState &st, int nz);
 hipError_t launch_transport(const DeviceState &st, int nx, int nz, int ny, int periodic_x,
                             int periodic_y, const double *prob_h, const double *prob_v,
@@ -146,7 +159,7 @@ hipError_t launch_halo_pack(const DeviceState &st, int nx, int nz, int ny, void 
 hipError_t launch_halo_unpack(const DeviceState &st, int nx, int nz, int ny, void *outbox,
                               int32_t *n_out, int32_t *n_exp, uint64_t *dest_mask, int ghost_row,
                               int real_row, const int32_t *counts, int32_t *offsets, const void *recs,
-                              hipStream_t s);
+                              int32_t *bad, hipStream_t s);
 // per_cell6: [6][n_cells] aer_res_a, ustar, alpha, big_a, height, inv_density
 hipError_t launch_dry_deposition(const DeviceState &st, double dt, uint64_t seed, uint32_t step,
                                  const int32_t *surface, const double *per_cell6,

@@ -2199,6 +2199,64 @@ __global__ __launch_bounds__(64) void k_scenario_update(DeviceState st, double d
     }
 }
 
+// ------------------------------------------------------------ gas scenario
+//
+// scenario_update_gas_state (call: wrf_pmc_driver.F90:202-205) on every cell: one thread per
+// (cell, gas species).  The scenario's series are interpolated at the step's time (constant
+// outside, linear inside), emissions become ppb through the cell's air molar density,
+// dilution pulls towards the background.  Streams mix_rat once: 16 B per value plus the
+// scenario rows it reads.  [UPSTREAM-UNCITED formulas: include/pmcx.h]
+
+__device__ __forceinline__ void interp_find(const double *x, int n, double xq, int &p, double &alpha)
+{
+    // constant before the first and after the last point, linear in between
+    p = 0; alpha = 0.0;
+    if (n <= 1 || xq <= x[0]) return;
+    if (xq >= x[n - 1]) { p = n - 1; return; }
+    while (p < n - 2 && xq >= x[p + 1]) p++;
+    alpha = (xq - x[p]) / (x[p + 1] - x[p]);
+}
+__device__ __forceinline__ double interp_at(const double *y, int64_t stride, int n, int p, double alpha)
+{
+    if (n <= 1 || (p == 0 && alpha == 0.0)) return y[0];   // (the oracle returns y[0] / y[n-1] there)
+    if (p >= n - 1) return y[(int64_t)(n - 1) * stride];
+    return (1.0 - alpha) * y[(int64_t)p * stride] + alpha * y[(int64_t)(p + 1) * stride];
+}
+
+__global__ __launch_bounds__(256) void k_gas_update(GasScenarioDev g, double *mix_rat,
+                                                    const double *temp, const double *pressure,
+                                                    const double *height, const double *old_height,
+                                                    int n_cells, double dt, double t)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= (int64_t)n_cells * g.n_gas) return;
+    const int c = (int)(j / g.n_gas), q = (int)(j - (int64_t)c * g.n_gas);
+    double x = mix_rat[j];
+    const double h = height[c], h_old = old_height ? old_height[c] : h;
+    if (g.n_time_e > 0) {
+        int p; double a;
+        interp_find(g.emission_time, g.n_time_e, t, p, a);
+        const double scale = interp_at(g.emission_rate_scale, 1, g.n_time_e, p, a);
+        const double em = interp_at(g.emission + ((int64_t)c * g.n_time_e) * g.n_gas + q, g.n_gas,
+                                    g.n_time_e, p, a);
+        const double air_molar_den = pressure[c] / (UNIV_GAS * temp[c]);
+        const double p_emit = scale * dt / h;
+        x = x + p_emit * (em / air_molar_den * 1e9);
+    }
+    if (g.n_time_d > 0) {
+        int p; double a;
+        interp_find(g.dilution_time, g.n_time_d, t, p, a);
+        const double rate = interp_at(g.dilution_rate + (int64_t)c * g.n_time_d, 1, g.n_time_d, p, a);
+        const double bg = interp_at(g.background + ((int64_t)c * g.n_time_d) * g.n_gas + q, g.n_gas,
+                                    g.n_time_d, p, a);
+        double keep = det_exp(-rate * dt);
+        if (h > h_old) keep = keep * h_old / h;
+        x = x * keep;
+        x = x + bg * (1.0 - keep);
+    }
+    mix_rat[j] = x < 0.0 ? 0.0 : x;
+}
+
 // ----------------------------------------------------------- dry deposition
 //
 // dry_dep_aero_state (interface/wrf_pmc_dep_aero.F90:154-192) on the cells flagged as
@@ -2676,7 +2734,7 @@ __global__ __launch_bounds__(64) void k_halo_unpack(DeviceState st, TransGrid tg
                                                     int real_row, const int32_t *counts,
                                                     const int32_t *offsets,
                                                     const unsigned char *recs, int rec_bytes,
-                                                    uint64_t mask_bit)
+                                                    uint64_t mask_bit, int32_t *bad)
 {
     const int lane = threadIdx.x, r = blockIdx.x;
     const int row_cells = tg.nx * tg.nz;
@@ -2684,18 +2742,25 @@ __global__ __launch_bounds__(64) void k_halo_unpack(DeviceState st, TransGrid tg
     const int64_t cb = (int64_t)c * st.cap;
     int2 *box = tg.outbox + cb;
     const int S = st.n_spec, NS = st.n_source;
-    const int cnt = counts[r];
+    int cnt = counts[r]; // (the host has checked 0 <= cnt <= cap and that the records fit the buffer)
+    cnt = cnt < 0 ? 0 : (cnt > st.cap ? st.cap : cnt);
     for (int e = lane; e < cnt; e += 64) {
         const unsigned char *rec = recs + (size_t)(offsets[r] + e) * rec_bytes;
         const int32_t *h = (const int32_t *)rec;
-        const int slot = h[4]; // = e: records of a cell arrive in order
-        const int dest = real_row * row_cells + h[1], copies = h[2];
+        const int slot = e; // records of a cell arrive in outbox order (h[4] repeats it)
+        int copies = h[2];
+        // the buffer was written by another process: what indexes this block is checked; a
+        // record that fails becomes an entry without copies (dropped) and is counted
+        const bool ok = h[4] == e && (unsigned)h[1] < (unsigned)row_cells &&
+                        (unsigned)copies < 32768u && (unsigned)h[3] < (unsigned)st.n_class;
+        if (!ok) { atomicAdd(bad, 1); copies = 0; }
+        const int dest = real_row * row_cells + (ok ? h[1] : 0);
         const double *d = (const double *)(rec + 24);
         st.vm[cb + slot].x = d[0]; st.vm[cb + slot].y = d[1];
         st.meta[cb + slot].lct = d[2]; st.meta[cb + slot].gct = d[3];
         st.meta[cb + slot].id = ((const int64_t *)d)[4];
         st.meta[cb + slot].n_orig0 = ((const int32_t *)(d + 5))[0];
-        st.wclass[cb + slot] = h[3];
+        st.wclass[cb + slot] = ok ? h[3] : 0;
         for (int sp = 0; sp < S; sp++) st.vol[(cb + slot) * S + sp] = d[6 + sp];
         const int32_t *no = (const int32_t *)(d + 6 + S);
         for (int sp = 1; sp < NS; sp++) norig(st, cb, sp, slot) = no[sp - 1];
@@ -3204,6 +3269,16 @@ hipError_t launch_scenario_update(const DeviceState &st, double dt, double creat
                        seed, step, e, dilution_rate, b, n_emit, n_dil_in, n_dil_out);
     return hipGetLastError();
 }
+hipError_t launch_gas_update(const GasScenarioDev &g, double *mix_rat, const double *temp,
+                             const double *pressure, const double *height, const double *old_height,
+                             int n_cells, double dt, double elapsed_time, hipStream_t s)
+{
+    const int64_t n = (int64_t)n_cells * g.n_gas;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gas_update, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, mix_rat,
+                       temp, pressure, height, old_height, n_cells, dt, elapsed_time);
+    return hipGetLastError();
+}
 size_t transport_lds_bytes(const DeviceState &st, int nz)
 {
     const size_t nd = (size_t)(4 + nz), C = (size_t)st.n_class;
@@ -3287,7 +3362,7 @@ hipError_t launch_halo_pack(const DeviceState &st, int nx, int nz, int ny, void 
 hipError_t launch_halo_unpack(const DeviceState &st, int nx, int nz, int ny, void *outbox,
                               int32_t *n_out, int32_t *n_exp, uint64_t *dest_mask, int ghost_row,
                               int real_row, const int32_t *counts, int32_t *offsets, const void *recs,
-                              hipStream_t s)
+                              int32_t *bad, hipStream_t s)
 {
     const TransGrid tg = make_grid(nx, nz, ny, 0, 0, nullptr, nullptr, nullptr, outbox, n_out, nullptr,
                                    n_exp, dest_mask, 0);
@@ -3298,7 +3373,7 @@ hipError_t launch_halo_unpack(const DeviceState &st, int nx, int nz, int ny, voi
     hipLaunchKernelGGL(k_halo_scan, dim3(1), dim3(64), 0, s, counts, offsets, nx * nz);
     hipLaunchKernelGGL(k_halo_unpack, dim3(nx * nz), dim3(64), 0, s, st, tg, ghost_row, real_row,
                        counts, offsets, (const unsigned char *)recs,
-                       (int)halo_rec_bytes(st.n_spec, st.n_source), bit);
+                       (int)halo_rec_bytes(st.n_spec, st.n_source), bit, bad);
     return hipGetLastError();
 }
 hipError_t launch_dry_deposition(const DeviceState &st, double dt, uint64_t seed, uint32_t step,

@@ -8,7 +8,11 @@
 ! pmcx_shim uses the real PartMC modules instead (see INTEGRATION.md).
 !
 ! Field sources (all under /root/reference/interface):
-!   aero_particle_t      wrf_pmc_driver.F90:1419-1466
+!   aero_particle_t      wrf_pmc_driver.F90:1419-1466 (vol, component(:)%source_id/%create_time,
+!                        weight_group/class, water_hyst_leg, id, least/greatest_create_time,
+!                        absorb/scatter_cross_sect, asymmetry, refract_shell/core, core_vol);
+!                        reader wrf_pmc_init.F90:1226-1277
+!   aero_data%source_name, %weight_class_name   wrf_pmc_driver.F90:1842-1845
 !   aero_weight_t/array  wrf_pmc_driver.F90:1617-1630
 !   apa%n_part           wrf_pmc_trans_aero.F90:2302
 !   env_state_t          wrf_pmc_driver.F90:611-637
@@ -18,6 +22,9 @@ module pmc_mock
   implicit none
 
   integer, parameter :: dp = c_double
+  integer, parameter :: dc = c_double_complex
+  integer, parameter :: AERO_SOURCE_NAME_LEN = 100   ! wrf_pmc_init.F90:623
+  integer, parameter :: n_swbands = 5                ! wrf_pmc_driver.F90:1405
 
   integer, parameter :: COAG_KERNEL_TYPE_SEDI = 1
   integer, parameter :: COAG_KERNEL_TYPE_ADDITIVE = 2
@@ -26,14 +33,24 @@ module pmc_mock
   integer, parameter :: COAG_KERNEL_TYPE_ZERO = 5
   integer, parameter :: AERO_WEIGHT_TYPE_FLAT = 2
 
+  type aero_component_t                            ! driver:1432-1436
+     integer :: source_id = 0
+     real(kind=dp) :: create_time = 0d0
+  end type aero_component_t
+
   type aero_particle_t
-     real(kind=dp), allocatable :: vol(:)          ! species volumes (m^3)
-     integer, allocatable :: n_orig_part(:)        ! constituents per source
-     integer :: weight_group = 1
-     integer :: weight_class = 1
-     integer(kind=8) :: id = 0
-     real(kind=dp) :: least_create_time = 0d0
-     real(kind=dp) :: greatest_create_time = 0d0
+     real(kind=dp), allocatable :: vol(:)          ! species volumes (m^3), driver:1420
+     type(aero_component_t), allocatable :: component(:)   ! one per constituent, driver:1421-1437
+     integer :: weight_group = 1                   ! driver:1438-1439
+     integer :: weight_class = 1                   ! driver:1440-1441
+     integer :: water_hyst_leg = 0                 ! driver:1442-1443
+     integer(kind=8) :: id = 0                     ! driver:1447
+     real(kind=dp) :: least_create_time = 0d0      ! driver:1448-1449
+     real(kind=dp) :: greatest_create_time = 0d0   ! driver:1450-1451
+     ! optics, written by MOSAIC when do_optical (driver:1452-1466)
+     real(kind=dp), allocatable :: absorb_cross_sect(:), scatter_cross_sect(:), asymmetry(:)
+     complex(kind=dc), allocatable :: refract_shell(:), refract_core(:)
+     real(kind=dp) :: core_vol = 0d0
   end type aero_particle_t
 
   type aero_particle_array_t
@@ -71,7 +88,12 @@ module pmc_mock
      real(kind=dp), allocatable :: kappa(:)
      real(kind=dp), allocatable :: molec_weight(:)
      integer :: i_water = 0
+     character(len=AERO_SOURCE_NAME_LEN), allocatable :: source_name(:)        ! driver:1842
+     character(len=AERO_SOURCE_NAME_LEN), allocatable :: weight_class_name(:)  ! driver:1844
   end type aero_data_t
+
+  ! PartMC's particle id counter (module variable next_id, wrf_pmc_driver.F90:1652)
+  integer(kind=8), save :: next_id = 1
 
 contains
 
@@ -84,5 +106,17 @@ contains
     type(aero_data_t), intent(in) :: aero_data
     aero_data_n_spec = size(aero_data%density)
   end function aero_data_n_spec
+
+  integer function aero_data_n_source(aero_data)         ! driver:862
+    type(aero_data_t), intent(in) :: aero_data
+    aero_data_n_source = 0
+    if (allocated(aero_data%source_name)) aero_data_n_source = size(aero_data%source_name)
+  end function aero_data_n_source
+
+  integer function aero_particle_n_components(aero_particle)   ! driver:1422
+    type(aero_particle_t), intent(in) :: aero_particle
+    aero_particle_n_components = 0
+    if (allocated(aero_particle%component)) aero_particle_n_components = size(aero_particle%component)
+  end function aero_particle_n_components
 
 end module pmc_mock

@@ -26,13 +26,24 @@
 !
 ! `use pmc_mock` is the stand-in for `use pmc_aero_state; use pmc_env_state;
 ! use pmc_aero_data` when built outside WRF.
+!
+! What crosses the boundary per particle (wrf_pmc_driver.F90:1419-1466): vol(:), weight_class,
+! id, least/greatest_create_time and component(:) -- the latter as a per-source histogram
+! (the device keeps counts per source, not the list: DESIGN.md 3.2).  Everything else a
+! particle carries on the Fortran side (water_hyst_leg, weight_group, the optics arrays,
+! core_vol, the create_time of each constituent) stays on the host and is re-attached BY ID
+! after a download; a particle whose composition changed gets its optics reset, a particle the
+! host has never seen (emission, transport arrival, doubling) starts from defaults, and
+! constituents gained in a coagulation are appended to component(:) with a create_time
+! bounded by the particle's least/greatest create time (the exact value is not carried).
 module pmcx_shim
   use iso_c_binding
   use pmc_mock
   implicit none
   private
   public :: pmcx_shim_init, pmcx_shim_finalize, pmcx_set_rng, mc_coag_pmcx, &
-       partmc_coag_cells_pmcx, aero_state_rebalance_cells_pmcx, pmcx_config
+       partmc_coag_cells_pmcx, aero_state_rebalance_cells_pmcx, aero_state_rebalance_pmcx, &
+       pmcx_config
   ! the device-resident sequence (INTEGRATION.md 2c): upload once, step on the device,
   ! download when the host needs the particles (output, restart)
   public :: pmcx_upload_states, pmcx_download_states, mc_coag_resident_pmcx, &
@@ -98,6 +109,11 @@ module pmcx_shim
        type(c_ptr), value :: ctx
        real(c_double), intent(in) :: n_ideal(*)
      end function pmcx_set_n_part_ideal
+     integer(c_int) function pmcx_set_cell_id_base(ctx, cell_id_base) bind(c, name="pmcx_set_cell_id_base")
+       import :: c_ptr, c_int, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: cell_id_base
+     end function pmcx_set_cell_id_base
      integer(c_int) function pmcx_set_next_id(ctx, next_id) bind(c, name="pmcx_set_next_id")
        import :: c_ptr, c_int, c_int64_t
        type(c_ptr), value :: ctx
@@ -262,7 +278,14 @@ contains
     integer, intent(in), optional :: first_cell_id
     rng_seed = seed
     rng_step = step
-    if (present(first_cell_id)) cell_id_base = first_cell_id
+    if (present(first_cell_id)) then
+       cell_id_base = first_cell_id
+       ! an existing context is re-keyed in place (no rebuild between the cells of a loop)
+       if (have_ctx) then
+          cfg%cell_id_base = cell_id_base
+          call pmcx_die(pmcx_set_cell_id_base(ctx, cell_id_base), 'pmcx_set_cell_id_base')
+       end if
+    end if
   end subroutine pmcx_set_rng
 
   subroutine pmcx_shim_init(n_cells, cap, aero_data, n_class, n_source, device)
@@ -298,36 +321,42 @@ contains
   end function pmcx_shim_context
 
   !> Gather aero_states(:) into flat arrays (the layout pmcx_upload_cells documents) and
-  !> upload them with the cells' environment and weights.  cap_min: room per cell the caller
-  !> wants beyond the present populations (arrivals of the transport, emissions).
+  !> upload them with the cells' environment, weights and ideal particle counts.  cap_min:
+  !> room per cell the caller wants beyond the present populations (arrivals of the transport,
+  !> emissions); a rebalance may double a cell up to its ideal count, so the capacity is never
+  !> below twice that.
   subroutine pmcx_upload_states(env_states, aero_data, aero_states, cap_min)
     type(env_state_t), intent(in) :: env_states(:)
     type(aero_data_t), intent(in) :: aero_data
     type(aero_state_t), intent(in) :: aero_states(:)
     integer, intent(in), optional :: cap_min
 
-    integer :: n_cells, n_spec, n_class, n_source, c, i, s, cap_needed
+    integer :: n_cells, n_spec, n_class, n_source, c, i, s, k, cap_needed
     integer(c_int64_t) :: nt, o
     integer(c_int64_t), allocatable :: part_offset(:), id(:)
-    real(c_double), allocatable :: vol(:,:), lct(:), gct(:), temp(:), pres(:), rh(:), mag(:,:)
+    real(c_double), allocatable :: vol(:,:), lct(:), gct(:), temp(:), pres(:), rh(:), mag(:,:), &
+         n_ideal(:,:)
     integer(c_int32_t), allocatable, target :: n_orig(:,:)
     integer(c_int32_t), allocatable :: wclass(:)
     type(c_ptr) :: p_norig
+    logical :: have_ideal
 
     n_cells = size(aero_states)
     n_spec = size(aero_data%density)
     n_class = size(aero_states(1)%awa%weight, 2)
-    n_source = 0
-    if (aero_states(1)%apa%n_part > 0) then
-       if (allocated(aero_states(1)%apa%particle(1)%n_orig_part)) &
-            n_source = size(aero_states(1)%apa%particle(1)%n_orig_part)
-    end if
+    n_source = aero_data_n_source(aero_data)
     cap_needed = 64
     if (present(cap_min)) cap_needed = max(cap_needed, cap_min)
+    have_ideal = .true.
     do c = 1, n_cells
        cap_needed = max(cap_needed, aero_states(c)%apa%n_part)
+       if (allocated(aero_states(c)%n_part_ideal)) then
+          cap_needed = max(cap_needed, 2 * ceiling(sum(aero_states(c)%n_part_ideal(1, :))))
+       else
+          have_ideal = .false.
+       end if
     end do
-    cap_needed = ((cap_needed + 63) / 64) * 64
+    cap_needed = min(((cap_needed + 63) / 64) * 64, 65280)
     if (.not. have_ctx .or. cfg%n_cells /= n_cells .or. cfg%cap < cap_needed &
          .or. cfg%n_spec /= n_spec .or. cfg%n_class /= n_class .or. cfg%n_source /= n_source) then
        call pmcx_shim_init(n_cells, cap_needed, aero_data, n_class, n_source, 0)
@@ -342,15 +371,19 @@ contains
     allocate(vol(max(nt, 1_c_int64_t), n_spec), wclass(max(nt, 1_c_int64_t)), &
          id(max(nt, 1_c_int64_t)), lct(max(nt, 1_c_int64_t)), gct(max(nt, 1_c_int64_t)))
     allocate(n_orig(max(nt, 1_c_int64_t), max(n_source, 1)))
-    allocate(temp(n_cells), pres(n_cells), rh(n_cells), mag(n_class, n_cells))
+    allocate(temp(n_cells), pres(n_cells), rh(n_cells), mag(n_class, n_cells), &
+         n_ideal(n_class, n_cells))
+    n_orig = 0
     do c = 1, n_cells
        o = part_offset(c)
        do i = 1, aero_states(c)%apa%n_part
           do s = 1, n_spec
              vol(o + i, s) = aero_states(c)%apa%particle(i)%vol(s)
           end do
-          do s = 1, n_source
-             n_orig(o + i, s) = aero_states(c)%apa%particle(i)%n_orig_part(s)
+          ! component(:) -> constituents per source (driver:1421-1437)
+          do k = 1, aero_particle_n_components(aero_states(c)%apa%particle(i))
+             s = aero_states(c)%apa%particle(i)%component(k)%source_id
+             if (s >= 1 .and. s <= n_source) n_orig(o + i, s) = n_orig(o + i, s) + 1
           end do
           wclass(o + i) = aero_states(c)%apa%particle(i)%weight_class - 1
           id(o + i) = aero_states(c)%apa%particle(i)%id
@@ -362,6 +395,7 @@ contains
        rh(c) = env_states(c)%rel_humid
        do s = 1, n_class
           mag(s, c) = aero_states(c)%awa%weight(1, s)%magnitude
+          if (have_ideal) n_ideal(s, c) = aero_states(c)%n_part_ideal(1, s)
        end do
     end do
     p_norig = c_null_ptr
@@ -369,22 +403,76 @@ contains
 
     call pmcx_die(pmcx_set_env(ctx, temp, pres, rh), 'pmcx_set_env')
     call pmcx_die(pmcx_set_weights(ctx, mag), 'pmcx_set_weights')
+    ! aero_state%n_part_ideal (aero_state_set_n_part_ideal, wrf_pmc_init.F90:254): without it
+    ! pmcx_rebalance refuses to run (PMCX_ESTATE)
+    if (have_ideal) call pmcx_die(pmcx_set_n_part_ideal(ctx, n_ideal), 'pmcx_set_n_part_ideal')
+    ! ids of particles created on the device (doubling, emission, transport copies): every cell
+    ! draws from its own block of PartMC's counter, which moves past all of them
+    block
+      integer(c_int64_t), allocatable :: nid(:)
+      allocate(nid(n_cells))
+      do c = 1, n_cells
+         nid(c) = next_id + int(c - 1, 8) * int(2 * cfg%cap, 8)
+      end do
+      call pmcx_die(pmcx_set_next_id(ctx, nid), 'pmcx_set_next_id')
+      next_id = next_id + int(n_cells, 8) * int(2 * cfg%cap, 8)
+    end block
     call pmcx_die(pmcx_upload_cells(ctx, 0, n_cells, part_offset, vol, wclass, id, lct, gct, &
          p_norig), 'pmcx_upload_cells')
   end subroutine pmcx_upload_states
 
-  !> Download the resident cells and scatter them back into aero_states(:) (populations may
-  !> have grown: transport arrivals, emissions) together with the weights a rebalance changed.
+  !> ids(order(1)) <= ids(order(2)) <= ... (heap sort of an index array)
+  subroutine sort_index_by_id(ids, order)
+    integer(kind=8), intent(in) :: ids(:)
+    integer, intent(out) :: order(:)
+    integer :: n, i, root, child, last, tmp
+    n = size(ids)
+    do i = 1, n
+       order(i) = i
+    end do
+    do i = n / 2, 1, -1
+       call sift(i, n)
+    end do
+    do last = n, 2, -1
+       tmp = order(1); order(1) = order(last); order(last) = tmp
+       call sift(1, last - 1)
+    end do
+  contains
+    subroutine sift(start, bottom)
+      integer, intent(in) :: start, bottom
+      root = start
+      do while (2 * root <= bottom)
+         child = 2 * root
+         if (child < bottom) then
+            if (ids(order(child)) < ids(order(child + 1))) child = child + 1
+         end if
+         if (ids(order(root)) >= ids(order(child))) return
+         tmp = order(root); order(root) = order(child); order(child) = tmp
+         root = child
+      end do
+    end subroutine sift
+  end subroutine sort_index_by_id
+
+  !> Download the resident cells and rebuild aero_states(:): the mirrored fields come from the
+  !> device; the fields the device does not carry are re-attached to the particle with the
+  !> same id (see the module header), reset when its composition changed, defaulted for a
+  !> particle the host has not seen.  Weights come back too (a rebalance changes them).
   subroutine pmcx_download_states(aero_states)
     type(aero_state_t), intent(inout) :: aero_states(:)
 
-    integer :: n_cells, n_spec, n_class, n_source, c, i, s
+    integer :: n_cells, n_spec, n_class, n_source, c, i, s, k, j, lo, hi, mid, n_old, n_have, n_add
     integer(c_int64_t) :: nt, o
     integer(c_int64_t), allocatable :: part_offset(:), id(:)
     real(c_double), allocatable :: vol(:,:), lct(:), gct(:), mag(:,:)
     integer(c_int32_t), allocatable, target :: n_orig(:,:)
     integer(c_int32_t), allocatable :: wclass(:), n_part(:)
-    type(aero_particle_t), allocatable :: grown(:)
+    type(aero_particle_t), allocatable :: old(:), new(:)
+    type(aero_component_t), allocatable :: comp(:)
+    integer(kind=8), allocatable :: old_id(:)
+    integer, allocatable :: order(:), have(:)
+    logical, allocatable :: taken(:)
+    logical :: changed
+    real(kind=dp) :: t_new
     type(c_ptr) :: p_norig
 
     n_cells = cfg%n_cells
@@ -407,31 +495,120 @@ contains
     if (n_source > 0) p_norig = c_loc(n_orig)
     call pmcx_die(pmcx_download_cells(ctx, 0, n_cells, part_offset, vol, wclass, id, lct, gct, &
          p_norig), 'pmcx_download_cells')
+    allocate(have(max(n_source, 1)))
     do c = 1, n_cells
        o = part_offset(c)
-       if (.not. allocated(aero_states(c)%apa%particle)) allocate(aero_states(c)%apa%particle(n_part(c)))
-       if (size(aero_states(c)%apa%particle) < n_part(c)) then
-          allocate(grown(n_part(c)))
-          grown(1:size(aero_states(c)%apa%particle)) = aero_states(c)%apa%particle
-          call move_alloc(grown, aero_states(c)%apa%particle)
+       ! the host's particles of this cell, findable by id
+       n_old = 0
+       if (allocated(aero_states(c)%apa%particle)) then
+          n_old = min(aero_states(c)%apa%n_part, size(aero_states(c)%apa%particle))
+          call move_alloc(aero_states(c)%apa%particle, old)
        end if
-       aero_states(c)%apa%n_part = n_part(c)
-       do i = 1, n_part(c)
-          if (.not. allocated(aero_states(c)%apa%particle(i)%vol)) &
-               allocate(aero_states(c)%apa%particle(i)%vol(n_spec))
-          if (.not. allocated(aero_states(c)%apa%particle(i)%n_orig_part)) &
-               allocate(aero_states(c)%apa%particle(i)%n_orig_part(n_source))
-          do s = 1, n_spec
-             aero_states(c)%apa%particle(i)%vol(s) = vol(o + i, s)
-          end do
-          do s = 1, n_source
-             aero_states(c)%apa%particle(i)%n_orig_part(s) = n_orig(o + i, s)
-          end do
-          aero_states(c)%apa%particle(i)%weight_class = wclass(o + i) + 1
-          aero_states(c)%apa%particle(i)%id = id(o + i)
-          aero_states(c)%apa%particle(i)%least_create_time = lct(o + i)
-          aero_states(c)%apa%particle(i)%greatest_create_time = gct(o + i)
+       if (allocated(old_id)) deallocate(old_id, order, taken)
+       allocate(old_id(n_old), order(n_old), taken(n_old))
+       do i = 1, n_old
+          old_id(i) = old(i)%id
        end do
+       call sort_index_by_id(old_id, order)
+       taken = .false.
+       allocate(new(n_part(c)))
+       do i = 1, n_part(c)
+          j = 0
+          lo = 1; hi = n_old
+          do while (lo <= hi)
+             mid = (lo + hi) / 2
+             if (old_id(order(mid)) < id(o + i)) then
+                lo = mid + 1
+             else if (old_id(order(mid)) > id(o + i)) then
+                hi = mid - 1
+             else
+                j = order(mid); exit
+             end if
+          end do
+          if (j > 0) then
+             if (taken(j)) j = 0
+          end if
+          changed = .true.
+          if (j > 0) then
+             ! the same particle: what the device does not carry stays with it
+             taken(j) = .true.
+             changed = .false.
+             do s = 1, n_spec
+                if (old(j)%vol(s) /= vol(o + i, s)) changed = .true.
+             end do
+             if (allocated(old(j)%component)) call move_alloc(old(j)%component, new(i)%component)
+             new(i)%weight_group = old(j)%weight_group
+             new(i)%water_hyst_leg = old(j)%water_hyst_leg  ! kept by the merged particle [UPSTREAM-UNCITED]
+             if (.not. changed) then
+                if (allocated(old(j)%absorb_cross_sect)) call move_alloc(old(j)%absorb_cross_sect, new(i)%absorb_cross_sect)
+                if (allocated(old(j)%scatter_cross_sect)) call move_alloc(old(j)%scatter_cross_sect, new(i)%scatter_cross_sect)
+                if (allocated(old(j)%asymmetry)) call move_alloc(old(j)%asymmetry, new(i)%asymmetry)
+                if (allocated(old(j)%refract_shell)) call move_alloc(old(j)%refract_shell, new(i)%refract_shell)
+                if (allocated(old(j)%refract_core)) call move_alloc(old(j)%refract_core, new(i)%refract_core)
+                new(i)%core_vol = old(j)%core_vol
+             end if
+          end if
+          if (changed) then
+             ! optics belong to a composition that no longer exists (or never did on this
+             ! host): zero until MOSAIC computes them again (driver:1452-1466)
+             allocate(new(i)%absorb_cross_sect(n_swbands), new(i)%scatter_cross_sect(n_swbands), &
+                  new(i)%asymmetry(n_swbands), new(i)%refract_shell(n_swbands), &
+                  new(i)%refract_core(n_swbands))
+             new(i)%absorb_cross_sect = 0d0; new(i)%scatter_cross_sect = 0d0
+             new(i)%asymmetry = 0d0
+             new(i)%refract_shell = (0d0, 0d0); new(i)%refract_core = (0d0, 0d0)
+             new(i)%core_vol = 0d0
+          end if
+          allocate(new(i)%vol(n_spec))
+          do s = 1, n_spec
+             new(i)%vol(s) = vol(o + i, s)
+          end do
+          new(i)%weight_class = wclass(o + i) + 1
+          new(i)%id = id(o + i)
+          ! component(:) <- the source histogram: constituents the particle had keep their
+          ! create_time; the ones it gained are appended with the bound that moved
+          if (n_source > 0) then
+             have = 0
+             n_have = aero_particle_n_components(new(i))
+             do k = 1, n_have
+                s = new(i)%component(k)%source_id
+                if (s >= 1 .and. s <= n_source) have(s) = have(s) + 1
+             end do
+             n_add = 0
+             do s = 1, n_source
+                if (n_orig(o + i, s) < have(s)) n_have = -1   ! (cannot shrink: rebuild)
+                n_add = n_add + max(0, n_orig(o + i, s) - have(s))
+             end do
+             if (n_have < 0) then
+                if (allocated(new(i)%component)) deallocate(new(i)%component)
+                have = 0; n_have = 0
+                n_add = sum(n_orig(o + i, 1:n_source))
+             end if
+             if (n_add > 0) then
+                allocate(comp(n_have + n_add))
+                if (n_have > 0) comp(1:n_have) = new(i)%component(1:n_have)
+                t_new = gct(o + i)
+                if (j > 0) then
+                   if (lct(o + i) < old(j)%least_create_time) t_new = lct(o + i)
+                end if
+                k = n_have
+                do s = 1, n_source
+                   do mid = 1, n_orig(o + i, s) - have(s)
+                      k = k + 1
+                      comp(k)%source_id = s
+                      comp(k)%create_time = t_new
+                   end do
+                end do
+                if (j == 0) comp(1)%create_time = lct(o + i)   ! a new particle: both bounds appear
+                call move_alloc(comp, new(i)%component)
+             end if
+          end if
+          new(i)%least_create_time = lct(o + i)
+          new(i)%greatest_create_time = gct(o + i)
+       end do
+       if (allocated(old)) deallocate(old)
+       call move_alloc(new, aero_states(c)%apa%particle)
+       aero_states(c)%apa%n_part = n_part(c)
        do s = 1, n_class
           aero_states(c)%awa%weight(1, s)%magnitude = mag(s, c)
        end do
@@ -530,13 +707,30 @@ contains
     to%valid_sort = from%valid_sort
   end subroutine move_alloc_state
 
-  !> aero_state_rebalance on the cells last uploaded (state stays on the device).
+  !> aero_state_rebalance on the RESIDENT cells (state stays on the device; INTEGRATION.md 2c).
   subroutine aero_state_rebalance_cells_pmcx(allow_doubling, allow_halving)
     logical, intent(in) :: allow_doubling, allow_halving
     integer(c_int32_t) :: d, h
+    integer(c_int32_t), allocatable :: ns(:), nc(:), st(:)
     d = merge(1, 0, allow_doubling)
     h = merge(1, 0, allow_halving)
     call pmcx_die(pmcx_rebalance(ctx, d, h, rng_seed, rng_step), 'pmcx_rebalance')
+    allocate(ns(cfg%n_cells), nc(cfg%n_cells), st(cfg%n_cells))
+    call pmcx_die(pmcx_get_coag_counters(ctx, ns, nc, st), 'pmcx_get_coag_counters')
+    if (any(iand(st, 16) /= 0)) call pmcx_die(5, 'aero_state_rebalance (a doubled cell exceeds its capacity)')
   end subroutine aero_state_rebalance_cells_pmcx
+
+  !> aero_state_rebalance on host states (interface/wrf_pmc_driver.F90:248-250 for every
+  !> cell): upload (with n_part_ideal), rebalance, download.  The form for a host that keeps
+  !> aero_states(:) authoritative between calls (INTEGRATION.md 2b).
+  subroutine aero_state_rebalance_pmcx(env_states, aero_data, aero_states, allow_doubling, allow_halving)
+    type(env_state_t), intent(in) :: env_states(:)
+    type(aero_data_t), intent(in) :: aero_data
+    type(aero_state_t), intent(inout) :: aero_states(:)
+    logical, intent(in) :: allow_doubling, allow_halving
+    call pmcx_upload_states(env_states, aero_data, aero_states)
+    call aero_state_rebalance_cells_pmcx(allow_doubling, allow_halving)
+    call pmcx_download_states(aero_states)
+  end subroutine aero_state_rebalance_pmcx
 
 end module pmcx_shim

@@ -10,9 +10,15 @@
 !         the end (the per-step record is then n_moved, n_arrived, n_removed, n_samp, n_coag)
 ! in.bin : int32 n_cells, n_part, n_spec, n_class, n_source, kernel, n_steps;
 !          int64 seed; float64 del_t; float64 density(n_spec);
-!          per cell: float64 temp, pressure, mag(n_class);
+!          per cell: float64 temp, pressure, mag(n_class), n_part_ideal(n_class);
 !                    per particle: float64 vol(n_spec), int32 n_orig(n_source),
 !                                  int32 class (1-based), int64 id, float64 lct, gct
+! Every particle is given component(:) from its source counts (create_time = lct) and marks in
+! the fields the device does not carry (water_hyst_leg = mod(id, 7) + 1, core_vol and
+! absorb_cross_sect(:) = id): the output shows where they ended up.
+! out.bin: per step the counters; then per cell n_part and per particle the input record followed
+!          by int32 water_hyst_leg, float64 core_vol, float64 absorb_cross_sect(1), int32 n_components,
+!          float64 min and max of component(:)%create_time
 program test_shim
   use iso_c_binding
   use pmc_mock
@@ -26,7 +32,9 @@ program test_shim
   type(env_state_t), allocatable :: env_states(:)
   type(aero_state_t), allocatable :: aero_states(:)
   integer, allocatable :: n_samp(:), n_coag(:)
-  integer :: c, i, s, step, u, q, k, nx, nz, ny, lev
+  integer :: c, i, s, step, u, q, k, nx, nz, ny, lev, n_comp
+  integer, allocatable :: cnt(:)
+  real(kind=dp) :: t_lo, t_hi
   integer, allocatable :: n_moved(:), n_arrived(:), n_removed(:), surface(:)
   real(kind=dp), allocatable :: prob_h(:,:,:), prob_v(:,:,:), cell_volume(:), ra(:), ustar(:), &
        alpha(:), big_a(:), height(:), inv_density(:)
@@ -42,6 +50,10 @@ program test_shim
   read(u) del_t
   allocate(aero_data%density(n_spec))
   read(u) aero_data%density
+  allocate(aero_data%source_name(n_source), cnt(max(n_source, 1)))
+  do s = 1, n_source
+     write(aero_data%source_name(s), '(a,i0)') 'source_', s
+  end do
   allocate(env_states(n_cells), aero_states(n_cells), n_samp(n_cells), n_coag(n_cells))
   do c = 1, n_cells
      read(u) env_states(c)%temp, env_states(c)%pressure
@@ -49,17 +61,33 @@ program test_shim
      do s = 1, n_class
         read(u) aero_states(c)%awa%weight(1, s)%magnitude
      end do
+     allocate(aero_states(c)%n_part_ideal(1, n_class))
+     read(u) aero_states(c)%n_part_ideal
      aero_states(c)%apa%n_part = n_part
      allocate(aero_states(c)%apa%particle(n_part))
      do i = 1, n_part
         allocate(aero_states(c)%apa%particle(i)%vol(n_spec))
-        allocate(aero_states(c)%apa%particle(i)%n_orig_part(n_source))
         read(u) aero_states(c)%apa%particle(i)%vol
-        read(u) aero_states(c)%apa%particle(i)%n_orig_part
+        read(u) cnt(1:n_source)
         read(u) aero_states(c)%apa%particle(i)%weight_class
         read(u) aero_states(c)%apa%particle(i)%id
         read(u) aero_states(c)%apa%particle(i)%least_create_time, &
              aero_states(c)%apa%particle(i)%greatest_create_time
+        allocate(aero_states(c)%apa%particle(i)%component(sum(cnt(1:n_source))))
+        k = 0
+        do s = 1, n_source
+           do q = 1, cnt(s)
+              k = k + 1
+              aero_states(c)%apa%particle(i)%component(k)%source_id = s
+              aero_states(c)%apa%particle(i)%component(k)%create_time = &
+                   aero_states(c)%apa%particle(i)%least_create_time
+           end do
+        end do
+        aero_states(c)%apa%particle(i)%water_hyst_leg = &
+             int(mod(aero_states(c)%apa%particle(i)%id, 7_8)) + 1
+        aero_states(c)%apa%particle(i)%core_vol = real(aero_states(c)%apa%particle(i)%id, dp)
+        allocate(aero_states(c)%apa%particle(i)%absorb_cross_sect(n_swbands))
+        aero_states(c)%apa%particle(i)%absorb_cross_sect = real(aero_states(c)%apa%particle(i)%id, dp)
      end do
   end do
   close(u)
@@ -99,6 +127,7 @@ program test_shim
         call dry_dep_cells_pmcx(del_t, surface, ra, ustar, alpha, big_a, height, inv_density, &
              n_removed)
         call mc_coag_resident_pmcx(kernel, del_t, n_samp, n_coag)
+        call aero_state_rebalance_cells_pmcx(.true., .true.)
         write(u) n_moved, n_arrived, n_removed, n_samp, n_coag
      end do
      call pmcx_download_states(aero_states)
@@ -111,23 +140,39 @@ program test_shim
      else
         ! the reference's loop shape: one mc_coag call per cell (driver:169-198)
         do c = 1, n_cells
-           call pmcx_set_rng(seed, step, c - 1)
-           call pmcx_shim_finalize()   ! cell id changes: new context keyed by it
+           call pmcx_set_rng(seed, step, c - 1)   ! the documented per-cell sequence (INTEGRATION.md 2a)
            call mc_coag_pmcx(kernel, env_states(c), aero_data, aero_states(c), del_t, &
                 n_samp(c), n_coag(c))
         end do
      end if
+     ! aero_state_rebalance on the host states (driver:248-250)
+     call pmcx_set_rng(seed, step, 0)
+     call aero_state_rebalance_pmcx(env_states, aero_data, aero_states, .true., .true.)
      write(u) n_samp, n_coag
   end do
   do c = 1, n_cells
      write(u) aero_states(c)%apa%n_part
      do i = 1, aero_states(c)%apa%n_part
         write(u) aero_states(c)%apa%particle(i)%vol
-        write(u) aero_states(c)%apa%particle(i)%n_orig_part
+        cnt = 0
+        n_comp = aero_particle_n_components(aero_states(c)%apa%particle(i))
+        t_lo = huge(1d0); t_hi = -huge(1d0)
+        do k = 1, n_comp
+           s = aero_states(c)%apa%particle(i)%component(k)%source_id
+           cnt(s) = cnt(s) + 1
+           t_lo = min(t_lo, aero_states(c)%apa%particle(i)%component(k)%create_time)
+           t_hi = max(t_hi, aero_states(c)%apa%particle(i)%component(k)%create_time)
+        end do
+        write(u) cnt(1:n_source)
         write(u) aero_states(c)%apa%particle(i)%weight_class
         write(u) aero_states(c)%apa%particle(i)%id
         write(u) aero_states(c)%apa%particle(i)%least_create_time, &
              aero_states(c)%apa%particle(i)%greatest_create_time
+        write(u) aero_states(c)%apa%particle(i)%water_hyst_leg
+        write(u) aero_states(c)%apa%particle(i)%core_vol
+        write(u) aero_states(c)%apa%particle(i)%absorb_cross_sect(1)
+        write(u) n_comp
+        write(u) t_lo, t_hi
      end do
   end do
   close(u)

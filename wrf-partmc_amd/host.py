@@ -37,7 +37,8 @@ EXPORTED_SYMBOLS = [
     "pmcx_transport_begin", "pmcx_transport_export_size", "pmcx_transport_export",
     "pmcx_transport_import", "pmcx_transport_finish", "pmcx_device_alloc", "pmcx_device_free",
     "pmcx_device_copy",
-    "pmcx_memory_bytes", "pmcx_device_memory_info",
+    "pmcx_memory_bytes", "pmcx_device_memory_info", "pmcx_set_cell_id_base", "pmcx_set_gas_state",
+    "pmcx_get_gas_state", "pmcx_set_gas_scenario", "pmcx_scenario_update_gas_state",
 ]
 
 
@@ -71,6 +72,8 @@ class PmcxStepFlags(C.Structure):
         ("allow_halving", C.c_int32), ("kernel_type", C.c_int32), ("dt", C.c_double),
         ("partmc_chem_dt", C.c_double), ("elapsed_time", C.c_double),
         ("random_seed", C.c_uint64),
+        ("height", C.c_void_p), ("old_height", C.c_void_p), ("aero_emission", C.c_void_p),
+        ("aero_dilution_rate", C.c_void_p), ("aero_background", C.c_void_p),
     ]
 
 
@@ -141,6 +144,13 @@ def load_library():
     L.pmcx_device_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
     L.pmcx_dry_deposition.argtypes = [C.c_void_p, C.c_double, C.c_uint64, C.c_uint32] + [C.c_void_p] * 9
     L.pmcx_timestep.argtypes = [C.c_void_p, C.POINTER(PmcxStepFlags)]
+    L.pmcx_set_cell_id_base.argtypes = [C.c_void_p, C.c_uint32]
+    L.pmcx_set_gas_state.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    L.pmcx_get_gas_state.argtypes = [C.c_void_p, C.c_void_p]
+    L.pmcx_set_gas_scenario.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pmcx_scenario_update_gas_state.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p,
+                                                 C.c_void_p]
     for name in ("pmcx_upload_cells", "pmcx_download_cells"):
         getattr(L, name).argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 7
     _LIB = L
@@ -514,6 +524,10 @@ class CellBlock:
             if ops:
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()
+                if not on_host:
+                    # on RCCL wait() only orders torch's current stream behind the transfer;
+                    # the library unpacks on its own stream: the receive must have landed
+                    torch.cuda.current_stream().synchronize()
             if rbuf is not None:
                 if on_host:
                     d = DeviceBuffer(self, rbuf.numel())
@@ -558,11 +572,74 @@ class CellBlock:
         """EXTENSION: water condensation sub-step (see include/pmcx.h)."""
         self._ck(self._lib.pmcx_condense(self._h, del_t, n_sub))
 
+    # -- gas phase (row a9) -------------------------------------------------
+    def set_cell_id_base(self, cell_id_base):
+        self._ck(self._lib.pmcx_set_cell_id_base(self._h, int(cell_id_base)))
+        self.cfg.cell_id_base = int(cell_id_base)
+
+    def set_gas_state(self, mix_rat):
+        """gas_state%mix_rat of every cell, [n_cells][n_gas] ppb."""
+        m = np.ascontiguousarray(mix_rat, dtype=np.float64)
+        assert m.ndim == 2 and m.shape[0] == self.cfg.n_cells
+        self._n_gas = m.shape[1]
+        self._ck(self._lib.pmcx_set_gas_state(self._h, self._n_gas, _ptr(m)))
+
+    def get_gas_state(self):
+        m = np.zeros((self.cfg.n_cells, self._n_gas))
+        self._ck(self._lib.pmcx_get_gas_state(self._h, _ptr(m)))
+        return m
+
+    def set_gas_scenario(self, emission_time=None, emission_rate_scale=None, emission=None,
+                         dilution_time=None, dilution_rate=None, background=None):
+        """The gas half of scenario_t, kept on the device: emission [n_cells][n_time_e][n_gas]
+        (mol m^-2 s^-1), dilution_rate [n_cells][n_time_d] (1/s), background
+        [n_cells][n_time_d][n_gas] (ppb); either half may be left out."""
+        n, g = self.cfg.n_cells, self._n_gas
+        nte = 0 if emission_time is None else len(emission_time)
+        ntd = 0 if dilution_time is None else len(dilution_time)
+        et, es = _f64(emission_time), _f64(emission_rate_scale)
+        em = None if not nte else np.ascontiguousarray(np.broadcast_to(_f64(emission), (n, nte, g)))
+        dt_, dr = _f64(dilution_time), None
+        bg = None
+        if ntd:
+            dr = np.ascontiguousarray(np.broadcast_to(_f64(dilution_rate), (n, ntd)))
+            bg = np.ascontiguousarray(np.broadcast_to(_f64(background), (n, ntd, g)))
+        self._ck(self._lib.pmcx_set_gas_scenario(self._h, nte, _ptr(et), _ptr(es), _ptr(em), ntd,
+                                                 _ptr(dt_), _ptr(dr), _ptr(bg)))
+
+    def scenario_update_gas_state(self, dt, elapsed_time, height, old_height=None):
+        """scenario_update_gas_state on every cell (driver:202-205)."""
+        n = self.cfg.n_cells
+        h = np.ascontiguousarray(np.broadcast_to(_f64(height), (n,)))
+        ho = None if old_height is None else np.ascontiguousarray(np.broadcast_to(_f64(old_height), (n,)))
+        self._ck(self._lib.pmcx_scenario_update_gas_state(self._h, dt, elapsed_time, _ptr(h), _ptr(ho)))
+
     def partmc_timestep(self, elapsed_time, dt, partmc_chem_dt, do_coagulation=True,
                         allow_doubling=True, allow_halving=True,
-                        kernel_type=COAG_KERNEL_TYPE_BROWN, random_seed=0):
+                        kernel_type=COAG_KERNEL_TYPE_BROWN, random_seed=0, height=None,
+                        old_height=None, emission=None, emission_rate=None, dilution_rate=None,
+                        background=None, background_conc=None):
+        """The loop body of partmc_timestep over every cell (driver:169-254): gated mc_coag,
+        gas and aerosol scenario updates, rebalance."""
+        n = self.cfg.n_cells
         f = PmcxStepFlags(int(do_coagulation), int(allow_doubling), int(allow_halving),
                           kernel_type, dt, partmc_chem_dt, elapsed_time, random_seed)
+        keep = []
+        if height is not None:
+            h = np.ascontiguousarray(np.broadcast_to(_f64(height), (n,))); keep.append(h)
+            f.height = h.ctypes.data
+            if old_height is not None:
+                ho = np.ascontiguousarray(np.broadcast_to(_f64(old_height), (n,))); keep.append(ho)
+                f.old_height = ho.ctypes.data
+        e, ke = self._aero_dist(emission, emission_rate)
+        b, kb = self._aero_dist(background, background_conc)
+        if e:
+            f.aero_emission = C.addressof(e)
+        if b:
+            f.aero_background = C.addressof(b)
+        if dilution_rate is not None:
+            dl = np.ascontiguousarray(np.broadcast_to(_f64(dilution_rate), (n,))); keep.append(dl)
+            f.aero_dilution_rate = dl.ctypes.data
         self._ck(self._lib.pmcx_timestep(self._h, C.byref(f)))
 
     def diagnostics(self):
