@@ -89,86 +89,160 @@ def aggregate(local, dist=None):
     return out
 
 
+def host_cpu_info():
+    """CPU model, sockets and logical cores of this host (from /proc/cpuinfo), and the cores
+    this process may run on."""
+    model, sockets, logical = "unknown", set(), 0
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name") and model == "unknown":
+                model = ln.split(":", 1)[1].strip()
+            elif ln.startswith("physical id"):
+                sockets.add(ln.split(":", 1)[1].strip())
+            elif ln.startswith("processor"):
+                logical += 1
+    except OSError:
+        pass
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = os.cpu_count() or 1
+    return dict(model=model, sockets=max(len(sockets), 1), logical_cores=logical or (os.cpu_count() or 1),
+                allowed_cores=allowed)
+
+
+_BARRIER = None
+
+
+def _pool_init(barrier):
+    global _BARRIER
+    _BARRIER = barrier
+
+
 def cpu_baseline(args, n_cells_total):
-    """Times the CPU oracle (a restatement: the reference's PartMC submodule is
-    not vendored) on a bounded sample of the same
-    workload: the first cells of the domain, same seeds, one mc_coag step."""
+    """Times the CPU oracle (a restatement: the reference's PartMC submodule is not vendored,
+    BASELINE.md section 2; kind "port") on a bounded sample of the same workload -- cells of the
+    same domain, same seeds -- compiled -O3 -march=native on this host: one process
+    per allowed core, every worker sets its cells up, all wait at a barrier, then step together
+    for at least args.cpu_seconds; plus the single-thread figure.  Also steps the cross-check
+    cells (spread over the domain) through every step the GPU will run."""
     import multiprocessing as mp
     from oracle import pmco_py
     pmco_py.build()
-    cores = min(os.cpu_count() or 1, args.cpu_cores)
-    budget = args.cpu_seconds
-    # calibrate on a few cells, single thread (after one warm call: library load, tables)
-    _oracle_cells((args, [0]))
-    t0 = time.perf_counter()
-    r = _oracle_cells((args, list(range(0, 8))))
-    per_cell = (time.perf_counter() - t0) / 8          # setup + steps, bounds the wall time
-    single = dict(cells=8, events=r["events"], seconds=r["step_s"])
-    n_sample = int(max(cores, min(n_cells_total, budget * cores / max(per_cell, 1e-6))))
-    n_sample -= n_sample % cores
+    info = host_cpu_info()
+    flags = "gcc -O3 -march=native"
+    try:
+        os.environ["PMCO_LIBRARY"] = pmco_py.build_native()
+    except Exception:                                   # no compiler on the box: the portable build
+        os.environ.pop("PMCO_LIBRARY", None)
+        flags = "gcc -O2 (native build failed)"
+    cores = max(1, min(info["allowed_cores"], args.cpu_cores or info["allowed_cores"]))
+    ctx = mp.get_context("fork")
+    # calibrate in a child (the parent never loads the library: its workers fork clean)
+    max_steps = 24          # the populations stay in the regime of the GPU's run (25 steps)
+    with ctx.Pool(1, initializer=_pool_init, initargs=(None,)) as pool:
+        cal = pool.apply(_oracle_cells, ((args, list(range(64)), 4),))
+        per_cell_setup = cal["setup_s"] / 64
+        per_cell_step = cal["step_s"] / max(cal["cell_steps"], 1)
+        # the single-thread figure: about half of cpu_seconds of stepping, 8 steps
+        n1 = int(max(64, min(n_cells_total, 0.5 * args.cpu_seconds / (8 * max(per_cell_step, 1e-9)))))
+        one = pool.apply(_oracle_cells, ((args, list(range(n1)), 8),))
+    single = one["events"] / max(one["step_s"], 1e-9)
+    # cells per worker: set-up bounded to about cpu_setup_seconds; steps: enough for cpu_seconds
+    per_worker = int(max(8, min(n_cells_total // cores, args.cpu_setup_seconds / max(per_cell_setup, 1e-6))))
+    steps = int(min(max_steps, max(2, np.ceil(args.cpu_seconds / max(per_worker * per_cell_step, 1e-9)))))
+    n_sample = per_worker * cores
     chunks = [list(range(k, n_sample, cores)) for k in range(cores)]
-    with mp.get_context("fork").Pool(cores) as pool:
-        t0 = time.perf_counter()
-        res = pool.map(_oracle_cells, [(args, ch) for ch in chunks])
-        wall = time.perf_counter() - t0
-    # workers overlap setup and stepping; charge only the stepping share of the wall time
-    step_frac = sum(x["step_s"] for x in res) / max(sum(x["step_s"] + x["setup_s"] for x in res), 1e-9)
-    step_wall = wall * step_frac
+    barrier = ctx.Barrier(cores)
+    with ctx.Pool(cores, initializer=_pool_init, initargs=(barrier,)) as pool:
+        res = pool.map(_oracle_cells, [(args, ch, steps) for ch in chunks], chunksize=1)
+    step_wall = max(x["step_s"] for x in res)           # all workers start stepping together
     events = sum(x["events"] for x in res)
     parts = sum(x["particles"] for x in res)
+    # the cross-check cells: spread over the domain, stepped through the GPU's whole run
+    chk_ids = sorted(set(np.linspace(0, n_cells_total - 1, args.check_cells).astype(int).tolist()))
+    n_run = args.warmup + args.steps
+    with ctx.Pool(min(cores, 8), initializer=_pool_init, initargs=(None,)) as pool:
+        parts_chk = pool.map(_oracle_check, [(args, chk_ids[k::8], n_run) for k in range(8)], chunksize=1)
+    chk = {}
+    for d in parts_chk:
+        chk.update(d)
     out = {
         "value": events / step_wall, "unit": "events/s", "cores": cores, "kind": "port",
-        "sample": f"{n_sample} cells x {args.particles} particles x {args.cpu_steps} steps after "
-                  f"one warm-up step (oracle/libpmco.so, gcc -O2, {cores} processes; "
-                  "setup and warm-up excluded)",
+        "sample": f"{n_sample} cells x {args.particles} particles x {steps} steps after one warm-up "
+                  f"step, {cores} processes stepping together from a barrier (oracle/pmco.c, {flags}; "
+                  "set-up and warm-up excluded)",
+        "cpu_model": info["model"], "sockets": info["sockets"], "logical_cores": info["logical_cores"],
+        "allowed_cores": info["allowed_cores"],
         "particle_steps_per_sec": parts / step_wall,
-        "single_thread_events_per_sec": single["events"] / max(single["seconds"], 1e-9),
+        "single_thread_events_per_sec": single,
+        "single_thread_sample": f"{n1} cells x 8 steps, {one['step_s']:.2f} s",
         "events": events, "seconds": step_wall,
     }
-    chk = {}
-    for x in res:
-        chk.update(x["n_coag"])
     return out, chk
 
 
+def _make_oracle_cell(o, args, gid, dens, ve, vs, temp, pres, modes, kcache):
+    k = gid % args.levels
+    c = o.Cell(args.n_spec, 1, 0, args.cap, dens, ve, temp[k], pres[k],
+               max_events=args.max_events, max_appends=args.max_appends)
+    c.mag[:] = args.num_conc / args.particles
+    c.generate(modes, args.particles, args.seed, gid, first_id=gid << 32)
+    if k not in kcache:
+        kcache[k] = o.kmax_table(o.KERNEL_BROWN, vs, dens.min(), dens.max(), temp[k], pres[k])
+    c.kmax[:] = kcache[k]
+    return c
+
+
 def _oracle_cells(job):
-    args, cell_ids = job
+    """Timing worker: set up the cells, one warm-up step (which sorts every cell), then `steps`
+    timed steps over all of them."""
+    args, cell_ids, steps = job
     from oracle import pmco_py as o
-    import wrf_partmc_amd as wp
     t_setup = time.perf_counter()
     dens = bench_density(args.n_spec)
     ve, vs = o.make_bin_tables(80, 1e-10, 1e-2)
     temp, pres = level_profile(args.levels)
     modes = bench_modes(args.n_spec)
-    cells, kcache = [], {}
-    for gid in cell_ids:
-        k = gid % args.levels
-        c = o.Cell(args.n_spec, 1, 0, args.cap, dens, ve, temp[k], pres[k],
-                   max_events=args.max_events, max_appends=args.max_appends)
-        c.mag[:] = args.num_conc / args.particles
-        c.generate(modes, args.particles, args.seed, gid, first_id=gid << 32)
-        if k not in kcache:
-            kcache[k] = o.kmax_table(o.KERNEL_BROWN, vs, dens.min(), dens.max(), temp[k], pres[k])
-        c.kmax[:] = kcache[k]
-        cells.append((gid, c))
-    t_setup = time.perf_counter() - t_setup
-    # step 0 (which sorts every cell) is the warm-up, as in the GPU loop; steps 1..cpu_steps
-    # run on the lists the previous call left (aero_state%valid_sort) and are the timed ones
-    n_coag = {}
-    t_warm = time.perf_counter()
+    kcache = {}
+    cells = [(gid, _make_oracle_cell(o, args, gid, dens, ve, vs, temp, pres, modes, kcache))
+             for gid in cell_ids]
     for gid, c in cells:
-        st, ns, nc = c.mc_coag(o.KERNEL_BROWN, args.del_t, args.seed, gid, 0)
-        n_coag[gid] = nc
-    t_warm = time.perf_counter() - t_warm
-    ev, parts = 0, 0
+        c.mc_coag(o.KERNEL_BROWN, args.del_t, args.seed, gid, 0)
+    t_setup = time.perf_counter() - t_setup
+    if _BARRIER is not None:
+        _BARRIER.wait(timeout=900)
+    ev, parts, cell_steps = 0, 0, 0
     t0 = time.perf_counter()
-    for step in range(1, 1 + args.cpu_steps):
+    for step in range(1, 1 + steps):
         for gid, c in cells:
             parts += int(c.n_part[0])
             st, ns, nc = c.mc_coag(o.KERNEL_BROWN, args.del_t, args.seed, gid, step)
             ev += nc
-    return dict(events=ev, particles=parts, n_coag=n_coag,
-                step_s=time.perf_counter() - t0, setup_s=t_setup + t_warm)
+        cell_steps += len(cells)
+    return dict(events=ev, particles=parts, cell_steps=cell_steps,
+                step_s=time.perf_counter() - t0, setup_s=t_setup)
+
+
+def _oracle_check(job):
+    """Cross-check worker: the cells through n_run steps of mc_coag + rebalance, as one_step()
+    does on the GPU; returns per cell (n_coag of the last step, n_part after it)."""
+    args, cell_ids, n_run = job
+    from oracle import pmco_py as o
+    dens = bench_density(args.n_spec)
+    ve, vs = o.make_bin_tables(80, 1e-10, 1e-2)
+    temp, pres = level_profile(args.levels)
+    modes = bench_modes(args.n_spec)
+    kcache, out = {}, {}
+    ideal = np.full(1, float(args.particles))
+    for gid in cell_ids:
+        c = _make_oracle_cell(o, args, gid, dens, ve, vs, temp, pres, modes, kcache)
+        nid, nc = int((gid << 32) + (1 << 24)), 0
+        for step in range(n_run):
+            st, ns, nc = c.mc_coag(o.KERNEL_BROWN, args.del_t, args.seed, gid, step)
+            _, nid = c.rebalance(ideal, True, True, args.seed, gid, step, nid)
+        out[gid] = (int(nc), int(c.n_part[0]))
+    return out
 
 
 def bench_density(n_spec):
@@ -198,9 +272,13 @@ def main():
     ap.add_argument("--seed", type=int, default=0)            # registry.partmc:13
     ap.add_argument("--max-events", type=int, default=1024)
     ap.add_argument("--max-appends", type=int, default=128)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--cpu-cores", type=int, default=16)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-seconds", type=float, default=3.0,
+                    help="timed stepping per CPU worker (after set-up, from a common barrier)")
+    ap.add_argument("--cpu-setup-seconds", type=float, default=9.0,
+                    help="set-up time per CPU worker that bounds its number of cells")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="0: every core this process may use")
+    ap.add_argument("--check-cells", type=int, default=96,
+                    help="cells spread over the domain that the oracle steps through the whole run")
     ap.add_argument("--resort-steps", type=int, default=3,
                     help="extra steps after the timed region with the sort invalidated before "
                          "each (reported as resort_every_step; 0 to skip)")
@@ -292,14 +370,9 @@ def main():
         blk.aero_state_rebalance(True, True, args.seed, step)   # no host sync inside the step
 
     prof_main = {}
-    # the first step's per-cell event counts, for the oracle cross-check
-    first_counts = None
     step = 0
     for _ in range(args.warmup):
         one_step(step)
-        if step == 0 and rank == 0:
-            ns, nc, st = blk.coag_counters()
-            first_counts = {first_cell + i: int(v) for i, v in enumerate(nc[:4096])}
         step += 1
     blk.read_accumulated(reset=True)      # drop the warm-up steps' sums
     blk.profile_enable(True)
@@ -308,13 +381,18 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step(step)
-        if step == 0 and rank == 0:
-            ns, nc, st = blk.coag_counters()
-            first_counts = {first_cell + i: int(v) for i, v in enumerate(nc[:4096])}
         step += 1
     barrier()
     elapsed = time.perf_counter() - t0
     blk.profile_enable(False)
+    # the last timed step's per-cell event counts and the populations it left, for the
+    # cross-check against the oracle on cells spread over the whole domain
+    last_counts = None
+    if cpu_counts is not None:
+        _, nc_last, _ = blk.coag_counters()
+        np_last = blk.aero_state_total_particles()
+        last_counts = {g: (int(nc_last[g - first_cell]), int(np_last[g - first_cell]))
+                       for g in cpu_counts if first_cell <= g < first_cell + n_cells}
     samp, coag, parts_after, status = blk.read_accumulated(reset=True)
     parts = parts_after + coag    # one class: particles entering a step = survivors + events
     for k in KERNELS:
@@ -437,10 +515,13 @@ def main():
                 "bin_sort_gbs": (algorithmic_bytes("bin_sort", args.n_spec, 1, 0, **per_launch)
                                  / max(agg["r_ms_sort"] / world / args.resort_steps * 1e-3, 1e-12) / 1e9)}
         if cpu_line is not None:
-            both = [c for c in cpu_counts if c in (first_counts or {})]
+            both = [c for c in cpu_counts if c in (last_counts or {})]
             cpu_line["cells_compared_with_gpu"] = len(both)
+            cpu_line["compared"] = (f"n_coag of step {args.warmup + args.steps - 1} (the last timed one) and "
+                                    f"n_part after it, cells {both[0]}..{both[-1]} spread over the domain"
+                                    if both else "nothing")
             cpu_line["gpu_matches_oracle_on_sample"] = bool(
-                both and all(cpu_counts[c] == first_counts[c] for c in both))
+                both and all(tuple(cpu_counts[c]) == last_counts[c] for c in both))
             line["cpu_baseline"] = cpu_line
             line["gpu_vs_cpu_events_per_sec"] = line["value"] / cpu_line["value"]
         print(json.dumps(line), flush=True)

@@ -896,13 +896,20 @@ void pmco_scenario_update_gas(int n_gas, double *mix_rat, double dt, double temp
 {
     const double air_molar_den = pressure / (8.314472 * temp); /* env_state_air_molar_den */
     const double p_emit = emission_rate_scale * dt / height;
-    double p = pmco_exp(-dilution_rate * dt);
-    if (height > old_height) p = p * old_height / height;
+    /* the dilution half (exchange with the background, entrainment when the layer grows)
+     * needs a background to exchange with: a scenario without one skips it whole */
+    double p = 1.0;
+    if (background) {
+        p = pmco_exp(-dilution_rate * dt);
+        if (height > old_height) p = p * old_height / height;
+    }
     for (int g = 0; g < n_gas; g++) {
         double x = mix_rat[g];
         if (emission) x = x + p_emit * (emission[g] / air_molar_den * 1e9);
-        x = x * p;
-        if (background) x = x + background[g] * (1.0 - p);
+        if (background) {
+            x = x * p;
+            x = x + background[g] * (1.0 - p);
+        }
         mix_rat[g] = x < 0.0 ? 0.0 : x;
     }
 }
