@@ -320,9 +320,9 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
     A_(st.work_list, 2 * nc + 2);
     A_(st.n_part, nc); A_(st.n_hi, nc); A_(st.next_id, nc);
     A_(st.vol, nc * cfg->n_spec * cap);
-    A_(st.vm, nc * cap);
+    A_(st.hot, nc * cap);
     A_(st.wclass, nc * cap);
-    A_(st.meta, nc * cap);
+    A_(st.cold, nc * cap);
     A_(st.n_orig, nc * (size_t)(cfg->n_source > 1 ? cfg->n_source - 1 : 0) * cap + 1);
     A_(st.perm, nc * (size_t)st.pcap);
     A_(st.gcnt, nc * G); A_(st.goff, nc * (G + 1)); A_(st.sort_valid, nc);
@@ -568,25 +568,25 @@ int pmcx_upload_cells(pmcx_ctx *ctx, int32_t cell_first, int32_t n_up, const int
         }
         if (id) {
             const double *s = (const double *)h2d(id, sizeof(int64_t) * (size_t)nt);
-            HIP_TRY(ctx, launch_scatter_f64(s, (double *)&st.meta[c0 * cap].id, ctx->d_offsets, n_up,
-                                            cf.cap, (int64_t)cap * 4, nt, 1, (int64_t)cap, ctx->stream, 4));
+            HIP_TRY(ctx, launch_scatter_f64(s, (double *)&st.cold[c0 * cap].id, ctx->d_offsets, n_up,
+                                            cf.cap, (int64_t)cap * 2, nt, 1, (int64_t)cap, ctx->stream, 2));
         }
         if (least_ct) {
             const double *s = (const double *)h2d(least_ct, sizeof(double) * (size_t)nt);
-            HIP_TRY(ctx, launch_scatter_f64(s, &st.meta[c0 * cap].lct, ctx->d_offsets, n_up, cf.cap,
+            HIP_TRY(ctx, launch_scatter_f64(s, &st.hot[c0 * cap].lct, ctx->d_offsets, n_up, cf.cap,
                                             (int64_t)cap * 4, nt, 1, (int64_t)cap, ctx->stream, 4));
         }
         if (greatest_ct) {
             const double *s = (const double *)h2d(greatest_ct, sizeof(double) * (size_t)nt);
-            HIP_TRY(ctx, launch_scatter_f64(s, &st.meta[c0 * cap].gct, ctx->d_offsets, n_up, cf.cap,
+            HIP_TRY(ctx, launch_scatter_f64(s, &st.hot[c0 * cap].gct, ctx->d_offsets, n_up, cf.cap,
                                             (int64_t)cap * 4, nt, 1, (int64_t)cap, ctx->stream, 4));
         }
         if (n_orig && cf.n_source > 0) {
             const int32_t *s =
                 (const int32_t *)h2d(n_orig, sizeof(int32_t) * cf.n_source * (size_t)nt);
-            // source 0 lives in the metadata record (8 int32 per record), the rest in planes
-            HIP_TRY(ctx, launch_scatter_i32(s, &st.meta[c0 * cap].n_orig0, ctx->d_offsets, n_up,
-                                            cf.cap, (int64_t)cap * 8, nt, 1, (int64_t)cap, ctx->stream, 8));
+            // source 0 lives in the cold record (4 int32 per record), the rest in planes
+            HIP_TRY(ctx, launch_scatter_i32(s, &st.cold[c0 * cap].n_orig0, ctx->d_offsets, n_up,
+                                            cf.cap, (int64_t)cap * 4, nt, 1, (int64_t)cap, ctx->stream, 4));
             if (cf.n_source > 1)
                 HIP_TRY(ctx, launch_scatter_i32(s + nt, st.n_orig + c0 * (cf.n_source - 1) * cap,
                                                 ctx->d_offsets, n_up, cf.cap,
@@ -637,8 +637,8 @@ int pmcx_download_cells(pmcx_ctx *ctx, int32_t cell_first, int32_t n_dn, const i
         // with one species the volume of that species is the cached total (the lane-per-cell
         // sampler does not keep the plane current): gathered from the (vtot, mass) records
         if (cf.n_spec == 1)
-            HIP_TRY(ctx, launch_gather_f64((double *)ctx->stage, &st.vm[c0 * cap].x, ctx->d_offsets,
-                                           n_dn, (int64_t)cap * 2, nt, 1, (int64_t)cap, ctx->stream, 2));
+            HIP_TRY(ctx, launch_gather_f64((double *)ctx->stage, &st.hot[c0 * cap].vtot, ctx->d_offsets,
+                                           n_dn, (int64_t)cap * 4, nt, 1, (int64_t)cap, ctx->stream, 4));
         else
         HIP_TRY(ctx, launch_gather_f64((double *)ctx->stage, st.vol + c0 * cf.n_spec * cap,
                                        ctx->d_offsets, n_dn, (int64_t)cf.n_spec * cap, nt,
@@ -656,9 +656,9 @@ int pmcx_download_cells(pmcx_ctx *ctx, int32_t cell_first, int32_t n_dn, const i
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         return PMCX_OK;
     };
-    if (id && (rc = one_f64((double *)id, (const double *)&st.meta[0].id, 4))) return rc;
-    if (least_ct && (rc = one_f64(least_ct, &st.meta[0].lct, 4))) return rc;
-    if (greatest_ct && (rc = one_f64(greatest_ct, &st.meta[0].gct, 4))) return rc;
+    if (id && (rc = one_f64((double *)id, (const double *)&st.cold[0].id, 2))) return rc;
+    if (least_ct && (rc = one_f64(least_ct, &st.hot[0].lct, 4))) return rc;
+    if (greatest_ct && (rc = one_f64(greatest_ct, &st.hot[0].gct, 4))) return rc;
     if (wclass) {
         HIP_TRY(ctx, launch_gather_i32((int32_t *)ctx->stage, st.wclass + c0 * cap, ctx->d_offsets,
                                        n_dn, (int64_t)cap, nt, 1, (int64_t)cap, ctx->stream));
@@ -667,9 +667,9 @@ int pmcx_download_cells(pmcx_ctx *ctx, int32_t cell_first, int32_t n_dn, const i
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     if (n_orig && cf.n_source > 0) {
-        HIP_TRY(ctx, launch_gather_i32((int32_t *)ctx->stage, &st.meta[c0 * cap].n_orig0,
-                                       ctx->d_offsets, n_dn, (int64_t)cap * 8, nt, 1, (int64_t)cap,
-                                       ctx->stream, 8));
+        HIP_TRY(ctx, launch_gather_i32((int32_t *)ctx->stage, &st.cold[c0 * cap].n_orig0,
+                                       ctx->d_offsets, n_dn, (int64_t)cap * 4, nt, 1, (int64_t)cap,
+                                       ctx->stream, 4));
         if (cf.n_source > 1)
             HIP_TRY(ctx, launch_gather_i32((int32_t *)ctx->stage + nt,
                                            st.n_orig + c0 * (cf.n_source - 1) * cap, ctx->d_offsets,
@@ -1476,11 +1476,11 @@ int pmcx_get_caches(pmcx_ctx *ctx, int32_t cell, double *vtot, double *mass)
     int rc = PMCX_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     HIP_TRY(ctx, launch_compact(ctx->st, cell, 1, 0, 1, ctx->stream));
-    // the two caches are interleaved on the device: strided copies
-    const double2 *src = ctx->st.vm + (size_t)cell * cap;
-    if (vtot) HIP_TRY(ctx, hipMemcpy2DAsync(vtot, sizeof(double), &src->x, sizeof(double2), sizeof(double),
+    // the two caches sit in the particles' 32-byte records: strided copies
+    const Hot *src = ctx->st.hot + (size_t)cell * cap;
+    if (vtot) HIP_TRY(ctx, hipMemcpy2DAsync(vtot, sizeof(double), &src->vtot, sizeof(Hot), sizeof(double),
                                             cap, hipMemcpyDeviceToHost, ctx->stream));
-    if (mass) HIP_TRY(ctx, hipMemcpy2DAsync(mass, sizeof(double), &src->y, sizeof(double2), sizeof(double),
+    if (mass) HIP_TRY(ctx, hipMemcpy2DAsync(mass, sizeof(double), &src->mass, sizeof(Hot), sizeof(double),
                                             cap, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return rc;

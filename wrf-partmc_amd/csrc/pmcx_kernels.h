@@ -15,10 +15,16 @@ enum : int {
     ST_KMAX_RANGE = 32
 };
 
-// Per-particle metadata that only coagulation events and whole-particle moves touch, kept
-// together so that an event costs one memory request per particle for all of it.
-struct __attribute__((aligned(32))) Meta {
+// What the pair sampler reads and writes of a particle -- the cached total volume and mass a
+// kernel evaluation needs, the create times a coagulation merges -- is one 32-byte record:
+// the sampler is bound by the number of distinct 64-byte lines it touches,
+// and a candidate pair now costs one line per particle, events write to lines they have read.
+struct __attribute__((aligned(32))) Hot {
+    double vtot, mass; // sum_s vol (< 0: tombstone), sum_s density_s vol
     double lct, gct;   // least / greatest create time
+};
+// What only whole-particle moves touch (and events, when sources are tracked).
+struct __attribute__((aligned(16))) Cold {
     int64_t id;
     int32_t n_orig0;   // constituents from source 0 (the other sources: DeviceState::n_orig)
     int32_t pad;
@@ -58,9 +64,9 @@ struct DeviceState {
     int64_t *next_id;              // [n_cells]
     // particles
     double *vol;     // [n_cells][cap][n_spec]: a particle's species are contiguous
-    double2 *vm;     // [n_cells][cap] (cached total volume, cached mass): one request per particle
+    Hot *hot;        // [n_cells][cap] cached total volume and mass, create times
     int32_t *wclass; // [n_cells][cap]
-    Meta *meta;      // [n_cells][cap] create times, id, source-0 count
+    Cold *cold;      // [n_cells][cap] id, source-0 count
     int32_t *n_orig; // [n_cells][n_source - 1][cap] sources 1.. (source 0 is in meta)
     // scratch / outputs of the coagulation step
     // aero_sorted, kept between calls while sort_valid (aero_state%valid_sort)

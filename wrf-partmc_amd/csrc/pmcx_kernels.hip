@@ -9,10 +9,12 @@
 // Layout in HBM (structure of arrays, one slab of `cap` slots per cell):
 //   vol   [n_cells][cap][n_spec] f64   particle%vol(:): a particle's species are contiguous,
 //                                      a coagulation touches 3 lines per particle at 20 species
-//   vm    [n_cells][cap] 2 x f64       (cached sum_s vol, cached sum_s density_s*vol):
-//                                      interleaved, a pair evaluation is one request per particle
+//   hot   [n_cells][cap] 32 B          {cached sum_s vol, cached sum_s density_s*vol, least,
+//                                      greatest create time}: what a pair evaluation AND a
+//                                      coagulation read and write of a particle: one line
+//   cold  [n_cells][cap] 16 B          {id, source-0 count}: whole-particle moves only (and
+//                                      events when sources are tracked)
 //   wclass[n_cells][cap] i32
-//   meta  [n_cells][cap] 32 B          {least, greatest create time, id, source-0 count}
 //   n_orig[n_cells][n_source-1][cap] i32  constituents from sources 1..
 // Kernels:
 //   k_bin_sort     one 256-thread workgroup per cell; stable counting sort of
@@ -72,7 +74,7 @@ __device__ __forceinline__ void st_u32(uint32_t *p, uint32_t v)
 // their own planes
 __device__ __forceinline__ int32_t &norig(const DeviceState &st, int64_t cb, int s, int64_t i)
 {
-    if (s == 0) return st.meta[cb + i].n_orig0;
+    if (s == 0) return st.cold[cb + i].n_orig0;
     return st.n_orig[cb * (st.n_source - 1) + (int64_t)(s - 1) * st.cap + i];
 }
 
@@ -80,7 +82,7 @@ __device__ __forceinline__ int32_t &norig(const DeviceState &st, int64_t cb, int
 // total volume is the one mark; wclass of a dead slot is unspecified)
 __device__ __forceinline__ void mark_dead(const DeviceState &st, int64_t cb, int i)
 {
-    st_f64(&st.vm[cb + i].x, -1.0);
+    st_f64(&st.hot[cb + i].vtot, -1.0);
 }
 
 // Class of the particle in slot i, or -1 for a tombstone.  A slot is dead when its cached
@@ -89,13 +91,13 @@ __device__ __forceinline__ void mark_dead(const DeviceState &st, int64_t cb, int
 // costs it 5 % of its time); wclass of a dead slot is unspecified.
 __device__ __forceinline__ int live_class(const DeviceState &st, int64_t cb, int i)
 {
-    if (st.vm[cb + i].x < 0.0) return -1;
+    if (st.hot[cb + i].vtot < 0.0) return -1;
     return st.n_class > 1 ? st.wclass[cb + i] : 0;
 }
 // same, for kernels that kill particles themselves before looking again
 __device__ __forceinline__ int live_class_c(const DeviceState &st, int64_t cb, int i)
 {
-    if (ld_f64(&st.vm[cb + i].x) < 0.0) return -1;
+    if (ld_f64(&st.hot[cb + i].vtot) < 0.0) return -1;
     return st.n_class > 1 ? (int32_t)ld_u32((const uint32_t *)&st.wclass[cb + i]) : 0;
 }
 // volume of species s of slot i.  With ONE species the plane `vol` is not kept current by the
@@ -104,7 +106,7 @@ __device__ __forceinline__ int live_class_c(const DeviceState &st, int64_t cb, i
 // and emission only).
 __device__ __forceinline__ double spec_vol(const DeviceState &st, int64_t cb, int s, int i)
 {
-    if (st.n_spec == 1) return st.vm[cb + i].x;
+    if (st.n_spec == 1) return st.hot[cb + i].vtot;
     return st.vol[(cb + i) * st.n_spec + s];
 }
 
@@ -267,8 +269,8 @@ __global__ void k_refresh_caches(DeviceState st, int cell_first, int n_cells_do)
             vt = vt + v;
             ms = ms + st.density[s] * v;
         }
-        st.vm[cb + i].x = vt;
-        st.vm[cb + i].y = ms;
+        st.hot[cb + i].vtot = vt;
+        st.hot[cb + i].mass = ms;
     }
 }
 
@@ -519,7 +521,7 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st, const int32_t 
     // this wave's slots: a contiguous range whose length is a multiple of 64
     const int per = (((n + 3) >> 2) + 63) & ~63;
     const int lo = min(n, wave * per), hi = min(n, lo + per);
-    const double2 *vt = st.vm + cb; // .x = cached total volume
+    const Hot *vt = st.hot + cb; // .vtot = cached total volume
     const int32_t *wc = st.wclass + cb;
     const double v_lo = edge[0], v_hi = edge[B];
     uint32_t *myhist = hist + (size_t)wave * G;
@@ -534,7 +536,7 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st, const int32_t 
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int i = i0 + u * 64 + lane;
-            v[u] = i < hi ? vt[i].x : v_lo;
+            v[u] = i < hi ? vt[i].vtot : v_lo;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -649,7 +651,7 @@ __host__ __device__ inline size_t sampler_lds_bytes(int G, int C, int max_append
 struct CellCtx {
     CellLds L;
     uint32_t *perm;
-    double2 *vm; // (cached total volume, cached mass) per slot
+    Hot *hot; // (cached total volume, cached mass, create times) per slot
 };
 
 __device__ __forceinline__ uint32_t list_get(const CellCtx &X, int g, int i)
@@ -798,7 +800,7 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
         X.L.act = (uint8_t *)(base + o);
     }
     X.perm = st.perm + (int64_t)c * st.pcap;
-    X.vm = st.vm + cb;
+    X.hot = st.hot + cb;
 
     int32_t *gcnt_g = st.gcnt + (int64_t)c * G;
     const int32_t *goff_g = st.goff + (int64_t)c * (G + 1);
@@ -981,8 +983,8 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
             }
             p1 = list_get(X, gA, i1);
             p2 = list_get(X, gB, i2);
-            v1 = ld_f64(&X.vm[p1].x); v2 = ld_f64(&X.vm[p2].x);
-            m1 = ld_f64(&X.vm[p1].y); m2 = ld_f64(&X.vm[p2].y);
+            v1 = ld_f64(&X.hot[p1].vtot); v2 = ld_f64(&X.hot[p2].vtot);
+            m1 = ld_f64(&X.hot[p1].mass); m2 = ld_f64(&X.hot[p2].mass);
             const double k_max = kmax[b1 * B + b2] * fmax;
             const PartProps qa = props_for(ktype, v1, m1, env);
             const PartProps qb = props_for(ktype, v2, m2, env);
@@ -1053,8 +1055,8 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
         }
         double lo_n = 0, lo_o = 0, go_n = 0, go_o = 0;
         if (lead) {
-            lo_n = ld_f64(&st.meta[cb + pn].lct); lo_o = ld_f64(&st.meta[cb + po].lct);
-            go_n = ld_f64(&st.meta[cb + pn].gct); go_o = ld_f64(&st.meta[cb + po].gct);
+            lo_n = ld_f64(&st.hot[cb + pn].lct); lo_o = ld_f64(&st.hot[cb + po].lct);
+            go_n = ld_f64(&st.hot[cb + pn].gct); go_o = ld_f64(&st.hot[cb + po].gct);
         }
         if (rem_o) {
             const int last = list_remove(X, g_o, io, B, lead);
@@ -1067,9 +1069,9 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
             n_app += list_append(X, g_new, pn, n_app, B, lead);
         }
         if (lead) {
-            st_f64(&X.vm[pn].x, vn); st_f64(&X.vm[pn].y, mn);
-            if (lo_o < lo_n) st_f64(&st.meta[cb + pn].lct, lo_o);
-            if (go_o > go_n) st_f64(&st.meta[cb + pn].gct, go_o);
+            st_f64(&X.hot[pn].vtot, vn); st_f64(&X.hot[pn].mass, mn);
+            if (lo_o < lo_n) st_f64(&st.hot[cb + pn].lct, lo_o);
+            if (go_o > go_n) st_f64(&st.hot[cb + pn].gct, go_o);
             if (C > 1) st_u32((uint32_t *)&st.wclass[cb + pn], (uint32_t)cc);
         }
         {
@@ -1088,7 +1090,7 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
             }
         }
         if (rem_o) {
-            if (lead) st_f64(&X.vm[po].x, -1.0); // tombstone, in the record just read
+            if (lead) st_f64(&X.hot[po].vtot, -1.0); // tombstone, in the record just read
             n_dead++;
         }
         // (the stores above are waited for just before the next gathers, see "evaluate")
@@ -1222,8 +1224,8 @@ void k_coag_seq(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint3
     for (int j = lane; j <= POISSON_RCP_N; j += 64) rcp[j] = g_poisson_rcp[j];
 
     uint32_t *perm = st.perm + (int64_t)c * st.pcap;
-    double2 *vm = st.vm + cb;  // (cached total volume, cached mass)
-    Meta *meta = st.meta + cb; // create times, id, first source count
+    Hot *hot = st.hot + cb;    // cached total volume and mass, create times: one line per particle
+    Cold *cold = st.cold + cb; // id, first source count (touched by events with sources only)
     // (per-lane pointers cost two registers each: the rarely used ones are formed on use)
 #define gcnt_g (st.gcnt + (int64_t)c * G)
 #define goff_g (st.goff + (int64_t)c * (G + 1))
@@ -1461,14 +1463,16 @@ void k_coag_seq(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint3
         double vol1 = 0, vol2 = 0, lct1 = 0, lct2 = 0, gct1 = 0, gct2 = 0; // first species, times
         int32_t no1 = 0, no2 = 0;               // first source
         if (evalid) {
-            const double2 a1 = vm[p1], a2 = vm[p2];
+            // the record's two 16-byte halves: everything a pair evaluation and a coagulation
+            // need of a particle sits in one 32-byte record, one line
+            const double2 a1 = *(const double2 *)&hot[p1].vtot, a2 = *(const double2 *)&hot[p2].vtot;
+            const double2 t1 = *(const double2 *)&hot[p1].lct, t2 = *(const double2 *)&hot[p2].lct;
             v1 = a1.x; m1 = a1.y; v2 = a2.x; m2 = a2.y;
+            lct1 = t1.x; gct1 = t1.y; lct2 = t2.x; gct2 = t2.y;
             // (with one species the volume of that species IS the cached total: both are sums
             // of the same terms)
             if (S > 1) { vol1 = st.vol[(cb + p1) * S]; vol2 = st.vol[(cb + p2) * S]; }
-            // (the record's two 16-byte halves are two requests: the second only when sources exist)
-            lct1 = meta[p1].lct; gct1 = meta[p1].gct; lct2 = meta[p2].lct; gct2 = meta[p2].gct;
-            if (NS > 0) { no1 = meta[p1].n_orig0; no2 = meta[p2].n_orig0; }
+            if (NS > 0) { no1 = cold[p1].n_orig0; no2 = cold[p2].n_orig0; }
         }
 
         // ---- (4) drawing lanes: first count; still empty-handed: second slot ----
@@ -1583,7 +1587,7 @@ void k_coag_seq(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint3
                     }
                     cnt_set(cc, b_new, en, n + 1);
                 }
-                vm[pn] = make_double2(vn, mn);
+                *(double2 *)&hot[pn].vtot = make_double2(vn, mn);
                 // species volumes, source histogram, create times, class [aero_particle_coagulate]
                 if (S > 1) st.vol[(cb + pn) * S] = (pn_is_1 ? vol1 : vol2) + (pn_is_1 ? vol2 : vol1);
                 for (int s0 = 1; s0 < S; s0 += 4) { // four species' loads in flight
@@ -1606,12 +1610,12 @@ void k_coag_seq(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint3
                 {   // create times and first source count share the particle's metadata record
                     const double lo_n = pn_is_1 ? lct1 : lct2, lo_o = pn_is_1 ? lct2 : lct1;
                     const double go_n = pn_is_1 ? gct1 : gct2, go_o = pn_is_1 ? gct2 : gct1;
-                    if (lo_o < lo_n) meta[pn].lct = lo_o;
-                    if (go_o > go_n) meta[pn].gct = go_o;
-                    if (NS > 0) meta[pn].n_orig0 = (int32_t)((uint32_t)no1 + (uint32_t)no2);
+                    if (lo_o < lo_n) hot[pn].lct = lo_o;
+                    if (go_o > go_n) hot[pn].gct = go_o;
+                    if (NS > 0) cold[pn].n_orig0 = (int32_t)((uint32_t)no1 + (uint32_t)no2);
                 }
                 if (C > 1) st.wclass[cb + pn] = cc;
-                if (rem_o) { vm[po].x = -1.0; n_dead++; } // tombstone: in the record just read
+                if (rem_o) { hot[po].vtot = -1.0; n_dead++; } // tombstone: in the record just read
                 tot_coag++;
             } while (false);
         }
@@ -1686,12 +1690,12 @@ __device__ __forceinline__ void move_particle(const DeviceState &st, int64_t cb,
     for (int s = 0; s < st.n_source; s++)
         norig(st, cb, s, dst) =
             norig(st, cb, s, src);
-    st.vm[cb + dst].x = st.vm[cb + src].x;
-    st.vm[cb + dst].y = st.vm[cb + src].y;
+    st.hot[cb + dst].vtot = st.hot[cb + src].vtot;
+    st.hot[cb + dst].mass = st.hot[cb + src].mass;
     st.wclass[cb + dst] = st.wclass[cb + src];
-    st.meta[cb + dst].id = st.meta[cb + src].id;
-    st.meta[cb + dst].lct = st.meta[cb + src].lct;
-    st.meta[cb + dst].gct = st.meta[cb + src].gct;
+    st.cold[cb + dst].id = st.cold[cb + src].id;
+    st.hot[cb + dst].lct = st.hot[cb + src].lct;
+    st.hot[cb + dst].gct = st.hot[cb + src].gct;
 }
 
 // Stable compaction of one cell by one wavefront: 64 slots at a time, every
@@ -1723,7 +1727,7 @@ __device__ void compact_wave(const DeviceState &st, int c, int lane, uint32_t *c
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int i = i0 + u * 64 + lane;
-            x[u] = i < n_hi ? ld_f64(&st.vm[cb + i].x) : -1.0;
+            x[u] = i < n_hi ? ld_f64(&st.hot[cb + i].vtot) : -1.0;
         }
         bool any = false;
 #pragma unroll
@@ -1749,9 +1753,9 @@ __device__ void compact_wave(const DeviceState &st, int c, int lane, uint32_t *c
             const int i = i0 + u * 64 + lane;
             a1[u] = a2[u] = a3[u] = 0; idv[u] = 0; wc[u] = 0;
             if (mv[u]) {
-                a1[u] = ld_f64(&st.vm[cb + i].y);
-                a2[u] = ld_f64(&st.meta[cb + i].lct); a3[u] = ld_f64(&st.meta[cb + i].gct);
-                idv[u] = (int64_t)d2u(ld_f64((const double *)&st.meta[cb + i].id));
+                a1[u] = ld_f64(&st.hot[cb + i].mass);
+                a2[u] = ld_f64(&st.hot[cb + i].lct); a3[u] = ld_f64(&st.hot[cb + i].gct);
+                idv[u] = (int64_t)d2u(ld_f64((const double *)&st.cold[cb + i].id));
                 wc[u] = (int32_t)ld_u32((const uint32_t *)&st.wclass[cb + i]);
             }
         }
@@ -1761,9 +1765,9 @@ __device__ void compact_wave(const DeviceState &st, int c, int lane, uint32_t *c
         for (int u = 0; u < U; u++)
             if (mv[u]) {
                 const int d = dst[u];
-                st_f64(&st.vm[cb + d].x, x[u]); st_f64(&st.vm[cb + d].y, a1[u]);
-                st_f64(&st.meta[cb + d].lct, a2[u]); st_f64(&st.meta[cb + d].gct, a3[u]);
-                st_f64((double *)&st.meta[cb + d].id, u2d((uint64_t)idv[u]));
+                st_f64(&st.hot[cb + d].vtot, x[u]); st_f64(&st.hot[cb + d].mass, a1[u]);
+                st_f64(&st.hot[cb + d].lct, a2[u]); st_f64(&st.hot[cb + d].gct, a3[u]);
+                st_f64((double *)&st.cold[cb + d].id, u2d((uint64_t)idv[u]));
                 st_u32((uint32_t *)&st.wclass[cb + d], (uint32_t)wc[u]);
             }
         // species volumes (with one species the plane is not kept current: nothing to move)
@@ -1884,7 +1888,7 @@ __global__ __launch_bounds__(64) void k_rebalance(DeviceState st, int allow_doub
                     const uint32_t k = base + (uint32_t)__popcll(m & lt);
                     if (is) {
                         move_particle(st, cb, c, n_hi + (int)k, i);
-                        st.meta[cb + n_hi + k].id = nid + (int64_t)k;
+                        st.cold[cb + n_hi + k].id = nid + (int64_t)k;
                     }
                     base += (uint32_t)__popcll(m);
                 }
@@ -1982,7 +1986,7 @@ __global__ __launch_bounds__(256) void k_diagnostics(DeviceState st, double *tot
         if (cl < 0) continue; // tombstone
         double vdry = 0.0, ms = 0.0;
         for (int s = 0; s < S; s++) {
-            const double v = S > 1 ? tile[lane * (S + 1) + s] : st.vm[cb + i].x;
+            const double v = S > 1 ? tile[lane * (S + 1) + s] : st.hot[cb + i].vtot;
             if (s != st.i_water) vdry = vdry + v;
             ms = ms + st.density[s] * v;
         }
@@ -2059,7 +2063,7 @@ __global__ __launch_bounds__(256) void k_diagnostics_ext(DeviceState st, double 
         const double nc = mag[cl];
         double vdry = 0.0, mdry = 0.0;
         for (int s = 0; s < S; s++) {
-            const double v = S > 1 ? tile[lane * (S + 1) + s] : st.vm[cb + i].x;
+            const double v = S > 1 ? tile[lane * (S + 1) + s] : st.hot[cb + i].vtot;
             atomicAdd(&acc[s], st.density[s] * v * nc);
             if (s != st.i_water) { vdry = vdry + v; mdry = mdry + st.density[s] * v; }
         }
@@ -2125,12 +2129,12 @@ __device__ int add_dist_sample(const DeviceState &st, int c, const AeroDistDev &
             }
             for (int s = 0; s < st.n_source; s++)
                 norig(st, cb, s, i) = (s == d.mode_source[m]) ? 1 : 0;
-            st.vm[cb + i].x = vt;
-            st.vm[cb + i].y = ms;
+            st.hot[cb + i].vtot = vt;
+            st.hot[cb + i].mass = ms;
             st.wclass[cb + i] = cl;
-            st.meta[cb + i].id = nid + k;
-            st.meta[cb + i].lct = create_time;
-            st.meta[cb + i].gct = create_time;
+            st.cold[cb + i].id = nid + k;
+            st.hot[cb + i].lct = create_time;
+            st.hot[cb + i].gct = create_time;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
@@ -2308,7 +2312,7 @@ __global__ __launch_bounds__(256) void k_dry_deposition(DeviceState st, DepArgs 
         const uint64_t mlive = __ballot(live);
         bool drop = false;
         if (live) {
-            const double v = st.vm[cb + i].x, m = st.vm[cb + i].y;
+            const double v = st.hot[cb + i].vtot, m = st.hot[cb + i].mass;
             const double diam = 2.0 * det_cbrt(v * (0.75 / PI));
             const double vd = dep_velocity(diam, m / v, temp, rrho, ustar, ra, alpha, big_a);
             const double prob = dt_dz * vd;
@@ -2587,8 +2591,8 @@ __global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid t
             if (copies > 0) {
                 // the record is read once (one request per plane), then written per copy; with
                 // one species the species plane is not kept current (see spec_vol): not moved
-                const double2 vmv = st.vm[sb + from];
-                const Meta mt = st.meta[sb + from];
+                const Hot hv = st.hot[sb + from];
+                const Cold cv = st.cold[sb + from];
                 const int32_t wc = st.n_class > 1 ? st.wclass[sb + from] : 0; // one class: all zero
                 for (int g = 0; g < copies; g++) {
                     const int dst = (int)first + g;
@@ -2598,11 +2602,11 @@ __global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid t
                             st.vol[(cb + dst) * S + sp] = st.vol[(sb + from) * S + sp];
                     for (int sp = 1; sp < NS; sp++)
                         norig(st, cb, sp, dst) = norig(st, sb, sp, from);
-                    st.vm[cb + dst] = vmv;
+                    st.hot[cb + dst] = hv;
                     if (st.n_class > 1) st.wclass[cb + dst] = wc;
-                    Meta m2 = mt;
-                    if (g != copies - 1) m2.id = id0 + g;
-                    st.meta[cb + dst] = m2;
+                    Cold c2 = cv;
+                    if (g != copies - 1) c2.id = id0 + g;
+                    st.cold[cb + dst] = c2;
                 }
             }
             at += (int)__shfl(inc, 63, 64);
@@ -2716,10 +2720,10 @@ __global__ __launch_bounds__(64) void k_halo_pack(DeviceState st, TransGrid tg, 
             h[0] = r; h[1] = en.y - dst_row * row_cells; h[2] = en.x >> 16;
             h[3] = st.wclass[cb + from]; h[4] = idx; h[5] = 0;
             double *d = (double *)(rec + 24);
-            d[0] = st.vm[cb + from].x; d[1] = st.vm[cb + from].y;
-            d[2] = st.meta[cb + from].lct; d[3] = st.meta[cb + from].gct;
-            ((int64_t *)d)[4] = st.meta[cb + from].id;
-            ((int32_t *)(d + 5))[0] = st.meta[cb + from].n_orig0; ((int32_t *)(d + 5))[1] = 0;
+            d[0] = st.hot[cb + from].vtot; d[1] = st.hot[cb + from].mass;
+            d[2] = st.hot[cb + from].lct; d[3] = st.hot[cb + from].gct;
+            ((int64_t *)d)[4] = st.cold[cb + from].id;
+            ((int32_t *)(d + 5))[0] = st.cold[cb + from].n_orig0; ((int32_t *)(d + 5))[1] = 0;
             for (int sp = 0; sp < S; sp++) d[6 + sp] = spec_vol(st, cb, sp, from);
             int32_t *no = (int32_t *)(d + 6 + S);
             for (int sp = 1; sp < NS; sp++) no[sp - 1] = norig(st, cb, sp, from);
@@ -2756,10 +2760,10 @@ __global__ __launch_bounds__(64) void k_halo_unpack(DeviceState st, TransGrid tg
         if (!ok) { atomicAdd(bad, 1); copies = 0; }
         const int dest = real_row * row_cells + (ok ? h[1] : 0);
         const double *d = (const double *)(rec + 24);
-        st.vm[cb + slot].x = d[0]; st.vm[cb + slot].y = d[1];
-        st.meta[cb + slot].lct = d[2]; st.meta[cb + slot].gct = d[3];
-        st.meta[cb + slot].id = ((const int64_t *)d)[4];
-        st.meta[cb + slot].n_orig0 = ((const int32_t *)(d + 5))[0];
+        st.hot[cb + slot].vtot = d[0]; st.hot[cb + slot].mass = d[1];
+        st.hot[cb + slot].lct = d[2]; st.hot[cb + slot].gct = d[3];
+        st.cold[cb + slot].id = ((const int64_t *)d)[4];
+        st.cold[cb + slot].n_orig0 = ((const int32_t *)(d + 5))[0];
         st.wclass[cb + slot] = ok ? h[3] : 0;
         for (int sp = 0; sp < S; sp++) st.vol[(cb + slot) * S + sp] = d[6 + sp];
         const int32_t *no = (const int32_t *)(d + 6 + S);
@@ -2860,8 +2864,8 @@ __global__ __launch_bounds__(256) void k_condense(DeviceState st, const double *
                 ms = ms + st.density[s] * v;
             }
         }
-        st.vm[cb + i].x = vt;
-        st.vm[cb + i].y = ms;
+        st.hot[cb + i].vtot = vt;
+        st.hot[cb + i].mass = ms;
     }
 }
 
@@ -2893,12 +2897,12 @@ __global__ void k_generate(DeviceState st, GenSpecDev g, int n, uint64_t seed, d
         }
         for (int s = 0; s < st.n_source; s++)
             norig(st, cb, s, i) = (s == g.mode_source[mode]) ? 1 : 0;
-        st.vm[cb + i].x = vt;
-        st.vm[cb + i].y = ms;
+        st.hot[cb + i].vtot = vt;
+        st.hot[cb + i].mass = ms;
         st.wclass[cb + i] = g.mode_class[mode];
-        st.meta[cb + i].id = ((int64_t)cell_id << 32) + i;
-        st.meta[cb + i].lct = create_time;
-        st.meta[cb + i].gct = create_time;
+        st.cold[cb + i].id = ((int64_t)cell_id << 32) + i;
+        st.hot[cb + i].lct = create_time;
+        st.hot[cb + i].gct = create_time;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { st.n_part[c] = n; st.n_hi[c] = n; }
 }
