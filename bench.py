@@ -399,11 +399,13 @@ def main():
         prof_main[k] = blk.profile_get(k)
     if os.environ.get("PMCX_SEQ_STAMPS") == "1" and rank == 0:   # diagnostic build of the sampler
         ph = blk.profile_phase_cycles()
-        w = max(ph[7], 1)
-        print("seq sampler, mean shader cycles per wavefront: " + json.dumps(dict(
-            setup=ph[0] / w, pair_and_first_draw=ph[1] / w, particle_data_and_second_draw=ph[2] / w,
-            kernel_and_coagulation=ph[3] / w, write_back=ph[4] / w, draws=ph[5] / w,
-            passes=ph[6] / w, wavefronts=ph[7])), file=sys.stderr)
+        w = max(ph[11], 1)
+        names = ["setup", "1_pair_picked_entries_requested", "2_first_slot_found_philox",
+                 "3_records_requested", "4_first_count_second_slot", "5_kernel_accept",
+                 "6_second_count", "7_coagulation", "write_back"]
+        d = {n: ph[k] / w for k, n in enumerate(names)}
+        d.update(draws=ph[9] / w, passes=ph[10] / w, wavefronts=ph[11])
+        print("seq sampler, mean s_memtime ticks per wavefront: " + json.dumps(d), file=sys.stderr)
 
     # Side measurement, outside the timed region: the same step when something other than
     # mc_coag touched every cell in between (transport, emission: aero_state%valid_sort

@@ -424,7 +424,9 @@ int pmcx_get_sort(pmcx_ctx *ctx, int32_t cell, uint32_t *perm, int32_t *gcnt,
  * 6 poisson(mean=in, u=in2), 7 kernel K(v1=in, m1=in2, v2=in3, m2=in4)
  * at (temp, pressure) with kernel id ktype, 8 dry-deposition velocity
  * (diameter=in, density=in2, ustar=in3, aer_res_a=in4; pressure carries
- * 1/rho_air; ktype 0: alpha 1.2, A 0.002; 1: alpha 100, A 9.999). */
+ * 1/rho_air; ktype 0: alpha 1.2, A 0.002; 1: alpha 100, A 9.999), 9 the single-precision
+ * screen of the Brownian kernel the lane-per-cell sampler consults before the fp64 value
+ * (same operands as 7; -1 where the screen declines to answer). */
 int pmcx_test_math(pmcx_ctx *ctx, int32_t op, int64_t n, const double *in,
                    const double *in2, const double *in3, const double *in4,
                    int32_t ktype, double temp, double pressure, double *out);
@@ -439,12 +441,12 @@ int pmcx_profile_enable(pmcx_ctx *ctx, int32_t on);
 int pmcx_profile_reset(pmcx_ctx *ctx);
 int pmcx_profile_get(pmcx_ctx *ctx, const char *name, double *ms, int64_t *launches);
 
-/* Diagnostic: shader cycles per stage of the lane-per-cell sampler's pass, summed over
+/* Diagnostic: s_memtime ticks per stage of the lane-per-cell sampler's pass, summed over
  * wavefronts, when the library runs with PMCX_SEQ_STAMPS=1 (a separate, slower
- * instantiation of the kernel; zeros otherwise).  out[0..7]: setup; pair picked and
- * first draw; particle data requested, first count, second draw; kernel evaluation,
- * second count, coagulation; write-back (cycles); draws; passes; wavefronts (counts).
- * out[8..11] unused. */
+ * instantiation of the kernel; zeros otherwise).  out[0] set-up; out[1..7] the seven stages of
+ * a pass (pair picked and list entries requested; first slot found and Philox; particle
+ * records requested; first count and second slot; kernel and accept; second count;
+ * coagulation); out[8] write-back; out[9] draws; out[10] passes; out[11] wavefronts. */
 int pmcx_profile_phase_cycles(pmcx_ctx *ctx, uint64_t out[12], int32_t reset);
 
 /* device memory held by the context, bytes (replaces memtrack, interface/mem.c) */

@@ -414,8 +414,10 @@ int pmco_mc_coag(pmco_cell *c, int kernel_type, const pmco_kernel_params *kp,
         const double mean = k_max * del_t * n_possible;
         const uint32_t slot = ((uint32_t)gA << 16) | (uint32_t)gB;
         uint32_t w[4];
-        pmco_rng_block(seed, cell_id, step, slot, PMCO_SITE_POISSON, 0, w);
-        const int32_t ns = pmco_poisson(mean, pmco_u53(w[0], w[1]));
+        /* the slot's uniform: word gB & 3 of the block addressed by (gA, gB & ~3), 32 bits (the
+         * resolution of the reference's GSL uniform): four partner bins of a row share a block */
+        pmco_rng_block(seed, cell_id, step, slot & ~3u, PMCO_SITE_POISSON, 0, w);
+        const int32_t ns = pmco_poisson(mean, (double)w[gB & 3] * 0x1.0p-32);
         tot_samp += ns;
         const double factor = n1 * n2 / nmin;     /* coag_num_conc_factor, flat */
 

@@ -78,6 +78,33 @@ def test_device_kernel_bitwise(wp, oracle, ktype):
             assert np.array_equal(got, ref)
 
 
+def test_brownian_screen_is_within_its_margin(wp):
+    """The lane-per-cell sampler decides a Brownian accept test from a single-precision estimate
+    of K whenever |u k_max - K f| > 1e-3 K f (pmcx_device_math.h): the estimate must then be
+    within 1e-3 of the fp64 kernel wherever it answers.  Swept here over the whole size grid
+    (radius 1e-10 .. 1e-4 m, both particles), three densities and four (T, p): wherever the screen
+    answers it is within 2.5e-4 (a quarter of the margin); it answers on the sizes the
+    benchmark populates, and declines where single precision cancels too much."""
+    r = np.logspace(-10, -4, 240)
+    r1, r2 = [x.ravel() for x in np.meshgrid(r, r)]
+    worst, answered = 0.0, 0
+    with wp.CellBlock(1, 64, 1) as blk:
+        for T, p in ((288.15, 101325.0), (220.0, 25000.0), (300.0, 85000.0), (250.0, 50000.0)):
+            for d1, d2 in ((1770.0, 1770.0), (1000.0, 2600.0), (1900.0, 1400.0)):
+                v1, v2 = 4 / 3 * np.pi * r1 ** 3, 4 / 3 * np.pi * r2 ** 3
+                k64 = blk.test_math(7, v1, v1 * d1, v2, v2 * d2, ktype=K_BROWN, temp=T, pressure=p)
+                k32 = blk.test_math(9, v1, v1 * d1, v2, v2 * d2, ktype=K_BROWN, temp=T, pressure=p)
+                ok = k32 > 0
+                worst = max(worst, float(np.abs(k32[ok] / k64[ok] - 1).max()))
+                answered += int(ok.sum())
+                # the sizes of the benchmark's population (2e-8 m, sigma_log10 0.25, +- 3 sigma and
+                # what coagulation grows them to) are all answered
+                core = (r1 > 3e-9) & (r1 < 3e-7) & (r2 > 3e-9) & (r2 < 3e-7)
+                assert ok[core].all()
+    assert worst < 2.5e-4, worst
+    assert answered > 0.3 * 12 * r1.size
+
+
 def test_bin_tables_and_kmax(wp, oracle):
     with wp.CellBlock(2, 64, 2) as blk:
         ve, vs = blk.bin_tables()

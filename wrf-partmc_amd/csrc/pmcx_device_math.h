@@ -59,6 +59,23 @@ __device__ __forceinline__ void rng_block(uint64_t seed, uint32_t cell, uint32_t
     philox4x32_10(w, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 
+// The uniform that decides a slot's Poisson count: word gB & 3 of the block addressed by
+// (gA, gB & ~3), 32 bits (the resolution of the reference's GSL uniform).  A sweep along a row
+// of partner bins draws four slots from one Philox block.
+__device__ __forceinline__ double slot_uniform(const uint32_t (&w)[4], uint32_t gB)
+{
+    const uint32_t k = gB & 3u;
+    const uint32_t x = k == 0 ? w[0] : (k == 1 ? w[1] : (k == 2 ? w[2] : w[3]));
+    return (double)x * 0x1.0p-32;
+}
+__device__ __forceinline__ double poisson_uniform(uint64_t seed, uint32_t cell, uint32_t step,
+                                                  uint32_t gA, uint32_t gB)
+{
+    uint32_t w[4];
+    rng_block(seed, cell, step, (gA << 16) | (gB & ~3u), SITE_POISSON, 0, w);
+    return slot_uniform(w, gB);
+}
+
 __device__ __forceinline__ double u53(uint32_t hi, uint32_t lo)
 {
     const uint64_t x = ((uint64_t)hi << 32) | lo;
@@ -325,6 +342,73 @@ __device__ inline double brown_pair(const PartProps &a, const PartProps &b)
     const double Rd = R + __builtin_sqrt(a.deltasq + b.deltasq);
     const double Rc = R * __builtin_sqrt(a.speedsq + b.speedsq);
     return (4.0 * PI) * (R * D) * (Rd * Rc) / (R * Rc + 4.0 * D * Rd);
+}
+
+// ---- single-precision estimate of the Brownian kernel (a SCREEN, never a result) ----
+//
+// The accept test of a candidate pair is  u k_max < K f  with K in fp64 (the value both this
+// library and the oracle define).  Most tests are far from the boundary: an estimate of K good to
+// 2.5e-4 decides them, and only a test within 1e-3 of the boundary (or a particle outside the
+// range where the estimate is that good) needs the fp64 value.  The decision taken is always the
+// fp64 one; the estimate only tells when it cannot differ.  The fp64 evaluation costs about 600
+// issue slots per pair (two IEEE square roots and two divisions per particle), this one about 120
+// (v_log_f32 / v_exp_f32 / v_rcp_f32 / v_sqrt_f32).
+//
+// Accuracy: tests/test_gpu_parity.py::test_brownian_screen_is_within_its_margin sweeps the size
+// range below at several temperatures and pressures (op 9 of pmcx_test_math): the largest
+// relative deviation from the fp64 kernel found is asserted below 2.5e-4, a quarter of the margin.
+// Outside  FREEPATH_MIN < particle mean free path / radius < FREEPATH_MAX  the difference of
+// cubes that gives Fuchs' delta cancels too much in single precision: such pairs report
+// `ok = false` and take the fp64 path.
+struct EnvF32 {
+    float gasfreepath, inv_gfp, c_diff, c_speed, c_inv_speed;
+};
+constexpr float BROWN_SCREEN_MARGIN = 1.0e-3f;
+constexpr float BROWN_SCREEN_FP_MIN = 1.0f / 16.0f, BROWN_SCREEN_FP_MAX = 256.0f;
+
+struct PartPropsF32 {
+    float rad, diffus, speedsq, deltasq;
+    bool ok;
+};
+
+__device__ __forceinline__ PartPropsF32 particle_props_f32(float v, float m, const EnvF32 &e)
+{
+    PartPropsF32 q;
+    const float x = v * (float)(0.75 / PI);
+    const float inv_rad = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (-1.0f / 3.0f));
+    const float rad = x * inv_rad * inv_rad;
+    const float knud = e.gasfreepath * inv_rad;
+    const float cunning =
+        1.0f + knud * (1.249f + 0.42f * __builtin_amdgcn_exp2f(-0.87f * 1.44269504f * (rad * e.inv_gfp)));
+    const float diffus = e.c_diff * cunning * inv_rad;
+    const float speedsq = e.c_speed * __builtin_amdgcn_rcpf(m);
+    const float inv_speed = __builtin_amdgcn_sqrtf(m * e.c_inv_speed);
+    const float freepath = (float)(8.0 / PI) * diffus * inv_speed;
+    const float t1 = 2.0f * rad + freepath;
+    const float tmp1 = t1 * t1 * t1;
+    const float t2 = 4.0f * rad * rad + freepath * freepath;
+    const float tmp2 = t2 * __builtin_amdgcn_sqrtf(t2);
+    const float d = (tmp1 - tmp2) * __builtin_amdgcn_rcpf(6.0f * rad * freepath) - 2.0f * rad;
+    const float ratio = freepath * inv_rad;
+    q.rad = rad; q.diffus = diffus; q.speedsq = speedsq; q.deltasq = d * d;
+    q.ok = ratio > BROWN_SCREEN_FP_MIN && ratio < BROWN_SCREEN_FP_MAX;
+    return q;
+}
+
+// estimate of brown_pair() for particles (v1, m1), (v2, m2); ok = false: do not trust it
+__device__ __forceinline__ float brown_screen_f32(double v1, double m1, double v2, double m2,
+                                                  const EnvF32 &e, bool &ok)
+{
+    const PartPropsF32 a = particle_props_f32((float)v1, (float)m1, e);
+    const PartPropsF32 b = particle_props_f32((float)v2, (float)m2, e);
+    const float R = a.rad + b.rad;
+    const float D = a.diffus + b.diffus;
+    const float Rd = R + __builtin_amdgcn_sqrtf(a.deltasq + b.deltasq);
+    const float Rc = R * __builtin_amdgcn_sqrtf(a.speedsq + b.speedsq);
+    ok = a.ok && b.ok;
+    // K = 4 pi R D / (R / Rd + 4 D / Rc)
+    return (float)(4.0 * PI) * (R * D) *
+           __builtin_amdgcn_rcpf(R * __builtin_amdgcn_rcpf(Rd) + 4.0f * D * __builtin_amdgcn_rcpf(Rc));
 }
 
 // E pi (r1+r2)^2 |w1-w2|, Long (1974) efficiency, Stokes-Cunningham fall speed
