@@ -82,10 +82,10 @@ def test_brownian_screen_is_within_its_margin(wp):
     """The lane-per-cell sampler decides a Brownian accept test from a single-precision estimate
     of K whenever |u k_max - K f| > 1e-3 K f (pmcx_device_math.h): the estimate must then be
     within 1e-3 of the fp64 kernel wherever it answers.  Swept here over the whole size grid
-    (radius 1e-10 .. 1e-4 m, both particles), three densities and four (T, p): wherever the screen
+    (radius 1e-10 .. 3e-4 m, both particles), three densities and four (T, p): wherever the screen
     answers it is within 2.5e-4 (a quarter of the margin); it answers on the sizes the
     benchmark populates, and declines where single precision cancels too much."""
-    r = np.logspace(-10, -4, 240)
+    r = np.logspace(-10, -3.5, 260)
     r1, r2 = [x.ravel() for x in np.meshgrid(r, r)]
     worst, answered = 0.0, 0
     with wp.CellBlock(1, 64, 1) as blk:
@@ -97,12 +97,12 @@ def test_brownian_screen_is_within_its_margin(wp):
                 ok = k32 > 0
                 worst = max(worst, float(np.abs(k32[ok] / k64[ok] - 1).max()))
                 answered += int(ok.sum())
-                # the sizes of the benchmark's population (2e-8 m, sigma_log10 0.25, +- 3 sigma and
-                # what coagulation grows them to) are all answered
-                core = (r1 > 3e-9) & (r1 < 3e-7) & (r2 > 3e-9) & (r2 < 3e-7)
+                # every size an aerosol population holds is answered (the benchmark's: 2e-8 m,
+                # sigma_log10 0.25, and what coagulation grows it to)
+                core = (r1 < 2e-5) & (r2 < 2e-5)
                 assert ok[core].all()
     assert worst < 2.5e-4, worst
-    assert answered > 0.3 * 12 * r1.size
+    assert answered > 0.7 * 12 * r1.size
 
 
 def test_bin_tables_and_kmax(wp, oracle):

@@ -357,14 +357,15 @@ __device__ inline double brown_pair(const PartProps &a, const PartProps &b)
 // Accuracy: tests/test_gpu_parity.py::test_brownian_screen_is_within_its_margin sweeps the size
 // range below at several temperatures and pressures (op 9 of pmcx_test_math): the largest
 // relative deviation from the fp64 kernel found is asserted below 2.5e-4, a quarter of the margin.
-// Outside  FREEPATH_MIN < particle mean free path / radius < FREEPATH_MAX  the difference of
-// cubes that gives Fuchs' delta cancels too much in single precision: such pairs report
-// `ok = false` and take the fp64 path.
+// (measured: 1e-5 up to 1 um of radius, 1e-4 at 100 um, growing with radius / mean free path of
+// the particle, where the difference of cubes that gives Fuchs' delta cancels in single
+// precision).  Outside  FP_MIN < particle mean free path / radius < FP_MAX  (radius above about
+// 100 um) a pair reports `ok = false` and takes the fp64 path.
 struct EnvF32 {
     float gasfreepath, inv_gfp, c_diff, c_speed, c_inv_speed;
 };
 constexpr float BROWN_SCREEN_MARGIN = 1.0e-3f;
-constexpr float BROWN_SCREEN_FP_MIN = 1.0f / 16.0f, BROWN_SCREEN_FP_MAX = 256.0f;
+constexpr float BROWN_SCREEN_FP_MIN = 1.0f / 256.0f, BROWN_SCREEN_FP_MAX = 16384.0f;
 
 struct PartPropsF32 {
     float rad, diffus, speedsq, deltasq;

@@ -1683,8 +1683,14 @@ void k_coag_seq(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint3
 // decides the accept test of a Brownian pair from a single-precision estimate whenever the
 // fp64 kernel cannot decide differently (pmcx_device_math.h).  Same results, bit for bit.
 
+#ifndef PMCX_NTRY
+#define PMCX_NTRY 4
+#endif
+#ifndef PMCX_LANE_WAVES
+#define PMCX_LANE_WAVES 3
+#endif
 template <bool STAMPS, bool SIMPLE, int KT>
-__global__ __launch_bounds__(64, 3)
+__global__ __launch_bounds__(64, PMCX_LANE_WAVES)
 void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint32_t step,
                 uint16_t *ovf_mem)
 {
@@ -1771,9 +1777,26 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
         const int g = cl * B + b;
         return (uint32_t)gcnt_g[g] | ((uint32_t)goff_g[g] << 16);
     };
+    // One class: the non-empty bins blo .. blo + 63 as a register word (bit k: bin blo + k), what
+    // the sweep scans.  `far`: some particle lives beyond even that (the general scan serves);
+    // `wide`: some particle lives outside the LDS window (its list length comes from memory).
+    uint64_t wmask = 0;
+    bool far = false, wide = false;
     auto cnt_set = [&](int cl, int b, uint32_t e, int n) { // new length n of the group with entry e
-        if (in_win(b)) ent[(cl * SEQ_W + (b - blo)) * 64 + lane] = (e & 0xFFFF0000u) | (uint32_t)n;
-        else gcnt_g[cl * B + b] = n;
+        if (in_win(b)) {
+            ent[(cl * SEQ_W + (b - blo)) * 64 + lane] = (e & 0xFFFF0000u) | (uint32_t)n;
+        } else {
+            gcnt_g[cl * B + b] = n;
+            if (n > 0) wide = true;
+        }
+        if (SIMPLE) {
+            if ((unsigned)(b - blo) < 64u) {
+                if (n == 0) wmask &= ~(1ull << (b - blo));
+                else wmask |= 1ull << (b - blo);
+            } else if (n > 0) {
+                far = true;
+            }
+        }
         if (n == 0) MASK(cl * 2 + (b >> 6)) &= ~(1ull << (b & 63));
         else if (n == 1) MASK(cl * 2 + (b >> 6)) |= 1ull << (b & 63);
     };
@@ -1819,15 +1842,30 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
     double n1 = 0, n2 = 0, nmin = 0, fmax = 0, factor = 0, k_max = 0;
     uint32_t ns_rem = 0, s = 0;
     bool done = !live;
+    if (SIMPLE) {
+        // bins blo .. blo + 63 of the 128-bit mask (m1 : m0), shifted down by blo
+        const uint64_t m0 = MASK(0), m1 = MASK(1);
+        if (blo == 0) wmask = m0;
+        else if (blo < 64) wmask = (m0 >> blo) | (m1 << (64 - blo));
+        else wmask = m1 >> (blo - 64);
+        // (bins below blo hold nothing: blo is the first non-empty bin unless the grid is
+        // narrower than the window; bins from blo + 64 on are beyond the word)
+        far = blo < 64 && (m1 >> blo) != 0;
+        if (blo > 0 && blo < 64 && (m0 & ((1ull << blo) - 1ull))) far = true;
+        if (blo >= 64 && (m0 || (m1 & ((1ull << (blo - 64)) - 1ull)))) far = true;
+        wide = far || (wmask >> SEQ_W) != 0;
+    }
     STAMP(0)
 
     // ---- where the lane stands in the sweep, what it holds, the Philox block and the bounds of
     // ---- the four partner bins it is drawing from ----
     constexpr uint32_t TAG_NONE = 0xFFFFFFFFu;
-    constexpr int NTRY = 4;          // slots a drawing lane may settle per pass
+    constexpr int NTRY = PMCX_NTRY;  // slots a drawing lane may settle per pass
     uint32_t blk_tag = TAG_NONE;     // (gA << 16) | (gB & ~3) of the cached block
-    uint32_t wq0 = 0, wq1 = 0, wq2 = 0, wq3 = 0;   // its four words: the uniforms of slots gB & 3
-    float kq0 = 0, kq1 = 0, kq2 = 0, kq3 = 0;      // kmax[b1][b2] of the same four partner bins
+    // its four words (the uniforms of slots gB & 3) and kmax[b1][b2] of the same four partner
+    // bins, two to a 64-bit value: picked with shifts (a chain of selects over four scalars is
+    // turned into a table in scratch memory by the compiler, a memory round trip per slot)
+    uint64_t wq01 = 0, wq23 = 0, kq01 = 0, kq23 = 0;
     int rc1 = -1, rc2 = -1;          // classes the row constants below belong to
     if (SIMPLE) { // one class: the row constants are the cell's
         n1 = n2 = nmin = fmax = factor = magl[lane];
@@ -1837,7 +1875,8 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
     // The slot the lane would draw next from where it stands, with the lists as they are now:
     // the sweep order c1, c2 <= c1, b1, b2 (>= b1 within a class), skipping what cannot give a
     // pair.  Does not move the lane (the caller commits).  False: the sweep is over.
-    auto find_next = [&](int &t1, int &t2, int &tb1, int &tb2, uint32_t &eA, uint32_t &eB) -> bool {
+    auto find_next = [&](int &t1, int &t2, int &tb1, int &tb2, uint32_t &eA, uint32_t &eB)
+        __attribute__((always_inline)) -> bool {
         t1 = c1; t2 = c2; tb1 = b1; tb2 = b2;
         while (true) {
             if (tb1 >= 0) {
@@ -1875,6 +1914,9 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
     while (true) {
         if (__ballot(!done) == 0) break;
         if (STAMPS) t_acc[10]++;
+        // (uniform: they pick the scan and the list-length reads for the whole wavefront)
+        const bool any_far = !SIMPLE || __ballot(far) != 0;
+        const bool any_wide = any_far || __ballot(wide) != 0;
 
         // ---- (1) evaluating lanes: the sample's pair, list entries requested ----
         bool evalid = false, acc = false;
@@ -1885,8 +1927,13 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
         const int gA = c1 * B + b1, gB = c2 * B + b2;
         const bool same = (gA == gB);
         if (!done && ns_rem > 0) {
-            eA = ent_get(c1, b1);
-            eB = same ? eA : ent_get(c2, b2);
+            if (SIMPLE && !any_wide) {
+                eA = ent[(b1 - blo) * 64 + lane];
+                eB = same ? eA : ent[(b2 - blo) * 64 + lane];
+            } else {
+                eA = ent_get(c1, b1);
+                eB = same ? eA : ent_get(c2, b2);
+            }
             const int nA = (int)(eA & 0xFFFFu), nB = (int)(eB & 0xFFFFu);
             if (nA < 1 || nB < 1 || (same && nA < 2)) {
                 ns_rem = 0; // a list ran out: the slot ends (the lane draws below)
@@ -1929,37 +1976,84 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
         bool pending = false;            // a slot whose count needs the exact Poisson
         double p_mean = 0, p_u = 0;
         uint32_t want = TAG_NONE;        // the block of the next slot, when it is not the cached one
-        if (drawing) {
-            if (STAMPS) t_acc[9]++;
-#pragma unroll 1
+        if (STAMPS && drawing) t_acc[9]++;
+        // the slot's mean and uniform from the cached block; ZERO = true: its count is surely zero
+#define PMCX_SETTLE(hA, hB, dA, dB, ZERO)                                                           \
+    {                                                                                             \
+        const uint32_t sh_ = ((hB) & 1u) * 32u;                                                   \
+        const uint32_t wu_ = (uint32_t)((((hB) & 2u) ? wq23 : wq01) >> sh_);                      \
+        const float kf_ = __uint_as_float((uint32_t)((((hB) & 2u) ? kq23 : kq01) >> sh_));       \
+        const double nA_ = (double)((dA) & 0xFFFFu), nB_ = (double)((dB) & 0xFFFFu);              \
+        k_max = (double)kf_ * fmax;                                                               \
+        const double n_possible_ = ((hA) == (hB)) ? nA_ * (nA_ - 1.0) / 2.0 : nA_ * nB_;          \
+        const double mean_ = k_max * del_t * n_possible_;                                         \
+        const double u_ = (double)wu_ * 0x1.0p-32;                                                \
+        /* u < 1 - mean - 4e-15  =>  u < det_exp(-mean): no sample, exactly as poisson() says */  \
+        ZERO = u_ < (1.0 - mean_) - 4e-15;                                                        \
+        if (!ZERO) { pending = true; p_mean = mean_; p_u = u_; }                                  \
+    }
+        if (SIMPLE && !any_far) {
+            // One class, every particle inside the window: straight-line code, NTRY times.  The
+            // next slot of the sweep is the next set bit of the window word behind b2, or the
+            // first bin of the next populated row with itself as partner; a bin that holds one
+            // particle gives n_possible = 0 as its own partner, i.e. a mean of zero.
+            bool active = drawing;
+#pragma unroll
             for (int t = 0; t < NTRY; t++) {
-                if (pending || want != TAG_NONE || done) break;
-                int t1, t2, tb1, tb2;
-                uint32_t dA = 0, dB = 0;
-                if (!find_next(t1, t2, tb1, tb2, dA, dB)) { done = true; break; }
+                if (active) {
+                    // (shifts by 64 are avoided: a position at bit 63 has nothing behind it)
+                    const int p1_ = b1 - blo, p2_ = b2 - blo;
+                    const bool rowok = b1 >= 0 && ((wmask >> p1_) & 1ull);
+                    const uint64_t m = (rowok && p2_ < 63) ? (wmask & (~0ull << (p2_ + 1))) : 0ull;
+                    const uint64_t mr = b1 < 0 ? wmask : (p1_ < 63 ? (wmask & (~0ull << (p1_ + 1))) : 0ull);
+                    const int nb1 = m ? b1 : blo + __builtin_ctzll(mr | 0x8000000000000000ull);
+                    const int nb2 = m ? blo + __builtin_ctzll(m) : nb1;
+                    if (!m && !mr) { done = true; active = false; }
+                    else {
+                        const uint32_t tag = ((uint32_t)nb1 << 16) | ((uint32_t)nb2 & ~3u);
+                        if (tag != blk_tag) { want = tag; active = false; }
+                        else {
+                            b1 = nb1; b2 = nb2;
+                            uint32_t dA, dB;
+                            if (!any_wide) {
+                                dA = ent[(nb1 - blo) * 64 + lane];
+                                dB = ent[(nb2 - blo) * 64 + lane];
+                            } else {
+                                dA = ent_get(0, nb1);
+                                dB = ent_get(0, nb2);
+                            }
+                            bool zero;
+                            PMCX_SETTLE((uint32_t)nb1, (uint32_t)nb2, dA, dB, zero)
+                            if (!zero) active = false;
+                        }
+                    }
+                }
+            }
+        } else if (drawing) {
+            // the general scan (several classes, or a particle outside the window): one slot a pass
+            int t1, t2, tb1, tb2;
+            uint32_t dA = 0, dB = 0;
+            if (!find_next(t1, t2, tb1, tb2, dA, dB)) {
+                done = true;
+            } else {
                 const uint32_t hA = (uint32_t)(t1 * B + tb1), hB = (uint32_t)(t2 * B + tb2);
                 const uint32_t tag = (hA << 16) | (hB & ~3u);
-                if (tag != blk_tag) { want = tag; break; }
-                c1 = t1; c2 = t2; b1 = tb1; b2 = tb2;
-                if (!SIMPLE && (c1 != rc1 || c2 != rc2)) {
-                    n1 = magl[c1 * 64 + lane]; n2 = magl[c2 * 64 + lane];
-                    cc = (n1 < n2) ? c1 : c2;
-                    nmin = (n1 < n2) ? n1 : n2;
-                    fmax = (n1 < n2) ? n2 : n1;
-                    factor = n1 * n2 / nmin;
-                    rc1 = c1; rc2 = c2;
+                if (tag != blk_tag) {
+                    want = tag;
+                } else {
+                    c1 = t1; c2 = t2; b1 = tb1; b2 = tb2;
+                    if (!SIMPLE && (c1 != rc1 || c2 != rc2)) {
+                        n1 = magl[c1 * 64 + lane]; n2 = magl[c2 * 64 + lane];
+                        cc = (n1 < n2) ? c1 : c2;
+                        nmin = (n1 < n2) ? n1 : n2;
+                        fmax = (n1 < n2) ? n2 : n1;
+                        factor = n1 * n2 / nmin;
+                        rc1 = c1; rc2 = c2;
+                    }
+                    bool zero;
+                    PMCX_SETTLE(hA, hB, dA, dB, zero)
+                    (void)zero;
                 }
-                const uint32_t q = hB & 3u;
-                const float kf = q == 0 ? kq0 : (q == 1 ? kq1 : (q == 2 ? kq2 : kq3));
-                const uint32_t wu = q == 0 ? wq0 : (q == 1 ? wq1 : (q == 2 ? wq2 : wq3));
-                const double nA = (double)(dA & 0xFFFFu), nB = (double)(dB & 0xFFFFu);
-                k_max = (double)kf * fmax;
-                const double n_possible = (hA == hB) ? nA * (nA - 1.0) / 2.0 : nA * nB;
-                const double mean = k_max * del_t * n_possible;
-                const double u = (double)wu * 0x1.0p-32;
-                // u < 1 - mean - 4e-15  =>  u < det_exp(-mean): no sample, exactly as poisson() says
-                if (u < (1.0 - mean) - 4e-15) continue;
-                pending = true; p_mean = mean; p_u = u;
             }
         }
         STAMP(2)
@@ -1992,15 +2086,17 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
         if (want != TAG_NONE) {
             uint32_t w[4];
             rng_block(seed, cell_id, step, want, SITE_POISSON, 0, w);
-            wq0 = w[0]; wq1 = w[1]; wq2 = w[2]; wq3 = w[3];
+            wq01 = (uint64_t)w[0] | ((uint64_t)w[1] << 32); wq23 = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
             const int hA = (int)(want >> 16), hBq = (int)(want & 0xFFFFu);
             const int rb1 = SIMPLE ? hA : hA % B;
             const float *row = st.kmax + (int64_t)c * st.kmax_stride + rb1 * B;
             // (a group index beyond the last one belongs to no slot: its bound is never read)
-            kq0 = row[SIMPLE ? min(hBq, B - 1) : (hBq % B)];
-            kq1 = row[SIMPLE ? min(hBq + 1, B - 1) : ((hBq + 1) % B)];
-            kq2 = row[SIMPLE ? min(hBq + 2, B - 1) : ((hBq + 2) % B)];
-            kq3 = row[SIMPLE ? min(hBq + 3, B - 1) : ((hBq + 3) % B)];
+            const float kq0 = row[SIMPLE ? min(hBq, B - 1) : (hBq % B)];
+            const float kq1 = row[SIMPLE ? min(hBq + 1, B - 1) : ((hBq + 1) % B)];
+            const float kq2 = row[SIMPLE ? min(hBq + 2, B - 1) : ((hBq + 2) % B)];
+            const float kq3 = row[SIMPLE ? min(hBq + 3, B - 1) : ((hBq + 3) % B)];
+            kq01 = (uint64_t)__float_as_uint(kq0) | ((uint64_t)__float_as_uint(kq1) << 32);
+            kq23 = (uint64_t)__float_as_uint(kq2) | ((uint64_t)__float_as_uint(kq3) << 32);
             blk_tag = want;
         }
         STAMP(4)
@@ -2178,6 +2274,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
         for (int k = 0; k < 11; k++) atomicAdd(&g_seq_stamps[k], (unsigned long long)t_acc[k]);
         atomicAdd(&g_seq_stamps[11], 1ull);
     }
+#undef PMCX_SETTLE
 #undef STAMP
 #undef MASK
 #undef gcnt_g
@@ -3498,6 +3595,7 @@ __global__ void k_test_math(int op, int64_t n, const double *a, const double *b,
         bool ok;
         const float k32 = brown_screen_f32(a[i], b[i], c3[i], c4[i], ef, ok);
         r = (ok && k32 > 1.0e-30f) ? (double)k32 : -1.0;
+        if (ktype == 1000) r = (double)k32; // (test hook: the estimate whether trusted or not)
         break;
     }
     default: break;
