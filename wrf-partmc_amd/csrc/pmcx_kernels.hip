@@ -1777,10 +1777,11 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
         const int g = cl * B + b;
         return (uint32_t)gcnt_g[g] | ((uint32_t)goff_g[g] << 16);
     };
-    // One class: the non-empty bins blo .. blo + 63 as a register word (bit k: bin blo + k), what
-    // the sweep scans.  `far`: some particle lives beyond even that (the general scan serves);
-    // `wide`: some particle lives outside the LDS window (its list length comes from memory).
-    uint64_t wmask = 0;
+    // One class: the non-empty bins blo .. blo + 31 as a register word (bit k: bin blo + k), what
+    // the sweep scans (32 bins are 3.2 decades of radius).  `far`: some particle lives beyond
+    // even that (the general scan serves); `wide`: some particle lives outside the LDS window
+    // (its list length comes from memory).
+    uint32_t wmask = 0;
     bool far = false, wide = false;
     auto cnt_set = [&](int cl, int b, uint32_t e, int n) { // new length n of the group with entry e
         if (in_win(b)) {
@@ -1790,9 +1791,9 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
             if (n > 0) wide = true;
         }
         if (SIMPLE) {
-            if ((unsigned)(b - blo) < 64u) {
-                if (n == 0) wmask &= ~(1ull << (b - blo));
-                else wmask |= 1ull << (b - blo);
+            if ((unsigned)(b - blo) < 32u) {
+                if (n == 0) wmask &= ~(1u << (b - blo));
+                else wmask |= 1u << (b - blo);
             } else if (n > 0) {
                 far = true;
             }
@@ -1845,12 +1846,14 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
     if (SIMPLE) {
         // bins blo .. blo + 63 of the 128-bit mask (m1 : m0), shifted down by blo
         const uint64_t m0 = MASK(0), m1 = MASK(1);
-        if (blo == 0) wmask = m0;
-        else if (blo < 64) wmask = (m0 >> blo) | (m1 << (64 - blo));
-        else wmask = m1 >> (blo - 64);
+        uint64_t w64;
+        if (blo == 0) w64 = m0;
+        else if (blo < 64) w64 = (m0 >> blo) | (m1 << (64 - blo));
+        else w64 = m1 >> (blo - 64);
+        wmask = (uint32_t)w64;
         // (bins below blo hold nothing: blo is the first non-empty bin unless the grid is
-        // narrower than the window; bins from blo + 64 on are beyond the word)
-        far = blo < 64 && (m1 >> blo) != 0;
+        // narrower than the window; bins from blo + 32 on are beyond the word)
+        far = (w64 >> 32) != 0 || (blo < 64 && (m1 >> blo) != 0);
         if (blo > 0 && blo < 64 && (m0 & ((1ull << blo) - 1ull))) far = true;
         if (blo >= 64 && (m0 || (m1 & ((1ull << (blo - 64)) - 1ull)))) far = true;
         wide = far || (wmask >> SEQ_W) != 0;
@@ -2001,13 +2004,13 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
 #pragma unroll
             for (int t = 0; t < NTRY; t++) {
                 if (active) {
-                    // (shifts by 64 are avoided: a position at bit 63 has nothing behind it)
+                    // (shifts by 32 are avoided: a position at bit 31 has nothing behind it)
                     const int p1_ = b1 - blo, p2_ = b2 - blo;
-                    const bool rowok = b1 >= 0 && ((wmask >> p1_) & 1ull);
-                    const uint64_t m = (rowok && p2_ < 63) ? (wmask & (~0ull << (p2_ + 1))) : 0ull;
-                    const uint64_t mr = b1 < 0 ? wmask : (p1_ < 63 ? (wmask & (~0ull << (p1_ + 1))) : 0ull);
-                    const int nb1 = m ? b1 : blo + __builtin_ctzll(mr | 0x8000000000000000ull);
-                    const int nb2 = m ? blo + __builtin_ctzll(m) : nb1;
+                    const bool rowok = b1 >= 0 && ((wmask >> p1_) & 1u);
+                    const uint32_t m = (rowok && p2_ < 31) ? (wmask & (~0u << (p2_ + 1))) : 0u;
+                    const uint32_t mr = b1 < 0 ? wmask : (p1_ < 31 ? (wmask & (~0u << (p1_ + 1))) : 0u);
+                    const int nb1 = m ? b1 : blo + __builtin_ctz(mr | 0x80000000u);
+                    const int nb2 = m ? blo + __builtin_ctz(m) : nb1;
                     if (!m && !mr) { done = true; active = false; }
                     else {
                         const uint32_t tag = ((uint32_t)nb1 << 16) | ((uint32_t)nb2 & ~3u);
@@ -2143,7 +2146,77 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
         STAMP(6)
 
         // ---- (7) coagulate ----
-        if (acc) {
+        // One class, every list inside the window and in perm, room behind the new bin's list:
+        // the event in straight-line code (no weighted removal, no table of entries past a
+        // group's room, no look outside the window).  A lane that misses a condition takes the
+        // general form below.
+        bool gen = acc;
+        if (SIMPLE && !any_wide && __ballot(n_app != 0) == 0) {
+            if (acc) {
+                const double vn = v1 + v2, mn = m1 + m2;
+                const bool big1 = (v1 >= v2);
+                const uint32_t pn = big1 ? p1 : p2, po = big1 ? p2 : p1;
+                int in = big1 ? i1 : i2;
+                const int io = big1 ? i2 : i1;
+                const int b_old = big1 ? b1 : b2, b_o = big1 ? b2 : b1;
+                const uint32_t e_o = big1 ? eB : eA;
+                const int b_new = bin_index(edge, B, vn, st);
+                const bool move = b_new != b_old;
+                const bool in_grid = !(vn < edge[0] || vn >= edge[B]);
+                // (the new bin and the one behind it inside the window: their entries are in LDS)
+                bool ok = n_ev < st.max_events && in_grid &&
+                          (!move || ((unsigned)(b_new - blo) < (unsigned)(SEQ_W - 1) && b_new + 1 < B));
+                uint32_t en = 0;
+                if (ok && move) {
+                    en = ent[(b_new - blo) * 64 + lane];
+                    const uint32_t nxt = ent[(b_new + 1 - blo) * 64 + lane];
+                    ok = (int)(en >> 16) + (int)(en & 0xFFFFu) < (int)(nxt >> 16);
+                }
+                if (ok) {
+                    gen = false;
+                    if (b_new > (KT == KERNEL_BROWN ? (int)envs[6 * 64 + lane] : st.kmax_rng[4 * (int64_t)c + 1]))
+                        status |= ST_KMAX_RANGE; // no bound was computed there
+                    n_ev++;
+                    // swap-with-last removal of the other particle
+                    const int last_o = (int)(e_o & 0xFFFFu) - 1;
+                    if (io != last_o) perm[(e_o >> 16) + io] = big1 ? last2 : last1;
+                    cnt_set(0, b_o, e_o, last_o);
+                    if (same && in == last_o) in = io;
+                    if (move) {
+                        // the merged particle leaves its list (look again when that list just changed)
+                        uint32_t e = big1 ? eA : eB;
+                        uint32_t lastv = big1 ? last1 : last2;
+                        if (same) {
+                            e = (e_o & 0xFFFF0000u) | (uint32_t)last_o;
+                            lastv = perm[(e >> 16) + (last_o > 0 ? last_o - 1 : 0)];
+                        }
+                        const int last = (int)(e & 0xFFFFu) - 1;
+                        if (in != last) perm[(e >> 16) + in] = lastv;
+                        cnt_set(0, b_old, e, last);
+                        // ... and joins the list of its new bin, behind it in perm
+                        const int n = (int)(en & 0xFFFFu);
+                        perm[(en >> 16) + n] = pn;
+                        cnt_set(0, b_new, en, n + 1);
+                    }
+                    *(double2 *)&hot[pn].vtot = make_double2(vn, mn);
+                    {
+                        const double lo_n = big1 ? lct1 : lct2, lo_o = big1 ? lct2 : lct1;
+                        const double go_n = big1 ? gct1 : gct2, go_o = big1 ? gct2 : gct1;
+                        if (lo_o < lo_n) hot[pn].lct = lo_o;
+                        if (go_o > go_n) hot[pn].gct = go_o;
+                        if (NS > 0) cold[pn].n_orig0 = (int32_t)((uint32_t)no1 + (uint32_t)no2);
+                    }
+                    for (int sp = 1; sp < NS; sp++) {
+                        int32_t *a = &norig(st, cb, sp, pn);
+                        *a = (int32_t)((uint32_t)*a + (uint32_t)norig(st, cb, sp, po));
+                    }
+                    hot[po].vtot = -1.0; // tombstone: in the record just read
+                    n_dead++;
+                    tot_coag++;
+                }
+            }
+        }
+        if (gen) {
             do {
                 if (n_ev >= st.max_events) { status |= ST_EVENT_OVERFLOW; done = true; break; }
                 bool rem1 = true, rem2 = true;
