@@ -20,9 +20,9 @@
 //   k_bin_sort     one 256-thread workgroup per cell; stable counting sort of
 //                  the slots by (class, bin) -> perm, gcnt, goff.  Streams
 //                  vtot once: the HBM-bound pass (12 B per particle).
-//   k_coag_seq     the pair sampler for large blocks of cells: ONE LANE PER CELL, every
+//   k_coag_lane    the pair sampler for large blocks of cells: ONE LANE PER CELL, every
 //                  lane runs the sequential PartMC sweep of its own cell; bound by the
-//                  chip's rate of random 64-byte requests.
+//                  instructions a wavefront issues per pass.
 //   k_coag_sample  the pair sampler for small blocks (or many classes): 8, 16 or 64 lanes
 //                  per cell; candidate pairs of the sweep evaluated a window at a time, first
 //                  accepted pair found by ballot, applied, later slots redrawn.
@@ -36,9 +36,6 @@
 
 #include <cstdlib>
 
-#ifndef PMCX_ABLATE
-#define PMCX_ABLATE 0 // TEMPORARY timing hooks (results invalid when non-zero)
-#endif
 #ifndef PMCX_WIN
 #define PMCX_WIN 8 // partner slots per sampler window (lanes-per-cell < 64)
 #endif
@@ -1153,7 +1150,7 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
 constexpr int SEQ_W = 24;      // bins per class with list state in LDS
 constexpr int SEQ_ENV = 7;     // air properties kept per cell
 
-constexpr size_t SEQ_SHARED_BYTES = 64 * (4 * sizeof(uint32_t) + sizeof(double)); // SPLIT: a lane's sweep state
+constexpr size_t SEQ_SHARED_BYTES = 64 * (5 * sizeof(uint32_t) + sizeof(double)); // SPLIT: a lane's sweep state
 
 __host__ __device__ inline size_t seq_lds_bytes(int B, int C)
 {
@@ -1177,511 +1174,22 @@ __device__ unsigned long long g_seq_stamps[12];
 // draws and the class bookkeeping fold away, which is worth registers in the hot loop.
 // KT: the coagulation kernel when known at compile time (COAG_KERNEL_TYPE_BROWN, the one the
 // reference selects, wrf_pmc_driver.F90:192), 0 = chosen at run time.
-// SPLIT: two wavefronts share the 64 cells of a workgroup -- the first evaluates the samples
-// (and coagulates), the second draws the counts -- each executing its own half of the pass.
-// A lane's sweep state (slot, samples left, bound, done) lives in LDS between passes and the
-// lane is worked on by exactly one of the two in a pass (the evaluator while it holds samples,
-// else the drawer), so per lane the sequence of operations is the one of the single
-// wavefront, bit for bit.  For blocks of cells too few to fill the chip: a wavefront alone on
-// its SIMD is bound by the instructions of a pass, and this halves them (launch_coag_sample).
-template <bool STAMPS, bool SIMPLE, int KT, bool SPLIT = false>
-__global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 2 : 3)
-void k_coag_seq(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint32_t step,
-                uint16_t *ovf_mem)
-{
-    uint64_t t_last = 0, t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (STAMPS) t_last = __builtin_amdgcn_s_memtime();
-#define STAMP(k)                                                                                  \
-    if (STAMPS) {                                                                                 \
-        const uint64_t t_now = __builtin_amdgcn_s_memtime();                                      \
-        t_acc[k] += t_now - t_last;                                                               \
-        t_last = t_now;                                                                           \
-    }
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = threadIdx.x & 63;
-    const bool role_e = !SPLIT || (threadIdx.x >> 6) == 0; // evaluates and coagulates
-    const bool role_d = !SPLIT || (threadIdx.x >> 6) == 1; // draws the counts
-    const int cidx = blockIdx.x * 64 + lane;
-    const bool live = cidx < st.n_cells;
-    const int c = live ? cidx : st.n_cells - 1;
-    const int ktype = KT ? KT : ktype_rt;
-    const int B = st.n_bin, C = SIMPLE ? 1 : st.n_class, G = B * C;
-    const int S = SIMPLE ? 1 : st.n_spec, NS = st.n_source;
-    const int64_t cb = (int64_t)c * st.cap;
-    const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
-
-    double *edge = (double *)smem;
-    double *rcp = (double *)(smem + (((size_t)(B + 1) * sizeof(double) + 15) & ~(size_t)15));
-    double *envs = rcp + (POISSON_RCP_N + 2);
-    double *magl = envs + SEQ_ENV * 64;                   // [C][64] weight magnitudes
-    uint64_t *mask = (uint64_t *)(magl + (size_t)C * 64); // [C*2][64]
-    uint32_t *ent = (uint32_t *)(mask + 2 * (size_t)C * 64); // [C*SEQ_W][64]
-    // SPLIT: the sweep state of each lane, handed from one wavefront to the other
-    uint32_t *sh_pos = ent + (size_t)C * SEQ_W * 64;  // c1 | c2 << 8 | (b1 + 1) << 16 | (b2 + 1) << 24
-    uint32_t *sh_ns = sh_pos + 64, *sh_s = sh_ns + 64, *sh_done = sh_s + 64;
-    double *sh_kmax = (double *)(sh_done + 64);
-#define MASK(j) mask[(j) * 64 + lane]
-
-    for (int j = lane; j <= B; j += 64) edge[j] = st.v_edge[j];
-    for (int j = lane; j <= POISSON_RCP_N; j += 64) rcp[j] = g_poisson_rcp[j];
-
-    uint32_t *perm = st.perm + (int64_t)c * st.pcap;
-    Hot *hot = st.hot + cb;    // cached total volume and mass, create times: one line per particle
-    Cold *cold = st.cold + cb; // id, first source count (touched by events with sources only)
-    // (per-lane pointers cost two registers each: the rarely used ones are formed on use)
-#define gcnt_g (st.gcnt + (int64_t)c * G)
-#define goff_g (st.goff + (int64_t)c * (G + 1))
-#define O_ovf_n(g) (ovf_mem[(size_t)c * (2 * (size_t)G + 2 * (size_t)st.max_appends) + (g)])
-#define O_last_app(g) (ovf_mem[(size_t)c * (2 * (size_t)G + 2 * (size_t)st.max_appends) + G + (g)])
-#define O_app_slot(e) (ovf_mem[(size_t)c * (2 * (size_t)G + 2 * (size_t)st.max_appends) + 2 * G + (e)])
-#define O_app_prev(e) (ovf_mem[(size_t)c * (2 * (size_t)G + 2 * (size_t)st.max_appends) + 2 * G + st.max_appends + (e)])
-
-    // non-empty bins of every class; the window starts at the cell's first one
-    int blo = B;
-    for (int cl = 0; cl < C; cl++) {
-        uint64_t m0 = 0, m1 = 0;
-        for (int b = 0; b < B; b++)
-            if (gcnt_g[cl * B + b] > 0) {
-                if (b < 64) m0 |= 1ull << b; else m1 |= 1ull << (b - 64);
-                if (b < blo) blo = b;
-            }
-        MASK(cl * 2) = m0; MASK(cl * 2 + 1) = m1;
-    }
-    if (blo > B - SEQ_W) blo = (B - SEQ_W > 0) ? B - SEQ_W : 0;
-    for (int cl = 0; cl < C; cl++)
-        for (int k = 0; k < SEQ_W; k++) {
-            const int b = blo + k;
-            uint32_t e = 0;
-            if (b < B) e = (uint32_t)gcnt_g[cl * B + b] | ((uint32_t)goff_g[cl * B + b] << 16);
-            ent[(cl * SEQ_W + k) * 64 + lane] = e;
-        }
-    for (int cl = 0; cl < C; cl++) magl[cl * 64 + lane] = st.mag[(int64_t)c * C + cl];
-    {
-        const EnvDerived e = env_derive(st.temp[c], st.pressure[c]);
-        envs[0 * 64 + lane] = e.gasfreepath; envs[1 * 64 + lane] = e.inv_gfp;
-        envs[2 * 64 + lane] = e.c_diff; envs[3 * 64 + lane] = e.c_speed;
-        envs[4 * 64 + lane] = e.c_inv_speed; envs[5 * 64 + lane] = e.c_fall;
-        envs[6 * 64 + lane] = e.rhoair;
-        // The last bin the cell's bounds cover, looked at when an event creates a particle.  The
-        // Brownian kernel does not use the air density: its slot carries it (another 512 bytes
-        // of LDS per wavefront would cost the twelfth wavefront of the CU).
-        if (KT == KERNEL_BROWN) envs[6 * 64 + lane] = (double)st.kmax_rng[4 * (int64_t)c + 1];
-    }
-    __syncthreads(); // one wavefront: orders the edge table
-
-    const KernelParams kp{st.const_k, st.additive_beta};
-
-    // ---- list state: packed entry = count | offset << 16 ----
-    auto in_win = [&](int b) -> bool { return (unsigned)(b - blo) < (unsigned)SEQ_W; };
-    auto ent_get = [&](int cl, int b) -> uint32_t {
-        if (in_win(b)) return ent[(cl * SEQ_W + (b - blo)) * 64 + lane];
-        const int g = cl * B + b;
-        return (uint32_t)gcnt_g[g] | ((uint32_t)goff_g[g] << 16);
-    };
-    auto cnt_set = [&](int cl, int b, uint32_t e, int n) { // new length n of the group with entry e
-        if (in_win(b)) ent[(cl * SEQ_W + (b - blo)) * 64 + lane] = (e & 0xFFFF0000u) | (uint32_t)n;
-        else gcnt_g[cl * B + b] = n;
-        if (n == 0) MASK(cl * 2 + (b >> 6)) &= ~(1ull << (b & 63));
-        else if (n == 1) MASK(cl * 2 + (b >> 6)) |= 1ull << (b & 63);
-    };
-    auto room_end = [&](int cl, int b) -> int { // offset where the room behind the group ends
-        if (b + 1 < B && in_win(b + 1)) return (int)(ent[(cl * SEQ_W + (b + 1 - blo)) * 64 + lane] >> 16);
-        return goff_g[cl * B + b + 1];
-    };
-    // entries beyond a group's room (rare): linked through the per-cell table
-    auto ovf_of = [&](int g, int n_app) -> int { return n_app ? (int)O_ovf_n(g) : 0; };
-    auto list_get = [&](int g, uint32_t e, int i, int n_app) -> uint32_t {
-        const int n = (int)(e & 0xFFFFu), nb = n - ovf_of(g, n_app);
-        if (i < nb) return perm[(e >> 16) + i];
-        int x = O_last_app(g);
-        for (int k = n - 1 - i; k > 0; k--) x = O_app_prev(x);
-        return O_app_slot(x);
-    };
-    auto list_set = [&](int g, uint32_t e, int i, uint32_t val, int n_app) {
-        const int n = (int)(e & 0xFFFFu), nb = n - ovf_of(g, n_app);
-        if (i < nb) {
-            if (!(PMCX_ABLATE & 8)) perm[(e >> 16) + i] = val;
-        } else {
-            int x = O_last_app(g);
-            for (int k = n - 1 - i; k > 0; k--) x = O_app_prev(x);
-            O_app_slot(x) = (uint16_t)val;
-        }
-    };
-    auto next_bin = [&](int cl, int from) -> int { // next non-empty bin >= from, or -1
-        if (from < 64) {
-            const uint64_t w = MASK(cl * 2) & (~0ull << from);
-            if (w) return __builtin_ctzll(w);
-            from = 64;
-        }
-        if (from < 128) {
-            const uint64_t w = MASK(cl * 2 + 1) & (~0ull << (from - 64));
-            if (w) return 64 + __builtin_ctzll(w);
-        }
-        return -1;
-    };
-
-    int n_ev = 0, n_app = 0, n_dead = 0, tot_coag = 0, status = 0;
-    uint64_t tot_samp = 0;
-    int c1 = 0, c2 = 0, b1 = -1, b2 = -1, cc = 0;
-    double n1 = 0, n2 = 0, nmin = 0, fmax = 0, factor = 0, k_max = 0;
-    uint32_t ns_rem = 0, s = 0;
-    bool done = !live;
-    STAMP(0)
-
-    // One draw step of a lane that holds no sample: move to the next slot of the sweep
-    // c1, c2 <= c1, b1, b2 (>= b1 within a class) whose lists can give a pair now, and
-    // request its bound.  Returns false when there is none left (done is set).
-    auto draw_find = [&](uint32_t &eA, uint32_t &eB, double &km) -> bool {
-        bool found = false;
-        while (!found && !done) {
-            if (b1 >= 0) {
-                eA = ent_get(c1, b1);
-                if ((eA & 0xFFFFu) > 0) {
-                    const int nb2 = next_bin(c2, b2 + 1);
-                    if (nb2 >= 0 && nb2 < B) {
-                        b2 = nb2;
-                        const bool same = (c1 == c2 && b1 == b2);
-                        eB = same ? eA : ent_get(c2, b2);
-                        found = !(same && (eA & 0xFFFFu) < 2);
-                        continue;
-                    }
-                }
-            }
-            b1 = next_bin(c1, b1 + 1);
-            if (b1 < 0 || b1 >= B) {
-                b1 = -1;
-                if (++c2 > c1) { c2 = 0; ++c1; }
-                if (c1 >= C) done = true;
-                continue;
-            }
-            b2 = ((c1 == c2) ? b1 : 0) - 1;
-            n1 = magl[c1 * 64 + lane]; n2 = magl[c2 * 64 + lane];
-            cc = (n1 < n2) ? c1 : c2;
-            nmin = (n1 < n2) ? n1 : n2;
-            fmax = (n1 < n2) ? n2 : n1;
-            factor = n1 * n2 / nmin;
-        }
-        if (found) {
-            if (PMCX_ABLATE & 4) km = 2e-15 * (1.0 + 0.01 * (b2 - b1));
-            else km = (double)st.kmax[(int64_t)c * st.kmax_stride + b1 * B + b2];
-        }
-        return found;
-    };
-    // the slot's Poisson count from its uniform u
-    auto draw_count = [&](uint32_t eA, uint32_t eB, double km, double u) {
-        const double nA = (double)(eA & 0xFFFFu), nB = (double)(eB & 0xFFFFu);
-        k_max = km * fmax;
-        const double n_possible = (c1 == c2 && b1 == b2) ? nA * (nA - 1.0) / 2.0 : nA * nB;
-        const double mean = k_max * del_t * n_possible;
-        ns_rem = (uint32_t)poisson(mean, u, rcp);
-        tot_samp += ns_rem;
-        s = 0;
-    };
-
-    // Every pass of the loop a lane either evaluates one sample (and coagulates the pair when
-    // accepted) or, holding none, draws the counts of up to two slots.  The memory requests
-    // of one kind of lane are issued before the arithmetic of the other kind, so that each
-    // wait of the wavefront is covered by work: list entries | first draw's search and
-    // Philox -> volumes, masses and event data | first Poisson, second search and Philox ->
-    // kernel evaluation, second Poisson, coagulation.
-    if (SPLIT) { // (both wavefronts write the same values)
-        sh_pos[lane] = 0; sh_ns[lane] = 0; sh_s[lane] = 0; sh_done[lane] = done; sh_kmax[lane] = 0.0;
-        __syncthreads();
-    }
-    while (true) {
-        bool own = true; // SPLIT: this wavefront works on the lane in this pass
-        if (SPLIT) {
-            const uint32_t pk = sh_pos[lane];
-            c1 = (int)(pk & 255u); c2 = (int)((pk >> 8) & 255u);
-            b1 = (int)((pk >> 16) & 255u) - 1; b2 = (int)(pk >> 24) - 1;
-            ns_rem = sh_ns[lane]; s = sh_s[lane]; done = sh_done[lane] != 0; k_max = sh_kmax[lane];
-            // what draw_find derives from the classes of the slot
-            n1 = magl[(c1 < C ? c1 : C - 1) * 64 + lane]; n2 = magl[(c2 < C ? c2 : C - 1) * 64 + lane];
-            cc = (n1 < n2) ? c1 : c2;
-            nmin = (n1 < n2) ? n1 : n2;
-            fmax = (n1 < n2) ? n2 : n1;
-            factor = n1 * n2 / nmin;
-            own = !done && (role_e ? ns_rem > 0 : ns_rem == 0);
-        }
-        if (__ballot(!done) == 0) break;
-        if (STAMPS) t_acc[10]++;
-
-        // ---- (1) evaluating lanes: the sample's pair, list entries requested ----
-        bool evalid = false, acc = false;
-        int i1 = 0, i2 = 0;
-        uint32_t p1 = 0, p2 = 0, s_ev = 0, eA = 0, eB = 0;
-        uint32_t last1 = 0, last2 = 0;          // entries at the ends of the two lists
-        double u_acc = 0;
-        const int gA = c1 * B + b1, gB = c2 * B + b2;
-        const bool same = (gA == gB);
-        if (role_e && own && !done && ns_rem > 0) {
-            eA = ent_get(c1, b1);
-            eB = same ? eA : ent_get(c2, b2);
-            const int nA = (int)(eA & 0xFFFFu), nB = (int)(eB & 0xFFFFu);
-            if (nA < 1 || nB < 1 || (same && nA < 2)) {
-                ns_rem = 0; // a list ran out: the slot ends (the lane draws below)
-            } else {
-                uint32_t w[4];
-                rng_block(seed, cell_id, step, ((uint32_t)gA << 16) | (uint32_t)gB, SITE_CAND, s, w);
-                i1 = (int)index_of(w[0], (uint32_t)nA);
-                if (same) {
-                    i2 = (int)index_of(w[1], (uint32_t)(nA - 1));
-                    if (i2 >= i1) i2++;
-                } else {
-                    i2 = (int)index_of(w[1], (uint32_t)nB);
-                }
-                u_acc = u53(w[2], w[3]);
-                if (n_app == 0) { // every entry sits in perm
-                    if (PMCX_ABLATE & 32) {
-                        p1 = (uint32_t)(((eA >> 16) + i1) % st.cap); p2 = (uint32_t)(((eB >> 16) + i2) % st.cap);
-                    } else {
-                    p1 = perm[(eA >> 16) + i1];
-                    p2 = perm[(eB >> 16) + i2];
-                    }
-                    if (PMCX_ABLATE & 1) { last1 = p1; last2 = p2; } else {
-                    last1 = perm[(eA >> 16) + nA - 1];
-                    last2 = perm[(eB >> 16) + nB - 1];
-                    }
-                } else {
-                    p1 = list_get(gA, eA, i1, n_app);
-                    p2 = list_get(gB, eB, i2, n_app);
-                    last1 = list_get(gA, eA, nA - 1, n_app);
-                    last2 = list_get(gB, eB, nB - 1, n_app);
-                }
-                evalid = true;
-            }
-        }
-
-        // ---- (2) drawing lanes: first slot, bound requested, Philox ----
-        const bool drawing = role_d && own && !done && !evalid && ns_rem == 0;
-        uint32_t dA = 0, dB = 0;
-        double km = 0, u_d = 0;
-        bool found = false;
-        STAMP(1)
-        if (drawing) {
-            if (STAMPS) t_acc[9]++;
-            found = draw_find(dA, dB, km);
-            if (found) {
-                u_d = poisson_uniform(seed, cell_id, step, (uint32_t)(c1 * B + b1), (uint32_t)(c2 * B + b2));
-            }
-        }
-        STAMP(2)
-
-        // ---- (3) evaluating lanes: volumes, masses and what a coagulation will need ----
-        double v1 = 0, v2 = 0, m1 = 0, m2 = 0;
-        double vol1 = 0, vol2 = 0, lct1 = 0, lct2 = 0, gct1 = 0, gct2 = 0; // first species, times
-        int32_t no1 = 0, no2 = 0;               // first source
-        if (evalid) {
-            // the record's two 16-byte halves: everything a pair evaluation and a coagulation
-            // need of a particle sits in one 32-byte record, one line
-            const double2 a1 = *(const double2 *)&hot[p1].vtot, a2 = *(const double2 *)&hot[p2].vtot;
-            double2 t1 = make_double2(0.0, 0.0), t2 = t1;
-            if (!(PMCX_ABLATE & 2)) { t1 = *(const double2 *)&hot[p1].lct; t2 = *(const double2 *)&hot[p2].lct; }
-            v1 = a1.x; m1 = a1.y; v2 = a2.x; m2 = a2.y;
-            lct1 = t1.x; gct1 = t1.y; lct2 = t2.x; gct2 = t2.y;
-            // (with one species the volume of that species IS the cached total: both are sums
-            // of the same terms)
-            if (S > 1) { vol1 = st.vol[(cb + p1) * S]; vol2 = st.vol[(cb + p2) * S]; }
-            if (NS > 0) { no1 = cold[p1].n_orig0; no2 = cold[p2].n_orig0; }
-        }
-
-        STAMP(3)
-        // ---- (4) drawing lanes: first count; still empty-handed: second slot ----
-        bool found2 = false;
-        if (drawing) {
-            if (found) draw_count(dA, dB, km, u_d);
-            if (!done && ns_rem == 0) {
-                if (STAMPS) t_acc[9]++;
-                found2 = draw_find(dA, dB, km);
-                if (found2) {
-                    u_d = poisson_uniform(seed, cell_id, step, (uint32_t)(c1 * B + b1), (uint32_t)(c2 * B + b2));
-                }
-            }
-        }
-        STAMP(4)
-
-        // ---- (5) evaluating lanes: kernel, accept ----
-        if (evalid) {
-            EnvDerived env;
-            env.gasfreepath = envs[0 * 64 + lane]; env.inv_gfp = envs[1 * 64 + lane];
-            env.c_diff = envs[2 * 64 + lane]; env.c_speed = envs[3 * 64 + lane];
-            env.c_inv_speed = envs[4 * 64 + lane]; env.c_fall = envs[5 * 64 + lane];
-            env.rhoair = envs[6 * 64 + lane];
-            const PartProps qa = props_for(ktype, v1, m1, env);
-            const PartProps qb = props_for(ktype, v2, m2, env);
-            const double k = kernel_pair(ktype, v1, v2, qa, qb, kp);
-            const double kf = k * factor;
-            if (kf > k_max) status |= ST_KMAX_EXCEEDED;
-            acc = u_acc * k_max < kf;
-            s_ev = s;
-            s++;
-            ns_rem--;
-        }
-        STAMP(5)
-        // ---- (6) drawing lanes: second count ----
-        if (found2) draw_count(dA, dB, km, u_d);
-        STAMP(6)
-
-        // ---- (7) coagulate ----
-        if (acc) {
-            do {
-                if (n_ev >= st.max_events) { status |= ST_EVENT_OVERFLOW; done = true; break; }
-                bool rem1 = true, rem2 = true;
-                if (n1 != n2) {
-                    uint32_t w[4];
-                    rng_block(seed, cell_id, step, ((uint32_t)gA << 16) | (uint32_t)gB, SITE_COAG,
-                              s_ev, w);
-                    rem1 = u53(w[0], w[1]) < nmin / n1;
-                    rem2 = u53(w[2], w[3]) < nmin / n2;
-                }
-                const double vn = v1 + v2, mn = m1 + m2;
-                const bool big1 = (v1 >= v2);
-                const bool pn_is_1 = (rem1 && rem2) ? big1 : rem1;
-                const uint32_t pn = pn_is_1 ? p1 : p2, po = pn_is_1 ? p2 : p1;
-                const bool rem_o = pn_is_1 ? rem2 : rem1;
-                int in = pn_is_1 ? i1 : i2;
-                const int io = pn_is_1 ? i2 : i1;
-                // the merged particle's list (old) and the other particle's list (o)
-                const int cl_old = pn_is_1 ? c1 : c2, b_old = pn_is_1 ? b1 : b2;
-                const int cl_o = pn_is_1 ? c2 : c1, b_o = pn_is_1 ? b2 : b1;
-                const int g_old = cl_old * B + b_old, g_o = cl_o * B + b_o;
-                if (vn < edge[0] || vn >= edge[B]) status |= ST_OUT_OF_GRID;
-                const int b_new = bin_index(edge, B, vn, st);
-                if (b_new > (KT == KERNEL_BROWN ? (int)envs[6 * 64 + lane] : st.kmax_rng[4 * (int64_t)c + 1]))
-                    status |= ST_KMAX_RANGE; // no bound was computed there
-                const int g_new = cc * B + b_new;
-                if (g_new != g_old && n_app >= st.max_appends) {
-                    status |= ST_APPEND_OVERFLOW; done = true; break;
-                }
-                n_ev++;
-                if (rem_o) { // swap-with-last removal of the other particle
-                    const uint32_t e = pn_is_1 ? eB : eA;
-                    const int last = (int)(e & 0xFFFFu) - 1;
-                    if (io != last) list_set(g_o, e, io, pn_is_1 ? last2 : last1, n_app);
-                    if (ovf_of(g_o, n_app) > 0) {
-                        O_last_app(g_o) = O_app_prev(O_last_app(g_o));
-                        O_ovf_n(g_o) = (uint16_t)(O_ovf_n(g_o) - 1);
-                    }
-                    cnt_set(cl_o, b_o, e, last);
-                    if (same && in == last) in = io;
-                }
-                if (g_new != g_old) {
-                    // the merged particle leaves its list ...
-                    uint32_t e = pn_is_1 ? eA : eB;
-                    uint32_t lastv = pn_is_1 ? last1 : last2;
-                    if (same && rem_o) { // the list just changed: look again
-                        e = ent_get(cl_old, b_old);
-                        lastv = list_get(g_old, e, (int)(e & 0xFFFFu) - 1, n_app);
-                    }
-                    const int last = (int)(e & 0xFFFFu) - 1;
-                    if (in != last) list_set(g_old, e, in, lastv, n_app);
-                    if (ovf_of(g_old, n_app) > 0) {
-                        O_last_app(g_old) = O_app_prev(O_last_app(g_old));
-                        O_ovf_n(g_old) = (uint16_t)(O_ovf_n(g_old) - 1);
-                    }
-                    cnt_set(cl_old, b_old, e, last);
-                    // ... and joins the list of its new bin: behind it in perm while there is
-                    // room (and nothing of the group sits in the table already), else the table
-                    const uint32_t en = ent_get(cc, b_new);
-                    const int n = (int)(en & 0xFFFFu), o = (int)(en >> 16);
-                    if (ovf_of(g_new, n_app) == 0 && o + n < room_end(cc, b_new)) {
-                        if (!(PMCX_ABLATE & 8)) perm[o + n] = pn;
-                    } else {
-                        if (n_app == 0) // first use of the table in this call
-                            for (int k = 0; k < G; k++) { O_ovf_n(k) = 0; O_last_app(k) = 0xFFFF; }
-                        O_app_slot(n_app) = (uint16_t)pn;
-                        O_app_prev(n_app) = O_last_app(g_new);
-                        O_last_app(g_new) = (uint16_t)n_app;
-                        O_ovf_n(g_new) = (uint16_t)(O_ovf_n(g_new) + 1);
-                        n_app++;
-                    }
-                    cnt_set(cc, b_new, en, n + 1);
-                }
-                if (!(PMCX_ABLATE & 8)) *(double2 *)&hot[pn].vtot = make_double2(vn, mn);
-                // species volumes, source histogram, create times, class [aero_particle_coagulate]
-                if (S > 1) st.vol[(cb + pn) * S] = (pn_is_1 ? vol1 : vol2) + (pn_is_1 ? vol2 : vol1);
-                for (int s0 = 1; s0 < S; s0 += 4) { // four species' loads in flight
-                    double a[4], b[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        if (s0 + k < S) {
-                            a[k] = st.vol[(cb + pn) * S + (s0 + k)];
-                            b[k] = st.vol[(cb + po) * S + (s0 + k)];
-                        }
-#pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        if (s0 + k < S)
-                            st.vol[(cb + pn) * S + (s0 + k)] = a[k] + b[k];
-                }
-                for (int sp = 1; sp < NS; sp++) {
-                    int32_t *a = &norig(st, cb, sp, pn);
-                    *a = (int32_t)((uint32_t)*a + (uint32_t)norig(st, cb, sp, po));
-                }
-                {   // create times and first source count share the particle's metadata record
-                    const double lo_n = pn_is_1 ? lct1 : lct2, lo_o = pn_is_1 ? lct2 : lct1;
-                    const double go_n = pn_is_1 ? gct1 : gct2, go_o = pn_is_1 ? gct2 : gct1;
-                    if (lo_o < lo_n) hot[pn].lct = lo_o;
-                    if (go_o > go_n) hot[pn].gct = go_o;
-                    if (NS > 0) cold[pn].n_orig0 = (int32_t)((uint32_t)no1 + (uint32_t)no2);
-                }
-                if (C > 1) st.wclass[cb + pn] = cc;
-                if (rem_o) { if (!(PMCX_ABLATE & 8)) hot[po].vtot = -1.0; n_dead++; } // tombstone: in the record just read
-                tot_coag++;
-            } while (false);
-        }
-        if (done) ns_rem = 0;
-        if (SPLIT) {
-            if (own) {
-                sh_pos[lane] = (uint32_t)c1 | ((uint32_t)c2 << 8) | ((uint32_t)(b1 + 1) << 16) |
-                               ((uint32_t)(b2 + 1) << 24);
-                sh_ns[lane] = ns_rem; sh_s[lane] = s; sh_done[lane] = done; sh_kmax[lane] = k_max;
-            }
-            __syncthreads(); // the other wavefront's lanes and list updates, before the next pass
-        }
-        STAMP(7)
-    }
-
-    if (live && role_d) // (the drawer counts the samples)
-        st.n_samp[c] = tot_samp > 0x7FFFFFFFull ? 0x7FFFFFFF : (int32_t)tot_samp;
-    if (live && role_e) {
-        for (int cl = 0; cl < C; cl++)
-            for (int k = 0; k < SEQ_W && blo + k < B; k++)
-                gcnt_g[cl * B + blo + k] = (int32_t)(ent[(cl * SEQ_W + k) * 64 + lane] & 0xFFFFu);
-        if (n_app) {
-            bool ovf = false;
-            for (int g = 0; g < G; g++) ovf |= O_ovf_n(g) != 0;
-            if (ovf) st.sort_valid[c] = 0;
-        }
-        st.n_events[c] = n_ev;
-        st.n_part[c] = st.n_part[c] - n_dead;
-        st.n_coag[c] = tot_coag;
-        if (status) atomicOr(&st.status[c], status);
-    }
-    STAMP(8)
-    if (STAMPS && lane == 0) {
-        for (int k = 0; k < 11; k++) atomicAdd(&g_seq_stamps[k], (unsigned long long)t_acc[k]);
-        atomicAdd(&g_seq_stamps[11], 1ull);
-    }
-#undef STAMP
-#undef MASK
-#undef gcnt_g
-#undef goff_g
-#undef O_ovf_n
-#undef O_last_app
-#undef O_app_slot
-#undef O_app_prev
-}
 
 // ---------------------------------------- coag sampler, lane per cell, block-wise draws
 //
-// k_coag_lane: the sweep of k_coag_seq with the draw side rebuilt around what bounds the kernel
-// once its memory requests were cut -- the instructions a wavefront issues per pass (stamped:
-// more than half of a pass went into finding slots and drawing their counts, one Philox block
-// and one exponential per slot).  Here a lane caches the Philox block and the four bounds of the
-// partner bins gB & ~3 it is sweeping, settles up to four slots per pass with a compare each
-// (count surely zero), takes the exact Poisson count only for a slot that fails the compare, and
-// decides the accept test of a Brownian pair from a single-precision estimate whenever the
-// fp64 kernel cannot decide differently (pmcx_device_math.h).  Same results, bit for bit.
+// k_coag_lane.  What bounds this kernel, once its memory requests were cut (one 32-byte record
+// per particle), is the instructions a wavefront issues per pass: stamped (PMCX_SEQ_STAMPS),
+// more than half of a pass went into finding slots and drawing their counts -- a Philox block
+// and an exponential per slot, and a scan through LDS bit masks in nested divergent loops.
+// Hence: a lane caches the Philox block and the four bounds of the partner bins gB & ~3 it is
+// sweeping; with one class it scans a register word of the non-empty bins in straight-line
+// code and settles up to NTRY slots per pass with a compare each (count surely zero); the
+// exact Poisson count is taken only for a slot that fails the compare; the accept test of a
+// Brownian pair is decided from a single-precision estimate whenever the fp64 kernel cannot
+// decide differently (pmcx_device_math.h); the usual event runs in straight-line code.
+// Select chains over scalars and by-reference lambda captures are avoided in the loop: the
+// compiler turns them into tables and closures in scratch memory, a round trip per use.
+// Same results as the oracle's sequential sweep, bit for bit.
 
 #ifndef PMCX_NTRY
 #define PMCX_NTRY 4
@@ -1689,8 +1197,15 @@ void k_coag_seq(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint3
 #ifndef PMCX_LANE_WAVES
 #define PMCX_LANE_WAVES 3
 #endif
-template <bool STAMPS, bool SIMPLE, int KT>
-__global__ __launch_bounds__(64, PMCX_LANE_WAVES)
+// SPLIT: two wavefronts share the 64 cells of a workgroup -- the first evaluates the samples and
+// coagulates (stages 1, 3, 5, 7), the second settles the slots (stages 2, 4) -- for blocks of
+// cells too few to fill the chip, where a wavefront alone on its SIMD is bound by the
+// instructions of its own pass.  What both need of a lane (position, samples left, bound, the
+// window word) lives in LDS between passes; in a pass a lane is worked on by exactly one of the
+// two (the evaluator while it holds samples, else the drawer), one barrier per pass: per lane
+// the sequence of operations, and every result, is the single wavefront's.
+template <bool STAMPS, bool SIMPLE, int KT, bool SPLIT = false>
+__global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 2 : PMCX_LANE_WAVES)
 void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint32_t step,
                 uint16_t *ovf_mem)
 {
@@ -1704,6 +1219,8 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
     }
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63;
+    const bool role_e = !SPLIT || (threadIdx.x >> 6) == 0; // evaluates and coagulates
+    const bool role_d = !SPLIT || (threadIdx.x >> 6) == 1; // settles the slots
     const int cidx = blockIdx.x * 64 + lane;
     const bool live = cidx < st.n_cells;
     const int c = live ? cidx : st.n_cells - 1;
@@ -1719,6 +1236,10 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
     double *magl = envs + SEQ_ENV * 64;                   // [C][64] weight magnitudes
     uint64_t *mask = (uint64_t *)(magl + (size_t)C * 64); // [C*2][64]
     uint32_t *ent = (uint32_t *)(mask + 2 * (size_t)C * 64); // [C*SEQ_W][64]
+    // SPLIT: what the two wavefronts hand each other
+    uint32_t *sh_pos = ent + (size_t)C * SEQ_W * 64;  // c1 | c2 << 8 | (b1 + 1) << 16 | (b2 + 1) << 24
+    uint32_t *sh_ns = sh_pos + 64, *sh_s = sh_ns + 64, *sh_flag = sh_s + 64, *sh_wmask = sh_flag + 64;
+    double *sh_kmax = (double *)(sh_wmask + 64);
 #define MASK(j) mask[(j) * 64 + lane]
 
     for (int j = lane; j <= B; j += 64) edge[j] = st.v_edge[j];
@@ -1817,7 +1338,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
     auto list_set = [&](int g, uint32_t e, int i, uint32_t val, int n_app) {
         const int n = (int)(e & 0xFFFFu), nb = n - ovf_of(g, n_app);
         if (i < nb) {
-            if (!(PMCX_ABLATE & 8)) perm[(e >> 16) + i] = val;
+            perm[(e >> 16) + i] = val;
         } else {
             int x = O_last_app(g);
             for (int k = n - 1 - i; k > 0; k--) x = O_app_prev(x);
@@ -1914,7 +1435,31 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
     // fails it takes the exact count, and a lane that leaves its block fetches the next one (one
     // Philox block, four bounds) for the following pass.  Memory requests of one kind of lane
     // are issued before the arithmetic of the other kind.
+    if (SPLIT) { // (both wavefronts write the same values)
+        sh_pos[lane] = 0; sh_ns[lane] = 0; sh_s[lane] = 0; sh_kmax[lane] = 0.0;
+        sh_flag[lane] = (done ? 1u : 0u) | (far ? 2u : 0u) | (wide ? 4u : 0u);
+        sh_wmask[lane] = wmask;
+        __syncthreads();
+    }
     while (true) {
+        bool own = true; // SPLIT: this wavefront works on the lane in this pass
+        if (SPLIT) {
+            const uint32_t pk = sh_pos[lane], fl = sh_flag[lane];
+            c1 = (int)(pk & 255u); c2 = (int)((pk >> 8) & 255u);
+            b1 = (int)((pk >> 16) & 255u) - 1; b2 = (int)(pk >> 24) - 1;
+            ns_rem = sh_ns[lane]; s = sh_s[lane]; k_max = sh_kmax[lane];
+            done = (fl & 1u) != 0; far = (fl & 2u) != 0; wide = (fl & 4u) != 0;
+            wmask = sh_wmask[lane];
+            if (!SIMPLE) { // what the scan derives from the classes of the slot
+                n1 = magl[(c1 < C ? c1 : C - 1) * 64 + lane]; n2 = magl[(c2 < C ? c2 : C - 1) * 64 + lane];
+                cc = (n1 < n2) ? c1 : c2;
+                nmin = (n1 < n2) ? n1 : n2;
+                fmax = (n1 < n2) ? n2 : n1;
+                factor = n1 * n2 / nmin;
+                rc1 = c1; rc2 = c2;
+            }
+            own = !done && (role_e ? ns_rem > 0 : ns_rem == 0);
+        }
         if (__ballot(!done) == 0) break;
         if (STAMPS) t_acc[10]++;
         // (uniform: they pick the scan and the list-length reads for the whole wavefront)
@@ -1929,7 +1474,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
         double u_acc = 0;
         const int gA = c1 * B + b1, gB = c2 * B + b2;
         const bool same = (gA == gB);
-        if (!done && ns_rem > 0) {
+        if (role_e && own && !done && ns_rem > 0) {
             if (SIMPLE && !any_wide) {
                 eA = ent[(b1 - blo) * 64 + lane];
                 eB = same ? eA : ent[(b2 - blo) * 64 + lane];
@@ -1952,16 +1497,10 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                 }
                 u_acc = u53(w[2], w[3]);
                 if (n_app == 0) { // every entry sits in perm
-                    if (PMCX_ABLATE & 32) {
-                        p1 = (uint32_t)(((eA >> 16) + i1) % st.cap); p2 = (uint32_t)(((eB >> 16) + i2) % st.cap);
-                    } else {
                     p1 = perm[(eA >> 16) + i1];
                     p2 = perm[(eB >> 16) + i2];
-                    }
-                    if (PMCX_ABLATE & 1) { last1 = p1; last2 = p2; } else {
                     last1 = perm[(eA >> 16) + nA - 1];
                     last2 = perm[(eB >> 16) + nB - 1];
-                    }
                 } else {
                     p1 = list_get(gA, eA, i1, n_app);
                     p2 = list_get(gB, eB, i2, n_app);
@@ -1975,7 +1514,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
         STAMP(1)
 
         // ---- (2) drawing lanes: settle slots inside the cached block ----
-        const bool drawing = !done && !evalid && ns_rem == 0;
+        const bool drawing = role_d && own && !done && !evalid && ns_rem == 0;
         bool pending = false;            // a slot whose count needs the exact Poisson
         double p_mean = 0, p_u = 0;
         uint32_t want = TAG_NONE;        // the block of the next slot, when it is not the cached one
@@ -2069,8 +1608,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
             // the record's two 16-byte halves: everything a pair evaluation and a coagulation
             // need of a particle sits in one 32-byte record, one line
             const double2 a1 = *(const double2 *)&hot[p1].vtot, a2 = *(const double2 *)&hot[p2].vtot;
-            double2 t1 = make_double2(0.0, 0.0), t2 = t1;
-            if (!(PMCX_ABLATE & 2)) { t1 = *(const double2 *)&hot[p1].lct; t2 = *(const double2 *)&hot[p2].lct; }
+            const double2 t1 = *(const double2 *)&hot[p1].lct, t2 = *(const double2 *)&hot[p2].lct;
             v1 = a1.x; m1 = a1.y; v2 = a2.x; m2 = a2.y;
             lct1 = t1.x; gct1 = t1.y; lct2 = t2.x; gct2 = t2.y;
             // (with one species the volume of that species IS the cached total: both are sums
@@ -2278,7 +1816,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                     const uint32_t en = ent_get(cc, b_new);
                     const int n = (int)(en & 0xFFFFu), o = (int)(en >> 16);
                     if (ovf_of(g_new, n_app) == 0 && o + n < room_end(cc, b_new)) {
-                        if (!(PMCX_ABLATE & 8)) perm[o + n] = pn;
+                        perm[o + n] = pn;
                     } else {
                         if (n_app == 0) // first use of the table in this call
                             for (int k = 0; k < G; k++) { O_ovf_n(k) = 0; O_last_app(k) = 0xFFFF; }
@@ -2290,7 +1828,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                     }
                     cnt_set(cc, b_new, en, n + 1);
                 }
-                if (!(PMCX_ABLATE & 8)) *(double2 *)&hot[pn].vtot = make_double2(vn, mn);
+                *(double2 *)&hot[pn].vtot = make_double2(vn, mn);
                 // species volumes, source histogram, create times, class [aero_particle_coagulate]
                 if (S > 1) st.vol[(cb + pn) * S] = (pn_is_1 ? vol1 : vol2) + (pn_is_1 ? vol2 : vol1);
                 for (int s0 = 1; s0 < S; s0 += 4) { // four species' loads in flight
@@ -2318,17 +1856,28 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                     if (NS > 0) cold[pn].n_orig0 = (int32_t)((uint32_t)no1 + (uint32_t)no2);
                 }
                 if (C > 1) st.wclass[cb + pn] = cc;
-                if (rem_o) { if (!(PMCX_ABLATE & 8)) hot[po].vtot = -1.0; n_dead++; } // tombstone: in the record just read
+                if (rem_o) { hot[po].vtot = -1.0; n_dead++; } // tombstone: in the record just read
                 tot_coag++;
             } while (false);
         }
         if (done) ns_rem = 0;
+        if (SPLIT) {
+            if (own) {
+                sh_pos[lane] = (uint32_t)c1 | ((uint32_t)c2 << 8) | ((uint32_t)(b1 + 1) << 16) |
+                               ((uint32_t)(b2 + 1) << 24);
+                sh_ns[lane] = ns_rem; sh_s[lane] = s; sh_kmax[lane] = k_max;
+                sh_flag[lane] = (done ? 1u : 0u) | (far ? 2u : 0u) | (wide ? 4u : 0u);
+                if (role_e) sh_wmask[lane] = wmask;
+            }
+            __syncthreads(); // the other wavefront's lanes and list updates, before the next pass
+        }
         STAMP(7)
     }
 
-    if (live)
+    if (live && role_d) // (the drawer counts the samples)
         st.n_samp[c] = tot_samp > 0x7FFFFFFFull ? 0x7FFFFFFF : (int32_t)tot_samp;
-    if (live) {
+    if (live && !role_e && status) atomicOr(&st.status[c], status);
+    if (live && role_e) {
         for (int cl = 0; cl < C; cl++)
             for (int k = 0; k < SEQ_W && blo + k < B; k++)
                 gcnt_g[cl * B + blo + k] = (int32_t)(ent[(cl * SEQ_W + k) * 64 + lane] & 0xFFFFu);
@@ -3875,13 +3424,13 @@ hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, ui
         const size_t lds = seq_lds_bytes(st.n_bin, st.n_class) + SEQ_SHARED_BYTES;
         const bool simple = st.n_spec == 1 && st.n_class == 1;
         if (simple && ktype == KERNEL_BROWN)
-            hipLaunchKernelGGL((k_coag_seq<false, true, KERNEL_BROWN, true>), grid, block, lds, s, st,
+            hipLaunchKernelGGL((k_coag_lane<false, true, KERNEL_BROWN, true>), grid, block, lds, s, st,
                                ktype, del_t, seed, step, st.seq_ovf);
         else if (ktype == KERNEL_BROWN)
-            hipLaunchKernelGGL((k_coag_seq<false, false, KERNEL_BROWN, true>), grid, block, lds, s, st,
+            hipLaunchKernelGGL((k_coag_lane<false, false, KERNEL_BROWN, true>), grid, block, lds, s, st,
                                ktype, del_t, seed, step, st.seq_ovf);
         else
-            hipLaunchKernelGGL((k_coag_seq<false, false, 0, true>), grid, block, lds, s, st, ktype,
+            hipLaunchKernelGGL((k_coag_lane<false, false, 0, true>), grid, block, lds, s, st, ktype,
                                del_t, seed, step, st.seq_ovf);
         return hipGetLastError();
     }
