@@ -107,8 +107,25 @@ def host_cpu_info():
         allowed = len(os.sched_getaffinity(0))
     except AttributeError:
         allowed = os.cpu_count() or 1
+    # the container's CPU quota (cgroup v2 cpu.max "quota period", v1 cfs_quota_us / cfs_period_us):
+    # more runnable processes than this only share the same cores
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = int(q) / int(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota:
+        allowed = max(1, min(allowed, int(quota)))
     return dict(model=model, sockets=max(len(sockets), 1), logical_cores=logical or (os.cpu_count() or 1),
-                allowed_cores=allowed)
+                allowed_cores=allowed, cpu_quota=quota)
 
 
 _BARRIER = None
@@ -173,7 +190,7 @@ def cpu_baseline(args, n_cells_total):
                   f"step, {cores} processes stepping together from a barrier (oracle/pmco.c, {flags}; "
                   "set-up and warm-up excluded)",
         "cpu_model": info["model"], "sockets": info["sockets"], "logical_cores": info["logical_cores"],
-        "allowed_cores": info["allowed_cores"],
+        "allowed_cores": info["allowed_cores"], "cpu_quota_cores": info["cpu_quota"],
         "particle_steps_per_sec": parts / step_wall,
         "single_thread_events_per_sec": single,
         "single_thread_sample": f"{n1} cells x 8 steps, {one['step_s']:.2f} s",
@@ -412,12 +429,16 @@ def main():
     # false), so that every cell is sorted again on every step.
     resort = None
     if args.resort_steps > 0:
+        blk.invalidate_sort()        # warm-up: the keys are computed from the records once
+        one_step(step)
+        step += 1
+        blk.read_accumulated(reset=True)
         blk.profile_enable(True)
         blk.profile_reset()
         barrier()
         t1 = time.perf_counter()
         for _ in range(args.resort_steps):
-            blk.invalidate_sort()
+            blk.invalidate_lists()   # (the slots' sort keys hold: what transport or deposition leave)
             one_step(step)
             step += 1
         barrier()

@@ -416,6 +416,15 @@ int pmcx_sort_only(pmcx_ctx *ctx);
 /* aero_state%valid_sort = .false. for every cell (what a host-side edit of the
  * particles implies; also used to time the sort on every step) */
 int pmcx_invalidate_sort(pmcx_ctx *ctx);
+/* The lists only: the library keeps, per slot, the sort key (group, or "tombstone") it was
+ * last binned under, and a kernel that changes a population while keeping those keys current
+ * leaves exactly this behind -- lists to be rebuilt from keys that hold.  The next sort then
+ * streams 2 bytes per particle instead of the particle records (also used to time that). */
+int pmcx_invalidate_lists(pmcx_ctx *ctx);
+/* inspection (tests): the keys of one cell [cap], whether they hold, the pending event log of
+ * the pair sampler [256] (slot | key << 16) and its length; any pointer may be NULL */
+int pmcx_get_keys(pmcx_ctx *ctx, int32_t cell, uint16_t *gkey, int32_t *key_valid, uint32_t *evlog,
+                  int32_t *n_log);
 int pmcx_get_sort(pmcx_ctx *ctx, int32_t cell, uint32_t *perm, int32_t *gcnt,
                   int32_t *goff);
 

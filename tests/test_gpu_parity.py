@@ -547,6 +547,51 @@ def test_sort_persists_between_calls(wp, oracle):
     blk.close()
 
 
+def test_sort_from_kept_keys(wp, oracle):
+    """The slots' sort keys persist between sorts; the pair sampler logs the slots it re-bins or
+    removes; a sort that only has to rebuild the lists (pmcx_invalidate_lists: what a kernel
+    that keeps the keys current leaves behind) streams the keys and applies the log.  Held to
+    the definition: after every such sort the keys, the lists and the following mc_coag equal
+    what a sort from the particle records gives (the oracle), also when a slot is logged more
+    than once, when the log runs over, and across a compaction."""
+    blk, cells = _ragged_pair(wp, oracle, [3000, 1500, 200, 0, 2500], n_spec=1, n_class=2,
+                              max_events=4096, max_appends=256, compact_den=4)
+    B, cap = blk.cfg.n_bin, blk.cfg.cap
+    ve, _ = blk.bin_tables()
+    saw_log, saw_overflow = False, False
+    for step in range(12):
+        if step % 3 == 2 or step > 8:        # lists rebuilt from kept keys (+ log)
+            for c in range(len(cells)):
+                k, valid, lg = blk.get_keys(c)
+                saw_log |= valid == 1 and len(lg) > 0
+                saw_overflow |= valid == 0
+            blk.invalidate_lists()
+            for oc in cells:
+                oc.sort_valid[0] = 0
+        ns, nc, st = blk.mc_coag(K_BROWN, 2500.0, 9, step)
+        for c, oc in enumerate(cells):
+            ost, ons, onc = oc.mc_coag(K_BROWN, 2500.0, 9, c, step)
+            assert (ons, onc, ost) == (int(ns[c]), int(nc[c]), int(st[c])), (step, c)
+    assert saw_log and saw_overflow
+    # the keys as the definition gives them, right after a sort
+    blk.invalidate_lists()
+    blk.sort_only()
+    for c, oc in enumerate(cells):
+        k, valid, lg = blk.get_keys(c)
+        assert valid == 1 and len(lg) == 0
+        vt, _ = blk.caches(c)                # (closes the holes: slot order of the oracle)
+    blk.invalidate_lists()
+    blk.sort_only()
+    for c, oc in enumerate(cells):
+        n = int(oc.n_part[0])
+        k, valid, lg = blk.get_keys(c)
+        bins = np.clip(np.searchsorted(ve, oc.vtot[:n], side="right") - 1, 0, B - 1)
+        assert np.array_equal(k[:n], (oc.wclass[:n] * B + bins).astype(np.uint16)), c
+    ok, msg = parity.compare_state(blk, cells)
+    assert ok, msg
+    blk.close()
+
+
 def test_api_error_paths(wp):
     blk = wp.CellBlock(2, 128, 1)
     with pytest.raises(wp.PmcxError):          # aero_data must come before particles

@@ -326,6 +326,7 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
     A_(st.n_orig, nc * (size_t)(cfg->n_source > 1 ? cfg->n_source - 1 : 0) * cap + 1);
     A_(st.perm, nc * (size_t)st.pcap);
     A_(st.gcnt, nc * G); A_(st.goff, nc * (G + 1)); A_(st.sort_valid, nc);
+    A_(st.gkey, nc * cap); A_(st.key_valid, nc); A_(st.evlog, nc * (size_t)EVLOG_CAP); A_(st.n_log, nc);
     A_(st.seq_ovf, nc * (2 * G + 2 * (size_t)cfg->max_appends));
     A_(st.n_events, nc); A_(st.n_samp, nc); A_(st.n_coag, nc); A_(st.status, nc);
     A_(ctx->d_totals, (size_t)4);
@@ -456,9 +457,14 @@ int pmcx_set_env(pmcx_ctx *ctx, const double *temp, const double *pressure,
 }
 
 // the lists of these cells no longer describe their particles (aero_state%valid_sort = .false.)
-static hipError_t invalidate_sort(pmcx_ctx *ctx, int cell_first, int n)
+static hipError_t invalidate_sort(pmcx_ctx *ctx, int cell_first, int n, bool keys = true)
 {
     ctx->bounds_dirty = true; // whatever changed the populations may have moved their bin ranges
+    if (keys) { // the particles themselves changed: the sort keys are to be computed again
+        hipError_t e = hipMemsetAsync(ctx->st.key_valid + cell_first, 0, sizeof(int32_t) * (size_t)n,
+                                      ctx->stream);
+        if (e != hipSuccess) return e;
+    }
     return hipMemsetAsync(ctx->st.sort_valid + cell_first, 0, sizeof(int32_t) * (size_t)n, ctx->stream);
 }
 
@@ -734,6 +740,26 @@ int pmcx_invalidate_sort(pmcx_ctx *ctx)
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     HIP_TRY(ctx, invalidate_sort(ctx, 0, ctx->cfg.n_cells));
     return PMCX_OK;
+}
+
+int pmcx_invalidate_lists(pmcx_ctx *ctx)
+{
+    if (!ctx) return PMCX_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, invalidate_sort(ctx, 0, ctx->cfg.n_cells, false));
+    return PMCX_OK;
+}
+
+int pmcx_get_keys(pmcx_ctx *ctx, int32_t cell, uint16_t *gkey, int32_t *key_valid, uint32_t *evlog,
+                  int32_t *n_log)
+{
+    if (!ctx || cell < 0 || cell >= ctx->cfg.n_cells) return fail(ctx, PMCX_EINVAL, "pmcx_get_keys: bad argument");
+    int rc = PMCX_OK;
+    if (gkey) rc = copy_cells_d2h(ctx, gkey, ctx->st.gkey + (size_t)cell * ctx->cfg.cap, sizeof(uint16_t) * (size_t)ctx->cfg.cap);
+    if (!rc && key_valid) rc = copy_cells_d2h(ctx, key_valid, ctx->st.key_valid + cell, sizeof(int32_t));
+    if (!rc && evlog) rc = copy_cells_d2h(ctx, evlog, ctx->st.evlog + (size_t)cell * EVLOG_CAP, sizeof(uint32_t) * EVLOG_CAP);
+    if (!rc && n_log) rc = copy_cells_d2h(ctx, n_log, ctx->st.n_log + cell, sizeof(int32_t));
+    return rc;
 }
 
 int pmcx_mc_coag(pmcx_ctx *ctx, int32_t kernel_type, double del_t, uint64_t seed, uint32_t step)

@@ -30,6 +30,8 @@ struct __attribute__((aligned(16))) Cold {
     int32_t pad;
 };
 
+constexpr int EVLOG_CAP = 256; // entries of a cell's event log (two per coagulation at most)
+
 // Plain view of everything a kernel needs; passed by value.
 struct DeviceState {
     int32_t n_cells, cap, n_spec, n_class, n_source, n_bin, n_dbin, i_water;
@@ -74,6 +76,15 @@ struct DeviceState {
     int32_t *gcnt;   // [n_cells][n_class*n_bin] list lengths
     int32_t *goff;   // [n_cells][n_class*n_bin + 1] list starts
     int32_t *sort_valid; // [n_cells]
+    // Sort keys, kept between sorts: the group (class * n_bin + bin) of every slot, 0xFFFF for a
+    // tombstone.  While key_valid[c], applying the cell's event log (the slots the pair sampler
+    // re-binned or removed since the keys were last brought up to date: slot | key << 16) to
+    // gkey gives the key of every slot below n_hi -- the sort then streams 2 bytes per particle
+    // instead of its record.  Whatever else changes a cell's particles clears key_valid.
+    uint16_t *gkey;      // [n_cells][cap]
+    int32_t *key_valid;  // [n_cells]
+    uint32_t *evlog;     // [n_cells][EVLOG_CAP]
+    int32_t *n_log;      // [n_cells]
     uint16_t *seq_ovf;   // [n_cells][2 G + 2 max_appends] lane-per-cell sampler: entries past a group's room
     int32_t *n_events, *n_samp, *n_coag, *status; // [n_cells]
 };

@@ -50,6 +50,15 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+// Same for LDS traffic only: a wavefront's LDS operations are served in order, so its lanes
+// see each other's LDS writes once the counter of outstanding LDS operations is zero; global
+// stores in flight are not waited for (wave_sync's fence waits for their acknowledgement).
+__device__ __forceinline__ void lds_sync()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ double ld_f64(const double *p)
 {
     const uint64_t u = __hip_atomic_load((const uint64_t *)p, __ATOMIC_RELAXED,
@@ -508,14 +517,18 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st, const int32_t 
     const int n = st.n_hi[c]; // slots in use; dead ones (vtot < 0) are skipped
     const int64_t cb = (int64_t)c * st.cap;
 
+    const size_t o_tab = (sizeof(double) * (size_t)(B + 1) + 15) & ~(size_t)15;
+    const size_t o_key = (o_tab + (sizeof(uint64_t) * 4 + sizeof(uint32_t) * 5) * (size_t)G + 15) & ~(size_t)15;
     double *edge = (double *)smem;                    // [B+1]
-    uint64_t *pmask = (uint64_t *)(edge + (B + 1));   // [4][G] lanes of the chunk holding group g
+    uint64_t *pmask = (uint64_t *)(smem + o_tab);     // [4][G] lanes of the chunk holding group g
     uint32_t *hist = (uint32_t *)(pmask + 4 * (size_t)G); // [4][G] per-wave counts -> cursors
     uint32_t *tot = hist + 4 * (size_t)G;             // [G] totals -> offsets
-    uint16_t *key = (uint16_t *)(tot + G);            // [cap] group of slot
+    uint16_t *key = (uint16_t *)(smem + o_key);       // [cap] group of slot (16-byte aligned)
 
     for (int j = t; j <= B; j += 256) edge[j] = st.v_edge[j];
     for (int j = t; j < 4 * G; j += 256) { hist[j] = 0; pmask[j] = 0; }
+    const bool keyed = st.key_valid[c] != 0; // (the whole workgroup: the slots' keys still hold)
+    uint16_t *gk = st.gkey + cb;
     __syncthreads();
 
     // this wave's slots: a contiguous range whose length is a multiple of 64
@@ -528,9 +541,50 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st, const int32_t 
 
     const uint64_t lt = (1ull << lane) - 1ull;
 
+    int oog = 0;
+    if (keyed) {
+        // pass 1, keys kept: 2 bytes per slot instead of its 32-byte record.  The slots the pair
+        // sampler re-binned or removed since the keys were written are in the cell's event log,
+        // applied in order (a slot may appear more than once) and written back to the keys.
+        if ((st.cap & 7) == 0) {
+            // eight keys per lane and request: the wave's whole range is in flight at once.  The
+            // range starts at a multiple of 64 slots and the cell's keys at a multiple of 8: both
+            // the global and the LDS side are 16-byte aligned; keys past hi (below cap) ride along
+            // and are never looked at.
+            const uint4 *g4 = (const uint4 *)(gk + lo);
+            uint4 *k4 = (uint4 *)(key + lo);
+            const int n8 = (hi - lo + 7) >> 3;
+            for (int j = lane; j < n8; j += 64) k4[j] = g4[j];
+        } else {
+            for (int i = lo + lane; i < hi; i += 64) key[i] = gk[i];
+        }
+        __syncthreads();
+        const int nl = min(st.n_log[c], EVLOG_CAP);
+        if (nl > 0) {
+            // (the log is read by all threads at once -- one entry each, EVLOG_CAP <= 256 -- and
+            // applied from LDS by one: a later entry of the same slot must win)
+            __shared__ uint32_t s_log[EVLOG_CAP];
+            const uint32_t mine = t < nl ? st.evlog[(int64_t)c * EVLOG_CAP + t] : 0u;
+            if (t < nl) s_log[t] = mine;
+            __syncthreads();
+            if (t == 0)
+                for (int j = 0; j < nl; j++) {
+                    const uint32_t e = s_log[j];
+                    if ((int)(e & 0xFFFFu) < n) key[e & 0xFFFFu] = (uint16_t)(e >> 16);
+                }
+            __syncthreads();
+            if (t < nl) {
+                const uint32_t sl = mine & 0xFFFFu;
+                if ((int)sl < n) gk[sl] = key[sl];
+            }
+        }
+        for (int i = lo + lane; i < hi; i += 64) {
+            const uint32_t g = key[i];
+            if (g != 0xFFFFu) atomicAdd(&myhist[g], 1u);
+        }
+    } else {
     // pass 1: keys + per-wave histogram (LDS atomics: counting is order-independent).
     // Four loads are issued before the first use so a wave keeps 2 KiB in flight.
-    int oog = 0;
     for (int i0 = lo; i0 < hi; i0 += 256) {
         double v[4];
 #pragma unroll
@@ -547,12 +601,15 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st, const int32_t 
                     uint32_t g = (uint32_t)bin_index(edge, B, v[u], st);
                     if (C > 1) g += (uint32_t)wc[i] * (uint32_t)B;
                     key[i] = (uint16_t)g;
+                    gk[i] = (uint16_t)g;
                     atomicAdd(&myhist[g], 1u);
                 } else {
                     key[i] = 0xFFFFu; // tombstone
+                    gk[i] = (uint16_t)0xFFFFu;
                 }
             }
         }
+    }
     }
     if (oog) atomicOr(&st.status[c], ST_OUT_OF_GRID);
     __syncthreads();
@@ -585,23 +642,24 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st, const int32_t 
     // the hardware serves the atomics); rank = popcount of the lower lanes in that word.
     uint32_t *perm = st.perm + (int64_t)c * st.pcap;
     uint64_t *mymask = pmask + (size_t)wave * G;
-    if (t == 0) st.sort_valid[c] = 1;
+    if (t == 0) { st.sort_valid[c] = 1; st.key_valid[c] = 1; st.n_log[c] = 0; }
     for (int i0 = lo; i0 < hi; i0 += 64) {
         const int i = i0 + lane;
         const uint32_t gk = i < hi ? key[i] : 0xFFFFu;
         const bool valid = gk != 0xFFFFu;
         if (valid) atomicOr((unsigned long long *)&mymask[gk], 1ull << lane);
-        wave_sync();
+        lds_sync();
         uint64_t peers = 0;
-        if (valid) peers = mymask[gk];
+        uint32_t cur = 0;
+        if (valid) { peers = mymask[gk]; cur = myhist[gk]; }
         const uint32_t rank = (uint32_t)__popcll(peers & lt);
-        if (valid) perm[myhist[gk] + rank] = (uint32_t)i;
-        wave_sync();
+        lds_sync(); // every lane has read the word and the cursor
+        if (valid) perm[cur + rank] = (uint32_t)i; // (not waited for: nothing here reads perm)
         if (valid && rank == 0) { // the group's first lane advances the cursor, clears the word
-            myhist[gk] += (uint32_t)__popcll(peers);
+            myhist[gk] = cur + (uint32_t)__popcll(peers);
             mymask[gk] = 0;
         }
-        wave_sync();
+        lds_sync();
     }
     __syncthreads(); // the LDS tables are reused by the next cell
   }
@@ -831,6 +889,8 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
     const double *mag = st.mag + (int64_t)c * C;
     int n_ev = 0, n_app = 0, n_dead = 0, tot_coag = 0, status = 0;
     uint64_t tot_samp = 0;
+    // the cell's event log for the next sort (as in k_coag_lane): uniform within the group
+    int n_lg = st.key_valid[c] != 0 ? st.n_log[c] : -1;
 
     // Row state (uniform inside the group).  The partner slots of a row are
     // visited through a window of up to WN non-empty partner bins: counts are
@@ -1091,6 +1151,16 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
             if (lead) st_f64(&X.hot[po].vtot, -1.0); // tombstone, in the record just read
             n_dead++;
         }
+        if (n_lg >= 0) { // (group-uniform; the leading lane writes)
+            const int need = (g_new != g_old ? 1 : 0) + (rem_o ? 1 : 0);
+            if (n_lg + need <= EVLOG_CAP) {
+                uint32_t *lg = st.evlog + (int64_t)c * EVLOG_CAP;
+                if (g_new != g_old) { if (lead) st_u32(&lg[n_lg], pn | ((uint32_t)g_new << 16)); n_lg++; }
+                if (rem_o) { if (lead) st_u32(&lg[n_lg], po | 0xFFFF0000u); n_lg++; }
+            } else {
+                n_lg = -2;
+            }
+        }
         // (the stores above are waited for just before the next gathers, see "evaluate")
         wave_sync();
         tot_coag++;
@@ -1120,6 +1190,8 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
         if (ovf) st.sort_valid[c] = 0;
     }
     if (live && lead) {
+        if (n_lg >= 0) st.n_log[c] = n_lg;
+        else if (n_lg == -2) st.key_valid[c] = 0;
         st.n_events[c] = n_ev;
         st.n_part[c] = st.n_part[c] - n_dead;
         st.n_samp[c] = tot_samp > 0x7FFFFFFFull ? 0x7FFFFFFF : (int32_t)tot_samp;
@@ -1360,6 +1432,14 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
 
     int n_ev = 0, n_app = 0, n_dead = 0, tot_coag = 0, status = 0;
     uint64_t tot_samp = 0;
+    // the cell's event log (what the next sort needs to bring the slots' keys up to date):
+    // entries so far, -1: the keys do not hold anyway, -2: the log ran over (they no longer do)
+    int n_lg = st.key_valid[c] != 0 ? st.n_log[c] : -1;
+#define PMCX_LOG(slot, key)                                                                         \
+    if (n_lg >= 0) {                                                                              \
+        if (n_lg < EVLOG_CAP) st.evlog[(int64_t)c * EVLOG_CAP + n_lg++] = (uint32_t)(slot) | ((uint32_t)(key) << 16); \
+        else n_lg = -2;                                                                           \
+    }
     int c1 = 0, c2 = 0, b1 = -1, b2 = -1, cc = 0;
     double n1 = 0, n2 = 0, nmin = 0, fmax = 0, factor = 0, k_max = 0;
     uint32_t ns_rem = 0, s = 0;
@@ -1735,7 +1815,9 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                         const int n = (int)(en & 0xFFFFu);
                         perm[(en >> 16) + n] = pn;
                         cnt_set(0, b_new, en, n + 1);
+                        PMCX_LOG(pn, b_new)
                     }
+                    PMCX_LOG(po, 0xFFFFu)
                     *(double2 *)&hot[pn].vtot = make_double2(vn, mn);
                     {
                         const double lo_n = big1 ? lct1 : lct2, lo_o = big1 ? lct2 : lct1;
@@ -1827,7 +1909,9 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                         n_app++;
                     }
                     cnt_set(cc, b_new, en, n + 1);
+                    PMCX_LOG(pn, g_new)
                 }
+                if (rem_o) PMCX_LOG(po, 0xFFFFu)
                 *(double2 *)&hot[pn].vtot = make_double2(vn, mn);
                 // species volumes, source histogram, create times, class [aero_particle_coagulate]
                 if (S > 1) st.vol[(cb + pn) * S] = (pn_is_1 ? vol1 : vol2) + (pn_is_1 ? vol2 : vol1);
@@ -1886,6 +1970,8 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
             for (int g = 0; g < G; g++) ovf |= O_ovf_n(g) != 0;
             if (ovf) st.sort_valid[c] = 0;
         }
+        if (n_lg >= 0) st.n_log[c] = n_lg;
+        else if (n_lg == -2) st.key_valid[c] = 0;
         st.n_events[c] = n_ev;
         st.n_part[c] = st.n_part[c] - n_dead;
         st.n_coag[c] = tot_coag;
@@ -1897,6 +1983,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
         atomicAdd(&g_seq_stamps[11], 1ull);
     }
 #undef PMCX_SETTLE
+#undef PMCX_LOG
 #undef STAMP
 #undef MASK
 #undef gcnt_g
@@ -2045,7 +2132,10 @@ __device__ void compact_wave(const DeviceState &st, int c, int lane, uint32_t *c
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
     }
-    if (lane == 0) st.n_hi[c] = base;
+    if (lane == 0) {
+        st.n_hi[c] = base;
+        if (base != n_hi) st.key_valid[c] = 0; // slots were renamed: keys and event log no longer fit
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wave_sync();
     if (lists && base != n_hi) {
@@ -2143,7 +2233,7 @@ __global__ __launch_bounds__(64) void k_rebalance(DeviceState st, int allow_doub
                     st.n_hi[c] = n_hi + ncl;
                     st.n_part[c] = n_live + ncl;
                     mag[cl] = mag[cl] / 2.0;
-                    st.sort_valid[c] = 0;
+                    st.sort_valid[c] = 0; st.key_valid[c] = 0;
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __threadfence_block();
@@ -2170,7 +2260,7 @@ __global__ __launch_bounds__(64) void k_rebalance(DeviceState st, int allow_doub
                 if (lane == 0) {
                     st.n_part[c] = n_live - (int)nd;
                     mag[cl] = mag[cl] * 2.0;
-                    st.sort_valid[c] = 0;
+                    st.sort_valid[c] = 0; st.key_valid[c] = 0;
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __threadfence_block();
@@ -2579,7 +2669,7 @@ __global__ __launch_bounds__(256) void k_dry_deposition(DeviceState st, DepArgs 
     __syncthreads();
     if (t == 0) {
         st.n_part[c] = st.n_part[c] - s_nd;
-        if (s_nd) st.sort_valid[c] = 0;
+        if (s_nd) { st.sort_valid[c] = 0; st.key_valid[c] = 0; }
         a.n_removed[c] = s_nd;
         a.unrealistic[c] = s_bad;
     }
@@ -3031,6 +3121,7 @@ __global__ void k_halo_clear(DeviceState st, TransGrid tg, int row_a, int row_b)
     if (j >= 2 * row_cells) return;
     const int c = (j < row_cells ? row_a : row_b) * row_cells + (j % row_cells);
     st.n_hi[c] = 0; st.n_part[c] = 0; tg.n_out[c] = 0; tg.dest_mask[c] = 0; st.sort_valid[c] = 0;
+    st.key_valid[c] = 0;
 }
 
 // ------------------------------------------------------------- condensation
@@ -3238,9 +3329,9 @@ __global__ void k_test_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
 size_t bin_sort_lds_bytes(const DeviceState &st)
 {
     const size_t B = st.n_bin, G = (size_t)st.n_bin * st.n_class;
-    const size_t o = sizeof(double) * (B + 1) + sizeof(uint64_t) * 4 * G + sizeof(uint32_t) * 5 * G +
-                     sizeof(uint16_t) * (size_t)st.cap;
-    return (o + 15) & ~(size_t)15;
+    const size_t o_tab = (sizeof(double) * (B + 1) + 15) & ~(size_t)15;
+    const size_t o_key = (o_tab + (sizeof(uint64_t) * 4 + sizeof(uint32_t) * 5) * G + 15) & ~(size_t)15;
+    return o_key + sizeof(uint16_t) * (((size_t)st.cap + 7) & ~(size_t)7);
 }
 static size_t sampler_lds_for(const DeviceState &st, int lanes)
 {

@@ -39,6 +39,7 @@ EXPORTED_SYMBOLS = [
     "pmcx_device_copy",
     "pmcx_memory_bytes", "pmcx_device_memory_info", "pmcx_set_cell_id_base", "pmcx_set_gas_state",
     "pmcx_get_gas_state", "pmcx_set_gas_scenario", "pmcx_scenario_update_gas_state",
+    "pmcx_invalidate_lists", "pmcx_get_keys",
 ]
 
 
@@ -144,6 +145,7 @@ def load_library():
     L.pmcx_device_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
     L.pmcx_dry_deposition.argtypes = [C.c_void_p, C.c_double, C.c_uint64, C.c_uint32] + [C.c_void_p] * 9
     L.pmcx_timestep.argtypes = [C.c_void_p, C.POINTER(PmcxStepFlags)]
+    L.pmcx_get_keys.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pmcx_set_cell_id_base.argtypes = [C.c_void_p, C.c_uint32]
     L.pmcx_set_gas_state.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     L.pmcx_get_gas_state.argtypes = [C.c_void_p, C.c_void_p]
@@ -697,6 +699,18 @@ class CellBlock:
     def invalidate_sort(self):
         """aero_state%valid_sort = .false. for every cell: the next mc_coag sorts them again."""
         self._ck(self._lib.pmcx_invalidate_sort(self._h))
+
+    def invalidate_lists(self):
+        """The lists of every cell are to be rebuilt, from sort keys that still hold."""
+        self._ck(self._lib.pmcx_invalidate_lists(self._h))
+
+    def get_keys(self, cell):
+        """(gkey [cap], key_valid, evlog [n_log]) of one cell."""
+        k = np.zeros(self.cfg.cap, dtype=np.uint16)
+        v, n = C.c_int32(), C.c_int32()
+        lg = np.zeros(256, dtype=np.uint32)
+        self._ck(self._lib.pmcx_get_keys(self._h, cell, _ptr(k), C.byref(v), _ptr(lg), C.byref(n)))
+        return k, v.value, lg[:n.value]
 
     def get_sort(self, cell):
         G = self.cfg.n_class * self.cfg.n_bin
