@@ -592,6 +592,79 @@ def test_sort_from_kept_keys(wp, oracle):
     blk.close()
 
 
+def _effective_keys(blk, c):
+    """The keys of cell c with its pending event log applied; None when they do not hold."""
+    k, valid, lg = blk.get_keys(c)
+    if not valid:
+        return None
+    k = k.copy()
+    for e in lg:
+        k[int(e) & 0xFFFF] = int(e) >> 16
+    return k
+
+
+def test_sort_keys_survive_every_kernel(wp, oracle):
+    """Transport, dry deposition, emission / dilution, the rebalance and compaction keep the
+    slots' sort keys current (arrivals and new particles are binned as they are written, removals
+    marked, copies inherit, holes closed with the keys moving along): after each of them the keys
+    (with the sampler's pending log) are what the definition gives for every slot in use, and the
+    mc_coag that follows -- sorting from those keys -- equals the oracle, which sorts from the
+    particle records."""
+    nx, nz, ny = 2, 2, 2
+    n_cells, n_part, n_spec, n_class = nx * nz * ny, 1200, 1, 2
+    blk, cells, info = parity.setup_pair(wp, oracle, n_cells, n_part, n_spec, n_class, 17, K_BROWN,
+                                         cap=4096, n_source=2, compact_den=4)
+    B = blk.cfg.n_bin
+    ve = info["v_edge"]
+    mag = info["mag"]
+    n_ideal = np.tile(np.array([0.3, 1.0]) * n_part / n_class, (n_cells, 1))
+    blk.set_n_part_ideal(n_ideal)
+    nid = np.array([oc.next_id for oc in cells], dtype=np.int64)
+    prob_h = np.full((n_cells, n_class, 4), 0.04); prob_v = np.full((n_cells, n_class, nz), 0.02)
+    em = [dict(gm_radius=3e-8, gsd_log10=0.2, vol_frac=[1.0], wclass=0, source=1)]
+    em_rate = np.array([[mag[c, 0] * 1.0] for c in range(n_cells)])
+    checked = 0
+
+    def check(what):
+        nonlocal checked
+        for c, oc in enumerate(cells):
+            k = _effective_keys(blk, c)
+            assert k is not None, (what, c)
+            vt, _ = blk.caches(c)                       # (closes the holes on both views)
+            k = _effective_keys(blk, c)
+            n = int(oc.n_part[0])
+            bins = np.clip(np.searchsorted(ve, oc.vtot[:n], side="right") - 1, 0, B - 1)
+            assert np.array_equal(k[:n], (oc.wclass[:n] * B + bins).astype(np.uint16)), (what, c)
+            checked += n
+
+    for step in range(4):
+        ns, nc, st = blk.mc_coag(K_BROWN, 1500.0, 17, step)
+        for c, oc in enumerate(cells):
+            assert oc.mc_coag(K_BROWN, 1500.0, 17, oc.cell_id, step) == (int(st[c]), int(ns[c]), int(nc[c]))
+        check("mc_coag")
+        blk.transport(nx, nz, ny, prob_h, prob_v, np.ones(n_cells), seed=17, step=step)
+        oracle.transport(cells, nx, nz, ny, prob_h, prob_v, np.ones(n_cells), 17, 0, step, nid)
+        check("transport")
+        blk.dry_deposition(600.0, 40.0, 0.3, 1.2, 2e-3, 30.0, 0.8, seed=17, step=step)
+        for c, oc in enumerate(cells):
+            oc.dry_deposition(600.0, 17, oc.cell_id, step, 40.0, 0.3, 1.2, 2e-3, 30.0, 0.8)
+        check("deposition")
+        blk.scenario_update_aero_state(60.0, 60.0 * step, 17, step, em, em_rate, np.full(n_cells, 1e-3))
+        for c, oc in enumerate(cells):
+            oe = [dict(m, num_conc=em_rate[c, j]) for j, m in enumerate(em)]
+            _, nid[c], _, _, _ = oc.scenario_update(60.0, 60.0 * step, 17, oc.cell_id, step, oe, 1e-3,
+                                                    None, int(nid[c]))
+        check("scenario")
+        blk.aero_state_rebalance(True, True, 17, step)
+        for c, oc in enumerate(cells):
+            _, nid[c] = oc.rebalance(n_ideal[c], True, True, 17, oc.cell_id, step, int(nid[c]))
+        check("rebalance")
+    ok, msg = parity.compare_state(blk, cells)
+    assert ok, msg
+    assert checked > 50000
+    blk.close()
+
+
 def test_api_error_paths(wp):
     blk = wp.CellBlock(2, 128, 1)
     with pytest.raises(wp.PmcxError):          # aero_data must come before particles

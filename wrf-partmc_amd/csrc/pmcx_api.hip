@@ -943,7 +943,7 @@ int pmcx_scenario_update_aero_state(pmcx_ctx *ctx, double dt, double elapsed_tim
     if (e == hipSuccess && n_dil_out) e = hipMemcpyAsync(n_dil_out, d_cnt + 2 * nc, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     cleanup();
-    HIP_TRY(ctx, invalidate_sort(ctx, 0, ctx->cfg.n_cells));
+    HIP_TRY(ctx, invalidate_sort(ctx, 0, ctx->cfg.n_cells, false)); // (the kernel keeps the sort keys current)
     if (e != hipSuccess) return fail(ctx, PMCX_EDEVICE, "pmcx_scenario_update_aero_state: %s", hipGetErrorString(e));
     return PMCX_OK;
 }
@@ -1025,7 +1025,7 @@ int pmcx_transport(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int32_t pe
     if (n_moved) HIP_TRY(ctx, hipMemcpyAsync(n_moved, ctx->d_n_out, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));
     if (n_arrived) HIP_TRY(ctx, hipMemcpyAsync(n_arrived, ctx->d_n_arr, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, invalidate_sort(ctx, 0, ctx->cfg.n_cells));
+    HIP_TRY(ctx, invalidate_sort(ctx, 0, ctx->cfg.n_cells, false)); // (the kernels keep the sort keys current)
     return PMCX_OK;
 }
 
@@ -1222,7 +1222,7 @@ int pmcx_transport_finish(pmcx_ctx *ctx, int32_t *n_moved, int32_t *n_arrived)
     if (n_moved) HIP_TRY(ctx, hipMemcpyAsync(n_moved, ctx->d_n_out, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));
     if (n_arrived) HIP_TRY(ctx, hipMemcpyAsync(n_arrived, ctx->d_n_arr, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, invalidate_sort(ctx, 0, ctx->cfg.n_cells));
+    HIP_TRY(ctx, invalidate_sort(ctx, 0, ctx->cfg.n_cells, false)); // (the kernels keep the sort keys current)
     ctx->halo_nx = 0;
     return PMCX_OK;
 }

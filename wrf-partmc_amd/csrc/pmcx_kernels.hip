@@ -92,6 +92,7 @@ __device__ __forceinline__ int32_t &norig(const DeviceState &st, int64_t cb, int
 __device__ __forceinline__ void mark_dead(const DeviceState &st, int64_t cb, int i)
 {
     st_f64(&st.hot[cb + i].vtot, -1.0);
+    st.gkey[cb + i] = (uint16_t)0xFFFFu; // (the slot's sort key: DeviceState::gkey)
 }
 
 // Class of the particle in slot i, or -1 for a tombstone.  A slot is dead when its cached
@@ -186,6 +187,36 @@ __device__ __forceinline__ int bin_index(const double *v_edge, int n_bin, double
     const double e_lo = v_edge[b], e_hi = v_edge[b + 1];
     b += (int)(v >= e_hi) - (int)(v < e_lo);
     return b < 0 ? 0 : (b > n_bin - 1 ? n_bin - 1 : b);
+}
+
+// Brings the sort keys of cell c up to date: the slots the pair sampler re-binned or removed
+// since the last sort are in the cell's event log (DeviceState::evlog), applied here in order (a
+// slot may appear more than once: one lane stores, entry by entry).  Every kernel that changes a
+// cell's particles and keeps its keys current calls this first; one wavefront, all lanes.
+__device__ __forceinline__ void apply_event_log(const DeviceState &st, int c, int lane)
+{
+    if (st.key_valid[c] == 0) return;
+    const int nl = min(st.n_log[c], EVLOG_CAP);
+    if (nl <= 0) return;
+    const int64_t cb = (int64_t)c * st.cap;
+    const int n_hi = st.n_hi[c];
+    for (int j0 = 0; j0 < nl; j0 += 64) {
+        const uint32_t e = j0 + lane < nl ? st.evlog[(int64_t)c * EVLOG_CAP + j0 + lane] : 0u;
+        const int m = min(64, nl - j0);
+        for (int l = 0; l < m; l++) {
+            const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)e, l);
+            if (lane == 0 && (int)(x & 0xFFFFu) < n_hi) st.gkey[cb + (x & 0xFFFFu)] = (uint16_t)(x >> 16);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) st.n_log[c] = 0;
+    wave_sync();
+}
+
+// sort key of a live particle: its group class * n_bin + bin
+__device__ __forceinline__ uint16_t key_of(const DeviceState &st, double vtot, int cl)
+{
+    return (uint16_t)(cl * st.n_bin + bin_index(st.v_edge, st.n_bin, vtot, st));
 }
 
 // ------------------------------------------------------------ upload/download
@@ -504,7 +535,7 @@ __global__ __launch_bounds__(256) void k_list_cells(DeviceState st, int what, in
 }
 
 __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st, const int32_t *list,
-                                                  const int32_t *count)
+                                                  const int32_t *count, int abl)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint32_t wsum[4];
@@ -643,7 +674,7 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st, const int32_t 
     uint32_t *perm = st.perm + (int64_t)c * st.pcap;
     uint64_t *mymask = pmask + (size_t)wave * G;
     if (t == 0) { st.sort_valid[c] = 1; st.key_valid[c] = 1; st.n_log[c] = 0; }
-    for (int i0 = lo; i0 < hi; i0 += 64) {
+    for (int i0 = lo; i0 < hi && !(abl & 1); i0 += 64) {
         const int i = i0 + lane;
         const uint32_t gk = i < hi ? key[i] : 0xFFFFu;
         const bool valid = gk != 0xFFFFu;
@@ -654,7 +685,7 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st, const int32_t 
         if (valid) { peers = mymask[gk]; cur = myhist[gk]; }
         const uint32_t rank = (uint32_t)__popcll(peers & lt);
         lds_sync(); // every lane has read the word and the cursor
-        if (valid) perm[cur + rank] = (uint32_t)i; // (not waited for: nothing here reads perm)
+        if (valid && !(abl & 4)) perm[cur + rank] = (uint32_t)i; // (not waited for: nothing here reads perm)
         if (valid && rank == 0) { // the group's first lane advances the cursor, clears the word
             myhist[gk] = cur + (uint32_t)__popcll(peers);
             mymask[gk] = 0;
@@ -2023,6 +2054,7 @@ __device__ __forceinline__ void move_particle(const DeviceState &st, int64_t cb,
             norig(st, cb, s, src);
     st.hot[cb + dst].vtot = st.hot[cb + src].vtot;
     st.hot[cb + dst].mass = st.hot[cb + src].mass;
+    st.gkey[cb + dst] = st.gkey[cb + src];
     st.wclass[cb + dst] = st.wclass[cb + src];
     st.cold[cb + dst].id = st.cold[cb + src].id;
     st.hot[cb + dst].lct = st.hot[cb + src].lct;
@@ -2043,6 +2075,7 @@ __device__ void compact_wave(const DeviceState &st, int c, int lane, uint32_t *c
     const int n_hi = st.n_hi[c];
     const int S = st.n_spec, NS = st.n_source;
     const uint64_t lt = (1ull << lane) - 1ull;
+    apply_event_log(st, c, lane); // (its entries name slots as they are numbered now)
     // the slot map (chunk bases and live masks) is filled for the caller when the cell's lists
     // hold (they are renamed below) or when the caller renames something itself (map_always)
     const bool lists = cbase != nullptr && st.sort_valid[c] != 0;
@@ -2079,11 +2112,13 @@ __device__ void compact_wave(const DeviceState &st, int c, int lane, uint32_t *c
         double a1[U], a2[U], a3[U];
         int64_t idv[U];
         int32_t wc[U];
+        uint16_t kk[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int i = i0 + u * 64 + lane;
-            a1[u] = a2[u] = a3[u] = 0; idv[u] = 0; wc[u] = 0;
+            a1[u] = a2[u] = a3[u] = 0; idv[u] = 0; wc[u] = 0; kk[u] = 0;
             if (mv[u]) {
+                kk[u] = st.gkey[cb + i];
                 a1[u] = ld_f64(&st.hot[cb + i].mass);
                 a2[u] = ld_f64(&st.hot[cb + i].lct); a3[u] = ld_f64(&st.hot[cb + i].gct);
                 idv[u] = (int64_t)d2u(ld_f64((const double *)&st.cold[cb + i].id));
@@ -2100,6 +2135,7 @@ __device__ void compact_wave(const DeviceState &st, int c, int lane, uint32_t *c
                 st_f64(&st.hot[cb + d].lct, a2[u]); st_f64(&st.hot[cb + d].gct, a3[u]);
                 st_f64((double *)&st.cold[cb + d].id, u2d((uint64_t)idv[u]));
                 st_u32((uint32_t *)&st.wclass[cb + d], (uint32_t)wc[u]);
+                st.gkey[cb + d] = kk[u];
             }
         // species volumes (with one species the plane is not kept current: nothing to move)
         if (S > 1)
@@ -2132,10 +2168,7 @@ __device__ void compact_wave(const DeviceState &st, int c, int lane, uint32_t *c
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
     }
-    if (lane == 0) {
-        st.n_hi[c] = base;
-        if (base != n_hi) st.key_valid[c] = 0; // slots were renamed: keys and event log no longer fit
-    }
+    if (lane == 0) st.n_hi[c] = base;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wave_sync();
     if (lists && base != n_hi) {
@@ -2196,6 +2229,7 @@ __global__ __launch_bounds__(64) void k_rebalance(DeviceState st, int allow_doub
     double *mag = st.mag + (int64_t)c * st.n_class;
     const double *n_ideal = st.n_ideal + (int64_t)c * st.n_class;
     int status = 0;
+    apply_event_log(st, c, lane);
     for (int cl = 0; cl < st.n_class; cl++) {
         for (uint32_t iter = 0; iter < 32; iter++) {
             int n_hi = st.n_hi[c];
@@ -2233,7 +2267,7 @@ __global__ __launch_bounds__(64) void k_rebalance(DeviceState st, int allow_doub
                     st.n_hi[c] = n_hi + ncl;
                     st.n_part[c] = n_live + ncl;
                     mag[cl] = mag[cl] / 2.0;
-                    st.sort_valid[c] = 0; st.key_valid[c] = 0;
+                    st.sort_valid[c] = 0;
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __threadfence_block();
@@ -2260,7 +2294,7 @@ __global__ __launch_bounds__(64) void k_rebalance(DeviceState st, int allow_doub
                 if (lane == 0) {
                     st.n_part[c] = n_live - (int)nd;
                     mag[cl] = mag[cl] * 2.0;
-                    st.sort_valid[c] = 0; st.key_valid[c] = 0;
+                    st.sort_valid[c] = 0;
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __threadfence_block();
@@ -2466,6 +2500,7 @@ __device__ int add_dist_sample(const DeviceState &st, int c, const AeroDistDev &
             st.hot[cb + i].vtot = vt;
             st.hot[cb + i].mass = ms;
             st.wclass[cb + i] = cl;
+            st.gkey[cb + i] = key_of(st, vt, cl);
             st.cold[cb + i].id = nid + k;
             st.hot[cb + i].lct = create_time;
             st.hot[cb + i].gct = create_time;
@@ -2497,6 +2532,7 @@ __global__ __launch_bounds__(64) void k_scenario_update(DeviceState st, double d
     const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
     const uint64_t lt = (1ull << lane) - 1ull;
     int status = 0, ne = 0, ni = 0, no = 0;
+    apply_event_log(st, c, lane);
     if (emission.n_mode > 0)
         ne = add_dist_sample(st, c, emission, dt, 0u, create_time, seed, step, status, lane);
     const double rate = dilution_rate ? dilution_rate[c] : 0.0;
@@ -2625,6 +2661,8 @@ __global__ __launch_bounds__(256) void k_dry_deposition(DeviceState st, DepArgs 
     const double ra = a.aer_res_a[c], ustar = a.ustar[c], alpha = a.alpha[c], big_a = a.big_a[c];
     const double rrho = a.inv_density[c], temp = st.temp[c], dt_dz = dt / a.height[c];
     const int n_hi = st.n_hi[c];
+    if (wave == 0) apply_event_log(st, c, lane);
+    __syncthreads();
     // Each wavefront takes a contiguous quarter of the slots (a multiple of 64).  A particle's
     // uniform is keyed by its rank among the live ones: the quarters are counted first.
     const int per = (((n_hi + 3) >> 2) + 63) & ~63;
@@ -2669,7 +2707,7 @@ __global__ __launch_bounds__(256) void k_dry_deposition(DeviceState st, DepArgs 
     __syncthreads();
     if (t == 0) {
         st.n_part[c] = st.n_part[c] - s_nd;
-        if (s_nd) { st.sort_valid[c] = 0; st.key_valid[c] = 0; }
+        if (s_nd) st.sort_valid[c] = 0;
         a.n_removed[c] = s_nd;
         a.unrealistic[c] = s_bad;
     }
@@ -2734,6 +2772,7 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
     const int64_t cb = (int64_t)c * st.cap;
     const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
     const uint64_t lt = (1ull << lane) - 1ull;
+    apply_event_log(st, c, lane); // (this step's removals and arrivals keep the cell's keys current)
 
     // destination tables (serial per class: the cumulative sums are order dependent)
     if (lane < C) {
@@ -2928,6 +2967,7 @@ __global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid t
                 const Hot hv = st.hot[sb + from];
                 const Cold cv = st.cold[sb + from];
                 const int32_t wc = st.n_class > 1 ? st.wclass[sb + from] : 0; // one class: all zero
+                const uint16_t kd = key_of(st, hv.vtot, wc); // (from the record: the source's keys may not hold)
                 for (int g = 0; g < copies; g++) {
                     const int dst = (int)first + g;
                     if (dst >= st.cap) { status |= ST_CAP_OVERFLOW; break; }
@@ -2937,6 +2977,7 @@ __global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid t
                     for (int sp = 1; sp < NS; sp++)
                         norig(st, cb, sp, dst) = norig(st, sb, sp, from);
                     st.hot[cb + dst] = hv;
+                    st.gkey[cb + dst] = kd;
                     if (st.n_class > 1) st.wclass[cb + dst] = wc;
                     Cold c2 = cv;
                     if (g != copies - 1) c2.id = id0 + g;
@@ -3502,7 +3543,7 @@ hipError_t launch_bin_sort(const DeviceState &st, hipStream_t s)
     list_cells(st, LIST_SORT, 0, 0, 0, st.n_cells, s);
     hipLaunchKernelGGL(k_bin_sort, dim3(st.n_cells < 16384 ? st.n_cells : 16384), dim3(256),
                        bin_sort_lds_bytes(st), s, st, (const int32_t *)(st.work_list + 1),
-                       (const int32_t *)st.work_list);
+                       (const int32_t *)st.work_list, getenv("PMCX_SORT_ABL") ? atoi(getenv("PMCX_SORT_ABL")) : 0);
     return hipGetLastError();
 }
 hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, uint64_t seed,
