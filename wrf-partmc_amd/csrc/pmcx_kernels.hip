@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256) void k_list_cells(DeviceState st, int what, in
 }
 
 __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st, const int32_t *list,
-                                                  const int32_t *count, int abl)
+                                                  const int32_t *count)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint32_t wsum[4];
@@ -674,7 +674,7 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st, const int32_t 
     uint32_t *perm = st.perm + (int64_t)c * st.pcap;
     uint64_t *mymask = pmask + (size_t)wave * G;
     if (t == 0) { st.sort_valid[c] = 1; st.key_valid[c] = 1; st.n_log[c] = 0; }
-    for (int i0 = lo; i0 < hi && !(abl & 1); i0 += 64) {
+    for (int i0 = lo; i0 < hi; i0 += 64) {
         const int i = i0 + lane;
         const uint32_t gk = i < hi ? key[i] : 0xFFFFu;
         const bool valid = gk != 0xFFFFu;
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st, const int32_t 
         if (valid) { peers = mymask[gk]; cur = myhist[gk]; }
         const uint32_t rank = (uint32_t)__popcll(peers & lt);
         lds_sync(); // every lane has read the word and the cursor
-        if (valid && !(abl & 4)) perm[cur + rank] = (uint32_t)i; // (not waited for: nothing here reads perm)
+        if (valid) perm[cur + rank] = (uint32_t)i; // (not waited for: nothing here reads perm)
         if (valid && rank == 0) { // the group's first lane advances the cursor, clears the word
             myhist[gk] = cur + (uint32_t)__popcll(peers);
             mymask[gk] = 0;
@@ -2865,10 +2865,21 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
         n_out += (uint32_t)__popcll(mm);
         rank0 += (uint32_t)__popcll(mlive);
     };
+    // Liveness and class of a slot come from its 2-byte sort key while the cell's keys hold
+    // (the log was applied above): a dense plane instead of one field of the 32-byte records.
+    const bool keyed = st.key_valid[c] != 0;
+    const uint16_t *gk = st.gkey + cb;
+    const int Bn = st.n_bin;
+    auto slot_class = [&](int sl) -> int {
+        if (sl >= n_hi) return -1;
+        if (!keyed) return live_class(st, cb, sl);
+        const uint32_t kq = gk[sl];
+        return kq == 0xFFFFu ? -1 : (int)(kq / (uint32_t)Bn);
+    };
     for (int i0 = 0; i0 < n_hi; i0 += 128) {
         const int sa = i0 + lane, sb = i0 + 64 + lane;
-        const int cla = sa < n_hi ? live_class(st, cb, sa) : -1;
-        const int clb = sb < n_hi ? live_class(st, cb, sb) : -1;
+        const int cla = slot_class(sa);
+        const int clb = slot_class(sb);
         chunk(sa, cla);
         if (i0 + 64 < n_hi) chunk(sb, clb);
     }
@@ -3543,7 +3554,7 @@ hipError_t launch_bin_sort(const DeviceState &st, hipStream_t s)
     list_cells(st, LIST_SORT, 0, 0, 0, st.n_cells, s);
     hipLaunchKernelGGL(k_bin_sort, dim3(st.n_cells < 16384 ? st.n_cells : 16384), dim3(256),
                        bin_sort_lds_bytes(st), s, st, (const int32_t *)(st.work_list + 1),
-                       (const int32_t *)st.work_list, getenv("PMCX_SORT_ABL") ? atoi(getenv("PMCX_SORT_ABL")) : 0);
+                       (const int32_t *)st.work_list);
     return hipGetLastError();
 }
 hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, uint64_t seed,
