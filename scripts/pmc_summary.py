@@ -25,7 +25,7 @@ traffic = {}
 names = {"pmcx::k_bin_sort": ("bin_sort", 2.0), "pmcx::k_rebalance": ("rebalance", 1.0),
          "pmcx::k_compact": ("compact", 1.0)}
 # the sampler under whichever template arguments it ran with (the one with the most traffic)
-samplers = [k for k in out if k.startswith("pmcx::k_coag_seq<") or k.startswith("pmcx::k_coag_sample<")]
+samplers = [k for k in out if k.startswith("pmcx::k_coag_lane<") or k.startswith("pmcx::k_coag_sample<")]
 samplers = [k for k in samplers if "FETCH_SIZE" in out[k] and "WRITE_SIZE" in out[k]]
 if samplers:
     names[max(samplers, key=lambda k: out[k]["FETCH_SIZE"])] = ("coag_sample", 1.0)

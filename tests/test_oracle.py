@@ -576,6 +576,29 @@ def test_cdf_codec_against_scipy(tmp_path):
     assert dims == {"n": 3} and np.array_equal(vs["id"][0], big) and vs["id"][0].dtype == np.int64
 
 
+def test_cdf5_encoder_against_a_hand_assembled_file(tmp_path):
+    """CDF-5 is never checked against a netCDF library here (none in the image): instead the
+    encoder must reproduce, byte for byte, a file assembled by hand from the format grammar
+    (tests/golden/cdf5_minimal.hex, every field annotated), and the decoder must read it."""
+    from wrf_partmc_amd import ncio
+    here = os.path.dirname(os.path.abspath(__file__))
+    text = open(os.path.join(here, "golden", "cdf5_minimal.hex")).read()
+    want = bytes.fromhex("".join(ln.split("#")[0] for ln in text.splitlines()).replace(" ", ""))
+    assert len(want) == 300
+    w = ncio.CdfWriter(version=5)
+    w.att("title", "t")
+    w.dim("n", 3)
+    w.var("aero_id", ["n"], np.array([1, 1 << 40, -5], dtype=np.int64), unit="1")
+    w.var("x", ["n"], np.array([0.5, -1.0, 2.0]))
+    assert w.tobytes() == want
+    p = str(tmp_path / "hand.nc")
+    open(p, "wb").write(want)
+    dims, gatts, vs = ncio.read_cdf(p)
+    assert dims == {"n": 3} and gatts == {"title": "t"}
+    assert vs["aero_id"][0].dtype == np.int64 and list(vs["aero_id"][0]) == [1, 1 << 40, -5]
+    assert vs["aero_id"][1] == {"unit": "1"} and list(vs["x"][0]) == [0.5, -1.0, 2.0]
+
+
 def test_column_file_round_trip(oracle, tmp_path):
     """a column written in the layout of output_column_to_file_new
     (wrf_pmc_driver.F90:1508-1653) and read back the way init_read_in_restart does
