@@ -76,13 +76,20 @@ blk.profile_reset()
 t0 = time.perf_counter()
 elapsed = 0.0
 moved = deposited = emitted = events = 0
+host = {"transport": 0.0, "dry_deposition": 0.0, "scenario": 0.0, "mc_coag": 0.0, "rebalance": 0.0}
+step_wall = []
 for step in range(a.steps):
+    ts = time.perf_counter()
     nm, na = blk.transport(nx, nz, ny, prob_h, prob_v, cell_volume, seed=0, step=step)
+    host["transport"] += time.perf_counter() - ts
     assert nm.sum() == na.sum(), "transport lost particles (capacity)"   # equal weights: 1 copy each
+    t1 = time.perf_counter()
     nr, bad = blk.dry_deposition(a.dt, ra, ustar, alpha, big_a, height, rrho, seed=0, step=step,
                                  surface=surface)
+    t2 = time.perf_counter(); host["dry_deposition"] += t2 - t1
     ne, ni, no = blk.scenario_update_aero_state(a.dt, elapsed, seed=0, step=step, emission=emission,
                                                 emission_rate=emit_rate)
+    t3 = time.perf_counter(); host["scenario"] += t3 - t2
     if elapsed % a.chem_dt == 0.0:
         # WRF hands PartMC new air every step (wrf_to_partmc, driver:611-637): the kernel bounds
         # of every cell are computed again inside mc_coag
@@ -91,7 +98,11 @@ for step in range(a.steps):
         ns, nc, st = blk.mc_coag(wp.COAG_KERNEL_TYPE_BROWN, a.chem_dt, 0, int(elapsed // a.chem_dt))
         events += int(nc.sum())
         assert not (st & ~4).any(), "status"
+    t4 = time.perf_counter(); host["mc_coag"] += t4 - t3
     blk.aero_state_rebalance(True, True, 0, step)
+    blk.synchronize()
+    host["rebalance"] += time.perf_counter() - t4
+    step_wall.append((time.perf_counter() - ts) * 1e3)
     moved += int(nm.sum()); deposited += int(nr.sum()); emitted += int(ne.sum())
     elapsed += a.dt
 tn, tm, nd, md = blk.diagnostics()
@@ -101,6 +112,8 @@ out = {"cells": n, "particles_per_cell": N, "steps": a.steps, "wall_ms_per_step"
        "moved_per_step": moved / a.steps, "deposited_per_step": deposited / a.steps,
        "emitted_per_step": emitted / a.steps, "coag_events": events,
        "particles_end": int(blk.aero_state_total_particles().sum()),
+       "wall_ms_each_step": [round(x, 2) for x in step_wall],
+       "host_wall_ms_per_step": {k: v / a.steps * 1e3 for k, v in host.items()},
        "device_ms": {}}
 for name in names:
     ms, cnt = blk.profile_get(name)
