@@ -226,6 +226,25 @@ int pmcx_scenario_update_aero_state(pmcx_ctx *ctx, double dt, double elapsed_tim
                                     const pmcx_aero_dist *background, int32_t *n_emit,
                                     int32_t *n_dil_in, int32_t *n_dil_out);
 
+/* seasalt_emissions (interface/wrf_pmc_driver.F90:212-223, 1767-1924) on every cell with
+ * ocean_surface[c] != 0 (the reference: lowest level, grid%xland > 1.5): log-normal modes of Na
+ * and Cl (volume fractions mw_na / (mw_na + mw_cl) and the rest, :1830-1833) --
+ *   sea_salt_opt 1  Gong, the two MAM3-matched modes, number fluxes x wind_speed**3.41
+ *                   (:1819-1822, 1834-1854)
+ *   sea_salt_opt 2  Ovadnevaite et al. 2014, five modes, F_i = coef (Re - offset)**expon with the
+ *                   reference's fixed Re = 3.1e6 (:1800-1805, 1886-1912)
+ * -- sampled like an emission: Poisson(flux * rate_scale * dt / height / magnitude) new particles
+ * per mode (:1917-1924).  wind_speed = sqrt(u10^2 + v10^2) [n_cells] (driver:215-216), height =
+ * env_state%height [n_cells]; i_na, i_cl: 0-based species indices; mode_class / mode_source
+ * [n_modes] (the reference looks "sea_salt_NN" up in aero_data%weight_class_name / %source_name;
+ * NULL: class 0, source 0).  n_emit [n_cells] and rate [n_cells][n_modes] (the emission rate
+ * used, # m^-3 s^-1) are outputs and may be NULL.  Synchronises. */
+int pmcx_seasalt_emissions(pmcx_ctx *ctx, double dt, double elapsed_time, uint64_t seed, uint32_t step,
+                           int32_t sea_salt_opt, int32_t i_na, int32_t i_cl,
+                           const int32_t *ocean_surface, const double *wind_speed,
+                           const double *height, const int32_t *mode_class,
+                           const int32_t *mode_source, int32_t *n_emit, double *rate);
+
 /* The same transport for a SLAB of a domain decomposed in y across ranks (one process per
  * GPU; wrf_pmc_trans_aero.F90 exchanges the movers between MPI patches).  The block carries
  * one ghost row below its first real row (j = 0) and one above its last (j = ny - 1); the

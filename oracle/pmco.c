@@ -879,6 +879,76 @@ int pmco_scenario_update(pmco_cell *c, double dt, double create_time, uint64_t s
 }
 
 /* ------------------------------------------------------------------------
+ * Sea-salt source (interface/wrf_pmc_driver.F90:1767-1924).  The constants are the
+ * reference's (in-tree): restated as values.
+ * ---------------------------------------------------------------------- */
+int pmco_seasalt_modes(int sea_salt_opt, double wind_speed, double *flux, double *gm_radius,
+                       double *gsd_log10, double *rate_scale, double *vol_frac_na)
+{
+    *vol_frac_na = 22.990 / (22.990 + 35.450);                       /* driver:1830-1831 */
+    if (sea_salt_opt == 1) {                                          /* Gong, MAM3 modes */
+        /* default-real literals in the reference (driver:1819-1822, and the exponent 3.41 at
+         * :1853): the doubles those single-precision values convert to */
+        static const float num_flux[2] = {73.7095947f, 10.1706810f};
+        static const float diam[2] = {2.03347408e-07f, 1.09840811e-06f};
+        static const float gsd[2] = {2.0f, 2.2f};
+        for (int m = 0; m < 2; m++) {
+            flux[m] = (double)num_flux[m];
+            gm_radius[m] = (double)diam[m] / 2;                       /* driver:1849 */
+            gsd_log10[m] = log10((double)gsd[m]);                     /* driver:1850 */
+        }
+        *rate_scale = pow(wind_speed, (double)3.41f);                 /* driver:1853 */
+        return 2;
+    }
+    if (sea_salt_opt == 2) {                                          /* Ovadnevaite 2014 */
+        /* default-real literals in the reference (driver:1801-1805): the doubles those
+         * single-precision values convert to */
+        static const float sigma[5] = {1.37f, 1.5f, 1.42f, 1.53f, 1.85f};
+        static const float cmd[5] = {.018f, .041f, .09f, .23f, .83f};
+        static const float coef[5] = {104.5f, .0442f, 149.6f, 2.96f, .51f};
+        static const double offset[5] = {1e5, 1e5, 1e5, 1e5, 2e5};
+        static const float expon[5] = {.556f, 1.08f, .545f, .79f, .87f};
+        const double Re = 3.1e6;                                      /* driver:1909 */
+        for (int m = 0; m < 5; m++) {
+            gm_radius[m] = .5 * (double)cmd[m] * 1e-6;                /* driver:1906 */
+            gsd_log10[m] = log10((double)sigma[m]);
+            flux[m] = (double)coef[m] * pow(Re - offset[m], (double)expon[m]);  /* driver:1910 */
+        }
+        *rate_scale = 1.0;
+        return 5;
+    }
+    return 0;
+}
+
+int pmco_seasalt_emissions(pmco_cell *c, double dt, double create_time, uint64_t seed,
+                           uint32_t cell_id, uint32_t step, int sea_salt_opt, double wind_speed,
+                           double height, int i_na, int i_cl, const int32_t *mode_class,
+                           const int32_t *mode_source, int64_t *next_id, int32_t *n_emit)
+{
+    double flux[5], gm[5], gsd[5], scale, f_na, rate[5], lg[5], ls[5];
+    int32_t cls[5] = {0, 0, 0, 0, 0}, src[5] = {0, 0, 0, 0, 0};
+    const int M = pmco_seasalt_modes(sea_salt_opt, wind_speed, flux, gm, gsd, &scale, &f_na);
+    int status = 0;
+    *n_emit = 0;
+    if (M == 0) return 0;
+    double *vf = (double *)calloc((size_t)M * c->n_spec, sizeof(double));
+    for (int m = 0; m < M; m++) {
+        rate[m] = flux[m] * scale / height;       /* p = emission_rate_scale dt / height, :1917 */
+        lg[m] = log(gm[m]);
+        ls[m] = gsd[m] * log(10.0);
+        vf[m * c->n_spec + i_na] = f_na;
+        vf[m * c->n_spec + i_cl] = 1.0 - f_na;
+        if (mode_class) cls[m] = mode_class[m];
+        if (mode_source) src[m] = mode_source[m];
+    }
+    pmco_aero_dist d = {M, rate, lg, ls, vf, cls, src};
+    *c->sort_valid = 0;
+    *n_emit = add_dist_sample(c, &d, dt, 2, create_time, seed, cell_id, step, next_id, &status);
+    free(vf);
+    return status;
+}
+
+/* ------------------------------------------------------------------------
  * scenario_update_gas_state of one cell (pmco.h).  [UPSTREAM-UNCITED]
  * ---------------------------------------------------------------------- */
 double pmco_interp_1d(int n, const double *x, const double *y, int y_stride, double xq)

@@ -192,6 +192,22 @@ int pmco_scenario_update(pmco_cell *c, double dt, double create_time, uint64_t s
                          int64_t *next_id, int32_t *n_emit, int32_t *n_dil_in,
                          int32_t *n_dil_out);
 
+/* seasalt_emissions (interface/wrf_pmc_driver.F90:1767-1924): the modes of the sea-salt source
+ * for option 1 (Gong, the MAM3-matched pair of log-normal modes, :1834-1854) or 2 (Ovadnevaite
+ * et al. 2014, five modes, :1886-1912, with the reference's fixed Re = 3.1e6, :1909), and the
+ * factor emission_rate_scale (wind_speed**3.41 or 1).  flux [n_modes] in # m^-2 s^-1,
+ * gm_radius [m], gsd_log10; returns n_modes (0: unknown option).  Particles are Na and Cl with
+ * volume fractions mw_na / (mw_na + mw_cl) and the rest (:1830-1833). */
+int pmco_seasalt_modes(int sea_salt_opt, double wind_speed, double *flux, double *gm_radius,
+                       double *gsd_log10, double *rate_scale, double *vol_frac_na);
+/* one cell's sea-salt source over dt: the emission law of pmco_scenario_update with those modes,
+ * rate = flux * rate_scale / height per mode, drawn at RNG kind 2 (so that it is independent of
+ * the scenario's own emission in the same step) */
+int pmco_seasalt_emissions(pmco_cell *c, double dt, double create_time, uint64_t seed,
+                           uint32_t cell_id, uint32_t step, int sea_salt_opt, double wind_speed,
+                           double height, int i_na, int i_cl, const int32_t *mode_class,
+                           const int32_t *mode_source, int64_t *next_id, int32_t *n_emit);
+
 /* scenario_update_gas_state (call: wrf_pmc_driver.F90:202-205) for one cell: the gas phase
  * gas_state%mix_rat(:) [ppb] gains the emissions and is diluted towards the background
  * [UPSTREAM-UNCITED: PartMC scenario.F90; restated from the published model description,

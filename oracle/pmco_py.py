@@ -240,6 +240,20 @@ class Cell:
                                         C.byref(ni), C.byref(no))
         return st, nid.value, ne.value, ni.value, no.value
 
+    def seasalt_emissions(self, dt, create_time, seed, cell_id, step, sea_salt_opt, wind_speed,
+                          height, i_na, i_cl, mode_class, mode_source, next_id):
+        """pmco_seasalt_emissions of this cell; returns (status, next_id, n_emit)."""
+        f = lib().pmco_seasalt_emissions
+        f.restype = C.c_int
+        f.argtypes = [C.POINTER(CellStruct), C.c_double, C.c_double, C.c_uint64, C.c_uint32,
+                      C.c_uint32, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, _ip, _ip, _lp, _ip]
+        mc = np.ascontiguousarray(mode_class, dtype=np.int32)
+        ms = np.ascontiguousarray(mode_source, dtype=np.int32)
+        nid, ne = C.c_int64(next_id), C.c_int32(0)
+        st = f(C.byref(self.view()), dt, create_time, seed, cell_id, step, sea_salt_opt, wind_speed,
+               height, i_na, i_cl, _p(mc, _ip), _p(ms, _ip), C.byref(nid), C.byref(ne))
+        return st, nid.value, ne.value
+
     def dry_deposition(self, dt, seed, cell_id, step, aer_res_a, ustar, alpha, big_a, height,
                        inv_density):
         """dry_dep_aero_state of this cell; returns (n_removed, unrealistic)."""
@@ -321,6 +335,17 @@ def scenario_update_gas(mix_rat, dt, temp, pressure, height, old_height, emissio
       None if em is None else _p(em, _dp), emission_rate_scale,
       None if bg is None else _p(bg, _dp), dilution_rate)
     return mr
+
+
+def seasalt_modes(sea_salt_opt, wind_speed):
+    """(flux, gm_radius, gsd_log10, rate_scale, vol_frac_na) of the sea-salt source."""
+    f = lib().pmco_seasalt_modes
+    f.restype = C.c_int
+    f.argtypes = [C.c_int, C.c_double, _dp, _dp, _dp, _dp, _dp]
+    fl, gm, gs = np.zeros(5), np.zeros(5), np.zeros(5)
+    sc, na = C.c_double(), C.c_double()
+    m = f(sea_salt_opt, wind_speed, _p(fl, _dp), _p(gm, _dp), _p(gs, _dp), C.byref(sc), C.byref(na))
+    return fl[:m], gm[:m], gs[:m], sc.value, na.value
 
 
 def sort(cell):

@@ -754,6 +754,62 @@ def test_scenario_update_parity(wp, oracle):
     blk.close()
 
 
+@pytest.mark.parametrize("sea_salt_opt", [1, 2])
+def test_seasalt_emissions_parity(wp, oracle, sea_salt_opt):
+    """seasalt_emissions (driver:212-223, 1767-1924) on the ocean surface cells, both options."""
+    n_cells, n_part, n_spec, n_class = 4, 600, 3, 2
+    n_modes = 2 if sea_salt_opt == 1 else 5
+    blk, cells, info = parity.setup_pair(wp, oracle, n_cells, n_part, n_spec, n_class, 5, K_BROWN,
+                                         cap=8192, n_source=n_modes)
+    i_na, i_cl = 2, 0
+    ocean = np.array([1, 0, 1, 1], dtype=np.int32)
+    wind = np.array([7.5, 9.0, 0.0, 12.25])
+    height = np.array([55.0, 60.0, 48.0, 71.5])
+    # weights such that a 600 s step adds a few hundred computational particles per mode
+    fl, _, _, _, f_na = oracle.seasalt_modes(sea_salt_opt, 10.0)
+    assert len(fl) == n_modes and abs(f_na - 22.990 / 58.44) < 1e-15
+    mag = np.tile([[fl.sum() * 600.0 / 50.0 / 300.0, fl.sum() * 600.0 / 50.0 / 40.0]], (n_cells, 1))
+    if sea_salt_opt == 1:
+        mag *= 10.0 ** 3.41
+    blk.set_weights(mag)
+    for oc in cells:
+        oc.mag[:] = mag[0]
+    mode_class = np.arange(n_modes, dtype=np.int32) % n_class
+    mode_source = np.arange(n_modes, dtype=np.int32)
+    for step in range(2):
+        ne, rate = blk.seasalt_emissions(600.0, 600.0 * step, sea_salt_opt, i_na, i_cl, ocean, wind,
+                                         height, seed=5, step=step, mode_class=mode_class,
+                                         mode_source=mode_source)
+        for c, oc in enumerate(cells):
+            flux, _, _, scale, _ = oracle.seasalt_modes(sea_salt_opt, wind[c])
+            if not ocean[c]:
+                assert ne[c] == 0 and not rate[c].any()
+                continue
+            np.testing.assert_array_equal(rate[c], flux * scale / height[c])
+            st, oc.next_id, one = oc.seasalt_emissions(600.0, 600.0 * step, 5, oc.cell_id, step,
+                                                       sea_salt_opt, wind[c], height[c], i_na, i_cl,
+                                                       mode_class, mode_source, oc.next_id)
+            assert st == 0 and one == int(ne[c]), (step, c)
+        ok, msg = parity.compare_state(blk, cells)
+        assert ok, f"step {step}: {msg}"
+        assert np.array_equal(blk.get_next_id(), [oc.next_id for oc in cells])
+        ns, nc, st = blk.mc_coag(K_BROWN, 60.0, 5, step)
+        for c, oc in enumerate(cells):
+            assert oc.mc_coag(K_BROWN, 60.0, 5, oc.cell_id, step) == (int(st[c]), int(ns[c]), int(nc[c]))
+    assert ne[0] > 40 and ne[3] > 40 and ne[1] == 0
+    if sea_salt_opt == 1:
+        assert ne[2] == 0 and ne[3] > 2 * ne[0]          # no wind, no Gong flux; u**3.41
+    else:
+        assert ne[2] > 40                                # Ovadnevaite: the reference's fixed Re
+    ok, msg = parity.compare_state(blk, cells)
+    assert ok, msg
+    with pytest.raises(wp.PmcxError):
+        blk.seasalt_emissions(600.0, 0.0, 3, i_na, i_cl, ocean, wind, height)
+    with pytest.raises(wp.PmcxError):
+        blk.seasalt_emissions(600.0, 0.0, 1, 1, 1, ocean, wind, height)
+    blk.close()
+
+
 def test_golden_config1_on_gpu(wp):
     """BASELINE config 1 (1 cell, 1000 particles, Brownian, seed 0, 10 x 60 s) through the
     HIP path against the committed fixture tests/golden/single_cell_1000_seed0.json."""

@@ -651,3 +651,24 @@ def test_column_file_round_trip(oracle, tmp_path):
     assert np.array_equal(back["weight_magnitude"], wmag) and back["time"] == 126.0 and back["index"] == 42
     # mass = vol * density, vol = mass / density (:1421, init:1232): exact to one rounding each way
     np.testing.assert_allclose(back["vol"], state["vol"], rtol=3e-16, atol=0)
+
+
+def test_seasalt_modes_against_the_published_formulas(oracle):
+    """pmco_seasalt_modes against a numpy transcription of driver:1800-1822, 1830-1854, 1886-1914:
+    single-precision literals widened to double, Re fixed at 3.1e6."""
+    f32 = lambda *v: np.array(v, dtype=np.float32).astype(np.float64)
+    fl, gm, gs, sc, na = oracle.seasalt_modes(1, 8.0)
+    np.testing.assert_array_equal(fl, f32(73.7095947, 10.1706810))
+    np.testing.assert_array_equal(gm, f32(2.03347408e-07, 1.09840811e-06) / 2)
+    np.testing.assert_allclose(gs, np.log10([2.0, f32(2.2)[0]]), rtol=1e-15)
+    assert abs(sc - 8.0 ** f32(3.41)[0]) <= 1e-12 * sc and na == 22.990 / (22.990 + 35.450)
+    fl, gm, gs, sc, na = oracle.seasalt_modes(2, 8.0)
+    coef, expon = f32(104.5, .0442, 149.6, 2.96, .51), f32(.556, 1.08, .545, .79, .87)
+    off = np.array([1e5, 1e5, 1e5, 1e5, 2e5])
+    np.testing.assert_allclose(fl, coef * (3.1e6 - off) ** expon, rtol=1e-14)
+    np.testing.assert_array_equal(gm, .5 * f32(.018, .041, .09, .23, .83) * 1e-6)
+    np.testing.assert_allclose(gs, np.log10(f32(1.37, 1.5, 1.42, 1.53, 1.85)), rtol=1e-15)
+    assert sc == 1.0
+    # Ovadnevaite et al. 2014 table: total flux at Re = 3.1e6 is ~2e6 m^-2 s^-1
+    assert 1.5e6 < fl.sum() < 2.5e6
+    assert oracle.seasalt_modes(3, 8.0)[0].size == 0

@@ -948,6 +948,79 @@ int pmcx_scenario_update_aero_state(pmcx_ctx *ctx, double dt, double elapsed_tim
     return PMCX_OK;
 }
 
+int pmcx_seasalt_emissions(pmcx_ctx *ctx, double dt, double elapsed_time, uint64_t seed, uint32_t step,
+                           int32_t sea_salt_opt, int32_t i_na, int32_t i_cl,
+                           const int32_t *ocean_surface, const double *wind_speed,
+                           const double *height, const int32_t *mode_class,
+                           const int32_t *mode_source, int32_t *n_emit, double *rate)
+{
+    if (!ctx || !ocean_surface || !wind_speed || !height)
+        return fail(ctx, PMCX_EINVAL, "pmcx_seasalt_emissions: null argument");
+    if (!ctx->aero_data_set) return fail(ctx, PMCX_ESTATE, "pmcx_set_aero_data must come first");
+    const int S = ctx->cfg.n_spec;
+    if (i_na < 0 || i_na >= S || i_cl < 0 || i_cl >= S || i_na == i_cl || !(dt >= 0))
+        return fail(ctx, PMCX_EINVAL, "pmcx_seasalt_emissions: bad species index or dt");
+    // the reference's constants (interface/wrf_pmc_driver.F90; default-real literals are the
+    // doubles their single-precision values convert to)
+    int M = 0;
+    double flux[5], gm[5], gsd[5];
+    const double f_na = 22.990 / (22.990 + 35.450);                      // driver:1830-1831
+    if (sea_salt_opt == 1) {                                             // Gong, MAM3 modes
+        const float nf[2] = {73.7095947f, 10.1706810f}, dm[2] = {2.03347408e-07f, 1.09840811e-06f},
+                    sg[2] = {2.0f, 2.2f};                                // driver:1819-1822
+        M = 2;
+        for (int m = 0; m < M; m++) { flux[m] = (double)nf[m]; gm[m] = (double)dm[m] / 2; gsd[m] = std::log10((double)sg[m]); }
+    } else if (sea_salt_opt == 2) {                                      // Ovadnevaite 2014
+        const float sigma[5] = {1.37f, 1.5f, 1.42f, 1.53f, 1.85f}, cmd[5] = {.018f, .041f, .09f, .23f, .83f},
+                    coef[5] = {104.5f, .0442f, 149.6f, 2.96f, .51f}, expon[5] = {.556f, 1.08f, .545f, .79f, .87f};
+        const double offset[5] = {1e5, 1e5, 1e5, 1e5, 2e5}, Re = 3.1e6;  // driver:1800-1805, 1909
+        M = 5;
+        for (int m = 0; m < M; m++) {
+            gm[m] = .5 * (double)cmd[m] * 1e-6;
+            gsd[m] = std::log10((double)sigma[m]);
+            flux[m] = (double)coef[m] * std::pow(Re - offset[m], (double)expon[m]);
+        }
+    } else {
+        return fail(ctx, PMCX_EINVAL, "pmcx_seasalt_emissions: sea_salt_opt must be 1 (Gong) or 2 (Ovadnevaite)");
+    }
+    const size_t nc = (size_t)ctx->cfg.n_cells;
+    std::vector<double> conc(nc * (size_t)M, 0.0), vf((size_t)M * S, 0.0);
+    for (size_t c = 0; c < nc; c++) {
+        if (!ocean_surface[c]) continue;
+        if (!(height[c] > 0) || !(wind_speed[c] >= 0))
+            return fail(ctx, PMCX_EINVAL, "pmcx_seasalt_emissions: height must be positive, wind speed non-negative (cell %zu)", c);
+        const double scale = sea_salt_opt == 1 ? std::pow(wind_speed[c], (double)3.41f) : 1.0; // driver:1853, 1914
+        for (int m = 0; m < M; m++) conc[c * M + m] = flux[m] * scale / height[c];              // driver:1917
+    }
+    for (int m = 0; m < M; m++) { vf[(size_t)m * S + i_na] = f_na; vf[(size_t)m * S + i_cl] = 1.0 - f_na; }
+    if (rate) memcpy(rate, conc.data(), sizeof(double) * conc.size());
+    pmcx_aero_dist d{};
+    d.n_mode = M; d.num_conc = conc.data(); d.gm_radius = gm; d.gsd_log10 = gsd; d.vol_frac = vf.data();
+    d.mode_class = mode_class; d.mode_source = mode_source;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    std::vector<void *> tmp;
+    auto cleanup = [&]() { for (void *p : tmp) (void)hipFree(p); };
+    GenSpecDev ge{};
+    double *ce = nullptr;
+    int32_t *d_cnt = nullptr;
+    int rc = upload_dist(ctx, &d, tmp, ge, ce);
+    if (rc) { cleanup(); return rc; }
+    hipError_t e = hipMalloc((void **)&d_cnt, sizeof(int32_t) * nc);
+    if (e == hipSuccess) tmp.push_back(d_cnt);
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->st.status, 0, sizeof(int32_t) * nc, ctx->stream);
+    if (e == hipSuccess) {
+        ProfScope ps(ctx, "scenario");
+        e = launch_scenario_update(ctx->st, dt, elapsed_time, seed, step, &ge, ce, nullptr, nullptr, nullptr,
+                                   d_cnt, nullptr, nullptr, ctx->stream, 2u);
+    }
+    if (e == hipSuccess && n_emit) e = hipMemcpyAsync(n_emit, d_cnt, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    cleanup();
+    HIP_TRY(ctx, invalidate_sort(ctx, 0, ctx->cfg.n_cells, false));
+    if (e != hipSuccess) return fail(ctx, PMCX_EDEVICE, "pmcx_seasalt_emissions: %s", hipGetErrorString(e));
+    return PMCX_OK;
+}
+
 int pmcx_dry_deposition(pmcx_ctx *ctx, double dt, uint64_t seed, uint32_t step,
                         const int32_t *surface, const double *aer_res_a, const double *ustar,
                         const double *alpha, const double *big_a, const double *height,

@@ -2524,7 +2524,8 @@ __global__ __launch_bounds__(64) void k_scenario_update(DeviceState st, double d
                                                         uint64_t seed, uint32_t step,
                                                         AeroDistDev emission, const double *dilution_rate,
                                                         AeroDistDev background, int32_t *n_emit,
-                                                        int32_t *n_dil_in, int32_t *n_dil_out)
+                                                        int32_t *n_dil_in, int32_t *n_dil_out,
+                                                        uint32_t emit_kind)
 {
     const int lane = threadIdx.x;
     const int c = blockIdx.x;
@@ -2534,7 +2535,7 @@ __global__ __launch_bounds__(64) void k_scenario_update(DeviceState st, double d
     int status = 0, ne = 0, ni = 0, no = 0;
     apply_event_log(st, c, lane);
     if (emission.n_mode > 0)
-        ne = add_dist_sample(st, c, emission, dt, 0u, create_time, seed, step, status, lane);
+        ne = add_dist_sample(st, c, emission, dt, emit_kind, create_time, seed, step, status, lane);
     const double rate = dilution_rate ? dilution_rate[c] : 0.0;
     if (rate > 0.0) {
         const double p_loss = 1.0 - det_exp(-rate * dt);
@@ -3665,7 +3666,7 @@ hipError_t launch_scenario_update(const DeviceState &st, double dt, double creat
                                   uint32_t step, const GenSpecDev *em, const double *em_conc,
                                   const double *dilution_rate, const GenSpecDev *bg,
                                   const double *bg_conc, int32_t *n_emit, int32_t *n_dil_in,
-                                  int32_t *n_dil_out, hipStream_t s)
+                                  int32_t *n_dil_out, hipStream_t s, uint32_t emit_kind)
 {
     AeroDistDev e{0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, b = e;
     if (em) e = AeroDistDev{em->n_mode, em_conc, em->ln_gm_radius, em->ln_gsd, em->vol_frac,
@@ -3673,7 +3674,7 @@ hipError_t launch_scenario_update(const DeviceState &st, double dt, double creat
     if (bg) b = AeroDistDev{bg->n_mode, bg_conc, bg->ln_gm_radius, bg->ln_gsd, bg->vol_frac,
                             bg->mode_class, bg->mode_source};
     hipLaunchKernelGGL(k_scenario_update, dim3(st.n_cells), dim3(64), 0, s, st, dt, create_time,
-                       seed, step, e, dilution_rate, b, n_emit, n_dil_in, n_dil_out);
+                       seed, step, e, dilution_rate, b, n_emit, n_dil_in, n_dil_out, emit_kind);
     return hipGetLastError();
 }
 hipError_t launch_gas_update(const GasScenarioDev &g, double *mix_rat, const double *temp,

@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = [
     "pmcx_device_copy",
     "pmcx_memory_bytes", "pmcx_device_memory_info", "pmcx_set_cell_id_base", "pmcx_set_gas_state",
     "pmcx_get_gas_state", "pmcx_set_gas_scenario", "pmcx_scenario_update_gas_state",
-    "pmcx_invalidate_lists", "pmcx_get_keys",
+    "pmcx_invalidate_lists", "pmcx_get_keys", "pmcx_seasalt_emissions",
 ]
 
 
@@ -145,6 +145,8 @@ def load_library():
     L.pmcx_device_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
     L.pmcx_dry_deposition.argtypes = [C.c_void_p, C.c_double, C.c_uint64, C.c_uint32] + [C.c_void_p] * 9
     L.pmcx_timestep.argtypes = [C.c_void_p, C.POINTER(PmcxStepFlags)]
+    L.pmcx_seasalt_emissions.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_uint64, C.c_uint32,
+                                         C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 7
     L.pmcx_get_keys.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pmcx_set_cell_id_base.argtypes = [C.c_void_p, C.c_uint32]
     L.pmcx_set_gas_state.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
@@ -448,6 +450,24 @@ class CellBlock:
             self._h, dt, elapsed_time, seed, step, C.addressof(e) if e else None, _ptr(dil),
             C.addressof(b) if b else None, _ptr(ne), _ptr(ni), _ptr(no)))
         return ne, ni, no
+
+    def seasalt_emissions(self, dt, elapsed_time, sea_salt_opt, i_na, i_cl, ocean_surface, wind_speed,
+                          height, seed=0, step=0, mode_class=None, mode_source=None):
+        """seasalt_emissions on the ocean surface cells (driver:212-223, 1767-1924): option 1
+        Gong (two MAM3-matched modes x wind**3.41), 2 Ovadnevaite 2014 (five modes).
+        Returns (n_emit [n_cells], rate [n_cells][n_modes])."""
+        n = self.cfg.n_cells
+        M = 2 if sea_salt_opt == 1 else 5
+        oc = np.ascontiguousarray(np.broadcast_to(ocean_surface, (n,)), dtype=np.int32)
+        ws = np.ascontiguousarray(np.broadcast_to(_f64(wind_speed), (n,)))
+        h = np.ascontiguousarray(np.broadcast_to(_f64(height), (n,)))
+        mc = None if mode_class is None else np.ascontiguousarray(mode_class, dtype=np.int32)
+        ms = None if mode_source is None else np.ascontiguousarray(mode_source, dtype=np.int32)
+        ne, rate = np.zeros(n, dtype=np.int32), np.zeros((n, M))
+        self._ck(self._lib.pmcx_seasalt_emissions(self._h, dt, elapsed_time, seed, step, sea_salt_opt,
+                                                  i_na, i_cl, _ptr(oc), _ptr(ws), _ptr(h), _ptr(mc),
+                                                  _ptr(ms), _ptr(ne), _ptr(rate)))
+        return ne, rate
 
     # -- transport of a slab across ranks (ghost rows j = 0 and j = ny - 1) -----
     def transport_begin(self, nx, nz, ny, prob_h, prob_v, cell_volume, seed=0, step=0,
