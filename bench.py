@@ -300,6 +300,10 @@ def main():
                     help="extra steps after the timed region with the sort invalidated before "
                          "each (reported as resort_every_step; 0 to skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sampler-lanes", type=int, default=0,
+                    help="diagnostic: pin the pair sampler's variant (pmcx_set_sampler_variant); 0 = automatic")
+    ap.add_argument("--sampler-stamps", action="store_true",
+                    help="diagnostic: the instantiation that records cycles per stage")
     ap.add_argument("--kernel", type=int, default=4,
                     help="coag_kernel_type (4 = COAG_KERNEL_TYPE_BROWN, the reference's; others for tuning)")
     ap.add_argument("--workload", choices=["domain", "config3"], default="domain",
@@ -349,6 +353,8 @@ def main():
     blk = wp.CellBlock(n_cells, args.cap, args.n_spec, n_class=1, n_source=0, device=device,
                        cell_id_base=first_cell, max_events=args.max_events,
                        max_appends=args.max_appends, i_water=(19 if config3 else -1))
+    if args.sampler_lanes or args.sampler_stamps:
+        blk.set_sampler_variant(args.sampler_lanes, 0, int(args.sampler_stamps))
     temp, pres = level_profile(args.levels)
     lev = (first_cell + np.arange(n_cells)) % args.levels
     if config3:
@@ -414,7 +420,7 @@ def main():
     parts = parts_after + coag    # one class: particles entering a step = survivors + events
     for k in KERNELS:
         prof_main[k] = blk.profile_get(k)
-    if os.environ.get("PMCX_SEQ_STAMPS") == "1" and rank == 0:   # diagnostic build of the sampler
+    if args.sampler_stamps and rank == 0:   # diagnostic build of the sampler
         ph = blk.profile_phase_cycles()
         w = max(ph[11], 1)
         names = ["setup", "1_pair_picked_entries_requested", "2_first_slot_found_philox",

@@ -245,6 +245,41 @@ int pmcx_seasalt_emissions(pmcx_ctx *ctx, double dt, double elapsed_time, uint64
                            const double *height, const int32_t *mode_class,
                            const int32_t *mode_source, int32_t *n_emit, double *rate);
 
+/*
+ * The transport probabilities of one step, built on the device from WRF's fields and the
+ * particle counts where they are (wrf_pmc_trans_driver's first half,
+ * interface/wrf_pmc_trans.F90:95-156): compute_advect_probs_wrf (:205-286),
+ * compute_diffusion_probs (:358-409), compute_vertical_probs (:414-562) with stable_timestep
+ * (:629-651), normalize_probs (:692-773).  Host arrays, single precision as grid% holds them,
+ * for the nx x nz x ny block, cell = (j*nz + k)*nx + i:
+ *   alt, xkhh       [ny+2][nz][nx+2]   one halo cell in x and y (grid%alt, grid%xkhh at i-1 .. i+1,
+ *                                      j-1 .. j+1 of WRF's memory)
+ *   u_flux          [n_class][ny][nz][nx+1]   (class c: grid%u_flux(:,:,:,c+2) in Fortran counting)
+ *   v_flux          [n_class][ny+1][nz][nx]
+ *   w_flux          [n_class][ny][nz+1][nx]
+ *   z               [ny][nz][nx];   z_at_w, exch_h  [ny][nz+1][nx]
+ * dt, dx, dy: grid%dt, %dx, %dy; do_vertmix: config_flags%vertmix_onoff; all_columns: do_uniform,
+ * do_scm or doubly periodic (:119-131) -- otherwise vertical probabilities exist only for the
+ * columns 2 .. global_n-1 (1-based) of the global domain, the block's first column being
+ * (i_offset, j_offset) (0-based).  aero_state_total_particles per class and the weight
+ * magnitudes are read from the context.
+ * The result stays on the device for the NEXT pmcx_transport / pmcx_transport_begin called with
+ * prob_h == prob_v == NULL (used once: the probabilities describe the populations as they were).
+ * Optional host copies: prob_h [n_cells][n_class][4], prob_v [n_cells][n_class][nz], n_substeps
+ * [ny][nx] (stable_timestep's count; 0: column skipped), bad [n_cells] (the reference's
+ * assertions 414897882 / 184874367 / 184874369 / 414897881 as bits 1 / 2 / 4 / 8; bit 16: more
+ * than 10^6 sub-steps asked for), n_class_part [n_cells][n_class].  Synchronises.
+ */
+typedef struct pmcx_trans_fields {
+    int32_t nx, nz, ny;
+    int32_t do_vertmix, all_columns;
+    int32_t i_offset, j_offset, global_nx, global_ny;
+    double dt, dx, dy;
+    const float *alt, *xkhh, *u_flux, *v_flux, *w_flux, *z, *z_at_w, *exch_h;
+} pmcx_trans_fields;
+int pmcx_transport_probs(pmcx_ctx *ctx, const pmcx_trans_fields *f, double *prob_h, double *prob_v,
+                         int32_t *n_substeps, int32_t *bad, int32_t *n_class_part);
+
 /* The same transport for a SLAB of a domain decomposed in y across ranks (one process per
  * GPU; wrf_pmc_trans_aero.F90 exchanges the movers between MPI patches).  The block carries
  * one ghost row below its first real row (j = 0) and one above its last (j = ny - 1); the
@@ -309,6 +344,7 @@ int pmcx_dry_deposition(pmcx_ctx *ctx, double dt, uint64_t seed, uint32_t step,
  * :2446-2460; the own level is ignored); cell_volume [n_cells] (the
  * dz_source/dz_dest weight factor, :2214-2218).  Lateral boundaries are periodic
  * or closed; exchange with other contexts (other GPUs) is not part of this call.
+ * prob_h == prob_v == NULL: the probabilities pmcx_transport_probs built (PMCX_ESTATE if none).
  * n_moved / n_arrived: [n_cells], may be NULL.  Synchronises.
  */
 int pmcx_transport(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int32_t periodic_x,
@@ -435,6 +471,14 @@ int pmcx_sort_only(pmcx_ctx *ctx);
 /* aero_state%valid_sort = .false. for every cell (what a host-side edit of the
  * particles implies; also used to time the sort on every step) */
 int pmcx_invalidate_sort(pmcx_ctx *ctx);
+/* Diagnostic: pin the pair sampler's launch shape instead of the library's own choice by
+ * domain size, so that tests can hold every variant to the oracle at small sizes.  lanes: 0
+ * automatic; 1 lane per cell (the full domain's kernel); 2 its two-wavefront form (a rank's
+ * share at N = 4, 8); 8, 16, 64 lanes per cell (small blocks).  wavefronts_per_group: 0
+ * automatic, 1, 2 or 4 (the 8/16/64 kernels).  stamps: 1 = the instantiation that records
+ * cycles per stage (pmcx_profile_phase_cycles).  Results do not depend on any of them. */
+int pmcx_set_sampler_variant(pmcx_ctx *ctx, int32_t lanes, int32_t wavefronts_per_group, int32_t stamps);
+
 /* The lists only: the library keeps, per slot, the sort key (group, or "tombstone") it was
  * last binned under, and a kernel that changes a population while keeping those keys current
  * leaves exactly this behind -- lists to be rebuilt from keys that hold.  The next sort then
@@ -470,7 +514,7 @@ int pmcx_profile_reset(pmcx_ctx *ctx);
 int pmcx_profile_get(pmcx_ctx *ctx, const char *name, double *ms, int64_t *launches);
 
 /* Diagnostic: s_memtime ticks per stage of the lane-per-cell sampler's pass, summed over
- * wavefronts, when the library runs with PMCX_SEQ_STAMPS=1 (a separate, slower
+ * wavefronts, after pmcx_set_sampler_variant(ctx, …, 1) (a separate, slower
  * instantiation of the kernel; zeros otherwise).  out[0] set-up; out[1..7] the seven stages of
  * a pass (pair picked and list entries requested; first slot found and Philox; particle
  * records requested; first count and second slot; kernel and accept; second count;

@@ -1234,3 +1234,189 @@ int pmco_transport(pmco_cell *cells, int n_cells, int nx, int nz, int ny, int pe
     return status;
 }
 
+
+/* ------------------------------------------------------------------------
+ * Transport probabilities (interface/wrf_pmc_trans.F90:95-156 and the routines it calls).
+ * ------------------------------------------------------------------------ */
+int pmco_transport_probs(const pmco_trans_fields *f, const int32_t *n_parts, const double *mag,
+                         double *prob_h, double *prob_v, int32_t *n_substeps, int32_t *bad)
+{
+    const int nx = f->nx, nz = f->nz, ny = f->ny, C = f->n_class;
+    if (nx < 1 || ny < 1 || nz < 2 || C < 1) return -1;
+    const size_t nc = (size_t)nx * nz * ny;
+    const double dt = f->dt, dx = f->dx, dy = f->dy;
+    /* prob_advection (1,0,0) (-1,0,0) (0,0,1) (0,0,-1) (0,1,0) (0,-1,0) per cell and class */
+    double *adv = (double *)calloc(nc * (size_t)C * 6, sizeof(double));
+    double *dif = (double *)calloc(nc * 4, sizeof(double));      /* x+, x-, y+, y- (all classes) */
+    double *B = (double *)malloc(sizeof(double) * (size_t)nz * nz * 4);
+    double *Bt = B + (size_t)nz * nz, *R = Bt + (size_t)nz * nz, *A = R + (size_t)nz * nz;
+    double *zm = (double *)malloc(sizeof(double) * (size_t)(5 * nz + 5));
+    double *rm = zm + nz, *zw = rm + nz, *kw = zw + nz + 1, *rw = kw + nz + 1;
+#define HALO(a, i, k, j) ((double)(a)[((size_t)((j) + 1) * nz + (k)) * (size_t)(nx + 2) + (size_t)((i) + 1)])
+#define HALOF(a, i, k, j) ((a)[((size_t)((j) + 1) * nz + (k)) * (size_t)(nx + 2) + (size_t)((i) + 1)])
+    for (int j = 0; j < ny; j++)
+        for (int k = 0; k < nz; k++)
+            for (int i = 0; i < nx; i++) {
+                const size_t c = ((size_t)j * nz + k) * nx + i;
+                const double rho_mass = 1.0 / HALO(f->alt, i, k, j);
+                /* compute_advect_probs_wrf (:205-286) */
+                for (int cl = 0; cl < C; cl++) {
+                    double *a = adv + (c * C + cl) * 6;
+                    const double mix_rat = (double)n_parts[c * C + cl] * mag[c * C + cl] / rho_mass;
+                    const float ue = f->u_flux[(((size_t)cl * ny + j) * nz + k) * (size_t)(nx + 1) + i + 1];
+                    const float uw = f->u_flux[(((size_t)cl * ny + j) * nz + k) * (size_t)(nx + 1) + i];
+                    const float vn = f->v_flux[(((size_t)cl * (ny + 1) + j + 1) * nz + k) * (size_t)nx + i];
+                    const float vs = f->v_flux[(((size_t)cl * (ny + 1) + j) * nz + k) * (size_t)nx + i];
+                    const float wu = f->w_flux[(((size_t)cl * ny + j) * (nz + 1) + k + 1) * (size_t)nx + i];
+                    const float wd = f->w_flux[(((size_t)cl * ny + j) * (nz + 1) + k) * (size_t)nx + i];
+                    if (mix_rat > 0.0) {
+                        if (ue > 0.0f) a[0] = (double)ue / mix_rat;
+                        if (uw < 0.0f) a[1] = -1.0 * (double)uw / mix_rat;
+                        if (vn > 0.0f) a[2] = (double)vn / mix_rat;
+                        if (vs < 0.0f) a[3] = -1.0 * (double)vs / mix_rat;
+                        if (wu > 0.0f) { const double q = (double)wu / mix_rat; a[4] = q < .95 ? q : .95; }
+                        if (wd < 0.0f) { const double q = -1.0 * (double)wd / mix_rat; a[5] = q < .95 ? q : .95; }
+                    }
+                    /* sum over (-1:1,-1:1,-1:1) in array element order: y-, z-, x-, x+, z+, y+ */
+                    const double ps = ((((a[3] + a[5]) + a[1]) + a[0]) + a[4]) + a[2];
+                    if (ps > 1.0)
+                        for (int d = 0; d < 6; d++) a[d] = a[d] / (ps + 1.0e-8);
+                }
+                /* compute_diffusion_probs (:358-409) */
+                const int di[4] = {1, -1, 0, 0}, dj[4] = {0, 0, 1, -1};
+                for (int d = 0; d < 4; d++) {
+                    const float ksum = HALOF(f->xkhh, i, k, j) + HALOF(f->xkhh, i + di[d], k, j + dj[d]);
+                    double diff_coef = .5 * (double)ksum;
+                    if (!(diff_coef > 0.0)) diff_coef = 0.0;
+                    const double rho_edge = .5 * (rho_mass + (1.0 / HALO(f->alt, i + di[d], k, j + dj[d])));
+                    const double h = d < 2 ? dx : dy;
+                    dif[c * 4 + d] = (dt * diff_coef * rho_edge) / (h * h * rho_mass);
+                }
+            }
+    memset(prob_v, 0, sizeof(double) * nc * (size_t)C * nz);
+    for (int j = 0; j < ny; j++)
+        for (int i = 0; i < nx; i++) {
+            if (n_substeps) n_substeps[(size_t)j * nx + i] = 0;
+            if (!f->all_columns) {
+                const int gi = i + f->i_offset + 1, gj = j + f->j_offset + 1;
+                if (gi < 2 || gi > f->global_nx - 1 || gj < 2 || gj > f->global_ny - 1) continue;
+            }
+#define COL(a, k, nzz) ((a)[((size_t)j * (nzz) + (k)) * (size_t)nx + i])
+            /* stable_timestep (:629-651) */
+            const double min_dz = (double)(COL(f->z, 1, nz) - COL(f->z, 0, nz));  /* single-precision difference */
+            float kmaxf = COL(f->exch_h, 0, nz + 1);
+            for (int k = 1; k <= nz; k++) if (COL(f->exch_h, k, nz + 1) > kmaxf) kmaxf = COL(f->exch_h, k, nz + 1);
+            const double max_k = (double)kmaxf > 1.0e-6 ? (double)kmaxf : 1.0e-6;
+            const double max_time = .1 * (min_dz * min_dz) / max_k;
+            const int num_steps = (int)ceil(dt / max_time);
+            const double small_dt = dt / num_steps;
+            if (n_substeps) n_substeps[(size_t)j * nx + i] = num_steps;
+            /* compute_vertical_probs (:414-562) */
+            for (int k = 0; k < nz; k++) {
+                zm[k] = (double)COL(f->z, k, nz);
+                rm[k] = 1.0 / HALO(f->alt, i, k, j);
+            }
+            for (int k = 0; k <= nz; k++) { zw[k] = (double)COL(f->z_at_w, k, nz + 1); kw[k] = 0.0; }
+            for (int k = 0; k < nz - 1; k++) {
+                const double e = (double)COL(f->exch_h, k + 1, nz + 1);
+                kw[k] = e > 1.0e-6 ? e : 1.0e-6;
+                const double tmp = zm[k + 1] - zm[k];
+                rw[k] = ((zm[k + 1] - zw[k + 1]) / tmp) * rm[k] + ((zw[k + 1] - zm[k]) / tmp) * rm[k + 1];
+            }
+            memset(B, 0, sizeof(double) * (size_t)nz * nz);
+#define M(a, r, q) ((a)[(size_t)(r) * nz + (q)])
+            for (int k = 1; k < nz - 1; k++) {
+                M(B, k, k - 1) = (small_dt / ((zw[k + 1] - zw[k]) * (zm[k] - zm[k - 1]))) * (rw[k - 1] / rm[k]) * kw[k - 1];
+                M(B, k, k + 1) = (small_dt / ((zw[k + 1] - zw[k]) * (zm[k + 1] - zm[k]))) * (rw[k] / rm[k]) * kw[k];
+                M(B, k, k) = 1.0 - M(B, k, k - 1) - M(B, k, k + 1);
+            }
+            M(B, 0, 1) = (small_dt / ((zw[1] - zw[0]) * (zm[1] - zm[0]))) * (rw[0] / rm[0]) * kw[0];
+            M(B, 0, 0) = 1.0 - M(B, 0, 1);
+            M(B, nz - 1, nz - 2) = (small_dt / ((zw[nz] - zw[nz - 1]) * (zm[nz - 1] - zm[nz - 2])))
+                                   * (rw[nz - 2] / rm[nz - 1]) * kw[nz - 2];
+            M(B, nz - 1, nz - 1) = 1.0 - M(B, nz - 1, nz - 2);
+            memcpy(Bt, B, sizeof(double) * (size_t)nz * nz);
+            for (int t = 2; t <= num_steps; t++) {
+                for (int r = 0; r < nz; r++)
+                    for (int q = 0; q < nz; q++) {
+                        double acc = 0.0;
+                        for (int m = 0; m < nz; m++) acc = acc + M(Bt, r, m) * M(B, m, q);
+                        M(R, r, q) = acc;
+                    }
+                for (int r = 0; r < nz; r++) {
+                    double rs = 0.0;
+                    for (int q = 0; q < nz; q++) rs = rs + M(R, r, q);
+                    for (int q = 0; q < nz; q++) M(Bt, r, q) = M(R, r, q) / rs;
+                }
+            }
+            for (int cl = 0; cl < C; cl++) {
+#define ADV(k, d) adv[((((size_t)j * nz + (k)) * nx + i) * C + cl) * 6 + (d)]
+                memset(A, 0, sizeof(double) * (size_t)nz * nz);
+                for (int k = 1; k < nz - 1; k++) {
+                    M(A, k, k) = 1.0 - (ADV(k, 4) + ADV(k, 5));
+                    M(A, k, k - 1) = ADV(k, 5);
+                    M(A, k, k + 1) = ADV(k, 4);
+                }
+                M(A, 0, 0) = 1.0 - ADV(0, 4);
+                M(A, 0, 1) = ADV(0, 4);
+                M(A, nz - 1, nz - 1) = 1.0 - ADV(nz - 1, 5);
+                M(A, nz - 1, nz - 2) = ADV(nz - 1, 5);
+                for (int r = 0; r < nz; r++)
+                    for (int q = 0; q < nz; q++) {
+                        double acc = 0.0;
+                        if (f->do_vertmix > 0)
+                            for (int m = 0; m < nz; m++) acc = acc + M(Bt, r, m) * M(A, m, q);
+                        else
+                            acc = M(A, r, q);
+                        prob_v[((((size_t)j * nz + r) * nx + i) * C + cl) * nz + q] = acc;
+                    }
+            }
+        }
+    /* normalize_probs (:692-773) */
+    for (size_t c = 0; c < nc; c++) {
+        const int k_own = (int)((c / (size_t)nx) % (size_t)nz);
+        int flag = 0;
+        for (int cl = 0; cl < C; cl++) {
+            double *a = adv + (c * C + cl) * 6, *pv = prob_v + (c * C + cl) * nz;
+            double dl[4];
+            for (int d = 0; d < 4; d++) dl[d] = dif[c * 4 + d];
+            int neg = 0;
+            for (int d = 0; d < 6; d++) neg |= !(a[d] >= 0.0);
+            for (int d = 0; d < 4; d++) neg |= !(dl[d] >= 0.0);
+            for (int k = 0; k < nz; k++) neg |= !(pv[k] >= 0.0);
+            if (neg) flag |= 1;
+            /* sums in array element order: y-, x-, x+, y+ */
+            double ps = ((a[3] + a[1]) + a[0]) + a[2];
+            ps = ps + (((dl[3] + dl[1]) + dl[0]) + dl[2]);
+            for (int k = 0; k < nz; k++) if (k != k_own) ps = ps + pv[k];
+            if (ps >= 1.0) {
+                for (int k = 0; k < nz; k++) pv[k] = pv[k] / ps;
+                for (int d = 0; d < 4; d++) { dl[d] = dl[d] / ps; a[d] = a[d] / ps; }
+            }
+            neg = 0;
+            int big = 0;
+            for (int d = 0; d < 6; d++) { neg |= !(a[d] >= 0.0); big |= !(a[d] <= 1.0); }
+            for (int d = 0; d < 4; d++) { neg |= !(dl[d] >= 0.0); big |= !(dl[d] <= 1.0); }
+            for (int k = 0; k < nz; k++) { neg |= !(pv[k] >= 0.0); big |= !(pv[k] <= 1.0); }
+            if (neg) flag |= 2;
+            if (big) flag |= 4;
+            ps = ((a[3] + a[1]) + a[0]) + a[2];
+            ps = ps + (((dl[3] + dl[1]) + dl[0]) + dl[2]);
+            for (int k = 0; k < nz; k++) if (k != k_own) ps = ps + pv[k];
+            if (!(ps < 1.0 + 1.0e-8)) flag |= 8;
+            double *ph = prob_h + (c * C + cl) * 4;    /* i-1, i+1, j-1, j+1 */
+            ph[0] = a[1] + dl[1];
+            ph[1] = a[0] + dl[0];
+            ph[2] = a[3] + dl[3];
+            ph[3] = a[2] + dl[2];
+        }
+        if (bad) bad[c] = flag;
+    }
+#undef HALO
+#undef HALOF
+#undef COL
+#undef M
+#undef ADV
+    free(adv); free(dif); free(B); free(zm);
+    return 0;
+}

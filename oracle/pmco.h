@@ -239,6 +239,35 @@ int pmco_transport(pmco_cell *cells, int n_cells, int nx, int nz, int ny, int pe
                    const double *cell_volume, uint64_t seed, uint32_t cell_id_base,
                    uint32_t step, int64_t *next_id, int32_t *n_moved, int32_t *n_arrived);
 
+/* The transport probabilities of one step (wrf_pmc_trans_driver's first half,
+ * interface/wrf_pmc_trans.F90:95-156): compute_advect_probs_wrf (:205-286),
+ * compute_diffusion_probs (:358-409), compute_vertical_probs (:414-562) with
+ * stable_timestep (:629-651), normalize_probs (:692-773), for the nx x nz x ny block
+ * cell = (j*nz + k)*nx + i.  The WRF fields are single precision, as in grid%:
+ *   alt, xkhh         [ny+2][nz][nx+2]  with one halo cell in x and y (the reference reads
+ *                                       i-1, i+1, j-1, j+1 of WRF's memory)
+ *   u_flux            [n_class][ny][nz][nx+1]   (class c is the reference's u_flux(:,:,:,c+1))
+ *   v_flux            [n_class][ny+1][nz][nx]
+ *   w_flux            [n_class][ny][nz+1][nx]
+ *   z                 [ny][nz][nx]    z_at_w, exch_h  [ny][nz+1][nx]
+ * all_columns: do_uniform, do_scm or doubly periodic (:119-131); otherwise the vertical
+ * probabilities exist only for columns with global index 2 .. global_n-1 (1-based), the
+ * block's first column being (i_offset, j_offset) of the global domain (0-based).
+ * n_parts [n_cells][n_class]: aero_state_total_particles per class; mag likewise.
+ * Out: prob_h [n_cells][n_class][4] = prob_advection + prob_diffusion towards i-1, i+1,
+ * j-1, j+1; prob_v [n_cells][n_class][nz]; n_substeps [ny][nx] (0 where no vertical
+ * probabilities were built); bad [n_cells]: which of the reference's assertions would have
+ * stopped the run (1: negative before, 2: negative after, 4: above one, 8: sum >= 1 + 1e-8).
+ * The matrix products add their three non-zero terms in ascending inner index. */
+typedef struct {
+    int nx, nz, ny, n_class;
+    double dt, dx, dy;
+    int do_vertmix, all_columns, i_offset, j_offset, global_nx, global_ny;
+    const float *alt, *xkhh, *u_flux, *v_flux, *w_flux, *z, *z_at_w, *exch_h;
+} pmco_trans_fields;
+int pmco_transport_probs(const pmco_trans_fields *f, const int32_t *n_parts, const double *mag,
+                         double *prob_h, double *prob_v, int32_t *n_substeps, int32_t *bad);
+
 /* EXTENSION (no call site on the reference's timestep): water condensation,
  * kappa-Koehler growth ODE per particle, environment fixed over del_t. */
 void pmco_condense(pmco_cell *c, const double *kappa /*[n_spec]*/, int i_water,

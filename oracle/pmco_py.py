@@ -358,6 +358,48 @@ def sort(cell):
     return st.value
 
 
+class TransFields(C.Structure):
+    _fields_ = [("nx", C.c_int), ("nz", C.c_int), ("ny", C.c_int), ("n_class", C.c_int),
+                ("dt", C.c_double), ("dx", C.c_double), ("dy", C.c_double),
+                ("do_vertmix", C.c_int), ("all_columns", C.c_int), ("i_offset", C.c_int),
+                ("j_offset", C.c_int), ("global_nx", C.c_int), ("global_ny", C.c_int)] + \
+               [(n, C.POINTER(C.c_float)) for n in ("alt", "xkhh", "u_flux", "v_flux", "w_flux", "z",
+                                                    "z_at_w", "exch_h")]
+
+
+TRANS_FIELD_SHAPES = {   # (nx, nz, ny, n_class) -> shape
+    "alt": lambda nx, nz, ny, C_: (ny + 2, nz, nx + 2), "xkhh": lambda nx, nz, ny, C_: (ny + 2, nz, nx + 2),
+    "u_flux": lambda nx, nz, ny, C_: (C_, ny, nz, nx + 1), "v_flux": lambda nx, nz, ny, C_: (C_, ny + 1, nz, nx),
+    "w_flux": lambda nx, nz, ny, C_: (C_, ny, nz + 1, nx), "z": lambda nx, nz, ny, C_: (ny, nz, nx),
+    "z_at_w": lambda nx, nz, ny, C_: (ny, nz + 1, nx), "exch_h": lambda nx, nz, ny, C_: (ny, nz + 1, nx)}
+
+
+def transport_probs(nx, nz, ny, n_class, dt, dx, dy, fields, n_parts, mag, do_vertmix=1,
+                    all_columns=True, i_offset=0, j_offset=0, global_nx=None, global_ny=None):
+    """pmco_transport_probs; fields: dict of float32 arrays (TRANS_FIELD_SHAPES).
+    Returns (prob_h [n_cells][n_class][4], prob_v [n_cells][n_class][nz], n_substeps [ny][nx], bad)."""
+    keep = {}
+    tf = TransFields(nx, nz, ny, n_class, dt, dx, dy, int(do_vertmix), int(all_columns), i_offset,
+                     j_offset, nx if global_nx is None else global_nx, ny if global_ny is None else global_ny)
+    for name, shp in TRANS_FIELD_SHAPES.items():
+        a = np.ascontiguousarray(fields[name], dtype=np.float32)
+        assert a.shape == shp(nx, nz, ny, n_class), (name, a.shape)
+        keep[name] = a
+        setattr(tf, name, a.ctypes.data_as(C.POINTER(C.c_float)))
+    n = nx * nz * ny
+    npart = np.ascontiguousarray(n_parts, dtype=np.int32).reshape(n, n_class)
+    mg = np.ascontiguousarray(mag, dtype=np.float64).reshape(n, n_class)
+    ph, pv = np.zeros((n, n_class, 4)), np.zeros((n, n_class, nz))
+    ns, bad = np.zeros((ny, nx), dtype=np.int32), np.zeros(n, dtype=np.int32)
+    f = lib().pmco_transport_probs
+    f.restype = C.c_int
+    f.argtypes = [C.POINTER(TransFields), _ip, _dp, _dp, _dp, _ip, _ip]
+    rc = f(C.byref(tf), _p(npart, _ip), _p(mg, _dp), _p(ph, _dp), _p(pv, _dp), _p(ns, _ip), _p(bad, _ip))
+    if rc:
+        raise ValueError("pmco_transport_probs: bad dimensions")
+    return ph, pv, ns, bad
+
+
 def transport(cells, nx, nz, ny, prob_h, prob_v, cell_volume, seed, cell_id_base, step, next_id,
               periodic_x=True, periodic_y=True):
     """pmco_transport over a list of Cell objects (WRF order).  next_id: int64 array, updated."""

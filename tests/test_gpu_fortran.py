@@ -222,7 +222,6 @@ def test_transport_across_two_ranks():
     import subprocess
     import sys
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", PMCX_TEST_BACKEND="gloo")
-    env.pop("PMCX_SAMPLER_LANES", None)
     out = subprocess.run(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
          "--master-addr", "127.0.0.1", "--master-port", "29533",

@@ -14,17 +14,14 @@ K_BROWN, K_SEDI, K_ADD, K_CONST, K_ZERO, K_BS = 4, 1, 2, 3, 5, 101
 
 
 @pytest.fixture(autouse=True, params=["dispatch", "lane-per-cell", "lane-per-cell-split"])
-def sampler_variant(request, monkeypatch):
+def sampler_variant(request, monkeypatch, wp):
     """Every test of this module runs three times: with the library's own choice of sampler (the
     lanes-per-cell kernels at these cell counts), with the lane-per-cell kernel forced (the one
     the full-size domain runs) and with its two-wavefront form (evaluator + drawer, what a
     rank's share of the domain runs at N = 4, 8), so that all are held to the oracle."""
-    if request.param == "lane-per-cell":
-        monkeypatch.setenv("PMCX_SAMPLER_LANES", "1")
-    elif request.param == "lane-per-cell-split":
-        monkeypatch.setenv("PMCX_SAMPLER_LANES", "2")
-    else:
-        monkeypatch.delenv("PMCX_SAMPLER_LANES", raising=False)
+    variant = {"lane-per-cell": (1, 0, 0), "lane-per-cell-split": (2, 0, 0)}.get(request.param)
+    from wrf_partmc_amd import host
+    monkeypatch.setattr(host, "SAMPLER_VARIANT", variant)   # -> pmcx_set_sampler_variant
     return request.param
 
 
@@ -863,10 +860,9 @@ def test_results_independent_of_launch_geometry(wp, oracle, monkeypatch):
     """Same cells through the sampler with 1, 8, 16 and 64 lanes per cell and different
     workgroup sizes: identical particle data, counters and status."""
     outs = []
-    for lanes, wpb in (("8", "2"), ("16", "4"), ("64", "1"), ("8", "1"), ("1", "1")):
-        monkeypatch.setenv("PMCX_SAMPLER_LANES", lanes)
-        monkeypatch.setenv("PMCX_SAMPLER_WPB", wpb)
+    for lanes, wpb in ((8, 2), (16, 4), (64, 1), (8, 1), (1, 1), (2, 0)):
         blk = wp.CellBlock(5, 1536, 2, n_class=2, n_source=2, max_appends=128)
+        blk.set_sampler_variant(lanes, wpb)
         names, dens = parity.default_species(2)
         blk.set_aero_data(dens)
         blk.set_env(np.linspace(290, 240, 5), np.linspace(1e5, 4e4, 5))
@@ -923,6 +919,56 @@ def test_transport_parity(wp, oracle, nx, nz, ny, px, py):
     assert nm.sum() > n_cells * 10
     ok, msg = parity.compare_state(blk, cells)
     assert ok, msg
+    blk.close()
+
+
+@pytest.mark.parametrize("n_class,all_columns,do_vertmix", [(2, True, 1), (1, False, 1), (2, True, 0)])
+def test_transport_probs_built_on_the_device(wp, oracle, n_class, all_columns, do_vertmix):
+    """wrf_pmc_trans_driver's probability half (wrf_pmc_trans.F90:95-156) on the device from
+    WRF-shaped fields and the particle counts where they are: every probability bit for bit the
+    oracle's, and the transport that consumes them from device memory equals the oracle's
+    transport with the oracle's probabilities -- before and after a coagulation step (keys and
+    event logs in play), three steps."""
+    from tests import trans_fields as tf
+    nx, nz, ny = 4, 6, 3
+    n_cells, n_part = nx * nz * ny, 700
+    blk, cells, info = parity.setup_pair(wp, oracle, n_cells, n_part, 2, n_class, 17, K_BROWN, cap=4096,
+                                         n_source=2)
+    cv = np.random.RandomState(2).uniform(0.8, 1.25, n_cells)
+    next_id = np.array([oc.next_id for oc in cells], dtype=np.int64)
+    kw = dict(do_vertmix=do_vertmix, all_columns=all_columns, i_offset=0, j_offset=0, global_nx=nx,
+              global_ny=ny)
+    moved = 0
+    for step in range(3):
+        # fluxes scaled to the populations' mixing ratios so that a few percent move per step
+        F = tf.make_fields(nx, nz, ny, n_class, seed=step, k_scale=8.0,
+                           flux_scale=0.04 * n_part * info["mag"][0, 0])
+        counts = np.array([[int((oc.wclass[:int(oc.n_part[0])] == q).sum()) for q in range(n_class)]
+                           for oc in cells])
+        mag = np.array([oc.mag for oc in cells])
+        oph, opv, ons, obad = oracle.transport_probs(nx, nz, ny, n_class, 60.0, 3000.0, 3000.0, F, counts,
+                                                     mag, **kw)
+        ph, pv, ns, bad, ncp = blk.transport_probs(nx, nz, ny, 60.0, 3000.0, 3000.0, F, **kw)
+        assert np.array_equal(ncp, counts), step
+        assert np.array_equal(ns, ons) and np.array_equal(bad, obad) and not bad.any()
+        assert np.array_equal(ph, oph), (step, np.abs(ph - oph).max())
+        assert np.array_equal(pv, opv), (step, np.abs(pv - opv).max())
+        nm, na = blk.transport(nx, nz, ny, None, None, cv, 17, step, all_columns, all_columns)
+        st, onm, ona = oracle.transport(cells, nx, nz, ny, oph, opv, cv, 17, 0, step, next_id, all_columns,
+                                        all_columns)
+        assert st == 0 and np.array_equal(nm, onm) and np.array_equal(na, ona), step
+        ok, msg = parity.compare_state(blk, cells)
+        assert ok, f"step {step}: {msg}"
+        moved += int(nm.sum())
+        ns_, nc_, s2 = blk.mc_coag(K_BROWN, 600.0, 17, step)
+        for c, oc in enumerate(cells):
+            assert oc.mc_coag(K_BROWN, 600.0, 17, oc.cell_id, step) == (int(s2[c]), int(ns_[c]), int(nc_[c]))
+    assert moved > 20 * n_cells and ons.max() > 1
+    if not all_columns:
+        assert (ons[:, 0] == 0).all() and (ons[1:-1, 1:-1] > 0).all()
+    # used once: a second transport without a new build is refused
+    with pytest.raises(wp.PmcxError):
+        blk.transport(nx, nz, ny, None, None, cv, 17, 9, True, True)
     blk.close()
 
 

@@ -672,3 +672,40 @@ def test_seasalt_modes_against_the_published_formulas(oracle):
     # Ovadnevaite et al. 2014 table: total flux at Re = 3.1e6 is ~2e6 m^-2 s^-1
     assert 1.5e6 < fl.sum() < 2.5e6
     assert oracle.seasalt_modes(3, 8.0)[0].size == 0
+
+
+@pytest.mark.parametrize("all_columns,do_vertmix", [(True, 1), (False, 1), (True, 0)])
+def test_transport_probs_against_a_numpy_transcription(oracle, all_columns, do_vertmix):
+    """pmco_transport_probs (wrf_pmc_trans.F90:95-156, 205-286, 358-409, 414-562, 629-651,
+    692-773) against tests/trans_fields.numpy_probs, written array-wise with numpy's matmul."""
+    from tests import trans_fields as tf
+    nx, nz, ny, C = 5, 12, 4, 2
+    F = tf.make_fields(nx, nz, ny, C, seed=4)
+    r = np.random.RandomState(1)
+    n_parts = r.randint(0, 4000, (nx * nz * ny, C))
+    n_parts[7] = 0                                           # an empty cell: no advective flux out
+    mag = r.uniform(2e-3, 8e-3, (nx * nz * ny, C))           # some cells saturate (sum > 1)
+    kw = dict(do_vertmix=do_vertmix, all_columns=all_columns, i_offset=0, j_offset=1, global_nx=nx,
+              global_ny=ny + 2)
+    ph, pv, ns, bad = oracle.transport_probs(nx, nz, ny, C, 60.0, 4000.0, 4000.0, F, n_parts, mag, **kw)
+    rh, rv, rn = tf.numpy_probs(nx, nz, ny, C, 60.0, 4000.0, 4000.0, F, n_parts, mag, **kw)
+    assert np.array_equal(ns, rn) and ns.max() > 3
+    np.testing.assert_allclose(ph, rh, rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose(pv, rv, rtol=1e-11, atol=1e-18)
+    assert not bad.any()
+    tot = ph.sum(axis=2)
+    k_own = (np.arange(nx * nz * ny) // nx) % nz
+    off = pv.sum(axis=2) - pv[np.arange(nx * nz * ny), :, k_own]
+    assert (tot + off < 1.0 + 1e-8).all() and (tot + off).max() > 0.999   # normalised cells exist
+    if not all_columns:
+        ncol = pv.reshape(ny, nz, nx, C, nz)
+        assert not ncol[:, :, 0].any() and not ncol[:, :, nx - 1].any() and ncol[:, :, 1].any()
+        assert (ns[:, 0] == 0).all() and (ns[:, 1:nx - 1] > 0).all()
+    elif do_vertmix:
+        rows = pv.reshape(ny, nz, nx, C, nz)[1, :, 2, 0, :]  # a column's matrix: rows sum to <= 1
+        assert (rows.sum(axis=1) <= 1.0 + 1e-12).all() and (rows > 0).sum() > 3 * nz
+    # a negative flux input trips the reference's assertion, reported per cell
+    F2 = dict(F); F2["xkhh"] = F["xkhh"].copy(); F2["alt"] = F["alt"].copy()
+    F2["alt"][2, 3, 2] = -F2["alt"][2, 3, 2]
+    _, _, _, bad2 = oracle.transport_probs(nx, nz, ny, C, 60.0, 4000.0, 4000.0, F2, n_parts, mag, **kw)
+    assert bad2.any()

@@ -61,6 +61,10 @@ struct pmcx_ctx {
     double *d_halo_cv = nullptr;    // [n_cells] cell volumes of the open transport (own buffer: the
                                     // staging area may be reallocated between _begin and _finish)
     int32_t *d_halo_bad = nullptr;  // [1] records of an imported buffer that failed validation
+    // probabilities built on the device (pmcx_transport_probs), consumed by the next transport
+    double *d_prob_h = nullptr, *d_prob_v = nullptr;
+    int32_t *d_prob_i = nullptr;    // [n_cells] bad | [n_cells n_class] particles per class | [n_cells] sub-steps
+    int probs_nx = 0, probs_nz = 0, probs_ny = 0; // geometry they were built for (probs_nx != 0: ready)
     int64_t *d_acc = nullptr;   // running sums over calls: n_samp, n_coag, n_part, status
     double *d_diag = nullptr; // [n_cells*(2+2*n_dbin)]
     bool aero_data_set = false, env_set = false, n_ideal_set = false;
@@ -742,6 +746,20 @@ int pmcx_invalidate_sort(pmcx_ctx *ctx)
     return PMCX_OK;
 }
 
+int pmcx_set_sampler_variant(pmcx_ctx *ctx, int32_t lanes, int32_t wavefronts_per_group, int32_t stamps)
+{
+    if (!ctx) return PMCX_EINVAL;
+    if (!(lanes == 0 || lanes == 1 || lanes == 2 || lanes == 8 || lanes == 16 || lanes == 64) ||
+        !(wavefronts_per_group == 0 || wavefronts_per_group == 1 || wavefronts_per_group == 2 ||
+          wavefronts_per_group == 4) || (stamps != 0 && stamps != 1))
+        return fail(ctx, PMCX_EINVAL, "pmcx_set_sampler_variant: lanes in {0,1,2,8,16,64}, "
+                                      "wavefronts_per_group in {0,1,2,4}, stamps in {0,1}");
+    ctx->st.force_lanes = lanes;
+    ctx->st.force_wpb = wavefronts_per_group;
+    ctx->st.force_stamps = stamps;
+    return PMCX_OK;
+}
+
 int pmcx_invalidate_lists(pmcx_ctx *ctx)
 {
     if (!ctx) return PMCX_EINVAL;
@@ -1063,8 +1081,12 @@ int pmcx_transport(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int32_t pe
                    const double *cell_volume, uint64_t seed, uint32_t step, int32_t *n_moved,
                    int32_t *n_arrived)
 {
-    if (!ctx || !prob_h || !prob_v || !cell_volume)
+    if (!ctx || !cell_volume || (!prob_h) != (!prob_v))
         return fail(ctx, PMCX_EINVAL, "pmcx_transport: null argument");
+    const bool built = !prob_h; // the probabilities pmcx_transport_probs left on the device
+    if (built && (ctx->probs_nx != nx || ctx->probs_nz != nz || ctx->probs_ny != ny))
+        return fail(ctx, PMCX_ESTATE, "pmcx_transport: no probabilities were built for this grid "
+                                      "(pmcx_transport_probs comes first, once per transport)");
     const pmcx_config &cf = ctx->cfg;
     if (nx < 1 || nz < 1 || ny < 1 || nz > 128 || (int64_t)nx * nz * ny != cf.n_cells)
         return fail(ctx, PMCX_EINVAL, "pmcx_transport: nx*nz*ny must equal n_cells (nz <= 128)");
@@ -1085,8 +1107,13 @@ int pmcx_transport(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int32_t pe
     int rc = ensure_stage(ctx, bh + bv + bc + 64);
     if (rc) return rc;
     double *d_ph = (double *)ctx->stage, *d_pv = d_ph + nc * C * 4, *d_cv = d_pv + nc * C * (size_t)nz;
-    HIP_TRY(ctx, hipMemcpyAsync(d_ph, prob_h, bh, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(d_pv, prob_v, bv, hipMemcpyHostToDevice, ctx->stream));
+    if (built) {
+        d_ph = ctx->d_prob_h; d_pv = ctx->d_prob_v;
+        ctx->probs_nx = 0; // (they describe the populations as they were: used once)
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(d_ph, prob_h, bh, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_pv, prob_v, bv, hipMemcpyHostToDevice, ctx->stream));
+    }
     HIP_TRY(ctx, hipMemcpyAsync(d_cv, cell_volume, bc, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->st.status, 0, sizeof(int32_t) * nc, ctx->stream));
     {
@@ -1099,6 +1126,70 @@ int pmcx_transport(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int32_t pe
     if (n_arrived) HIP_TRY(ctx, hipMemcpyAsync(n_arrived, ctx->d_n_arr, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, invalidate_sort(ctx, 0, ctx->cfg.n_cells, false)); // (the kernels keep the sort keys current)
+    return PMCX_OK;
+}
+
+int pmcx_transport_probs(pmcx_ctx *ctx, const pmcx_trans_fields *f, double *prob_h, double *prob_v,
+                         int32_t *n_substeps, int32_t *bad, int32_t *n_class_part)
+{
+    if (!ctx || !f || !f->alt || !f->xkhh || !f->u_flux || !f->v_flux || !f->w_flux || !f->z ||
+        !f->z_at_w || !f->exch_h)
+        return fail(ctx, PMCX_EINVAL, "pmcx_transport_probs: null argument");
+    const pmcx_config &cf = ctx->cfg;
+    const int nx = f->nx, nz = f->nz, ny = f->ny;
+    if (nx < 1 || nz < 2 || ny < 1 || nz > 128 || (int64_t)nx * nz * ny != cf.n_cells)
+        return fail(ctx, PMCX_EINVAL, "pmcx_transport_probs: nx*nz*ny must equal n_cells, 2 <= nz <= 128");
+    if (!(f->dt > 0) || !(f->dx > 0) || !(f->dy > 0))
+        return fail(ctx, PMCX_EINVAL, "pmcx_transport_probs: dt, dx, dy must be positive");
+    if (trans_probs_lds_bytes(ctx->st, nz) > 160 * 1024)
+        return fail(ctx, PMCX_EINVAL, "pmcx_transport_probs: the column matrices (2 nz^2 doubles) exceed LDS");
+    HIP_TRY(ctx, hipSetDevice(cf.device));
+    const size_t nc = (size_t)cf.n_cells, C = (size_t)cf.n_class, col = (size_t)nx * ny;
+    if (!ctx->d_prob_h || ctx->probs_nz != nz) {
+        if (ctx->d_prob_h) return fail(ctx, PMCX_ESTATE, "pmcx_transport_probs: nz differs from the first call's");
+        int rc = dev_alloc(ctx, &ctx->d_prob_h, nc * C * 4);
+        if (!rc) rc = dev_alloc(ctx, &ctx->d_prob_v, nc * C * (size_t)nz);
+        if (!rc) rc = dev_alloc(ctx, &ctx->d_prob_i, nc + nc * C + nc);
+        if (rc) return rc;
+        ctx->probs_nz = nz;
+    }
+    ctx->probs_nx = 0;
+    // the fields, single precision as in WRF's grid%
+    const size_t n_halo = (size_t)(ny + 2) * nz * (nx + 2), n_u = C * ny * nz * (size_t)(nx + 1),
+                 n_v = C * (size_t)(ny + 1) * nz * nx, n_w = C * ny * (size_t)(nz + 1) * nx,
+                 n_z = (size_t)ny * nz * nx, n_zw = (size_t)ny * (nz + 1) * nx;
+    const size_t counts[8] = {n_halo, n_halo, n_u, n_v, n_w, n_z, n_zw, n_zw};
+    const float *src[8] = {f->alt, f->xkhh, f->u_flux, f->v_flux, f->w_flux, f->z, f->z_at_w, f->exch_h};
+    size_t total = 0;
+    for (size_t n : counts) total += (n + 3) & ~(size_t)3;
+    int rc = ensure_stage(ctx, sizeof(float) * total + 64);
+    if (rc) return rc;
+    const float *dev[8];
+    float *at = (float *)ctx->stage;
+    for (int k = 0; k < 8; k++) {
+        HIP_TRY(ctx, hipMemcpyAsync(at, src[k], sizeof(float) * counts[k], hipMemcpyHostToDevice, ctx->stream));
+        dev[k] = at;
+        at += (counts[k] + 3) & ~(size_t)3;
+    }
+    TransFieldsArgs a{};
+    a.nx = nx; a.nz = nz; a.ny = ny; a.do_vertmix = f->do_vertmix; a.all_columns = f->all_columns;
+    a.i_offset = f->i_offset; a.j_offset = f->j_offset; a.global_nx = f->global_nx; a.global_ny = f->global_ny;
+    a.dt = f->dt; a.dx = f->dx; a.dy = f->dy;
+    a.alt = dev[0]; a.xkhh = dev[1]; a.u_flux = dev[2]; a.v_flux = dev[3]; a.w_flux = dev[4];
+    a.z = dev[5]; a.z_at_w = dev[6]; a.exch_h = dev[7];
+    a.prob_h = ctx->d_prob_h; a.prob_v = ctx->d_prob_v;
+    a.bad = ctx->d_prob_i; a.n_class_part = ctx->d_prob_i + nc; a.n_substeps = ctx->d_prob_i + nc + nc * C;
+    {
+        ProfScope ps(ctx, "transport_probs");
+        HIP_TRY(ctx, launch_transport_probs(ctx->st, a, ctx->stream));
+    }
+    if (prob_h) HIP_TRY(ctx, hipMemcpyAsync(prob_h, ctx->d_prob_h, sizeof(double) * nc * C * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (prob_v) HIP_TRY(ctx, hipMemcpyAsync(prob_v, ctx->d_prob_v, sizeof(double) * nc * C * (size_t)nz, hipMemcpyDeviceToHost, ctx->stream));
+    if (bad) HIP_TRY(ctx, hipMemcpyAsync(bad, a.bad, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));
+    if (n_class_part) HIP_TRY(ctx, hipMemcpyAsync(n_class_part, a.n_class_part, sizeof(int32_t) * nc * C, hipMemcpyDeviceToHost, ctx->stream));
+    if (n_substeps) HIP_TRY(ctx, hipMemcpyAsync(n_substeps, a.n_substeps, sizeof(int32_t) * col, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->probs_nx = nx; ctx->probs_ny = ny;
     return PMCX_OK;
 }
 
@@ -1151,8 +1242,12 @@ int pmcx_transport_begin(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int3
                          const double *prob_h, const double *prob_v, const double *cell_volume,
                          uint64_t seed, uint32_t step)
 {
-    if (!ctx || !prob_h || !prob_v || !cell_volume)
+    if (!ctx || !cell_volume || (!prob_h) != (!prob_v))
         return fail(ctx, PMCX_EINVAL, "pmcx_transport_begin: null argument");
+    const bool built = !prob_h;
+    if (built && (ctx->probs_nx != nx || ctx->probs_nz != nz || ctx->probs_ny != ny))
+        return fail(ctx, PMCX_ESTATE, "pmcx_transport_begin: no probabilities were built for this grid "
+                                      "(pmcx_transport_probs comes first, once per transport)");
     const pmcx_config &cf = ctx->cfg;
     if (nx < 1 || nz < 1 || ny < 3 || nz > 128 || (int64_t)nx * nz * ny != cf.n_cells)
         return fail(ctx, PMCX_EINVAL, "pmcx_transport_begin: nx*nz*ny must equal n_cells, ny >= 3 "
@@ -1181,8 +1276,13 @@ int pmcx_transport_begin(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int3
     rc = ensure_stage(ctx, bh + bv + bc + 64);
     if (rc) return rc;
     double *d_ph = (double *)ctx->stage, *d_pv = d_ph + nc * C * 4, *d_cv = ctx->d_halo_cv;
-    HIP_TRY(ctx, hipMemcpyAsync(d_ph, prob_h, bh, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(d_pv, prob_v, bv, hipMemcpyHostToDevice, ctx->stream));
+    if (built) {
+        d_ph = ctx->d_prob_h; d_pv = ctx->d_prob_v;
+        ctx->probs_nx = 0;
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(d_ph, prob_h, bh, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_pv, prob_v, bv, hipMemcpyHostToDevice, ctx->stream));
+    }
     HIP_TRY(ctx, hipMemcpyAsync(d_cv, cell_volume, bc, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->st.status, 0, sizeof(int32_t) * nc, ctx->stream));
     ctx->halo_nx = nx; ctx->halo_nz = nz; ctx->halo_ny = ny; ctx->halo_px = periodic_x;

@@ -85,6 +85,8 @@ struct DeviceState {
     int32_t *key_valid;  // [n_cells]
     uint32_t *evlog;     // [n_cells][EVLOG_CAP]
     int32_t *n_log;      // [n_cells]
+    // pmcx_set_sampler_variant (diagnostic): 0 = the library's own choice
+    int32_t force_lanes, force_wpb, force_stamps;
     uint16_t *seq_ovf;   // [n_cells][2 G + 2 max_appends] lane-per-cell sampler: entries past a group's room
     int32_t *n_events, *n_samp, *n_coag, *status; // [n_cells]
 };
@@ -134,7 +136,7 @@ hipError_t launch_kernel_bounds(const DeviceState &st, int ktype, int margin, in
 hipError_t launch_bin_sort(const DeviceState &st, hipStream_t s);
 hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, uint64_t seed,
                               uint32_t step, hipStream_t s);
-hipError_t seq_stamps_read(uint64_t out[12], bool reset); // diagnostic (PMCX_SEQ_STAMPS=1)
+hipError_t seq_stamps_read(uint64_t out[12], bool reset); // diagnostic (pmcx_set_sampler_variant, stamps = 1)
 hipError_t launch_rebalance(const DeviceState &st, int allow_doubling, int allow_halving,
                             uint64_t seed, uint32_t step, hipStream_t s);
 hipError_t launch_diagnostics(const DeviceState &st, double *tot_num, double *tot_mass,
@@ -168,6 +170,16 @@ hipError_t launch_transport_finish(const DeviceState &st, int nx, int nz, int ny
                                    int periodic_y, const double *cell_volume, void *outbox,
                                    int32_t *n_out, int32_t *n_arr, int32_t *n_exp,
                                    uint64_t *dest_mask, int row_first, int n_rows, hipStream_t s);
+// transport probabilities (k_trans_probs); every pointer is device memory
+struct TransFieldsArgs {
+    int32_t nx, nz, ny, do_vertmix, all_columns, i_offset, j_offset, global_nx, global_ny;
+    double dt, dx, dy;
+    const float *alt, *xkhh, *u_flux, *v_flux, *w_flux, *z, *z_at_w, *exch_h;
+    double *prob_h, *prob_v;
+    int32_t *n_substeps, *bad, *n_class_part;
+};
+size_t trans_probs_lds_bytes(const DeviceState &st, int nz);
+hipError_t launch_transport_probs(const DeviceState &st, const TransFieldsArgs &a, hipStream_t s);
 size_t halo_record_bytes(const DeviceState &st);
 hipError_t launch_halo_count(const DeviceState &st, int nx, int nz, int ny, void *outbox,
                              int32_t *n_out, int src_row, int dst_row, int32_t *counts,

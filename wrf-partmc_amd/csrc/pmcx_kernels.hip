@@ -1265,7 +1265,7 @@ __host__ __device__ inline size_t seq_lds_bytes(int B, int C)
     return (o + 15) & ~(size_t)15;
 }
 
-// diagnostic build only (STAMPS = true, PMCX_SEQ_STAMPS=1): s_memtime ticks per phase, summed
+// diagnostic build only (STAMPS = true, pmcx_set_sampler_variant): s_memtime ticks per phase, summed
 // over wavefronts: [0] setup, [1]..[7] the seven stages of a pass (pair picked and list entries
 // requested | first slot found, Philox | particle records requested | first count, second slot |
 // kernel and accept | second count | coagulation), [8] write-back, [9] draws, [10] passes,
@@ -1281,7 +1281,7 @@ __device__ unsigned long long g_seq_stamps[12];
 // ---------------------------------------- coag sampler, lane per cell, block-wise draws
 //
 // k_coag_lane.  What bounds this kernel, once its memory requests were cut (one 32-byte record
-// per particle), is the instructions a wavefront issues per pass: stamped (PMCX_SEQ_STAMPS),
+// per particle), is the instructions a wavefront issues per pass: stamped (the STAMPS instantiation),
 // more than half of a pass went into finding slots and drawing their counts -- a Philox block
 // and an exponential per slot, and a scan through LDS bit masks in nested divergent loops.
 // Hence: a lane caches the Philox block and the four bounds of the partner bins gB & ~3 it is
@@ -2892,6 +2892,276 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
     if (lane == 0) { tg.n_out[c] = (int32_t)n_out; tg.dest_mask[c] = bits; }
 }
 
+// The transport probabilities of one step, built where the particles are (SURVEY 8 f2,
+// wrf_pmc_trans_driver's first half, interface/wrf_pmc_trans.F90:95-156): one workgroup per
+// column (i, j).
+//   phase 0  particles per class of every level (aero_state_total_particles): the live count
+//            with one class, else the 2-byte sort keys while they hold, else the records
+//   phase 1  compute_advect_probs_wrf (:205-286) and compute_diffusion_probs (:358-409), one
+//            thread per (level, class) / (level, direction)
+//   phase 2  stable_timestep (:629-651), the tridiagonal B of compute_vertical_probs (:414-492)
+//            and B* = B^N with the reference's row normalisation after every product (:494-504):
+//            B* dense in LDS, one thread per element, three terms (B is tridiagonal) added in
+//            ascending inner index, row sums by one thread per row in element order
+//   phase 3  per class R = B* A (:507-530), then normalize_probs (:692-773) per level
+// Arithmetic is the reference's, operation for operation (single-precision where grid% is).
+struct TransFieldsDev {
+    int32_t nx, nz, ny, do_vertmix, all_columns, i_offset, j_offset, global_nx, global_ny;
+    double dt, dx, dy;
+    const float *alt, *xkhh, *u_flux, *v_flux, *w_flux, *z, *z_at_w, *exch_h;
+    double *prob_h, *prob_v;
+    int32_t *n_substeps, *bad, *n_class_part;
+};
+
+__global__ __launch_bounds__(256) void k_trans_probs(DeviceState st, TransFieldsDev f)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int nx = f.nx, nz = f.nz, ny = f.ny, C = st.n_class;
+    const int i = blockIdx.x % nx, j = blockIdx.x / nx;
+    double *Bt = (double *)smem;              // [nz][nz]
+    double *R = Bt + nz * nz;                 // [nz][nz]
+    double *up = R + nz * nz;                 // [nz] B(k,k+1)
+    double *dn = up + nz;                     // [nz] B(k,k-1)
+    double *dg = dn + nz;                     // [nz] B(k,k)
+    double *rsum = dg + nz;                   // [nz]
+    double *zm = rsum + nz, *rm = zm + nz, *rw = rm + nz, *kw = rw + nz; // [nz] each
+    double *zw = kw + nz;                     // [nz+1]
+    double *adv = zw + nz + 1;                // [nz][C][6]: x+, x-, y+, y-, z+, z-
+    double *dif = adv + nz * C * 6;           // [nz][4]: x+, x-, y+, y-
+    double *au = dif + nz * 4, *ad = au + nz, *ag = ad + nz; // [nz] A's three diagonals
+    int *cnt = (int *)(ag + nz);              // [nz][C]
+    __shared__ int s_nsteps, s_clamped;
+    __shared__ double s_sdt;
+    if (t == 0) s_clamped = 0;
+    auto cell_of = [&](int k) { return ((int64_t)j * nz + k) * nx + i; };
+    auto halo = [&](const float *a, int ii, int k, int jj) {
+        return a[((int64_t)(jj + 1) * nz + k) * (int64_t)(nx + 2) + (ii + 1)];
+    };
+    auto col = [&](const float *a, int k, int nzz) { return a[((int64_t)j * nzz + k) * (int64_t)nx + i]; };
+
+    // phase 0
+    for (int x = t; x < nz * C; x += 256) cnt[x] = 0;
+    __syncthreads();
+    for (int k = wave; k < nz; k += 4) {
+        const int c = (int)cell_of(k);
+        if (C == 1) { if (lane == 0) cnt[k] = st.n_part[c]; continue; }
+        apply_event_log(st, c, lane);
+        const int64_t cb = (int64_t)c * st.cap;
+        const int n_hi = st.n_hi[c];
+        const bool keyed = st.key_valid[c] != 0;
+        for (int s0 = 0; s0 < n_hi; s0 += 64) {
+            const int sl = s0 + lane;
+            int cl = -1;
+            if (sl < n_hi) {
+                if (keyed) {
+                    const uint32_t kq = st.gkey[cb + sl];
+                    cl = kq == 0xFFFFu ? -1 : (int)(kq / (uint32_t)st.n_bin);
+                } else {
+                    cl = live_class(st, cb, sl);
+                }
+            }
+            for (int q = 0; q < C; q++) {
+                const int n = __popcll(__ballot(cl == q));
+                if (lane == 0) cnt[k * C + q] += n;
+            }
+        }
+    }
+    __syncthreads();
+
+    // phase 1
+    for (int x = t; x < nz * C; x += 256) {
+        const int k = x / C, cl = x % C;
+        const int64_t c = cell_of(k);
+        if (f.n_class_part) f.n_class_part[c * C + cl] = cnt[x];
+        const double rho_mass = 1.0 / (double)halo(f.alt, i, k, j);
+        const double mix_rat = (double)cnt[x] * st.mag[c * C + cl] / rho_mass;
+        const float ue = f.u_flux[(((int64_t)cl * ny + j) * nz + k) * (int64_t)(nx + 1) + i + 1];
+        const float uw = f.u_flux[(((int64_t)cl * ny + j) * nz + k) * (int64_t)(nx + 1) + i];
+        const float vn = f.v_flux[(((int64_t)cl * (ny + 1) + j + 1) * nz + k) * (int64_t)nx + i];
+        const float vs = f.v_flux[(((int64_t)cl * (ny + 1) + j) * nz + k) * (int64_t)nx + i];
+        const float wu = f.w_flux[(((int64_t)cl * ny + j) * (nz + 1) + k + 1) * (int64_t)nx + i];
+        const float wd = f.w_flux[(((int64_t)cl * ny + j) * (nz + 1) + k) * (int64_t)nx + i];
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0;
+        if (mix_rat > 0.0) {
+            if (ue > 0.0f) a0 = (double)ue / mix_rat;
+            if (uw < 0.0f) a1 = -1.0 * (double)uw / mix_rat;
+            if (vn > 0.0f) a2 = (double)vn / mix_rat;
+            if (vs < 0.0f) a3 = -1.0 * (double)vs / mix_rat;
+            if (wu > 0.0f) { const double q = (double)wu / mix_rat; a4 = q < .95 ? q : .95; }
+            if (wd < 0.0f) { const double q = -1.0 * (double)wd / mix_rat; a5 = q < .95 ? q : .95; }
+        }
+        const double ps = ((((a3 + a5) + a1) + a0) + a4) + a2; // array element order (:279)
+        if (ps > 1.0) {
+            const double q = ps + 1.0e-8;
+            a0 = a0 / q; a1 = a1 / q; a2 = a2 / q; a3 = a3 / q; a4 = a4 / q; a5 = a5 / q;
+        }
+        double *a = adv + x * 6;
+        a[0] = a0; a[1] = a1; a[2] = a2; a[3] = a3; a[4] = a4; a[5] = a5;
+    }
+    for (int x = t; x < nz * 4; x += 256) {
+        const int k = x >> 2, d = x & 3;
+        const int di = d == 0 ? 1 : d == 1 ? -1 : 0, dj = d == 2 ? 1 : d == 3 ? -1 : 0;
+        const double rho_mass = 1.0 / (double)halo(f.alt, i, k, j);
+        const float ksum = halo(f.xkhh, i, k, j) + halo(f.xkhh, i + di, k, j + dj);
+        double diff_coef = .5 * (double)ksum;
+        if (!(diff_coef > 0.0)) diff_coef = 0.0;
+        const double rho_edge = .5 * (rho_mass + (1.0 / (double)halo(f.alt, i + di, k, j + dj)));
+        const double h = d < 2 ? f.dx : f.dy;
+        dif[x] = (f.dt * diff_coef * rho_edge) / (h * h * rho_mass);
+    }
+
+    // phase 2
+    bool vertical = true;
+    if (!f.all_columns) {
+        const int gi = i + f.i_offset + 1, gj = j + f.j_offset + 1;
+        vertical = !(gi < 2 || gi > f.global_nx - 1 || gj < 2 || gj > f.global_ny - 1);
+    }
+    if (vertical) {
+        if (wave == 0) {   // stable_timestep: the column's largest exchange coefficient
+            float km = -3.0e38f;
+            for (int k = lane; k <= nz; k += 64) km = fmaxf(km, col(f.exch_h, k, nz + 1));
+            for (int d = 32; d >= 1; d >>= 1) km = fmaxf(km, __shfl_xor(km, d, 64));
+            if (lane == 0) {
+                const double min_dz = (double)(col(f.z, 1, nz) - col(f.z, 0, nz));
+                const double max_k = (double)km > 1.0e-6 ? (double)km : 1.0e-6;
+                const double max_time = .1 * (min_dz * min_dz) / max_k;
+                double ns = ceil(f.dt / max_time);
+                if (!(ns >= 1.0)) ns = 1.0;
+                if (ns > 1.0e6) { ns = 1.0e6; s_clamped = 1; } // (flagged: bit 16 of bad)
+                s_nsteps = (int)ns;
+                s_sdt = f.dt / (double)(int)ns;
+            }
+        }
+        for (int k = t; k <= nz; k += 256) {
+            zw[k] = (double)col(f.z_at_w, k, nz + 1);
+            if (k < nz) {
+                zm[k] = (double)col(f.z, k, nz);
+                rm[k] = 1.0 / (double)halo(f.alt, i, k, j);
+                double e = k < nz - 1 ? (double)col(f.exch_h, k + 1, nz + 1) : 0.0;
+                kw[k] = k < nz - 1 ? (e > 1.0e-6 ? e : 1.0e-6) : 0.0;
+            }
+        }
+        __syncthreads();
+        for (int k = t; k < nz - 1; k += 256) {
+            const double tmp = zm[k + 1] - zm[k];
+            rw[k] = ((zm[k + 1] - zw[k + 1]) / tmp) * rm[k] + ((zw[k + 1] - zm[k]) / tmp) * rm[k + 1];
+        }
+        __syncthreads();
+        const int n_steps = s_nsteps;
+        const double sdt = s_sdt;
+        for (int k = t; k < nz; k += 256) {
+            double d_ = 0.0, u_ = 0.0;
+            if (k > 0)
+                d_ = (sdt / ((zw[k + 1] - zw[k]) * (zm[k] - zm[k - 1]))) * (rw[k - 1] / rm[k]) * kw[k - 1];
+            if (k < nz - 1)
+                u_ = (sdt / ((zw[k + 1] - zw[k]) * (zm[k + 1] - zm[k]))) * (rw[k] / rm[k]) * kw[k];
+            dn[k] = d_; up[k] = u_;
+            dg[k] = k == 0 ? 1.0 - u_ : k == nz - 1 ? 1.0 - d_ : 1.0 - d_ - u_;
+        }
+        __syncthreads();
+        for (int x = t; x < nz * nz; x += 256) {
+            const int r = x / nz, q = x % nz;
+            Bt[x] = q == r ? dg[r] : q == r + 1 ? up[r] : q == r - 1 ? dn[r] : 0.0;
+        }
+        __syncthreads();
+        for (int it = 2; it <= n_steps; it++) {
+            for (int x = t; x < nz * nz; x += 256) {
+                const int r = x / nz, q = x % nz;
+                double acc = 0.0;
+                if (q > 0) acc = acc + Bt[r * nz + q - 1] * up[q - 1];       // B(q-1, q)
+                acc = acc + Bt[x] * dg[q];                                    // B(q, q)
+                if (q < nz - 1) acc = acc + Bt[r * nz + q + 1] * dn[q + 1];   // B(q+1, q)
+                R[x] = acc;
+            }
+            __syncthreads();
+            if (t < nz) {
+                double rs = 0.0;
+                for (int q = 0; q < nz; q++) rs = rs + R[t * nz + q];
+                rsum[t] = rs;
+            }
+            __syncthreads();
+            for (int x = t; x < nz * nz; x += 256) Bt[x] = R[x] / rsum[x / nz];
+            __syncthreads();
+        }
+        if (t == 0 && f.n_substeps) f.n_substeps[(int64_t)j * nx + i] = n_steps;
+    } else {
+        if (t == 0 && f.n_substeps) f.n_substeps[(int64_t)j * nx + i] = 0;
+    }
+    __syncthreads();
+
+    // phase 3: per class, R = B* A (or A), then normalize_probs per level and the outputs
+    for (int cl = 0; cl < C; cl++) {
+        if (vertical) {
+            for (int k = t; k < nz; k += 256) {
+                const double zp = adv[(k * C + cl) * 6 + 4], zn = adv[(k * C + cl) * 6 + 5];
+                au[k] = k < nz - 1 ? zp : 0.0;
+                ad[k] = k > 0 ? zn : 0.0;
+                ag[k] = k == 0 ? 1.0 - zp : k == nz - 1 ? 1.0 - zn : 1.0 - (zp + zn);
+            }
+            __syncthreads();
+            for (int x = t; x < nz * nz; x += 256) {
+                const int r = x / nz, q = x % nz;
+                double acc = 0.0;
+                if (f.do_vertmix > 0) {
+                    if (q > 0) acc = acc + Bt[r * nz + q - 1] * au[q - 1];
+                    acc = acc + Bt[x] * ag[q];
+                    if (q < nz - 1) acc = acc + Bt[r * nz + q + 1] * ad[q + 1];
+                } else {
+                    acc = q == r ? ag[r] : q == r + 1 ? au[r] : q == r - 1 ? ad[r] : 0.0;
+                }
+                R[x] = acc;
+            }
+        } else {
+            for (int x = t; x < nz * nz; x += 256) R[x] = 0.0;
+        }
+        __syncthreads();
+        if (t < nz) {   // normalize_probs of level t (serial sums in the reference's order)
+            const int k = t;
+            const int64_t c = cell_of(k);
+            double a[6], dl[4];
+            for (int d = 0; d < 6; d++) a[d] = adv[(k * C + cl) * 6 + d];
+            for (int d = 0; d < 4; d++) dl[d] = dif[k * 4 + d];
+            double *pv = R + k * nz;
+            int flag = 0, neg = 0, big = 0;
+            for (int d = 0; d < 6; d++) neg |= !(a[d] >= 0.0);
+            for (int d = 0; d < 4; d++) neg |= !(dl[d] >= 0.0);
+            for (int q = 0; q < nz; q++) neg |= !(pv[q] >= 0.0);
+            if (neg) flag |= 1;
+            double ps = ((a[3] + a[1]) + a[0]) + a[2];
+            ps = ps + (((dl[3] + dl[1]) + dl[0]) + dl[2]);
+            for (int q = 0; q < nz; q++) if (q != k) ps = ps + pv[q];
+            if (ps >= 1.0) {
+                for (int q = 0; q < nz; q++) pv[q] = pv[q] / ps;
+                for (int d = 0; d < 4; d++) { dl[d] = dl[d] / ps; a[d] = a[d] / ps; }
+            }
+            neg = 0;
+            for (int d = 0; d < 6; d++) { neg |= !(a[d] >= 0.0); big |= !(a[d] <= 1.0); }
+            for (int d = 0; d < 4; d++) { neg |= !(dl[d] >= 0.0); big |= !(dl[d] <= 1.0); }
+            for (int q = 0; q < nz; q++) { neg |= !(pv[q] >= 0.0); big |= !(pv[q] <= 1.0); }
+            if (neg) flag |= 2;
+            if (big) flag |= 4;
+            ps = ((a[3] + a[1]) + a[0]) + a[2];
+            ps = ps + (((dl[3] + dl[1]) + dl[0]) + dl[2]);
+            for (int q = 0; q < nz; q++) if (q != k) ps = ps + pv[q];
+            if (!(ps < 1.0 + 1.0e-8)) flag |= 8;
+            double *ph = f.prob_h + (c * C + cl) * 4;   // i-1, i+1, j-1, j+1
+            ph[0] = a[1] + dl[1];
+            ph[1] = a[0] + dl[0];
+            ph[2] = a[3] + dl[3];
+            ph[3] = a[2] + dl[2];
+            if (s_clamped) flag |= 16;
+            if (f.bad) { if (cl == 0) f.bad[c] = flag; else f.bad[c] |= flag; }
+        }
+        __syncthreads();
+        for (int x = t; x < nz * nz; x += 256) {
+            const int r = x / nz, q = x % nz;
+            f.prob_v[((cell_of(r)) * C + cl) * nz + q] = R[x];
+        }
+        __syncthreads();
+    }
+}
+
 // Arrivals are appended behind n_hi.  A cell that would run out of slots while it has holes
 // closes them now (stable, as always) and renames the slots its own outbox names; this is the
 // only moment it can: the outboxes exist, nobody has read them yet.
@@ -3396,13 +3666,14 @@ size_t sampler_lds_bytes_per_cell(const DeviceState &st)
     return sampler_lds_for(st, 64); // upper bound over the lane variants
 }
 // lanes per cell of the sampler: 16 (four cells per wavefront) while a cell's
-// list state is small, 64 otherwise.  PMCX_SAMPLER_LANES overrides (tuning).
+// list state is small, 64 otherwise.  pmcx_set_sampler_variant overrides (tests hold every
+// variant to the oracle at small sizes).
 int sampler_lanes(const DeviceState &st)
 {
-    const char *e = getenv("PMCX_SAMPLER_LANES");
+    const int fl = st.force_lanes;
     const bool seq_fits = seq_lds_bytes(st.n_bin, st.n_class) + SEQ_SHARED_BYTES <= 64 * 1024;
-    if (e && (atoi(e) == 1 || atoi(e) == 2) && seq_fits) return atoi(e);
-    if (e && (atoi(e) == 8 || atoi(e) == 16 || atoi(e) == 64)) return atoi(e);
+    if ((fl == 1 || fl == 2) && seq_fits) return fl;
+    if (fl == 8 || fl == 16 || fl == 64) return fl;
     // one lane per cell once the cells alone fill the chip (256 CUs x 4 SIMDs x 64 lanes); while
     // its wavefronts would still find a SIMD each even twice as many, the two-wavefront form
     // (measured, scripts/gpu_split.sh: 1.29 against 1.83 ms at 39 000 cells, 1.57 against 2.12 at
@@ -3579,14 +3850,14 @@ hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, ui
         return hipGetLastError();
     }
     if (L == 1) {
-        const char *e_st = getenv("PMCX_SEQ_STAMPS");
+        const bool stamps = st.force_stamps == 1;
         const dim3 grid((st.n_cells + 63) / 64), block(64);
         const size_t lds = seq_lds_bytes(st.n_bin, st.n_class);
         const bool simple = st.n_spec == 1 && st.n_class == 1;
-        if (e_st && atoi(e_st) == 1 && simple && ktype == KERNEL_BROWN)
+        if (stamps && simple && ktype == KERNEL_BROWN)
             hipLaunchKernelGGL((k_coag_lane<true, true, KERNEL_BROWN>), grid, block, lds, s, st, ktype, del_t,
                                seed, step, st.seq_ovf);
-        else if (e_st && atoi(e_st) == 1)
+        else if (stamps)
             hipLaunchKernelGGL((k_coag_lane<true, false, 0>), grid, block, lds, s, st, ktype, del_t, seed,
                                step, st.seq_ovf);
         else if (simple && ktype == KERNEL_BROWN)
@@ -3602,9 +3873,8 @@ hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, ui
     }
     const size_t per = sampler_lds_for(st, L);
     const int gpw = 64 / L;
-    // PMCX_SAMPLER_WPB: wavefronts per workgroup (tuning; 2 measured best)
-    const char *e_wpb = getenv("PMCX_SAMPLER_WPB");
-    int wpb = e_wpb ? atoi(e_wpb) : 2;
+    // wavefronts per workgroup: 2 measured best
+    int wpb = st.force_wpb ? st.force_wpb : 2;
     if (wpb != 1 && wpb != 2 && wpb != 4) wpb = 2;
     while (wpb > 1 && shared + per * wpb * gpw > 64 * 1024) wpb >>= 1;
     if (shared + per * wpb * gpw > 160 * 1024) return hipErrorInvalidConfiguration;
@@ -3744,6 +4014,26 @@ hipError_t launch_transport(const DeviceState &st, int nx, int nz, int ny, int p
     if (e != hipSuccess) return e;
     return launch_transport_finish(st, nx, nz, ny, periodic_x, periodic_y, cell_volume, outbox, n_out,
                                    n_arr, n_exp, dest_mask, 0, ny, s);
+}
+size_t trans_probs_lds_bytes(const DeviceState &st, int nz)
+{
+    return sizeof(double) * ((size_t)2 * nz * nz + 8 * (size_t)nz + nz + 1 + (size_t)nz * st.n_class * 6 +
+                             (size_t)nz * 4 + 3 * (size_t)nz) + sizeof(int) * (size_t)nz * st.n_class + 16;
+}
+hipError_t launch_transport_probs(const DeviceState &st, const TransFieldsArgs &a, hipStream_t s)
+{
+    TransFieldsDev f{};
+    f.nx = a.nx; f.nz = a.nz; f.ny = a.ny; f.do_vertmix = a.do_vertmix; f.all_columns = a.all_columns;
+    f.i_offset = a.i_offset; f.j_offset = a.j_offset; f.global_nx = a.global_nx; f.global_ny = a.global_ny;
+    f.dt = a.dt; f.dx = a.dx; f.dy = a.dy;
+    f.alt = a.alt; f.xkhh = a.xkhh; f.u_flux = a.u_flux; f.v_flux = a.v_flux; f.w_flux = a.w_flux;
+    f.z = a.z; f.z_at_w = a.z_at_w; f.exch_h = a.exch_h;
+    f.prob_h = a.prob_h; f.prob_v = a.prob_v; f.n_substeps = a.n_substeps; f.bad = a.bad;
+    f.n_class_part = a.n_class_part;
+    const size_t lds = trans_probs_lds_bytes(st, a.nz);
+    allow_lds(k_trans_probs, lds);
+    hipLaunchKernelGGL(k_trans_probs, dim3(a.nx * a.ny), dim3(256), lds, s, st, f);
+    return hipGetLastError();
 }
 size_t halo_record_bytes(const DeviceState &st) { return halo_rec_bytes(st.n_spec, st.n_source); }
 // counts[row_cells] and offsets[row_cells + 1] of the movers of row src_row bound for dst_row

@@ -40,7 +40,23 @@ EXPORTED_SYMBOLS = [
     "pmcx_memory_bytes", "pmcx_device_memory_info", "pmcx_set_cell_id_base", "pmcx_set_gas_state",
     "pmcx_get_gas_state", "pmcx_set_gas_scenario", "pmcx_scenario_update_gas_state",
     "pmcx_invalidate_lists", "pmcx_get_keys", "pmcx_seasalt_emissions",
+    "pmcx_transport_probs", "pmcx_set_sampler_variant",
 ]
+
+
+# Diagnostic default for new CellBlocks: (lanes, wavefronts_per_group, stamps) handed to
+# pmcx_set_sampler_variant, None = the library's own choice (what production runs).
+SAMPLER_VARIANT = None
+
+
+class PmcxTransFields(C.Structure):
+    """pmcx_trans_fields (include/pmcx.h)."""
+    _fields_ = [("nx", C.c_int32), ("nz", C.c_int32), ("ny", C.c_int32), ("do_vertmix", C.c_int32),
+                ("all_columns", C.c_int32), ("i_offset", C.c_int32), ("j_offset", C.c_int32),
+                ("global_nx", C.c_int32), ("global_ny", C.c_int32), ("dt", C.c_double),
+                ("dx", C.c_double), ("dy", C.c_double)] + \
+               [(n, C.c_void_p) for n in ("alt", "xkhh", "u_flux", "v_flux", "w_flux", "z", "z_at_w",
+                                          "exch_h")]
 
 
 class PmcxError(RuntimeError):
@@ -145,6 +161,8 @@ def load_library():
     L.pmcx_device_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
     L.pmcx_dry_deposition.argtypes = [C.c_void_p, C.c_double, C.c_uint64, C.c_uint32] + [C.c_void_p] * 9
     L.pmcx_timestep.argtypes = [C.c_void_p, C.POINTER(PmcxStepFlags)]
+    L.pmcx_set_sampler_variant.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+    L.pmcx_transport_probs.argtypes = [C.c_void_p, C.POINTER(PmcxTransFields)] + [C.c_void_p] * 5
     L.pmcx_seasalt_emissions.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_uint64, C.c_uint32,
                                          C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 7
     L.pmcx_get_keys.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -223,6 +241,8 @@ class CellBlock:
         if rc != 0:
             raise PmcxError(f"pmcx_create failed ({rc}): "
                             f"{self._lib.pmcx_last_error(None).decode()}")
+        if SAMPLER_VARIANT is not None:     # (tests pin a variant for every block they create)
+            self.set_sampler_variant(*SAMPLER_VARIANT)
 
     # -- plumbing ---------------------------------------------------------
     def _ck(self, rc):
@@ -473,8 +493,8 @@ class CellBlock:
     def transport_begin(self, nx, nz, ny, prob_h, prob_v, cell_volume, seed=0, step=0,
                         periodic_x=True):
         n, Cn = self.cfg.n_cells, self.cfg.n_class
-        self._tr = (np.ascontiguousarray(np.broadcast_to(_f64(prob_h), (n, Cn, 4))),
-                    np.ascontiguousarray(np.broadcast_to(_f64(prob_v), (n, Cn, nz))),
+        self._tr = (None if prob_h is None else np.ascontiguousarray(np.broadcast_to(_f64(prob_h), (n, Cn, 4))),
+                    None if prob_v is None else np.ascontiguousarray(np.broadcast_to(_f64(prob_v), (n, Cn, nz))),
                     np.ascontiguousarray(np.broadcast_to(_f64(cell_volume), (n,))))
         self._ck(self._lib.pmcx_transport_begin(self._h, nx, nz, ny, int(periodic_x), _ptr(self._tr[0]),
                                                 _ptr(self._tr[1]), _ptr(self._tr[2]), seed, step))
@@ -577,13 +597,46 @@ class CellBlock:
                                                _ptr(nr), _ptr(bad)))
         return nr, bad
 
+    def transport_probs(self, nx, nz, ny, dt, dx, dy, fields, do_vertmix=1, all_columns=True,
+                        i_offset=0, j_offset=0, global_nx=None, global_ny=None, download=True):
+        """The transport probabilities of one step from WRF's fields (float32 arrays: alt, xkhh
+        [ny+2][nz][nx+2]; u_flux [n_class][ny][nz][nx+1]; v_flux [n_class][ny+1][nz][nx]; w_flux
+        [n_class][ny][nz+1][nx]; z [ny][nz][nx]; z_at_w, exch_h [ny][nz+1][nx]) and the block's
+        particle counts (wrf_pmc_trans.F90:95-156).  They stay on the device for the next
+        transport(…, prob_h=None, prob_v=None).  download: also return (prob_h, prob_v,
+        n_substeps, bad, n_class_part)."""
+        n, Cn = self.cfg.n_cells, self.cfg.n_class
+        shapes = dict(alt=(ny + 2, nz, nx + 2), xkhh=(ny + 2, nz, nx + 2), u_flux=(Cn, ny, nz, nx + 1),
+                      v_flux=(Cn, ny + 1, nz, nx), w_flux=(Cn, ny, nz + 1, nx), z=(ny, nz, nx),
+                      z_at_w=(ny, nz + 1, nx), exch_h=(ny, nz + 1, nx))
+        tf = PmcxTransFields(nx, nz, ny, int(do_vertmix), int(all_columns), i_offset, j_offset,
+                             nx if global_nx is None else global_nx,
+                             ny if global_ny is None else global_ny, dt, dx, dy)
+        keep = []
+        for name, shp in shapes.items():
+            a = np.ascontiguousarray(fields[name], dtype=np.float32)
+            if a.shape != shp:
+                raise ValueError(f"transport_probs: {name} has shape {a.shape}, expected {shp}")
+            keep.append(a)
+            setattr(tf, name, a.ctypes.data)
+        if not download:
+            self._ck(self._lib.pmcx_transport_probs(self._h, C.byref(tf), None, None, None, None, None))
+            return None
+        ph, pv = np.zeros((n, Cn, 4)), np.zeros((n, Cn, nz))
+        ns, bad = np.zeros((ny, nx), dtype=np.int32), np.zeros(n, dtype=np.int32)
+        ncp = np.zeros((n, Cn), dtype=np.int32)
+        self._ck(self._lib.pmcx_transport_probs(self._h, C.byref(tf), _ptr(ph), _ptr(pv), _ptr(ns),
+                                                _ptr(bad), _ptr(ncp)))
+        return ph, pv, ns, bad, ncp
+
     def transport(self, nx, nz, ny, prob_h, prob_v, cell_volume, seed=0, step=0, periodic_x=True,
                   periodic_y=True):
         """Stochastic transport between the block's cells (wrf_pmc_trans_aero.F90:2351-2482).
+        prob_h = prob_v = None: the probabilities transport_probs left on the device.
         Returns (n_moved, n_arrived) per cell."""
         n, Cn = self.cfg.n_cells, self.cfg.n_class
-        ph = np.ascontiguousarray(np.broadcast_to(_f64(prob_h), (n, Cn, 4)))
-        pv = np.ascontiguousarray(np.broadcast_to(_f64(prob_v), (n, Cn, nz)))
+        ph = None if prob_h is None else np.ascontiguousarray(np.broadcast_to(_f64(prob_h), (n, Cn, 4)))
+        pv = None if prob_v is None else np.ascontiguousarray(np.broadcast_to(_f64(prob_v), (n, Cn, nz)))
         cv = np.ascontiguousarray(np.broadcast_to(_f64(cell_volume), (n,)))
         nm, na = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
         self._ck(self._lib.pmcx_transport(self._h, nx, nz, ny, int(periodic_x), int(periodic_y),
@@ -720,6 +773,10 @@ class CellBlock:
         """aero_state%valid_sort = .false. for every cell: the next mc_coag sorts them again."""
         self._ck(self._lib.pmcx_invalidate_sort(self._h))
 
+    def set_sampler_variant(self, lanes=0, wavefronts_per_group=0, stamps=0):
+        """Diagnostic: pin the pair sampler's launch shape (include/pmcx.h); 0 = automatic."""
+        self._ck(self._lib.pmcx_set_sampler_variant(self._h, lanes, wavefronts_per_group, stamps))
+
     def invalidate_lists(self):
         """The lists of every cell are to be rebuilt, from sort keys that still hold."""
         self._ck(self._lib.pmcx_invalidate_lists(self._h))
@@ -762,7 +819,7 @@ class CellBlock:
         self._ck(self._lib.pmcx_profile_reset(self._h))
 
     def profile_phase_cycles(self, reset=True):
-        """Diagnostic (PMCX_SEQ_STAMPS=1): cycles per phase of the lane-per-cell sampler."""
+        """Diagnostic (set_sampler_variant(stamps=1)): cycles per phase of the lane-per-cell sampler."""
         out = (C.c_uint64 * 12)()
         self._ck(self._lib.pmcx_profile_phase_cycles(self._h, out, 1 if reset else 0))
         return list(out)
