@@ -423,9 +423,8 @@ def main():
     if args.sampler_stamps and rank == 0:   # diagnostic build of the sampler
         ph = blk.profile_phase_cycles()
         w = max(ph[11], 1)
-        names = ["setup", "1_pair_picked_entries_requested", "2_first_slot_found_philox",
-                 "3_records_requested", "4_first_count_second_slot", "5_kernel_accept",
-                 "6_second_count", "7_coagulation", "write_back"]
+        names = ["setup", "1_slots_settled_blocks_fetched", "2_exact_counts", "3_pair_picked_entries_requested",
+                 "4_records_requested", "5_kernel_accept", "6_unused", "7_coagulation", "write_back"]
         d = {n: ph[k] / w for k, n in enumerate(names)}
         d.update(draws=ph[9] / w, passes=ph[10] / w, wavefronts=ph[11])
         print("seq sampler, mean s_memtime ticks per wavefront: " + json.dumps(d), file=sys.stderr)

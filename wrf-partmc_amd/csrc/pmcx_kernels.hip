@@ -1297,6 +1297,9 @@ __device__ unsigned long long g_seq_stamps[12];
 #ifndef PMCX_NTRY
 #define PMCX_NTRY 4
 #endif
+#ifndef PMCX_NROUND
+#define PMCX_NROUND 2
+#endif
 #ifndef PMCX_LANE_WAVES
 #define PMCX_LANE_WAVES 3
 #endif
@@ -1495,7 +1498,8 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
     // ---- where the lane stands in the sweep, what it holds, the Philox block and the bounds of
     // ---- the four partner bins it is drawing from ----
     constexpr uint32_t TAG_NONE = 0xFFFFFFFFu;
-    constexpr int NTRY = PMCX_NTRY;  // slots a drawing lane may settle per pass
+    constexpr int NTRY = PMCX_NTRY;  // slots a drawing lane may settle per round
+    constexpr int NROUND = PMCX_NROUND; // rounds (settle, fetch the next block) per pass
     uint32_t blk_tag = TAG_NONE;     // (gA << 16) | (gB & ~3) of the cached block
     // its four words (the uniforms of slots gB & 3) and kmax[b1][b2] of the same four partner
     // bins, two to a 64-bit value: picked with shifts (a chain of selects over four scalars is
@@ -1577,7 +1581,125 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
         const bool any_far = !SIMPLE || __ballot(far) != 0;
         const bool any_wide = any_far || __ballot(wide) != 0;
 
-        // ---- (1) evaluating lanes: the sample's pair, list entries requested ----
+        // ---- (1) drawing lanes (no samples in hand): settle slots inside the cached block, fetch
+        // ---- the next block when the sweep leaves it, settle on -- NROUND rounds a pass ----
+        bool pending = false;            // a slot whose count needs the exact Poisson
+        double p_mean = 0, p_u = 0;
+        bool dr = role_d && own && !done && ns_rem == 0;
+        if (STAMPS && dr) t_acc[9]++;
+        // the slot's mean and uniform from the cached block; ZERO = true: its count is surely zero
+#define PMCX_SETTLE(hA, hB, dA, dB, ZERO)                                                           \
+    {                                                                                             \
+        const uint32_t sh_ = ((hB) & 1u) * 32u;                                                   \
+        const uint32_t wu_ = (uint32_t)((((hB) & 2u) ? wq23 : wq01) >> sh_);                      \
+        const float kf_ = __uint_as_float((uint32_t)((((hB) & 2u) ? kq23 : kq01) >> sh_));       \
+        const double nA_ = (double)((dA) & 0xFFFFu), nB_ = (double)((dB) & 0xFFFFu);              \
+        k_max = (double)kf_ * fmax;                                                               \
+        const double n_possible_ = ((hA) == (hB)) ? nA_ * (nA_ - 1.0) / 2.0 : nA_ * nB_;          \
+        const double mean_ = k_max * del_t * n_possible_;                                         \
+        const double u_ = (double)wu_ * 0x1.0p-32;                                                \
+        /* u < 1 - mean - 4e-15  =>  u < det_exp(-mean): no sample, exactly as poisson() says */  \
+        ZERO = u_ < (1.0 - mean_) - 4e-15;                                                        \
+        if (!ZERO) { pending = true; p_mean = mean_; p_u = u_; }                                  \
+    }
+        for (int r = 0; r < NROUND; r++) {
+            if (__ballot(dr) == 0) break;
+            uint32_t want = TAG_NONE;    // the block of the next slot, when it is not the cached one
+            if (SIMPLE && !any_far) {
+                // One class, every particle inside the window: straight-line code, NTRY times.  The
+                // next slot of the sweep is the next set bit of the window word behind b2, or the
+                // first bin of the next populated row with itself as partner; a bin that holds one
+                // particle gives n_possible = 0 as its own partner, i.e. a mean of zero.
+                bool active = dr;
+#pragma unroll
+                for (int t = 0; t < NTRY; t++) {
+                    if (active) {
+                        // (shifts by 32 are avoided: a position at bit 31 has nothing behind it)
+                        const int p1_ = b1 - blo, p2_ = b2 - blo;
+                        const bool rowok = b1 >= 0 && ((wmask >> p1_) & 1u);
+                        const uint32_t m = (rowok && p2_ < 31) ? (wmask & (~0u << (p2_ + 1))) : 0u;
+                        const uint32_t mr = b1 < 0 ? wmask : (p1_ < 31 ? (wmask & (~0u << (p1_ + 1))) : 0u);
+                        const int nb1 = m ? b1 : blo + __builtin_ctz(mr | 0x80000000u);
+                        const int nb2 = m ? blo + __builtin_ctz(m) : nb1;
+                        if (!m && !mr) { done = true; active = false; }
+                        else {
+                            const uint32_t tag = ((uint32_t)nb1 << 16) | ((uint32_t)nb2 & ~3u);
+                            if (tag != blk_tag) { want = tag; active = false; }
+                            else {
+                                b1 = nb1; b2 = nb2;
+                                uint32_t dA, dB;
+                                if (!any_wide) {
+                                    dA = ent[(nb1 - blo) * 64 + lane];
+                                    dB = ent[(nb2 - blo) * 64 + lane];
+                                } else {
+                                    dA = ent_get(0, nb1);
+                                    dB = ent_get(0, nb2);
+                                }
+                                bool zero;
+                                PMCX_SETTLE((uint32_t)nb1, (uint32_t)nb2, dA, dB, zero)
+                                if (!zero) active = false;
+                            }
+                        }
+                    }
+                }
+            } else if (dr) {
+                // the general scan (several classes, or a particle outside the window): one slot a round
+                int t1, t2, tb1, tb2;
+                uint32_t dA = 0, dB = 0;
+                if (!find_next(t1, t2, tb1, tb2, dA, dB)) {
+                    done = true;
+                } else {
+                    const uint32_t hA = (uint32_t)(t1 * B + tb1), hB = (uint32_t)(t2 * B + tb2);
+                    const uint32_t tag = (hA << 16) | (hB & ~3u);
+                    if (tag != blk_tag) {
+                        want = tag;
+                    } else {
+                        c1 = t1; c2 = t2; b1 = tb1; b2 = tb2;
+                        if (!SIMPLE && (c1 != rc1 || c2 != rc2)) {
+                            n1 = magl[c1 * 64 + lane]; n2 = magl[c2 * 64 + lane];
+                            cc = (n1 < n2) ? c1 : c2;
+                            nmin = (n1 < n2) ? n1 : n2;
+                            fmax = (n1 < n2) ? n2 : n1;
+                            factor = n1 * n2 / nmin;
+                            rc1 = c1; rc2 = c2;
+                        }
+                        bool zero;
+                        PMCX_SETTLE(hA, hB, dA, dB, zero)
+                        (void)zero;
+                    }
+                }
+            }
+            // the block the sweep moves into: one Philox block, four bounds
+            if (want != TAG_NONE) {
+                uint32_t w[4];
+                rng_block(seed, cell_id, step, want, SITE_POISSON, 0, w);
+                wq01 = (uint64_t)w[0] | ((uint64_t)w[1] << 32); wq23 = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+                const int hA = (int)(want >> 16), hBq = (int)(want & 0xFFFFu);
+                const int rb1 = SIMPLE ? hA : hA % B;
+                const float *row = st.kmax + (int64_t)c * st.kmax_stride + rb1 * B;
+                // (a group index beyond the last one belongs to no slot: its bound is never read)
+                const float kq0 = row[SIMPLE ? min(hBq, B - 1) : (hBq % B)];
+                const float kq1 = row[SIMPLE ? min(hBq + 1, B - 1) : ((hBq + 1) % B)];
+                const float kq2 = row[SIMPLE ? min(hBq + 2, B - 1) : ((hBq + 2) % B)];
+                const float kq3 = row[SIMPLE ? min(hBq + 3, B - 1) : ((hBq + 3) % B)];
+                kq01 = (uint64_t)__float_as_uint(kq0) | ((uint64_t)__float_as_uint(kq1) << 32);
+                kq23 = (uint64_t)__float_as_uint(kq2) | ((uint64_t)__float_as_uint(kq3) << 32);
+                blk_tag = want;
+            }
+            dr = dr && !done && !pending;
+        }
+        STAMP(1)
+
+        // ---- (2) the exact count of the slot that needs it ----
+        if (pending) {
+            ns_rem = (uint32_t)poisson(p_mean, p_u, rcp);
+            tot_samp += ns_rem;
+            s = 0;
+        }
+        STAMP(2)
+
+        // ---- (3) lanes holding samples (also the ones just drawn): the sample's pair, list
+        // ---- entries requested ----
         bool evalid = false, acc = false;
         int i1 = 0, i2 = 0;
         uint32_t p1 = 0, p2 = 0, s_ev = 0, eA = 0, eB = 0;
@@ -1595,7 +1717,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
             }
             const int nA = (int)(eA & 0xFFFFu), nB = (int)(eB & 0xFFFFu);
             if (nA < 1 || nB < 1 || (same && nA < 2)) {
-                ns_rem = 0; // a list ran out: the slot ends (the lane draws below)
+                ns_rem = 0; // a list ran out: the slot ends (the lane draws in the next pass)
             } else {
                 uint32_t w[4];
                 rng_block(seed, cell_id, step, ((uint32_t)gA << 16) | (uint32_t)gB, SITE_CAND, s, w);
@@ -1621,97 +1743,9 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                 evalid = true;
             }
         }
+        STAMP(3)
 
-        STAMP(1)
-
-        // ---- (2) drawing lanes: settle slots inside the cached block ----
-        const bool drawing = role_d && own && !done && !evalid && ns_rem == 0;
-        bool pending = false;            // a slot whose count needs the exact Poisson
-        double p_mean = 0, p_u = 0;
-        uint32_t want = TAG_NONE;        // the block of the next slot, when it is not the cached one
-        if (STAMPS && drawing) t_acc[9]++;
-        // the slot's mean and uniform from the cached block; ZERO = true: its count is surely zero
-#define PMCX_SETTLE(hA, hB, dA, dB, ZERO)                                                           \
-    {                                                                                             \
-        const uint32_t sh_ = ((hB) & 1u) * 32u;                                                   \
-        const uint32_t wu_ = (uint32_t)((((hB) & 2u) ? wq23 : wq01) >> sh_);                      \
-        const float kf_ = __uint_as_float((uint32_t)((((hB) & 2u) ? kq23 : kq01) >> sh_));       \
-        const double nA_ = (double)((dA) & 0xFFFFu), nB_ = (double)((dB) & 0xFFFFu);              \
-        k_max = (double)kf_ * fmax;                                                               \
-        const double n_possible_ = ((hA) == (hB)) ? nA_ * (nA_ - 1.0) / 2.0 : nA_ * nB_;          \
-        const double mean_ = k_max * del_t * n_possible_;                                         \
-        const double u_ = (double)wu_ * 0x1.0p-32;                                                \
-        /* u < 1 - mean - 4e-15  =>  u < det_exp(-mean): no sample, exactly as poisson() says */  \
-        ZERO = u_ < (1.0 - mean_) - 4e-15;                                                        \
-        if (!ZERO) { pending = true; p_mean = mean_; p_u = u_; }                                  \
-    }
-        if (SIMPLE && !any_far) {
-            // One class, every particle inside the window: straight-line code, NTRY times.  The
-            // next slot of the sweep is the next set bit of the window word behind b2, or the
-            // first bin of the next populated row with itself as partner; a bin that holds one
-            // particle gives n_possible = 0 as its own partner, i.e. a mean of zero.
-            bool active = drawing;
-#pragma unroll
-            for (int t = 0; t < NTRY; t++) {
-                if (active) {
-                    // (shifts by 32 are avoided: a position at bit 31 has nothing behind it)
-                    const int p1_ = b1 - blo, p2_ = b2 - blo;
-                    const bool rowok = b1 >= 0 && ((wmask >> p1_) & 1u);
-                    const uint32_t m = (rowok && p2_ < 31) ? (wmask & (~0u << (p2_ + 1))) : 0u;
-                    const uint32_t mr = b1 < 0 ? wmask : (p1_ < 31 ? (wmask & (~0u << (p1_ + 1))) : 0u);
-                    const int nb1 = m ? b1 : blo + __builtin_ctz(mr | 0x80000000u);
-                    const int nb2 = m ? blo + __builtin_ctz(m) : nb1;
-                    if (!m && !mr) { done = true; active = false; }
-                    else {
-                        const uint32_t tag = ((uint32_t)nb1 << 16) | ((uint32_t)nb2 & ~3u);
-                        if (tag != blk_tag) { want = tag; active = false; }
-                        else {
-                            b1 = nb1; b2 = nb2;
-                            uint32_t dA, dB;
-                            if (!any_wide) {
-                                dA = ent[(nb1 - blo) * 64 + lane];
-                                dB = ent[(nb2 - blo) * 64 + lane];
-                            } else {
-                                dA = ent_get(0, nb1);
-                                dB = ent_get(0, nb2);
-                            }
-                            bool zero;
-                            PMCX_SETTLE((uint32_t)nb1, (uint32_t)nb2, dA, dB, zero)
-                            if (!zero) active = false;
-                        }
-                    }
-                }
-            }
-        } else if (drawing) {
-            // the general scan (several classes, or a particle outside the window): one slot a pass
-            int t1, t2, tb1, tb2;
-            uint32_t dA = 0, dB = 0;
-            if (!find_next(t1, t2, tb1, tb2, dA, dB)) {
-                done = true;
-            } else {
-                const uint32_t hA = (uint32_t)(t1 * B + tb1), hB = (uint32_t)(t2 * B + tb2);
-                const uint32_t tag = (hA << 16) | (hB & ~3u);
-                if (tag != blk_tag) {
-                    want = tag;
-                } else {
-                    c1 = t1; c2 = t2; b1 = tb1; b2 = tb2;
-                    if (!SIMPLE && (c1 != rc1 || c2 != rc2)) {
-                        n1 = magl[c1 * 64 + lane]; n2 = magl[c2 * 64 + lane];
-                        cc = (n1 < n2) ? c1 : c2;
-                        nmin = (n1 < n2) ? n1 : n2;
-                        fmax = (n1 < n2) ? n2 : n1;
-                        factor = n1 * n2 / nmin;
-                        rc1 = c1; rc2 = c2;
-                    }
-                    bool zero;
-                    PMCX_SETTLE(hA, hB, dA, dB, zero)
-                    (void)zero;
-                }
-            }
-        }
-        STAMP(2)
-
-        // ---- (3) evaluating lanes: volumes, masses and what a coagulation will need ----
+        // ---- (4) volumes, masses and what a coagulation will need ----
         double v1 = 0, v2 = 0, m1 = 0, m2 = 0;
         double vol1 = 0, vol2 = 0, lct1 = 0, lct2 = 0, gct1 = 0, gct2 = 0; // first species, times
         int32_t no1 = 0, no2 = 0;               // first source
@@ -1726,30 +1760,6 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
             // of the same terms)
             if (S > 1) { vol1 = st.vol[(cb + p1) * S]; vol2 = st.vol[(cb + p2) * S]; }
             if (NS > 0) { no1 = cold[p1].n_orig0; no2 = cold[p2].n_orig0; }
-        }
-        STAMP(3)
-
-        // ---- (4) drawing lanes: the exact count of the slot that needs it; next block ----
-        if (pending) {
-            ns_rem = (uint32_t)poisson(p_mean, p_u, rcp);
-            tot_samp += ns_rem;
-            s = 0;
-        }
-        if (want != TAG_NONE) {
-            uint32_t w[4];
-            rng_block(seed, cell_id, step, want, SITE_POISSON, 0, w);
-            wq01 = (uint64_t)w[0] | ((uint64_t)w[1] << 32); wq23 = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
-            const int hA = (int)(want >> 16), hBq = (int)(want & 0xFFFFu);
-            const int rb1 = SIMPLE ? hA : hA % B;
-            const float *row = st.kmax + (int64_t)c * st.kmax_stride + rb1 * B;
-            // (a group index beyond the last one belongs to no slot: its bound is never read)
-            const float kq0 = row[SIMPLE ? min(hBq, B - 1) : (hBq % B)];
-            const float kq1 = row[SIMPLE ? min(hBq + 1, B - 1) : ((hBq + 1) % B)];
-            const float kq2 = row[SIMPLE ? min(hBq + 2, B - 1) : ((hBq + 2) % B)];
-            const float kq3 = row[SIMPLE ? min(hBq + 3, B - 1) : ((hBq + 3) % B)];
-            kq01 = (uint64_t)__float_as_uint(kq0) | ((uint64_t)__float_as_uint(kq1) << 32);
-            kq23 = (uint64_t)__float_as_uint(kq2) | ((uint64_t)__float_as_uint(kq3) << 32);
-            blk_tag = want;
         }
         STAMP(4)
 
