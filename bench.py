@@ -302,6 +302,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sampler-lanes", type=int, default=0,
                     help="diagnostic: pin the pair sampler's variant (pmcx_set_sampler_variant); 0 = automatic")
+    ap.add_argument("--sampler-wpb", type=int, default=0,
+                    help="diagnostic: wavefronts per SIMD the lane-per-cell sampler may hold (LDS padding)")
     ap.add_argument("--sampler-stamps", action="store_true",
                     help="diagnostic: the instantiation that records cycles per stage")
     ap.add_argument("--kernel", type=int, default=4,
@@ -353,8 +355,8 @@ def main():
     blk = wp.CellBlock(n_cells, args.cap, args.n_spec, n_class=1, n_source=0, device=device,
                        cell_id_base=first_cell, max_events=args.max_events,
                        max_appends=args.max_appends, i_water=(19 if config3 else -1))
-    if args.sampler_lanes or args.sampler_stamps:
-        blk.set_sampler_variant(args.sampler_lanes, 0, int(args.sampler_stamps))
+    if args.sampler_lanes or args.sampler_stamps or args.sampler_wpb:
+        blk.set_sampler_variant(args.sampler_lanes, args.sampler_wpb, int(args.sampler_stamps))
     temp, pres = level_profile(args.levels)
     lev = (first_cell + np.arange(n_cells)) % args.levels
     if config3:

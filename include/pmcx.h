@@ -475,7 +475,8 @@ int pmcx_invalidate_sort(pmcx_ctx *ctx);
  * domain size, so that tests can hold every variant to the oracle at small sizes.  lanes: 0
  * automatic; 1 lane per cell (the full domain's kernel); 2 its two-wavefront form (a rank's
  * share at N = 4, 8); 8, 16, 64 lanes per cell (small blocks).  wavefronts_per_group: 0
- * automatic, 1, 2 or 4 (the 8/16/64 kernels).  stamps: 1 = the instantiation that records
+ * automatic, 1, 2 or 4 (the 8/16/64 kernels; with lanes = 1: 1, 2 cap the wavefronts a SIMD
+ * holds).  stamps: 1 = the instantiation that records
  * cycles per stage (pmcx_profile_phase_cycles).  Results do not depend on any of them. */
 int pmcx_set_sampler_variant(pmcx_ctx *ctx, int32_t lanes, int32_t wavefronts_per_group, int32_t stamps);
 
@@ -515,10 +516,10 @@ int pmcx_profile_get(pmcx_ctx *ctx, const char *name, double *ms, int64_t *launc
 
 /* Diagnostic: s_memtime ticks per stage of the lane-per-cell sampler's pass, summed over
  * wavefronts, after pmcx_set_sampler_variant(ctx, …, 1) (a separate, slower
- * instantiation of the kernel; zeros otherwise).  out[0] set-up; out[1..7] the seven stages of
- * a pass (pair picked and list entries requested; first slot found and Philox; particle
- * records requested; first count and second slot; kernel and accept; second count;
- * coagulation); out[8] write-back; out[9] draws; out[10] passes; out[11] wavefronts. */
+ * instantiation of the kernel; zeros otherwise).  out[0] set-up; out[1..7] the stages of a pass
+ * (slots settled and blocks fetched; exact counts; pair picked and list entries requested;
+ * particle records requested; kernel and accept; unused; coagulation); out[8] write-back;
+ * out[9] draws; out[10] passes; out[11] wavefronts. */
 int pmcx_profile_phase_cycles(pmcx_ctx *ctx, uint64_t out[12], int32_t reset);
 
 /* device memory held by the context, bytes (replaces memtrack, interface/mem.c) */

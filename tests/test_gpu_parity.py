@@ -18,7 +18,7 @@ def sampler_variant(request, monkeypatch, wp):
     """Every test of this module runs three times: with the library's own choice of sampler (the
     lanes-per-cell kernels at these cell counts), with the lane-per-cell kernel forced (the one
     the full-size domain runs) and with its two-wavefront form (evaluator + drawer, what a
-    rank's share of the domain runs at N = 4, 8), so that all are held to the oracle."""
+    rank's share of the domain runs at N = 8), so that all are held to the oracle."""
     variant = {"lane-per-cell": (1, 0, 0), "lane-per-cell-split": (2, 0, 0)}.get(request.param)
     from wrf_partmc_amd import host
     monkeypatch.setattr(host, "SAMPLER_VARIANT", variant)   # -> pmcx_set_sampler_variant
@@ -860,7 +860,7 @@ def test_results_independent_of_launch_geometry(wp, oracle, monkeypatch):
     """Same cells through the sampler with 1, 8, 16 and 64 lanes per cell and different
     workgroup sizes: identical particle data, counters and status."""
     outs = []
-    for lanes, wpb in ((8, 2), (16, 4), (64, 1), (8, 1), (1, 1), (2, 0)):
+    for lanes, wpb in ((8, 2), (16, 4), (64, 1), (8, 1), (1, 1), (1, 2), (2, 0)):
         blk = wp.CellBlock(5, 1536, 2, n_class=2, n_source=2, max_appends=128)
         blk.set_sampler_variant(lanes, wpb)
         names, dens = parity.default_species(2)
