@@ -280,6 +280,23 @@ typedef struct pmcx_trans_fields {
 int pmcx_transport_probs(pmcx_ctx *ctx, const pmcx_trans_fields *f, double *prob_h, double *prob_v,
                          int32_t *n_substeps, int32_t *bad, int32_t *n_class_part);
 
+/* trans_aero_preweight (interface/wrf_pmc_trans_aero.F90:1103-1423, compute_fluxes :1428-1627),
+ * the step in front of the sampling: the number concentration every (cell, class) is expected
+ * to hold after this transport (particles x magnitude, less prob x that towards every
+ * destination, plus the same x dest_vol / source_vol where it arrives; accumulated in the
+ * reference's order) and, where that is more than twice n_part_ideal, aero_state_scale_weight
+ * by n_parts_new / n_part_ideal (the magnitude grows, every particle of the class stays with
+ * probability n_part_ideal / n_parts_new).  periodic_x && periodic_y is the reference's "ideal"
+ * case; otherwise lateral boundary cells only send inwards and corners nothing.  prob_h ==
+ * prob_v == NULL: the probabilities pmcx_transport_probs built (they stay for the transport).
+ * Outputs (may be NULL): expected_num_conc [n_cells][n_class], n_removed [n_cells].
+ * One block of cells (the exchange of ghost sums between ranks is not part of this call).
+ * Synchronises. */
+int pmcx_transport_preweight(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int32_t periodic_x,
+                             int32_t periodic_y, const double *prob_h, const double *prob_v,
+                             const double *cell_volume, uint64_t seed, uint32_t step,
+                             double *expected_num_conc, int32_t *n_removed);
+
 /* The same transport for a SLAB of a domain decomposed in y across ranks (one process per
  * GPU; wrf_pmc_trans_aero.F90 exchanges the movers between MPI patches).  The block carries
  * one ghost row below its first real row (j = 0) and one above its last (j = ny - 1); the

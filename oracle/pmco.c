@@ -1420,3 +1420,110 @@ int pmco_transport_probs(const pmco_trans_fields *f, const int32_t *n_parts, con
     free(adv); free(dif); free(B); free(zm);
     return 0;
 }
+
+/* ------------------------------------------------------------------------
+ * trans_aero_preweight + compute_fluxes (interface/wrf_pmc_trans_aero.F90:1103-1423, 1428-1627)
+ * ------------------------------------------------------------------------ */
+int pmco_transport_preweight(pmco_cell *cells, int n_cells, int nx, int nz, int ny, int periodic_x,
+                             int periodic_y, const double *prob_h, const double *prob_v,
+                             const double *cell_volume, const double *n_ideal, uint64_t seed,
+                             uint32_t cell_id_base, uint32_t step, double *expected,
+                             int32_t *n_removed)
+{
+    const int C = cells[0].n_class;
+    const int ideal = periodic_x && periodic_y;
+    double *old = (double *)calloc((size_t)n_cells * C, sizeof(double));
+    /* ghost cells beyond the four lateral edges (ideal case): [side][k][along][class] */
+    double *gy = (double *)calloc((size_t)2 * nz * nx * C, sizeof(double));
+    double *gx = (double *)calloc((size_t)2 * nz * ny * C, sizeof(double));
+    for (int c = 0; c < n_cells; c++)
+        for (int cl = 0; cl < C; cl++) {
+            int n = 0;
+            for (int i = 0; i < *cells[c].n_part; i++) n += (cells[c].wclass[i] == cl);
+            old[(size_t)c * C + cl] = (double)n * cells[c].mag[cl];        /* :1211-1217 */
+            expected[(size_t)c * C + cl] = old[(size_t)c * C + cl];
+        }
+#define CELL(i, k, j) (((size_t)(j) * nz + (k)) * nx + (i))
+    for (int j = 0; j < ny; j++)
+        for (int k = 0; k < nz; k++)
+            for (int i = 0; i < nx; i++)
+                for (int cl = 0; cl < C; cl++) {
+                    const size_t c = CELL(i, k, j);
+                    const double o = old[c * C + cl], sv = cell_volume[c];
+                    double *self = &expected[c * C + cl];
+                    const double *ph = prob_h + (c * C + cl) * 4;          /* i-1, i+1, j-1, j+1 */
+                    int dirs[4] = {0, 0, 0, 0}, vert = 0;                  /* which moves the cell makes */
+                    if (ideal) { dirs[0] = dirs[1] = dirs[2] = dirs[3] = 1; vert = 1; }
+                    else if (i == 0) { if (j != 0 && j != ny - 1) dirs[1] = 1; }        /* :1510-1524 */
+                    else if (i == nx - 1) { if (j != 0 && j != ny - 1) dirs[0] = 1; }   /* :1525-1539 */
+                    else if (j == 0) { dirs[3] = 1; }                                   /* :1540-1554 */
+                    else if (j == ny - 1) { dirs[2] = 1; }                              /* :1555-1569 */
+                    else { dirs[0] = dirs[1] = dirs[2] = dirs[3] = 1; vert = 1; }
+                    /* the reference's order: j-1, j+1, i-1, i+1, then the levels */
+                    const int order[4] = {2, 3, 0, 1};
+                    for (int q = 0; q < 4; q++) {
+                        const int d = order[q];
+                        if (!dirs[d]) continue;
+                        const int ii = i + (d == 0 ? -1 : d == 1 ? 1 : 0), jj = j + (d == 2 ? -1 : d == 3 ? 1 : 0);
+                        const double flux = ph[d] * o;
+                        double *dst;
+                        double dv;
+                        if (jj < 0) { dst = &gy[(((size_t)0 * nz + k) * nx + i) * C + cl]; dv = cell_volume[CELL(i, k, ny - 1)]; }
+                        else if (jj >= ny) { dst = &gy[(((size_t)1 * nz + k) * nx + i) * C + cl]; dv = cell_volume[CELL(i, k, 0)]; }
+                        else if (ii < 0) { dst = &gx[(((size_t)0 * nz + k) * ny + j) * C + cl]; dv = cell_volume[CELL(nx - 1, k, j)]; }
+                        else if (ii >= nx) { dst = &gx[(((size_t)1 * nz + k) * ny + j) * C + cl]; dv = cell_volume[CELL(0, k, j)]; }
+                        else { dst = &expected[CELL(ii, k, jj) * C + cl]; dv = cell_volume[CELL(ii, k, jj)]; }
+                        *dst = *dst + flux * (dv / sv);
+                        *self = *self - flux;
+                    }
+                    if (vert)
+                        for (int kk = 0; kk < nz; kk++) {
+                            if (kk == k) continue;
+                            const double flux = prob_v[(c * C + cl) * nz + kk] * o;
+                            double *dst = &expected[CELL(i, kk, j) * C + cl];
+                            *dst = *dst + flux * (cell_volume[CELL(i, kk, j)] / sv);
+                            *self = *self - flux;
+                        }
+                }
+    if (ideal) {   /* what the ghost cells gathered arrives at the cells they stand for */
+        for (int k = 0; k < nz; k++) for (int i = 0; i < nx; i++) for (int cl = 0; cl < C; cl++)
+            expected[CELL(i, k, ny - 1) * C + cl] += gy[(((size_t)0 * nz + k) * nx + i) * C + cl];
+        for (int k = 0; k < nz; k++) for (int i = 0; i < nx; i++) for (int cl = 0; cl < C; cl++)
+            expected[CELL(i, k, 0) * C + cl] += gy[(((size_t)1 * nz + k) * nx + i) * C + cl];
+        for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int cl = 0; cl < C; cl++)
+            expected[CELL(nx - 1, k, j) * C + cl] += gx[(((size_t)0 * nz + k) * ny + j) * C + cl];
+        for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int cl = 0; cl < C; cl++)
+            expected[CELL(0, k, j) * C + cl] += gx[(((size_t)1 * nz + k) * ny + j) * C + cl];
+    }
+#undef CELL
+    /* the comparison with n_part_ideal and aero_state_scale_weight (:1386-1398) */
+    for (int c = 0; c < n_cells; c++) {
+        pmco_cell *s = &cells[c];
+        int removed = 0;
+        for (int cl = 0; cl < C; cl++) {
+            const double n_parts_new = expected[(size_t)c * C + cl] / s->mag[cl];
+            const double ideal_n = n_ideal[(size_t)c * C + cl];
+            if (!(n_parts_new > 2.0 * ideal_n)) continue;
+            const double ratio = n_parts_new / ideal_n;
+            const double p_drop = 1.0 - 1.0 / ratio;
+            const int n = *s->n_part;
+            unsigned char *dead = (unsigned char *)calloc((size_t)(n > 0 ? n : 1), 1);
+            int n_dead = 0;
+            for (int i = 0; i < n; i++) {
+                if (s->wclass[i] != cl) continue;
+                uint32_t w[4];
+                pmco_rng_block(seed, cell_id_base + (uint32_t)c, step, (uint32_t)i, PMCO_SITE_SCALE,
+                               (uint32_t)cl, w);
+                if (pmco_u53(w[0], w[1]) < p_drop) { dead[i] = 1; n_dead++; }
+            }
+            compact_stable(s, dead, n, n_dead);
+            free(dead);
+            s->mag[cl] = s->mag[cl] * ratio;
+            *s->sort_valid = 0;
+            removed += n_dead;
+        }
+        if (n_removed) n_removed[c] = removed;
+    }
+    free(old); free(gy); free(gx);
+    return 0;
+}

@@ -268,6 +268,26 @@ typedef struct {
 int pmco_transport_probs(const pmco_trans_fields *f, const int32_t *n_parts, const double *mag,
                          double *prob_h, double *prob_v, int32_t *n_substeps, int32_t *bad);
 
+/* trans_aero_preweight (interface/wrf_pmc_trans_aero.F90:1103-1423) with compute_fluxes
+ * (:1428-1627): the number concentration every (cell, class) is expected to hold after the
+ * transport -- num_conc_old = particles x magnitude, minus prob x num_conc_old towards every
+ * destination, plus the same times dest_vol / source_vol at the destination, accumulated in the
+ * reference's order (sources in j, k, i order; within a source j-1, j+1, i-1, i+1, then the
+ * levels; what crosses a periodic edge gathers in a ghost cell and is added afterwards, y edges
+ * before x edges) -- and, where that exceeds twice n_part_ideal, aero_state_scale_weight by
+ * n_parts_new / n_part_ideal: the magnitude grows by the ratio and every particle of the class
+ * stays with probability 1 / ratio ([upstream, uncited: a prob_round'ed number of random
+ * removals]; here one uniform per particle, site SCALE, as the halving of the rebalance).
+ * ideal = periodic_x && periodic_y (:1183-1184); otherwise the lateral boundary cells only send
+ * inwards and the corner cells nothing (:1510-1565).  prob_h / prob_v / cell_volume as for
+ * pmco_transport; n_ideal [n_cells][n_class].  expected [n_cells][n_class] (= expected_num_conc),
+ * n_removed [n_cells]. */
+int pmco_transport_preweight(pmco_cell *cells, int n_cells, int nx, int nz, int ny, int periodic_x,
+                             int periodic_y, const double *prob_h, const double *prob_v,
+                             const double *cell_volume, const double *n_ideal, uint64_t seed,
+                             uint32_t cell_id_base, uint32_t step, double *expected,
+                             int32_t *n_removed);
+
 /* EXTENSION (no call site on the reference's timestep): water condensation,
  * kappa-Koehler growth ODE per particle, environment fixed over del_t. */
 void pmco_condense(pmco_cell *c, const double *kappa /*[n_spec]*/, int i_water,

@@ -400,6 +400,26 @@ def transport_probs(nx, nz, ny, n_class, dt, dx, dy, fields, n_parts, mag, do_ve
     return ph, pv, ns, bad
 
 
+def transport_preweight(cells, nx, nz, ny, prob_h, prob_v, cell_volume, n_ideal, seed, cell_id_base,
+                        step, periodic_x=True, periodic_y=True):
+    """pmco_transport_preweight over a list of Cell objects; returns (expected [n][C], n_removed)."""
+    n = len(cells)
+    Cn = cells[0].n_class
+    arr = (CellStruct * n)(*[c.view() for c in cells])
+    ph = np.ascontiguousarray(prob_h, dtype=np.float64)
+    pv = np.ascontiguousarray(prob_v, dtype=np.float64)
+    cv = np.ascontiguousarray(cell_volume, dtype=np.float64)
+    ni = np.ascontiguousarray(np.broadcast_to(np.asarray(n_ideal, dtype=np.float64), (n, Cn)))
+    ex, nr = np.zeros((n, Cn)), np.zeros(n, dtype=np.int32)
+    f = lib().pmco_transport_preweight
+    f.restype = C.c_int
+    f.argtypes = [C.POINTER(CellStruct), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp,
+                  _dp, _dp, _dp, C.c_uint64, C.c_uint32, C.c_uint32, _dp, _ip]
+    f(arr, n, nx, nz, ny, int(periodic_x), int(periodic_y), _p(ph, _dp), _p(pv, _dp), _p(cv, _dp),
+      _p(ni, _dp), seed, cell_id_base, step, _p(ex, _dp), _p(nr, _ip))
+    return ex, nr
+
+
 def transport(cells, nx, nz, ny, prob_h, prob_v, cell_volume, seed, cell_id_base, step, next_id,
               periodic_x=True, periodic_y=True):
     """pmco_transport over a list of Cell objects (WRF order).  next_id: int64 array, updated."""

@@ -972,6 +972,62 @@ def test_transport_probs_built_on_the_device(wp, oracle, n_class, all_columns, d
     blk.close()
 
 
+@pytest.mark.parametrize("periodic,n_class", [(True, 2), (False, 2), (True, 1)])
+def test_transport_preweight_parity(wp, oracle, periodic, n_class):
+    """trans_aero_preweight (wrf_pmc_trans_aero.F90:1103-1423): expected number concentrations
+    bit for bit the oracle's sequential scatter (the device gathers, adding in the same order),
+    weights scaled and particles thinned where the expectation exceeds twice the ideal count;
+    then the chain the reference runs -- probabilities, preweight, sampling -- from device memory."""
+    from tests import trans_fields as tf
+    nx, nz, ny = 4, 5, 4
+    n_cells, n_part = nx * nz * ny, 600
+    blk, cells, info = parity.setup_pair(wp, oracle, n_cells, n_part, 2, n_class, 23, K_BROWN, cap=4096,
+                                         n_source=2)
+    r = np.random.RandomState(3)
+    cv = r.uniform(0.8, 1.25, n_cells)
+    n_ideal = np.full((n_cells, n_class), float(n_part) / n_class)
+    n_ideal[5] = 40.0; n_ideal[33, -1] = 25.0; n_ideal[60] = 1e-3 + 90.0
+    blk.set_n_part_ideal(n_ideal)
+    next_id = np.array([oc.next_id for oc in cells], dtype=np.int64)
+    kw = dict(do_vertmix=1, all_columns=periodic, i_offset=0, j_offset=0, global_nx=nx, global_ny=ny)
+    removed = 0
+    for step in range(2):
+        # explicit probabilities first ...
+        ph = r.uniform(0.0, 0.06, (n_cells, n_class, 4)); pv = r.uniform(0.0, 0.04, (n_cells, n_class, nz))
+        ex, nr = blk.transport_preweight(nx, nz, ny, ph, pv, cv, 23, step, periodic, periodic)
+        oex, onr = oracle.transport_preweight(cells, nx, nz, ny, ph, pv, cv, n_ideal, 23, 0, step, periodic,
+                                              periodic)
+        assert np.array_equal(ex, oex), (step, np.abs(ex - oex).max())
+        assert np.array_equal(nr, onr)
+        ok, msg = parity.compare_state(blk, cells)
+        assert ok, f"step {step} after preweight: {msg}"
+        assert np.array_equal(blk.get_weights(), np.array([oc.mag for oc in cells]))
+        removed += int(nr.sum())
+        # ... then the reference's chain with the probabilities built on the device
+        F = tf.make_fields(nx, nz, ny, n_class, seed=10 + step, k_scale=8.0,
+                           flux_scale=0.04 * n_part * info["mag"][0, 0])
+        counts = np.array([[int((oc.wclass[:int(oc.n_part[0])] == q).sum()) for q in range(n_class)]
+                           for oc in cells])
+        oph, opv, _, _ = oracle.transport_probs(nx, nz, ny, n_class, 60.0, 3000.0, 3000.0, F, counts,
+                                                np.array([oc.mag for oc in cells]), **kw)
+        blk.transport_probs(nx, nz, ny, 60.0, 3000.0, 3000.0, F, download=False, **kw)
+        ex, nr = blk.transport_preweight(nx, nz, ny, None, None, cv, 23, 100 + step, periodic, periodic)
+        oex, onr = oracle.transport_preweight(cells, nx, nz, ny, oph, opv, cv, n_ideal, 23, 0, 100 + step,
+                                              periodic, periodic)
+        assert np.array_equal(ex, oex) and np.array_equal(nr, onr), step
+        nm, na = blk.transport(nx, nz, ny, None, None, cv, 23, step, periodic, periodic)
+        st, onm, ona = oracle.transport(cells, nx, nz, ny, oph, opv, cv, 23, 0, step, next_id, periodic,
+                                        periodic)
+        assert st == 0 and np.array_equal(nm, onm) and np.array_equal(na, ona), step
+        ok, msg = parity.compare_state(blk, cells)
+        assert ok, f"step {step} after transport: {msg}"
+        ns_, nc_, s2 = blk.mc_coag(K_BROWN, 600.0, 23, step)
+        for c, oc in enumerate(cells):
+            assert oc.mc_coag(K_BROWN, 600.0, 23, oc.cell_id, step) == (int(s2[c]), int(ns_[c]), int(nc_[c]))
+    assert removed > 300
+    blk.close()
+
+
 def test_transport_makes_room_among_tombstones(wp, oracle):
     """Arrivals are appended behind the last used slot; with holes closed lazily (compact_den = 2)
     a cell can be short of room while a third of its slots are dead.  pmcx_transport closes the

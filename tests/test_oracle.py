@@ -709,3 +709,69 @@ def test_transport_probs_against_a_numpy_transcription(oracle, all_columns, do_v
     F2["alt"][2, 3, 2] = -F2["alt"][2, 3, 2]
     _, _, _, bad2 = oracle.transport_probs(nx, nz, ny, C, 60.0, 4000.0, 4000.0, F2, n_parts, mag, **kw)
     assert bad2.any()
+
+
+@pytest.mark.parametrize("periodic", [True, False])
+def test_transport_preweight_against_numpy(oracle, periodic):
+    """pmco_transport_preweight (wrf_pmc_trans_aero.F90:1103-1423, 1428-1627) against an
+    array-wise numpy form of compute_fluxes (sums in another order: equal to rounding), and the
+    weight scaling where the expected count exceeds twice the ideal one."""
+    nx, nz, ny, C, n_part = 4, 3, 5, 2, 300
+    n = nx * nz * ny
+    r = np.random.RandomState(5)
+    dens = np.array([1800.0, 1200.0])
+    ve, vs = oracle.make_bin_tables(80, 1e-10, 1e-2)
+    cells = []
+    for c in range(n):
+        oc = oracle.Cell(2, C, 0, 2048, dens, ve, 288.0, 1e5)
+        oc.mag[:] = [3e6, 5e6]
+        modes = [dict(frac=0.6, gm_radius=3e-8, gsd_log10=0.2, vol_frac=[1, 0], wclass=0, source=0),
+                 dict(frac=0.4, gm_radius=1e-7, gsd_log10=0.15, vol_frac=[0, 1], wclass=1, source=0)]
+        oc.generate(modes, n_part + 10 * (c % 7), 5, c, first_id=c << 32)
+        cells.append(oc)
+    ph = r.uniform(0.0, 0.08, (n, C, 4)); pv = r.uniform(0.0, 0.05, (n, C, nz))
+    cv = r.uniform(0.7, 1.4, n)
+    n_ideal = np.full((n, C), 1e9); n_ideal[3] = [40.0, 1e9]; n_ideal[17] = [1e9, 25.0]
+    cnt = np.array([[int((oc.wclass[:int(oc.n_part[0])] == q).sum()) for q in range(C)] for oc in cells])
+    mag0 = np.array([oc.mag.copy() for oc in cells])
+    old = cnt * mag0
+    ex, nr = oracle.transport_preweight(cells, nx, nz, ny, ph, pv, cv, n_ideal, 5, 0, 2, periodic, periodic)
+    # numpy: losses and gains per direction
+    O = old.reshape(ny, nz, nx, C); V = cv.reshape(ny, nz, nx, 1)
+    PH = ph.reshape(ny, nz, nx, C, 4); PV = pv.reshape(ny, nz, nx, C, nz)
+    jj, kk, ii = np.meshgrid(np.arange(ny), np.arange(nz), np.arange(nx), indexing="ij")
+    if periodic:
+        moves = np.ones((ny, nz, nx, 5), bool)
+    else:
+        inner = (ii > 0) & (ii < nx - 1) & (jj > 0) & (jj < ny - 1)
+        notcorner_x = (jj > 0) & (jj < ny - 1)
+        moves = np.zeros((ny, nz, nx, 5), bool)
+        moves[..., :] = inner[..., None]
+        moves[..., 1] |= (ii == 0) & notcorner_x
+        moves[..., 0] |= (ii == nx - 1) & notcorner_x
+        moves[..., 3] |= (jj == 0) & (ii > 0) & (ii < nx - 1)
+        moves[..., 2] |= (jj == ny - 1) & (ii > 0) & (ii < nx - 1)
+    new = O.copy()
+    shifts = [(2, 1), (2, -1), (0, 1), (0, -1)]          # np.roll of the SOURCE field to its destination
+    for d, (ax, sh) in enumerate([(2, -1), (2, 1), (0, -1), (0, 1)]):
+        flux = PH[..., d] * O * moves[..., d:d + 1]
+        new -= flux
+        new += np.roll(flux * 1.0 / V, sh, axis=ax) * V   # flux * (dest_vol / source_vol)
+    for k2 in range(nz):
+        flux = PV[..., k2] * O * moves[..., 4:5]
+        flux[:, k2] = 0.0
+        new -= flux
+        new[:, k2] += (flux / V).sum(axis=1) * V[:, k2]
+    np.testing.assert_allclose(ex, new.reshape(n, C), rtol=1e-12)
+    # scaling: only the two (cell, class) pairs with a small ideal count
+    for c in range(n):
+        for q in range(C):
+            npn = ex[c, q] / mag0[c, q]
+            if npn > 2 * n_ideal[c, q]:
+                ratio = npn / n_ideal[c, q]
+                assert cells[c].mag[q] == mag0[c, q] * ratio
+                kept = int((cells[c].wclass[:int(cells[c].n_part[0])] == q).sum())
+                assert abs(kept - cnt[c, q] / ratio) < 5 * np.sqrt(cnt[c, q] / ratio) + 3
+            else:
+                assert cells[c].mag[q] == mag0[c, q]
+    assert nr[3] > 0 and nr[17] > 0 and nr.sum() == nr[3] + nr[17]

@@ -64,6 +64,7 @@ struct pmcx_ctx {
     // probabilities built on the device (pmcx_transport_probs), consumed by the next transport
     double *d_prob_h = nullptr, *d_prob_v = nullptr;
     int32_t *d_prob_i = nullptr;    // [n_cells] bad | [n_cells n_class] particles per class | [n_cells] sub-steps
+    double *d_preweight = nullptr;  // [2][n_cells][n_class] num_conc_old, expected_num_conc
     int probs_nx = 0, probs_nz = 0, probs_ny = 0; // geometry they were built for (probs_nx != 0: ready)
     int64_t *d_acc = nullptr;   // running sums over calls: n_samp, n_coag, n_part, status
     double *d_diag = nullptr; // [n_cells*(2+2*n_dbin)]
@@ -1190,6 +1191,55 @@ int pmcx_transport_probs(pmcx_ctx *ctx, const pmcx_trans_fields *f, double *prob
     if (n_substeps) HIP_TRY(ctx, hipMemcpyAsync(n_substeps, a.n_substeps, sizeof(int32_t) * col, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->probs_nx = nx; ctx->probs_ny = ny;
+    return PMCX_OK;
+}
+
+int pmcx_transport_preweight(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int32_t periodic_x,
+                             int32_t periodic_y, const double *prob_h, const double *prob_v,
+                             const double *cell_volume, uint64_t seed, uint32_t step,
+                             double *expected_num_conc, int32_t *n_removed)
+{
+    if (!ctx || !cell_volume || (!prob_h) != (!prob_v))
+        return fail(ctx, PMCX_EINVAL, "pmcx_transport_preweight: null argument");
+    const bool built = !prob_h;
+    if (built && (ctx->probs_nx != nx || ctx->probs_nz != nz || ctx->probs_ny != ny))
+        return fail(ctx, PMCX_ESTATE, "pmcx_transport_preweight: no probabilities were built for this grid");
+    if (!ctx->n_ideal_set) return fail(ctx, PMCX_ESTATE, "pmcx_set_n_part_ideal must come first");
+    const pmcx_config &cf = ctx->cfg;
+    if (nx < 1 || nz < 1 || ny < 1 || nz > 128 || (int64_t)nx * nz * ny != cf.n_cells)
+        return fail(ctx, PMCX_EINVAL, "pmcx_transport_preweight: nx*nz*ny must equal n_cells (nz <= 128)");
+    HIP_TRY(ctx, hipSetDevice(cf.device));
+    const size_t nc = (size_t)cf.n_cells, C = (size_t)cf.n_class;
+    if (!ctx->d_preweight) {
+        int rc = dev_alloc(ctx, &ctx->d_preweight, 2 * nc * C);
+        if (rc) return rc;
+    }
+    const size_t bh = sizeof(double) * nc * C * 4, bv = sizeof(double) * nc * C * (size_t)nz,
+                 bc = sizeof(double) * nc;
+    int rc = ensure_stage(ctx, bh + bv + bc + sizeof(int32_t) * nc + 64);
+    if (rc) return rc;
+    double *d_ph = (double *)ctx->stage, *d_pv = d_ph + nc * C * 4, *d_cv = d_pv + nc * C * (size_t)nz;
+    int32_t *d_nr = (int32_t *)(d_cv + nc);
+    if (built) { d_ph = ctx->d_prob_h; d_pv = ctx->d_prob_v; } // (left in place for the transport)
+    else {
+        HIP_TRY(ctx, hipMemcpyAsync(d_ph, prob_h, bh, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_pv, prob_v, bv, hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(d_cv, cell_volume, bc, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(d_nr, 0, sizeof(int32_t) * nc, ctx->stream));
+    {
+        ProfScope ps(ctx, "transport_preweight");
+        HIP_TRY(ctx, launch_transport_preweight(ctx->st, nx, nz, ny, periodic_x && periodic_y, d_ph, d_pv,
+                                                d_cv, ctx->d_preweight, ctx->d_preweight + nc * C, d_nr,
+                                                seed, step, ctx->stream));
+    }
+    if (expected_num_conc)
+        HIP_TRY(ctx, hipMemcpyAsync(expected_num_conc, ctx->d_preweight + nc * C, sizeof(double) * nc * C,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+    if (n_removed) HIP_TRY(ctx, hipMemcpyAsync(n_removed, d_nr, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, invalidate_sort(ctx, 0, cf.n_cells, false)); // (removals keep the sort keys current)
+    ctx->bounds_dirty = true;
     return PMCX_OK;
 }
 

@@ -46,7 +46,8 @@ enum : uint32_t {
     SITE_EMIT_P = 8,
     SITE_DILUTE = 9,
     SITE_TRANS = 10,
-    SITE_DEPOSIT = 11
+    SITE_DEPOSIT = 11,
+    SITE_SCALE = 12
 };
 
 // counter = (cell, step, a, site<<28 | b); key = seed

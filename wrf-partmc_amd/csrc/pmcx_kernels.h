@@ -178,6 +178,10 @@ struct TransFieldsArgs {
     double *prob_h, *prob_v;
     int32_t *n_substeps, *bad, *n_class_part;
 };
+hipError_t launch_transport_preweight(const DeviceState &st, int nx, int nz, int ny, int ideal,
+                                      const double *prob_h, const double *prob_v,
+                                      const double *cell_volume, double *old, double *expect,
+                                      int32_t *n_removed, uint64_t seed, uint32_t step, hipStream_t s);
 size_t trans_probs_lds_bytes(const DeviceState &st, int nz);
 hipError_t launch_transport_probs(const DeviceState &st, const TransFieldsArgs &a, hipStream_t s);
 size_t halo_record_bytes(const DeviceState &st);

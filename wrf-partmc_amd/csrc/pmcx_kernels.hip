@@ -3180,6 +3180,159 @@ __global__ __launch_bounds__(256) void k_trans_probs(DeviceState st, TransFields
     }
 }
 
+// trans_aero_preweight (interface/wrf_pmc_trans_aero.F90:1103-1423): the number concentration
+// every (cell, class) is expected to hold after the transport, and a larger weight where that
+// is more than twice the ideal particle count.
+//   k_preweight_old    one wavefront per cell: particles per class x magnitude
+//   k_preweight_new    one thread per (cell, class): compute_fluxes (:1428-1627) turned into a
+//                      gather that adds its terms in the order the reference's scatter applies them
+//                      to that cell -- sources in (j, k, i) order, the cell's own losses at its place
+//                      in that order (j-1, j+1, i-1, i+1, then the levels), what crosses a periodic
+//                      edge last (it waits in a ghost cell until the exchange, :1252-1366)
+//   k_preweight_scale  one wavefront per cell: aero_state_scale_weight where n_parts_new > 2 ideal
+struct PreweightArgs {
+    int32_t nx, nz, ny, ideal;
+    const double *prob_h, *prob_v, *cell_volume;
+    double *old, *expect;   // [n_cells][n_class]
+    int32_t *n_removed;     // [n_cells]
+};
+
+__global__ __launch_bounds__(64) void k_preweight_old(DeviceState st, PreweightArgs a)
+{
+    const int lane = threadIdx.x, c = blockIdx.x, C = st.n_class;
+    const int64_t cb = (int64_t)c * st.cap;
+    apply_event_log(st, c, lane);
+    const int n_hi = st.n_hi[c];
+    const bool keyed = st.key_valid[c] != 0;
+    for (int cl = 0; cl < C; cl++) {
+        int n = st.n_part[c];
+        if (C > 1) {
+            uint32_t cnt = 0;
+            for (int i = lane; i < n_hi; i += 64) {
+                int wc;
+                if (keyed) {
+                    const uint32_t kq = st.gkey[cb + i];
+                    wc = kq == 0xFFFFu ? -1 : (int)(kq / (uint32_t)st.n_bin);
+                } else {
+                    wc = live_class(st, cb, i);
+                }
+                cnt += (wc == cl);
+            }
+            n = (int)wave_sum_u64(cnt);
+        }
+        if (lane == 0) a.old[(int64_t)c * C + cl] = (double)n * st.mag[(int64_t)c * C + cl];
+    }
+}
+
+// which moves a source cell makes: bit d of the result = towards i-1, i+1, j-1, j+1; bit 4 = levels
+__device__ __forceinline__ int preweight_moves(int i, int j, int nx, int ny, int ideal)
+{
+    if (ideal) return 31;
+    if (i == 0) return (j != 0 && j != ny - 1) ? 2 : 0;
+    if (i == nx - 1) return (j != 0 && j != ny - 1) ? 1 : 0;
+    if (j == 0) return 8;
+    if (j == ny - 1) return 4;
+    return 31;
+}
+
+__global__ __launch_bounds__(256) void k_preweight_new(DeviceState st, PreweightArgs a)
+{
+    const int C = st.n_class, nx = a.nx, nz = a.nz, ny = a.ny;
+    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (x >= (int64_t)st.n_cells * C) return;
+    const int cl = (int)(x % C);
+    const int64_t d = x / C;
+    const int i = (int)(d % nx), k = (int)((d / nx) % nz), j = (int)(d / ((int64_t)nx * nz));
+    auto cell = [&](int ii, int kk, int jj) { return ((int64_t)jj * nz + kk) * nx + ii; };
+    const double vd = a.cell_volume[d];
+    // what source s sends towards this cell through its horizontal move `dir`
+    auto from_h = [&](int64_t s, int dir) {
+        const double flux = a.prob_h[(s * C + cl) * 4 + dir] * a.old[s * C + cl];
+        return flux * (vd / a.cell_volume[s]);
+    };
+    auto from_v = [&](int64_t s) {
+        const double flux = a.prob_v[(s * C + cl) * nz + k] * a.old[s * C + cl];
+        return flux * (vd / a.cell_volume[s]);
+    };
+    double acc = a.old[d * C + cl];
+    if (j >= 1 && (preweight_moves(i, j - 1, nx, ny, a.ideal) & 8)) acc = acc + from_h(cell(i, k, j - 1), 3);
+    const bool col_vert = (preweight_moves(i, j, nx, ny, a.ideal) & 16) != 0; // (the whole column alike)
+    if (col_vert)
+        for (int kk = 0; kk < k; kk++) acc = acc + from_v(cell(i, kk, j));
+    if (i >= 1 && (preweight_moves(i - 1, j, nx, ny, a.ideal) & 2)) acc = acc + from_h(cell(i - 1, k, j), 1);
+    {   // the cell's own losses, in the order compute_fluxes takes them
+        const int mv = preweight_moves(i, j, nx, ny, a.ideal);
+        const double o = a.old[d * C + cl];
+        const double *ph = a.prob_h + (d * C + cl) * 4;
+        if (mv & 4) acc = acc - ph[2] * o;
+        if (mv & 8) acc = acc - ph[3] * o;
+        if (mv & 1) acc = acc - ph[0] * o;
+        if (mv & 2) acc = acc - ph[1] * o;
+        if (mv & 16)
+            for (int kk = 0; kk < nz; kk++)
+                if (kk != k) acc = acc - a.prob_v[(d * C + cl) * nz + kk] * o;
+    }
+    if (i + 1 < nx && (preweight_moves(i + 1, j, nx, ny, a.ideal) & 1)) acc = acc + from_h(cell(i + 1, k, j), 0);
+    if (col_vert)
+        for (int kk = k + 1; kk < nz; kk++) acc = acc + from_v(cell(i, kk, j));
+    if (j + 1 < ny && (preweight_moves(i, j + 1, nx, ny, a.ideal) & 4)) acc = acc + from_h(cell(i, k, j + 1), 2);
+    if (a.ideal) { // across the periodic edges: the ghost cell's single term, added after everything else
+        if (j == ny - 1) acc = acc + from_h(cell(i, k, 0), 2);
+        if (j == 0) acc = acc + from_h(cell(i, k, ny - 1), 3);
+        if (i == nx - 1) acc = acc + from_h(cell(0, k, j), 0);
+        if (i == 0) acc = acc + from_h(cell(nx - 1, k, j), 1);
+    }
+    a.expect[d * C + cl] = acc;
+}
+
+__global__ __launch_bounds__(64) void k_preweight_scale(DeviceState st, PreweightArgs a, uint64_t seed,
+                                                        uint32_t step)
+{
+    const int lane = threadIdx.x, c = blockIdx.x, C = st.n_class;
+    const int64_t cb = (int64_t)c * st.cap;
+    const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    double *mag = st.mag + (int64_t)c * C;
+    uint32_t removed = 0;
+    for (int cl = 0; cl < C; cl++) {
+        const double n_parts_new = a.expect[(int64_t)c * C + cl] / mag[cl];
+        const double ideal_n = st.n_ideal[(int64_t)c * C + cl];
+        if (!(n_parts_new > 2.0 * ideal_n)) continue; // (uniform over the wavefront)
+        const double ratio = n_parts_new / ideal_n;
+        const double p_drop = 1.0 - 1.0 / ratio;
+        const int n_hi = st.n_hi[c], n_live = st.n_part[c];
+        uint32_t nd = 0, rank0 = 0;
+        for (int i0 = 0; i0 < n_hi; i0 += 64) {
+            const int i = i0 + lane;
+            const int wc = i < n_hi ? live_class_c(st, cb, i) : -1;
+            const uint64_t mlive = __ballot(wc >= 0);
+            const uint32_t rank = rank0 + (uint32_t)__popcll(mlive & lt);
+            bool drop = false;
+            if (wc == cl) {
+                uint32_t w[4];
+                rng_block(seed, cell_id, step, rank, SITE_SCALE, (uint32_t)cl, w);
+                drop = u53(w[0], w[1]) < p_drop;
+            }
+            if (drop) mark_dead(st, cb, i);
+            nd += (uint32_t)__popcll(__ballot(drop));
+            rank0 += (uint32_t)__popcll(mlive);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_sync();
+        if (lane == 0) {
+            st.n_part[c] = n_live - (int)nd;
+            mag[cl] = mag[cl] * ratio;
+            st.sort_valid[c] = 0;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __threadfence_block();
+        wave_sync();
+        removed += nd;
+        if (((int)nd + n_hi - n_live) * st.compact_den > n_hi) compact_wave(st, c, lane);
+    }
+    if (lane == 0 && a.n_removed) a.n_removed[c] = (int32_t)removed;
+}
+
 // Arrivals are appended behind n_hi.  A cell that would run out of slots while it has holes
 // closes them now (stable, as always) and renames the slots its own outbox names; this is the
 // only moment it can: the outboxes exist, nobody has read them yet.
@@ -4029,6 +4182,18 @@ hipError_t launch_transport(const DeviceState &st, int nx, int nz, int ny, int p
     if (e != hipSuccess) return e;
     return launch_transport_finish(st, nx, nz, ny, periodic_x, periodic_y, cell_volume, outbox, n_out,
                                    n_arr, n_exp, dest_mask, 0, ny, s);
+}
+hipError_t launch_transport_preweight(const DeviceState &st, int nx, int nz, int ny, int ideal,
+                                      const double *prob_h, const double *prob_v,
+                                      const double *cell_volume, double *old, double *expect,
+                                      int32_t *n_removed, uint64_t seed, uint32_t step, hipStream_t s)
+{
+    PreweightArgs a{nx, nz, ny, ideal, prob_h, prob_v, cell_volume, old, expect, n_removed};
+    hipLaunchKernelGGL(k_preweight_old, dim3(st.n_cells), dim3(64), 0, s, st, a);
+    const int64_t n = (int64_t)st.n_cells * st.n_class;
+    hipLaunchKernelGGL(k_preweight_new, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, a);
+    hipLaunchKernelGGL(k_preweight_scale, dim3(st.n_cells), dim3(64), 0, s, st, a, seed, step);
+    return hipGetLastError();
 }
 size_t trans_probs_lds_bytes(const DeviceState &st, int nz)
 {

@@ -40,7 +40,7 @@ EXPORTED_SYMBOLS = [
     "pmcx_memory_bytes", "pmcx_device_memory_info", "pmcx_set_cell_id_base", "pmcx_set_gas_state",
     "pmcx_get_gas_state", "pmcx_set_gas_scenario", "pmcx_scenario_update_gas_state",
     "pmcx_invalidate_lists", "pmcx_get_keys", "pmcx_seasalt_emissions",
-    "pmcx_transport_probs", "pmcx_set_sampler_variant",
+    "pmcx_transport_probs", "pmcx_set_sampler_variant", "pmcx_transport_preweight",
 ]
 
 
@@ -162,6 +162,9 @@ def load_library():
     L.pmcx_dry_deposition.argtypes = [C.c_void_p, C.c_double, C.c_uint64, C.c_uint32] + [C.c_void_p] * 9
     L.pmcx_timestep.argtypes = [C.c_void_p, C.POINTER(PmcxStepFlags)]
     L.pmcx_set_sampler_variant.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+    L.pmcx_transport_preweight.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                           C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                           C.c_uint32, C.c_void_p, C.c_void_p]
     L.pmcx_transport_probs.argtypes = [C.c_void_p, C.POINTER(PmcxTransFields)] + [C.c_void_p] * 5
     L.pmcx_seasalt_emissions.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_uint64, C.c_uint32,
                                          C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 7
@@ -628,6 +631,21 @@ class CellBlock:
         self._ck(self._lib.pmcx_transport_probs(self._h, C.byref(tf), _ptr(ph), _ptr(pv), _ptr(ns),
                                                 _ptr(bad), _ptr(ncp)))
         return ph, pv, ns, bad, ncp
+
+    def transport_preweight(self, nx, nz, ny, prob_h, prob_v, cell_volume, seed=0, step=0,
+                            periodic_x=True, periodic_y=True):
+        """trans_aero_preweight (wrf_pmc_trans_aero.F90:1103-1423): expected number
+        concentrations after this transport; weights scaled up where they exceed twice the ideal
+        particle count.  Returns (expected_num_conc [n_cells][n_class], n_removed [n_cells])."""
+        n, Cn = self.cfg.n_cells, self.cfg.n_class
+        ph = None if prob_h is None else np.ascontiguousarray(np.broadcast_to(_f64(prob_h), (n, Cn, 4)))
+        pv = None if prob_v is None else np.ascontiguousarray(np.broadcast_to(_f64(prob_v), (n, Cn, nz)))
+        cv = np.ascontiguousarray(np.broadcast_to(_f64(cell_volume), (n,)))
+        ex, nr = np.zeros((n, Cn)), np.zeros(n, dtype=np.int32)
+        self._ck(self._lib.pmcx_transport_preweight(self._h, nx, nz, ny, int(periodic_x), int(periodic_y),
+                                                    _ptr(ph), _ptr(pv), _ptr(cv), seed, step, _ptr(ex),
+                                                    _ptr(nr)))
+        return ex, nr
 
     def transport(self, nx, nz, ny, prob_h, prob_v, cell_volume, seed=0, step=0, periodic_x=True,
                   periodic_y=True):
