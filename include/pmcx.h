@@ -280,6 +280,31 @@ typedef struct pmcx_trans_fields {
 int pmcx_transport_probs(pmcx_ctx *ctx, const pmcx_trans_fields *f, double *prob_h, double *prob_v,
                          int32_t *n_substeps, int32_t *bad, int32_t *n_class_part);
 
+/* Open lateral boundaries for pmcx_transport, the reference's real case with neither direction
+ * periodic (interface/wrf_pmc_trans_aero.F90:497-534, 689-801): cells 1 .. n-2 sample as always
+ * (also towards the boundary cells); a lateral boundary cell only sends inwards, with
+ * min(prob_advection + prob_diffusion, 1); a corner cell sends nothing; what is sent to a boundary
+ * cell leaves the domain.  The boundary cells are then refilled by pmcx_boundary_copy (outflow) or
+ * pmcx_boundary_resample (inflow), as :803-955 does.  One block of at least 3 x 3 columns. */
+int pmcx_set_transport_lateral(pmcx_ctx *ctx, int32_t on);
+
+/* The refill of the lateral boundary cells after the transport (interface/
+ * wrf_pmc_trans_aero.F90:803-955).
+ * pmcx_boundary_copy: outflow (:829-831) -- cell to_cell[q] becomes a copy of from_cell[q]
+ *   (aero_state_dup_all_particles [upstream, uncited]: the same particles in the same order under
+ *   new ids, the same weights).
+ * pmcx_boundary_resample: inflow (:832-845) -- aero_state_resample (:976-1098) of the listed cells
+ *   against the background (num_conc [n_list][n_mode]: number mixing ratios; density [n_list] =
+ *   1 / inverse_density; create_time: 0 at the reference's call sites).  throw_away[q] != 0: the
+ *   cell is emptied and sampled anew; else every class is brought to a Poisson-distributed target
+ *   count -- short of it, new particles from its modes (only if the shortfall is more than a tenth
+ *   of the target, :1066-1079); over it, a uniformly random subset of exactly the excess leaves.
+ *   n_added / n_removed [n_list] may be NULL.  Both synchronise. */
+int pmcx_boundary_copy(pmcx_ctx *ctx, int32_t n_pairs, const int32_t *from_cell, const int32_t *to_cell);
+int pmcx_boundary_resample(pmcx_ctx *ctx, int32_t n_list, const int32_t *cell, const int32_t *throw_away,
+                           const pmcx_aero_dist *background, const double *density, double create_time,
+                           uint64_t seed, uint32_t step, int32_t *n_added, int32_t *n_removed);
+
 /* trans_aero_preweight (interface/wrf_pmc_trans_aero.F90:1103-1423, compute_fluxes :1428-1627),
  * the step in front of the sampling: the number concentration every (cell, class) is expected
  * to hold after this transport (particles x magnitude, less prob x that towards every

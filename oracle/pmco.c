@@ -809,15 +809,17 @@ void pmco_condense(pmco_cell *c, const double *kappa, int i_water, double rel_hu
  *   background : per mode, Poisson((1 - exp(-rate dt)) N_bg / magnitude) new particles
  * New particles are appended in order; ids come from next_id.
  * ---------------------------------------------------------------------- */
-static int add_dist_sample(pmco_cell *c, const pmco_aero_dist *d, double factor, int kind,
-                           double create_time, uint64_t seed, uint32_t cell_id, uint32_t step,
-                           int64_t *next_id, int *status)
+/* means != NULL: the Poisson mean of every mode is given (negative: the mode is skipped) */
+static int add_dist_sample_means(pmco_cell *c, const pmco_aero_dist *d, double factor, const double *means,
+                                 int kind, double create_time, uint64_t seed, uint32_t cell_id,
+                                 uint32_t step, int64_t *next_id, int *status)
 {
     int added = 0;
     for (int m = 0; m < d->n_mode; m++) {
         uint32_t w[4];
         const int cl = d->mode_class[m];
-        const double mean = d->num_conc[m] * factor / c->mag[cl];
+        const double mean = means ? means[m] : d->num_conc[m] * factor / c->mag[cl];
+        if (means && mean < 0.0) continue;
         pmco_rng_block(seed, cell_id, step, ((uint32_t)kind << 8) | (uint32_t)m, PMCO_SITE_EMIT_N, 0, w);
         int n = pmco_poisson(mean, pmco_u53(w[0], w[1]));
         const int n0 = *c->n_part;
@@ -844,6 +846,13 @@ static int add_dist_sample(pmco_cell *c, const pmco_aero_dist *d, double factor,
         added += n;
     }
     return added;
+}
+
+static int add_dist_sample(pmco_cell *c, const pmco_aero_dist *d, double factor, int kind,
+                           double create_time, uint64_t seed, uint32_t cell_id, uint32_t step,
+                           int64_t *next_id, int *status)
+{
+    return add_dist_sample_means(c, d, factor, NULL, kind, create_time, seed, cell_id, step, next_id, status);
 }
 
 int pmco_scenario_update(pmco_cell *c, double dt, double create_time, uint64_t seed,
@@ -1087,6 +1096,8 @@ void pmco_diagnostics_ext(const pmco_cell *c, int i_water, double *species_mass,
 typedef struct { int dest; double lo, hi, ratio; } trans_dest;
 
 /* destination table of (cell c, class cl): returns the number of entries */
+static int g_trans_lateral = 0; /* pmco_transport_lateral: the reference's open lateral boundaries */
+
 static int trans_table(const pmco_cell *cells, int c, int cl, int nx, int nz, int ny, int px, int py,
                        const double *prob_h, const double *prob_v, const double *vol, int n_class,
                        trans_dest *out)
@@ -1095,6 +1106,22 @@ static int trans_table(const pmco_cell *cells, int c, int cl, int nx, int nz, in
     double p[4 + 128];
     int dcell[4 + 128], n = 0;
     const int di[4] = {-1, 1, 0, 0}, dj[4] = {0, 0, -1, 1};
+    const int bx = (i == 0 || i == nx - 1), by = (j == 0 || j == ny - 1);
+    if (g_trans_lateral && (bx || by)) {
+        /* a lateral boundary cell only sends inwards, with min(prob, 1); a corner nothing
+         * (wrf_pmc_trans_aero.F90:689-768) */
+        if (bx && by) return 0;
+        const int d = i == 0 ? 1 : i == nx - 1 ? 0 : j == 0 ? 3 : 2;
+        double pr = prob_h[((size_t)c * n_class + cl) * 4 + d];
+        if (pr > 1.0) pr = 1.0;
+        if (!(pr > 0.0)) return 0;
+        const int dc = ((j + dj[d]) * nz + k) * nx + (i + di[d]);
+        out[0].dest = dc;
+        out[0].lo = 0.0;
+        out[0].hi = pr;
+        out[0].ratio = (cells[dc].mag[cl] / (vol[c] / vol[dc])) / cells[c].mag[cl];
+        return 1;
+    }
     for (int d = 0; d < 4; d++) {
         int ii = i + di[d], jj = j + dj[d];
         if (ii < 0 || ii >= nx) { if (!px) continue; ii = (ii + nx) % nx; }
@@ -1181,6 +1208,10 @@ int pmco_transport(pmco_cell *cells, int n_cells, int nx, int nz, int ny, int pe
     for (int c = 0; c < n_cells; c++) {
         pmco_cell *dst = &cells[c];
         const int i = c % nx, k = (c / nx) % nz, j = c / (nx * nz);
+        if (g_trans_lateral && (i == 0 || i == nx - 1 || j == 0 || j == ny - 1)) {
+            n_arrived[c] = 0; /* what is sent to a lateral boundary cell leaves the domain (:775-801) */
+            continue;
+        }
         int src[4 + 128], ns = 0;
         const int di[4] = {1, -1, 0, 0}, dj[4] = {0, 0, 1, -1}; /* east, west, north, south neighbour */
         for (int d = 0; d < 4; d++) {
@@ -1526,4 +1557,120 @@ int pmco_transport_preweight(pmco_cell *cells, int n_cells, int nx, int nz, int 
     }
     free(old); free(gy); free(gx);
     return 0;
+}
+
+/* pmco_transport with the reference's open lateral boundaries (real case, neither direction
+ * periodic; interface/wrf_pmc_trans_aero.F90:497-534, 689-801): cells 1 .. n-2 sample as always,
+ * a lateral boundary cell only sends inwards with min(prob, 1), a corner nothing, and what is
+ * sent to a boundary cell is dropped. */
+int pmco_transport_lateral(pmco_cell *cells, int n_cells, int nx, int nz, int ny,
+                           const double *prob_h, const double *prob_v, const double *cell_volume,
+                           uint64_t seed, uint32_t cell_id_base, uint32_t step, int64_t *next_id,
+                           int32_t *n_moved, int32_t *n_arrived)
+{
+    if (nx < 3 || ny < 3) return -1;
+    g_trans_lateral = 1;
+    const int st = pmco_transport(cells, n_cells, nx, nz, ny, 0, 0, prob_h, prob_v, cell_volume, seed,
+                                  cell_id_base, step, next_id, n_moved, n_arrived);
+    g_trans_lateral = 0;
+    return st;
+}
+
+/* ------------------------------------------------------------------------
+ * The refill of the lateral boundary cells after the transport
+ * (interface/wrf_pmc_trans_aero.F90:803-955).
+ * ------------------------------------------------------------------------ */
+
+/* aero_state_dup_all_particles(from, to) [upstream, uncited], as the reference uses it on an
+ * outflow boundary (:829-831): the boundary cell becomes a copy of its inner neighbour -- the
+ * same particles in the same order under new ids, the same weights. */
+void pmco_boundary_copy(pmco_cell *dst, const pmco_cell *src, int64_t *next_id_dst)
+{
+    const int n = *src->n_part;
+    for (int i = 0; i < n; i++) {
+        for (int sp = 0; sp < dst->n_spec; sp++)
+            dst->vol[(size_t)sp * dst->cap + i] = src->vol[(size_t)sp * src->cap + i];
+        for (int sp = 0; sp < dst->n_source; sp++)
+            dst->n_orig[(size_t)sp * dst->cap + i] = src->n_orig[(size_t)sp * src->cap + i];
+        dst->vtot[i] = src->vtot[i]; dst->mass[i] = src->mass[i];
+        dst->wclass[i] = src->wclass[i];
+        dst->lct[i] = src->lct[i]; dst->gct[i] = src->gct[i];
+        dst->id[i] = *next_id_dst + i;
+    }
+    *next_id_dst += n;
+    *dst->n_part = n;
+    for (int cl = 0; cl < dst->n_class; cl++) dst->mag[cl] = src->mag[cl];
+    *dst->sort_valid = 0;
+}
+
+/* aero_state_resample (interface/wrf_pmc_trans_aero.F90:976-1098) on an inflow boundary
+ * (:832-845): bg->num_conc are the background's per-mode number mixing ratios, density the air's
+ * (1 / inverse_density), sample_prop = 1 and the create time 0 at the reference's call sites
+ * (create_time here).
+ *   throw_away: the cell is emptied and sampled anew, Poisson(num_conc density / magnitude) per
+ *               mode (:1028-1032; aero_state_add_aero_dist_sample [upstream, uncited], as the
+ *               emission of the scenario update)
+ *   otherwise, per class: n_samp = Poisson(total_num_conc density / magnitude) is the count the
+ *               class should have (:1037-1049).  Short of it by n_parts_to_add: per mode of the
+ *               class Poisson(share n_parts_to_add) particles are sampled and added if the
+ *               magnitude exceeds 0.1 density num_conc / (share n_parts_to_add) (:1050-1084; with
+ *               flat weights: if the shortfall is more than a tenth of the target).  Over it:
+ *               min(excess, particles) particles chosen at random leave (:1085-1095; here
+ *               selection sampling in rank order: particle t of n goes when
+ *               u (n - t) < still to go -- a uniformly random subset of exactly that size).
+ * [aero_mode_sample_radius takes a size_factor in this fork (:1073-1075) whose meaning is in
+ * the absent submodule: the radius is drawn from the plain log-normal mode.] */
+int pmco_boundary_resample(pmco_cell *c, int throw_away, const pmco_aero_dist *bg, double density,
+                           double create_time, uint64_t seed, uint32_t cell_id, uint32_t step,
+                           int64_t *next_id, int32_t *n_added, int32_t *n_removed)
+{
+    int status = 0;
+    *n_added = *n_removed = 0;
+    *c->sort_valid = 0;
+    if (throw_away) {
+        *n_removed = *c->n_part;
+        *c->n_part = 0;                                             /* aero_state_zero */
+        *n_added = add_dist_sample(c, bg, density, 3, create_time, seed, cell_id, step, next_id, &status);
+        return status;
+    }
+    double means[64];
+    for (int cl = 0; cl < c->n_class; cl++) {
+        int n_before = 0;
+        for (int i = 0; i < *c->n_part; i++) n_before += (c->wclass[i] == cl);
+        double total = 0.0;
+        for (int m = 0; m < bg->n_mode; m++)
+            if (bg->mode_class[m] == cl) total = total + bg->num_conc[m] * density;
+        const double n_parts_new = total / c->mag[cl];
+        uint32_t w[4];
+        pmco_rng_block(seed, cell_id, step, (uint32_t)cl, PMCO_SITE_RESAMPLE, 0, w);
+        const int n_samp = pmco_poisson(n_parts_new, pmco_u53(w[0], w[1]));
+        const int n_to_add = n_samp - n_before;
+        if (n_to_add > 0) {
+            for (int m = 0; m < bg->n_mode; m++) {
+                means[m] = -1.0;
+                if (bg->mode_class[m] != cl) continue;
+                const double share = (density * bg->num_conc[m]) / total;
+                const double n_samp_avg = share * (double)n_to_add;
+                const double threshold = (density * bg->num_conc[m] / n_samp_avg) * .1;
+                if (c->mag[cl] > threshold) means[m] = n_samp_avg;
+            }
+            *n_added += add_dist_sample_means(c, bg, density, means, 3, create_time, seed, cell_id, step,
+                                              next_id, &status);
+        } else {
+            const int n = *c->n_part;
+            int m_rm = -n_to_add < n_before ? -n_to_add : n_before;
+            unsigned char *dead = (unsigned char *)calloc((size_t)(n > 0 ? n : 1), 1);
+            int t = 0, k = 0;
+            for (int i = 0; i < n; i++) {
+                if (c->wclass[i] != cl) continue;
+                pmco_rng_block(seed, cell_id, step, (uint32_t)i, PMCO_SITE_RESAMPLE, 1u + (uint32_t)cl, w);
+                if (pmco_u53(w[0], w[1]) * (double)(n_before - t) < (double)(m_rm - k)) { dead[i] = 1; k++; }
+                t++;
+            }
+            compact_stable(c, dead, n, k);
+            free(dead);
+            *n_removed += k;
+        }
+    }
+    return status;
 }

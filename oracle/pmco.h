@@ -268,6 +268,24 @@ typedef struct {
 int pmco_transport_probs(const pmco_trans_fields *f, const int32_t *n_parts, const double *mag,
                          double *prob_h, double *prob_v, int32_t *n_substeps, int32_t *bad);
 
+/* The refill of a lateral boundary cell after the transport (interface/
+ * wrf_pmc_trans_aero.F90:803-955): a copy of the inner neighbour on outflow
+ * (aero_state_dup_all_particles), aero_state_resample (:976-1098) against the background on
+ * inflow.  See oracle/pmco.c for the law of each. */
+void pmco_boundary_copy(pmco_cell *dst, const pmco_cell *src, int64_t *next_id_dst);
+int pmco_boundary_resample(pmco_cell *c, int throw_away, const pmco_aero_dist *bg, double density,
+                           double create_time, uint64_t seed, uint32_t cell_id, uint32_t step,
+                           int64_t *next_id, int32_t *n_added, int32_t *n_removed);
+
+/* pmco_transport with the reference's open lateral boundaries (real case; interface/
+ * wrf_pmc_trans_aero.F90:497-534, 689-801): cells 1 .. n-2 sample as always, a lateral boundary
+ * cell only sends inwards with min(prob, 1), a corner nothing, and what is sent to a boundary
+ * cell is dropped.  nx, ny >= 3. */
+int pmco_transport_lateral(pmco_cell *cells, int n_cells, int nx, int nz, int ny,
+                           const double *prob_h, const double *prob_v, const double *cell_volume,
+                           uint64_t seed, uint32_t cell_id_base, uint32_t step, int64_t *next_id,
+                           int32_t *n_moved, int32_t *n_arrived);
+
 /* trans_aero_preweight (interface/wrf_pmc_trans_aero.F90:1103-1423) with compute_fluxes
  * (:1428-1627): the number concentration every (cell, class) is expected to hold after the
  * transport -- num_conc_old = particles x magnitude, minus prob x num_conc_old towards every

@@ -63,7 +63,8 @@ enum {
     PMCO_SITE_DILUTE  = 9,  /* scenario: keep/drop one particle (dilution) */
     PMCO_SITE_TRANS   = 10, /* transport: destination and copies of one particle */
     PMCO_SITE_DEPOSIT = 11, /* dry deposition: keep/drop one particle          */
-    PMCO_SITE_SCALE   = 12  /* weight scaling: keep/drop one particle (preweight) */
+    PMCO_SITE_SCALE   = 12, /* weight scaling: keep/drop one particle (preweight) */
+    PMCO_SITE_RESAMPLE = 13 /* boundary resampling: target count of a class; one particle's removal */
 };
 
 /* One 128-bit block of the stream: counter = (cell, step, a, site<<28 | b),

@@ -240,6 +240,30 @@ class Cell:
                                         C.byref(ni), C.byref(no))
         return st, nid.value, ne.value, ni.value, no.value
 
+    def boundary_copy_from(self, src, next_id):
+        """pmco_boundary_copy: this cell becomes a copy of src; returns the new next_id."""
+        nid = C.c_int64(next_id)
+        f = lib().pmco_boundary_copy
+        f.restype = None
+        f.argtypes = [C.POINTER(CellStruct), C.POINTER(CellStruct), _lp]
+        f(C.byref(self.view()), C.byref(src.view()), C.byref(nid))
+        return nid.value
+
+    def boundary_resample(self, throw_away, background, density, create_time, seed, cell_id, step,
+                          next_id):
+        """pmco_boundary_resample; background: list of mode dicts (num_conc = mixing ratio).
+        Returns (status, next_id, n_added, n_removed)."""
+        b, kb = self._dist(background)
+        nid = C.c_int64(next_id)
+        na, nr = C.c_int32(0), C.c_int32(0)
+        f = lib().pmco_boundary_resample
+        f.restype = C.c_int
+        f.argtypes = [C.POINTER(CellStruct), C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_uint64,
+                      C.c_uint32, C.c_uint32, _lp, _ip, _ip]
+        st = f(C.byref(self.view()), int(throw_away), C.cast(C.byref(b), C.c_void_p), density,
+               create_time, seed, cell_id, step, C.byref(nid), C.byref(na), C.byref(nr))
+        return st, nid.value, na.value, nr.value
+
     def seasalt_emissions(self, dt, create_time, seed, cell_id, step, sea_salt_opt, wind_speed,
                           height, i_na, i_cl, mode_class, mode_source, next_id):
         """pmco_seasalt_emissions of this cell; returns (status, next_id, n_emit)."""
@@ -421,9 +445,24 @@ def transport_preweight(cells, nx, nz, ny, prob_h, prob_v, cell_volume, n_ideal,
 
 
 def transport(cells, nx, nz, ny, prob_h, prob_v, cell_volume, seed, cell_id_base, step, next_id,
-              periodic_x=True, periodic_y=True):
-    """pmco_transport over a list of Cell objects (WRF order).  next_id: int64 array, updated."""
+              periodic_x=True, periodic_y=True, lateral=False):
+    """pmco_transport over a list of Cell objects (WRF order).  next_id: int64 array, updated.
+    lateral: pmco_transport_lateral (open lateral boundaries, neither direction periodic)."""
     n = len(cells)
+    if lateral:
+        assert not periodic_x and not periodic_y
+        arr = (CellStruct * n)(*[c.view() for c in cells])
+        ph = np.ascontiguousarray(prob_h, dtype=np.float64)
+        pv = np.ascontiguousarray(prob_v, dtype=np.float64)
+        cv = np.ascontiguousarray(cell_volume, dtype=np.float64)
+        nm, na = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+        f = lib().pmco_transport_lateral
+        f.restype = C.c_int
+        f.argtypes = [C.POINTER(CellStruct), C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
+                      C.c_uint64, C.c_uint32, C.c_uint32, _lp, _ip, _ip]
+        st = f(arr, n, nx, nz, ny, _p(ph, _dp), _p(pv, _dp), _p(cv, _dp), seed, cell_id_base, step,
+               _p(next_id, _lp), _p(nm, _ip), _p(na, _ip))
+        return st, nm, na
     arr = (CellStruct * n)(*[c.view() for c in cells])
     ph = np.ascontiguousarray(prob_h, dtype=np.float64)
     pv = np.ascontiguousarray(prob_v, dtype=np.float64)

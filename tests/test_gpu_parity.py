@@ -1028,6 +1028,77 @@ def test_transport_preweight_parity(wp, oracle, periodic, n_class):
     blk.close()
 
 
+def test_open_lateral_boundaries(wp, oracle):
+    """The reference's real case (wrf_pmc_trans_aero.F90:497-534, 689-955): interior cells sample
+    as always, lateral boundary cells only inwards, what reaches a boundary cell is gone; then the
+    boundary cells are refilled -- a copy of the inner neighbour on outflow, aero_state_resample
+    against the background on inflow (emptied first where the wind has turned) -- all against the
+    oracle, cell by cell, with a coagulation step on the result."""
+    nx, nz, ny, n_class = 5, 3, 4, 2
+    n_cells, n_part = nx * nz * ny, 500
+    blk, cells, info = parity.setup_pair(wp, oracle, n_cells, n_part, 2, n_class, 31, K_BROWN, cap=4096,
+                                         n_source=2)
+    blk.set_transport_lateral(True)
+    r = np.random.RandomState(8)
+    cv = r.uniform(0.8, 1.25, n_cells)
+    mag = info["mag"]
+    bg = [dict(gm_radius=4e-8, gsd_log10=0.25, vol_frac=[1.0, 0.0], wclass=0, source=0),
+          dict(gm_radius=9e-8, gsd_log10=0.2, vol_frac=[0.3, 0.7], wclass=1, source=1),
+          dict(gm_radius=2e-7, gsd_log10=0.15, vol_frac=[0.0, 1.0], wclass=1, source=1)]
+    density = r.uniform(0.9, 1.2, n_cells)
+    # mixing ratios: classes around, well above and well below their present populations
+    bg_conc = np.zeros((n_cells, 3))
+    for c in range(n_cells):
+        tgt = n_part / n_class * np.array([1.0, 1.6, 0.5])[c % 3]
+        bg_conc[c] = [tgt * mag[c, 0] / density[c], 0.7 * tgt * mag[c, 1] / density[c],
+                      0.3 * tgt * mag[c, 1] / density[c]]
+    next_id = np.array([oc.next_id for oc in cells], dtype=np.int64)
+    cell = lambda i, k, j: (j * nz + k) * nx + i
+    with pytest.raises(wp.PmcxError):
+        blk.transport(nx, nz, ny, 0.01, 0.01, cv, 31, 0, True, False)       # needs both non-periodic
+    added = removed = copied = 0
+    for step in range(2):
+        ph = r.uniform(0.0, 0.07, (n_cells, n_class, 4)); pv = r.uniform(0.0, 0.04, (n_cells, n_class, nz))
+        ph[cell(0, 1, 1)] = 1.7                                             # min(prob, 1) at a boundary cell
+        nm, na = blk.transport(nx, nz, ny, ph, pv, cv, 31, step, False, False)
+        st, onm, ona = oracle.transport(cells, nx, nz, ny, ph, pv, cv, 31, 0, step, next_id, False, False,
+                                        lateral=True)
+        assert st == 0 and np.array_equal(nm, onm) and np.array_equal(na, ona), step
+        ok, msg = parity.compare_state(blk, cells)
+        assert ok, f"step {step} after transport: {msg}"
+        assert nm[cell(0, 0, 0)] == 0 and nm[cell(nx - 1, 2, ny - 1)] == 0   # corners send nothing
+        assert na[cell(0, 1, 1)] == 0 and na[cell(2, 0, 0)] == 0             # boundary cells take nothing
+        assert nm[cell(0, 1, 1)] >= int(cells[cell(0, 1, 1)].n_part[0]) * 0   # (everything left it)
+        # the refill
+        u_w = r.normal(0, 1, (ny, nz)); u_e = r.normal(0, 1, (ny, nz))
+        v_s = r.normal(0, 1, (nx, nz)); v_n = r.normal(0, 1, (nx, nz))
+        u_w[1, :] = np.abs(u_w[1, :])                  # inflow on that row of the west side ...
+        u_w_old = u_w.copy(); u_w_old[1, :2] *= -1.0   # ... where the wind has just turned at two levels
+        out = blk.lateral_boundary_conditions(nx, nz, ny, u_w, u_e, v_s, v_n, bg, bg_conc, density, seed=31,
+                                              step=step, u_west_old=u_w_old)
+        for f, t in zip(out["copied_from"], out["copied"]):
+            next_id[t] = cells[t].boundary_copy_from(cells[f], int(next_id[t]))
+        for q, c in enumerate(out["resampled"]):
+            modes = [dict(m, num_conc=bg_conc[c, k]) for k, m in enumerate(bg)]
+            st, nid, ona_, onr_ = cells[c].boundary_resample(out["throw_away"][q], modes, density[c], 0.0, 31,
+                                                             cells[c].cell_id, step, int(next_id[c]))
+            next_id[c] = nid
+            assert st == 0 and (ona_, onr_) == (int(out["n_added"][q]), int(out["n_removed"][q])), (step, c)
+        for c, oc in enumerate(cells):
+            oc.next_id = int(next_id[c])
+        ok, msg = parity.compare_state(blk, cells)
+        assert ok, f"step {step} after the refill: {msg}"
+        assert np.array_equal(blk.get_next_id(), next_id)
+        assert np.array_equal(blk.get_weights(), np.array([oc.mag for oc in cells]))
+        added += int(out["n_added"].sum()); removed += int(out["n_removed"].sum()); copied += len(out["copied"])
+        assert sum(out["throw_away"]) == 2
+        ns_, nc_, s2 = blk.mc_coag(K_BROWN, 600.0, 31, step)
+        for c, oc in enumerate(cells):
+            assert oc.mc_coag(K_BROWN, 600.0, 31, oc.cell_id, step) == (int(s2[c]), int(ns_[c]), int(nc_[c]))
+    assert added > 200 and removed > 200 and copied > 5
+    blk.close()
+
+
 def test_transport_makes_room_among_tombstones(wp, oracle):
     """Arrivals are appended behind the last used slot; with holes closed lazily (compact_den = 2)
     a cell can be short of room while a third of its slots are dead.  pmcx_transport closes the

@@ -775,3 +775,52 @@ def test_transport_preweight_against_numpy(oracle, periodic):
             else:
                 assert cells[c].mag[q] == mag0[c, q]
     assert nr[3] > 0 and nr[17] > 0 and nr.sum() == nr[3] + nr[17]
+
+
+def test_boundary_resample_law(oracle):
+    """pmco_boundary_resample (aero_state_resample, wrf_pmc_trans_aero.F90:976-1098): a class over
+    its Poisson target loses exactly the excess (what stays IS the draw: mean = variance = target);
+    a class short of it by less than a tenth of the target gains nothing (:1066-1079), by more it
+    gains about the shortfall; a thrown-away cell is sampled anew; and the copy of a neighbour."""
+    dens = np.array([1800.0])
+    ve, vs = oracle.make_bin_tables(80, 1e-10, 1e-2)
+    mode = dict(gm_radius=5e-8, gsd_log10=0.2, vol_frac=[1.0], wclass=0, source=0)
+    def cell(n, gid):
+        oc = oracle.Cell(1, 1, 1, 4096, dens, ve, 288.0, 1e5)
+        oc.mag[:] = 2e6
+        oc.generate([dict(mode, frac=1.0)], n, 9, gid, first_id=gid << 32)
+        return oc
+    rho = 1.1
+    conc = lambda target: target * 2e6 / rho
+    left = []
+    for g in range(300):                                    # 800 particles, target 500
+        oc = cell(800, g)
+        ids0 = set(oc.id[:800].tolist())
+        st, nid, na, nr = oc.boundary_resample(0, [dict(mode, num_conc=conc(500.0))], rho, 0.0, 9, g, 0, 1 << 40)
+        n = int(oc.n_part[0])
+        assert st == 0 and na == 0 and nr == 800 - n and set(oc.id[:n].tolist()) <= ids0
+        left.append(n)
+    left = np.array(left)
+    assert abs(left.mean() - 500.0) < 4 * np.sqrt(500.0 / 300) and 0.75 < left.var() / 500.0 < 1.3
+    near, far = [], []
+    for g in range(200):
+        oc = cell(490, g)                                   # target 500: short by ~2 % -> nothing added
+        _, _, na, nr = oc.boundary_resample(0, [dict(mode, num_conc=conc(500.0))], rho, 0.0, 9, g, 1, 1 << 40)
+        near.append((na, nr, int(oc.n_part[0])))
+        oc = cell(300, g)                                   # short by 40 %: about 200 arrive
+        _, _, na, nr = oc.boundary_resample(0, [dict(mode, num_conc=conc(500.0))], rho, 0.0, 9, g, 2, 1 << 40)
+        far.append((na, nr, int(oc.n_part[0])))
+    near, far = np.array(near), np.array(far)
+    # (a draw above 540 is a shortfall of more than a tenth: then, and only then, particles arrive)
+    assert ((near[:, 0] == 0) | (near[:, 0] > 30)).all() and (near[:, 0] == 0).mean() > 0.9
+    assert (far[:, 1] == 0).all() and abs(far[:, 0].mean() - 200.0) < 6.0 and abs(far[:, 2].mean() - 500.0) < 6.0
+    oc = cell(700, 7)
+    st, nid, na, nr = oc.boundary_resample(1, [dict(mode, num_conc=conc(350.0))], rho, 5.0, 9, 7, 3, 1 << 40)
+    n = int(oc.n_part[0])
+    assert nr == 700 and na == n and abs(n - 350) < 5 * np.sqrt(350) and (oc.id[:n] >= 1 << 40).all()
+    assert (oc.lct[:n] == 5.0).all() and nid == (1 << 40) + n
+    src, dst = cell(333, 1), cell(50, 2)
+    src.mag[:] = 7e6
+    nid = dst.boundary_copy_from(src, 1 << 41)
+    assert int(dst.n_part[0]) == 333 and nid == (1 << 41) + 333 and dst.mag[0] == 7e6
+    assert np.array_equal(dst.vtot[:333], src.vtot[:333]) and np.array_equal(dst.id[:333], (1 << 41) + np.arange(333))

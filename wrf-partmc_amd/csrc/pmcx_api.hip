@@ -747,6 +747,13 @@ int pmcx_invalidate_sort(pmcx_ctx *ctx)
     return PMCX_OK;
 }
 
+int pmcx_set_transport_lateral(pmcx_ctx *ctx, int32_t on)
+{
+    if (!ctx) return PMCX_EINVAL;
+    ctx->st.trans_lateral = on ? 1 : 0;
+    return PMCX_OK;
+}
+
 int pmcx_set_sampler_variant(pmcx_ctx *ctx, int32_t lanes, int32_t wavefronts_per_group, int32_t stamps)
 {
     if (!ctx) return PMCX_EINVAL;
@@ -1091,6 +1098,9 @@ int pmcx_transport(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int32_t pe
     const pmcx_config &cf = ctx->cfg;
     if (nx < 1 || nz < 1 || ny < 1 || nz > 128 || (int64_t)nx * nz * ny != cf.n_cells)
         return fail(ctx, PMCX_EINVAL, "pmcx_transport: nx*nz*ny must equal n_cells (nz <= 128)");
+    if (ctx->st.trans_lateral && (periodic_x || periodic_y || nx < 3 || ny < 3))
+        return fail(ctx, PMCX_EINVAL, "pmcx_transport: open lateral boundaries (pmcx_set_transport_lateral) "
+                                      "need a non-periodic block of at least 3 x 3 columns");
     if (transport_lds_bytes(ctx->st, nz) > 160 * 1024)
         return fail(ctx, PMCX_EINVAL, "pmcx_transport: n_class x (4+nz) destination tables exceed LDS");
     HIP_TRY(ctx, hipSetDevice(cf.device));
@@ -1191,6 +1201,96 @@ int pmcx_transport_probs(pmcx_ctx *ctx, const pmcx_trans_fields *f, double *prob
     if (n_substeps) HIP_TRY(ctx, hipMemcpyAsync(n_substeps, a.n_substeps, sizeof(int32_t) * col, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->probs_nx = nx; ctx->probs_ny = ny;
+    return PMCX_OK;
+}
+
+int pmcx_boundary_copy(pmcx_ctx *ctx, int32_t n_pairs, const int32_t *from_cell, const int32_t *to_cell)
+{
+    if (!ctx || n_pairs < 0 || (n_pairs > 0 && (!from_cell || !to_cell)))
+        return fail(ctx, PMCX_EINVAL, "pmcx_boundary_copy: bad argument");
+    if (n_pairs == 0) return PMCX_OK;
+    const int nc = ctx->cfg.n_cells;
+    std::vector<unsigned char> is_to((size_t)nc, 0);
+    for (int q = 0; q < n_pairs; q++) {
+        if (from_cell[q] < 0 || from_cell[q] >= nc || to_cell[q] < 0 || to_cell[q] >= nc || from_cell[q] == to_cell[q])
+            return fail(ctx, PMCX_EINVAL, "pmcx_boundary_copy: pair %d names a cell outside the block (or itself)", q);
+        if (is_to[(size_t)to_cell[q]]++) return fail(ctx, PMCX_EINVAL, "pmcx_boundary_copy: cell %d is filled twice", to_cell[q]);
+    }
+    for (int q = 0; q < n_pairs; q++)
+        if (is_to[(size_t)from_cell[q]])
+            return fail(ctx, PMCX_EINVAL, "pmcx_boundary_copy: cell %d is both copied from and filled", from_cell[q]);
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    int rc = ensure_stage(ctx, sizeof(int32_t) * 2 * (size_t)n_pairs + 64);
+    if (rc) return rc;
+    int32_t *d_from = (int32_t *)ctx->stage, *d_to = d_from + n_pairs;
+    HIP_TRY(ctx, hipMemcpyAsync(d_from, from_cell, sizeof(int32_t) * n_pairs, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_to, to_cell, sizeof(int32_t) * n_pairs, hipMemcpyHostToDevice, ctx->stream));
+    {
+        ProfScope ps(ctx, "boundary");
+        HIP_TRY(ctx, launch_boundary_copy(ctx->st, n_pairs, d_from, d_to, ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->bounds_dirty = true;
+    return PMCX_OK;
+}
+
+int pmcx_boundary_resample(pmcx_ctx *ctx, int32_t n_list, const int32_t *cell, const int32_t *throw_away,
+                           const pmcx_aero_dist *background, const double *density, double create_time,
+                           uint64_t seed, uint32_t step, int32_t *n_added, int32_t *n_removed)
+{
+    if (!ctx || n_list < 0 || (n_list > 0 && (!cell || !background || !density)))
+        return fail(ctx, PMCX_EINVAL, "pmcx_boundary_resample: bad argument");
+    if (!ctx->aero_data_set) return fail(ctx, PMCX_ESTATE, "pmcx_set_aero_data must come first");
+    if (n_list == 0) return PMCX_OK;
+    const size_t nc = (size_t)ctx->cfg.n_cells;
+    const int M = background->n_mode;
+    if (M < 1 || M > 64 || !background->num_conc) return fail(ctx, PMCX_EINVAL, "pmcx_boundary_resample: bad background");
+    // per-cell arrays over the whole block (the kernel's wavefronts leave cells without action alone)
+    std::vector<int32_t> act(nc, 0), pos(nc, -1);
+    std::vector<double> conc(nc * (size_t)M, 0.0), dens(nc, 0.0);
+    for (int q = 0; q < n_list; q++) {
+        const int c = cell[q];
+        if (c < 0 || (size_t)c >= nc || act[(size_t)c])
+            return fail(ctx, PMCX_EINVAL, "pmcx_boundary_resample: entry %d names a cell outside the block or twice", q);
+        if (!(density[q] > 0)) return fail(ctx, PMCX_EINVAL, "pmcx_boundary_resample: density must be positive");
+        act[(size_t)c] = (throw_away && throw_away[q]) ? 2 : 1;
+        pos[(size_t)c] = q;
+        dens[(size_t)c] = density[q];
+        for (int m = 0; m < M; m++) conc[(size_t)c * M + m] = background->num_conc[(size_t)q * M + m];
+    }
+    pmcx_aero_dist d = *background;
+    d.num_conc = conc.data();
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    std::vector<void *> tmp;
+    auto cleanup = [&]() { for (void *p : tmp) (void)hipFree(p); };
+    GenSpecDev gb{};
+    double *cbg = nullptr, *d_dens = nullptr;
+    int32_t *d_i = nullptr;
+    int rc = upload_dist(ctx, &d, tmp, gb, cbg);
+    if (rc) { cleanup(); return rc; }
+    hipError_t e = hipMalloc((void **)&d_dens, sizeof(double) * nc);
+    if (e == hipSuccess) tmp.push_back(d_dens);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_i, sizeof(int32_t) * 3 * nc);
+    if (e == hipSuccess) tmp.push_back(d_i);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_dens, dens.data(), sizeof(double) * nc, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_i, act.data(), sizeof(int32_t) * nc, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_i + nc, 0, sizeof(int32_t) * 2 * nc, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->st.status, 0, sizeof(int32_t) * nc, ctx->stream);
+    if (e == hipSuccess) {
+        ProfScope ps(ctx, "boundary");
+        e = launch_boundary_resample(ctx->st, d_i, gb, cbg, d_dens, create_time, seed, step, d_i + nc,
+                                     d_i + 2 * nc, ctx->stream);
+    }
+    std::vector<int32_t> h_cnt(2 * nc);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_cnt.data(), d_i + nc, sizeof(int32_t) * 2 * nc, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(ctx, PMCX_EDEVICE, "pmcx_boundary_resample: %s", hipGetErrorString(e));
+    for (int q = 0; q < n_list; q++) {
+        if (n_added) n_added[q] = h_cnt[(size_t)cell[q]];
+        if (n_removed) n_removed[q] = h_cnt[nc + (size_t)cell[q]];
+    }
+    HIP_TRY(ctx, invalidate_sort(ctx, 0, ctx->cfg.n_cells, false));
     return PMCX_OK;
 }
 
@@ -1304,6 +1404,9 @@ int pmcx_transport_begin(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int3
                                       "(two ghost rows), nz <= 128");
     if (transport_lds_bytes(ctx->st, nz) > 160 * 1024)
         return fail(ctx, PMCX_EINVAL, "pmcx_transport_begin: destination tables exceed LDS");
+    if (ctx->st.trans_lateral)
+        return fail(ctx, PMCX_EINVAL, "pmcx_transport_begin: open lateral boundaries are built for one block "
+                                      "of cells only (pmcx_transport)");
     HIP_TRY(ctx, hipSetDevice(cf.device));
     int rc = transport_buffers(ctx);
     if (rc) return rc;

@@ -47,7 +47,8 @@ enum : uint32_t {
     SITE_DILUTE = 9,
     SITE_TRANS = 10,
     SITE_DEPOSIT = 11,
-    SITE_SCALE = 12
+    SITE_SCALE = 12,
+    SITE_RESAMPLE = 13
 };
 
 // counter = (cell, step, a, site<<28 | b); key = seed

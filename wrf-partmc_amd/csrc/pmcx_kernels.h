@@ -85,6 +85,7 @@ struct DeviceState {
     int32_t *key_valid;  // [n_cells]
     uint32_t *evlog;     // [n_cells][EVLOG_CAP]
     int32_t *n_log;      // [n_cells]
+    int32_t trans_lateral; // pmcx_set_transport_lateral: the reference's open lateral boundaries
     // pmcx_set_sampler_variant (diagnostic): 0 = the library's own choice
     int32_t force_lanes, force_wpb, force_stamps;
     uint16_t *seq_ovf;   // [n_cells][2 G + 2 max_appends] lane-per-cell sampler: entries past a group's room
@@ -178,6 +179,12 @@ struct TransFieldsArgs {
     double *prob_h, *prob_v;
     int32_t *n_substeps, *bad, *n_class_part;
 };
+hipError_t launch_boundary_copy(const DeviceState &st, int n_pairs, const int32_t *from, const int32_t *to,
+                                hipStream_t s);
+hipError_t launch_boundary_resample(const DeviceState &st, const int32_t *action, const GenSpecDev &bg,
+                                    const double *bg_conc, const double *density, double create_time,
+                                    uint64_t seed, uint32_t step, int32_t *n_added, int32_t *n_removed,
+                                    hipStream_t s);
 hipError_t launch_transport_preweight(const DeviceState &st, int nx, int nz, int ny, int ideal,
                                       const double *prob_h, const double *prob_v,
                                       const double *cell_volume, double *old, double *expect,

@@ -2482,9 +2482,10 @@ struct AeroDistDev {
 };
 
 // appends Poisson(num_conc*factor/magnitude) particles per mode; returns how many
+// means != nullptr: the Poisson mean of every mode is given (negative: the mode is skipped)
 __device__ int add_dist_sample(const DeviceState &st, int c, const AeroDistDev &d, double factor,
                                uint32_t kind, double create_time, uint64_t seed, uint32_t step,
-                               int &status, int lane)
+                               int &status, int lane, const double *means = nullptr)
 {
     const int64_t cb = (int64_t)c * st.cap;
     const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
@@ -2493,7 +2494,8 @@ __device__ int add_dist_sample(const DeviceState &st, int c, const AeroDistDev &
     for (int m = 0; m < d.n_mode; m++) {
         uint32_t w[4];
         const int cl = d.mode_class[m];
-        const double mean = d.num_conc[(int64_t)c * d.n_mode + m] * factor / mag[cl];
+        const double mean = means ? means[m] : d.num_conc[(int64_t)c * d.n_mode + m] * factor / mag[cl];
+        if (means && mean < 0.0) continue; // (uniform over the wavefront)
         rng_block(seed, cell_id, step, (kind << 8) | (uint32_t)m, SITE_EMIT_N, 0, w);
         int n = poisson(mean, u53(w[0], w[1]));
         int n_hi = st.n_hi[c];
@@ -2799,6 +2801,17 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
         double *p = t_p + cl * ND;
         int *dc = t_tmpd + cl * ND, n = 0;
         const int di[4] = {-1, 1, 0, 0}, dj[4] = {0, 0, -1, 1};
+        const bool bx = (i == 0 || i == nx - 1), by = (j == 0 || j == ny - 1);
+        if (st.trans_lateral && (bx || by)) {
+            // open lateral boundaries (wrf_pmc_trans_aero.F90:689-768): a boundary cell only sends
+            // inwards, with min(prob, 1); a corner sends nothing
+            if (!(bx && by)) {
+                const int d = i == 0 ? 1 : i == nx - 1 ? 0 : j == 0 ? 3 : 2;
+                double pr = tg.prob_h[((int64_t)c * C + cl) * 4 + d];
+                if (pr > 1.0) pr = 1.0;
+                if (pr > 0.0) { p[0] = pr; dc[0] = ((j + dj[d]) * nz + k) * nx + (i + di[d]); n = 1; }
+            }
+        } else {
         for (int d = 0; d < 4; d++) {
             int ii = i + di[d], jj = j + dj[d];
             if (ii < 0 || ii >= nx) { if (!tg.periodic_x) continue; ii = (ii + nx) % nx; }
@@ -2810,6 +2823,7 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
             if (kk == k) continue;
             const double pr = tg.prob_v[((int64_t)c * C + cl) * nz + kk];
             if (pr > 0.0) { p[n] = pr; dc[n] = (j * nz + kk) * nx + i; n++; }
+        }
         }
         // stable ascending order by probability, then thresholds in that order
         double rem = 1.0, cum = 0.0;
@@ -2905,7 +2919,12 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
     // the arrivals each destination has to expect: one atomic per destination, not per mover
     wave_sync();
     for (int x = lane; x < C * ND; x += 64)
-        if (x % ND < t_n[x / ND] && t_cnt[x] > 0) atomicAdd(&tg.n_exp[t_dest[x]], t_cnt[x]);
+        if (x % ND < t_n[x / ND] && t_cnt[x] > 0) {
+            const int dcell = t_dest[x], di_ = dcell % nx, dj_ = dcell / (nx * nz);
+            // (what is sent to an open lateral boundary cell leaves the domain: nobody gathers it)
+            if (st.trans_lateral && (di_ == 0 || di_ == nx - 1 || dj_ == 0 || dj_ == ny - 1)) continue;
+            atomicAdd(&tg.n_exp[dcell], t_cnt[x]);
+        }
     for (int d = 32; d >= 1; d >>= 1) bits |= __shfl_xor(bits, d, 64);
     if (lane == 0) { tg.n_out[c] = (int32_t)n_out; tg.dest_mask[c] = bits; }
 }
@@ -3180,6 +3199,162 @@ __global__ __launch_bounds__(256) void k_trans_probs(DeviceState st, TransFields
     }
 }
 
+// The refill of the lateral boundary cells after the transport
+// (interface/wrf_pmc_trans_aero.F90:803-955), one wavefront per cell.
+//   k_boundary_copy      outflow: the boundary cell becomes a copy of its inner neighbour
+//                        (aero_state_dup_all_particles): same particles, same order, new ids, same
+//                        weights
+//   k_boundary_resample  inflow: aero_state_resample (:976-1098) against the background -- emptied
+//                        and sampled anew, or per class brought to a Poisson target count: short of
+//                        it, new particles from the class's modes; over it, a uniformly random
+//                        subset of exactly the excess leaves (selection sampling in rank order: the
+//                        decisions are serial in the particles, taken lane by lane from uniforms
+//                        the wavefront draws 64 at a time)
+__global__ __launch_bounds__(64) void k_boundary_copy(DeviceState st, int n_pairs, const int32_t *from,
+                                                      const int32_t *to)
+{
+    const int lane = threadIdx.x, q = blockIdx.x;
+    if (q >= n_pairs) return;
+    const int cs = from[q], cd = to[q];
+    const int64_t sb = (int64_t)cs * st.cap, db = (int64_t)cd * st.cap;
+    const int S = st.n_spec, NS = st.n_source, C = st.n_class;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const int n_hi = st.n_hi[cs];
+    const int64_t nid = st.next_id[cd];
+    int base = 0;
+    for (int i0 = 0; i0 < n_hi; i0 += 64) {
+        const int i = i0 + lane;
+        const int wc = i < n_hi ? live_class(st, sb, i) : -1;
+        const uint64_t m = __ballot(wc >= 0);
+        if (wc >= 0) {
+            const int dst = base + __popcll(m & lt);
+            for (int sp = 0; sp < S; sp++) st.vol[(db + dst) * S + sp] = spec_vol(st, sb, sp, i);
+            for (int sp = 1; sp < NS; sp++) norig(st, db, sp, dst) = norig(st, sb, sp, i);
+            st.hot[db + dst] = st.hot[sb + i];
+            Cold cv = st.cold[sb + i];
+            cv.id = nid + dst;
+            st.cold[db + dst] = cv;
+            st.wclass[db + dst] = wc;
+        }
+        base += __popcll(m);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wave_sync();
+    if (lane == 0) {
+        st.n_hi[cd] = base; st.n_part[cd] = base;
+        st.next_id[cd] = nid + base;
+        st.sort_valid[cd] = 0; st.key_valid[cd] = 0; st.n_log[cd] = 0;
+    }
+    for (int cl = lane; cl < C; cl += 64) st.mag[(int64_t)cd * C + cl] = st.mag[(int64_t)cs * C + cl];
+}
+
+__global__ __launch_bounds__(64) void k_boundary_resample(DeviceState st, const int32_t *action,
+                                                          AeroDistDev bg, const double *density,
+                                                          double create_time, uint64_t seed, uint32_t step,
+                                                          int32_t *n_added, int32_t *n_removed)
+{
+    __shared__ double s_means[64];
+    const int lane = threadIdx.x, c = blockIdx.x;
+    const int act = action[c];
+    if (act == 0) return;
+    const int64_t cb = (int64_t)c * st.cap;
+    const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const int C = st.n_class;
+    const double dens = density[c];
+    int status = 0, na = 0, nr = 0;
+    apply_event_log(st, c, lane);
+    if (act == 2) { // aero_state_zero, then sampled anew
+        nr = st.n_part[c];
+        wave_sync();
+        if (lane == 0) { st.n_hi[c] = 0; st.n_part[c] = 0; st.sort_valid[c] = 0; st.key_valid[c] = 0; st.n_log[c] = 0; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __threadfence_block();
+        wave_sync();
+        na = add_dist_sample(st, c, bg, dens, 3u, create_time, seed, step, status, lane);
+    } else {
+        for (int cl = 0; cl < C; cl++) {
+            const int n_hi = st.n_hi[c];
+            int n_before = st.n_part[c];
+            if (C > 1) {
+                uint32_t cnt = 0;
+                for (int i = lane; i < n_hi; i += 64) cnt += (live_class_c(st, cb, i) == cl);
+                n_before = (int)wave_sum_u64(cnt);
+            }
+            double total = 0.0;
+            for (int m = 0; m < bg.n_mode; m++)
+                if (bg.mode_class[m] == cl) total = total + bg.num_conc[(int64_t)c * bg.n_mode + m] * dens;
+            const double mag = st.mag[(int64_t)c * C + cl];
+            const double n_parts_new = total / mag;
+            uint32_t w[4];
+            rng_block(seed, cell_id, step, (uint32_t)cl, SITE_RESAMPLE, 0, w);
+            const int n_samp = poisson(n_parts_new, u53(w[0], w[1]));
+            const int n_to_add = n_samp - n_before;
+            if (n_to_add > 0) {
+                wave_sync();
+                if (lane < bg.n_mode) {
+                    double mean = -1.0;
+                    if (bg.mode_class[lane] == cl) {
+                        const double cm = bg.num_conc[(int64_t)c * bg.n_mode + lane];
+                        const double share = (dens * cm) / total;
+                        const double n_samp_avg = share * (double)n_to_add;
+                        const double threshold = (dens * cm / n_samp_avg) * .1;
+                        if (mag > threshold) mean = n_samp_avg;
+                    }
+                    s_means[lane] = mean;
+                }
+                lds_sync();
+                na += add_dist_sample(st, c, bg, dens, 3u, create_time, seed, step, status, lane, s_means);
+            } else {
+                const int m_rm = -n_to_add < n_before ? -n_to_add : n_before;
+                int t0 = 0, k = 0; // class members seen, removed so far (uniform)
+                uint32_t rank0 = 0;
+                for (int i0 = 0; i0 < n_hi && k < m_rm; i0 += 64) {
+                    const int i = i0 + lane;
+                    const int wc = i < n_hi ? live_class_c(st, cb, i) : -1;
+                    const uint64_t mlive = __ballot(wc >= 0);
+                    const uint64_t mcls = __ballot(wc == cl);
+                    double u = 0.0;
+                    if (wc == cl) {
+                        rng_block(seed, cell_id, step, rank0 + (uint32_t)__popcll(mlive & lt), SITE_RESAMPLE,
+                                  1u + (uint32_t)cl, w);
+                        u = u53(w[0], w[1]);
+                    }
+                    // the decisions, in rank order (each depends on how many have gone before)
+                    uint64_t msel = 0, rest = mcls;
+                    int t = t0;
+                    while (rest) {
+                        const int l = __builtin_ctzll(rest);
+                        rest &= rest - 1;
+                        const double ul = u2d(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(d2u(u) >> 32), l) << 32) |
+                                              (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)d2u(u), l));
+                        if (ul * (double)(n_before - t) < (double)(m_rm - k)) { msel |= 1ull << l; k++; }
+                        t++;
+                    }
+                    t0 = t;
+                    if ((msel >> lane) & 1ull) mark_dead(st, cb, i);
+                    rank0 += (uint32_t)__popcll(mlive);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                wave_sync();
+                if (lane == 0 && k > 0) { st.n_part[c] = st.n_part[c] - k; st.sort_valid[c] = 0; }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __threadfence_block();
+                wave_sync();
+                nr += k;
+            }
+        }
+        const int hi = st.n_hi[c], live = st.n_part[c];
+        if ((hi - live) * st.compact_den > hi) compact_wave(st, c, lane);
+    }
+    if (lane == 0) {
+        st.sort_valid[c] = 0;
+        if (n_added) n_added[c] = na;
+        if (n_removed) n_removed[c] = nr;
+        if (status) atomicOr(&st.status[c], status);
+    }
+}
+
 // trans_aero_preweight (interface/wrf_pmc_trans_aero.F90:1103-1423): the number concentration
 // every (cell, class) is expected to hold after the transport, and a larger weight where that
 // is more than twice the ideal particle count.
@@ -3364,6 +3539,10 @@ __global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid t
     const int lane = threadIdx.x, c = tg.c_first + blockIdx.x;
     const int nx = tg.nx, nz = tg.nz, ny = tg.ny;
     const int i = c % nx, k = (c / nx) % nz, j = c / (nx * nz);
+    if (st.trans_lateral && (i == 0 || i == nx - 1 || j == 0 || j == ny - 1)) {
+        if (lane == 0) tg.n_arr[c] = 0; // an open lateral boundary cell takes nothing in (:775-801)
+        return;
+    }
     const int64_t cb = (int64_t)c * st.cap;
     const int S = st.n_spec, NS = st.n_source;
     const int n_hi0 = st.n_hi[c];
@@ -4182,6 +4361,23 @@ hipError_t launch_transport(const DeviceState &st, int nx, int nz, int ny, int p
     if (e != hipSuccess) return e;
     return launch_transport_finish(st, nx, nz, ny, periodic_x, periodic_y, cell_volume, outbox, n_out,
                                    n_arr, n_exp, dest_mask, 0, ny, s);
+}
+hipError_t launch_boundary_copy(const DeviceState &st, int n_pairs, const int32_t *from, const int32_t *to,
+                                hipStream_t s)
+{
+    if (n_pairs > 0) hipLaunchKernelGGL(k_boundary_copy, dim3(n_pairs), dim3(64), 0, s, st, n_pairs, from, to);
+    return hipGetLastError();
+}
+hipError_t launch_boundary_resample(const DeviceState &st, const int32_t *action, const GenSpecDev &bg,
+                                    const double *bg_conc, const double *density, double create_time,
+                                    uint64_t seed, uint32_t step, int32_t *n_added, int32_t *n_removed,
+                                    hipStream_t s)
+{
+    const AeroDistDev b{bg.n_mode, bg_conc, bg.ln_gm_radius, bg.ln_gsd, bg.vol_frac, bg.mode_class,
+                        bg.mode_source};
+    hipLaunchKernelGGL(k_boundary_resample, dim3(st.n_cells), dim3(64), 0, s, st, action, b, density,
+                       create_time, seed, step, n_added, n_removed);
+    return hipGetLastError();
 }
 hipError_t launch_transport_preweight(const DeviceState &st, int nx, int nz, int ny, int ideal,
                                       const double *prob_h, const double *prob_v,

@@ -41,6 +41,7 @@ EXPORTED_SYMBOLS = [
     "pmcx_get_gas_state", "pmcx_set_gas_scenario", "pmcx_scenario_update_gas_state",
     "pmcx_invalidate_lists", "pmcx_get_keys", "pmcx_seasalt_emissions",
     "pmcx_transport_probs", "pmcx_set_sampler_variant", "pmcx_transport_preweight",
+    "pmcx_set_transport_lateral", "pmcx_boundary_copy", "pmcx_boundary_resample",
 ]
 
 
@@ -162,6 +163,11 @@ def load_library():
     L.pmcx_dry_deposition.argtypes = [C.c_void_p, C.c_double, C.c_uint64, C.c_uint32] + [C.c_void_p] * 9
     L.pmcx_timestep.argtypes = [C.c_void_p, C.POINTER(PmcxStepFlags)]
     L.pmcx_set_sampler_variant.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+    L.pmcx_set_transport_lateral.argtypes = [C.c_void_p, C.c_int32]
+    L.pmcx_boundary_copy.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    L.pmcx_boundary_resample.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_double, C.c_uint64, C.c_uint32, C.c_void_p,
+                                         C.c_void_p]
     L.pmcx_transport_preweight.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                            C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                            C.c_uint32, C.c_void_p, C.c_void_p]
@@ -631,6 +637,87 @@ class CellBlock:
         self._ck(self._lib.pmcx_transport_probs(self._h, C.byref(tf), _ptr(ph), _ptr(pv), _ptr(ns),
                                                 _ptr(bad), _ptr(ncp)))
         return ph, pv, ns, bad, ncp
+
+    # -- open lateral boundaries (wrf_pmc_trans_aero.F90:497-534, 689-955) -----------------
+    def set_transport_lateral(self, on=True):
+        """transport() then treats the block's lateral boundary cells as the reference's real
+        case does: they only send inwards, corners nothing, what reaches them leaves the domain."""
+        self._ck(self._lib.pmcx_set_transport_lateral(self._h, int(bool(on))))
+
+    def boundary_copy(self, from_cells, to_cells):
+        """Outflow: every to_cell becomes a copy of its from_cell (aero_state_dup_all_particles)."""
+        f = np.ascontiguousarray(from_cells, dtype=np.int32)
+        t = np.ascontiguousarray(to_cells, dtype=np.int32)
+        assert f.shape == t.shape
+        self._ck(self._lib.pmcx_boundary_copy(self._h, len(f), _ptr(f), _ptr(t)))
+
+    def boundary_resample(self, cells, throw_away, background, background_conc, density,
+                          create_time=0.0, seed=0, step=0):
+        """Inflow: aero_state_resample (wrf_pmc_trans_aero.F90:976-1098) of the listed cells
+        against the background (modes: list of dicts as for scenario_update_aero_state;
+        background_conc [n_list][n_mode] number mixing ratios; density [n_list]).
+        Returns (n_added, n_removed) per listed cell."""
+        cl = np.ascontiguousarray(cells, dtype=np.int32)
+        n = len(cl)
+        ta = np.ascontiguousarray(np.broadcast_to(np.asarray(throw_away, dtype=np.int32), (n,)))
+        keep = dict(
+            nc=np.ascontiguousarray(np.broadcast_to(_f64(background_conc), (n, len(background)))),
+            gm=_f64([m["gm_radius"] for m in background]), gs=_f64([m["gsd_log10"] for m in background]),
+            vf=_f64([m["vol_frac"] for m in background]),
+            mc=np.array([m.get("wclass", 0) for m in background], dtype=np.int32),
+            ms=np.array([m.get("source", 0) for m in background], dtype=np.int32))
+        d = PmcxAeroDist(len(background), keep["nc"].ctypes.data, keep["gm"].ctypes.data,
+                         keep["gs"].ctypes.data, keep["vf"].ctypes.data, keep["mc"].ctypes.data,
+                         keep["ms"].ctypes.data)
+        dn = np.ascontiguousarray(np.broadcast_to(_f64(density), (n,)))
+        na, nr = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+        self._ck(self._lib.pmcx_boundary_resample(self._h, n, _ptr(cl), _ptr(ta), C.addressof(d), _ptr(dn),
+                                                  create_time, seed, step, _ptr(na), _ptr(nr)))
+        return na, nr
+
+    def lateral_boundary_conditions(self, nx, nz, ny, u_west, u_east, v_south, v_north, background,
+                                    background_conc, density, seed=0, step=0, u_west_old=None,
+                                    u_east_old=None, v_south_old=None, v_north_old=None,
+                                    change_boundary_conditions=False):
+        """The refill of the lateral boundary cells after the transport, as
+        wrf_pmc_trans_aero.F90:803-955 orders it: on the west side (i = 0, rows 1 .. ny-2) a cell
+        whose u (grid%u_2 at its outer face; u_west [ny][nz]) is negative copies its inner
+        neighbour, otherwise it is resampled against the background -- emptied first when the
+        wind has turned since the last step (u * u_old < 0) or the background has moved to its
+        next time level; east (u_east: the face behind i = nx-1, outflow when positive), south
+        (v_south [nx][nz], columns 1 .. nx-2) and north alike.  background_conc, density: per cell
+        of the block ([n_cells][n_mode], [n_cells]); only the boundary cells' rows are used.
+        Returns dict(copied=[cells], resampled=[cells], n_added, n_removed)."""
+        cell = lambda i, k, j: (j * nz + k) * nx + i
+        u_w, u_e = np.asarray(u_west, float), np.asarray(u_east, float)
+        v_s, v_n = np.asarray(v_south, float), np.asarray(v_north, float)
+        old = [None if a is None else np.asarray(a, float)
+               for a in (u_west_old, u_east_old, v_south_old, v_north_old)]
+        frm, to, res, thr = [], [], [], []
+        def side(cells_inner, vel, vel_old, outflow_negative):
+            for (c, c_in, idx) in cells_inner:
+                v = vel[idx]
+                if (v < 0.0) if outflow_negative else (v > 0.0):
+                    frm.append(c_in); to.append(c)
+                else:
+                    turned = vel_old is not None and v * vel_old[idx] < 0.0
+                    res.append(c); thr.append(int(turned or change_boundary_conditions))
+        side([(cell(0, k, j), cell(1, k, j), (j, k)) for j in range(1, ny - 1) for k in range(nz)],
+             u_w, old[0], True)
+        side([(cell(nx - 1, k, j), cell(nx - 2, k, j), (j, k)) for j in range(1, ny - 1) for k in range(nz)],
+             u_e, old[1], False)
+        side([(cell(i, k, 0), cell(i, k, 1), (i, k)) for i in range(1, nx - 1) for k in range(nz)],
+             v_s, old[2], True)
+        side([(cell(i, k, ny - 1), cell(i, k, ny - 2), (i, k)) for i in range(1, nx - 1) for k in range(nz)],
+             v_n, old[3], False)
+        if frm:
+            self.boundary_copy(frm, to)
+        na = nr = np.zeros(0, dtype=np.int32)
+        if res:
+            bc = np.broadcast_to(_f64(background_conc), (self.cfg.n_cells, len(background)))
+            dn = np.broadcast_to(_f64(density), (self.cfg.n_cells,))
+            na, nr = self.boundary_resample(res, thr, background, bc[res], dn[res], 0.0, seed, step)
+        return dict(copied=to, copied_from=frm, resampled=res, throw_away=thr, n_added=na, n_removed=nr)
 
     def transport_preweight(self, nx, nz, ny, prob_h, prob_v, cell_volume, seed=0, step=0,
                             periodic_x=True, periodic_y=True):
