@@ -31,6 +31,9 @@ ap.add_argument("--particles", type=int, default=10000)
 ap.add_argument("--steps", type=int, default=6)
 ap.add_argument("--dt", type=float, default=20.0)          # WRF step, s
 ap.add_argument("--chem-dt", type=float, default=60.0)     # registry.partmc:24
+ap.add_argument("--given-probs", action="store_true",
+                help="hand the transport fixed probabilities instead of building them from WRF-shaped "
+                     "fields on the device every step (transport_probs + transport_preweight)")
 a = ap.parse_args()
 
 nx, ny, nz, N = a.nx, a.ny, a.levels, a.particles
@@ -69,20 +72,39 @@ rrho = 1.0 / (pres[k] / (287.0 * temp[k]))
 emission = [dict(num_conc=None, gm_radius=3e-8, gsd_log10=0.2, vol_frac=[1.0], wclass=0, source=1)]
 emit_rate = np.where(surface[:, None] == 1, 2.0e5, 0.0)                   # m^-3 s^-1 at the ground
 
-names = ("transport", "dry_deposition", "scenario", "kernel_bounds", "bin_sort", "coag_sample", "compact",
+fields = None
+if not a.given_probs:
+    # WRF-shaped single-precision fields (tests/trans_fields.py); fluxes scaled to the cells'
+    # mixing ratios so that a few particles in a thousand leave through a face per step
+    from tests import trans_fields
+    fields = trans_fields.make_fields(nx, nz, ny, 1, seed=3, k_scale=20.0, flux_scale=0.004 * 1e10)
+
+names = ("transport_probs", "transport_preweight", "transport", "dry_deposition", "scenario", "kernel_bounds", "bin_sort", "coag_sample", "compact",
          "rebalance", "diagnostics")
 blk.profile_enable(True)
 blk.profile_reset()
 t0 = time.perf_counter()
 elapsed = 0.0
 moved = deposited = emitted = events = 0
-host = {"transport": 0.0, "dry_deposition": 0.0, "scenario": 0.0, "mc_coag": 0.0, "rebalance": 0.0}
+host = {"transport_probs": 0.0, "transport_preweight": 0.0, "transport": 0.0, "dry_deposition": 0.0, "scenario": 0.0, "mc_coag": 0.0, "rebalance": 0.0}
 step_wall = []
 for step in range(a.steps):
     ts = time.perf_counter()
-    nm, na = blk.transport(nx, nz, ny, prob_h, prob_v, cell_volume, seed=0, step=step)
-    host["transport"] += time.perf_counter() - ts
-    assert nm.sum() == na.sum(), "transport lost particles (capacity)"   # equal weights: 1 copy each
+    if fields is not None:
+        # wrf_pmc_trans_driver: probabilities from the fields and the populations, preweight, sampling
+        blk.transport_probs(nx, nz, ny, a.dt, 4000.0, 4000.0, fields, download=False)
+        host["transport_probs"] += time.perf_counter() - ts
+        tp = time.perf_counter()
+        blk.transport_preweight(nx, nz, ny, None, None, cell_volume, seed=0, step=step)
+        host["transport_preweight"] += time.perf_counter() - tp
+        tp = time.perf_counter()
+        nm, na = blk.transport(nx, nz, ny, None, None, cell_volume, seed=0, step=step)
+        host["transport"] += time.perf_counter() - tp
+    else:
+        nm, na = blk.transport(nx, nz, ny, prob_h, prob_v, cell_volume, seed=0, step=step)
+        host["transport"] += time.perf_counter() - ts
+    if fields is None:
+        assert nm.sum() == na.sum(), "transport lost particles (capacity)"   # equal weights: 1 copy each
     t1 = time.perf_counter()
     nr, bad = blk.dry_deposition(a.dt, ra, ustar, alpha, big_a, height, rrho, seed=0, step=step,
                                  surface=surface)
