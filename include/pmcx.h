@@ -315,12 +315,33 @@ int pmcx_boundary_resample(pmcx_ctx *ctx, int32_t n_list, const int32_t *cell, c
  * case; otherwise lateral boundary cells only send inwards and corners nothing.  prob_h ==
  * prob_v == NULL: the probabilities pmcx_transport_probs built (they stay for the transport).
  * Outputs (may be NULL): expected_num_conc [n_cells][n_class], n_removed [n_cells].
- * One block of cells (the exchange of ghost sums between ranks is not part of this call).
+ * One block of cells (across ranks: pmcx_transport_preweight_begin / _finish below).
  * Synchronises. */
 int pmcx_transport_preweight(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int32_t periodic_x,
                              int32_t periodic_y, const double *prob_h, const double *prob_v,
                              const double *cell_volume, uint64_t seed, uint32_t step,
                              double *expected_num_conc, int32_t *n_removed);
+
+/* pmcx_transport_preweight for a SLAB of a domain cut in y across ranks (rows 0 and ny - 1 of the
+ * block are ghosts of the neighbours' rows, as for pmcx_transport_begin .. _finish), with the
+ * whole domain's result bit for bit: what a rank's first and last real rows send across the cut
+ * travels as ready terms (flux x dest_vol / source_vol per cell and class), and the receiver adds
+ * them where the whole domain's order of summation has them.
+ *   _begin   j_global0: the domain row the block's row 0 stands for (-1 for the first rank's lower
+ *            ghost); global_ny: rows of the whole domain; prob_h / prob_v [n_cells][..] for every
+ *            local cell (ghost rows: unused) or NULL for the ones pmcx_transport_probs built -- given
+ *            ones stay on the device for _finish and for a pmcx_transport_begin(.., NULL, NULL, ..)
+ *            that follows; edge_terms [2][nx nz][n_class] out: side 0 for the rank below, 1 above
+ *   _finish  the neighbours' terms (from below: their side 1; from above: their side 0; NULL: no
+ *            neighbour); *_is_edge: that neighbour lies across the domain's periodic edge; then
+ *            the scaling.  Outputs as pmcx_transport_preweight ([n_cells], ghost rows zero). */
+int pmcx_transport_preweight_begin(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int32_t periodic_x,
+                                   int32_t periodic_y, int32_t j_global0, int32_t global_ny,
+                                   const double *prob_h, const double *prob_v, const double *cell_volume,
+                                   double *edge_terms);
+int pmcx_transport_preweight_finish(pmcx_ctx *ctx, const double *terms_from_below, const double *terms_from_above,
+                                    int32_t below_is_edge, int32_t above_is_edge, uint64_t seed, uint32_t step,
+                                    double *expected_num_conc, int32_t *n_removed);
 
 /* The same transport for a SLAB of a domain decomposed in y across ranks (one process per
  * GPU; wrf_pmc_trans_aero.F90 exchanges the movers between MPI patches).  The block carries

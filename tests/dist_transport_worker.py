@@ -1,6 +1,7 @@
 """Worker of tests/test_gpu_fortran.py-style multi-process test: run under torch.distributed.run
 with 2 ranks sharing one GPU over gloo.  Each rank owns one slab of a 4 x 3 x 6 domain, steps the
-transport with CellBlock.transport_distributed, and checks its real rows against
+preweight and the transport with CellBlock.transport_preweight_distributed /
+.transport_distributed, and checks its real rows against pmcx_transport_preweight and
 pmcx_transport on the whole domain (computed locally by every rank)."""
 import os
 import sys
@@ -32,6 +33,9 @@ def main():
     whole = wp.CellBlock(n, cap, n_spec, n_class=n_class, n_source=2)
     whole.set_aero_data(dens); whole.set_env(280.0, 9e4); whole.set_weights(mag)
     whole.set_next_id((np.arange(n, dtype=np.int64) << 32) + (1 << 20))
+    n_ideal = np.full((n, n_class), 1e9)
+    n_ideal[[2, row + 1, 3 * row - 2, 3 * row + 5, n - 3]] = 60.0      # cells whose weights get scaled: both
+    whole.set_n_part_ideal(n_ideal)                                     # sides of the cut and of the edge
     whole.generate_lognormal(n_part, modes, seed=3)
     dn = whole.download_cells()
     j0 = 3 * rank
@@ -42,6 +46,7 @@ def main():
                      cell_id_base=((j0 - 1) * row) % (1 << 32))
     b.set_aero_data(dens); b.set_env(280.0, 9e4); b.set_weights(mag[cells])
     b.set_next_id((cells.astype(np.int64) << 32) + (1 << 20))
+    b.set_n_part_ideal(n_ideal[cells])
     po = np.concatenate([[0], np.cumsum(np.diff(dn["part_offset"])[real])])
     sel = np.concatenate([np.arange(dn["part_offset"][c], dn["part_offset"][c + 1]) for c in real])
     b.upload_cells(row, po, dn["vol"][:, sel], dn["wclass"][sel], dn["id"][sel], dn["least_ct"][sel],
@@ -49,8 +54,16 @@ def main():
     for g0 in (0, len(cells) - row):
         b.upload_cells(g0, np.zeros(row + 1, np.int64), np.zeros((n_spec, 0)))
     for step in range(3):
+        ex_w, nr_w = whole.transport_preweight(nx, nz, ny, ph, pv, cv, 9, step, True, True)
+        ex, nr = b.transport_preweight_distributed(dist, nx, nz, 5, ph[cells], pv[cells], cv[cells], ny, 9, step)
+        assert np.array_equal(ex[row:-row], ex_w[real]), (rank, step, np.abs(ex[row:-row] - ex_w[real]).max())
+        assert np.array_equal(nr[row:-row], nr_w[real]) and (step > 0 or nr_w.sum() > 0)
+        assert np.array_equal(b.get_weights()[row:-row], whole.get_weights()[real])
+        # (the ghost rows stand for the neighbours' rows: their weights followed the scaling there)
+        assert np.array_equal(b.get_weights(), whole.get_weights()[cells])
         nm_w, na_w = whole.transport(nx, nz, ny, ph, pv, cv, 9, step, True, True)
-        nm, na = b.transport_distributed(dist, nx, nz, 5, ph[cells], pv[cells], cv[cells], 9, step)
+        # the probabilities the preweight left on the device serve the transport
+        nm, na = b.transport_distributed(dist, nx, nz, 5, None, None, cv[cells], 9, step)
         assert np.array_equal(nm[row:-row], nm_w[real]) and np.array_equal(na[row:-row], na_w[real])
         ref = whole.download_cells()
         got = b.download_cells(row, len(real))

@@ -65,6 +65,8 @@ struct pmcx_ctx {
     double *d_prob_h = nullptr, *d_prob_v = nullptr;
     int32_t *d_prob_i = nullptr;    // [n_cells] bad | [n_cells n_class] particles per class | [n_cells] sub-steps
     double *d_preweight = nullptr;  // [2][n_cells][n_class] num_conc_old, expected_num_conc
+    double *d_pw_edge = nullptr;    // [4][nx nz][n_class] slab form: terms sent out (2 sides), terms received
+    int pw_nx = 0, pw_nz = 0, pw_ny = 0, pw_ideal = 0, pw_jg0 = 0, pw_gny = 0; // pw_nx != 0: a slab preweight is open
     int probs_nx = 0, probs_nz = 0, probs_ny = 0; // geometry they were built for (probs_nx != 0: ready)
     int64_t *d_acc = nullptr;   // running sums over calls: n_samp, n_coag, n_part, status
     double *d_diag = nullptr; // [n_cells*(2+2*n_dbin)]
@@ -1340,6 +1342,94 @@ int pmcx_transport_preweight(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, 
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, invalidate_sort(ctx, 0, cf.n_cells, false)); // (removals keep the sort keys current)
     ctx->bounds_dirty = true;
+    return PMCX_OK;
+}
+
+// ---- the preweight of a slab: the sums over the cut rows come from the neighbouring ranks ----
+
+static int transport_buffers(pmcx_ctx *ctx);
+
+int pmcx_transport_preweight_begin(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int32_t periodic_x,
+                                   int32_t periodic_y, int32_t j_global0, int32_t global_ny,
+                                   const double *prob_h, const double *prob_v, const double *cell_volume,
+                                   double *edge_terms)
+{
+    if (!ctx || !cell_volume || !edge_terms || (!prob_h) != (!prob_v))
+        return fail(ctx, PMCX_EINVAL, "pmcx_transport_preweight_begin: null argument");
+    const pmcx_config &cf = ctx->cfg;
+    if (nx < 1 || nz < 1 || ny < 3 || nz > 128 || (int64_t)nx * nz * ny != cf.n_cells || global_ny < ny - 2)
+        return fail(ctx, PMCX_EINVAL, "pmcx_transport_preweight_begin: nx*nz*ny must equal n_cells, ny >= 3 "
+                                      "(two ghost rows), nz <= 128");
+    if (!ctx->n_ideal_set) return fail(ctx, PMCX_ESTATE, "pmcx_set_n_part_ideal must come first");
+    HIP_TRY(ctx, hipSetDevice(cf.device));
+    const size_t nc = (size_t)cf.n_cells, C = (size_t)cf.n_class, row = (size_t)nx * nz;
+    int rc = transport_buffers(ctx);
+    if (rc) return rc;
+    if (!ctx->d_preweight) { rc = dev_alloc(ctx, &ctx->d_preweight, 2 * nc * C); if (rc) return rc; }
+    if (!ctx->d_pw_edge) { rc = dev_alloc(ctx, &ctx->d_pw_edge, 4 * row * C); if (rc) return rc; }
+    if (prob_h) { // kept on the device for _finish and for the transport that follows
+        if (!ctx->d_prob_h) {
+            rc = dev_alloc(ctx, &ctx->d_prob_h, nc * C * 4);
+            if (!rc) rc = dev_alloc(ctx, &ctx->d_prob_v, nc * C * (size_t)nz);
+            if (!rc) rc = dev_alloc(ctx, &ctx->d_prob_i, nc + nc * C + nc);
+            if (rc) return rc;
+            ctx->probs_nz = nz;
+        } else if (ctx->probs_nz != nz) {
+            return fail(ctx, PMCX_ESTATE, "pmcx_transport_preweight_begin: nz differs from the first call's");
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_prob_h, prob_h, sizeof(double) * nc * C * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_prob_v, prob_v, sizeof(double) * nc * C * (size_t)nz, hipMemcpyHostToDevice, ctx->stream));
+        ctx->probs_nx = nx; ctx->probs_ny = ny;
+    } else if (ctx->probs_nx != nx || ctx->probs_nz != nz || ctx->probs_ny != ny) {
+        return fail(ctx, PMCX_ESTATE, "pmcx_transport_preweight_begin: no probabilities were built for this grid");
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_halo_cv, cell_volume, sizeof(double) * nc, hipMemcpyHostToDevice, ctx->stream));
+    const int ideal = periodic_x && periodic_y;
+    {
+        ProfScope ps(ctx, "transport_preweight");
+        HIP_TRY(ctx, launch_preweight_slab_begin(ctx->st, nx, nz, ny, ideal, j_global0, global_ny, ctx->d_prob_h,
+                                                 ctx->d_prob_v, ctx->d_halo_cv, ctx->d_preweight, ctx->d_pw_edge,
+                                                 ctx->stream));
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(edge_terms, ctx->d_pw_edge, sizeof(double) * 2 * row * C, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pw_nx = nx; ctx->pw_nz = nz; ctx->pw_ny = ny; ctx->pw_ideal = ideal;
+    ctx->pw_jg0 = j_global0; ctx->pw_gny = global_ny;
+    return PMCX_OK;
+}
+
+int pmcx_transport_preweight_finish(pmcx_ctx *ctx, const double *terms_from_below, const double *terms_from_above,
+                                    int32_t below_is_edge, int32_t above_is_edge, uint64_t seed, uint32_t step,
+                                    double *expected_num_conc, int32_t *n_removed)
+{
+    if (!ctx) return PMCX_EINVAL;
+    if (!ctx->pw_nx) return fail(ctx, PMCX_ESTATE, "pmcx_transport_preweight_finish: no preweight is open");
+    const pmcx_config &cf = ctx->cfg;
+    const int nx = ctx->pw_nx, nz = ctx->pw_nz, ny = ctx->pw_ny;
+    ctx->pw_nx = 0;
+    HIP_TRY(ctx, hipSetDevice(cf.device));
+    const size_t nc = (size_t)cf.n_cells, C = (size_t)cf.n_class, row = (size_t)nx * nz;
+    double *g_lo = ctx->d_pw_edge + 2 * row * C, *g_hi = g_lo + row * C;
+    if (terms_from_below) HIP_TRY(ctx, hipMemcpyAsync(g_lo, terms_from_below, sizeof(double) * row * C, hipMemcpyHostToDevice, ctx->stream));
+    if (terms_from_above) HIP_TRY(ctx, hipMemcpyAsync(g_hi, terms_from_above, sizeof(double) * row * C, hipMemcpyHostToDevice, ctx->stream));
+    int rc = ensure_stage(ctx, sizeof(int32_t) * nc + 64);
+    if (rc) return rc;
+    int32_t *d_nr = (int32_t *)ctx->stage;
+    HIP_TRY(ctx, hipMemsetAsync(d_nr, 0, sizeof(int32_t) * nc, ctx->stream));
+    {
+        ProfScope ps(ctx, "transport_preweight");
+        HIP_TRY(ctx, launch_preweight_slab_finish(ctx->st, nx, nz, ny, ctx->pw_ideal, ctx->pw_jg0, ctx->pw_gny,
+                                                  below_is_edge, above_is_edge, ctx->d_prob_h, ctx->d_prob_v,
+                                                  ctx->d_halo_cv, ctx->d_preweight, ctx->d_preweight + nc * C,
+                                                  terms_from_below ? g_lo : nullptr,
+                                                  terms_from_above ? g_hi : nullptr, d_nr, seed, step, ctx->stream));
+    }
+    if (expected_num_conc)
+        HIP_TRY(ctx, hipMemcpyAsync(expected_num_conc, ctx->d_preweight + nc * C, sizeof(double) * nc * C,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+    if (n_removed) HIP_TRY(ctx, hipMemcpyAsync(n_removed, d_nr, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, invalidate_sort(ctx, 0, cf.n_cells, false));
     return PMCX_OK;
 }
 

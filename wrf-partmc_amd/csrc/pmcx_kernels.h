@@ -185,6 +185,16 @@ hipError_t launch_boundary_resample(const DeviceState &st, const int32_t *action
                                     const double *bg_conc, const double *density, double create_time,
                                     uint64_t seed, uint32_t step, int32_t *n_added, int32_t *n_removed,
                                     hipStream_t s);
+hipError_t launch_preweight_slab_begin(const DeviceState &st, int nx, int nz, int ny, int ideal,
+                                       int j_global0, int global_ny, const double *prob_h,
+                                       const double *prob_v, const double *cell_volume, double *old,
+                                       double *edge_out, hipStream_t s);
+hipError_t launch_preweight_slab_finish(const DeviceState &st, int nx, int nz, int ny, int ideal,
+                                        int j_global0, int global_ny, int lo_edge, int hi_edge,
+                                        const double *prob_h, const double *prob_v,
+                                        const double *cell_volume, double *old, double *expect,
+                                        const double *gin_lo, const double *gin_hi, int32_t *n_removed,
+                                        uint64_t seed, uint32_t step, hipStream_t s);
 hipError_t launch_transport_preweight(const DeviceState &st, int nx, int nz, int ny, int ideal,
                                       const double *prob_h, const double *prob_v,
                                       const double *cell_volume, double *old, double *expect,

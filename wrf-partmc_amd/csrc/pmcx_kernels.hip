@@ -3370,6 +3370,14 @@ struct PreweightArgs {
     const double *prob_h, *prob_v, *cell_volume;
     double *old, *expect;   // [n_cells][n_class]
     int32_t *n_removed;     // [n_cells]
+    // slab of a domain cut in y across ranks: rows 0 and ny - 1 are ghosts of the neighbours' rows;
+    // what those rows send this way arrives as ready terms (the sender's flux x dest_vol /
+    // source_vol, [nx nz][n_class] per side; nullptr: nothing) and joins the sum where the
+    // whole domain's order has it: in sequence at a cut, after everything else across the
+    // domain's periodic edge (lo_edge / hi_edge)
+    int32_t slab, lo_edge, hi_edge, j_global0, global_ny;
+    const double *gin_lo, *gin_hi;
+    double *edge_out;       // [2][nx nz][n_class] what the first and last real rows send out
 };
 
 __global__ __launch_bounds__(64) void k_preweight_old(DeviceState st, PreweightArgs a)
@@ -3418,7 +3426,11 @@ __global__ __launch_bounds__(256) void k_preweight_new(DeviceState st, Preweight
     const int cl = (int)(x % C);
     const int64_t d = x / C;
     const int i = (int)(d % nx), k = (int)((d / nx) % nz), j = (int)(d / ((int64_t)nx * nz));
+    if (a.slab && (j == 0 || j == ny - 1)) { a.expect[d * C + cl] = 0.0; return; } // a ghost row
     auto cell = [&](int ii, int kk, int jj) { return ((int64_t)jj * nz + kk) * nx + ii; };
+    // moves of the cell in local row jj (its place in the whole domain decides at open boundaries)
+    const int gny = a.slab ? a.global_ny : ny;
+    auto moves = [&](int ii, int jj) { return preweight_moves(ii, a.slab ? jj + a.j_global0 : jj, nx, gny, a.ideal); };
     const double vd = a.cell_volume[d];
     // what source s sends towards this cell through its horizontal move `dir`
     auto from_h = [&](int64_t s, int dir) {
@@ -3429,14 +3441,17 @@ __global__ __launch_bounds__(256) void k_preweight_new(DeviceState st, Preweight
         const double flux = a.prob_v[(s * C + cl) * nz + k] * a.old[s * C + cl];
         return flux * (vd / a.cell_volume[s]);
     };
+    const int64_t r = ((int64_t)k * nx + i) * C + cl; // place in a row's table of ready terms
+    const bool lo_ghost = a.slab && j - 1 == 0, hi_ghost = a.slab && j + 1 == ny - 1;
     double acc = a.old[d * C + cl];
-    if (j >= 1 && (preweight_moves(i, j - 1, nx, ny, a.ideal) & 8)) acc = acc + from_h(cell(i, k, j - 1), 3);
-    const bool col_vert = (preweight_moves(i, j, nx, ny, a.ideal) & 16) != 0; // (the whole column alike)
+    if (lo_ghost) { if (a.gin_lo && !a.lo_edge) acc = acc + a.gin_lo[r]; }
+    else if (j >= 1 && (moves(i, j - 1) & 8)) acc = acc + from_h(cell(i, k, j - 1), 3);
+    const bool col_vert = (moves(i, j) & 16) != 0; // (the whole column alike)
     if (col_vert)
         for (int kk = 0; kk < k; kk++) acc = acc + from_v(cell(i, kk, j));
-    if (i >= 1 && (preweight_moves(i - 1, j, nx, ny, a.ideal) & 2)) acc = acc + from_h(cell(i - 1, k, j), 1);
+    if (i >= 1 && (moves(i - 1, j) & 2)) acc = acc + from_h(cell(i - 1, k, j), 1);
     {   // the cell's own losses, in the order compute_fluxes takes them
-        const int mv = preweight_moves(i, j, nx, ny, a.ideal);
+        const int mv = moves(i, j);
         const double o = a.old[d * C + cl];
         const double *ph = a.prob_h + (d * C + cl) * 4;
         if (mv & 4) acc = acc - ph[2] * o;
@@ -3447,17 +3462,44 @@ __global__ __launch_bounds__(256) void k_preweight_new(DeviceState st, Preweight
             for (int kk = 0; kk < nz; kk++)
                 if (kk != k) acc = acc - a.prob_v[(d * C + cl) * nz + kk] * o;
     }
-    if (i + 1 < nx && (preweight_moves(i + 1, j, nx, ny, a.ideal) & 1)) acc = acc + from_h(cell(i + 1, k, j), 0);
+    if (i + 1 < nx && (moves(i + 1, j) & 1)) acc = acc + from_h(cell(i + 1, k, j), 0);
     if (col_vert)
         for (int kk = k + 1; kk < nz; kk++) acc = acc + from_v(cell(i, kk, j));
-    if (j + 1 < ny && (preweight_moves(i, j + 1, nx, ny, a.ideal) & 4)) acc = acc + from_h(cell(i, k, j + 1), 2);
+    if (hi_ghost) { if (a.gin_hi && !a.hi_edge) acc = acc + a.gin_hi[r]; }
+    else if (j + 1 < ny && (moves(i, j + 1) & 4)) acc = acc + from_h(cell(i, k, j + 1), 2);
     if (a.ideal) { // across the periodic edges: the ghost cell's single term, added after everything else
-        if (j == ny - 1) acc = acc + from_h(cell(i, k, 0), 2);
-        if (j == 0) acc = acc + from_h(cell(i, k, ny - 1), 3);
+        if (a.slab) {
+            if (hi_ghost && a.hi_edge && a.gin_hi) acc = acc + a.gin_hi[r]; // the domain's last row
+            if (lo_ghost && a.lo_edge && a.gin_lo) acc = acc + a.gin_lo[r]; // the domain's first row
+        } else {
+            if (j == ny - 1) acc = acc + from_h(cell(i, k, 0), 2);
+            if (j == 0) acc = acc + from_h(cell(i, k, ny - 1), 3);
+        }
         if (i == nx - 1) acc = acc + from_h(cell(0, k, j), 0);
         if (i == 0) acc = acc + from_h(cell(nx - 1, k, j), 1);
     }
     a.expect[d * C + cl] = acc;
+}
+
+// slab: what the first real row sends down and the last real row sends up, as ready terms for
+// the neighbouring ranks' sums (side 0: towards row 0, side 1: towards row ny - 1)
+__global__ __launch_bounds__(256) void k_preweight_edge(DeviceState st, PreweightArgs a)
+{
+    const int C = st.n_class, nx = a.nx, nz = a.nz, ny = a.ny;
+    const int64_t row = (int64_t)nx * nz * C;
+    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (x >= 2 * row) return;
+    const int side = (int)(x / row);
+    const int64_t r = x % row;
+    const int cl = (int)(r % C), i = (int)((r / C) % nx), k = (int)(r / ((int64_t)C * nx));
+    const int j = side == 0 ? 1 : ny - 2, jg = side == 0 ? 0 : ny - 1, dir = side == 0 ? 2 : 3;
+    const int64_t s = ((int64_t)j * nz + k) * nx + i, g = ((int64_t)jg * nz + k) * nx + i;
+    double term = 0.0;
+    if (preweight_moves(i, j + a.j_global0, nx, a.global_ny, a.ideal) & (side == 0 ? 4 : 8)) {
+        const double flux = a.prob_h[(s * C + cl) * 4 + dir] * a.old[s * C + cl];
+        term = flux * (a.cell_volume[g] / a.cell_volume[s]);
+    }
+    a.edge_out[x] = term;
 }
 
 __global__ __launch_bounds__(64) void k_preweight_scale(DeviceState st, PreweightArgs a, uint64_t seed,
@@ -4379,12 +4421,45 @@ hipError_t launch_boundary_resample(const DeviceState &st, const int32_t *action
                        create_time, seed, step, n_added, n_removed);
     return hipGetLastError();
 }
+hipError_t launch_preweight_slab_begin(const DeviceState &st, int nx, int nz, int ny, int ideal,
+                                       int j_global0, int global_ny, const double *prob_h,
+                                       const double *prob_v, const double *cell_volume, double *old,
+                                       double *edge_out, hipStream_t s)
+{
+    PreweightArgs a{};
+    a.nx = nx; a.nz = nz; a.ny = ny; a.ideal = ideal; a.prob_h = prob_h; a.prob_v = prob_v;
+    a.cell_volume = cell_volume; a.old = old; a.slab = 1; a.j_global0 = j_global0; a.global_ny = global_ny;
+    a.edge_out = edge_out;
+    hipLaunchKernelGGL(k_preweight_old, dim3(st.n_cells), dim3(64), 0, s, st, a);
+    const int64_t n = 2 * (int64_t)nx * nz * st.n_class;
+    hipLaunchKernelGGL(k_preweight_edge, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, a);
+    return hipGetLastError();
+}
+hipError_t launch_preweight_slab_finish(const DeviceState &st, int nx, int nz, int ny, int ideal,
+                                        int j_global0, int global_ny, int lo_edge, int hi_edge,
+                                        const double *prob_h, const double *prob_v,
+                                        const double *cell_volume, double *old, double *expect,
+                                        const double *gin_lo, const double *gin_hi, int32_t *n_removed,
+                                        uint64_t seed, uint32_t step, hipStream_t s)
+{
+    PreweightArgs a{};
+    a.nx = nx; a.nz = nz; a.ny = ny; a.ideal = ideal; a.prob_h = prob_h; a.prob_v = prob_v;
+    a.cell_volume = cell_volume; a.old = old; a.expect = expect; a.n_removed = n_removed;
+    a.slab = 1; a.lo_edge = lo_edge; a.hi_edge = hi_edge; a.j_global0 = j_global0; a.global_ny = global_ny;
+    a.gin_lo = gin_lo; a.gin_hi = gin_hi;
+    const int64_t n = (int64_t)st.n_cells * st.n_class;
+    hipLaunchKernelGGL(k_preweight_new, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, a);
+    hipLaunchKernelGGL(k_preweight_scale, dim3(st.n_cells), dim3(64), 0, s, st, a, seed, step);
+    return hipGetLastError();
+}
 hipError_t launch_transport_preweight(const DeviceState &st, int nx, int nz, int ny, int ideal,
                                       const double *prob_h, const double *prob_v,
                                       const double *cell_volume, double *old, double *expect,
                                       int32_t *n_removed, uint64_t seed, uint32_t step, hipStream_t s)
 {
-    PreweightArgs a{nx, nz, ny, ideal, prob_h, prob_v, cell_volume, old, expect, n_removed};
+    PreweightArgs a{};
+    a.nx = nx; a.nz = nz; a.ny = ny; a.ideal = ideal; a.prob_h = prob_h; a.prob_v = prob_v;
+    a.cell_volume = cell_volume; a.old = old; a.expect = expect; a.n_removed = n_removed;
     hipLaunchKernelGGL(k_preweight_old, dim3(st.n_cells), dim3(64), 0, s, st, a);
     const int64_t n = (int64_t)st.n_cells * st.n_class;
     hipLaunchKernelGGL(k_preweight_new, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, a);

@@ -42,6 +42,7 @@ EXPORTED_SYMBOLS = [
     "pmcx_invalidate_lists", "pmcx_get_keys", "pmcx_seasalt_emissions",
     "pmcx_transport_probs", "pmcx_set_sampler_variant", "pmcx_transport_preweight",
     "pmcx_set_transport_lateral", "pmcx_boundary_copy", "pmcx_boundary_resample",
+    "pmcx_transport_preweight_begin", "pmcx_transport_preweight_finish",
 ]
 
 
@@ -62,6 +63,16 @@ class PmcxTransFields(C.Structure):
 
 class PmcxError(RuntimeError):
     pass
+
+
+def dist_rows_before(dist, my_rows):
+    """Domain rows held by the ranks below this one (ranks ordered along y)."""
+    import torch
+    t = torch.tensor([my_rows], dtype=torch.int64,
+                     device="cpu" if dist.get_backend() != "nccl" else "cuda")
+    allr = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(allr, t)
+    return int(sum(int(x.item()) for x in allr[:dist.get_rank()]))
 
 
 class PmcxConfig(C.Structure):
@@ -163,6 +174,9 @@ def load_library():
     L.pmcx_dry_deposition.argtypes = [C.c_void_p, C.c_double, C.c_uint64, C.c_uint32] + [C.c_void_p] * 9
     L.pmcx_timestep.argtypes = [C.c_void_p, C.POINTER(PmcxStepFlags)]
     L.pmcx_set_sampler_variant.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+    L.pmcx_transport_preweight_begin.argtypes = [C.c_void_p] + [C.c_int32] * 7 + [C.c_void_p] * 4
+    L.pmcx_transport_preweight_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                                  C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
     L.pmcx_set_transport_lateral.argtypes = [C.c_void_p, C.c_int32]
     L.pmcx_boundary_copy.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     L.pmcx_boundary_resample.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -732,6 +746,70 @@ class CellBlock:
         self._ck(self._lib.pmcx_transport_preweight(self._h, nx, nz, ny, int(periodic_x), int(periodic_y),
                                                     _ptr(ph), _ptr(pv), _ptr(cv), seed, step, _ptr(ex),
                                                     _ptr(nr)))
+        return ex, nr
+
+    def transport_preweight_distributed(self, dist, nx, nz, ny, prob_h, prob_v, cell_volume, global_ny,
+                                        seed=0, step=0, periodic_x=True, periodic_y=True):
+        """transport_preweight of this rank's slab inside a torch.distributed job (ranks ordered
+        along y, rows 0 and ny - 1 ghosts): the terms the cut rows send each other travel as small
+        host arrays; the result on the real rows is the whole domain's, bit for bit.  The
+        probabilities stay on the device: transport_distributed(…, prob_h=None, prob_v=None) may
+        follow.  Returns (expected_num_conc, n_removed) per local cell."""
+        import torch
+        rank, world = dist.get_rank(), dist.get_world_size()
+        n, Cn = self.cfg.n_cells, self.cfg.n_class
+        ph = None if prob_h is None else np.ascontiguousarray(np.broadcast_to(_f64(prob_h), (n, Cn, 4)))
+        pv = None if prob_v is None else np.ascontiguousarray(np.broadcast_to(_f64(prob_v), (n, Cn, nz)))
+        cv = np.ascontiguousarray(np.broadcast_to(_f64(cell_volume), (n,)))
+        rows_before = dist_rows_before(dist, ny - 2)
+        edge = np.zeros((2, nx * nz, Cn))
+        self._ck(self._lib.pmcx_transport_preweight_begin(self._h, nx, nz, ny, int(periodic_x), int(periodic_y),
+                                                          rows_before - 1, global_ny, _ptr(ph), _ptr(pv),
+                                                          _ptr(cv), _ptr(edge)))
+        below = (rank - 1) % world if (periodic_y or rank > 0) else None
+        above = (rank + 1) % world if (periodic_y or rank < world - 1) else None
+        dev = "cpu" if dist.get_backend() != "nccl" else f"cuda:{self.cfg.device}"
+        out = [torch.from_numpy(edge[0].copy()).to(dev), torch.from_numpy(edge[1].copy()).to(dev)]
+        got = [None, None]                                   # from below, from above
+        for phase, (to, frm, slot) in enumerate(((below, above, 1), (above, below, 0))):
+            ops, rbuf = [], None
+            if to is not None:
+                ops.append(dist.P2POp(dist.isend, out[phase], to))
+            if frm is not None:
+                rbuf = torch.empty_like(out[0])
+                ops.append(dist.P2POp(dist.irecv, rbuf, frm))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+                if dev != "cpu":
+                    torch.cuda.current_stream().synchronize()
+            if rbuf is not None:
+                got[slot] = np.ascontiguousarray(rbuf.cpu().numpy())
+        ex, nr = np.zeros((n, Cn)), np.zeros(n, dtype=np.int32)
+        self._ck(self._lib.pmcx_transport_preweight_finish(
+            self._h, _ptr(got[0]), _ptr(got[1]), int(below is not None and rank == 0),
+            int(above is not None and rank == world - 1), seed, step, _ptr(ex), _ptr(nr)))
+        # the ghost rows stand for the neighbours' boundary rows: their weight magnitudes follow
+        # the scaling done there (the reference ships the weight arrays of its ghost points,
+        # wrf_pmc_trans_aero.F90:380-470)
+        row = nx * nz
+        mag = self.get_weights()
+        out = [torch.from_numpy(mag[row:2 * row].copy()).to(dev), torch.from_numpy(mag[n - 2 * row:n - row].copy()).to(dev)]
+        for phase, (to, frm, lo) in enumerate(((below, above, n - row), (above, below, 0))):
+            ops, rbuf = [], None
+            if to is not None:
+                ops.append(dist.P2POp(dist.isend, out[phase], to))
+            if frm is not None:
+                rbuf = torch.empty_like(out[0])
+                ops.append(dist.P2POp(dist.irecv, rbuf, frm))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+                if dev != "cpu":
+                    torch.cuda.current_stream().synchronize()
+            if rbuf is not None:
+                mag[lo:lo + row] = rbuf.cpu().numpy()
+        self.set_weights(mag)
         return ex, nr
 
     def transport(self, nx, nz, ny, prob_h, prob_v, cell_volume, seed=0, step=0, periodic_x=True,
