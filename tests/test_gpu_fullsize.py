@@ -114,3 +114,72 @@ def test_rank_share_of_the_domain(wp, oracle, n_cols, first_col):
     """What a rank holds at N = 4 (75 000 cells) and N = 8 (39 000 cells: the last rank's
     block, two-wavefront form of the sampler), keyed by global cell ids."""
     _run_block(wp, oracle, n_cols * LEVELS, first_col * LEVELS)
+
+
+def test_transport_driver_on_the_full_domain(wp, oracle):
+    """wrf_pmc_trans_driver's particle half at BASELINE configs[4]'s grid (100 x 30 x 100 cells in
+    WRF's (i, k, j) order, 9 000 particles each so that arrivals find room below cap): the
+    probabilities built on the device equal the oracle's for EVERY cell and class bit for bit, the
+    preweight's expected concentrations equal an array-wise numpy evaluation, and the sampling
+    that consumes both from device memory conserves particles cell by cell -- with slot and
+    outbox indices past 2^31 in play (cells beyond 213 730)."""
+    from tests import trans_fields as tf
+    nx, nz, ny, n_part = 100, LEVELS, 100, 9000
+    n_cells = nx * nz * ny
+    free, total = wp.device_memory_info(0)
+    need = n_cells * (CAP * 78 + 80 * 80 * 4 + 4096 + 8 * (4 + nz) * 2) + (3 << 30)
+    if free < need:
+        pytest.skip(f"the transport at {n_cells} cells needs {need / 1e9:.0f} GB of HBM, {free / 1e9:.0f} free")
+    blk = wp.CellBlock(n_cells, CAP, 1, n_class=1, n_source=0, max_events=1024, max_appends=128)
+    temp, pres = bench.level_profile(LEVELS)
+    k = (np.arange(n_cells) // nx) % nz
+    blk.set_aero_data(bench.bench_density(1))
+    blk.set_env(temp[k], pres[k], np.full(n_cells, 0.5))
+    mag = NUM_CONC / n_part
+    blk.set_weights(np.full((n_cells, 1), mag))
+    blk.set_n_part_ideal(np.full((n_cells, 1), float(n_part)))
+    blk.set_next_id((np.arange(n_cells, dtype=np.int64) << 32) + (1 << 24))
+    blk.generate_lognormal(n_part, bench.bench_modes(1), seed=SEED)
+    # (exchange coefficients of a few m^2/s: with 40 m levels and a 20 s step a few per cent of a
+    # cell's particles change level; stronger mixing would need more room than cap leaves)
+    F = tf.make_fields(nx, nz, ny, 1, seed=11, k_scale=6.0, flux_scale=0.004 * NUM_CONC)
+    kw = dict(do_vertmix=1, all_columns=True)
+    ph, pv, ns, bad, ncp = blk.transport_probs(nx, nz, ny, 20.0, 4000.0, 4000.0, F, **kw)
+    assert not bad.any() and (ncp == n_part).all() and ns.min() >= 1 and ns.max() > 1
+    oph, opv, ons, obad = oracle.transport_probs(nx, nz, ny, 1, 20.0, 4000.0, 4000.0, F,
+                                                 np.full((n_cells, 1), n_part), np.full((n_cells, 1), mag), **kw)
+    assert np.array_equal(ns, ons) and np.array_equal(ph, oph) and np.array_equal(pv, opv)
+    cv = np.full(n_cells, 1.0e9)
+    ex, nr = blk.transport_preweight(nx, nz, ny, None, None, cv, SEED, 0, True, True)
+    # numpy: losses and gains per direction with equal cell volumes (sums in another order)
+    O = np.full((ny, nz, nx), n_part * mag)
+    PH, PV = ph.reshape(ny, nz, nx, 4), pv.reshape(ny, nz, nx, nz)
+    new = O.copy()
+    for d, (ax, sh) in enumerate([(2, -1), (2, 1), (0, -1), (0, 1)]):
+        flux = PH[..., d] * O
+        new -= flux
+        new += np.roll(flux, sh, axis=ax)
+    own = np.eye(nz, dtype=bool)[None, :, None, :]
+    fl = np.where(own, 0.0, PV * O[..., None])                    # [j][k_src][i][k_dst]
+    new -= fl.sum(axis=3)
+    new += np.moveaxis(fl.sum(axis=1), 2, 1)
+    np.testing.assert_allclose(ex[:, 0], new.reshape(-1), rtol=1e-12)
+    assert not nr.any()                                           # nowhere near twice the ideal count
+    n0 = blk.aero_state_total_particles().astype(np.int64)
+    nm, na = blk.transport(nx, nz, ny, None, None, cv, SEED, 0, True, True)
+    n1 = blk.aero_state_total_particles().astype(np.int64)
+    assert not blk.coag_counters()[2].any(), "status bits after the transport (capacity?)"
+    assert np.array_equal(n1, n0 - nm + na) and nm.sum() == na.sum() and np.count_nonzero(nm) > 0.99 * n_cells
+    assert 0.005 * n_part < nm.mean() < 0.2 * n_part
+    # the movers of a cell follow its probabilities (a column of cells past 2^31 in slot index)
+    p_leave = ph[:, 0].sum(axis=1) + pv[:, 0].sum(axis=1) - pv[np.arange(n_cells), 0, k]
+    far = np.arange(n_cells - 3000, n_cells)
+    assert abs(nm[far].sum() - (p_leave[far] * n_part).sum()) < 5 * np.sqrt((p_leave[far] * n_part).sum())
+    for c in (0, 213731, 250001, n_cells - 1):
+        dn = blk.download_cells(c, 1)
+        assert dn["part_offset"][1] == n1[c] and len(np.unique(dn["id"])) == n1[c]
+        assert (dn["vol"][0] > 0).all()
+    # and the coagulation step copes with what the transport left (lists rebuilt from the keys)
+    ns_, nc_, st = blk.mc_coag(K_BROWN, DEL_T, SEED, 0)
+    assert not st.any() and nc_.min() > 0
+    blk.close()
