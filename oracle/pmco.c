@@ -1086,6 +1086,9 @@ void pmco_diagnostics_ext(const pmco_cell *c, int i_water, double *species_mass,
  *   r  < 1: G >= 1 copies arrive, P(G = g) = r (1-r)^(g-1), capped at 16;
  *           the last keeps the id, the others get new ids      (:2258-2266,2279-2283)
  *           [the reference reaches the same mean 1/r with repeated picks]
+ * The placing uniform of the particle of rank i (among the cell's live particles) is 32 bits:
+ * word i & 3 of the Philox block (seed, cell, step, i >> 2, site TRANS, 0) times 2^-32; a mover
+ * with r != 1 draws the uniform of its copies from the block (…, i, site TRANS, 1).
  * Arrivals are appended to the destination in a fixed order: from the east,
  * west, north, south neighbour, then from levels 0..nz-1 of the column; inside
  * one source in the order of the particles' rank.
@@ -1184,18 +1187,25 @@ int pmco_transport(pmco_cell *cells, int n_cells, int nx, int nz, int ny, int pe
             const int cl = s->wclass[i];
             const trans_dest *t = tab + (size_t)cl * (4 + 128);
             if (ntab[cl] == 0) continue;
+            /* the destination uniform: 32 bits, four particles to a Philox block (word i & 3 of
+             * the block addressed by i >> 2); the uniform of the copies, needed only by a mover
+             * whose weight changes, from a block of its own */
             uint32_t w[4];
-            pmco_rng_block(seed, cell_id_base + (uint32_t)c, step, (uint32_t)i, PMCO_SITE_TRANS, 0, w);
-            const double u = pmco_u53(w[0], w[1]);
+            pmco_rng_block(seed, cell_id_base + (uint32_t)c, step, (uint32_t)i >> 2, PMCO_SITE_TRANS, 0, w);
+            const double u = (double)w[i & 3] * 0x1.0p-32;
             if (!(u < t[ntab[cl] - 1].hi)) continue;      /* stays */
             int d = 0;
             while (!(u < t[d].hi)) d++;
-            const double r = t[d].ratio, u2 = pmco_u53(w[2], w[3]);
+            const double r = t[d].ratio;
             int copies = 1;
-            if (r > 1.0) copies = (u2 < 1.0 / r) ? 1 : 0;
-            else if (r < 1.0) {
-                copies = 1 + (int)(pmco_log(1.0 - u2) / pmco_log(1.0 - r));
-                if (copies > PMCO_TRANS_MAX_COPIES) copies = PMCO_TRANS_MAX_COPIES;
+            if (r != 1.0) {
+                pmco_rng_block(seed, cell_id_base + (uint32_t)c, step, (uint32_t)i, PMCO_SITE_TRANS, 1, w);
+                const double u2 = pmco_u53(w[0], w[1]);
+                if (r > 1.0) copies = (u2 < 1.0 / r) ? 1 : 0;
+                else {
+                    copies = 1 + (int)(pmco_log(1.0 - u2) / pmco_log(1.0 - r));
+                    if (copies > PMCO_TRANS_MAX_COPIES) copies = PMCO_TRANS_MAX_COPIES;
+                }
             }
             box[c][nbox[c]].slot = i; box[c][nbox[c]].dest = t[d].dest; box[c][nbox[c]].copies = copies;
             nbox[c]++;

@@ -2749,7 +2749,8 @@ __global__ __launch_bounds__(256) void k_dry_deposition(DeviceState st, DepArgs 
 // (every particle draws its own destination; see oracle/pmco.c for the law).
 //   k_trans_decide  one wavefront per source cell: destination tables of each
 //                   class in LDS (sorted by probability, cumulative thresholds,
-//                   weight ratios), one Philox block per live particle, movers
+//                   weight ratios), a 32-bit destination uniform per live particle (four
+//                   particles to a Philox block, addressed by rank), movers
 //                   compacted into the cell's outbox in rank order
 //   k_trans_gather  one wavefront per destination cell: scans the outboxes of
 //                   its sources in a fixed order and appends the arrivals
@@ -2795,126 +2796,194 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
     const uint64_t lt = (1ull << lane) - 1ull;
     apply_event_log(st, c, lane); // (this step's removals and arrivals keep the cell's keys current)
 
-    // destination tables (serial per class: the cumulative sums are order dependent)
-    if (lane < C) {
-        const int cl = lane;
+    // destination tables, class by class: the candidates (four neighbours, then the levels) are
+    // looked at one per lane and kept in that order; every kept one finds its place in the stable
+    // ascending order of the probabilities by counting (n compares per lane instead of n^2 on
+    // one); its weight ratio and its bit of the destination mask are its own lane's work; only
+    // the cumulative thresholds are taken in sequence (their sums depend on the order).
+    for (int cl = 0; cl < C; cl++) {
         double *p = t_p + cl * ND;
-        int *dc = t_tmpd + cl * ND, n = 0;
-        const int di[4] = {-1, 1, 0, 0}, dj[4] = {0, 0, -1, 1};
+        int *dc = t_tmpd + cl * ND;
+        int *ord = t_cnt + cl * ND; // rank -> element (t_cnt is cleared again below)
         const bool bx = (i == 0 || i == nx - 1), by = (j == 0 || j == ny - 1);
-        if (st.trans_lateral && (bx || by)) {
-            // open lateral boundaries (wrf_pmc_trans_aero.F90:689-768): a boundary cell only sends
-            // inwards, with min(prob, 1); a corner sends nothing
-            if (!(bx && by)) {
-                const int d = i == 0 ? 1 : i == nx - 1 ? 0 : j == 0 ? 3 : 2;
-                double pr = tg.prob_h[((int64_t)c * C + cl) * 4 + d];
-                if (pr > 1.0) pr = 1.0;
-                if (pr > 0.0) { p[0] = pr; dc[0] = ((j + dj[d]) * nz + k) * nx + (i + di[d]); n = 1; }
+        const bool lateral_cell = st.trans_lateral && (bx || by);
+        int n = 0;
+        for (int d0 = 0; d0 < ND; d0 += 64) {
+            const int d = d0 + lane;
+            double pr = 0.0;
+            int dcell = 0;
+            if (d < ND) {
+                if (lateral_cell) {
+                    // open lateral boundaries (wrf_pmc_trans_aero.F90:689-768): a boundary cell only
+                    // sends inwards, with min(prob, 1); a corner sends nothing
+                    const int din = i == 0 ? 1 : i == nx - 1 ? 0 : j == 0 ? 3 : 2;
+                    if (!(bx && by) && d == din) {
+                        pr = tg.prob_h[((int64_t)c * C + cl) * 4 + d];
+                        if (pr > 1.0) pr = 1.0;
+                        dcell = ((j + (d == 2 ? -1 : d == 3 ? 1 : 0)) * nz + k) * nx + (i + (d == 0 ? -1 : d == 1 ? 1 : 0));
+                    }
+                } else if (d < 4) {
+                    int ii = i + (d == 0 ? -1 : d == 1 ? 1 : 0), jj = j + (d == 2 ? -1 : d == 3 ? 1 : 0);
+                    bool ok = true;
+                    if (ii < 0 || ii >= nx) { if (!tg.periodic_x) ok = false; else ii = (ii + nx) % nx; }
+                    if (jj < 0 || jj >= ny) { if (!tg.periodic_y) ok = false; else jj = (jj + ny) % ny; }
+                    if (ok) { pr = tg.prob_h[((int64_t)c * C + cl) * 4 + d]; dcell = (jj * nz + k) * nx + ii; }
+                } else {
+                    const int kk = d - 4;
+                    if (kk != k) { pr = tg.prob_v[((int64_t)c * C + cl) * nz + kk]; dcell = (j * nz + kk) * nx + i; }
+                }
             }
-        } else {
-        for (int d = 0; d < 4; d++) {
-            int ii = i + di[d], jj = j + dj[d];
-            if (ii < 0 || ii >= nx) { if (!tg.periodic_x) continue; ii = (ii + nx) % nx; }
-            if (jj < 0 || jj >= ny) { if (!tg.periodic_y) continue; jj = (jj + ny) % ny; }
-            const double pr = tg.prob_h[((int64_t)c * C + cl) * 4 + d];
-            if (pr > 0.0) { p[n] = pr; dc[n] = (jj * nz + k) * nx + ii; n++; }
+            const bool keep = pr > 0.0;
+            const uint64_t mk = __ballot(keep);
+            if (keep) { const int at = n + __popcll(mk & lt); p[at] = pr; dc[at] = dcell; }
+            n += __popcll(mk);
         }
-        for (int kk = 0; kk < nz; kk++) {
-            if (kk == k) continue;
-            const double pr = tg.prob_v[((int64_t)c * C + cl) * nz + kk];
-            if (pr > 0.0) { p[n] = pr; dc[n] = (j * nz + kk) * nx + i; n++; }
-        }
-        }
-        // stable ascending order by probability, then thresholds in that order
-        double rem = 1.0, cum = 0.0;
-        const double mag_from = st.mag[(int64_t)c * C + cl];
-        int *ord = t_dest + cl * ND; // rank -> element, overwritten by the destinations below
-        for (int x = 0; x < n; x++) {
+        lds_sync();
+        for (int x = lane; x < n; x += 64) {
+            const double px = p[x];
             int rk = 0;
-            for (int y = 0; y < n; y++) rk += (p[y] < p[x]) || (p[y] == p[x] && y < x);
+            for (int y = 0; y < n; y++) { const double py = p[y]; rk += (py < px) || (py == px && y < x); }
             ord[rk] = x;
         }
-        for (int r = 0; r < n; r++) {
-            const int a = ord[r];
-            t_dest[cl * ND + r] = dc[a];
-            t_lo[cl * ND + r] = cum;
-            if (rem >= 1e-8) {
-                cum = cum + p[a];
-                if (cum > 1.0) cum = 1.0;
-                rem = rem - p[a];
+        lds_sync();
+        const double mag_from = st.mag[(int64_t)c * C + cl];
+        for (int r = lane; r < n; r += 64) {
+            const int a = ord[r], dca = dc[a];
+            t_dest[cl * ND + r] = dca;
+            const double factor = tg.cell_volume[c] / tg.cell_volume[dca];
+            t_ratio[cl * ND + r] = (st.mag[(int64_t)dca * C + cl] / factor) / mag_from;
+            // where the destination lies, as the gather of that cell will look for it
+            const int di_ = dca % nx, dk_ = (dca / nx) % nz, dj_ = dca / (nx * nz);
+            uint64_t bit = ~0ull;
+            if (mask_ok) {
+                if (di_ == i && dj_ == j) bit = 1ull << (4 + dk_);
+                else if (dj_ == j) bit = (di_ == (i + 1) % nx) ? 1ull : 2ull;
+                else bit = (dj_ == (j + 1) % ny) ? 4ull : 8ull;
             }
-            t_hi[cl * ND + r] = cum;
-            const double factor = tg.cell_volume[c] / tg.cell_volume[dc[a]];
-            t_ratio[cl * ND + r] = (st.mag[(int64_t)dc[a] * C + cl] / factor) / mag_from;
-            {   // where the destination lies, as the gather of that cell will look for it
-                const int di_ = dc[a] % nx, dk_ = (dc[a] / nx) % nz, dj_ = dc[a] / (nx * nz);
-                uint64_t bit = ~0ull;
-                if (mask_ok) {
-                    if (di_ == i && dj_ == j) bit = 1ull << (4 + dk_);
-                    else if (dj_ == j) bit = (di_ == (i + 1) % nx) ? 1ull : 2ull;
-                    else bit = (dj_ == (j + 1) % ny) ? 4ull : 8ull;
-                }
-                t_bit[cl * ND + r] = bit;
-            }
+            t_bit[cl * ND + r] = bit;
         }
-        t_n[cl] = n;
+        if (lane == 0) {
+            double rem = 1.0, cum = 0.0;
+            for (int r = 0; r < n; r++) {
+                const double pa = p[ord[r]];
+                t_lo[cl * ND + r] = cum;
+                if (rem >= 1e-8) {
+                    cum = cum + pa;
+                    if (cum > 1.0) cum = 1.0;
+                    rem = rem - pa;
+                }
+                t_hi[cl * ND + r] = cum;
+            }
+            t_n[cl] = n;
+        }
+        lds_sync();
     }
-    wave_sync();
+    for (int x = lane; x < C * ND; x += 64) t_cnt[x] = 0;
+    lds_sync();
 
     const int n_hi = st.n_hi[c];
     int2 *box = tg.outbox + cb;
     uint32_t rank0 = 0, n_out = 0;
     uint64_t bits = 0;
-    // two chunks of 64 slots per trip: both liveness loads are in flight before the first draw
-    auto chunk = [&](int s, int cl) {
-        const uint64_t mlive = __ballot(cl >= 0);
-        const uint32_t rank = rank0 + (uint32_t)__popcll(mlive & lt);
-        bool moves = false;
-        int dest = 0, copies = 0, dslot = 0;
-        if (cl >= 0 && t_n[cl] > 0) {
-            uint32_t w[4];
-            rng_block(seed, cell_id, step, rank, SITE_TRANS, 0, w);
-            const double u = u53(w[0], w[1]);
-            const int nt = t_n[cl];
-            if (u < t_hi[cl * ND + nt - 1]) {
-                int d = 0;
-                while (!(u < t_hi[cl * ND + d])) d++;
-                const double r = t_ratio[cl * ND + d], u2 = u53(w[2], w[3]);
-                copies = 1;
-                if (r > 1.0) copies = (u2 < 1.0 / r) ? 1 : 0;
-                else if (r < 1.0) {
-                    copies = 1 + (int)(det_log(1.0 - u2) / det_log(1.0 - r));
-                    if (copies > TRANS_MAX_COPIES) copies = TRANS_MAX_COPIES;
-                }
-                dslot = cl * ND + d;
-                dest = t_dest[dslot];
-                bits |= t_bit[dslot];
-                moves = true;
-            }
-        }
-        const uint64_t mm = __ballot(moves);
-        if (moves) box[n_out + (uint32_t)__popcll(mm & lt)] = make_int2(s | (copies << 16), dest);
-        if (moves && copies > 0) atomicAdd(&t_cnt[dslot], copies);
-        n_out += (uint32_t)__popcll(mm);
-        rank0 += (uint32_t)__popcll(mlive);
-    };
     // Liveness and class of a slot come from its 2-byte sort key while the cell's keys hold
     // (the log was applied above): a dense plane instead of one field of the 32-byte records.
     const bool keyed = st.key_valid[c] != 0;
     const uint16_t *gk = st.gkey + cb;
     const int Bn = st.n_bin;
+    const float inv_bn = 1.0f / (float)Bn;
     auto slot_class = [&](int sl) -> int {
         if (sl >= n_hi) return -1;
         if (!keyed) return live_class(st, cb, sl);
         const uint32_t kq = gk[sl];
-        return kq == 0xFFFFu ? -1 : (int)(kq / (uint32_t)Bn);
+        if (kq == 0xFFFFu) return -1;
+        if (C == 1) return 0;
+        // kq / Bn without the integer division (keys are below 65 536: the estimate is off by one at most)
+        uint32_t q = (uint32_t)((float)kq * inv_bn);
+        if (q * (uint32_t)Bn > kq) q--;
+        else if ((q + 1u) * (uint32_t)Bn <= kq) q++;
+        return (int)q;
     };
-    for (int i0 = 0; i0 < n_hi; i0 += 128) {
-        const int sa = i0 + lane, sb = i0 + 64 + lane;
-        const int cla = slot_class(sa);
-        const int clb = slot_class(sb);
-        chunk(sa, cla);
-        if (i0 + 64 < n_hi) chunk(sb, clb);
+    // (one class: the stay-or-go threshold is the same for every particle of the cell)
+    const double hi_last0 = t_n[0] > 0 ? t_hi[t_n[0] - 1] : 0.0;
+    // The destination uniform of the particle of rank r is 32 bits: word r & 3 of the Philox block
+    // addressed by r >> 2 -- four particles to a block.  A trip covers 4 x 63 slots: their ranks
+    // span fewer than 256, i.e. at most 64 blocks from (rank of the trip's first particle) >> 2 on,
+    // one per lane; a particle fetches its word from the lane that holds its block.  Only a mover
+    // whose weight changes on the way draws again (the number of copies), from a block of its own.
+    // (the keys of the next trip are requested before this trip's work: a wavefront alone with
+    // its cell would otherwise wait out a memory round trip forty times)
+    auto key_of_slot = [&](int sl) -> uint32_t { return (lane < 63 && sl < n_hi) ? (uint32_t)gk[sl] : 0xFFFFu; };
+    auto class_of_key = [&](uint32_t kq) -> int {
+        if (kq == 0xFFFFu) return -1;
+        if (C == 1) return 0;
+        uint32_t q = (uint32_t)((float)kq * inv_bn);
+        if (q * (uint32_t)Bn > kq) q--;
+        else if ((q + 1u) * (uint32_t)Bn <= kq) q++;
+        return (int)q;
+    };
+    uint32_t knext[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
+    if (keyed) {
+#pragma unroll
+        for (int ch = 0; ch < 4; ch++) knext[ch] = key_of_slot(ch * 63 + lane);
+    }
+    for (int i0 = 0; i0 < n_hi; i0 += 4 * 63) {
+        int cls[4];
+        if (keyed) {
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++) cls[ch] = class_of_key(knext[ch]);
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++) knext[ch] = key_of_slot(i0 + 4 * 63 + ch * 63 + lane);
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++) cls[ch] = lane < 63 ? slot_class(i0 + ch * 63 + lane) : -1;
+        }
+        const uint32_t B0 = rank0 >> 2;
+        uint32_t wb[4];
+        rng_block(seed, cell_id, step, B0 + (uint32_t)lane, SITE_TRANS, 0, wb);
+#pragma unroll
+        for (int ch = 0; ch < 4; ch++) {
+            const int s = i0 + ch * 63 + lane, cl = cls[ch];
+            const uint64_t mlive = __ballot(cl >= 0);
+            const uint32_t rank = rank0 + (uint32_t)__popcll(mlive & lt);
+            const int src = (int)((rank >> 2) - B0) & 63;
+            const uint32_t w0 = (uint32_t)__shfl((int)wb[0], src, 64), w1 = (uint32_t)__shfl((int)wb[1], src, 64);
+            const uint32_t w2 = (uint32_t)__shfl((int)wb[2], src, 64), w3 = (uint32_t)__shfl((int)wb[3], src, 64);
+            const uint32_t wsel = (rank & 2u) ? ((rank & 1u) ? w3 : w2) : ((rank & 1u) ? w1 : w0);
+            bool moves = false;
+            int dest = 0, copies = 0, dslot = 0;
+            const double u = (double)wsel * 0x1.0p-32;
+            // (one class: no table look-up for the particles that stay, almost all of them)
+            if (cl >= 0 && (C == 1 ? u < hi_last0 : t_n[cl] > 0)) {
+                const int nt = t_n[cl];
+                if (u < t_hi[cl * ND + nt - 1]) {
+                    // the first threshold above u, looked for from the top: the probabilities are in
+                    // ascending order, the last few destinations hold most of the mass
+                    int d = nt - 1;
+                    while (d > 0 && u < t_hi[cl * ND + d - 1]) d--;
+                    const double r = t_ratio[cl * ND + d];
+                    copies = 1;
+                    if (r != 1.0) {
+                        uint32_t w[4];
+                        rng_block(seed, cell_id, step, rank, SITE_TRANS, 1, w);
+                        const double u2 = u53(w[0], w[1]);
+                        if (r > 1.0) copies = (u2 < 1.0 / r) ? 1 : 0;
+                        else {
+                            copies = 1 + (int)(det_log(1.0 - u2) / det_log(1.0 - r));
+                            if (copies > TRANS_MAX_COPIES) copies = TRANS_MAX_COPIES;
+                        }
+                    }
+                    dslot = cl * ND + d;
+                    dest = t_dest[dslot];
+                    bits |= t_bit[dslot];
+                    moves = true;
+                }
+            }
+            const uint64_t mm = __ballot(moves);
+            if (moves) box[n_out + (uint32_t)__popcll(mm & lt)] = make_int2(s | (copies << 16), dest);
+            if (moves && copies > 0) atomicAdd(&t_cnt[dslot], copies);
+            n_out += (uint32_t)__popcll(mm);
+            rank0 += (uint32_t)__popcll(mlive);
+        }
     }
     // the arrivals each destination has to expect: one atomic per destination, not per mover
     wave_sync();
