@@ -180,22 +180,27 @@ def test_fortran_resident_sequence(tmp_path, wp):
                          n_orig.transpose(1, 0, 2).reshape(n_source, -1))
         off = 0
         for step in range(n_steps):
+            ex, npw = blk.transport_preweight(nx, nz, ny, prob_h, prob_v, np.ones(n_cells), seed=seed, step=step)
             nm, na = blk.transport(nx, nz, ny, prob_h, prob_v, np.ones(n_cells), seed=seed, step=step)
             nr, bad = blk.dry_deposition(del_t, 30.0 + c0 + 1, 0.3, 1.2, 2e-3, 40.0, 0.8, seed=seed,
                                          step=step, surface=(lev == 0).astype(np.int32))
             ns, nc, st = blk.mc_coag(kernel, del_t, seed, step)
             assert not (st & 3).any()
-            n_before = blk.aero_state_total_particles().sum()
             blk.aero_state_rebalance(True, True, seed, step)
             if step == 0:
-                assert blk.aero_state_total_particles().sum() < 0.7 * n_before   # it halved
-            for want in (nm, na, nr, ns, nc):
+                # the ideal counts are far below the populations: the preweight scaled every weight
+                # up (and thinned the particles) before anything moved
+                assert npw.sum() > 0.4 * n_cells * n_part
+                assert blk.aero_state_total_particles().sum() < 0.7 * n_cells * n_part
+            for want in (npw, nm, na, nr, ns, nc):
                 got = np.frombuffer(out, "<i4", n_cells, off); off += 4 * n_cells
                 assert np.array_equal(got, want), step
+            got = np.frombuffer(out, "<f8", n_cells * n_class, off).reshape(n_cells, n_class); off += 8 * n_cells * n_class
+            assert np.array_equal(got, ex), step          # trans_aero_preweight's expected_num_conc
             assert nm.sum() > 0 and nr.sum() > 0 and nc.sum() > 0
         d = blk.download_cells()
         w_dev = blk.get_weights()
-    assert (w_dev > mag * 1.5).all()                       # halving doubled the magnitudes
+    assert (w_dev > mag * 1.5).all()                       # the scaling raised the magnitudes
     rec = 8 * n_spec + 4 * n_source + 4 + 8 + 16 + 4 + 8 + 8 + 4 + 16
     po = d["part_offset"]
     for c in range(n_cells):

@@ -47,7 +47,8 @@ module pmcx_shim
   ! the device-resident sequence (INTEGRATION.md 2c): upload once, step on the device,
   ! download when the host needs the particles (output, restart)
   public :: pmcx_upload_states, pmcx_download_states, mc_coag_resident_pmcx, &
-       trans_cells_pmcx, dry_dep_cells_pmcx
+       trans_cells_pmcx, dry_dep_cells_pmcx, trans_preweight_cells_pmcx, &
+       trans_from_fields_cells_pmcx, seasalt_cells_pmcx
   ! slab transport across MPI ranks: the host moves the packed buffers (GPU-aware MPI on
   ! the device pointers, or staged through pmcx_device_copy)
   public :: pmcx_shim_context, pmcx_transport_begin, pmcx_transport_export_size, &
@@ -62,6 +63,13 @@ module pmcx_shim
      integer(c_int32_t) :: cell_id_base, compact_den
      real(c_double) :: const_k, additive_beta
   end type pmcx_config
+
+  !> pmcx_trans_fields (include/pmcx.h): WRF's fields for the transport probabilities
+  type, bind(c) :: pmcx_trans_fields_t
+     integer(c_int32_t) :: nx, nz, ny, do_vertmix, all_columns, i_offset, j_offset, global_nx, global_ny
+     real(c_double) :: dt, dx, dy
+     type(c_ptr) :: alt, xkhh, u_flux, v_flux, w_flux, z, z_at_w, exch_h
+  end type pmcx_trans_fields_t
 
   interface
      subroutine pmcx_config_default(cfg) bind(c, name="pmcx_config_default")
@@ -172,11 +180,46 @@ module pmcx_shim
        import :: c_ptr, c_int, c_int32_t, c_int64_t, c_double
        type(c_ptr), value :: ctx
        integer(c_int32_t), value :: nx, nz, ny, periodic_x, periodic_y
-       real(c_double), intent(in) :: prob_h(*), prob_v(*), cell_volume(*)
+       type(c_ptr), value :: prob_h, prob_v        ! c_null_ptr twice: the probabilities built on the device
+       real(c_double), intent(in) :: cell_volume(*)
        integer(c_int64_t), value :: seed
        integer(c_int32_t), value :: step
        integer(c_int32_t), intent(out) :: n_moved(*), n_arrived(*)
      end function pmcx_transport
+     integer(c_int) function pmcx_transport_preweight(ctx, nx, nz, ny, periodic_x, periodic_y, prob_h, &
+          prob_v, cell_volume, seed, step, expected_num_conc, n_removed) &
+          bind(c, name="pmcx_transport_preweight")
+       import :: c_ptr, c_int, c_int32_t, c_int64_t, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: nx, nz, ny, periodic_x, periodic_y
+       type(c_ptr), value :: prob_h, prob_v        ! c_null_ptr: the ones pmcx_transport_probs built
+       real(c_double), intent(in) :: cell_volume(*)
+       integer(c_int64_t), value :: seed
+       integer(c_int32_t), value :: step
+       real(c_double), intent(out) :: expected_num_conc(*)
+       integer(c_int32_t), intent(out) :: n_removed(*)
+     end function pmcx_transport_preweight
+     integer(c_int) function pmcx_transport_probs(ctx, fields, prob_h, prob_v, n_substeps, bad, &
+          n_class_part) bind(c, name="pmcx_transport_probs")
+       import :: c_ptr, c_int, pmcx_trans_fields_t
+       type(c_ptr), value :: ctx
+       type(pmcx_trans_fields_t), intent(in) :: fields
+       type(c_ptr), value :: prob_h, prob_v, n_substeps, bad, n_class_part
+     end function pmcx_transport_probs
+     integer(c_int) function pmcx_seasalt_emissions(ctx, dt, elapsed_time, seed, step, sea_salt_opt, &
+          i_na, i_cl, ocean_surface, wind_speed, height, mode_class, mode_source, n_emit, rate) &
+          bind(c, name="pmcx_seasalt_emissions")
+       import :: c_ptr, c_int, c_int32_t, c_int64_t, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), value :: dt, elapsed_time
+       integer(c_int64_t), value :: seed
+       integer(c_int32_t), value :: step, sea_salt_opt, i_na, i_cl
+       integer(c_int32_t), intent(in) :: ocean_surface(*)
+       real(c_double), intent(in) :: wind_speed(*), height(*)
+       integer(c_int32_t), intent(in) :: mode_class(*), mode_source(*)
+       integer(c_int32_t), intent(out) :: n_emit(*)
+       type(c_ptr), value :: rate
+     end function pmcx_seasalt_emissions
      integer(c_int) function pmcx_transport_begin(ctx, nx, nz, ny, periodic_x, prob_h, prob_v, &
           cell_volume, seed, step) bind(c, name="pmcx_transport_begin")
        import :: c_ptr, c_int, c_int32_t, c_int64_t, c_double
@@ -638,15 +681,90 @@ contains
        n_moved, n_arrived)
     integer, intent(in) :: nx, nz, ny
     logical, intent(in) :: periodic_x, periodic_y
-    real(kind=dp), intent(in) :: prob_h(:,:,:), prob_v(:,:,:), cell_volume(:)
+    real(kind=dp), intent(in), target :: prob_h(:,:,:), prob_v(:,:,:)
+    real(kind=dp), intent(in) :: cell_volume(:)
     integer, intent(out) :: n_moved(:), n_arrived(:)
     integer(c_int32_t), allocatable :: nm(:), na(:)
     allocate(nm(cfg%n_cells), na(cfg%n_cells))
     call pmcx_die(pmcx_transport(ctx, nx, nz, ny, merge(1, 0, periodic_x), merge(1, 0, periodic_y), &
-         prob_h, prob_v, cell_volume, rng_seed, rng_step, nm, na), 'pmcx_transport')
+         c_loc(prob_h), c_loc(prob_v), cell_volume, rng_seed, rng_step, nm, na), 'pmcx_transport')
     n_moved = nm
     n_arrived = na
   end subroutine trans_cells_pmcx
+
+  !> trans_aero_preweight (interface/wrf_pmc_trans_aero.F90:1103-1423) on the resident cells, with
+  !> the probabilities handed over (as for trans_cells_pmcx).  expected_num_conc(n_class, n_cells).
+  subroutine trans_preweight_cells_pmcx(nx, nz, ny, periodic_x, periodic_y, prob_h, prob_v, &
+       cell_volume, expected_num_conc, n_removed)
+    integer, intent(in) :: nx, nz, ny
+    logical, intent(in) :: periodic_x, periodic_y
+    real(kind=dp), intent(in), target :: prob_h(:,:,:), prob_v(:,:,:)
+    real(kind=dp), intent(in) :: cell_volume(:)
+    real(kind=dp), intent(out) :: expected_num_conc(:,:)
+    integer, intent(out) :: n_removed(:)
+    integer(c_int32_t), allocatable :: nr(:)
+    allocate(nr(cfg%n_cells))
+    call pmcx_die(pmcx_transport_preweight(ctx, nx, nz, ny, merge(1, 0, periodic_x), &
+         merge(1, 0, periodic_y), c_loc(prob_h), c_loc(prob_v), cell_volume, rng_seed, rng_step, &
+         expected_num_conc, nr), 'pmcx_transport_preweight')
+    n_removed = nr
+  end subroutine trans_preweight_cells_pmcx
+
+  !> The whole particle half of wrf_pmc_trans_driver (interface/wrf_pmc_trans.F90:95-200) from WRF's
+  !> fields: probabilities built on the device, preweight, sampling -- nothing but the fields
+  !> crosses the boundary.  The arrays are the tile's copies of grid%alt, %xkhh (one halo cell in
+  !> x and y), %u_flux, %v_flux, %w_flux (class c in the last index), %z, %z_at_w, %exch_h in WRF's
+  !> (i, k, j) order, single precision as the registry declares them.
+  subroutine trans_from_fields_cells_pmcx(nx, nz, ny, periodic_x, periodic_y, dt, dx, dy, &
+       vertmix_onoff, alt, xkhh, u_flux, v_flux, w_flux, z, z_at_w, exch_h, cell_volume, &
+       n_moved, n_arrived)
+    integer, intent(in) :: nx, nz, ny, vertmix_onoff
+    logical, intent(in) :: periodic_x, periodic_y
+    real(kind=dp), intent(in) :: dt, dx, dy
+    real(c_float), intent(in), target :: alt(:,:,:), xkhh(:,:,:), u_flux(:,:,:,:), v_flux(:,:,:,:), &
+         w_flux(:,:,:,:), z(:,:,:), z_at_w(:,:,:), exch_h(:,:,:)
+    real(kind=dp), intent(in) :: cell_volume(:)
+    integer, intent(out) :: n_moved(:), n_arrived(:)
+    type(pmcx_trans_fields_t) :: f
+    integer(c_int32_t), allocatable :: nm(:), na(:), nr(:)
+    real(c_double), allocatable :: ex(:)
+    f%nx = nx; f%nz = nz; f%ny = ny
+    f%do_vertmix = vertmix_onoff
+    f%all_columns = merge(1, 0, periodic_x .and. periodic_y)
+    f%i_offset = 0; f%j_offset = 0; f%global_nx = nx; f%global_ny = ny
+    f%dt = dt; f%dx = dx; f%dy = dy
+    f%alt = c_loc(alt); f%xkhh = c_loc(xkhh); f%u_flux = c_loc(u_flux); f%v_flux = c_loc(v_flux)
+    f%w_flux = c_loc(w_flux); f%z = c_loc(z); f%z_at_w = c_loc(z_at_w); f%exch_h = c_loc(exch_h)
+    call pmcx_die(pmcx_transport_probs(ctx, f, c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr, &
+         c_null_ptr), 'pmcx_transport_probs')
+    allocate(nm(cfg%n_cells), na(cfg%n_cells), nr(cfg%n_cells), ex(cfg%n_cells * cfg%n_class))
+    call pmcx_die(pmcx_transport_preweight(ctx, nx, nz, ny, merge(1, 0, periodic_x), &
+         merge(1, 0, periodic_y), c_null_ptr, c_null_ptr, cell_volume, rng_seed, rng_step, ex, nr), &
+         'pmcx_transport_preweight')
+    call pmcx_die(pmcx_transport(ctx, nx, nz, ny, merge(1, 0, periodic_x), merge(1, 0, periodic_y), &
+         c_null_ptr, c_null_ptr, cell_volume, rng_seed, rng_step, nm, na), 'pmcx_transport')
+    n_moved = nm
+    n_arrived = na
+  end subroutine trans_from_fields_cells_pmcx
+
+  !> seasalt_emissions (interface/wrf_pmc_driver.F90:212-223, 1767-1924) on the resident cells whose
+  !> ocean_surface flag is set; i_na, i_cl: aero_data_spec_by_name (1-based).
+  subroutine seasalt_cells_pmcx(dt, elapsed_time, sea_salt_opt, i_na, i_cl, ocean_surface, wind_speed, &
+       height, mode_class, mode_source, n_emit)
+    real(kind=dp), intent(in) :: dt, elapsed_time
+    integer, intent(in) :: sea_salt_opt, i_na, i_cl
+    integer, intent(in) :: ocean_surface(:), mode_class(:), mode_source(:)
+    real(kind=dp), intent(in) :: wind_speed(:), height(:)
+    integer, intent(out) :: n_emit(:)
+    integer(c_int32_t), allocatable :: oc(:), mc(:), ms(:), ne(:)
+    allocate(oc(cfg%n_cells), ne(cfg%n_cells), mc(size(mode_class)), ms(size(mode_source)))
+    oc = ocean_surface
+    mc = mode_class - 1          ! string_array_find is 1-based
+    ms = mode_source - 1
+    call pmcx_die(pmcx_seasalt_emissions(ctx, dt, elapsed_time, rng_seed, rng_step, sea_salt_opt, &
+         i_na - 1, i_cl - 1, oc, wind_speed, height, mc, ms, ne, c_null_ptr), 'pmcx_seasalt_emissions')
+    n_emit = ne
+  end subroutine seasalt_cells_pmcx
 
   !> Dry deposition of wrf_pmc_dep_aero.F90:28-192 on the resident surface cells
   !> (surface(c) /= 0); the per-cell inputs are the ones the reference reads from grid%.

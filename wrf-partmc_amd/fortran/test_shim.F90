@@ -35,7 +35,8 @@ program test_shim
   integer :: c, i, s, step, u, q, k, nx, nz, ny, lev, n_comp
   integer, allocatable :: cnt(:)
   real(kind=dp) :: t_lo, t_hi
-  integer, allocatable :: n_moved(:), n_arrived(:), n_removed(:), surface(:)
+  integer, allocatable :: n_moved(:), n_arrived(:), n_removed(:), surface(:), n_thinned(:)
+  real(kind=dp), allocatable :: expected(:,:)
   real(kind=dp), allocatable :: prob_h(:,:,:), prob_v(:,:,:), cell_volume(:), ra(:), ustar(:), &
        alpha(:), big_a(:), height(:), inv_density(:)
 
@@ -96,6 +97,7 @@ program test_shim
   if (mode == 2) then
      nx = 2; nz = 2; ny = n_cells / 4
      allocate(n_moved(n_cells), n_arrived(n_cells), n_removed(n_cells), surface(n_cells))
+     allocate(expected(n_class, n_cells), n_thinned(n_cells))
      allocate(prob_h(4, n_class, n_cells), prob_v(nz, n_class, n_cells), cell_volume(n_cells))
      allocate(ra(n_cells), ustar(n_cells), alpha(n_cells), big_a(n_cells), height(n_cells), &
           inv_density(n_cells))
@@ -122,13 +124,16 @@ program test_shim
      call pmcx_upload_states(env_states, aero_data, aero_states, 2 * n_part)
      do step = 0, n_steps - 1
         call pmcx_set_rng(seed, step, 0)
+        call trans_preweight_cells_pmcx(nx, nz, ny, .true., .true., prob_h, prob_v, cell_volume, &
+             expected, n_thinned)
         call trans_cells_pmcx(nx, nz, ny, .true., .true., prob_h, prob_v, cell_volume, &
              n_moved, n_arrived)
         call dry_dep_cells_pmcx(del_t, surface, ra, ustar, alpha, big_a, height, inv_density, &
              n_removed)
         call mc_coag_resident_pmcx(kernel, del_t, n_samp, n_coag)
         call aero_state_rebalance_cells_pmcx(.true., .true.)
-        write(u) n_moved, n_arrived, n_removed, n_samp, n_coag
+        write(u) n_thinned, n_moved, n_arrived, n_removed, n_samp, n_coag
+        write(u) expected
      end do
      call pmcx_download_states(aero_states)
   end if
