@@ -219,6 +219,97 @@ def test_fortran_resident_sequence(tmp_path, wp):
     assert off == len(out)
 
 
+def test_fortran_resident_sequence_from_fields(tmp_path, wp):
+    """The shim's trans_from_fields_cells_pmcx (probabilities from WRF-shaped fields, preweight and
+    sampling on the device: only the fields cross the boundary) and seasalt_cells_pmcx, then
+    mc_coag and rebalance, against the same sequence through the Python host: counters per step
+    and every downloaded particle."""
+    _build()
+    from tests import trans_fields as tf
+    n_cells, n_part, n_spec, n_class, n_source, kernel, n_steps = 8, 600, 2, 2, 2, 4, 3
+    seed, del_t = 77, 600.0
+    nx, nz, ny = 2, 2, n_cells // 4
+    names, dens = parity.default_species(n_spec)
+    rs = np.random.RandomState(6)
+    cap = (2 * n_part + 63) // 64 * 64
+    T = 288.15 - 3.0 * np.arange(n_cells)
+    P = 101325.0 - 4000.0 * np.arange(n_cells)
+    mag = (1e9 / n_part) * (1 + 0.5 * np.arange(n_class))[None, :] * np.ones((n_cells, 1))
+    r = 10 ** rs.uniform(-8.0, -6.0, (n_cells, n_part))
+    frac = rs.uniform(0.1, 0.9, (n_cells, n_part))
+    vtot = 4.0 / 3.0 * np.pi * r ** 3
+    vol = np.stack([vtot * frac, vtot * (1 - frac)], axis=1)
+    wcl = rs.randint(0, n_class, (n_cells, n_part)).astype(np.int32)
+    src = rs.randint(0, n_source, (n_cells, n_part))
+    n_orig = np.zeros((n_cells, n_source, n_part), np.int32)
+    for s in range(n_source):
+        n_orig[:, s, :] = src == s
+    ids = (np.arange(n_cells, dtype=np.int64)[:, None] << 32) + np.arange(1, n_part + 1)
+    lct = np.tile(np.arange(n_part) * 0.5, (n_cells, 1))
+    n_ideal = np.full(n_class, 0.6 * n_part / n_class)
+    buf = struct.pack("<7i", n_cells, n_part, n_spec, n_class, n_source, kernel, n_steps)
+    buf += struct.pack("<q", seed) + struct.pack("<d", del_t) + dens.astype("<f8").tobytes()
+    for c in range(n_cells):
+        buf += struct.pack("<2d", T[c], P[c]) + mag[c].astype("<f8").tobytes() + n_ideal.astype("<f8").tobytes()
+        for i in range(n_part):
+            buf += vol[c, :, i].astype("<f8").tobytes() + n_orig[c, :, i].astype("<i4").tobytes()
+            buf += struct.pack("<i", int(wcl[c, i]) + 1) + struct.pack("<q", int(ids[c, i]))
+            buf += struct.pack("<2d", lct[c, i], lct[c, i] + 1.0)
+    F = tf.make_fields(nx, nz, ny, n_class, seed=2, k_scale=4.0, flux_scale=0.03 * 0.5 * n_part * mag[0, 0])
+    dt, dx, dy = 30.0, 3000.0, 3000.0
+    fb = struct.pack("<3d", dt, dx, dy)
+    for name in ("alt", "xkhh", "u_flux", "v_flux", "w_flux", "z", "z_at_w", "exch_h"):
+        fb += np.ascontiguousarray(F[name], dtype="<f4").tobytes()
+    fin, fout, ffld = tmp_path / "in.bin", tmp_path / "out.bin", tmp_path / "fields.bin"
+    fin.write_bytes(buf); ffld.write_bytes(fb)
+    run = subprocess.run([EXE, str(fin), str(fout), "3", str(ffld)], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    out = fout.read_bytes()
+
+    lev = (np.arange(n_cells) // nx) % nz
+    with wp.CellBlock(n_cells, cap, n_spec, n_class=n_class, n_source=n_source) as blk:
+        blk.set_aero_data(dens)
+        blk.set_env(T, P, np.full(n_cells, 0.5))
+        blk.set_weights(mag)
+        blk.set_n_part_ideal(np.tile(n_ideal, (n_cells, 1)))
+        blk.set_next_id(1 + np.arange(n_cells, dtype=np.int64) * 2 * cap)
+        po = np.arange(n_cells + 1, dtype=np.int64) * n_part
+        blk.upload_cells(0, po, vol.transpose(1, 0, 2).reshape(n_spec, -1), wcl.reshape(-1),
+                         ids.reshape(-1), lct.reshape(-1), lct.reshape(-1) + 1.0,
+                         n_orig.transpose(1, 0, 2).reshape(n_source, -1))
+        off = 0
+        tot_emit = 0
+        for step in range(n_steps):
+            blk.transport_probs(nx, nz, ny, dt, dx, dy, F, download=False)
+            blk.transport_preweight(nx, nz, ny, None, None, np.ones(n_cells), seed=seed, step=step)
+            nm, na = blk.transport(nx, nz, ny, None, None, np.ones(n_cells), seed=seed, step=step)
+            ne, _ = blk.seasalt_emissions(del_t, del_t * step, 1, 0, 1, (lev == 0).astype(np.int32),
+                                          6.0 + 0.5 * (np.arange(n_cells) + 1), 40.0, seed=seed, step=step,
+                                          mode_class=[0, 1], mode_source=[0, 1])
+            ns, nc, st = blk.mc_coag(kernel, del_t, seed, step)
+            assert not (st & 3).any()
+            blk.aero_state_rebalance(True, True, seed, step)
+            for want in (nm, na, ne, ns, nc):
+                got = np.frombuffer(out, "<i4", n_cells, off); off += 4 * n_cells
+                assert np.array_equal(got, want), step
+            tot_emit += int(ne.sum())
+            assert nm.sum() > 0 and nc.sum() > 0
+        assert tot_emit > 0
+        d = blk.download_cells()
+    rec = 8 * n_spec + 4 * n_source + 4 + 8 + 16 + 4 + 8 + 8 + 4 + 16
+    po = d["part_offset"]
+    for c in range(n_cells):
+        n = int(np.frombuffer(out, "<i4", 1, off)[0]); off += 4
+        assert n == po[c + 1] - po[c]
+        blob = np.frombuffer(out, np.uint8, rec * n, off).reshape(n, rec); off += rec * n
+        sl = slice(po[c], po[c + 1])
+        o = 8 * n_spec
+        assert np.array_equal(blob[:, :o].copy().view("<f8").T, d["vol"][:, sl])
+        o += 4 * n_source
+        assert np.array_equal(blob[:, o + 4:o + 12].copy().view("<i8")[:, 0], d["id"][sl])
+    assert off == len(out)
+
+
 def test_transport_across_two_ranks():
     """The N > 1 form of the transport: two processes (one slab each, sharing this GPU, gloo
     rendezvous on 127.0.0.1) exchange their boundary rows' movers with

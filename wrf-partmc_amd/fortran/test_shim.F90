@@ -4,7 +4,12 @@
 ! (batched).  Input and output are raw binary files so a test can compare the
 ! result bit for bit with the CPU oracle.
 !
-! usage: test_shim <in.bin> <out.bin> <mode: 0 per-cell, 1 batched, 2 resident>
+! usage: test_shim <in.bin> <out.bin> <mode: 0 per-cell, 1 batched, 2 resident, 3 resident from fields> [fields.bin]
+! mode 3: as mode 2, but the transport is driven from WRF-shaped fields (fields.bin: float64 dt, dx,
+!         dy; float32 alt, xkhh (nx+2, nz, ny+2), u_flux (nx+1, nz, ny, n_class), v_flux (nx, nz,
+!         ny+1, n_class), w_flux (nx, nz+1, ny, n_class), z (nx, nz, ny), z_at_w, exch_h (nx, nz+1,
+!         ny)) through trans_from_fields_cells_pmcx, followed by seasalt_cells_pmcx on level 0
+!         (the per-step record is then n_moved, n_arrived, n_emit, n_samp, n_coag)
 ! mode 2: the cells are a 2 x 2 x (n_cells / 4) grid (x, level, y), uploaded once; every step
 !         runs transport, dry deposition on level 0 and mc_coag on the device; one download at
 !         the end (the per-step record is then n_moved, n_arrived, n_removed, n_samp, n_coag)
@@ -37,6 +42,13 @@ program test_shim
   real(kind=dp) :: t_lo, t_hi
   integer, allocatable :: n_moved(:), n_arrived(:), n_removed(:), surface(:), n_thinned(:)
   real(kind=dp), allocatable :: expected(:,:)
+  character(len=512) :: ffields
+  integer :: uf
+  real(kind=dp) :: f_dt, f_dx, f_dy
+  real(c_float), allocatable :: f_alt(:,:,:), f_xkhh(:,:,:), f_u(:,:,:,:), f_v(:,:,:,:), f_w(:,:,:,:), &
+       f_z(:,:,:), f_zw(:,:,:), f_exch(:,:,:)
+  integer, allocatable :: n_emit(:), ocean(:)
+  real(kind=dp), allocatable :: wind(:)
   real(kind=dp), allocatable :: prob_h(:,:,:), prob_v(:,:,:), cell_volume(:), ra(:), ustar(:), &
        alpha(:), big_a(:), height(:), inv_density(:)
 
@@ -94,6 +106,38 @@ program test_shim
   close(u)
 
   open(newunit=u, file=trim(fout), access='stream', form='unformatted', status='replace')
+  if (mode == 3) then
+     nx = 2; nz = 2; ny = n_cells / 4
+     call get_command_argument(4, ffields)
+     open(newunit=uf, file=trim(ffields), access='stream', form='unformatted', status='old')
+     allocate(f_alt(nx + 2, nz, ny + 2), f_xkhh(nx + 2, nz, ny + 2), f_u(nx + 1, nz, ny, n_class), &
+          f_v(nx, nz, ny + 1, n_class), f_w(nx, nz + 1, ny, n_class), f_z(nx, nz, ny), &
+          f_zw(nx, nz + 1, ny), f_exch(nx, nz + 1, ny))
+     read(uf) f_dt, f_dx, f_dy
+     read(uf) f_alt, f_xkhh, f_u, f_v, f_w, f_z, f_zw, f_exch
+     close(uf)
+     allocate(n_moved(n_cells), n_arrived(n_cells), n_emit(n_cells), ocean(n_cells), wind(n_cells), &
+          cell_volume(n_cells), height(n_cells))
+     do c = 1, n_cells
+        lev = mod((c - 1) / nx, nz)
+        ocean(c) = merge(1, 0, lev == 0)
+        wind(c) = 6d0 + 0.5d0 * c
+        height(c) = 40d0
+        cell_volume(c) = 1d0
+     end do
+     call pmcx_set_rng(seed, 0, 0)
+     call pmcx_upload_states(env_states, aero_data, aero_states, 2 * n_part)
+     do step = 0, n_steps - 1
+        call pmcx_set_rng(seed, step, 0)
+        call trans_from_fields_cells_pmcx(nx, nz, ny, .true., .true., f_dt, f_dx, f_dy, 1, f_alt, f_xkhh, &
+             f_u, f_v, f_w, f_z, f_zw, f_exch, cell_volume, n_moved, n_arrived)
+        call seasalt_cells_pmcx(del_t, del_t * step, 1, 1, 2, ocean, wind, height, (/1, 2/), (/1, 2/), n_emit)
+        call mc_coag_resident_pmcx(kernel, del_t, n_samp, n_coag)
+        call aero_state_rebalance_cells_pmcx(.true., .true.)
+        write(u) n_moved, n_arrived, n_emit, n_samp, n_coag
+     end do
+     call pmcx_download_states(aero_states)
+  end if
   if (mode == 2) then
      nx = 2; nz = 2; ny = n_cells / 4
      allocate(n_moved(n_cells), n_arrived(n_cells), n_removed(n_cells), surface(n_cells))
@@ -137,7 +181,7 @@ program test_shim
      end do
      call pmcx_download_states(aero_states)
   end if
-  do step = 0, merge(-1, n_steps - 1, mode == 2)
+  do step = 0, merge(-1, n_steps - 1, mode >= 2)
      if (mode == 1) then
         call pmcx_set_rng(seed, step, 0)
         call partmc_coag_cells_pmcx(kernel, env_states, aero_data, aero_states, del_t, &
