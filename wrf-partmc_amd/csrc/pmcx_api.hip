@@ -1932,7 +1932,11 @@ int pmcx_get_sort(pmcx_ctx *ctx, int32_t cell, uint32_t *perm, int32_t *gcnt, in
     if (!ctx || cell < 0 || cell >= ctx->cfg.n_cells) return fail(ctx, PMCX_EINVAL, "pmcx_get_sort: bad argument");
     const size_t pcap = (size_t)ctx->st.pcap, G = (size_t)ctx->cfg.n_class * ctx->cfg.n_bin;
     int rc = PMCX_OK;
-    if (perm) rc = copy_cells_d2h(ctx, perm, ctx->st.perm + cell * pcap, sizeof(uint32_t) * pcap);
+    if (perm) { // (the lists hold 16-bit slot numbers; the interface keeps its 32-bit entries)
+        std::vector<uint16_t> h(pcap);
+        rc = copy_cells_d2h(ctx, h.data(), ctx->st.perm + cell * pcap, sizeof(uint16_t) * pcap);
+        for (size_t k = 0; k < pcap; k++) perm[k] = h[k];
+    }
     if (!rc && gcnt) rc = copy_cells_d2h(ctx, gcnt, ctx->st.gcnt + cell * G, sizeof(int32_t) * G);
     if (!rc && goff) rc = copy_cells_d2h(ctx, goff, ctx->st.goff + cell * (G + 1), sizeof(int32_t) * (G + 1));
     return rc;

@@ -72,7 +72,7 @@ struct DeviceState {
     int32_t *n_orig; // [n_cells][n_source - 1][cap] sources 1.. (source 0 is in meta)
     // scratch / outputs of the coagulation step
     // aero_sorted, kept between calls while sort_valid (aero_state%valid_sort)
-    uint32_t *perm;  // [n_cells][pcap] slot lists, group after group, room behind each
+    uint16_t *perm;  // [n_cells][pcap] slot lists (slots are below 65 280), group after group, room behind each
     int32_t *gcnt;   // [n_cells][n_class*n_bin] list lengths
     int32_t *goff;   // [n_cells][n_class*n_bin + 1] list starts
     int32_t *sort_valid; // [n_cells]

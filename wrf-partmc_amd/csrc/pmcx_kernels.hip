@@ -77,6 +77,14 @@ __device__ __forceinline__ void st_u32(uint32_t *p, uint32_t v)
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ uint32_t ld_u16(const uint16_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_u16(uint16_t *p, uint32_t v)
+{
+    __hip_atomic_store(p, (uint16_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // particles of source s among the constituents of slot i: the first source sits in the
 // particle's metadata record (it is read and written with the create times), the others in
@@ -671,7 +679,7 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st, const int32_t 
     // same group.  The lanes of a group are collected by OR-ing their lane bit into the
     // group's 64-bit word in LDS (commutative, so the result does not depend on the order
     // the hardware serves the atomics); rank = popcount of the lower lanes in that word.
-    uint32_t *perm = st.perm + (int64_t)c * st.pcap;
+    uint16_t *perm = st.perm + (int64_t)c * st.pcap;
     uint64_t *mymask = pmask + (size_t)wave * G;
     if (t == 0) { st.sort_valid[c] = 1; st.key_valid[c] = 1; st.n_log[c] = 0; }
     for (int i0 = lo; i0 < hi; i0 += 64) {
@@ -685,7 +693,7 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st, const int32_t 
         if (valid) { peers = mymask[gk]; cur = myhist[gk]; }
         const uint32_t rank = (uint32_t)__popcll(peers & lt);
         lds_sync(); // every lane has read the word and the cursor
-        if (valid) perm[cur + rank] = (uint32_t)i; // (not waited for: nothing here reads perm)
+        if (valid) perm[cur + rank] = (uint16_t)i; // (not waited for: nothing here reads perm)
         if (valid && rank == 0) { // the group's first lane advances the cursor, clears the word
             myhist[gk] = cur + (uint32_t)__popcll(peers);
             mymask[gk] = 0;
@@ -739,14 +747,14 @@ __host__ __device__ inline size_t sampler_lds_bytes(int G, int C, int max_append
 
 struct CellCtx {
     CellLds L;
-    uint32_t *perm;
+    uint16_t *perm;
     Hot *hot; // (cached total volume, cached mass, create times) per slot
 };
 
 __device__ __forceinline__ uint32_t list_get(const CellCtx &X, int g, int i)
 {
     const int nb = X.L.nb[g];
-    if (i < nb) return ld_u32(&X.perm[X.L.off[g] + i]);
+    if (i < nb) return ld_u16(&X.perm[X.L.off[g] + i]);
     int e = X.L.last_app[g];
     for (int k = X.L.cnt[g] - 1 - i; k > 0; k--) e = X.L.app_prev[e];
     return X.L.app_slot[e];
@@ -757,7 +765,7 @@ __device__ __forceinline__ void list_set(const CellCtx &X, int g, int i, uint32_
 {
     const int nb = X.L.nb[g];
     if (i < nb) {
-        if (lead) st_u32(&X.perm[X.L.off[g] + i], val);
+        if (lead) st_u16(&X.perm[X.L.off[g] + i], val);
     } else {
         int e = X.L.last_app[g];
         for (int k = X.L.cnt[g] - 1 - i; k > 0; k--) e = X.L.app_prev[e];
@@ -788,7 +796,7 @@ __device__ __forceinline__ int list_append(const CellCtx &X, int g, uint32_t slo
     const int n = X.L.cnt[g];
     int used = 0;
     if (X.L.last_app[g] == 0xFFFF && n < (int)X.L.room[g]) {
-        if (lead) st_u32(&X.perm[X.L.off[g] + n], slot);
+        if (lead) st_u16(&X.perm[X.L.off[g] + n], slot);
         X.L.nb[g] = (uint16_t)(n + 1);
     } else {
         X.L.app_slot[e] = (uint16_t)slot;
@@ -1350,7 +1358,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
     for (int j = lane; j <= B; j += 64) edge[j] = st.v_edge[j];
     for (int j = lane; j <= POISSON_RCP_N; j += 64) rcp[j] = g_poisson_rcp[j];
 
-    uint32_t *perm = st.perm + (int64_t)c * st.pcap;
+    uint16_t *perm = st.perm + (int64_t)c * st.pcap;
     Hot *hot = st.hot + cb;    // cached total volume and mass, create times: one line per particle
     Cold *cold = st.cold + cb; // id, first source count (touched by events with sources only)
     // (per-lane pointers cost two registers each: the rarely used ones are formed on use)
@@ -2192,14 +2200,14 @@ __device__ void compact_wave(const DeviceState &st, int c, int lane, uint32_t *c
     if (lists && base != n_hi) {
         // every position of perm up to the end of the last list; room behind a list holds
         // stale entries, renaming them is harmless
-        uint32_t *perm = st.perm + (int64_t)c * st.pcap;
+        uint16_t *perm = st.perm + (int64_t)c * st.pcap;
         const int G = st.n_bin * st.n_class;
         const int used = st.goff[(int64_t)c * (G + 1) + G];
         for (int j = lane; j < used; j += 64) {
             const uint32_t e = perm[j];
             if (e < (uint32_t)n_hi) {
                 const uint32_t k = e >> 6;
-                perm[j] = cbase[k] + (uint32_t)__popcll(cmask[k] & ((1ull << (e & 63)) - 1ull));
+                perm[j] = (uint16_t)(cbase[k] + (uint32_t)__popcll(cmask[k] & ((1ull << (e & 63)) - 1ull)));
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
