@@ -285,8 +285,11 @@ int pmcx_transport_probs(pmcx_ctx *ctx, const pmcx_trans_fields *f, double *prob
  * (also towards the boundary cells); a lateral boundary cell only sends inwards, with
  * min(prob_advection + prob_diffusion, 1); a corner cell sends nothing; what is sent to a boundary
  * cell leaves the domain.  The boundary cells are then refilled by pmcx_boundary_copy (outflow) or
- * pmcx_boundary_resample (inflow), as :803-955 does.  One block of at least 3 x 3 columns. */
-int pmcx_set_transport_lateral(pmcx_ctx *ctx, int32_t on);
+ * pmcx_boundary_resample (inflow), as :803-955 does.  At least 3 x 3 columns.  For a slab of a
+ * domain cut in y (pmcx_transport_begin .. _finish): j_global0 = the domain row its row 0 stands
+ * for (-1 for the first rank's lower ghost row), global_ny = the domain's rows; 0, 0: the block is
+ * the domain (pmcx_transport). */
+int pmcx_set_transport_lateral(pmcx_ctx *ctx, int32_t on, int32_t j_global0, int32_t global_ny);
 
 /* The refill of the lateral boundary cells after the transport (interface/
  * wrf_pmc_trans_aero.F90:803-955).

@@ -70,6 +70,53 @@ def main():
         sel = np.concatenate([np.arange(ref["part_offset"][c], ref["part_offset"][c + 1]) for c in real])
         for k in ("vol", "wclass", "id", "least_ct", "greatest_ct", "n_orig"):
             assert np.array_equal(got[k], ref[k][..., sel]), (rank, step, k)
+    whole.close(); b.close()
+
+    # ---- open lateral boundaries (neither direction periodic), the refill included ----
+    whole = wp.CellBlock(n, cap, n_spec, n_class=n_class, n_source=2)
+    whole.set_aero_data(dens); whole.set_env(280.0, 9e4); whole.set_weights(mag)
+    whole.set_next_id((np.arange(n, dtype=np.int64) << 32) + (1 << 20))
+    whole.set_n_part_ideal(np.full((n, n_class), 1e9))
+    whole.generate_lognormal(n_part, modes, seed=4)
+    whole.set_transport_lateral(True)
+    dn = whole.download_cells()
+    rows = [j0 - 1, j0, j0 + 1, j0 + 2, j0 + 3]                    # (rows outside the domain: unused ghosts)
+    cells = np.concatenate([np.arange((j % ny) * row, ((j % ny) + 1) * row) for j in rows])
+    real = cells[row:-row]
+    b = wp.CellBlock(len(cells), cap, n_spec, n_class=n_class, n_source=2,
+                     cell_id_base=((j0 - 1) * row) % (1 << 32))
+    b.set_aero_data(dens); b.set_env(280.0, 9e4); b.set_weights(mag[cells])
+    b.set_next_id((cells.astype(np.int64) << 32) + (1 << 20))
+    b.set_n_part_ideal(np.full((len(cells), n_class), 1e9))
+    b.set_transport_lateral(True, j0 - 1, ny)
+    po = np.concatenate([[0], np.cumsum(np.diff(dn["part_offset"])[real])])
+    sel = np.concatenate([np.arange(dn["part_offset"][c], dn["part_offset"][c + 1]) for c in real])
+    b.upload_cells(row, po, dn["vol"][:, sel], dn["wclass"][sel], dn["id"][sel], dn["least_ct"][sel],
+                   dn["greatest_ct"][sel], dn["n_orig"][:, sel])
+    for g0 in (0, len(cells) - row):
+        b.upload_cells(g0, np.zeros(row + 1, np.int64), np.zeros((n_spec, 0)))
+    bg = [dict(gm_radius=5e-8, gsd_log10=0.2, vol_frac=[0.5, 0.5], wclass=0, source=0),
+          dict(gm_radius=1e-7, gsd_log10=0.2, vol_frac=[1.0, 0.0], wclass=1, source=1)]
+    rho = rng.uniform(0.9, 1.2, n)
+    bg_conc = np.stack([0.8 * n_part / n_class * mag[:, 0] / rho, 1.3 * n_part / n_class * mag[:, 1] / rho], axis=1)
+    for step in range(2):
+        u_w = rng.normal(0, 1, (ny, nz)); u_e = rng.normal(0, 1, (ny, nz))
+        v_s = rng.normal(0, 1, (nx, nz)); v_n = rng.normal(0, 1, (nx, nz))
+        nm_w, na_w = whole.transport(nx, nz, ny, ph, pv, cv, 21, step, False, False)
+        out_w = whole.lateral_boundary_conditions(nx, nz, ny, u_w, u_e, v_s, v_n, bg, bg_conc, rho, seed=21, step=step)
+        nm, na = b.transport_distributed(dist, nx, nz, 5, ph[cells], pv[cells], cv[cells], 21, step, False, False)
+        assert np.array_equal(nm[row:-row], nm_w[real]) and np.array_equal(na[row:-row], na_w[real]), (rank, step)
+        lj = [(j % ny) for j in rows]
+        out = b.lateral_boundary_conditions(nx, nz, 5, u_w[lj], u_e[lj], v_s, v_n, bg, bg_conc[cells], rho[cells],
+                                            seed=21, step=step, j_global0=j0 - 1, global_ny=ny)
+        assert len(out["copied"]) + len(out["resampled"]) > 0
+        ref = whole.download_cells()
+        got = b.download_cells(row, len(real))
+        sel = np.concatenate([np.arange(ref["part_offset"][c], ref["part_offset"][c + 1]) for c in real])
+        assert np.array_equal(np.diff(got["part_offset"]), np.diff(ref["part_offset"])[real]), (rank, step)
+        for k in ("vol", "wclass", "id", "least_ct", "greatest_ct", "n_orig"):
+            assert np.array_equal(got[k], ref[k][..., sel]), (rank, step, k)
+        assert np.array_equal(b.get_weights()[row:-row], whole.get_weights()[real])
     dist.barrier()
     if rank == 0:
         print(f"distributed transport ok: {world} ranks, {int(nm_w.sum())} movers in the last step")

@@ -749,10 +749,14 @@ int pmcx_invalidate_sort(pmcx_ctx *ctx)
     return PMCX_OK;
 }
 
-int pmcx_set_transport_lateral(pmcx_ctx *ctx, int32_t on)
+int pmcx_set_transport_lateral(pmcx_ctx *ctx, int32_t on, int32_t j_global0, int32_t global_ny)
 {
     if (!ctx) return PMCX_EINVAL;
+    if (global_ny < 0 || (global_ny == 0 && j_global0 != 0))
+        return fail(ctx, PMCX_EINVAL, "pmcx_set_transport_lateral: global_ny = 0 means the block is the domain (j_global0 = 0)");
     ctx->st.trans_lateral = on ? 1 : 0;
+    ctx->st.trans_j0 = j_global0;
+    ctx->st.trans_gny = global_ny;
     return PMCX_OK;
 }
 
@@ -1100,9 +1104,11 @@ int pmcx_transport(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int32_t pe
     const pmcx_config &cf = ctx->cfg;
     if (nx < 1 || nz < 1 || ny < 1 || nz > 128 || (int64_t)nx * nz * ny != cf.n_cells)
         return fail(ctx, PMCX_EINVAL, "pmcx_transport: nx*nz*ny must equal n_cells (nz <= 128)");
-    if (ctx->st.trans_lateral && (periodic_x || periodic_y || nx < 3 || ny < 3))
+    if (ctx->st.trans_lateral && (periodic_x || periodic_y || nx < 3 || ny < 3 || ctx->st.trans_j0 != 0 ||
+                                  (ctx->st.trans_gny != 0 && ctx->st.trans_gny != ny)))
         return fail(ctx, PMCX_EINVAL, "pmcx_transport: open lateral boundaries (pmcx_set_transport_lateral) "
-                                      "need a non-periodic block of at least 3 x 3 columns");
+                                      "need a non-periodic block of at least 3 x 3 columns that is the whole "
+                                      "domain (a slab goes through pmcx_transport_begin)");
     if (transport_lds_bytes(ctx->st, nz) > 160 * 1024)
         return fail(ctx, PMCX_EINVAL, "pmcx_transport: n_class x (4+nz) destination tables exceed LDS");
     HIP_TRY(ctx, hipSetDevice(cf.device));
@@ -1494,9 +1500,9 @@ int pmcx_transport_begin(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int3
                                       "(two ghost rows), nz <= 128");
     if (transport_lds_bytes(ctx->st, nz) > 160 * 1024)
         return fail(ctx, PMCX_EINVAL, "pmcx_transport_begin: destination tables exceed LDS");
-    if (ctx->st.trans_lateral)
-        return fail(ctx, PMCX_EINVAL, "pmcx_transport_begin: open lateral boundaries are built for one block "
-                                      "of cells only (pmcx_transport)");
+    if (ctx->st.trans_lateral && (periodic_x || nx < 3 || ctx->st.trans_gny < 3))
+        return fail(ctx, PMCX_EINVAL, "pmcx_transport_begin: open lateral boundaries need a non-periodic domain "
+                                      "and the slab's place in it (pmcx_set_transport_lateral)");
     HIP_TRY(ctx, hipSetDevice(cf.device));
     int rc = transport_buffers(ctx);
     if (rc) return rc;

@@ -86,6 +86,7 @@ struct DeviceState {
     uint32_t *evlog;     // [n_cells][EVLOG_CAP]
     int32_t *n_log;      // [n_cells]
     int32_t trans_lateral; // pmcx_set_transport_lateral: the reference's open lateral boundaries
+    int32_t trans_j0, trans_gny; // a slab's place in the domain: the row its row 0 stands for, the domain's rows (0: the block is the domain)
     // pmcx_set_sampler_variant (diagnostic): 0 = the library's own choice
     int32_t force_lanes, force_wpb, force_stamps;
     uint16_t *seq_ovf;   // [n_cells][2 G + 2 max_appends] lane-per-cell sampler: entries past a group's room

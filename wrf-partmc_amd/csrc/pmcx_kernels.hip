@@ -2766,6 +2766,13 @@ __global__ __launch_bounds__(256) void k_dry_deposition(DeviceState st, DepArgs 
 
 constexpr int TRANS_MAX_COPIES = 16;
 
+// open lateral boundaries: is local row j the domain's first or last row?
+__device__ __forceinline__ bool lateral_row(const DeviceState &st, int j, int ny)
+{
+    const int gj = j + st.trans_j0, gny = st.trans_gny ? st.trans_gny : ny;
+    return gj == 0 || gj == gny - 1;
+}
+
 struct TransGrid {
     int32_t nx, nz, ny, periodic_x, periodic_y;
     const double *prob_h, *prob_v, *cell_volume;
@@ -2813,7 +2820,7 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
         double *p = t_p + cl * ND;
         int *dc = t_tmpd + cl * ND;
         int *ord = t_cnt + cl * ND; // rank -> element (t_cnt is cleared again below)
-        const bool bx = (i == 0 || i == nx - 1), by = (j == 0 || j == ny - 1);
+        const bool bx = (i == 0 || i == nx - 1), by = lateral_row(st, j, ny);
         const bool lateral_cell = st.trans_lateral && (bx || by);
         int n = 0;
         for (int d0 = 0; d0 < ND; d0 += 64) {
@@ -2824,7 +2831,7 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
                 if (lateral_cell) {
                     // open lateral boundaries (wrf_pmc_trans_aero.F90:689-768): a boundary cell only
                     // sends inwards, with min(prob, 1); a corner sends nothing
-                    const int din = i == 0 ? 1 : i == nx - 1 ? 0 : j == 0 ? 3 : 2;
+                    const int din = i == 0 ? 1 : i == nx - 1 ? 0 : (j + st.trans_j0 == 0) ? 3 : 2;
                     if (!(bx && by) && d == din) {
                         pr = tg.prob_h[((int64_t)c * C + cl) * 4 + d];
                         if (pr > 1.0) pr = 1.0;
@@ -2999,7 +3006,7 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
         if (x % ND < t_n[x / ND] && t_cnt[x] > 0) {
             const int dcell = t_dest[x], di_ = dcell % nx, dj_ = dcell / (nx * nz);
             // (what is sent to an open lateral boundary cell leaves the domain: nobody gathers it)
-            if (st.trans_lateral && (di_ == 0 || di_ == nx - 1 || dj_ == 0 || dj_ == ny - 1)) continue;
+            if (st.trans_lateral && (di_ == 0 || di_ == nx - 1 || lateral_row(st, dj_, ny))) continue;
             atomicAdd(&tg.n_exp[dcell], t_cnt[x]);
         }
     for (int d = 32; d >= 1; d >>= 1) bits |= __shfl_xor(bits, d, 64);
@@ -3658,7 +3665,7 @@ __global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid t
     const int lane = threadIdx.x, c = tg.c_first + blockIdx.x;
     const int nx = tg.nx, nz = tg.nz, ny = tg.ny;
     const int i = c % nx, k = (c / nx) % nz, j = c / (nx * nz);
-    if (st.trans_lateral && (i == 0 || i == nx - 1 || j == 0 || j == ny - 1)) {
+    if (st.trans_lateral && (i == 0 || i == nx - 1 || lateral_row(st, j, ny))) {
         if (lane == 0) tg.n_arr[c] = 0; // an open lateral boundary cell takes nothing in (:775-801)
         return;
     }

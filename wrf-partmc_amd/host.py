@@ -177,7 +177,7 @@ def load_library():
     L.pmcx_transport_preweight_begin.argtypes = [C.c_void_p] + [C.c_int32] * 7 + [C.c_void_p] * 4
     L.pmcx_transport_preweight_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                                   C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
-    L.pmcx_set_transport_lateral.argtypes = [C.c_void_p, C.c_int32]
+    L.pmcx_set_transport_lateral.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     L.pmcx_boundary_copy.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     L.pmcx_boundary_resample.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_double, C.c_uint64, C.c_uint32, C.c_void_p,
@@ -653,10 +653,12 @@ class CellBlock:
         return ph, pv, ns, bad, ncp
 
     # -- open lateral boundaries (wrf_pmc_trans_aero.F90:497-534, 689-955) -----------------
-    def set_transport_lateral(self, on=True):
-        """transport() then treats the block's lateral boundary cells as the reference's real
-        case does: they only send inwards, corners nothing, what reaches them leaves the domain."""
-        self._ck(self._lib.pmcx_set_transport_lateral(self._h, int(bool(on))))
+    def set_transport_lateral(self, on=True, j_global0=0, global_ny=0):
+        """transport() then treats the domain's lateral boundary cells as the reference's real
+        case does: they only send inwards, corners nothing, what reaches them leaves the domain.
+        A slab (transport_distributed) says where it lies: j_global0 = the domain row of its row 0
+        (its lower ghost row), global_ny = the domain's rows."""
+        self._ck(self._lib.pmcx_set_transport_lateral(self._h, int(bool(on)), j_global0, global_ny))
 
     def boundary_copy(self, from_cells, to_cells):
         """Outflow: every to_cell becomes a copy of its from_cell (aero_state_dup_all_particles)."""
@@ -692,7 +694,7 @@ class CellBlock:
     def lateral_boundary_conditions(self, nx, nz, ny, u_west, u_east, v_south, v_north, background,
                                     background_conc, density, seed=0, step=0, u_west_old=None,
                                     u_east_old=None, v_south_old=None, v_north_old=None,
-                                    change_boundary_conditions=False):
+                                    change_boundary_conditions=False, j_global0=0, global_ny=None):
         """The refill of the lateral boundary cells after the transport, as
         wrf_pmc_trans_aero.F90:803-955 orders it: on the west side (i = 0, rows 1 .. ny-2) a cell
         whose u (grid%u_2 at its outer face; u_west [ny][nz]) is negative copies its inner
@@ -701,8 +703,17 @@ class CellBlock:
         next time level; east (u_east: the face behind i = nx-1, outflow when positive), south
         (v_south [nx][nz], columns 1 .. nx-2) and north alike.  background_conc, density: per cell
         of the block ([n_cells][n_mode], [n_cells]); only the boundary cells' rows are used.
+        A slab of a domain cut in y (rows 0 and ny - 1 ghosts) passes j_global0 (the domain row
+        of its row 0) and global_ny: its west and east columns are refilled on its own real rows,
+        the south / north row only by the rank that holds it (u_west, u_east indexed by local row).
         Returns dict(copied=[cells], resampled=[cells], n_added, n_removed)."""
         cell = lambda i, k, j: (j * nz + k) * nx + i
+        gny = ny if global_ny is None else global_ny
+        slab = global_ny is not None
+        rows = [j for j in (range(1, ny - 1) if slab else range(ny)) if 0 <= j + j_global0 < gny]
+        x_rows = [j for j in rows if 0 < j + j_global0 < gny - 1]
+        j_south = [j for j in rows if j + j_global0 == 0]
+        j_north = [j for j in rows if j + j_global0 == gny - 1]
         u_w, u_e = np.asarray(u_west, float), np.asarray(u_east, float)
         v_s, v_n = np.asarray(v_south, float), np.asarray(v_north, float)
         old = [None if a is None else np.asarray(a, float)
@@ -716,14 +727,15 @@ class CellBlock:
                 else:
                     turned = vel_old is not None and v * vel_old[idx] < 0.0
                     res.append(c); thr.append(int(turned or change_boundary_conditions))
-        side([(cell(0, k, j), cell(1, k, j), (j, k)) for j in range(1, ny - 1) for k in range(nz)],
-             u_w, old[0], True)
-        side([(cell(nx - 1, k, j), cell(nx - 2, k, j), (j, k)) for j in range(1, ny - 1) for k in range(nz)],
+        side([(cell(0, k, j), cell(1, k, j), (j, k)) for j in x_rows for k in range(nz)], u_w, old[0], True)
+        side([(cell(nx - 1, k, j), cell(nx - 2, k, j), (j, k)) for j in x_rows for k in range(nz)],
              u_e, old[1], False)
-        side([(cell(i, k, 0), cell(i, k, 1), (i, k)) for i in range(1, nx - 1) for k in range(nz)],
-             v_s, old[2], True)
-        side([(cell(i, k, ny - 1), cell(i, k, ny - 2), (i, k)) for i in range(1, nx - 1) for k in range(nz)],
-             v_n, old[3], False)
+        for j in j_south:
+            side([(cell(i, k, j), cell(i, k, j + 1), (i, k)) for i in range(1, nx - 1) for k in range(nz)],
+                 v_s, old[2], True)
+        for j in j_north:
+            side([(cell(i, k, j), cell(i, k, j - 1), (i, k)) for i in range(1, nx - 1) for k in range(nz)],
+                 v_n, old[3], False)
         if frm:
             self.boundary_copy(frm, to)
         na = nr = np.zeros(0, dtype=np.int32)
