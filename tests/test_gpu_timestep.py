@@ -211,3 +211,60 @@ def test_transport_import_rejects_a_bad_buffer(wp):
         for _ in range(3):
             begin(); blk.transport_import(0, None); blk.transport_import(1, None); blk.transport_finish()
         assert blk.memory_bytes() == m0
+
+
+def test_transport_driver_calls_refuse_bad_input(wp):
+    """The error behaviour of the transport driver's entry points: every misuse comes back as a
+    PmcxError with the reason (the reference aborts; the C-ABI returns a status and a message)."""
+    from tests import trans_fields as tf
+    nx, nz, ny = 3, 4, 3
+    n = nx * nz * ny
+    with wp.CellBlock(n, 512, 1) as blk:
+        blk.set_aero_data([1800.0]); blk.set_env(285.0, 9e4)
+        blk.set_weights(np.full((n, 1), 1e6))
+        blk.generate_lognormal(300, [dict(frac=1.0, gm_radius=5e-8, gsd_log10=0.2, vol_frac=[1.0])], seed=1)
+        cv = np.ones(n)
+        with pytest.raises(wp.PmcxError, match="n_part_ideal"):
+            blk.transport_preweight(nx, nz, ny, 0.01, 0.01, cv)                 # ideal counts not set
+        blk.set_n_part_ideal(np.full((n, 1), 300.0))
+        with pytest.raises(wp.PmcxError, match="built"):
+            blk.transport_preweight(nx, nz, ny, None, None, cv)                 # nothing built yet
+        with pytest.raises(wp.PmcxError, match="built"):
+            blk.transport(nx, nz, ny, None, None, cv)
+        with pytest.raises(wp.PmcxError):
+            blk.transport(nx, nz, ny, np.full((n, 1, 4), 0.01), None, cv)       # one of the two
+        F = tf.make_fields(nx, nz, ny, 1, seed=0)
+        with pytest.raises(ValueError, match="shape"):
+            blk.transport_probs(nx, nz, ny, 20.0, 1e3, 1e3, dict(F, alt=F["alt"][1:]))
+        with pytest.raises(wp.PmcxError, match="positive"):
+            blk.transport_probs(nx, nz, ny, 0.0, 1e3, 1e3, F)
+        with pytest.raises(wp.PmcxError, match="n_cells"):
+            blk.transport_probs(nx, nz, ny + 1, 20.0, 1e3, 1e3, tf.make_fields(nx, nz, ny + 1, 1))
+        blk.transport_probs(nx, nz, ny, 20.0, 1e3, 1e3, F, download=False)
+        with pytest.raises(wp.PmcxError, match="built"):
+            blk.transport(nx, nz + 1, ny, None, None, cv)                       # built for another grid
+        blk.transport_preweight(nx, nz, ny, None, None, cv)                     # leaves them in place
+        blk.transport(nx, nz, ny, None, None, cv)                               # consumes them
+        with pytest.raises(wp.PmcxError, match="built"):
+            blk.transport(nx, nz, ny, None, None, cv)
+        with pytest.raises(wp.PmcxError, match="itself"):
+            blk.boundary_copy([1], [1])
+        with pytest.raises(wp.PmcxError, match="twice"):
+            blk.boundary_copy([1, 2], [0, 0])
+        with pytest.raises(wp.PmcxError, match="both"):
+            blk.boundary_copy([1, 2], [2, 3])
+        with pytest.raises(wp.PmcxError, match="outside"):
+            blk.boundary_copy([1], [n])
+        bg = [dict(gm_radius=5e-8, gsd_log10=0.2, vol_frac=[1.0])]
+        with pytest.raises(wp.PmcxError, match="twice"):
+            blk.boundary_resample([4, 4], 0, bg, np.full((2, 1), 1e8), 1.1)
+        with pytest.raises(wp.PmcxError, match="density"):
+            blk.boundary_resample([4], 0, bg, np.full((1, 1), 1e8), 0.0)
+        blk.set_transport_lateral(True)
+        with pytest.raises(wp.PmcxError, match="lateral"):
+            blk.transport(nx, nz, ny, 0.01, 0.01, cv, 0, 0, True, True)         # needs both non-periodic
+        with pytest.raises(wp.PmcxError, match="lateral"):
+            blk.set_transport_lateral(True, 2, 0)
+        blk.set_transport_lateral(False)
+        blk.transport(nx, nz, ny, 0.01, 0.01, cv, 0, 1, True, True)
+        assert not blk.coag_counters()[2].any()
