@@ -21,8 +21,8 @@
 //                  the slots by (class, bin) -> perm, gcnt, goff.  Streams
 //                  vtot once: the HBM-bound pass (12 B per particle).
 //   k_coag_lane    the pair sampler for large blocks of cells: ONE LANE PER CELL, every
-//                  lane runs the sequential PartMC sweep of its own cell; bound by the
-//                  instructions a wavefront issues per pass.
+//                  lane runs the sequential PartMC sweep of its own cell; at the full domain
+//                  bound by the random 64-byte lines its lists ask for.
 //   k_coag_sample  the pair sampler for small blocks (or many classes): 8, 16 or 64 lanes
 //                  per cell; candidate pairs of the sweep evaluated a window at a time, first
 //                  accepted pair found by ballot, applied, later slots redrawn.
@@ -1287,10 +1287,11 @@ __device__ unsigned long long g_seq_stamps[12];
 
 // ---------------------------------------- coag sampler, lane per cell, block-wise draws
 //
-// k_coag_lane.  What bounds this kernel, once its memory requests were cut (one 32-byte record
-// per particle), is the instructions a wavefront issues per pass: stamped (the STAMPS instantiation),
+// k_coag_lane.  Once its memory requests were cut (one 32-byte record per particle) the kernel
+// was bound by the instructions a wavefront issues per pass: stamped (the STAMPS instantiation),
 // more than half of a pass went into finding slots and drawing their counts -- a Philox block
 // and an exponential per slot, and a scan through LDS bit masks in nested divergent loops.
+// Halving those brought it back to the rate the chip serves random lines at.
 // Hence: a lane caches the Philox block and the four bounds of the partner bins gB & ~3 it is
 // sweeping; with one class it scans a register word of the non-empty bins in straight-line
 // code and settles up to NTRY slots per pass with a compare each (count surely zero); the
