@@ -94,3 +94,48 @@ def test_integration_notes_cover_every_entry_point():
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     missing = [s for s in _declared_symbols() if s not in doc]
     assert not missing, missing
+
+
+def test_lateral_boundary_logic_picks_the_cells_the_reference_does():
+    """CellBlock.lateral_boundary_conditions (host logic of wrf_pmc_trans_aero.F90:803-955) on a
+    stand-in block: which boundary cells copy their inner neighbour, which are resampled, which
+    of those are emptied first -- for one block and for a slab of a domain cut in y."""
+    import numpy as np
+    from types import SimpleNamespace
+    from wrf_partmc_amd.host import CellBlock
+
+    class Fake:
+        cfg = SimpleNamespace(n_cells=0)
+        def __init__(self, n): self.cfg = SimpleNamespace(n_cells=n); self.copied = None; self.res = None
+        def boundary_copy(self, f, t): self.copied = (list(f), list(t))
+        def boundary_resample(self, cells, thr, bg, conc, dens, ct, seed, step):
+            self.res = (list(cells), list(thr)); return np.zeros(len(cells), np.int32), np.zeros(len(cells), np.int32)
+
+    nx, nz, ny = 4, 2, 5
+    cell = lambda i, k, j: (j * nz + k) * nx + i
+    u_w = np.full((ny, nz), 1.0); u_w[2, :] = -1.0          # row 2 of the west side flows out
+    u_e = np.full((ny, nz), -1.0); u_e[1, 0] = 2.0          # one east cell flows out
+    v_s = np.full((nx, nz), 1.0); v_n = np.full((nx, nz), 1.0)   # south: inflow, north: outflow
+    u_w_old = u_w.copy(); u_w_old[3, 1] = -0.5              # the wind turned there: emptied first
+    bg = [dict(gm_radius=5e-8, gsd_log10=0.2, vol_frac=[1.0])]
+    f = Fake(nx * nz * ny)
+    out = CellBlock.lateral_boundary_conditions(f, nx, nz, ny, u_w, u_e, v_s, v_n, bg, 1.0, 1.0, u_west_old=u_w_old)
+    pairs = set(zip(*f.copied))
+    assert {(cell(1, k, 2), cell(0, k, 2)) for k in range(nz)} <= pairs           # west outflow row
+    assert (cell(nx - 2, 0, 1), cell(nx - 1, 0, 1)) in pairs                      # the east outflow cell
+    assert {(cell(i, k, ny - 2), cell(i, k, ny - 1)) for i in (1, 2) for k in range(nz)} <= pairs   # north
+    assert len(pairs) == 2 + 1 + 4
+    res, thr = f.res
+    assert cell(0, 0, 0) not in res and cell(nx - 1, 1, ny - 1) not in res and cell(0, 0, 0) not in f.copied[1]  # corners
+    assert set(res) == ({cell(0, k, j) for j in (1, 3) for k in range(nz)} |
+                        {cell(nx - 1, k, j) for j in (1, 2, 3) for k in range(nz)} - {cell(nx - 1, 0, 1)} |
+                        {cell(i, k, 0) for i in (1, 2) for k in range(nz)})
+    assert [c for c, t in zip(res, thr) if t] == [cell(0, 1, 3)]
+    # a slab holding domain rows 2..4 (local rows 1..3, ghosts 0 and 4) of a 5-row domain: its
+    # west/east columns on rows 2, 3; the north row (4) is its own; no south row
+    g = Fake(nx * nz * 5)
+    CellBlock.lateral_boundary_conditions(g, nx, nz, 5, u_w[[1, 2, 3, 4, 0]], u_e[[1, 2, 3, 4, 0]], v_s, v_n, bg, 1.0, 1.0,
+                                          j_global0=1, global_ny=ny)
+    to = set(g.copied[1]) | set(g.res[0])
+    assert to == ({cell(i, k, j) for i in (0, nx - 1) for k in range(nz) for j in (1, 2)} |
+                  {cell(i, k, 3) for i in (1, 2) for k in range(nz)})
