@@ -70,6 +70,38 @@ def main():
         sel = np.concatenate([np.arange(ref["part_offset"][c], ref["part_offset"][c + 1]) for c in real])
         for k in ("vol", "wclass", "id", "least_ct", "greatest_ct", "n_orig"):
             assert np.array_equal(got[k], ref[k][..., sel]), (rank, step, k)
+    # ---- the probabilities built on the device from WRF-shaped fields, slab by slab ----
+    from tests import trans_fields as tf
+    F = tf.make_fields(nx, nz, ny, n_class, seed=7, k_scale=5.0, flux_scale=0.03 * n_part * 1e7)
+    F["v_flux"][:, ny] = F["v_flux"][:, 0]                               # one face: the domain is periodic in y
+    rows5 = [(j0 - 1) % ny, j0, j0 + 1, j0 + 2, (j0 + 3) % ny]
+    halo = lambda a: np.concatenate([a[-1:], a, a[:1]], axis=0)          # periodic rows around the domain
+    alt_p, xk_p = halo(F["alt"][1:-1]), halo(F["xkhh"][1:-1])            # [ny+2][nz][nx+2], rows wrapped
+    Fw = dict(F, alt=alt_p, xkhh=xk_p)
+    # the slab's fields: its five rows (two ghosts) with their own halo rows
+    rr = [(r - 1) % ny for r in rows5[:1]] + rows5 + [(rows5[-1] + 1) % ny]
+    vf = F["v_flux"]                                                     # ny + 1 faces: face j lies below row j
+    Fs = dict(alt=alt_p[[r + 1 for r in rr]], xkhh=xk_p[[r + 1 for r in rr]],
+              u_flux=F["u_flux"][:, rows5], w_flux=F["w_flux"][:, rows5],
+              v_flux=np.stack([vf[:, r] for r in rows5] + [vf[:, rows5[-1] + 1]], axis=1),
+              z=F["z"][rows5], z_at_w=F["z_at_w"][rows5], exch_h=F["exch_h"][rows5])
+    for step in range(3, 5):
+        phw, pvw, nsw, badw, _ = whole.transport_probs(nx, nz, ny, 30.0, 3000.0, 3000.0, Fw)
+        phs, pvs, nss, bads, _ = b.transport_probs(nx, nz, 5, 30.0, 3000.0, 3000.0, Fs, j_offset=j0 - 1,
+                                                   global_nx=nx, global_ny=ny)
+        assert not badw.any() and not bads[row:-row].any()
+        assert np.array_equal(phs[row:-row], phw[real]) and np.array_equal(pvs[row:-row], pvw[real]), (rank, step)
+        ex_w, nr_w = whole.transport_preweight(nx, nz, ny, None, None, cv, 9, step, True, True)
+        ex, nr = b.transport_preweight_distributed(dist, nx, nz, 5, None, None, cv[cells], ny, 9, step)
+        assert np.array_equal(ex[row:-row], ex_w[real]) and np.array_equal(nr[row:-row], nr_w[real]), (rank, step)
+        nm_w, na_w = whole.transport(nx, nz, ny, None, None, cv, 9, step, True, True)
+        nm, na = b.transport_distributed(dist, nx, nz, 5, None, None, cv[cells], 9, step)
+        assert np.array_equal(nm[row:-row], nm_w[real]) and np.array_equal(na[row:-row], na_w[real]), (rank, step)
+        ref = whole.download_cells()
+        got = b.download_cells(row, len(real))
+        sel = np.concatenate([np.arange(ref["part_offset"][c], ref["part_offset"][c + 1]) for c in real])
+        for k in ("vol", "wclass", "id", "least_ct", "greatest_ct", "n_orig"):
+            assert np.array_equal(got[k], ref[k][..., sel]), (rank, step, k)
     whole.close(); b.close()
 
     # ---- open lateral boundaries (neither direction periodic), the refill included ----
