@@ -1254,7 +1254,7 @@ int pmcx_boundary_resample(pmcx_ctx *ctx, int32_t n_list, const int32_t *cell, c
     const int M = background->n_mode;
     if (M < 1 || M > 64 || !background->num_conc) return fail(ctx, PMCX_EINVAL, "pmcx_boundary_resample: bad background");
     // per-cell arrays over the whole block (the kernel's wavefronts leave cells without action alone)
-    std::vector<int32_t> act(nc, 0), pos(nc, -1);
+    std::vector<int32_t> act(nc, 0);
     std::vector<double> conc(nc * (size_t)M, 0.0), dens(nc, 0.0);
     for (int q = 0; q < n_list; q++) {
         const int c = cell[q];
@@ -1262,7 +1262,6 @@ int pmcx_boundary_resample(pmcx_ctx *ctx, int32_t n_list, const int32_t *cell, c
             return fail(ctx, PMCX_EINVAL, "pmcx_boundary_resample: entry %d names a cell outside the block or twice", q);
         if (!(density[q] > 0)) return fail(ctx, PMCX_EINVAL, "pmcx_boundary_resample: density must be positive");
         act[(size_t)c] = (throw_away && throw_away[q]) ? 2 : 1;
-        pos[(size_t)c] = q;
         dens[(size_t)c] = density[q];
         for (int m = 0; m < M; m++) conc[(size_t)c * M + m] = background->num_conc[(size_t)q * M + m];
     }
