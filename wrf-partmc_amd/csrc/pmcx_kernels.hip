@@ -2926,10 +2926,11 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
     };
     // (one class: the stay-or-go threshold is the same for every particle of the cell)
     const double hi_last0 = t_n[0] > 0 ? t_hi[t_n[0] - 1] : 0.0;
+    __shared__ __align__(16) uint32_t s_words[256];
     // The destination uniform of the particle of rank r is 32 bits: word r & 3 of the Philox block
     // addressed by r >> 2 -- four particles to a block.  A trip covers 4 x 63 slots: their ranks
     // span fewer than 256, i.e. at most 64 blocks from (rank of the trip's first particle) >> 2 on,
-    // one per lane; a particle fetches its word from the lane that holds its block.  Only a mover
+    // one per lane; the lanes lay their words side by side in LDS and a particle reads its own.  Only a mover
     // whose weight changes on the way draws again (the number of copies), from a block of its own.
     // (the keys of the next trip are requested before this trip's work: a wavefront alone with
     // its cell would otherwise wait out a memory round trip forty times)
@@ -2961,15 +2962,16 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
         const uint32_t B0 = rank0 >> 2;
         uint32_t wb[4];
         rng_block(seed, cell_id, step, B0 + (uint32_t)lane, SITE_TRANS, 0, wb);
+        // the trip's 256 words side by side in LDS: the particle of rank r reads word r - 4 B0
+        lds_sync(); // (the previous trip's reads are done)
+        *(uint4 *)&s_words[4 * lane] = make_uint4(wb[0], wb[1], wb[2], wb[3]);
+        lds_sync();
 #pragma unroll
         for (int ch = 0; ch < 4; ch++) {
             const int s = i0 + ch * 63 + lane, cl = cls[ch];
             const uint64_t mlive = __ballot(cl >= 0);
             const uint32_t rank = rank0 + (uint32_t)__popcll(mlive & lt);
-            const int src = (int)((rank >> 2) - B0) & 63;
-            const uint32_t w0 = (uint32_t)__shfl((int)wb[0], src, 64), w1 = (uint32_t)__shfl((int)wb[1], src, 64);
-            const uint32_t w2 = (uint32_t)__shfl((int)wb[2], src, 64), w3 = (uint32_t)__shfl((int)wb[3], src, 64);
-            const uint32_t wsel = (rank & 2u) ? ((rank & 1u) ? w3 : w2) : ((rank & 1u) ? w1 : w0);
+            const uint32_t wsel = s_words[(rank - 4u * B0) & 255u];
             bool moves = false;
             int dest = 0, copies = 0, dslot = 0;
             const double u = (double)wsel * 0x1.0p-32;
