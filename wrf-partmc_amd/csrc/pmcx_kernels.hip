@@ -1421,9 +1421,17 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
     // (its list length comes from memory).
     uint32_t wmask = 0;
     bool far = false, wide = false;
+    // Copies of the lane and cell numbers the compiler cannot see through, refreshed every pass
+    // in front of the event code: what an event forms from them (list-state addresses in LDS, the
+    // cell's place in the event log) is then computed where it is used.  Formed from `lane` and
+    // `c` these are loop invariants, hoisted out of the loop and -- the loop being short of
+    // registers -- spilled: six scratch reloads per event, each behind a wait for every
+    // store the event had just issued.
+    int lane_c = lane, c_c = c;
+#define MASKC(j) mask[(j) * 64 + lane_c]
     auto cnt_set = [&](int cl, int b, uint32_t e, int n) { // new length n of the group with entry e
         if (in_win(b)) {
-            ent[(cl * SEQ_W + (b - blo)) * 64 + lane] = (e & 0xFFFF0000u) | (uint32_t)n;
+            ent[(cl * SEQ_W + (b - blo)) * 64 + lane_c] = (e & 0xFFFF0000u) | (uint32_t)n;
         } else {
             gcnt_g[cl * B + b] = n;
             if (n > 0) wide = true;
@@ -1436,8 +1444,8 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                 far = true;
             }
         }
-        if (n == 0) MASK(cl * 2 + (b >> 6)) &= ~(1ull << (b & 63));
-        else if (n == 1) MASK(cl * 2 + (b >> 6)) |= 1ull << (b & 63);
+        if (n == 0) MASKC(cl * 2 + (b >> 6)) &= ~(1ull << (b & 63));
+        else if (n == 1) MASKC(cl * 2 + (b >> 6)) |= 1ull << (b & 63);
     };
     auto room_end = [&](int cl, int b) -> int { // offset where the room behind the group ends
         if (b + 1 < B && in_win(b + 1)) return (int)(ent[(cl * SEQ_W + (b + 1 - blo)) * 64 + lane] >> 16);
@@ -1482,7 +1490,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
     int n_lg = st.key_valid[c] != 0 ? st.n_log[c] : -1;
 #define PMCX_LOG(slot, key)                                                                         \
     if (n_lg >= 0) {                                                                              \
-        if (n_lg < EVLOG_CAP) st.evlog[(int64_t)c * EVLOG_CAP + n_lg++] = (uint32_t)(slot) | ((uint32_t)(key) << 16); \
+        if (n_lg < EVLOG_CAP) st.evlog[(int64_t)c_c * EVLOG_CAP + n_lg++] = (uint32_t)(slot) | ((uint32_t)(key) << 16); \
         else n_lg = -2;                                                                           \
     }
     int c1 = 0, c2 = 0, b1 = -1, b2 = -1, cc = 0;
@@ -1606,6 +1614,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
         int i1 = 0, i2 = 0;
         uint32_t p1 = 0, p2 = 0, s_ev = 0, eA = 0, eB = 0;
         uint32_t last1 = 0, last2 = 0;          // entries at the ends of the two lists
+        uint32_t last1b = 0;                    // a pair within one list: the entry in front of its end
         double u_acc = 0;
         int gA = 0, gB = 0;
         bool same = false;
@@ -1760,6 +1769,9 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                     p2 = perm[(eB >> 16) + i2];
                     last1 = perm[(eA >> 16) + nA - 1];
                     last2 = perm[(eB >> 16) + nB - 1];
+                    // (what the list's end will hold once one of the pair is gone: asked for
+                    // here, with the others, an event does not wait for memory half-way)
+                    if (same) last1b = perm[(eA >> 16) + nA - 2];
                 } else {
                     p1 = list_get(gA, eA, i1, n_app);
                     p2 = list_get(gB, eB, i2, n_app);
@@ -1833,6 +1845,8 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
         // group's room, no look outside the window).  A lane that misses a condition takes the
         // general form below.
         bool gen = acc;
+        lane_c = lane; c_c = c;
+        asm volatile("" : "+v"(lane_c), "+v"(c_c));
         if (SIMPLE && !any_wide && __ballot(n_app != 0) == 0) {
             if (acc) {
                 const double vn = v1 + v2, mn = m1 + m2;
@@ -1868,9 +1882,9 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                         // the merged particle leaves its list (look again when that list just changed)
                         uint32_t e = big1 ? eA : eB;
                         uint32_t lastv = big1 ? last1 : last2;
-                        if (same) {
+                        if (same) { // (the list as the removal above left it)
                             e = (e_o & 0xFFFF0000u) | (uint32_t)last_o;
-                            lastv = perm[(e >> 16) + (last_o > 0 ? last_o - 1 : 0)];
+                            lastv = (io == last_o - 1) ? last1 : last1b;
                         }
                         const int last = (int)(e & 0xFFFFu) - 1;
                         if (in != last) perm[(e >> 16) + in] = lastv;
@@ -2049,6 +2063,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
 #undef PMCX_LOG
 #undef STAMP
 #undef MASK
+#undef MASKC
 #undef gcnt_g
 #undef goff_g
 #undef O_ovf_n
