@@ -1374,24 +1374,38 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
 #define O_app_prev(e) (ovf_mem[(size_t)c * (2 * (size_t)G + 2 * (size_t)st.max_appends) + 2 * G + st.max_appends + (e)])
 
     // non-empty bins of every class; the window starts at the cell's first one
+    // (the list lengths are requested eight at a time, the window's entries all at once: one
+    // request per wait made the set-up 180 memory round trips, 8 % of the kernel)
     int blo = B;
     for (int cl = 0; cl < C; cl++) {
         uint64_t m0 = 0, m1 = 0;
-        for (int b = 0; b < B; b++)
-            if (gcnt_g[cl * B + b] > 0) {
-                if (b < 64) m0 |= 1ull << b; else m1 |= 1ull << (b - 64);
-                if (b < blo) blo = b;
+        for (int b0 = 0; b0 < B; b0 += 8) {
+            int32_t n8[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) n8[k] = gcnt_g[cl * B + min(b0 + k, B - 1)];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int b = b0 + k; // (uniform)
+                const bool has = b < B && n8[k] > 0;
+                const uint64_t bit = has ? 1ull << (b & 63) : 0ull;
+                if (b < 64) m0 |= bit; else m1 |= bit;
+                blo = (has && b < blo) ? b : blo;
             }
+        }
         MASK(cl * 2) = m0; MASK(cl * 2 + 1) = m1;
     }
     if (blo > B - SEQ_W) blo = (B - SEQ_W > 0) ? B - SEQ_W : 0;
-    for (int cl = 0; cl < C; cl++)
+    for (int cl = 0; cl < C; cl++) {
+        uint32_t e[SEQ_W];
+#pragma unroll
         for (int k = 0; k < SEQ_W; k++) {
-            const int b = blo + k;
-            uint32_t e = 0;
-            if (b < B) e = (uint32_t)gcnt_g[cl * B + b] | ((uint32_t)goff_g[cl * B + b] << 16);
-            ent[(cl * SEQ_W + k) * 64 + lane] = e;
+            const int b = min(blo + k, B - 1);
+            e[k] = (uint32_t)gcnt_g[cl * B + b] | ((uint32_t)goff_g[cl * B + b] << 16);
         }
+#pragma unroll
+        for (int k = 0; k < SEQ_W; k++)
+            ent[(cl * SEQ_W + k) * 64 + lane] = (blo + k < B) ? e[k] : 0u;
+    }
     for (int cl = 0; cl < C; cl++) magl[cl * 64 + lane] = st.mag[(int64_t)c * C + cl];
     {
         const EnvDerived e = env_derive(st.temp[c], st.pressure[c]);
