@@ -1859,6 +1859,12 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
         // group's room, no look outside the window).  A lane that misses a condition takes the
         // general form below.
         bool gen = acc;
+        // Nothing is in flight here on the usual path (the records have just arrived).  Saying so
+        // (vmcnt(0), free there) tells the compiler that the block's bounds -- requested during
+        // the draw -- are in their registers on EVERY path: otherwise the next pass's first
+        // settle waits for them with the only means it has, vmcnt(0), i.e. for the event's stores
+        // below, a round trip per pass in front of arithmetic that does not need it.
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         lane_c = lane; c_c = c;
         asm volatile("" : "+v"(lane_c), "+v"(c_c));
         if (SIMPLE && !any_wide && __ballot(n_app != 0) == 0) {
