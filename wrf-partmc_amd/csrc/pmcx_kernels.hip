@@ -1302,11 +1302,20 @@ __device__ unsigned long long g_seq_stamps[12];
 // compiler turns them into tables and closures in scratch memory, a round trip per use.
 // Same results as the oracle's sequential sweep, bit for bit.
 
+// slots a drawing lane may settle per round, rounds (settle, fetch the next block) per pass: one
+// wavefront per 64 cells / its two-wavefront form.  Measured on one box each (ms per launch):
+//   3*10^5 cells  2 x 4: 3.97-4.10   1 x 6: 3.92   1 x 8: 3.93   1 x 12: 3.94-4.19   3 x 4: 4.11
+//   75 000 cells  2 x 4: 1.39-1.42   1 x 6: 1.33   1 x 8: 1.32   1 x 12: 1.38
+//   39 000 cells (two wavefronts)  2 x 4: 0.96-0.99   1 x 6, 2 x 6, 1 x 8, 2 x 8: 0.99-1.02
+// (with one round the block's bounds are never waited for in the pass that asks for them)
 #ifndef PMCX_NTRY
-#define PMCX_NTRY 4
+#define PMCX_NTRY 8
 #endif
 #ifndef PMCX_NROUND
-#define PMCX_NROUND 2
+#define PMCX_NROUND 1
+#endif
+#ifndef PMCX_NTRY_SPLIT
+#define PMCX_NTRY_SPLIT 4
 #endif
 #ifndef PMCX_NROUND_SPLIT
 #define PMCX_NROUND_SPLIT 2
@@ -1531,7 +1540,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
     // ---- where the lane stands in the sweep, what it holds, the Philox block and the bounds of
     // ---- the four partner bins it is drawing from ----
     constexpr uint32_t TAG_NONE = 0xFFFFFFFFu;
-    constexpr int NTRY = PMCX_NTRY;  // slots a drawing lane may settle per round
+    constexpr int NTRY = SPLIT ? PMCX_NTRY_SPLIT : PMCX_NTRY;  // slots a drawing lane may settle per round
     // rounds (settle, fetch the next block) per pass; in the two-wavefront form, measured at 37 500
     // cells: 1 round 1.05 ms, 2 rounds 0.96, 3 rounds 1.07, 4 rounds 1.21 (the drawer is on the
     // pass's critical path as much as the evaluator)
