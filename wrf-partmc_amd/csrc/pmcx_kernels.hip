@@ -2429,8 +2429,9 @@ __global__ __launch_bounds__(256) void k_diagnostics(DeviceState st, double *tot
         const int cl = live_class(st, cb, i);
         if (cl < 0) continue; // tombstone
         double vdry = 0.0, ms = 0.0;
+        const double v_only = st.hot[cb + i].vtot; // (one species: its volume is the cached total)
         for (int s = 0; s < S; s++) {
-            const double v = S > 1 ? tile[lane * (S + 1) + s] : st.hot[cb + i].vtot;
+            const double v = S > 1 ? tile[lane * (S + 1) + s] : v_only;
             if (s != st.i_water) vdry = vdry + v;
             ms = ms + st.density[s] * v;
         }
@@ -2506,8 +2507,9 @@ __global__ __launch_bounds__(256) void k_diagnostics_ext(DeviceState st, double 
         if (cl < 0) continue;
         const double nc = mag[cl];
         double vdry = 0.0, mdry = 0.0;
+        const double v_only = st.hot[cb + i].vtot; // (one species: its volume is the cached total)
         for (int s = 0; s < S; s++) {
-            const double v = S > 1 ? tile[lane * (S + 1) + s] : st.hot[cb + i].vtot;
+            const double v = S > 1 ? tile[lane * (S + 1) + s] : v_only;
             atomicAdd(&acc[s], st.density[s] * v * nc);
             if (s != st.i_water) { vdry = vdry + v; mdry = mdry + st.density[s] * v; }
         }
@@ -2851,7 +2853,10 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
     int *t_dest = (int *)(t_p + C * ND);     // [C][ND]
     int *t_tmpd = t_dest + C * ND;           // scratch: destinations before sorting
     int *t_n = t_tmpd + C * ND;              // [C]
-    uint64_t *t_bit = (uint64_t *)(((uintptr_t)(t_n + C) + 7) & ~(uintptr_t)7); // [C][ND] dest_mask bit
+    // (formed from smem and an offset: through an integer the pointer would lose its address space
+    // and every access of the mover's path become a FLAT one, whose wait is for all the
+    // wavefront's requests, the next trip's keys among them)
+    uint64_t *t_bit = (uint64_t *)(smem + ((((size_t)((unsigned char *)(t_n + C) - smem)) + 7) & ~(size_t)7)); // [C][ND] dest_mask bit
     int *t_cnt = (int *)(t_bit + C * ND);    // [C][ND] copies sent to each destination
     for (int x = lane; x < C * ND; x += 64) t_cnt[x] = 0;
     const int i = c % nx, k = (c / nx) % nz, j = c / (nx * nz);
