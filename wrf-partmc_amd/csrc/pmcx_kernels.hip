@@ -1926,10 +1926,11 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                     }
                     PMCX_LOG(po, 0xFFFFu)
                     *(double2 *)&hot[pn].vtot = make_double2(vn, mn);
-                    {   // (the record's other half in one store: both times, changed or not)
+                    {   // (the record's other half in one store, when either time changes)
                         const double lo_n = big1 ? lct1 : lct2, lo_o = big1 ? lct2 : lct1;
                         const double go_n = big1 ? gct1 : gct2, go_o = big1 ? gct2 : gct1;
-                        *(double2 *)&hot[pn].lct = make_double2(lo_o < lo_n ? lo_o : lo_n, go_o > go_n ? go_o : go_n);
+                        if (lo_o < lo_n || go_o > go_n)
+                            *(double2 *)&hot[pn].lct = make_double2(lo_o < lo_n ? lo_o : lo_n, go_o > go_n ? go_o : go_n);
                         if (NS > 0) cold[pn].n_orig0 = (int32_t)((uint32_t)no1 + (uint32_t)no2);
                     }
                     for (int sp = 1; sp < NS; sp++) {
