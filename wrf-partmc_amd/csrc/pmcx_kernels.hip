@@ -3720,6 +3720,14 @@ __global__ __launch_bounds__(256) void k_trans_room(DeviceState st, TransGrid tg
 
 __global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid tg)
 {
+    // The arrivals of a cell are the entries addressed to it in the outboxes of its sources, in
+    // the fixed order of the sources and, within one, of its outbox.  They are few among what
+    // is scanned (a source sends to half a dozen cells), so the scan only collects them -- the
+    // sources' counts requested by a lane each at once, the outboxes walked as ONE sequence,
+    // the next chunk of entries requested before the current one is looked at -- into a small
+    // queue in LDS, and the records are moved 64 arrivals at a time from the queue: dense
+    // lanes and a memory round trip per 64 arrivals instead of two per 64 scanned entries.
+    __shared__ int32_t s_qsc[128], s_qx[128]; // queue: source cell, slot | copies << 16
     const int lane = threadIdx.x, c = tg.c_first + blockIdx.x;
     const int nx = tg.nx, nz = tg.nz, ny = tg.ny;
     const int i = c % nx, k = (c / nx) % nz, j = c / (nx * nz);
@@ -3733,8 +3741,59 @@ __global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid t
     int at = n_hi0;                 // next free slot of this cell
     int64_t nid = st.next_id[c];
     int status = 0;
-    // sources in the fixed order: east, west, north, south neighbour, then the column
-    for (int q = 0; q < 4 + nz; q++) {
+    int queued = 0;                 // entries in the queue (uniform)
+
+    // move the first `take` queued arrivals (records, keys, ids), in queue order
+    auto emit = [&](int take) {
+        const int sc = lane < take ? s_qsc[lane] : 0, x = lane < take ? s_qx[lane] : 0;
+        const int copies = lane < take ? (x >> 16) : 0, from = x & 0xFFFF;
+        const int64_t sb = (int64_t)sc * st.cap;
+        // slots and new ids of this entry's copies: prefix sums over the chunk
+        const uint32_t inc = wave_incl_scan_u32((uint32_t)copies, lane);
+        const uint32_t first = (uint32_t)at + inc - (uint32_t)copies;
+        const uint32_t n_new = copies > 0 ? (uint32_t)(copies - 1) : 0u;
+        const uint32_t inc_new = wave_incl_scan_u32(n_new, lane);
+        const int64_t id0 = nid + (int64_t)(inc_new - n_new);
+        if (copies > 0) {
+            // the record is read once (one request per plane), then written per copy; with
+            // one species the species plane is not kept current (see spec_vol): not moved
+            const Hot hv = st.hot[sb + from];
+            const Cold cv = st.cold[sb + from];
+            const int32_t wc = st.n_class > 1 ? st.wclass[sb + from] : 0; // one class: all zero
+            const uint16_t kd = key_of(st, hv.vtot, wc); // (from the record: the source's keys may not hold)
+            for (int g = 0; g < copies; g++) {
+                const int dst = (int)first + g;
+                if (dst >= st.cap) { status |= ST_CAP_OVERFLOW; break; }
+                if (S > 1)
+                    for (int sp = 0; sp < S; sp++)
+                        st.vol[(cb + dst) * S + sp] = st.vol[(sb + from) * S + sp];
+                for (int sp = 1; sp < NS; sp++)
+                    norig(st, cb, sp, dst) = norig(st, sb, sp, from);
+                st.hot[cb + dst] = hv;
+                st.gkey[cb + dst] = kd;
+                if (st.n_class > 1) st.wclass[cb + dst] = wc;
+                Cold c2 = cv;
+                if (g != copies - 1) c2.id = id0 + g;
+                st.cold[cb + dst] = c2;
+            }
+        }
+        at += (int)__shfl(inc, 63, 64);
+        nid += (int64_t)__shfl(inc_new, 63, 64);
+        // what is left moves to the front of the queue
+        lds_sync();
+        const int rest = queued - take;
+        int rsc = 0, rx = 0;
+        if (lane < rest) { rsc = s_qsc[take + lane]; rx = s_qx[take + lane]; }
+        lds_sync();
+        if (lane < rest) { s_qsc[lane] = rsc; s_qx[lane] = rx; }
+        queued = rest;
+        lds_sync();
+    };
+
+    // sources in the fixed order: east, west, north, south neighbour, then the column -- a lane
+    // each, 64 at a time
+    for (int q0 = 0; q0 < 4 + nz; q0 += 64) {
+        const int q = q0 + lane;
         int sc = -1;
         if (q < 4) {
             const int di[4] = {1, -1, 0, 0}, dj[4] = {0, 0, 1, -1};
@@ -3752,58 +3811,55 @@ __global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid t
                 if (ok2 && (j2 * nz + k) * nx + i2 == sc) sc = -1;
             }
             if (sc == c) sc = -1;
-        } else {
+        } else if (q < 4 + nz) {
             const int kk = q - 4;
             if (kk != k) sc = (j * nz + kk) * nx + i;
         }
-        if (sc < 0) continue;
-        {   // does that source send anything this way?  (this cell as seen from the source)
+        // does that source send anything this way?  (this cell as seen from the source)
+        int n_src = 0;
+        if (sc >= 0) {
             const int need = q < 4 ? (q ^ 1) : 4 + k;
-            if (need < 64 && !((tg.dest_mask[sc] >> need) & 1ull)) continue;
+            const uint64_t dm = tg.dest_mask[sc];
+            const int no = tg.n_out[sc];
+            if (need >= 64 || ((dm >> need) & 1ull)) n_src = no;
         }
-        const int64_t sb = (int64_t)sc * st.cap;
-        const int2 *box = tg.outbox + sb;
-        const int n_out = tg.n_out[sc];
-        for (int e0 = 0; e0 < n_out; e0 += 64) {
-            const int e = e0 + lane;
+        const uint32_t incl = wave_incl_scan_u32((uint32_t)n_src, lane);
+        const int start = (int)(incl - (uint32_t)n_src);
+        const int total = (int)__shfl(incl, 63, 64);
+        const uint64_t act = __ballot(n_src > 0);
+        // entry f of the sources' outboxes laid end to end
+        auto fetch = [&](int f, int &fsc) -> int2 {
             int2 en = make_int2(0, -1);
-            if (e < n_out) en = box[e];
-            const bool mine = en.y == c;
-            const int copies = mine ? (en.x >> 16) : 0;
-            const int from = en.x & 0xFFFF;
-            // slots and new ids of this entry's copies: prefix sums over the chunk
-            const uint32_t inc = wave_incl_scan_u32((uint32_t)copies, lane);
-            const uint32_t first = (uint32_t)at + inc - (uint32_t)copies;
-            const uint32_t n_new = copies > 0 ? (uint32_t)(copies - 1) : 0u;
-            const uint32_t inc_new = wave_incl_scan_u32(n_new, lane);
-            const int64_t id0 = nid + (int64_t)(inc_new - n_new);
-            if (copies > 0) {
-                // the record is read once (one request per plane), then written per copy; with
-                // one species the species plane is not kept current (see spec_vol): not moved
-                const Hot hv = st.hot[sb + from];
-                const Cold cv = st.cold[sb + from];
-                const int32_t wc = st.n_class > 1 ? st.wclass[sb + from] : 0; // one class: all zero
-                const uint16_t kd = key_of(st, hv.vtot, wc); // (from the record: the source's keys may not hold)
-                for (int g = 0; g < copies; g++) {
-                    const int dst = (int)first + g;
-                    if (dst >= st.cap) { status |= ST_CAP_OVERFLOW; break; }
-                    if (S > 1)
-                        for (int sp = 0; sp < S; sp++)
-                            st.vol[(cb + dst) * S + sp] = st.vol[(sb + from) * S + sp];
-                    for (int sp = 1; sp < NS; sp++)
-                        norig(st, cb, sp, dst) = norig(st, sb, sp, from);
-                    st.hot[cb + dst] = hv;
-                    st.gkey[cb + dst] = kd;
-                    if (st.n_class > 1) st.wclass[cb + dst] = wc;
-                    Cold c2 = cv;
-                    if (g != copies - 1) c2.id = id0 + g;
-                    st.cold[cb + dst] = c2;
-                }
+            int sq = 0, e = 0;
+            for (uint64_t m = act; m; m &= m - 1) { // (a handful of sources: every lane walks them)
+                const int sl = __builtin_ctzll(m);
+                const int st_s = __builtin_amdgcn_readlane(start, sl);
+                const int sc_s = __builtin_amdgcn_readlane(sc, sl);
+                if (f >= st_s) { sq = sc_s; e = f - st_s; }
             }
-            at += (int)__shfl(inc, 63, 64);
-            nid += (int64_t)__shfl(inc_new, 63, 64);
+            fsc = sq;
+            if (f < total) en = tg.outbox[(int64_t)sq * st.cap + e];
+            return en;
+        };
+        int nsc = 0;
+        int2 nen = make_int2(0, -1);
+        if (total > 0) nen = fetch(lane, nsc);
+        for (int f0 = 0; f0 < total; f0 += 64) {
+            const int2 en = nen;
+            const int esc = nsc;
+            if (f0 + 64 < total) nen = fetch(f0 + 64 + lane, nsc); // requested before this chunk's work
+            const bool mine = en.y == c && (en.x >> 16) > 0;
+            const uint64_t mm = __ballot(mine);
+            if (mine) {
+                const int pos = queued + __popcll(mm & ((1ull << lane) - 1ull));
+                s_qsc[pos] = esc; s_qx[pos] = en.x;
+            }
+            queued += __popcll(mm);
+            lds_sync();
+            if (queued >= 64) emit(64);
         }
     }
+    if (queued > 0) emit(queued);
     if (__ballot(status != 0)) status = ST_CAP_OVERFLOW;
     if (at > st.cap) at = st.cap;
     if (lane == 0) {
