@@ -3053,6 +3053,9 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
             }
             const uint64_t mm = __ballot(moves);
             if (moves) box[n_out + (uint32_t)__popcll(mm & lt)] = make_int2(s | (copies << 16), dest);
+            // (a mover's sort key says "gone" from here on -- in the line just read; its record
+            // lives until the gather of its destination, or k_trans_remove, has dealt with it)
+            if (moves && keyed) st.gkey[cb + s] = (uint16_t)0xFFFFu;
             if (moves && copies > 0) atomicAdd(&t_cnt[dslot], copies);
             n_out += (uint32_t)__popcll(mm);
             rank0 += (uint32_t)__popcll(mlive);
@@ -3761,6 +3764,9 @@ __global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid t
             const Cold cv = st.cold[sb + from];
             const int32_t wc = st.n_class > 1 ? st.wclass[sb + from] : 0; // one class: all zero
             const uint16_t kd = key_of(st, hv.vtot, wc); // (from the record: the source's keys may not hold)
+            // the mover's tombstone, into the line just read (k_trans_remove leaves these alone:
+            // a store to a line nobody has read costs a read-modify-write in memory)
+            st.hot[sb + from].vtot = -1.0;
             for (int g = 0; g < copies; g++) {
                 const int dst = (int)first + g;
                 if (dst >= st.cap) { status |= ST_CAP_OVERFLOW; break; }
@@ -3877,7 +3883,21 @@ __global__ __launch_bounds__(64) void k_trans_remove(DeviceState st, TransGrid t
     const int64_t cb = (int64_t)c * st.cap;
     const int n_out = tg.n_out[c];
     const int2 *box = tg.outbox + cb;
-    for (int e = lane; e < n_out; e += 64) mark_dead(st, cb, box[e].x & 0xFFFF);
+    // Tombstones of the movers no gather has left one for: those that arrive nowhere (no copy
+    // survives the change of weight), go to a cell outside the rows gathered here (a ghost
+    // row: packed for the neighbouring rank) or to an open lateral boundary cell.  The sort
+    // keys were seen to by k_trans_decide.
+    const int nx = tg.nx, nz = tg.nz, ny = tg.ny;
+    for (int e = lane; e < n_out; e += 64) {
+        const int2 en = box[e];
+        const int dest = en.y;
+        bool gathered = (en.x >> 16) > 0 && dest >= tg.c_first && dest < tg.c_first + (int)gridDim.x;
+        if (gathered && st.trans_lateral) {
+            const int di = dest % nx, dj = dest / (nx * nz);
+            if (di == 0 || di == nx - 1 || lateral_row(st, dj, ny)) gathered = false;
+        }
+        if (!gathered) st_f64(&st.hot[cb + (en.x & 0xFFFF)].vtot, -1.0);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wave_sync();
     const int n_live = st.n_part[c] - n_out;
