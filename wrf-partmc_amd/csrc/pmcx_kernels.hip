@@ -2812,10 +2812,13 @@ __global__ __launch_bounds__(256) void k_dry_deposition(DeviceState st, DepArgs 
 //                   class in LDS (sorted by probability, cumulative thresholds,
 //                   weight ratios), a 32-bit destination uniform per live particle (four
 //                   particles to a Philox block, addressed by rank), movers
-//                   compacted into the cell's outbox in rank order
+//                   compacted into the cell's outbox in rank order; a mover's sort key is
+//                   marked dead here, in the line just read
 //   k_trans_gather  one wavefront per destination cell: scans the outboxes of
-//                   its sources in a fixed order and appends the arrivals
-//   k_trans_remove  one wavefront per source cell: movers become tombstones
+//                   its sources in a fixed order, appends the arrivals and leaves each
+//                   mover's tombstone in the record it has just read
+//   k_trans_remove  one wavefront per source cell: the cell's live count, and the
+//                   tombstones of the movers that no gather of this block reads
 
 constexpr int TRANS_MAX_COPIES = 16;
 
