@@ -895,7 +895,10 @@ def _transport_probs(n_cells, n_class, nz, seed, scale=0.08):
 
 
 @pytest.mark.parametrize("nx,nz,ny,px,py", [(3, 4, 2, True, True), (2, 3, 2, True, True),
-                                            (4, 5, 1, False, False)])
+                                            (4, 5, 1, False, False),
+                                            # a column taller than a wavefront is wide: more than
+                                            # 64 sources per cell, no destination mask
+                                            (1, 66, 1, False, False)])
 def test_transport_parity(wp, oracle, nx, nz, ny, px, py):
     """stochastic transport between cells, GPU vs oracle bit for bit, followed by
     a coagulation step on the mixed populations."""
