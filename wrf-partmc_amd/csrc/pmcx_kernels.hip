@@ -1551,9 +1551,11 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
     // turned into a table in scratch memory by the compiler, a memory round trip per slot)
     uint64_t wq01 = 0, wq23 = 0, kq01 = 0, kq23 = 0;
     int rc1 = -1, rc2 = -1;          // classes the row constants below belong to
+    float cf_up = 0.0f;              // one class: an upper bound of fmax * del_t in single precision
     if (SIMPLE) { // one class: the row constants are the cell's
         n1 = n2 = nmin = fmax = factor = magl[lane];
         cc = 0; rc1 = rc2 = 0;
+        cf_up = (float)(fmax * del_t) * 1.000001f;
     }
 
     // The slot the lane would draw next from where it stands, with the lists as they are now:
@@ -1699,9 +1701,26 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                                     dA = ent_get(0, nb1);
                                     dB = ent_get(0, nb2);
                                 }
+                                // Surely no sample: decided in single precision from upper bounds of
+                                // the uniform and of the mean (u <= u_up < 1 - mean_up - 1e-6 implies
+                                // the double-precision test of PMCX_SETTLE, hence a count of zero);
+                                // a slot that fails it -- the one with samples, or one within 1e-6 of
+                                // the line -- takes the double-precision values and the exact count.
                                 bool zero;
-                                PMCX_SETTLE((uint32_t)nb1, (uint32_t)nb2, dA, dB, zero)
-                                if (!zero) active = false;
+                                {
+                                    const uint32_t hB_ = (uint32_t)nb2, sh_ = (hB_ & 1u) * 32u;
+                                    const uint32_t wu_ = (uint32_t)(((hB_ & 2u) ? wq23 : wq01) >> sh_);
+                                    const float kf_ = __uint_as_float((uint32_t)(((hB_ & 2u) ? kq23 : kq01) >> sh_));
+                                    const uint32_t nA_ = dA & 0xFFFFu, nB_ = dB & 0xFFFFu;
+                                    const uint32_t np_ = nb1 == nb2 ? (nA_ * (nA_ - 1u)) >> 1 : nA_ * nB_;
+                                    const float mean_up = (kf_ * cf_up) * ((float)np_ * 1.00001f);
+                                    const float u_up = (float)((wu_ >> 8) + 1u) * 0x1.0p-24f;
+                                    zero = u_up < (1.0f - mean_up) - 1e-6f;
+                                }
+                                if (!zero) {
+                                    PMCX_SETTLE((uint32_t)nb1, (uint32_t)nb2, dA, dB, zero)
+                                    if (!zero) active = false;
+                                }
                             }
                         }
                     }
