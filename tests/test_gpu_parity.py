@@ -455,6 +455,49 @@ def test_dry_deposition_parity(wp, oracle):
     blk.close()
 
 
+def test_dry_deposition_screen_is_sound(wp, oracle):
+    """k_dry_deposition settles most particles with a single-precision bound of the removal
+    probability, (dt/dz)(vs_up + 1/ra), and evaluates the rest from a queue.
+    (a) The bound, restated here in float32, lies above the oracle's probability with room to
+    spare over the whole range of sizes, densities and surface parameters.  (b) With inputs for
+    which the bound does not hold (a non-positive aerodynamic resistance) or does not help
+    (probabilities of the order of one: the `unrealistic` flag) the kernel still equals the
+    oracle: counts, flags, particles."""
+    rng = np.random.RandomState(21)
+    n = 4000
+    d = 10 ** rng.uniform(-8.7, -3.6, n); rho = rng.uniform(800, 3000, n)
+    us = rng.uniform(0.02, 1.2, n); ra = 10 ** rng.uniform(-1, 3, n)
+    f32 = np.float32
+    for alpha, big_a in ((1.2, 0.002), (100.0, 9.999), (50.0, 2.0), (0.6, 0.01)):
+        vd = np.array([oracle.dep_velocity(a, b, 281.0, 1 / 1.15, c, e, alpha, big_a)
+                       for a, b, c, e in zip(d, rho, us, ra)])
+        v = (np.pi / 6.0) * d ** 3
+        vf, mf = v.astype(f32), (v * rho).astype(f32)
+        d_up = f32(2.0002) * np.exp2(np.log2(vf * f32(0.238732415)) * f32(0.333333343)).astype(f32)
+        dens_up = (mf / vf) * f32(1.0001)
+        vs_up = dens_up * f32(9.80665 / (18.0 * 1.78e-5)) * f32(1.0001) * (d_up * d_up + f32(2.1542e-7) * d_up)
+        bound = (vs_up.astype(np.float64) + (1.0 / ra) * 1.0001) * 1.001
+        assert np.all(bound >= vd * 1.0005), float((bound / vd).min())
+    counts = [1800, 1200, 2047, 600]
+    blk, cells = _ragged_pair(wp, oracle, counts, n_spec=2, n_class=2, cap=2048)
+    nc = len(counts)
+    alpha = np.array([1.2, 100.0, 50.0, 1.5]); big_a = np.array([0.002, 9.999, 2.0, 0.005])
+    ra = np.array([-5.0, 0.0, 40.0, 1e-3]); us = np.array([0.3, 0.4, 0.5, 0.9])
+    height = np.array([40.0, 50.0, 0.5, 20.0]); rrho = 1 / np.array([1.2, 1.1, 1.15, 1.0])
+    flagged = 0
+    for step in range(2):
+        nr, bad = blk.dry_deposition(3000.0, ra, us, alpha, big_a, height, rrho, seed=9, step=step)
+        for c, oc in enumerate(cells):
+            ond, obad = oc.dry_deposition(3000.0, 9, c, step, ra[c], us[c], alpha[c], big_a[c],
+                                          height[c], rrho[c])
+            assert (int(nr[c]), int(bad[c])) == (ond, obad), (step, c)
+            flagged += obad
+        ok, msg = parity.compare_state(blk, cells)
+        assert ok, f"step {step}: {msg}"
+    assert flagged > 0 and nr.sum() > 0
+    blk.close()
+
+
 def test_column_file_output_and_restart(wp, oracle, tmp_path):
     """device state -> column file (output_column_to_file_new layout) -> a fresh
     block (init_read_in_restart): ids, classes, create times, source counts, weights, next_id
