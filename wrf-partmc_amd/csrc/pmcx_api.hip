@@ -71,6 +71,10 @@ struct pmcx_ctx {
     int64_t *d_acc = nullptr;   // running sums over calls: n_samp, n_coag, n_part, status
     double *d_diag = nullptr; // [n_cells*(2+2*n_dbin)]
     bool aero_data_set = false, env_set = false, n_ideal_set = false;
+    // device blocks for the temporaries of one call (per-cell inputs, counters), kept between
+    // calls: a hipMalloc/hipFree pair per call costs more than the kernels of the smaller stages
+    struct TmpBlock { void *p; size_t bytes; bool used; };
+    std::vector<TmpBlock> tmp_blocks;
     // gas phase (pmcx_set_gas_state, pmcx_set_gas_scenario)
     int32_t n_gas = 0;
     double *d_gas = nullptr;            // [n_cells][n_gas] mix_rat, ppb
@@ -125,6 +129,27 @@ int dev_alloc(pmcx_ctx *ctx, T **p, size_t count, bool zero = true)
     ctx->bytes += (int64_t)bytes;
     *p = (T *)q;
     return PMCX_OK;
+}
+
+// a block of at least `bytes` for the duration of a call (every call synchronises its stream
+// before it returns, so a released block is free for the next one)
+hipError_t tmp_malloc(pmcx_ctx *ctx, void **p, size_t bytes)
+{
+    if (bytes == 0) bytes = 1;
+    for (auto &b : ctx->tmp_blocks)
+        if (!b.used && b.bytes >= bytes && b.bytes <= 2 * bytes + 4096) { b.used = true; *p = b.p; return hipSuccess; }
+    void *q = nullptr;
+    const hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return e;
+    ctx->tmp_blocks.push_back({q, bytes, true});
+    ctx->bytes += (int64_t)bytes;
+    *p = q;
+    return hipSuccess;
+}
+void tmp_release(pmcx_ctx *ctx, void *p)
+{
+    for (auto &b : ctx->tmp_blocks)
+        if (b.p == p) b.used = false;
 }
 
 int ensure_stage(pmcx_ctx *ctx, size_t bytes)
@@ -386,6 +411,7 @@ int pmcx_destroy(pmcx_ctx *ctx)
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     for (void *p : ctx->allocs) (void)hipFree(p);
     for (void *p : ctx->gas_scn_allocs) (void)hipFree(p);
+    for (auto &b : ctx->tmp_blocks) (void)hipFree(b.p);
     if (ctx->stage) (void)hipFree(ctx->stage);
     if (ctx->d_offsets) (void)hipFree(ctx->d_offsets);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -924,9 +950,9 @@ int upload_dist(pmcx_ctx *ctx, const pmcx_aero_dist *d, std::vector<void *> &tmp
             return fail(ctx, PMCX_EINVAL, "aero_dist: mode_class[%d] out of range", m);
     }
     double *dd = nullptr; int32_t *di = nullptr;
-    HIP_TRY(ctx, hipMalloc((void **)&dd, sizeof(double) * h.size())); tmp.push_back(dd);
-    HIP_TRY(ctx, hipMalloc((void **)&di, sizeof(int32_t) * hi.size())); tmp.push_back(di);
-    HIP_TRY(ctx, hipMalloc((void **)&conc_dev, sizeof(double) * nc * M)); tmp.push_back(conc_dev);
+    HIP_TRY(ctx, tmp_malloc(ctx, (void **)&dd, sizeof(double) * h.size())); tmp.push_back(dd);
+    HIP_TRY(ctx, tmp_malloc(ctx, (void **)&di, sizeof(int32_t) * hi.size())); tmp.push_back(di);
+    HIP_TRY(ctx, tmp_malloc(ctx, (void **)&conc_dev, sizeof(double) * nc * M)); tmp.push_back(conc_dev);
     HIP_TRY(ctx, hipMemcpyAsync(dd, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(di, hi.data(), sizeof(int32_t) * hi.size(), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(conc_dev, d->num_conc, sizeof(double) * nc * M, hipMemcpyHostToDevice, ctx->stream));
@@ -949,7 +975,7 @@ int pmcx_scenario_update_aero_state(pmcx_ctx *ctx, double dt, double elapsed_tim
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     const size_t nc = (size_t)ctx->cfg.n_cells;
     std::vector<void *> tmp;
-    auto cleanup = [&]() { for (void *p : tmp) (void)hipFree(p); };
+    auto cleanup = [&]() { for (void *p : tmp) tmp_release(ctx, p); };
     GenSpecDev ge{}, gb{};
     double *ce = nullptr, *cbg = nullptr, *d_dil = nullptr;
     int32_t *d_cnt = nullptr;
@@ -959,10 +985,10 @@ int pmcx_scenario_update_aero_state(pmcx_ctx *ctx, double dt, double elapsed_tim
     if (rc) { cleanup(); return rc; }
     hipError_t e = hipSuccess;
     if (dilution_rate) {
-        e = hipMalloc((void **)&d_dil, sizeof(double) * nc);
+        e = tmp_malloc(ctx, (void **)&d_dil, sizeof(double) * nc);
         if (e == hipSuccess) { tmp.push_back(d_dil); e = hipMemcpyAsync(d_dil, dilution_rate, sizeof(double) * nc, hipMemcpyHostToDevice, ctx->stream); }
     }
-    if (e == hipSuccess) { e = hipMalloc((void **)&d_cnt, sizeof(int32_t) * 3 * nc); if (e == hipSuccess) tmp.push_back(d_cnt); }
+    if (e == hipSuccess) { e = tmp_malloc(ctx, (void **)&d_cnt, sizeof(int32_t) * 3 * nc); if (e == hipSuccess) tmp.push_back(d_cnt); }
     if (e == hipSuccess) e = hipMemsetAsync(ctx->st.status, 0, sizeof(int32_t) * nc, ctx->stream);
     if (e == hipSuccess) {
         ProfScope ps(ctx, "scenario");
@@ -1031,13 +1057,13 @@ int pmcx_seasalt_emissions(pmcx_ctx *ctx, double dt, double elapsed_time, uint64
     d.mode_class = mode_class; d.mode_source = mode_source;
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     std::vector<void *> tmp;
-    auto cleanup = [&]() { for (void *p : tmp) (void)hipFree(p); };
+    auto cleanup = [&]() { for (void *p : tmp) tmp_release(ctx, p); };
     GenSpecDev ge{};
     double *ce = nullptr;
     int32_t *d_cnt = nullptr;
     int rc = upload_dist(ctx, &d, tmp, ge, ce);
     if (rc) { cleanup(); return rc; }
-    hipError_t e = hipMalloc((void **)&d_cnt, sizeof(int32_t) * nc);
+    hipError_t e = tmp_malloc(ctx, (void **)&d_cnt, sizeof(int32_t) * nc);
     if (e == hipSuccess) tmp.push_back(d_cnt);
     if (e == hipSuccess) e = hipMemsetAsync(ctx->st.status, 0, sizeof(int32_t) * nc, ctx->stream);
     if (e == hipSuccess) {
@@ -1069,8 +1095,8 @@ int pmcx_dry_deposition(pmcx_ctx *ctx, double dt, uint64_t seed, uint32_t step,
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     double *d6 = nullptr;
     int32_t *d_i = nullptr;
-    hipError_t e = hipMalloc((void **)&d6, sizeof(double) * 6 * nc);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_i, sizeof(int32_t) * 3 * nc);
+    hipError_t e = tmp_malloc(ctx, (void **)&d6, sizeof(double) * 6 * nc);
+    if (e == hipSuccess) e = tmp_malloc(ctx, (void **)&d_i, sizeof(int32_t) * 3 * nc);
     const double *src[6] = {aer_res_a, ustar, alpha, big_a, height, inv_density};
     for (int k = 0; k < 6 && e == hipSuccess; k++)
         e = hipMemcpyAsync(d6 + k * nc, src[k], sizeof(double) * nc, hipMemcpyHostToDevice, ctx->stream);
@@ -1084,8 +1110,8 @@ int pmcx_dry_deposition(pmcx_ctx *ctx, double dt, uint64_t seed, uint32_t step,
     if (e == hipSuccess && n_removed) e = hipMemcpyAsync(n_removed, d_i, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && unrealistic) e = hipMemcpyAsync(unrealistic, d_i + nc, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (d6) (void)hipFree(d6);
-    if (d_i) (void)hipFree(d_i);
+    if (d6) tmp_release(ctx, d6);
+    if (d_i) tmp_release(ctx, d_i);
     if (e != hipSuccess) return fail(ctx, PMCX_EDEVICE, "pmcx_dry_deposition: %s", hipGetErrorString(e));
     return PMCX_OK;
 }
@@ -1269,15 +1295,15 @@ int pmcx_boundary_resample(pmcx_ctx *ctx, int32_t n_list, const int32_t *cell, c
     d.num_conc = conc.data();
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     std::vector<void *> tmp;
-    auto cleanup = [&]() { for (void *p : tmp) (void)hipFree(p); };
+    auto cleanup = [&]() { for (void *p : tmp) tmp_release(ctx, p); };
     GenSpecDev gb{};
     double *cbg = nullptr, *d_dens = nullptr;
     int32_t *d_i = nullptr;
     int rc = upload_dist(ctx, &d, tmp, gb, cbg);
     if (rc) { cleanup(); return rc; }
-    hipError_t e = hipMalloc((void **)&d_dens, sizeof(double) * nc);
+    hipError_t e = tmp_malloc(ctx, (void **)&d_dens, sizeof(double) * nc);
     if (e == hipSuccess) tmp.push_back(d_dens);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_i, sizeof(int32_t) * 3 * nc);
+    if (e == hipSuccess) e = tmp_malloc(ctx, (void **)&d_i, sizeof(int32_t) * 3 * nc);
     if (e == hipSuccess) tmp.push_back(d_i);
     if (e == hipSuccess) e = hipMemcpyAsync(d_dens, dens.data(), sizeof(double) * nc, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_i, act.data(), sizeof(int32_t) * nc, hipMemcpyHostToDevice, ctx->stream);
