@@ -308,6 +308,9 @@ def main():
                     help="diagnostic: the instantiation that records cycles per stage")
     ap.add_argument("--kernel", type=int, default=4,
                     help="coag_kernel_type (4 = COAG_KERNEL_TYPE_BROWN, the reference's; others for tuning)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend of the N > 1 run: nccl (RCCL, one rank per GPU; what the "
+                         "driver's scaling runs use) or gloo (rehearsal: several ranks may share one GPU)")
     ap.add_argument("--workload", choices=["domain", "config3"], default="domain",
                     help="domain: BASELINE configs[4] (default). config3: 1000 cells x 10^4, "
                          "20 species, condensation sub-step + coagulation (BASELINE configs[2])")
@@ -334,9 +337,9 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU is visible and there is no CPU path")
-    # PMCX_BENCH_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N>1
+    # --backend gloo lets several ranks share one GPU (rehearsal of the N>1
     # path on a one-GPU box); the driver's multi-GPU runs use the default, RCCL.
-    backend = os.environ.get("PMCX_BENCH_BACKEND", "nccl")
+    backend = args.backend
     device = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(device)
     if world > 1:
@@ -482,14 +485,28 @@ def main():
         alg = algorithmic_bytes(dom, args.n_spec, 1, 0, **per_launch)
         avg_ms = kern_ms[dom] / launches
         achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
+        # HBM bytes per launch from the PMC passes (profiles/pmc_traffic.json, scripts/gpu_pmc_shape.sh):
+        # taken at a run shape (--warmup, --steps) because the cells thin out as a run goes on; this
+        # run's shape when it was profiled, else the nearest profiled shape scaled by events per launch
+        # (the sampler's traffic is per event and candidate), and said so
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        # the committed PMC passes were taken on the default full-size workload only
         full_default = (args.workload == "domain" and (args.nx, args.ny, args.levels) == (100, 100, 30)
                         and args.particles == 10000 and args.n_spec == 1 and world == 1)
-        if full_default and os.path.exists(tpath):
+        if full_default and dom == "coag_sample" and os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom, {}).get("bytes_per_launch")
+                shapes = json.load(open(tpath)).get("shapes", {})
+                key = f"w{args.warmup}s{args.steps}"
+                if key in shapes:
+                    e = shapes[key]
+                    # (the same steps of the same simulation: events per launch agree exactly)
+                    traffic = e["bytes_per_launch"] * per_launch["events"] / e["events_per_launch"]
+                    traffic_src = f"PMC passes of this run shape ({key}), profiles/pmc_traffic.json"
+                elif shapes:
+                    k2, e = min(shapes.items(), key=lambda kv: abs(kv[1]["events_per_launch"] - per_launch["events"]))
+                    traffic = e["bytes_per_event"] * per_launch["events"]
+                    traffic_src = (f"PMC passes of run shape {k2} ({e['events_per_launch']:.4g} events per launch) "
+                                   f"scaled by events per launch to this run's {per_launch['events']:.4g}")
             except Exception:
                 traffic = None
         line = {
@@ -507,11 +524,16 @@ def main():
             "particle_steps_per_sec": agg["particle_steps"] / el,
             "candidate_pairs_per_sec": agg["n_samp"] / el,
             "events_per_step": agg["n_coag"] / args.steps,
+            # the populations thin by about 0.5 % a step (no doubling until a cell falls below half
+            # its ideal count): ms_per_step depends on which steps are timed, events/s much less
+            "n_part_mean": agg["particle_steps"] / args.steps / n_cells_total,
+            "timed_steps": f"simulation steps {args.warmup} .. {args.warmup + args.steps - 1}",
             "status_or": status,
             "device_memory_gb_rank0": mem / 1e9,
             "kernel_ms_per_step": {k: kern_ms[k] / args.steps for k in KERNELS},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms},
         }
         if traffic:
@@ -522,7 +544,7 @@ def main():
                 "kernel": dom, "unit": "64-B requests/s", "achieved": req_s,
                 "peak": GATHER_PEAK_PER_S, "frac": req_s / GATHER_PEAK_PER_S,
                 "requests_per_launch": traffic / 64.0,
-                "source": "FETCH_SIZE + WRITE_SIZE of profiles/pmc_traffic.json over 64 B; "
+                "source": "FETCH_SIZE + WRITE_SIZE (roofline.traffic_source) over 64 B; "
                           "peak from scripts/gather_probe.hip"}
         # secondary rooflines of the other kernels (same accounting)
         others = {}

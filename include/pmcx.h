@@ -218,7 +218,22 @@ typedef struct {
     const double *vol_frac;    /* [n_mode][n_spec] */
     const int32_t *mode_class; /* [n_mode] */
     const int32_t *mode_source;/* [n_mode] */
+    int32_t per_cell;          /* 0: as above, one set of mode parameters for every cell.
+                                * 1: every cell has its own -- gm_radius, gsd_log10, mode_class,
+                                * mode_source [n_cells][n_mode], vol_frac [n_cells][n_mode][n_spec] -- as
+                                * scenario(i,k,j)%aero_emission / %aero_background hold them: read from
+                                * each cell's own file (wrf_pmc_init.F90:689-693,705-706,768-786;
+                                * 886-892,927-943).  For pmcx_boundary_resample: [n_list][..]. */
 } pmcx_aero_dist;
+
+/* The mode parameters of scenario(i,k,j)%aero_emission (which = 0) or %aero_background (1) at
+ * their current time level, kept on the device: everything of `dist` but num_conc.  Afterwards a
+ * pmcx_aero_dist handed to pmcx_scenario_update_aero_state / pmcx_timestep with gm_radius == NULL
+ * stands for these modes and brings only its num_conc [n_cells][n_mode] -- what changes from step
+ * to step (rate_scale / height) while the modes hold until a cell's series moves to its next time
+ * point (aero_dist_interp_1d keeps a dist between two points [upstream, uncited]).  dist == NULL:
+ * forgotten. */
+int pmcx_set_aero_scenario_modes(pmcx_ctx *ctx, int32_t which, const pmcx_aero_dist *dist);
 
 int pmcx_scenario_update_aero_state(pmcx_ctx *ctx, double dt, double elapsed_time, uint64_t seed,
                                     uint32_t step, const pmcx_aero_dist *emission,
@@ -268,7 +283,9 @@ int pmcx_seasalt_emissions(pmcx_ctx *ctx, double dt, double elapsed_time, uint64
  * Optional host copies: prob_h [n_cells][n_class][4], prob_v [n_cells][n_class][nz], n_substeps
  * [ny][nx] (stable_timestep's count; 0: column skipped), bad [n_cells] (the reference's
  * assertions 414897882 / 184874367 / 184874369 / 414897881 as bits 1 / 2 / 4 / 8; bit 16: more
- * than 10^6 sub-steps asked for), n_class_part [n_cells][n_class].  Synchronises.
+ * than 10^4 sub-steps asked for -- the call then fails with PMCX_EINVAL and no probabilities are
+ * left for the transport: the reference would loop that often on the CPU), n_class_part
+ * [n_cells][n_class].  Synchronises.
  */
 typedef struct pmcx_trans_fields {
     int32_t nx, nz, ny;
@@ -487,6 +504,18 @@ int pmcx_set_gas_scenario(pmcx_ctx *ctx, int32_t n_time_e, const double *emissio
 int pmcx_scenario_update_gas_state(pmcx_ctx *ctx, double dt, double elapsed_time,
                                    const double *height, const double *old_height);
 
+/* The cells the loop nest of partmc_timestep covers (wrf_pmc_driver.F90:157-171): every owned cell
+ * when the domain is doubly periodic, otherwise the interior 2 .. global_n-1 in x and y.  in_loop
+ * [n_cells], 0: pmcx_timestep (mc_coag, both scenario updates, sea salt, rebalance) and pmcx_rebalance
+ * (trans_aero's rebalance runs over the same cells, wrf_pmc_trans_aero.F90:775-801) leave the cell
+ * alone; its counters read zero.  NULL: every cell again (the default).  pmcx_mc_coag and the
+ * scenario updates called on their own honour it too. */
+int pmcx_set_loop_cells(pmcx_ctx *ctx, const int32_t *in_loop);
+
+/* The largest cap a configuration admits: list entries and offsets are 16-bit, so
+ * cap + cap/8 + 16 n_class n_bin <= 65535 (and cap <= 65280); a multiple of 64.  0 if none. */
+int32_t pmcx_max_cap(const pmcx_config *cfg);
+
 /* Global id of local cell 0 (the RNG key, pmcx_config.cell_id_base) of an existing context:
  * what a per-cell caller changes between cells instead of rebuilding the context. */
 int pmcx_set_cell_id_base(pmcx_ctx *ctx, uint32_t cell_id_base);
@@ -496,10 +525,12 @@ int pmcx_set_cell_id_base(pmcx_ctx *ctx, uint32_t cell_id_base);
  *   mc_coag when do_coagulation and mod(elapsed_time, partmc_chem_dt) == 0     driver:189-198
  *   scenario_update_gas_state (when a gas scenario is resident and height given) driver:202-205
  *   scenario_update_aero_state (when any of the three aerosol inputs is given)  driver:207-210
+ *   seasalt_emissions on the ocean surface cells (when sea_salt_opt > 0)         driver:212-223
  *   aero_state_rebalance                                                        driver:248-250
- * Sea salt (driver:212-223) and MOSAIC (driver:232-245) are outside this library.  RNG step
- * index: chemistry-step count for mc_coag, WRF-step count (elapsed_time / dt) for the rest. */
+ * over the cells of pmcx_set_loop_cells.  MOSAIC (driver:232-245) is outside this library.  RNG
+ * step index: chemistry-step count for mc_coag, WRF-step count (elapsed_time / dt) for the rest. */
 typedef struct {
+    int32_t struct_size;     /* sizeof(pmcx_step_flags): checked (pmcx_step_flags_default sets it) */
     int32_t do_coagulation;  /* grid%do_coagulation                       */
     int32_t allow_doubling;  /* grid%allow_doubling                       */
     int32_t allow_halving;   /* grid%allow_halving                        */
@@ -514,7 +545,18 @@ typedef struct {
     const pmcx_aero_dist *aero_emission;   /* as pmcx_scenario_update_aero_state                 */
     const double *aero_dilution_rate;      /* [n_cells]                                          */
     const pmcx_aero_dist *aero_background;
+    /* seasalt_emissions between the scenario update and the rebalance (driver:212-223), when
+     * sea_salt_opt = grid%partmc_seasalt_param > 0: arguments as pmcx_seasalt_emissions (height above
+     * is env_state%height and is required then) */
+    int32_t sea_salt_opt, i_na, i_cl, pad_;
+    const int32_t *ocean_surface;          /* [n_cells] k == 1 .and. xland > 1.5                 */
+    const double *wind_speed;              /* [n_cells]                                           */
+    const int32_t *ss_mode_class, *ss_mode_source;
 } pmcx_step_flags;
+
+/* zeros, struct_size, kernel_type = COAG_KERNEL_TYPE_BROWN, do_coagulation = allow_doubling =
+ * allow_halving = 1 (registry.partmc:2,14-15), partmc_chem_dt = 60 (registry.partmc:24) */
+void pmcx_step_flags_default(pmcx_step_flags *flags);
 
 int pmcx_timestep(pmcx_ctx *ctx, const pmcx_step_flags *flags);
 

@@ -67,26 +67,83 @@ def test_code_objects_are_gfx950_only(wp):
         assert b"gfx950" in data and b"gfx942" not in data and b"sm_90" not in data
 
 
-def test_fortran_shim_binds_only_declared_entry_points():
-    """Every bind(c, name=...) of the ISO_C_BINDING shim names a function include/pmcx.h
-    declares, and the bind(c) mirror of pmcx_config lists the header's fields in order."""
-    shim = open(os.path.join(ROOT, "wrf-partmc_amd", "fortran", "pmcx_shim.F90")).read()
-    bound = set(re.findall(r'bind\(c,\s*name="(pmcx_[a-z0-9_]+)"\)', shim))
+# test hooks and diagnostics of include/pmcx.h: everything else is a product entry point
+_TEST_HOOKS = {"pmcx_get_bin_tables", "pmcx_get_diag_grid", "pmcx_get_kmax", "pmcx_get_caches", "pmcx_get_sort",
+               "pmcx_get_keys", "pmcx_test_math", "pmcx_test_philox", "pmcx_set_sampler_variant",
+               "pmcx_profile_phase_cycles", "pmcx_invalidate_lists"}
+
+
+def _struct_fields(header, name):
+    body = header[:header.index("} %s;" % name)]
+    body = body[body.rindex("typedef struct"):]
+    out = []
+    for decl in re.findall(r"\b(?:const\s+)?(?:u?int32_t|u?int64_t|double|float|pmcx_aero_dist)\s*\*?\s*([a-z_0-9, *]+);", body):
+        out += [f.strip().lstrip("*").strip() for f in decl.split(",")]
+    return out
+
+
+def test_fortran_binds_every_product_entry_point():
+    """wrf-partmc_amd/fortran/pmcx_c.F90 binds every function include/pmcx.h declares except the
+    test hooks -- a product entry point without a Fortran binding fails here -- names nothing the
+    header does not declare, and its bind(c) mirrors list the header's struct fields in order."""
+    fdir = os.path.join(ROOT, "wrf-partmc_amd", "fortran")
+    iface = open(os.path.join(fdir, "pmcx_c.F90")).read()
+    shim = open(os.path.join(fdir, "pmcx_shim.F90")).read()
+    bound = set(re.findall(r'bind\(c,\s*name="(pmcx_[a-z0-9_]+)"\)', iface))
     declared = set(_declared_symbols())
-    assert len(bound) >= 20 and bound <= declared, sorted(bound - declared)
-    # the path itself and the rows around it are all reachable from Fortran
-    for name in ("pmcx_mc_coag", "pmcx_rebalance", "pmcx_transport", "pmcx_dry_deposition",
-                 "pmcx_transport_begin", "pmcx_transport_finish", "pmcx_upload_cells",
-                 "pmcx_download_cells"):
-        assert name in bound, name
+    assert bound <= declared, sorted(bound - declared)
+    unbound = declared - bound - _TEST_HOOKS
+    assert not unbound, f"product entry points without a Fortran binding: {sorted(unbound)}"
+    assert 'bind(c' not in shim.replace("bind(c) ::", "")       # the shim declares no interface of its own
+    # the two drop-in drivers carry the reference's argument lists
+    def args(src, name):
+        m = re.search(r"subroutine\s+%s\s*\(([^)]*)\)" % name, src, flags=re.S)
+        return [a.strip() for a in re.sub(r"&|\s", "", m.group(1)).split(",")]
+    ref_ts = ["grid", "config_flags", "scenario", "env_states", "aero_data", "aero_states", "gas_data", "gas_states",
+              "pmc_is", "pmc_ie", "pmc_js", "pmc_je", "pmc_ks", "pmc_ke", "global_nx", "global_ny", "global_nz"]
+    ref_tr = ["grid", "config_flags", "env_states", "scenario", "aero_data", "aero_states", "gas_states", "pmc_is",
+              "pmc_ie", "pmc_js", "pmc_je", "pmc_ks", "pmc_ke", "global_nx", "global_ny", "global_nz"]
+    assert args(shim, "partmc_timestep_pmcx") == ref_ts            # wrf_pmc_driver.F90:46-48
+    assert args(shim, "wrf_pmc_trans_driver_pmcx") == ref_tr       # wrf_pmc_trans.F90:37-39
+    assert args(shim, "mc_coag_pmcx") == ["coag_kernel_type", "env_state", "aero_data", "aero_state", "del_t",
+                                           "tot_n_samp", "tot_n_coag"]                       # driver:192-194
     header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "pmcx.h")).read(), flags=re.S)
-    struct = header[header.index("typedef struct {"):header.index("} pmcx_config;")]
-    c_fields = re.findall(r"\b(?:u?int32_t|double)\s+([a-z_0-9, ]+);", struct)
-    c_fields = [f.strip() for grp in c_fields for f in grp.split(",")]
-    f_type = shim[shim.index("type, bind(c) :: pmcx_config"):shim.index("end type pmcx_config")]
-    f_fields = [f.strip() for grp in re.findall(r"::\s*([a-z_0-9, ]+)", f_type.split("\n", 1)[1])
-                for f in grp.split(",")]
-    assert f_fields == c_fields, (f_fields, c_fields)
+    for c_name, f_name in (("pmcx_config", "pmcx_config"), ("pmcx_trans_fields", "pmcx_trans_fields_t"),
+                           ("pmcx_aero_dist", "pmcx_aero_dist_t"), ("pmcx_step_flags", "pmcx_step_flags_t")):
+        f_type = iface[iface.index("type, bind(c) :: %s\n" % f_name):iface.index("end type %s\n" % f_name)]
+        f_fields = [f.strip() for grp in re.findall(r"::\s*([a-z_0-9, ]+)", f_type.split("\n", 1)[1])
+                    for f in grp.split(",")]
+        assert f_fields == _struct_fields(header, c_name), (c_name, f_fields, _struct_fields(header, c_name))
+
+
+def test_ctypes_mirrors_match_the_header_layout(wp, tmp_path):
+    """The ctypes Structures of host.py against the C compiler's own layout of include/pmcx.h:
+    size and every field offset (a caller built against another header must not pass a shorter
+    struct unnoticed: pmcx_config and pmcx_step_flags also carry their size)."""
+    import subprocess
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "pmcx.h")).read(), flags=re.S)
+    pairs = (("pmcx_config", wp.PmcxConfig), ("pmcx_trans_fields", wp.host.PmcxTransFields),
+             ("pmcx_aero_dist", wp.host.PmcxAeroDist), ("pmcx_step_flags", wp.host.PmcxStepFlags))
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "pmcx.h"\nint main(void){\n'
+    for c_name, _ in pairs:
+        src += 'printf("%s %%zu", sizeof(%s));\n' % (c_name, c_name)
+        for f in _struct_fields(header, c_name):
+            src += 'printf(" %s=%%zu", offsetof(%s, %s));\n' % (f, c_name, f)
+        src += 'printf("\\n");\n'
+    src += "return 0;}\n"
+    (tmp_path / "layout.c").write_text(src)
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(tmp_path / "layout"),
+                           str(tmp_path / "layout.c")])
+    lines = subprocess.check_output([str(tmp_path / "layout")], text=True).strip().split("\n")
+    for (c_name, cls), line in zip(pairs, lines):
+        parts = line.split()
+        assert parts[0] == c_name and int(parts[1]) == ctypes.sizeof(cls), (line, ctypes.sizeof(cls))
+        want = [(p.split("=")[0], int(p.split("=")[1])) for p in parts[2:]]
+        got = [(n, getattr(cls, n).offset) for n, _ in cls._fields_]
+        assert got == want, (c_name, got, want)
+    flags = wp.host.PmcxStepFlags()
+    wp.load_library().pmcx_step_flags_default(ctypes.byref(flags))
+    assert flags.struct_size == ctypes.sizeof(wp.host.PmcxStepFlags) and flags.partmc_chem_dt == 60.0
 
 
 def test_integration_notes_cover_every_entry_point():

@@ -172,8 +172,8 @@ def test_fortran_resident_sequence(tmp_path, wp):
         blk.set_env(T, P, np.full(n_cells, 0.5))
         blk.set_weights(mag)
         blk.set_n_part_ideal(np.tile(n_ideal, (n_cells, 1)))
-        # the shim gives every cell its own block of PartMC's id counter (pmcx_upload_states)
-        blk.set_next_id(1 + np.arange(n_cells, dtype=np.int64) * 2 * cap)
+        # the shim gives every cell its own block of 2**32 ids of PartMC's counter (pmcx_upload_states)
+        blk.set_next_id(1 + (np.arange(n_cells, dtype=np.int64) << 32))
         po = np.arange(n_cells + 1, dtype=np.int64) * n_part
         blk.upload_cells(0, po, vol.transpose(1, 0, 2).reshape(n_spec, -1), wcl.reshape(-1),
                          ids.reshape(-1), lct.reshape(-1), lct.reshape(-1) + 1.0,
@@ -272,7 +272,7 @@ def test_fortran_resident_sequence_from_fields(tmp_path, wp):
         blk.set_env(T, P, np.full(n_cells, 0.5))
         blk.set_weights(mag)
         blk.set_n_part_ideal(np.tile(n_ideal, (n_cells, 1)))
-        blk.set_next_id(1 + np.arange(n_cells, dtype=np.int64) * 2 * cap)
+        blk.set_next_id(1 + (np.arange(n_cells, dtype=np.int64) << 32))
         po = np.arange(n_cells + 1, dtype=np.int64) * n_part
         blk.upload_cells(0, po, vol.transpose(1, 0, 2).reshape(n_spec, -1), wcl.reshape(-1),
                          ids.reshape(-1), lct.reshape(-1), lct.reshape(-1) + 1.0,

@@ -532,8 +532,9 @@ def test_aerodynamic_resistance_and_landuse_tables():
     assert ra[1] > ra[0] > ra[2] > 0            # stable > neutral > unstable
     assert aerodynamic_resistance(0.0, 0.1, 0.0) == 0.74 * np.log(20.0) / (0.4 * 1e-4)
     alpha, big_a = zhang_surface_parameters([1, 7, 16, 24, 0, 99])
-    assert list(alpha) == [1.5, 1.2, 100.0, 50.0, 1.2, 1.2]        # urban, grass, water, ice, fallback
-    assert list(big_a) == [0.010, 0.002, 9.999, 9.999, 0.002, 0.002]
+    w = lambda xs: [float(np.float32(x)) for x in xs]   # (default-real literals of the reference, widened)
+    assert list(alpha) == w([1.5, 1.2, 100.0, 50.0, 1.2, 1.2])     # urban, grass, water, ice, fallback
+    assert list(big_a) == w([0.010, 0.002, 9.999, 9.999, 0.002, 0.002])
 
 
 def test_cdf_codec_against_scipy(tmp_path):

@@ -81,6 +81,10 @@ struct pmcx_ctx {
     GasScenarioDev gas_scn{};
     std::vector<void *> gas_scn_allocs; // the scenario's device arrays
     double *d_height = nullptr;         // [2][n_cells] height, old height of the current update
+    uint8_t *d_loop_mask = nullptr;     // [n_cells] pmcx_set_loop_cells (allocated on first use)
+    // pmcx_set_aero_scenario_modes: the mode parameters of the emission (0) and background (1)
+    // distributions kept between calls (a dist passed with gm_radius == NULL refers to them)
+    struct ResidentModes { GenSpecDev g{}; void *dd = nullptr, *di = nullptr; } res_modes[2];
     int bounds_kernel = 0; // kernel type the kmax tables are valid for (0 = none)
     int bounds_margin = 8;     // bins above a cell's populated range its bounds cover (< 0: whole tables)
     bool bounds_dirty = true;  // something other than mc_coag changed a population since the last check
@@ -411,6 +415,7 @@ int pmcx_destroy(pmcx_ctx *ctx)
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     for (void *p : ctx->allocs) (void)hipFree(p);
     for (void *p : ctx->gas_scn_allocs) (void)hipFree(p);
+    for (auto &r : ctx->res_modes) { if (r.dd) (void)hipFree(r.dd); if (r.di) (void)hipFree(r.di); }
     for (auto &b : ctx->tmp_blocks) (void)hipFree(b.p);
     if (ctx->stage) (void)hipFree(ctx->stage);
     if (ctx->d_offsets) (void)hipFree(ctx->d_offsets);
@@ -930,36 +935,81 @@ int pmcx_rebalance(pmcx_ctx *ctx, int32_t allow_doubling, int32_t allow_halving,
 }
 
 namespace {
-// uploads one aero_dist into a fresh device block; returns the device view
-int upload_dist(pmcx_ctx *ctx, const pmcx_aero_dist *d, std::vector<void *> &tmp, GenSpecDev &g,
-                double *&conc_dev)
+// The mode parameters of an aero_dist (everything but num_conc) as host arrays in the device's
+// layout: parameters of cell c at [c][m] when per_cell (a list's rows go to their cells' places).
+int pack_modes(pmcx_ctx *ctx, const pmcx_aero_dist *d, size_t n_rows, const int32_t *row_cell,
+               std::vector<double> &h, std::vector<int32_t> &hi, size_t &R)
 {
     const int S = ctx->cfg.n_spec, M = d->n_mode;
     const size_t nc = (size_t)ctx->cfg.n_cells;
-    if (M < 1 || M > 64 || !d->num_conc || !d->gm_radius || !d->gsd_log10 || !d->vol_frac)
+    if (M < 1 || M > 64 || !d->gm_radius || !d->gsd_log10 || !d->vol_frac)
         return fail(ctx, PMCX_EINVAL, "aero_dist: bad n_mode or null array");
-    std::vector<double> h(2 * (size_t)M + (size_t)M * S);
-    std::vector<int32_t> hi(2 * (size_t)M);
-    for (int m = 0; m < M; m++) {
-        h[m] = std::log(d->gm_radius[m]);
-        h[M + m] = d->gsd_log10[m] * std::log(10.0);
-        for (int s = 0; s < S; s++) h[2 * M + (size_t)m * S + s] = d->vol_frac[(size_t)m * S + s];
-        hi[m] = d->mode_class ? d->mode_class[m] : 0;
-        hi[M + m] = d->mode_source ? d->mode_source[m] : 0;
-        if (hi[m] < 0 || hi[m] >= ctx->cfg.n_class)
-            return fail(ctx, PMCX_EINVAL, "aero_dist: mode_class[%d] out of range", m);
+    const bool pc = d->per_cell != 0;
+    if (pc && (!d->mode_class || !d->mode_source))
+        return fail(ctx, PMCX_EINVAL, "aero_dist: per_cell needs mode_class and mode_source");
+    if (!n_rows) n_rows = nc;
+    R = pc ? nc : 1;
+    h.assign(R * (2 * (size_t)M + (size_t)M * S), 0.0);
+    hi.assign(R * 2 * (size_t)M, 0);
+    double *h_gm = h.data(), *h_gs = h_gm + R * M, *h_vf = h_gs + R * M;
+    int32_t *h_mc = hi.data(), *h_ms = h_mc + R * M;
+    const size_t rows = pc ? n_rows : 1;
+    for (size_t r = 0; r < rows; r++) {
+        const size_t c = pc ? (row_cell ? (size_t)row_cell[r] : r) : 0;
+        for (int m = 0; m < M; m++) {
+            const size_t src = r * M + m, dst = c * M + m;
+            if (!(d->gm_radius[src] > 0)) return fail(ctx, PMCX_EINVAL, "aero_dist: gm_radius must be positive");
+            h_gm[dst] = std::log(d->gm_radius[src]);
+            h_gs[dst] = d->gsd_log10[src] * std::log(10.0);
+            for (int s = 0; s < S; s++) h_vf[dst * S + s] = d->vol_frac[src * S + s];
+            h_mc[dst] = d->mode_class ? d->mode_class[src] : 0;
+            h_ms[dst] = d->mode_source ? d->mode_source[src] : 0;
+            if (h_mc[dst] < 0 || h_mc[dst] >= ctx->cfg.n_class)
+                return fail(ctx, PMCX_EINVAL, "aero_dist: mode_class[%d] out of range", m);
+        }
     }
-    double *dd = nullptr; int32_t *di = nullptr;
-    HIP_TRY(ctx, tmp_malloc(ctx, (void **)&dd, sizeof(double) * h.size())); tmp.push_back(dd);
-    HIP_TRY(ctx, tmp_malloc(ctx, (void **)&di, sizeof(int32_t) * hi.size())); tmp.push_back(di);
+    return PMCX_OK;
+}
+
+void modes_view(GenSpecDev &g, int M, size_t R, double *dd, int32_t *di, bool pc)
+{
+    g.n_mode = M; g.mode_frac = nullptr;
+    g.ln_gm_radius = dd; g.ln_gsd = dd + R * M; g.vol_frac = dd + 2 * R * M;
+    g.mode_class = di; g.mode_source = di + R * M;
+    g.per_cell = pc ? 1 : 0;
+}
+
+// uploads one aero_dist into device blocks of the call; returns the device view.  n_rows: cells the
+// per-cell arrays of a per_cell dist cover (n_cells, or the entries of a list).  kind: 0 emission,
+// 1 background -- a dist whose gm_radius is NULL stands for the resident modes of that kind
+// (pmcx_set_aero_scenario_modes) and brings only its num_conc.
+int upload_dist(pmcx_ctx *ctx, const pmcx_aero_dist *d, std::vector<void *> &tmp, GenSpecDev &g,
+                double *&conc_dev, size_t n_rows = 0, const int32_t *row_cell = nullptr, int kind = -1)
+{
+    const int M = d->n_mode;
+    const size_t nc = (size_t)ctx->cfg.n_cells;
+    if (!d->num_conc) return fail(ctx, PMCX_EINVAL, "aero_dist: num_conc is NULL");
+    if (!d->gm_radius) {
+        if (kind < 0 || kind > 1 || !ctx->res_modes[kind].dd)
+            return fail(ctx, PMCX_ESTATE, "aero_dist without mode parameters: pmcx_set_aero_scenario_modes "
+                                          "has not set the %s modes", kind == 1 ? "background" : "emission");
+        g = ctx->res_modes[kind].g;
+        if (M != g.n_mode) return fail(ctx, PMCX_EINVAL, "aero_dist: n_mode %d, the resident modes are %d", M, g.n_mode);
+    } else {
+        std::vector<double> h; std::vector<int32_t> hi; size_t R = 1;
+        int rc = pack_modes(ctx, d, n_rows, row_cell, h, hi, R);
+        if (rc) return rc;
+        double *dd = nullptr; int32_t *di = nullptr;
+        HIP_TRY(ctx, tmp_malloc(ctx, (void **)&dd, sizeof(double) * h.size())); tmp.push_back(dd);
+        HIP_TRY(ctx, tmp_malloc(ctx, (void **)&di, sizeof(int32_t) * hi.size())); tmp.push_back(di);
+        HIP_TRY(ctx, hipMemcpyAsync(dd, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(di, hi.data(), sizeof(int32_t) * hi.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // (h, hi go out of scope)
+        modes_view(g, M, R, dd, di, d->per_cell != 0);
+    }
     HIP_TRY(ctx, tmp_malloc(ctx, (void **)&conc_dev, sizeof(double) * nc * M)); tmp.push_back(conc_dev);
-    HIP_TRY(ctx, hipMemcpyAsync(dd, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(di, hi.data(), sizeof(int32_t) * hi.size(), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(conc_dev, d->num_conc, sizeof(double) * nc * M, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    g.n_mode = M; g.mode_frac = nullptr;
-    g.ln_gm_radius = dd; g.ln_gsd = dd + M; g.vol_frac = dd + 2 * M;
-    g.mode_class = di; g.mode_source = di + M;
     return PMCX_OK;
 }
 } // namespace
@@ -980,8 +1030,8 @@ int pmcx_scenario_update_aero_state(pmcx_ctx *ctx, double dt, double elapsed_tim
     double *ce = nullptr, *cbg = nullptr, *d_dil = nullptr;
     int32_t *d_cnt = nullptr;
     int rc = PMCX_OK;
-    if (emission) rc = upload_dist(ctx, emission, tmp, ge, ce);
-    if (!rc && background) rc = upload_dist(ctx, background, tmp, gb, cbg);
+    if (emission) rc = upload_dist(ctx, emission, tmp, ge, ce, 0, nullptr, 0);
+    if (!rc && background) rc = upload_dist(ctx, background, tmp, gb, cbg, 0, nullptr, 1);
     if (rc) { cleanup(); return rc; }
     hipError_t e = hipSuccess;
     if (dilution_rate) {
@@ -1003,6 +1053,28 @@ int pmcx_scenario_update_aero_state(pmcx_ctx *ctx, double dt, double elapsed_tim
     cleanup();
     HIP_TRY(ctx, invalidate_sort(ctx, 0, ctx->cfg.n_cells, false)); // (the kernel keeps the sort keys current)
     if (e != hipSuccess) return fail(ctx, PMCX_EDEVICE, "pmcx_scenario_update_aero_state: %s", hipGetErrorString(e));
+    return PMCX_OK;
+}
+
+int pmcx_set_aero_scenario_modes(pmcx_ctx *ctx, int32_t which, const pmcx_aero_dist *dist)
+{
+    if (!ctx || which < 0 || which > 1) return fail(ctx, PMCX_EINVAL, "pmcx_set_aero_scenario_modes: which is 0 (emission) or 1 (background)");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    auto &r = ctx->res_modes[which];
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (r.dd) { (void)hipFree(r.dd); r.dd = nullptr; }
+    if (r.di) { (void)hipFree(r.di); r.di = nullptr; }
+    r.g = GenSpecDev{};
+    if (!dist) return PMCX_OK; // forgotten
+    std::vector<double> h; std::vector<int32_t> hi; size_t R = 1;
+    int rc = pack_modes(ctx, dist, 0, nullptr, h, hi, R);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMalloc(&r.dd, sizeof(double) * h.size()));
+    HIP_TRY(ctx, hipMalloc(&r.di, sizeof(int32_t) * hi.size()));
+    HIP_TRY(ctx, hipMemcpyAsync(r.dd, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(r.di, hi.data(), sizeof(int32_t) * hi.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    modes_view(r.g, dist->n_mode, R, (double *)r.dd, (int32_t *)r.di, dist->per_cell != 0);
     return PMCX_OK;
 }
 
@@ -1194,7 +1266,7 @@ int pmcx_transport_probs(pmcx_ctx *ctx, const pmcx_trans_fields *f, double *prob
         if (ctx->d_prob_h) return fail(ctx, PMCX_ESTATE, "pmcx_transport_probs: nz differs from the first call's");
         int rc = dev_alloc(ctx, &ctx->d_prob_h, nc * C * 4);
         if (!rc) rc = dev_alloc(ctx, &ctx->d_prob_v, nc * C * (size_t)nz);
-        if (!rc) rc = dev_alloc(ctx, &ctx->d_prob_i, nc + nc * C + nc);
+        if (!rc) rc = dev_alloc(ctx, &ctx->d_prob_i, nc + nc * C + nc + 1);
         if (rc) return rc;
         ctx->probs_nz = nz;
     }
@@ -1224,16 +1296,24 @@ int pmcx_transport_probs(pmcx_ctx *ctx, const pmcx_trans_fields *f, double *prob
     a.z = dev[5]; a.z_at_w = dev[6]; a.exch_h = dev[7];
     a.prob_h = ctx->d_prob_h; a.prob_v = ctx->d_prob_v;
     a.bad = ctx->d_prob_i; a.n_class_part = ctx->d_prob_i + nc; a.n_substeps = ctx->d_prob_i + nc + nc * C;
+    a.clamp_flag = ctx->d_prob_i + nc + nc * C + nc;
+    HIP_TRY(ctx, hipMemsetAsync(a.clamp_flag, 0, sizeof(int32_t), ctx->stream));
     {
         ProfScope ps(ctx, "transport_probs");
         HIP_TRY(ctx, launch_transport_probs(ctx->st, a, ctx->stream));
     }
+    int32_t clamped = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&clamped, a.clamp_flag, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (prob_h) HIP_TRY(ctx, hipMemcpyAsync(prob_h, ctx->d_prob_h, sizeof(double) * nc * C * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (prob_v) HIP_TRY(ctx, hipMemcpyAsync(prob_v, ctx->d_prob_v, sizeof(double) * nc * C * (size_t)nz, hipMemcpyDeviceToHost, ctx->stream));
     if (bad) HIP_TRY(ctx, hipMemcpyAsync(bad, a.bad, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));
     if (n_class_part) HIP_TRY(ctx, hipMemcpyAsync(n_class_part, a.n_class_part, sizeof(int32_t) * nc * C, hipMemcpyDeviceToHost, ctx->stream));
     if (n_substeps) HIP_TRY(ctx, hipMemcpyAsync(n_substeps, a.n_substeps, sizeof(int32_t) * col, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (clamped)
+        return fail(ctx, PMCX_EINVAL, "pmcx_transport_probs: a column asks for more than 10^4 vertical "
+                                      "sub-steps (z(2) - z(1) too small or exch_h too large; bit 16 of bad[]): "
+                                      "the probabilities were not built");
     ctx->probs_nx = nx; ctx->probs_ny = ny;
     return PMCX_OK;
 }
@@ -1299,7 +1379,7 @@ int pmcx_boundary_resample(pmcx_ctx *ctx, int32_t n_list, const int32_t *cell, c
     GenSpecDev gb{};
     double *cbg = nullptr, *d_dens = nullptr;
     int32_t *d_i = nullptr;
-    int rc = upload_dist(ctx, &d, tmp, gb, cbg);
+    int rc = upload_dist(ctx, &d, tmp, gb, cbg, (size_t)n_list, cell); // (per_cell: rows follow the list)
     if (rc) { cleanup(); return rc; }
     hipError_t e = tmp_malloc(ctx, (void **)&d_dens, sizeof(double) * nc);
     if (e == hipSuccess) tmp.push_back(d_dens);
@@ -1402,7 +1482,7 @@ int pmcx_transport_preweight_begin(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_
         if (!ctx->d_prob_h) {
             rc = dev_alloc(ctx, &ctx->d_prob_h, nc * C * 4);
             if (!rc) rc = dev_alloc(ctx, &ctx->d_prob_v, nc * C * (size_t)nz);
-            if (!rc) rc = dev_alloc(ctx, &ctx->d_prob_i, nc + nc * C + nc);
+            if (!rc) rc = dev_alloc(ctx, &ctx->d_prob_i, nc + nc * C + nc + 1);
             if (rc) return rc;
             ctx->probs_nz = nz;
         } else if (ctx->probs_nz != nz) {
@@ -1882,17 +1962,63 @@ int pmcx_scenario_update_gas_state(pmcx_ctx *ctx, double dt, double elapsed_time
     ProfScope ps(ctx, "gas_scenario");
     HIP_TRY(ctx, launch_gas_update(ctx->gas_scn, ctx->d_gas, ctx->d_temp, ctx->d_pressure, ctx->d_height,
                                    old_height ? ctx->d_height + nc : nullptr, ctx->cfg.n_cells, dt,
-                                   elapsed_time, ctx->stream));
+                                   elapsed_time, ctx->stream, ctx->st.loop_mask));
     return PMCX_OK;
+}
+
+void pmcx_step_flags_default(pmcx_step_flags *f)
+{
+    memset(f, 0, sizeof *f);
+    f->struct_size = (int32_t)sizeof(pmcx_step_flags);
+    f->do_coagulation = 1; f->allow_doubling = 1; f->allow_halving = 1;
+    f->kernel_type = PMCX_COAG_KERNEL_TYPE_BROWN;
+    f->partmc_chem_dt = 60.0;
+}
+
+int pmcx_set_loop_cells(pmcx_ctx *ctx, const int32_t *in_loop)
+{
+    if (!ctx) return PMCX_EINVAL;
+    if (!in_loop) { ctx->st.loop_mask = nullptr; return PMCX_OK; }
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t nc = (size_t)ctx->cfg.n_cells;
+    if (!ctx->d_loop_mask) {
+        int rc = dev_alloc(ctx, &ctx->d_loop_mask, nc);
+        if (rc) return rc;
+    }
+    std::vector<uint8_t> h(nc);
+    for (size_t k = 0; k < nc; k++) h[k] = in_loop[k] ? 1 : 0;
+    int rc = copy_cells_h2d(ctx, ctx->d_loop_mask, h.data(), nc);
+    if (rc) return rc;
+    ctx->st.loop_mask = ctx->d_loop_mask;
+    return PMCX_OK;
+}
+
+int32_t pmcx_max_cap(const pmcx_config *cfg)
+{
+    if (!cfg || cfg->n_class < 1 || cfg->n_bin < 1) return 0;
+    // cap + cap / 8 + 16 n_class n_bin <= 65535, cap <= 65280, cap a multiple of 64
+    const int64_t room = 65535 - 16 * (int64_t)cfg->n_class * cfg->n_bin;
+    if (room < 72) return 0;
+    int64_t cap = room * 8 / 9;
+    if (cap > 65280) cap = 65280;
+    cap &= ~(int64_t)63;
+    while (cap >= 64 && cap + cap / 8 > room) cap -= 64;
+    return cap >= 64 ? (int32_t)cap : 0;
 }
 
 int pmcx_timestep(pmcx_ctx *ctx, const pmcx_step_flags *f)
 {
     if (!ctx || !f) return fail(ctx, PMCX_EINVAL, "pmcx_timestep: null argument");
+    if (f->struct_size != (int32_t)sizeof(pmcx_step_flags))
+        return fail(ctx, PMCX_EINVAL, "pmcx_step_flags size mismatch (%d vs %zu): built against another "
+                                      "include/pmcx.h? (pmcx_step_flags_default sets it)",
+                    f->struct_size, sizeof(pmcx_step_flags));
     if (!(f->dt > 0) || !(f->partmc_chem_dt > 0) || !(f->elapsed_time >= 0))
         return fail(ctx, PMCX_EINVAL, "pmcx_timestep: dt and partmc_chem_dt must be positive");
     if (!ctx->n_ideal_set)
         return fail(ctx, PMCX_ESTATE, "pmcx_timestep: pmcx_set_n_part_ideal must come first");
+    if (f->sea_salt_opt > 0 && (!f->height || !f->ocean_surface || !f->wind_speed))
+        return fail(ctx, PMCX_EINVAL, "pmcx_timestep: sea salt needs height, ocean_surface and wind_speed");
     // chemistry-step gate, interface/wrf_pmc_driver.F90:189
     const bool chem_step = std::fmod(f->elapsed_time, f->partmc_chem_dt) == 0.0;
     const uint32_t step = (uint32_t)(f->elapsed_time / f->partmc_chem_dt);
@@ -1910,6 +2036,12 @@ int pmcx_timestep(pmcx_ctx *ctx, const pmcx_step_flags *f)
         rc = pmcx_scenario_update_aero_state(ctx, f->dt, f->elapsed_time, f->random_seed, wrf_step,
                                              f->aero_emission, f->aero_dilution_rate,
                                              f->aero_background, nullptr, nullptr, nullptr);
+        if (rc) return rc;
+    }
+    if (f->sea_salt_opt > 0) {                                                   // driver:212-223
+        rc = pmcx_seasalt_emissions(ctx, f->dt, f->elapsed_time, f->random_seed, wrf_step, f->sea_salt_opt,
+                                    f->i_na, f->i_cl, f->ocean_surface, f->wind_speed, f->height,
+                                    f->ss_mode_class, f->ss_mode_source, nullptr, nullptr);
         if (rc) return rc;
     }
     return pmcx_rebalance(ctx, f->allow_doubling, f->allow_halving, f->random_seed, wrf_step); // :248-250

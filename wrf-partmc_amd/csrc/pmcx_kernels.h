@@ -91,12 +91,15 @@ struct DeviceState {
     int32_t force_lanes, force_wpb, force_stamps;
     uint16_t *seq_ovf;   // [n_cells][2 G + 2 max_appends] lane-per-cell sampler: entries past a group's room
     int32_t *n_events, *n_samp, *n_coag, *status; // [n_cells]
+    // pmcx_set_loop_cells: the cells partmc_timestep's loop nest covers (nullptr: every cell)
+    const uint8_t *loop_mask;
 };
 
 struct GenSpecDev {
     int32_t n_mode;
     const double *mode_frac, *ln_gm_radius, *ln_gsd, *vol_frac;
     const int32_t *mode_class, *mode_source;
+    int32_t per_cell; // 1: ln_gm_radius .. mode_source are [n_cells][n_mode] (k_scenario_update, k_boundary_resample)
 };
 
 // the gas half of scenario_t, resident (pmcx_set_gas_scenario)
@@ -156,7 +159,8 @@ hipError_t launch_scenario_update(const DeviceState &st, double dt, double creat
 // background's, 2 the sea-salt source -- so that sources acting in one step stay independent)
 hipError_t launch_gas_update(const GasScenarioDev &g, double *mix_rat, const double *temp,
                              const double *pressure, const double *height, const double *old_height,
-                             int n_cells, double dt, double elapsed_time, hipStream_t s);
+                             int n_cells, double dt, double elapsed_time, hipStream_t s,
+                             const uint8_t *loop_mask = nullptr);
 size_t transport_lds_bytes(const DeviceState &st, int nz);
 hipError_t launch_transport(const DeviceState &st, int nx, int nz, int ny, int periodic_x,
                             int periodic_y, const double *prob_h, const double *prob_v,
@@ -179,6 +183,7 @@ struct TransFieldsArgs {
     const float *alt, *xkhh, *u_flux, *v_flux, *w_flux, *z, *z_at_w, *exch_h;
     double *prob_h, *prob_v;
     int32_t *n_substeps, *bad, *n_class_part;
+    int32_t *clamp_flag;
 };
 hipError_t launch_boundary_copy(const DeviceState &st, int n_pairs, const int32_t *from, const int32_t *to,
                                 hipStream_t s);

@@ -95,6 +95,15 @@ __device__ __forceinline__ int32_t &norig(const DeviceState &st, int64_t cb, int
     return st.n_orig[cb * (st.n_source - 1) + (int64_t)(s - 1) * st.cap + i];
 }
 
+// The cells the loop nest of partmc_timestep covers (interface/wrf_pmc_driver.F90:157-171: every
+// owned cell when the domain is doubly periodic, otherwise the interior 2 .. n-1 in x and y):
+// pmcx_set_loop_cells.  A cell outside it is left alone by mc_coag, the scenario updates and the
+// rebalance (its lists may still be sorted: that changes nothing a result depends on).
+__device__ __forceinline__ bool in_loop(const DeviceState &st, int c)
+{
+    return !st.loop_mask || st.loop_mask[c] != 0;
+}
+
 // tombstone: the slot stays allocated, every consumer skips it (live_class: a negative cached
 // total volume is the one mark; wclass of a dead slot is unspecified)
 __device__ __forceinline__ void mark_dead(const DeviceState &st, int64_t cb, int i)
@@ -865,12 +874,14 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
     const bool lead = gl == 0;
     const int cpb = (blockDim.x >> 6) * GPW;
     const int cidx = blockIdx.x * cpb + wave * GPW + sub;
-    const bool live = cidx < st.n_cells;
+    const bool in_range = cidx < st.n_cells;
+    const bool live = in_range && in_loop(st, cidx);
     const int c = live ? cidx : st.n_cells - 1;
     const int B = st.n_bin, C = st.n_class, G = B * C;
     const int64_t cb = (int64_t)c * st.cap;
     const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
     const uint64_t lt = (1ull << gl) - 1ull;
+    if (in_range && !live && lead) { st.n_samp[cidx] = 0; st.n_coag[cidx] = 0; st.n_events[cidx] = 0; }
 
     // sort-grid edges, shared by the workgroup
     double *edge = (double *)smem;
@@ -1348,8 +1359,9 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
     const bool role_e = !SPLIT || (threadIdx.x >> 6) == 0; // evaluates and coagulates
     const bool role_d = !SPLIT || (threadIdx.x >> 6) == 1; // settles the slots
     const int cidx = blockIdx.x * 64 + lane;
-    const bool live = cidx < st.n_cells;
+    const bool live = cidx < st.n_cells && in_loop(st, cidx);
     const int c = live ? cidx : st.n_cells - 1;
+    if (cidx < st.n_cells && !live && role_e) { st.n_samp[cidx] = 0; st.n_coag[cidx] = 0; st.n_events[cidx] = 0; }
     const int ktype = KT ? KT : ktype_rt;
     const int B = st.n_bin, C = SIMPLE ? 1 : st.n_class, G = B * C;
     const int S = SIMPLE ? 1 : st.n_spec, NS = st.n_source;
@@ -2319,6 +2331,7 @@ __global__ __launch_bounds__(64) void k_rebalance(DeviceState st, int allow_doub
     const int n_work = list ? *count : st.n_cells;
   for (int wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
     const int c = list ? list[wi] : wi;
+    if (!in_loop(st, c)) continue; // (uniform over the wavefront)
     const int64_t cb = (int64_t)c * st.cap;
     const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
     const uint64_t lt = (1ull << lane) - 1ull;
@@ -2559,6 +2572,11 @@ struct AeroDistDev {
     const double *num_conc;     // [n_cells][n_mode]
     const double *ln_gm_radius, *ln_gsd, *vol_frac;
     const int32_t *mode_class, *mode_source;
+    // 0: the mode parameters are [n_mode] ([n_mode][n_spec]), shared by every cell; 1: every cell has
+    // its own, [n_cells][n_mode] (the reference reads a cell's emission and boundary modes from that
+    // cell's file, wrf_pmc_init.F90:583-804, 809-967)
+    int32_t per_cell;
+    __device__ __forceinline__ int64_t mo(int c) const { return per_cell ? (int64_t)c * n_mode : 0; }
 };
 
 // appends Poisson(num_conc*factor/magnitude) particles per mode; returns how many
@@ -2570,10 +2588,11 @@ __device__ int add_dist_sample(const DeviceState &st, int c, const AeroDistDev &
     const int64_t cb = (int64_t)c * st.cap;
     const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
     const double *mag = st.mag + (int64_t)c * st.n_class;
+    const int64_t mo = d.mo(c);
     int added = 0;
     for (int m = 0; m < d.n_mode; m++) {
         uint32_t w[4];
-        const int cl = d.mode_class[m];
+        const int cl = d.mode_class[mo + m];
         const double mean = means ? means[m] : d.num_conc[(int64_t)c * d.n_mode + m] * factor / mag[cl];
         if (means && mean < 0.0) continue; // (uniform over the wavefront)
         rng_block(seed, cell_id, step, (kind << 8) | (uint32_t)m, SITE_EMIT_N, 0, w);
@@ -2586,17 +2605,17 @@ __device__ int add_dist_sample(const DeviceState &st, int c, const AeroDistDev &
             const int i = n_hi + k;
             rng_block(seed, cell_id, step, (kind << 28) | ((uint32_t)m << 20) | (uint32_t)k, SITE_EMIT_P, 0, w);
             const double z = det_norminv(u53(w[2], w[3]));
-            const double r = det_exp(d.ln_gm_radius[m] + d.ln_gsd[m] * z);
+            const double r = det_exp(d.ln_gm_radius[mo + m] + d.ln_gsd[mo + m] * z);
             const double v = (4.0 / 3.0) * PI * r * r * r;
             double vt = 0.0, ms = 0.0;
             for (int s = 0; s < st.n_spec; s++) {
-                const double vs = d.vol_frac[m * st.n_spec + s] * v;
+                const double vs = d.vol_frac[(mo + m) * st.n_spec + s] * v;
                 st.vol[(cb + i) * st.n_spec + s] = vs;
                 vt = vt + vs;
                 ms = ms + st.density[s] * vs;
             }
             for (int s = 0; s < st.n_source; s++)
-                norig(st, cb, s, i) = (s == d.mode_source[m]) ? 1 : 0;
+                norig(st, cb, s, i) = (s == d.mode_source[mo + m]) ? 1 : 0;
             st.hot[cb + i].vtot = vt;
             st.hot[cb + i].mass = ms;
             st.wclass[cb + i] = cl;
@@ -2633,6 +2652,14 @@ __global__ __launch_bounds__(64) void k_scenario_update(DeviceState st, double d
     const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
     const uint64_t lt = (1ull << lane) - 1ull;
     int status = 0, ne = 0, ni = 0, no = 0;
+    if (!in_loop(st, c)) {
+        if (lane == 0) {
+            if (n_emit) n_emit[c] = 0;
+            if (n_dil_in) n_dil_in[c] = 0;
+            if (n_dil_out) n_dil_out[c] = 0;
+        }
+        return;
+    }
     apply_event_log(st, c, lane);
     if (emission.n_mode > 0)
         ne = add_dist_sample(st, c, emission, dt, emit_kind, create_time, seed, step, status, lane);
@@ -2701,11 +2728,13 @@ __device__ __forceinline__ double interp_at(const double *y, int64_t stride, int
 __global__ __launch_bounds__(256) void k_gas_update(GasScenarioDev g, double *mix_rat,
                                                     const double *temp, const double *pressure,
                                                     const double *height, const double *old_height,
-                                                    int n_cells, double dt, double t)
+                                                    int n_cells, double dt, double t,
+                                                    const uint8_t *loop_mask)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= (int64_t)n_cells * g.n_gas) return;
     const int c = (int)(j / g.n_gas), q = (int)(j - (int64_t)c * g.n_gas);
+    if (loop_mask && !loop_mask[c]) return;
     double x = mix_rat[j];
     const double h = height[c], h_old = old_height ? old_height[c] : h;
     if (g.n_time_e > 0) {
@@ -3172,7 +3201,13 @@ struct TransFieldsDev {
     const float *alt, *xkhh, *u_flux, *v_flux, *w_flux, *z, *z_at_w, *exch_h;
     double *prob_h, *prob_v;
     int32_t *n_substeps, *bad, *n_class_part;
+    int32_t *clamp_flag; // [1] set when some column asked for more than TRANS_MAX_SUBSTEPS sub-steps
 };
+
+// stable_timestep's count (wrf_pmc_trans.F90:629-651) is unbounded in the reference; a degenerate
+// column (z(2) == z(1), a huge exch_h) would turn one launch into seconds of serial matrix steps.
+// The count is clamped here, the column flagged (bit 16 of bad) and the call fails.
+constexpr double TRANS_MAX_SUBSTEPS = 1.0e4;
 
 __global__ __launch_bounds__(256) void k_trans_probs(DeviceState st, TransFieldsDev f)
 {
@@ -3289,7 +3324,10 @@ __global__ __launch_bounds__(256) void k_trans_probs(DeviceState st, TransFields
                 const double max_time = .1 * (min_dz * min_dz) / max_k;
                 double ns = ceil(f.dt / max_time);
                 if (!(ns >= 1.0)) ns = 1.0;
-                if (ns > 1.0e6) { ns = 1.0e6; s_clamped = 1; } // (flagged: bit 16 of bad)
+                if (ns > TRANS_MAX_SUBSTEPS) { // (flagged: bit 16 of bad; pmcx_transport_probs fails)
+                    ns = TRANS_MAX_SUBSTEPS; s_clamped = 1;
+                    if (f.clamp_flag) atomicOr(f.clamp_flag, 1);
+                }
                 s_nsteps = (int)ns;
                 s_sdt = f.dt / (double)(int)ns;
             }
@@ -3507,7 +3545,7 @@ __global__ __launch_bounds__(64) void k_boundary_resample(DeviceState st, const 
             }
             double total = 0.0;
             for (int m = 0; m < bg.n_mode; m++)
-                if (bg.mode_class[m] == cl) total = total + bg.num_conc[(int64_t)c * bg.n_mode + m] * dens;
+                if (bg.mode_class[bg.mo(c) + m] == cl) total = total + bg.num_conc[(int64_t)c * bg.n_mode + m] * dens;
             const double mag = st.mag[(int64_t)c * C + cl];
             const double n_parts_new = total / mag;
             uint32_t w[4];
@@ -3518,7 +3556,7 @@ __global__ __launch_bounds__(64) void k_boundary_resample(DeviceState st, const 
                 wave_sync();
                 if (lane < bg.n_mode) {
                     double mean = -1.0;
-                    if (bg.mode_class[lane] == cl) {
+                    if (bg.mode_class[bg.mo(c) + lane] == cl) {
                         const double cm = bg.num_conc[(int64_t)c * bg.n_mode + lane];
                         const double share = (dens * cm) / total;
                         const double n_samp_avg = share * (double)n_to_add;
@@ -4624,23 +4662,24 @@ hipError_t launch_scenario_update(const DeviceState &st, double dt, double creat
                                   const double *bg_conc, int32_t *n_emit, int32_t *n_dil_in,
                                   int32_t *n_dil_out, hipStream_t s, uint32_t emit_kind)
 {
-    AeroDistDev e{0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, b = e;
+    AeroDistDev e{0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0}, b = e;
     if (em) e = AeroDistDev{em->n_mode, em_conc, em->ln_gm_radius, em->ln_gsd, em->vol_frac,
-                            em->mode_class, em->mode_source};
+                            em->mode_class, em->mode_source, em->per_cell};
     if (bg) b = AeroDistDev{bg->n_mode, bg_conc, bg->ln_gm_radius, bg->ln_gsd, bg->vol_frac,
-                            bg->mode_class, bg->mode_source};
+                            bg->mode_class, bg->mode_source, bg->per_cell};
     hipLaunchKernelGGL(k_scenario_update, dim3(st.n_cells), dim3(64), 0, s, st, dt, create_time,
                        seed, step, e, dilution_rate, b, n_emit, n_dil_in, n_dil_out, emit_kind);
     return hipGetLastError();
 }
 hipError_t launch_gas_update(const GasScenarioDev &g, double *mix_rat, const double *temp,
                              const double *pressure, const double *height, const double *old_height,
-                             int n_cells, double dt, double elapsed_time, hipStream_t s)
+                             int n_cells, double dt, double elapsed_time, hipStream_t s,
+                             const uint8_t *loop_mask)
 {
     const int64_t n = (int64_t)n_cells * g.n_gas;
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_gas_update, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, mix_rat,
-                       temp, pressure, height, old_height, n_cells, dt, elapsed_time);
+                       temp, pressure, height, old_height, n_cells, dt, elapsed_time, loop_mask);
     return hipGetLastError();
 }
 size_t transport_lds_bytes(const DeviceState &st, int nz)
@@ -4713,7 +4752,7 @@ hipError_t launch_boundary_resample(const DeviceState &st, const int32_t *action
                                     hipStream_t s)
 {
     const AeroDistDev b{bg.n_mode, bg_conc, bg.ln_gm_radius, bg.ln_gsd, bg.vol_frac, bg.mode_class,
-                        bg.mode_source};
+                        bg.mode_source, bg.per_cell};
     hipLaunchKernelGGL(k_boundary_resample, dim3(st.n_cells), dim3(64), 0, s, st, action, b, density,
                        create_time, seed, step, n_added, n_removed);
     return hipGetLastError();
@@ -4777,7 +4816,7 @@ hipError_t launch_transport_probs(const DeviceState &st, const TransFieldsArgs &
     f.alt = a.alt; f.xkhh = a.xkhh; f.u_flux = a.u_flux; f.v_flux = a.v_flux; f.w_flux = a.w_flux;
     f.z = a.z; f.z_at_w = a.z_at_w; f.exch_h = a.exch_h;
     f.prob_h = a.prob_h; f.prob_v = a.prob_v; f.n_substeps = a.n_substeps; f.bad = a.bad;
-    f.n_class_part = a.n_class_part;
+    f.n_class_part = a.n_class_part; f.clamp_flag = a.clamp_flag;
     const size_t lds = trans_probs_lds_bytes(st, a.nz);
     allow_lds(k_trans_probs, lds);
     hipLaunchKernelGGL(k_trans_probs, dim3(a.nx * a.ny), dim3(256), lds, s, st, f);

@@ -80,8 +80,10 @@ def zhang_surface_parameters(ivgtyp, season=1):
     import numpy as np
     iv = np.atleast_1d(np.asarray(ivgtyp, dtype=np.int64))
     z = np.where((iv >= 1) & (iv <= 25), np.asarray(ZHANG_FROM_USGS)[np.clip(iv, 1, 25) - 1], 7)
-    alpha = np.asarray(ZHANG_ALPHA)[z - 1]
-    big_a = np.asarray([row[season - 1] for row in ZHANG_A])[z - 1]
+    # the reference fills its real(dp) tables from default-real literals (DATA statements,
+    # wrf_pmc_dep_aero.F90:94-130): the values in use are those single-precision numbers widened
+    alpha = np.asarray(ZHANG_ALPHA, dtype=np.float32).astype(np.float64)[z - 1]
+    big_a = np.asarray([row[season - 1] for row in ZHANG_A], dtype=np.float32).astype(np.float64)[z - 1]
     return alpha, big_a
 
 

@@ -38,9 +38,16 @@
 ! bounded by the particle's least/greatest create time (the exact value is not carried).
 module pmcx_shim
   use iso_c_binding
-  use pmc_mock
+  use pmcx_c           ! the C entry points of include/pmcx.h, every one bound (pmcx_c.F90)
+  use pmc_mock         ! inside WRF: pmc_aero_state, pmc_aero_data, pmc_env_state, pmc_scenario, ...
+  use wrf_mock         ! inside WRF: module_domain, module_configure, module_model_constants
   implicit none
   private
+  ! the two drop-in drivers (the reference's exact argument lists): one partmc_timestep, one
+  ! wrf_pmc_trans_driver per WRF step on the device-resident block; partmc_sync_host_pmcx
+  ! brings aero_states / gas_states up to date when the Fortran side needs them (output, restart)
+  public :: partmc_timestep_pmcx, wrf_pmc_trans_driver_pmcx, partmc_sync_host_pmcx, &
+       partmc_process_pmcx, pmcx_shim_is_resident
   public :: pmcx_shim_init, pmcx_shim_finalize, pmcx_set_rng, mc_coag_pmcx, &
        partmc_coag_cells_pmcx, aero_state_rebalance_cells_pmcx, aero_state_rebalance_pmcx, &
        pmcx_config
@@ -53,235 +60,9 @@ module pmcx_shim
   ! the device pointers, or staged through pmcx_device_copy)
   public :: pmcx_shim_context, pmcx_transport_begin, pmcx_transport_export_size, &
        pmcx_transport_export, pmcx_transport_import, pmcx_transport_finish, &
-       pmcx_device_alloc, pmcx_device_free, pmcx_device_copy
+       pmcx_device_alloc, pmcx_device_free, pmcx_device_copy, pmcx_transport_preweight_begin, &
+       pmcx_transport_preweight_finish, pmcx_set_transport_lateral
 
-  type, bind(c) :: pmcx_config
-     integer(c_int32_t) :: struct_size, device, n_cells, cap, n_spec, n_class, n_source, n_bin
-     real(c_double) :: r_min, r_max
-     integer(c_int32_t) :: max_events, max_appends, n_dbin, i_water
-     real(c_double) :: d_min, d_max
-     integer(c_int32_t) :: cell_id_base, compact_den
-     real(c_double) :: const_k, additive_beta
-  end type pmcx_config
-
-  !> pmcx_trans_fields (include/pmcx.h): WRF's fields for the transport probabilities
-  type, bind(c) :: pmcx_trans_fields_t
-     integer(c_int32_t) :: nx, nz, ny, do_vertmix, all_columns, i_offset, j_offset, global_nx, global_ny
-     real(c_double) :: dt, dx, dy
-     type(c_ptr) :: alt, xkhh, u_flux, v_flux, w_flux, z, z_at_w, exch_h
-  end type pmcx_trans_fields_t
-
-  interface
-     subroutine pmcx_config_default(cfg) bind(c, name="pmcx_config_default")
-       import :: pmcx_config
-       type(pmcx_config), intent(out) :: cfg
-     end subroutine pmcx_config_default
-     integer(c_int) function pmcx_create(cfg, ctx) bind(c, name="pmcx_create")
-       import :: pmcx_config, c_ptr, c_int
-       type(pmcx_config), intent(in) :: cfg
-       type(c_ptr), intent(out) :: ctx
-     end function pmcx_create
-     integer(c_int) function pmcx_destroy(ctx) bind(c, name="pmcx_destroy")
-       import :: c_ptr, c_int
-       type(c_ptr), value :: ctx
-     end function pmcx_destroy
-     function pmcx_last_error(ctx) bind(c, name="pmcx_last_error") result(msg)
-       import :: c_ptr
-       type(c_ptr), value :: ctx
-       type(c_ptr) :: msg
-     end function pmcx_last_error
-     integer(c_int) function pmcx_set_aero_data(ctx, density, kappa, molec_weight) &
-          bind(c, name="pmcx_set_aero_data")
-       import :: c_ptr, c_int, c_double
-       type(c_ptr), value :: ctx
-       real(c_double), intent(in) :: density(*)
-       type(c_ptr), value :: kappa, molec_weight
-     end function pmcx_set_aero_data
-     integer(c_int) function pmcx_set_env(ctx, temp, pressure, rel_humid) bind(c, name="pmcx_set_env")
-       import :: c_ptr, c_int, c_double
-       type(c_ptr), value :: ctx
-       real(c_double), intent(in) :: temp(*), pressure(*), rel_humid(*)
-     end function pmcx_set_env
-     integer(c_int) function pmcx_set_weights(ctx, magnitude) bind(c, name="pmcx_set_weights")
-       import :: c_ptr, c_int, c_double
-       type(c_ptr), value :: ctx
-       real(c_double), intent(in) :: magnitude(*)
-     end function pmcx_set_weights
-     integer(c_int) function pmcx_get_weights(ctx, magnitude) bind(c, name="pmcx_get_weights")
-       import :: c_ptr, c_int, c_double
-       type(c_ptr), value :: ctx
-       real(c_double), intent(out) :: magnitude(*)
-     end function pmcx_get_weights
-     integer(c_int) function pmcx_set_n_part_ideal(ctx, n_ideal) bind(c, name="pmcx_set_n_part_ideal")
-       import :: c_ptr, c_int, c_double
-       type(c_ptr), value :: ctx
-       real(c_double), intent(in) :: n_ideal(*)
-     end function pmcx_set_n_part_ideal
-     integer(c_int) function pmcx_set_cell_id_base(ctx, cell_id_base) bind(c, name="pmcx_set_cell_id_base")
-       import :: c_ptr, c_int, c_int32_t
-       type(c_ptr), value :: ctx
-       integer(c_int32_t), value :: cell_id_base
-     end function pmcx_set_cell_id_base
-     integer(c_int) function pmcx_set_next_id(ctx, next_id) bind(c, name="pmcx_set_next_id")
-       import :: c_ptr, c_int, c_int64_t
-       type(c_ptr), value :: ctx
-       integer(c_int64_t), intent(in) :: next_id(*)
-     end function pmcx_set_next_id
-     integer(c_int) function pmcx_upload_cells(ctx, cell_first, n_up, part_offset, vol, wclass, &
-          id, least_ct, greatest_ct, n_orig) bind(c, name="pmcx_upload_cells")
-       import :: c_ptr, c_int, c_int32_t, c_int64_t, c_double
-       type(c_ptr), value :: ctx
-       integer(c_int32_t), value :: cell_first, n_up
-       integer(c_int64_t), intent(in) :: part_offset(*), id(*)
-       real(c_double), intent(in) :: vol(*), least_ct(*), greatest_ct(*)
-       integer(c_int32_t), intent(in) :: wclass(*)
-       type(c_ptr), value :: n_orig
-     end function pmcx_upload_cells
-     integer(c_int) function pmcx_get_n_part(ctx, n_part) bind(c, name="pmcx_get_n_part")
-       import :: c_ptr, c_int, c_int32_t
-       type(c_ptr), value :: ctx
-       integer(c_int32_t), intent(out) :: n_part(*)
-     end function pmcx_get_n_part
-     integer(c_int) function pmcx_download_cells(ctx, cell_first, n_dn, part_offset, vol, wclass, &
-          id, least_ct, greatest_ct, n_orig) bind(c, name="pmcx_download_cells")
-       import :: c_ptr, c_int, c_int32_t, c_int64_t, c_double
-       type(c_ptr), value :: ctx
-       integer(c_int32_t), value :: cell_first, n_dn
-       integer(c_int64_t), intent(in) :: part_offset(*)
-       integer(c_int64_t), intent(out) :: id(*)
-       real(c_double), intent(out) :: vol(*), least_ct(*), greatest_ct(*)
-       integer(c_int32_t), intent(out) :: wclass(*)
-       type(c_ptr), value :: n_orig
-     end function pmcx_download_cells
-     integer(c_int) function pmcx_mc_coag(ctx, kernel_type, del_t, seed, step) bind(c, name="pmcx_mc_coag")
-       import :: c_ptr, c_int, c_int32_t, c_int64_t, c_double
-       type(c_ptr), value :: ctx
-       integer(c_int32_t), value :: kernel_type
-       real(c_double), value :: del_t
-       integer(c_int64_t), value :: seed
-       integer(c_int32_t), value :: step
-     end function pmcx_mc_coag
-     integer(c_int) function pmcx_get_coag_counters(ctx, n_samp, n_coag, status) &
-          bind(c, name="pmcx_get_coag_counters")
-       import :: c_ptr, c_int, c_int32_t
-       type(c_ptr), value :: ctx
-       integer(c_int32_t), intent(out) :: n_samp(*), n_coag(*), status(*)
-     end function pmcx_get_coag_counters
-     integer(c_int) function pmcx_rebalance(ctx, allow_doubling, allow_halving, seed, step) &
-          bind(c, name="pmcx_rebalance")
-       import :: c_ptr, c_int, c_int32_t, c_int64_t
-       type(c_ptr), value :: ctx
-       integer(c_int32_t), value :: allow_doubling, allow_halving
-       integer(c_int64_t), value :: seed
-       integer(c_int32_t), value :: step
-     end function pmcx_rebalance
-     integer(c_int) function pmcx_transport(ctx, nx, nz, ny, periodic_x, periodic_y, prob_h, prob_v, &
-          cell_volume, seed, step, n_moved, n_arrived) bind(c, name="pmcx_transport")
-       import :: c_ptr, c_int, c_int32_t, c_int64_t, c_double
-       type(c_ptr), value :: ctx
-       integer(c_int32_t), value :: nx, nz, ny, periodic_x, periodic_y
-       type(c_ptr), value :: prob_h, prob_v        ! c_null_ptr twice: the probabilities built on the device
-       real(c_double), intent(in) :: cell_volume(*)
-       integer(c_int64_t), value :: seed
-       integer(c_int32_t), value :: step
-       integer(c_int32_t), intent(out) :: n_moved(*), n_arrived(*)
-     end function pmcx_transport
-     integer(c_int) function pmcx_transport_preweight(ctx, nx, nz, ny, periodic_x, periodic_y, prob_h, &
-          prob_v, cell_volume, seed, step, expected_num_conc, n_removed) &
-          bind(c, name="pmcx_transport_preweight")
-       import :: c_ptr, c_int, c_int32_t, c_int64_t, c_double
-       type(c_ptr), value :: ctx
-       integer(c_int32_t), value :: nx, nz, ny, periodic_x, periodic_y
-       type(c_ptr), value :: prob_h, prob_v        ! c_null_ptr: the ones pmcx_transport_probs built
-       real(c_double), intent(in) :: cell_volume(*)
-       integer(c_int64_t), value :: seed
-       integer(c_int32_t), value :: step
-       real(c_double), intent(out) :: expected_num_conc(*)
-       integer(c_int32_t), intent(out) :: n_removed(*)
-     end function pmcx_transport_preweight
-     integer(c_int) function pmcx_transport_probs(ctx, fields, prob_h, prob_v, n_substeps, bad, &
-          n_class_part) bind(c, name="pmcx_transport_probs")
-       import :: c_ptr, c_int, pmcx_trans_fields_t
-       type(c_ptr), value :: ctx
-       type(pmcx_trans_fields_t), intent(in) :: fields
-       type(c_ptr), value :: prob_h, prob_v, n_substeps, bad, n_class_part
-     end function pmcx_transport_probs
-     integer(c_int) function pmcx_seasalt_emissions(ctx, dt, elapsed_time, seed, step, sea_salt_opt, &
-          i_na, i_cl, ocean_surface, wind_speed, height, mode_class, mode_source, n_emit, rate) &
-          bind(c, name="pmcx_seasalt_emissions")
-       import :: c_ptr, c_int, c_int32_t, c_int64_t, c_double
-       type(c_ptr), value :: ctx
-       real(c_double), value :: dt, elapsed_time
-       integer(c_int64_t), value :: seed
-       integer(c_int32_t), value :: step, sea_salt_opt, i_na, i_cl
-       integer(c_int32_t), intent(in) :: ocean_surface(*)
-       real(c_double), intent(in) :: wind_speed(*), height(*)
-       integer(c_int32_t), intent(in) :: mode_class(*), mode_source(*)
-       integer(c_int32_t), intent(out) :: n_emit(*)
-       type(c_ptr), value :: rate
-     end function pmcx_seasalt_emissions
-     integer(c_int) function pmcx_transport_begin(ctx, nx, nz, ny, periodic_x, prob_h, prob_v, &
-          cell_volume, seed, step) bind(c, name="pmcx_transport_begin")
-       import :: c_ptr, c_int, c_int32_t, c_int64_t, c_double
-       type(c_ptr), value :: ctx
-       integer(c_int32_t), value :: nx, nz, ny, periodic_x
-       real(c_double), intent(in) :: prob_h(*), prob_v(*), cell_volume(*)
-       integer(c_int64_t), value :: seed
-       integer(c_int32_t), value :: step
-     end function pmcx_transport_begin
-     integer(c_int) function pmcx_transport_export_size(ctx, side, n_bytes) &
-          bind(c, name="pmcx_transport_export_size")
-       import :: c_ptr, c_int, c_int32_t, c_int64_t
-       type(c_ptr), value :: ctx
-       integer(c_int32_t), value :: side
-       integer(c_int64_t), intent(out) :: n_bytes
-     end function pmcx_transport_export_size
-     integer(c_int) function pmcx_transport_export(ctx, side, dev_buf) bind(c, name="pmcx_transport_export")
-       import :: c_ptr, c_int, c_int32_t
-       type(c_ptr), value :: ctx, dev_buf
-       integer(c_int32_t), value :: side
-     end function pmcx_transport_export
-     integer(c_int) function pmcx_transport_import(ctx, side, dev_buf, n_bytes) &
-          bind(c, name="pmcx_transport_import")
-       import :: c_ptr, c_int, c_int32_t, c_int64_t
-       type(c_ptr), value :: ctx, dev_buf
-       integer(c_int32_t), value :: side
-       integer(c_int64_t), value :: n_bytes
-     end function pmcx_transport_import
-     integer(c_int) function pmcx_transport_finish(ctx, n_moved, n_arrived) &
-          bind(c, name="pmcx_transport_finish")
-       import :: c_ptr, c_int, c_int32_t
-       type(c_ptr), value :: ctx
-       integer(c_int32_t), intent(out) :: n_moved(*), n_arrived(*)
-     end function pmcx_transport_finish
-     integer(c_int) function pmcx_device_alloc(ctx, n_bytes, dev_ptr) bind(c, name="pmcx_device_alloc")
-       import :: c_ptr, c_int, c_int64_t
-       type(c_ptr), value :: ctx
-       integer(c_int64_t), value :: n_bytes
-       type(c_ptr), intent(out) :: dev_ptr
-     end function pmcx_device_alloc
-     integer(c_int) function pmcx_device_free(ctx, dev_ptr) bind(c, name="pmcx_device_free")
-       import :: c_ptr, c_int
-       type(c_ptr), value :: ctx, dev_ptr
-     end function pmcx_device_free
-     integer(c_int) function pmcx_device_copy(ctx, dst, src, n_bytes, kind) bind(c, name="pmcx_device_copy")
-       import :: c_ptr, c_int, c_int32_t, c_int64_t
-       type(c_ptr), value :: ctx, dst, src
-       integer(c_int64_t), value :: n_bytes
-       integer(c_int32_t), value :: kind
-     end function pmcx_device_copy
-     integer(c_int) function pmcx_dry_deposition(ctx, dt, seed, step, surface, aer_res_a, ustar, alpha, &
-          big_a, height, inv_density, n_removed, unrealistic) bind(c, name="pmcx_dry_deposition")
-       import :: c_ptr, c_int, c_int32_t, c_int64_t, c_double
-       type(c_ptr), value :: ctx
-       real(c_double), value :: dt
-       integer(c_int64_t), value :: seed
-       integer(c_int32_t), value :: step
-       integer(c_int32_t), intent(in) :: surface(*)
-       real(c_double), intent(in) :: aer_res_a(*), ustar(*), alpha(*), big_a(*), height(*), inv_density(*)
-       integer(c_int32_t), intent(out) :: n_removed(*), unrealistic(*)
-     end function pmcx_dry_deposition
-  end interface
 
   ! one context per (rank, cell count); rebuilt when the shape changes
   type(c_ptr), save :: ctx = c_null_ptr
@@ -290,6 +71,20 @@ module pmcx_shim
   integer(c_int64_t), save :: rng_seed = 0     ! grid%random_seed (wrf_pmc_init.F90:131)
   integer(c_int32_t), save :: rng_step = 0     ! chemistry-step index
   integer(c_int32_t), save :: cell_id_base = 0 ! global id of this rank's first cell
+  integer(kind=8), parameter :: ID_BLOCK = 4294967296_8   ! ids a cell may create between uploads
+  integer(kind=8), save :: id_block_base = 0              ! first id of cell 1's block
+  ! the resident block of the two drivers
+  logical, save :: resident = .false., have_gas = .false.
+  integer, save :: res_nx = 0, res_nz = 0, res_ny = 0
+  integer(kind=8), save, public :: last_n_samp = 0, last_n_coag = 0, last_n_moved = 0, last_n_deposited = 0
+  ! depvel_partmc's aerodynamic resistance of the last deposition call, per cell (inspection)
+  real(c_double), allocatable, save, public :: last_aer_res(:)
+  ! scenario(i,k,j)'s aerosol modes at their current time levels, as sent to the device
+  integer, save :: em_n_mode = -1, bg_n_mode = -1
+  integer, allocatable, save :: em_level(:), bg_level(:)
+  real(c_double), allocatable, save, target :: em_num(:,:), em_gm(:,:), em_gs(:,:), em_vf(:,:,:), em_scale(:)
+  real(c_double), allocatable, save, target :: bg_num(:,:), bg_gm(:,:), bg_gs(:,:), bg_vf(:,:,:), bg_rate(:)
+  integer(c_int32_t), allocatable, save, target :: em_cls(:,:), em_src(:,:), bg_cls(:,:), bg_src(:,:)
 
 contains
 
@@ -355,6 +150,10 @@ contains
     if (have_ctx) rc = pmcx_destroy(ctx)
     have_ctx = .false.
     ctx = c_null_ptr
+    resident = .false.
+    em_n_mode = -1; bg_n_mode = -1
+    if (allocated(em_level)) deallocate(em_level, em_num, em_gm, em_gs, em_vf, em_cls, em_src, em_scale)
+    if (allocated(bg_level)) deallocate(bg_level, bg_num, bg_gm, bg_gs, bg_vf, bg_cls, bg_src, bg_rate)
   end subroutine pmcx_shim_finalize
 
   !> The context handle, for the C entry points the shim has no wrapper for.
@@ -373,8 +172,19 @@ contains
     type(aero_data_t), intent(in) :: aero_data
     type(aero_state_t), intent(in) :: aero_states(:)
     integer, intent(in), optional :: cap_min
+    call upload_states_n(size(aero_states), env_states, aero_data, aero_states, cap_min)
+  end subroutine pmcx_upload_states
 
-    integer :: n_cells, n_spec, n_class, n_source, c, i, s, k, cap_needed
+  !> The same with the number of cells explicit: aero_states / env_states of any rank in memory
+  !> order (the (i,k,j) arrays of the reference are the cells c = (j nz + k) nx + i in sequence).
+  subroutine upload_states_n(n_cells, env_states, aero_data, aero_states, cap_min)
+    integer, intent(in) :: n_cells
+    type(env_state_t), intent(in) :: env_states(n_cells)
+    type(aero_data_t), intent(in) :: aero_data
+    type(aero_state_t), intent(in) :: aero_states(n_cells)
+    integer, intent(in), optional :: cap_min
+
+    integer :: n_spec, n_class, n_source, c, i, s, k, cap_needed, cap_max
     integer(c_int64_t) :: nt, o
     integer(c_int64_t), allocatable :: part_offset(:), id(:)
     real(c_double), allocatable :: vol(:,:), lct(:), gct(:), temp(:), pres(:), rh(:), mag(:,:), &
@@ -384,7 +194,6 @@ contains
     type(c_ptr) :: p_norig
     logical :: have_ideal
 
-    n_cells = size(aero_states)
     n_spec = size(aero_data%density)
     n_class = size(aero_states(1)%awa%weight, 2)
     n_source = aero_data_n_source(aero_data)
@@ -399,7 +208,20 @@ contains
           have_ideal = .false.
        end if
     end do
-    cap_needed = min(((cap_needed + 63) / 64) * 64, 65280)
+    ! list entries and offsets are 16-bit on the device: cap + cap/8 + 16 n_class n_bin <= 65535
+    ! (pmcx_max_cap; about 57 000 slots with 80 bins and one class)
+    block
+      type(pmcx_config) :: probe
+      call pmcx_config_default(probe)
+      probe%n_class = n_class
+      cap_max = pmcx_max_cap(probe)
+    end block
+    cap_needed = ((cap_needed + 63) / 64) * 64
+    if (cap_needed > cap_max) then
+       write(0,'(a,i0,a,i0,a)') 'pmcx_shim: a cell needs ', cap_needed, ' particle slots (its particles, or twice &
+            &its n_part_ideal); the device holds at most ', cap_max, ' per cell (16-bit list entries)'
+       call pmcx_die(1, 'pmcx_upload_states')
+    end if
     if (.not. have_ctx .or. cfg%n_cells /= n_cells .or. cfg%cap < cap_needed &
          .or. cfg%n_spec /= n_spec .or. cfg%n_class /= n_class .or. cfg%n_source /= n_source) then
        call pmcx_shim_init(n_cells, cap_needed, aero_data, n_class, n_source, 0)
@@ -449,20 +271,22 @@ contains
     ! aero_state%n_part_ideal (aero_state_set_n_part_ideal, wrf_pmc_init.F90:254): without it
     ! pmcx_rebalance refuses to run (PMCX_ESTATE)
     if (have_ideal) call pmcx_die(pmcx_set_n_part_ideal(ctx, n_ideal), 'pmcx_set_n_part_ideal')
-    ! ids of particles created on the device (doubling, emission, transport copies): every cell
-    ! draws from its own block of PartMC's counter, which moves past all of them
+    ! ids of particles created on the device (doubling, emission, transport copies, boundary
+    ! copies): every cell draws from its own block of 2**32 ids of PartMC's counter, which moves
+    ! past all of them; pmcx_download_states checks that no cell left its block
     block
       integer(c_int64_t), allocatable :: nid(:)
       allocate(nid(n_cells))
+      id_block_base = next_id
       do c = 1, n_cells
-         nid(c) = next_id + int(c - 1, 8) * int(2 * cfg%cap, 8)
+         nid(c) = next_id + int(c - 1, 8) * ID_BLOCK
       end do
       call pmcx_die(pmcx_set_next_id(ctx, nid), 'pmcx_set_next_id')
-      next_id = next_id + int(n_cells, 8) * int(2 * cfg%cap, 8)
+      next_id = next_id + int(n_cells, 8) * ID_BLOCK
     end block
     call pmcx_die(pmcx_upload_cells(ctx, 0, n_cells, part_offset, vol, wclass, id, lct, gct, &
          p_norig), 'pmcx_upload_cells')
-  end subroutine pmcx_upload_states
+  end subroutine upload_states_n
 
   !> ids(order(1)) <= ids(order(2)) <= ... (heap sort of an index array)
   subroutine sort_index_by_id(ids, order)
@@ -502,8 +326,15 @@ contains
   !> particle the host has not seen.  Weights come back too (a rebalance changes them).
   subroutine pmcx_download_states(aero_states)
     type(aero_state_t), intent(inout) :: aero_states(:)
+    if (size(aero_states) /= cfg%n_cells) call pmcx_die(1, 'pmcx_download_states (array size /= resident cells)')
+    call download_states_n(size(aero_states), aero_states)
+  end subroutine pmcx_download_states
 
-    integer :: n_cells, n_spec, n_class, n_source, c, i, s, k, j, lo, hi, mid, n_old, n_have, n_add
+  subroutine download_states_n(n_cells, aero_states)
+    integer, intent(in) :: n_cells
+    type(aero_state_t), intent(inout) :: aero_states(n_cells)
+
+    integer :: n_spec, n_class, n_source, c, i, s, k, j, lo, hi, mid, n_old, n_have, n_add
     integer(c_int64_t) :: nt, o
     integer(c_int64_t), allocatable :: part_offset(:), id(:)
     real(c_double), allocatable :: vol(:,:), lct(:), gct(:), mag(:,:)
@@ -518,11 +349,20 @@ contains
     real(kind=dp) :: t_new
     type(c_ptr) :: p_norig
 
-    n_cells = cfg%n_cells
     n_spec = cfg%n_spec
     n_class = cfg%n_class
     n_source = cfg%n_source
     allocate(n_part(n_cells), part_offset(n_cells + 1), mag(n_class, n_cells))
+    ! ids created on the device: every cell inside its block, or ids are no longer unique
+    block
+      integer(c_int64_t), allocatable :: nid(:)
+      allocate(nid(n_cells))
+      call pmcx_die(pmcx_get_next_id(ctx, nid), 'pmcx_get_next_id')
+      do c = 1, n_cells
+         if (nid(c) > id_block_base + int(c, 8) * ID_BLOCK) &
+              call pmcx_die(5, 'pmcx_download_states (a cell created more than 2**32 particle ids)')
+      end do
+    end block
     call pmcx_die(pmcx_get_n_part(ctx, n_part), 'pmcx_get_n_part')
     call pmcx_die(pmcx_get_weights(ctx, mag), 'pmcx_get_weights')
     part_offset(1) = 0
@@ -657,7 +497,7 @@ contains
        end do
        aero_states(c)%valid_sort = .false.
     end do
-  end subroutine pmcx_download_states
+  end subroutine download_states_n
 
   !> mc_coag on the resident cells (interface/wrf_pmc_driver.F90:192-194 for every cell).
   subroutine mc_coag_resident_pmcx(coag_kernel_type, del_t, tot_n_samp, tot_n_coag)
@@ -850,5 +690,798 @@ contains
     call aero_state_rebalance_cells_pmcx(allow_doubling, allow_halving)
     call pmcx_download_states(aero_states)
   end subroutine aero_state_rebalance_pmcx
+
+  ! ===========================================================================================
+  ! The two drop-in drivers.  One line changes in WRFV3/frame/module_integrate.F:409-421:
+  !     call partmc_timestep_pmcx(grid, config_flags, scenario, env_states, aero_data, aero_states, &
+  !          gas_data, gas_states, pmc_is, pmc_ie, pmc_js, pmc_je, pmc_ks, pmc_ke, global_nx, &
+  !          global_ny, global_nz)
+  !     call wrf_pmc_trans_driver_pmcx(grid, config_flags, env_states, scenario, aero_data, &
+  !          aero_states, gas_states, pmc_is, pmc_ie, pmc_js, pmc_je, pmc_ks, pmc_ke, global_nx, &
+  !          global_ny, global_nz)
+  ! The rank's block of cells lives on the device from the first call on; aero_states / gas_states
+  ! on the host are stale until partmc_sync_host_pmcx (output and restart times).  One rank owning
+  ! the whole domain is what these two cover; a domain cut across ranks uses the slab entry points
+  ! (pmcx_transport_begin .. _finish, pmcx_transport_preweight_begin / _finish) underneath.
+  ! ===========================================================================================
+
+  !> Whether the block is on the device (partmc_timestep_pmcx uploads it on its first call).
+  logical function pmcx_shim_is_resident()
+    pmcx_shim_is_resident = resident
+  end function pmcx_shim_is_resident
+
+  !> wrf_to_partmc (interface/wrf_pmc_driver.F90:576-644): env_states from WRF's fields, the same
+  !> expressions; the previous heights are what scenario_update_gas_state wants of old_env_states.
+  subroutine wrf_to_partmc_pmcx(grid, nx, nz, ny, is, ks, js, env_states, old_height)
+    type(domain), intent(in) :: grid
+    integer, intent(in) :: nx, nz, ny, is, ks, js
+    type(env_state_t), intent(inout) :: env_states(nx, nz, ny)
+    real(kind=dp), intent(out) :: old_height(nx, nz, ny)
+    integer :: i, j, k, gi, gj, gk
+    real(kind=dp) :: pressure, potential_temp, temperature, rh, dx, dy, dz
+    do j = 1, ny
+    do k = 1, nz
+    do i = 1, nx
+       gi = is + i - 1; gk = ks + k - 1; gj = js + j - 1
+       old_height(i,k,j) = env_states(i,k,j)%height                       ! driver:615
+       pressure = grid%p(gi,gk,gj) + grid%pb(gi,gk,gj)                    ! driver:617
+       potential_temp = grid%t_2(gi,gk,gj) + t0                           ! driver:619
+       temperature = potential_temp * (pressure / p0)**(rcp)              ! driver:620
+       env_states(i,k,j)%pressure = pressure
+       env_states(i,k,j)%temp = temperature
+       ! rel_hum, driver:649-666 (chem_prep's formula, clamped to 0.1 .. 0.95)
+       rh = real(grid%moist(gi,gk,gj,p_qv), dp) / (3.8d0 * exp(17.27 * (temperature - 273.0d0) &
+            / (temperature - 36.0d0)) / (.01 * pressure))
+       env_states(i,k,j)%rel_humid = max(.1d0, min(rh, .95d0))
+       env_states(i,k,j)%height = grid%z_at_w(gi,gk+1,gj) - grid%z_at_w(gi,gk,gj)   ! driver:627
+       env_states(i,k,j)%altitude = grid%z(gi,gk,gj)
+       env_states(i,k,j)%z_min = grid%z_at_w(gi,gk,gj)
+       env_states(i,k,j)%z_max = grid%z_at_w(gi,gk+1,gj)
+       env_states(i,k,j)%inverse_density = grid%alt(gi,gk,gj)             ! driver:633
+       ! get_grid_cell_volume, driver:2002-2020
+       dz = real(grid%z_at_w(gi,gk+1,gj) - grid%z_at_w(gi,gk,gj), kind=dp)
+       dx = real((1.0d0 / grid%rdx) / grid%msftx(gi,gj), kind=dp)
+       dy = real((1.0d0 / grid%rdy) / grid%msfty(gi,gj), kind=dp)
+       env_states(i,k,j)%cell_volume = dx * dy * dz
+       env_states(i,k,j)%cell_ix = gi; env_states(i,k,j)%cell_iy = gj; env_states(i,k,j)%cell_iz = gk
+    end do
+    end do
+    end do
+  end subroutine wrf_to_partmc_pmcx
+
+  !> The cells of the reference's loop nests over the interior (wrf_pmc_driver.F90:157-171,
+  !> wrf_pmc_trans_aero.F90:497-516): 1 inside, 0 for the lateral boundary cells of a domain that
+  !> is not doubly periodic.
+  subroutine interior_cells(config_flags, nx, nz, ny, is, js, global_nx, global_ny, inside)
+    type(grid_config_rec_type), intent(in) :: config_flags
+    integer, intent(in) :: nx, nz, ny, is, js, global_nx, global_ny
+    integer(c_int32_t), intent(out) :: inside(nx, nz, ny)
+    integer :: i, j, gi, gj
+    inside = 1
+    if (config_flags%periodic_x .and. config_flags%periodic_y) return
+    do j = 1, ny
+       do i = 1, nx
+          gi = is + i - 1; gj = js + j - 1
+          if (gi < 2 .or. gi > global_nx - 1 .or. gj < 2 .or. gj > global_ny - 1) inside(i,:,j) = 0
+       end do
+    end do
+  end subroutine interior_cells
+
+  !> aero_dist_interp_1d [upstream, uncited: a dist is held constant from a time point to the
+  !> next; before the first point the first, from the last on the last]: the index into the list.
+  integer function dist_level(n, times, t)
+    integer, intent(in) :: n
+    real(kind=dp), intent(in) :: times(n), t
+    dist_level = max(1, min(find_1d(n, times, t), n))
+  end function dist_level
+
+  !> Gathers the modes of one kind (which = 0: aero_emission, 1: aero_background) of every cell's
+  !> scenario at its current time level into the flat per-cell arrays of a pmcx_aero_dist
+  !> (per_cell = 1); a cell without such a series gets modes of zero concentration.  level(c) is
+  !> the time level each cell's arrays were filled for: the (large) mode arrays are rebuilt, and
+  !> sent to the device again, only when some cell's level has changed.
+  subroutine scenario_modes(which, n_cells, scenario, t, n_spec, n_mode, level, changed, &
+       num_conc, gm, gs, vf, cls, src, rate)
+    integer, intent(in) :: which, n_cells, n_spec
+    type(scenario_t), intent(in) :: scenario(n_cells)
+    real(kind=dp), intent(in) :: t
+    integer, intent(inout) :: n_mode
+    integer, allocatable, intent(inout) :: level(:)
+    logical, intent(out) :: changed
+    real(c_double), allocatable, intent(inout) :: num_conc(:,:), gm(:,:), gs(:,:), vf(:,:,:), rate(:)
+    integer(c_int32_t), allocatable, intent(inout) :: cls(:,:), src(:,:)
+    integer :: c, m, p, nt, nm, s
+    nm = 0
+    do c = 1, n_cells
+       if (which == 0) then
+          if (allocated(scenario(c)%aero_emission)) then
+             if (size(scenario(c)%aero_emission) > 0) nm = max(nm, size(scenario(c)%aero_emission(1)%mode))
+          end if
+       else
+          if (allocated(scenario(c)%aero_background)) then
+             if (size(scenario(c)%aero_background) > 0) nm = max(nm, size(scenario(c)%aero_background(1)%mode))
+          end if
+       end if
+    end do
+    changed = .false.
+    if (nm /= n_mode .or. .not. allocated(level)) then
+       n_mode = nm
+       if (allocated(level)) deallocate(level, num_conc, gm, gs, vf, cls, src, rate)
+       allocate(level(n_cells), num_conc(max(nm, 1), n_cells), gm(max(nm, 1), n_cells), gs(max(nm, 1), n_cells), &
+            vf(n_spec, max(nm, 1), n_cells), cls(max(nm, 1), n_cells), src(max(nm, 1), n_cells), rate(n_cells))
+       level = -1
+       changed = .true.
+    end if
+    if (nm == 0) return
+    do c = 1, n_cells
+       nt = 0
+       if (which == 0) then
+          if (allocated(scenario(c)%aero_emission_time)) nt = size(scenario(c)%aero_emission_time)
+       else
+          if (allocated(scenario(c)%aero_dilution_time)) nt = size(scenario(c)%aero_dilution_time)
+       end if
+       p = 0
+       if (nt > 0) then
+          if (which == 0) then
+             p = dist_level(nt, scenario(c)%aero_emission_time, t)
+          else
+             p = dist_level(nt, scenario(c)%aero_dilution_time, t)
+          end if
+       end if
+       if (p /= level(c)) then
+          changed = .true.
+          level(c) = p
+          num_conc(:, c) = 0d0; gm(:, c) = 1d0; gs(:, c) = 0.1d0; vf(:, :, c) = 0d0; vf(1, :, c) = 1d0
+          cls(:, c) = 0; src(:, c) = 0
+          if (p > 0) then
+             if (which == 0) then
+                call fill(scenario(c)%aero_emission(p))
+             else
+                call fill(scenario(c)%aero_background(p))
+             end if
+          end if
+       end if
+       rate(c) = 0d0
+       if (p > 0) then
+          if (which == 0) then
+             rate(c) = scenario(c)%aero_emission_rate_scale(p)
+          else
+             rate(c) = scenario(c)%aero_dilution_rate(p)
+          end if
+       end if
+    end do
+  contains
+    subroutine fill(dist)
+      type(aero_dist_t), intent(in) :: dist
+      do m = 1, size(dist%mode)
+         num_conc(m, c) = dist%mode(m)%num_conc
+         gm(m, c) = dist%mode(m)%char_radius
+         gs(m, c) = dist%mode(m)%log10_std_dev_radius
+         do s = 1, n_spec
+            vf(s, m, c) = dist%mode(m)%vol_frac(s)
+         end do
+         cls(m, c) = dist%mode(m)%weight_class - 1
+         src(m, c) = dist%mode(m)%source - 1
+      end do
+    end subroutine fill
+  end subroutine scenario_modes
+
+  !> Uploads the rank's block (particles, weights, ideal counts, id blocks, gas states and the gas
+  !> half of the scenarios) and names the cells of the interior loops.
+  subroutine upload_domain(config_flags, scenario, env_states, aero_data, aero_states, gas_data, gas_states, &
+       nx, nz, ny, is, js, global_nx, global_ny, cap_min)
+    type(grid_config_rec_type), intent(in) :: config_flags
+    integer, intent(in) :: nx, nz, ny, is, js, global_nx, global_ny, cap_min
+    type(scenario_t), intent(in) :: scenario(nx * nz * ny)
+    type(env_state_t), intent(in) :: env_states(nx * nz * ny)
+    type(aero_data_t), intent(in) :: aero_data
+    type(aero_state_t), intent(in) :: aero_states(nx * nz * ny)
+    type(gas_data_t), intent(in) :: gas_data
+    type(gas_state_t), intent(in) :: gas_states(nx * nz * ny)
+    integer :: n_cells, n_gas, c, q, nte, ntd, k
+    real(c_double), allocatable, target :: mix(:,:), et(:), es(:), em(:,:,:), dtm(:), dr(:,:), bg(:,:,:)
+    integer(c_int32_t), allocatable, target :: inside(:)
+    n_cells = nx * nz * ny
+    call upload_states_n(n_cells, env_states, aero_data, aero_states, cap_min)
+    allocate(inside(n_cells))
+    call interior_cells(config_flags, nx, nz, ny, is, js, global_nx, global_ny, inside)
+    if (all(inside == 1)) then
+       call pmcx_die(pmcx_set_loop_cells(ctx, c_null_ptr), 'pmcx_set_loop_cells')
+    else
+       call pmcx_die(pmcx_set_loop_cells(ctx, c_loc(inside)), 'pmcx_set_loop_cells')
+    end if
+    ! gas_states(i,k,j)%mix_rat and the gas half of scenario(i,k,j) (wrf_pmc_init.F90:646-657,
+    ! 718-720, 789-791, 901-919): resident from here on.  The time axes are those of the first cell
+    ! that has them (the reference reads the same axes into every cell's scenario).
+    n_gas = gas_data_n_spec(gas_data)
+    have_gas = n_gas > 0
+    if (.not. have_gas) return
+    allocate(mix(n_gas, n_cells))
+    do c = 1, n_cells
+       mix(:, c) = gas_states(c)%mix_rat(1:n_gas)
+    end do
+    call pmcx_die(pmcx_set_gas_state(ctx, n_gas, mix), 'pmcx_set_gas_state')
+    nte = 0; ntd = 0
+    do c = 1, n_cells
+       if (allocated(scenario(c)%gas_emission_time)) then
+          if (nte == 0 .and. size(scenario(c)%gas_emission_time) > 0) then
+             nte = size(scenario(c)%gas_emission_time)
+             et = scenario(c)%gas_emission_time; es = scenario(c)%gas_emission_rate_scale
+          end if
+       end if
+       if (allocated(scenario(c)%gas_dilution_time)) then
+          if (ntd == 0 .and. size(scenario(c)%gas_dilution_time) > 0) then
+             ntd = size(scenario(c)%gas_dilution_time)
+             dtm = scenario(c)%gas_dilution_time
+          end if
+       end if
+    end do
+    if (nte > 0) then
+       allocate(em(n_gas, nte, n_cells))
+       em = 0d0
+       do c = 1, n_cells
+          if (.not. allocated(scenario(c)%gas_emission_time)) cycle
+          if (size(scenario(c)%gas_emission_time) /= nte) cycle     ! (init_zero_emissions: no source here)
+          do k = 1, nte
+             em(:, k, c) = scenario(c)%gas_emission(k)%mix_rat(1:n_gas)
+          end do
+       end do
+    end if
+    if (ntd > 0) then
+       allocate(dr(ntd, n_cells), bg(n_gas, ntd, n_cells))
+       dr = 0d0; bg = 0d0
+       do c = 1, n_cells
+          if (.not. allocated(scenario(c)%gas_dilution_time)) cycle
+          if (size(scenario(c)%gas_dilution_time) /= ntd) cycle
+          dr(:, c) = scenario(c)%gas_dilution_rate
+          do k = 1, ntd
+             if (allocated(scenario(c)%gas_background(k)%mix_rat)) &
+                  bg(:, k, c) = scenario(c)%gas_background(k)%mix_rat(1:n_gas)
+          end do
+       end do
+    end if
+    q = 0
+    call pmcx_die(pmcx_set_gas_scenario(ctx, nte, ptr1(et, nte), ptr1(es, nte), ptr3(em, nte), &
+         ntd, ptr1(dtm, ntd), ptr2(dr, ntd), ptr3(bg, ntd)), 'pmcx_set_gas_scenario')
+  contains
+    type(c_ptr) function ptr1(a, n)
+      real(c_double), allocatable, target, intent(in) :: a(:)
+      integer, intent(in) :: n
+      ptr1 = c_null_ptr
+      if (n > 0) ptr1 = c_loc(a)
+    end function ptr1
+    type(c_ptr) function ptr2(a, n)
+      real(c_double), allocatable, target, intent(in) :: a(:,:)
+      integer, intent(in) :: n
+      ptr2 = c_null_ptr
+      if (n > 0) ptr2 = c_loc(a)
+    end function ptr2
+    type(c_ptr) function ptr3(a, n)
+      real(c_double), allocatable, target, intent(in) :: a(:,:,:)
+      integer, intent(in) :: n
+      ptr3 = c_null_ptr
+      if (n > 0) ptr3 = c_loc(a)
+    end function ptr3
+  end subroutine upload_domain
+
+  !> Do a single PartMC timestep: partmc_timestep (interface/wrf_pmc_driver.F90:46-290) with its
+  !> argument list, the loop body of every owned cell as ONE device call (pmcx_timestep): mc_coag on
+  !> chemistry steps, scenario_update_gas_state, scenario_update_aero_state, seasalt_emissions,
+  !> aero_state_rebalance, over the cells of the reference's loop nest.  MOSAIC (driver:232-245) is
+  !> not part of the library: grid%do_mosaic must be off.
+  subroutine partmc_timestep_pmcx(grid, config_flags, scenario, env_states, &
+       aero_data, aero_states, gas_data, gas_states, pmc_is, pmc_ie, pmc_js, &
+       pmc_je, pmc_ks, pmc_ke, global_nx, global_ny, global_nz)
+    integer, intent(in) :: pmc_is, pmc_ie, pmc_js, pmc_je, pmc_ks, pmc_ke
+    type(domain), intent(inout) :: grid
+    type(grid_config_rec_type), intent(in) :: config_flags
+    type(aero_data_t), intent(in) :: aero_data
+    type(aero_state_t), dimension(pmc_is:pmc_ie,pmc_ks:pmc_ke,pmc_js:pmc_je), intent(inout) :: aero_states
+    type(scenario_t), dimension(pmc_is:pmc_ie,pmc_ks:pmc_ke,pmc_js:pmc_je), intent(inout) :: scenario
+    type(env_state_t), dimension(pmc_is:pmc_ie,pmc_ks:pmc_ke,pmc_js:pmc_je), intent(inout) :: env_states
+    type(gas_data_t), intent(in) :: gas_data
+    type(gas_state_t), dimension(pmc_is:pmc_ie,pmc_ks:pmc_ke,pmc_js:pmc_je), intent(inout) :: gas_states
+    integer :: global_nx, global_ny, global_nz
+
+    integer :: nx, nz, ny, n_cells, i, j, k, c
+    real(kind=dp) :: elapsed_time
+    real(c_double), allocatable, target :: old_height(:), height(:), temp(:), pres(:), rh(:), wind(:)
+    real(c_double), allocatable, target :: em_rate(:,:), bg_conc(:,:), dil(:)
+    integer(c_int32_t), allocatable, target :: ocean(:), st(:), ns(:), nc(:)
+    integer(c_int32_t), target :: ss_class(5), ss_source(5)
+    type(pmcx_step_flags_t) :: flags
+    type(pmcx_aero_dist_t), target :: d_em, d_bg
+    logical :: changed
+    integer :: m
+
+    if (grid%do_mosaic) then
+       write(0,'(a)') 'partmc_timestep_pmcx: grid%do_mosaic is on; MOSAIC is not part of libpmcx &
+            &(run it on host states between partmc_sync_host_pmcx and a new upload, or switch it off)'
+       call pmcx_die(4, 'partmc_timestep_pmcx')
+    end if
+    nx = pmc_ie - pmc_is + 1; nz = pmc_ke - pmc_ks + 1; ny = pmc_je - pmc_js + 1
+    n_cells = nx * nz * ny
+    allocate(old_height(n_cells), height(n_cells), temp(n_cells), pres(n_cells), rh(n_cells))
+
+    ! Update the meteorology (driver:120-135)
+    call wrf_to_partmc_pmcx(grid, nx, nz, ny, pmc_is, pmc_ks, pmc_js, env_states, old_height)
+    elapsed_time = real(real_time_since_sim_start(grid), kind=dp)
+    c = 0
+    do j = pmc_js, pmc_je
+    do k = pmc_ks, pmc_ke
+    do i = pmc_is, pmc_ie
+       c = c + 1
+       env_states(i,k,j)%elapsed_time = elapsed_time
+       temp(c) = env_states(i,k,j)%temp
+       pres(c) = env_states(i,k,j)%pressure
+       rh(c) = env_states(i,k,j)%rel_humid
+       height(c) = env_states(i,k,j)%height
+       if (.not. (old_height(c) > 0d0)) old_height(c) = height(c)   ! (no previous state yet)
+    end do
+    end do
+    end do
+
+    if (.not. resident) then
+       ! room for a rebalance's doubling and a step's arrivals: twice the ideal count (the
+       ! reference's num_particles) and then some
+       call upload_domain(config_flags, scenario, env_states, aero_data, aero_states, gas_data, &
+            gas_states, nx, nz, ny, pmc_is, pmc_js, global_nx, global_ny, &
+            int(2.5 * grid%num_particles))
+       resident = .true.
+       res_nx = nx; res_nz = nz; res_ny = ny
+    else if (nx /= res_nx .or. nz /= res_nz .or. ny /= res_ny) then
+       call pmcx_die(4, 'partmc_timestep_pmcx (the resident block has another shape)')
+    end if
+    call pmcx_die(pmcx_set_env(ctx, temp, pres, rh), 'pmcx_set_env')
+
+    call pmcx_step_flags_default(flags)
+    flags%do_coagulation = merge(1, 0, grid%do_coagulation)                     ! driver:190
+    flags%allow_doubling = merge(1, 0, grid%allow_doubling)                    ! driver:249
+    flags%allow_halving = merge(1, 0, grid%allow_halving)
+    flags%kernel_type = COAG_KERNEL_TYPE_BROWN                                 ! driver:192
+    flags%dt = real(grid%dt, dp)                                               ! driver:203
+    flags%partmc_chem_dt = real(grid%partmc_chem_dt, kind=dp)                  ! driver:155
+    flags%elapsed_time = elapsed_time
+    flags%random_seed = int(grid%random_seed, c_int64_t)                       ! wrf_pmc_init.F90:131
+    flags%height = c_loc(height)
+    flags%old_height = c_loc(old_height)
+
+    ! scenario(i,k,j) at this time: the modes live on the device until a cell's series moves on;
+    ! what travels every step is one number per (cell, mode) -- the emission rate
+    ! num_conc * rate_scale / height [# m^-3 s^-1], the background concentration -- and the cells'
+    ! dilution rates
+    call scenario_modes(0, n_cells, scenario, elapsed_time, cfg%n_spec, em_n_mode, em_level, changed, &
+         em_num, em_gm, em_gs, em_vf, em_cls, em_src, em_scale)
+    if (em_n_mode > 0) then
+       d_em%n_mode = em_n_mode
+       if (changed) then
+          d_em%num_conc = c_loc(em_num); d_em%gm_radius = c_loc(em_gm); d_em%gsd_log10 = c_loc(em_gs)
+          d_em%vol_frac = c_loc(em_vf); d_em%mode_class = c_loc(em_cls); d_em%mode_source = c_loc(em_src)
+          d_em%per_cell = 1
+          call pmcx_die(pmcx_set_aero_scenario_modes(ctx, 0, c_loc(d_em)), 'pmcx_set_aero_scenario_modes')
+       end if
+       allocate(em_rate(em_n_mode, n_cells))
+       do c = 1, n_cells
+          do m = 1, em_n_mode
+             em_rate(m, c) = em_num(m, c) * (em_scale(c) / height(c))
+          end do
+       end do
+       d_em%num_conc = c_loc(em_rate)
+       d_em%gm_radius = c_null_ptr; d_em%gsd_log10 = c_null_ptr; d_em%vol_frac = c_null_ptr
+       d_em%mode_class = c_null_ptr; d_em%mode_source = c_null_ptr; d_em%per_cell = 0
+       flags%aero_emission = c_loc(d_em)
+    end if
+    call scenario_modes(1, n_cells, scenario, elapsed_time, cfg%n_spec, bg_n_mode, bg_level, changed, &
+         bg_num, bg_gm, bg_gs, bg_vf, bg_cls, bg_src, bg_rate)
+    if (bg_n_mode > 0) then
+       d_bg%n_mode = bg_n_mode
+       if (changed) then
+          d_bg%num_conc = c_loc(bg_num); d_bg%gm_radius = c_loc(bg_gm); d_bg%gsd_log10 = c_loc(bg_gs)
+          d_bg%vol_frac = c_loc(bg_vf); d_bg%mode_class = c_loc(bg_cls); d_bg%mode_source = c_loc(bg_src)
+          d_bg%per_cell = 1
+          call pmcx_die(pmcx_set_aero_scenario_modes(ctx, 1, c_loc(d_bg)), 'pmcx_set_aero_scenario_modes')
+       end if
+       d_bg%num_conc = c_loc(bg_num)
+       d_bg%gm_radius = c_null_ptr; d_bg%gsd_log10 = c_null_ptr; d_bg%vol_frac = c_null_ptr
+       d_bg%mode_class = c_null_ptr; d_bg%mode_source = c_null_ptr; d_bg%per_cell = 0
+       flags%aero_background = c_loc(d_bg)
+       flags%aero_dilution_rate = c_loc(bg_rate)
+    end if
+
+    ! sea salt on the lowest level of ocean cells (driver:212-223)
+    if (grid%partmc_seasalt_param > 0) then
+       allocate(ocean(n_cells), wind(n_cells))
+       ocean = 0; wind = 0d0
+       c = 0
+       do j = pmc_js, pmc_je
+       do k = pmc_ks, pmc_ke
+       do i = pmc_is, pmc_ie
+          c = c + 1
+          if (k == 1) then
+             if (grid%xland(i,j) > 1.5) then
+                ocean(c) = 1
+                wind(c) = (grid%u10(i,j) * grid%u10(i,j) + grid%v10(i,j) * grid%v10(i,j))**.5
+             end if
+          end if
+       end do
+       end do
+       end do
+       flags%sea_salt_opt = grid%partmc_seasalt_param
+       flags%i_na = aero_data_spec_by_name_pmcx(aero_data, 'Na') - 1           ! driver:1828-1829
+       flags%i_cl = aero_data_spec_by_name_pmcx(aero_data, 'Cl') - 1
+       do m = 1, 5                                                            ! "sea_salt_NN", driver:1841-1846
+          ss_class(m) = name_index(aero_data%weight_class_name, 'sea_salt_', m) - 1
+          ss_source(m) = name_index(aero_data%source_name, 'sea_salt_', m) - 1
+       end do
+       flags%ocean_surface = c_loc(ocean); flags%wind_speed = c_loc(wind)
+       flags%ss_mode_class = c_loc(ss_class); flags%ss_mode_source = c_loc(ss_source)
+    end if
+
+    call pmcx_die(pmcx_timestep(ctx, flags), 'pmcx_timestep')
+    ! the reference aborts inside PartMC; here a cell's status bits say what went wrong
+    allocate(ns(n_cells), nc(n_cells), st(n_cells))
+    call pmcx_die(pmcx_get_coag_counters(ctx, ns, nc, st), 'pmcx_get_coag_counters')
+    if (any(iand(st, 3) /= 0)) call pmcx_die(5, 'partmc_timestep_pmcx (event / append log overflow in mc_coag)')
+    if (any(iand(st, 16) /= 0)) call pmcx_die(5, 'partmc_timestep_pmcx (a cell ran out of particle slots)')
+    if (any(iand(st, 32) /= 0)) call pmcx_die(5, 'partmc_timestep_pmcx (particle created above the kernel-bounds range)')
+    last_n_samp = 0; last_n_coag = 0
+    if (mod(elapsed_time, flags%partmc_chem_dt) == 0.0d0 .and. grid%do_coagulation) then   ! driver:189-190
+       last_n_samp = sum(int(ns, 8)); last_n_coag = sum(int(nc, 8))
+    end if
+  end subroutine partmc_timestep_pmcx
+
+  integer function aero_data_spec_by_name_pmcx(aero_data, name)
+    type(aero_data_t), intent(in) :: aero_data
+    character(len=*), intent(in) :: name
+    integer :: s
+    aero_data_spec_by_name_pmcx = 0
+    if (.not. allocated(aero_data%name)) return
+    do s = 1, size(aero_data%name)
+       if (trim(aero_data%name(s)) == name) aero_data_spec_by_name_pmcx = s
+    end do
+  end function aero_data_spec_by_name_pmcx
+
+  integer function name_index(names, prefix, m)
+    character(len=*), allocatable, intent(in) :: names(:)
+    character(len=*), intent(in) :: prefix
+    integer, intent(in) :: m
+    character(len=AERO_SOURCE_NAME_LEN) :: want
+    integer :: s
+    name_index = 1
+    if (.not. allocated(names)) return
+    write(want, '(a,i2.2)') prefix, m
+    do s = 1, size(names)
+       if (trim(names(s)) == trim(want)) name_index = s
+    end do
+  end function name_index
+
+  !> depvel_partmc (interface/wrf_pmc_dep.F90:190-215): aerodynamic resistance from the inverse
+  !> Monin-Obukhov length, the roughness length and the friction velocity.  In a WRF build the
+  !> reference's own routine is used instead.
+  subroutine depvel_pmcx(rmol, zr, z0, ustar, aer_res)
+    real, intent(inout) :: rmol
+    real(kind=dp), intent(in) :: zr, z0, ustar
+    real(kind=dp), intent(out) :: aer_res
+    real(kind=dp) :: ao, ar, polint, vk
+    vk = 0.40d0
+    if (abs(rmol) < 1.0e-6) rmol = 0.
+    if (rmol < 0.0) then
+       ar = ((1.0 - 9.0 * zr * rmol)**(0.25) + 0.001)**2
+       ao = ((1.0 - 9.0 * z0 * rmol)**(0.25) + 0.001)**2
+       polint = 0.74 * (dlog((ar - 1.0) / (ar + 1.0)) - dlog((ao - 1.0) / (ao + 1.0)))
+    else if (rmol == 0.0) then
+       polint = 0.74 * dlog(zr / z0)
+    else
+       polint = 0.74 * dlog(zr / z0) + 4.7 * rmol * (zr - z0)
+    end if
+    aer_res = polint / (vk * max(ustar, 1.0e-4))
+  end subroutine depvel_pmcx
+
+  !> Top level subroutine for aerosol transport and deposition: wrf_pmc_trans_driver
+  !> (interface/wrf_pmc_trans.F90:37-200) with its argument list, on the resident block.  The
+  !> probabilities are built on the device from grid%'s fields (compute_advect_probs_wrf,
+  !> compute_diffusion_probs, compute_vertical_probs, normalize_probs), then trans_aero:
+  !> trans_aero_preweight, the sampling, the rebalance of the interior cells, the refill of the
+  !> lateral boundary cells (wrf_pmc_trans_aero.F90:40-971); then dry deposition on the lowest level.
+  subroutine wrf_pmc_trans_driver_pmcx(grid, config_flags, env_states, scenario, &
+       aero_data, aero_states, gas_states, pmc_is, pmc_ie, pmc_js, pmc_je, &
+       pmc_ks, pmc_ke, global_nx, global_ny, global_nz)
+    integer, intent(in) :: pmc_is, pmc_ie, pmc_js, pmc_je, pmc_ks, pmc_ke
+    type(domain), intent(inout) :: grid
+    type(grid_config_rec_type), intent(in) :: config_flags
+    type(env_state_t), dimension(pmc_is:pmc_ie,pmc_ks:pmc_ke,pmc_js:pmc_je), intent(inout) :: env_states
+    type(scenario_t), dimension(pmc_is:pmc_ie,pmc_ks:pmc_ke,pmc_js:pmc_je), intent(inout) :: scenario
+    type(aero_data_t), intent(in) :: aero_data
+    type(aero_state_t), dimension(pmc_is:pmc_ie,pmc_ks:pmc_ke,pmc_js:pmc_je), intent(inout) :: aero_states
+    type(gas_state_t), dimension(pmc_is:pmc_ie,pmc_ks:pmc_ke,pmc_js:pmc_je), intent(inout) :: gas_states
+    integer, intent(in) :: global_nx, global_ny, global_nz
+
+    integer :: nx, nz, ny, n_cells, n_class, i, j, k, c, step, n_copy, n_res, q, m, p, nm
+    logical :: ideal
+    real(kind=dp) :: elapsed_time, zr
+    type(pmcx_trans_fields_t) :: f
+    real(c_float), allocatable, target :: alt(:,:,:), xkhh(:,:,:), uf(:,:,:,:), vf(:,:,:,:), wf(:,:,:,:), &
+         z(:,:,:), zw(:,:,:), exch(:,:,:)
+    real(c_double), allocatable, target :: cell_volume(:), expected(:), dens(:), conc(:,:), gm(:,:), gs(:,:), &
+         vfr(:,:,:), ra(:), ust(:), alpha_c(:), biga_c(:), height(:), rrho(:)
+    integer(c_int32_t), allocatable, target :: n_moved(:), n_arrived(:), n_rem(:), from_c(:), to_c(:), res_c(:), &
+         thr(:), cls(:,:), src(:,:), n_add(:), n_rm(:), surface(:), bad(:), st(:), ns(:), nc(:)
+    type(pmcx_aero_dist_t) :: bgd
+
+    if (.not. resident) call pmcx_die(4, 'wrf_pmc_trans_driver_pmcx (partmc_timestep_pmcx comes first: nothing is resident)')
+    nx = pmc_ie - pmc_is + 1; nz = pmc_ke - pmc_ks + 1; ny = pmc_je - pmc_js + 1
+    n_cells = nx * nz * ny
+    n_class = cfg%n_class
+    ideal = config_flags%periodic_x .and. config_flags%periodic_y                  ! trans_aero:127-131
+    if (config_flags%periodic_x .neqv. config_flags%periodic_y) &
+         call pmcx_die(1, 'wrf_pmc_trans_driver_pmcx (periodic in one direction only: not supported)')
+    elapsed_time = env_states(pmc_is,pmc_ks,pmc_js)%elapsed_time
+    step = int(elapsed_time / real(grid%dt, dp))            ! the WRF-step count pmcx_timestep uses
+
+    if (grid%do_transport) then
+       ! the fields the probabilities read, single precision as grid% holds them (wrf_pmc_trans.F90:
+       ! 227-275, 374-406, 451-463, 645-646), copied out of WRF's memory order tile by tile
+       allocate(alt(0:nx+1, nz, 0:ny+1), xkhh(0:nx+1, nz, 0:ny+1), uf(nx+1, nz, ny, n_class), &
+            vf(nx, nz, ny+1, n_class), wf(nx, nz+1, ny, n_class), z(nx, nz, ny), zw(nx, nz+1, ny), &
+            exch(nx, nz+1, ny))
+       alt = grid%alt(pmc_is-1:pmc_ie+1, pmc_ks:pmc_ke, pmc_js-1:pmc_je+1)
+       xkhh = grid%xkhh(pmc_is-1:pmc_ie+1, pmc_ks:pmc_ke, pmc_js-1:pmc_je+1)
+       uf = grid%u_flux(pmc_is:pmc_ie+1, pmc_ks:pmc_ke, pmc_js:pmc_je, 2:n_class+1)   ! wrf_class = i_class + 1
+       vf = grid%v_flux(pmc_is:pmc_ie, pmc_ks:pmc_ke, pmc_js:pmc_je+1, 2:n_class+1)
+       wf = grid%w_flux(pmc_is:pmc_ie, pmc_ks:pmc_ke+1, pmc_js:pmc_je, 2:n_class+1)
+       z = grid%z(pmc_is:pmc_ie, pmc_ks:pmc_ke, pmc_js:pmc_je)
+       zw = grid%z_at_w(pmc_is:pmc_ie, pmc_ks:pmc_ke+1, pmc_js:pmc_je)
+       exch = grid%exch_h(pmc_is:pmc_ie, pmc_ks:pmc_ke+1, pmc_js:pmc_je)
+       f%nx = nx; f%nz = nz; f%ny = ny
+       f%do_vertmix = config_flags%vertmix_onoff                                   ! wrf_pmc_trans.F90:143
+       f%all_columns = merge(1, 0, config_flags%do_uniform .or. config_flags%do_scm .or. ideal)   ! :116-136
+       f%i_offset = pmc_is - 1; f%j_offset = pmc_js - 1
+       f%global_nx = global_nx; f%global_ny = global_ny
+       f%dt = real(grid%dt, dp); f%dx = real(grid%dx, dp); f%dy = real(grid%dy, dp)
+       f%alt = c_loc(alt); f%xkhh = c_loc(xkhh); f%u_flux = c_loc(uf); f%v_flux = c_loc(vf)
+       f%w_flux = c_loc(wf); f%z = c_loc(z); f%z_at_w = c_loc(zw); f%exch_h = c_loc(exch)
+       allocate(bad(n_cells))
+       call pmcx_die(pmcx_transport_probs(ctx, f, c_null_ptr, c_null_ptr, c_null_ptr, c_loc(bad), &
+            c_null_ptr), 'pmcx_transport_probs')
+       ! normalize_probs' assertions (wrf_pmc_trans.F90:713,746,759,771)
+       if (any(bad /= 0)) call pmcx_die(5, 'wrf_pmc_trans_driver_pmcx (normalize_probs: a probability is negative, above one, or their sum is)')
+
+       allocate(cell_volume(n_cells), expected(n_cells * n_class), n_rem(n_cells), n_moved(n_cells), &
+            n_arrived(n_cells))
+       c = 0
+       do j = pmc_js, pmc_je
+       do k = pmc_ks, pmc_ke
+       do i = pmc_is, pmc_ie
+          c = c + 1
+          cell_volume(c) = env_states(i,k,j)%cell_volume
+       end do
+       end do
+       end do
+       ! trans_aero (wrf_pmc_trans_aero.F90:40-971)
+       call pmcx_die(pmcx_set_transport_lateral(ctx, merge(0, 1, ideal), 0, 0), 'pmcx_set_transport_lateral')
+       call pmcx_die(pmcx_transport_preweight(ctx, nx, nz, ny, merge(1, 0, ideal), merge(1, 0, ideal), &
+            c_null_ptr, c_null_ptr, cell_volume, int(grid%random_seed, c_int64_t), step, expected, n_rem), &
+            'pmcx_transport_preweight')                                           ! trans_aero:294
+       call pmcx_die(pmcx_transport(ctx, nx, nz, ny, merge(1, 0, ideal), merge(1, 0, ideal), c_null_ptr, &
+            c_null_ptr, cell_volume, int(grid%random_seed, c_int64_t), step, n_moved, n_arrived), &
+            'pmcx_transport')                                                     ! trans_aero:519-801
+       ! aero_state_rebalance + aero_state_sort of the interior cells (trans_aero:798-801): its draws
+       ! are keyed apart from those of partmc_timestep's rebalance in the same WRF step
+       call pmcx_die(pmcx_rebalance(ctx, merge(1, 0, grid%allow_doubling), merge(1, 0, grid%allow_halving), &
+            int(grid%random_seed, c_int64_t), ior(step, ishft(1, 30))), 'pmcx_rebalance')
+       last_n_moved = sum(int(n_moved, 8))
+
+       if (.not. ideal) then
+          ! the refill of the lateral boundary cells (trans_aero:803-955): which copy their inner
+          ! neighbour (outflow), which are resampled against the background (inflow; emptied first
+          ! where the wind has turned or the background has moved to its next time level)
+          allocate(from_c(n_cells), to_c(n_cells), res_c(n_cells), thr(n_cells))
+          n_copy = 0; n_res = 0
+          if (pmc_is == 1) call side(1, 0, 1, 0, .true.)                          ! west,  u_2(i,k,j) < 0: outflow
+          if (pmc_ie == global_nx) call side(global_nx, 0, -1, 0, .false.)        ! east,  u_2(i+1,k,j) > 0
+          if (pmc_js == 1) call side(0, 1, 0, 1, .true.)                          ! south, v_2(i,k,j) < 0
+          if (pmc_je == global_ny) call side(0, global_ny, 0, -1, .false.)        ! north, v_2(i,k,j+1) > 0
+          if (n_copy > 0) call pmcx_die(pmcx_boundary_copy(ctx, n_copy, from_c, to_c), 'pmcx_boundary_copy')
+          if (n_res > 0) then
+             nm = 0
+             do q = 1, n_res
+                call cell_ijk(res_c(q), i, k, j)
+                nm = max(nm, size(scenario(i,k,j)%aero_background(1)%mode))
+             end do
+             allocate(conc(nm, n_res), gm(nm, n_res), gs(nm, n_res), vfr(cfg%n_spec, nm, n_res), cls(nm, n_res), &
+                  src(nm, n_res), dens(n_res), n_add(n_res), n_rm(n_res))
+             conc = 0d0; gm = 1d0; gs = 0.1d0; vfr = 0d0; vfr(1,:,:) = 1d0; cls = 0; src = 0
+             do q = 1, n_res
+                call cell_ijk(res_c(q), i, k, j)
+                p = dist_level(size(scenario(i,k,j)%aero_dilution_time), scenario(i,k,j)%aero_dilution_time, &
+                     env_states(i,k,j)%elapsed_time)                              ! aero_dist_interp_1d, trans_aero:834-838
+                do m = 1, size(scenario(i,k,j)%aero_background(p)%mode)
+                   conc(m, q) = scenario(i,k,j)%aero_background(p)%mode(m)%num_conc
+                   gm(m, q) = scenario(i,k,j)%aero_background(p)%mode(m)%char_radius
+                   gs(m, q) = scenario(i,k,j)%aero_background(p)%mode(m)%log10_std_dev_radius
+                   vfr(:, m, q) = scenario(i,k,j)%aero_background(p)%mode(m)%vol_frac(1:cfg%n_spec)
+                   cls(m, q) = scenario(i,k,j)%aero_background(p)%mode(m)%weight_class - 1
+                   src(m, q) = scenario(i,k,j)%aero_background(p)%mode(m)%source - 1
+                end do
+                dens(q) = 1.0d0 / env_states(i,k,j)%inverse_density                ! trans_aero:842
+             end do
+             bgd%n_mode = nm
+             bgd%num_conc = c_loc(conc); bgd%gm_radius = c_loc(gm); bgd%gsd_log10 = c_loc(gs)
+             bgd%vol_frac = c_loc(vfr); bgd%mode_class = c_loc(cls); bgd%mode_source = c_loc(src)
+             bgd%per_cell = 1
+             call pmcx_die(pmcx_boundary_resample(ctx, n_res, res_c, thr, bgd, dens, 0.0d0, &
+                  int(grid%random_seed, c_int64_t), step, n_add, n_rm), 'pmcx_boundary_resample')
+          end if
+       end if
+       allocate(ns(n_cells), nc(n_cells), st(n_cells))
+       call pmcx_die(pmcx_get_coag_counters(ctx, ns, nc, st), 'pmcx_get_coag_counters')
+       if (any(iand(st, 16) /= 0)) call pmcx_die(5, 'wrf_pmc_trans_driver_pmcx (a cell ran out of particle slots)')
+    end if
+
+    ! Do deposition on lowest layer (wrf_pmc_trans.F90:182-198, wrf_pmc_dep.F90:30-96,
+    ! wrf_pmc_dep_aero.F90:28-151)
+    if (pmc_ks == 1 .and. grid%do_deposition) then
+       allocate(surface(n_cells), ra(n_cells), ust(n_cells), alpha_c(n_cells), biga_c(n_cells), &
+            height(n_cells), rrho(n_cells))
+       if (.not. allocated(n_rem)) allocate(n_rem(n_cells))
+       if (.not. allocated(bad)) allocate(bad(n_cells))
+       surface = 0; ra = 1d0; ust = 1d0; alpha_c = 1d0; biga_c = 1d0; height = 1d0; rrho = 1d0
+       zr = 2.0
+       do j = max(pmc_js, 2), min(pmc_je, global_ny - 1)
+          do i = max(pmc_is, 2), min(pmc_ie, global_nx - 1)
+             c = ((j - pmc_js) * nz + 0) * nx + (i - pmc_is) + 1
+             surface(c) = 1
+             ust(c) = real(grid%ust(i,j), dp)
+             call depvel_pmcx(grid%rmol(i,j), zr, real(grid%znt(i,j), kind=dp), ust(c), ra(c))
+             call zhang_parameters(grid%ivgtyp(i,j), alpha_c(c), biga_c(c))
+             height(c) = env_states(i,1,j)%height
+             rrho(c) = env_states(i,1,j)%inverse_density
+          end do
+       end do
+       call pmcx_die(pmcx_dry_deposition(ctx, real(grid%dt, dp), int(grid%random_seed, c_int64_t), step, &
+            surface, ra, ust, alpha_c, biga_c, height, rrho, n_rem, bad), 'pmcx_dry_deposition')
+       last_n_deposited = sum(int(n_rem, 8))
+       last_aer_res = ra
+    end if
+
+  contains
+
+    !> 0-based cell number -> WRF's (i, k, j)
+    subroutine cell_ijk(c0, i_, k_, j_)
+      integer(c_int32_t), intent(in) :: c0
+      integer, intent(out) :: i_, k_, j_
+      i_ = pmc_is + mod(c0, nx)
+      k_ = pmc_ks + mod(c0 / nx, nz)
+      j_ = pmc_js + c0 / (nx * nz)
+    end subroutine cell_ijk
+
+    !> One lateral side (trans_aero:803-955).  West/east: i_b is the boundary column, inward = +1 /
+    !> -1 in x; south/north: j_b the boundary row.  lower: the velocity that decides is the one on
+    !> the cell's own lower face (u_2(i,k,j) / v_2(i,k,j)), outflow when negative; otherwise the
+    !> upper face (i + 1 / j + 1), outflow when positive.
+    subroutine side(i_b, j_b, di, dj, lower)
+      integer, intent(in) :: i_b, j_b, di, dj
+      logical, intent(in) :: lower
+      integer :: ii, jj, kk, a, b, t, i0, j0, p_t, p_tm1
+      logical :: change_bc, outflow, turned
+      real :: v2, v1
+      if (i_b > 0) then
+         a = max(pmc_js, 2); b = min(pmc_je, global_ny - 1)
+         i0 = i_b; j0 = pmc_js
+      else
+         a = max(pmc_is, 2); b = min(pmc_ie, global_nx - 1)
+         i0 = pmc_is; j0 = j_b
+      end if
+      ! the background moves to its next time level in this step (decided at the side's first cell,
+      ! as the reference does: trans_aero:811-822)
+      change_bc = .false.
+      if (allocated(scenario(i0,pmc_ks,j0)%aero_dilution_time)) then
+         p_tm1 = find_1d(size(scenario(i0,pmc_ks,j0)%aero_background), scenario(i0,pmc_ks,j0)%aero_dilution_time, &
+              env_states(i0,pmc_ks,j0)%elapsed_time - grid%dt)
+         p_t = find_1d(size(scenario(i0,pmc_ks,j0)%aero_background), scenario(i0,pmc_ks,j0)%aero_dilution_time, &
+              env_states(i0,pmc_ks,j0)%elapsed_time)
+         change_bc = p_t > p_tm1 .and. p_t > 1
+      end if
+      do t = a, b
+         do kk = pmc_ks, pmc_ke
+            if (i_b > 0) then
+               ii = i_b; jj = t
+               v2 = grid%u_2(merge(ii, ii + 1, lower), kk, jj); v1 = grid%u_1(merge(ii, ii + 1, lower), kk, jj)
+            else
+               ii = t; jj = j_b
+               v2 = grid%v_2(ii, kk, merge(jj, jj + 1, lower)); v1 = grid%v_1(ii, kk, merge(jj, jj + 1, lower))
+            end if
+            if (lower) then
+               outflow = v2 < 0.0d0
+            else
+               outflow = v2 > 0.0d0
+            end if
+            c = ((jj - pmc_js) * nz + (kk - pmc_ks)) * nx + (ii - pmc_is)
+            if (outflow) then                            ! aero_state_dup_all_particles(inner, boundary)
+               n_copy = n_copy + 1
+               to_c(n_copy) = c
+               from_c(n_copy) = ((jj + dj - pmc_js) * nz + (kk - pmc_ks)) * nx + (ii + di - pmc_is)
+            else                                         ! aero_state_resample against the background
+               turned = v2 * v1 < 0.0d0
+               n_res = n_res + 1
+               res_c(n_res) = c
+               thr(n_res) = merge(1, 0, turned .or. change_bc)
+            end if
+         end do
+      end do
+    end subroutine side
+
+  end subroutine wrf_pmc_trans_driver_pmcx
+
+  !> The land-use parameters of Zhang et al. (2001) the reference's dep_aero_dry_driver looks up
+  !> (interface/wrf_pmc_dep_aero.F90:66-151): USGS vegetation type -> Zhang surface type -> alpha and
+  !> the collector radius A of season 1 (the reference's fixed iseason; its gamma is overwritten at
+  !> :325 and not an input).
+  subroutine zhang_parameters(ivgtyp, alpha, big_a)
+    integer, intent(in) :: ivgtyp
+    real(kind=dp), intent(out) :: alpha, big_a
+    integer, parameter :: zhang_from_usgs(25) = (/ 15, 7, 7, 7, 7, 10, 6, 6, 6, 6, 4, 3, 2, 1, 5, 14, 11, &
+         10, 8, 9, 10, 9, 8, 12, 8 /)
+    real(kind=dp), parameter :: alpha_t(15) = (/ 1.0, 0.6, 1.1, 0.8, 0.8, 1.2, 1.2, 50.0, 50.0, 1.3, 2.0, &
+         50.0, 100.0, 100.0, 1.5 /)
+    real(kind=dp), parameter :: a_season1(15) = (/ 0.002, 0.005, 0.002, 0.005, 0.005, 0.002, 0.002, 9.999, &
+         9.999, 0.010, 0.010, 9.999, 9.999, 9.999, 0.010 /)
+    integer :: isurftype
+    isurftype = 7
+    if (ivgtyp >= 1 .and. ivgtyp <= 25) isurftype = zhang_from_usgs(ivgtyp)
+    alpha = alpha_t(isurftype)
+    big_a = a_season1(isurftype)
+  end subroutine zhang_parameters
+
+  !> Brings the host's aero_states / gas_states up to date with the resident block (what
+  !> partmc_before_solve_io needs at output and restart times, wrf_pmc_driver.F90:300-386).
+  subroutine partmc_sync_host_pmcx(aero_states, gas_states, pmc_is, pmc_ie, pmc_js, pmc_je, pmc_ks, pmc_ke)
+    integer, intent(in) :: pmc_is, pmc_ie, pmc_js, pmc_je, pmc_ks, pmc_ke
+    type(aero_state_t), dimension(pmc_is:pmc_ie,pmc_ks:pmc_ke,pmc_js:pmc_je), intent(inout) :: aero_states
+    type(gas_state_t), dimension(pmc_is:pmc_ie,pmc_ks:pmc_ke,pmc_js:pmc_je), intent(inout) :: gas_states
+    integer :: n_cells, n_gas, c, i, j, k
+    real(c_double), allocatable :: mix(:,:)
+    if (.not. resident) return
+    n_cells = (pmc_ie - pmc_is + 1) * (pmc_ke - pmc_ks + 1) * (pmc_je - pmc_js + 1)
+    if (n_cells /= cfg%n_cells) call pmcx_die(1, 'partmc_sync_host_pmcx (array shape /= resident block)')
+    call download_states_n(n_cells, aero_states)
+    if (.not. have_gas) return
+    n_gas = size(gas_states(pmc_is,pmc_ks,pmc_js)%mix_rat)
+    allocate(mix(n_gas, n_cells))
+    call pmcx_die(pmcx_get_gas_state(ctx, mix), 'pmcx_get_gas_state')
+    c = 0
+    do j = pmc_js, pmc_je
+    do k = pmc_ks, pmc_ke
+    do i = pmc_is, pmc_ie
+       c = c + 1
+       gas_states(i,k,j)%mix_rat(1:n_gas) = mix(:, c)
+    end do
+    end do
+    end do
+  end subroutine partmc_sync_host_pmcx
+
+  !> The core of partmc_process (interface/wrf_pmc_driver.F90:783,838-857,858-932,1137,1153-1157) on
+  !> the resident block: per cell tot_num_conc, tot_mass_conc and the 100-bin num_dist / mass_dist;
+  !> optionally the species masses, number by source, PM1/2.5/10 and particle counts.  Arrays are
+  !> (bins, cells) / (species, cells) in the cells' memory order.
+  subroutine partmc_process_pmcx(tot_num_conc, tot_mass_conc, num_dist, mass_dist, species_mass_conc, &
+       num_conc_by_source, pm_mass_conc, n_parts)
+    real(kind=dp), intent(out), target :: tot_num_conc(:), tot_mass_conc(:), num_dist(:,:), mass_dist(:,:)
+    real(kind=dp), intent(out), target, optional :: species_mass_conc(:,:), num_conc_by_source(:,:), pm_mass_conc(:,:)
+    integer(c_int32_t), intent(out), target, optional :: n_parts(:)
+    type(c_ptr) :: p1, p2, p3, p4
+    if (.not. have_ctx) call pmcx_die(4, 'partmc_process_pmcx (no resident block)')
+    if (size(tot_num_conc) /= cfg%n_cells .or. size(num_dist, 1) /= cfg%n_dbin) &
+         call pmcx_die(1, 'partmc_process_pmcx (array shapes)')
+    call pmcx_die(pmcx_diagnostics(ctx, c_loc(tot_num_conc), c_loc(tot_mass_conc), c_loc(num_dist), &
+         c_loc(mass_dist)), 'pmcx_diagnostics')
+    p1 = c_null_ptr; p2 = c_null_ptr; p3 = c_null_ptr; p4 = c_null_ptr
+    if (present(species_mass_conc)) p1 = c_loc(species_mass_conc)
+    if (present(num_conc_by_source)) p2 = c_loc(num_conc_by_source)
+    if (present(pm_mass_conc)) p3 = c_loc(pm_mass_conc)
+    if (present(n_parts)) p4 = c_loc(n_parts)
+    if (c_associated(p1) .or. c_associated(p2) .or. c_associated(p3) .or. c_associated(p4)) &
+         call pmcx_die(pmcx_diagnostics_ext(ctx, p1, p2, p3, p4), 'pmcx_diagnostics_ext')
+  end subroutine partmc_process_pmcx
 
 end module pmcx_shim

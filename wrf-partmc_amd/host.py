@@ -43,6 +43,7 @@ EXPORTED_SYMBOLS = [
     "pmcx_transport_probs", "pmcx_set_sampler_variant", "pmcx_transport_preweight",
     "pmcx_set_transport_lateral", "pmcx_boundary_copy", "pmcx_boundary_resample",
     "pmcx_transport_preweight_begin", "pmcx_transport_preweight_finish",
+    "pmcx_step_flags_default", "pmcx_set_loop_cells", "pmcx_max_cap", "pmcx_set_aero_scenario_modes",
 ]
 
 
@@ -91,24 +92,27 @@ class PmcxAeroDist(C.Structure):
     _fields_ = [
         ("n_mode", C.c_int32), ("num_conc", C.c_void_p), ("gm_radius", C.c_void_p),
         ("gsd_log10", C.c_void_p), ("vol_frac", C.c_void_p), ("mode_class", C.c_void_p),
-        ("mode_source", C.c_void_p),
+        ("mode_source", C.c_void_p), ("per_cell", C.c_int32),
     ]
 
 
 class PmcxStepFlags(C.Structure):
     _fields_ = [
+        ("struct_size", C.c_int32),
         ("do_coagulation", C.c_int32), ("allow_doubling", C.c_int32),
         ("allow_halving", C.c_int32), ("kernel_type", C.c_int32), ("dt", C.c_double),
         ("partmc_chem_dt", C.c_double), ("elapsed_time", C.c_double),
         ("random_seed", C.c_uint64),
         ("height", C.c_void_p), ("old_height", C.c_void_p), ("aero_emission", C.c_void_p),
         ("aero_dilution_rate", C.c_void_p), ("aero_background", C.c_void_p),
+        ("sea_salt_opt", C.c_int32), ("i_na", C.c_int32), ("i_cl", C.c_int32), ("pad_", C.c_int32),
+        ("ocean_surface", C.c_void_p), ("wind_speed", C.c_void_p), ("ss_mode_class", C.c_void_p),
+        ("ss_mode_source", C.c_void_p),
     ]
 
 
 def library_path():
-    # PMCX_LIBRARY: another build of the same library (A/B timing of two builds on one box)
-    return os.environ.get("PMCX_LIBRARY") or os.path.join(_HERE, "libpmcx.so")
+    return os.path.join(_HERE, "libpmcx.so")
 
 
 def build_library(force=False):
@@ -144,8 +148,7 @@ def load_library():
     L.pmcx_create.argtypes = [C.POINTER(PmcxConfig), C.POINTER(C.c_void_p)]
     L.pmcx_mc_coag.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_uint64, C.c_uint32]
     L.pmcx_rebalance.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_uint32]
-    if hasattr(L, "pmcx_set_kernel_bounds_margin"):   # (absent from an older build under PMCX_LIBRARY)
-        L.pmcx_set_kernel_bounds_margin.argtypes = [C.c_void_p, C.c_int32]
+    L.pmcx_set_kernel_bounds_margin.argtypes = [C.c_void_p, C.c_int32]
     L.pmcx_condense.argtypes = [C.c_void_p, C.c_double, C.c_int32]
     L.pmcx_transport.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
@@ -173,6 +176,12 @@ def load_library():
     L.pmcx_device_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
     L.pmcx_dry_deposition.argtypes = [C.c_void_p, C.c_double, C.c_uint64, C.c_uint32] + [C.c_void_p] * 9
     L.pmcx_timestep.argtypes = [C.c_void_p, C.POINTER(PmcxStepFlags)]
+    L.pmcx_step_flags_default.restype = None
+    L.pmcx_step_flags_default.argtypes = [C.POINTER(PmcxStepFlags)]
+    L.pmcx_set_loop_cells.argtypes = [C.c_void_p, C.c_void_p]
+    L.pmcx_set_aero_scenario_modes.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    L.pmcx_max_cap.restype = C.c_int32
+    L.pmcx_max_cap.argtypes = [C.POINTER(PmcxConfig)]
     L.pmcx_set_sampler_variant.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     L.pmcx_transport_preweight_begin.argtypes = [C.c_void_p] + [C.c_int32] * 7 + [C.c_void_p] * 4
     L.pmcx_transport_preweight_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
@@ -463,21 +472,45 @@ class CellBlock:
         self._ck(self._lib.pmcx_rebalance(self._h, int(allow_doubling), int(allow_halving), seed,
                                           step))
 
-    def _aero_dist(self, modes, num_conc):
-        """modes: list of dict(gm_radius, gsd_log10, vol_frac, wclass, source);
-        num_conc: [n_cells][n_mode] (or broadcastable)."""
+    def _aero_dist(self, modes, num_conc, n_rows=None):
+        """modes: list of dict(gm_radius, gsd_log10, vol_frac, wclass, source) shared by every cell,
+        or -- per cell, as scenario(i,k,j) holds them -- a list (one entry per cell) of such lists;
+        num_conc: [n_cells][n_mode] (or broadcastable).  n_rows: rows of a per-cell list other than
+        n_cells (pmcx_boundary_resample's list of cells)."""
         if not modes:
             return None, None
+        n = self.cfg.n_cells if n_rows is None else n_rows
+        if isinstance(modes, int):      # the resident modes (set_aero_scenario_modes): only num_conc travels
+            keep = dict(nc=np.broadcast_to(_f64(num_conc), (n, modes)).copy())
+            return PmcxAeroDist(modes, keep["nc"].ctypes.data, None, None, None, None, None, 0), keep
+        per_cell = isinstance(modes[0], (list, tuple))
+        if per_cell:
+            assert len(modes) == n and all(len(m) == len(modes[0]) for m in modes)
+            flat = [m for cell in modes for m in cell]
+            M = len(modes[0])
+        else:
+            flat, M = modes, len(modes)
         keep = dict(
-            nc=np.broadcast_to(_f64(num_conc), (self.cfg.n_cells, len(modes))).copy(),
-            gm=_f64([m["gm_radius"] for m in modes]), gs=_f64([m["gsd_log10"] for m in modes]),
-            vf=_f64([m["vol_frac"] for m in modes]),
-            mc=np.array([m.get("wclass", 0) for m in modes], dtype=np.int32),
-            ms=np.array([m.get("source", 0) for m in modes], dtype=np.int32))
-        d = PmcxAeroDist(len(modes), keep["nc"].ctypes.data, keep["gm"].ctypes.data,
+            nc=np.broadcast_to(_f64(num_conc), (n, M)).copy(),
+            gm=_f64([m["gm_radius"] for m in flat]), gs=_f64([m["gsd_log10"] for m in flat]),
+            vf=_f64([m["vol_frac"] for m in flat]),
+            mc=np.array([m.get("wclass", 0) for m in flat], dtype=np.int32),
+            ms=np.array([m.get("source", 0) for m in flat], dtype=np.int32))
+        d = PmcxAeroDist(M, keep["nc"].ctypes.data, keep["gm"].ctypes.data,
                          keep["gs"].ctypes.data, keep["vf"].ctypes.data, keep["mc"].ctypes.data,
-                         keep["ms"].ctypes.data)
+                         keep["ms"].ctypes.data, int(per_cell))
         return d, keep
+
+    def set_aero_scenario_modes(self, which, modes):
+        """Keeps the mode parameters of the emission (which = 0) or background (1) distribution on
+        the device (modes as for scenario_update_aero_state, shared or per cell); afterwards pass
+        the number of modes (an int) instead of the modes and only num_conc travels."""
+        if modes is None:
+            self._ck(self._lib.pmcx_set_aero_scenario_modes(self._h, which, None))
+            return
+        M = len(modes[0]) if isinstance(modes[0], (list, tuple)) else len(modes)
+        d, keep = self._aero_dist(modes, np.zeros((self.cfg.n_cells, M)))
+        self._ck(self._lib.pmcx_set_aero_scenario_modes(self._h, which, C.addressof(d)))
 
     def scenario_update_aero_state(self, dt, elapsed_time, seed=0, step=0, emission=None,
                                    emission_rate=None, dilution_rate=None, background=None,
@@ -676,15 +709,7 @@ class CellBlock:
         cl = np.ascontiguousarray(cells, dtype=np.int32)
         n = len(cl)
         ta = np.ascontiguousarray(np.broadcast_to(np.asarray(throw_away, dtype=np.int32), (n,)))
-        keep = dict(
-            nc=np.ascontiguousarray(np.broadcast_to(_f64(background_conc), (n, len(background)))),
-            gm=_f64([m["gm_radius"] for m in background]), gs=_f64([m["gsd_log10"] for m in background]),
-            vf=_f64([m["vol_frac"] for m in background]),
-            mc=np.array([m.get("wclass", 0) for m in background], dtype=np.int32),
-            ms=np.array([m.get("source", 0) for m in background], dtype=np.int32))
-        d = PmcxAeroDist(len(background), keep["nc"].ctypes.data, keep["gm"].ctypes.data,
-                         keep["gs"].ctypes.data, keep["vf"].ctypes.data, keep["mc"].ctypes.data,
-                         keep["ms"].ctypes.data)
+        d, keep = self._aero_dist(background, background_conc, n_rows=n)
         dn = np.ascontiguousarray(np.broadcast_to(_f64(density), (n,)))
         na, nr = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
         self._ck(self._lib.pmcx_boundary_resample(self._h, n, _ptr(cl), _ptr(ta), C.addressof(d), _ptr(dn),
@@ -884,16 +909,30 @@ class CellBlock:
         ho = None if old_height is None else np.ascontiguousarray(np.broadcast_to(_f64(old_height), (n,)))
         self._ck(self._lib.pmcx_scenario_update_gas_state(self._h, dt, elapsed_time, _ptr(h), _ptr(ho)))
 
+    def set_loop_cells(self, in_loop):
+        """The cells partmc_timestep's loop nest covers (driver:157-171): in_loop [n_cells] of 0/1,
+        None: every cell.  mc_coag, the scenario updates and the rebalance leave the others alone."""
+        a = None if in_loop is None else np.ascontiguousarray(in_loop, dtype=np.int32)
+        assert a is None or a.shape == (self.cfg.n_cells,)
+        self._ck(self._lib.pmcx_set_loop_cells(self._h, _ptr(a)))
+
+    def max_cap(self):
+        return int(self._lib.pmcx_max_cap(C.byref(self.cfg)))
+
     def partmc_timestep(self, elapsed_time, dt, partmc_chem_dt, do_coagulation=True,
                         allow_doubling=True, allow_halving=True,
                         kernel_type=COAG_KERNEL_TYPE_BROWN, random_seed=0, height=None,
                         old_height=None, emission=None, emission_rate=None, dilution_rate=None,
-                        background=None, background_conc=None):
+                        background=None, background_conc=None, sea_salt_opt=0, i_na=0, i_cl=0,
+                        ocean_surface=None, wind_speed=None, ss_mode_class=None, ss_mode_source=None):
         """The loop body of partmc_timestep over every cell (driver:169-254): gated mc_coag,
-        gas and aerosol scenario updates, rebalance."""
+        gas and aerosol scenario updates, sea salt, rebalance."""
         n = self.cfg.n_cells
-        f = PmcxStepFlags(int(do_coagulation), int(allow_doubling), int(allow_halving),
-                          kernel_type, dt, partmc_chem_dt, elapsed_time, random_seed)
+        f = PmcxStepFlags()
+        self._lib.pmcx_step_flags_default(C.byref(f))
+        f.do_coagulation, f.allow_doubling, f.allow_halving = int(do_coagulation), int(allow_doubling), int(allow_halving)
+        f.kernel_type, f.dt, f.partmc_chem_dt, f.elapsed_time = kernel_type, dt, partmc_chem_dt, elapsed_time
+        f.random_seed = random_seed
         keep = []
         if height is not None:
             h = np.ascontiguousarray(np.broadcast_to(_f64(height), (n,))); keep.append(h)
@@ -910,6 +949,18 @@ class CellBlock:
         if dilution_rate is not None:
             dl = np.ascontiguousarray(np.broadcast_to(_f64(dilution_rate), (n,))); keep.append(dl)
             f.aero_dilution_rate = dl.ctypes.data
+        if sea_salt_opt:
+            oc = np.ascontiguousarray(np.broadcast_to(ocean_surface, (n,)), dtype=np.int32)
+            ws = np.ascontiguousarray(np.broadcast_to(_f64(wind_speed), (n,)))
+            keep += [oc, ws]
+            f.sea_salt_opt, f.i_na, f.i_cl = int(sea_salt_opt), int(i_na), int(i_cl)
+            f.ocean_surface, f.wind_speed = oc.ctypes.data, ws.ctypes.data
+            if ss_mode_class is not None:
+                mc = np.ascontiguousarray(ss_mode_class, dtype=np.int32); keep.append(mc)
+                f.ss_mode_class = mc.ctypes.data
+            if ss_mode_source is not None:
+                ms = np.ascontiguousarray(ss_mode_source, dtype=np.int32); keep.append(ms)
+                f.ss_mode_source = ms.ctypes.data
         self._ck(self._lib.pmcx_timestep(self._h, C.byref(f)))
 
     def diagnostics(self):
