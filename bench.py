@@ -421,6 +421,7 @@ def main():
         np_last = blk.aero_state_total_particles()
         last_counts = {g: (int(nc_last[g - first_cell]), int(np_last[g - first_cell]))
                        for g in cpu_counts if first_cell <= g < first_cell + n_cells}
+    sampler_left = blk.sampler_info()     # cells the sampler's split-off draw left to its second launch (last step)
     samp, coag, parts_after, status = blk.read_accumulated(reset=True)
     parts = parts_after + coag    # one class: particles entering a step = survivors + events
     for k in KERNELS:
@@ -529,6 +530,7 @@ def main():
             "n_part_mean": agg["particle_steps"] / args.steps / n_cells_total,
             "timed_steps": f"simulation steps {args.warmup} .. {args.warmup + args.steps - 1}",
             "status_or": status,
+            "sampler_cells_left_to_second_launch": sampler_left,
             "device_memory_gb_rank0": mem / 1e9,
             "kernel_ms_per_step": {k: kern_ms[k] / args.steps for k in KERNELS},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,

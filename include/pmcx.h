@@ -581,12 +581,18 @@ int pmcx_sort_only(pmcx_ctx *ctx);
 int pmcx_invalidate_sort(pmcx_ctx *ctx);
 /* Diagnostic: pin the pair sampler's launch shape instead of the library's own choice by
  * domain size, so that tests can hold every variant to the oracle at small sizes.  lanes: 0
- * automatic; 1 lane per cell (the full domain's kernel); 2 its two-wavefront form (a rank's
- * share at N = 4, 8); 8, 16, 64 lanes per cell (small blocks).  wavefronts_per_group: 0
+ * automatic; 1 lane per cell (the full domain's kernel: with one class, one species and the
+ * Brownian kernel its draw runs ahead of the sweep as a phase of its own); 3 lane per cell
+ * without that; 2 its two-wavefront form (a rank's share at N = 4, 8); 8, 16, 64 lanes per cell
+ * (small blocks).  wavefronts_per_group: 0
  * automatic, 1, 2 or 4 (the 8/16/64 kernels; with lanes = 1: 1, 2 cap the wavefronts a SIMD
  * holds).  stamps: 1 = the instantiation that records
  * cycles per stage (pmcx_profile_phase_cycles).  Results do not depend on any of them. */
 int pmcx_set_sampler_variant(pmcx_ctx *ctx, int32_t lanes, int32_t wavefronts_per_group, int32_t stamps);
+
+/* Inspection: out[0] = cells the lane-per-cell sampler's split-off draw left to its second launch in
+ * the last pmcx_mc_coag (-1: that form did not run); out[1..3] reserved (0).  Synchronises. */
+int pmcx_get_sampler_info(pmcx_ctx *ctx, int32_t out[4]);
 
 /* The lists only: the library keeps, per slot, the sort key (group, or "tombstone") it was
  * last binned under, and a kernel that changes a population while keeping those keys current

@@ -32,7 +32,7 @@ def make_modes(n_spec, n_class, coarse=False):
 
 def setup_pair(wp, oracle, n_cells, n_part, n_spec, n_class, seed, kernel, cap=None,
                n_source=3, coarse=False, cell_id_base=0, max_events=None, max_appends=None,
-               num_conc_scale=1.0, device=0, explicit_bounds=True, **cfg_over):
+               num_conc_scale=1.0, device=0, explicit_bounds=True, modes=None, num_conc=None, **cfg_over):
     """Build a CellBlock and matching oracle cells with identical contents."""
     cap = cap or int(np.ceil(n_part * 1.0 / 64) * 64)
     over = dict(cfg_over)
@@ -48,7 +48,8 @@ def setup_pair(wp, oracle, n_cells, n_part, n_spec, n_class, seed, kernel, cap=N
     pres = 101325.0 * (temp / 288.15) ** 5.256
     blk.set_env(temp, pres, np.full(n_cells, 0.5))
     v_edge, v_samp = blk.bin_tables()
-    modes, num_conc = make_modes(n_spec, n_class, coarse)
+    if modes is None:
+        modes, num_conc = make_modes(n_spec, n_class, coarse)
     num_conc *= num_conc_scale
     # flat weights: every computational particle of class c stands for mag[c] m^-3
     frac_cls = np.zeros(n_class)

@@ -70,7 +70,7 @@ def test_code_objects_are_gfx950_only(wp):
 # test hooks and diagnostics of include/pmcx.h: everything else is a product entry point
 _TEST_HOOKS = {"pmcx_get_bin_tables", "pmcx_get_diag_grid", "pmcx_get_kmax", "pmcx_get_caches", "pmcx_get_sort",
                "pmcx_get_keys", "pmcx_test_math", "pmcx_test_philox", "pmcx_set_sampler_variant",
-               "pmcx_profile_phase_cycles", "pmcx_invalidate_lists"}
+               "pmcx_profile_phase_cycles", "pmcx_invalidate_lists", "pmcx_get_sampler_info"}
 
 
 def _struct_fields(header, name):

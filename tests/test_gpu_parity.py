@@ -13,13 +13,16 @@ pytestmark = pytest.mark.gpu
 K_BROWN, K_SEDI, K_ADD, K_CONST, K_ZERO, K_BS = 4, 1, 2, 3, 5, 101
 
 
-@pytest.fixture(autouse=True, params=["dispatch", "lane-per-cell", "lane-per-cell-split"])
+@pytest.fixture(autouse=True, params=["dispatch", "lane-per-cell", "lane-per-cell-split", "lane-per-cell-one-phase"])
 def sampler_variant(request, monkeypatch, wp):
-    """Every test of this module runs three times: with the library's own choice of sampler (the
+    """Every test of this module runs four times: with the library's own choice of sampler (the
     lanes-per-cell kernels at these cell counts), with the lane-per-cell kernel forced (the one
-    the full-size domain runs) and with its two-wavefront form (evaluator + drawer, what a
-    rank's share of the domain runs at N = 8), so that all are held to the oracle."""
-    variant = {"lane-per-cell": (1, 0, 0), "lane-per-cell-split": (2, 0, 0)}.get(request.param)
+    the full-size domain runs: with one class, one species and the Brownian kernel its draw runs
+    ahead of the sweep, and the kernel without that finishes what it leaves), with its
+    two-wavefront form (evaluator + drawer, what a rank's share of the domain runs at N = 8) and
+    with the lane-per-cell kernel drawing as it sweeps, so that all are held to the oracle."""
+    variant = {"lane-per-cell": (1, 0, 0), "lane-per-cell-split": (2, 0, 0),
+               "lane-per-cell-one-phase": (3, 0, 0)}.get(request.param)
     from wrf_partmc_amd import host
     monkeypatch.setattr(host, "SAMPLER_VARIANT", variant)   # -> pmcx_set_sampler_variant
     return request.param
@@ -180,6 +183,44 @@ def test_mc_coag_parity_10k(wp):
                           kernel=K_BS, del_t=300.0, coarse=True)
     assert res["bitwise_equal"], res["first_mismatch"]
     assert res["n_coag_total"] > 10
+    res["blk"].close()
+
+
+@pytest.mark.parametrize("n_cells,n_part,del_t,steps", [
+    (130, 3000, 900.0, 4),      # a few tens of events a cell: a list mostly holds to the end of the sweep
+    (70, 6000, 6000.0, 3),      # hundreds of events: every cell outgrows its list several times
+    (5, 12000, 40000.0, 2),     # so dense that a cell's list runs full
+])
+def test_split_off_draw(wp, oracle, n_cells, n_part, del_t, steps):
+    """One class, one species, Brownian -- the configuration whose draw the lane-per-cell sampler
+    runs ahead of the sweep: cells whose list describes them to the end, and cells that outgrow it
+    (a bin takes more merged particles than it allows for, a particle is born in a bin it did not
+    walk, the list runs full) and walk their remaining slots again; counters and every particle
+    against the oracle."""
+    res = parity.run_pair(n_cells=n_cells, n_part=n_part, n_spec=1, n_class=1, steps=steps, seed=19,
+                          kernel=K_BROWN, del_t=del_t, n_source=0, max_events=8192, max_appends=2048,
+                          cap=(n_part + 63) // 64 * 64)
+    assert res["bitwise_equal"], res["first_mismatch"]
+    assert res["status_or"] == 0 and res["n_coag_total"] > 20 * n_cells
+    from wrf_partmc_amd import host
+    if host.SAMPLER_VARIANT == (1, 0, 0):        # the form with the draw split off ran
+        assert res["blk"].sampler_info() == 0    # (only a population beyond 32 bins goes to the second launch)
+    res["blk"].close()
+
+
+def test_split_off_draw_holds_for_the_benchmark_population(wp, oracle):
+    """The idealised initial condition of the reference (one log-normal mode, wrf_pmc_init.F90:
+    1764-1777), 10^4 particles a cell as in BASELINE configs[4], through the sampler with its draw
+    split off: five steps bit for bit against the oracle."""
+    from wrf_partmc_amd.data import idealised_modes
+    n_cells, n_part = 200, 10000
+    res = parity.run_pair(n_cells=n_cells, n_part=n_part, n_spec=1, n_class=1, steps=5, seed=0, kernel=K_BROWN,
+                          del_t=300.0, n_source=0, cap=10048, modes=idealised_modes(1, 1), num_conc=1e10)
+    assert res["bitwise_equal"], res["first_mismatch"]
+    assert res["status_or"] == 0 and res["n_coag_total"] > 30 * n_cells * 5
+    from wrf_partmc_amd import host
+    if host.SAMPLER_VARIANT == (1, 0, 0):
+        assert res["blk"].sampler_info() == 0
     res["blk"].close()
 
 
@@ -405,6 +446,8 @@ def test_wide_distribution_beyond_lds_window(wp, oracle, sampler_variant):
             assert (ons, onc, ost) == (int(ns[c]), int(nc[c]), int(st[c])), (step, c)
         total += int(nc.sum())
     assert total > 1000
+    if sampler_variant == "lane-per-cell":   # beyond the 32 bins its draw can walk: the second launch does these cells
+        assert blk.sampler_info() == n_cells
     ok, msg = parity.compare_state(blk, cells)
     assert ok, msg
     blk.close()
@@ -1436,6 +1479,20 @@ def test_transport_follows_the_sampling_law(wp):
     phys0 = n_part * (n0 * 1.0 + n1 * 2.0)
     phys1 = float((n_after * vol).sum())
     assert abs(phys1 - phys0) < 5 * np.sqrt(dn * 2 * 1.0 + up * 0.25 * 4.0) + 1e-9
+    # The VARIANCE of a cell's arrivals, over the 2048 cells of each level.  Per source
+    # cell of n particles and destination with probability p and weight ratio r:
+    #   r >= 1  this law and the reference's (wrf_pmc_trans_aero.F90:2244-2300: Binomial(n, p) picks,
+    #           each added with probability 1/r) agree: arrivals ~ Binomial(n, p / r)
+    #   r < 1   here: Binomial(n, p) movers x (1 + geometric) copies: n p (2 - r - p) / r^2;
+    #           the reference: Poisson(n p / r) picks with replacement, each a copy: n p / r
+    horiz = 4 * n_part * p_h * (1 - p_h)
+    var_up_here = n_part * (p_up / 2) * (1 - p_up / 2)                  # r = 2: the same under both laws
+    var_dn_here = n_part * p_dn * (2 - 0.5 - p_dn) / 0.25               # r = 1/2
+    var_dn_ref = n_part * p_dn / 0.5
+    v1, v0 = na[lev == 1].var(ddof=1), na[lev == 0].var(ddof=1)
+    assert abs(v1 / (horiz + var_up_here) - 1) < 0.15, (v1, horiz + var_up_here)
+    assert abs(v0 / (horiz + var_dn_here) - 1) < 0.15, (v0, horiz + var_dn_here)
+    assert v0 > 1.5 * (horiz + var_dn_ref)             # (and it is not the reference's: stated, not hidden)
 
 
 def test_dry_deposition_follows_zhang_2001(wp):

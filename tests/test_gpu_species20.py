@@ -91,6 +91,69 @@ def test_config3_shape_twenty_species(wp, oracle):
     blk.close()
 
 
+def test_config3_at_its_stated_size(wp, oracle):
+    """BASELINE configs[2] at its stated size: 1000 independent cells x 10^4 particles x 20 species,
+    condensation sub-step (extension) + Brownian coagulation, two steps.  Properties on ALL cells --
+    every dry species' number-weighted volume conserved by coagulation to rounding, one particle
+    lost per event, water taken up, no status bit, ids unique -- and every particle field against
+    the oracle, bit for bit, on 64 cells spread over the block."""
+    n_cells, n_part, cap = 1000, 10000, 10048
+    dens, kappa, _, names = aero_data_arrays()
+    n_spec, i_water = len(dens), names.index("H2O")
+    modes, num_conc = scm_init_modes()
+    blk = wp.CellBlock(n_cells, cap, n_spec, n_class=1, n_source=0, i_water=i_water)
+    blk.set_aero_data(dens, kappa=kappa)
+    temp, pres = bench.level_profile(30)
+    lev = np.arange(n_cells) % 30
+    rh = np.random.RandomState(0).uniform(0.3, 0.95, n_cells)
+    blk.set_env(temp[lev], pres[lev], rh)
+    blk.set_weights(np.full((n_cells, 1), num_conc / n_part))
+    blk.set_n_part_ideal(np.full((n_cells, 1), float(n_part)))
+    blk.generate_lognormal(n_part, modes, seed=3)
+    ve, vs = blk.bin_tables()
+    chk = sorted(set(np.linspace(0, n_cells - 1, 64).astype(int).tolist()))
+    cells, kcache = {}, {}
+    for c in chk:
+        oc = oracle.Cell(n_spec, 1, 0, cap, dens, ve, temp[lev[c]], pres[lev[c]],
+                         max_events=blk.cfg.max_events, max_appends=blk.cfg.max_appends)
+        oc.mag[:] = num_conc / n_part
+        oc.generate(modes, n_part, 3, c, first_id=c << 32)
+        if lev[c] not in kcache:
+            kcache[lev[c]] = oracle.kmax_table(K_BROWN, vs, dens.min(), dens.max(), temp[lev[c]], pres[lev[c]])
+        oc.kmax[:] = kcache[lev[c]]
+        cells[c] = oc
+    sm0 = blk.diagnostics_ext()[0]                                  # species mass concentrations [cell][spec]
+    events = np.zeros(n_cells, np.int64)
+    dry = [s for s in range(n_spec) if s != i_water]
+    for step in range(2):
+        blk.condense(300.0, 4)
+        sm_c = blk.diagnostics_ext()[0]
+        np.testing.assert_allclose(sm_c[:, dry], sm0[:, dry], rtol=1e-12, atol=1e-30)   # condensation moves water only
+        n_before = blk.aero_state_total_particles().astype(np.int64)
+        ns, nc, st = blk.mc_coag(K_BROWN, 300.0, 3, step)
+        assert not st.any()
+        n_after = blk.aero_state_total_particles().astype(np.int64)
+        assert np.array_equal(n_before - n_after, nc)               # one class: one particle lost per event
+        sm1 = blk.diagnostics_ext()[0]
+        np.testing.assert_allclose(sm1, sm_c, rtol=1e-11, atol=1e-30)   # coagulation conserves every species
+        events += nc
+        for c, oc in cells.items():
+            oc.condense(kappa, i_water, rh[c], 300.0, 4)
+            assert oc.mc_coag(K_BROWN, 300.0, 3, c, step) == (int(st[c]), int(ns[c]), int(nc[c])), (step, c)
+        sm0 = sm1
+    assert events.min() > 0 and events.sum() > 10 * n_cells
+    assert sm0[:, i_water].min() > 0.0                               # every cell took up water
+    for c, oc in cells.items():
+        dn = blk.download_cells(c, 1)
+        n = int(oc.n_part[0])
+        assert dn["part_offset"][1] == n
+        assert np.array_equal(dn["vol"], oc.vol[:, :n]) and np.array_equal(dn["id"], oc.id[:n]), c
+        assert np.array_equal(dn["least_ct"], oc.lct[:n]), c
+    ids = blk.download_cells(0, 40)["id"]
+    assert len(np.unique(ids)) == len(ids)
+    blk.close()
+
+
 def test_config4_shape_column_through_the_fortran_shim(tmp_path, wp, oracle):
     """30 levels x 10^4 particles x 20 species: Fortran driver -> pmcx_shim -> libpmcx, batched."""
     from tests.test_gpu_fortran import EXE, _build

@@ -85,6 +85,7 @@ struct pmcx_ctx {
     // pmcx_set_aero_scenario_modes: the mode parameters of the emission (0) and background (1)
     // distributions kept between calls (a dist passed with gm_radius == NULL refers to them)
     struct ResidentModes { GenSpecDev g{}; void *dd = nullptr, *di = nullptr; } res_modes[2];
+    bool sampler_pre_ran = false; // the last pmcx_mc_coag ran the sampler with its draw split off
     int bounds_kernel = 0; // kernel type the kmax tables are valid for (0 = none)
     int bounds_margin = 8;     // bins above a cell's populated range its bounds cover (< 0: whole tables)
     bool bounds_dirty = true;  // something other than mc_coag changed a population since the last check
@@ -365,6 +366,9 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
     A_(st.gkey, nc * cap); A_(st.key_valid, nc); A_(st.evlog, nc * (size_t)EVLOG_CAP); A_(st.n_log, nc);
     A_(st.seq_ovf, nc * (2 * G + 2 * (size_t)cfg->max_appends));
     A_(st.n_events, nc); A_(st.n_samp, nc); A_(st.n_coag, nc); A_(st.status, nc);
+    if (cfg->n_spec == 1 && cfg->n_class == 1) { // the sampler's split-off draw (2 KB per cell)
+        A_(st.pre, nc * 128); A_(st.resume, nc * 2); A_(st.work2, nc + 1);
+    }
     A_(ctx->d_totals, (size_t)4);
     A_(ctx->d_acc, (size_t)4);
     A_(ctx->d_diag, nc * (size_t)(2 + 2 * nd));
@@ -794,15 +798,23 @@ int pmcx_set_transport_lateral(pmcx_ctx *ctx, int32_t on, int32_t j_global0, int
 int pmcx_set_sampler_variant(pmcx_ctx *ctx, int32_t lanes, int32_t wavefronts_per_group, int32_t stamps)
 {
     if (!ctx) return PMCX_EINVAL;
-    if (!(lanes == 0 || lanes == 1 || lanes == 2 || lanes == 8 || lanes == 16 || lanes == 64) ||
+    if (!(lanes == 0 || lanes == 1 || lanes == 2 || lanes == 3 || lanes == 8 || lanes == 16 || lanes == 64) ||
         !(wavefronts_per_group == 0 || wavefronts_per_group == 1 || wavefronts_per_group == 2 ||
           wavefronts_per_group == 4) || (stamps != 0 && stamps != 1))
-        return fail(ctx, PMCX_EINVAL, "pmcx_set_sampler_variant: lanes in {0,1,2,8,16,64}, "
+        return fail(ctx, PMCX_EINVAL, "pmcx_set_sampler_variant: lanes in {0,1,2,3,8,16,64}, "
                                       "wavefronts_per_group in {0,1,2,4}, stamps in {0,1}");
     ctx->st.force_lanes = lanes;
     ctx->st.force_wpb = wavefronts_per_group;
     ctx->st.force_stamps = stamps;
     return PMCX_OK;
+}
+
+int pmcx_get_sampler_info(pmcx_ctx *ctx, int32_t out[4])
+{
+    if (!ctx || !out) return fail(ctx, PMCX_EINVAL, "pmcx_get_sampler_info: null argument");
+    out[0] = -1; out[1] = out[2] = out[3] = 0;
+    if (!ctx->st.work2 || !ctx->sampler_pre_ran) return PMCX_OK;
+    return copy_cells_d2h(ctx, out, ctx->st.work2, sizeof(int32_t));
 }
 
 int pmcx_invalidate_lists(pmcx_ctx *ctx)
@@ -858,6 +870,7 @@ int pmcx_mc_coag(pmcx_ctx *ctx, int32_t kernel_type, double del_t, uint64_t seed
     {
         ProfScope ps(ctx, "coag_sample");
         HIP_TRY(ctx, launch_coag_sample(ctx->st, kernel_type, del_t, seed, step, ctx->stream));
+        ctx->sampler_pre_ran = coag_sample_splits_draw(ctx->st, kernel_type);
     }
     {
         // close holes in the cells where more than 1/compact_den of the slots are tombstones

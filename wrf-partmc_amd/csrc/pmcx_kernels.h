@@ -93,6 +93,11 @@ struct DeviceState {
     int32_t *n_events, *n_samp, *n_coag, *status; // [n_cells]
     // pmcx_set_loop_cells: the cells partmc_timestep's loop nest covers (nullptr: every cell)
     const uint8_t *loop_mask;
+    // the lane-per-cell sampler with its draw split off (k_coag_lane<.., PRE>): a cell's list of the
+    // slots whose count could be non-zero, where an unfinished cell stands, the cells to finish
+    uint4 *pre;        // [n_cells][128] {uniform, bound, slot, -} (nullptr: not allocated)
+    int32_t *resume;   // [n_cells][2] slot settled last (-1: none), entries in the overflow table
+    int32_t *work2;    // [1 + n_cells] count, cells
 };
 
 struct GenSpecDev {
@@ -141,6 +146,7 @@ hipError_t launch_kernel_bounds(const DeviceState &st, int ktype, int margin, in
 hipError_t launch_bin_sort(const DeviceState &st, hipStream_t s);
 hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, uint64_t seed,
                               uint32_t step, hipStream_t s);
+bool coag_sample_splits_draw(const DeviceState &st, int ktype); // the form launch_coag_sample picks
 hipError_t seq_stamps_read(uint64_t out[12], bool reset); // diagnostic (pmcx_set_sampler_variant, stamps = 1)
 hipError_t launch_rebalance(const DeviceState &st, int allow_doubling, int allow_halving,
                             uint64_t seed, uint32_t step, hipStream_t s);

@@ -1274,13 +1274,13 @@ constexpr int SEQ_ENV = 7;     // air properties kept per cell
 
 constexpr size_t SEQ_SHARED_BYTES = 64 * (5 * sizeof(uint32_t) + sizeof(double)); // SPLIT: a lane's sweep state
 
-__host__ __device__ inline size_t seq_lds_bytes(int B, int C)
+__host__ __device__ inline size_t seq_lds_bytes(int B, int C, int W = SEQ_W)
 {
     size_t o = ((size_t)(B + 1) * sizeof(double) + 15) & ~(size_t)15; // sort-grid edges
     o += sizeof(double) * (POISSON_RCP_N + 2);                        // 1/n of the Poisson walk
     o += sizeof(double) * (SEQ_ENV + (size_t)C) * 64;                 // air properties, weights
     o += sizeof(uint64_t) * 2 * (size_t)C * 64;                       // non-empty bins
-    o += sizeof(uint32_t) * (size_t)C * SEQ_W * 64;                   // count | offset << 16
+    o += sizeof(uint32_t) * (size_t)C * W * 64;                       // count | offset << 16
     return (o + 15) & ~(size_t)15;
 }
 
@@ -1341,11 +1341,44 @@ __device__ unsigned long long g_seq_stamps[12];
 // window word) lives in LDS between passes; in a pass a lane is worked on by exactly one of the
 // two (the evaluator while it holds samples, else the drawer), one barrier per pass: per lane
 // the sequence of operations, and every result, is the single wavefront's.
-template <bool STAMPS, bool SIMPLE, int KT, bool SPLIT = false>
+// PRE (one class, one species, Brownian: the benchmark's and the reference's configuration): the
+// draw is split off the sweep.  Phase 0, every lane busy: the lane walks ALL slots of its cell in
+// sweep order, four to a Philox block as the sweep would, and keeps the few whose count could be
+// non-zero -- tested with both lists PRE_M entries longer than they are now, which bounds their
+// length for as long as no bin has taken more than PRE_M merged particles in this call (a list
+// only grows by those) -- as 16-byte entries {uniform, bound, slot} in a per-cell list in global
+// memory (three slots in four drop out; about 60 of a benchmark cell's 210 remain, 50 of them
+// with samples).  Bins that are empty now but could take a merged particle -- gaps in the
+// populated range, the two bins above it -- are walked too, as lists of at most PRE_M.  The sweep then takes its slots from that list,
+// two entries a load: no bit scan, no block to fetch, no Philox in the draw; a lane goes from one
+// possible slot straight to the next (about 95 passes instead of 150, each a third shorter).
+// The exact count of an entry is still taken with the lists as they are when the sweep reaches
+// it, so every count is the oracle's.  When the list stops describing the cell -- a bin took more
+// than PRE_M, a particle was born in a bin phase 0 did not walk, the list ran full -- the lane walks
+// the slots behind the one it stands at again, with the lists as they are then (the wavefront
+// waits for it: rare).  Only a population that reaches beyond the 32 bins of the window word is left
+// to the kernel without PRE, launched behind this one over the cells listed.
+// Measured (MI355X, profiles/r3*): passes per wavefront 152 -> 109; at the full domain, where the
+// kernel runs at the rate the chip serves random lines, nothing is gained (the list costs lines
+// of its own: 4.2 against 3.6 ms), so launch_coag_sample keeps the one-phase form there; on a
+// rank's share at N = 4 and 8, where a wavefront's own chain is the floor, 1.24 against 1.46 ms
+// (75 000 cells) and 0.77 against 0.99 (39 000).
+constexpr int PRE_CAP = 128;  // entries of a cell's list (the last one ends it)
+#ifndef PMCX_PRE_M
+#define PMCX_PRE_M 12   // arrivals a bin may take before the list stops describing the cell (<= 31)
+#endif
+constexpr uint32_t PRE_END = 0xFFFFu, PRE_MORE = 0xFFFEu; // slot ids: end of the sweep / list full, go on from .y
+
+// SW: bins of the cell's window with list state in LDS (SEQ_W; 32 -- the whole window word -- in the
+// form with the draw split off, which runs where LDS does not limit the wavefronts a SIMD holds)
+template <bool STAMPS, bool SIMPLE, int KT, bool SPLIT = false, bool PRE = false, int SW = PRE ? 32 : SEQ_W>
 __global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 2 : PMCX_LANE_WAVES)
 void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint32_t step,
-                uint16_t *ovf_mem)
+                uint16_t *ovf_mem, const int32_t *resume_list, int32_t *resume_count)
 {
+    static_assert(!PRE || (SIMPLE && !SPLIT && KT == KERNEL_BROWN), "PRE: one class, one species, Brownian");
+    // the second launch: only the cells the first one listed (nothing listed: nothing to do)
+    if (!PRE && resume_list && (int)blockIdx.x * 64 >= *resume_count) return;
     uint64_t t_last = 0, t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (STAMPS) t_last = __builtin_amdgcn_s_memtime();
 #define STAMP(k)                                                                                  \
@@ -1358,7 +1391,9 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
     const int lane = threadIdx.x & 63;
     const bool role_e = !SPLIT || (threadIdx.x >> 6) == 0; // evaluates and coagulates
     const bool role_d = !SPLIT || (threadIdx.x >> 6) == 1; // settles the slots
-    const int cidx = blockIdx.x * 64 + lane;
+    const bool resuming = !PRE && resume_list != nullptr;
+    int cidx = blockIdx.x * 64 + lane;
+    if (resuming) cidx = cidx < *resume_count ? resume_list[cidx] : st.n_cells;
     const bool live = cidx < st.n_cells && in_loop(st, cidx);
     const int c = live ? cidx : st.n_cells - 1;
     if (cidx < st.n_cells && !live && role_e) { st.n_samp[cidx] = 0; st.n_coag[cidx] = 0; st.n_events[cidx] = 0; }
@@ -1373,9 +1408,9 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
     double *envs = rcp + (POISSON_RCP_N + 2);
     double *magl = envs + SEQ_ENV * 64;                   // [C][64] weight magnitudes
     uint64_t *mask = (uint64_t *)(magl + (size_t)C * 64); // [C*2][64]
-    uint32_t *ent = (uint32_t *)(mask + 2 * (size_t)C * 64); // [C*SEQ_W][64]
+    uint32_t *ent = (uint32_t *)(mask + 2 * (size_t)C * 64); // [C*SW][64]
     // SPLIT: what the two wavefronts hand each other
-    uint32_t *sh_pos = ent + (size_t)C * SEQ_W * 64;  // c1 | c2 << 8 | (b1 + 1) << 16 | (b2 + 1) << 24
+    uint32_t *sh_pos = ent + (size_t)C * SW * 64;  // c1 | c2 << 8 | (b1 + 1) << 16 | (b2 + 1) << 24
     uint32_t *sh_ns = sh_pos + 64, *sh_s = sh_ns + 64, *sh_flag = sh_s + 64, *sh_wmask = sh_flag + 64;
     double *sh_kmax = (double *)(sh_wmask + 64);
 #define MASK(j) mask[(j) * 64 + lane]
@@ -1415,17 +1450,17 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
         }
         MASK(cl * 2) = m0; MASK(cl * 2 + 1) = m1;
     }
-    if (blo > B - SEQ_W) blo = (B - SEQ_W > 0) ? B - SEQ_W : 0;
+    if (blo > B - SW) blo = (B - SW > 0) ? B - SW : 0;
     for (int cl = 0; cl < C; cl++) {
-        uint32_t e[SEQ_W];
+        uint32_t e[SW];
 #pragma unroll
-        for (int k = 0; k < SEQ_W; k++) {
+        for (int k = 0; k < SW; k++) {
             const int b = min(blo + k, B - 1);
             e[k] = (uint32_t)gcnt_g[cl * B + b] | ((uint32_t)goff_g[cl * B + b] << 16);
         }
 #pragma unroll
-        for (int k = 0; k < SEQ_W; k++)
-            ent[(cl * SEQ_W + k) * 64 + lane] = (blo + k < B) ? e[k] : 0u;
+        for (int k = 0; k < SW; k++)
+            ent[(cl * SW + k) * 64 + lane] = (blo + k < B) ? e[k] : 0u;
     }
     for (int cl = 0; cl < C; cl++) magl[cl * 64 + lane] = st.mag[(int64_t)c * C + cl];
     {
@@ -1444,9 +1479,9 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
     const KernelParams kp{st.const_k, st.additive_beta};
 
     // ---- list state: packed entry = count | offset << 16 ----
-    auto in_win = [&](int b) -> bool { return (unsigned)(b - blo) < (unsigned)SEQ_W; };
+    auto in_win = [&](int b) -> bool { return (unsigned)(b - blo) < (unsigned)SW; };
     auto ent_get = [&](int cl, int b) -> uint32_t {
-        if (in_win(b)) return ent[(cl * SEQ_W + (b - blo)) * 64 + lane];
+        if (in_win(b)) return ent[(cl * SW + (b - blo)) * 64 + lane];
         const int g = cl * B + b;
         return (uint32_t)gcnt_g[g] | ((uint32_t)goff_g[g] << 16);
     };
@@ -1466,7 +1501,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
 #define MASKC(j) mask[(j) * 64 + lane_c]
     auto cnt_set = [&](int cl, int b, uint32_t e, int n) { // new length n of the group with entry e
         if (in_win(b)) {
-            ent[(cl * SEQ_W + (b - blo)) * 64 + lane_c] = (e & 0xFFFF0000u) | (uint32_t)n;
+            ent[(cl * SW + (b - blo)) * 64 + lane_c] = (e & 0xFFFF0000u) | (uint32_t)n;
         } else {
             gcnt_g[cl * B + b] = n;
             if (n > 0) wide = true;
@@ -1483,7 +1518,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
         else if (n == 1) MASKC(cl * 2 + (b >> 6)) |= 1ull << (b & 63);
     };
     auto room_end = [&](int cl, int b) -> int { // offset where the room behind the group ends
-        if (b + 1 < B && in_win(b + 1)) return (int)(ent[(cl * SEQ_W + (b + 1 - blo)) * 64 + lane] >> 16);
+        if (b + 1 < B && in_win(b + 1)) return (int)(ent[(cl * SW + (b + 1 - blo)) * 64 + lane] >> 16);
         return goff_g[cl * B + b + 1];
     };
     // entries beyond a group's room (rare): linked through the per-cell table
@@ -1532,6 +1567,14 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
     double n1 = 0, n2 = 0, nmin = 0, fmax = 0, factor = 0, k_max = 0;
     uint32_t ns_rem = 0, s = 0;
     bool done = !live;
+    if (resuming && live) {
+        // where the first launch left the cell (a slot boundary): what it counted so far, the slot
+        // it settled last, the entries it had put in the table past the groups' rooms
+        const int32_t pos = st.resume[2 * (int64_t)c];
+        n_app = st.resume[2 * (int64_t)c + 1];
+        n_ev = st.n_events[c]; tot_coag = st.n_coag[c]; tot_samp = (uint64_t)(uint32_t)st.n_samp[c];
+        if (pos >= 0) { b1 = pos & 0xFF; b2 = (pos >> 8) & 0xFF; c1 = (pos >> 16) & 0xFF; c2 = (pos >> 24) & 0xFF; }
+    }
     if (SIMPLE) {
         // bins blo .. blo + 63 of the 128-bit mask (m1 : m0), shifted down by blo
         const uint64_t m0 = MASK(0), m1 = MASK(1);
@@ -1545,7 +1588,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
         far = (w64 >> 32) != 0 || (blo < 64 && (m1 >> blo) != 0);
         if (blo > 0 && blo < 64 && (m0 & ((1ull << blo) - 1ull))) far = true;
         if (blo >= 64 && (m0 || (m1 & ((1ull << (blo - 64)) - 1ull)))) far = true;
-        wide = far || (wmask >> SEQ_W) != 0;
+        wide = far || (SW < 32 && ((uint64_t)wmask >> SW) != 0);
     }
     STAMP(0)
 
@@ -1609,6 +1652,23 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
     // fails it takes the exact count, and a lane that leaves its block fetches the next one (one
     // Philox block, four bounds) for the following pass.  Memory requests of one kind of lane
     // are issued before the arithmetic of the other kind.
+    // ---- PRE: the cell's list of the slots whose count could be non-zero (made in the loop below,
+    // ---- at the start and again whenever it stops describing the cell) ----
+    uint4 *pre = nullptr;            // the cell's list
+    uint32_t pmask0 = 0;             // the bins walked when it was made
+    uint4 ea = make_uint4(0, 0, PRE_END, 0), eb = ea; // the two entries in hand (.x uniform, .y bound, .z slot)
+    int pk = 0, pk_pair = 0;         // entries taken so far; the pair in hand starts there
+    bool pre_stop = false;           // the list no longer describes the cell
+    bool unfinished = false;
+    bool need_pre = false;           // the lane is to walk its slots (again) from where it stands
+    uint64_t arr0 = 0, arr1 = 0;     // merged particles each bin of the window has taken (5 bits a bin)
+    if (PRE) {
+        pre = st.pre + (int64_t)c * PRE_CAP;
+        if (live && far) { unfinished = true; done = true; }  // (beyond the 32 bins of the window word: the other kernel)
+        if (done) { far = false; wide = false; }   // (these pick the wavefront's paths: finished lanes do not vote)
+        need_pre = !done;
+    }
+
     if (SPLIT) { // (both wavefronts write the same values)
         sh_pos[lane] = 0; sh_ns[lane] = 0; sh_s[lane] = 0; sh_kmax[lane] = 0.0;
         sh_flag[lane] = (done ? 1u : 0u) | (far ? 2u : 0u) | (wide ? 4u : 0u);
@@ -1636,6 +1696,74 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
         }
         if (__ballot(!done) == 0) break;
         if (STAMPS) t_acc[10]++;
+        // ---- PRE, phase 0: the lane walks the slots behind (b1, b2) in sweep order, four to a Philox
+        // ---- block, and lists those whose count could be non-zero while no bin takes more than
+        // ---- PRE_M arrivals.  All lanes at the start; later a lane whose list stopped holding.
+        if (PRE && __ballot(need_pre) != 0) {
+            if (need_pre) {
+                // the bins walked: the populated ones, the gaps between them, two above the last
+                // (the window's last bin cannot take an arrival on the fast path)
+                {
+                    const int top = 31 - __builtin_clz(wmask | 1u), lo = __builtin_ctz(wmask | 0x80000000u);
+                    int hi = top + 2;
+                    if (hi > SW - 2) hi = SW - 2;
+                    if (hi < top) hi = top;
+                    pmask0 = wmask | ((hi >= 31 ? ~0u : ((1u << (hi + 1)) - 1u)) & (~0u << lo));
+                    if (blo + 32 > B) pmask0 &= (B - blo >= 32) ? ~0u : ((1u << (B - blo)) - 1u);
+                }
+                const float *kmx = st.kmax + (int64_t)c * st.kmax_stride;
+                int npre = 0;
+                int32_t prev = b1 < 0 ? -1 : (b1 | (b2 << 8));   // the slot tested last
+                bool full = false;
+                const int r1s = b1 < 0 ? -1 : b1 - blo, r2s = b2 - blo;   // (walk what lies behind this slot)
+                uint32_t rows = r1s < 0 ? pmask0 : (pmask0 & (~0u << r1s));
+                while (rows && !full) {
+                    const int r1 = __builtin_ctz(rows);
+                    rows &= rows - 1;
+                    const int pb1 = blo + r1;
+                    const double nA_up = (double)((ent_get(0, pb1) & 0xFFFFu) + (uint32_t)PMCX_PRE_M);
+                    uint32_t pm = pmask0 & (~0u << r1);
+                    if (r1 == r1s) pm = r2s >= 31 ? 0u : (pm & (~0u << (r2s + 1)));
+                    while (pm && !full) {
+                        const int q4 = (blo + __builtin_ctz(pm)) & ~3;        // the block's first bin
+                        uint32_t w[4];
+                        rng_block(seed, cell_id, step, ((uint32_t)pb1 << 16) | (uint32_t)q4, SITE_POISSON, 0, w);
+                        const float4 kf4 = *(const float4 *)(kmx + pb1 * B + q4);
+                        const float kfa[4] = {kf4.x, kf4.y, kf4.z, kf4.w};
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int pb2 = q4 + k, r2 = pb2 - blo;
+                            if (r2 >= r1 && r2 < 32 && ((pm >> r2) & 1u) && !full) {
+                                const double nB_up = (double)((ent_get(0, pb2) & 0xFFFFu) + (uint32_t)PMCX_PRE_M);
+                                const double np_up = (pb2 == pb1) ? nA_up * (nA_up - 1.0) / 2.0 : nA_up * nB_up;
+                                const double mean_up = ((double)kfa[k] * fmax) * del_t * np_up; // (the sweep's expression)
+                                const double u_ = (double)w[k] * 0x1.0p-32;
+                                if (!(u_ < (1.0 - mean_up) - 4e-15)) {
+                                    if (npre < PRE_CAP - 1) {
+                                        pre[npre++] = make_uint4(w[k], __float_as_uint(kfa[k]),
+                                                                 (uint32_t)pb1 | ((uint32_t)pb2 << 8), 0u);
+                                    } else {
+                                        full = true;   // (go on from the slot tested before this one)
+                                    }
+                                }
+                                if (!full) prev = pb1 | (pb2 << 8);
+                            }
+                        }
+                        const int end = q4 + 4 - blo;                          // bins below it are done
+                        pm = end >= 32 ? 0u : (pm & (~0u << end));
+                    }
+                }
+                pre[npre] = full ? make_uint4(0u, (uint32_t)prev, PRE_MORE, 0u) : make_uint4(0u, 0u, PRE_END, 0u);
+            }
+            // (a lane reads what it wrote itself: its stores are ordered before its loads)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (need_pre) {
+                ea = pre[0]; eb = pre[1];
+                pk = 0; pk_pair = 0; arr0 = 0; arr1 = 0;
+                pre_stop = false; need_pre = false;
+            }
+            STAMP(6)   // (phase 0 in the stage-6 slot of the diagnostic build)
+        }
         // (uniform: they pick the scan and the list-length reads for the whole wavefront)
         const bool any_far = !SIMPLE || __ballot(far) != 0;
         const bool any_wide = any_far || __ballot(wide) != 0;
@@ -1648,6 +1776,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
         // benchmark's cells instead of 200 (measured on one box, 3*10^5 cells: 4.19-4.24 ms
         // against 4.50 with PICK in front of DRAW; 1.41 against 1.70 at 75 000 cells).
         bool evalid = false, acc = false;
+        int ev_bnew = -1;                       // PRE: the bin an event's merged particle moved into
         int i1 = 0, i2 = 0;
         uint32_t p1 = 0, p2 = 0, s_ev = 0, eA = 0, eB = 0;
         uint32_t last1 = 0, last2 = 0;          // entries at the ends of the two lists
@@ -1680,6 +1809,48 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
         ZERO = u_ < (1.0 - mean_) - 4e-15;                                                        \
         if (!ZERO) { pending = true; p_mean = mean_; p_u = u_; }                                  \
     }
+        if (PRE) {
+            // the next slots from the cell's list: two entries in hand, two tries a pass
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                if (__ballot(dr) == 0) break;
+                if (pk >= pk_pair + 2) dr = false;   // (both entries in hand are used: the next pair is on its way)
+                if (dr) {
+                    if (pre_stop) {            // the list no longer describes the cell
+                        if (far) { unfinished = true; done = true; far = false; wide = false; }  // (the other kernel goes on)
+                        else need_pre = true;  // it is made again from here, at the top of the next pass
+                    } else {
+                        const uint4 e = (pk & 1) ? eb : ea;
+                        if (e.z == PRE_END) {
+                            done = true;
+                        } else if (e.z == PRE_MORE) {  // the list ran full: made again from the slot it reached
+                            const int32_t pv = (int32_t)e.y;
+                            if (pv >= 0) { b1 = pv & 0xFF; b2 = (pv >> 8) & 0xFF; } else { b1 = -1; b2 = -1; }
+                            need_pre = true;
+                        } else {
+                            b1 = (int)(e.z & 0xFFu); b2 = (int)((e.z >> 8) & 0xFFu);
+                            uint32_t dA, dB;
+                            if (!any_wide) { dA = ent[(b1 - blo) * 64 + lane]; dB = ent[(b2 - blo) * 64 + lane]; }
+                            else { dA = ent_get(0, b1); dB = ent_get(0, b2); }
+                            const double nA_ = (double)(dA & 0xFFFFu), nB_ = (double)(dB & 0xFFFFu);
+                            k_max = (double)__uint_as_float(e.y) * fmax;
+                            const double n_possible_ = (b1 == b2) ? nA_ * (nA_ - 1.0) / 2.0 : nA_ * nB_;
+                            const double mean_ = k_max * del_t * n_possible_;
+                            const double u_ = (double)e.x * 0x1.0p-32;
+                            // (a list that ran out gives n_possible <= 0: no sample, as the sweep has it)
+                            if (!(u_ < (1.0 - mean_) - 4e-15)) { pending = true; p_mean = mean_; p_u = u_; }
+                            pk++;
+                        }
+                    }
+                }
+                dr = dr && !done && !pending && !need_pre;
+            }
+            // both entries used: the next two (they arrive while the wavefront evaluates)
+            if (!done && !need_pre && pk >= pk_pair + 2) {
+                ea = pre[pk]; eb = pre[pk + 1];
+                pk_pair = pk;
+            }
+        } else
         for (int r = 0; r < NROUND; r++) {
             if (__ballot(dr) == 0) break;
             uint32_t want = TAG_NONE;    // the block of the next slot, when it is not the cached one
@@ -1921,7 +2092,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                 const bool in_grid = !(vn < edge[0] || vn >= edge[B]);
                 // (the new bin and the one behind it inside the window: their entries are in LDS)
                 bool ok = n_ev < st.max_events && in_grid &&
-                          (!move || ((unsigned)(b_new - blo) < (unsigned)(SEQ_W - 1) && b_new + 1 < B));
+                          (!move || ((unsigned)(b_new - blo) < (unsigned)(SW - 1) && b_new + 1 < B));
                 uint32_t en = 0;
                 if (ok && move) {
                     en = ent[(b_new - blo) * 64 + lane];
@@ -1971,6 +2142,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                     hot[po].vtot = -1.0; // tombstone: in the record just read
                     n_dead++;
                     tot_coag++;
+                    if (PRE && move) ev_bnew = b_new;
                 }
             }
         }
@@ -2048,6 +2220,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                     }
                     cnt_set(cc, b_new, en, n + 1);
                     PMCX_LOG(pn, g_new)
+                    if (PRE) ev_bnew = b_new;
                 }
                 if (rem_o) PMCX_LOG(po, 0xFFFFu)
                 *(double2 *)&hot[pn].vtot = make_double2(vn, mn);
@@ -2082,6 +2255,25 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                 tot_coag++;
             } while (false);
         }
+        // PRE: the list holds while the lists it was made for bound the present ones -- no bin has
+        // taken more than PRE_M merged particles, none was born in a bin phase 0 did not walk
+        if (PRE && acc) {
+            bool bad = far;
+            if (ev_bnew >= 0) {
+                const int r = ev_bnew - blo;
+                if (!((unsigned)r < 32u && ((pmask0 >> r) & 1u))) {
+                    bad = true;                       // born in a bin phase 0 did not walk
+                } else {
+                    // (bins 24 .. 31 of a population wider than the LDS window share a counter)
+                    const int rr = r < 24 ? r : 23;
+                    const int sh = (rr < 12 ? rr : rr - 12) * 5;
+                    const uint64_t a = (rr < 12 ? arr0 : arr1) + (1ull << sh);
+                    if (rr < 12) arr0 = a; else arr1 = a;
+                    if (((a >> sh) & 31u) > (uint64_t)PMCX_PRE_M) bad = true;   // its list outgrew the bound
+                }
+            }
+            if (bad) pre_stop = true;
+        }
         if (done) ns_rem = 0;
         if (SPLIT) {
             if (own) {
@@ -2101,8 +2293,8 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
     if (live && !role_e && status) atomicOr(&st.status[c], status);
     if (live && role_e) {
         for (int cl = 0; cl < C; cl++)
-            for (int k = 0; k < SEQ_W && blo + k < B; k++)
-                gcnt_g[cl * B + blo + k] = (int32_t)(ent[(cl * SEQ_W + k) * 64 + lane] & 0xFFFFu);
+            for (int k = 0; k < SW && blo + k < B; k++)
+                gcnt_g[cl * B + blo + k] = (int32_t)(ent[(cl * SW + k) * 64 + lane] & 0xFFFFu);
         if (n_app) {
             bool ovf = false;
             for (int g = 0; g < G; g++) ovf |= O_ovf_n(g) != 0;
@@ -2110,6 +2302,11 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
         }
         if (n_lg >= 0) st.n_log[c] = n_lg;
         else if (n_lg == -2) st.key_valid[c] = 0;
+        if (PRE && unfinished) { // where the cell stands, for the launch behind this one
+            st.resume[2 * (int64_t)c] = b1 < 0 ? -1 : (b1 | (b2 << 8));
+            st.resume[2 * (int64_t)c + 1] = n_app;
+            resume_count[1 + atomicAdd(resume_count, 1)] = c;
+        }
         st.n_events[c] = n_ev;
         st.n_part[c] = st.n_part[c] - n_dead;
         st.n_coag[c] = tot_coag;
@@ -4392,20 +4589,34 @@ size_t sampler_lds_bytes_per_cell(const DeviceState &st)
 {
     return sampler_lds_for(st, 64); // upper bound over the lane variants
 }
-// lanes per cell of the sampler: 16 (four cells per wavefront) while a cell's
-// list state is small, 64 otherwise.  pmcx_set_sampler_variant overrides (tests hold every
-// variant to the oracle at small sizes).
-int sampler_lanes(const DeviceState &st)
+// The sampler's form.  1: one lane per cell with the draw split off the sweep (k_coag_lane<.., PRE>;
+// one class, one species, Brownian); 3: one lane per cell, drawing as it sweeps; 2: that in its
+// two-wavefront form; 8, 16, 64: lanes per cell (k_coag_sample).  pmcx_set_sampler_variant overrides
+// (tests hold every form to the oracle at small sizes).
+static bool pre_available(const DeviceState &st, int ktype)
+{
+    return st.n_spec == 1 && st.n_class == 1 && ktype == KERNEL_BROWN && (st.n_bin & 3) == 0 && st.pre != nullptr &&
+           seq_lds_bytes(st.n_bin, st.n_class, 32) <= 64 * 1024;
+}
+int sampler_lanes(const DeviceState &st, int ktype)
 {
     const int fl = st.force_lanes;
     const bool seq_fits = seq_lds_bytes(st.n_bin, st.n_class) + SEQ_SHARED_BYTES <= 64 * 1024;
-    if ((fl == 1 || fl == 2) && seq_fits) return fl;
+    if (fl == 1) return pre_available(st, ktype) ? 1 : (seq_fits ? 3 : 64);
+    if ((fl == 2 || fl == 3) && seq_fits) return fl;
     if (fl == 8 || fl == 16 || fl == 64) return fl;
+    // One lane per cell with the draw split off wherever a wavefront's own chain is the floor --
+    // measured (profiles/r3b_sampler_forms.txt, ms per launch against the best other form): 3 000
+    // cells 0.65 / 0.73, 12 000 0.69 / 0.85, 39 000 0.82 / 0.98, 75 000 1.20 / 1.40, 120 000 1.69 /
+    // 1.91, 150 000 2.14 / 2.17-2.31; at the full domain the kernel runs at the rate the chip serves
+    // random lines, the list costs lines of its own and the one-phase form wins (300 000: 4.1-4.2
+    // against 3.6-3.95 depending on the box).
+    if (pre_available(st, ktype) && (long)st.n_cells >= 600L && (long)st.n_cells <= 200000L) return 1;
     // one lane per cell once the cells alone fill the chip (256 CUs x 4 SIMDs x 64 lanes); while
     // its wavefronts would still find a SIMD each even twice as many, the two-wavefront form
     // (measured, scripts/gpu_split.sh: 1.29 against 1.83 ms at 39 000 cells, 1.57 against 2.12 at
     // 63 000; at 75 000 a third wavefront lands on some SIMDs and it loses, 2.55 against 2.18)
-    if (seq_fits && (long)st.n_cells > 256L * 4L * 64L) return 1;
+    if (seq_fits && (long)st.n_cells > 256L * 4L * 64L) return 3;
     if (seq_fits && (long)st.n_cells >= 24000L) return 2;
     if (sampler_lds_for(st, 16) > 4 * 1024) return 64;
     // 8 lanes per cell (8 cells per wavefront) is the throughput optimum; with few
@@ -4556,27 +4767,31 @@ hipError_t launch_bin_sort(const DeviceState &st, hipStream_t s)
                        (const int32_t *)st.work_list);
     return hipGetLastError();
 }
+bool coag_sample_splits_draw(const DeviceState &st, int ktype)
+{
+    return sampler_lanes(st, ktype) == 1;
+}
 hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, uint64_t seed,
                               uint32_t step, hipStream_t s)
 {
     const size_t shared = (sizeof(double) * (size_t)(st.n_bin + 1) + 15) & ~(size_t)15;
-    const int L = sampler_lanes(st);
+    const int L = sampler_lanes(st, ktype);
     if (L == 2) { // lane per cell, two wavefronts (evaluator, drawer) per 64 cells
         const dim3 grid((st.n_cells + 63) / 64), block(128);
         const size_t lds = seq_lds_bytes(st.n_bin, st.n_class) + SEQ_SHARED_BYTES;
         const bool simple = st.n_spec == 1 && st.n_class == 1;
         if (simple && ktype == KERNEL_BROWN)
             hipLaunchKernelGGL((k_coag_lane<false, true, KERNEL_BROWN, true>), grid, block, lds, s, st,
-                               ktype, del_t, seed, step, st.seq_ovf);
+                               ktype, del_t, seed, step, st.seq_ovf, (const int32_t *)nullptr, (int32_t *)nullptr);
         else if (ktype == KERNEL_BROWN)
             hipLaunchKernelGGL((k_coag_lane<false, false, KERNEL_BROWN, true>), grid, block, lds, s, st,
-                               ktype, del_t, seed, step, st.seq_ovf);
+                               ktype, del_t, seed, step, st.seq_ovf, (const int32_t *)nullptr, (int32_t *)nullptr);
         else
             hipLaunchKernelGGL((k_coag_lane<false, false, 0, true>), grid, block, lds, s, st, ktype,
-                               del_t, seed, step, st.seq_ovf);
+                               del_t, seed, step, st.seq_ovf, (const int32_t *)nullptr, (int32_t *)nullptr);
         return hipGetLastError();
     }
-    if (L == 1) {
+    if (L == 1 || L == 3) {
         const bool stamps = st.force_stamps == 1;
         const dim3 grid((st.n_cells + 63) / 64), block(64);
         size_t lds = seq_lds_bytes(st.n_bin, st.n_class);
@@ -4584,9 +4799,27 @@ hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, ui
         if ((st.force_wpb == 1 || st.force_wpb == 2) && lds < (size_t)160 * 1024 / (4 * st.force_wpb) - 1024)
             lds = (size_t)160 * 1024 / (4 * st.force_wpb) - 1024;
         const bool simple = st.n_spec == 1 && st.n_class == 1;
+        const int32_t *no_list = nullptr;
+        int32_t *no_count = nullptr;
 #define PMCX_LAUNCH_LANE(STAMPS_, SIMPLE_, KT_)                                                     \
     hipLaunchKernelGGL((k_coag_lane<STAMPS_, SIMPLE_, KT_>), grid, block, lds, s, st, ktype, del_t, seed, step, \
-                       st.seq_ovf)
+                       st.seq_ovf, no_list, no_count)
+        // The draw split off the sweep (PRE) for the reference's configuration: one class, one
+        // species, Brownian; the cells it does not finish are listed and finished by the kernel
+        // without PRE right behind it (its blocks beyond the list return at once).
+        if (coag_sample_splits_draw(st, ktype)) {
+            (void)hipMemsetAsync(st.work2, 0, sizeof(int32_t), s);
+            const size_t lds32 = lds + (seq_lds_bytes(st.n_bin, st.n_class, 32) - seq_lds_bytes(st.n_bin, st.n_class));
+            if (stamps)
+                hipLaunchKernelGGL((k_coag_lane<true, true, KERNEL_BROWN, false, true>), grid, block, lds32, s, st,
+                                   ktype, del_t, seed, step, st.seq_ovf, no_list, st.work2);
+            else
+                hipLaunchKernelGGL((k_coag_lane<false, true, KERNEL_BROWN, false, true>), grid, block, lds32, s, st,
+                                   ktype, del_t, seed, step, st.seq_ovf, no_list, st.work2);
+            hipLaunchKernelGGL((k_coag_lane<false, true, KERNEL_BROWN>), grid, block, lds, s, st, ktype, del_t,
+                               seed, step, st.seq_ovf, (const int32_t *)(st.work2 + 1), st.work2);
+            return hipGetLastError();
+        }
         if (stamps && simple && ktype == KERNEL_BROWN) PMCX_LAUNCH_LANE(true, true, KERNEL_BROWN);
         else if (stamps) PMCX_LAUNCH_LANE(true, false, 0);
         else if (simple && ktype == KERNEL_BROWN) PMCX_LAUNCH_LANE(false, true, KERNEL_BROWN);

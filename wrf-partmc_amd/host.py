@@ -43,7 +43,7 @@ EXPORTED_SYMBOLS = [
     "pmcx_transport_probs", "pmcx_set_sampler_variant", "pmcx_transport_preweight",
     "pmcx_set_transport_lateral", "pmcx_boundary_copy", "pmcx_boundary_resample",
     "pmcx_transport_preweight_begin", "pmcx_transport_preweight_finish",
-    "pmcx_step_flags_default", "pmcx_set_loop_cells", "pmcx_max_cap", "pmcx_set_aero_scenario_modes",
+    "pmcx_get_sampler_info", "pmcx_step_flags_default", "pmcx_set_loop_cells", "pmcx_max_cap", "pmcx_set_aero_scenario_modes",
 ]
 
 
@@ -1022,6 +1022,13 @@ class CellBlock:
     def set_sampler_variant(self, lanes=0, wavefronts_per_group=0, stamps=0):
         """Diagnostic: pin the pair sampler's launch shape (include/pmcx.h); 0 = automatic."""
         self._ck(self._lib.pmcx_set_sampler_variant(self._h, lanes, wavefronts_per_group, stamps))
+
+    def sampler_info(self):
+        """Cells the split-off draw of the lane-per-cell sampler left to its second launch in the
+        last mc_coag (-1: that form did not run)."""
+        out = (C.c_int32 * 4)()
+        self._ck(self._lib.pmcx_get_sampler_info(self._h, out))
+        return int(out[0])
 
     def invalidate_lists(self):
         """The lists of every cell are to be rebuilt, from sort keys that still hold."""
