@@ -94,6 +94,11 @@ typedef struct {
                              full-population passes to skip                      */
     double const_k;       /* constant-kernel value, m^3/s                     */
     double additive_beta; /* additive-kernel coefficient, 1/s                 */
+    int32_t n_comp_max;   /* particle%component(:) (driver:1421-1437): entries of a particle's
+                             list carried on the device, 0..8 (0, the default: only the source
+                             histogram n_orig and the least/greatest create times); needs
+                             1 <= n_source <= 255; 8 (1 + n_comp_max) bytes per slot  */
+    int32_t pad_;
 } pmcx_config;
 
 /* Fills cfg with the reference's defaults (registry.partmc:1-38, driver:783). */
@@ -154,6 +159,30 @@ int pmcx_download_cells(pmcx_ctx *ctx, int32_t cell_first, int32_t n_dn,
                         const int64_t *part_offset, double *vol, int32_t *wclass,
                         int64_t *id, double *least_ct, double *greatest_ct,
                         int32_t *n_orig);
+
+/*
+ * particle%component(:)%source_id / %create_time (wrf_pmc_driver.F90:1421-1437) of the cells
+ * pmcx_upload_cells has just laid out (same part_offset; call it right behind that upload), for
+ * a context created with n_comp_max > 0:
+ *   comp_len    [n_total]              entries given for the particle (those beyond n_comp_max
+ *                                      are not carried)
+ *   comp_source [n_total][n_comp_max]  source_id - 1
+ *   comp_time   [n_total][n_comp_max]  create_time
+ * Without this call an uploaded particle's list is rebuilt from its histogram: n_orig(s) entries
+ * per source in source order, the first created at least_ct, the others at greatest_ct (exact for
+ * a particle of one constituent).  From then on the lists follow the particles through every
+ * entry point: a new particle has one entry (its mode's source, the create time of the call), a
+ * copy its original's list, and a coagulated particle the list of its first candidate followed by
+ * that of its second [aero_particle_coagulate: upstream, uncited], cut at n_comp_max -- the
+ * untruncated length stays available as sum_s n_orig(s).  The download returns, per particle, the
+ * entries held (comp_len <= n_comp_max), -1 / 0 past the end.
+ */
+int pmcx_upload_components(pmcx_ctx *ctx, int32_t cell_first, int32_t n_up,
+                           const int64_t *part_offset, const int32_t *comp_len,
+                           const int32_t *comp_source, const double *comp_time);
+int pmcx_download_components(pmcx_ctx *ctx, int32_t cell_first, int32_t n_dn,
+                             const int64_t *part_offset, int32_t *comp_len,
+                             int32_t *comp_source, double *comp_time);
 
 /* est_k_minmax_binned_unweighted: (re)compute every cell's kernel upper
  * bounds for kernel_type from the current env (PartMC caches this per

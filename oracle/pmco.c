@@ -48,6 +48,49 @@ double pmco_dep_velocity_(double diameter, double density, double temp, double r
  * (1.257/0.42/1.1 there; 1.249/0.42/0.87 here, Jacobson's values).
  * ---------------------------------------------------------------------- */
 
+
+/* ---- particle%component(:) (see pmco_cell) ---- */
+static void comp_copy(pmco_cell *d, int at, const pmco_cell *s, int from)
+{
+    if (!d->n_comp_max) return;
+    const int K = d->n_comp_max;
+    d->comp_n[at] = s->comp_n[from];
+    for (int k = 0; k < K; k++) {
+        d->comp_src[(size_t)at * K + k] = s->comp_src[(size_t)from * K + k];
+        d->comp_time[(size_t)at * K + k] = s->comp_time[(size_t)from * K + k];
+    }
+}
+
+static void comp_single(pmco_cell *c, int i, int source, double t)
+{
+    if (!c->n_comp_max) return;
+    const int K = c->n_comp_max;
+    c->comp_n[i] = 1;
+    for (int k = 0; k < K; k++) { c->comp_src[(size_t)i * K + k] = -1; c->comp_time[(size_t)i * K + k] = 0.0; }
+    c->comp_src[(size_t)i * K] = source;
+    c->comp_time[(size_t)i * K] = t;
+}
+
+/* list(first) ++ list(second), cut at n_comp_max, becomes the list of slot pn (one of the two) */
+static void comp_merge(pmco_cell *c, int pn, int first, int second)
+{
+    if (!c->n_comp_max) return;
+    const int K = c->n_comp_max;
+    int32_t src[64]; double tm[64];
+    int n = 0;
+    for (int k = 0; k < c->comp_n[first] && n < K; k++, n++) {
+        src[n] = c->comp_src[(size_t)first * K + k]; tm[n] = c->comp_time[(size_t)first * K + k];
+    }
+    for (int k = 0; k < c->comp_n[second] && n < K; k++, n++) {
+        src[n] = c->comp_src[(size_t)second * K + k]; tm[n] = c->comp_time[(size_t)second * K + k];
+    }
+    c->comp_n[pn] = n;
+    for (int k = 0; k < K; k++) {
+        c->comp_src[(size_t)pn * K + k] = k < n ? src[k] : -1;
+        c->comp_time[(size_t)pn * K + k] = k < n ? tm[k] : 0.0;
+    }
+}
+
 typedef struct {
     double kT;          /* k_B T                              */
     double viscosd;     /* dynamic viscosity of air, kg/m/s   */
@@ -309,7 +352,7 @@ static void il_push(ilist *l, int32_t x)
     l->e[l->n++] = x;
 }
 
-typedef struct { int32_t pn, po, rem_o, cc; } coag_event;
+typedef struct { int32_t pn, po, rem_o, cc, pn_is_1; } coag_event;
 
 static void compact_stable(pmco_cell *c, const unsigned char *dead, int n_old,
                               int n_dead);
@@ -469,6 +512,7 @@ int pmco_mc_coag(pmco_cell *c, int kernel_type, const pmco_kernel_params *kp,
                 status |= PMCO_ST_APPEND_OVERFLOW; stop = 1; break;
             }
             ev[n_ev].pn = pn; ev[n_ev].po = po; ev[n_ev].rem_o = rem_o; ev[n_ev].cc = cc;
+            ev[n_ev].pn_is_1 = pn_is_1;
             n_ev++;
             if (rem_o) {                       /* swap-with-last removal */
                 const int last = Lo->n - 1;
@@ -497,6 +541,7 @@ int pmco_mc_coag(pmco_cell *c, int kernel_type, const pmco_kernel_params *kp,
         if (c->lct[po] < c->lct[pn]) c->lct[pn] = c->lct[po];
         if (c->gct[po] > c->gct[pn]) c->gct[pn] = c->gct[po];
         c->wclass[pn] = ev[e].cc;
+        if (ev[e].pn_is_1) comp_merge(c, pn, pn, po); else comp_merge(c, pn, po, pn);
         if (ev[e].rem_o) { dead[po] = 1; n_dead++; }
     }
     /* vtot/mass of merged particles stay the sums of their parents' caches
@@ -542,6 +587,7 @@ static void move_particle(pmco_cell *c, int dst, int src)
     c->id[dst] = c->id[src];
     c->lct[dst] = c->lct[src];
     c->gct[dst] = c->gct[src];
+    comp_copy(c, dst, c, src);
 }
 
 /* Close the holes left by removed particles, keeping the survivors' relative
@@ -674,6 +720,7 @@ void pmco_generate(pmco_cell *c, const pmco_gen_spec *g, int32_t n, uint64_t see
         c->id[i] = first_id + i;
         c->lct[i] = create_time;
         c->gct[i] = create_time;
+        comp_single(c, i, g->mode_source[mode], create_time);
         refresh_one(c, i);
     }
     *c->n_part = n;
@@ -839,6 +886,7 @@ static int add_dist_sample_means(pmco_cell *c, const pmco_aero_dist *d, double f
             c->id[i] = *next_id + k;
             c->lct[i] = create_time;
             c->gct[i] = create_time;
+            comp_single(c, i, d->mode_source[m], create_time);
             refresh_one(c, i);
         }
         *next_id += n;
@@ -1252,6 +1300,7 @@ int pmco_transport(pmco_cell *cells, int n_cells, int nx, int nz, int ny, int pe
                     dst->vtot[at] = s->vtot[from]; dst->mass[at] = s->mass[from];
                     dst->wclass[at] = s->wclass[from];
                     dst->lct[at] = s->lct[from]; dst->gct[at] = s->gct[from];
+                    comp_copy(dst, at, s, from);
                     if (g == box[sc][e].copies - 1) dst->id[at] = s->id[from];
                     else { dst->id[at] = next_id[c]; next_id[c]++; }
                     *dst->n_part = at + 1;
@@ -1605,6 +1654,7 @@ void pmco_boundary_copy(pmco_cell *dst, const pmco_cell *src, int64_t *next_id_d
         dst->vtot[i] = src->vtot[i]; dst->mass[i] = src->mass[i];
         dst->wclass[i] = src->wclass[i];
         dst->lct[i] = src->lct[i]; dst->gct[i] = src->gct[i];
+        comp_copy(dst, i, src, i);
         dst->id[i] = *next_id_dst + i;
     }
     *next_id_dst += n;

@@ -86,6 +86,14 @@ typedef struct {
     int32_t *perm;         /* [pcap] slot lists, group after group           */
     int32_t *gcnt;         /* [n_class*n_bin] list lengths                   */
     int32_t *goff;         /* [n_class*n_bin + 1] list starts in perm        */
+    /* particle%component(:) (wrf_pmc_driver.F90:1421-1437: source_id, create_time per
+     * constituent), the first n_comp_max of the list; 0 / NULL: not carried.  A coagulated
+     * particle's list is its first candidate's followed by its second's
+     * [aero_particle_coagulate, upstream, uncited]; sum_s n_orig is the untruncated length. */
+    int32_t n_comp_max;
+    int32_t *comp_n;       /* [cap] entries held (<= n_comp_max)             */
+    int32_t *comp_src;     /* [cap][n_comp_max] source_id (0-based), -1 past the end */
+    double *comp_time;     /* [cap][n_comp_max] create_time, 0 past the end  */
 } pmco_cell;
 
 void pmco_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

@@ -36,6 +36,7 @@ class CellStruct(C.Structure):
         ("mag", _dp), ("n_part", _ip), ("vol", _dp), ("vtot", _dp), ("mass", _dp),
         ("wclass", _ip), ("id", _lp), ("lct", _dp), ("gct", _dp), ("n_orig", _ip),
         ("pcap", C.c_int32), ("sort_valid", _ip), ("perm", _ip), ("gcnt", _ip), ("goff", _ip),
+        ("n_comp_max", C.c_int32), ("comp_n", _ip), ("comp_src", _ip), ("comp_time", _dp),
     ]
 
 
@@ -152,8 +153,13 @@ class Cell:
     """One cell's state as numpy arrays + the C view over them."""
 
     def __init__(self, n_spec, n_class, n_source, cap, density, v_edge, temp=288.15,
-                 pressure=101325.0, max_events=1 << 20, max_appends=1 << 20):
+                 pressure=101325.0, max_events=1 << 20, max_appends=1 << 20, n_comp_max=0):
         self.n_spec, self.n_class, self.n_source, self.cap = n_spec, n_class, n_source, cap
+        # particle%component(:): the first n_comp_max (source, create_time) pairs of each particle
+        self.n_comp_max = n_comp_max
+        self.comp_n = np.zeros(cap, dtype=np.int32)
+        self.comp_src = np.full((cap, max(n_comp_max, 1)), -1, dtype=np.int32)
+        self.comp_time = np.zeros((cap, max(n_comp_max, 1)))
         self.density = np.ascontiguousarray(density, dtype=np.float64)
         self.v_edge = np.ascontiguousarray(v_edge, dtype=np.float64)
         self.n_bin = len(self.v_edge) - 1
@@ -193,6 +199,9 @@ class Cell:
         s.lct = _p(self.lct, _dp); s.gct = _p(self.gct, _dp); s.n_orig = _p(self.n_orig, _ip)
         s.pcap = self.pcap; s.sort_valid = _p(self.sort_valid, _ip)
         s.perm = _p(self.perm, _ip); s.gcnt = _p(self.gcnt, _ip); s.goff = _p(self.goff, _ip)
+        s.n_comp_max = self.n_comp_max
+        s.comp_n = _p(self.comp_n, _ip); s.comp_src = _p(self.comp_src, _ip)
+        s.comp_time = _p(self.comp_time, _dp)
         return s
 
     def refresh_caches(self):

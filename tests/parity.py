@@ -30,12 +30,31 @@ def make_modes(n_spec, n_class, coarse=False):
     return modes, sum(b[0] for b in base)
 
 
+# particle%component(:) entries carried by the blocks setup_pair builds (tests/test_gpu_components.py
+# runs the parity tests again with it set): every comparison then covers the lists as well
+N_COMP_MAX = 0
+
+
+def upload_components(blk, cells, po):
+    """The oracle cells' component lists to the block (after upload_cells with the same offsets)."""
+    K, nt = blk.cfg.n_comp_max, int(po[-1])
+    ln = np.zeros(nt, np.int32); sr = np.full((nt, K), -1, np.int32); tm = np.zeros((nt, K))
+    for c, oc in enumerate(cells):
+        s = slice(po[c], po[c + 1])
+        n = po[c + 1] - po[c]
+        ln[s] = oc.comp_n[:n]; sr[s] = oc.comp_src[:n]; tm[s] = oc.comp_time[:n]
+    blk.upload_components(0, po, ln, sr, tm)
+
+
 def setup_pair(wp, oracle, n_cells, n_part, n_spec, n_class, seed, kernel, cap=None,
                n_source=3, coarse=False, cell_id_base=0, max_events=None, max_appends=None,
                num_conc_scale=1.0, device=0, explicit_bounds=True, modes=None, num_conc=None, **cfg_over):
     """Build a CellBlock and matching oracle cells with identical contents."""
     cap = cap or int(np.ceil(n_part * 1.0 / 64) * 64)
     over = dict(cfg_over)
+    if N_COMP_MAX and n_source > 0:
+        over.setdefault("n_comp_max", N_COMP_MAX)
+    kc = over.get("n_comp_max", 0)
     if max_events is not None:
         over["max_events"] = max_events
     if max_appends is not None:
@@ -67,10 +86,12 @@ def setup_pair(wp, oracle, n_cells, n_part, n_spec, n_class, seed, kernel, cap=N
     po = np.zeros(n_cells + 1, dtype=np.int64)
     for c in range(n_cells):
         oc = oracle.Cell(n_spec, n_class, n_source, cap, dens, v_edge, temp[c], pres[c],
-                         max_events=blk.cfg.max_events, max_appends=blk.cfg.max_appends)
+                         max_events=blk.cfg.max_events, max_appends=blk.cfg.max_appends, n_comp_max=kc)
         oc.mag[:] = mag[c]
         gid = cell_id_base + c
         oc.generate(modes, n_part, seed, gid, first_id=gid << 32, create_time=float(c))
+        if kc:      # every particle its own create time, so that a list shows whose entries it holds
+            oc.lct[:n_part] = oc.gct[:n_part] = oc.comp_time[:n_part, 0] = c + 1e-4 * np.arange(n_part)
         oc.cell_id = gid
         oc.next_id = int((gid << 32) + (1 << 24))
         cells.append(oc)
@@ -83,6 +104,8 @@ def setup_pair(wp, oracle, n_cells, n_part, n_spec, n_class, seed, kernel, cap=N
         vol[:, s] = oc.vol[:, :n_part]; wc[s] = oc.wclass[:n_part]; ids[s] = oc.id[:n_part]
         lct[s] = oc.lct[:n_part]; gct[s] = oc.gct[:n_part]; norig[:, s] = oc.n_orig[:, :n_part]
     blk.upload_cells(0, po, vol, wc, ids, lct, gct, norig if n_source > 0 else None)
+    if kc:
+        upload_components(blk, cells, po)
     if explicit_bounds:      # whole tables now; otherwise mc_coag computes what each cell needs
         blk.update_kernel_bounds(kernel)
     for c, oc in enumerate(cells):
@@ -96,6 +119,7 @@ def compare_state(blk, cells, check_caches=True):
     """Returns (equal, message).  Bitwise on every particle field."""
     dn = blk.download_cells()
     po = dn["part_offset"]
+    comps = None
     for c, oc in enumerate(cells):
         n = int(oc.n_part[0])
         if po[c + 1] - po[c] != n:
@@ -110,6 +134,18 @@ def compare_state(blk, cells, check_caches=True):
                                   np.ascontiguousarray(b).view(np.uint8)):
                 bad = np.argwhere(np.asarray(a) != np.asarray(b))
                 return False, f"cell {c}: field {name} differs at {bad[:4].tolist()} ({len(bad)} entries)"
+        if blk.cfg.n_comp_max > 0:
+            if oc.n_comp_max != blk.cfg.n_comp_max:
+                return False, f"cell {c}: the oracle cell was built without component lists"
+            if comps is None:
+                comps = blk.download_components()
+            for name, a, b in [("comp_len", comps["comp_len"][s], oc.comp_n[:n]),
+                               ("comp_source", comps["comp_source"][s], oc.comp_src[:n]),
+                               ("comp_time", comps["comp_time"][s], oc.comp_time[:n])]:
+                if not np.array_equal(np.ascontiguousarray(a).view(np.uint8),
+                                      np.ascontiguousarray(b).view(np.uint8)):
+                    bad = np.argwhere(np.asarray(a) != np.asarray(b))
+                    return False, f"cell {c}: field {name} differs at {bad[:4].tolist()} ({len(bad)} entries)"
         if check_caches:
             vt, ms = blk.caches(c)
             if not (np.array_equal(vt[:n], oc.vtot[:n]) and np.array_equal(ms[:n], oc.mass[:n])):

@@ -23,6 +23,18 @@ def _build():
         pytest.skip("flang or the prebuilt test_shim is not available")
 
 
+def _check_lists(out, off, ncomp, cm, sl):
+    """The component(:) lists test_shim wrote behind a cell's particles against the device's
+    (CellBlock.download_components of the same sequence): every source_id and create_time."""
+    lists = np.frombuffer(out, np.dtype([("s", "<i4"), ("t", "<f8")]), int(ncomp.sum()), off)
+    at = np.concatenate([[0], np.cumsum(ncomp)])
+    assert np.array_equal(ncomp, cm["comp_len"][sl])       # (no particle of more than 8 constituents here)
+    for i, k in enumerate(ncomp):
+        assert np.array_equal(lists["s"][at[i]:at[i + 1]] - 1, cm["comp_source"][sl][i, :k])
+        assert np.array_equal(lists["t"][at[i]:at[i + 1]], cm["comp_time"][sl][i, :k])
+    return off + 12 * int(ncomp.sum())
+
+
 @pytest.mark.parametrize("mode", [1, 0])
 def test_fortran_shim_matches_oracle(tmp_path, wp, oracle, mode):
     _build()
@@ -44,9 +56,11 @@ def test_fortran_shim_matches_oracle(tmp_path, wp, oracle, mode):
     for c in range(n_cells):
         T, p = 288.15 - 5 * c, 101325.0 - 8000 * c
         oc = oracle.Cell(n_spec, n_class, n_source, 1024, dens, ve, T, p,
-                         max_events=max_events, max_appends=max_appends)
+                         max_events=max_events, max_appends=max_appends, n_comp_max=8)
         oc.mag[:] = num_conc / n_part * (1 + 0.5 * np.arange(n_class))
         oc.generate(modes, n_part, seed, c, first_id=c << 32, create_time=float(c))
+        # every particle its own create time: a coagulated particle's list shows whose entries it holds
+        oc.lct[:n_part] = oc.gct[:n_part] = oc.comp_time[:n_part, 0] = c + 1e-4 * np.arange(n_part)
         oc.kmax[:] = oracle.kmax_table(kernel, vs, dens.min(), dens.max(), T, p, const_k, beta)
         cells.append(oc)
         buf += struct.pack("<2d", T, p) + oc.mag.astype("<f8").tobytes() + n_ideal.astype("<f8").tobytes()
@@ -116,6 +130,17 @@ def test_fortran_shim_matches_oracle(tmp_path, wp, oracle, mode):
         assert np.array_equal(ncomp, cnt.sum(1))
         assert (tlim[:, 0] >= oc.lct[:n]).all() and (tlim[:, 1] <= oc.gct[:n]).all()
         assert np.array_equal(tlim[~was_merged, 0], oc.lct[:n][~was_merged])
+        # component(:) itself (driver:1421-1437): source_id and create_time of EVERY constituent, in
+        # the order the coagulations put them, as the oracle's lists have them
+        lists = np.frombuffer(out, np.dtype([("s", "<i4"), ("t", "<f8")]), int(ncomp.sum()), off)
+        off += 12 * int(ncomp.sum())
+        assert ncomp.max() <= 8 and (ncomp[was_merged] >= 2).all()
+        at = np.concatenate([[0], np.cumsum(ncomp)])
+        for i in range(n):
+            k = int(ncomp[i])
+            assert k == oc.comp_n[i], (c, i)
+            assert np.array_equal(lists["s"][at[i]:at[i + 1]] - 1, oc.comp_src[i, :k]), (c, i)
+            assert np.array_equal(lists["t"][at[i]:at[i + 1]], oc.comp_time[i, :k]), (c, i)
     assert off == len(out)
 
 
@@ -167,7 +192,7 @@ def test_fortran_resident_sequence(tmp_path, wp):
     prob_h = np.broadcast_to(prob_h, (n_cells, n_class, 4))
     prob_v = np.where(np.arange(nz)[None, None, :] == lev[:, None, None], 0.0, 0.01)
     prob_v = np.broadcast_to(prob_v, (n_cells, n_class, nz))
-    with wp.CellBlock(n_cells, cap, n_spec, n_class=n_class, n_source=n_source) as blk:
+    with wp.CellBlock(n_cells, cap, n_spec, n_class=n_class, n_source=n_source, n_comp_max=8) as blk:
         blk.set_aero_data(dens)
         blk.set_env(T, P, np.full(n_cells, 0.5))
         blk.set_weights(mag)
@@ -199,6 +224,7 @@ def test_fortran_resident_sequence(tmp_path, wp):
             assert np.array_equal(got, ex), step          # trans_aero_preweight's expected_num_conc
             assert nm.sum() > 0 and nr.sum() > 0 and nc.sum() > 0
         d = blk.download_cells()
+        cm = blk.download_components()
         w_dev = blk.get_weights()
     assert (w_dev > mag * 1.5).all()                       # the scaling raised the magnitudes
     rec = 8 * n_spec + 4 * n_source + 4 + 8 + 16 + 4 + 8 + 8 + 4 + 16
@@ -216,6 +242,7 @@ def test_fortran_resident_sequence(tmp_path, wp):
         assert np.array_equal(blob[:, o + 4:o + 12].copy().view("<i8")[:, 0], d["id"][sl])
         assert np.array_equal(blob[:, o + 12:o + 28].copy().view("<f8"),
                               np.stack([d["least_ct"][sl], d["greatest_ct"][sl]], axis=1))
+        off = _check_lists(out, off, blob[:, o + 48:o + 52].copy().view("<i4")[:, 0], cm, sl)
     assert off == len(out)
 
 
@@ -267,7 +294,7 @@ def test_fortran_resident_sequence_from_fields(tmp_path, wp):
     out = fout.read_bytes()
 
     lev = (np.arange(n_cells) // nx) % nz
-    with wp.CellBlock(n_cells, cap, n_spec, n_class=n_class, n_source=n_source) as blk:
+    with wp.CellBlock(n_cells, cap, n_spec, n_class=n_class, n_source=n_source, n_comp_max=8) as blk:
         blk.set_aero_data(dens)
         blk.set_env(T, P, np.full(n_cells, 0.5))
         blk.set_weights(mag)
@@ -296,6 +323,7 @@ def test_fortran_resident_sequence_from_fields(tmp_path, wp):
             assert nm.sum() > 0 and nc.sum() > 0
         assert tot_emit > 0
         d = blk.download_cells()
+        cm = blk.download_components()
     rec = 8 * n_spec + 4 * n_source + 4 + 8 + 16 + 4 + 8 + 8 + 4 + 16
     po = d["part_offset"]
     for c in range(n_cells):
@@ -307,6 +335,7 @@ def test_fortran_resident_sequence_from_fields(tmp_path, wp):
         assert np.array_equal(blob[:, :o].copy().view("<f8").T, d["vol"][:, sl])
         o += 4 * n_source
         assert np.array_equal(blob[:, o + 4:o + 12].copy().view("<i8")[:, 0], d["id"][sl])
+        off = _check_lists(out, off, blob[:, o + 48:o + 52].copy().view("<i4")[:, 0], cm, sl)
     assert off == len(out)
 
 

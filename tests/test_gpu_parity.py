@@ -1236,11 +1236,20 @@ def test_transport_slabs_match_whole_domain(wp):
     mag = rng.uniform(0.5e7, 2e7, (n, n_class))
     cv = rng.uniform(0.8e9, 1.3e9, n)
     ph = rng.uniform(0, 0.08, (n, n_class, 4)); pv = rng.uniform(0, 0.04, (n, n_class, nz))
-    whole = wp.CellBlock(n, cap, n_spec, n_class=n_class, n_source=2)
+    kc = parity.N_COMP_MAX            # (tests/test_gpu_components.py: the lists travel in the records)
+    whole = wp.CellBlock(n, cap, n_spec, n_class=n_class, n_source=2, n_comp_max=kc)
     whole.set_aero_data(dens); whole.set_env(280.0, 9e4); whole.set_weights(mag)
     whole.set_next_id((np.arange(n, dtype=np.int64) << 32) + (1 << 20))
     whole.generate_lognormal(n_part, modes, seed=3)
     dn = whole.download_cells()
+    if kc:
+        nt = int(dn["part_offset"][-1])
+        c_len = rng.randint(1, kc + 1, nt).astype(np.int32)
+        c_src = np.where(np.arange(kc)[None, :] < c_len[:, None], rng.randint(0, 2, (nt, kc)), -1).astype(np.int32)
+        c_tim = np.where(c_src >= 0, rng.uniform(0, 100, (nt, kc)), 0.0)
+        whole.upload_cells(0, dn["part_offset"], dn["vol"], dn["wclass"], dn["id"], dn["least_ct"],
+                           dn["greatest_ct"], dn["n_orig"])
+        whole.upload_components(0, dn["part_offset"], c_len, c_src, c_tim)
     slabs = []
     rows_per = ny // 2
     for a in range(2):
@@ -1248,7 +1257,7 @@ def test_transport_slabs_match_whole_domain(wp):
         rows = [(j0 - 1) % ny] + list(range(j0, j0 + rows_per)) + [(j0 + rows_per) % ny]   # global rows
         cells = np.concatenate([np.arange(j * row, (j + 1) * row) for j in rows])
         nloc = len(cells)
-        b = wp.CellBlock(nloc, cap, n_spec, n_class=n_class, n_source=2,
+        b = wp.CellBlock(nloc, cap, n_spec, n_class=n_class, n_source=2, n_comp_max=kc,
                          cell_id_base=((j0 - 1) * row) % (1 << 32))
         b.set_aero_data(dens); b.set_env(280.0, 9e4)
         b.set_weights(mag[cells])                       # ghost rows: the neighbour's weights
@@ -1258,6 +1267,8 @@ def test_transport_slabs_match_whole_domain(wp):
         sel = np.concatenate([np.arange(dn["part_offset"][c], dn["part_offset"][c + 1]) for c in real])
         b.upload_cells(row, po, dn["vol"][:, sel], dn["wclass"][sel], dn["id"][sel], dn["least_ct"][sel],
                        dn["greatest_ct"][sel], dn["n_orig"][:, sel])
+        if kc:
+            b.upload_components(row, po, c_len[sel], c_src[sel], c_tim[sel])
         for g0 in (0, nloc - row):                      # ghost rows start empty
             b.upload_cells(g0, np.zeros(row + 1, np.int64), np.zeros((n_spec, 0)))
         slabs.append((b, cells, real))
@@ -1271,6 +1282,7 @@ def test_transport_slabs_match_whole_domain(wp):
             b.transport_import(0, hi[(a - 1) % 2].copy_to(b))  # from below: its top row's movers
             b.transport_import(1, lo[(a + 1) % 2].copy_to(b))  # from above: its bottom row's movers
         ref = whole.download_cells()
+        ref_c = whole.download_components() if kc else None
         for b, cells, real in slabs:
             nm, na = b.transport_finish()
             assert np.array_equal(nm[row:-row], nm_w[real]) and np.array_equal(na[row:-row], na_w[real]), step
@@ -1280,6 +1292,10 @@ def test_transport_slabs_match_whole_domain(wp):
             sel = np.concatenate([np.arange(ref["part_offset"][c], ref["part_offset"][c + 1]) for c in real])
             for k in ("vol", "wclass", "id", "least_ct", "greatest_ct", "n_orig"):
                 assert np.array_equal(got[k], ref[k][..., sel]), (step, k)
+            if kc:
+                got_c = b.download_components(row, len(real))
+                for k in ("comp_len", "comp_source", "comp_time"):
+                    assert np.array_equal(got_c[k], ref_c[k][sel]), (step, k)
             assert np.array_equal(b.get_next_id()[row:-row], whole.get_next_id()[real])
             assert not b.aero_state_total_particles()[:row].any()      # ghost rows are empty again
     assert nm_w.sum() > 1000

@@ -173,6 +173,73 @@ def _cell(oracle, n_part, n_spec, n_class, kernel, seed, cell_id=0, coarse=False
     return c
 
 
+@pytest.mark.parametrize("K,n_class", [(8, 1), (3, 1), (4, 2)])
+def test_component_lists_follow_the_particles(oracle, K, n_class):
+    """particle%component(:) in the oracle (interface/wrf_pmc_driver.F90:1421-1437; the merge rule
+    is upstream's, uncited): pinned by what the lists must satisfy whatever the order of events --
+    an untruncated list has n_orig(s) entries of source s and spans exactly the particle's least
+    and greatest create times; a truncated one is full; a doubled particle carries its original's
+    list; and a merged particle's list is its first candidate's followed by its second's (checked
+    by replaying one coagulation by hand)."""
+    n_part = 1500
+    names, dens = parity.default_species(2)
+    ve, vs = oracle.make_bin_tables(80, 1e-10, 1e-2)
+    modes, nc = parity.make_modes(2, n_class)
+    c = oracle.Cell(2, n_class, 3, 4096, dens, ve, n_comp_max=K)
+    c.mag[:] = nc * 40.0 / n_part * (1 + 0.5 * np.arange(n_class))
+    c.generate(modes, n_part, 9, 0)
+    c.lct[:n_part] = c.gct[:n_part] = c.comp_time[:n_part, 0] = 1e-3 * np.arange(n_part)
+    assert (c.comp_n[:n_part] == 1).all() and np.array_equal(c.comp_src[:n_part, 0], c.n_orig[:, :n_part].argmax(0))
+    c.kmax[:] = oracle.kmax_table(K_BROWN, vs, dens.min(), dens.max(), c.temp, c.pressure)
+    next_id = 1 << 40
+    for step in range(4):
+        before = {int(i): (c.comp_src[k].copy(), c.comp_time[k].copy(), int(c.comp_n[k]))
+                  for k, i in enumerate(c.id[:int(c.n_part[0])])}
+        st, ns, nco = c.mc_coag(K_BROWN, 900.0, 9, 0, step)
+        assert st == 0 and nco > 20
+        n = int(c.n_part[0])
+        # a particle whose list grew by exactly one other list: the other is a particle that left
+        gone = set(before) - set(int(i) for i in c.id[:n])
+        seen = 0
+        for k in range(n):
+            src0, t0, n0 = before[int(c.id[k])]
+            n1 = int(c.comp_n[k])
+            if n1 == n0 or n1 == K:
+                continue
+            mine = set(t0[:n0].tolist())
+            other = [t for t in c.comp_time[k, :n1].tolist() if t not in mine]
+            # its own entries stay together and in order: lists are only ever concatenated
+            own_pos = [j for j, t in enumerate(c.comp_time[k, :n1].tolist()) if t in mine]
+            assert own_pos == list(range(own_pos[0], own_pos[0] + n0)) and len(other) == n1 - n0
+            assert c.comp_time[k, own_pos[0]:own_pos[0] + n0].tolist() == t0[:n0].tolist()
+            seen += 1
+        assert seen > 10 and (n_class > 1 or len(gone) == nco)
+        _, next_id = c.rebalance(np.full(n_class, 0.9 * n_part / n_class), True, True, 9, 0, step, next_id)
+    n = int(c.n_part[0])
+    tot = c.n_orig[:, :n].sum(0)
+    assert np.array_equal(c.comp_n[:n], np.minimum(tot, K)) and (tot > 1).sum() > 100
+    whole = tot <= K
+    assert whole.any() and (K > 4 or (~whole).any())
+    for s in range(3):
+        assert np.array_equal((c.comp_src[:n][whole] == s).sum(1), c.n_orig[s, :n][whole])
+    t = np.where(c.comp_src[:n] >= 0, c.comp_time[:n], np.nan)
+    assert np.array_equal(np.nanmin(t[whole], 1), c.lct[:n][whole])
+    assert np.array_equal(np.nanmax(t[whole], 1), c.gct[:n][whole])
+    assert (np.nanmin(t[~whole], 1) >= c.lct[:n][~whole]).all() and (np.nanmax(t[~whole], 1) <= c.gct[:n][~whole]).all()
+    assert (c.comp_src[:n][np.arange(K)[None, :] >= c.comp_n[:n, None]] == -1).all()
+    assert (c.comp_time[:n][np.arange(K)[None, :] >= c.comp_n[:n, None]] == 0).all()
+    # doubling copies the list: afterwards slot n + k holds the list of the k-th particle of the class
+    src0, t0, wc0 = c.comp_src[:n].copy(), c.comp_time[:n].copy(), c.wclass[:n].copy()
+    c.rebalance(np.full(n_class, 3.0 * n), True, False, 9, 0, 99, 1 << 50)
+    n2 = int(c.n_part[0])
+    assert n2 >= 2 * n
+    assert np.array_equal(c.comp_src[:n], src0) and np.array_equal(c.comp_time[:n], t0)
+    first = int((wc0 == 0).sum())       # the first doubling: the particles of class 0 in slot order
+    assert np.array_equal(c.comp_src[n:n + first], src0[wc0 == 0]) and np.array_equal(c.comp_time[n:n + first], t0[wc0 == 0])
+    have = {(tuple(a), tuple(b)) for a, b in zip(src0.tolist(), t0.tolist())}
+    assert all((tuple(a), tuple(b)) in have for a, b in zip(c.comp_src[n:n2].tolist(), c.comp_time[n:n2].tolist()))
+
+
 def test_single_class_conservation(oracle):
     c = _cell(oracle, 3000, 3, 1, K_BROWN, seed=4)
     n0 = 3000

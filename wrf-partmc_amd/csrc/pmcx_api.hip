@@ -273,6 +273,11 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
         cfg->n_dbin < 1 || !(cfg->d_min > 0) || !(cfg->d_max > cfg->d_min) ||
         cfg->n_class * cfg->n_bin > 65535 || cfg->i_water >= cfg->n_spec)
         return fail(nullptr, PMCX_EINVAL, "pmcx_create: configuration out of range");
+    if (cfg->n_comp_max < 0 || cfg->n_comp_max > 8 ||
+        (cfg->n_comp_max > 0 && (cfg->n_source < 1 || cfg->n_source > 255)))
+        return fail(nullptr, PMCX_EINVAL,
+                    "pmcx_create: n_comp_max = %d needs 0 <= n_comp_max <= 8 and 1 <= n_source <= 255",
+                    cfg->n_comp_max);
     // list offsets are 16-bit in the sampler's LDS: lists + the room behind them must fit
     if ((int64_t)cfg->cap + cfg->cap / 8 + 16 * (int64_t)cfg->n_class * cfg->n_bin > 65535)
         return fail(nullptr, PMCX_EINVAL,
@@ -303,6 +308,7 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
     st.n_class = cfg->n_class; st.n_source = cfg->n_source; st.n_bin = cfg->n_bin;
     st.n_dbin = cfg->n_dbin; st.i_water = cfg->i_water;
     st.max_events = cfg->max_events; st.max_appends = cfg->max_appends;
+    st.n_comp_max = cfg->n_comp_max;
     st.compact_den = cfg->compact_den ? (int32_t)cfg->compact_den : 2;
     st.pcap = cfg->cap + cfg->cap / 8 + 16 * cfg->n_class * cfg->n_bin;
     st.cell_id_base = cfg->cell_id_base;
@@ -368,6 +374,10 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
     A_(st.n_events, nc); A_(st.n_samp, nc); A_(st.n_coag, nc); A_(st.status, nc);
     if (cfg->n_spec == 1 && cfg->n_class == 1) { // the sampler's split-off draw (2 KB per cell)
         A_(st.pre, nc * 128); A_(st.resume, nc * 2); A_(st.work2, nc + 1);
+    }
+    if (cfg->n_comp_max > 0) { // particle%component(:): 8 (1 + n_comp_max) bytes per slot
+        A_(st.comp_src, nc * cap); A_(st.comp_time, nc * cap * (size_t)cfg->n_comp_max);
+        A_(st.mlog, nc * (size_t)cfg->max_events);
     }
     A_(ctx->d_totals, (size_t)4);
     A_(ctx->d_acc, (size_t)4);
@@ -643,6 +653,7 @@ int pmcx_upload_cells(pmcx_ctx *ctx, int32_t cell_first, int32_t n_up, const int
         }
     }
     HIP_TRY(ctx, launch_set_n_part(st.n_part + c0, st.n_hi + c0, ctx->d_offsets, n_up, ctx->stream));
+    if (cf.n_comp_max > 0) HIP_TRY(ctx, launch_comp_default(st, cell_first, n_up, ctx->stream));
     HIP_TRY(ctx, launch_refresh_caches(st, cell_first, n_up, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, invalidate_sort(ctx, cell_first, n_up));
@@ -727,6 +738,87 @@ int pmcx_download_cells(pmcx_ctx *ctx, int32_t cell_first, int32_t n_dn, const i
                                     hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
+    return PMCX_OK;
+}
+
+int pmcx_upload_components(pmcx_ctx *ctx, int32_t cell_first, int32_t n_up, const int64_t *part_offset,
+                           const int32_t *comp_len, const int32_t *comp_source, const double *comp_time)
+{
+    if (!ctx || !part_offset || !comp_len || !comp_source || !comp_time)
+        return fail(ctx, PMCX_EINVAL, "pmcx_upload_components: null argument");
+    const pmcx_config &cf = ctx->cfg;
+    if (cf.n_comp_max < 1) return fail(ctx, PMCX_ESTATE, "pmcx_upload_components: the context was created with n_comp_max = 0");
+    if (cell_first < 0 || n_up < 1 || cell_first + n_up > cf.n_cells)
+        return fail(ctx, PMCX_EINVAL, "cell range outside the context");
+    HIP_TRY(ctx, hipSetDevice(cf.device));
+    std::vector<int32_t> np((size_t)n_up);
+    HIP_TRY(ctx, hipMemcpyAsync(np.data(), ctx->st.n_hi + cell_first, sizeof(int32_t) * n_up,
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < n_up; k++) // (slots as pmcx_upload_cells laid them out: nothing removed since)
+        if (part_offset[k + 1] - part_offset[k] != np[k])
+            return fail(ctx, PMCX_EINVAL, "pmcx_upload_components: part_offset does not match the upload at cell %d",
+                        cell_first + k);
+    const int64_t nt = part_offset[n_up];
+    if (nt == 0) return PMCX_OK;
+    for (int64_t i = 0; i < nt; i++)
+        for (int q = 0; q < comp_len[i] && q < cf.n_comp_max; q++)
+            if (comp_source[i * cf.n_comp_max + q] < 0 || comp_source[i * cf.n_comp_max + q] >= 255)
+                return fail(ctx, PMCX_EINVAL, "pmcx_upload_components: source %d of particle %lld outside [0,255) (a byte each)",
+                            comp_source[i * cf.n_comp_max + q], (long long)i);
+    int rc = ensure_offsets(ctx, (size_t)n_up + 1);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_offsets, part_offset, sizeof(int64_t) * ((size_t)n_up + 1),
+                                hipMemcpyHostToDevice, ctx->stream));
+    const size_t K = (size_t)cf.n_comp_max, b_len = (sizeof(int32_t) * (size_t)nt + 15) & ~(size_t)15;
+    const size_t b_src = (sizeof(int32_t) * K * (size_t)nt + 15) & ~(size_t)15, b_tim = sizeof(double) * K * (size_t)nt;
+    rc = ensure_stage(ctx, b_len + b_src + b_tim);
+    if (rc) return rc;
+    unsigned char *sp = (unsigned char *)ctx->stage;
+    HIP_TRY(ctx, hipMemcpyAsync(sp, comp_len, sizeof(int32_t) * (size_t)nt, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(sp + b_len, comp_source, sizeof(int32_t) * K * (size_t)nt, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(sp + b_len + b_src, comp_time, b_tim, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, launch_comp_upload(ctx->st, cell_first, n_up, ctx->d_offsets, (const int32_t *)sp,
+                                    (const int32_t *)(sp + b_len), (const double *)(sp + b_len + b_src), ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PMCX_OK;
+}
+
+int pmcx_download_components(pmcx_ctx *ctx, int32_t cell_first, int32_t n_dn, const int64_t *part_offset,
+                             int32_t *comp_len, int32_t *comp_source, double *comp_time)
+{
+    if (!ctx || !part_offset || !comp_len || !comp_source || !comp_time)
+        return fail(ctx, PMCX_EINVAL, "pmcx_download_components: null argument");
+    const pmcx_config &cf = ctx->cfg;
+    if (cf.n_comp_max < 1) return fail(ctx, PMCX_ESTATE, "pmcx_download_components: the context was created with n_comp_max = 0");
+    if (cell_first < 0 || n_dn < 1 || cell_first + n_dn > cf.n_cells)
+        return fail(ctx, PMCX_EINVAL, "cell range outside the context");
+    HIP_TRY(ctx, hipSetDevice(cf.device));
+    HIP_TRY(ctx, launch_compact(ctx->st, cell_first, n_dn, 0, 1, ctx->stream)); // the host view is dense
+    std::vector<int32_t> np((size_t)n_dn);
+    HIP_TRY(ctx, hipMemcpyAsync(np.data(), ctx->st.n_part + cell_first, sizeof(int32_t) * n_dn,
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < n_dn; k++)
+        if (part_offset[k + 1] - part_offset[k] != np[k])
+            return fail(ctx, PMCX_EINVAL, "part_offset does not match n_part at cell %d", cell_first + k);
+    const int64_t nt = part_offset[n_dn];
+    if (nt == 0) return PMCX_OK;
+    int rc = ensure_offsets(ctx, (size_t)n_dn + 1);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_offsets, part_offset, sizeof(int64_t) * ((size_t)n_dn + 1),
+                                hipMemcpyHostToDevice, ctx->stream));
+    const size_t K = (size_t)cf.n_comp_max, b_len = (sizeof(int32_t) * (size_t)nt + 15) & ~(size_t)15;
+    const size_t b_src = (sizeof(int32_t) * K * (size_t)nt + 15) & ~(size_t)15, b_tim = sizeof(double) * K * (size_t)nt;
+    rc = ensure_stage(ctx, b_len + b_src + b_tim);
+    if (rc) return rc;
+    unsigned char *sp = (unsigned char *)ctx->stage;
+    HIP_TRY(ctx, launch_comp_download(ctx->st, cell_first, n_dn, ctx->d_offsets, (int32_t *)sp,
+                                      (int32_t *)(sp + b_len), (double *)(sp + b_len + b_src), ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(comp_len, sp, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(comp_source, sp + b_len, sizeof(int32_t) * K * (size_t)nt, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(comp_time, sp + b_len + b_src, b_tim, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PMCX_OK;
 }
 

@@ -98,6 +98,13 @@ struct DeviceState {
     uint4 *pre;        // [n_cells][128] {uniform, bound, slot, -} (nullptr: not allocated)
     int32_t *resume;   // [n_cells][2] slot settled last (-1: none), entries in the overflow table
     int32_t *work2;    // [1 + n_cells] count, cells
+    // particle%component(:) (interface/wrf_pmc_driver.F90:1421-1437), the first n_comp_max of a
+    // particle's list (0: not carried): source ids a byte each (0xFF past the end), create times;
+    // the coagulations of the last mc_coag in event order, merged by k_comp_merge behind the sampler
+    int32_t n_comp_max;
+    uint64_t *comp_src;  // [n_cells][cap]
+    double *comp_time;   // [n_cells][cap][n_comp_max]
+    uint64_t *mlog;      // [n_cells][max_events] pn | po << 16 | (pn is the first candidate) << 32
 };
 
 struct GenSpecDev {
@@ -148,6 +155,11 @@ hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, ui
                               uint32_t step, hipStream_t s);
 bool coag_sample_splits_draw(const DeviceState &st, int ktype); // the form launch_coag_sample picks
 hipError_t seq_stamps_read(uint64_t out[12], bool reset); // diagnostic (pmcx_set_sampler_variant, stamps = 1)
+hipError_t launch_comp_upload(const DeviceState &st, int cell_first, int n_up, const int64_t *part_offset,
+                              const int32_t *len, const int32_t *source, const double *time, hipStream_t s);
+hipError_t launch_comp_download(const DeviceState &st, int cell_first, int n_dn, const int64_t *part_offset,
+                                int32_t *len, int32_t *source, double *time, hipStream_t s);
+hipError_t launch_comp_default(const DeviceState &st, int cell_first, int n_up, hipStream_t s);
 hipError_t launch_rebalance(const DeviceState &st, int allow_doubling, int allow_halving,
                             uint64_t seed, uint32_t step, hipStream_t s);
 hipError_t launch_diagnostics(const DeviceState &st, double *tot_num, double *tot_mass,

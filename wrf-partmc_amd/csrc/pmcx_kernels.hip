@@ -95,6 +95,29 @@ __device__ __forceinline__ int32_t &norig(const DeviceState &st, int64_t cb, int
     return st.n_orig[cb * (st.n_source - 1) + (int64_t)(s - 1) * st.cap + i];
 }
 
+// particle%component(:), see DeviceState::comp_src (at, dst, src: cell base + slot)
+__device__ __forceinline__ void comp_copy(const DeviceState &st, int64_t dst, int64_t src)
+{
+    if (!st.n_comp_max) return;
+    const int K = st.n_comp_max;
+    st.comp_src[dst] = st.comp_src[src];
+    for (int k = 0; k < K; k++) st.comp_time[dst * K + k] = st.comp_time[src * K + k];
+}
+__device__ __forceinline__ void comp_single(const DeviceState &st, int64_t at, int source, double t)
+{
+    if (!st.n_comp_max) return;
+    const int K = st.n_comp_max;
+    st.comp_src[at] = ~0xFFull | (uint64_t)(source & 0xFF);
+    st.comp_time[at * K] = t;
+    for (int k = 1; k < K; k++) st.comp_time[at * K + k] = 0.0;
+}
+__device__ __forceinline__ int comp_count(uint64_t w)
+{
+    int n = 0;
+    for (int k = 0; k < 8; k++) n += ((w >> (8 * k)) & 0xFFu) != 0xFFu;
+    return n;
+}
+
 // The cells the loop nest of partmc_timestep covers (interface/wrf_pmc_driver.F90:157-171: every
 // owned cell when the domain is doubly periodic, otherwise the interior 2 .. n-1 in x and y):
 // pmcx_set_loop_cells.  A cell outside it is left alone by mc_coag, the scenario updates and the
@@ -1147,6 +1170,8 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
             status |= ST_APPEND_OVERFLOW; done = true; continue;
         }
         n_ev++;
+        if (st.mlog && lead)
+            st.mlog[(int64_t)c * st.max_events + n_ev - 1] = (uint64_t)pn | ((uint64_t)po << 16) | ((uint64_t)pn_is_1 << 32);
         // Species volumes, source histogram, create times and class of the merged
         // particle [aero_particle_coagulate]: loads go out now and are consumed after
         // the list updates below; lanes of the group split the species.
@@ -2104,6 +2129,8 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                     if (b_new > (KT == KERNEL_BROWN ? (int)envs[6 * 64 + lane] : st.kmax_rng[4 * (int64_t)c + 1]))
                         status |= ST_KMAX_RANGE; // no bound was computed there
                     n_ev++;
+                    if (st.mlog)
+                        st.mlog[(int64_t)c * st.max_events + n_ev - 1] = (uint64_t)pn | ((uint64_t)po << 16) | ((uint64_t)big1 << 32);
                     // swap-with-last removal of the other particle
                     const int last_o = (int)(e_o & 0xFFFFu) - 1;
                     if (io != last_o) perm[(e_o >> 16) + io] = big1 ? last2 : last1;
@@ -2177,6 +2204,8 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                     status |= ST_APPEND_OVERFLOW; done = true; break;
                 }
                 n_ev++;
+                if (st.mlog)
+                    st.mlog[(int64_t)c * st.max_events + n_ev - 1] = (uint64_t)pn | ((uint64_t)po << 16) | ((uint64_t)pn_is_1 << 32);
                 if (rem_o) { // swap-with-last removal of the other particle
                     const uint32_t e = pn_is_1 ? eB : eA;
                     const int last = (int)(e & 0xFFFFu) - 1;
@@ -2340,6 +2369,93 @@ hipError_t seq_stamps_read(uint64_t out[12], bool reset)
     return e;
 }
 
+// ---------------------------------------------------------------- components
+//
+// particle%component(:) (interface/wrf_pmc_driver.F90:1421-1437).  The samplers only log which
+// slots coagulated (DeviceState::mlog, a word per event); the lists are merged here, a thread per
+// cell in event order: the merged particle's list is its first candidate's followed by its
+// second's [aero_particle_coagulate, upstream, uncited], cut at n_comp_max (sum_s n_orig is the
+// untruncated length).  Runs behind the sampler and before anything closes the cell's holes: the
+// log names slots as the sampler saw them.
+__global__ __launch_bounds__(64) void k_comp_merge(DeviceState st)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= st.n_cells || !in_loop(st, c)) return;
+    const int n_ev = st.n_events[c];
+    const int K = st.n_comp_max;
+    const int64_t cb = (int64_t)c * st.cap;
+    const uint64_t *lg = st.mlog + (int64_t)c * st.max_events;
+    for (int e = 0; e < n_ev; e++) {
+        const uint64_t ev = lg[e];
+        const int pn = (int)(ev & 0xFFFFu), po = (int)((ev >> 16) & 0xFFFFu);
+        const bool pn1 = ((ev >> 32) & 1u) != 0;
+        const int64_t first = cb + (pn1 ? pn : po), second = cb + (pn1 ? po : pn);
+        const uint64_t sa = st.comp_src[first], sb = st.comp_src[second];
+        const int na = comp_count(sa), nb = comp_count(sb);
+        double t[8];
+        for (int k = 0; k < K; k++)
+            t[k] = k < na ? st.comp_time[first * K + k]
+                          : (k - na < nb ? st.comp_time[second * K + (k - na)] : 0.0);
+        uint64_t sm = na >= 8 ? sa : ((sa & ((1ull << (8 * na)) - 1ull)) | (sb << (8 * na)));
+        if (K < 8) sm |= ~0ull << (8 * K);
+        st.comp_src[cb + pn] = sm;
+        for (int k = 0; k < K; k++) st.comp_time[(cb + pn) * K + k] = t[k];
+    }
+}
+
+// the host's view of the lists: len [n] entries held, source [n][K] (0-based, -1 past the end),
+// time [n][K]; particles of cell k at part_offset[k].. (as pmcx_upload_cells)
+__global__ void k_comp_upload(DeviceState st, int cell_first, const int64_t *part_offset,
+                              const int32_t *len, const int32_t *source, const double *time)
+{
+    const int k = blockIdx.y, c = cell_first + k, K = st.n_comp_max;
+    const int64_t o0 = part_offset[k], n = part_offset[k + 1] - o0, cb = (int64_t)c * st.cap;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int m = len[o0 + i];
+        m = m < 0 ? 0 : (m > K ? K : m);
+        uint64_t w = ~0ull;
+        for (int q = 0; q < K; q++) {
+            if (q < m) w = (w & ~(0xFFull << (8 * q))) | ((uint64_t)(source[(o0 + i) * K + q] & 0xFF) << (8 * q));
+            st.comp_time[(cb + i) * K + q] = q < m ? time[(o0 + i) * K + q] : 0.0;
+        }
+        st.comp_src[cb + i] = w;
+    }
+}
+__global__ void k_comp_download(DeviceState st, int cell_first, const int64_t *part_offset,
+                                int32_t *len, int32_t *source, double *time)
+{
+    const int k = blockIdx.y, c = cell_first + k, K = st.n_comp_max;
+    const int64_t o0 = part_offset[k], n = part_offset[k + 1] - o0, cb = (int64_t)c * st.cap;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t w = st.comp_src[cb + i];
+        len[o0 + i] = comp_count(w);
+        for (int q = 0; q < K; q++) {
+            const uint32_t b = (uint32_t)(w >> (8 * q)) & 0xFFu;
+            source[(o0 + i) * K + q] = b == 0xFFu ? -1 : (int32_t)b;
+            time[(o0 + i) * K + q] = st.comp_time[(cb + i) * K + q];
+        }
+    }
+}
+// what an upload without lists leaves: n_orig(s) entries per source in source order, the first
+// created at the least create time and the others at the greatest (exact for a particle of
+// one constituent)
+__global__ void k_comp_default(DeviceState st, int cell_first)
+{
+    const int c = cell_first + blockIdx.y, K = st.n_comp_max;
+    const int64_t cb = (int64_t)c * st.cap;
+    const int n = st.n_hi[c];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        uint64_t w = ~0ull;
+        int m = 0;
+        for (int s = 0; s < st.n_source && m < K; s++)
+            for (int q = norig(st, cb, s, i); q > 0 && m < K; q--, m++)
+                w = (w & ~(0xFFull << (8 * m))) | ((uint64_t)s << (8 * m));
+        for (int q = 0; q < K; q++)
+            st.comp_time[(cb + i) * K + q] = q >= m ? 0.0 : (q == 0 ? st.hot[cb + i].lct : st.hot[cb + i].gct);
+        st.comp_src[cb + i] = w;
+    }
+}
+
 // ---------------------------------------------------------------- compaction
 //
 // Removed particles become tombstones (cached volume -1): slots [0, n_hi) hold
@@ -2364,6 +2480,7 @@ __device__ __forceinline__ void move_particle(const DeviceState &st, int64_t cb,
     st.cold[cb + dst].id = st.cold[cb + src].id;
     st.hot[cb + dst].lct = st.hot[cb + src].lct;
     st.hot[cb + dst].gct = st.hot[cb + src].gct;
+    comp_copy(st, cb + dst, cb + src);
 }
 
 // Stable compaction of one cell by one wavefront: 64 slots at a time, every
@@ -2469,6 +2586,26 @@ __device__ void compact_wave(const DeviceState &st, int c, int lane, uint32_t *c
 #pragma unroll
             for (int u = 0; u < U; u++)
                 if (mv[u]) st_u32((uint32_t *)&norig(st, cb, s, dst[u]), xo[u]);
+        }
+        if (st.n_comp_max) { // the component lists: the source word, then one create time at a time
+            const int K = st.n_comp_max;
+            for (int k = -1; k < K; k++) {
+                double xc[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int64_t at = cb + i0 + u * 64 + lane;
+                    xc[u] = !mv[u] ? 0.0 : k < 0 ? ld_f64((const double *)&st.comp_src[at])
+                                                  : ld_f64(&st.comp_time[at * K + k]);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                wave_sync();
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    if (mv[u]) {
+                        if (k < 0) st_f64((double *)&st.comp_src[cb + dst[u]], xc[u]);
+                        else st_f64(&st.comp_time[(cb + dst[u]) * K + k], xc[u]);
+                    }
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
@@ -2820,6 +2957,7 @@ __device__ int add_dist_sample(const DeviceState &st, int c, const AeroDistDev &
             st.cold[cb + i].id = nid + k;
             st.hot[cb + i].lct = create_time;
             st.hot[cb + i].gct = create_time;
+            comp_single(st, cb + i, d.mode_source[mo + m], create_time);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
@@ -3694,6 +3832,7 @@ __global__ __launch_bounds__(64) void k_boundary_copy(DeviceState st, int n_pair
             cv.id = nid + dst;
             st.cold[db + dst] = cv;
             st.wclass[db + dst] = wc;
+            comp_copy(st, db + dst, sb + i);
         }
         base += __popcll(m);
     }
@@ -4095,6 +4234,7 @@ __global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid t
                 Cold c2 = cv;
                 if (g != copies - 1) c2.id = id0 + g;
                 st.cold[cb + dst] = c2;
+                comp_copy(st, cb + dst, sb + from);
             }
         }
         at += (int)__shfl(inc, 63, 64);
@@ -4235,10 +4375,11 @@ __global__ __launch_bounds__(64) void k_trans_remove(DeviceState st, TransGrid t
 // wclass, index within the source cell, pad} | vtot, mass | lct, gct, id, n_orig0 |
 // vol[n_spec] | n_orig[1..] (padded to 8 bytes).
 
-__host__ __device__ inline size_t halo_rec_bytes(int n_spec, int n_source)
+__host__ __device__ inline size_t halo_rec_bytes(int n_spec, int n_source, int n_comp_max)
 {
     const size_t extra = n_source > 1 ? (size_t)(n_source - 1) * 4 : 0;
-    return 24 + 16 + 32 + 8 * (size_t)n_spec + ((extra + 7) & ~(size_t)7);
+    const size_t comp = n_comp_max ? 8 * (size_t)(1 + n_comp_max) : 0; // source word, create times
+    return 24 + 16 + 32 + 8 * (size_t)n_spec + ((extra + 7) & ~(size_t)7) + comp;
 }
 
 // entries of the cells of row src_row that go to row dst_row: counts per source cell
@@ -4308,6 +4449,11 @@ __global__ __launch_bounds__(64) void k_halo_pack(DeviceState st, TransGrid tg, 
             for (int sp = 0; sp < S; sp++) d[6 + sp] = spec_vol(st, cb, sp, from);
             int32_t *no = (int32_t *)(d + 6 + S);
             for (int sp = 1; sp < NS; sp++) no[sp - 1] = norig(st, cb, sp, from);
+            if (st.n_comp_max) {
+                double *cm = (double *)(rec + rec_bytes - 8 * (1 + st.n_comp_max));
+                ((uint64_t *)cm)[0] = st.comp_src[cb + from];
+                for (int q = 0; q < st.n_comp_max; q++) cm[1 + q] = st.comp_time[(cb + from) * st.n_comp_max + q];
+            }
         }
         at += __popcll(m);
     }
@@ -4349,6 +4495,11 @@ __global__ __launch_bounds__(64) void k_halo_unpack(DeviceState st, TransGrid tg
         for (int sp = 0; sp < S; sp++) st.vol[(cb + slot) * S + sp] = d[6 + sp];
         const int32_t *no = (const int32_t *)(d + 6 + S);
         for (int sp = 1; sp < NS; sp++) norig(st, cb, sp, slot) = no[sp - 1];
+        if (st.n_comp_max) {
+            const double *cm = (const double *)(rec + rec_bytes - 8 * (1 + st.n_comp_max));
+            st.comp_src[cb + slot] = ((const uint64_t *)cm)[0];
+            for (int q = 0; q < st.n_comp_max; q++) st.comp_time[(cb + slot) * st.n_comp_max + q] = cm[1 + q];
+        }
         box[slot] = make_int2(slot | (copies << 16), dest);
         if (copies > 0) atomicAdd(&tg.n_exp[dest], copies);
     }
@@ -4485,6 +4636,7 @@ __global__ void k_generate(DeviceState st, GenSpecDev g, int n, uint64_t seed, d
         st.cold[cb + i].id = ((int64_t)cell_id << 32) + i;
         st.hot[cb + i].lct = create_time;
         st.hot[cb + i].gct = create_time;
+        comp_single(st, cb + i, g.mode_source[mode], create_time);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { st.n_part[c] = n; st.n_hi[c] = n; }
 }
@@ -4771,8 +4923,8 @@ bool coag_sample_splits_draw(const DeviceState &st, int ktype)
 {
     return sampler_lanes(st, ktype) == 1;
 }
-hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, uint64_t seed,
-                              uint32_t step, hipStream_t s)
+static hipError_t launch_coag_sample_only(const DeviceState &st, int ktype, double del_t, uint64_t seed,
+                                          uint32_t step, hipStream_t s)
 {
     const size_t shared = (sizeof(double) * (size_t)(st.n_bin + 1) + 15) & ~(size_t)15;
     const int L = sampler_lanes(st, ktype);
@@ -4850,6 +5002,35 @@ hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, ui
 #undef PMCX_LAUNCH_SAMPLER
     return hipGetLastError();
 }
+hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, uint64_t seed,
+                              uint32_t step, hipStream_t s)
+{
+    const hipError_t e = launch_coag_sample_only(st, ktype, del_t, seed, step, s);
+    if (e != hipSuccess || !st.n_comp_max) return e;
+    hipLaunchKernelGGL(k_comp_merge, dim3((st.n_cells + 63) / 64), dim3(64), 0, s, st);
+    return hipGetLastError();
+}
+
+hipError_t launch_comp_upload(const DeviceState &st, int cell_first, int n_up, const int64_t *part_offset,
+                              const int32_t *len, const int32_t *source, const double *time, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_comp_upload, grid2(st.cap, n_up), dim3(256), 0, s, st, cell_first, part_offset,
+                       len, source, time);
+    return hipGetLastError();
+}
+hipError_t launch_comp_download(const DeviceState &st, int cell_first, int n_dn, const int64_t *part_offset,
+                                int32_t *len, int32_t *source, double *time, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_comp_download, grid2(st.cap, n_dn), dim3(256), 0, s, st, cell_first, part_offset,
+                       len, source, time);
+    return hipGetLastError();
+}
+hipError_t launch_comp_default(const DeviceState &st, int cell_first, int n_up, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_comp_default, grid2(st.cap, n_up), dim3(256), 0, s, st, cell_first);
+    return hipGetLastError();
+}
+
 hipError_t launch_rebalance(const DeviceState &st, int allow_doubling, int allow_halving,
                             uint64_t seed, uint32_t step, hipStream_t s)
 {
@@ -5055,7 +5236,7 @@ hipError_t launch_transport_probs(const DeviceState &st, const TransFieldsArgs &
     hipLaunchKernelGGL(k_trans_probs, dim3(a.nx * a.ny), dim3(256), lds, s, st, f);
     return hipGetLastError();
 }
-size_t halo_record_bytes(const DeviceState &st) { return halo_rec_bytes(st.n_spec, st.n_source); }
+size_t halo_record_bytes(const DeviceState &st) { return halo_rec_bytes(st.n_spec, st.n_source, st.n_comp_max); }
 // counts[row_cells] and offsets[row_cells + 1] of the movers of row src_row bound for dst_row
 hipError_t launch_halo_count(const DeviceState &st, int nx, int nz, int ny, void *outbox,
                              int32_t *n_out, int src_row, int dst_row, int32_t *counts,
@@ -5074,7 +5255,7 @@ hipError_t launch_halo_pack(const DeviceState &st, int nx, int nz, int ny, void 
     const TransGrid tg = make_grid(nx, nz, ny, 0, 0, nullptr, nullptr, nullptr, outbox, n_out, nullptr,
                                    nullptr, nullptr, 0);
     hipLaunchKernelGGL(k_halo_pack, dim3(nx * nz), dim3(64), 0, s, st, tg, src_row, dst_row, offsets,
-                       (unsigned char *)recs, (int)halo_rec_bytes(st.n_spec, st.n_source));
+                       (unsigned char *)recs, (int)halo_rec_bytes(st.n_spec, st.n_source, st.n_comp_max));
     return hipGetLastError();
 }
 hipError_t launch_halo_unpack(const DeviceState &st, int nx, int nz, int ny, void *outbox,
@@ -5091,7 +5272,7 @@ hipError_t launch_halo_unpack(const DeviceState &st, int nx, int nz, int ny, voi
     hipLaunchKernelGGL(k_halo_scan, dim3(1), dim3(64), 0, s, counts, offsets, nx * nz);
     hipLaunchKernelGGL(k_halo_unpack, dim3(nx * nz), dim3(64), 0, s, st, tg, ghost_row, real_row,
                        counts, offsets, (const unsigned char *)recs,
-                       (int)halo_rec_bytes(st.n_spec, st.n_source), bit, bad);
+                       (int)halo_rec_bytes(st.n_spec, st.n_source, st.n_comp_max), bit, bad);
     return hipGetLastError();
 }
 hipError_t launch_dry_deposition(const DeviceState &st, double dt, uint64_t seed, uint32_t step,

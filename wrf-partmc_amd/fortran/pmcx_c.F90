@@ -17,6 +17,7 @@ module pmcx_c
      real(c_double) :: d_min, d_max
      integer(c_int32_t) :: cell_id_base, compact_den
      real(c_double) :: const_k, additive_beta
+     integer(c_int32_t) :: n_comp_max, pad_
   end type pmcx_config
 
   !> pmcx_trans_fields: WRF's fields for the transport probabilities
@@ -158,6 +159,24 @@ module pmcx_c
        integer(c_int32_t), intent(out) :: wclass(*)
        type(c_ptr), value :: n_orig
      end function pmcx_download_cells
+     integer(c_int) function pmcx_upload_components(ctx, cell_first, n_up, part_offset, comp_len, &
+          comp_source, comp_time) bind(c, name="pmcx_upload_components")
+       import :: c_ptr, c_int, c_int32_t, c_int64_t, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: cell_first, n_up
+       integer(c_int64_t), intent(in) :: part_offset(*)
+       integer(c_int32_t), intent(in) :: comp_len(*), comp_source(*)
+       real(c_double), intent(in) :: comp_time(*)
+     end function pmcx_upload_components
+     integer(c_int) function pmcx_download_components(ctx, cell_first, n_dn, part_offset, comp_len, &
+          comp_source, comp_time) bind(c, name="pmcx_download_components")
+       import :: c_ptr, c_int, c_int32_t, c_int64_t, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: cell_first, n_dn
+       integer(c_int64_t), intent(in) :: part_offset(*)
+       integer(c_int32_t), intent(out) :: comp_len(*), comp_source(*)
+       real(c_double), intent(out) :: comp_time(*)
+     end function pmcx_download_components
      integer(c_int) function pmcx_generate_lognormal(ctx, n_part, n_mode, mode_frac, gm_radius, &
           gsd_log10, vol_frac, mode_class, mode_source, seed, create_time) &
           bind(c, name="pmcx_generate_lognormal")

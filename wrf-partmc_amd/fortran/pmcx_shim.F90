@@ -28,14 +28,16 @@
 ! use pmc_aero_data` when built outside WRF.
 !
 ! What crosses the boundary per particle (wrf_pmc_driver.F90:1419-1466): vol(:), weight_class,
-! id, least/greatest_create_time and component(:) -- the latter as a per-source histogram
-! (the device keeps counts per source, not the list: DESIGN.md 3.2).  Everything else a
-! particle carries on the Fortran side (water_hyst_leg, weight_group, the optics arrays,
-! core_vol, the create_time of each constituent) stays on the host and is re-attached BY ID
-! after a download; a particle whose composition changed gets its optics reset, a particle the
-! host has never seen (emission, transport arrival, doubling) starts from defaults, and
-! constituents gained in a coagulation are appended to component(:) with a create_time
-! bounded by the particle's least/greatest create time (the exact value is not carried).
+! id, least/greatest_create_time and component(:) -- as a per-source histogram and, with
+! pmcx_shim_set_components(n) (n = 1..8, default 8), as the list itself: source_id and
+! create_time of a particle's first n constituents travel with it on the device and
+! component(:) comes back exactly for every particle of at most n constituents (DESIGN.md 3.2).
+! Everything else a particle carries on the Fortran side (water_hyst_leg, weight_group, the
+! optics arrays, core_vol) stays on the host and is re-attached BY ID after a download; a
+! particle whose composition changed gets its optics reset, a particle the host has never seen
+! (emission, transport arrival, doubling) starts from defaults.  Constituents beyond the n
+! carried (or all of them with n = 0) are rebuilt from the histogram with a create_time bounded
+! by the particle's least/greatest create time.
 module pmcx_shim
   use iso_c_binding
   use pmcx_c           ! the C entry points of include/pmcx.h, every one bound (pmcx_c.F90)
@@ -48,6 +50,7 @@ module pmcx_shim
   ! brings aero_states / gas_states up to date when the Fortran side needs them (output, restart)
   public :: partmc_timestep_pmcx, wrf_pmc_trans_driver_pmcx, partmc_sync_host_pmcx, &
        partmc_process_pmcx, pmcx_shim_is_resident
+  public :: pmcx_shim_set_components
   public :: pmcx_shim_init, pmcx_shim_finalize, pmcx_set_rng, mc_coag_pmcx, &
        partmc_coag_cells_pmcx, aero_state_rebalance_cells_pmcx, aero_state_rebalance_pmcx, &
        pmcx_config
@@ -68,6 +71,7 @@ module pmcx_shim
   type(c_ptr), save :: ctx = c_null_ptr
   type(pmcx_config), save :: cfg
   logical, save :: have_ctx = .false.
+  integer, save :: want_comp_max = 8           ! entries of component(:) carried per particle
   integer(c_int64_t), save :: rng_seed = 0     ! grid%random_seed (wrf_pmc_init.F90:131)
   integer(c_int32_t), save :: rng_step = 0     ! chemistry-step index
   integer(c_int32_t), save :: cell_id_base = 0 ! global id of this rank's first cell
@@ -126,6 +130,13 @@ contains
     end if
   end subroutine pmcx_set_rng
 
+  !> How many entries of particle%component(:) the device carries per particle (0..8; 0: only
+  !> the source histogram).  Takes effect at the next upload that builds a context.
+  subroutine pmcx_shim_set_components(n)
+    integer, intent(in) :: n
+    want_comp_max = max(0, min(8, n))
+  end subroutine pmcx_shim_set_components
+
   subroutine pmcx_shim_init(n_cells, cap, aero_data, n_class, n_source, device)
     integer, intent(in) :: n_cells, cap, n_class, n_source, device
     type(aero_data_t), intent(in) :: aero_data
@@ -137,6 +148,8 @@ contains
     cfg%n_spec = size(aero_data%density)
     cfg%n_class = n_class
     cfg%n_source = n_source
+    cfg%n_comp_max = 0
+    if (n_source >= 1 .and. n_source <= 255) cfg%n_comp_max = want_comp_max
     cfg%i_water = aero_data%i_water - 1
     cfg%cell_id_base = cell_id_base
     call pmcx_die(pmcx_create(cfg, ctx), 'pmcx_create')
@@ -223,7 +236,8 @@ contains
        call pmcx_die(1, 'pmcx_upload_states')
     end if
     if (.not. have_ctx .or. cfg%n_cells /= n_cells .or. cfg%cap < cap_needed &
-         .or. cfg%n_spec /= n_spec .or. cfg%n_class /= n_class .or. cfg%n_source /= n_source) then
+         .or. cfg%n_spec /= n_spec .or. cfg%n_class /= n_class .or. cfg%n_source /= n_source &
+         .or. cfg%n_comp_max /= merge(want_comp_max, 0, n_source >= 1 .and. n_source <= 255)) then
        call pmcx_shim_init(n_cells, cap_needed, aero_data, n_class, n_source, 0)
     end if
 
@@ -286,6 +300,34 @@ contains
     end block
     call pmcx_die(pmcx_upload_cells(ctx, 0, n_cells, part_offset, vol, wclass, id, lct, gct, &
          p_norig), 'pmcx_upload_cells')
+    ! component(:) itself, the first n_comp_max entries of every particle (driver:1421-1437)
+    if (cfg%n_comp_max > 0) then
+       block
+         integer(c_int32_t), allocatable :: clen(:), csrc(:,:)
+         real(c_double), allocatable :: ctim(:,:)
+         integer :: kc, nk
+         kc = cfg%n_comp_max
+         allocate(clen(max(nt, 1_c_int64_t)), csrc(kc, max(nt, 1_c_int64_t)), ctim(kc, max(nt, 1_c_int64_t)))
+         clen = 0; csrc = -1; ctim = 0d0
+         do c = 1, n_cells
+            o = part_offset(c)
+            do i = 1, aero_states(c)%apa%n_part
+               nk = 0
+               do k = 1, aero_particle_n_components(aero_states(c)%apa%particle(i))
+                  s = aero_states(c)%apa%particle(i)%component(k)%source_id
+                  if (s < 1 .or. s > n_source) cycle   ! (as the histogram: not a source of aero_data)
+                  if (nk >= kc) exit
+                  nk = nk + 1
+                  csrc(nk, o + i) = s - 1
+                  ctim(nk, o + i) = aero_states(c)%apa%particle(i)%component(k)%create_time
+               end do
+               clen(o + i) = nk
+            end do
+         end do
+         call pmcx_die(pmcx_upload_components(ctx, 0, n_cells, part_offset, clen, csrc, ctim), &
+              'pmcx_upload_components')
+       end block
+    end if
   end subroutine upload_states_n
 
   !> ids(order(1)) <= ids(order(2)) <= ... (heap sort of an index array)
@@ -348,6 +390,9 @@ contains
     logical :: changed
     real(kind=dp) :: t_new
     type(c_ptr) :: p_norig
+    integer(c_int32_t), allocatable :: clen(:), csrc(:,:)
+    real(c_double), allocatable :: ctim(:,:)
+    integer :: kc
 
     n_spec = cfg%n_spec
     n_class = cfg%n_class
@@ -378,6 +423,12 @@ contains
     if (n_source > 0) p_norig = c_loc(n_orig)
     call pmcx_die(pmcx_download_cells(ctx, 0, n_cells, part_offset, vol, wclass, id, lct, gct, &
          p_norig), 'pmcx_download_cells')
+    kc = cfg%n_comp_max
+    if (kc > 0) then
+       allocate(clen(max(nt, 1_c_int64_t)), csrc(kc, max(nt, 1_c_int64_t)), ctim(kc, max(nt, 1_c_int64_t)))
+       call pmcx_die(pmcx_download_components(ctx, 0, n_cells, part_offset, clen, csrc, ctim), &
+            'pmcx_download_components')
+    end if
     allocate(have(max(n_source, 1)))
     do c = 1, n_cells
        o = part_offset(c)
@@ -450,7 +501,29 @@ contains
           new(i)%id = id(o + i)
           ! component(:) <- the source histogram: constituents the particle had keep their
           ! create_time; the ones it gained are appended with the bound that moved
-          if (n_source > 0) then
+          if (n_source > 0 .and. kc > 0) then
+             ! the list travelled with the particle: its first clen entries are exact; those a
+             ! particle of more than n_comp_max constituents has beyond them follow from the
+             ! histogram, created within the particle's create-time bounds
+             if (allocated(new(i)%component)) deallocate(new(i)%component)
+             n_add = sum(n_orig(o + i, 1:n_source))
+             allocate(comp(max(n_add, int(clen(o + i)))))
+             have = 0
+             do k = 1, clen(o + i)
+                comp(k)%source_id = csrc(k, o + i) + 1
+                comp(k)%create_time = ctim(k, o + i)
+                have(csrc(k, o + i) + 1) = have(csrc(k, o + i) + 1) + 1
+             end do
+             k = clen(o + i)
+             do s = 1, n_source
+                do mid = 1, n_orig(o + i, s) - have(s)
+                   k = k + 1
+                   comp(k)%source_id = s
+                   comp(k)%create_time = gct(o + i)
+                end do
+             end do
+             call move_alloc(comp, new(i)%component)
+          else if (n_source > 0) then
              have = 0
              n_have = aero_particle_n_components(new(i))
              do k = 1, n_have

@@ -23,7 +23,8 @@
 ! absorb_cross_sect(:) = id): the output shows where they ended up.
 ! out.bin: per step the counters; then per cell n_part and per particle the input record followed
 !          by int32 water_hyst_leg, float64 core_vol, float64 absorb_cross_sect(1), int32 n_components,
-!          float64 min and max of component(:)%create_time
+!          float64 min and max of component(:)%create_time; behind a cell's particles their
+!          component(:) lists one after the other, (int32 source_id, float64 create_time) per entry
 program test_shim
   use iso_c_binding
   use pmc_mock
@@ -222,6 +223,13 @@ program test_shim
         write(u) aero_states(c)%apa%particle(i)%absorb_cross_sect(1)
         write(u) n_comp
         write(u) t_lo, t_hi
+     end do
+     ! ... and the lists themselves, particle after particle
+     do i = 1, aero_states(c)%apa%n_part
+        do k = 1, aero_particle_n_components(aero_states(c)%apa%particle(i))
+           write(u) aero_states(c)%apa%particle(i)%component(k)%source_id
+           write(u) aero_states(c)%apa%particle(i)%component(k)%create_time
+        end do
      end do
   end do
   close(u)

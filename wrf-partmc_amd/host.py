@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "pmcx_config_default", "pmcx_create", "pmcx_destroy", "pmcx_last_error", "pmcx_synchronize",
     "pmcx_set_aero_data", "pmcx_set_env", "pmcx_set_weights", "pmcx_get_weights",
     "pmcx_set_n_part_ideal", "pmcx_set_next_id", "pmcx_get_next_id", "pmcx_upload_cells",
-    "pmcx_get_n_part", "pmcx_download_cells", "pmcx_update_kernel_bounds",
+    "pmcx_get_n_part", "pmcx_download_cells", "pmcx_upload_components", "pmcx_download_components", "pmcx_update_kernel_bounds",
     "pmcx_set_kernel_bounds_margin", "pmcx_mc_coag",
     "pmcx_get_coag_counters", "pmcx_get_coag_totals", "pmcx_accumulate_totals",
     "pmcx_read_accumulated", "pmcx_rebalance", "pmcx_condense",
@@ -85,6 +85,7 @@ class PmcxConfig(C.Structure):
         ("n_dbin", C.c_int32), ("i_water", C.c_int32), ("d_min", C.c_double),
         ("d_max", C.c_double), ("cell_id_base", C.c_uint32), ("compact_den", C.c_uint32),
         ("const_k", C.c_double), ("additive_beta", C.c_double),
+        ("n_comp_max", C.c_int32), ("pad_", C.c_int32),
     ]
 
 
@@ -207,6 +208,8 @@ def load_library():
                                                  C.c_void_p]
     for name in ("pmcx_upload_cells", "pmcx_download_cells"):
         getattr(L, name).argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 7
+    for name in ("pmcx_upload_components", "pmcx_download_components"):
+        getattr(L, name).argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 4
     _LIB = L
     return L
 
@@ -351,6 +354,31 @@ class CellBlock:
         self._ck(self._lib.pmcx_upload_cells(self._h, cell_first, n_up, _ptr(po), _ptr(v),
                                              _ptr(wc), _ptr(ii), _ptr(_f64(least_ct)),
                                              _ptr(_f64(greatest_ct)), _ptr(no)))
+
+    def upload_components(self, cell_first, part_offset, comp_len, comp_source, comp_time):
+        """particle%component(:) of the cells upload_cells has just laid out (driver:1421-1437):
+        comp_len [n], comp_source [n][n_comp_max] (0-based), comp_time [n][n_comp_max]."""
+        po = np.ascontiguousarray(part_offset, dtype=np.int64)
+        K, nt = self.cfg.n_comp_max, int(po[-1])
+        ln = np.ascontiguousarray(comp_len, dtype=np.int32)
+        sr = np.ascontiguousarray(comp_source, dtype=np.int32)
+        tm = _f64(comp_time)
+        assert ln.shape == (nt,) and sr.shape == (nt, K) and tm.shape == (nt, K), (ln.shape, sr.shape, tm.shape)
+        self._ck(self._lib.pmcx_upload_components(self._h, cell_first, len(po) - 1, _ptr(po), _ptr(ln),
+                                                  _ptr(sr), _ptr(tm)))
+
+    def download_components(self, cell_first=0, n_cells=None):
+        """dict(part_offset, comp_len [n], comp_source [n][n_comp_max] (-1 past the end), comp_time)."""
+        n_cells = self.cfg.n_cells - cell_first if n_cells is None else n_cells
+        npart = self.aero_state_total_particles()[cell_first:cell_first + n_cells]
+        po = np.zeros(n_cells + 1, dtype=np.int64)
+        po[1:] = np.cumsum(npart)
+        nt, K = int(po[-1]), self.cfg.n_comp_max
+        out = dict(part_offset=po, comp_len=np.zeros(nt, dtype=np.int32),
+                   comp_source=np.full((nt, K), -1, dtype=np.int32), comp_time=np.zeros((nt, K)))
+        self._ck(self._lib.pmcx_download_components(self._h, cell_first, n_cells, _ptr(po), _ptr(out["comp_len"]),
+                                                    _ptr(out["comp_source"]), _ptr(out["comp_time"])))
+        return out
 
     # -- column files (SURVEY f3) ------------------------------------------
     def output_column(self, prefix, ix, iy, index, cell_first, nz, species_names, time=0.0,
