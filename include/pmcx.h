@@ -359,8 +359,9 @@ int pmcx_boundary_resample(pmcx_ctx *ctx, int32_t n_list, const int32_t *cell, c
  * to hold after this transport (particles x magnitude, less prob x that towards every
  * destination, plus the same x dest_vol / source_vol where it arrives; accumulated in the
  * reference's order) and, where that is more than twice n_part_ideal, aero_state_scale_weight
- * by n_parts_new / n_part_ideal (the magnitude grows, every particle of the class stays with
- * probability n_part_ideal / n_parts_new).  periodic_x && periodic_y is the reference's "ideal"
+ * by n_parts_new / n_part_ideal (the magnitude grows by that ratio and exactly
+ * prob_round(n (1 - n_part_ideal / n_parts_new)) of the class's n particles, a uniformly random
+ * subset, leave).  periodic_x && periodic_y is the reference's "ideal"
  * case; otherwise lateral boundary cells only send inwards and corners nothing.  prob_h ==
  * prob_v == NULL: the probabilities pmcx_transport_probs built (they stay for the transport).
  * Outputs (may be NULL): expected_num_conc [n_cells][n_class], n_removed [n_cells].

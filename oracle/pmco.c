@@ -1235,20 +1235,24 @@ int pmco_transport(pmco_cell *cells, int n_cells, int nx, int nz, int ny, int pe
             const int cl = s->wclass[i];
             const trans_dest *t = tab + (size_t)cl * (4 + 128);
             if (ntab[cl] == 0) continue;
-            /* the destination uniform: 32 bits, four particles to a Philox block (word i & 3 of
-             * the block addressed by i >> 2); the uniform of the copies, needed only by a mover
-             * whose weight changes, from a block of its own */
+            /* the destination uniform starts with an 8-bit prefix, sixteen particles to a Philox
+             * block (byte i & 15 of the block addressed by i >> 4): prefix / 256 at or above the
+             * class's total probability of leaving says the particle stays.  One the prefix cannot
+             * tell for draws the rest from a block of its own -- u = (prefix + w0 2^-32) / 256, a
+             * uniform of 40 bits -- and from the same block the uniform of its copies. */
             uint32_t w[4];
-            pmco_rng_block(seed, cell_id_base + (uint32_t)c, step, (uint32_t)i >> 2, PMCO_SITE_TRANS, 0, w);
-            const double u = (double)w[i & 3] * 0x1.0p-32;
+            pmco_rng_block(seed, cell_id_base + (uint32_t)c, step, (uint32_t)i >> 4, PMCO_SITE_TRANS, 0, w);
+            const uint32_t p8 = (w[(i & 15) >> 2] >> (8 * (i & 3))) & 0xFFu;
+            if (!((double)p8 * 0x1.0p-8 < t[ntab[cl] - 1].hi)) continue;      /* stays */
+            pmco_rng_block(seed, cell_id_base + (uint32_t)c, step, (uint32_t)i, PMCO_SITE_TRANS, 1, w);
+            const double u = ((double)p8 + (double)w[0] * 0x1.0p-32) * 0x1.0p-8;
             if (!(u < t[ntab[cl] - 1].hi)) continue;      /* stays */
             int d = 0;
             while (!(u < t[d].hi)) d++;
             const double r = t[d].ratio;
             int copies = 1;
             if (r != 1.0) {
-                pmco_rng_block(seed, cell_id_base + (uint32_t)c, step, (uint32_t)i, PMCO_SITE_TRANS, 1, w);
-                const double u2 = pmco_u53(w[0], w[1]);
+                const double u2 = pmco_u53(w[2], w[3]);
                 if (r > 1.0) copies = (u2 < 1.0 / r) ? 1 : 0;
                 else {
                     copies = 1 + (int)(pmco_log(1.0 - u2) / pmco_log(1.0 - r));
@@ -1599,12 +1603,26 @@ int pmco_transport_preweight(pmco_cell *cells, int n_cells, int nx, int nz, int 
             const int n = *s->n_part;
             unsigned char *dead = (unsigned char *)calloc((size_t)(n > 0 ? n : 1), 1);
             int n_dead = 0;
-            for (int i = 0; i < n; i++) {
+            /* aero_state_scale_weight with weight_ratio > 1 [upstream, uncited]:
+             * n_remove = prob_round(n_class_members (1 - 1 / ratio)) particles chosen uniformly at
+             * random leave.  Here: the count from one uniform (key 0xFFFFFFFF), the subset by
+             * selection sampling in slot order -- member t of n goes when u (n - t) < still to go,
+             * a uniformly random subset of exactly that size. */
+            int n_cls = 0;
+            for (int i = 0; i < n; i++) n_cls += (s->wclass[i] == cl);
+            uint32_t w[4];
+            pmco_rng_block(seed, cell_id_base + (uint32_t)c, step, 0xFFFFFFFFu, PMCO_SITE_SCALE, (uint32_t)cl, w);
+            const double x_rm = (double)n_cls * p_drop;
+            const double x_fl = (double)(int64_t)x_rm;
+            int m_rm = (int)x_fl + ((pmco_u53(w[0], w[1]) < x_rm - x_fl) ? 1 : 0);
+            if (m_rm > n_cls) m_rm = n_cls;
+            int t = 0;
+            for (int i = 0; i < n && n_dead < m_rm; i++) {
                 if (s->wclass[i] != cl) continue;
-                uint32_t w[4];
                 pmco_rng_block(seed, cell_id_base + (uint32_t)c, step, (uint32_t)i, PMCO_SITE_SCALE,
                                (uint32_t)cl, w);
-                if (pmco_u53(w[0], w[1]) < p_drop) { dead[i] = 1; n_dead++; }
+                if (pmco_u53(w[0], w[1]) * (double)(n_cls - t) < (double)(m_rm - n_dead)) { dead[i] = 1; n_dead++; }
+                t++;
             }
             compact_stable(s, dead, n, n_dead);
             free(dead);

@@ -301,9 +301,10 @@ int pmco_transport_lateral(pmco_cell *cells, int n_cells, int nx, int nz, int ny
  * reference's order (sources in j, k, i order; within a source j-1, j+1, i-1, i+1, then the
  * levels; what crosses a periodic edge gathers in a ghost cell and is added afterwards, y edges
  * before x edges) -- and, where that exceeds twice n_part_ideal, aero_state_scale_weight by
- * n_parts_new / n_part_ideal: the magnitude grows by the ratio and every particle of the class
- * stays with probability 1 / ratio ([upstream, uncited: a prob_round'ed number of random
- * removals]; here one uniform per particle, site SCALE, as the halving of the rebalance).
+ * n_parts_new / n_part_ideal: the magnitude grows by the ratio and
+ * prob_round(n (1 - 1 / ratio)) of the class's n particles, chosen uniformly at random, leave
+ * ([upstream, uncited]; here the count from one uniform, the subset by selection sampling in slot
+ * order, site SCALE).
  * ideal = periodic_x && periodic_y (:1183-1184); otherwise the lateral boundary cells only send
  * inwards and the corner cells nothing (:1510-1565).  prob_h / prob_v / cell_volume as for
  * pmco_transport; n_ideal [n_cells][n_class].  expected [n_cells][n_class] (= expected_num_conc),

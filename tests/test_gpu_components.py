@@ -86,3 +86,31 @@ def test_components_need_a_source_table(wp):
     with pytest.raises(wp.PmcxError):
         blk.download_components()
     blk.close()
+
+
+def test_column_file_carries_the_lists(wp, oracle, tmp_path, carried):
+    """f3 with a5: output_column writes aero_component_* from the lists on the device, a fresh block
+    restarted from the file holds the same lists (wrf_pmc_driver.F90:1421-1437 -> wrf_pmc_init.F90
+    restart reader), and a particle of more constituents than a slot holds gets the rest from its
+    histogram."""
+    from wrf_partmc_amd import ncio
+    K = carried
+    blk, cells, info = parity.setup_pair(wp, oracle, 3, 800, 2, 2, 21, 4, cap=1024, n_source=3, num_conc_scale=20.0)
+    for step in range(3):
+        blk.mc_coag(4, 3000.0, 21, step)
+    path = blk.output_column(str(tmp_path / "col"), 1, 2, 3, 0, 3, ["SO4", "OC"])
+    dn, cm = blk.download_cells(), blk.download_components()
+    col = ncio.read_column(path)
+    tot = dn["n_orig"].sum(0)
+    assert np.array_equal(col["comp_len"], tot) and (tot > 1).sum() > 100
+    for i in np.flatnonzero(tot > 1)[:400]:
+        k = int(cm["comp_len"][i])
+        assert np.array_equal(col["comp_source"][i, :k], cm["comp_source"][i, :k])
+        assert np.array_equal(col["comp_time"][i, :k], cm["comp_time"][i, :k])
+    b2 = wp.CellBlock(3, 1024, 2, n_class=2, n_source=3, n_comp_max=K)
+    b2.set_aero_data(info["dens"]); b2.set_env(280.0, 9e4)
+    b2.restart_column(path, 0)
+    cm2 = b2.download_components()
+    for k in ("comp_len", "comp_source", "comp_time"):
+        assert np.array_equal(cm2[k], cm[k]), k
+    blk.close(); b2.close()

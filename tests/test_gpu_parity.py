@@ -1083,11 +1083,20 @@ def test_transport_preweight_parity(wp, oracle, periodic, n_class):
     for step in range(2):
         # explicit probabilities first ...
         ph = r.uniform(0.0, 0.06, (n_cells, n_class, 4)); pv = r.uniform(0.0, 0.04, (n_cells, n_class, nz))
+        cls_n = lambda: np.array([[int((oc.wclass[:int(oc.n_part[0])] == q).sum()) for q in range(n_class)]
+                                  for oc in cells])
+        n0, mag0 = cls_n(), np.array([oc.mag for oc in cells])
         ex, nr = blk.transport_preweight(nx, nz, ny, ph, pv, cv, 23, step, periodic, periodic)
         oex, onr = oracle.transport_preweight(cells, nx, nz, ny, ph, pv, cv, n_ideal, 23, 0, step, periodic,
                                               periodic)
         assert np.array_equal(ex, oex), (step, np.abs(ex - oex).max())
         assert np.array_equal(nr, onr)
+        # aero_state_scale_weight: a scaled class loses prob_round(n (1 - 1 / ratio)) particles -- the
+        # count is one of the two integers around that, never a binomial's spread
+        ratio = np.array([oc.mag for oc in cells]) / mag0
+        x = n0 * (1.0 - 1.0 / ratio)
+        gone = n0 - cls_n()
+        assert (gone[ratio == 1.0] == 0).all() and ((gone >= np.floor(x)) & (gone <= np.floor(x) + 1)).all()
         ok, msg = parity.compare_state(blk, cells)
         assert ok, f"step {step} after preweight: {msg}"
         assert np.array_equal(blk.get_weights(), np.array([oc.mag for oc in cells]))

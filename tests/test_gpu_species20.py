@@ -214,4 +214,7 @@ def test_config4_shape_column_through_the_fortran_shim(tmp_path, wp, oracle):
         ids = blob[:, o + 4:o + 12].copy().view("<i8")[:, 0]
         assert np.array_equal(vol.T, oc.vol[:, :n]), c
         assert np.array_equal(ids, oc.id[:n]), c
+        ncomp = blob[:, o + 48:o + 52].copy().view("<i4")[:, 0]     # the component(:) lists follow the cell
+        assert np.array_equal(ncomp, oc.n_orig[:, :n].sum(0)), c
+        off += 12 * int(ncomp.sum())
     assert off == len(out)

@@ -667,6 +667,59 @@ def test_cdf5_encoder_against_a_hand_assembled_file(tmp_path):
     assert vs["aero_id"][1] == {"unit": "1"} and list(vs["x"][0]) == [0.5, -1.0, 2.0]
 
 
+def test_column_writer_against_the_assembled_cdf5_column(tmp_path):
+    """SURVEY f3 / the whole variable set of output_column_to_file_new (wrf_pmc_driver.F90:1372-1379,
+    1478-1653), aero_component_* with per-constituent create times included: write_column must
+    reproduce, byte for byte, the file tests/golden/make_cdf5_column.py assembles from the format
+    grammar with code of its own (tests/golden/cdf5_column.hex, every field annotated), and
+    read_column must give back the values that script states."""
+    from wrf_partmc_amd import ncio
+    here = os.path.dirname(os.path.abspath(__file__))
+    text = open(os.path.join(here, "golden", "cdf5_column.hex")).read()
+    want = bytes.fromhex("".join(ln.split("#")[0] for ln in text.splitlines()).replace(" ", ""))
+    assert len(want) == 5988 and want[:4] == b"CDF\x05"
+    dens = np.array([1800.0, 1700.0])
+    vol = np.array([[1e-21, 2.5e-21, 4e-22], [0.0, 5e-22, 6e-22]])
+    ids = np.array([7, (3 << 32) + 11, (1 << 40) + 2], dtype=np.int64)
+    lct, gct = np.array([0.0, 12.5, 300.0]), np.array([0.0, 86400.25, 300.0])
+    n_orig = np.array([[1, 2, 0], [0, 1, 1]])
+    comp_len = np.array([1, 3, 1]); comp_source = np.array([[0, -1, -1], [1, 0, 0], [1, -1, -1]])
+    comp_time = np.array([[0.0, 0, 0], [86400.25, 12.5, 3600.0], [300.0, 0, 0]])
+    path = str(tmp_path / "col.nc")
+    ncio.write_column(path, species_names=["SO4", "BC"], density=dens, part_offset=[0, 2, 3], vol=vol,
+                      wclass=[0, 0, 0], ids=ids, least_ct=lct, greatest_ct=gct, n_orig=n_orig,
+                      weight_magnitude=[[2.5e7], [1.25e7]], next_id=(1 << 40) + 3, time=7200.0, del_t=60.0,
+                      index=120, kappa=[0.65, 0.0], molec_weight=[0.096, 0.001], source_names=["traffic", "sea"],
+                      gas_names=["o3"], gas_mixing_ratio=[[41.5], [38.25]],
+                      uuid="c0ffee00-0000-4000-8000-000000000001", cell_ix=12, cell_iy=7,
+                      comp_len=comp_len, comp_source=comp_source, comp_time=comp_time)
+    got = open(path, "rb").read()
+    if got != want:
+        k = next(i for i in range(min(len(got), len(want))) if got[i] != want[i])
+        raise AssertionError(f"first difference at byte {k}: {got[k - 8:k + 24].hex()} != {want[k - 8:k + 24].hex()}")
+    fx = str(tmp_path / "fixture.nc")
+    open(fx, "wb").write(want)
+    col = ncio.read_column(fx)
+    assert list(col["part_offset"]) == [0, 2, 3] and col["next_id"] == (1 << 40) + 3 and col["index"] == 120
+    assert np.array_equal(col["ids"], ids) and np.array_equal(col["n_orig"], n_orig)
+    assert np.array_equal(col["comp_len"], comp_len) and np.array_equal(col["comp_source"], comp_source)
+    assert np.array_equal(col["comp_time"], comp_time)
+    assert np.array_equal(col["least_ct"], lct) and np.array_equal(col["greatest_ct"], gct)
+    np.testing.assert_allclose(col["vol"], vol, rtol=3e-16, atol=0)
+    assert np.array_equal(col["weight_magnitude"], [[2.5e7], [1.25e7]]) and np.array_equal(col["gas_mixing_ratio"], [[41.5], [38.25]])
+    # without the lists the writer expands the histogram: the same particles, source order, bounds as times
+    ncio.write_column(path, species_names=["SO4", "BC"], density=dens, part_offset=[0, 2, 3], vol=vol,
+                      wclass=[0, 0, 0], ids=ids, least_ct=lct, greatest_ct=gct, n_orig=n_orig,
+                      weight_magnitude=[[2.5e7], [1.25e7]], next_id=1)
+    col = ncio.read_column(path)
+    assert col["comp_source"].tolist() == [[0, -1, -1], [0, 0, 1], [1, -1, -1]]
+    assert col["comp_time"].tolist() == [[0.0, 0, 0], [12.5, 86400.25, 86400.25], [300.0, 0, 0]]
+    # a netCDF-4 (HDF5) container is named for what it is
+    open(path, "wb").write(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
+    with pytest.raises(ValueError, match="nccopy -k cdf5"):
+        ncio.read_cdf(path)
+
+
 def test_column_file_round_trip(oracle, tmp_path):
     """a column written in the layout of output_column_to_file_new
     (wrf_pmc_driver.F90:1508-1653) and read back the way init_read_in_restart does
@@ -681,9 +734,10 @@ def test_column_file_round_trip(oracle, tmp_path):
     counts = [300, 0, 120, 77]
     cells = []
     for k, n in enumerate(counts):
-        c = oracle.Cell(20, 2, 3, 512, dens, ve, 280.0, 9e4)
+        c = oracle.Cell(20, 2, 3, 512, dens, ve, 280.0, 9e4, n_comp_max=2)
         c.mag[:] = [1e7 + k, 3e7 + k]
         c.generate(modes, n, 2, k, first_id=(k << 40) + 5)
+        c.lct[:n] = c.gct[:n] = c.comp_time[:n, 0] = 10.0 * k + 0.01 * np.arange(n)
         c.kmax[:] = oracle.kmax_table(4, vs, dens.min(), dens.max(), 280.0, 9e4)
         for s in range(3):
             c.mc_coag(4, 4000.0, 2, k, s)           # merged particles: several constituents
@@ -694,12 +748,14 @@ def test_column_file_round_trip(oracle, tmp_path):
     state = dict(vol=cat(lambda c, n: c.vol[:, :n]), wclass=cat(lambda c, n: c.wclass[:n]),
                  ids=cat(lambda c, n: c.id[:n]), least_ct=cat(lambda c, n: c.lct[:n]),
                  greatest_ct=cat(lambda c, n: c.gct[:n]), n_orig=cat(lambda c, n: c.n_orig[:, :n]))
+    lists = dict(comp_len=cat(lambda c, n: c.comp_n[:n]), comp_source=cat(lambda c, n: c.comp_src[:n].T).T,
+                 comp_time=cat(lambda c, n: c.comp_time[:n].T).T)
     wmag = np.array([c.mag for c in cells])
     path = ncio.column_filename(str(tmp_path / "out"), 12, 7, 42)
     assert path.endswith("out_012_007_00000042.nc")
     ncio.write_column(path, species_names=names, density=dens, part_offset=po, weight_magnitude=wmag,
                       next_id=(9 << 40) + 1, time=126.0, del_t=3.0, index=42, kappa=kappa,
-                      molec_weight=mw, gas_names=["so2", "o3"], gas_mixing_ratio=np.ones((4, 2)), **state)
+                      molec_weight=mw, gas_names=["so2", "o3"], gas_mixing_ratio=np.ones((4, 2)), **state, **lists)
     dims, gatts, v = ncio.read_cdf(path)
     assert dims["number_levels"] == 4 and dims["aero_particle"] == po[-1] and dims["aero_species"] == 20
     assert dims["aero_weight_class"] == 2 and dims["aero_weight_group"] == 1
@@ -717,6 +773,19 @@ def test_column_file_round_trip(oracle, tmp_path):
     for k in ("wclass", "ids", "least_ct", "greatest_ct", "n_orig"):
         assert np.array_equal(back[k], state[k]), k
     assert np.array_equal(back["weight_magnitude"], wmag) and back["time"] == 126.0 and back["index"] == 42
+    # aero_component_* (driver:1421-1437): the lists the cells carry (two entries here), then what
+    # the histogram holds beyond them; scalars have no dimension
+    assert v["time"][2] == [] and v["next_id"][2] == [] and "scalar" not in dims
+    tot = state["n_orig"].sum(0)
+    assert (tot > 2).any() and np.array_equal(back["comp_len"], tot) and back["comp_source"].shape[1] == tot.max()
+    for i in range(int(po[-1])):
+        k = int(lists["comp_len"][i])
+        assert np.array_equal(back["comp_source"][i, :k], lists["comp_source"][i, :k]), i
+        assert np.array_equal(back["comp_time"][i, :k], lists["comp_time"][i, :k]), i
+        assert (back["comp_time"][i, k:tot[i]] == state["greatest_ct"][i]).all(), i
+        assert np.array_equal(np.bincount(back["comp_source"][i, :tot[i]], minlength=3), state["n_orig"][:, i]), i
+    assert "create time" not in v["aero_component_create_time"][1].get("description", "")
+    assert v["aero_least_create_time"][1]["description"].startswith("least (earliest) creation time")
     # mass = vol * density, vol = mass / density (:1421, init:1232): exact to one rounding each way
     np.testing.assert_allclose(back["vol"], state["vol"], rtol=3e-16, atol=0)
 

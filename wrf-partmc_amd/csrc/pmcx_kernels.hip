@@ -3250,10 +3250,12 @@ __global__ __launch_bounds__(256) void k_dry_deposition(DeviceState st, DepArgs 
 // (every particle draws its own destination; see oracle/pmco.c for the law).
 //   k_trans_decide  one wavefront per source cell: destination tables of each
 //                   class in LDS (sorted by probability, cumulative thresholds,
-//                   weight ratios), a 32-bit destination uniform per live particle (four
-//                   particles to a Philox block, addressed by rank), movers
+//                   weight ratios), an 8-bit prefix of the destination uniform per live particle
+//                   (sixteen particles to a Philox block, addressed by rank) that settles who
+//                   stays; the few it cannot tell for are queued and finished 64 at a time (the
+//                   rest of the uniform and the copies from a block of their own); movers
 //                   compacted into the cell's outbox in rank order; a mover's sort key is
-//                   marked dead here, in the line just read
+//                   marked dead here
 //   k_trans_gather  one wavefront per destination cell: scans the outboxes of
 //                   its sources in a fixed order, appends the arrivals and leaves each
 //                   mover's tombstone in the record it has just read
@@ -3420,11 +3422,14 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
     // (one class: the stay-or-go threshold is the same for every particle of the cell)
     const double hi_last0 = t_n[0] > 0 ? t_hi[t_n[0] - 1] : 0.0;
     __shared__ __align__(16) uint32_t s_words[256];
-    // The destination uniform of the particle of rank r is 32 bits: word r & 3 of the Philox block
-    // addressed by r >> 2 -- four particles to a block.  A trip covers 4 x 63 slots: their ranks
-    // span fewer than 256, i.e. at most 64 blocks from (rank of the trip's first particle) >> 2 on,
-    // one per lane; the lanes lay their words side by side in LDS and a particle reads its own.  Only a mover
-    // whose weight changes on the way draws again (the number of copies), from a block of its own.
+    __shared__ uint32_t s_qent[128], s_qrank[128]; // particles the prefix cannot tell for: slot | prefix << 16 | class << 24, rank
+    // The destination uniform of the particle of rank r starts with an 8-bit prefix: byte r & 15 of
+    // the Philox block addressed by r >> 4 -- sixteen particles to a block.  prefix / 256 at or above
+    // the class's total probability of leaving says "stays" (u >= prefix / 256), which settles all
+    // but a few per cent of the particles; one the prefix cannot tell for draws the rest from a
+    // block of its own, u = (prefix + w0 2^-32) / 256, and from the same block the uniform of its
+    // copies.  64 blocks (one per lane, side by side in LDS) cover 1024 ranks, four trips of 4 x 63
+    // slots; the undecided are queued in rank order and evaluated 64 at a time, dense lanes.
     // (the keys of the next trip are requested before this trip's work: a wavefront alone with
     // its cell would otherwise wait out a memory round trip forty times)
     auto key_of_slot = [&](int sl) -> uint32_t { return (lane < 63 && sl < n_hi) ? (uint32_t)gk[sl] : 0xFFFFu; };
@@ -3436,11 +3441,62 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
         else if ((q + 1u) * (uint32_t)Bn <= kq) q++;
         return (int)q;
     };
+    int queued = 0; // entries in the queue (uniform)
+    // the first `take` queued particles: the rest of their uniform, destination, copies, outbox
+    auto evaluate = [&](int take) {
+        const uint32_t ent = lane < take ? s_qent[lane] : 0u, rank = lane < take ? s_qrank[lane] : 0u;
+        const int s = (int)(ent & 0xFFFFu), cl = (int)(ent >> 24);
+        bool moves = false;
+        int dest = 0, copies = 0, dslot = 0;
+        if (lane < take) {
+            uint32_t w[4];
+            rng_block(seed, cell_id, step, rank, SITE_TRANS, 1, w);
+            const double u = ((double)((ent >> 16) & 0xFFu) + (double)w[0] * 0x1.0p-32) * 0x1.0p-8;
+            const int nt = t_n[cl];
+            if (u < t_hi[cl * ND + nt - 1]) {
+                // the first threshold above u, looked for from the top: the probabilities are in
+                // ascending order, the last few destinations hold most of the mass
+                int d = nt - 1;
+                while (d > 0 && u < t_hi[cl * ND + d - 1]) d--;
+                const double r = t_ratio[cl * ND + d];
+                copies = 1;
+                if (r != 1.0) {
+                    const double u2 = u53(w[2], w[3]);
+                    if (r > 1.0) copies = (u2 < 1.0 / r) ? 1 : 0;
+                    else {
+                        copies = 1 + (int)(det_log(1.0 - u2) / det_log(1.0 - r));
+                        if (copies > TRANS_MAX_COPIES) copies = TRANS_MAX_COPIES;
+                    }
+                }
+                dslot = cl * ND + d;
+                dest = t_dest[dslot];
+                bits |= t_bit[dslot];
+                moves = true;
+            }
+        }
+        const uint64_t mm = __ballot(moves);
+        if (moves) box[n_out + (uint32_t)__popcll(mm & lt)] = make_int2(s | (copies << 16), dest);
+        // (a mover's sort key says "gone" from here on; its record lives until the gather of its
+        // destination, or k_trans_remove, has dealt with it)
+        if (moves && keyed) st.gkey[cb + s] = (uint16_t)0xFFFFu;
+        if (moves && copies > 0) atomicAdd(&t_cnt[dslot], copies);
+        n_out += (uint32_t)__popcll(mm);
+        // what is left moves to the front of the queue
+        lds_sync();
+        const int rest = queued - take;
+        uint32_t re = 0, rr = 0;
+        if (lane < rest) { re = s_qent[take + lane]; rr = s_qrank[take + lane]; }
+        lds_sync();
+        if (lane < rest) { s_qent[lane] = re; s_qrank[lane] = rr; }
+        queued = rest;
+        lds_sync();
+    };
     uint32_t knext[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
     if (keyed) {
 #pragma unroll
         for (int ch = 0; ch < 4; ch++) knext[ch] = key_of_slot(ch * 63 + lane);
     }
+    uint32_t B0 = 0, covered = 0; // the blocks in LDS cover ranks [16 B0, covered)
     for (int i0 = 0; i0 < n_hi; i0 += 4 * 63) {
         int cls[4];
         if (keyed) {
@@ -3452,58 +3508,37 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
 #pragma unroll
             for (int ch = 0; ch < 4; ch++) cls[ch] = lane < 63 ? slot_class(i0 + ch * 63 + lane) : -1;
         }
-        const uint32_t B0 = rank0 >> 2;
-        uint32_t wb[4];
-        rng_block(seed, cell_id, step, B0 + (uint32_t)lane, SITE_TRANS, 0, wb);
-        // the trip's 256 words side by side in LDS: the particle of rank r reads word r - 4 B0
-        lds_sync(); // (the previous trip's reads are done)
-        *(uint4 *)&s_words[4 * lane] = make_uint4(wb[0], wb[1], wb[2], wb[3]);
-        lds_sync();
+        if (rank0 + 4u * 63u > covered) { // (uniform) the next 64 blocks, one per lane
+            B0 = rank0 >> 4;
+            covered = 16u * (B0 + 64u);
+            uint32_t wb[4];
+            rng_block(seed, cell_id, step, B0 + (uint32_t)lane, SITE_TRANS, 0, wb);
+            lds_sync(); // (the previous trips' reads are done)
+            *(uint4 *)&s_words[4 * lane] = make_uint4(wb[0], wb[1], wb[2], wb[3]);
+            lds_sync();
+        }
 #pragma unroll
         for (int ch = 0; ch < 4; ch++) {
             const int s = i0 + ch * 63 + lane, cl = cls[ch];
             const uint64_t mlive = __ballot(cl >= 0);
             const uint32_t rank = rank0 + (uint32_t)__popcll(mlive & lt);
-            const uint32_t wsel = s_words[(rank - 4u * B0) & 255u];
-            bool moves = false;
-            int dest = 0, copies = 0, dslot = 0;
-            const double u = (double)wsel * 0x1.0p-32;
+            const uint32_t idx = (rank - 16u * B0) & 1023u;
+            const uint32_t p8 = (s_words[idx >> 2] >> (8u * (idx & 3u))) & 0xFFu;
             // (one class: no table look-up for the particles that stay, almost all of them)
-            if (cl >= 0 && (C == 1 ? u < hi_last0 : t_n[cl] > 0)) {
-                const int nt = t_n[cl];
-                if (u < t_hi[cl * ND + nt - 1]) {
-                    // the first threshold above u, looked for from the top: the probabilities are in
-                    // ascending order, the last few destinations hold most of the mass
-                    int d = nt - 1;
-                    while (d > 0 && u < t_hi[cl * ND + d - 1]) d--;
-                    const double r = t_ratio[cl * ND + d];
-                    copies = 1;
-                    if (r != 1.0) {
-                        uint32_t w[4];
-                        rng_block(seed, cell_id, step, rank, SITE_TRANS, 1, w);
-                        const double u2 = u53(w[0], w[1]);
-                        if (r > 1.0) copies = (u2 < 1.0 / r) ? 1 : 0;
-                        else {
-                            copies = 1 + (int)(det_log(1.0 - u2) / det_log(1.0 - r));
-                            if (copies > TRANS_MAX_COPIES) copies = TRANS_MAX_COPIES;
-                        }
-                    }
-                    dslot = cl * ND + d;
-                    dest = t_dest[dslot];
-                    bits |= t_bit[dslot];
-                    moves = true;
-                }
+            const bool need = cl >= 0 && (double)p8 * 0x1.0p-8 < (C == 1 ? hi_last0 : (t_n[cl] > 0 ? t_hi[cl * ND + t_n[cl] - 1] : 0.0));
+            const uint64_t mneed = __ballot(need);
+            if (need) {
+                const int pos = queued + __popcll(mneed & lt);
+                s_qent[pos] = (uint32_t)s | (p8 << 16) | ((uint32_t)cl << 24);
+                s_qrank[pos] = rank;
             }
-            const uint64_t mm = __ballot(moves);
-            if (moves) box[n_out + (uint32_t)__popcll(mm & lt)] = make_int2(s | (copies << 16), dest);
-            // (a mover's sort key says "gone" from here on -- in the line just read; its record
-            // lives until the gather of its destination, or k_trans_remove, has dealt with it)
-            if (moves && keyed) st.gkey[cb + s] = (uint16_t)0xFFFFu;
-            if (moves && copies > 0) atomicAdd(&t_cnt[dslot], copies);
-            n_out += (uint32_t)__popcll(mm);
+            queued += __popcll(mneed);
             rank0 += (uint32_t)__popcll(mlive);
+            if (mneed) lds_sync();
+            if (queued >= 64) evaluate(64);
         }
     }
+    if (queued > 0) evaluate(queued);
     // the arrivals each destination has to expect: one atomic per destination, not per mover
     wave_sync();
     for (int x = lane; x < C * ND; x += 64)
@@ -4116,22 +4151,49 @@ __global__ __launch_bounds__(64) void k_preweight_scale(DeviceState st, Preweigh
         const double ratio = n_parts_new / ideal_n;
         const double p_drop = 1.0 - 1.0 / ratio;
         const int n_hi = st.n_hi[c], n_live = st.n_part[c];
+        // aero_state_scale_weight, weight_ratio > 1 [upstream, uncited]: exactly
+        // prob_round(n (1 - 1 / ratio)) of the class's n particles leave, a uniformly random subset
+        // (here selection sampling in rank order, as k_boundary_resample: member t goes when
+        // u (n - t) < still to go)
+        int n_before = n_live;
+        if (C > 1) {
+            uint32_t cnt = 0;
+            for (int i = lane; i < n_hi; i += 64) cnt += (live_class_c(st, cb, i) == cl);
+            n_before = (int)wave_sum_u64(cnt);
+        }
+        uint32_t w[4];
+        rng_block(seed, cell_id, step, 0xFFFFFFFFu, SITE_SCALE, (uint32_t)cl, w);
+        const double x_rm = (double)n_before * p_drop;
+        const double x_fl = (double)(int64_t)x_rm;
+        int m_rm = (int)x_fl + ((u53(w[0], w[1]) < x_rm - x_fl) ? 1 : 0);
+        m_rm = m_rm < n_before ? m_rm : n_before;
         uint32_t nd = 0, rank0 = 0;
-        for (int i0 = 0; i0 < n_hi; i0 += 64) {
+        int t0 = 0, k_rm = 0; // class members seen, removed so far (uniform)
+        for (int i0 = 0; i0 < n_hi && k_rm < m_rm; i0 += 64) {
             const int i = i0 + lane;
             const int wc = i < n_hi ? live_class_c(st, cb, i) : -1;
             const uint64_t mlive = __ballot(wc >= 0);
-            const uint32_t rank = rank0 + (uint32_t)__popcll(mlive & lt);
-            bool drop = false;
+            const uint64_t mcls = __ballot(wc == cl);
+            double u = 0.0;
             if (wc == cl) {
-                uint32_t w[4];
-                rng_block(seed, cell_id, step, rank, SITE_SCALE, (uint32_t)cl, w);
-                drop = u53(w[0], w[1]) < p_drop;
+                rng_block(seed, cell_id, step, rank0 + (uint32_t)__popcll(mlive & lt), SITE_SCALE, (uint32_t)cl, w);
+                u = u53(w[0], w[1]);
             }
-            if (drop) mark_dead(st, cb, i);
-            nd += (uint32_t)__popcll(__ballot(drop));
+            uint64_t msel = 0, rest = mcls;
+            int t = t0;
+            while (rest) {
+                const int l = __builtin_ctzll(rest);
+                rest &= rest - 1;
+                const double ul = u2d(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(d2u(u) >> 32), l) << 32) |
+                                      (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)d2u(u), l));
+                if (ul * (double)(n_before - t) < (double)(m_rm - k_rm)) { msel |= 1ull << l; k_rm++; }
+                t++;
+            }
+            t0 = t;
+            if ((msel >> lane) & 1ull) mark_dead(st, cb, i);
             rank0 += (uint32_t)__popcll(mlive);
         }
+        nd = (uint32_t)k_rm;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
         if (lane == 0) {

@@ -387,6 +387,9 @@ class CellBlock:
         output_column_to_file_new (wrf_pmc_driver.F90:1292-1658); returns the path."""
         from . import ncio
         dn = self.download_cells(cell_first, nz)
+        if self.cfg.n_comp_max > 0:         # particle%component(:) as the device carries it (driver:1421-1437)
+            cm = self.download_components(cell_first, nz)
+            extra.update(comp_len=cm["comp_len"], comp_source=cm["comp_source"], comp_time=cm["comp_time"])
         path = ncio.column_filename(prefix, ix, iy, index)
         ncio.write_column(
             path, species_names=species_names, density=self._density, part_offset=dn["part_offset"],
@@ -409,6 +412,11 @@ class CellBlock:
             no = np.vstack([no, np.zeros((self.cfg.n_source - no.shape[0], no.shape[1]), np.int32)])
         self.upload_cells(cell_first, col["part_offset"], col["vol"], col["wclass"], col["ids"],
                           col["least_ct"], col["greatest_ct"], no if self.cfg.n_source > 0 else None)
+        if self.cfg.n_comp_max > 0:         # the lists of the file, cut at what a slot holds
+            K, have = self.cfg.n_comp_max, col["comp_source"].shape[1]
+            src = np.full((len(col["comp_len"]), K), -1, np.int32); tim = np.zeros((len(col["comp_len"]), K))
+            src[:, :min(K, have)] = col["comp_source"][:, :K]; tim[:, :min(K, have)] = col["comp_time"][:, :K]
+            self.upload_components(cell_first, col["part_offset"], np.minimum(col["comp_len"], K), src, tim)
         w = self.get_weights()
         w[cell_first:cell_first + nz] = col["weight_magnitude"]
         self.set_weights(w)

@@ -11,10 +11,22 @@ the encoder/decoder below is self-contained (the file format is short: header of
 attribute and variable lists, then the big-endian arrays, each padded to 4 bytes); it also
 speaks CDF-2, which is how it is cross-checked against `scipy.io.netcdf_file` in the tests.
 
-What the device state does not carry: the per-constituent `aero_component` records are
-expanded from the per-source histogram `n_orig` (one component per constituent, all with the
-particle's least create time), gas mixing ratios are passed through as given (MOSAIC is out
+The `aero_component_*` records are the particles' own lists (`particle%component(:)`, driver:1421-1437)
+when the block carries them (`pmcx_config.n_comp_max`, CellBlock.download_components); constituents a
+particle has beyond the entries carried -- or all of them without lists -- are expanded from the
+per-source histogram `n_orig` in source order, the first created at the particle's least create
+time and the others at its greatest.  Gas mixing ratios are passed through as given (MOSAIC is out
 of scope), optical properties are not written (`record_optical = .false.`).
+
+Container [UPSTREAM-UNCITED]: which format `pmc_nc_open_write` creates is decided in PartMC's netcdf
+module (absent submodule).  `aero_id` and `next_id` are written with `pmc_nc_write_integer64*`
+(driver:1553,1652), i.e. NF90_INT64, which the classic CDF-1/2 formats cannot hold: the reference's
+files are therefore either CDF-5 (NF90_64BIT_DATA) or netCDF-4/HDF5 (NF90_NETCDF4).  This module
+writes and reads CDF-5; a netCDF-4 file is recognised by its HDF5 signature and refused with the
+conversion that makes it readable (`nccopy -k cdf5 in.nc out.nc`); any netCDF library >= 4.4 opens
+what is written here.  Scalars (`time`, `timestep`, `timestep_index`, `next_id`) are variables
+without dimensions, as `pmc_nc_write_real` / `_integer` / `_integer64` define them upstream; the
+reader also accepts them with a dimension of length one.
 """
 import struct
 
@@ -130,6 +142,9 @@ def read_cdf(path):
     """Reads a CDF-1/2/5 file without record variables: (dims dict, global attrs dict,
     variables dict name -> (array, attrs, dim names))."""
     buf = open(path, "rb").read()
+    if buf[:8] == b"\x89HDF\r\n\x1a\n":
+        raise ValueError(f"{path}: a netCDF-4 (HDF5) file; this reader speaks the classic formats -- convert "
+                         f"with `nccopy -k cdf5 {path} out.nc` (the data model is the same)")
     if buf[:3] != b"CDF" or buf[3] not in (1, 2, 5):
         raise ValueError(f"{path}: not a classic-model NetCDF file (magic {buf[:4]!r})")
     v5 = buf[3] == 5
@@ -207,15 +222,58 @@ def column_filename(prefix, ix, iy, index):
     return f"{prefix}_{ix:03d}_{iy:03d}_{index:08d}.nc"
 
 
+def component_records(n_orig, least_ct, greatest_ct, comp_len=None, comp_source=None, comp_time=None):
+    """aero_component_len / _start_ind / _particle_num / _source_num / _create_time
+    (wrf_pmc_driver.F90:1421-1437) of n_total particles: the entries of the lists given
+    (comp_len [n], comp_source [n][K] 0-based, comp_time [n][K]; None: no lists), then what the
+    histogram n_orig [n_source][n] holds beyond them, in source order -- created at the particle's
+    greatest create time, or at its least if it is the particle's first entry."""
+    n_orig = np.asarray(n_orig, dtype=np.int64)
+    n_source, nt = n_orig.shape
+    least_ct = np.asarray(least_ct, dtype=np.float64); greatest_ct = np.asarray(greatest_ct, dtype=np.float64)
+    if comp_len is None:
+        comp_len = np.zeros(nt, np.int64); comp_source = np.zeros((nt, 0), np.int64); comp_time = np.zeros((nt, 0))
+    comp_len = np.asarray(comp_len, dtype=np.int64)
+    comp_source = np.asarray(comp_source, dtype=np.int64).reshape(nt, -1)
+    comp_time = np.asarray(comp_time, dtype=np.float64).reshape(nt, -1)
+    K = comp_source.shape[1]
+    held = np.arange(K)[None, :] < comp_len[:, None]
+    have = np.zeros((n_source, nt), np.int64)
+    for s_ in range(n_source):
+        have[s_] = ((comp_source == s_) & held).sum(1)
+    extra = np.maximum(n_orig - have, 0)
+    length = np.maximum(comp_len + extra.sum(0), 1)           # (a particle without a source: one entry)
+    start = np.concatenate([[1], 1 + np.cumsum(length)[:-1]]) if nt else np.zeros(0, np.int64)
+    ncomp = int(length.sum())
+    part = np.repeat(np.arange(1, nt + 1), length)
+    src = np.ones(ncomp, dtype=np.int64)
+    tim = np.repeat(least_ct, length)
+    for i in np.flatnonzero((comp_len > 0) | (length > 1) | (n_orig.sum(0) > 0)):
+        at = int(start[i]) - 1
+        k = int(comp_len[i])
+        src[at:at + k] = comp_source[i, :k] + 1
+        tim[at:at + k] = comp_time[i, :k]
+        for s_ in range(n_source):
+            c = int(extra[s_, i])
+            src[at + k:at + k + c] = s_ + 1
+            tim[at + k:at + k + c] = greatest_ct[i]
+            if k == 0 and c > 0:
+                tim[at] = least_ct[i]
+            k += c
+    return length, start, part, src, tim
+
+
 def write_column(path, *, species_names, density, part_offset, vol, wclass, ids, least_ct,
                  greatest_ct, n_orig, weight_magnitude, next_id, time=0.0, del_t=0.0, index=0,
                  kappa=None, molec_weight=None, num_ions=None, source_names=None,
-                 gas_names=(), gas_mixing_ratio=None, version=5, uuid="", cell_ix=1, cell_iy=1):
+                 gas_names=(), gas_mixing_ratio=None, version=5, uuid="", cell_ix=1, cell_iy=1,
+                 comp_len=None, comp_source=None, comp_time=None):
     """One column (nz levels) in the layout of output_column_to_file_new.
 
     part_offset [nz+1]; vol [n_spec][n_total] (m^3); wclass/ids/least_ct/greatest_ct [n_total];
     n_orig [n_source][n_total] or None; weight_magnitude [nz][n_class] (one weight group, flat
-    weights: AERO_STATE_WEIGHT_FLAT_SPECIFIED, wrf_pmc_init.F90:252-253)."""
+    weights: AERO_STATE_WEIGHT_FLAT_SPECIFIED, wrf_pmc_init.F90:252-253); comp_len / comp_source /
+    comp_time: the particles' component lists (component_records)."""
     po = np.asarray(part_offset, dtype=np.int64)
     nz, nt = po.size - 1, int(po[-1])
     vol = np.asarray(vol, dtype=np.float64).reshape(len(species_names), nt)
@@ -229,20 +287,9 @@ def write_column(path, *, species_names, density, part_offset, vol, wclass, ids,
     n_source = n_orig.shape[0]
     source_names = list(source_names or [f"source_{k + 1}" for k in range(n_source)])
     level = np.repeat(np.arange(nz), np.diff(po))
-    comp_len = np.maximum(n_orig.sum(axis=0), 1)
-    comp_start = np.concatenate([[1], 1 + np.cumsum(comp_len)[:-1]]) if nt else np.zeros(0, np.int64)
+    comp_len, comp_start, comp_part, comp_src, comp_time = component_records(
+        n_orig, least_ct, greatest_ct, comp_len, comp_source, comp_time)
     ncomp = int(comp_len.sum())
-    comp_part = np.repeat(np.arange(1, nt + 1), comp_len)
-    comp_src = np.ones(ncomp, dtype=np.int64)
-    pos = 0
-    for i in range(nt):   # sources in ascending order inside a particle
-        k = 0
-        for s in range(n_source):
-            c = int(n_orig[s, i])
-            comp_src[pos + k:pos + k + c] = s + 1
-            k += c
-        pos += int(comp_len[i])
-    comp_time = np.repeat(np.asarray(least_ct, dtype=np.float64), comp_len)
 
     w = CdfWriter(version)
     w.att("title", "PartMC version WRF-PartMC output file")
@@ -259,10 +306,9 @@ def write_column(path, *, species_names, density, part_offset, vol, wclass, ids,
     w.dim("aero_weight_class", n_class)
     if len(gas_names):
         w.dim("gas_species", len(gas_names))
-    w.dim("scalar", 1)
-    w.var("time", ["scalar"], [float(time)], unit="s", description="time elapsed since simulation start")
-    w.var("timestep", ["scalar"], [float(del_t)], unit="s", description="current timestep size")
-    w.var("timestep_index", ["scalar"], np.array([index], dtype=np.int32))
+    w.var("time", [], [float(time)], unit="s", description="time elapsed since simulation start")
+    w.var("timestep", [], [float(del_t)], unit="s", description="current timestep size")
+    w.var("timestep_index", [], np.array([index], dtype=np.int32))
     w.var("aero_species", ["aero_species"], np.arange(1, len(species_names) + 1, dtype=np.int32),
           names=",".join(species_names), description="dummy dimension variable (no useful value)")
     w.var("aero_source", ["aero_source"], np.arange(1, n_source + 1, dtype=np.int32),
@@ -308,15 +354,22 @@ def write_column(path, *, species_names, density, part_offset, vol, wclass, ids,
           nc_type=NC_INT64 if version == 5 else NC_INT,
           long_name="unique ID number of each aerosol particle")
     w.var("aero_least_create_time", ["aero_particle"], np.asarray(least_ct, dtype=np.float64), unit="s",
-          long_name="least creation time of each aerosol particle")
+          long_name="least creation time of each aerosol particle",
+          description="least (earliest) creation time of any original constituent particles that "
+                      "coagulated to form each particle, measured from the start of the simulation")
     w.var("aero_greatest_create_time", ["aero_particle"], np.asarray(greatest_ct, dtype=np.float64),
-          unit="s", long_name="greatest creation time of each aerosol particle")
+          unit="s", long_name="greatest creation time of each aerosol particle",
+          description="greatest (latest) creation time of any original constituent particles that "
+                      "coagulated to form each particle, measured from the start of the simulation")
     wshape = ["aero_weight_class", "aero_weight_group", "number_levels"]
     w.var("weight_type", wshape, np.full((n_class, 1, nz), 1, dtype=np.int32),
-          description="type of each aerosol weighting function: 0 = invalid, 1 = none (w(D) = 1)")
-    w.var("weight_magnitude", wshape, wmag.T.reshape(n_class, 1, nz), unit="m^{-3}")
-    w.var("weight_exponent", wshape, np.zeros((n_class, 1, nz)), unit="1")
-    w.var("next_id", ["scalar"], np.array([next_id], dtype=np.int64),
+          description="type of each aerosol weighting function: 0 = invalid, 1 = none (w(D) = 1), "
+                      "2 = power (w(D) = (D/D_0)^alpha), 3 = MFA (mass flow) (w(D) = (D/D_0)^(-3))")
+    w.var("weight_magnitude", wshape, wmag.T.reshape(n_class, 1, nz), unit="m^{-3}",
+          description="magnitude for each weighting function")
+    w.var("weight_exponent", wshape, np.zeros((n_class, 1, nz)), unit="1",
+          description="exponent alpha for the power weight_type, set to -3 for MFA, and zero otherwise")
+    w.var("next_id", [], np.array([next_id], dtype=np.int64),
           nc_type=NC_INT64 if version == 5 else NC_INT, unit="1",
           description="next_id for particle creation")
     w.write(path)
@@ -340,13 +393,27 @@ def read_column(path):
     n_orig = np.zeros((n_source, nt), dtype=np.int32)
     cpart, csrc = get("aero_component_particle_num"), get("aero_component_source_num")
     np.add.at(n_orig, (csrc - 1, cpart - 1), 1)
+    # the lists themselves, padded to the longest (-1 / 0 past a particle's end): what
+    # CellBlock.upload_components takes, cut to the block's n_comp_max by the caller
+    clen = get("aero_component_len").astype(np.int64)
+    cstart = get("aero_component_start_ind").astype(np.int64)
+    assert np.array_equal(cstart, np.concatenate([[1], 1 + np.cumsum(clen)[:-1]])[:nt]), \
+        "aero_component_start_ind is not the running sum of aero_component_len"
+    assert np.array_equal(cpart, np.repeat(np.arange(1, nt + 1), clen)), "aero_component_particle_num"
+    kmax = int(clen.max()) if nt else 0
+    comp_source = np.full((nt, kmax), -1, dtype=np.int32); comp_time = np.zeros((nt, kmax))
+    within = np.arange(int(clen.sum())) - np.repeat(cstart - 1, clen)
+    comp_source[cpart - 1, within] = csrc - 1
+    comp_time[cpart - 1, within] = get("aero_component_create_time")
     wmag = get("weight_magnitude")                               # [class][group][level]
+    scalar = lambda k: np.asarray(get(k)).reshape(-1)[0]         # (no dimension, or one of length 1)
     return dict(
+        comp_len=clen.astype(np.int32), comp_source=comp_source, comp_time=comp_time,
         species_names=v["aero_species"][1].get("names", "").split(","), density=density,
         part_offset=po, vol=vol, wclass=(get("aero_particle_weight_class") - 1).astype(np.int32),
         ids=get("aero_id").astype(np.int64), least_ct=get("aero_least_create_time"),
         greatest_ct=get("aero_greatest_create_time"), n_orig=n_orig,
-        weight_magnitude=np.ascontiguousarray(wmag[:, 0, :].T), next_id=int(get("next_id")[0]),
-        time=float(get("time")[0]), del_t=float(get("timestep")[0]),
-        index=int(get("timestep_index")[0]), num_conc=get("aero_num_conc"),
+        weight_magnitude=np.ascontiguousarray(wmag[:, 0, :].T), next_id=int(scalar("next_id")),
+        time=float(scalar("time")), del_t=float(scalar("timestep")),
+        index=int(scalar("timestep_index")), num_conc=get("aero_num_conc"),
         gas_mixing_ratio=(get("gas_mixing_ratio").T if "gas_mixing_ratio" in v else None))
