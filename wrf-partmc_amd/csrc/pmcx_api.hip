@@ -1694,6 +1694,22 @@ int pmcx_device_copy(pmcx_ctx *ctx, void *dst, const void *src, int64_t n_bytes,
     return PMCX_OK;
 }
 
+int pmcx_host_alloc(pmcx_ctx *ctx, int64_t n_bytes, void **host_ptr)
+{
+    if (!ctx || !host_ptr || n_bytes < 1) return fail(ctx, PMCX_EINVAL, "pmcx_host_alloc: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    *host_ptr = nullptr;
+    const hipError_t e = hipHostMalloc(host_ptr, (size_t)n_bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(ctx, PMCX_ENOMEM, "pmcx_host_alloc(%lld bytes): %s", (long long)n_bytes, hipGetErrorString(e));
+    return PMCX_OK;
+}
+int pmcx_host_free(pmcx_ctx *ctx, void *host_ptr)
+{
+    if (!ctx) return PMCX_EINVAL;
+    if (host_ptr) HIP_TRY(ctx, hipHostFree(host_ptr));
+    return PMCX_OK;
+}
+
 int pmcx_transport_begin(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int32_t periodic_x,
                          const double *prob_h, const double *prob_v, const double *cell_volume,
                          uint64_t seed, uint32_t step)

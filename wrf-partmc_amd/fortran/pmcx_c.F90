@@ -464,6 +464,16 @@ module pmcx_c
        import :: c_ptr, c_int
        type(c_ptr), value :: ctx, dev_ptr
      end function pmcx_device_free
+     integer(c_int) function pmcx_host_alloc(ctx, n_bytes, host_ptr) bind(c, name="pmcx_host_alloc")
+       import :: c_ptr, c_int, c_int64_t
+       type(c_ptr), value :: ctx
+       integer(c_int64_t), value :: n_bytes
+       type(c_ptr), intent(out) :: host_ptr
+     end function pmcx_host_alloc
+     integer(c_int) function pmcx_host_free(ctx, host_ptr) bind(c, name="pmcx_host_free")
+       import :: c_ptr, c_int
+       type(c_ptr), value :: ctx, host_ptr
+     end function pmcx_host_free
      integer(c_int) function pmcx_device_copy(ctx, dst, src, n_bytes, kind) bind(c, name="pmcx_device_copy")
        import :: c_ptr, c_int, c_int32_t, c_int64_t
        type(c_ptr), value :: ctx, dst, src

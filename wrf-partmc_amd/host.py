@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "pmcx_test_philox", "pmcx_profile_enable", "pmcx_profile_reset", "pmcx_profile_get", "pmcx_profile_phase_cycles", "pmcx_dry_deposition",
     "pmcx_transport_begin", "pmcx_transport_export_size", "pmcx_transport_export",
     "pmcx_transport_import", "pmcx_transport_finish", "pmcx_device_alloc", "pmcx_device_free",
-    "pmcx_device_copy",
+    "pmcx_device_copy", "pmcx_host_alloc", "pmcx_host_free",
     "pmcx_memory_bytes", "pmcx_device_memory_info", "pmcx_set_cell_id_base", "pmcx_set_gas_state",
     "pmcx_get_gas_state", "pmcx_set_gas_scenario", "pmcx_scenario_update_gas_state",
     "pmcx_invalidate_lists", "pmcx_get_keys", "pmcx_seasalt_emissions",
@@ -174,6 +174,8 @@ def load_library():
     L.pmcx_transport_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.pmcx_device_alloc.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
     L.pmcx_device_free.argtypes = [C.c_void_p, C.c_void_p]
+    L.pmcx_host_alloc.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
+    L.pmcx_host_free.argtypes = [C.c_void_p, C.c_void_p]
     L.pmcx_device_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
     L.pmcx_dry_deposition.argtypes = [C.c_void_p, C.c_double, C.c_uint64, C.c_uint32] + [C.c_void_p] * 9
     L.pmcx_timestep.argtypes = [C.c_void_p, C.POINTER(PmcxStepFlags)]
@@ -286,6 +288,9 @@ class CellBlock:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
+            for p in getattr(self, "_pinned", []):
+                self._lib.pmcx_host_free(self._h, p)
+            self._pinned = []
             self._lib.pmcx_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -314,9 +319,9 @@ class CellBlock:
 
     def set_env(self, temp, pressure, rel_humid=None):
         n = self.cfg.n_cells
-        t = np.broadcast_to(_f64(temp), (n,)).copy()
-        p = np.broadcast_to(_f64(pressure), (n,)).copy()
-        r = None if rel_humid is None else np.broadcast_to(_f64(rel_humid), (n,)).copy()
+        t = np.ascontiguousarray(np.broadcast_to(_f64(temp), (n,)))
+        p = np.ascontiguousarray(np.broadcast_to(_f64(pressure), (n,)))
+        r = None if rel_humid is None else np.ascontiguousarray(np.broadcast_to(_f64(rel_humid), (n,)))
         self._ck(self._lib.pmcx_set_env(self._h, _ptr(t), _ptr(p), _ptr(r)))
 
     def set_weights(self, magnitude):
@@ -340,6 +345,32 @@ class CellBlock:
         a = np.zeros(self.cfg.n_cells, dtype=np.int64)
         self._ck(self._lib.pmcx_get_next_id(self._h, _ptr(a)))
         return a
+
+    def host_array(self, shape, dtype=np.float64):
+        """A numpy array over page-locked host memory (pmcx_host_alloc) for per-step inputs and
+        outputs: uploads from it are one DMA that overlaps the device's work.  Lives as long as
+        the block."""
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) if np.ndim(shape) else int(shape)
+        p = C.c_void_p()
+        self._ck(self._lib.pmcx_host_alloc(self._h, max(n, 1) * dt.itemsize, C.byref(p)))
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p)
+        buf = (C.c_char * (max(n, 1) * dt.itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+
+    # Set True by a caller that consumes a call's per-cell results before its next call of the same
+    # kind (a time loop): the result arrays are then page-locked and reused instead of allocated.
+    reuse_outputs = False
+
+    def _out(self, key, shape, dtype=np.int32):
+        if not self.reuse_outputs:
+            return np.zeros(shape, dtype=dtype)
+        cache = self.__dict__.setdefault("_out_cache", {})
+        k = (key, tuple(np.atleast_1d(shape).tolist()), np.dtype(dtype).str)
+        if k not in cache:
+            cache[k] = self.host_array(shape, dtype)
+        return cache[k]
 
     # -- particle data ----------------------------------------------------
     def upload_cells(self, cell_first, part_offset, vol, wclass=None, id=None, least_ct=None,
@@ -484,7 +515,7 @@ class CellBlock:
 
     def coag_counters(self):
         n = self.cfg.n_cells
-        a, b, s = (np.zeros(n, dtype=np.int32) for _ in range(3))
+        a, b, s = (self._out("coag%d" % k, n) for k in range(3))
         self._ck(self._lib.pmcx_get_coag_counters(self._h, _ptr(a), _ptr(b), _ptr(s)))
         return a, b, s
 
@@ -557,7 +588,7 @@ class CellBlock:
         e, ke = self._aero_dist(emission, emission_rate)
         b, kb = self._aero_dist(background, background_conc)
         dil = None if dilution_rate is None else np.broadcast_to(_f64(dilution_rate), (n,)).copy()
-        ne, ni, no = (np.zeros(n, dtype=np.int32) for _ in range(3))
+        ne, ni, no = (self._out("scen%d" % k, n) for k in range(3))
         self._ck(self._lib.pmcx_scenario_update_aero_state(
             self._h, dt, elapsed_time, seed, step, C.addressof(e) if e else None, _ptr(dil),
             C.addressof(b) if b else None, _ptr(ne), _ptr(ni), _ptr(no)))
@@ -684,7 +715,7 @@ class CellBlock:
         arr = [np.ascontiguousarray(np.broadcast_to(_f64(x), (n,))) for x in
                (aer_res_a, ustar, alpha, big_a, height, inv_density)]
         sf = None if surface is None else np.ascontiguousarray(np.broadcast_to(surface, (n,)), dtype=np.int32)
-        nr, bad = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+        nr, bad = self._out("dep0", n), self._out("dep1", n)
         self._ck(self._lib.pmcx_dry_deposition(self._h, dt, seed, step, _ptr(sf), *[_ptr(a) for a in arr],
                                                _ptr(nr), _ptr(bad)))
         return nr, bad
@@ -815,7 +846,7 @@ class CellBlock:
         ph = None if prob_h is None else np.ascontiguousarray(np.broadcast_to(_f64(prob_h), (n, Cn, 4)))
         pv = None if prob_v is None else np.ascontiguousarray(np.broadcast_to(_f64(prob_v), (n, Cn, nz)))
         cv = np.ascontiguousarray(np.broadcast_to(_f64(cell_volume), (n,)))
-        ex, nr = np.zeros((n, Cn)), np.zeros(n, dtype=np.int32)
+        ex, nr = self._out("pre0", (n, Cn), np.float64), self._out("pre1", n)
         self._ck(self._lib.pmcx_transport_preweight(self._h, nx, nz, ny, int(periodic_x), int(periodic_y),
                                                     _ptr(ph), _ptr(pv), _ptr(cv), seed, step, _ptr(ex),
                                                     _ptr(nr)))
@@ -894,7 +925,7 @@ class CellBlock:
         ph = None if prob_h is None else np.ascontiguousarray(np.broadcast_to(_f64(prob_h), (n, Cn, 4)))
         pv = None if prob_v is None else np.ascontiguousarray(np.broadcast_to(_f64(prob_v), (n, Cn, nz)))
         cv = np.ascontiguousarray(np.broadcast_to(_f64(cell_volume), (n,)))
-        nm, na = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+        nm, na = self._out("tr0", n), self._out("tr1", n)
         self._ck(self._lib.pmcx_transport(self._h, nx, nz, ny, int(periodic_x), int(periodic_y),
                                           _ptr(ph), _ptr(pv), _ptr(cv), seed, step, _ptr(nm), _ptr(na)))
         return nm, na
