@@ -72,6 +72,11 @@ module pmcx_shim
   type(pmcx_config), save :: cfg
   logical, save :: have_ctx = .false.
   integer, save :: want_comp_max = 8           ! entries of component(:) carried per particle
+  ! per-step staging arrays in page-locked memory (pmcx_host_alloc): an upload from them is one
+  ! DMA that overlaps the device's work; they grow as needed and live until pmcx_shim_finalize
+  integer, parameter :: N_PIN = 24
+  type(c_ptr), save :: pin_p(N_PIN) = c_null_ptr
+  integer(c_int64_t), save :: pin_bytes(N_PIN) = 0
   integer(c_int64_t), save :: rng_seed = 0     ! grid%random_seed (wrf_pmc_init.F90:131)
   integer(c_int32_t), save :: rng_step = 0     ! chemistry-step index
   integer(c_int32_t), save :: cell_id_base = 0 ! global id of this rank's first cell
@@ -158,8 +163,29 @@ contains
          'pmcx_set_aero_data')
   end subroutine pmcx_shim_init
 
+  !> Page-locked staging buffer number `slot`, at least `bytes` long.
+  function pinned(slot, bytes) result(p)
+    integer, intent(in) :: slot
+    integer(c_int64_t), intent(in) :: bytes
+    type(c_ptr) :: p
+    if (pin_bytes(slot) < bytes .or. .not. c_associated(pin_p(slot))) then
+       if (c_associated(pin_p(slot))) call pmcx_die(pmcx_host_free(ctx, pin_p(slot)), 'pmcx_host_free')
+       call pmcx_die(pmcx_host_alloc(ctx, max(bytes, 8_c_int64_t), pin_p(slot)), 'pmcx_host_alloc')
+       pin_bytes(slot) = bytes
+    end if
+    p = pin_p(slot)
+  end function pinned
+
   subroutine pmcx_shim_finalize()
     integer(c_int) :: rc
+    integer :: q
+    if (have_ctx) then
+       do q = 1, N_PIN
+          if (c_associated(pin_p(q))) rc = pmcx_host_free(ctx, pin_p(q))
+       end do
+    end if
+    pin_p = c_null_ptr
+    pin_bytes = 0
     if (have_ctx) rc = pmcx_destroy(ctx)
     have_ctx = .false.
     ctx = c_null_ptr
@@ -1273,12 +1299,14 @@ contains
     logical :: ideal
     real(kind=dp) :: elapsed_time, zr
     type(pmcx_trans_fields_t) :: f
-    real(c_float), allocatable, target :: alt(:,:,:), xkhh(:,:,:), uf(:,:,:,:), vf(:,:,:,:), wf(:,:,:,:), &
-         z(:,:,:), zw(:,:,:), exch(:,:,:)
-    real(c_double), allocatable, target :: cell_volume(:), expected(:), dens(:), conc(:,:), gm(:,:), gs(:,:), &
-         vfr(:,:,:), ra(:), ust(:), alpha_c(:), biga_c(:), height(:), rrho(:)
-    integer(c_int32_t), allocatable, target :: n_moved(:), n_arrived(:), n_rem(:), from_c(:), to_c(:), res_c(:), &
-         thr(:), cls(:,:), src(:,:), n_add(:), n_rm(:), surface(:), bad(:), st(:), ns(:), nc(:)
+    ! (staging arrays of n_cells and more: page-locked, see pinned())
+    real(c_float), pointer :: alt(:,:,:), xkhh(:,:,:), uf(:,:,:,:), vf(:,:,:,:), wf(:,:,:,:), &
+         z(:,:,:), zw(:,:,:), exch(:,:,:), f3(:,:,:)
+    real(c_double), pointer :: cell_volume(:), expected(:), ra(:), ust(:), alpha_c(:), biga_c(:), height(:), rrho(:)
+    real(c_double), allocatable, target :: dens(:), conc(:,:), gm(:,:), gs(:,:), vfr(:,:,:)
+    integer(c_int32_t), pointer :: n_moved(:), n_arrived(:), n_rem(:), surface(:), bad(:)
+    integer(c_int32_t), allocatable, target :: from_c(:), to_c(:), res_c(:), &
+         thr(:), cls(:,:), src(:,:), n_add(:), n_rm(:), st(:), ns(:), nc(:)
     type(pmcx_aero_dist_t) :: bgd
 
     if (.not. resident) call pmcx_die(4, 'wrf_pmc_trans_driver_pmcx (partmc_timestep_pmcx comes first: nothing is resident)')
@@ -1294,9 +1322,14 @@ contains
     if (grid%do_transport) then
        ! the fields the probabilities read, single precision as grid% holds them (wrf_pmc_trans.F90:
        ! 227-275, 374-406, 451-463, 645-646), copied out of WRF's memory order tile by tile
-       allocate(alt(0:nx+1, nz, 0:ny+1), xkhh(0:nx+1, nz, 0:ny+1), uf(nx+1, nz, ny, n_class), &
-            vf(nx, nz, ny+1, n_class), wf(nx, nz+1, ny, n_class), z(nx, nz, ny), zw(nx, nz+1, ny), &
-            exch(nx, nz+1, ny))
+       call c_f_pointer(pinned(1, 4_c_int64_t * (nx+2) * nz * (ny+2)), f3, [nx+2, nz, ny+2]); alt(0:, 1:, 0:) => f3
+       call c_f_pointer(pinned(2, 4_c_int64_t * (nx+2) * nz * (ny+2)), f3, [nx+2, nz, ny+2]); xkhh(0:, 1:, 0:) => f3
+       call c_f_pointer(pinned(3, 4_c_int64_t * (nx+1) * nz * ny * n_class), uf, [nx+1, nz, ny, n_class])
+       call c_f_pointer(pinned(4, 4_c_int64_t * nx * nz * (ny+1) * n_class), vf, [nx, nz, ny+1, n_class])
+       call c_f_pointer(pinned(5, 4_c_int64_t * nx * (nz+1) * ny * n_class), wf, [nx, nz+1, ny, n_class])
+       call c_f_pointer(pinned(6, 4_c_int64_t * nx * nz * ny), z, [nx, nz, ny])
+       call c_f_pointer(pinned(7, 4_c_int64_t * nx * (nz+1) * ny), zw, [nx, nz+1, ny])
+       call c_f_pointer(pinned(8, 4_c_int64_t * nx * (nz+1) * ny), exch, [nx, nz+1, ny])
        alt = grid%alt(pmc_is-1:pmc_ie+1, pmc_ks:pmc_ke, pmc_js-1:pmc_je+1)
        xkhh = grid%xkhh(pmc_is-1:pmc_ie+1, pmc_ks:pmc_ke, pmc_js-1:pmc_je+1)
        uf = grid%u_flux(pmc_is:pmc_ie+1, pmc_ks:pmc_ke, pmc_js:pmc_je, 2:n_class+1)   ! wrf_class = i_class + 1
@@ -1313,14 +1346,17 @@ contains
        f%dt = real(grid%dt, dp); f%dx = real(grid%dx, dp); f%dy = real(grid%dy, dp)
        f%alt = c_loc(alt); f%xkhh = c_loc(xkhh); f%u_flux = c_loc(uf); f%v_flux = c_loc(vf)
        f%w_flux = c_loc(wf); f%z = c_loc(z); f%z_at_w = c_loc(zw); f%exch_h = c_loc(exch)
-       allocate(bad(n_cells))
+       call c_f_pointer(pinned(9, 4_c_int64_t * n_cells), bad, [n_cells])
        call pmcx_die(pmcx_transport_probs(ctx, f, c_null_ptr, c_null_ptr, c_null_ptr, c_loc(bad), &
             c_null_ptr), 'pmcx_transport_probs')
        ! normalize_probs' assertions (wrf_pmc_trans.F90:713,746,759,771)
        if (any(bad /= 0)) call pmcx_die(5, 'wrf_pmc_trans_driver_pmcx (normalize_probs: a probability is negative, above one, or their sum is)')
 
-       allocate(cell_volume(n_cells), expected(n_cells * n_class), n_rem(n_cells), n_moved(n_cells), &
-            n_arrived(n_cells))
+       call c_f_pointer(pinned(10, 8_c_int64_t * n_cells), cell_volume, [n_cells])
+       call c_f_pointer(pinned(11, 8_c_int64_t * n_cells * n_class), expected, [n_cells * n_class])
+       call c_f_pointer(pinned(12, 4_c_int64_t * n_cells), n_rem, [n_cells])
+       call c_f_pointer(pinned(13, 4_c_int64_t * n_cells), n_moved, [n_cells])
+       call c_f_pointer(pinned(14, 4_c_int64_t * n_cells), n_arrived, [n_cells])
        c = 0
        do j = pmc_js, pmc_je
        do k = pmc_ks, pmc_ke
@@ -1394,10 +1430,15 @@ contains
     ! Do deposition on lowest layer (wrf_pmc_trans.F90:182-198, wrf_pmc_dep.F90:30-96,
     ! wrf_pmc_dep_aero.F90:28-151)
     if (pmc_ks == 1 .and. grid%do_deposition) then
-       allocate(surface(n_cells), ra(n_cells), ust(n_cells), alpha_c(n_cells), biga_c(n_cells), &
-            height(n_cells), rrho(n_cells))
-       if (.not. allocated(n_rem)) allocate(n_rem(n_cells))
-       if (.not. allocated(bad)) allocate(bad(n_cells))
+       call c_f_pointer(pinned(15, 4_c_int64_t * n_cells), surface, [n_cells])
+       call c_f_pointer(pinned(16, 8_c_int64_t * n_cells), ra, [n_cells])
+       call c_f_pointer(pinned(17, 8_c_int64_t * n_cells), ust, [n_cells])
+       call c_f_pointer(pinned(18, 8_c_int64_t * n_cells), alpha_c, [n_cells])
+       call c_f_pointer(pinned(19, 8_c_int64_t * n_cells), biga_c, [n_cells])
+       call c_f_pointer(pinned(20, 8_c_int64_t * n_cells), height, [n_cells])
+       call c_f_pointer(pinned(21, 8_c_int64_t * n_cells), rrho, [n_cells])
+       call c_f_pointer(pinned(12, 4_c_int64_t * n_cells), n_rem, [n_cells])
+       call c_f_pointer(pinned(9, 4_c_int64_t * n_cells), bad, [n_cells])
        surface = 0; ra = 1d0; ust = 1d0; alpha_c = 1d0; biga_c = 1d0; height = 1d0; rrho = 1d0
        zr = 2.0
        do j = max(pmc_js, 2), min(pmc_je, global_ny - 1)
