@@ -423,7 +423,7 @@ int pmcx_device_copy(pmcx_ctx *ctx, void *dst, const void *src, int64_t n_bytes,
  * pmcx_transport_probs, the resistances of pmcx_dry_deposition, emission rates, the counters that
  * come back): from such a buffer an upload is one DMA at the link's rate that overlaps whatever
  * the device is doing, from pageable memory the runtime pins or stages page by page while the
- * caller waits (1.5 ms of a 6.6 ms step at 122 880 cells, DESIGN.md 7).  The Fortran shim keeps its
+ * caller waits (1.5 ms of a 6.6 ms step at 122 880 cells, DESIGN.md 6 and 9).  The Fortran shim keeps its
  * per-step staging arrays in it.  Any host pointer is accepted everywhere; this only makes it fast. */
 int pmcx_host_alloc(pmcx_ctx *ctx, int64_t n_bytes, void **host_ptr);
 int pmcx_host_free(pmcx_ctx *ctx, void *host_ptr);
