@@ -108,6 +108,16 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out);
 int pmcx_destroy(pmcx_ctx *ctx);
 const char *pmcx_last_error(const pmcx_ctx *ctx); /* ctx may be NULL: create errors */
 int pmcx_synchronize(pmcx_ctx *ctx);
+/* on != 0: the per-step stage calls -- pmcx_set_env, pmcx_transport_probs, pmcx_transport_preweight,
+ * pmcx_transport, pmcx_dry_deposition, pmcx_scenario_update_aero_state (pmcx_mc_coag, the gas update
+ * and pmcx_rebalance never wait) -- enqueue their uploads, kernels and downloads on the context's
+ * stream and return without waiting for the device: one WRF step is then one uninterrupted queue
+ * and the host's work (staging the next call's arrays) overlaps the device's.  The caller keeps
+ * the input arrays unchanged, and does not read the output arrays, until pmcx_synchronize (or
+ * any call that returns values: counters, downloads); with page-locked arrays (pmcx_host_alloc)
+ * the transfers themselves are asynchronous too.  What a stage call would have reported after
+ * waiting (pmcx_transport_probs' sub-step clamp) is reported by that pmcx_synchronize. */
+int pmcx_set_async(pmcx_ctx *ctx, int32_t on);
 
 /* aero_data_t: density(:) [kg/m^3], kappa(:), molec_weight(:)
  * (aero_data.dat columns; wrf_pmc_driver.F90:1420). kappa/molec_weight may be NULL. */

@@ -268,3 +268,71 @@ def test_transport_driver_calls_refuse_bad_input(wp):
         blk.set_transport_lateral(False)
         blk.transport(nx, nz, ny, 0.01, 0.01, cv, 0, 1, True, True)
         assert not blk.coag_counters()[2].any()
+
+
+def test_asynchronous_stage_calls_give_the_same_step(wp):
+    """pmcx_set_async: the stage calls of a step only enqueue (inputs and results in page-locked
+    arrays, one synchronize at the end of the step); particles, weights, gases and the per-cell
+    results are those of the same calls made one by one, bit for bit -- also when a later step
+    overwrites the staging arrays the way a time loop does."""
+    from tests import trans_fields as tf
+    nx, nz, ny, n_part = 6, 5, 4, 400
+    n = nx * nz * ny
+    dens = np.array([1800.0, 1200.0])
+    modes = [dict(frac=0.7, gm_radius=3e-8, gsd_log10=0.2, vol_frac=[1.0, 0.0], wclass=0, source=0),
+             dict(frac=0.3, gm_radius=1.2e-7, gsd_log10=0.15, vol_frac=[0.4, 0.6], wclass=0, source=1)]
+    emission = [dict(gm_radius=2e-8, gsd_log10=0.2, vol_frac=[1.0, 0.0], wclass=0, source=1)]
+    rs = np.random.RandomState(3)
+    surface = ((np.arange(n) // nx) % nz == 0).astype(np.int32)
+    results = []
+    for use_async in (False, True):
+        blk = wp.CellBlock(n, 1024, 2, n_class=1, n_source=2)
+        blk.set_aero_data(dens)
+        blk.set_env(285.0, 9.5e4, 0.5)
+        blk.set_weights(np.full((n, 1), 1e9 / n_part))
+        blk.set_n_part_ideal(np.full((n, 1), float(n_part)))
+        blk.set_next_id((np.arange(n, dtype=np.int64) << 32) + (1 << 20))
+        blk.generate_lognormal(n_part, modes, seed=5)
+        mk = (lambda a: a)
+        if use_async:
+            blk.reuse_outputs = True
+            blk.set_async(True)
+
+            def mk(a):
+                out = blk.host_array(np.shape(a), np.asarray(a).dtype)
+                out[...] = a
+                return out
+        cv, ra, ust, alpha, big_a, height, rrho, rate = (mk(np.zeros(n)) for _ in range(8))
+        rate = mk(np.zeros((n, 1)))
+        F0 = tf.make_fields(nx, nz, ny, 1, seed=1, k_scale=6.0, flux_scale=0.004 * 1e9)
+        F = {k: mk(np.ascontiguousarray(v, dtype=np.float32)) for k, v in F0.items()}
+        per_step = []
+        for step in range(4):
+            r = np.random.RandomState(100 + step)          # new inputs every step, in the same arrays
+            Fs = tf.make_fields(nx, nz, ny, 1, seed=10 + step, k_scale=6.0, flux_scale=0.004 * 1e9)
+            for k in F:
+                F[k][...] = Fs[k]
+            cv[:] = r.uniform(0.9e9, 1.1e9, n); ra[:] = r.uniform(20, 60, n); ust[:] = r.uniform(0.2, 0.5, n)
+            alpha[:] = 1.2; big_a[:] = 0.002; height[:] = 50.0; rrho[:] = r.uniform(0.8, 0.9, n)
+            rate[:, 0] = np.where(surface == 1, r.uniform(1e5, 3e5, n), 0.0)
+            blk.transport_probs(nx, nz, ny, 20.0, 4000.0, 4000.0, F, download=False)
+            ex, nrm = blk.transport_preweight(nx, nz, ny, None, None, cv, seed=2, step=step)
+            nm, na = blk.transport(nx, nz, ny, None, None, cv, seed=2, step=step)
+            nd, bad = blk.dry_deposition(20.0, ra, ust, alpha, big_a, height, rrho, seed=2, step=step, surface=surface)
+            ne, ni, no = blk.scenario_update_aero_state(20.0, 20.0 * step, seed=2, step=step, emission=emission,
+                                                        emission_rate=rate)
+            if step % 2 == 0:
+                blk.mc_coag(wp.COAG_KERNEL_TYPE_BROWN, 40.0, 2, step // 2, counters=False)
+            blk.aero_state_rebalance(True, True, 2, step)
+            blk.synchronize()
+            per_step.append([np.array(x) for x in (ex, nrm, nm, na, nd, bad, ne)])
+        results.append((blk.download_cells(), blk.get_weights(), per_step))
+        blk.close()
+    (a, wa, pa), (b, wb, pb) = results
+    for k in ("part_offset", "vol", "wclass", "id", "least_ct", "greatest_ct", "n_orig"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(wa, wb)
+    for step, (x, y) in enumerate(zip(pa, pb)):
+        for q, (u, v) in enumerate(zip(x, y)):
+            assert np.array_equal(u, v), (step, q)
+    assert sum(int(x[2].sum()) for x in pa) > 1000 and sum(int(x[4].sum()) for x in pa) > 0

@@ -92,6 +92,9 @@ struct pmcx_ctx {
     int bounds_age = 0;        // mc_coag calls since the last check (coagulation moves the range up)
     // profiling
     bool prof = false;
+    // pmcx_set_async: the per-step stage calls return without waiting for the device
+    bool async_stages = false;
+    int32_t *h_flags = nullptr; // page-locked: [0] pmcx_transport_probs' sub-step clamp, read at the next synchronisation
     std::map<std::string, ProfEntry> profile;
     std::vector<hipEvent_t> event_pool;
 };
@@ -155,6 +158,12 @@ void tmp_release(pmcx_ctx *ctx, void *p)
 {
     for (auto &b : ctx->tmp_blocks)
         if (b.p == p) b.used = false;
+}
+
+// the end of a per-step stage call: wait for the device, unless the caller asked not to
+static inline hipError_t stage_end(pmcx_ctx *ctx)
+{
+    return ctx->async_stages ? hipSuccess : hipStreamSynchronize(ctx->stream);
 }
 
 int ensure_stage(pmcx_ctx *ctx, size_t bytes)
@@ -433,6 +442,7 @@ int pmcx_destroy(pmcx_ctx *ctx)
     for (auto &b : ctx->tmp_blocks) (void)hipFree(b.p);
     if (ctx->stage) (void)hipFree(ctx->stage);
     if (ctx->d_offsets) (void)hipFree(ctx->d_offsets);
+    if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PMCX_OK;
@@ -442,6 +452,25 @@ int pmcx_synchronize(pmcx_ctx *ctx)
 {
     if (!ctx) return PMCX_EINVAL;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->h_flags && ctx->h_flags[0]) { // (what an asynchronous pmcx_transport_probs could not report)
+        ctx->h_flags[0] = 0;
+        return fail(ctx, PMCX_EINVAL, "pmcx_transport_probs: a column asked for more than 10^4 vertical "
+                                      "sub-steps (z(2) - z(1) too small or exch_h too large; bit 16 of bad[]): "
+                                      "the probabilities of that step were clamped");
+    }
+    return PMCX_OK;
+}
+
+int pmcx_set_async(pmcx_ctx *ctx, int32_t on)
+{
+    if (!ctx) return PMCX_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    if (on && !ctx->h_flags) {
+        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_flags, sizeof(int32_t) * 4, hipHostMallocDefault));
+        memset(ctx->h_flags, 0, sizeof(int32_t) * 4);
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->async_stages = on != 0;
     return PMCX_OK;
 }
 
@@ -502,7 +531,7 @@ int pmcx_set_env(pmcx_ctx *ctx, const double *temp, const double *pressure,
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pressure, pressure, b, hipMemcpyHostToDevice, ctx->stream));
     if (rel_humid)
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_rh, rel_humid, b, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, stage_end(ctx));
     ctx->env_set = true;
     ctx->bounds_kernel = 0; // the bounds are those of the environment they were computed in
     return PMCX_OK;
@@ -1114,7 +1143,8 @@ int upload_dist(pmcx_ctx *ctx, const pmcx_aero_dist *d, std::vector<void *> &tmp
     }
     HIP_TRY(ctx, tmp_malloc(ctx, (void **)&conc_dev, sizeof(double) * nc * M)); tmp.push_back(conc_dev);
     HIP_TRY(ctx, hipMemcpyAsync(conc_dev, d->num_conc, sizeof(double) * nc * M, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // (kind >= 0: num_conc is the caller's array, which an asynchronous stage call may leave in flight)
+    if (!(ctx->async_stages && kind >= 0)) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PMCX_OK;
 }
 } // namespace
@@ -1154,7 +1184,7 @@ int pmcx_scenario_update_aero_state(pmcx_ctx *ctx, double dt, double elapsed_tim
     if (e == hipSuccess && n_emit) e = hipMemcpyAsync(n_emit, d_cnt, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && n_dil_in) e = hipMemcpyAsync(n_dil_in, d_cnt + nc, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && n_dil_out) e = hipMemcpyAsync(n_dil_out, d_cnt + 2 * nc, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = stage_end(ctx);
     cleanup();
     HIP_TRY(ctx, invalidate_sort(ctx, 0, ctx->cfg.n_cells, false)); // (the kernel keeps the sort keys current)
     if (e != hipSuccess) return fail(ctx, PMCX_EDEVICE, "pmcx_scenario_update_aero_state: %s", hipGetErrorString(e));
@@ -1286,7 +1316,7 @@ int pmcx_dry_deposition(pmcx_ctx *ctx, double dt, uint64_t seed, uint32_t step,
     }
     if (e == hipSuccess && n_removed) e = hipMemcpyAsync(n_removed, d_i, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && unrealistic) e = hipMemcpyAsync(unrealistic, d_i + nc, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = stage_end(ctx);
     if (d6) tmp_release(ctx, d6);
     if (d_i) tmp_release(ctx, d_i);
     if (e != hipSuccess) return fail(ctx, PMCX_EDEVICE, "pmcx_dry_deposition: %s", hipGetErrorString(e));
@@ -1346,7 +1376,7 @@ int pmcx_transport(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int32_t pe
     }
     if (n_moved) HIP_TRY(ctx, hipMemcpyAsync(n_moved, ctx->d_n_out, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));
     if (n_arrived) HIP_TRY(ctx, hipMemcpyAsync(n_arrived, ctx->d_n_arr, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, stage_end(ctx));
     HIP_TRY(ctx, invalidate_sort(ctx, 0, ctx->cfg.n_cells, false)); // (the kernels keep the sort keys current)
     return PMCX_OK;
 }
@@ -1408,13 +1438,16 @@ int pmcx_transport_probs(pmcx_ctx *ctx, const pmcx_trans_fields *f, double *prob
         HIP_TRY(ctx, launch_transport_probs(ctx->st, a, ctx->stream));
     }
     int32_t clamped = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&clamped, a.clamp_flag, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->async_stages) // (reported by the next pmcx_synchronize)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags, a.clamp_flag, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    else
+        HIP_TRY(ctx, hipMemcpyAsync(&clamped, a.clamp_flag, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (prob_h) HIP_TRY(ctx, hipMemcpyAsync(prob_h, ctx->d_prob_h, sizeof(double) * nc * C * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (prob_v) HIP_TRY(ctx, hipMemcpyAsync(prob_v, ctx->d_prob_v, sizeof(double) * nc * C * (size_t)nz, hipMemcpyDeviceToHost, ctx->stream));
     if (bad) HIP_TRY(ctx, hipMemcpyAsync(bad, a.bad, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));
     if (n_class_part) HIP_TRY(ctx, hipMemcpyAsync(n_class_part, a.n_class_part, sizeof(int32_t) * nc * C, hipMemcpyDeviceToHost, ctx->stream));
     if (n_substeps) HIP_TRY(ctx, hipMemcpyAsync(n_substeps, a.n_substeps, sizeof(int32_t) * col, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, stage_end(ctx));
     if (clamped)
         return fail(ctx, PMCX_EINVAL, "pmcx_transport_probs: a column asks for more than 10^4 vertical "
                                       "sub-steps (z(2) - z(1) too small or exch_h too large; bit 16 of bad[]): "
@@ -1555,7 +1588,7 @@ int pmcx_transport_preweight(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, 
         HIP_TRY(ctx, hipMemcpyAsync(expected_num_conc, ctx->d_preweight + nc * C, sizeof(double) * nc * C,
                                     hipMemcpyDeviceToHost, ctx->stream));
     if (n_removed) HIP_TRY(ctx, hipMemcpyAsync(n_removed, d_nr, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, stage_end(ctx));
     HIP_TRY(ctx, invalidate_sort(ctx, 0, cf.n_cells, false)); // (removals keep the sort keys current)
     ctx->bounds_dirty = true;
     return PMCX_OK;

@@ -464,6 +464,11 @@ module pmcx_c
        import :: c_ptr, c_int
        type(c_ptr), value :: ctx, dev_ptr
      end function pmcx_device_free
+     integer(c_int) function pmcx_set_async(ctx, on) bind(c, name="pmcx_set_async")
+       import :: c_ptr, c_int, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: on
+     end function pmcx_set_async
      integer(c_int) function pmcx_host_alloc(ctx, n_bytes, host_ptr) bind(c, name="pmcx_host_alloc")
        import :: c_ptr, c_int, c_int64_t
        type(c_ptr), value :: ctx

@@ -1304,7 +1304,7 @@ contains
          z(:,:,:), zw(:,:,:), exch(:,:,:), f3(:,:,:)
     real(c_double), pointer :: cell_volume(:), expected(:), ra(:), ust(:), alpha_c(:), biga_c(:), height(:), rrho(:)
     real(c_double), allocatable, target :: dens(:), conc(:,:), gm(:,:), gs(:,:), vfr(:,:,:)
-    integer(c_int32_t), pointer :: n_moved(:), n_arrived(:), n_rem(:), surface(:), bad(:)
+    integer(c_int32_t), pointer :: n_moved(:), n_arrived(:), n_rem(:), surface(:), bad(:), n_dep(:), unreal(:)
     integer(c_int32_t), allocatable, target :: from_c(:), to_c(:), res_c(:), &
          thr(:), cls(:,:), src(:,:), n_add(:), n_rm(:), st(:), ns(:), nc(:)
     type(pmcx_aero_dist_t) :: bgd
@@ -1346,11 +1346,13 @@ contains
        f%dt = real(grid%dt, dp); f%dx = real(grid%dx, dp); f%dy = real(grid%dy, dp)
        f%alt = c_loc(alt); f%xkhh = c_loc(xkhh); f%u_flux = c_loc(uf); f%v_flux = c_loc(vf)
        f%w_flux = c_loc(wf); f%z = c_loc(z); f%z_at_w = c_loc(zw); f%exch_h = c_loc(exch)
+       ! (the stage calls below only enqueue, pmcx_set_async: what they report -- normalize_probs'
+       ! assertions, the movers, cells out of slots, the deposited -- is looked at once, behind the
+       ! pmcx_synchronize at the end of this routine)
+       call pmcx_die(pmcx_set_async(ctx, 1), 'pmcx_set_async')
        call c_f_pointer(pinned(9, 4_c_int64_t * n_cells), bad, [n_cells])
        call pmcx_die(pmcx_transport_probs(ctx, f, c_null_ptr, c_null_ptr, c_null_ptr, c_loc(bad), &
             c_null_ptr), 'pmcx_transport_probs')
-       ! normalize_probs' assertions (wrf_pmc_trans.F90:713,746,759,771)
-       if (any(bad /= 0)) call pmcx_die(5, 'wrf_pmc_trans_driver_pmcx (normalize_probs: a probability is negative, above one, or their sum is)')
 
        call c_f_pointer(pinned(10, 8_c_int64_t * n_cells), cell_volume, [n_cells])
        call c_f_pointer(pinned(11, 8_c_int64_t * n_cells * n_class), expected, [n_cells * n_class])
@@ -1378,9 +1380,11 @@ contains
        ! are keyed apart from those of partmc_timestep's rebalance in the same WRF step
        call pmcx_die(pmcx_rebalance(ctx, merge(1, 0, grid%allow_doubling), merge(1, 0, grid%allow_halving), &
             int(grid%random_seed, c_int64_t), ior(step, ishft(1, 30))), 'pmcx_rebalance')
-       last_n_moved = sum(int(n_moved, 8))
 
        if (.not. ideal) then
+          ! (pmcx_boundary_resample starts a new status word: the transport's is looked at first)
+          call pmcx_die(pmcx_synchronize(ctx), 'pmcx_synchronize')
+          call check_transport_status()
           ! the refill of the lateral boundary cells (trans_aero:803-955): which copy their inner
           ! neighbour (outflow), which are resampled against the background (inflow; emptied first
           ! where the wind has turned or the background has moved to its next time level)
@@ -1422,9 +1426,6 @@ contains
                   int(grid%random_seed, c_int64_t), step, n_add, n_rm), 'pmcx_boundary_resample')
           end if
        end if
-       allocate(ns(n_cells), nc(n_cells), st(n_cells))
-       call pmcx_die(pmcx_get_coag_counters(ctx, ns, nc, st), 'pmcx_get_coag_counters')
-       if (any(iand(st, 16) /= 0)) call pmcx_die(5, 'wrf_pmc_trans_driver_pmcx (a cell ran out of particle slots)')
     end if
 
     ! Do deposition on lowest layer (wrf_pmc_trans.F90:182-198, wrf_pmc_dep.F90:30-96,
@@ -1437,8 +1438,8 @@ contains
        call c_f_pointer(pinned(19, 8_c_int64_t * n_cells), biga_c, [n_cells])
        call c_f_pointer(pinned(20, 8_c_int64_t * n_cells), height, [n_cells])
        call c_f_pointer(pinned(21, 8_c_int64_t * n_cells), rrho, [n_cells])
-       call c_f_pointer(pinned(12, 4_c_int64_t * n_cells), n_rem, [n_cells])
-       call c_f_pointer(pinned(9, 4_c_int64_t * n_cells), bad, [n_cells])
+       call c_f_pointer(pinned(22, 4_c_int64_t * n_cells), n_dep, [n_cells])
+       call c_f_pointer(pinned(23, 4_c_int64_t * n_cells), unreal, [n_cells])
        surface = 0; ra = 1d0; ust = 1d0; alpha_c = 1d0; biga_c = 1d0; height = 1d0; rrho = 1d0
        zr = 2.0
        do j = max(pmc_js, 2), min(pmc_je, global_ny - 1)
@@ -1453,12 +1454,30 @@ contains
           end do
        end do
        call pmcx_die(pmcx_dry_deposition(ctx, real(grid%dt, dp), int(grid%random_seed, c_int64_t), step, &
-            surface, ra, ust, alpha_c, biga_c, height, rrho, n_rem, bad), 'pmcx_dry_deposition')
-       last_n_deposited = sum(int(n_rem, 8))
+            surface, ra, ust, alpha_c, biga_c, height, rrho, n_dep, unreal), 'pmcx_dry_deposition')
        last_aer_res = ra
     end if
 
+    ! the step's queue ends here: wait for it, then look at what it reported
+    call pmcx_die(pmcx_synchronize(ctx), 'pmcx_synchronize')
+    call pmcx_die(pmcx_set_async(ctx, 0), 'pmcx_set_async')
+    if (grid%do_transport) then
+       ! normalize_probs' assertions (wrf_pmc_trans.F90:713,746,759,771)
+       if (any(bad /= 0)) call pmcx_die(5, 'wrf_pmc_trans_driver_pmcx (normalize_probs: a probability is negative, above one, or their sum is)')
+       last_n_moved = sum(int(n_moved, 8))
+       if (ideal) call check_transport_status()
+    end if
+    if (pmc_ks == 1 .and. grid%do_deposition) last_n_deposited = sum(int(n_dep, 8))
+
   contains
+
+    !> the cells' status after the transport: no cell may have run out of slots
+    subroutine check_transport_status()
+      allocate(ns(n_cells), nc(n_cells), st(n_cells))
+      call pmcx_die(pmcx_get_coag_counters(ctx, ns, nc, st), 'pmcx_get_coag_counters')
+      if (any(iand(st, 16) /= 0)) call pmcx_die(5, 'wrf_pmc_trans_driver_pmcx (a cell ran out of particle slots)')
+      deallocate(ns, nc, st)
+    end subroutine check_transport_status
 
     !> 0-based cell number -> WRF's (i, k, j)
     subroutine cell_ijk(c0, i_, k_, j_)

@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "pmcx_test_philox", "pmcx_profile_enable", "pmcx_profile_reset", "pmcx_profile_get", "pmcx_profile_phase_cycles", "pmcx_dry_deposition",
     "pmcx_transport_begin", "pmcx_transport_export_size", "pmcx_transport_export",
     "pmcx_transport_import", "pmcx_transport_finish", "pmcx_device_alloc", "pmcx_device_free",
-    "pmcx_device_copy", "pmcx_host_alloc", "pmcx_host_free",
+    "pmcx_device_copy", "pmcx_host_alloc", "pmcx_host_free", "pmcx_set_async",
     "pmcx_memory_bytes", "pmcx_device_memory_info", "pmcx_set_cell_id_base", "pmcx_set_gas_state",
     "pmcx_get_gas_state", "pmcx_set_gas_scenario", "pmcx_scenario_update_gas_state",
     "pmcx_invalidate_lists", "pmcx_get_keys", "pmcx_seasalt_emissions",
@@ -176,6 +176,7 @@ def load_library():
     L.pmcx_device_free.argtypes = [C.c_void_p, C.c_void_p]
     L.pmcx_host_alloc.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
     L.pmcx_host_free.argtypes = [C.c_void_p, C.c_void_p]
+    L.pmcx_set_async.argtypes = [C.c_void_p, C.c_int32]
     L.pmcx_device_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
     L.pmcx_dry_deposition.argtypes = [C.c_void_p, C.c_double, C.c_uint64, C.c_uint32] + [C.c_void_p] * 9
     L.pmcx_timestep.argtypes = [C.c_void_p, C.POINTER(PmcxStepFlags)]
@@ -345,6 +346,11 @@ class CellBlock:
         a = np.zeros(self.cfg.n_cells, dtype=np.int64)
         self._ck(self._lib.pmcx_get_next_id(self._h, _ptr(a)))
         return a
+
+    def set_async(self, on=True):
+        """The per-step stage calls return without waiting for the device (pmcx_set_async): results
+        are valid after synchronize(); use with reuse_outputs and host_array inputs."""
+        self._ck(self._lib.pmcx_set_async(self._h, int(bool(on))))
 
     def host_array(self, shape, dtype=np.float64):
         """A numpy array over page-locked host memory (pmcx_host_alloc) for per-step inputs and
@@ -548,7 +554,7 @@ class CellBlock:
             return None, None
         n = self.cfg.n_cells if n_rows is None else n_rows
         if isinstance(modes, int):      # the resident modes (set_aero_scenario_modes): only num_conc travels
-            keep = dict(nc=np.broadcast_to(_f64(num_conc), (n, modes)).copy())
+            keep = dict(nc=np.ascontiguousarray(np.broadcast_to(_f64(num_conc), (n, modes))))
             return PmcxAeroDist(modes, keep["nc"].ctypes.data, None, None, None, None, None, 0), keep
         per_cell = isinstance(modes[0], (list, tuple))
         if per_cell:
@@ -558,7 +564,7 @@ class CellBlock:
         else:
             flat, M = modes, len(modes)
         keep = dict(
-            nc=np.broadcast_to(_f64(num_conc), (n, M)).copy(),
+            nc=np.ascontiguousarray(np.broadcast_to(_f64(num_conc), (n, M))),
             gm=_f64([m["gm_radius"] for m in flat]), gs=_f64([m["gsd_log10"] for m in flat]),
             vf=_f64([m["vol_frac"] for m in flat]),
             mc=np.array([m.get("wclass", 0) for m in flat], dtype=np.int32),
@@ -587,7 +593,8 @@ class CellBlock:
         n = self.cfg.n_cells
         e, ke = self._aero_dist(emission, emission_rate)
         b, kb = self._aero_dist(background, background_conc)
-        dil = None if dilution_rate is None else np.broadcast_to(_f64(dilution_rate), (n,)).copy()
+        dil = None if dilution_rate is None else np.ascontiguousarray(np.broadcast_to(_f64(dilution_rate), (n,)))
+        self._inflight = (e, ke, b, kb, dil)    # (an asynchronous call reads them after it has returned)
         ne, ni, no = (self._out("scen%d" % k, n) for k in range(3))
         self._ck(self._lib.pmcx_scenario_update_aero_state(
             self._h, dt, elapsed_time, seed, step, C.addressof(e) if e else None, _ptr(dil),
