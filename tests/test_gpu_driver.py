@@ -66,7 +66,17 @@ def test_wrf_steps_through_the_two_drivers(tmp_path, wp, oracle, periodic):
         assert np.array_equal(fc["n_orig"], oc.n_orig[:, :n]), c
         assert np.array_equal(fc["ct"][:, 0], oc.lct[:n]) and np.array_equal(fc["ct"][:, 1], oc.gct[:n]), c
         assert np.array_equal(fc["mag"], oc.mag), c
+        # component(:) (driver:1421-1437): source and create time of every constituent, through
+        # coagulation, doubling, transport copies, boundary copies and refills, emissions, sea salt
+        tot = oc.n_orig[:, :n].sum(0)
+        for i in range(n):
+            k, lst = int(oc.comp_n[i]), fc["comp"][i]
+            assert len(lst) == tot[i] and k == min(int(tot[i]), 8), (c, i)
+            assert np.array_equal(lst["s"][:k] - 1, oc.comp_src[i, :k]), (c, i)
+            assert np.array_equal(lst["t"][:k], oc.comp_time[i, :k]), (c, i)
+            assert (lst["t"][k:] == oc.gct[i]).all(), (c, i)
         assert np.array_equal(fc["gas"].view(np.uint64), gas[c].view(np.uint64)), c
+    assert any(len(l) >= 2 for fc in final for l in fc["comp"])           # coagulated particles: lists of two constituents
     # the case exercises what it claims to
     tot = lambda k: sum(st[k] for st in steps)
     chem = [st["n_coag"] for st in steps]

@@ -142,9 +142,12 @@ class Case:
         cells = []
         for c in range(self.n_cells):
             oc = oracle.Cell(self.n_spec, self.n_class, self.n_source, cap, self.density, v_edge,
-                             max_events=max_events, max_appends=max_appends)
+                             max_events=max_events, max_appends=max_appends, n_comp_max=8)   # (the shim's default)
             oc.mag[:] = self.mag[c]
             oc.generate(modes, self.n_part, self.seed, c, first_id=((c + 1) << 40) + 7, create_time=-float(c))
+            # every particle its own create time: the lists show whose constituents they hold
+            oc.lct[:self.n_part] = oc.gct[:self.n_part] = oc.comp_time[:self.n_part, 0] = \
+                -float(c) - 1e-3 * np.arange(self.n_part)
             oc.cell_id = c
             oc.next_id = 1 + (c << 32)          # the shim's id blocks (pmcx_upload_states)
             cells.append(oc)
@@ -208,6 +211,11 @@ class Case:
                               wclass=blob[:, o + 4 * self.n_source:o + 4 * self.n_source + 4].copy().view("<i4")[:, 0] - 1,
                               id=blob[:, o + 4 * self.n_source + 4:o + 4 * self.n_source + 12].copy().view("<i8")[:, 0],
                               ct=blob[:, o + 4 * self.n_source + 12:].copy().view("<f8")))
+            comp = []           # component(:) of every particle: arrays of (source_id, create_time)
+            for _ in range(npt):
+                k = int(np.frombuffer(out, "<i4", 1, off)[0]); off += 4
+                comp.append(np.frombuffer(out, np.dtype([("s", "<i4"), ("t", "<f8")]), k, off)); off += 12 * k
+            final[-1]["comp"] = comp
         assert off == len(out), (off, len(out))
         return steps, final
 

@@ -198,6 +198,16 @@ program test_driver
         write(uo) aero_states(i,k,j)%apa%particle(q)%least_create_time, &
              aero_states(i,k,j)%apa%particle(q)%greatest_create_time
      end do
+     ! component(:) of the cell's particles, one list after the other: int32 length, then
+     ! (int32 source_id, float64 create_time) per entry
+     do q = 1, aero_states(i,k,j)%apa%n_part
+        n_comp = aero_particle_n_components(aero_states(i,k,j)%apa%particle(q))
+        write(uo) n_comp
+        do kk = 1, n_comp
+           write(uo) aero_states(i,k,j)%apa%particle(q)%component(kk)%source_id
+           write(uo) aero_states(i,k,j)%apa%particle(q)%component(kk)%create_time
+        end do
+     end do
   end do
   end do
   end do
