@@ -97,7 +97,8 @@ typedef struct {
     int32_t n_comp_max;   /* particle%component(:) (driver:1421-1437): entries of a particle's
                              list carried on the device, 0..8 (0, the default: only the source
                              histogram n_orig and the least/greatest create times); needs
-                             1 <= n_source <= 255; 8 (1 + n_comp_max) bytes per slot  */
+                             1 <= n_source <= 255; 8 (1 + n_comp_max) bytes per slot and
+                             8 max_events bytes per cell                             */
     int32_t pad_;
 } pmcx_config;
 

@@ -139,8 +139,10 @@ int dev_alloc(pmcx_ctx *ctx, T **p, size_t count, bool zero = true)
     return PMCX_OK;
 }
 
-// a block of at least `bytes` for the duration of a call (every call synchronises its stream
-// before it returns, so a released block is free for the next one)
+// a block of at least `bytes` for the duration of a call: released blocks are reused by later
+// calls, whose uploads and kernels run behind this call's on the one stream (so a block is never
+// overwritten before the kernel that read it has finished, also when the calls do not wait:
+// pmcx_set_async)
 hipError_t tmp_malloc(pmcx_ctx *ctx, void **p, size_t bytes)
 {
     if (bytes == 0) bytes = 1;
@@ -394,6 +396,13 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
 #undef A_
     if (rc != PMCX_OK) {
         g_create_error = ctx->err;
+        if (rc == PMCX_ENOMEM) {
+            char more[256];
+            snprintf(more, sizeof more, " (%d cells x %d slots, %.1f GB allocated before it; n_comp_max = %d "
+                     "takes %d bytes of every slot)", cfg->n_cells, cfg->cap, (double)ctx->bytes / 1e9,
+                     cfg->n_comp_max, cfg->n_comp_max > 0 ? 8 * (1 + cfg->n_comp_max) : 0);
+            g_create_error += more;
+        }
         pmcx_destroy(ctx);
         return rc;
     }
