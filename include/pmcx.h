@@ -424,6 +424,18 @@ int pmcx_transport_preweight_finish(pmcx_ctx *ctx, const double *terms_from_belo
  *                               included), movers removed, ghost rows emptied
  * The result on the real rows is bit for bit the one of pmcx_transport on the whole domain
  * (tests/test_gpu_parity.py::test_transport_slabs_match_whole_domain). */
+/* A block cut in x as well (the reference decomposes in x and y, wrf_pmc_trans_aero.F90:148-273):
+ * cut_x != 0 says columns 0 and nx_local - 1 of the block are ghosts of the ranks to the west and
+ * east, local column 0 standing for the domain's column i_global0 (-1 on the west-most rank of a
+ * periodic domain means its last column) of global_nx.  The exchange then has four sides -- 0 below,
+ * 1 above, 2 west, 3 east -- in pmcx_transport_export_size / _export / _import; a mover goes to one
+ * of its four neighbours or a level of its column, so corners never carry anything.  Because a row
+ * of such a block is shorter than a row of the domain, the global id of local cell c -- the key of
+ * every random draw, in every entry point -- becomes cell_id_base + (c / nx_local) global_nx +
+ * c % nx_local, cell_id_base being the global id of local cell 0 (modulo 2^32).  cut_x = 0: back to
+ * slabs along y (global id = cell_id_base + c).  Set once, before anything draws. */
+int pmcx_set_transport_cuts(pmcx_ctx *ctx, int32_t cut_x, int32_t nx_local, int32_t i_global0,
+                            int32_t global_nx);
 /* plain device buffers on the context's GPU for the halo exchange (callers that already hold
  * device memory, e.g. torch tensors handed to RCCL, pass their own pointers instead) */
 int pmcx_device_alloc(pmcx_ctx *ctx, int64_t n_bytes, void **dev_ptr);

@@ -1313,6 +1313,102 @@ def test_transport_slabs_match_whole_domain(wp):
         b.close()
 
 
+@pytest.mark.parametrize("periodic", [True, False])
+def test_transport_blocks_cut_in_x_and_y(wp, periodic):
+    """The transport exchange with both cut directions (the reference decomposes in x and y,
+    wrf_pmc_trans_aero.F90:148-273): the domain as 2 x 2 blocks, each with a ghost row and a ghost
+    column on every side, movers exported / imported through the four sides (what RCCL would carry
+    between four ranks), gives on every real cell exactly the particles -- order, ids of the copies,
+    component lists when they are carried -- of pmcx_transport on the whole domain.  periodic:
+    doubly periodic; otherwise open lateral boundaries (boundary cells send inwards only, what
+    reaches them leaves)."""
+    nx, nz, ny, n_class, n_spec, cap, n_part = 8, 3, 6, 2, 2, 1024, 400
+    bx, by = 2, 2
+    rx, ry = nx // bx, ny // by                      # real columns / rows per block
+    n = nx * nz * ny
+    rng = np.random.RandomState(17)
+    names, dens = parity.default_species(n_spec)
+    modes, _ = parity.make_modes(n_spec, n_class)
+    for m in modes:
+        m["source"] = m["source"] % 2
+    mag = rng.uniform(0.5e7, 2e7, (n, n_class))
+    cv = rng.uniform(0.8e9, 1.3e9, n)
+    ph = rng.uniform(0, 0.08, (n, n_class, 4)); pv = rng.uniform(0, 0.04, (n, n_class, nz))
+    kc = parity.N_COMP_MAX
+    whole = wp.CellBlock(n, cap, n_spec, n_class=n_class, n_source=2, n_comp_max=kc)
+    whole.set_aero_data(dens); whole.set_env(280.0, 9e4); whole.set_weights(mag)
+    whole.set_next_id((np.arange(n, dtype=np.int64) << 32) + (1 << 20))
+    whole.generate_lognormal(n_part, modes, seed=3)
+    if not periodic:
+        whole.set_transport_lateral(True)
+    dn = whole.download_cells()
+    cm = whole.download_components() if kc else None
+    blocks = []
+    for b in range(by):
+        for a in range(bx):
+            gi0, gj0 = a * rx - 1, b * ry - 1                     # the domain's column / row of local (0, 0)
+            nxl, nyl = rx + 2, ry + 2
+            lj, lk, li = np.meshgrid(np.arange(nyl), np.arange(nz), np.arange(nxl), indexing="ij")
+            gmap = ((((gj0 + lj) % ny) * nz + lk) * nx + (gi0 + li) % nx).ravel()     # local cell -> the domain's
+            real = ((li >= 1) & (li <= rx) & (lj >= 1) & (lj <= ry)).ravel()
+            nloc = nxl * nz * nyl
+            blk = wp.CellBlock(nloc, cap, n_spec, n_class=n_class, n_source=2, n_comp_max=kc,
+                               cell_id_base=((gj0 * nz) * nx + gi0) % (1 << 32))
+            blk.set_transport_cuts(True, nxl, gi0, nx)
+            if not periodic:
+                blk.set_transport_lateral(True, gj0, ny)
+            blk.set_aero_data(dens); blk.set_env(280.0, 9e4)
+            blk.set_weights(mag[gmap])                              # ghosts: the neighbours' weights
+            blk.set_next_id((gmap.astype(np.int64) << 32) + (1 << 20))
+            counts = np.where(real, np.diff(dn["part_offset"])[gmap], 0)
+            po = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+            sel = np.concatenate([np.arange(dn["part_offset"][g], dn["part_offset"][g + 1])
+                                  for g, r in zip(gmap, real) if r])
+            blk.upload_cells(0, po, dn["vol"][:, sel], dn["wclass"][sel], dn["id"][sel], dn["least_ct"][sel],
+                             dn["greatest_ct"][sel], dn["n_orig"][:, sel])
+            if kc:
+                blk.upload_components(0, po, cm["comp_len"][sel], cm["comp_source"][sel], cm["comp_time"][sel])
+            blocks.append(dict(blk=blk, gmap=gmap, real=real, a=a, b=b, nxl=nxl, nyl=nyl))
+    at = lambda a, b: blocks[(b % by) * bx + (a % bx)]
+    total_moved = 0
+    for step in range(3):
+        nm_w, na_w = whole.transport(nx, nz, ny, ph, pv, cv, 9, step, periodic, periodic)
+        for B in blocks:
+            B["blk"].transport_begin(B["nxl"], nz, B["nyl"], ph[B["gmap"]], pv[B["gmap"]], cv[B["gmap"]], 9, step, False)
+        out = [[B["blk"].transport_export(side) for side in range(4)] for B in blocks]
+        ex = lambda a, b, side: out[(b % by) * bx + (a % bx)][side]
+        for B in blocks:
+            a, b, blk = B["a"], B["b"], B["blk"]
+            # below <- the block below's upward movers, above <- ..., west <- the western block's eastward movers
+            nb = [(a, b - 1, 1), (a, b + 1, 0), (a - 1, b, 3), (a + 1, b, 2)]
+            for side, (na_, nb_, their) in enumerate(nb):
+                inside = periodic or (0 <= na_ < bx and 0 <= nb_ < by)
+                blk.transport_import(side, ex(na_, nb_, their).copy_to(blk) if inside else None)
+        ref = whole.download_cells()
+        ref_c = whole.download_components() if kc else None
+        for B in blocks:
+            blk, gmap, real = B["blk"], B["gmap"], B["real"]
+            nm, na = blk.transport_finish()
+            assert np.array_equal(nm[real], nm_w[gmap[real]]) and np.array_equal(na[real], na_w[gmap[real]]), step
+            assert not blk.aero_state_total_particles()[~real].any()       # the ghosts are empty again
+            got = blk.download_cells()
+            gl = np.flatnonzero(real)
+            assert np.array_equal(np.diff(got["part_offset"])[gl], np.diff(ref["part_offset"])[gmap[gl]]), step
+            sel = np.concatenate([np.arange(ref["part_offset"][g], ref["part_offset"][g + 1]) for g in gmap[gl]])
+            for k in ("vol", "wclass", "id", "least_ct", "greatest_ct", "n_orig"):
+                assert np.array_equal(got[k], ref[k][..., sel]), (step, k)
+            if kc:
+                got_c = blk.download_components()
+                for k in ("comp_len", "comp_source", "comp_time"):
+                    assert np.array_equal(got_c[k], ref_c[k][sel]), (step, k)
+            assert np.array_equal(blk.get_next_id()[gl], whole.get_next_id()[gmap[gl]])
+        total_moved += int(nm_w.sum())
+    assert total_moved > 2000
+    whole.close()
+    for B in blocks:
+        B["blk"].close()
+
+
 def test_transport_conserves_with_equal_weights(wp):
     """Equal weights and volumes everywhere: every mover arrives exactly once, so the total
     particle count and the multiset of ids are conserved; a closed box keeps everything in."""

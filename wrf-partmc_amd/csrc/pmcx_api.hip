@@ -57,7 +57,7 @@ struct pmcx_ctx {
     int32_t *d_halo = nullptr;      // [2 sides][counts(row_cells) | offsets(row_cells + 1)] + import scratch
     int halo_nx = 0, halo_nz = 0, halo_ny = 0, halo_px = 0; // halo_nx != 0: a transport is open
     int halo_row_cells = 0;         // row size d_halo was allocated for (kept across steps)
-    int64_t halo_total[2] = {0, 0}; // records to export per side (after _export_size)
+    int64_t halo_total[4] = {0, 0, 0, 0}; // records to export per side (after _export_size)
     double *d_halo_cv = nullptr;    // [n_cells] cell volumes of the open transport (own buffer: the
                                     // staging area may be reallocated between _begin and _finish)
     int32_t *d_halo_bad = nullptr;  // [1] records of an imported buffer that failed validation
@@ -911,6 +911,25 @@ int pmcx_invalidate_sort(pmcx_ctx *ctx)
     if (!ctx) return PMCX_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     HIP_TRY(ctx, invalidate_sort(ctx, 0, ctx->cfg.n_cells));
+    return PMCX_OK;
+}
+
+int pmcx_set_transport_cuts(pmcx_ctx *ctx, int32_t cut_x, int32_t nx_local, int32_t i_global0, int32_t global_nx)
+{
+    if (!ctx) return PMCX_EINVAL;
+    if (!cut_x) {
+        ctx->st.trans_cut_x = 0; ctx->st.trans_i0 = 0; ctx->st.trans_gnx = 0;
+        ctx->st.id_nx_local = 0; ctx->st.id_nx_global = 0;
+        return PMCX_OK;
+    }
+    if (nx_local < 3 || global_nx < nx_local - 2 || ctx->cfg.n_cells % nx_local != 0)
+        return fail(ctx, PMCX_EINVAL, "pmcx_set_transport_cuts: a block cut in x has nx_local >= 3 columns (two of "
+                                      "them ghosts), n_cells a multiple of it, and global_nx >= nx_local - 2");
+    ctx->st.trans_cut_x = 1;
+    ctx->st.trans_i0 = i_global0;
+    ctx->st.trans_gnx = global_nx;
+    ctx->st.id_nx_local = nx_local;   // cell ids: rows of nx_local cells inside rows of global_nx
+    ctx->st.id_nx_global = global_nx;
     return PMCX_OK;
 }
 
@@ -1771,20 +1790,25 @@ int pmcx_transport_begin(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int3
     if (ctx->st.trans_lateral && (periodic_x || nx < 3 || ctx->st.trans_gny < 3))
         return fail(ctx, PMCX_EINVAL, "pmcx_transport_begin: open lateral boundaries need a non-periodic domain "
                                       "and the slab's place in it (pmcx_set_transport_lateral)");
+    if (ctx->st.trans_cut_x && (nx < 3 || ctx->st.trans_gnx < nx - 2))
+        return fail(ctx, PMCX_EINVAL, "pmcx_transport_begin: a block cut in x has two ghost columns (nx >= 3) and "
+                                      "knows the domain's columns (pmcx_set_transport_cuts)");
+    if (ctx->st.trans_cut_x) periodic_x = 0; // (the ghost columns stand for whatever lies beyond)
     HIP_TRY(ctx, hipSetDevice(cf.device));
     int rc = transport_buffers(ctx);
     if (rc) return rc;
-    const size_t nc = (size_t)cf.n_cells, C = (size_t)cf.n_class, row = (size_t)nx * nz;
-    if (!ctx->d_halo || ctx->halo_row_cells < (int)row) { // grown only when the rows get longer
+    const size_t nc = (size_t)cf.n_cells, C = (size_t)cf.n_class;
+    const size_t row = std::max((size_t)nx * nz, ctx->st.trans_cut_x ? (size_t)ny * nz : (size_t)0); // the longest strip
+    if (!ctx->d_halo || ctx->halo_row_cells < (int)row) { // grown only when the strips get longer
         if (ctx->d_halo) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             for (auto it = ctx->allocs.begin(); it != ctx->allocs.end(); ++it)
                 if (*it == (void *)ctx->d_halo) { ctx->allocs.erase(it); break; }
             HIP_TRY(ctx, hipFree(ctx->d_halo));
-            ctx->bytes -= (int64_t)sizeof(int32_t) * 6 * ((int64_t)ctx->halo_row_cells + 1);
+            ctx->bytes -= (int64_t)sizeof(int32_t) * 12 * ((int64_t)ctx->halo_row_cells + 1);
             ctx->d_halo = nullptr;
         }
-        rc = dev_alloc(ctx, &ctx->d_halo, 6 * (row + 1));
+        rc = dev_alloc(ctx, &ctx->d_halo, 12 * (row + 1)); // counts + offsets of 4 export sides, offsets of 4 imports
         if (rc) return rc;
         ctx->halo_row_cells = (int)row;
     }
@@ -1803,7 +1827,7 @@ int pmcx_transport_begin(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int3
     HIP_TRY(ctx, hipMemcpyAsync(d_cv, cell_volume, bc, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->st.status, 0, sizeof(int32_t) * nc, ctx->stream));
     ctx->halo_nx = nx; ctx->halo_nz = nz; ctx->halo_ny = ny; ctx->halo_px = periodic_x;
-    ctx->halo_total[0] = ctx->halo_total[1] = -1;
+    ctx->halo_total[0] = ctx->halo_total[1] = ctx->halo_total[2] = ctx->halo_total[3] = -1;
     ProfScope ps(ctx, "transport");
     HIP_TRY(ctx, launch_transport_begin(ctx->st, nx, nz, ny, periodic_x, 0, d_ph, d_pv, d_cv,
                                         ctx->d_outbox, ctx->d_n_out, ctx->d_n_arr, ctx->d_n_exp,
@@ -1816,35 +1840,51 @@ int pmcx_transport_begin(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int3
 
 static inline size_t halo_header_bytes(int row_cells) { return ((size_t)row_cells * 4 + 15) & ~(size_t)15; }
 
+// The strips of one side of the exchange (0: towards the rank below, 1: above, 2: west, 3: east):
+// the real boundary strip whose movers travel, the ghost strip behind it they are addressed to, and
+// the bit by which a cell of the ghost strip says "I send to the real strip" (k_trans_decide's code).
+struct HaloSide { Strip real, ghost; uint64_t bit_in; };
+static HaloSide halo_side(const pmcx_ctx *ctx, int side)
+{
+    const int nx = ctx->halo_nx, nz = ctx->halo_nz, ny = ctx->halo_ny, row = nx * nz, col = ny * nz;
+    switch (side) {
+    case 0: return {{1 * row, 1, row}, {0, 1, row}, 4ull};                       // ghost row 0 sends north
+    case 1: return {{(ny - 2) * row, 1, row}, {(ny - 1) * row, 1, row}, 8ull};   // ghost row ny-1 sends south
+    case 2: return {{1, nx, col}, {0, nx, col}, 1ull};                           // ghost column 0 sends east
+    default: return {{nx - 2, nx, col}, {nx - 1, nx, col}, 2ull};                // ghost column nx-1 sends west
+    }
+}
+static inline int halo_sides(const pmcx_ctx *ctx) { return ctx->st.trans_cut_x ? 4 : 2; }
+
 int pmcx_transport_export_size(pmcx_ctx *ctx, int32_t side, int64_t *n_bytes)
 {
-    if (!ctx || !n_bytes || side < 0 || side > 1 || !ctx->halo_nx)
+    if (!ctx || !n_bytes || !ctx->halo_nx || side < 0 || side >= halo_sides(ctx))
         return fail(ctx, PMCX_EINVAL, "pmcx_transport_export_size: bad argument or no pmcx_transport_begin");
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
-    const int row = ctx->halo_nx * ctx->halo_nz, ny = ctx->halo_ny;
-    const int src_row = side == 0 ? 1 : ny - 2, dst_row = side == 0 ? 0 : ny - 1;
-    int32_t *counts = ctx->d_halo + (size_t)side * 2 * (row + 1), *offsets = counts + row;
-    HIP_TRY(ctx, launch_halo_count(ctx->st, ctx->halo_nx, ctx->halo_nz, ny, ctx->d_outbox, ctx->d_n_out,
-                                   src_row, dst_row, counts, offsets, ctx->stream));
+    const HaloSide h = halo_side(ctx, side);
+    const int L = ctx->halo_row_cells, n = h.real.n;
+    int32_t *counts = ctx->d_halo + (size_t)side * 2 * (L + 1), *offsets = counts + L;
+    HIP_TRY(ctx, launch_halo_count(ctx->st, ctx->halo_nx, ctx->halo_nz, ctx->halo_ny, ctx->d_outbox, ctx->d_n_out,
+                                   h.real, h.ghost, counts, offsets, ctx->stream));
     int32_t total = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&total, offsets + row, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&total, offsets + n, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->halo_total[side] = total;
-    *n_bytes = (int64_t)halo_header_bytes(row) + (int64_t)total * (int64_t)halo_record_bytes(ctx->st);
+    *n_bytes = (int64_t)halo_header_bytes(n) + (int64_t)total * (int64_t)halo_record_bytes(ctx->st);
     return PMCX_OK;
 }
 
 int pmcx_transport_export(pmcx_ctx *ctx, int32_t side, void *dev_buf)
 {
-    if (!ctx || !dev_buf || side < 0 || side > 1 || !ctx->halo_nx || ctx->halo_total[side] < 0)
+    if (!ctx || !dev_buf || !ctx->halo_nx || side < 0 || side >= halo_sides(ctx) || ctx->halo_total[side] < 0)
         return fail(ctx, PMCX_EINVAL, "pmcx_transport_export: call pmcx_transport_export_size first");
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
-    const int row = ctx->halo_nx * ctx->halo_nz, ny = ctx->halo_ny;
-    const int src_row = side == 0 ? 1 : ny - 2, dst_row = side == 0 ? 0 : ny - 1;
-    const int32_t *counts = ctx->d_halo + (size_t)side * 2 * (row + 1), *offsets = counts + row;
-    HIP_TRY(ctx, hipMemcpyAsync(dev_buf, counts, sizeof(int32_t) * row, hipMemcpyDeviceToDevice, ctx->stream));
-    HIP_TRY(ctx, launch_halo_pack(ctx->st, ctx->halo_nx, ctx->halo_nz, ny, ctx->d_outbox, ctx->d_n_out,
-                                  src_row, dst_row, offsets, (unsigned char *)dev_buf + halo_header_bytes(row),
+    const HaloSide h = halo_side(ctx, side);
+    const int L = ctx->halo_row_cells, n = h.real.n;
+    const int32_t *counts = ctx->d_halo + (size_t)side * 2 * (L + 1), *offsets = counts + L;
+    HIP_TRY(ctx, hipMemcpyAsync(dev_buf, counts, sizeof(int32_t) * n, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, launch_halo_pack(ctx->st, ctx->halo_nx, ctx->halo_nz, ctx->halo_ny, ctx->d_outbox, ctx->d_n_out,
+                                  h.real, h.ghost, offsets, (unsigned char *)dev_buf + halo_header_bytes(n),
                                   ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PMCX_OK;
@@ -1852,15 +1892,15 @@ int pmcx_transport_export(pmcx_ctx *ctx, int32_t side, void *dev_buf)
 
 int pmcx_transport_import(pmcx_ctx *ctx, int32_t side, const void *dev_buf, int64_t n_bytes)
 {
-    if (!ctx || side < 0 || side > 1 || !ctx->halo_nx)
+    if (!ctx || !ctx->halo_nx || side < 0 || side >= halo_sides(ctx))
         return fail(ctx, PMCX_EINVAL, "pmcx_transport_import: bad argument or no pmcx_transport_begin");
-    if (!dev_buf || n_bytes == 0) return PMCX_OK; // no neighbour on that side: the ghost row stays empty
+    if (!dev_buf || n_bytes == 0) return PMCX_OK; // no neighbour on that side: the ghost strip stays empty
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
-    const int row = ctx->halo_nx * ctx->halo_nz, ny = ctx->halo_ny;
+    const HaloSide h = halo_side(ctx, side);
+    const int L = ctx->halo_row_cells, row = h.ghost.n;
     if (n_bytes < (int64_t)halo_header_bytes(row))
         return fail(ctx, PMCX_EINVAL, "pmcx_transport_import: buffer shorter than its header");
-    const int ghost_row = side == 0 ? 0 : ny - 1, real_row = side == 0 ? 1 : ny - 2;
-    int32_t *offsets = ctx->d_halo + 4 * (size_t)(row + 1) + (size_t)side * (row + 1);
+    int32_t *offsets = ctx->d_halo + 8 * (size_t)(L + 1) + (size_t)side * (L + 1);
     // The buffer comes from another process: its counts index this block's slabs.  Checked on the
     // host (counts within a cell's capacity, records within the buffer) before anything is
     // written; destinations, copies and classes are checked record by record in the kernel.
@@ -1883,8 +1923,8 @@ int pmcx_transport_import(pmcx_ctx *ctx, int32_t side, const void *dev_buf, int6
                         (long long)n_bytes);
     }
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_halo_bad, 0, sizeof(int32_t), ctx->stream));
-    HIP_TRY(ctx, launch_halo_unpack(ctx->st, ctx->halo_nx, ctx->halo_nz, ny, ctx->d_outbox, ctx->d_n_out,
-                                    ctx->d_n_exp, ctx->d_dest_mask, ghost_row, real_row,
+    HIP_TRY(ctx, launch_halo_unpack(ctx->st, ctx->halo_nx, ctx->halo_nz, ctx->halo_ny, ctx->d_outbox, ctx->d_n_out,
+                                    ctx->d_n_exp, ctx->d_dest_mask, h.ghost, h.real, h.bit_in,
                                     (const int32_t *)dev_buf, offsets,
                                     (const unsigned char *)dev_buf + halo_header_bytes(row),
                                     ctx->d_halo_bad, ctx->stream));

@@ -87,6 +87,12 @@ struct DeviceState {
     int32_t *n_log;      // [n_cells]
     int32_t trans_lateral; // pmcx_set_transport_lateral: the reference's open lateral boundaries
     int32_t trans_j0, trans_gny; // a slab's place in the domain: the row its row 0 stands for, the domain's rows (0: the block is the domain)
+    // a block cut in x as well (pmcx_set_transport_cuts): columns 0 and nx - 1 are ghosts of the
+    // neighbouring ranks; the column its column 0 stands for, the domain's columns
+    int32_t trans_cut_x, trans_i0, trans_gnx;
+    // the global id of local cell c (the RNG key): cell_id_base + c when a row of the block is a row
+    // of the domain (id_nx_local = 0), else cell_id_base + (c / id_nx_local) id_nx_global + c % id_nx_local
+    int32_t id_nx_local, id_nx_global;
     // pmcx_set_sampler_variant (diagnostic): 0 = the library's own choice
     int32_t force_lanes, force_wpb, force_stamps;
     uint16_t *seq_ovf;   // [n_cells][2 G + 2 max_appends] lane-per-cell sampler: entries past a group's room
@@ -185,6 +191,19 @@ hipError_t launch_transport(const DeviceState &st, int nx, int nz, int ny, int p
                             const double *cell_volume, void *outbox, int32_t *n_out, int32_t *n_arr,
                             int32_t *n_exp, uint64_t *dest_mask, uint64_t seed, uint32_t step,
                             hipStream_t s);
+// a strip of cells: cell(r) = base + r * stride, r < n (a row of the block: stride 1; a column: stride nx)
+struct Strip { int32_t base, stride, n; };
+// counts[n] and offsets[n + 1] of the movers of strip src bound for strip dst; their records; the
+// receiving side (ghost strip <- the neighbour's boundary strip, destinations in strip real;
+// mask_bit: the direction ghost -> real as k_trans_decide codes it)
+hipError_t launch_halo_count(const DeviceState &st, int nx, int nz, int ny, void *outbox, int32_t *n_out,
+                             Strip src, Strip dst, int32_t *counts, int32_t *offsets, hipStream_t s);
+hipError_t launch_halo_pack(const DeviceState &st, int nx, int nz, int ny, void *outbox, int32_t *n_out,
+                            Strip src, Strip dst, const int32_t *offsets, void *recs, hipStream_t s);
+hipError_t launch_halo_unpack(const DeviceState &st, int nx, int nz, int ny, void *outbox, int32_t *n_out,
+                              int32_t *n_exp, uint64_t *dest_mask, Strip ghost, Strip real, uint64_t mask_bit,
+                              const int32_t *counts, int32_t *offsets, const void *recs, int32_t *bad,
+                              hipStream_t s);
 hipError_t launch_transport_begin(const DeviceState &st, int nx, int nz, int ny, int periodic_x,
                                   int periodic_y, const double *prob_h, const double *prob_v,
                                   const double *cell_volume, void *outbox, int32_t *n_out,
@@ -226,16 +245,6 @@ hipError_t launch_transport_preweight(const DeviceState &st, int nx, int nz, int
 size_t trans_probs_lds_bytes(const DeviceState &st, int nz);
 hipError_t launch_transport_probs(const DeviceState &st, const TransFieldsArgs &a, hipStream_t s);
 size_t halo_record_bytes(const DeviceState &st);
-hipError_t launch_halo_count(const DeviceState &st, int nx, int nz, int ny, void *outbox,
-                             int32_t *n_out, int src_row, int dst_row, int32_t *counts,
-                             int32_t *offsets, hipStream_t s);
-hipError_t launch_halo_pack(const DeviceState &st, int nx, int nz, int ny, void *outbox,
-                            int32_t *n_out, int src_row, int dst_row, const int32_t *offsets,
-                            void *recs, hipStream_t s);
-hipError_t launch_halo_unpack(const DeviceState &st, int nx, int nz, int ny, void *outbox,
-                              int32_t *n_out, int32_t *n_exp, uint64_t *dest_mask, int ghost_row,
-                              int real_row, const int32_t *counts, int32_t *offsets, const void *recs,
-                              int32_t *bad, hipStream_t s);
 // per_cell6: [6][n_cells] aer_res_a, ustar, alpha, big_a, height, inv_density
 hipError_t launch_dry_deposition(const DeviceState &st, double dt, uint64_t seed, uint32_t step,
                                  const int32_t *surface, const double *per_cell6,

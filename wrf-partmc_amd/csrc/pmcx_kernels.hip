@@ -86,6 +86,14 @@ __device__ __forceinline__ void st_u16(uint16_t *p, uint32_t v)
     __hip_atomic_store(p, (uint16_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// the global id of local cell c: the key of every random draw (results do not depend on how the
+// domain is cut into blocks)
+__device__ __forceinline__ uint32_t cell_gid(const DeviceState &st, int c)
+{
+    if (st.id_nx_local == 0) return st.cell_id_base + (uint32_t)c;
+    return st.cell_id_base + (uint32_t)(c / st.id_nx_local) * (uint32_t)st.id_nx_global + (uint32_t)(c % st.id_nx_local);
+}
+
 // particles of source s among the constituents of slot i: the first source sits in the
 // particle's metadata record (it is read and written with the create times), the others in
 // their own planes
@@ -902,7 +910,7 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
     const int c = live ? cidx : st.n_cells - 1;
     const int B = st.n_bin, C = st.n_class, G = B * C;
     const int64_t cb = (int64_t)c * st.cap;
-    const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
+    const uint32_t cell_id = cell_gid(st, c);
     const uint64_t lt = (1ull << gl) - 1ull;
     if (in_range && !live && lead) { st.n_samp[cidx] = 0; st.n_coag[cidx] = 0; st.n_events[cidx] = 0; }
 
@@ -1426,7 +1434,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
     const int B = st.n_bin, C = SIMPLE ? 1 : st.n_class, G = B * C;
     const int S = SIMPLE ? 1 : st.n_spec, NS = st.n_source;
     const int64_t cb = (int64_t)c * st.cap;
-    const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
+    const uint32_t cell_id = cell_gid(st, c);
 
     double *edge = (double *)smem;
     double *rcp = (double *)(smem + (((size_t)(B + 1) * sizeof(double) + 15) & ~(size_t)15));
@@ -2667,7 +2675,7 @@ __global__ __launch_bounds__(64) void k_rebalance(DeviceState st, int allow_doub
     const int c = list ? list[wi] : wi;
     if (!in_loop(st, c)) continue; // (uniform over the wavefront)
     const int64_t cb = (int64_t)c * st.cap;
-    const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
+    const uint32_t cell_id = cell_gid(st, c);
     const uint64_t lt = (1ull << lane) - 1ull;
     double *mag = st.mag + (int64_t)c * st.n_class;
     const double *n_ideal = st.n_ideal + (int64_t)c * st.n_class;
@@ -2920,7 +2928,7 @@ __device__ int add_dist_sample(const DeviceState &st, int c, const AeroDistDev &
                                int &status, int lane, const double *means = nullptr)
 {
     const int64_t cb = (int64_t)c * st.cap;
-    const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
+    const uint32_t cell_id = cell_gid(st, c);
     const double *mag = st.mag + (int64_t)c * st.n_class;
     const int64_t mo = d.mo(c);
     int added = 0;
@@ -2984,7 +2992,7 @@ __global__ __launch_bounds__(64) void k_scenario_update(DeviceState st, double d
     const int lane = threadIdx.x;
     const int c = blockIdx.x;
     const int64_t cb = (int64_t)c * st.cap;
-    const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
+    const uint32_t cell_id = cell_gid(st, c);
     const uint64_t lt = (1ull << lane) - 1ull;
     int status = 0, ne = 0, ni = 0, no = 0;
     if (!in_loop(st, c)) {
@@ -3121,7 +3129,7 @@ __global__ __launch_bounds__(256) void k_dry_deposition(DeviceState st, DepArgs 
         return;
     }
     const int64_t cb = (int64_t)c * st.cap;
-    const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
+    const uint32_t cell_id = cell_gid(st, c);
     const uint64_t lt = (1ull << lane) - 1ull;
     const double ra = a.aer_res_a[c], ustar = a.ustar[c], alpha = a.alpha[c], big_a = a.big_a[c];
     const double rrho = a.inv_density[c], temp = st.temp[c], dt_dz = dt / a.height[c];
@@ -3271,6 +3279,19 @@ __device__ __forceinline__ bool lateral_row(const DeviceState &st, int j, int ny
     return gj == 0 || gj == gny - 1;
 }
 
+// ... and is local column i the domain's first or last column?  (a block cut in x carries ghost
+// columns: its column 0 stands for the domain's column trans_i0)
+__device__ __forceinline__ bool lateral_col(const DeviceState &st, int i, int nx)
+{
+    const int gi = i + st.trans_i0, gnx = st.trans_gnx ? st.trans_gnx : nx;
+    return gi == 0 || gi == gnx - 1;
+}
+// a ghost column of a block cut in x
+__device__ __forceinline__ bool ghost_col(const DeviceState &st, int i, int nx)
+{
+    return st.trans_cut_x && (i == 0 || i == nx - 1);
+}
+
 struct TransGrid {
     int32_t nx, nz, ny, periodic_x, periodic_y;
     const double *prob_h, *prob_v, *cell_volume;
@@ -3308,7 +3329,7 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
     const int i = c % nx, k = (c / nx) % nz, j = c / (nx * nz);
     const bool mask_ok = ND <= 64 && (nx >= 3 || !tg.periodic_x) && (ny >= 3 || !tg.periodic_y);
     const int64_t cb = (int64_t)c * st.cap;
-    const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
+    const uint32_t cell_id = cell_gid(st, c);
     const uint64_t lt = (1ull << lane) - 1ull;
     apply_event_log(st, c, lane); // (this step's removals and arrivals keep the cell's keys current)
 
@@ -3321,7 +3342,7 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
         double *p = t_p + cl * ND;
         int *dc = t_tmpd + cl * ND;
         int *ord = t_cnt + cl * ND; // rank -> element (t_cnt is cleared again below)
-        const bool bx = (i == 0 || i == nx - 1), by = lateral_row(st, j, ny);
+        const bool bx = lateral_col(st, i, nx), by = lateral_row(st, j, ny);
         const bool lateral_cell = st.trans_lateral && (bx || by);
         int n = 0;
         for (int d0 = 0; d0 < ND; d0 += 64) {
@@ -3332,7 +3353,8 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
                 if (lateral_cell) {
                     // open lateral boundaries (wrf_pmc_trans_aero.F90:689-768): a boundary cell only
                     // sends inwards, with min(prob, 1); a corner sends nothing
-                    const int din = i == 0 ? 1 : i == nx - 1 ? 0 : (j + st.trans_j0 == 0) ? 3 : 2;
+                    const int gi0 = i + st.trans_i0, gnx0 = st.trans_gnx ? st.trans_gnx : nx;
+                    const int din = gi0 == 0 ? 1 : gi0 == gnx0 - 1 ? 0 : (j + st.trans_j0 == 0) ? 3 : 2;
                     if (!(bx && by) && d == din) {
                         pr = tg.prob_h[((int64_t)c * C + cl) * 4 + d];
                         if (pr > 1.0) pr = 1.0;
@@ -3545,7 +3567,7 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
         if (x % ND < t_n[x / ND] && t_cnt[x] > 0) {
             const int dcell = t_dest[x], di_ = dcell % nx, dj_ = dcell / (nx * nz);
             // (what is sent to an open lateral boundary cell leaves the domain: nobody gathers it)
-            if (st.trans_lateral && (di_ == 0 || di_ == nx - 1 || lateral_row(st, dj_, ny))) continue;
+            if (st.trans_lateral && (lateral_col(st, di_, nx) || lateral_row(st, dj_, ny))) continue;
             atomicAdd(&tg.n_exp[dcell], t_cnt[x]);
         }
     for (int d = 32; d >= 1; d >>= 1) bits |= __shfl_xor(bits, d, 64);
@@ -3891,7 +3913,7 @@ __global__ __launch_bounds__(64) void k_boundary_resample(DeviceState st, const 
     const int act = action[c];
     if (act == 0) return;
     const int64_t cb = (int64_t)c * st.cap;
-    const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
+    const uint32_t cell_id = cell_gid(st, c);
     const uint64_t lt = (1ull << lane) - 1ull;
     const int C = st.n_class;
     const double dens = density[c];
@@ -4140,7 +4162,7 @@ __global__ __launch_bounds__(64) void k_preweight_scale(DeviceState st, Preweigh
 {
     const int lane = threadIdx.x, c = blockIdx.x, C = st.n_class;
     const int64_t cb = (int64_t)c * st.cap;
-    const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
+    const uint32_t cell_id = cell_gid(st, c);
     const uint64_t lt = (1ull << lane) - 1ull;
     double *mag = st.mag + (int64_t)c * C;
     uint32_t removed = 0;
@@ -4249,8 +4271,8 @@ __global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid t
     const int lane = threadIdx.x, c = tg.c_first + blockIdx.x;
     const int nx = tg.nx, nz = tg.nz, ny = tg.ny;
     const int i = c % nx, k = (c / nx) % nz, j = c / (nx * nz);
-    if (st.trans_lateral && (i == 0 || i == nx - 1 || lateral_row(st, j, ny))) {
-        if (lane == 0) tg.n_arr[c] = 0; // an open lateral boundary cell takes nothing in (:775-801)
+    if (ghost_col(st, i, nx) || (st.trans_lateral && (lateral_col(st, i, nx) || lateral_row(st, j, ny)))) {
+        if (lane == 0) tg.n_arr[c] = 0; // an open lateral boundary cell takes nothing in (:775-801); nor does a ghost
         return;
     }
     const int64_t cb = (int64_t)c * st.cap;
@@ -4404,13 +4426,15 @@ __global__ __launch_bounds__(64) void k_trans_remove(DeviceState st, TransGrid t
     // row: packed for the neighbouring rank) or to an open lateral boundary cell.  The sort
     // keys were seen to by k_trans_decide.
     const int nx = tg.nx, nz = tg.nz, ny = tg.ny;
+    if (ghost_col(st, c % nx, nx)) return; // (a ghost column's cells are emptied by k_halo_clear)
     for (int e = lane; e < n_out; e += 64) {
         const int2 en = box[e];
         const int dest = en.y;
-        bool gathered = (en.x >> 16) > 0 && dest >= tg.c_first && dest < tg.c_first + (int)gridDim.x;
+        bool gathered = (en.x >> 16) > 0 && dest >= tg.c_first && dest < tg.c_first + (int)gridDim.x &&
+                        !ghost_col(st, dest % nx, nx); // (to a ghost column: packed for the neighbouring rank)
         if (gathered && st.trans_lateral) {
             const int di = dest % nx, dj = dest / (nx * nz);
-            if (di == 0 || di == nx - 1 || lateral_row(st, dj, ny)) gathered = false;
+            if (lateral_col(st, di, nx) || lateral_row(st, dj, ny)) gathered = false;
         }
         if (!gathered) st_f64(&st.hot[cb + (en.x & 0xFFFF)].vtot, -1.0);
     }
@@ -4444,19 +4468,28 @@ __host__ __device__ inline size_t halo_rec_bytes(int n_spec, int n_source, int n
     return 24 + 16 + 32 + 8 * (size_t)n_spec + ((extra + 7) & ~(size_t)7) + comp;
 }
 
-// entries of the cells of row src_row that go to row dst_row: counts per source cell
-__global__ __launch_bounds__(64) void k_halo_count(DeviceState st, TransGrid tg, int src_row,
-                                                   int dst_row, int32_t *counts)
+// A strip is a row of the block (cells base + r, r < nx nz) or, for a block cut in x as well, a column
+// (cells i0 + r nx, r < ny nz).  Place of a cell in a strip, -1 when it is not in it:
+__device__ __forceinline__ int strip_index(const Strip &t, int cell)
 {
-    const int lane = threadIdx.x, r = blockIdx.x; // r: cell index within the row
-    const int row_cells = tg.nx * tg.nz;
-    const int c = src_row * row_cells + r;
+    const int d = cell - t.base;
+    if (d < 0 || d % t.stride != 0) return -1;
+    const int r = d / t.stride;
+    return r < t.n ? r : -1;
+}
+
+// entries of the cells of strip src that go to strip dst: counts per source cell
+__global__ __launch_bounds__(64) void k_halo_count(DeviceState st, TransGrid tg, Strip src, Strip dst,
+                                                   int32_t *counts)
+{
+    const int lane = threadIdx.x, r = blockIdx.x; // r: cell index within the strip
+    const int c = src.base + r * src.stride;
     const int2 *box = tg.outbox + (int64_t)c * st.cap;
     const int n_out = tg.n_out[c];
     int cnt = 0;
     for (int e0 = 0; e0 < n_out; e0 += 64) {
         const int e = e0 + lane;
-        const bool mine = e < n_out && box[e].y / row_cells == dst_row;
+        const bool mine = e < n_out && strip_index(dst, box[e].y) >= 0;
         cnt += __popcll(__ballot(mine));
     }
     if (lane == 0) counts[r] = cnt;
@@ -4477,13 +4510,11 @@ __global__ __launch_bounds__(64) void k_halo_scan(const int32_t *counts, int32_t
     if (lane == 0) offsets[n] = (int32_t)base;
 }
 
-__global__ __launch_bounds__(64) void k_halo_pack(DeviceState st, TransGrid tg, int src_row,
-                                                  int dst_row, const int32_t *offsets,
-                                                  unsigned char *recs, int rec_bytes)
+__global__ __launch_bounds__(64) void k_halo_pack(DeviceState st, TransGrid tg, Strip src, Strip dst,
+                                                  const int32_t *offsets, unsigned char *recs, int rec_bytes)
 {
     const int lane = threadIdx.x, r = blockIdx.x;
-    const int row_cells = tg.nx * tg.nz;
-    const int c = src_row * row_cells + r;
+    const int c = src.base + r * src.stride;
     const int64_t cb = (int64_t)c * st.cap;
     const int2 *box = tg.outbox + cb;
     const int n_out = tg.n_out[c];
@@ -4494,14 +4525,15 @@ __global__ __launch_bounds__(64) void k_halo_pack(DeviceState st, TransGrid tg, 
         const int e = e0 + lane;
         int2 en = make_int2(0, -1);
         if (e < n_out) en = box[e];
-        const bool mine = e < n_out && en.y / row_cells == dst_row;
+        const int didx = e < n_out ? strip_index(dst, en.y) : -1;
+        const bool mine = didx >= 0;
         const uint64_t m = __ballot(mine);
         if (mine) {
             const int idx = at + __popcll(m & lt);
             unsigned char *rec = recs + (size_t)(offsets[r] + idx) * rec_bytes;
             const int from = en.x & 0xFFFF;
             int32_t *h = (int32_t *)rec;
-            h[0] = r; h[1] = en.y - dst_row * row_cells; h[2] = en.x >> 16;
+            h[0] = r; h[1] = didx; h[2] = en.x >> 16;
             h[3] = st.wclass[cb + from]; h[4] = idx; h[5] = 0;
             double *d = (double *)(rec + 24);
             d[0] = st.hot[cb + from].vtot; d[1] = st.hot[cb + from].mass;
@@ -4523,15 +4555,13 @@ __global__ __launch_bounds__(64) void k_halo_pack(DeviceState st, TransGrid tg, 
 
 // the receiving side: ghost cell r of row ghost_row gets its records' particles in slots 0..,
 // an outbox naming them with destinations in row real_row, and tells those cells what is coming
-__global__ __launch_bounds__(64) void k_halo_unpack(DeviceState st, TransGrid tg, int ghost_row,
-                                                    int real_row, const int32_t *counts,
-                                                    const int32_t *offsets,
+__global__ __launch_bounds__(64) void k_halo_unpack(DeviceState st, TransGrid tg, Strip ghost, Strip real,
+                                                    const int32_t *counts, const int32_t *offsets,
                                                     const unsigned char *recs, int rec_bytes,
                                                     uint64_t mask_bit, int32_t *bad)
 {
     const int lane = threadIdx.x, r = blockIdx.x;
-    const int row_cells = tg.nx * tg.nz;
-    const int c = ghost_row * row_cells + r;
+    const int c = ghost.base + r * ghost.stride;
     const int64_t cb = (int64_t)c * st.cap;
     int2 *box = tg.outbox + cb;
     const int S = st.n_spec, NS = st.n_source;
@@ -4544,10 +4574,10 @@ __global__ __launch_bounds__(64) void k_halo_unpack(DeviceState st, TransGrid tg
         int copies = h[2];
         // the buffer was written by another process: what indexes this block is checked; a
         // record that fails becomes an entry without copies (dropped) and is counted
-        const bool ok = h[4] == e && (unsigned)h[1] < (unsigned)row_cells &&
+        const bool ok = h[4] == e && (unsigned)h[1] < (unsigned)real.n &&
                         (unsigned)copies < 32768u && (unsigned)h[3] < (unsigned)st.n_class;
         if (!ok) { atomicAdd(bad, 1); copies = 0; }
-        const int dest = real_row * row_cells + (ok ? h[1] : 0);
+        const int dest = real.base + (ok ? h[1] : 0) * real.stride;
         const double *d = (const double *)(rec + 24);
         st.hot[cb + slot].vtot = d[0]; st.hot[cb + slot].mass = d[1];
         st.hot[cb + slot].lct = d[2]; st.hot[cb + slot].gct = d[3];
@@ -4574,12 +4604,11 @@ __global__ __launch_bounds__(64) void k_halo_unpack(DeviceState st, TransGrid tg
 }
 
 // ghost rows are scratch: empty again once the step is over
-__global__ void k_halo_clear(DeviceState st, TransGrid tg, int row_a, int row_b)
+__global__ void k_halo_clear(DeviceState st, TransGrid tg, Strip a, Strip b)
 {
-    const int row_cells = tg.nx * tg.nz;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= 2 * row_cells) return;
-    const int c = (j < row_cells ? row_a : row_b) * row_cells + (j % row_cells);
+    if (j >= a.n + b.n) return;
+    const int c = j < a.n ? a.base + j * a.stride : b.base + (j - a.n) * b.stride;
     st.n_hi[c] = 0; st.n_part[c] = 0; tg.n_out[c] = 0; tg.dest_mask[c] = 0; st.sort_valid[c] = 0;
     st.key_valid[c] = 0;
 }
@@ -4673,7 +4702,7 @@ __global__ void k_generate(DeviceState st, GenSpecDev g, int n, uint64_t seed, d
 {
     const int c = blockIdx.y;
     const int64_t cb = (int64_t)c * st.cap;
-    const uint32_t cell_id = st.cell_id_base + (uint32_t)c;
+    const uint32_t cell_id = cell_gid(st, c);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         uint32_t w[4];
         rng_block(seed, cell_id, 0u, (uint32_t)i, SITE_GEN, 0, w);
@@ -5199,8 +5228,14 @@ hipError_t launch_transport_finish(const DeviceState &st, int nx, int nz, int ny
     hipLaunchKernelGGL(k_trans_room, dim3((st.n_cells + 3) / 4), dim3(256), compact_lds_bytes(st), s, st, tg);
     hipLaunchKernelGGL(k_trans_gather, dim3(n_do), dim3(64), 0, s, st, tg);
     hipLaunchKernelGGL(k_trans_remove, dim3(n_do), dim3(64), 0, s, st, tg);
-    if (n_rows != ny) // a slab: rows 0 and ny - 1 are ghosts
-        hipLaunchKernelGGL(k_halo_clear, dim3((2 * nx * nz + 255) / 256), dim3(256), 0, s, st, tg, 0, ny - 1);
+    if (n_rows != ny) { // a slab: rows 0 and ny - 1 are ghosts
+        const Strip a{0, 1, nx * nz}, b{(ny - 1) * nx * nz, 1, nx * nz};
+        hipLaunchKernelGGL(k_halo_clear, dim3((a.n + b.n + 255) / 256), dim3(256), 0, s, st, tg, a, b);
+    }
+    if (st.trans_cut_x) { // cut in x as well: columns 0 and nx - 1 are ghosts
+        const Strip a{0, nx, ny * nz}, b{nx - 1, nx, ny * nz};
+        hipLaunchKernelGGL(k_halo_clear, dim3((a.n + b.n + 255) / 256), dim3(256), 0, s, st, tg, a, b);
+    }
     return hipGetLastError();
 }
 hipError_t launch_transport(const DeviceState &st, int nx, int nz, int ny, int periodic_x,
@@ -5299,42 +5334,38 @@ hipError_t launch_transport_probs(const DeviceState &st, const TransFieldsArgs &
     return hipGetLastError();
 }
 size_t halo_record_bytes(const DeviceState &st) { return halo_rec_bytes(st.n_spec, st.n_source, st.n_comp_max); }
-// counts[row_cells] and offsets[row_cells + 1] of the movers of row src_row bound for dst_row
-hipError_t launch_halo_count(const DeviceState &st, int nx, int nz, int ny, void *outbox,
-                             int32_t *n_out, int src_row, int dst_row, int32_t *counts,
-                             int32_t *offsets, hipStream_t s)
+hipError_t launch_halo_count(const DeviceState &st, int nx, int nz, int ny, void *outbox, int32_t *n_out,
+                             Strip src, Strip dst, int32_t *counts, int32_t *offsets, hipStream_t s)
 {
     const TransGrid tg = make_grid(nx, nz, ny, 0, 0, nullptr, nullptr, nullptr, outbox, n_out, nullptr,
                                    nullptr, nullptr, 0);
-    hipLaunchKernelGGL(k_halo_count, dim3(nx * nz), dim3(64), 0, s, st, tg, src_row, dst_row, counts);
-    hipLaunchKernelGGL(k_halo_scan, dim3(1), dim3(64), 0, s, counts, offsets, nx * nz);
+    hipLaunchKernelGGL(k_halo_count, dim3(src.n), dim3(64), 0, s, st, tg, src, dst, counts);
+    hipLaunchKernelGGL(k_halo_scan, dim3(1), dim3(64), 0, s, counts, offsets, src.n);
     return hipGetLastError();
 }
-hipError_t launch_halo_pack(const DeviceState &st, int nx, int nz, int ny, void *outbox,
-                            int32_t *n_out, int src_row, int dst_row, const int32_t *offsets,
-                            void *recs, hipStream_t s)
+hipError_t launch_halo_pack(const DeviceState &st, int nx, int nz, int ny, void *outbox, int32_t *n_out,
+                            Strip src, Strip dst, const int32_t *offsets, void *recs, hipStream_t s)
 {
     const TransGrid tg = make_grid(nx, nz, ny, 0, 0, nullptr, nullptr, nullptr, outbox, n_out, nullptr,
                                    nullptr, nullptr, 0);
-    hipLaunchKernelGGL(k_halo_pack, dim3(nx * nz), dim3(64), 0, s, st, tg, src_row, dst_row, offsets,
+    hipLaunchKernelGGL(k_halo_pack, dim3(src.n), dim3(64), 0, s, st, tg, src, dst, offsets,
                        (unsigned char *)recs, (int)halo_rec_bytes(st.n_spec, st.n_source, st.n_comp_max));
     return hipGetLastError();
 }
-hipError_t launch_halo_unpack(const DeviceState &st, int nx, int nz, int ny, void *outbox,
-                              int32_t *n_out, int32_t *n_exp, uint64_t *dest_mask, int ghost_row,
-                              int real_row, const int32_t *counts, int32_t *offsets, const void *recs,
-                              int32_t *bad, hipStream_t s)
+hipError_t launch_halo_unpack(const DeviceState &st, int nx, int nz, int ny, void *outbox, int32_t *n_out,
+                              int32_t *n_exp, uint64_t *dest_mask, Strip ghost, Strip real, uint64_t mask_bit,
+                              const int32_t *counts, int32_t *offsets, const void *recs, int32_t *bad,
+                              hipStream_t s)
 {
     const TransGrid tg = make_grid(nx, nz, ny, 0, 0, nullptr, nullptr, nullptr, outbox, n_out, nullptr,
                                    n_exp, dest_mask, 0);
-    // the gather of row real_row looks at the ghost row as its south (ghost below) or north
-    // neighbour: bit 2 = "sends north", bit 3 = "sends south" (k_trans_decide's code)
+    // (the direction codes are unambiguous on grids of at least 3 x 3 columns and at most 60 levels:
+    // otherwise the gathers look at every source)
     const bool ok = 4 + nz <= 64 && nx >= 3 && ny >= 3;
-    const uint64_t bit = !ok ? ~0ull : (ghost_row < real_row ? 4ull : 8ull);
-    hipLaunchKernelGGL(k_halo_scan, dim3(1), dim3(64), 0, s, counts, offsets, nx * nz);
-    hipLaunchKernelGGL(k_halo_unpack, dim3(nx * nz), dim3(64), 0, s, st, tg, ghost_row, real_row,
-                       counts, offsets, (const unsigned char *)recs,
-                       (int)halo_rec_bytes(st.n_spec, st.n_source, st.n_comp_max), bit, bad);
+    hipLaunchKernelGGL(k_halo_scan, dim3(1), dim3(64), 0, s, counts, offsets, ghost.n);
+    hipLaunchKernelGGL(k_halo_unpack, dim3(ghost.n), dim3(64), 0, s, st, tg, ghost, real, counts, offsets,
+                       (const unsigned char *)recs, (int)halo_rec_bytes(st.n_spec, st.n_source, st.n_comp_max),
+                       ok ? mask_bit : ~0ull, bad);
     return hipGetLastError();
 }
 hipError_t launch_dry_deposition(const DeviceState &st, double dt, uint64_t seed, uint32_t step,

@@ -464,6 +464,12 @@ module pmcx_c
        import :: c_ptr, c_int
        type(c_ptr), value :: ctx, dev_ptr
      end function pmcx_device_free
+     integer(c_int) function pmcx_set_transport_cuts(ctx, cut_x, nx_local, i_global0, global_nx) &
+          bind(c, name="pmcx_set_transport_cuts")
+       import :: c_ptr, c_int, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: cut_x, nx_local, i_global0, global_nx
+     end function pmcx_set_transport_cuts
      integer(c_int) function pmcx_set_async(ctx, on) bind(c, name="pmcx_set_async")
        import :: c_ptr, c_int, c_int32_t
        type(c_ptr), value :: ctx

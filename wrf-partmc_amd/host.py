@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "pmcx_test_philox", "pmcx_profile_enable", "pmcx_profile_reset", "pmcx_profile_get", "pmcx_profile_phase_cycles", "pmcx_dry_deposition",
     "pmcx_transport_begin", "pmcx_transport_export_size", "pmcx_transport_export",
     "pmcx_transport_import", "pmcx_transport_finish", "pmcx_device_alloc", "pmcx_device_free",
-    "pmcx_device_copy", "pmcx_host_alloc", "pmcx_host_free", "pmcx_set_async",
+    "pmcx_device_copy", "pmcx_host_alloc", "pmcx_host_free", "pmcx_set_async", "pmcx_set_transport_cuts",
     "pmcx_memory_bytes", "pmcx_device_memory_info", "pmcx_set_cell_id_base", "pmcx_set_gas_state",
     "pmcx_get_gas_state", "pmcx_set_gas_scenario", "pmcx_scenario_update_gas_state",
     "pmcx_invalidate_lists", "pmcx_get_keys", "pmcx_seasalt_emissions",
@@ -177,6 +177,7 @@ def load_library():
     L.pmcx_host_alloc.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
     L.pmcx_host_free.argtypes = [C.c_void_p, C.c_void_p]
     L.pmcx_set_async.argtypes = [C.c_void_p, C.c_int32]
+    L.pmcx_set_transport_cuts.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.pmcx_device_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
     L.pmcx_dry_deposition.argtypes = [C.c_void_p, C.c_double, C.c_uint64, C.c_uint32] + [C.c_void_p] * 9
     L.pmcx_timestep.argtypes = [C.c_void_p, C.POINTER(PmcxStepFlags)]
@@ -346,6 +347,11 @@ class CellBlock:
         a = np.zeros(self.cfg.n_cells, dtype=np.int64)
         self._ck(self._lib.pmcx_get_next_id(self._h, _ptr(a)))
         return a
+
+    def set_transport_cuts(self, cut_x, nx_local=0, i_global0=0, global_nx=0):
+        """The block is cut in x as well: columns 0 and nx_local - 1 are ghosts (pmcx_set_transport_cuts);
+        also switches the cells' global ids (RNG keys) to rows of nx_local inside rows of global_nx."""
+        self._ck(self._lib.pmcx_set_transport_cuts(self._h, int(bool(cut_x)), nx_local, i_global0, global_nx))
 
     def set_async(self, on=True):
         """The per-step stage calls return without waiting for the device (pmcx_set_async): results
