@@ -400,6 +400,13 @@ int pmcx_transport_preweight_begin(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_
                                    int32_t periodic_y, int32_t j_global0, int32_t global_ny,
                                    const double *prob_h, const double *prob_v, const double *cell_volume,
                                    double *edge_terms);
+/* A block cut in x as well (pmcx_set_transport_cuts): pmcx_transport_preweight_begin's edge_terms then
+ * hold [2][nx nz][n_class] (towards row 0, towards row ny - 1) followed by [2][ny nz][n_class] (what the
+ * first real column sends west, the last sends east), and the terms of the western / eastern neighbours
+ * are handed over here, between _begin and _finish ([ny nz][n_class] each, NULL: no neighbour;
+ * *_is_edge: that side is the domain's periodic edge, whose term joins the sum last). */
+int pmcx_transport_preweight_x_terms(pmcx_ctx *ctx, const double *terms_from_west, const double *terms_from_east,
+                                     int32_t west_is_edge, int32_t east_is_edge);
 int pmcx_transport_preweight_finish(pmcx_ctx *ctx, const double *terms_from_below, const double *terms_from_above,
                                     int32_t below_is_edge, int32_t above_is_edge, uint64_t seed, uint32_t step,
                                     double *expected_num_conc, int32_t *n_removed);

@@ -1338,6 +1338,7 @@ def test_transport_blocks_cut_in_x_and_y(wp, periodic):
     whole = wp.CellBlock(n, cap, n_spec, n_class=n_class, n_source=2, n_comp_max=kc)
     whole.set_aero_data(dens); whole.set_env(280.0, 9e4); whole.set_weights(mag)
     whole.set_next_id((np.arange(n, dtype=np.int64) << 32) + (1 << 20))
+    whole.set_n_part_ideal(np.full((n, n_class), 0.45 * n_part / n_class))
     whole.generate_lognormal(n_part, modes, seed=3)
     if not periodic:
         whole.set_transport_lateral(True)
@@ -1359,6 +1360,7 @@ def test_transport_blocks_cut_in_x_and_y(wp, periodic):
                 blk.set_transport_lateral(True, gj0, ny)
             blk.set_aero_data(dens); blk.set_env(280.0, 9e4)
             blk.set_weights(mag[gmap])                              # ghosts: the neighbours' weights
+            blk.set_n_part_ideal(np.full((nloc, n_class), 0.45 * n_part / n_class))
             blk.set_next_id((gmap.astype(np.int64) << 32) + (1 << 20))
             counts = np.where(real, np.diff(dn["part_offset"])[gmap], 0)
             po = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
@@ -1372,6 +1374,31 @@ def test_transport_blocks_cut_in_x_and_y(wp, periodic):
     at = lambda a, b: blocks[(b % by) * bx + (a % bx)]
     total_moved = 0
     for step in range(3):
+        # trans_aero_preweight first (wrf_pmc_trans_aero.F90:294): the terms of the cut rows AND columns
+        # travel as ready values; sums and thinning are the whole domain's
+        ex_w, nr_w = whole.transport_preweight(nx, nz, ny, ph, pv, cv, 9, step, periodic, periodic)
+        edges = [B["blk"].transport_preweight_begin(B["nxl"], nz, B["nyl"], ph[B["gmap"]], pv[B["gmap"]], cv[B["gmap"]],
+                                                    B["b"] * ry - 1, ny, periodic, periodic, cut_x=True) for B in blocks]
+        eg = lambda a, b: edges[(b % by) * bx + (a % bx)]
+        scaled = 0
+        for B in blocks:
+            a, b, blk = B["a"], B["b"], B["blk"]
+            has = lambda a_, b_: periodic or (0 <= a_ < bx and 0 <= b_ < by)
+            blk.transport_preweight_x_terms(eg(a - 1, b)[1][1] if has(a - 1, b) else None,      # the west block's eastward terms
+                                            eg(a + 1, b)[1][0] if has(a + 1, b) else None,
+                                            periodic and a == 0, periodic and a == bx - 1)
+            ex, nr = blk.transport_preweight_finish(eg(a, b - 1)[0][1] if has(a, b - 1) else None,   # the block below's upward terms
+                                                    eg(a, b + 1)[0][0] if has(a, b + 1) else None,
+                                                    periodic and b == 0, periodic and b == by - 1, 9, step)
+            real, gmap = B["real"], B["gmap"]
+            assert np.array_equal(ex[real], ex_w[gmap[real]]), (step, np.abs(ex[real] - ex_w[gmap[real]]).max())
+            assert np.array_equal(nr[real], nr_w[gmap[real]]), step
+            scaled += int(nr[real].sum())
+        assert step > 0 or scaled > 100                       # (the first step thins every cell)
+        mag_now = whole.get_weights()
+        for B in blocks:                                      # ghosts: the neighbours' new weights
+            assert np.array_equal(B["blk"].get_weights()[B["real"]], mag_now[B["gmap"][B["real"]]])
+            B["blk"].set_weights(mag_now[B["gmap"]])
         nm_w, na_w = whole.transport(nx, nz, ny, ph, pv, cv, 9, step, periodic, periodic)
         for B in blocks:
             B["blk"].transport_begin(B["nxl"], nz, B["nyl"], ph[B["gmap"]], pv[B["gmap"]], cv[B["gmap"]], 9, step, False)

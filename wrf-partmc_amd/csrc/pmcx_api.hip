@@ -58,6 +58,10 @@ struct pmcx_ctx {
     int halo_nx = 0, halo_nz = 0, halo_ny = 0, halo_px = 0; // halo_nx != 0: a transport is open
     int halo_row_cells = 0;         // row size d_halo was allocated for (kept across steps)
     int64_t halo_total[4] = {0, 0, 0, 0}; // records to export per side (after _export_size)
+    size_t pw_edge_len = 0;               // doubles in d_pw_edge
+    bool pw_x_set = false;                // pmcx_transport_preweight_x_terms has been called for the open preweight
+    const double *pw_gin_w = nullptr, *pw_gin_e = nullptr;
+    int pw_w_edge = 0, pw_e_edge = 0;
     double *d_halo_cv = nullptr;    // [n_cells] cell volumes of the open transport (own buffer: the
                                     // staging area may be reallocated between _begin and _finish)
     int32_t *d_halo_bad = nullptr;  // [1] records of an imported buffer that failed validation
@@ -1643,7 +1647,15 @@ int pmcx_transport_preweight_begin(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_
     int rc = transport_buffers(ctx);
     if (rc) return rc;
     if (!ctx->d_preweight) { rc = dev_alloc(ctx, &ctx->d_preweight, 2 * nc * C); if (rc) return rc; }
-    if (!ctx->d_pw_edge) { rc = dev_alloc(ctx, &ctx->d_pw_edge, 4 * row * C); if (rc) return rc; }
+    // ready terms out and in: two rows each, and (a block cut in x as well) two columns each
+    const size_t col = (size_t)ny * nz, pw_need = 4 * (row + col) * C;
+    if (!ctx->d_pw_edge || ctx->pw_edge_len < pw_need) {
+        rc = dev_alloc(ctx, &ctx->d_pw_edge, pw_need); // (a smaller one, if any, stays allocated until destroy)
+        if (rc) return rc;
+        ctx->pw_edge_len = pw_need;
+    }
+    if (ctx->st.trans_cut_x && (nx < 3 || ctx->st.trans_gnx < nx - 2))
+        return fail(ctx, PMCX_EINVAL, "pmcx_transport_preweight_begin: a block cut in x has two ghost columns (nx >= 3)");
     if (prob_h) { // kept on the device for _finish and for the transport that follows
         if (!ctx->d_prob_h) {
             rc = dev_alloc(ctx, &ctx->d_prob_h, nc * C * 4);
@@ -1668,10 +1680,30 @@ int pmcx_transport_preweight_begin(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_
                                                  ctx->d_prob_v, ctx->d_halo_cv, ctx->d_preweight, ctx->d_pw_edge,
                                                  ctx->stream));
     }
-    HIP_TRY(ctx, hipMemcpyAsync(edge_terms, ctx->d_pw_edge, sizeof(double) * 2 * row * C, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(edge_terms, ctx->d_pw_edge, sizeof(double) * (2 * row + (ctx->st.trans_cut_x ? 2 * col : 0)) * C,
+                                hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pw_x_set = false;
     ctx->pw_nx = nx; ctx->pw_nz = nz; ctx->pw_ny = ny; ctx->pw_ideal = ideal;
     ctx->pw_jg0 = j_global0; ctx->pw_gny = global_ny;
+    return PMCX_OK;
+}
+
+int pmcx_transport_preweight_x_terms(pmcx_ctx *ctx, const double *terms_from_west, const double *terms_from_east,
+                                     int32_t west_is_edge, int32_t east_is_edge)
+{
+    if (!ctx) return PMCX_EINVAL;
+    if (!ctx->pw_nx || !ctx->st.trans_cut_x)
+        return fail(ctx, PMCX_ESTATE, "pmcx_transport_preweight_x_terms: no preweight of a block cut in x is open");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t C = (size_t)ctx->cfg.n_class, row = (size_t)ctx->pw_nx * ctx->pw_nz, col = (size_t)ctx->pw_ny * ctx->pw_nz;
+    double *g_w = ctx->d_pw_edge + (4 * row + 2 * col) * C, *g_e = g_w + col * C;
+    if (terms_from_west) HIP_TRY(ctx, hipMemcpyAsync(g_w, terms_from_west, sizeof(double) * col * C, hipMemcpyHostToDevice, ctx->stream));
+    if (terms_from_east) HIP_TRY(ctx, hipMemcpyAsync(g_e, terms_from_east, sizeof(double) * col * C, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pw_x_set = true;
+    ctx->pw_gin_w = terms_from_west ? g_w : nullptr; ctx->pw_gin_e = terms_from_east ? g_e : nullptr;
+    ctx->pw_w_edge = west_is_edge; ctx->pw_e_edge = east_is_edge;
     return PMCX_OK;
 }
 
@@ -1683,10 +1715,14 @@ int pmcx_transport_preweight_finish(pmcx_ctx *ctx, const double *terms_from_belo
     if (!ctx->pw_nx) return fail(ctx, PMCX_ESTATE, "pmcx_transport_preweight_finish: no preweight is open");
     const pmcx_config &cf = ctx->cfg;
     const int nx = ctx->pw_nx, nz = ctx->pw_nz, ny = ctx->pw_ny;
+    if (ctx->st.trans_cut_x && !ctx->pw_x_set)
+        return fail(ctx, PMCX_ESTATE, "pmcx_transport_preweight_finish: the block is cut in x: "
+                                      "pmcx_transport_preweight_x_terms comes first");
     ctx->pw_nx = 0;
     HIP_TRY(ctx, hipSetDevice(cf.device));
-    const size_t nc = (size_t)cf.n_cells, C = (size_t)cf.n_class, row = (size_t)nx * nz;
-    double *g_lo = ctx->d_pw_edge + 2 * row * C, *g_hi = g_lo + row * C;
+    const size_t nc = (size_t)cf.n_cells, C = (size_t)cf.n_class, row = (size_t)nx * nz, col = (size_t)ny * nz;
+    // (layout of d_pw_edge: out rows [2 row], out columns [2 col], in rows [2 row], in columns [2 col])
+    double *g_lo = ctx->d_pw_edge + (2 * row + 2 * col) * C, *g_hi = g_lo + row * C;
     if (terms_from_below) HIP_TRY(ctx, hipMemcpyAsync(g_lo, terms_from_below, sizeof(double) * row * C, hipMemcpyHostToDevice, ctx->stream));
     if (terms_from_above) HIP_TRY(ctx, hipMemcpyAsync(g_hi, terms_from_above, sizeof(double) * row * C, hipMemcpyHostToDevice, ctx->stream));
     int rc = ensure_stage(ctx, sizeof(int32_t) * nc + 64);
@@ -1699,7 +1735,10 @@ int pmcx_transport_preweight_finish(pmcx_ctx *ctx, const double *terms_from_belo
                                                   below_is_edge, above_is_edge, ctx->d_prob_h, ctx->d_prob_v,
                                                   ctx->d_halo_cv, ctx->d_preweight, ctx->d_preweight + nc * C,
                                                   terms_from_below ? g_lo : nullptr,
-                                                  terms_from_above ? g_hi : nullptr, d_nr, seed, step, ctx->stream));
+                                                  terms_from_above ? g_hi : nullptr, d_nr, seed, step, ctx->stream,
+                                                  ctx->pw_w_edge, ctx->pw_e_edge,
+                                                  ctx->st.trans_cut_x ? ctx->pw_gin_w : nullptr,
+                                                  ctx->st.trans_cut_x ? ctx->pw_gin_e : nullptr));
     }
     if (expected_num_conc)
         HIP_TRY(ctx, hipMemcpyAsync(expected_num_conc, ctx->d_preweight + nc * C, sizeof(double) * nc * C,

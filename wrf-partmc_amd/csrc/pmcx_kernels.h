@@ -237,7 +237,8 @@ hipError_t launch_preweight_slab_finish(const DeviceState &st, int nx, int nz, i
                                         const double *prob_h, const double *prob_v,
                                         const double *cell_volume, double *old, double *expect,
                                         const double *gin_lo, const double *gin_hi, int32_t *n_removed,
-                                        uint64_t seed, uint32_t step, hipStream_t s);
+                                        uint64_t seed, uint32_t step, hipStream_t s, int w_edge = 0,
+                                        int e_edge = 0, const double *gin_w = nullptr, const double *gin_e = nullptr);
 hipError_t launch_transport_preweight(const DeviceState &st, int nx, int nz, int ny, int ideal,
                                       const double *prob_h, const double *prob_v,
                                       const double *cell_volume, double *old, double *expect,

@@ -4032,7 +4032,12 @@ struct PreweightArgs {
     // domain's periodic edge (lo_edge / hi_edge)
     int32_t slab, lo_edge, hi_edge, j_global0, global_ny;
     const double *gin_lo, *gin_hi;
-    double *edge_out;       // [2][nx nz][n_class] what the first and last real rows send out
+    double *edge_out;       // [2][nx nz][n_class] what the first and last real rows send out, then (a block
+                            // cut in x as well, DeviceState::trans_cut_x) [2][ny nz][n_class] what the first and
+                            // last real columns send west and east
+    // the same across a cut in x: the neighbours' ready terms, [ny nz][n_class] per side
+    int32_t w_edge, e_edge;
+    const double *gin_w, *gin_e;
 };
 
 __global__ __launch_bounds__(64) void k_preweight_old(DeviceState st, PreweightArgs a)
@@ -4082,10 +4087,14 @@ __global__ __launch_bounds__(256) void k_preweight_new(DeviceState st, Preweight
     const int64_t d = x / C;
     const int i = (int)(d % nx), k = (int)((d / nx) % nz), j = (int)(d / ((int64_t)nx * nz));
     if (a.slab && (j == 0 || j == ny - 1)) { a.expect[d * C + cl] = 0.0; return; } // a ghost row
+    const bool cut_x = a.slab && st.trans_cut_x;
+    if (cut_x && (i == 0 || i == nx - 1)) { a.expect[d * C + cl] = 0.0; return; }   // a ghost column
     auto cell = [&](int ii, int kk, int jj) { return ((int64_t)jj * nz + kk) * nx + ii; };
-    // moves of the cell in local row jj (its place in the whole domain decides at open boundaries)
-    const int gny = a.slab ? a.global_ny : ny;
-    auto moves = [&](int ii, int jj) { return preweight_moves(ii, a.slab ? jj + a.j_global0 : jj, nx, gny, a.ideal); };
+    // moves of the cell in local row jj, column ii (its place in the whole domain decides at open boundaries)
+    const int gny = a.slab ? a.global_ny : ny, gnx = cut_x ? st.trans_gnx : nx;
+    auto moves = [&](int ii, int jj) {
+        return preweight_moves(cut_x ? ii + st.trans_i0 : ii, a.slab ? jj + a.j_global0 : jj, gnx, gny, a.ideal);
+    };
     const double vd = a.cell_volume[d];
     // what source s sends towards this cell through its horizontal move `dir`
     auto from_h = [&](int64_t s, int dir) {
@@ -4097,14 +4106,17 @@ __global__ __launch_bounds__(256) void k_preweight_new(DeviceState st, Preweight
         return flux * (vd / a.cell_volume[s]);
     };
     const int64_t r = ((int64_t)k * nx + i) * C + cl; // place in a row's table of ready terms
+    const int64_t rc = ((int64_t)j * nz + k) * C + cl; // ... and in a column's
     const bool lo_ghost = a.slab && j - 1 == 0, hi_ghost = a.slab && j + 1 == ny - 1;
+    const bool w_ghost = cut_x && i - 1 == 0, e_ghost = cut_x && i + 1 == nx - 1;
     double acc = a.old[d * C + cl];
     if (lo_ghost) { if (a.gin_lo && !a.lo_edge) acc = acc + a.gin_lo[r]; }
     else if (j >= 1 && (moves(i, j - 1) & 8)) acc = acc + from_h(cell(i, k, j - 1), 3);
     const bool col_vert = (moves(i, j) & 16) != 0; // (the whole column alike)
     if (col_vert)
         for (int kk = 0; kk < k; kk++) acc = acc + from_v(cell(i, kk, j));
-    if (i >= 1 && (moves(i - 1, j) & 2)) acc = acc + from_h(cell(i - 1, k, j), 1);
+    if (w_ghost) { if (a.gin_w && !a.w_edge) acc = acc + a.gin_w[rc]; }
+    else if (i >= 1 && (moves(i - 1, j) & 2)) acc = acc + from_h(cell(i - 1, k, j), 1);
     {   // the cell's own losses, in the order compute_fluxes takes them
         const int mv = moves(i, j);
         const double o = a.old[d * C + cl];
@@ -4117,7 +4129,8 @@ __global__ __launch_bounds__(256) void k_preweight_new(DeviceState st, Preweight
             for (int kk = 0; kk < nz; kk++)
                 if (kk != k) acc = acc - a.prob_v[(d * C + cl) * nz + kk] * o;
     }
-    if (i + 1 < nx && (moves(i + 1, j) & 1)) acc = acc + from_h(cell(i + 1, k, j), 0);
+    if (e_ghost) { if (a.gin_e && !a.e_edge) acc = acc + a.gin_e[rc]; }
+    else if (i + 1 < nx && (moves(i + 1, j) & 1)) acc = acc + from_h(cell(i + 1, k, j), 0);
     if (col_vert)
         for (int kk = k + 1; kk < nz; kk++) acc = acc + from_v(cell(i, kk, j));
     if (hi_ghost) { if (a.gin_hi && !a.hi_edge) acc = acc + a.gin_hi[r]; }
@@ -4130,8 +4143,13 @@ __global__ __launch_bounds__(256) void k_preweight_new(DeviceState st, Preweight
             if (j == ny - 1) acc = acc + from_h(cell(i, k, 0), 2);
             if (j == 0) acc = acc + from_h(cell(i, k, ny - 1), 3);
         }
-        if (i == nx - 1) acc = acc + from_h(cell(0, k, j), 0);
-        if (i == 0) acc = acc + from_h(cell(nx - 1, k, j), 1);
+        if (cut_x) {
+            if (e_ghost && a.e_edge && a.gin_e) acc = acc + a.gin_e[rc]; // the domain's last column
+            if (w_ghost && a.w_edge && a.gin_w) acc = acc + a.gin_w[rc]; // the domain's first column
+        } else {
+            if (i == nx - 1) acc = acc + from_h(cell(0, k, j), 0);
+            if (i == 0) acc = acc + from_h(cell(nx - 1, k, j), 1);
+        }
     }
     a.expect[d * C + cl] = acc;
 }
@@ -4141,16 +4159,29 @@ __global__ __launch_bounds__(256) void k_preweight_new(DeviceState st, Preweight
 __global__ __launch_bounds__(256) void k_preweight_edge(DeviceState st, PreweightArgs a)
 {
     const int C = st.n_class, nx = a.nx, nz = a.nz, ny = a.ny;
-    const int64_t row = (int64_t)nx * nz * C;
+    const int64_t row = (int64_t)nx * nz * C, col = (int64_t)ny * nz * C;
+    const bool cut_x = st.trans_cut_x != 0;
+    const int gnx = cut_x ? st.trans_gnx : nx, i0 = cut_x ? st.trans_i0 : 0;
     const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (x >= 2 * row) return;
-    const int side = (int)(x / row);
-    const int64_t r = x % row;
-    const int cl = (int)(r % C), i = (int)((r / C) % nx), k = (int)(r / ((int64_t)C * nx));
-    const int j = side == 0 ? 1 : ny - 2, jg = side == 0 ? 0 : ny - 1, dir = side == 0 ? 2 : 3;
-    const int64_t s = ((int64_t)j * nz + k) * nx + i, g = ((int64_t)jg * nz + k) * nx + i;
+    if (x >= 2 * row + (cut_x ? 2 * col : 0)) return;
+    int i, k, j, ig, jg, dir, bit, cl;
+    if (x < 2 * row) { // side 0: towards row 0, side 1: towards row ny - 1
+        const int side = (int)(x / row);
+        const int64_t r = x % row;
+        cl = (int)(r % C); i = (int)((r / C) % nx); k = (int)(r / ((int64_t)C * nx));
+        j = side == 0 ? 1 : ny - 2; jg = side == 0 ? 0 : ny - 1; ig = i;
+        dir = side == 0 ? 2 : 3; bit = side == 0 ? 4 : 8;
+    } else {           // side 2: towards column 0, side 3: towards column nx - 1
+        const int64_t y = x - 2 * row;
+        const int side = (int)(y / col);
+        const int64_t r = y % col;
+        cl = (int)(r % C); k = (int)((r / C) % nz); j = (int)(r / ((int64_t)C * nz));
+        i = side == 0 ? 1 : nx - 2; ig = side == 0 ? 0 : nx - 1; jg = j;
+        dir = side == 0 ? 0 : 1; bit = side == 0 ? 1 : 2;
+    }
+    const int64_t s = ((int64_t)j * nz + k) * nx + i, g = ((int64_t)jg * nz + k) * nx + ig;
     double term = 0.0;
-    if (preweight_moves(i, j + a.j_global0, nx, a.global_ny, a.ideal) & (side == 0 ? 4 : 8)) {
+    if (preweight_moves(i + i0, j + a.j_global0, gnx, a.global_ny, a.ideal) & bit) {
         const double flux = a.prob_h[(s * C + cl) * 4 + dir] * a.old[s * C + cl];
         term = flux * (a.cell_volume[g] / a.cell_volume[s]);
     }
@@ -5278,7 +5309,7 @@ hipError_t launch_preweight_slab_begin(const DeviceState &st, int nx, int nz, in
     a.cell_volume = cell_volume; a.old = old; a.slab = 1; a.j_global0 = j_global0; a.global_ny = global_ny;
     a.edge_out = edge_out;
     hipLaunchKernelGGL(k_preweight_old, dim3(st.n_cells), dim3(64), 0, s, st, a);
-    const int64_t n = 2 * (int64_t)nx * nz * st.n_class;
+    const int64_t n = 2 * (int64_t)nx * nz * st.n_class + (st.trans_cut_x ? 2 * (int64_t)ny * nz * st.n_class : 0);
     hipLaunchKernelGGL(k_preweight_edge, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, a);
     return hipGetLastError();
 }
@@ -5287,13 +5318,15 @@ hipError_t launch_preweight_slab_finish(const DeviceState &st, int nx, int nz, i
                                         const double *prob_h, const double *prob_v,
                                         const double *cell_volume, double *old, double *expect,
                                         const double *gin_lo, const double *gin_hi, int32_t *n_removed,
-                                        uint64_t seed, uint32_t step, hipStream_t s)
+                                        uint64_t seed, uint32_t step, hipStream_t s, int w_edge,
+                                        int e_edge, const double *gin_w, const double *gin_e)
 {
     PreweightArgs a{};
     a.nx = nx; a.nz = nz; a.ny = ny; a.ideal = ideal; a.prob_h = prob_h; a.prob_v = prob_v;
     a.cell_volume = cell_volume; a.old = old; a.expect = expect; a.n_removed = n_removed;
     a.slab = 1; a.lo_edge = lo_edge; a.hi_edge = hi_edge; a.j_global0 = j_global0; a.global_ny = global_ny;
     a.gin_lo = gin_lo; a.gin_hi = gin_hi;
+    a.w_edge = w_edge; a.e_edge = e_edge; a.gin_w = gin_w; a.gin_e = gin_e;
     const int64_t n = (int64_t)st.n_cells * st.n_class;
     hipLaunchKernelGGL(k_preweight_new, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, a);
     hipLaunchKernelGGL(k_preweight_scale, dim3(st.n_cells), dim3(64), 0, s, st, a, seed, step);

@@ -470,6 +470,12 @@ module pmcx_c
        type(c_ptr), value :: ctx
        integer(c_int32_t), value :: cut_x, nx_local, i_global0, global_nx
      end function pmcx_set_transport_cuts
+     integer(c_int) function pmcx_transport_preweight_x_terms(ctx, terms_from_west, terms_from_east, &
+          west_is_edge, east_is_edge) bind(c, name="pmcx_transport_preweight_x_terms")
+       import :: c_ptr, c_int, c_int32_t
+       type(c_ptr), value :: ctx, terms_from_west, terms_from_east
+       integer(c_int32_t), value :: west_is_edge, east_is_edge
+     end function pmcx_transport_preweight_x_terms
      integer(c_int) function pmcx_set_async(ctx, on) bind(c, name="pmcx_set_async")
        import :: c_ptr, c_int, c_int32_t
        type(c_ptr), value :: ctx

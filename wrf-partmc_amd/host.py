@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "pmcx_test_philox", "pmcx_profile_enable", "pmcx_profile_reset", "pmcx_profile_get", "pmcx_profile_phase_cycles", "pmcx_dry_deposition",
     "pmcx_transport_begin", "pmcx_transport_export_size", "pmcx_transport_export",
     "pmcx_transport_import", "pmcx_transport_finish", "pmcx_device_alloc", "pmcx_device_free",
-    "pmcx_device_copy", "pmcx_host_alloc", "pmcx_host_free", "pmcx_set_async", "pmcx_set_transport_cuts",
+    "pmcx_device_copy", "pmcx_host_alloc", "pmcx_host_free", "pmcx_set_async", "pmcx_set_transport_cuts", "pmcx_transport_preweight_x_terms",
     "pmcx_memory_bytes", "pmcx_device_memory_info", "pmcx_set_cell_id_base", "pmcx_set_gas_state",
     "pmcx_get_gas_state", "pmcx_set_gas_scenario", "pmcx_scenario_update_gas_state",
     "pmcx_invalidate_lists", "pmcx_get_keys", "pmcx_seasalt_emissions",
@@ -178,6 +178,7 @@ def load_library():
     L.pmcx_host_free.argtypes = [C.c_void_p, C.c_void_p]
     L.pmcx_set_async.argtypes = [C.c_void_p, C.c_int32]
     L.pmcx_set_transport_cuts.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    L.pmcx_transport_preweight_x_terms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
     L.pmcx_device_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
     L.pmcx_dry_deposition.argtypes = [C.c_void_p, C.c_double, C.c_uint64, C.c_uint32] + [C.c_void_p] * 9
     L.pmcx_timestep.argtypes = [C.c_void_p, C.POINTER(PmcxStepFlags)]
@@ -863,6 +864,39 @@ class CellBlock:
         self._ck(self._lib.pmcx_transport_preweight(self._h, nx, nz, ny, int(periodic_x), int(periodic_y),
                                                     _ptr(ph), _ptr(pv), _ptr(cv), seed, step, _ptr(ex),
                                                     _ptr(nr)))
+        return ex, nr
+
+    def transport_preweight_begin(self, nx, nz, ny, prob_h, prob_v, cell_volume, j_global0, global_ny,
+                                  periodic_x=True, periodic_y=True, cut_x=False):
+        """First half of the preweight of a block with ghost rows (and, cut_x, ghost columns): returns
+        the ready terms its boundary strips send out -- rows [2][nx nz][n_class] (towards row 0, towards
+        row ny - 1) and, cut_x, columns [2][ny nz][n_class] (west, east), else None."""
+        n, Cn = self.cfg.n_cells, self.cfg.n_class
+        ph = None if prob_h is None else np.ascontiguousarray(np.broadcast_to(_f64(prob_h), (n, Cn, 4)))
+        pv = None if prob_v is None else np.ascontiguousarray(np.broadcast_to(_f64(prob_v), (n, Cn, nz)))
+        cv = np.ascontiguousarray(np.broadcast_to(_f64(cell_volume), (n,)))
+        edge = np.zeros(2 * nx * nz * Cn + (2 * ny * nz * Cn if cut_x else 0))
+        self._ck(self._lib.pmcx_transport_preweight_begin(self._h, nx, nz, ny, int(periodic_x), int(periodic_y),
+                                                          j_global0, global_ny, _ptr(ph), _ptr(pv), _ptr(cv),
+                                                          _ptr(edge)))
+        rows = edge[:2 * nx * nz * Cn].reshape(2, nx * nz, Cn)
+        cols = edge[2 * nx * nz * Cn:].reshape(2, ny * nz, Cn) if cut_x else None
+        return rows, cols
+
+    def transport_preweight_x_terms(self, from_west, from_east, west_is_edge=False, east_is_edge=False):
+        w = None if from_west is None else _f64(from_west)
+        e = None if from_east is None else _f64(from_east)
+        self._ck(self._lib.pmcx_transport_preweight_x_terms(self._h, _ptr(w), _ptr(e), int(west_is_edge),
+                                                            int(east_is_edge)))
+
+    def transport_preweight_finish(self, from_below, from_above, below_is_edge=False, above_is_edge=False,
+                                   seed=0, step=0):
+        n, Cn = self.cfg.n_cells, self.cfg.n_class
+        lo = None if from_below is None else _f64(from_below)
+        hi = None if from_above is None else _f64(from_above)
+        ex, nr = np.zeros((n, Cn)), np.zeros(n, dtype=np.int32)
+        self._ck(self._lib.pmcx_transport_preweight_finish(self._h, _ptr(lo), _ptr(hi), int(below_is_edge),
+                                                           int(above_is_edge), seed, step, _ptr(ex), _ptr(nr)))
         return ex, nr
 
     def transport_preweight_distributed(self, dist, nx, nz, ny, prob_h, prob_v, cell_volume, global_ny,
