@@ -1,0 +1,103 @@
+"""Worker of tests/test_gpu_fortran.py::test_transport_across_a_grid_of_ranks: run under
+torch.distributed.run with 4 ranks sharing one GPU over gloo, a 2 x 2 grid of blocks over an
+8 x 3 x 6 domain cut in x AND y.  Every rank steps the preweight and the transport of its block with
+CellBlock.transport_preweight_distributed_2d / .transport_distributed_2d and checks its real cells
+against pmcx_transport_preweight and pmcx_transport on the whole domain (computed locally by every
+rank), doubly periodic and with open lateral boundaries."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(os.environ.get("PMCX_TEST_BACKEND", "gloo"))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    assert world == 4
+    torch.cuda.set_device(0)
+    import wrf_partmc_amd as wp
+    from tests import parity
+    grid = (2, 2)
+    nx, nz, ny, n_class, n_spec, cap, n_part = 8, 3, 6, 2, 2, 1024, 400
+    rx, ry = nx // grid[0], ny // grid[1]
+    a, b = rank % grid[0], rank // grid[0]
+    n = nx * nz * ny
+    names, dens = parity.default_species(n_spec)
+    modes, _ = parity.make_modes(n_spec, n_class)
+    for m in modes:
+        m["source"] = m["source"] % 2
+    for periodic in (True, False):
+        rng = np.random.RandomState(23)
+        mag = rng.uniform(0.5e7, 2e7, (n, n_class)); cv = rng.uniform(0.8e9, 1.3e9, n)
+        ph = rng.uniform(0, 0.08, (n, n_class, 4)); pv = rng.uniform(0, 0.04, (n, n_class, nz))
+        whole = wp.CellBlock(n, cap, n_spec, n_class=n_class, n_source=2)
+        whole.set_aero_data(dens); whole.set_env(280.0, 9e4); whole.set_weights(mag)
+        whole.set_next_id((np.arange(n, dtype=np.int64) << 32) + (1 << 20))
+        whole.set_n_part_ideal(np.full((n, n_class), 0.45 * n_part / n_class))
+        whole.generate_lognormal(n_part, modes, seed=3)
+        if not periodic:
+            whole.set_transport_lateral(True)
+        dn = whole.download_cells()
+        gi0, gj0, nxl, nyl = a * rx - 1, b * ry - 1, rx + 2, ry + 2
+        lj, lk, li = np.meshgrid(np.arange(nyl), np.arange(nz), np.arange(nxl), indexing="ij")
+        gmap = ((((gj0 + lj) % ny) * nz + lk) * nx + (gi0 + li) % nx).ravel()
+        real = ((li >= 1) & (li <= rx) & (lj >= 1) & (lj <= ry)).ravel()
+        gl = np.flatnonzero(real)
+        blk = wp.CellBlock(len(gmap), cap, n_spec, n_class=n_class, n_source=2,
+                           cell_id_base=((gj0 * nz) * nx + gi0) % (1 << 32))
+        blk.set_transport_cuts(True, nxl, gi0, nx)
+        if not periodic:
+            blk.set_transport_lateral(True, gj0, ny)
+        blk.set_aero_data(dens); blk.set_env(280.0, 9e4); blk.set_weights(mag[gmap])
+        blk.set_next_id((gmap.astype(np.int64) << 32) + (1 << 20))
+        blk.set_n_part_ideal(np.full((len(gmap), n_class), 0.45 * n_part / n_class))
+        counts = np.where(real, np.diff(dn["part_offset"])[gmap], 0)
+        po = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        sel = np.concatenate([np.arange(dn["part_offset"][g], dn["part_offset"][g + 1]) for g in gmap[gl]])
+        blk.upload_cells(0, po, dn["vol"][:, sel], dn["wclass"][sel], dn["id"][sel], dn["least_ct"][sel],
+                         dn["greatest_ct"][sel], dn["n_orig"][:, sel])
+        moved = 0
+        for step in range(3):
+            ex_w, nr_w = whole.transport_preweight(nx, nz, ny, ph, pv, cv, 9, step, periodic, periodic)
+            ex, nr = blk.transport_preweight_distributed_2d(dist, grid, nxl, nz, nyl, ph[gmap], pv[gmap], cv[gmap],
+                                                            gj0, ny, 9, step, periodic, periodic)
+            assert np.array_equal(ex[real], ex_w[gmap[real]]), (rank, step, periodic)
+            assert np.array_equal(nr[real], nr_w[gmap[real]]) and (step > 0 or nr_w.sum() > 0)
+            w_now = whole.get_weights()
+            assert np.array_equal(blk.get_weights()[real], w_now[gmap[real]])
+            # every ghost cell that stands for a cell of the domain (no corner, nothing beyond an open
+            # boundary) has its owner's new weight
+            has = wp.host.grid_neighbours(rank, grid, periodic, periodic)
+            ghost_ok = ((lj == 0) & (li >= 1) & (li <= rx) & (has[0] is not None)) | \
+                       ((lj == nyl - 1) & (li >= 1) & (li <= rx) & (has[1] is not None)) | \
+                       ((li == 0) & (lj >= 1) & (lj <= ry) & (has[2] is not None)) | \
+                       ((li == nxl - 1) & (lj >= 1) & (lj <= ry) & (has[3] is not None))
+            ghost_ok = ghost_ok.ravel()
+            assert np.array_equal(blk.get_weights()[ghost_ok], w_now[gmap[ghost_ok]]), (rank, step, periodic)
+            nm_w, na_w = whole.transport(nx, nz, ny, ph, pv, cv, 9, step, periodic, periodic)
+            nm, na = blk.transport_distributed_2d(dist, grid, nxl, nz, nyl, None, None, cv[gmap], 9, step,
+                                                  periodic, periodic)
+            assert np.array_equal(nm[real], nm_w[gmap[real]]) and np.array_equal(na[real], na_w[gmap[real]])
+            assert not blk.aero_state_total_particles()[~real].any()
+            ref, got = whole.download_cells(), blk.download_cells()
+            assert np.array_equal(np.diff(got["part_offset"])[gl], np.diff(ref["part_offset"])[gmap[gl]])
+            sel = np.concatenate([np.arange(ref["part_offset"][g], ref["part_offset"][g + 1]) for g in gmap[gl]])
+            for k in ("vol", "wclass", "id", "least_ct", "greatest_ct", "n_orig"):
+                assert np.array_equal(got[k], ref[k][..., sel]), (rank, step, periodic, k)
+            moved += int(nm[real].sum())
+        assert moved > 100
+        whole.close(); blk.close()
+    dist.barrier()
+    if rank == 0:
+        print("dist_transport2d_worker ok: 4 ranks, 2 x 2 blocks, periodic and open boundaries")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -85,3 +85,52 @@ def test_two_ranks_equal_one_rank(tmp_path, oracle):
     assert agg["n_coag"] == sum(v[1] for v in serial.values()) > 0
     assert agg["particle_steps"] == sum(v[2] for v in serial.values())
     assert abs(agg["elapsed"] - 0.2) < 1e-12      # max over ranks
+
+
+def _grid_worker(rank, world, port, grid, periodic, path):
+    """Every rank of a px x py grid sends a tagged message of its own length towards each side; what
+    arrives from a side must be the message its neighbour there addressed to the opposite side."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from wrf_partmc_amd import host
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nbr = host.grid_neighbours(rank, grid, periodic, periodic)
+    out = [torch.full((3 + rank + 2 * side,), 100.0 * rank + side, dtype=torch.float64) for side in range(4)]
+    got = host.swap_sides(dist, out, nbr)
+    ok = True
+    for side in range(4):
+        frm = nbr[side]
+        if frm is None:
+            ok &= got[side] is None
+        else:                                   # the neighbour on my side s sent it towards ITS side s ^ 1
+            want = torch.full((3 + frm + 2 * (side ^ 1),), 100.0 * frm + (side ^ 1), dtype=torch.float64)
+            ok &= got[side] is not None and got[side].shape == want.shape and bool((got[side] == want).all())
+    flags = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(flags, torch.tensor([int(ok)]))
+    if rank == 0:
+        json.dump([int(f.item()) for f in flags], open(path, "w"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("grid,periodic", [((2, 2), True), ((2, 2), False), ((3, 2), True), ((1, 4), False)])
+def test_four_neighbour_exchange_of_a_grid_of_ranks(tmp_path, grid, periodic):
+    """host.grid_neighbours / host.swap_sides, the exchange pattern of CellBlock.transport_distributed_2d
+    and .transport_preweight_distributed_2d (a domain cut in x and y), on CPU over gloo."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    from wrf_partmc_amd import host
+    px, py = grid
+    # a rank's four neighbours, and being each other's opposite
+    for r in range(px * py):
+        nb = host.grid_neighbours(r, grid, periodic, periodic)
+        for side, q in enumerate(nb):
+            if q is not None:
+                assert host.grid_neighbours(q, grid, periodic, periodic)[side ^ 1] == r
+        a, b = r % px, r // px
+        assert (nb[0] is None) == (not periodic and b == 0) and (nb[3] is None) == (not periodic and a == px - 1)
+    path = str(tmp_path / "ok.json")
+    mp.spawn(_grid_worker, args=(px * py, _free_port(), grid, periodic, path), nprocs=px * py, join=True)
+    assert json.load(open(path)) == [1] * (px * py)

@@ -18,7 +18,7 @@ from tests.test_gpu_parity import (  # noqa: F401
     test_wide_distribution_beyond_lds_window, test_scenario_update_parity,
     test_seasalt_emissions_parity, test_transport_parity, test_transport_preweight_parity,
     test_open_lateral_boundaries, test_transport_makes_room_among_tombstones,
-    test_transport_slabs_match_whole_domain, test_dry_deposition_parity)
+    test_transport_slabs_match_whole_domain, test_transport_blocks_cut_in_x_and_y, test_dry_deposition_parity)
 from tests.test_gpu_timestep import test_partmc_timestep_loop  # noqa: F401
 
 pytestmark = pytest.mark.gpu

@@ -354,3 +354,22 @@ def test_transport_across_two_ranks():
         capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "distributed transport ok: 2 ranks" in out.stdout
+
+
+def test_transport_across_a_grid_of_ranks():
+    """The second cut direction (the reference decomposes in x and y, wrf_pmc_trans_aero.F90:148-273):
+    four processes, a 2 x 2 grid of blocks with ghost rows AND ghost columns, exchange preweight terms,
+    weights and movers with CellBlock.transport_preweight_distributed_2d / .transport_distributed_2d
+    (gloo rendezvous on 127.0.0.1, one shared GPU); every rank checks its real cells against the
+    whole-domain preweight and transport bit for bit, doubly periodic and with open lateral
+    boundaries (tests/dist_transport2d_worker.py)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PMCX_TEST_BACKEND="gloo")
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
+         "--master-addr", "127.0.0.1", "--master-port", "29537",
+         os.path.join(ROOT, "tests", "dist_transport2d_worker.py")],
+        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "dist_transport2d_worker ok: 4 ranks" in out.stdout

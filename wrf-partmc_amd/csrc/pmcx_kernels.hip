@@ -4482,15 +4482,18 @@ __global__ __launch_bounds__(64) void k_trans_remove(DeviceState st, TransGrid t
 
 // ------------------------------------------------------- transport across ranks
 //
-// Slab decomposition in y: a rank's block carries one ghost row below its first real row and
-// one above its last.  After k_trans_decide the movers of a boundary row that go to the
-// neighbouring rank are packed (source cell by source cell, in outbox order) and shipped;
-// the receiver lays them out in its ghost row exactly as the sender's boundary row looked to
-// a destination -- particles in slots 0.., an outbox that names them -- so that
-// k_trans_gather, unchanged, pulls them in the same place of its fixed source order as it
-// would inside one block.  Record: header {src, dest (cell index within its row), copies,
-// wclass, index within the source cell, pad} | vtot, mass | lct, gct, id, n_orig0 |
-// vol[n_spec] | n_orig[1..] (padded to 8 bytes).
+// The domain cut in y (slabs) or in x and y (the reference's two directions,
+// wrf_pmc_trans_aero.F90:148-273): a rank's block carries one ghost row below its first real row
+// and one above its last, and -- cut in x as well -- one ghost column west and east.  After
+// k_trans_decide the movers of a boundary strip (a row or a column: Strip) that go to the
+// neighbouring rank are packed (source cell by source cell, in outbox order) and shipped; the
+// receiver lays them out in its ghost strip exactly as the sender's boundary strip looked to a
+// destination -- particles in slots 0.., an outbox that names them -- so that k_trans_gather,
+// unchanged, pulls them in the same place of its fixed source order as it would inside one
+// block.  A mover goes to one of its four neighbours or a level of its column: corners carry
+// nothing.  Record: header {src, dest (cell index within its strip), copies, wclass, index within
+// the source cell, pad} | vtot, mass | lct, gct, id, n_orig0 | vol[n_spec] | n_orig[1..] (padded
+// to 8 bytes) | component list (n_comp_max > 0).
 
 __host__ __device__ inline size_t halo_rec_bytes(int n_spec, int n_source, int n_comp_max)
 {

@@ -66,6 +66,48 @@ class PmcxError(RuntimeError):
     pass
 
 
+def grid_neighbours(rank, grid, periodic_x, periodic_y):
+    """(below, above, west, east) ranks of `rank` in a px x py grid of blocks (rank = b * px + a), None
+    where the domain ends."""
+    px, py = grid
+    a, b = rank % px, rank // px
+    at = lambda a_, b_: (b_ % py) * px + (a_ % px)
+    return (at(a, b - 1) if (periodic_y or b > 0) else None, at(a, b + 1) if (periodic_y or b < py - 1) else None,
+            at(a - 1, b) if (periodic_x or a > 0) else None, at(a + 1, b) if (periodic_x or a < px - 1) else None)
+
+
+def swap_sides(dist, out, nbr):
+    """The four-neighbour exchange of a domain cut in x and y.  out[side]: what goes to the neighbour
+    on that side (0 below, 1 above, 2 west, 3 east; torch tensors of one dtype and device); nbr: the
+    neighbours' ranks (grid_neighbours).  Returns what arrives FROM each side (None: no neighbour
+    there).  Four phases: everybody sends one way and receives from the opposite side."""
+    import torch
+    world = dist.get_world_size()
+    sizes = torch.tensor([t.numel() for t in out], dtype=torch.int64, device=out[0].device)
+    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes)
+    got = [None] * 4
+    for side in range(4):
+        to, frm = nbr[side], nbr[side ^ 1]          # send towards `side`, receive from the opposite one
+        ops, rbuf = [], None
+        if to is not None:
+            ops.append(dist.P2POp(dist.isend, out[side], to))
+        if frm is not None:
+            # (the sender's message is the one it addresses to ITS side `side`)
+            rbuf = torch.empty(int(all_sizes[frm][side]), dtype=out[0].dtype, device=out[0].device)
+            ops.append(dist.P2POp(dist.irecv, rbuf, frm))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            if out[0].device.type != "cpu":
+                # on RCCL wait() only orders torch's current stream behind the transfer; the library
+                # unpacks on its own stream: the receive must have landed
+                torch.cuda.current_stream().synchronize()
+        if rbuf is not None:
+            got[side ^ 1] = rbuf
+    return got
+
+
 def dist_rows_before(dist, my_rows):
     """Domain rows held by the ranks below this one (ranks ordered along y)."""
     import torch
@@ -719,6 +761,75 @@ class CellBlock:
         self.transport_import(0, got[0])
         self.transport_import(1, got[1])
         return self.transport_finish()
+
+    # -- a domain cut in x and y over a px x py grid of ranks (rank = b * px + a): grid_neighbours,
+    # -- swap_sides above
+    def transport_distributed_2d(self, dist, grid, nx, nz, ny, prob_h, prob_v, cell_volume, seed=0, step=0,
+                                 periodic_x=True, periodic_y=True):
+        """One transport step of this rank's block of a domain cut in x AND y (grid = (px, py), rank =
+        b px + a; the block carries a ghost row and a ghost column on every side:
+        set_transport_cuts): the movers of its four boundary strips go to the four neighbours as
+        device buffers (RCCL point-to-point on "nccl", staged through the host on "gloo").  Returns
+        (n_moved, n_arrived) per local cell."""
+        import torch
+        rank = dist.get_rank()
+        nbr = grid_neighbours(rank, grid, periodic_x, periodic_y)
+        self.transport_begin(nx, nz, ny, prob_h, prob_v, cell_volume, seed, step, False)
+        on_host = dist.get_backend() != "nccl"
+        dev = "cpu" if on_host else f"cuda:{self.cfg.device}"
+        out = []
+        for side in range(4):
+            bf = self.transport_export(side)
+            t = torch.empty(bf.nbytes, dtype=torch.uint8, device=dev)
+            if bf.nbytes:
+                self._ck(self._lib.pmcx_device_copy(self._h, C.c_void_p(t.data_ptr()), bf.ptr, bf.nbytes,
+                                                    2 if on_host else 0))
+            out.append(t)
+        got = swap_sides(dist, out, nbr)
+        for side in range(4):
+            rbuf = got[side]
+            if rbuf is None:
+                self.transport_import(side, None)
+            elif on_host:
+                d = DeviceBuffer(self, rbuf.numel())
+                if rbuf.numel():
+                    self._ck(self._lib.pmcx_device_copy(self._h, d.ptr, C.c_void_p(rbuf.data_ptr()), rbuf.numel(), 1))
+                self.transport_import(side, d)
+            else:
+                self.transport_import(side, rbuf)
+        return self.transport_finish()
+
+    def transport_preweight_distributed_2d(self, dist, grid, nx, nz, ny, prob_h, prob_v, cell_volume, j_global0,
+                                           global_ny, seed=0, step=0, periodic_x=True, periodic_y=True):
+        """transport_preweight of this rank's block of a domain cut in x and y: the ready terms of the
+        cut rows and columns travel between the four neighbours, then the boundary strips' new
+        weight magnitudes for the neighbours' ghost strips.  Returns (expected_num_conc, n_removed)."""
+        import torch
+        rank = dist.get_rank()
+        px, py = grid
+        a, b = rank % px, rank // px
+        nbr = grid_neighbours(rank, grid, periodic_x, periodic_y)
+        dev = "cpu" if dist.get_backend() != "nccl" else f"cuda:{self.cfg.device}"
+        rows, cols = self.transport_preweight_begin(nx, nz, ny, prob_h, prob_v, cell_volume, j_global0, global_ny,
+                                                    periodic_x, periodic_y, cut_x=True)
+        as_t = lambda x: torch.from_numpy(np.ascontiguousarray(x).reshape(-1).copy()).to(dev)
+        got = swap_sides(dist, [as_t(rows[0]), as_t(rows[1]), as_t(cols[0]), as_t(cols[1])], nbr)
+        host = lambda t: None if t is None else np.ascontiguousarray(t.cpu().numpy())
+        self.transport_preweight_x_terms(host(got[2]), host(got[3]), nbr[2] is not None and a == 0,
+                                         nbr[3] is not None and a == px - 1)
+        ex, nr = self.transport_preweight_finish(host(got[0]), host(got[1]), nbr[0] is not None and b == 0,
+                                                 nbr[1] is not None and b == py - 1, seed, step)
+        # the ghost strips stand for the neighbours' boundary strips: their weights follow the scaling there
+        Cn = self.cfg.n_class
+        mag = self.get_weights().reshape(ny, nz, nx, Cn)
+        out = [as_t(mag[1]), as_t(mag[ny - 2]), as_t(mag[:, :, 1]), as_t(mag[:, :, nx - 2])]
+        got = swap_sides(dist, out, nbr)
+        if got[0] is not None: mag[0] = host(got[0]).reshape(nz, nx, Cn)
+        if got[1] is not None: mag[ny - 1] = host(got[1]).reshape(nz, nx, Cn)
+        if got[2] is not None: mag[:, :, 0] = host(got[2]).reshape(ny, nz, Cn)
+        if got[3] is not None: mag[:, :, nx - 1] = host(got[3]).reshape(ny, nz, Cn)
+        self.set_weights(mag.reshape(-1, Cn))
+        return ex, nr
 
     def dry_deposition(self, dt, aer_res_a, ustar, alpha, big_a, height, inv_density, seed=0,
                        step=0, surface=None):
