@@ -85,6 +85,22 @@ def main():
                                                   periodic, periodic)
             assert np.array_equal(nm[real], nm_w[gmap[real]]) and np.array_equal(na[real], na_w[gmap[real]])
             assert not blk.aero_state_total_particles()[~real].any()
+            if not periodic:
+                # the refill of the lateral boundary cells (wrf_pmc_trans_aero.F90:803-955): every rank
+                # sees to the boundary cells it holds
+                r2 = np.random.RandomState(40 + step)
+                u_w = r2.normal(0, 1, (ny, nz)); u_e = r2.normal(0, 1, (ny, nz))
+                v_s = r2.normal(0, 1, (nx, nz)); v_n = r2.normal(0, 1, (nx, nz))
+                rho = r2.uniform(0.9, 1.2, n)
+                bg = [dict(gm_radius=5e-8, gsd_log10=0.2, vol_frac=[0.5, 0.5], wclass=0, source=0),
+                      dict(gm_radius=1e-7, gsd_log10=0.2, vol_frac=[1.0, 0.0], wclass=1, source=1)]
+                bg_conc = np.stack([0.8 * n_part / n_class * mag[:, 0] / rho, 1.3 * n_part / n_class * mag[:, 1] / rho], axis=1)
+                whole.lateral_boundary_conditions(nx, nz, ny, u_w, u_e, v_s, v_n, bg, bg_conc, rho, seed=21, step=step)
+                gj = (gj0 + np.arange(nyl)) % ny; gi = (gi0 + np.arange(nxl)) % nx
+                out = blk.lateral_boundary_conditions(nxl, nz, nyl, u_w[gj], u_e[gj], v_s[gi], v_n[gi], bg, bg_conc[gmap],
+                                                      rho[gmap], seed=21, step=step, j_global0=gj0, global_ny=ny,
+                                                      i_global0=gi0, global_nx=nx)
+                assert len(out["copied"]) + len(out["resampled"]) > 0
             ref, got = whole.download_cells(), blk.download_cells()
             assert np.array_equal(np.diff(got["part_offset"])[gl], np.diff(ref["part_offset"])[gmap[gl]])
             sel = np.concatenate([np.arange(ref["part_offset"][g], ref["part_offset"][g + 1]) for g in gmap[gl]])

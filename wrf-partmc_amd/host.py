@@ -911,7 +911,8 @@ class CellBlock:
     def lateral_boundary_conditions(self, nx, nz, ny, u_west, u_east, v_south, v_north, background,
                                     background_conc, density, seed=0, step=0, u_west_old=None,
                                     u_east_old=None, v_south_old=None, v_north_old=None,
-                                    change_boundary_conditions=False, j_global0=0, global_ny=None):
+                                    change_boundary_conditions=False, j_global0=0, global_ny=None,
+                                    i_global0=0, global_nx=None):
         """The refill of the lateral boundary cells after the transport, as
         wrf_pmc_trans_aero.F90:803-955 orders it: on the west side (i = 0, rows 1 .. ny-2) a cell
         whose u (grid%u_2 at its outer face; u_west [ny][nz]) is negative copies its inner
@@ -923,7 +924,9 @@ class CellBlock:
         A slab of a domain cut in y (rows 0 and ny - 1 ghosts) passes j_global0 (the domain row
         of its row 0) and global_ny: its west and east columns are refilled on its own real rows,
         the south / north row only by the rank that holds it (u_west, u_east indexed by local row).
-        Returns dict(copied=[cells], resampled=[cells], n_added, n_removed)."""
+        A block cut in x as well (columns 0 and nx - 1 ghosts) passes i_global0 and global_nx too: the
+        west / east column is then refilled only by the rank that holds it (v_south, v_north indexed by
+        local column).  Returns dict(copied=[cells], resampled=[cells], n_added, n_removed)."""
         cell = lambda i, k, j: (j * nz + k) * nx + i
         gny = ny if global_ny is None else global_ny
         slab = global_ny is not None
@@ -944,14 +947,18 @@ class CellBlock:
                 else:
                     turned = vel_old is not None and v * vel_old[idx] < 0.0
                     res.append(c); thr.append(int(turned or change_boundary_conditions))
-        side([(cell(0, k, j), cell(1, k, j), (j, k)) for j in x_rows for k in range(nz)], u_w, old[0], True)
-        side([(cell(nx - 1, k, j), cell(nx - 2, k, j), (j, k)) for j in x_rows for k in range(nz)],
-             u_e, old[1], False)
+        gnx = nx if global_nx is None else global_nx
+        cols = [i for i in (range(1, nx - 1) if global_nx is not None else range(nx)) if 0 <= i + i_global0 < gnx]
+        y_cols = [i for i in cols if 0 < i + i_global0 < gnx - 1]
+        for i in (i for i in cols if i + i_global0 == 0):            # the domain's west column
+            side([(cell(i, k, j), cell(i + 1, k, j), (j, k)) for j in x_rows for k in range(nz)], u_w, old[0], True)
+        for i in (i for i in cols if i + i_global0 == gnx - 1):      # ... and its east column
+            side([(cell(i, k, j), cell(i - 1, k, j), (j, k)) for j in x_rows for k in range(nz)], u_e, old[1], False)
         for j in j_south:
-            side([(cell(i, k, j), cell(i, k, j + 1), (i, k)) for i in range(1, nx - 1) for k in range(nz)],
+            side([(cell(i, k, j), cell(i, k, j + 1), (i, k)) for i in y_cols for k in range(nz)],
                  v_s, old[2], True)
         for j in j_north:
-            side([(cell(i, k, j), cell(i, k, j - 1), (i, k)) for i in range(1, nx - 1) for k in range(nz)],
+            side([(cell(i, k, j), cell(i, k, j - 1), (i, k)) for i in y_cols for k in range(nz)],
                  v_n, old[3], False)
         if frm:
             self.boundary_copy(frm, to)
