@@ -108,6 +108,26 @@ def main():
                 assert np.array_equal(got[k], ref[k][..., sel]), (rank, step, periodic, k)
             moved += int(nm[real].sum())
         assert moved > 100
+        if periodic:
+            # the probabilities built on the device from WRF-shaped fields, block by block
+            from tests import trans_fields as tf
+            F = tf.make_fields(nx, nz, ny, n_class, seed=7, k_scale=5.0, flux_scale=0.03 * n_part * 1e7)
+            F["v_flux"][:, ny] = F["v_flux"][:, 0]; F["u_flux"][..., nx] = F["u_flux"][..., 0]   # one face each: periodic
+            wrap = lambda c: np.pad(c, ((1, 1), (0, 0), (1, 1)), mode="wrap")
+            Fw = dict(F, alt=wrap(F["alt"][1:-1, :, 1:-1]), xkhh=wrap(F["xkhh"][1:-1, :, 1:-1]))
+            rows, cols = (gj0 + np.arange(nyl)) % ny, (gi0 + np.arange(nxl)) % nx
+            rows_h, cols_h = (gj0 - 1 + np.arange(nyl + 2)) % ny, (gi0 - 1 + np.arange(nxl + 2)) % nx
+            fx, fy = (gi0 + np.arange(nxl + 1)) % nx, (gj0 + np.arange(nyl + 1)) % ny
+            core = lambda k: Fw[k][1:-1, :, 1:-1]
+            Fs = dict(alt=core("alt")[rows_h][:, :, cols_h], xkhh=core("xkhh")[rows_h][:, :, cols_h],
+                      u_flux=F["u_flux"][:, rows][..., fx], v_flux=F["v_flux"][:, fy][..., cols],
+                      w_flux=F["w_flux"][:, rows][..., cols], z=F["z"][rows][..., cols],
+                      z_at_w=F["z_at_w"][rows][..., cols], exch_h=F["exch_h"][rows][..., cols])
+            phw, pvw, nsw, badw, _ = whole.transport_probs(nx, nz, ny, 30.0, 3000.0, 3000.0, Fw)
+            phs, pvs, nss, bads, _ = blk.transport_probs(nxl, nz, nyl, 30.0, 3000.0, 3000.0, Fs, i_offset=gi0,
+                                                         j_offset=gj0, global_nx=nx, global_ny=ny)
+            assert not badw.any() and not bads[real].any()
+            assert np.array_equal(phs[real], phw[gmap[real]]) and np.array_equal(pvs[real], pvw[gmap[real]]), rank
         whole.close(); blk.close()
     dist.barrier()
     if rank == 0:
