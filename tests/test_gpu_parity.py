@@ -920,6 +920,69 @@ def test_golden_config1_on_gpu(wp):
     blk.close()
 
 
+def test_golden_grid_sequence_on_gpu(wp, oracle):
+    """The committed fixture tests/golden/grid_3x2x3_seed5.json (preweight -> transport -> mc_coag ->
+    rebalance on a periodic 3 x 2 x 3 grid, component lists carried) through the HIP path: the
+    same counters and the same checksums of volumes, ids, classes, weights and lists."""
+    import hashlib
+    import json
+    import os
+    from tests.golden.make_golden import run_grid
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "grid_3x2x3_seed5.json")))
+    # the fixture's initial state and inputs, rebuilt the way the generator builds them (seeded)
+    nx, nz, ny, n_class, n_spec, n_part, cap = 3, 2, 3, 2, 2, 300, 1024
+    n = nx * nz * ny
+    names, dens = parity.default_species(n_spec)
+    modes, num_conc = parity.make_modes(n_spec, n_class)
+    for m in modes:
+        m["source"] = m["source"] % 2
+    rng = np.random.RandomState(5)
+    mag0 = num_conc * 40.0 / n_part * (1.0 + 0.5 * np.arange(n_class))
+    blk = wp.CellBlock(n, cap, n_spec, n_class=n_class, n_source=2, n_comp_max=4, max_events=1024, max_appends=256)
+    blk.set_aero_data(dens); blk.set_env(285.0, 9.5e4)
+    ve, _ = blk.bin_tables()
+    cells, mag = [], np.zeros((n, n_class))
+    for c in range(n):
+        oc = oracle.Cell(n_spec, n_class, 2, cap, dens, ve, 285.0, 9.5e4, n_comp_max=4)
+        mag[c] = mag0 * rng.uniform(0.8, 1.25)
+        oc.generate(modes, n_part, 5, c, first_id=c << 32, create_time=float(c))
+        oc.lct[:n_part] = oc.gct[:n_part] = oc.comp_time[:n_part, 0] = c + 1e-3 * np.arange(n_part)
+        cells.append(oc)
+    cv = rng.uniform(0.8e9, 1.3e9, n)
+    ph = rng.uniform(0, 0.08, (n, n_class, 4)); pv = rng.uniform(0, 0.04, (n, n_class, nz))
+    blk.set_weights(mag)
+    blk.set_n_part_ideal(np.full((n, n_class), 0.45 * n_part / n_class))
+    blk.set_next_id((np.arange(n, dtype=np.int64) << 32) + (1 << 20))
+    po = np.arange(n + 1, dtype=np.int64) * n_part
+    cat = lambda f: np.concatenate([f(oc) for oc in cells], axis=-1)
+    blk.upload_cells(0, po, cat(lambda oc: oc.vol[:, :n_part]), cat(lambda oc: oc.wclass[:n_part]),
+                     cat(lambda oc: oc.id[:n_part]), cat(lambda oc: oc.lct[:n_part]), cat(lambda oc: oc.gct[:n_part]),
+                     cat(lambda oc: oc.n_orig[:, :n_part]))
+    parity.upload_components(blk, cells, po)
+    counters = []
+    for step in range(3):
+        ex, nr = blk.transport_preweight(nx, nz, ny, ph, pv, cv, 5, step, True, True)
+        nm, na = blk.transport(nx, nz, ny, ph, pv, cv, 5, step, True, True)
+        st_t = int(np.bitwise_or.reduce(blk.coag_counters()[2]))
+        ns, nc, st = blk.mc_coag(K_BROWN, 1800.0, 5, step)
+        tot = [int(st.sum()), int(ns.sum()), int(nc.sum())]
+        blk.aero_state_rebalance(True, True, 5, step)
+        counters.append(dict(thinned=int(nr.sum()), moved=int(nm.sum()), arrived=int(na.sum()), status=st_t, coag=tot))
+    assert counters == gold["counters"]
+    dn, cm = blk.download_cells(), blk.download_components()
+    assert np.diff(dn["part_offset"]).tolist() == gold["n_part"]
+    h = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    # (the fixture hashes cell after cell; the downloads are the cells laid end to end, species-major)
+    sl = [slice(dn["part_offset"][c], dn["part_offset"][c + 1]) for c in range(n)]
+    hh = lambda parts: hashlib.sha256(b"".join(np.ascontiguousarray(p).tobytes() for p in parts)).hexdigest()
+    assert hh(dn["vol"][:, s] for s in sl) == gold["vol"]
+    assert hh(dn["id"][s] for s in sl) == gold["id"] and hh(dn["wclass"][s] for s in sl) == gold["wclass"]
+    assert hh(blk.get_weights()[c] for c in range(n)) == gold["mag"]
+    assert hh(cm["comp_source"][s] for s in sl) == gold["comp_source"]
+    assert hh(cm["comp_time"][s] for s in sl) == gold["comp_time"]
+    blk.close()
+
+
 def test_run_part_driver(wp):
     """run_part-shaped loop (mc_coag + rebalance + diagnostics): number concentration falls
     monotonically, mass concentration is conserved (single class, no removal but merging)."""

@@ -432,6 +432,20 @@ def test_golden_event_log(oracle):
     assert got["id_checksum"] == gold["id_checksum"]
 
 
+def test_golden_grid_sequence(oracle):
+    """Preweight -> transport -> mc_coag -> rebalance on a 3 x 2 x 3 periodic grid with component
+    lists (tests/golden/grid_3x2x3_seed5.json): the transport's draw, the exact-count thinning, the
+    order of arrivals and the merge order of the lists, pinned across rounds."""
+    with open(os.path.join(GOLDEN, "grid_3x2x3_seed5.json")) as f:
+        gold = json.load(f)
+    from tests.golden.make_golden import run_grid
+    got = run_grid(oracle)
+    assert got["counters"] == gold["counters"] and got["n_part"] == gold["n_part"]
+    for k in ("vol", "id", "wclass", "mag", "comp_source", "comp_time"):
+        assert got[k] == gold[k], k
+    assert sum(c["moved"] for c in gold["counters"]) > 1000 and gold["counters"][0]["thinned"] > 1000
+
+
 # ------------------------------------------------ condensation (extension)
 
 def test_condensation_reaches_koehler_equilibrium(oracle):
