@@ -1369,6 +1369,9 @@ int pmcx_transport(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int32_t pe
     const pmcx_config &cf = ctx->cfg;
     if (nx < 1 || nz < 1 || ny < 1 || nz > 128 || (int64_t)nx * nz * ny != cf.n_cells)
         return fail(ctx, PMCX_EINVAL, "pmcx_transport: nx*nz*ny must equal n_cells (nz <= 128)");
+    if (ctx->st.trans_cut_x)
+        return fail(ctx, PMCX_ESTATE, "pmcx_transport: the block is one of a domain cut in x (pmcx_set_transport_cuts): "
+                                      "its transport goes through pmcx_transport_begin ... _finish");
     if (ctx->st.trans_lateral && (periodic_x || periodic_y || nx < 3 || ny < 3 || ctx->st.trans_j0 != 0 ||
                                   (ctx->st.trans_gny != 0 && ctx->st.trans_gny != ny)))
         return fail(ctx, PMCX_EINVAL, "pmcx_transport: open lateral boundaries (pmcx_set_transport_lateral) "
@@ -1591,6 +1594,9 @@ int pmcx_transport_preweight(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, 
     const pmcx_config &cf = ctx->cfg;
     if (nx < 1 || nz < 1 || ny < 1 || nz > 128 || (int64_t)nx * nz * ny != cf.n_cells)
         return fail(ctx, PMCX_EINVAL, "pmcx_transport_preweight: nx*nz*ny must equal n_cells (nz <= 128)");
+    if (ctx->st.trans_cut_x)
+        return fail(ctx, PMCX_ESTATE, "pmcx_transport_preweight: the block is one of a domain cut in x: its preweight "
+                                      "goes through pmcx_transport_preweight_begin, _x_terms, _finish");
     HIP_TRY(ctx, hipSetDevice(cf.device));
     const size_t nc = (size_t)cf.n_cells, C = (size_t)cf.n_class;
     if (!ctx->d_preweight) {
