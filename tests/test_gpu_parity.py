@@ -1376,8 +1376,9 @@ def test_transport_slabs_match_whole_domain(wp):
         b.close()
 
 
-@pytest.mark.parametrize("periodic", [True, False])
-def test_transport_blocks_cut_in_x_and_y(wp, periodic):
+@pytest.mark.parametrize("periodic,shape", [(True, (8, 6, 2, 2)), (False, (8, 6, 2, 2)), (True, (4, 6, 4, 2)),
+                                            (False, (9, 4, 3, 1)), (True, (6, 3, 2, 1))])
+def test_transport_blocks_cut_in_x_and_y(wp, periodic, shape):
     """The transport exchange with both cut directions (the reference decomposes in x and y,
     wrf_pmc_trans_aero.F90:148-273): the domain as 2 x 2 blocks, each with a ghost row and a ghost
     column on every side, movers exported / imported through the four sides (what RCCL would carry
@@ -1385,8 +1386,8 @@ def test_transport_blocks_cut_in_x_and_y(wp, periodic):
     component lists when they are carried -- of pmcx_transport on the whole domain.  periodic:
     doubly periodic; otherwise open lateral boundaries (boundary cells send inwards only, what
     reaches them leaves)."""
-    nx, nz, ny, n_class, n_spec, cap, n_part = 8, 3, 6, 2, 2, 1024, 400
-    bx, by = 2, 2
+    nx, ny, bx, by = shape                            # (also blocks of a single column, and one row of blocks)
+    nz, n_class, n_spec, cap, n_part = 3, 2, 2, 1024, 400
     rx, ry = nx // bx, ny // by                      # real columns / rows per block
     n = nx * nz * ny
     rng = np.random.RandomState(17)
