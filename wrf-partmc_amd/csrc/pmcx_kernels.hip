@@ -3975,18 +3975,19 @@ __global__ __launch_bounds__(64) void k_boundary_resample(DeviceState st, const 
                                   1u + (uint32_t)cl, w);
                         u = u53(w[0], w[1]);
                     }
-                    // the decisions, in rank order (each depends on how many have gone before)
+                    // the decisions, in rank order (each depends on how many have gone before).  Member t
+                    // goes when u (n - t) < m - k, i.e. -- both sides of the comparison being what they
+                    // are, an integer on the right -- when k <= m - 1 - floor(u (n - t)): every lane
+                    // works out that bound for itself, the serial part is one scalar compare a member
+                    const int t_l = t0 + __popcll(mcls & lt);
+                    const int a_l = (wc == cl) ? m_rm - 1 - (int)(u * (double)(n_before - t_l)) : -1;
                     uint64_t msel = 0, rest = mcls;
-                    int t = t0;
                     while (rest) {
                         const int l = __builtin_ctzll(rest);
                         rest &= rest - 1;
-                        const double ul = u2d(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(d2u(u) >> 32), l) << 32) |
-                                              (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)d2u(u), l));
-                        if (ul * (double)(n_before - t) < (double)(m_rm - k)) { msel |= 1ull << l; k++; }
-                        t++;
+                        if (k <= __builtin_amdgcn_readlane(a_l, l)) { msel |= 1ull << l; k++; }
                     }
-                    t0 = t;
+                    t0 += __popcll(mcls);
                     if ((msel >> lane) & 1ull) mark_dead(st, cb, i);
                     rank0 += (uint32_t)__popcll(mlive);
                 }
@@ -4232,17 +4233,17 @@ __global__ __launch_bounds__(64) void k_preweight_scale(DeviceState st, Preweigh
                 rng_block(seed, cell_id, step, rank0 + (uint32_t)__popcll(mlive & lt), SITE_SCALE, (uint32_t)cl, w);
                 u = u53(w[0], w[1]);
             }
+            // (member t goes when u (n - t) < m - k, i.e. when k <= m - 1 - floor(u (n - t)): a bound every
+            // lane works out for itself; the serial part is one scalar compare a member)
+            const int t_l = t0 + __popcll(mcls & lt);
+            const int a_l = (wc == cl) ? m_rm - 1 - (int)(u * (double)(n_before - t_l)) : -1;
             uint64_t msel = 0, rest = mcls;
-            int t = t0;
             while (rest) {
                 const int l = __builtin_ctzll(rest);
                 rest &= rest - 1;
-                const double ul = u2d(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(d2u(u) >> 32), l) << 32) |
-                                      (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)d2u(u), l));
-                if (ul * (double)(n_before - t) < (double)(m_rm - k_rm)) { msel |= 1ull << l; k_rm++; }
-                t++;
+                if (k_rm <= __builtin_amdgcn_readlane(a_l, l)) { msel |= 1ull << l; k_rm++; }
             }
-            t0 = t;
+            t0 += __popcll(mcls);
             if ((msel >> lane) & 1ull) mark_dead(st, cb, i);
             rank0 += (uint32_t)__popcll(mlive);
         }
