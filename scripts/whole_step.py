@@ -34,6 +34,7 @@ ap.add_argument("--chem-dt", type=float, default=60.0)     # registry.partmc:24
 ap.add_argument("--given-probs", action="store_true",
                 help="hand the transport fixed probabilities instead of building them from WRF-shaped "
                      "fields on the device every step (transport_probs + transport_preweight)")
+ap.add_argument("--trace", type=int, default=0, help="every TRACE steps: cells thinned by the preweight, weight and population spread (stderr)")
 ap.add_argument("--sync-stages", action="store_true", help="every stage call waits for the device (the default before round 3)")
 a = ap.parse_args()
 
@@ -121,7 +122,13 @@ for step in range(a.steps):
         blk.transport_probs(nx, nz, ny, a.dt, 4000.0, 4000.0, fields, download=False)
         host["transport_probs"] += time.perf_counter() - ts
         tp = time.perf_counter()
-        blk.transport_preweight(nx, nz, ny, None, None, cell_volume, seed=0, step=step)
+        ex_pw, nr_pw = blk.transport_preweight(nx, nz, ny, None, None, cell_volume, seed=0, step=step)
+        if a.trace and step % a.trace == 0:
+            blk.synchronize()
+            w_, np_ = blk.get_weights()[:, 0], blk.aero_state_total_particles()
+            print(f"step {step}: preweight thinned {int((nr_pw > 0).sum())} cells ({int(nr_pw.sum())} particles); weights "
+                  f"{w_.min():.3g} .. {w_.max():.3g} (median {np.median(w_):.3g}); particles per cell {np_.min()} .. {np_.max()} "
+                  f"(median {int(np.median(np_))})", file=sys.stderr)
         host["transport_preweight"] += time.perf_counter() - tp
         tp = time.perf_counter()
         nm, na = blk.transport(nx, nz, ny, None, None, cell_volume, seed=0, step=step)
