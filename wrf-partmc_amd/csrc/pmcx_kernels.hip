@@ -2475,19 +2475,27 @@ __global__ void k_comp_default(DeviceState st, int cell_first)
 __device__ __forceinline__ void move_particle(const DeviceState &st, int64_t cb, int c, int dst,
                                               int src)
 {
-    for (int s = 0; s < st.n_spec; s++)
-        st.vol[(cb + dst) * st.n_spec + s] =
-            st.vol[(cb + src) * st.n_spec + s];
-    for (int s = 0; s < st.n_source; s++)
-        norig(st, cb, s, dst) =
-            norig(st, cb, s, src);
-    st.hot[cb + dst].vtot = st.hot[cb + src].vtot;
-    st.hot[cb + dst].mass = st.hot[cb + src].mass;
-    st.gkey[cb + dst] = st.gkey[cb + src];
-    st.wclass[cb + dst] = st.wclass[cb + src];
-    st.cold[cb + dst].id = st.cold[cb + src].id;
-    st.hot[cb + dst].lct = st.hot[cb + src].lct;
-    st.hot[cb + dst].gct = st.hot[cb + src].gct;
+    // every record is read before any is written: the loads go out together (written field by
+    // field, each store would have to wait for the load behind it -- source and destination are
+    // the same arrays to the compiler)
+    const Hot h = st.hot[cb + src];
+    const Cold cd = st.cold[cb + src];
+    const uint16_t gk = st.gkey[cb + src];
+    const int32_t wc = st.wclass[cb + src];
+    double v4[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int s = 0; s < 4 && s < st.n_spec; s++) v4[s] = st.vol[(cb + src) * st.n_spec + s];
+    int32_t no4[4] = {0, 0, 0, 0};
+    for (int s = 1; s < 4 && s < st.n_source; s++) no4[s] = norig(st, cb, s, src);
+    st.hot[cb + dst] = h;
+    st.cold[cb + dst] = cd;
+    st.gkey[cb + dst] = gk;
+    st.wclass[cb + dst] = wc;
+    for (int s = 0; s < 4 && s < st.n_spec; s++) st.vol[(cb + dst) * st.n_spec + s] = v4[s];
+    for (int s = 1; s < 4 && s < st.n_source; s++) norig(st, cb, s, dst) = no4[s];
+    for (int s = 4; s < st.n_spec; s++)
+        st.vol[(cb + dst) * st.n_spec + s] = st.vol[(cb + src) * st.n_spec + s];
+    for (int s = 4; s < st.n_source; s++)
+        norig(st, cb, s, dst) = norig(st, cb, s, src);
     comp_copy(st, cb + dst, cb + src);
 }
 
@@ -2511,17 +2519,29 @@ __device__ void compact_wave(const DeviceState &st, int c, int lane, uint32_t *c
     const bool lists = cbase != nullptr && st.sort_valid[c] != 0;
     const bool remap = lists || (cbase != nullptr && map_always);
     int base = 0;
-    // four 64-slot chunks per trip: their liveness words, then every field of the slots that
-    // move, are requested together (one memory round trip each instead of one per chunk)
+    // Four 64-slot chunks per trip.  A trip's sources are slots nobody has written (destinations
+    // lie at or below their sources, and below the next trip's first slot): the only order that
+    // matters is inside a trip -- every field of its movers is in registers before the first is
+    // stored.  So a trip waits for memory ONCE: the liveness words of the NEXT trip are requested
+    // before this trip's fields, the source counts (four sources at a time) with them, and the
+    // stores drain while the next trip works.
     constexpr int U = 4;
+    double xn[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int i = u * 64 + lane;
+        xn[u] = i < n_hi ? ld_f64(&st.hot[cb + i].vtot) : -1.0;
+    }
     for (int i0 = 0; i0 < n_hi; i0 += 64 * U) {
         double x[U];
         int dst[U];
         bool mv[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int i = i0 + u * 64 + lane;
-            x[u] = i < n_hi ? ld_f64(&st.hot[cb + i].vtot) : -1.0;
+        for (int u = 0; u < U; u++) x[u] = xn[u];
+#pragma unroll
+        for (int u = 0; u < U; u++) { // (the next trip's liveness: on its way while this trip moves)
+            const int i = i0 + 64 * U + u * 64 + lane;
+            xn[u] = i < n_hi ? ld_f64(&st.hot[cb + i].vtot) : -1.0;
         }
         bool any = false;
 #pragma unroll
@@ -2543,16 +2563,23 @@ __device__ void compact_wave(const DeviceState &st, int c, int lane, uint32_t *c
         int64_t idv[U];
         int32_t wc[U];
         uint16_t kk[U];
+        uint32_t xo[4][U]; // the first four sources' counts travel with the records
+        const int NS4 = NS < 4 ? NS : 4;
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int i = i0 + u * 64 + lane;
             a1[u] = a2[u] = a3[u] = 0; idv[u] = 0; wc[u] = 0; kk[u] = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) xo[q][u] = 0u;
             if (mv[u]) {
                 kk[u] = st.gkey[cb + i];
                 a1[u] = ld_f64(&st.hot[cb + i].mass);
                 a2[u] = ld_f64(&st.hot[cb + i].lct); a3[u] = ld_f64(&st.hot[cb + i].gct);
                 idv[u] = (int64_t)d2u(ld_f64((const double *)&st.cold[cb + i].id));
                 wc[u] = (int32_t)ld_u32((const uint32_t *)&st.wclass[cb + i]);
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (q < NS4) xo[q][u] = ld_u32((const uint32_t *)&norig(st, cb, q, i));
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2566,6 +2593,9 @@ __device__ void compact_wave(const DeviceState &st, int c, int lane, uint32_t *c
                 st_f64((double *)&st.cold[cb + d].id, u2d((uint64_t)idv[u]));
                 st_u32((uint32_t *)&st.wclass[cb + d], (uint32_t)wc[u]);
                 st.gkey[cb + d] = kk[u];
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (q < NS4) st_u32((uint32_t *)&norig(st, cb, q, d), xo[q][u]);
             }
         // species volumes (with one species the plane is not kept current: nothing to move)
         if (S > 1)
@@ -2584,16 +2614,16 @@ __device__ void compact_wave(const DeviceState &st, int c, int lane, uint32_t *c
                         if (mv[u] && s0 + k < S) st_f64(&st.vol[(cb + dst[u]) * S + (s0 + k)], v[k]);
                 }
             }
-        for (int s = 0; s < NS; s++) {
-            uint32_t xo[U];
+        for (int s = 4; s < NS; s++) { // (sources beyond the fourth: one at a time)
+            uint32_t xs[U];
 #pragma unroll
             for (int u = 0; u < U; u++)
-                xo[u] = mv[u] ? ld_u32((const uint32_t *)&norig(st, cb, s, i0 + u * 64 + lane)) : 0u;
+                xs[u] = mv[u] ? ld_u32((const uint32_t *)&norig(st, cb, s, i0 + u * 64 + lane)) : 0u;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             wave_sync();
 #pragma unroll
             for (int u = 0; u < U; u++)
-                if (mv[u]) st_u32((uint32_t *)&norig(st, cb, s, dst[u]), xo[u]);
+                if (mv[u]) st_u32((uint32_t *)&norig(st, cb, s, dst[u]), xs[u]);
         }
         if (st.n_comp_max) { // the component lists: the source word, then one create time at a time
             const int K = st.n_comp_max;
@@ -2615,8 +2645,6 @@ __device__ void compact_wave(const DeviceState &st, int c, int lane, uint32_t *c
                     }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wave_sync();
     }
     if (lane == 0) st.n_hi[c] = base;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2700,9 +2728,11 @@ __global__ __launch_bounds__(64) void k_rebalance(DeviceState st, int allow_doub
                 if (n_hi + ncl > st.cap) { status |= ST_CAP_OVERFLOW; break; }
                 const int64_t nid = st.next_id[c];
                 uint32_t base = 0;
+                int wc_next = lane < n_hi ? live_class_c(st, cb, lane) : -1; // (requested a chunk ahead)
                 for (int i0 = 0; i0 < n_hi; i0 += 64) {
                     const int i = i0 + lane;
-                    const bool is = (i < n_hi) && (live_class_c(st, cb, i) == cl);
+                    const bool is = wc_next == cl;
+                    wc_next = i + 64 < n_hi ? live_class_c(st, cb, i + 64) : -1;
                     const uint64_t m = __ballot(is);
                     const uint32_t k = base + (uint32_t)__popcll(m & lt);
                     if (is) {
@@ -2725,9 +2755,11 @@ __global__ __launch_bounds__(64) void k_rebalance(DeviceState st, int allow_doub
                 wave_sync();
             } else if (allow_halving && (double)ncl > ideal * 2.0) {
                 uint32_t nd = 0, rank0 = 0;
+                int wc_next = lane < n_hi ? live_class_c(st, cb, lane) : -1; // (requested a chunk ahead)
                 for (int i0 = 0; i0 < n_hi; i0 += 64) {
                     const int i = i0 + lane;
-                    const int wc = i < n_hi ? live_class_c(st, cb, i) : -1;
+                    const int wc = wc_next;
+                    wc_next = i + 64 < n_hi ? live_class_c(st, cb, i + 64) : -1;
                     const uint64_t mlive = __ballot(wc >= 0);
                     const uint32_t rank = rank0 + (uint32_t)__popcll(mlive & lt);
                     bool drop = false;
@@ -4223,9 +4255,13 @@ __global__ __launch_bounds__(64) void k_preweight_scale(DeviceState st, Preweigh
         m_rm = m_rm < n_before ? m_rm : n_before;
         uint32_t nd = 0, rank0 = 0;
         int t0 = 0, k_rm = 0; // class members seen, removed so far (uniform)
+        // (the next chunk's liveness is requested before this chunk's work: a wavefront alone with a
+        // big cell would otherwise wait out a memory round trip per 64 slots)
+        int wc_next = lane < n_hi ? live_class_c(st, cb, lane) : -1;
         for (int i0 = 0; i0 < n_hi && k_rm < m_rm; i0 += 64) {
             const int i = i0 + lane;
-            const int wc = i < n_hi ? live_class_c(st, cb, i) : -1;
+            const int wc = wc_next;
+            wc_next = i + 64 < n_hi ? live_class_c(st, cb, i + 64) : -1;
             const uint64_t mlive = __ballot(wc >= 0);
             const uint64_t mcls = __ballot(wc == cl);
             double u = 0.0;
