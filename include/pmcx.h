@@ -623,7 +623,10 @@ typedef struct {
 } pmcx_step_flags;
 
 /* zeros, struct_size, kernel_type = COAG_KERNEL_TYPE_BROWN, do_coagulation = allow_doubling =
- * allow_halving = 1 (registry.partmc:2,14-15), partmc_chem_dt = 60 (registry.partmc:24) */
+ * allow_halving = 1 (registry.partmc:2,14-15), partmc_chem_dt = 60 (registry.partmc:24) * The step has ONE status word per cell: it is started here and every stage adds its bits (called by
+ * itself each stage starts its own), so that what mc_coag reported -- a full event log, a cell out of
+ * slots -- is still there when the step returns (pmcx_get_coag_counters).
+ */
 void pmcx_step_flags_default(pmcx_step_flags *flags);
 
 int pmcx_timestep(pmcx_ctx *ctx, const pmcx_step_flags *flags);

@@ -336,3 +336,19 @@ def test_asynchronous_stage_calls_give_the_same_step(wp):
         for q, (u, v) in enumerate(zip(x, y)):
             assert np.array_equal(u, v), (step, q)
     assert sum(int(x[2].sum()) for x in pa) > 1000 and sum(int(x[4].sum()) for x in pa) > 0
+
+
+def test_a_step_keeps_what_every_stage_reported(wp, oracle):
+    """pmcx_timestep runs mc_coag, the scenario updates and the rebalance on ONE status word: the
+    event-log overflow of mc_coag is still there after the stages behind it (each of them, called
+    by itself, starts a new word), and a step without coagulation does not inherit it."""
+    blk, cells, info = parity.setup_pair(wp, oracle, 4, 1500, 1, 1, 6, K_BROWN, n_source=1, num_conc_scale=300.0,
+                                         max_events=8, cap=2048)
+    blk.set_n_part_ideal(np.full((4, 1), 1500.0))
+    emission = [dict(gm_radius=3e-8, gsd_log10=0.2, vol_frac=[1.0], wclass=0, source=0)]
+    blk.partmc_timestep(0.0, 20.0, 60.0, random_seed=6, emission=emission, emission_rate=np.full((4, 1), 1e4))
+    ns, nc, st = blk.coag_counters()
+    assert (st & 1).all() and (nc == 8).all()            # every cell filled its event log of 8
+    blk.partmc_timestep(20.0, 20.0, 60.0, random_seed=6, emission=emission, emission_rate=np.full((4, 1), 1e4))
+    assert not blk.coag_counters()[2].any()              # (not a chemistry step: a clean word)
+    blk.close()

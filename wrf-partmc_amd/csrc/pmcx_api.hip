@@ -98,6 +98,8 @@ struct pmcx_ctx {
     bool prof = false;
     // pmcx_set_async: the per-step stage calls return without waiting for the device
     bool async_stages = false;
+    // pmcx_timestep: the status word of the step is started once and its stages add their bits
+    bool hold_status = false;
     int32_t *h_flags = nullptr; // page-locked: [0] pmcx_transport_probs' sub-step clamp, read at the next synchronisation
     std::map<std::string, ProfEntry> profile;
     std::vector<hipEvent_t> event_pool;
@@ -1003,8 +1005,9 @@ int pmcx_mc_coag(pmcx_ctx *ctx, int32_t kernel_type, double del_t, uint64_t seed
     if (!ctx->aero_data_set || !ctx->env_set)
         return fail(ctx, PMCX_ESTATE, "pmcx_set_aero_data and pmcx_set_env must come first");
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->st.status, 0, sizeof(int32_t) * (size_t)ctx->cfg.n_cells,
-                                ctx->stream));
+    if (!ctx->hold_status)
+        HIP_TRY(ctx, hipMemsetAsync(ctx->st.status, 0, sizeof(int32_t) * (size_t)ctx->cfg.n_cells,
+                                    ctx->stream));
     {
         ProfScope ps(ctx, "bin_sort");
         HIP_TRY(ctx, launch_bin_sort(ctx->st, ctx->stream));
@@ -1206,7 +1209,7 @@ int pmcx_scenario_update_aero_state(pmcx_ctx *ctx, double dt, double elapsed_tim
         if (e == hipSuccess) { tmp.push_back(d_dil); e = hipMemcpyAsync(d_dil, dilution_rate, sizeof(double) * nc, hipMemcpyHostToDevice, ctx->stream); }
     }
     if (e == hipSuccess) { e = tmp_malloc(ctx, (void **)&d_cnt, sizeof(int32_t) * 3 * nc); if (e == hipSuccess) tmp.push_back(d_cnt); }
-    if (e == hipSuccess) e = hipMemsetAsync(ctx->st.status, 0, sizeof(int32_t) * nc, ctx->stream);
+    if (e == hipSuccess && !ctx->hold_status) e = hipMemsetAsync(ctx->st.status, 0, sizeof(int32_t) * nc, ctx->stream);
     if (e == hipSuccess) {
         ProfScope ps(ctx, "scenario");
         e = launch_scenario_update(ctx->st, dt, elapsed_time, seed, step, emission ? &ge : nullptr, ce,
@@ -1304,7 +1307,7 @@ int pmcx_seasalt_emissions(pmcx_ctx *ctx, double dt, double elapsed_time, uint64
     if (rc) { cleanup(); return rc; }
     hipError_t e = tmp_malloc(ctx, (void **)&d_cnt, sizeof(int32_t) * nc);
     if (e == hipSuccess) tmp.push_back(d_cnt);
-    if (e == hipSuccess) e = hipMemsetAsync(ctx->st.status, 0, sizeof(int32_t) * nc, ctx->stream);
+    if (e == hipSuccess && !ctx->hold_status) e = hipMemsetAsync(ctx->st.status, 0, sizeof(int32_t) * nc, ctx->stream);
     if (e == hipSuccess) {
         ProfScope ps(ctx, "scenario");
         e = launch_scenario_update(ctx->st, dt, elapsed_time, seed, step, &ge, ce, nullptr, nullptr, nullptr,
@@ -2272,6 +2275,11 @@ int pmcx_timestep(pmcx_ctx *ctx, const pmcx_step_flags *f)
     const uint32_t step = (uint32_t)(f->elapsed_time / f->partmc_chem_dt);
     const uint32_t wrf_step = (uint32_t)(f->elapsed_time / f->dt);
     int rc = PMCX_OK;
+    // one status word for the step: every stage adds its bits (each of them, called by itself,
+    // would start a new one and wipe what mc_coag reported)
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->st.status, 0, sizeof(int32_t) * (size_t)ctx->cfg.n_cells, ctx->stream));
+    struct Hold { pmcx_ctx *c; Hold(pmcx_ctx *x) : c(x) { c->hold_status = true; } ~Hold() { c->hold_status = false; } } hold(ctx);
     if (chem_step && f->do_coagulation) {                                        // driver:189-198
         rc = pmcx_mc_coag(ctx, f->kernel_type, f->partmc_chem_dt, f->random_seed, step);
         if (rc) return rc;
