@@ -1467,7 +1467,12 @@ contains
        last_n_moved = sum(int(n_moved, 8))
        if (ideal) call check_transport_status()
     end if
-    if (pmc_ks == 1 .and. grid%do_deposition) last_n_deposited = sum(int(n_dep, 8))
+    if (pmc_ks == 1 .and. grid%do_deposition) then
+       last_n_deposited = sum(int(n_dep, 8))
+       ! the reference's message, not an abort (wrf_pmc_dep_aero.F90:194-196; it prints the extreme
+       ! probabilities of a cell, which stay on the device here: the cells are counted instead)
+       if (any(unreal /= 0)) print *, "Unrealistic deposition in", count(unreal /= 0), "cells"
+    end if
 
   contains
 
