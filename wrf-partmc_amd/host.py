@@ -367,6 +367,7 @@ class CellBlock:
         t = np.ascontiguousarray(np.broadcast_to(_f64(temp), (n,)))
         p = np.ascontiguousarray(np.broadcast_to(_f64(pressure), (n,)))
         r = None if rel_humid is None else np.ascontiguousarray(np.broadcast_to(_f64(rel_humid), (n,)))
+        self._inflight_env = (t, p, r)
         self._ck(self._lib.pmcx_set_env(self._h, _ptr(t), _ptr(p), _ptr(r)))
 
     def set_weights(self, magnitude):
@@ -841,6 +842,7 @@ class CellBlock:
                (aer_res_a, ustar, alpha, big_a, height, inv_density)]
         sf = None if surface is None else np.ascontiguousarray(np.broadcast_to(surface, (n,)), dtype=np.int32)
         nr, bad = self._out("dep0", n), self._out("dep1", n)
+        self._inflight_dep = (arr, sf)          # (an asynchronous call reads them after it has returned)
         self._ck(self._lib.pmcx_dry_deposition(self._h, dt, seed, step, _ptr(sf), *[_ptr(a) for a in arr],
                                                _ptr(nr), _ptr(bad)))
         return nr, bad
@@ -867,6 +869,7 @@ class CellBlock:
                 raise ValueError(f"transport_probs: {name} has shape {a.shape}, expected {shp}")
             keep.append(a)
             setattr(tf, name, a.ctypes.data)
+        self._inflight_probs = keep             # (an asynchronous call reads them after it has returned)
         if not download:
             self._ck(self._lib.pmcx_transport_probs(self._h, C.byref(tf), None, None, None, None, None))
             return None
@@ -979,6 +982,7 @@ class CellBlock:
         pv = None if prob_v is None else np.ascontiguousarray(np.broadcast_to(_f64(prob_v), (n, Cn, nz)))
         cv = np.ascontiguousarray(np.broadcast_to(_f64(cell_volume), (n,)))
         ex, nr = self._out("pre0", (n, Cn), np.float64), self._out("pre1", n)
+        self._inflight_pw = (ph, pv, cv)
         self._ck(self._lib.pmcx_transport_preweight(self._h, nx, nz, ny, int(periodic_x), int(periodic_y),
                                                     _ptr(ph), _ptr(pv), _ptr(cv), seed, step, _ptr(ex),
                                                     _ptr(nr)))
@@ -1091,6 +1095,7 @@ class CellBlock:
         pv = None if prob_v is None else np.ascontiguousarray(np.broadcast_to(_f64(prob_v), (n, Cn, nz)))
         cv = np.ascontiguousarray(np.broadcast_to(_f64(cell_volume), (n,)))
         nm, na = self._out("tr0", n), self._out("tr1", n)
+        self._inflight_tr = (ph, pv, cv)
         self._ck(self._lib.pmcx_transport(self._h, nx, nz, ny, int(periodic_x), int(periodic_y),
                                           _ptr(ph), _ptr(pv), _ptr(cv), seed, step, _ptr(nm), _ptr(na)))
         return nm, na
