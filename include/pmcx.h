@@ -494,7 +494,8 @@ int pmcx_dry_deposition(pmcx_ctx *ctx, double dt, uint64_t seed, uint32_t step,
  * [n_cells][n_class][nz]: to level k' of the column (prob_vert_diffusion,
  * :2446-2460; the own level is ignored); cell_volume [n_cells] (the
  * dz_source/dz_dest weight factor, :2214-2218).  Lateral boundaries are periodic
- * or closed; exchange with other contexts (other GPUs) is not part of this call.
+ * or closed (a periodic direction one cell wide counts as closed -- the cell would be its
+ * own neighbour -- here and in pmcx_transport_preweight); exchange with other contexts (other GPUs) is not part of this call.
  * prob_h == prob_v == NULL: the probabilities pmcx_transport_probs built (PMCX_ESTATE if none).
  * n_moved / n_arrived: [n_cells], may be NULL.  Synchronises.
  */

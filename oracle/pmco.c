@@ -1217,6 +1217,9 @@ int pmco_transport(pmco_cell *cells, int n_cells, int nx, int nz, int ny, int pe
 {
     const int C = cells[0].n_class;
     int status = 0;
+    /* a periodic direction one cell wide is closed: the cell would be its own neighbour */
+    periodic_x = periodic_x && nx > 1;
+    periodic_y = periodic_y && ny > 1;
     for (int k = 0; k < n_cells; k++) *cells[k].sort_valid = 0;
     /* phase 1: every particle decides; outbox entries (slot, dest, copies) in rank order */
     typedef struct { int32_t slot, dest, copies; } entry;
@@ -1295,7 +1298,11 @@ int pmco_transport(pmco_cell *cells, int n_cells, int nx, int nz, int ny, int pe
                 if (box[sc][e].dest != c) continue;
                 for (int g = 0; g < box[sc][e].copies; g++) {
                     const int at = *dst->n_part;
-                    if (at >= dst->cap) { status |= PMCO_ST_CAP_OVERFLOW; continue; }
+                    if (at >= dst->cap) { /* no room: flagged, and the copy's new id is spent all the same */
+                        status |= PMCO_ST_CAP_OVERFLOW;
+                        if (g != box[sc][e].copies - 1) next_id[c]++;
+                        continue;
+                    }
                     const int from = box[sc][e].slot;
                     for (int sp = 0; sp < dst->n_spec; sp++)
                         dst->vol[(size_t)sp * dst->cap + at] = s->vol[(size_t)sp * s->cap + from];
@@ -1547,7 +1554,8 @@ int pmco_transport_preweight(pmco_cell *cells, int n_cells, int nx, int nz, int 
                     double *self = &expected[c * C + cl];
                     const double *ph = prob_h + (c * C + cl) * 4;          /* i-1, i+1, j-1, j+1 */
                     int dirs[4] = {0, 0, 0, 0}, vert = 0;                  /* which moves the cell makes */
-                    if (ideal) { dirs[0] = dirs[1] = dirs[2] = dirs[3] = 1; vert = 1; }
+                    /* (a periodic direction one cell wide is closed: the cell would be its own neighbour) */
+                    if (ideal) { dirs[0] = dirs[1] = nx > 1; dirs[2] = dirs[3] = ny > 1; vert = 1; }
                     else if (i == 0) { if (j != 0 && j != ny - 1) dirs[1] = 1; }        /* :1510-1524 */
                     else if (i == nx - 1) { if (j != 0 && j != ny - 1) dirs[0] = 1; }   /* :1525-1539 */
                     else if (j == 0) { dirs[3] = 1; }                                   /* :1540-1554 */

@@ -1047,7 +1047,9 @@ def _transport_probs(n_cells, n_class, nz, seed, scale=0.08):
                                             (4, 5, 1, False, False),
                                             # a column taller than a wavefront is wide: more than
                                             # 64 sources per cell, no destination mask
-                                            (1, 66, 1, False, False)])
+                                            (1, 66, 1, False, False),
+                                            # one cell across a periodic direction: closed that way
+                                            (1, 3, 4, True, True), (3, 2, 1, True, True)])
 def test_transport_parity(wp, oracle, nx, nz, ny, px, py):
     """stochastic transport between cells, GPU vs oracle bit for bit, followed by
     a coagulation step on the mixed populations."""

@@ -558,6 +558,41 @@ def _dep_velocity_numpy(d, rho, temp, rrho, ustar, ra, alpha, big_a):
     return 1.0 / (ra + rs + ra * rs * vs) + vs
 
 
+@pytest.mark.parametrize("nx,ny", [(1, 3), (3, 1), (1, 1)])
+def test_a_periodic_direction_one_cell_wide_is_closed(oracle, nx, ny):
+    """With one cell across a periodic direction the cell would be its own neighbour: nothing moves
+    that way (pmcx.h, pmcx_transport) -- in the transport and in the expectation the preweight
+    forms -- and nobody is lost: the outcome is the one with those probabilities set to zero."""
+    nz, n_part = 2, 300
+    dens = np.array([1800.0]); ve, _ = oracle.make_bin_tables(80, 1e-10, 1e-2)
+    n = nx * nz * ny
+    rng = np.random.RandomState(4)
+    ph = rng.uniform(0.05, 0.2, (n, 1, 4)); pv = rng.uniform(0.0, 0.1, (n, 1, nz)); cv = rng.uniform(0.8, 1.2, n)
+    ph0 = ph.copy()
+    if nx == 1:
+        ph0[:, :, 0:2] = 0.0
+    if ny == 1:
+        ph0[:, :, 2:4] = 0.0
+    outs = []
+    for probs in (ph, ph0):
+        cells = []
+        for c in range(n):
+            oc = oracle.Cell(1, 1, 0, 4 * n_part, dens, ve)
+            oc.mag[:] = 1e6 * (1 + c)
+            oc.generate([dict(frac=1, gm_radius=3e-8, gsd_log10=0.2, vol_frac=[1.0])], n_part, 7, c, first_id=c << 32)
+            cells.append(oc)
+        next_id = (np.arange(n, dtype=np.int64) << 32) + (1 << 24)
+        ex, nr = oracle.transport_preweight(cells, nx, nz, ny, probs, pv, cv, np.full((n, 1), float(n_part)), 7, 0, 0)
+        st, nm, na = oracle.transport(cells, nx, nz, ny, probs, pv, cv, 7, 0, 0, next_id)
+        assert st == 0
+        outs.append((ex, nm, na, [oc.id[:int(oc.n_part[0])].copy() for oc in cells]))
+    a, b = outs
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert all(np.array_equal(x, y) for x, y in zip(a[3], b[3]))
+    if nx == 1 and ny == 1:     # only the levels exchange
+        assert a[1].sum() > 0 and a[1].sum() < 0.2 * n * n_part
+
+
 def test_dry_deposition_velocity(oracle):
     """Zhang (2001) deposition velocity (wrf_pmc_dep_aero.F90:265-420): equal to an independent
     numpy transcription to rounding, U-shaped in diameter, settling-dominated for coarse

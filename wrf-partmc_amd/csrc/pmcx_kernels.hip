@@ -4103,7 +4103,8 @@ __global__ __launch_bounds__(64) void k_preweight_old(DeviceState st, PreweightA
 // which moves a source cell makes: bit d of the result = towards i-1, i+1, j-1, j+1; bit 4 = levels
 __device__ __forceinline__ int preweight_moves(int i, int j, int nx, int ny, int ideal)
 {
-    if (ideal) return 31;
+    // (a periodic direction one cell wide is closed: the cell would be its own neighbour)
+    if (ideal) return 16 | (nx > 1 ? 3 : 0) | (ny > 1 ? 12 : 0);
     if (i == 0) return (j != 0 && j != ny - 1) ? 2 : 0;
     if (i == nx - 1) return (j != 0 && j != ny - 1) ? 1 : 0;
     if (j == 0) return 8;
@@ -4173,15 +4174,15 @@ __global__ __launch_bounds__(256) void k_preweight_new(DeviceState st, Preweight
             if (hi_ghost && a.hi_edge && a.gin_hi) acc = acc + a.gin_hi[r]; // the domain's last row
             if (lo_ghost && a.lo_edge && a.gin_lo) acc = acc + a.gin_lo[r]; // the domain's first row
         } else {
-            if (j == ny - 1) acc = acc + from_h(cell(i, k, 0), 2);
-            if (j == 0) acc = acc + from_h(cell(i, k, ny - 1), 3);
+            if (j == ny - 1 && ny > 1) acc = acc + from_h(cell(i, k, 0), 2);
+            if (j == 0 && ny > 1) acc = acc + from_h(cell(i, k, ny - 1), 3);
         }
         if (cut_x) {
             if (e_ghost && a.e_edge && a.gin_e) acc = acc + a.gin_e[rc]; // the domain's last column
             if (w_ghost && a.w_edge && a.gin_w) acc = acc + a.gin_w[rc]; // the domain's first column
         } else {
-            if (i == nx - 1) acc = acc + from_h(cell(0, k, j), 0);
-            if (i == 0) acc = acc + from_h(cell(nx - 1, k, j), 1);
+            if (i == nx - 1 && nx > 1) acc = acc + from_h(cell(0, k, j), 0);
+            if (i == 0 && nx > 1) acc = acc + from_h(cell(nx - 1, k, j), 1);
         }
     }
     a.expect[d * C + cl] = acc;
@@ -5268,6 +5269,9 @@ static TransGrid make_grid(int nx, int nz, int ny, int periodic_x, int periodic_
                            void *outbox, int32_t *n_out, int32_t *n_arr, int32_t *n_exp,
                            uint64_t *dest_mask, int c_first)
 {
+    // a periodic direction one cell wide is closed: the cell would be its own neighbour
+    periodic_x = periodic_x && nx > 1;
+    periodic_y = periodic_y && ny > 1;
     return TransGrid{nx, nz, ny, periodic_x, periodic_y, prob_h, prob_v, cell_volume, (int2 *)outbox,
                      n_out, n_arr, c_first, n_exp, dest_mask};
 }
