@@ -991,8 +991,8 @@ int pmco_seasalt_emissions(pmco_cell *c, double dt, double create_time, uint64_t
     double *vf = (double *)calloc((size_t)M * c->n_spec, sizeof(double));
     for (int m = 0; m < M; m++) {
         rate[m] = flux[m] * scale / height;       /* p = emission_rate_scale dt / height, :1917 */
-        lg[m] = log(gm[m]);
-        ls[m] = gsd[m] * log(10.0);
+        lg[m] = pmco_log(gm[m]);
+        ls[m] = gsd[m] * 2.302585092994046;   /* ln 10 */
         vf[m * c->n_spec + i_na] = f_na;
         vf[m * c->n_spec + i_cl] = 1.0 - f_na;
         if (mode_class) cls[m] = mode_class[m];

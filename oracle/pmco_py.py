@@ -69,6 +69,16 @@ def build_native():
     return os.path.join(_HERE, "_native", "libpmco.so")
 
 
+LN_10 = 2.302585092994046   # ln 10, correctly rounded
+
+
+def det_log(x):
+    """The logarithm of a mode's parameters: pmco_log, not numpy's nor libm's (numpy's vectorised
+    log and glibc's differ in the last bit for one argument in a few hundred; the product forms
+    these on the host with the same operations, pmcx_device_math.h)."""
+    return lib().pmco_log_(float(x))
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -227,8 +237,8 @@ class Cell:
             return None, None
         keep = dict(
             nc=np.array([m["num_conc"] for m in modes], dtype=np.float64),
-            lg=np.array([np.log(m["gm_radius"]) for m in modes], dtype=np.float64),
-            ls=np.array([m["gsd_log10"] * np.log(10.0) for m in modes], dtype=np.float64),
+            lg=np.array([det_log(m["gm_radius"]) for m in modes], dtype=np.float64),
+            ls=np.array([m["gsd_log10"] * LN_10 for m in modes], dtype=np.float64),
             vf=np.ascontiguousarray([m["vol_frac"] for m in modes], dtype=np.float64),
             mc=np.array([m.get("wclass", 0) for m in modes], dtype=np.int32),
             ms=np.array([m.get("source", 0) for m in modes], dtype=np.int32))
@@ -326,8 +336,8 @@ class Cell:
         """modes: list of dict(frac, gm_radius, gsd_log10, vol_frac[n_spec], wclass, source)."""
         fr = np.cumsum([m["frac"] for m in modes], dtype=np.float64)
         fr = fr / fr[-1]
-        lg = np.array([np.log(m["gm_radius"]) for m in modes], dtype=np.float64)
-        ls = np.array([m["gsd_log10"] * np.log(10.0) for m in modes], dtype=np.float64)
+        lg = np.array([det_log(m["gm_radius"]) for m in modes], dtype=np.float64)
+        ls = np.array([m["gsd_log10"] * LN_10 for m in modes], dtype=np.float64)
         vf = np.ascontiguousarray([m["vol_frac"] for m in modes], dtype=np.float64)
         mc = np.array([m.get("wclass", 0) for m in modes], dtype=np.int32)
         msrc = np.array([m.get("source", 0) for m in modes], dtype=np.int32)

@@ -30,10 +30,9 @@ def _build():
         pytest.skip("flang or the prebuilt test_driver is not available")
 
 
-@pytest.mark.parametrize("periodic", [False, True])
-def test_wrf_steps_through_the_two_drivers(tmp_path, wp, oracle, periodic):
-    _build()
-    case = wrf_case.Case(periodic=periodic, seed=91 if not periodic else 57)
+def run_case(case, tmp_path, wp, oracle):
+    """The Fortran driver and the oracle through the same case; every particle, list, weight and
+    gas compared.  Returns (steps, final) of the driver's dump.  (Also scripts/fuzz_driver.py.)"""
     with wp.CellBlock(1, 64, case.n_spec, n_class=case.n_class) as blk:      # the product's tables and defaults
         v_edge, v_samp = blk.bin_tables()
         const_k, beta = blk.cfg.const_k, blk.cfg.additive_beta
@@ -76,6 +75,14 @@ def test_wrf_steps_through_the_two_drivers(tmp_path, wp, oracle, periodic):
             assert np.array_equal(lst["t"][:k], oc.comp_time[i, :k]), (c, i)
             assert (lst["t"][k:] == oc.gct[i]).all(), (c, i)
         assert np.array_equal(fc["gas"].view(np.uint64), gas[c].view(np.uint64)), c
+    return steps, final
+
+
+@pytest.mark.parametrize("periodic", [False, True])
+def test_wrf_steps_through_the_two_drivers(tmp_path, wp, oracle, periodic):
+    _build()
+    case = wrf_case.Case(periodic=periodic, seed=91 if not periodic else 57)
+    steps, final = run_case(case, tmp_path, wp, oracle)
     assert any(len(l) >= 2 for fc in final for l in fc["comp"])           # coagulated particles: lists of two constituents
     # the case exercises what it claims to
     tot = lambda k: sum(st[k] for st in steps)

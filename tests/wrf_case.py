@@ -319,7 +319,7 @@ class Case:
                 for c, thr in zip(*lists.get("res", ([], []))):
                     st, cells[c].next_id, _, _ = cells[c].boundary_resample(
                         thr, self.bg[c][p], 1.0 / float(env["inv_density"][c]), 0.0, seed, c, wrf_step, cells[c].next_id)
-                    assert st == 0
+                    assert st == 0, (s, c, st, int(cells[c].n_part[0]), cells[c].cap)
             # dry deposition on the lowest level of the interior columns
             for j in range(1, ny - 1):
                 for i in range(1, nx - 1):

@@ -6,6 +6,7 @@
 // stream.  No CPU fallback: without a usable gfx950 device pmcx_create fails.
 #include "../../include/pmcx.h"
 #include "pmcx_kernels.h"
+#include "pmcx_device_math.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -20,6 +21,8 @@ using namespace pmcx;
 namespace {
 
 thread_local std::string g_create_error;
+
+constexpr double LN_10 = 2.302585092994046; // ln 10, correctly rounded (0x1.26bb1bbb55516p+1)
 
 struct ProfEntry {
     double ms = 0.0;
@@ -1128,8 +1131,8 @@ int pack_modes(pmcx_ctx *ctx, const pmcx_aero_dist *d, size_t n_rows, const int3
         for (int m = 0; m < M; m++) {
             const size_t src = r * M + m, dst = c * M + m;
             if (!(d->gm_radius[src] > 0)) return fail(ctx, PMCX_EINVAL, "aero_dist: gm_radius must be positive");
-            h_gm[dst] = std::log(d->gm_radius[src]);
-            h_gs[dst] = d->gsd_log10[src] * std::log(10.0);
+            h_gm[dst] = det_log(d->gm_radius[src]);     // (not libm's: see pmcx_device_math.h)
+            h_gs[dst] = d->gsd_log10[src] * LN_10;
             for (int s = 0; s < S; s++) h_vf[dst * S + s] = d->vol_frac[src * S + s];
             h_mc[dst] = d->mode_class ? d->mode_class[src] : 0;
             h_ms[dst] = d->mode_source ? d->mode_source[src] : 0;
@@ -2078,8 +2081,8 @@ int pmcx_generate_lognormal(pmcx_ctx *ctx, int32_t n_part, int32_t n_mode, const
     for (int m = 0; m < n_mode; m++) {
         acc += mode_frac[m];
         h[m] = acc / tot;
-        h[n_mode + m] = std::log(gm_radius[m]);
-        h[2 * n_mode + m] = gsd_log10[m] * std::log(10.0);
+        h[n_mode + m] = det_log(gm_radius[m]);
+        h[2 * n_mode + m] = gsd_log10[m] * LN_10;
         for (int s = 0; s < S; s++) h[3 * n_mode + (size_t)m * S + s] = vol_frac[(size_t)m * S + s];
     }
     std::vector<int32_t> hi(2 * (size_t)n_mode);

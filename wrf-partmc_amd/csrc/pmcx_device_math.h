@@ -91,10 +91,12 @@ __device__ __forceinline__ uint32_t index_of(uint32_t w, uint32_t n)
 
 // -------------------------------------------------------------- exp / log
 
-__device__ __forceinline__ double u2d(uint64_t u) { return __longlong_as_double((long long)u); }
-__device__ __forceinline__ uint64_t d2u(double x) { return (uint64_t)__double_as_longlong(x); }
+// (exp and log also run on the host: the logarithms of a mode's parameters are formed there, and
+// with these the result does not depend on the host's libm -- same operations, same bits)
+__host__ __device__ __forceinline__ double u2d(uint64_t u) { return __builtin_bit_cast(double, u); }
+__host__ __device__ __forceinline__ uint64_t d2u(double x) { return __builtin_bit_cast(uint64_t, x); }
 
-__device__ inline double det_exp(double x)
+__host__ __device__ inline double det_exp(double x)
 {
     if (x < -745.0) return 0.0;
     if (x > 709.0) return __builtin_inf();
@@ -123,7 +125,7 @@ __device__ inline double det_exp(double x)
     return (p * u2d((uint64_t)(k + 1000 + 1023) << 52)) * 0x1.0p-1000;
 }
 
-__device__ inline double det_log(double x)
+__host__ __device__ inline double det_log(double x)
 {
     const double ln2_hi = 6.93147180369123816490e-01;
     const double ln2_lo = 1.90821492927058770002e-10;

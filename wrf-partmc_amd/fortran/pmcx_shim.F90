@@ -1465,7 +1465,9 @@ contains
        ! normalize_probs' assertions (wrf_pmc_trans.F90:713,746,759,771)
        if (any(bad /= 0)) call pmcx_die(5, 'wrf_pmc_trans_driver_pmcx (normalize_probs: a probability is negative, above one, or their sum is)')
        last_n_moved = sum(int(n_moved, 8))
-       if (ideal) call check_transport_status()
+       ! (open boundaries: the transport's word was looked at before the refill started a new one;
+       ! this is the refill's -- a boundary cell resampled against a background it has no room for)
+       call check_transport_status()
     end if
     if (pmc_ks == 1 .and. grid%do_deposition) then
        last_n_deposited = sum(int(n_dep, 8))
