@@ -1384,7 +1384,7 @@ contains
        if (.not. ideal) then
           ! (pmcx_boundary_resample starts a new status word: the transport's is looked at first)
           call pmcx_die(pmcx_synchronize(ctx), 'pmcx_synchronize')
-          call check_transport_status()
+          call check_transport_status('in the transport')
           ! the refill of the lateral boundary cells (trans_aero:803-955): which copy their inner
           ! neighbour (outflow), which are resampled against the background (inflow; emptied first
           ! where the wind has turned or the background has moved to its next time level)
@@ -1467,7 +1467,11 @@ contains
        last_n_moved = sum(int(n_moved, 8))
        ! (open boundaries: the transport's word was looked at before the refill started a new one;
        ! this is the refill's -- a boundary cell resampled against a background it has no room for)
-       call check_transport_status()
+       if (ideal) then
+          call check_transport_status('in the transport')
+       else
+          call check_transport_status('in the lateral boundary refill')
+       end if
     end if
     if (pmc_ks == 1 .and. grid%do_deposition) then
        last_n_deposited = sum(int(n_dep, 8))
@@ -1479,10 +1483,12 @@ contains
   contains
 
     !> the cells' status after the transport: no cell may have run out of slots
-    subroutine check_transport_status()
+    subroutine check_transport_status(where)
+      character(len=*), intent(in) :: where
       allocate(ns(n_cells), nc(n_cells), st(n_cells))
       call pmcx_die(pmcx_get_coag_counters(ctx, ns, nc, st), 'pmcx_get_coag_counters')
-      if (any(iand(st, 16) /= 0)) call pmcx_die(5, 'wrf_pmc_trans_driver_pmcx (a cell ran out of particle slots)')
+      if (any(iand(st, 16) /= 0)) call pmcx_die(5, 'wrf_pmc_trans_driver_pmcx (a cell ran out of particle slots ' &
+           // trim(where) // ': raise cap_min of pmcx_upload_states)')
       deallocate(ns, nc, st)
     end subroutine check_transport_status
 
