@@ -430,7 +430,12 @@ int pmcx_transport_preweight_finish(pmcx_ctx *ctx, const double *terms_from_belo
  *   pmcx_transport_finish       arrivals are pulled in the fixed source order (ghost rows
  *                               included), movers removed, ghost rows emptied
  * The result on the real rows is bit for bit the one of pmcx_transport on the whole domain
- * (tests/test_gpu_parity.py::test_transport_slabs_match_whole_domain). */
+ * (tests/test_gpu_parity.py::test_transport_slabs_match_whole_domain).
+ * One shape is excluded: a PERIODIC direction of the whole domain two cells wide must not be
+ * cut.  Both neighbours of a cell are then one cell, whose movers pmcx_transport takes as a single
+ * sequence while the exchange delivers them as two (from below and from above): the arrival
+ * order would differ.  The host drivers refuse it (CellBlock.transport_distributed[_2d]);
+ * pmcx_transport_import does where it can see it (cut in x with global_nx == 2). */
 /* A block cut in x as well (the reference decomposes in x and y, wrf_pmc_trans_aero.F90:148-273):
  * cut_x != 0 says columns 0 and nx_local - 1 of the block are ghosts of the ranks to the west and
  * east, local column 0 standing for the domain's column i_global0 (-1 on the west-most rank of a

@@ -99,8 +99,16 @@ def _grid_worker(rank, world, port, grid, periodic, path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     nbr = host.grid_neighbours(rank, grid, periodic, periodic)
     out = [torch.full((3 + rank + 2 * side,), 100.0 * rank + side, dtype=torch.float64) for side in range(4)]
-    got = host.swap_sides(dist, out, nbr)
+    got = host.swap_sides(dist, out, nbr, extent=(3, 3, grid, periodic, periodic))
     ok = True
+    # a periodic direction of the whole domain two cells wide is refused, on every rank, before
+    # anything is sent (pmcx.h, pmcx_transport_begin): here px blocks of one column each
+    try:
+        host.swap_sides(dist, out, nbr, extent=(1, 3, grid, periodic, periodic))
+        refused = False
+    except host.PmcxError:
+        refused = True
+    ok &= refused == (periodic and grid[0] == 2)
     for side in range(4):
         frm = nbr[side]
         if frm is None:

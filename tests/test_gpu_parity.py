@@ -1381,6 +1381,13 @@ def test_transport_slabs_match_whole_domain(wp):
 @pytest.mark.parametrize("periodic,shape", [(True, (8, 6, 2, 2)), (False, (8, 6, 2, 2)), (True, (4, 6, 4, 2)),
                                             (False, (9, 4, 3, 1)), (True, (6, 3, 2, 1))])
 def test_transport_blocks_cut_in_x_and_y(wp, periodic, shape):
+    total_moved, scaled_first = blocks_cut_in_x_and_y(wp, periodic, shape)
+    assert scaled_first > 100                                 # (the first step thins every cell)
+    assert total_moved > 2000
+
+
+def blocks_cut_in_x_and_y(wp, periodic, shape, nz=3, n_class=2, n_spec=2, n_part=400, seed=17, prob=0.08,
+                          ideal=0.45, n_steps=3):
     """The transport exchange with both cut directions (the reference decomposes in x and y,
     wrf_pmc_trans_aero.F90:148-273): the domain as 2 x 2 blocks, each with a ghost row and a ghost
     column on every side, movers exported / imported through the four sides (what RCCL would carry
@@ -1389,22 +1396,22 @@ def test_transport_blocks_cut_in_x_and_y(wp, periodic, shape):
     doubly periodic; otherwise open lateral boundaries (boundary cells send inwards only, what
     reaches them leaves)."""
     nx, ny, bx, by = shape                            # (also blocks of a single column, and one row of blocks)
-    nz, n_class, n_spec, cap, n_part = 3, 2, 2, 1024, 400
+    cap = (int(2.56 * n_part) + 63) // 64 * 64
     rx, ry = nx // bx, ny // by                      # real columns / rows per block
     n = nx * nz * ny
-    rng = np.random.RandomState(17)
+    rng = np.random.RandomState(seed)
     names, dens = parity.default_species(n_spec)
     modes, _ = parity.make_modes(n_spec, n_class)
     for m in modes:
         m["source"] = m["source"] % 2
     mag = rng.uniform(0.5e7, 2e7, (n, n_class))
     cv = rng.uniform(0.8e9, 1.3e9, n)
-    ph = rng.uniform(0, 0.08, (n, n_class, 4)); pv = rng.uniform(0, 0.04, (n, n_class, nz))
+    ph = rng.uniform(0, prob, (n, n_class, 4)); pv = rng.uniform(0, prob / 2, (n, n_class, nz))
     kc = parity.N_COMP_MAX
     whole = wp.CellBlock(n, cap, n_spec, n_class=n_class, n_source=2, n_comp_max=kc)
     whole.set_aero_data(dens); whole.set_env(280.0, 9e4); whole.set_weights(mag)
     whole.set_next_id((np.arange(n, dtype=np.int64) << 32) + (1 << 20))
-    whole.set_n_part_ideal(np.full((n, n_class), 0.45 * n_part / n_class))
+    whole.set_n_part_ideal(np.full((n, n_class), ideal * n_part / n_class))
     whole.generate_lognormal(n_part, modes, seed=3)
     if not periodic:
         whole.set_transport_lateral(True)
@@ -1426,7 +1433,7 @@ def test_transport_blocks_cut_in_x_and_y(wp, periodic, shape):
                 blk.set_transport_lateral(True, gj0, ny)
             blk.set_aero_data(dens); blk.set_env(280.0, 9e4)
             blk.set_weights(mag[gmap])                              # ghosts: the neighbours' weights
-            blk.set_n_part_ideal(np.full((nloc, n_class), 0.45 * n_part / n_class))
+            blk.set_n_part_ideal(np.full((nloc, n_class), ideal * n_part / n_class))
             blk.set_next_id((gmap.astype(np.int64) << 32) + (1 << 20))
             counts = np.where(real, np.diff(dn["part_offset"])[gmap], 0)
             po = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
@@ -1438,8 +1445,8 @@ def test_transport_blocks_cut_in_x_and_y(wp, periodic, shape):
                 blk.upload_components(0, po, cm["comp_len"][sel], cm["comp_source"][sel], cm["comp_time"][sel])
             blocks.append(dict(blk=blk, gmap=gmap, real=real, a=a, b=b, nxl=nxl, nyl=nyl))
     at = lambda a, b: blocks[(b % by) * bx + (a % bx)]
-    total_moved = 0
-    for step in range(3):
+    total_moved = scaled_first = 0
+    for step in range(n_steps):
         # trans_aero_preweight first (wrf_pmc_trans_aero.F90:294): the terms of the cut rows AND columns
         # travel as ready values; sums and thinning are the whole domain's
         ex_w, nr_w = whole.transport_preweight(nx, nz, ny, ph, pv, cv, 9, step, periodic, periodic)
@@ -1460,7 +1467,8 @@ def test_transport_blocks_cut_in_x_and_y(wp, periodic, shape):
             assert np.array_equal(ex[real], ex_w[gmap[real]]), (step, np.abs(ex[real] - ex_w[gmap[real]]).max())
             assert np.array_equal(nr[real], nr_w[gmap[real]]), step
             scaled += int(nr[real].sum())
-        assert step > 0 or scaled > 100                       # (the first step thins every cell)
+        if step == 0:
+            scaled_first = scaled
         mag_now = whole.get_weights()
         for B in blocks:                                      # ghosts: the neighbours' new weights
             assert np.array_equal(B["blk"].get_weights()[B["real"]], mag_now[B["gmap"][B["real"]]])
@@ -1496,10 +1504,12 @@ def test_transport_blocks_cut_in_x_and_y(wp, periodic, shape):
                     assert np.array_equal(got_c[k], ref_c[k][sel]), (step, k)
             assert np.array_equal(blk.get_next_id()[gl], whole.get_next_id()[gmap[gl]])
         total_moved += int(nm_w.sum())
-    assert total_moved > 2000
+        st_w = int(np.bitwise_or.reduce(whole.coag_counters()[2]))
+        assert st_w == 0, f"a cell of the whole domain is full (status {st_w:#x}): nothing to compare"
     whole.close()
     for B in blocks:
         B["blk"].close()
+    return total_moved, scaled_first
 
 
 def test_transport_conserves_with_equal_weights(wp):

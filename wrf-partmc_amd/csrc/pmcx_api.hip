@@ -1946,6 +1946,10 @@ int pmcx_transport_import(pmcx_ctx *ctx, int32_t side, const void *dev_buf, int6
     if (!ctx || !ctx->halo_nx || side < 0 || side >= halo_sides(ctx))
         return fail(ctx, PMCX_EINVAL, "pmcx_transport_import: bad argument or no pmcx_transport_begin");
     if (!dev_buf || n_bytes == 0) return PMCX_OK; // no neighbour on that side: the ghost strip stays empty
+    if (side >= 2 && ctx->st.trans_gnx == 2)
+        return fail(ctx, PMCX_EINVAL, "pmcx_transport_import: a periodic direction two cells wide cannot be cut (both "
+                                      "neighbours of a cell are one cell, whose movers the whole domain takes as one "
+                                      "sequence): use pmcx_transport on the whole domain");
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     const HaloSide h = halo_side(ctx, side);
     const int L = ctx->halo_row_cells, row = h.ghost.n;

@@ -76,16 +76,24 @@ def grid_neighbours(rank, grid, periodic_x, periodic_y):
             at(a - 1, b) if (periodic_x or a > 0) else None, at(a + 1, b) if (periodic_x or a < px - 1) else None)
 
 
-def swap_sides(dist, out, nbr):
+def swap_sides(dist, out, nbr, extent=None):
     """The four-neighbour exchange of a domain cut in x and y.  out[side]: what goes to the neighbour
     on that side (0 below, 1 above, 2 west, 3 east; torch tensors of one dtype and device); nbr: the
     neighbours' ranks (grid_neighbours).  Returns what arrives FROM each side (None: no neighbour
-    there).  Four phases: everybody sends one way and receives from the opposite side."""
+    there).  Four phases: everybody sends one way and receives from the opposite side.
+    extent = (real columns, real rows of this block, grid, periodic_x, periodic_y): also checks that a
+    periodic direction of the whole domain is not two cells wide (check_periodic_extent)."""
     import torch
     world = dist.get_world_size()
-    sizes = torch.tensor([t.numel() for t in out], dtype=torch.int64, device=out[0].device)
+    sizes = torch.tensor([t.numel() for t in out] + (list(extent[:2]) if extent else []), dtype=torch.int64,
+                         device=out[0].device)
     all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
     dist.all_gather(all_sizes, sizes)
+    if extent:
+        (px, py), rank = extent[2], dist.get_rank()
+        a, b = rank % px, rank // px
+        check_periodic_extent(sum(int(all_sizes[b * px + a_][4]) for a_ in range(px)), extent[3], "x")
+        check_periodic_extent(sum(int(all_sizes[b_ * px + a][5]) for b_ in range(py)), extent[4], "y")
     got = [None] * 4
     for side in range(4):
         to, frm = nbr[side], nbr[side ^ 1]          # send towards `side`, receive from the opposite one
@@ -106,6 +114,16 @@ def swap_sides(dist, out, nbr):
         if rbuf is not None:
             got[side ^ 1] = rbuf
     return got
+
+
+def check_periodic_extent(n, periodic, name):
+    """A periodic direction of a cut domain is at least three cells wide: with two, both neighbours
+    of a cell are ONE cell, whose movers pmcx_transport takes as one sequence while the exchange
+    delivers them as two (from below and from above) -- the arrival order, and with it the
+    particles' slots, would differ from the whole domain's."""
+    if periodic and n == 2:
+        raise PmcxError(f"a periodic direction two cells wide cannot be cut (the domain's {name} extent is 2): "
+                        "use pmcx_transport on the whole domain")
 
 
 def dist_rows_before(dist, my_rows):
@@ -731,9 +749,10 @@ class CellBlock:
                 self._ck(self._lib.pmcx_device_copy(self._h, C.c_void_p(t.data_ptr()), bf.ptr, bf.nbytes,
                                                     2 if on_host else 0))
             out.append(t)
-        sizes = torch.tensor([out[0].numel(), out[1].numel()], dtype=torch.int64, device=dev)
+        sizes = torch.tensor([out[0].numel(), out[1].numel(), ny - 2], dtype=torch.int64, device=dev)
         all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
         dist.all_gather(all_sizes, sizes)
+        check_periodic_extent(sum(int(x[2]) for x in all_sizes), periodic_y, "y")
         got = [None, None]                                               # from below, from above
         # phase 0: everybody sends down and receives from above; phase 1: the other way round
         for phase, (to, frm, slot) in enumerate(((below, above, 1), (above, below, 0))):
@@ -786,7 +805,7 @@ class CellBlock:
                 self._ck(self._lib.pmcx_device_copy(self._h, C.c_void_p(t.data_ptr()), bf.ptr, bf.nbytes,
                                                     2 if on_host else 0))
             out.append(t)
-        got = swap_sides(dist, out, nbr)
+        got = swap_sides(dist, out, nbr, extent=(nx - 2, ny - 2, grid, periodic_x, periodic_y))
         for side in range(4):
             rbuf = got[side]
             if rbuf is None:
