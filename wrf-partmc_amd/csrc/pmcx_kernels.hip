@@ -2667,6 +2667,187 @@ __device__ void compact_wave(const DeviceState &st, int c, int lane, uint32_t *c
     }
 }
 
+// The same compaction by a whole workgroup of GW wavefronts (256 threads) on ONE cell: a trip is
+// GW x GU chunks of 64 slots, chunk q = u GW + wave of it belonging to `wave`, the running base
+// handed round through LDS.  One wavefront's compaction of a 10 000-slot cell is 39 dependent
+// trips; when a few cells of a block need one (a cell thinned by the preweight, one that makes
+// room for arrivals), those chains are the kernel's whole duration -- here they are a quarter as
+// long.  Same slot map, same result.  s_cnt: GW * GU + 2 ints of LDS.  Every thread of the
+// workgroup calls it with the same c (barriers inside).
+constexpr int GW = 4, GU = 2;
+constexpr int COMPACT_GROUP_MAX = 4096; // listed cells up to which k_compact takes a workgroup per cell
+__device__ void compact_group(const DeviceState &st, int c, int tid, uint32_t *cbase, uint64_t *cmask,
+                              bool map_always, int *s_cnt)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const int64_t cb = (int64_t)c * st.cap;
+    const int S = st.n_spec, NS = st.n_source;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    if (wave == 0) apply_event_log(st, c, lane);
+    __syncthreads();
+    const int n_hi = st.n_hi[c];
+    const bool lists = st.sort_valid[c] != 0;
+    const bool remap = lists || map_always;
+    int base = 0;
+    constexpr int T = 64 * GW * GU; // slots per trip
+    double xn[GU];
+#pragma unroll
+    for (int u = 0; u < GU; u++) {
+        const int i = (u * GW + wave) * 64 + lane;
+        xn[u] = i < n_hi ? ld_f64(&st.hot[cb + i].vtot) : -1.0;
+    }
+    for (int i0 = 0; i0 < n_hi; i0 += T) {
+        double x[GU];
+        int dst[GU], cnt[GU];
+        bool mv[GU];
+        uint64_t m[GU];
+#pragma unroll
+        for (int u = 0; u < GU; u++) x[u] = xn[u];
+#pragma unroll
+        for (int u = 0; u < GU; u++) { // (the next trip's liveness: on its way while this trip moves)
+            const int i = i0 + T + (u * GW + wave) * 64 + lane;
+            xn[u] = i < n_hi ? ld_f64(&st.hot[cb + i].vtot) : -1.0;
+        }
+#pragma unroll
+        for (int u = 0; u < GU; u++) {
+            m[u] = __ballot(x[u] >= 0.0); // tombstones carry a negative cached volume
+            cnt[u] = __popcll(m[u]);
+            if (lane == 0) s_cnt[u * GW + wave] = cnt[u];
+        }
+        __syncthreads();
+        int before[GU] = {}, total = 0;
+#pragma unroll
+        for (int q = 0; q < GW * GU; q++) {
+            const int v = s_cnt[q];
+#pragma unroll
+            for (int u = 0; u < GU; u++)
+                if (q == u * GW + wave) before[u] = total;
+            total += v;
+        }
+#pragma unroll
+        for (int u = 0; u < GU; u++) {
+            const int q = u * GW + wave, i = i0 + q * 64 + lane;
+            dst[u] = base + before[u] + __popcll(m[u] & lt);
+            mv[u] = x[u] >= 0.0 && dst[u] != i;
+            if (remap && lane == 0 && i0 + q * 64 < n_hi) {
+                cbase[(i0 >> 6) + q] = (uint32_t)(base + before[u]);
+                cmask[(i0 >> 6) + q] = m[u];
+            }
+        }
+        // nothing can move while no slot up to the end of this trip is dead (known to every
+        // wavefront alike: no word passes between them for it)
+        const bool dense = base == i0 && total == (n_hi - i0 < T ? n_hi - i0 : T);
+        base += total;
+        if (dense) {
+            __syncthreads(); // (s_cnt is rewritten by the next trip)
+            continue;
+        }
+        double a1[GU], a2[GU], a3[GU];
+        int64_t idv[GU];
+        int32_t wc[GU];
+        uint16_t kk[GU];
+        uint32_t xo[4][GU];
+        const int NS4 = NS < 4 ? NS : 4;
+#pragma unroll
+        for (int u = 0; u < GU; u++) {
+            const int i = i0 + (u * GW + wave) * 64 + lane;
+            a1[u] = a2[u] = a3[u] = 0; idv[u] = 0; wc[u] = 0; kk[u] = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) xo[q][u] = 0u;
+            if (mv[u]) {
+                kk[u] = st.gkey[cb + i];
+                a1[u] = ld_f64(&st.hot[cb + i].mass);
+                a2[u] = ld_f64(&st.hot[cb + i].lct); a3[u] = ld_f64(&st.hot[cb + i].gct);
+                idv[u] = (int64_t)d2u(ld_f64((const double *)&st.cold[cb + i].id));
+                wc[u] = (int32_t)ld_u32((const uint32_t *)&st.wclass[cb + i]);
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (q < NS4) xo[q][u] = ld_u32((const uint32_t *)&norig(st, cb, q, i));
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads(); // every wavefront holds its movers: their slots may be written
+#pragma unroll
+        for (int u = 0; u < GU; u++)
+            if (mv[u]) {
+                const int d = dst[u];
+                st_f64(&st.hot[cb + d].vtot, x[u]); st_f64(&st.hot[cb + d].mass, a1[u]);
+                st_f64(&st.hot[cb + d].lct, a2[u]); st_f64(&st.hot[cb + d].gct, a3[u]);
+                st_f64((double *)&st.cold[cb + d].id, u2d((uint64_t)idv[u]));
+                st_u32((uint32_t *)&st.wclass[cb + d], (uint32_t)wc[u]);
+                st.gkey[cb + d] = kk[u];
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (q < NS4) st_u32((uint32_t *)&norig(st, cb, q, d), xo[q][u]);
+            }
+        if (S > 1)
+            for (int s0 = 0; s0 < S; s0 += 4) {
+                double v[GU][4];
+#pragma unroll
+                for (int u = 0; u < GU; u++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        v[u][k] = (mv[u] && s0 + k < S)
+                                      ? ld_f64(&st.vol[(cb + i0 + (u * GW + wave) * 64 + lane) * S + (s0 + k)]) : 0.0;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < GU; u++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (mv[u] && s0 + k < S) st_f64(&st.vol[(cb + dst[u]) * S + (s0 + k)], v[u][k]);
+            }
+        for (int sq = 4; sq < NS; sq++) { // (sources beyond the fourth: one at a time)
+            uint32_t xs[GU];
+#pragma unroll
+            for (int u = 0; u < GU; u++)
+                xs[u] = mv[u] ? ld_u32((const uint32_t *)&norig(st, cb, sq, i0 + (u * GW + wave) * 64 + lane)) : 0u;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < GU; u++)
+                if (mv[u]) st_u32((uint32_t *)&norig(st, cb, sq, dst[u]), xs[u]);
+        }
+        if (st.n_comp_max) { // the component lists: the source word, then one create time at a time
+            const int K = st.n_comp_max;
+            for (int k = -1; k < K; k++) {
+                double xc[GU];
+#pragma unroll
+                for (int u = 0; u < GU; u++) {
+                    const int64_t at = cb + i0 + (u * GW + wave) * 64 + lane;
+                    xc[u] = !mv[u] ? 0.0 : k < 0 ? ld_f64((const double *)&st.comp_src[at])
+                                                  : ld_f64(&st.comp_time[at * K + k]);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < GU; u++)
+                    if (mv[u]) {
+                        if (k < 0) st_f64((double *)&st.comp_src[cb + dst[u]], xc[u]);
+                        else st_f64(&st.comp_time[(cb + dst[u]) * K + k], xc[u]);
+                    }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) st.n_hi[c] = base;
+    if (lists && base != n_hi) {
+        uint16_t *perm = st.perm + (int64_t)c * st.pcap;
+        const int G = st.n_bin * st.n_class;
+        const int used = st.goff[(int64_t)c * (G + 1) + G];
+        for (int j = tid; j < used; j += 64 * GW) {
+            const uint32_t e = perm[j];
+            if (e < (uint32_t)n_hi) {
+                const uint32_t k = e >> 6;
+                perm[j] = (uint16_t)(cbase[k] + (uint32_t)__popcll(cmask[k] & ((1ull << (e & 63)) - 1ull)));
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 // compacts the cells whose dead fraction exceeds num/den (num = 0: any dead slot)
 __global__ __launch_bounds__(256) void k_compact(DeviceState st, const int32_t *list,
                                                  const int32_t *count)
@@ -2678,6 +2859,16 @@ __global__ __launch_bounds__(256) void k_compact(DeviceState st, const int32_t *
     uint32_t *cbase = (uint32_t *)((uint64_t *)smem + (size_t)(blockDim.x >> 6) * n_chunk) +
                       (size_t)wave * n_chunk;
     const int n_work = *count, stride = gridDim.x * (blockDim.x >> 6);
+    // a few cells: a workgroup each (the duration is one cell's chain of trips, a quarter as long
+    // that way); many: a wavefront each (the same work with no barriers)
+    if (n_work <= COMPACT_GROUP_MAX) {
+        uint64_t *cmask0 = (uint64_t *)smem;
+        uint32_t *cbase0 = (uint32_t *)(cmask0 + (size_t)GW * n_chunk);
+        int *s_cnt = (int *)(cbase0 + (size_t)GW * n_chunk);
+        for (int w = blockIdx.x; w < n_work; w += gridDim.x)
+            compact_group(st, list[w], threadIdx.x, cbase0, cmask0, false, s_cnt);
+        return;
+    }
     for (int w = blockIdx.x * (blockDim.x >> 6) + wave; w < n_work; w += stride) {
         compact_wave(st, list[w], lane, cbase, cmask);
         wave_sync();
@@ -2782,7 +2973,7 @@ __global__ __launch_bounds__(64) void k_rebalance(DeviceState st, int allow_doub
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __threadfence_block();
                 wave_sync();
-                if (((int)nd + n_hi - n_live) * st.compact_den > n_hi) compact_wave(st, c, lane);
+                // (past the tombstone threshold: the k_compact that follows)
             } else {
                 break;
             }
@@ -4295,8 +4486,7 @@ __global__ __launch_bounds__(64) void k_preweight_scale(DeviceState st, Preweigh
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __threadfence_block();
         wave_sync();
-        removed += nd;
-        if (((int)nd + n_hi - n_live) * st.compact_den > n_hi) compact_wave(st, c, lane);
+        removed += nd; // (past the tombstone threshold: the k_compact that follows)
     }
     if (lane == 0 && a.n_removed) a.n_removed[c] = (int32_t)removed;
 }
@@ -4307,23 +4497,37 @@ __global__ __launch_bounds__(64) void k_preweight_scale(DeviceState st, Preweigh
 __global__ __launch_bounds__(256) void k_trans_room(DeviceState st, TransGrid tg)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    // four cells to a workgroup; the few that need room are compacted by the whole workgroup, one
+    // after the other (compact_group: the chain of trips is the kernel's duration)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * (blockDim.x >> 6) + wave;
-    if (c >= st.n_cells) return;
-    const int n_hi = st.n_hi[c], dead = n_hi - st.n_part[c];
-    if (dead <= 0 || n_hi + tg.n_exp[c] <= st.cap) return;
     const int n_chunk = (st.cap + 63) / 64 + 1;
-    uint64_t *cmask = (uint64_t *)smem + (size_t)wave * n_chunk;
-    uint32_t *cbase = (uint32_t *)((uint64_t *)smem + (size_t)(blockDim.x >> 6) * n_chunk) +
-                      (size_t)wave * n_chunk;
-    compact_wave(st, c, lane, cbase, cmask, true);
-    int2 *box = tg.outbox + (int64_t)c * st.cap;
-    const int n_out = tg.n_out[c];
-    for (int e = lane; e < n_out; e += 64) {
-        const int2 en = box[e];
-        const uint32_t sl = (uint32_t)en.x & 0xFFFFu, k = sl >> 6;
-        const uint32_t nw = cbase[k] + (uint32_t)__popcll(cmask[k] & ((1ull << (sl & 63)) - 1ull));
-        box[e] = make_int2((int)((uint32_t)en.x & 0xFFFF0000u) | (int)nw, en.y);
+    uint64_t *cmask = (uint64_t *)smem;
+    uint32_t *cbase = (uint32_t *)(cmask + (size_t)GW * n_chunk);
+    int *s_cnt = (int *)(cbase + (size_t)GW * n_chunk);
+    int *s_need = s_cnt + GW * GU + 2;
+    {
+        const int c = blockIdx.x * GW + wave;
+        bool need = false;
+        if (c < st.n_cells) {
+            const int n_hi = st.n_hi[c], dead = n_hi - st.n_part[c];
+            need = dead > 0 && n_hi + tg.n_exp[c] > st.cap;
+        }
+        if (lane == 0) s_need[wave] = need;
+    }
+    __syncthreads();
+    for (int w = 0; w < GW; w++) {
+        if (!s_need[w]) continue; // (the same for every thread)
+        const int c = blockIdx.x * GW + w;
+        compact_group(st, c, threadIdx.x, cbase, cmask, true, s_cnt);
+        int2 *box = tg.outbox + (int64_t)c * st.cap;
+        const int n_out = tg.n_out[c];
+        for (int e = threadIdx.x; e < n_out; e += 64 * GW) {
+            const int2 en = box[e];
+            const uint32_t sl = (uint32_t)en.x & 0xFFFFu, k = sl >> 6;
+            const uint32_t nw = cbase[k] + (uint32_t)__popcll(cmask[k] & ((1ull << (sl & 63)) - 1ull));
+            box[e] = make_int2((int)((uint32_t)en.x & 0xFFFF0000u) | (int)nw, en.y);
+        }
+        __syncthreads(); // (the slot map is rewritten by the next cell)
     }
 }
 
@@ -4514,8 +4718,8 @@ __global__ __launch_bounds__(64) void k_trans_remove(DeviceState st, TransGrid t
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __threadfence_block();
     wave_sync();
-    const int n_hi = st.n_hi[c];
-    if ((n_hi - n_live) * st.compact_den > n_hi) compact_wave(st, c, lane);
+    // (a cell past its tombstone threshold is compacted by the k_compact that follows: a workgroup
+    // per such cell, not this cell's one wavefront)
 }
 
 // ------------------------------------------------------- transport across ranks
@@ -4944,7 +5148,7 @@ int sampler_lanes(const DeviceState &st, int ktype)
 }
 size_t compact_lds_bytes(const DeviceState &st)
 {
-    return (size_t)4 * ((size_t)(st.cap + 63) / 64 + 1) * (sizeof(uint64_t) + sizeof(uint32_t));
+    return (size_t)4 * ((size_t)(st.cap + 63) / 64 + 1) * (sizeof(uint64_t) + sizeof(uint32_t)) + 64;
 }
 
 size_t diagnostics_lds_bytes(const DeviceState &st)
@@ -5202,11 +5406,12 @@ hipError_t launch_rebalance(const DeviceState &st, int allow_doubling, int allow
         hipLaunchKernelGGL(k_rebalance, dim3(st.n_cells < 32768 ? st.n_cells : 32768), dim3(64), 0, s,
                            st, allow_doubling, allow_halving, seed, step,
                            (const int32_t *)(st.work_list + 1), (const int32_t *)st.work_list);
-        return hipGetLastError();
+    } else {
+        hipLaunchKernelGGL(k_rebalance, dim3(st.n_cells), dim3(64), 0, s, st, allow_doubling,
+                           allow_halving, seed, step, (const int32_t *)nullptr, (const int32_t *)nullptr);
     }
-    hipLaunchKernelGGL(k_rebalance, dim3(st.n_cells), dim3(64), 0, s, st, allow_doubling,
-                       allow_halving, seed, step, (const int32_t *)nullptr, (const int32_t *)nullptr);
-    return hipGetLastError();
+    // the cells a halving left more than 1/compact_den dead
+    return allow_halving ? launch_compact(st, 0, st.n_cells, 1, st.compact_den, s) : hipGetLastError();
 }
 hipError_t launch_diagnostics(const DeviceState &st, double *tot_num, double *tot_mass,
                               double *num_dist, double *mass_dist, hipStream_t s)
@@ -5303,6 +5508,7 @@ hipError_t launch_transport_finish(const DeviceState &st, int nx, int nz, int ny
     hipLaunchKernelGGL(k_trans_room, dim3((st.n_cells + 3) / 4), dim3(256), compact_lds_bytes(st), s, st, tg);
     hipLaunchKernelGGL(k_trans_gather, dim3(n_do), dim3(64), 0, s, st, tg);
     hipLaunchKernelGGL(k_trans_remove, dim3(n_do), dim3(64), 0, s, st, tg);
+    launch_compact(st, c_first, n_do, 1, st.compact_den, s); // the cells the movers left more than 1/compact_den dead
     if (n_rows != ny) { // a slab: rows 0 and ny - 1 are ghosts
         const Strip a{0, 1, nx * nz}, b{(ny - 1) * nx * nz, 1, nx * nz};
         hipLaunchKernelGGL(k_halo_clear, dim3((a.n + b.n + 255) / 256), dim3(256), 0, s, st, tg, a, b);
@@ -5374,7 +5580,7 @@ hipError_t launch_preweight_slab_finish(const DeviceState &st, int nx, int nz, i
     const int64_t n = (int64_t)st.n_cells * st.n_class;
     hipLaunchKernelGGL(k_preweight_new, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, a);
     hipLaunchKernelGGL(k_preweight_scale, dim3(st.n_cells), dim3(64), 0, s, st, a, seed, step);
-    return hipGetLastError();
+    return launch_compact(st, 0, st.n_cells, 1, st.compact_den, s); // the cells thinned past 1/compact_den dead
 }
 hipError_t launch_transport_preweight(const DeviceState &st, int nx, int nz, int ny, int ideal,
                                       const double *prob_h, const double *prob_v,
@@ -5388,7 +5594,7 @@ hipError_t launch_transport_preweight(const DeviceState &st, int nx, int nz, int
     const int64_t n = (int64_t)st.n_cells * st.n_class;
     hipLaunchKernelGGL(k_preweight_new, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, a);
     hipLaunchKernelGGL(k_preweight_scale, dim3(st.n_cells), dim3(64), 0, s, st, a, seed, step);
-    return hipGetLastError();
+    return launch_compact(st, 0, st.n_cells, 1, st.compact_den, s); // the cells thinned past 1/compact_den dead
 }
 size_t trans_probs_lds_bytes(const DeviceState &st, int nz)
 {
