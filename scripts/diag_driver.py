@@ -16,7 +16,7 @@ for n_steps in range(1, kw["n_steps"] + 1):
         v_edge, v_samp = blk.bin_tables()
         const_k, beta = blk.cfg.const_k, blk.cfg.additive_beta
         max_events, max_appends = blk.cfg.max_events, blk.cfg.max_appends
-    cap = max(64, int(2.5 * case.num_particles), case.n_part, 2 * int(np.ceil(case.n_ideal.sum(1).max())))
+    cap = max(64, int(3.0 * case.num_particles), case.n_part, int(np.ceil(3.0 * case.n_ideal.sum(1).max())))
     cap = (cap + 63) // 64 * 64
     cells = case.make_cells(oracle, v_edge, cap, max_events, max_appends)
     with tempfile.TemporaryDirectory() as d:

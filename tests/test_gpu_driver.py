@@ -37,9 +37,9 @@ def run_case(case, tmp_path, wp, oracle):
         v_edge, v_samp = blk.bin_tables()
         const_k, beta = blk.cfg.const_k, blk.cfg.additive_beta
         max_events, max_appends = blk.cfg.max_events, blk.cfg.max_appends
-    # the shim's capacity rule (pmcx_upload_states): twice the ideal count, its caller's 2.5 x
+    # the shim's capacity rule (pmcx_upload_states): the headroom (3) times the ideal count, its caller's 3 x
     # num_particles, rounded up to 64
-    cap = max(64, int(2.5 * case.num_particles), case.n_part, 2 * int(np.ceil(case.n_ideal.sum(1).max())))
+    cap = max(64, int(3.0 * case.num_particles), case.n_part, int(np.ceil(3.0 * case.n_ideal.sum(1).max())))
     cap = (cap + 63) // 64 * 64
     cells = case.make_cells(oracle, v_edge, cap, max_events, max_appends)
     fstate, ffields, fout = tmp_path / "state.bin", tmp_path / "fields.bin", tmp_path / "out.bin"

@@ -50,7 +50,7 @@ module pmcx_shim
   ! brings aero_states / gas_states up to date when the Fortran side needs them (output, restart)
   public :: partmc_timestep_pmcx, wrf_pmc_trans_driver_pmcx, partmc_sync_host_pmcx, &
        partmc_process_pmcx, pmcx_shim_is_resident
-  public :: pmcx_shim_set_components
+  public :: pmcx_shim_set_components, pmcx_shim_set_headroom
   public :: pmcx_shim_init, pmcx_shim_finalize, pmcx_set_rng, mc_coag_pmcx, &
        partmc_coag_cells_pmcx, aero_state_rebalance_cells_pmcx, aero_state_rebalance_pmcx, &
        pmcx_config
@@ -72,6 +72,7 @@ module pmcx_shim
   type(pmcx_config), save :: cfg
   logical, save :: have_ctx = .false.
   integer, save :: want_comp_max = 8           ! entries of component(:) carried per particle
+  real(kind=dp), save :: headroom = 3.0d0      ! particle slots of a cell / its ideal count (pmcx_shim_set_headroom)
   ! per-step staging arrays in page-locked memory (pmcx_host_alloc): an upload from them is one
   ! DMA that overlaps the device's work; they grow as needed and live until pmcx_shim_finalize
   integer, parameter :: N_PIN = 24
@@ -141,6 +142,18 @@ contains
     integer, intent(in) :: n
     want_comp_max = max(0, min(8, n))
   end subroutine pmcx_shim_set_components
+
+  !> Particle slots per cell as a multiple of the ideal count (default 3).  The
+  !> reference's particle arrays grow; a cell here has its slots for the whole run: the rebalance
+  !> keeps a class below twice its ideal count at the END of a step, inside a step (arrivals
+  !> before the rebalance, 1/ratio copies per arrival, a boundary refill) it can be above.  A run
+  !> that stops with "a cell ran out of particle slots" wants a larger factor; it costs memory only
+  !> (about 100 bytes a slot with one species; a domain that fills the card wants a smaller one).
+  !> Takes effect at the next upload that builds a context.
+  subroutine pmcx_shim_set_headroom(factor)
+    real(kind=dp), intent(in) :: factor
+    headroom = max(1.0d0, factor)
+  end subroutine pmcx_shim_set_headroom
 
   subroutine pmcx_shim_init(n_cells, cap, aero_data, n_class, n_source, device)
     integer, intent(in) :: n_cells, cap, n_class, n_source, device
@@ -242,7 +255,7 @@ contains
     do c = 1, n_cells
        cap_needed = max(cap_needed, aero_states(c)%apa%n_part)
        if (allocated(aero_states(c)%n_part_ideal)) then
-          cap_needed = max(cap_needed, 2 * ceiling(sum(aero_states(c)%n_part_ideal(1, :))))
+          cap_needed = max(cap_needed, ceiling(headroom * sum(aero_states(c)%n_part_ideal(1, :))))
        else
           have_ideal = .false.
        end if
@@ -257,8 +270,8 @@ contains
     end block
     cap_needed = ((cap_needed + 63) / 64) * 64
     if (cap_needed > cap_max) then
-       write(0,'(a,i0,a,i0,a)') 'pmcx_shim: a cell needs ', cap_needed, ' particle slots (its particles, or twice &
-            &its n_part_ideal); the device holds at most ', cap_max, ' per cell (16-bit list entries)'
+       write(0,'(a,i0,a,i0,a)') 'pmcx_shim: a cell needs ', cap_needed, ' particle slots (its particles, or the &
+            &headroom times its n_part_ideal); the device holds at most ', cap_max, ' per cell (16-bit list entries)'
        call pmcx_die(1, 'pmcx_upload_states')
     end if
     if (.not. have_ctx .or. cfg%n_cells /= n_cells .or. cfg%cap < cap_needed &
@@ -1121,11 +1134,11 @@ contains
     end do
 
     if (.not. resident) then
-       ! room for a rebalance's doubling and a step's arrivals: twice the ideal count (the
-       ! reference's num_particles) and then some
+       ! room for a rebalance's doubling and a step's arrivals: the headroom (default 3) times the
+       ! ideal count (the reference's num_particles); pmcx_shim_set_headroom
        call upload_domain(config_flags, scenario, env_states, aero_data, aero_states, gas_data, &
             gas_states, nx, nz, ny, pmc_is, pmc_js, global_nx, global_ny, &
-            int(2.5 * grid%num_particles))
+            int(headroom * grid%num_particles))
        resident = .true.
        res_nx = nx; res_nz = nz; res_ny = ny
     else if (nx /= res_nx .or. nz /= res_nz .or. ny /= res_ny) then
@@ -1488,7 +1501,7 @@ contains
       allocate(ns(n_cells), nc(n_cells), st(n_cells))
       call pmcx_die(pmcx_get_coag_counters(ctx, ns, nc, st), 'pmcx_get_coag_counters')
       if (any(iand(st, 16) /= 0)) call pmcx_die(5, 'wrf_pmc_trans_driver_pmcx (a cell ran out of particle slots ' &
-           // trim(where) // ': raise cap_min of pmcx_upload_states)')
+           // trim(where) // ': pmcx_shim_set_headroom)')
       deallocate(ns, nc, st)
     end subroutine check_transport_status
 
