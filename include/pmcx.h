@@ -140,6 +140,25 @@ int pmcx_get_weights(pmcx_ctx *ctx, double *magnitude);
 /* aero_state_set_n_part_ideal (wrf_pmc_init.F90:254): [n_cells][n_class] */
 int pmcx_set_n_part_ideal(pmcx_ctx *ctx, const double *n_ideal);
 
+/* The allow_doubling / allow_halving the reference hands to every add of particles from a
+ * distribution -- scenario_update_aero_state (wrf_pmc_driver.F90:207-210), the sea-salt source
+ * (:1920-1922), the refill of an emptied boundary cell (wrf_pmc_trans_aero.F90:1030-1032).
+ * on != 0: before a mode's Poisson sample the class's weight is prepared for the add
+ * (aero_state_prepare_weight_for_add, [UPSTREAM-UNCITED]): with n the class's particles and
+ * n_add the sample's mean at the present weight, n + n_add outside [n_ideal / 2, 2 n_ideal]
+ * scales the weight by ratio = (n + n_add) / n_ideal (aero_state_scale_weight: ratio > 1 and
+ * allow_halving, or an empty class -- exactly prob_round(n (1 - 1 / ratio)) particles leave, a
+ * uniformly random subset; ratio < 1 and allow_doubling, or an empty class -- every particle
+ * gets prob_round(1 / ratio) - 1 copies under new ids, appended in rank order), and the sample is
+ * drawn at the new weight: the class comes to n_ideal, the number concentration stays what it
+ * was in expectation.  It is what keeps a boundary cell that was a copy of a much-doubled
+ * neighbour from being refilled with thousands of particles at that neighbour's weight.
+ * on == 0 (the default): plain Poisson samples at the present weight.  Applies to
+ * pmcx_scenario_update_aero_state, pmcx_seasalt_emissions, pmcx_boundary_resample (throw_away
+ * branch; the other branch is in-tree code without it, :1035-1095) and pmcx_timestep.
+ * PMCX_ESTATE without pmcx_set_n_part_ideal. */
+int pmcx_set_weight_preparation(pmcx_ctx *ctx, int32_t on, int32_t allow_doubling, int32_t allow_halving);
+
 /* next_id counters (module variable next_id, wrf_pmc_driver.F90:1652): [n_cells] */
 int pmcx_set_next_id(pmcx_ctx *ctx, const int64_t *next_id);
 int pmcx_get_next_id(pmcx_ctx *ctx, int64_t *next_id);

@@ -856,6 +856,82 @@ void pmco_condense(pmco_cell *c, const double *kappa, int i_water, double rel_hu
  *   background : per mode, Poisson((1 - exp(-rate dt)) N_bg / magnitude) new particles
  * New particles are appended in order; ids come from next_id.
  * ---------------------------------------------------------------------- */
+/* aero_state_scale_weight(weight_ratio) of one class [upstream, uncited].
+ *   ratio > 1 (and allow_halving, or the class is empty): prob_round(n (1 - 1 / ratio)) of the
+ *     class's n particles leave, a uniformly random subset -- the count from one uniform (key
+ *     0xFFFFFFFF), the subset by selection sampling in rank order: member t of n goes when
+ *     u (n - t) < still to go;
+ *   ratio < 1 (and allow_doubling, or the class is empty): every particle of the class stands for
+ *     prob_round(1 / ratio) >= 1 particles -- its copies, under new ids, are appended in rank order;
+ *   then the magnitude is multiplied by ratio.  The uniform of a particle is keyed by its rank
+ *   among the cell's particles; bkey separates the callers (the transport's preweight: the
+ *   class; an add: PMCO_SCALE_ADD | kind << 16 | mode << 8 | class).
+ * Returns the number removed (ratio > 1) or added (ratio < 1). */
+#define PMCO_SCALE_ADD 0x4000000u
+static int scale_weight(pmco_cell *c, int cl, double ratio, int allow_doubling, int allow_halving,
+                        uint64_t seed, uint32_t cell_id, uint32_t step, uint32_t bkey, int64_t *next_id,
+                        int *status)
+{
+    const int n = *c->n_part;
+    int n_cls = 0, changed = 0;
+    for (int i = 0; i < n; i++) n_cls += (c->wclass[i] == cl);
+    uint32_t w[4];
+    if (ratio > 1.0 && (allow_halving || n_cls == 0)) {
+        unsigned char *dead = (unsigned char *)calloc((size_t)(n > 0 ? n : 1), 1);
+        pmco_rng_block(seed, cell_id, step, 0xFFFFFFFFu, PMCO_SITE_SCALE, bkey, w);
+        const double x_rm = (double)n_cls * (1.0 - 1.0 / ratio);
+        const double x_fl = (double)(int64_t)x_rm;
+        int m_rm = (int)x_fl + ((pmco_u53(w[0], w[1]) < x_rm - x_fl) ? 1 : 0);
+        if (m_rm > n_cls) m_rm = n_cls;
+        int t = 0;
+        for (int i = 0; i < n && changed < m_rm; i++) {
+            if (c->wclass[i] != cl) continue;
+            pmco_rng_block(seed, cell_id, step, (uint32_t)i, PMCO_SITE_SCALE, bkey, w);
+            if (pmco_u53(w[0], w[1]) * (double)(n_cls - t) < (double)(m_rm - changed)) { dead[i] = 1; changed++; }
+            t++;
+        }
+        compact_stable(c, dead, n, changed);
+        free(dead);
+    } else if (ratio < 1.0 && (allow_doubling || n_cls == 0)) {
+        const double x = 1.0 / ratio, x_fl = (double)(int64_t)x;
+        for (int i = 0; i < n; i++) {
+            if (c->wclass[i] != cl) continue;
+            pmco_rng_block(seed, cell_id, step, (uint32_t)i, PMCO_SITE_SCALE, bkey, w);
+            const int copies = (int)x_fl + ((pmco_u53(w[0], w[1]) < x - x_fl) ? 1 : 0);
+            for (int g = 1; g < copies; g++) {
+                const int at = *c->n_part;
+                const int64_t id = (*next_id)++;        /* (spent whether or not the copy finds room) */
+                if (at >= c->cap) { *status |= PMCO_ST_CAP_OVERFLOW; continue; }
+                move_particle(c, at, i);
+                c->id[at] = id;
+                *c->n_part = at + 1;
+                changed++;
+            }
+        }
+    } else {
+        return 0;
+    }
+    c->mag[cl] = c->mag[cl] * ratio;
+    *c->sort_valid = 0;
+    return changed;
+}
+
+/* aero_state_prepare_weight_for_add [upstream, uncited]: about n_add particles are going to join
+ * class cl; if that leaves the class outside [n_ideal / 2, 2 n_ideal] the weight is scaled so
+ * that it comes to n_ideal.  Off unless the cell carries prep_n_ideal. */
+static void prepare_weight_for_add(pmco_cell *c, int cl, double n_add, uint64_t seed, uint32_t cell_id,
+                                   uint32_t step, uint32_t bkey, int64_t *next_id, int *status)
+{
+    if (!c->prep_n_ideal) return;
+    int n_cls = 0;
+    for (int i = 0; i < *c->n_part; i++) n_cls += (c->wclass[i] == cl);
+    const double n_new = (double)n_cls + n_add, ideal = c->prep_n_ideal[cl];
+    if (n_new == 0.0 || !(ideal > 0.0)) return;
+    if (n_new < ideal / 2.0 || n_new > ideal * 2.0)
+        scale_weight(c, cl, n_new / ideal, c->prep_doubling, c->prep_halving, seed, cell_id, step, bkey,
+                     next_id, status);
+}
+
 /* means != NULL: the Poisson mean of every mode is given (negative: the mode is skipped) */
 static int add_dist_sample_means(pmco_cell *c, const pmco_aero_dist *d, double factor, const double *means,
                                  int kind, double create_time, uint64_t seed, uint32_t cell_id,
@@ -865,6 +941,10 @@ static int add_dist_sample_means(pmco_cell *c, const pmco_aero_dist *d, double f
     for (int m = 0; m < d->n_mode; m++) {
         uint32_t w[4];
         const int cl = d->mode_class[m];
+        if (!means) /* adjust the weight if necessary, then the mean at the weight that holds now */
+            prepare_weight_for_add(c, cl, d->num_conc[m] * factor / c->mag[cl], seed, cell_id, step,
+                                   PMCO_SCALE_ADD | ((uint32_t)kind << 16) | ((uint32_t)m << 8) | (uint32_t)cl,
+                                   next_id, status);
         const double mean = means ? means[m] : d->num_conc[m] * factor / c->mag[cl];
         if (means && mean < 0.0) continue;
         pmco_rng_block(seed, cell_id, step, ((uint32_t)kind << 8) | (uint32_t)m, PMCO_SITE_EMIT_N, 0, w);
@@ -1607,36 +1687,10 @@ int pmco_transport_preweight(pmco_cell *cells, int n_cells, int nx, int nz, int 
             const double ideal_n = n_ideal[(size_t)c * C + cl];
             if (!(n_parts_new > 2.0 * ideal_n)) continue;
             const double ratio = n_parts_new / ideal_n;
-            const double p_drop = 1.0 - 1.0 / ratio;
-            const int n = *s->n_part;
-            unsigned char *dead = (unsigned char *)calloc((size_t)(n > 0 ? n : 1), 1);
-            int n_dead = 0;
-            /* aero_state_scale_weight with weight_ratio > 1 [upstream, uncited]:
-             * n_remove = prob_round(n_class_members (1 - 1 / ratio)) particles chosen uniformly at
-             * random leave.  Here: the count from one uniform (key 0xFFFFFFFF), the subset by
-             * selection sampling in slot order -- member t of n goes when u (n - t) < still to go,
-             * a uniformly random subset of exactly that size. */
-            int n_cls = 0;
-            for (int i = 0; i < n; i++) n_cls += (s->wclass[i] == cl);
-            uint32_t w[4];
-            pmco_rng_block(seed, cell_id_base + (uint32_t)c, step, 0xFFFFFFFFu, PMCO_SITE_SCALE, (uint32_t)cl, w);
-            const double x_rm = (double)n_cls * p_drop;
-            const double x_fl = (double)(int64_t)x_rm;
-            int m_rm = (int)x_fl + ((pmco_u53(w[0], w[1]) < x_rm - x_fl) ? 1 : 0);
-            if (m_rm > n_cls) m_rm = n_cls;
-            int t = 0;
-            for (int i = 0; i < n && n_dead < m_rm; i++) {
-                if (s->wclass[i] != cl) continue;
-                pmco_rng_block(seed, cell_id_base + (uint32_t)c, step, (uint32_t)i, PMCO_SITE_SCALE,
-                               (uint32_t)cl, w);
-                if (pmco_u53(w[0], w[1]) * (double)(n_cls - t) < (double)(m_rm - n_dead)) { dead[i] = 1; n_dead++; }
-                t++;
-            }
-            compact_stable(s, dead, n, n_dead);
-            free(dead);
-            s->mag[cl] = s->mag[cl] * ratio;
-            *s->sort_valid = 0;
-            removed += n_dead;
+            /* aero_state_scale_weight(weight_ratio > 1, .true., .true.) (:1390-1393) */
+            int st_ = 0;
+            removed += scale_weight(s, cl, ratio, 1, 1, seed, cell_id_base + (uint32_t)c, step, (uint32_t)cl,
+                                    NULL, &st_);
         }
         if (n_removed) n_removed[c] = removed;
     }

@@ -94,6 +94,12 @@ typedef struct {
     int32_t *comp_n;       /* [cap] entries held (<= n_comp_max)             */
     int32_t *comp_src;     /* [cap][n_comp_max] source_id (0-based), -1 past the end */
     double *comp_time;     /* [cap][n_comp_max] create_time, 0 past the end  */
+    /* aero_state_prepare_weight_for_add inside aero_state_add_aero_dist_sample [upstream, uncited;
+     * the reference hands allow_doubling / allow_halving to every add: wrf_pmc_driver.F90:207-210,
+     * 1920-1922, wrf_pmc_trans_aero.F90:1030-1032]: NULL = off (a plain Poisson sample at the
+     * class's present weight); else n_part_ideal [n_class] and the two flags */
+    const double *prep_n_ideal;
+    int32_t prep_doubling, prep_halving;
 } pmco_cell;
 
 void pmco_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

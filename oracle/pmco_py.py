@@ -37,6 +37,7 @@ class CellStruct(C.Structure):
         ("wclass", _ip), ("id", _lp), ("lct", _dp), ("gct", _dp), ("n_orig", _ip),
         ("pcap", C.c_int32), ("sort_valid", _ip), ("perm", _ip), ("gcnt", _ip), ("goff", _ip),
         ("n_comp_max", C.c_int32), ("comp_n", _ip), ("comp_src", _ip), ("comp_time", _dp),
+        ("prep_n_ideal", _dp), ("prep_doubling", C.c_int32), ("prep_halving", C.c_int32),
     ]
 
 
@@ -167,6 +168,7 @@ class Cell:
         self.n_spec, self.n_class, self.n_source, self.cap = n_spec, n_class, n_source, cap
         # particle%component(:): the first n_comp_max (source, create_time) pairs of each particle
         self.n_comp_max = n_comp_max
+        self.prep_n_ideal, self.prep_doubling, self.prep_halving = None, True, True
         self.comp_n = np.zeros(cap, dtype=np.int32)
         self.comp_src = np.full((cap, max(n_comp_max, 1)), -1, dtype=np.int32)
         self.comp_time = np.zeros((cap, max(n_comp_max, 1)))
@@ -212,7 +214,16 @@ class Cell:
         s.n_comp_max = self.n_comp_max
         s.comp_n = _p(self.comp_n, _ip); s.comp_src = _p(self.comp_src, _ip)
         s.comp_time = _p(self.comp_time, _dp)
+        if self.prep_n_ideal is not None:
+            s.prep_n_ideal = _p(self.prep_n_ideal, _dp)
+            s.prep_doubling, s.prep_halving = int(self.prep_doubling), int(self.prep_halving)
         return s
+
+    def set_weight_preparation(self, n_ideal, allow_doubling=True, allow_halving=True):
+        """aero_state_prepare_weight_for_add in every add of particles from a distribution
+        (emission, background, sea salt, the refill of an emptied boundary cell); n_ideal None: off."""
+        self.prep_n_ideal = None if n_ideal is None else np.ascontiguousarray(n_ideal, dtype=np.float64).copy()
+        self.prep_doubling, self.prep_halving = bool(allow_doubling), bool(allow_halving)
 
     def refresh_caches(self):
         lib().pmco_refresh_caches(C.byref(self.view()))

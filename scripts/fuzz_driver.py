@@ -28,7 +28,7 @@ for run in range(n_runs):
     lo = 2 if periodic else 3
     kw = dict(nx=int(rng.randint(lo, 7)), nz=int(rng.randint(2, 7)), ny=int(rng.randint(lo, 7)),
               n_part=int(rng.choice([60, 150, 300, 500])), n_steps=int(rng.randint(1, 10)), periodic=periodic,
-              seed=int(rng.randint(1 << 30)), sea_salt_opt=int(rng.randint(0, 2)))
+              seed=int(rng.randint(1 << 30)), sea_salt_opt=int(rng.randint(0, 3)))
     print(f"run {run}: {kw}", flush=True)
     case = wrf_case.Case(**kw)
     with tempfile.TemporaryDirectory() as d:
@@ -37,7 +37,9 @@ for run in range(n_runs):
         except AssertionError as e:
             if "ran out of particle slots" not in str(e):
                 raise
-            print("   the driver stopped: a cell ran out of particle slots (the shim's capacity rule)", flush=True)
+            msg = str(e)
+            at = msg.index("ran out of particle slots")
+            print("   the driver stopped: a cell " + msg[at:at + 70].split(":")[0] + " (the shim's capacity rule)", flush=True)
             full += 1
             continue
     print(f"   moved {sum(s['n_moved'] for s in steps)} coagulated {sum(s['n_coag'] for s in steps)} "

@@ -837,6 +837,79 @@ def test_scenario_update_parity(wp, oracle):
     blk.close()
 
 
+@pytest.mark.parametrize("n_class,flags", [(1, (True, True)), (2, (True, True)), (2, (False, True)), (2, (True, False))])
+def test_weight_preparation_parity(wp, oracle, n_class, flags):
+    """pmcx_set_weight_preparation: aero_state_prepare_weight_for_add in front of every mode's sample
+    (the allow_doubling / allow_halving the reference hands to scenario_update_aero_state, the sea-salt
+    source and the refill of an emptied boundary cell).  Cells whose ideal counts lie far below, at
+    and far above their populations -- thinned to the ideal count, left alone, multiplied by copies --
+    through emission + dilution + background, sea salt and the boundary refill, against the oracle."""
+    n_cells, n_part, n_spec = 6, 600, 2
+    blk, cells, info = parity.setup_pair(wp, oracle, n_cells, n_part, n_spec, n_class, 12, K_BROWN,
+                                         cap=8192, n_source=3)
+    mag = info["mag"]
+    # ideal counts per class: 0.2 x, 0.3 x (thinning), 1 x, 1 x (nothing), 4 x, 6 x (copies) the population
+    n_ideal = np.outer([0.2, 0.3, 1.0, 1.0, 4.0, 6.0], np.full(n_class, n_part / n_class))
+    blk.set_n_part_ideal(n_ideal)
+    with wp.CellBlock(2, 64, 1) as fresh:
+        with pytest.raises(wp.PmcxError):
+            fresh.set_weight_preparation(True)                          # needs the ideal counts
+    blk.set_weight_preparation(True, *flags)
+    for c, oc in enumerate(cells):
+        oc.set_weight_preparation(n_ideal[c], *flags)
+    em = [dict(gm_radius=2e-8, gsd_log10=0.2, vol_frac=[0.5, 0.5], wclass=0, source=1),
+          dict(gm_radius=1e-7, gsd_log10=0.1, vol_frac=[0.0, 1.0], wclass=n_class - 1, source=2)]
+    bg = [dict(gm_radius=5e-8, gsd_log10=0.3, vol_frac=[1.0, 0.0], wclass=0, source=0)]
+    em_rate = np.array([[mag[c, 0] * 1.5, mag[c, n_class - 1] * 0.6] for c in range(n_cells)])
+    bg_conc = np.array([[mag[c, 0] * 700.0] for c in range(n_cells)])
+    dil = np.array([1e-3, 0.0, 4e-3, 2e-3, 1e-3, 0.0])
+    mag0 = blk.get_weights()
+    for step in range(3):
+        ne, ni, no = blk.scenario_update_aero_state(60.0, 60.0 * step, 12, step, em, em_rate, dil, bg, bg_conc)
+        for c, oc in enumerate(cells):
+            oe = [dict(m, num_conc=em_rate[c, k]) for k, m in enumerate(em)]
+            ob = [dict(m, num_conc=bg_conc[c, k]) for k, m in enumerate(bg)]
+            st, oc.next_id, one, oni, ono = oc.scenario_update(60.0, 60.0 * step, 12, oc.cell_id, step, oe, dil[c], ob,
+                                                               oc.next_id)
+            assert st == 0 and (one, oni, ono) == (int(ne[c]), int(ni[c]), int(no[c])), (step, c)
+        ok, msg = parity.compare_state(blk, cells)
+        assert ok, f"step {step} after the scenario update: {msg}"
+        assert np.array_equal(blk.get_next_id(), [oc.next_id for oc in cells])
+        assert np.array_equal(blk.get_weights(), np.array([oc.mag for oc in cells]))
+        # the refill of boundary cells: two emptied first (their stale weight is replaced), two topped up
+        lst = np.array([0, 2, 4, 5], np.int32); thr = np.array([1, 0, 1, 0], np.int32)
+        modes = [dict(gm_radius=4e-8, gsd_log10=0.25, vol_frac=[1.0, 0.0], wclass=0, source=0),
+                 dict(gm_radius=9e-8, gsd_log10=0.2, vol_frac=[0.3, 0.7], wclass=n_class - 1, source=1)]
+        conc = np.array([[300.0 * mag0[c, 0], 200.0 * mag0[c, n_class - 1]] for c in lst])
+        na, nr = blk.boundary_resample(lst, thr, modes, conc, 1.1, 0.0, 12, step)
+        for q, c in enumerate(lst):
+            om = [dict(m, num_conc=conc[q, k]) for k, m in enumerate(modes)]
+            st, cells[c].next_id, ona, onr = cells[c].boundary_resample(int(thr[q]), om, 1.1, 0.0, 12, cells[c].cell_id,
+                                                                        step, cells[c].next_id)
+            assert st == 0 and (ona, onr) == (int(na[q]), int(nr[q])), (step, c)
+        ok, msg = parity.compare_state(blk, cells)
+        assert ok, f"step {step} after the refill: {msg}"
+        assert np.array_equal(blk.get_weights(), np.array([oc.mag for oc in cells]))
+        ns, nc, st = blk.mc_coag(K_BROWN, 600.0, 12, step)
+        for c, oc in enumerate(cells):
+            assert oc.mc_coag(K_BROWN, 600.0, 12, oc.cell_id, step) == (int(st[c]), int(ns[c]), int(nc[c]))
+    magn = blk.get_weights()
+    cnt = np.array([[int((oc.wclass[:int(oc.n_part[0])] == q).sum()) for q in range(n_class)] for oc in cells])
+    if flags == (True, True):
+        # every class the adds touched has come into [ideal / 2, 2 ideal] (the in-tree top-up of a
+        # boundary cell and the coagulation in between work without the preparation: some slack) ...
+        assert ((cnt[:, 0] > 0.4 * n_ideal[:, 0]) & (cnt[:, 0] < 2.3 * n_ideal[:, 0] + 30)).all(), (cnt, n_ideal)
+        # ... the thinned cells at a larger weight, the multiplied ones at a smaller
+        assert (magn[:2, 0] > 2 * mag0[:2, 0]).all() and (magn[4:, 0] < 0.5 * mag0[4:, 0]).all()
+    # (cells 0 and 4 are emptied by the refill: an empty class is scaled whatever the flags say)
+    if flags == (True, False):           # no thinning of a populated class
+        assert (magn[1] <= mag0[1]).all()
+    if flags == (False, True):           # no copies of a populated class
+        assert (magn[5] >= mag0[5]).all()
+    assert len(np.unique(blk.download_cells()["id"])) == int(blk.aero_state_total_particles().sum())
+    blk.close()
+
+
 @pytest.mark.parametrize("sea_salt_opt", [1, 2])
 def test_seasalt_emissions_parity(wp, oracle, sea_salt_opt):
     """seasalt_emissions (driver:212-223, 1767-1924) on the ocean surface cells, both options."""

@@ -593,6 +593,72 @@ def test_a_periodic_direction_one_cell_wide_is_closed(oracle, nx, ny):
         assert a[1].sum() > 0 and a[1].sum() < 0.2 * n * n_part
 
 
+def test_weight_preparation_of_an_add(oracle):
+    """aero_state_prepare_weight_for_add [upstream, uncited] in front of every mode's Poisson sample
+    (the reference hands allow_doubling / allow_halving to every add, wrf_pmc_driver.F90:207-210,
+    1920-1922, wrf_pmc_trans_aero.F90:1030-1032): when the class would leave [ideal / 2, 2 ideal]
+    its weight is scaled so that it comes to the ideal count -- an exact-count thinning above, copies
+    below -- and the number concentration stays what it was in expectation.  Off by default."""
+    dens = np.array([1800.0, 1000.0]); ve, _ = oracle.make_bin_tables(80, 1e-10, 1e-2)
+    ideal, mag0 = 400.0, 1e6
+    mode = dict(gm_radius=5e-8, gsd_log10=0.2, vol_frac=[0.5, 0.5], wclass=0, source=1)
+
+    def cell(n, prep=True, flags=(True, True), seed=0):
+        oc = oracle.Cell(2, 1, 2, 4096, dens, ve, n_comp_max=3)
+        oc.mag[:] = mag0
+        oc.generate([dict(frac=1, gm_radius=3e-8, gsd_log10=0.2, vol_frac=[1.0, 0.0], source=0)], n, seed, 0, first_id=1 << 40)
+        if prep:
+            oc.set_weight_preparation([ideal], *flags)
+        return oc
+
+    stats = {"over": [], "under": [], "empty": []}
+    for t in range(40):
+        # 1.9 ideal present, 0.5 ideal on their way: above 2 ideal -> thinned to the ideal count
+        oc = cell(760, seed=t)
+        em = [dict(mode, num_conc=0.5 * ideal * mag0 / 10.0)]           # rate: mean = rate dt / magnitude
+        st, nid, ne, ni, no = oc.scenario_update(10.0, 5.0, t, 0, 3, em, 0.0, None, 1)
+        n = int(oc.n_part[0])
+        assert st == 0 and oc.mag[0] == mag0 * 2.4                      # ratio = (760 + 200) / 400
+        kept = n - ne
+        assert kept in (int(760 / 2.4), int(760 / 2.4) + 1)             # prob_round(n (1 - 1 / ratio)) left
+        assert len(np.unique(oc.id[:n])) == n and nid == 1 + ne
+        stats["over"].append((n, ne))
+        # 0.2 ideal present, 0.1 ideal on their way: below ideal / 2 -> every particle stands for 1 / 0.3
+        oc = cell(80, seed=100 + t)
+        before = oc.vtot[:80].copy()
+        em = [dict(mode, num_conc=0.1 * ideal * mag0 / 10.0)]
+        st, nid, ne, ni, no = oc.scenario_update(10.0, 5.0, t, 0, 3, em, 0.0, None, 1)
+        n = int(oc.n_part[0])
+        assert st == 0 and oc.mag[0] == mag0 * (120.0 / 400.0)
+        copies = n - ne - 80
+        assert 2 * 80 <= copies <= 3 * 80                               # 3 or 4 of each: 2 or 3 copies
+        assert np.array_equal(oc.vtot[:80], before)                     # the originals stay where they are
+        assert np.isin(oc.vtot[80:80 + copies], before).all()           # the copies behind them, then the new ones
+        assert (oc.n_orig[1, 80 + copies:n] == 1).all() and (oc.comp_n[80:80 + copies] == 1).all()
+        assert len(np.unique(oc.id[:n])) == n and nid == 1 + copies + ne
+        stats["under"].append((n, ne))
+        # an emptied boundary cell at a stale weight: the refill comes at the weight that gives the ideal count
+        oc = cell(300, seed=200 + t)
+        oc.mag[:] = mag0 / 500.0                                        # (a copy of a much-doubled neighbour)
+        bg = [dict(mode, num_conc=2.0 * ideal * mag0)]                  # mixing ratio, density 1
+        st, nid, na, nr = oc.boundary_resample(True, bg, 1.0, 0.0, t, 0, 3, 1)
+        assert st == 0 and nr == 300 and oc.mag[0] == 2.0 * ideal * mag0 / ideal
+        stats["empty"].append((int(oc.n_part[0]), na))
+    for k, v in stats.items():
+        v = np.array(v, dtype=float)
+        assert abs(v[:, 0].mean() - ideal) < 4 * math.sqrt(ideal / len(v)) + 1, (k, v[:, 0].mean())
+    # flags: with particles present a scaling needs its flag; off by default
+    oc = cell(760, flags=(True, False))
+    st, nid, ne, *_ = oc.scenario_update(10.0, 5.0, 1, 0, 3, [dict(mode, num_conc=0.5 * ideal * mag0 / 10.0)], 0.0, None, 1)
+    assert oc.mag[0] == mag0 and int(oc.n_part[0]) == 760 + ne
+    oc = cell(80, flags=(False, True))
+    st, nid, ne, *_ = oc.scenario_update(10.0, 5.0, 1, 0, 3, [dict(mode, num_conc=0.1 * ideal * mag0 / 10.0)], 0.0, None, 1)
+    assert oc.mag[0] == mag0 and int(oc.n_part[0]) == 80 + ne
+    oc = cell(760, prep=False)
+    st, nid, ne, *_ = oc.scenario_update(10.0, 5.0, 1, 0, 3, [dict(mode, num_conc=0.5 * ideal * mag0 / 10.0)], 0.0, None, 1)
+    assert oc.mag[0] == mag0 and int(oc.n_part[0]) == 760 + ne
+
+
 def test_dry_deposition_velocity(oracle):
     """Zhang (2001) deposition velocity (wrf_pmc_dep_aero.F90:265-420): equal to an independent
     numpy transcription to rounding, U-shaped in diameter, settling-dominated for coarse

@@ -601,6 +601,16 @@ int pmcx_set_n_part_ideal(pmcx_ctx *ctx, const double *n_ideal)
     return copy_cells_h2d(ctx, ctx->d_n_ideal, n_ideal,
                           sizeof(double) * (size_t)ctx->cfg.n_cells * ctx->cfg.n_class);
 }
+int pmcx_set_weight_preparation(pmcx_ctx *ctx, int32_t on, int32_t allow_doubling, int32_t allow_halving)
+{
+    if (!ctx) return fail(ctx, PMCX_EINVAL, "pmcx_set_weight_preparation: null context");
+    if (on && !ctx->n_ideal_set)
+        return fail(ctx, PMCX_ESTATE, "pmcx_set_weight_preparation: pmcx_set_n_part_ideal must come first");
+    ctx->st.prep_on = on ? 1 : 0;
+    ctx->st.prep_doubling = allow_doubling ? 1 : 0;
+    ctx->st.prep_halving = allow_halving ? 1 : 0;
+    return PMCX_OK;
+}
 int pmcx_set_next_id(pmcx_ctx *ctx, const int64_t *next_id)
 {
     if (!ctx || !next_id) return fail(ctx, PMCX_EINVAL, "pmcx_set_next_id: null argument");

@@ -108,6 +108,8 @@ struct DeviceState {
     // particle's list (0: not carried): source ids a byte each (0xFF past the end), create times;
     // the coagulations of the last mc_coag in event order, merged by k_comp_merge behind the sampler
     int32_t n_comp_max;
+    // aero_state_prepare_weight_for_add in every add from a distribution (pmcx_set_weight_preparation)
+    int32_t prep_on, prep_doubling, prep_halving;
     uint64_t *comp_src;  // [n_cells][cap]
     double *comp_time;   // [n_cells][cap][n_comp_max]
     uint64_t *mlog;      // [n_cells][max_events] pn | po << 16 | (pn is the first candidate) << 32

@@ -3144,6 +3144,158 @@ struct AeroDistDev {
     __device__ __forceinline__ int64_t mo(int c) const { return per_cell ? (int64_t)c * n_mode : 0; }
 };
 
+// aero_state_scale_weight(weight_ratio) of one class by one wavefront [upstream, uncited]:
+//   ratio > 1 (and allow_halving, or the class is empty): exactly prob_round(n (1 - 1 / ratio)) of the
+//     class's n particles leave, a uniformly random subset (selection sampling in rank order:
+//     member t goes when u (n - t) < still to go); they become tombstones;
+//   ratio < 1 (and allow_doubling, or the class is empty): every particle of the class stands for
+//     prob_round(1 / ratio) >= 1: its copies, under new ids, are appended in rank order;
+//   then the magnitude is multiplied by ratio.  bkey separates the callers' random numbers (the
+//   transport's preweight: the class; an add: SCALE_ADD | kind << 16 | mode << 8 | class).
+// Returns the number removed or added.  The caller has applied the event log.
+constexpr uint32_t SCALE_ADD = 0x4000000u;
+__device__ int scale_weight_wave(const DeviceState &st, int c, int cl, double ratio, int allow_doubling,
+                                 int allow_halving, uint64_t seed, uint32_t step, uint32_t bkey, int lane,
+                                 int &status)
+{
+    const int C = st.n_class;
+    const int64_t cb = (int64_t)c * st.cap;
+    const uint32_t cell_id = cell_gid(st, c);
+    const uint64_t lt = (1ull << lane) - 1ull;
+    double *mag = st.mag + (int64_t)c * C;
+    int n_hi = st.n_hi[c];
+    const int n_live = st.n_part[c];
+    int n_before = n_live;
+    if (C > 1) {
+        uint32_t cnt = 0;
+        for (int i = lane; i < n_hi; i += 64) cnt += (live_class_c(st, cb, i) == cl);
+        n_before = (int)wave_sum_u64(cnt);
+    }
+    uint32_t w[4];
+    int changed = 0;
+    if (ratio > 1.0 && (allow_halving || n_before == 0)) {
+        rng_block(seed, cell_id, step, 0xFFFFFFFFu, SITE_SCALE, bkey, w);
+        const double x_rm = (double)n_before * (1.0 - 1.0 / ratio);
+        const double x_fl = (double)(int64_t)x_rm;
+        int m_rm = (int)x_fl + ((u53(w[0], w[1]) < x_rm - x_fl) ? 1 : 0);
+        m_rm = m_rm < n_before ? m_rm : n_before;
+        uint32_t rank0 = 0;
+        int t0 = 0, k_rm = 0; // class members seen, removed so far (uniform)
+        // (the next chunk's liveness is requested before this chunk's work: a wavefront alone with a
+        // big cell would otherwise wait out a memory round trip per 64 slots)
+        int wc_next = lane < n_hi ? live_class_c(st, cb, lane) : -1;
+        for (int i0 = 0; i0 < n_hi && k_rm < m_rm; i0 += 64) {
+            const int i = i0 + lane;
+            const int wc = wc_next;
+            wc_next = i + 64 < n_hi ? live_class_c(st, cb, i + 64) : -1;
+            const uint64_t mlive = __ballot(wc >= 0);
+            const uint64_t mcls = __ballot(wc == cl);
+            double u = 0.0;
+            if (wc == cl) {
+                rng_block(seed, cell_id, step, rank0 + (uint32_t)__popcll(mlive & lt), SITE_SCALE, bkey, w);
+                u = u53(w[0], w[1]);
+            }
+            // (member t goes when u (n - t) < m - k, i.e. when k <= m - 1 - floor(u (n - t)): a bound every
+            // lane works out for itself; the serial part is one scalar compare a member)
+            const int t_l = t0 + __popcll(mcls & lt);
+            const int a_l = (wc == cl) ? m_rm - 1 - (int)(u * (double)(n_before - t_l)) : -1;
+            uint64_t msel = 0, rest = mcls;
+            while (rest) {
+                const int l = __builtin_ctzll(rest);
+                rest &= rest - 1;
+                if (k_rm <= __builtin_amdgcn_readlane(a_l, l)) { msel |= 1ull << l; k_rm++; }
+            }
+            t0 += __popcll(mcls);
+            if ((msel >> lane) & 1ull) mark_dead(st, cb, i);
+            rank0 += (uint32_t)__popcll(mlive);
+        }
+        changed = k_rm;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_sync();
+        if (lane == 0) st.n_part[c] = n_live - changed;
+    } else if (ratio < 1.0 && (allow_doubling || n_before == 0)) {
+        const double x = 1.0 / ratio, x_fl = (double)(int64_t)x;
+        // how many copies a class member gets (its uniform is keyed by its rank: the same in both passes)
+        auto dups_of = [&](int wc, uint32_t rank) -> uint32_t {
+            if (wc != cl) return 0u;
+            uint32_t q[4];
+            rng_block(seed, cell_id, step, rank, SITE_SCALE, bkey, q);
+            return (uint32_t)((int)x_fl + ((u53(q[0], q[1]) < x - x_fl) ? 1 : 0) - 1);
+        };
+        uint32_t total = 0, rank0 = 0;
+        for (int i0 = 0; i0 < n_hi; i0 += 64) {
+            const int i = i0 + lane;
+            const int wc = i < n_hi ? live_class_c(st, cb, i) : -1;
+            const uint64_t mlive = __ballot(wc >= 0);
+            total += (uint32_t)wave_sum_u64(dups_of(wc, rank0 + (uint32_t)__popcll(mlive & lt)));
+            rank0 += (uint32_t)__popcll(mlive);
+        }
+        if (n_hi + (int)total > st.cap && n_hi > n_live) { // make room: close the holes first
+            compact_wave(st, c, lane);
+            n_hi = st.n_hi[c];
+        }
+        if (n_hi + (int)total > st.cap) status |= ST_CAP_OVERFLOW;
+        const int64_t nid = st.next_id[c];
+        uint32_t base = 0;
+        rank0 = 0;
+        for (int i0 = 0; i0 < n_hi; i0 += 64) {
+            const int i = i0 + lane;
+            const int wc = i < n_hi ? live_class_c(st, cb, i) : -1;
+            const uint64_t mlive = __ballot(wc >= 0);
+            const uint32_t nd = dups_of(wc, rank0 + (uint32_t)__popcll(mlive & lt));
+            const uint32_t inc = wave_incl_scan_u32(nd, lane);
+            const uint32_t first = base + inc - nd;
+            for (uint32_t g = 0; g < nd; g++) {
+                const int dst = n_hi + (int)(first + g);
+                if (dst >= st.cap) break; // (flagged above; the id is spent all the same)
+                move_particle(st, cb, c, dst, i);
+                st.cold[cb + dst].id = nid + (int64_t)(first + g);
+            }
+            base += (uint32_t)__shfl(inc, 63, 64);
+            rank0 += (uint32_t)__popcll(mlive);
+        }
+        changed = n_hi + (int)total > st.cap ? st.cap - n_hi : (int)total;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_sync();
+        if (lane == 0) {
+            st.next_id[c] = nid + (int64_t)total;
+            st.n_hi[c] = n_hi + changed;
+            st.n_part[c] = n_live + changed;
+        }
+    } else {
+        return 0;
+    }
+    if (lane == 0) {
+        mag[cl] = mag[cl] * ratio;
+        st.sort_valid[c] = 0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __threadfence_block();
+    wave_sync();
+    return changed;
+}
+
+// aero_state_prepare_weight_for_add [upstream, uncited]: about n_add particles are going to join
+// class cl; if that leaves the class outside [n_ideal / 2, 2 n_ideal] its weight is scaled so that
+// it comes to n_ideal (pmcx_set_weight_preparation; off: nothing happens)
+__device__ void prepare_weight_for_add(const DeviceState &st, int c, int cl, double n_add, uint64_t seed,
+                                       uint32_t step, uint32_t bkey, int lane, int &status)
+{
+    if (!st.prep_on) return;
+    const int64_t cb = (int64_t)c * st.cap;
+    int n_cls = st.n_part[c];
+    if (st.n_class > 1) {
+        const int n_hi = st.n_hi[c];
+        uint32_t cnt = 0;
+        for (int i = lane; i < n_hi; i += 64) cnt += (live_class_c(st, cb, i) == cl);
+        n_cls = (int)wave_sum_u64(cnt);
+    }
+    const double n_new = (double)n_cls + n_add, ideal = st.n_ideal[(int64_t)c * st.n_class + cl];
+    if (n_new == 0.0 || !(ideal > 0.0)) return;
+    if (n_new < ideal / 2.0 || n_new > ideal * 2.0)
+        scale_weight_wave(st, c, cl, n_new / ideal, st.prep_doubling, st.prep_halving, seed, step, bkey, lane, status);
+}
+
 // appends Poisson(num_conc*factor/magnitude) particles per mode; returns how many
 // means != nullptr: the Poisson mean of every mode is given (negative: the mode is skipped)
 __device__ int add_dist_sample(const DeviceState &st, int c, const AeroDistDev &d, double factor,
@@ -3158,7 +3310,10 @@ __device__ int add_dist_sample(const DeviceState &st, int c, const AeroDistDev &
     for (int m = 0; m < d.n_mode; m++) {
         uint32_t w[4];
         const int cl = d.mode_class[mo + m];
-        const double mean = means ? means[m] : d.num_conc[(int64_t)c * d.n_mode + m] * factor / mag[cl];
+        if (!means) // adjust the weight if necessary, then the mean at the weight that holds now
+            prepare_weight_for_add(st, c, cl, d.num_conc[(int64_t)c * d.n_mode + m] * factor / ld_f64(&mag[cl]), seed,
+                                   step, SCALE_ADD | (kind << 16) | ((uint32_t)m << 8) | (uint32_t)cl, lane, status);
+        const double mean = means ? means[m] : d.num_conc[(int64_t)c * d.n_mode + m] * factor / ld_f64(&mag[cl]);
         if (means && mean < 0.0) continue; // (uniform over the wavefront)
         rng_block(seed, cell_id, step, (kind << 8) | (uint32_t)m, SITE_EMIT_N, 0, w);
         int n = poisson(mean, u53(w[0], w[1]));
@@ -4417,76 +4572,17 @@ __global__ __launch_bounds__(64) void k_preweight_scale(DeviceState st, Preweigh
                                                         uint32_t step)
 {
     const int lane = threadIdx.x, c = blockIdx.x, C = st.n_class;
-    const int64_t cb = (int64_t)c * st.cap;
-    const uint32_t cell_id = cell_gid(st, c);
-    const uint64_t lt = (1ull << lane) - 1ull;
-    double *mag = st.mag + (int64_t)c * C;
+    const double *mag = st.mag + (int64_t)c * C;
     uint32_t removed = 0;
+    int status = 0;
     for (int cl = 0; cl < C; cl++) {
-        const double n_parts_new = a.expect[(int64_t)c * C + cl] / mag[cl];
+        const double n_parts_new = a.expect[(int64_t)c * C + cl] / ld_f64(&mag[cl]);
         const double ideal_n = st.n_ideal[(int64_t)c * C + cl];
         if (!(n_parts_new > 2.0 * ideal_n)) continue; // (uniform over the wavefront)
-        const double ratio = n_parts_new / ideal_n;
-        const double p_drop = 1.0 - 1.0 / ratio;
-        const int n_hi = st.n_hi[c], n_live = st.n_part[c];
-        // aero_state_scale_weight, weight_ratio > 1 [upstream, uncited]: exactly
-        // prob_round(n (1 - 1 / ratio)) of the class's n particles leave, a uniformly random subset
-        // (here selection sampling in rank order, as k_boundary_resample: member t goes when
-        // u (n - t) < still to go)
-        int n_before = n_live;
-        if (C > 1) {
-            uint32_t cnt = 0;
-            for (int i = lane; i < n_hi; i += 64) cnt += (live_class_c(st, cb, i) == cl);
-            n_before = (int)wave_sum_u64(cnt);
-        }
-        uint32_t w[4];
-        rng_block(seed, cell_id, step, 0xFFFFFFFFu, SITE_SCALE, (uint32_t)cl, w);
-        const double x_rm = (double)n_before * p_drop;
-        const double x_fl = (double)(int64_t)x_rm;
-        int m_rm = (int)x_fl + ((u53(w[0], w[1]) < x_rm - x_fl) ? 1 : 0);
-        m_rm = m_rm < n_before ? m_rm : n_before;
-        uint32_t nd = 0, rank0 = 0;
-        int t0 = 0, k_rm = 0; // class members seen, removed so far (uniform)
-        // (the next chunk's liveness is requested before this chunk's work: a wavefront alone with a
-        // big cell would otherwise wait out a memory round trip per 64 slots)
-        int wc_next = lane < n_hi ? live_class_c(st, cb, lane) : -1;
-        for (int i0 = 0; i0 < n_hi && k_rm < m_rm; i0 += 64) {
-            const int i = i0 + lane;
-            const int wc = wc_next;
-            wc_next = i + 64 < n_hi ? live_class_c(st, cb, i + 64) : -1;
-            const uint64_t mlive = __ballot(wc >= 0);
-            const uint64_t mcls = __ballot(wc == cl);
-            double u = 0.0;
-            if (wc == cl) {
-                rng_block(seed, cell_id, step, rank0 + (uint32_t)__popcll(mlive & lt), SITE_SCALE, (uint32_t)cl, w);
-                u = u53(w[0], w[1]);
-            }
-            // (member t goes when u (n - t) < m - k, i.e. when k <= m - 1 - floor(u (n - t)): a bound every
-            // lane works out for itself; the serial part is one scalar compare a member)
-            const int t_l = t0 + __popcll(mcls & lt);
-            const int a_l = (wc == cl) ? m_rm - 1 - (int)(u * (double)(n_before - t_l)) : -1;
-            uint64_t msel = 0, rest = mcls;
-            while (rest) {
-                const int l = __builtin_ctzll(rest);
-                rest &= rest - 1;
-                if (k_rm <= __builtin_amdgcn_readlane(a_l, l)) { msel |= 1ull << l; k_rm++; }
-            }
-            t0 += __popcll(mcls);
-            if ((msel >> lane) & 1ull) mark_dead(st, cb, i);
-            rank0 += (uint32_t)__popcll(mlive);
-        }
-        nd = (uint32_t)k_rm;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wave_sync();
-        if (lane == 0) {
-            st.n_part[c] = n_live - (int)nd;
-            mag[cl] = mag[cl] * ratio;
-            st.sort_valid[c] = 0;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __threadfence_block();
-        wave_sync();
-        removed += nd; // (past the tombstone threshold: the k_compact that follows)
+        // aero_state_scale_weight(weight_ratio > 1, .true., .true.) (:1390-1393); a cell past its
+        // tombstone threshold afterwards: the k_compact that follows
+        removed += (uint32_t)scale_weight_wave(st, c, cl, n_parts_new / ideal_n, 1, 1, seed, step, (uint32_t)cl, lane,
+                                               status);
     }
     if (lane == 0 && a.n_removed) a.n_removed[c] = (int32_t)removed;
 }

@@ -112,6 +112,12 @@ module pmcx_c
        type(c_ptr), value :: ctx
        real(c_double), intent(in) :: n_ideal(*)
      end function pmcx_set_n_part_ideal
+     integer(c_int) function pmcx_set_weight_preparation(ctx, on, allow_doubling, allow_halving) &
+          bind(c, name="pmcx_set_weight_preparation")
+       import :: c_ptr, c_int, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: on, allow_doubling, allow_halving
+     end function pmcx_set_weight_preparation
      integer(c_int) function pmcx_set_cell_id_base(ctx, cell_id_base) bind(c, name="pmcx_set_cell_id_base")
        import :: c_ptr, c_int, c_int32_t
        type(c_ptr), value :: ctx
