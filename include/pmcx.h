@@ -271,7 +271,9 @@ int pmcx_rebalance(pmcx_ctx *ctx, int32_t allow_doubling, int32_t allow_halving,
  */
 typedef struct {
     int32_t n_mode;
-    const double *num_conc;    /* [n_cells][n_mode] */
+    const double *num_conc;    /* [n_cells][n_mode]; negative: the cell's distribution has no such
+                                * mode (cells bring different numbers of modes, or none): nothing is
+                                * drawn for it and no weight is prepared (pmcx_set_weight_preparation) */
     const double *gm_radius;   /* [n_mode] */
     const double *gsd_log10;   /* [n_mode] */
     const double *vol_frac;    /* [n_mode][n_spec] */

@@ -941,6 +941,7 @@ static int add_dist_sample_means(pmco_cell *c, const pmco_aero_dist *d, double f
     for (int m = 0; m < d->n_mode; m++) {
         uint32_t w[4];
         const int cl = d->mode_class[m];
+        if (!means && d->num_conc[m] < 0.0) continue; /* the cell's distribution does not have this mode */
         if (!means) /* adjust the weight if necessary, then the mean at the weight that holds now */
             prepare_weight_for_add(c, cl, d->num_conc[m] * factor / c->mag[cl], seed, cell_id, step,
                                    PMCO_SCALE_ADD | ((uint32_t)kind << 16) | ((uint32_t)m << 8) | (uint32_t)cl,
@@ -1779,7 +1780,8 @@ int pmco_boundary_resample(pmco_cell *c, int throw_away, const pmco_aero_dist *b
         for (int i = 0; i < *c->n_part; i++) n_before += (c->wclass[i] == cl);
         double total = 0.0;
         for (int m = 0; m < bg->n_mode; m++)
-            if (bg->mode_class[m] == cl) total = total + bg->num_conc[m] * density;
+            if (bg->mode_class[m] == cl && bg->num_conc[m] >= 0.0) /* (negative: no such mode in this cell) */
+                total = total + bg->num_conc[m] * density;
         const double n_parts_new = total / c->mag[cl];
         uint32_t w[4];
         pmco_rng_block(seed, cell_id, step, (uint32_t)cl, PMCO_SITE_RESAMPLE, 0, w);
@@ -1788,7 +1790,7 @@ int pmco_boundary_resample(pmco_cell *c, int throw_away, const pmco_aero_dist *b
         if (n_to_add > 0) {
             for (int m = 0; m < bg->n_mode; m++) {
                 means[m] = -1.0;
-                if (bg->mode_class[m] != cl) continue;
+                if (bg->mode_class[m] != cl || bg->num_conc[m] < 0.0) continue;
                 const double share = (density * bg->num_conc[m]) / total;
                 const double n_samp_avg = share * (double)n_to_add;
                 const double threshold = (density * bg->num_conc[m] / n_samp_avg) * .1;

@@ -233,6 +233,8 @@ class Case:
         counts_per_step = []
         level = lambda times, t: max(1, min(int(np.searchsorted(times, t, side="right")), len(times))) - 1
         fake = type("Fake", (), {})()
+        for c, oc in enumerate(cells):       # grid%allow_doubling, grid%allow_halving (both .true.) in every add
+            oc.set_weight_preparation(self.n_ideal[c], True, True)
         for s in range(self.n_steps):
             env, g, t = steps_env[s], self.G[s], float(s) * self.dt
             wrf_step, chem = int(t / self.dt), (math.fmod(t, self.chem_dt) == 0.0)

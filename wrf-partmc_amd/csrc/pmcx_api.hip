@@ -1307,6 +1307,11 @@ int pmcx_seasalt_emissions(pmcx_ctx *ctx, double dt, double elapsed_time, uint64
     }
     for (int m = 0; m < M; m++) { vf[(size_t)m * S + i_na] = f_na; vf[(size_t)m * S + i_cl] = 1.0 - f_na; }
     if (rate) memcpy(rate, conc.data(), sizeof(double) * conc.size());
+    // the reference calls the source on ocean surface cells only (driver:212-223): elsewhere the
+    // modes are marked absent, so that nothing -- not even a weight preparation -- happens there
+    for (size_t c = 0; c < nc; c++)
+        if (!ocean_surface[c])
+            for (int m = 0; m < M; m++) conc[c * M + m] = -1.0;
     pmcx_aero_dist d{};
     d.n_mode = M; d.num_conc = conc.data(); d.gm_radius = gm; d.gsd_log10 = gsd; d.vol_frac = vf.data();
     d.mode_class = mode_class; d.mode_source = mode_source;

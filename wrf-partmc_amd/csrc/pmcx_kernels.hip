@@ -3310,6 +3310,9 @@ __device__ int add_dist_sample(const DeviceState &st, int c, const AeroDistDev &
     for (int m = 0; m < d.n_mode; m++) {
         uint32_t w[4];
         const int cl = d.mode_class[mo + m];
+        // a negative num_conc: the cell's distribution does not have this mode (a cell without
+        // emissions, land under the sea-salt source) -- nothing is drawn, no weight is prepared
+        if (!means && d.num_conc[(int64_t)c * d.n_mode + m] < 0.0) continue; // (uniform over the wavefront)
         if (!means) // adjust the weight if necessary, then the mean at the weight that holds now
             prepare_weight_for_add(st, c, cl, d.num_conc[(int64_t)c * d.n_mode + m] * factor / ld_f64(&mag[cl]), seed,
                                    step, SCALE_ADD | (kind << 16) | ((uint32_t)m << 8) | (uint32_t)cl, lane, status);
@@ -4315,8 +4318,9 @@ __global__ __launch_bounds__(64) void k_boundary_resample(DeviceState st, const 
                 n_before = (int)wave_sum_u64(cnt);
             }
             double total = 0.0;
-            for (int m = 0; m < bg.n_mode; m++)
-                if (bg.mode_class[bg.mo(c) + m] == cl) total = total + bg.num_conc[(int64_t)c * bg.n_mode + m] * dens;
+            for (int m = 0; m < bg.n_mode; m++) // (a negative num_conc: the cell's background has no such mode)
+                if (bg.mode_class[bg.mo(c) + m] == cl && bg.num_conc[(int64_t)c * bg.n_mode + m] >= 0.0)
+                    total = total + bg.num_conc[(int64_t)c * bg.n_mode + m] * dens;
             const double mag = st.mag[(int64_t)c * C + cl];
             const double n_parts_new = total / mag;
             uint32_t w[4];
@@ -4327,7 +4331,7 @@ __global__ __launch_bounds__(64) void k_boundary_resample(DeviceState st, const 
                 wave_sync();
                 if (lane < bg.n_mode) {
                     double mean = -1.0;
-                    if (bg.mode_class[bg.mo(c) + lane] == cl) {
+                    if (bg.mode_class[bg.mo(c) + lane] == cl && bg.num_conc[(int64_t)c * bg.n_mode + lane] >= 0.0) {
                         const double cm = bg.num_conc[(int64_t)c * bg.n_mode + lane];
                         const double share = (dens * cm) / total;
                         const double n_samp_avg = share * (double)n_to_add;

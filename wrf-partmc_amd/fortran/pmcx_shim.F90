@@ -943,7 +943,9 @@ contains
        if (p /= level(c)) then
           changed = .true.
           level(c) = p
-          num_conc(:, c) = 0d0; gm(:, c) = 1d0; gs(:, c) = 0.1d0; vf(:, :, c) = 0d0; vf(1, :, c) = 1d0
+          ! (-1: the cell's distribution does not have the mode -- nothing is drawn there and no
+          ! weight is prepared for it, as when the reference loops over the modes the cell has)
+          num_conc(:, c) = -1d0; gm(:, c) = 1d0; gs(:, c) = 0.1d0; vf(:, :, c) = 0d0; vf(1, :, c) = 1d0
           cls(:, c) = 0; src(:, c) = 0
           if (p > 0) then
              if (which == 0) then
@@ -1175,7 +1177,8 @@ contains
        allocate(em_rate(em_n_mode, n_cells))
        do c = 1, n_cells
           do m = 1, em_n_mode
-             em_rate(m, c) = em_num(m, c) * (em_scale(c) / height(c))
+             em_rate(m, c) = -1d0                                         ! (a mode the cell does not have)
+             if (em_num(m, c) >= 0d0) em_rate(m, c) = em_num(m, c) * (em_scale(c) / height(c))
           end do
        end do
        d_em%num_conc = c_loc(em_rate)
@@ -1229,6 +1232,11 @@ contains
        flags%ss_mode_class = c_loc(ss_class); flags%ss_mode_source = c_loc(ss_source)
     end if
 
+    ! the allow_doubling / allow_halving the reference hands to every add of particles from a
+    ! distribution (driver:207-210, 1920-1922; wrf_pmc_trans_aero.F90:1030-1032): the weight of a
+    ! class is prepared for the add; it stays in force for the transport driver's boundary refill
+    call pmcx_die(pmcx_set_weight_preparation(ctx, 1, merge(1, 0, grid%allow_doubling), &
+         merge(1, 0, grid%allow_halving)), 'pmcx_set_weight_preparation')
     call pmcx_die(pmcx_timestep(ctx, flags), 'pmcx_timestep')
     ! the reference aborts inside PartMC; here a cell's status bits say what went wrong
     allocate(ns(n_cells), nc(n_cells), st(n_cells))
@@ -1416,7 +1424,7 @@ contains
              end do
              allocate(conc(nm, n_res), gm(nm, n_res), gs(nm, n_res), vfr(cfg%n_spec, nm, n_res), cls(nm, n_res), &
                   src(nm, n_res), dens(n_res), n_add(n_res), n_rm(n_res))
-             conc = 0d0; gm = 1d0; gs = 0.1d0; vfr = 0d0; vfr(1,:,:) = 1d0; cls = 0; src = 0
+             conc = -1d0; gm = 1d0; gs = 0.1d0; vfr = 0d0; vfr(1,:,:) = 1d0; cls = 0; src = 0   ! (-1: no such mode)
              do q = 1, n_res
                 call cell_ijk(res_c(q), i, k, j)
                 p = dist_level(size(scenario(i,k,j)%aero_dilution_time), scenario(i,k,j)%aero_dilution_time, &
