@@ -110,6 +110,7 @@ struct DeviceState {
     int32_t n_comp_max;
     // aero_state_prepare_weight_for_add in every add from a distribution (pmcx_set_weight_preparation)
     int32_t prep_on, prep_doubling, prep_halving;
+    int32_t *prep_resume; // [1 + 5 n_cells]: count, then {cell, position, n_emit, n_dil_in, n_dil_out} (k_scenario_update)
     uint64_t *comp_src;  // [n_cells][cap]
     double *comp_time;   // [n_cells][cap][n_comp_max]
     uint64_t *mlog;      // [n_cells][max_events] pn | po << 16 | (pn is the first candidate) << 32

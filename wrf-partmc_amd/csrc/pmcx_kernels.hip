@@ -3154,6 +3154,9 @@ struct AeroDistDev {
 //   transport's preweight: the class; an add: SCALE_ADD | kind << 16 | mode << 8 | class).
 // Returns the number removed or added.  The caller has applied the event log.
 constexpr uint32_t SCALE_ADD = 0x4000000u;
+// COPIES = false: the caller only ever thins (the transport's preweight) and is spared the other
+// branch's code and registers.
+template <bool COPIES>
 __device__ int scale_weight_wave(const DeviceState &st, int c, int cl, double ratio, int allow_doubling,
                                  int allow_halving, uint64_t seed, uint32_t step, uint32_t bkey, int lane,
                                  int &status)
@@ -3213,7 +3216,7 @@ __device__ int scale_weight_wave(const DeviceState &st, int c, int cl, double ra
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
         if (lane == 0) st.n_part[c] = n_live - changed;
-    } else if (ratio < 1.0 && (allow_doubling || n_before == 0)) {
+    } else if (COPIES && ratio < 1.0 && (allow_doubling || n_before == 0)) {
         const double x = 1.0 / ratio, x_fl = (double)(int64_t)x;
         // how many copies a class member gets (its uniform is keyed by its rank: the same in both passes)
         auto dups_of = [&](int wc, uint32_t rank) -> uint32_t {
@@ -3276,12 +3279,13 @@ __device__ int scale_weight_wave(const DeviceState &st, int c, int cl, double ra
 }
 
 // aero_state_prepare_weight_for_add [upstream, uncited]: about n_add particles are going to join
-// class cl; if that leaves the class outside [n_ideal / 2, 2 n_ideal] its weight is scaled so that
-// it comes to n_ideal (pmcx_set_weight_preparation; off: nothing happens)
-__device__ void prepare_weight_for_add(const DeviceState &st, int c, int cl, double n_add, uint64_t seed,
-                                       uint32_t step, uint32_t bkey, int lane, int &status)
+// class cl; if that leaves the class outside [n_ideal / 2, 2 n_ideal] its weight is scaled by
+// ratio = (n + n_add) / n_ideal so that it comes to n_ideal (pmcx_set_weight_preparation).  Is a
+// scaling due -- and would aero_state_scale_weight act on it with the flags as they are?
+__device__ __forceinline__ bool weight_preparation_due(const DeviceState &st, int c, int cl, double n_add, int lane,
+                                                       double &ratio)
 {
-    if (!st.prep_on) return;
+    if (!st.prep_on) return false;
     const int64_t cb = (int64_t)c * st.cap;
     int n_cls = st.n_part[c];
     if (st.n_class > 1) {
@@ -3291,31 +3295,45 @@ __device__ void prepare_weight_for_add(const DeviceState &st, int c, int cl, dou
         n_cls = (int)wave_sum_u64(cnt);
     }
     const double n_new = (double)n_cls + n_add, ideal = st.n_ideal[(int64_t)c * st.n_class + cl];
-    if (n_new == 0.0 || !(ideal > 0.0)) return;
-    if (n_new < ideal / 2.0 || n_new > ideal * 2.0)
-        scale_weight_wave(st, c, cl, n_new / ideal, st.prep_doubling, st.prep_halving, seed, step, bkey, lane, status);
+    if (n_new == 0.0 || !(ideal > 0.0)) return false;
+    if (!(n_new < ideal / 2.0 || n_new > ideal * 2.0)) return false;
+    ratio = n_new / ideal;
+    return (ratio > 1.0 && (st.prep_halving || n_cls == 0)) || (ratio < 1.0 && (st.prep_doubling || n_cls == 0));
 }
 
 // appends Poisson(num_conc*factor/magnitude) particles per mode; returns how many
 // means != nullptr: the Poisson mean of every mode is given (negative: the mode is skipped)
+// Modes m_first .. are taken.  The weight preparation of a mode (weight_preparation_due) is a whole-
+// cell pass on the few cells that need one, and its code in every cell's straight path cost the
+// scenario update four fifths of its speed: HEAVY = false stops at such a mode (stop_at = its
+// index) and the caller hands the cell to the HEAVY = true instance of itself, which scales the
+// weight and goes on from there.
+template <bool HEAVY>
 __device__ int add_dist_sample(const DeviceState &st, int c, const AeroDistDev &d, double factor,
                                uint32_t kind, double create_time, uint64_t seed, uint32_t step,
-                               int &status, int lane, const double *means = nullptr)
+                               int &status, int lane, const double *means, int m_first, int &stop_at)
 {
     const int64_t cb = (int64_t)c * st.cap;
     const uint32_t cell_id = cell_gid(st, c);
     const double *mag = st.mag + (int64_t)c * st.n_class;
     const int64_t mo = d.mo(c);
     int added = 0;
-    for (int m = 0; m < d.n_mode; m++) {
+    stop_at = -1;
+    for (int m = m_first; m < d.n_mode; m++) {
         uint32_t w[4];
         const int cl = d.mode_class[mo + m];
         // a negative num_conc: the cell's distribution does not have this mode (a cell without
         // emissions, land under the sea-salt source) -- nothing is drawn, no weight is prepared
         if (!means && d.num_conc[(int64_t)c * d.n_mode + m] < 0.0) continue; // (uniform over the wavefront)
-        if (!means) // adjust the weight if necessary, then the mean at the weight that holds now
-            prepare_weight_for_add(st, c, cl, d.num_conc[(int64_t)c * d.n_mode + m] * factor / ld_f64(&mag[cl]), seed,
-                                   step, SCALE_ADD | (kind << 16) | ((uint32_t)m << 8) | (uint32_t)cl, lane, status);
+        if (!means) { // adjust the weight if necessary, then the mean at the weight that holds now
+            double ratio = 1.0;
+            if (weight_preparation_due(st, c, cl, d.num_conc[(int64_t)c * d.n_mode + m] * factor / ld_f64(&mag[cl]), lane,
+                                       ratio)) { // (uniform over the wavefront)
+                if (!HEAVY) { stop_at = m; return added; }
+                scale_weight_wave<true>(st, c, cl, ratio, st.prep_doubling, st.prep_halving, seed, step,
+                                        SCALE_ADD | (kind << 16) | ((uint32_t)m << 8) | (uint32_t)cl, lane, status);
+            }
+        }
         const double mean = means ? means[m] : d.num_conc[(int64_t)c * d.n_mode + m] * factor / ld_f64(&mag[cl]);
         if (means && mean < 0.0) continue; // (uniform over the wavefront)
         rng_block(seed, cell_id, step, (kind << 8) | (uint32_t)m, SITE_EMIT_N, 0, w);
@@ -3363,57 +3381,68 @@ __device__ int add_dist_sample(const DeviceState &st, int c, const AeroDistDev &
     return added;
 }
 
-__global__ __launch_bounds__(64) void k_scenario_update(DeviceState st, double dt, double create_time,
-                                                        uint64_t seed, uint32_t step,
-                                                        AeroDistDev emission, const double *dilution_rate,
-                                                        AeroDistDev background, int32_t *n_emit,
-                                                        int32_t *n_dil_in, int32_t *n_dil_out,
-                                                        uint32_t emit_kind)
+// HEAVY = false: one wavefront per cell of the block; a cell whose next mode calls for a weight
+// preparation stops there and leaves a record {cell, position, n_emit, n_dil_in, n_dil_out} in
+// st.prep_resume.  HEAVY = true: one wavefront per record, from that position on (position: the
+// emission mode to go on with, or 512 + the background mode when the dilution is behind it).
+template <bool HEAVY>
+__device__ __forceinline__ void scenario_cell(const DeviceState &st, int c, int pos, int ne, int ni, int no, double dt,
+                                              double create_time, uint64_t seed, uint32_t step,
+                                              const AeroDistDev &emission, const double *dilution_rate,
+                                              const AeroDistDev &background, int32_t *n_emit, int32_t *n_dil_in,
+                                              int32_t *n_dil_out, uint32_t emit_kind, int lane)
 {
-    const int lane = threadIdx.x;
-    const int c = blockIdx.x;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    int status = 0;
+  do {
     const int64_t cb = (int64_t)c * st.cap;
     const uint32_t cell_id = cell_gid(st, c);
-    const uint64_t lt = (1ull << lane) - 1ull;
-    int status = 0, ne = 0, ni = 0, no = 0;
-    if (!in_loop(st, c)) {
+    // the cell goes to the other instance from position p on
+    auto hand_over = [&](int p) {
         if (lane == 0) {
-            if (n_emit) n_emit[c] = 0;
-            if (n_dil_in) n_dil_in[c] = 0;
-            if (n_dil_out) n_dil_out[c] = 0;
+            int32_t *rec = st.prep_resume + 1 + 5 * (int64_t)atomicAdd(&st.prep_resume[0], 1);
+            rec[0] = c; rec[1] = p; rec[2] = ne; rec[3] = ni; rec[4] = no;
+            if (status) atomicOr(&st.status[c], status);
         }
-        return;
-    }
+    };
     apply_event_log(st, c, lane);
-    if (emission.n_mode > 0)
-        ne = add_dist_sample(st, c, emission, dt, emit_kind, create_time, seed, step, status, lane);
+    int stop = -1;
+    if (pos < 512 && emission.n_mode > 0) {
+        ne += add_dist_sample<HEAVY>(st, c, emission, dt, emit_kind, create_time, seed, step, status, lane, nullptr, pos, stop);
+        if (!HEAVY && stop >= 0) { hand_over(stop); break; }
+    }
     const double rate = dilution_rate ? dilution_rate[c] : 0.0;
     if (rate > 0.0) {
         const double p_loss = 1.0 - det_exp(-rate * dt);
-        const int n_hi = st.n_hi[c];
-        uint32_t rank0 = 0;
-        for (int i0 = 0; i0 < n_hi; i0 += 64) {
-            const int i = i0 + lane;
-            const int wc = i < n_hi ? live_class_c(st, cb, i) : -1;
-            const uint64_t mlive = __ballot(wc >= 0);
-            bool drop = false;
-            if (wc >= 0) {
-                uint32_t w[4];
-                rng_block(seed, cell_id, step, rank0 + (uint32_t)__popcll(mlive & lt), SITE_DILUTE, 0, w);
-                drop = u53(w[0], w[1]) < p_loss;
+        if (pos < 512) {
+            const int n_hi = st.n_hi[c];
+            uint32_t rank0 = 0;
+            for (int i0 = 0; i0 < n_hi; i0 += 64) {
+                const int i = i0 + lane;
+                const int wc = i < n_hi ? live_class_c(st, cb, i) : -1;
+                const uint64_t mlive = __ballot(wc >= 0);
+                bool drop = false;
+                if (wc >= 0) {
+                    uint32_t w[4];
+                    rng_block(seed, cell_id, step, rank0 + (uint32_t)__popcll(mlive & lt), SITE_DILUTE, 0, w);
+                    drop = u53(w[0], w[1]) < p_loss;
+                }
+                if (drop) mark_dead(st, cb, i);
+                no += __popcll(__ballot(drop));
+                rank0 += (uint32_t)__popcll(mlive);
             }
-            if (drop) mark_dead(st, cb, i);
-            no += __popcll(__ballot(drop));
-            rank0 += (uint32_t)__popcll(mlive);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wave_sync();
+            if (lane == 0) st.n_part[c] = st.n_part[c] - no;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __threadfence_block();
+            wave_sync();
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wave_sync();
-        if (lane == 0) st.n_part[c] = st.n_part[c] - no;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __threadfence_block();
-        wave_sync();
-        if (background.n_mode > 0)
-            ni = add_dist_sample(st, c, background, p_loss, 1u, create_time, seed, step, status, lane);
+        if (background.n_mode > 0) {
+            ni += add_dist_sample<HEAVY>(st, c, background, p_loss, 1u, create_time, seed, step, status, lane, nullptr,
+                                         pos >= 512 ? pos - 512 : 0, stop);
+            if (!HEAVY && stop >= 0) { hand_over(512 + stop); break; }
+        }
         const int hi = st.n_hi[c], live = st.n_part[c];
         if ((hi - live) * st.compact_den > hi) compact_wave(st, c, lane);
     }
@@ -3422,6 +3451,38 @@ __global__ __launch_bounds__(64) void k_scenario_update(DeviceState st, double d
         if (n_dil_in) n_dil_in[c] = ni;
         if (n_dil_out) n_dil_out[c] = no;
         if (status) atomicOr(&st.status[c], status);
+    }
+  } while (false);
+}
+
+template <bool HEAVY>
+__global__ __launch_bounds__(64) void k_scenario_update(DeviceState st, double dt, double create_time,
+                                                        uint64_t seed, uint32_t step,
+                                                        AeroDistDev emission, const double *dilution_rate,
+                                                        AeroDistDev background, int32_t *n_emit,
+                                                        int32_t *n_dil_in, int32_t *n_dil_out,
+                                                        uint32_t emit_kind)
+{
+    const int lane = threadIdx.x;
+    if (!HEAVY) {
+        const int c = blockIdx.x;
+        if (!in_loop(st, c)) {
+            if (lane == 0) {
+                if (n_emit) n_emit[c] = 0;
+                if (n_dil_in) n_dil_in[c] = 0;
+                if (n_dil_out) n_dil_out[c] = 0;
+            }
+            return;
+        }
+        scenario_cell<false>(st, c, 0, 0, 0, 0, dt, create_time, seed, step, emission, dilution_rate, background, n_emit,
+                             n_dil_in, n_dil_out, emit_kind, lane);
+        return;
+    }
+    const int n_work = st.prep_resume[0];
+    for (int wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+        const int32_t *rec = st.prep_resume + 1 + 5 * (int64_t)wi;
+        scenario_cell<true>(st, rec[0], rec[1], rec[2], rec[3], rec[4], dt, create_time, seed, step, emission,
+                            dilution_rate, background, n_emit, n_dil_in, n_dil_out, emit_kind, lane);
     }
 }
 
@@ -4307,7 +4368,8 @@ __global__ __launch_bounds__(64) void k_boundary_resample(DeviceState st, const 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __threadfence_block();
         wave_sync();
-        na = add_dist_sample(st, c, bg, dens, 3u, create_time, seed, step, status, lane);
+        int stop_ = -1; // (a handful of boundary cells: the whole of it here)
+        na = add_dist_sample<true>(st, c, bg, dens, 3u, create_time, seed, step, status, lane, nullptr, 0, stop_);
     } else {
         for (int cl = 0; cl < C; cl++) {
             const int n_hi = st.n_hi[c];
@@ -4341,7 +4403,8 @@ __global__ __launch_bounds__(64) void k_boundary_resample(DeviceState st, const 
                     s_means[lane] = mean;
                 }
                 lds_sync();
-                na += add_dist_sample(st, c, bg, dens, 3u, create_time, seed, step, status, lane, s_means);
+                int stop_ = -1;
+                na += add_dist_sample<false>(st, c, bg, dens, 3u, create_time, seed, step, status, lane, s_means, 0, stop_);
             } else {
                 const int m_rm = -n_to_add < n_before ? -n_to_add : n_before;
                 int t0 = 0, k = 0; // class members seen, removed so far (uniform)
@@ -4585,7 +4648,7 @@ __global__ __launch_bounds__(64) void k_preweight_scale(DeviceState st, Preweigh
         if (!(n_parts_new > 2.0 * ideal_n)) continue; // (uniform over the wavefront)
         // aero_state_scale_weight(weight_ratio > 1, .true., .true.) (:1390-1393); a cell past its
         // tombstone threshold afterwards: the k_compact that follows
-        removed += (uint32_t)scale_weight_wave(st, c, cl, n_parts_new / ideal_n, 1, 1, seed, step, (uint32_t)cl, lane,
+        removed += (uint32_t)scale_weight_wave<false>(st, c, cl, n_parts_new / ideal_n, 1, 1, seed, step, (uint32_t)cl, lane,
                                                status);
     }
     if (lane == 0 && a.n_removed) a.n_removed[c] = (int32_t)removed;
@@ -5549,8 +5612,12 @@ hipError_t launch_scenario_update(const DeviceState &st, double dt, double creat
                             em->mode_class, em->mode_source, em->per_cell};
     if (bg) b = AeroDistDev{bg->n_mode, bg_conc, bg->ln_gm_radius, bg->ln_gsd, bg->vol_frac,
                             bg->mode_class, bg->mode_source, bg->per_cell};
-    hipLaunchKernelGGL(k_scenario_update, dim3(st.n_cells), dim3(64), 0, s, st, dt, create_time,
+    if (st.prep_on) (void)hipMemsetAsync(st.prep_resume, 0, sizeof(int32_t), s);
+    hipLaunchKernelGGL(k_scenario_update<false>, dim3(st.n_cells), dim3(64), 0, s, st, dt, create_time,
                        seed, step, e, dilution_rate, b, n_emit, n_dil_in, n_dil_out, emit_kind);
+    if (st.prep_on) // the cells that stopped at a mode whose weight wants preparing: the rest of their update
+        hipLaunchKernelGGL(k_scenario_update<true>, dim3(st.n_cells < 2048 ? st.n_cells : 2048), dim3(64), 0, s, st, dt,
+                           create_time, seed, step, e, dilution_rate, b, n_emit, n_dil_in, n_dil_out, emit_kind);
     return hipGetLastError();
 }
 hipError_t launch_gas_update(const GasScenarioDev &g, double *mix_rat, const double *temp,
