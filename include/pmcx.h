@@ -145,7 +145,10 @@ int pmcx_set_n_part_ideal(pmcx_ctx *ctx, const double *n_ideal);
  * (:1920-1922), the refill of an emptied boundary cell (wrf_pmc_trans_aero.F90:1030-1032).
  * on != 0: before a mode's Poisson sample the class's weight is prepared for the add
  * (aero_state_prepare_weight_for_add, [UPSTREAM-UNCITED]): with n the class's particles and
- * n_add the sample's mean at the present weight, n + n_add outside [n_ideal / 2, 2 n_ideal]
+ * n_add the sample's mean at the present weight times the add's characteristic_factor
+ * (max(1, min(3600 s, elapsed_time)) / dt in the scenario update and the sea-salt source,
+ * wrf_pmc_driver.F90:1794, 1916-1922; 1 in the boundary refill, wrf_pmc_trans_aero.F90:1016,
+ * 1031), n + n_add outside [n_ideal / 2, 2 n_ideal]
  * scales the weight by ratio = (n + n_add) / n_ideal (aero_state_scale_weight: ratio > 1 and
  * allow_halving, or an empty class -- exactly prob_round(n (1 - 1 / ratio)) particles leave, a
  * uniformly random subset; ratio < 1 and allow_doubling, or an empty class -- every particle

@@ -933,7 +933,7 @@ static void prepare_weight_for_add(pmco_cell *c, int cl, double n_add, uint64_t 
 }
 
 /* means != NULL: the Poisson mean of every mode is given (negative: the mode is skipped) */
-static int add_dist_sample_means(pmco_cell *c, const pmco_aero_dist *d, double factor, const double *means,
+static int add_dist_sample_means(pmco_cell *c, const pmco_aero_dist *d, double factor, double char_factor, const double *means,
                                  int kind, double create_time, uint64_t seed, uint32_t cell_id,
                                  uint32_t step, int64_t *next_id, int *status)
 {
@@ -943,7 +943,7 @@ static int add_dist_sample_means(pmco_cell *c, const pmco_aero_dist *d, double f
         const int cl = d->mode_class[m];
         if (!means && d->num_conc[m] < 0.0) continue; /* the cell's distribution does not have this mode */
         if (!means) /* adjust the weight if necessary, then the mean at the weight that holds now */
-            prepare_weight_for_add(c, cl, d->num_conc[m] * factor / c->mag[cl], seed, cell_id, step,
+            prepare_weight_for_add(c, cl, (d->num_conc[m] * factor / c->mag[cl]) * char_factor, seed, cell_id, step,
                                    PMCO_SCALE_ADD | ((uint32_t)kind << 16) | ((uint32_t)m << 8) | (uint32_t)cl,
                                    next_id, status);
         const double mean = means ? means[m] : d->num_conc[m] * factor / c->mag[cl];
@@ -977,11 +977,23 @@ static int add_dist_sample_means(pmco_cell *c, const pmco_aero_dist *d, double f
     return added;
 }
 
-static int add_dist_sample(pmco_cell *c, const pmco_aero_dist *d, double factor, int kind,
+/* char_factor: the characteristic_factor of the add -- the weight is prepared for char_factor times
+ * the sample's mean, the particles expected over the sampling timescale rather than over this one
+ * call (wrf_pmc_driver.F90:1794, 1916-1922: max(1, min(3600 s, elapsed_time)) / delta_t in the
+ * sea-salt source, a copy of the library's emission code; 1 in the boundary refill,
+ * wrf_pmc_trans_aero.F90:1016, 1031) */
+static int add_dist_sample(pmco_cell *c, const pmco_aero_dist *d, double factor, double char_factor, int kind,
                            double create_time, uint64_t seed, uint32_t cell_id, uint32_t step,
                            int64_t *next_id, int *status)
 {
-    return add_dist_sample_means(c, d, factor, NULL, kind, create_time, seed, cell_id, step, next_id, status);
+    return add_dist_sample_means(c, d, factor, char_factor, NULL, kind, create_time, seed, cell_id, step, next_id,
+                                 status);
+}
+static double characteristic_factor(double elapsed_time, double dt)
+{
+    double t = elapsed_time < 3600.0 ? elapsed_time : 3600.0;
+    if (t < 1.0) t = 1.0;
+    return t / dt;
 }
 
 int pmco_scenario_update(pmco_cell *c, double dt, double create_time, uint64_t seed,
@@ -994,7 +1006,7 @@ int pmco_scenario_update(pmco_cell *c, double dt, double create_time, uint64_t s
     *n_emit = *n_dil_in = *n_dil_out = 0;
     *c->sort_valid = 0;
     if (emission && emission->n_mode > 0)
-        *n_emit = add_dist_sample(c, emission, dt, 0, create_time, seed, cell_id, step, next_id,
+        *n_emit = add_dist_sample(c, emission, dt, characteristic_factor(create_time, dt), 0, create_time, seed, cell_id, step, next_id,
                                   &status);
     if (dilution_rate > 0.0) {
         const double p_loss = 1.0 - pmco_exp(-dilution_rate * dt);
@@ -1010,7 +1022,7 @@ int pmco_scenario_update(pmco_cell *c, double dt, double create_time, uint64_t s
         free(dead);
         *n_dil_out = nd;
         if (background && background->n_mode > 0)
-            *n_dil_in = add_dist_sample(c, background, p_loss, 1, create_time, seed, cell_id, step,
+            *n_dil_in = add_dist_sample(c, background, p_loss, characteristic_factor(create_time, dt), 1, create_time, seed, cell_id, step,
                                         next_id, &status);
     }
     return status;
@@ -1081,7 +1093,7 @@ int pmco_seasalt_emissions(pmco_cell *c, double dt, double create_time, uint64_t
     }
     pmco_aero_dist d = {M, rate, lg, ls, vf, cls, src};
     *c->sort_valid = 0;
-    *n_emit = add_dist_sample(c, &d, dt, 2, create_time, seed, cell_id, step, next_id, &status);
+    *n_emit = add_dist_sample(c, &d, dt, characteristic_factor(create_time, dt), 2, create_time, seed, cell_id, step, next_id, &status);
     free(vf);
     return status;
 }
@@ -1771,7 +1783,7 @@ int pmco_boundary_resample(pmco_cell *c, int throw_away, const pmco_aero_dist *b
     if (throw_away) {
         *n_removed = *c->n_part;
         *c->n_part = 0;                                             /* aero_state_zero */
-        *n_added = add_dist_sample(c, bg, density, 3, create_time, seed, cell_id, step, next_id, &status);
+        *n_added = add_dist_sample(c, bg, density, 1.0, 3, create_time, seed, cell_id, step, next_id, &status);
         return status;
     }
     double means[64];
@@ -1796,7 +1808,7 @@ int pmco_boundary_resample(pmco_cell *c, int throw_away, const pmco_aero_dist *b
                 const double threshold = (density * bg->num_conc[m] / n_samp_avg) * .1;
                 if (c->mag[cl] > threshold) means[m] = n_samp_avg;
             }
-            *n_added += add_dist_sample_means(c, bg, density, means, 3, create_time, seed, cell_id, step,
+            *n_added += add_dist_sample_means(c, bg, density, 1.0, means, 3, create_time, seed, cell_id, step,
                                               next_id, &status);
         } else {
             const int n = *c->n_part;

@@ -616,7 +616,7 @@ def test_weight_preparation_of_an_add(oracle):
         # 1.9 ideal present, 0.5 ideal on their way: above 2 ideal -> thinned to the ideal count
         oc = cell(760, seed=t)
         em = [dict(mode, num_conc=0.5 * ideal * mag0 / 10.0)]           # rate: mean = rate dt / magnitude
-        st, nid, ne, ni, no = oc.scenario_update(10.0, 5.0, t, 0, 3, em, 0.0, None, 1)
+        st, nid, ne, ni, no = oc.scenario_update(10.0, 10.0, t, 0, 3, em, 0.0, None, 1)
         n = int(oc.n_part[0])
         assert st == 0 and oc.mag[0] == mag0 * 2.4                      # ratio = (760 + 200) / 400
         kept = n - ne
@@ -627,7 +627,7 @@ def test_weight_preparation_of_an_add(oracle):
         oc = cell(80, seed=100 + t)
         before = oc.vtot[:80].copy()
         em = [dict(mode, num_conc=0.1 * ideal * mag0 / 10.0)]
-        st, nid, ne, ni, no = oc.scenario_update(10.0, 5.0, t, 0, 3, em, 0.0, None, 1)
+        st, nid, ne, ni, no = oc.scenario_update(10.0, 10.0, t, 0, 3, em, 0.0, None, 1)
         n = int(oc.n_part[0])
         assert st == 0 and oc.mag[0] == mag0 * (120.0 / 400.0)
         copies = n - ne - 80
@@ -649,13 +649,21 @@ def test_weight_preparation_of_an_add(oracle):
         assert abs(v[:, 0].mean() - ideal) < 4 * math.sqrt(ideal / len(v)) + 1, (k, v[:, 0].mean())
     # flags: with particles present a scaling needs its flag; off by default
     oc = cell(760, flags=(True, False))
-    st, nid, ne, *_ = oc.scenario_update(10.0, 5.0, 1, 0, 3, [dict(mode, num_conc=0.5 * ideal * mag0 / 10.0)], 0.0, None, 1)
+    st, nid, ne, *_ = oc.scenario_update(10.0, 10.0, 1, 0, 3, [dict(mode, num_conc=0.5 * ideal * mag0 / 10.0)], 0.0, None, 1)
     assert oc.mag[0] == mag0 and int(oc.n_part[0]) == 760 + ne
     oc = cell(80, flags=(False, True))
-    st, nid, ne, *_ = oc.scenario_update(10.0, 5.0, 1, 0, 3, [dict(mode, num_conc=0.1 * ideal * mag0 / 10.0)], 0.0, None, 1)
+    st, nid, ne, *_ = oc.scenario_update(10.0, 10.0, 1, 0, 3, [dict(mode, num_conc=0.1 * ideal * mag0 / 10.0)], 0.0, None, 1)
     assert oc.mag[0] == mag0 and int(oc.n_part[0]) == 80 + ne
+    # the characteristic factor: the weight is prepared for the particles expected over the sampling
+    # timescale, max(1, min(3600 s, elapsed_time)) / delta_t times the call's mean (driver:1916-1918)
+    oc = cell(760)
+    st, nid, ne, *_ = oc.scenario_update(10.0, 7200.0, 1, 0, 3, [dict(mode, num_conc=0.5 * ideal * mag0 / 10.0)], 0.0, None, 1)
+    assert oc.mag[0] == mag0 * ((760 + 200 * 360.0) / ideal) and int(oc.n_part[0]) - ne in (4, 5)
+    oc = cell(760)
+    st, nid, ne, *_ = oc.scenario_update(10.0, 0.0, 1, 0, 3, [dict(mode, num_conc=0.5 * ideal * mag0 / 10.0)], 0.0, None, 1)
+    assert oc.mag[0] == mag0 and int(oc.n_part[0]) == 760 + ne          # 760 + 200 / 10 stays inside 2 ideal
     oc = cell(760, prep=False)
-    st, nid, ne, *_ = oc.scenario_update(10.0, 5.0, 1, 0, 3, [dict(mode, num_conc=0.5 * ideal * mag0 / 10.0)], 0.0, None, 1)
+    st, nid, ne, *_ = oc.scenario_update(10.0, 10.0, 1, 0, 3, [dict(mode, num_conc=0.5 * ideal * mag0 / 10.0)], 0.0, None, 1)
     assert oc.mag[0] == mag0 and int(oc.n_part[0]) == 760 + ne
 
 

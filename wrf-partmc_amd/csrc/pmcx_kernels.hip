@@ -3311,7 +3311,8 @@ __device__ __forceinline__ bool weight_preparation_due(const DeviceState &st, in
 template <bool HEAVY>
 __device__ int add_dist_sample(const DeviceState &st, int c, const AeroDistDev &d, double factor,
                                uint32_t kind, double create_time, uint64_t seed, uint32_t step,
-                               int &status, int lane, const double *means, int m_first, int &stop_at)
+                               int &status, int lane, const double *means, int m_first, int &stop_at,
+                               double char_factor = 1.0)
 {
     const int64_t cb = (int64_t)c * st.cap;
     const uint32_t cell_id = cell_gid(st, c);
@@ -3327,7 +3328,9 @@ __device__ int add_dist_sample(const DeviceState &st, int c, const AeroDistDev &
         if (!means && d.num_conc[(int64_t)c * d.n_mode + m] < 0.0) continue; // (uniform over the wavefront)
         if (!means) { // adjust the weight if necessary, then the mean at the weight that holds now
             double ratio = 1.0;
-            if (weight_preparation_due(st, c, cl, d.num_conc[(int64_t)c * d.n_mode + m] * factor / ld_f64(&mag[cl]), lane,
+            // (for char_factor times the mean: the particles expected over the sampling timescale)
+            if (weight_preparation_due(st, c, cl,
+                                       (d.num_conc[(int64_t)c * d.n_mode + m] * factor / ld_f64(&mag[cl])) * char_factor, lane,
                                        ratio)) { // (uniform over the wavefront)
                 if (!HEAVY) { stop_at = m; return added; }
                 scale_weight_wave<true>(st, c, cl, ratio, st.prep_doubling, st.prep_halving, seed, step,
@@ -3407,8 +3410,11 @@ __device__ __forceinline__ void scenario_cell(const DeviceState &st, int c, int 
     };
     apply_event_log(st, c, lane);
     int stop = -1;
+    // the add's characteristic_factor (wrf_pmc_driver.F90:1794, 1916-1918): sample timescale / step
+    const double cf = fmax(1.0, fmin(3600.0, create_time)) / dt;
     if (pos < 512 && emission.n_mode > 0) {
-        ne += add_dist_sample<HEAVY>(st, c, emission, dt, emit_kind, create_time, seed, step, status, lane, nullptr, pos, stop);
+        ne += add_dist_sample<HEAVY>(st, c, emission, dt, emit_kind, create_time, seed, step, status, lane, nullptr, pos, stop,
+                                     cf);
         if (!HEAVY && stop >= 0) { hand_over(stop); break; }
     }
     const double rate = dilution_rate ? dilution_rate[c] : 0.0;
@@ -3440,7 +3446,7 @@ __device__ __forceinline__ void scenario_cell(const DeviceState &st, int c, int 
         }
         if (background.n_mode > 0) {
             ni += add_dist_sample<HEAVY>(st, c, background, p_loss, 1u, create_time, seed, step, status, lane, nullptr,
-                                         pos >= 512 ? pos - 512 : 0, stop);
+                                         pos >= 512 ? pos - 512 : 0, stop, cf);
             if (!HEAVY && stop >= 0) { hand_over(512 + stop); break; }
         }
         const int hi = st.n_hi[c], live = st.n_part[c];
