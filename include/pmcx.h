@@ -299,11 +299,17 @@ typedef struct {
  * forgotten. */
 int pmcx_set_aero_scenario_modes(pmcx_ctx *ctx, int32_t which, const pmcx_aero_dist *dist);
 
+/* height / old_height [n_cells] = env_state%height / old_env_state%height (the reference hands both
+ * states to the update, wrf_pmc_driver.F90:207-209; NULL: unchanged): where the layer grew the
+ * dilution's p = exp(-rate dt) is multiplied by old_height / height, as in the gas update --
+ * entrainment of background air; a particle is lost with probability 1 - p and the background
+ * is sampled with that factor. */
 int pmcx_scenario_update_aero_state(pmcx_ctx *ctx, double dt, double elapsed_time, uint64_t seed,
                                     uint32_t step, const pmcx_aero_dist *emission,
                                     const double *dilution_rate,
                                     const pmcx_aero_dist *background, int32_t *n_emit,
-                                    int32_t *n_dil_in, int32_t *n_dil_out);
+                                    int32_t *n_dil_in, int32_t *n_dil_out,
+                                    const double *height, const double *old_height);
 
 /* seasalt_emissions (interface/wrf_pmc_driver.F90:212-223, 1767-1924) on every cell with
  * ocean_surface[c] != 0 (the reference: lowest level, grid%xland > 1.5): log-normal modes of Na

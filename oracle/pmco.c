@@ -1002,14 +1002,30 @@ int pmco_scenario_update(pmco_cell *c, double dt, double create_time, uint64_t s
                          int64_t *next_id, int32_t *n_emit, int32_t *n_dil_in,
                          int32_t *n_dil_out)
 {
+    return pmco_scenario_update_h(c, dt, create_time, seed, cell_id, step, emission, dilution_rate, background,
+                                  next_id, n_emit, n_dil_in, n_dil_out, 0.0, 0.0);
+}
+
+/* the same with env_state%height and old_env_state%height (the reference hands both states to the
+ * update, wrf_pmc_driver.F90:207-209): where the layer grew, p = exp(-rate dt) is multiplied by
+ * old_height / height [upstream, uncited; as scenario_update_gas_state] */
+int pmco_scenario_update_h(pmco_cell *c, double dt, double create_time, uint64_t seed,
+                           uint32_t cell_id, uint32_t step, const pmco_aero_dist *emission,
+                           double dilution_rate, const pmco_aero_dist *background,
+                           int64_t *next_id, int32_t *n_emit, int32_t *n_dil_in,
+                           int32_t *n_dil_out, double height, double old_height)
+{
     int status = 0;
     *n_emit = *n_dil_in = *n_dil_out = 0;
     *c->sort_valid = 0;
     if (emission && emission->n_mode > 0)
         *n_emit = add_dist_sample(c, emission, dt, characteristic_factor(create_time, dt), 0, create_time, seed, cell_id, step, next_id,
                                   &status);
-    if (dilution_rate > 0.0) {
-        const double p_loss = 1.0 - pmco_exp(-dilution_rate * dt);
+    const int grew = height > old_height && old_height > 0.0;
+    if (dilution_rate > 0.0 || grew) {
+        double p_keep = pmco_exp(-dilution_rate * dt);
+        if (grew) p_keep = p_keep * old_height / height;
+        const double p_loss = 1.0 - p_keep;
         const int n = *c->n_part;
         unsigned char *dead = (unsigned char *)calloc((size_t)(n > 0 ? n : 1), 1);
         int nd = 0;

@@ -206,6 +206,12 @@ int pmco_scenario_update(pmco_cell *c, double dt, double create_time, uint64_t s
                          int64_t *next_id, int32_t *n_emit, int32_t *n_dil_in,
                          int32_t *n_dil_out);
 
+int pmco_scenario_update_h(pmco_cell *c, double dt, double create_time, uint64_t seed,
+                           uint32_t cell_id, uint32_t step, const pmco_aero_dist *emission,
+                           double dilution_rate, const pmco_aero_dist *background,
+                           int64_t *next_id, int32_t *n_emit, int32_t *n_dil_in,
+                           int32_t *n_dil_out, double height, double old_height);
+
 /* seasalt_emissions (interface/wrf_pmc_driver.F90:1767-1924): the modes of the sea-salt source
  * for option 1 (Gong, the MAM3-matched pair of log-normal modes, :1834-1854) or 2 (Ovadnevaite
  * et al. 2014, five modes, :1886-1912, with the reference's fixed Re = 3.1e6, :1909), and the

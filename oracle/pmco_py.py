@@ -108,6 +108,8 @@ def lib():
         L.pmco_scenario_update.argtypes = [
             C.POINTER(CellStruct), C.c_double, C.c_double, C.c_uint64, C.c_uint32, C.c_uint32,
             C.POINTER(AeroDist), C.c_double, C.POINTER(AeroDist), _lp, _ip, _ip, _ip]
+        L.pmco_scenario_update_h.restype = C.c_int
+        L.pmco_scenario_update_h.argtypes = L.pmco_scenario_update.argtypes + [C.c_double, C.c_double]
         L.pmco_condense.restype = None
         L.pmco_condense.argtypes = [C.POINTER(CellStruct), _dp, C.c_int, C.c_double, C.c_double,
                                     C.c_int]
@@ -258,16 +260,17 @@ class Cell:
         return d, keep
 
     def scenario_update(self, dt, create_time, seed, cell_id, step, emission, dilution_rate,
-                        background, next_id):
-        """emission/background: lists of dict(num_conc, gm_radius, gsd_log10, vol_frac, wclass, source)."""
+                        background, next_id, height=0.0, old_height=0.0):
+        """emission/background: lists of dict(num_conc, gm_radius, gsd_log10, vol_frac, wclass, source).
+        height, old_height: env_state%height now and a step ago (0: unchanged)."""
         e, ke = self._dist(emission)
         b, kb = self._dist(background)
         nid = C.c_int64(next_id)
         ne, ni, no = C.c_int32(0), C.c_int32(0), C.c_int32(0)
-        st = lib().pmco_scenario_update(C.byref(self.view()), dt, create_time, seed, cell_id, step,
-                                        C.byref(e) if e else None, dilution_rate,
-                                        C.byref(b) if b else None, C.byref(nid), C.byref(ne),
-                                        C.byref(ni), C.byref(no))
+        st = lib().pmco_scenario_update_h(C.byref(self.view()), dt, create_time, seed, cell_id, step,
+                                          C.byref(e) if e else None, dilution_rate,
+                                          C.byref(b) if b else None, C.byref(nid), C.byref(ne),
+                                          C.byref(ni), C.byref(no), float(height), float(old_height))
         return st, nid.value, ne.value, ni.value, no.value
 
     def boundary_copy_from(self, src, next_id):

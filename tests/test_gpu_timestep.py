@@ -109,7 +109,7 @@ def test_partmc_timestep_loop(wp, oracle):
             oe = [dict(m, num_conc=em_rate[c, j]) for j, m in enumerate(em)]
             ob = [dict(m, num_conc=bg_conc[c, j]) for j, m in enumerate(bg)]
             _, oc.next_id, _, _, _ = oc.scenario_update(dt, t, seed, oc.cell_id, k, oe, dil[c], ob,
-                                                        oc.next_id)
+                                                        oc.next_id, height[c], h_old[c])   # (the layer grows on odd steps)
             _, oc.next_id = oc.rebalance(n_ideal[c], True, True, seed, oc.cell_id, k, oc.next_id)
         ok, msg = parity.compare_state(blk, cells)
         assert ok, f"WRF step {k}: {msg}"

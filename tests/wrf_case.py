@@ -268,7 +268,7 @@ class Case:
                           for m in self.em[c][p]]
                 p = level(self.bg_time, t)
                 _, oc.next_id, _, _, _ = oc.scenario_update(self.dt, t, seed, c, wrf_step, oe, float(self.bg_dil[c, p]),
-                                                            self.bg[c][p], oc.next_id)
+                                                            self.bg[c][p], oc.next_id, float(height[c]), float(h_old[c]))
                 if self.sea_salt_opt and self.lev[c] == 0 and g["xland"][self.jj[c] + 1, self.ii[c] + 1] > 1.5:
                     u10, v10 = g["u10"][self.jj[c] + 1, self.ii[c] + 1], g["v10"][self.jj[c] + 1, self.ii[c] + 1]
                     wind = float(np.sqrt(F32(u10 * u10 + v10 * v10)))

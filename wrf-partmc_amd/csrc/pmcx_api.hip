@@ -1204,9 +1204,11 @@ int upload_dist(pmcx_ctx *ctx, const pmcx_aero_dist *d, std::vector<void *> &tmp
 int pmcx_scenario_update_aero_state(pmcx_ctx *ctx, double dt, double elapsed_time, uint64_t seed,
                                     uint32_t step, const pmcx_aero_dist *emission,
                                     const double *dilution_rate, const pmcx_aero_dist *background,
-                                    int32_t *n_emit, int32_t *n_dil_in, int32_t *n_dil_out)
+                                    int32_t *n_emit, int32_t *n_dil_in, int32_t *n_dil_out,
+                                    const double *height, const double *old_height)
 {
     if (!ctx) return PMCX_EINVAL;
+    if (!height || !old_height) height = old_height = nullptr;
     if (!ctx->aero_data_set) return fail(ctx, PMCX_ESTATE, "pmcx_set_aero_data must come first");
     if (!(dt >= 0)) return fail(ctx, PMCX_EINVAL, "dt must be non-negative");
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
@@ -1214,7 +1216,7 @@ int pmcx_scenario_update_aero_state(pmcx_ctx *ctx, double dt, double elapsed_tim
     std::vector<void *> tmp;
     auto cleanup = [&]() { for (void *p : tmp) tmp_release(ctx, p); };
     GenSpecDev ge{}, gb{};
-    double *ce = nullptr, *cbg = nullptr, *d_dil = nullptr;
+    double *ce = nullptr, *cbg = nullptr, *d_dil = nullptr, *d_h = nullptr;
     int32_t *d_cnt = nullptr;
     int rc = PMCX_OK;
     if (emission) rc = upload_dist(ctx, emission, tmp, ge, ce, 0, nullptr, 0);
@@ -1225,13 +1227,18 @@ int pmcx_scenario_update_aero_state(pmcx_ctx *ctx, double dt, double elapsed_tim
         e = tmp_malloc(ctx, (void **)&d_dil, sizeof(double) * nc);
         if (e == hipSuccess) { tmp.push_back(d_dil); e = hipMemcpyAsync(d_dil, dilution_rate, sizeof(double) * nc, hipMemcpyHostToDevice, ctx->stream); }
     }
+    if (e == hipSuccess && height) { // env_state%height, old_env_state%height: the layer's growth
+        e = tmp_malloc(ctx, (void **)&d_h, sizeof(double) * 2 * nc);
+        if (e == hipSuccess) { tmp.push_back(d_h); e = hipMemcpyAsync(d_h, height, sizeof(double) * nc, hipMemcpyHostToDevice, ctx->stream); }
+        if (e == hipSuccess) e = hipMemcpyAsync(d_h + nc, old_height, sizeof(double) * nc, hipMemcpyHostToDevice, ctx->stream);
+    }
     if (e == hipSuccess) { e = tmp_malloc(ctx, (void **)&d_cnt, sizeof(int32_t) * 3 * nc); if (e == hipSuccess) tmp.push_back(d_cnt); }
     if (e == hipSuccess && !ctx->hold_status) e = hipMemsetAsync(ctx->st.status, 0, sizeof(int32_t) * nc, ctx->stream);
     if (e == hipSuccess) {
         ProfScope ps(ctx, "scenario");
         e = launch_scenario_update(ctx->st, dt, elapsed_time, seed, step, emission ? &ge : nullptr, ce,
                                    d_dil, background ? &gb : nullptr, cbg, d_cnt, d_cnt + nc,
-                                   d_cnt + 2 * nc, ctx->stream);
+                                   d_cnt + 2 * nc, ctx->stream, 0u, d_h, d_h ? d_h + nc : nullptr);
     }
     if (e == hipSuccess && n_emit) e = hipMemcpyAsync(n_emit, d_cnt, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && n_dil_in) e = hipMemcpyAsync(n_dil_in, d_cnt + nc, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream);
@@ -2317,7 +2324,7 @@ int pmcx_timestep(pmcx_ctx *ctx, const pmcx_step_flags *f)
     if (f->aero_emission || f->aero_dilution_rate || f->aero_background) {       // driver:207-210
         rc = pmcx_scenario_update_aero_state(ctx, f->dt, f->elapsed_time, f->random_seed, wrf_step,
                                              f->aero_emission, f->aero_dilution_rate,
-                                             f->aero_background, nullptr, nullptr, nullptr);
+                                             f->aero_background, nullptr, nullptr, nullptr, f->height, f->old_height);
         if (rc) return rc;
     }
     if (f->sea_salt_opt > 0) {                                                   // driver:212-223

@@ -181,7 +181,8 @@ hipError_t launch_scenario_update(const DeviceState &st, double dt, double creat
                                   uint32_t step, const GenSpecDev *em, const double *em_conc,
                                   const double *dilution_rate, const GenSpecDev *bg,
                                   const double *bg_conc, int32_t *n_emit, int32_t *n_dil_in,
-                                  int32_t *n_dil_out, hipStream_t s, uint32_t emit_kind = 0);
+                                  int32_t *n_dil_out, hipStream_t s, uint32_t emit_kind = 0,
+                                  const double *height = nullptr, const double *old_height = nullptr);
 // (emit_kind: the RNG stream of the emission draws -- 0 the scenario's emission, 1 is the
 // background's, 2 the sea-salt source -- so that sources acting in one step stay independent)
 hipError_t launch_gas_update(const GasScenarioDev &g, double *mix_rat, const double *temp,

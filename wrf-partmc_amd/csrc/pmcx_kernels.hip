@@ -3393,7 +3393,8 @@ __device__ __forceinline__ void scenario_cell(const DeviceState &st, int c, int 
                                               double create_time, uint64_t seed, uint32_t step,
                                               const AeroDistDev &emission, const double *dilution_rate,
                                               const AeroDistDev &background, int32_t *n_emit, int32_t *n_dil_in,
-                                              int32_t *n_dil_out, uint32_t emit_kind, int lane)
+                                              int32_t *n_dil_out, uint32_t emit_kind, int lane, const double *height,
+                                              const double *old_height)
 {
     const uint64_t lt = (1ull << lane) - 1ull;
     int status = 0;
@@ -3418,8 +3419,12 @@ __device__ __forceinline__ void scenario_cell(const DeviceState &st, int c, int 
         if (!HEAVY && stop >= 0) { hand_over(stop); break; }
     }
     const double rate = dilution_rate ? dilution_rate[c] : 0.0;
-    if (rate > 0.0) {
-        const double p_loss = 1.0 - det_exp(-rate * dt);
+    // p = exp(-rate dt), times old_height / height where the layer grew (as in the gas update)
+    const bool grew = height && height[c] > old_height[c] && old_height[c] > 0.0;
+    if (rate > 0.0 || grew) {
+        double p_keep = det_exp(-rate * dt);
+        if (grew) p_keep = p_keep * old_height[c] / height[c];
+        const double p_loss = 1.0 - p_keep;
         if (pos < 512) {
             const int n_hi = st.n_hi[c];
             uint32_t rank0 = 0;
@@ -3467,7 +3472,8 @@ __global__ __launch_bounds__(64) void k_scenario_update(DeviceState st, double d
                                                         AeroDistDev emission, const double *dilution_rate,
                                                         AeroDistDev background, int32_t *n_emit,
                                                         int32_t *n_dil_in, int32_t *n_dil_out,
-                                                        uint32_t emit_kind)
+                                                        uint32_t emit_kind, const double *height,
+                                                        const double *old_height)
 {
     const int lane = threadIdx.x;
     if (!HEAVY) {
@@ -3481,14 +3487,14 @@ __global__ __launch_bounds__(64) void k_scenario_update(DeviceState st, double d
             return;
         }
         scenario_cell<false>(st, c, 0, 0, 0, 0, dt, create_time, seed, step, emission, dilution_rate, background, n_emit,
-                             n_dil_in, n_dil_out, emit_kind, lane);
+                             n_dil_in, n_dil_out, emit_kind, lane, height, old_height);
         return;
     }
     const int n_work = st.prep_resume[0];
     for (int wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
         const int32_t *rec = st.prep_resume + 1 + 5 * (int64_t)wi;
         scenario_cell<true>(st, rec[0], rec[1], rec[2], rec[3], rec[4], dt, create_time, seed, step, emission,
-                            dilution_rate, background, n_emit, n_dil_in, n_dil_out, emit_kind, lane);
+                            dilution_rate, background, n_emit, n_dil_in, n_dil_out, emit_kind, lane, height, old_height);
     }
 }
 
@@ -5611,7 +5617,8 @@ hipError_t launch_scenario_update(const DeviceState &st, double dt, double creat
                                   uint32_t step, const GenSpecDev *em, const double *em_conc,
                                   const double *dilution_rate, const GenSpecDev *bg,
                                   const double *bg_conc, int32_t *n_emit, int32_t *n_dil_in,
-                                  int32_t *n_dil_out, hipStream_t s, uint32_t emit_kind)
+                                  int32_t *n_dil_out, hipStream_t s, uint32_t emit_kind,
+                                  const double *height, const double *old_height)
 {
     AeroDistDev e{0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0}, b = e;
     if (em) e = AeroDistDev{em->n_mode, em_conc, em->ln_gm_radius, em->ln_gsd, em->vol_frac,
@@ -5620,10 +5627,11 @@ hipError_t launch_scenario_update(const DeviceState &st, double dt, double creat
                             bg->mode_class, bg->mode_source, bg->per_cell};
     if (st.prep_on) (void)hipMemsetAsync(st.prep_resume, 0, sizeof(int32_t), s);
     hipLaunchKernelGGL(k_scenario_update<false>, dim3(st.n_cells), dim3(64), 0, s, st, dt, create_time,
-                       seed, step, e, dilution_rate, b, n_emit, n_dil_in, n_dil_out, emit_kind);
+                       seed, step, e, dilution_rate, b, n_emit, n_dil_in, n_dil_out, emit_kind, height, old_height);
     if (st.prep_on) // the cells that stopped at a mode whose weight wants preparing: the rest of their update
         hipLaunchKernelGGL(k_scenario_update<true>, dim3(st.n_cells < 2048 ? st.n_cells : 2048), dim3(64), 0, s, st, dt,
-                           create_time, seed, step, e, dilution_rate, b, n_emit, n_dil_in, n_dil_out, emit_kind);
+                           create_time, seed, step, e, dilution_rate, b, n_emit, n_dil_in, n_dil_out, emit_kind, height,
+                           old_height);
     return hipGetLastError();
 }
 hipError_t launch_gas_update(const GasScenarioDev &g, double *mix_rat, const double *temp,

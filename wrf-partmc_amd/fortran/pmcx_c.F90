@@ -260,7 +260,7 @@ module pmcx_c
        integer(c_int32_t), value :: step
      end function pmcx_rebalance
      integer(c_int) function pmcx_scenario_update_aero_state(ctx, dt, elapsed_time, seed, step, &
-          emission, dilution_rate, background, n_emit, n_dil_in, n_dil_out) &
+          emission, dilution_rate, background, n_emit, n_dil_in, n_dil_out, height, old_height) &
           bind(c, name="pmcx_scenario_update_aero_state")
        import :: c_ptr, c_int, c_int32_t, c_int64_t, c_double
        type(c_ptr), value :: ctx
@@ -269,6 +269,7 @@ module pmcx_c
        integer(c_int32_t), value :: step
        type(c_ptr), value :: emission, dilution_rate, background   ! pmcx_aero_dist_t*, double*, ...
        type(c_ptr), value :: n_emit, n_dil_in, n_dil_out           ! int32 [n_cells] or c_null_ptr
+       type(c_ptr), value :: height, old_height                    ! double [n_cells] or c_null_ptr
      end function pmcx_scenario_update_aero_state
      integer(c_int) function pmcx_set_aero_scenario_modes(ctx, which, dist) &
           bind(c, name="pmcx_set_aero_scenario_modes")

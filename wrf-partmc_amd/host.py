@@ -217,7 +217,7 @@ def load_library():
                                  C.c_void_p, C.c_void_p]
     L.pmcx_scenario_update_aero_state.argtypes = [
         C.c_void_p, C.c_double, C.c_double, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
-        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pmcx_generate_lognormal.argtypes = [
         C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
         C.c_void_p, C.c_void_p, C.c_uint64, C.c_double]
@@ -661,18 +661,21 @@ class CellBlock:
 
     def scenario_update_aero_state(self, dt, elapsed_time, seed=0, step=0, emission=None,
                                    emission_rate=None, dilution_rate=None, background=None,
-                                   background_conc=None):
-        """scenario_update_aero_state on every cell (driver:207-210).
+                                   background_conc=None, height=None, old_height=None):
+        """scenario_update_aero_state on every cell (driver:207-210).  height, old_height:
+        env_state%height now and a step ago (the dilution where the layer grew; None: unchanged).
         Returns (n_emit, n_dil_in, n_dil_out) per cell."""
         n = self.cfg.n_cells
         e, ke = self._aero_dist(emission, emission_rate)
         b, kb = self._aero_dist(background, background_conc)
         dil = None if dilution_rate is None else np.ascontiguousarray(np.broadcast_to(_f64(dilution_rate), (n,)))
-        self._inflight = (e, ke, b, kb, dil)    # (an asynchronous call reads them after it has returned)
+        h = None if height is None or old_height is None else np.ascontiguousarray(np.broadcast_to(_f64(height), (n,)))
+        ho = None if h is None else np.ascontiguousarray(np.broadcast_to(_f64(old_height), (n,)))
+        self._inflight = (e, ke, b, kb, dil, h, ho)    # (an asynchronous call reads them after it has returned)
         ne, ni, no = (self._out("scen%d" % k, n) for k in range(3))
         self._ck(self._lib.pmcx_scenario_update_aero_state(
             self._h, dt, elapsed_time, seed, step, C.addressof(e) if e else None, _ptr(dil),
-            C.addressof(b) if b else None, _ptr(ne), _ptr(ni), _ptr(no)))
+            C.addressof(b) if b else None, _ptr(ne), _ptr(ni), _ptr(no), _ptr(h), _ptr(ho)))
         return ne, ni, no
 
     def seasalt_emissions(self, dt, elapsed_time, sea_salt_opt, i_na, i_cl, ocean_surface, wind_speed,
