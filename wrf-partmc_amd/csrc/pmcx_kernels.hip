@@ -5689,7 +5689,8 @@ hipError_t launch_transport_finish(const DeviceState &st, int nx, int nz, int ny
     hipLaunchKernelGGL(k_trans_room, dim3((st.n_cells + 3) / 4), dim3(256), compact_lds_bytes(st), s, st, tg);
     hipLaunchKernelGGL(k_trans_gather, dim3(n_do), dim3(64), 0, s, st, tg);
     hipLaunchKernelGGL(k_trans_remove, dim3(n_do), dim3(64), 0, s, st, tg);
-    launch_compact(st, c_first, n_do, 1, st.compact_den, s); // the cells the movers left more than 1/compact_den dead
+    // the cells the movers left more than 1/compact_den dead
+    if (hipError_t ce = launch_compact(st, c_first, n_do, 1, st.compact_den, s); ce != hipSuccess) return ce;
     if (n_rows != ny) { // a slab: rows 0 and ny - 1 are ghosts
         const Strip a{0, 1, nx * nz}, b{(ny - 1) * nx * nz, 1, nx * nz};
         hipLaunchKernelGGL(k_halo_clear, dim3((a.n + b.n + 255) / 256), dim3(256), 0, s, st, tg, a, b);
