@@ -21,7 +21,7 @@ t0 = time.time()
 for run in range(n_runs):
     n_cells, n_class, n_spec = 24, int(rng.randint(1, 4)), int(rng.randint(1, 3))
     n_part = int(rng.choice([40, 60, 150, 400]))
-    cap = int(np.ceil(n_part * float(rng.choice([3.2, 6.0, 12.0])) / 64) * 64)
+    cap = int(np.ceil(n_part * float(rng.choice([8.0, 14.0, 24.0])) / 64) * 64)
     parity.N_COMP_MAX = int(rng.choice([0, 0, 3, 8]))
     seed = int(rng.randint(1 << 30))
     flags = (bool(rng.randint(4)), bool(rng.randint(4)))
@@ -43,13 +43,14 @@ for run in range(n_runs):
         em_rate = mag[:, [m["wclass"] for m in em]] * 10 ** rng.uniform(-1.5, 0.3, (n_cells, 2)) * n_part / 60.0
         bg_conc = mag[:, [m["wclass"] for m in bg]] * n_part * 10 ** rng.uniform(-1, 0.5, (n_cells, 1))
         dil = rng.uniform(0, 5e-3, n_cells) * (rng.rand(n_cells) < 0.7)
-        ne, ni, no = blk.scenario_update_aero_state(60.0, 60.0 * step, seed, step, em, em_rate, dil, bg, bg_conc)
+        hgt = rng.uniform(30, 300, n_cells); hgt_old = hgt * rng.choice([0.9, 1.0, 1.1], n_cells)   # the layer grew, stayed, shrank
+        ne, ni, no = blk.scenario_update_aero_state(60.0, 60.0 * (step + 1), seed, step, em, em_rate, dil, bg, bg_conc, hgt, hgt_old)
         st_o = 0
         for c, oc in enumerate(cells):
             oe = [dict(m, num_conc=em_rate[c, k]) for k, m in enumerate(em)]
             ob = [dict(m, num_conc=bg_conc[c, k]) for k, m in enumerate(bg)]
-            st, oc.next_id, one, oni, ono = oc.scenario_update(60.0, 60.0 * step, seed, oc.cell_id, step, oe, dil[c], ob,
-                                                               oc.next_id)
+            st, oc.next_id, one, oni, ono = oc.scenario_update(60.0, 60.0 * (step + 1), seed, oc.cell_id, step, oe, dil[c], ob,
+                                                               oc.next_id, hgt[c], hgt_old[c])
             st_o |= st
             assert (one, oni, ono) == (int(ne[c]), int(ni[c]), int(no[c])), ("scenario", run, step, c, (one, oni, ono),
                                                                               (int(ne[c]), int(ni[c]), int(no[c])))
