@@ -606,6 +606,8 @@ int pmcx_set_weight_preparation(pmcx_ctx *ctx, int32_t on, int32_t allow_doublin
     if (!ctx) return fail(ctx, PMCX_EINVAL, "pmcx_set_weight_preparation: null context");
     if (on && !ctx->n_ideal_set)
         return fail(ctx, PMCX_ESTATE, "pmcx_set_weight_preparation: pmcx_set_n_part_ideal must come first");
+    if (on && ctx->cfg.n_class > 64)
+        return fail(ctx, PMCX_EINVAL, "pmcx_set_weight_preparation: at most 64 weight classes (a class count per lane)");
     if (on && !ctx->st.prep_resume) {
         int rc = dev_alloc(ctx, &ctx->st.prep_resume, 1 + 5 * (size_t)ctx->cfg.n_cells);
         if (rc) return rc;

@@ -3282,18 +3282,29 @@ __device__ int scale_weight_wave(const DeviceState &st, int c, int cl, double ra
 // class cl; if that leaves the class outside [n_ideal / 2, 2 n_ideal] its weight is scaled by
 // ratio = (n + n_add) / n_ideal so that it comes to n_ideal (pmcx_set_weight_preparation).  Is a
 // scaling due -- and would aero_state_scale_weight act on it with the flags as they are?
+// cls_cnt: the cell's particles per class, class q in lane q (class_counts: ONE pass over the cell
+// for all the modes of a call; kept current by whoever adds or removes -- a count per mode was a
+// pass over every particle per mode); n_class == 1: the cell's n_part.
+__device__ int class_counts(const DeviceState &st, int c, int lane)
+{
+    if (!st.prep_on || st.n_class == 1) return 0;
+    const int64_t cb = (int64_t)c * st.cap;
+    const int n_hi = st.n_hi[c], C = st.n_class;
+    int cnt = 0;
+    for (int i0 = 0; i0 < n_hi; i0 += 64) {
+        const int wc = i0 + lane < n_hi ? live_class_c(st, cb, i0 + lane) : -1;
+        for (int q = 0; q < C; q++) {
+            const int k = __popcll(__ballot(wc == q));
+            if (lane == q) cnt += k;
+        }
+    }
+    return cnt;
+}
 __device__ __forceinline__ bool weight_preparation_due(const DeviceState &st, int c, int cl, double n_add, int lane,
-                                                       double &ratio)
+                                                       double &ratio, int cls_cnt)
 {
     if (!st.prep_on) return false;
-    const int64_t cb = (int64_t)c * st.cap;
-    int n_cls = st.n_part[c];
-    if (st.n_class > 1) {
-        const int n_hi = st.n_hi[c];
-        uint32_t cnt = 0;
-        for (int i = lane; i < n_hi; i += 64) cnt += (live_class_c(st, cb, i) == cl);
-        n_cls = (int)wave_sum_u64(cnt);
-    }
+    const int n_cls = st.n_class == 1 ? st.n_part[c] : __shfl(cls_cnt, cl, 64);
     const double n_new = (double)n_cls + n_add, ideal = st.n_ideal[(int64_t)c * st.n_class + cl];
     if (n_new == 0.0 || !(ideal > 0.0)) return false;
     if (!(n_new < ideal / 2.0 || n_new > ideal * 2.0)) return false;
@@ -3312,7 +3323,7 @@ template <bool HEAVY>
 __device__ int add_dist_sample(const DeviceState &st, int c, const AeroDistDev &d, double factor,
                                uint32_t kind, double create_time, uint64_t seed, uint32_t step,
                                int &status, int lane, const double *means, int m_first, int &stop_at,
-                               double char_factor = 1.0)
+                               int &cls_cnt, double char_factor = 1.0)
 {
     const int64_t cb = (int64_t)c * st.cap;
     const uint32_t cell_id = cell_gid(st, c);
@@ -3331,10 +3342,12 @@ __device__ int add_dist_sample(const DeviceState &st, int c, const AeroDistDev &
             // (for char_factor times the mean: the particles expected over the sampling timescale)
             if (weight_preparation_due(st, c, cl,
                                        (d.num_conc[(int64_t)c * d.n_mode + m] * factor / ld_f64(&mag[cl])) * char_factor, lane,
-                                       ratio)) { // (uniform over the wavefront)
+                                       ratio, cls_cnt)) { // (uniform over the wavefront)
                 if (!HEAVY) { stop_at = m; return added; }
-                scale_weight_wave<true>(st, c, cl, ratio, st.prep_doubling, st.prep_halving, seed, step,
-                                        SCALE_ADD | (kind << 16) | ((uint32_t)m << 8) | (uint32_t)cl, lane, status);
+                const int ch = scale_weight_wave<true>(st, c, cl, ratio, st.prep_doubling, st.prep_halving, seed, step,
+                                                       SCALE_ADD | (kind << 16) | ((uint32_t)m << 8) | (uint32_t)cl, lane,
+                                                       status);
+                if (lane == cl) cls_cnt += ratio > 1.0 ? -ch : ch; // (thinned, or copies added)
             }
         }
         const double mean = means ? means[m] : d.num_conc[(int64_t)c * d.n_mode + m] * factor / ld_f64(&mag[cl]);
@@ -3376,6 +3389,7 @@ __device__ int add_dist_sample(const DeviceState &st, int c, const AeroDistDev &
             st.n_hi[c] = n_hi + n;
             st.n_part[c] = st.n_part[c] + n;
         }
+        if (lane == cl) cls_cnt += n;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __threadfence_block();
         wave_sync();
@@ -3411,11 +3425,12 @@ __device__ __forceinline__ void scenario_cell(const DeviceState &st, int c, int 
     };
     apply_event_log(st, c, lane);
     int stop = -1;
+    int cls_cnt = class_counts(st, c, lane);
     // the add's characteristic_factor (wrf_pmc_driver.F90:1794, 1916-1918): sample timescale / step
     const double cf = fmax(1.0, fmin(3600.0, create_time)) / dt;
     if (pos < 512 && emission.n_mode > 0) {
         ne += add_dist_sample<HEAVY>(st, c, emission, dt, emit_kind, create_time, seed, step, status, lane, nullptr, pos, stop,
-                                     cf);
+                                     cls_cnt, cf);
         if (!HEAVY && stop >= 0) { hand_over(stop); break; }
     }
     const double rate = dilution_rate ? dilution_rate[c] : 0.0;
@@ -3439,7 +3454,13 @@ __device__ __forceinline__ void scenario_cell(const DeviceState &st, int c, int 
                     drop = u53(w[0], w[1]) < p_loss;
                 }
                 if (drop) mark_dead(st, cb, i);
-                no += __popcll(__ballot(drop));
+                const uint64_t mdrop = __ballot(drop);
+                if (mdrop && st.prep_on && st.n_class > 1) // (the class counts follow)
+                    for (int q = 0; q < st.n_class; q++) {
+                        const int k = __popcll(__ballot(drop && wc == q));
+                        if (lane == q) cls_cnt -= k;
+                    }
+                no += __popcll(mdrop);
                 rank0 += (uint32_t)__popcll(mlive);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -3451,7 +3472,7 @@ __device__ __forceinline__ void scenario_cell(const DeviceState &st, int c, int 
         }
         if (background.n_mode > 0) {
             ni += add_dist_sample<HEAVY>(st, c, background, p_loss, 1u, create_time, seed, step, status, lane, nullptr,
-                                         pos >= 512 ? pos - 512 : 0, stop, cf);
+                                         pos >= 512 ? pos - 512 : 0, stop, cls_cnt, cf);
             if (!HEAVY && stop >= 0) { hand_over(512 + stop); break; }
         }
         const int hi = st.n_hi[c], live = st.n_part[c];
@@ -4380,8 +4401,8 @@ __global__ __launch_bounds__(64) void k_boundary_resample(DeviceState st, const 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __threadfence_block();
         wave_sync();
-        int stop_ = -1; // (a handful of boundary cells: the whole of it here)
-        na = add_dist_sample<true>(st, c, bg, dens, 3u, create_time, seed, step, status, lane, nullptr, 0, stop_);
+        int stop_ = -1, cls_cnt = 0; // (a handful of boundary cells: the whole of it here; the cell is empty)
+        na = add_dist_sample<true>(st, c, bg, dens, 3u, create_time, seed, step, status, lane, nullptr, 0, stop_, cls_cnt);
     } else {
         for (int cl = 0; cl < C; cl++) {
             const int n_hi = st.n_hi[c];
@@ -4415,8 +4436,9 @@ __global__ __launch_bounds__(64) void k_boundary_resample(DeviceState st, const 
                     s_means[lane] = mean;
                 }
                 lds_sync();
-                int stop_ = -1;
-                na += add_dist_sample<false>(st, c, bg, dens, 3u, create_time, seed, step, status, lane, s_means, 0, stop_);
+                int stop_ = -1, cls_cnt = 0; // (given means: no weight preparation, the counts are not looked at)
+                na += add_dist_sample<false>(st, c, bg, dens, 3u, create_time, seed, step, status, lane, s_means, 0, stop_,
+                                             cls_cnt);
             } else {
                 const int m_rm = -n_to_add < n_before ? -n_to_add : n_before;
                 int t0 = 0, k = 0; // class members seen, removed so far (uniform)
