@@ -3425,7 +3425,17 @@ __device__ __forceinline__ void scenario_cell(const DeviceState &st, int c, int 
     };
     apply_event_log(st, c, lane);
     int stop = -1;
-    int cls_cnt = class_counts(st, c, lane);
+    // the class counts (several classes, weight preparation on): a pass over the cell in front of the
+    // emission only where the cell HAS an emission mode; everywhere else the dilution's pass, which
+    // looks at every particle anyway, leaves them behind for the background's modes
+    const bool want_cnt = st.prep_on && st.n_class > 1;
+    bool have_cnt = false;
+    int cls_cnt = 0;
+    if (want_cnt) {
+        bool emits = HEAVY;
+        for (int m = 0; m < emission.n_mode && pos < 512; m++) emits |= emission.num_conc[(int64_t)c * emission.n_mode + m] >= 0.0;
+        if (emits) { cls_cnt = class_counts(st, c, lane); have_cnt = true; }
+    }
     // the add's characteristic_factor (wrf_pmc_driver.F90:1794, 1916-1918): sample timescale / step
     const double cf = fmax(1.0, fmin(3600.0, create_time)) / dt;
     if (pos < 512 && emission.n_mode > 0) {
@@ -3455,10 +3465,11 @@ __device__ __forceinline__ void scenario_cell(const DeviceState &st, int c, int 
                 }
                 if (drop) mark_dead(st, cb, i);
                 const uint64_t mdrop = __ballot(drop);
-                if (mdrop && st.prep_on && st.n_class > 1) // (the class counts follow)
+                if (want_cnt && (mdrop || !have_cnt)) // (the class counts follow, or are taken here)
                     for (int q = 0; q < st.n_class; q++) {
-                        const int k = __popcll(__ballot(drop && wc == q));
-                        if (lane == q) cls_cnt -= k;
+                        const int k = have_cnt ? -(int)__popcll(__ballot(drop && wc == q))
+                                               : (int)__popcll(__ballot(!drop && wc == q));
+                        if (lane == q) cls_cnt += k;
                     }
                 no += __popcll(mdrop);
                 rank0 += (uint32_t)__popcll(mlive);
