@@ -3,7 +3,7 @@
 tests/test_gpu_driver.py -- WRF steps through partmc_timestep_pmcx and wrf_pmc_trans_driver_pmcx,
 the oracle through the same loop, every particle, component list, weight and gas compared bit for
 bit -- with grid shape, particle count, number of steps, boundaries, sea-salt option and seed at
-random.   python scripts/fuzz_driver.py [n_runs] [seed]"""
+random.   python scripts/fuzz_driver.py [n_runs] [seed] [max_steps]"""
 import os
 import pathlib
 import sys
@@ -20,6 +20,7 @@ from tests import test_gpu_driver as drv, wrf_case  # noqa: E402
 
 n_runs = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
+max_steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 assert os.path.exists(drv.EXE), "build wrf-partmc_amd/fortran first (make)"
 t0 = time.time()
 full = 0
@@ -27,7 +28,7 @@ for run in range(n_runs):
     periodic = bool(rng.randint(2))
     lo = 2 if periodic else 3
     kw = dict(nx=int(rng.randint(lo, 7)), nz=int(rng.randint(2, 7)), ny=int(rng.randint(lo, 7)),
-              n_part=int(rng.choice([60, 150, 300, 500])), n_steps=int(rng.randint(1, 10)), periodic=periodic,
+              n_part=int(rng.choice([60, 150, 300, 500])), n_steps=int(rng.randint(1, max_steps)), periodic=periodic,
               seed=int(rng.randint(1 << 30)), sea_salt_opt=int(rng.randint(0, 3)))
     print(f"run {run}: {kw}", flush=True)
     case = wrf_case.Case(**kw)
