@@ -893,7 +893,8 @@ static int scale_weight(pmco_cell *c, int cl, double ratio, int allow_doubling, 
         compact_stable(c, dead, n, changed);
         free(dead);
     } else if (ratio < 1.0 && (allow_doubling || n_cls == 0)) {
-        const double x = 1.0 / ratio, x_fl = (double)(int64_t)x;
+        /* (no particle stands for more than the cell has slots: the count stays an integer whatever the ratio) */
+        const double x = 1.0 / ratio < (double)c->cap ? 1.0 / ratio : (double)c->cap, x_fl = (double)(int64_t)x;
         for (int i = 0; i < n; i++) {
             if (c->wclass[i] != cl) continue;
             pmco_rng_block(seed, cell_id, step, (uint32_t)i, PMCO_SITE_SCALE, bkey, w);

@@ -3217,7 +3217,9 @@ __device__ int scale_weight_wave(const DeviceState &st, int c, int cl, double ra
         wave_sync();
         if (lane == 0) st.n_part[c] = n_live - changed;
     } else if (COPIES && ratio < 1.0 && (allow_doubling || n_before == 0)) {
-        const double x = 1.0 / ratio, x_fl = (double)(int64_t)x;
+        // (no particle stands for more than the cell has slots: the count stays an integer whatever
+        // the ratio, and a cell that cannot hold the copies is flagged full either way)
+        const double x = fmin(1.0 / ratio, (double)st.cap), x_fl = (double)(int64_t)x;
         // how many copies a class member gets (its uniform is keyed by its rank: the same in both passes)
         auto dups_of = [&](int wc, uint32_t rank) -> uint32_t {
             if (wc != cl) return 0u;
@@ -3225,39 +3227,40 @@ __device__ int scale_weight_wave(const DeviceState &st, int c, int cl, double ra
             rng_block(seed, cell_id, step, rank, SITE_SCALE, bkey, q);
             return (uint32_t)((int)x_fl + ((u53(q[0], q[1]) < x - x_fl) ? 1 : 0) - 1);
         };
-        uint32_t total = 0, rank0 = 0;
+        uint64_t total = 0; // (up to cap copies of up to cap particles)
+        uint32_t rank0 = 0;
         for (int i0 = 0; i0 < n_hi; i0 += 64) {
             const int i = i0 + lane;
             const int wc = i < n_hi ? live_class_c(st, cb, i) : -1;
             const uint64_t mlive = __ballot(wc >= 0);
-            total += (uint32_t)wave_sum_u64(dups_of(wc, rank0 + (uint32_t)__popcll(mlive & lt)));
+            total += wave_sum_u64(dups_of(wc, rank0 + (uint32_t)__popcll(mlive & lt)));
             rank0 += (uint32_t)__popcll(mlive);
         }
-        if (n_hi + (int)total > st.cap && n_hi > n_live) { // make room: close the holes first
+        if ((uint64_t)n_hi + total > (uint64_t)st.cap && n_hi > n_live) { // make room: close the holes first
             compact_wave(st, c, lane);
             n_hi = st.n_hi[c];
         }
-        if (n_hi + (int)total > st.cap) status |= ST_CAP_OVERFLOW;
+        if ((uint64_t)n_hi + total > (uint64_t)st.cap) status |= ST_CAP_OVERFLOW;
         const int64_t nid = st.next_id[c];
-        uint32_t base = 0;
+        uint64_t base = 0;
         rank0 = 0;
-        for (int i0 = 0; i0 < n_hi; i0 += 64) {
+        for (int i0 = 0; i0 < n_hi && base < (uint64_t)(st.cap - n_hi); i0 += 64) { // (nothing fits beyond: done)
             const int i = i0 + lane;
             const int wc = i < n_hi ? live_class_c(st, cb, i) : -1;
             const uint64_t mlive = __ballot(wc >= 0);
-            const uint32_t nd = dups_of(wc, rank0 + (uint32_t)__popcll(mlive & lt));
+            const uint32_t nd = dups_of(wc, rank0 + (uint32_t)__popcll(mlive & lt)); // (<= cap each: 64 of them fit 32 bits)
             const uint32_t inc = wave_incl_scan_u32(nd, lane);
-            const uint32_t first = base + inc - nd;
+            const uint64_t first = base + (uint64_t)(inc - nd);
             for (uint32_t g = 0; g < nd; g++) {
-                const int dst = n_hi + (int)(first + g);
-                if (dst >= st.cap) break; // (flagged above; the id is spent all the same)
-                move_particle(st, cb, c, dst, i);
+                const int64_t dst = (int64_t)n_hi + (int64_t)(first + g);
+                if (dst >= (int64_t)st.cap) break; // (flagged above; the id is spent all the same)
+                move_particle(st, cb, c, (int)dst, i);
                 st.cold[cb + dst].id = nid + (int64_t)(first + g);
             }
-            base += (uint32_t)__shfl(inc, 63, 64);
+            base += (uint64_t)(uint32_t)__shfl(inc, 63, 64);
             rank0 += (uint32_t)__popcll(mlive);
         }
-        changed = n_hi + (int)total > st.cap ? st.cap - n_hi : (int)total;
+        changed = (uint64_t)n_hi + total > (uint64_t)st.cap ? st.cap - n_hi : (int)total;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
         if (lane == 0) {
