@@ -1792,6 +1792,38 @@ def test_transport_follows_the_sampling_law(wp):
     assert v0 > 1.5 * (horiz + var_dn_ref)             # (and it is not the reference's: stated, not hidden)
 
 
+def test_transport_copies_at_a_small_weight_ratio(wp):
+    """r = 1/20 (a particle of a heavy-weight cell arriving where particles stand for a twentieth):
+    1 + geometric copies, twenty on average.  The count has a guard of 4096, not the 16 it had
+    until round 3 -- with 16 the mean would be (1 - 0.95^16) / 0.05 = 11.2 and the physical number
+    moved 44 % short."""
+    nx, nz, ny, n_part = 32, 2, 16, 500
+    n_cells = nx * nz * ny
+    lev = (np.arange(n_cells) // nx) % nz
+    vol = np.where(lev == 0, 1.0, 20.0)
+    p_dn = 0.01
+    ph = np.zeros((n_cells, 1, 4)); pv = np.zeros((n_cells, 1, nz))
+    pv[lev == 1, 0, 0] = p_dn
+    from wrf_partmc_amd.data import idealised_modes
+    with wp.CellBlock(n_cells, 4096, 1) as blk:
+        blk.set_aero_data([1500.0]); blk.set_env(280.0, 9e4)
+        blk.set_weights(np.full((n_cells, 1), 1e7))
+        blk.set_next_id((np.arange(n_cells, dtype=np.int64) << 32) + (1 << 24))
+        blk.generate_lognormal(n_part, idealised_modes(1), seed=6)
+        nm, na = blk.transport(nx, nz, ny, ph, pv, vol, seed=6, step=0)
+        assert not np.bitwise_or.reduce(blk.coag_counters()[2])
+        ids = blk.download_cells()["id"]
+    assert len(np.unique(ids)) == len(ids)
+    n1 = int((lev == 1).sum())
+    movers = float(nm[lev == 1].sum())
+    assert abs(movers - n1 * n_part * p_dn) < 5 * np.sqrt(n1 * n_part * p_dn)
+    r = 1.0 / 20.0
+    arrivals = float(na[lev == 0].sum())
+    assert abs(arrivals - movers / r) < 5 * np.sqrt(movers * (1 - r) / r ** 2), (arrivals, movers / r)
+    assert arrivals > 1.5 * movers * (1 - 0.95 ** 16) / 0.05          # (what a guard of 16 would have let through)
+    assert na[lev == 0].max() > 16 * nm[lev == 1].max() / 4           # single movers with far more than 16 copies
+
+
 def test_dry_deposition_follows_zhang_2001(wp):
     """Dry deposition on the HIP path against an independent numpy transcription of the in-tree
     scheme (wrf_pmc_dep_aero.F90:265-420; tests/test_oracle.py::_dep_velocity_numpy), without the
