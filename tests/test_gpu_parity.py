@@ -1460,7 +1460,7 @@ def test_transport_blocks_cut_in_x_and_y(wp, periodic, shape):
 
 
 def blocks_cut_in_x_and_y(wp, periodic, shape, nz=3, n_class=2, n_spec=2, n_part=400, seed=17, prob=0.08,
-                          ideal=0.45, n_steps=3):
+                          ideal=0.45, n_steps=3, cap_factor=2.56):
     """The transport exchange with both cut directions (the reference decomposes in x and y,
     wrf_pmc_trans_aero.F90:148-273): the domain as 2 x 2 blocks, each with a ghost row and a ghost
     column on every side, movers exported / imported through the four sides (what RCCL would carry
@@ -1469,7 +1469,7 @@ def blocks_cut_in_x_and_y(wp, periodic, shape, nz=3, n_class=2, n_spec=2, n_part
     doubly periodic; otherwise open lateral boundaries (boundary cells send inwards only, what
     reaches them leaves)."""
     nx, ny, bx, by = shape                            # (also blocks of a single column, and one row of blocks)
-    cap = (int(2.56 * n_part) + 63) // 64 * 64
+    cap = (int(cap_factor * n_part) + 63) // 64 * 64
     rx, ry = nx // bx, ny // by                      # real columns / rows per block
     n = nx * nz * ny
     rng = np.random.RandomState(seed)
