@@ -5621,8 +5621,10 @@ hipError_t launch_rebalance(const DeviceState &st, int allow_doubling, int allow
         hipLaunchKernelGGL(k_rebalance, dim3(st.n_cells), dim3(64), 0, s, st, allow_doubling,
                            allow_halving, seed, step, (const int32_t *)nullptr, (const int32_t *)nullptr);
     }
-    // the cells a halving left more than 1/compact_den dead
-    return allow_halving ? launch_compact(st, 0, st.n_cells, 1, st.compact_den, s) : hipGetLastError();
+    // (the cells a halving left more than 1/compact_den dead are compacted by whoever looks next:
+    // mc_coag's pass in front of the sampler, the transport's after its movers have left -- when
+    // holes are closed changes no result, and three launches a step are three launches)
+    return hipGetLastError();
 }
 hipError_t launch_diagnostics(const DeviceState &st, double *tot_num, double *tot_mass,
                               double *num_dist, double *mass_dist, hipStream_t s)
@@ -5798,7 +5800,7 @@ hipError_t launch_preweight_slab_finish(const DeviceState &st, int nx, int nz, i
     const int64_t n = (int64_t)st.n_cells * st.n_class;
     hipLaunchKernelGGL(k_preweight_new, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, a);
     hipLaunchKernelGGL(k_preweight_scale, dim3(st.n_cells), dim3(64), 0, s, st, a, seed, step);
-    return launch_compact(st, 0, st.n_cells, 1, st.compact_den, s); // the cells thinned past 1/compact_den dead
+    return hipGetLastError(); // (the cells thinned past 1/compact_den dead: the transport's compaction, after the movers have left)
 }
 hipError_t launch_transport_preweight(const DeviceState &st, int nx, int nz, int ny, int ideal,
                                       const double *prob_h, const double *prob_v,
@@ -5812,7 +5814,7 @@ hipError_t launch_transport_preweight(const DeviceState &st, int nx, int nz, int
     const int64_t n = (int64_t)st.n_cells * st.n_class;
     hipLaunchKernelGGL(k_preweight_new, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, a);
     hipLaunchKernelGGL(k_preweight_scale, dim3(st.n_cells), dim3(64), 0, s, st, a, seed, step);
-    return launch_compact(st, 0, st.n_cells, 1, st.compact_den, s); // the cells thinned past 1/compact_den dead
+    return hipGetLastError(); // (the cells thinned past 1/compact_den dead: the transport's compaction, after the movers have left)
 }
 size_t trans_probs_lds_bytes(const DeviceState &st, int nz)
 {
