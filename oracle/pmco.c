@@ -1256,6 +1256,18 @@ void pmco_diagnostics_ext(const pmco_cell *c, int i_water, double *species_mass,
 
 typedef struct { int dest; double lo, hi, ratio; } trans_dest;
 
+/* PROTOTYPE (oracle only, off by default): the r < 1 branch in the reference's own
+ * law, by Poisson thinning of its picks (wrf_pmc_trans_aero.F90:2244-2300: Poisson(n p / r) picks
+ * with replacement, each adds a copy and removes the picked particle with probability r).  The
+ * removing picks (rate p) are the movers -- a mover towards r < 1 arrives ONCE, id kept; the
+ * non-removing picks (rate mu = p (1 - r) / r) are copies from particles that STAY: behind the
+ * movers' intervals the placing uniform has one more, of width 1 - exp(-sum mu) -- an emitter,
+ * which draws a zero-truncated Poisson(sum mu) number of copies and deals them to the r < 1
+ * destinations in proportion mu, every copy under a new id.  Mean n p / r as law 0, variance
+ * n p / r as the reference's. */
+static int g_trans_law = 0;
+void pmco_set_transport_law(int law) { g_trans_law = law; }
+
 /* destination table of (cell c, class cl): returns the number of entries */
 static int g_trans_lateral = 0; /* pmco_transport_lateral: the reference's open lateral boundaries */
 
@@ -1332,7 +1344,7 @@ int pmco_transport(pmco_cell *cells, int n_cells, int nx, int nz, int ny, int pe
     periodic_y = periodic_y && ny > 1;
     for (int k = 0; k < n_cells; k++) *cells[k].sort_valid = 0;
     /* phase 1: every particle decides; outbox entries (slot, dest, copies) in rank order */
-    typedef struct { int32_t slot, dest, copies; } entry;
+    typedef struct { int32_t slot, dest, copies, stays; } entry;
     entry **box = (entry **)calloc((size_t)n_cells, sizeof(entry *));
     int *nbox = (int *)calloc((size_t)n_cells, sizeof(int));
     trans_dest *tab = (trans_dest *)malloc(sizeof(trans_dest) * (size_t)C * (4 + 128));
@@ -1340,7 +1352,9 @@ int pmco_transport(pmco_cell *cells, int n_cells, int nx, int nz, int ny, int pe
     for (int c = 0; c < n_cells; c++) {
         pmco_cell *s = &cells[c];
         const int n = *s->n_part;
-        box[c] = (entry *)malloc(sizeof(entry) * (size_t)(n > 0 ? n : 1));
+        size_t box_cap = (size_t)(n > 0 ? n : 1);
+        box[c] = (entry *)malloc(sizeof(entry) * box_cap);
+        int n_movers = 0;
         for (int cl = 0; cl < C; cl++)
             ntab[cl] = trans_table(cells, c, cl, nx, nz, ny, periodic_x, periodic_y, prob_h, prob_v,
                                    cell_volume, C, tab + (size_t)cl * (4 + 128));
@@ -1356,10 +1370,45 @@ int pmco_transport(pmco_cell *cells, int n_cells, int nx, int nz, int ny, int pe
             uint32_t w[4];
             pmco_rng_block(seed, cell_id_base + (uint32_t)c, step, (uint32_t)i >> 4, PMCO_SITE_TRANS, 0, w);
             const uint32_t p8 = (w[(i & 15) >> 2] >> (8 * (i & 3))) & 0xFFu;
-            if (!((double)p8 * 0x1.0p-8 < t[ntab[cl] - 1].hi)) continue;      /* stays */
+            /* law 1: the emitters' interval behind the movers' */
+            const double s_hi = t[ntab[cl] - 1].hi;
+            double sum_mu = 0.0, a_hi = s_hi;
+            if (g_trans_law == 1) {
+                for (int d = 0; d < ntab[cl]; d++)
+                    if (t[d].ratio < 1.0) sum_mu = sum_mu + (t[d].hi - t[d].lo) * (1.0 - t[d].ratio) / t[d].ratio;
+                a_hi = s_hi + (1.0 - pmco_exp(-sum_mu));
+                if (a_hi > 1.0) a_hi = 1.0;
+            }
+            if (!((double)p8 * 0x1.0p-8 < a_hi)) continue;      /* stays */
             pmco_rng_block(seed, cell_id_base + (uint32_t)c, step, (uint32_t)i, PMCO_SITE_TRANS, 1, w);
             const double u = ((double)p8 + (double)w[0] * 0x1.0p-32) * 0x1.0p-8;
-            if (!(u < t[ntab[cl] - 1].hi)) continue;      /* stays */
+            if (!(u < a_hi)) continue;      /* stays */
+            if (!(u < s_hi)) {              /* law 1: an emitter -- it stays and sends copies */
+                const double u2 = pmco_u53(w[2], w[3]);
+                const double e = pmco_exp(-sum_mu);
+                double term = e * sum_mu / (1.0 - e), cdf = term;   /* P(K = 1) of the zero-truncated Poisson */
+                int K = 1;
+                while (u2 >= cdf && K < PMCO_TRANS_MAX_COPIES) { K++; term = term * sum_mu / (double)K; cdf = cdf + term; }
+                for (int q = 0; q < K; q++) {
+                    uint32_t v[4];
+                    pmco_rng_block(seed, cell_id_base + (uint32_t)c, step, (uint32_t)i, PMCO_SITE_TRANS, 2u + (uint32_t)(q >> 1), v);
+                    const double x = pmco_u53(v[2 * (q & 1)], v[2 * (q & 1) + 1]) * sum_mu;
+                    double cm = 0.0;
+                    int d = -1, last = -1;
+                    for (int y = 0; y < ntab[cl]; y++) {
+                        if (!(t[y].ratio < 1.0)) continue;
+                        cm = cm + (t[y].hi - t[y].lo) * (1.0 - t[y].ratio) / t[y].ratio;
+                        last = y;
+                        if (x < cm) { d = y; break; }
+                    }
+                    if (d < 0) d = last;
+                    if ((size_t)nbox[c] == box_cap) { box_cap *= 2; box[c] = (entry *)realloc(box[c], sizeof(entry) * box_cap); }
+                    box[c][nbox[c]].slot = i; box[c][nbox[c]].dest = t[d].dest; box[c][nbox[c]].copies = 1;
+                    box[c][nbox[c]].stays = 1;
+                    nbox[c]++;
+                }
+                continue;
+            }
             int d = 0;
             while (!(u < t[d].hi)) d++;
             const double r = t[d].ratio;
@@ -1367,15 +1416,18 @@ int pmco_transport(pmco_cell *cells, int n_cells, int nx, int nz, int ny, int pe
             if (r != 1.0) {
                 const double u2 = pmco_u53(w[2], w[3]);
                 if (r > 1.0) copies = (u2 < 1.0 / r) ? 1 : 0;
-                else {
+                else if (g_trans_law == 0) {
                     copies = 1 + (int)(pmco_log(1.0 - u2) / pmco_log(1.0 - r));
                     if (copies > PMCO_TRANS_MAX_COPIES) copies = PMCO_TRANS_MAX_COPIES;
-                }
+                }   /* (law 1: a mover arrives once; the other 1 / r - 1 come from the emitters) */
             }
+            if ((size_t)nbox[c] == box_cap) { box_cap *= 2; box[c] = (entry *)realloc(box[c], sizeof(entry) * box_cap); }
             box[c][nbox[c]].slot = i; box[c][nbox[c]].dest = t[d].dest; box[c][nbox[c]].copies = copies;
+            box[c][nbox[c]].stays = 0;
             nbox[c]++;
+            n_movers++;
         }
-        n_moved[c] = nbox[c];
+        n_moved[c] = n_movers;
     }
     /* phase 2: arrivals appended in the fixed source order; sources still hold their data */
     int *n_old = (int *)malloc(sizeof(int) * (size_t)n_cells);
@@ -1410,7 +1462,7 @@ int pmco_transport(pmco_cell *cells, int n_cells, int nx, int nz, int ny, int pe
                     const int at = *dst->n_part;
                     if (at >= dst->cap) { /* no room: flagged, and the copy's new id is spent all the same */
                         status |= PMCO_ST_CAP_OVERFLOW;
-                        if (g != box[sc][e].copies - 1) next_id[c]++;
+                        if (g != box[sc][e].copies - 1 || box[sc][e].stays) next_id[c]++;
                         continue;
                     }
                     const int from = box[sc][e].slot;
@@ -1422,7 +1474,7 @@ int pmco_transport(pmco_cell *cells, int n_cells, int nx, int nz, int ny, int pe
                     dst->wclass[at] = s->wclass[from];
                     dst->lct[at] = s->lct[from]; dst->gct[at] = s->gct[from];
                     comp_copy(dst, at, s, from);
-                    if (g == box[sc][e].copies - 1) dst->id[at] = s->id[from];
+                    if (g == box[sc][e].copies - 1 && !box[sc][e].stays) dst->id[at] = s->id[from];
                     else { dst->id[at] = next_id[c]; next_id[c]++; }
                     *dst->n_part = at + 1;
                     arrived++;
@@ -1435,8 +1487,10 @@ int pmco_transport(pmco_cell *cells, int n_cells, int nx, int nz, int ny, int pe
     for (int c = 0; c < n_cells; c++) {
         const int n = *cells[c].n_part;
         unsigned char *dead = (unsigned char *)calloc((size_t)(n > 0 ? n : 1), 1);
-        for (int e = 0; e < nbox[c]; e++) dead[box[c][e].slot] = 1;
-        compact_stable(&cells[c], dead, n, nbox[c]);
+        int n_dead = 0;
+        for (int e = 0; e < nbox[c]; e++)
+            if (!box[c][e].stays) { dead[box[c][e].slot] = 1; n_dead++; }
+        compact_stable(&cells[c], dead, n, n_dead);
         free(dead);
         free(box[c]);
     }

@@ -206,6 +206,7 @@ int pmco_scenario_update(pmco_cell *c, double dt, double create_time, uint64_t s
                          int64_t *next_id, int32_t *n_emit, int32_t *n_dil_in,
                          int32_t *n_dil_out);
 
+void pmco_set_transport_law(int law);   /* 0 (default): the library's law; 1: prototype, pmco.c */
 int pmco_scenario_update_h(pmco_cell *c, double dt, double create_time, uint64_t seed,
                            uint32_t cell_id, uint32_t step, const pmco_aero_dist *emission,
                            double dilution_rate, const pmco_aero_dist *background,

@@ -477,6 +477,12 @@ def transport_preweight(cells, nx, nz, ny, prob_h, prob_v, cell_volume, n_ideal,
     return ex, nr
 
 
+def set_transport_law(law):
+    """0: the library's transport law (default); 1: the prototype of the reference's r < 1 law
+    (movers and emitters, pmco.c) -- oracle only."""
+    lib().pmco_set_transport_law(int(law))
+
+
 def transport(cells, nx, nz, ny, prob_h, prob_v, cell_volume, seed, cell_id_base, step, next_id,
               periodic_x=True, periodic_y=True, lateral=False):
     """pmco_transport over a list of Cell objects (WRF order).  next_id: int64 array, updated.

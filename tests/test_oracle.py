@@ -667,6 +667,49 @@ def test_weight_preparation_of_an_add(oracle):
     assert oc.mag[0] == mag0 and int(oc.n_part[0]) == 760 + ne
 
 
+@pytest.mark.parametrize("ratio", [0.4, 0.1])
+def test_prototype_of_the_reference_transport_law_for_small_ratios(oracle, ratio):
+    """DESIGN.md 11.4, oracle only (pmco_set_transport_law(1)): the r < 1 branch by Poisson thinning
+    of the reference's picks -- movers arrive once, particles that stay emit the other copies.
+    Against the transcription of the reference's pick loop: the same mean of arrivals and removals
+    AND the same variance of the arrivals (n p / r), where the library's law (0) has
+    n p (2 - r - p) / r^2."""
+    n_part, p, trials = 2000, 0.04, 150
+    dens = np.array([1500.0]); ve, _ = oracle.make_bin_tables(80, 1e-10, 1e-2)
+    rng = np.random.RandomState(11)
+    ref = np.array([_reference_sequential_sample(rng, n_part, p, ratio) for _ in range(1500)])
+    got = {0: [], 1: []}
+    try:
+        for law in (0, 1):
+            oracle.set_transport_law(law)
+            for t in range(trials):
+                cells = []
+                for c in range(2):
+                    oc = oracle.Cell(1, 1, 0, int(n_part * (1 + 3 * p / ratio)) + n_part, dens, ve)
+                    oc.mag[:] = 1e6 if c == 0 else 1e6 * ratio
+                    oc.generate([dict(frac=1, gm_radius=3e-8, gsd_log10=0.2, vol_frac=[1.0])], n_part, t, c, first_id=c << 32)
+                    cells.append(oc)
+                ph = np.zeros((2, 1, 4)); ph[0, 0, 1] = p
+                next_id = np.array([1 << 40, 2 << 40], dtype=np.int64)
+                st, nm, na = oracle.transport(cells, 2, 1, 1, ph, np.zeros((2, 1, 1)), np.ones(2), 1000 + t, 0, 0, next_id,
+                                              False, False)
+                assert st == 0 and int(cells[0].n_part[0]) == n_part - nm[0] and int(cells[1].n_part[0]) == n_part + na[1]
+                ids = np.concatenate([oc.id[:int(oc.n_part[0])] for oc in cells])
+                assert len(np.unique(ids)) == len(ids)
+                got[law].append((na[1], nm[0]))
+    finally:
+        oracle.set_transport_law(0)
+    g0, g1 = np.array(got[0], float), np.array(got[1], float)
+    mean_add = n_part * p / ratio
+    for g in (g0, g1):                                         # both laws: the reference's means
+        assert abs(g[:, 0].mean() - ref[:, 0].mean()) < 4 * math.sqrt(g[:, 0].var() / trials + ref[:, 0].var() / len(ref)) + 0.02 * mean_add
+        assert abs(g[:, 1].mean() - n_part * p) < 4 * math.sqrt(n_part * p / trials) + 0.03 * n_part * p
+    v_ref, v0, v1 = ref[:, 0].var(ddof=1), g0[:, 0].var(ddof=1), g1[:, 0].var(ddof=1)
+    assert abs(v_ref / (n_part * p / ratio) - 1) < 0.15                         # the reference: Poisson picks
+    assert abs(v1 / v_ref - 1) < 0.35, (v1, v_ref)                             # law 1: the reference's variance
+    assert v0 > (1.5 if ratio == 0.4 else 8.0) * v_ref, (v0, v_ref)           # law 0: (2 - r - p) / r times it
+
+
 def test_dry_deposition_velocity(oracle):
     """Zhang (2001) deposition velocity (wrf_pmc_dep_aero.F90:265-420): equal to an independent
     numpy transcription to rounding, U-shaped in diameter, settling-dominated for coarse
