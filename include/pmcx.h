@@ -534,6 +534,21 @@ int pmcx_dry_deposition(pmcx_ctx *ctx, double dt, uint64_t seed, uint32_t step,
  * prob_h == prob_v == NULL: the probabilities pmcx_transport_probs built (PMCX_ESTATE if none).
  * n_moved / n_arrived: [n_cells], may be NULL.  Synchronises.
  */
+/* How a particle that goes where particles stand for less (r = weight there / weight here < 1) turns
+ * into 1 / r arrivals.  The reference (wrf_pmc_trans_aero.F90:2236-2300) draws Poisson(n p / r) picks
+ * with replacement; every pick adds a copy and removes the picked particle with probability r.
+ *   law 0 (default)  a mover carries 1 + geometric copies (mean 1 / r): the reference's mean, its
+ *                    variance of the arrivals times (2 - r - p) / r
+ *   law 1            the reference's law by Poisson thinning of its picks: the removing picks are
+ *                    the movers, each arriving ONCE with its id; the non-removing picks, rate
+ *                    mu_d = p_d (1 - r_d) / r_d, are copies from particles that STAY -- behind the
+ *                    movers' intervals the placing uniform has one more of width 1 - exp(-sum mu):
+ *                    an emitter draws a zero-truncated Poisson(sum mu) number of copies and deals
+ *                    them to the r < 1 destinations in proportion mu, every copy under a new id.
+ *                    Mean n p / r, variance n p / r: the reference's.  At most 64 weight classes.
+ * Applies to pmcx_transport and pmcx_transport_begin ... _finish. */
+int pmcx_set_transport_law(pmcx_ctx *ctx, int32_t law);
+
 int pmcx_transport(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int32_t periodic_x,
                    int32_t periodic_y, const double *prob_h, const double *prob_v,
                    const double *cell_volume, uint64_t seed, uint32_t step, int32_t *n_moved,

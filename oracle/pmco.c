@@ -1402,6 +1402,7 @@ int pmco_transport(pmco_cell *cells, int n_cells, int nx, int nz, int ny, int pe
                         if (x < cm) { d = y; break; }
                     }
                     if (d < 0) d = last;
+                    if (nbox[c] >= s->cap) { status |= PMCO_ST_CAP_OVERFLOW; continue; }   /* an outbox holds cap entries */
                     if ((size_t)nbox[c] == box_cap) { box_cap *= 2; box[c] = (entry *)realloc(box[c], sizeof(entry) * box_cap); }
                     box[c][nbox[c]].slot = i; box[c][nbox[c]].dest = t[d].dest; box[c][nbox[c]].copies = 1;
                     box[c][nbox[c]].stays = 1;
@@ -1421,6 +1422,7 @@ int pmco_transport(pmco_cell *cells, int n_cells, int nx, int nz, int ny, int pe
                     if (copies > PMCO_TRANS_MAX_COPIES) copies = PMCO_TRANS_MAX_COPIES;
                 }   /* (law 1: a mover arrives once; the other 1 / r - 1 come from the emitters) */
             }
+            if (nbox[c] >= s->cap) { status |= PMCO_ST_CAP_OVERFLOW; continue; }   /* (law 1 only: the mover stays) */
             if ((size_t)nbox[c] == box_cap) { box_cap *= 2; box[c] = (entry *)realloc(box[c], sizeof(entry) * box_cap); }
             box[c][nbox[c]].slot = i; box[c][nbox[c]].dest = t[d].dest; box[c][nbox[c]].copies = copies;
             box[c][nbox[c]].stays = 0;

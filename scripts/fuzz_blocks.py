@@ -29,7 +29,7 @@ for run in range(n_runs):
     kw = dict(nz=int(rng.choice([1, 2, 3, 7])), n_class=int(rng.randint(1, 4)), n_spec=int(rng.randint(1, 3)),
               n_part=int(rng.choice([100, 400, 700])), seed=int(rng.randint(1 << 30)),
               prob=float(rng.choice([0.02, 0.08, 0.2])), ideal=float(rng.choice([0.45, 1.0, 3.0])),
-              n_steps=int(rng.randint(1, 4)), cap_factor=8.0)
+              n_steps=int(rng.randint(1, 4)), cap_factor=8.0, law=int(rng.randint(2)))
     parity.N_COMP_MAX = int(rng.choice([0, 0, 3, 8]))
     print(f"run {run}: periodic {periodic} shape {(nx, ny, bx, by)} lists {parity.N_COMP_MAX} {kw}", flush=True)
     try:

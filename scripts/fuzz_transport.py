@@ -31,6 +31,7 @@ for run in range(n_runs):
         nz = 2; n = nx * nz * ny
     kc = int(rng.choice([0, 0, 3, 8]))
     host.SAMPLER_VARIANT = [None, (1, 0, 0), (3, 0, 0)][rng.randint(3)]
+    law = int(rng.randint(2))            # pmcx_set_transport_law
     parity.N_COMP_MAX = kc
     seed = int(rng.randint(1 << 30))
     blk, cells, info = parity.setup_pair(wp, oracle, n, n_part, n_spec, n_class, seed, 4, cap=int(np.ceil(n_part * 3.0 / 64) * 64),
@@ -50,8 +51,9 @@ for run in range(n_runs):
     blk.set_n_part_ideal(n_ideal)
     if not periodic:
         blk.set_transport_lateral(True)
+    blk.set_transport_law(law); oracle.set_transport_law(law)
     print(f"run {run}: {nx} x {nz} x {ny} periodic {periodic} classes {n_class} species {n_spec} particles {n_part} "
-          f"lists {kc} variant {host.SAMPLER_VARIANT} seed {seed}", flush=True)
+          f"lists {kc} variant {host.SAMPLER_VARIANT} law {law} seed {seed}", flush=True)
     next_id = np.array([oc.next_id for oc in cells], dtype=np.int64)
     surface = ((np.arange(n) // nx) % nz == 0).astype(np.int32)
     for step in range(int(rng.randint(1, 4))):
@@ -93,4 +95,5 @@ for run in range(n_runs):
         assert ok, (run, step, "after mc_coag", msg)
         moved += int(nm.sum())
     blk.close()
+    oracle.set_transport_law(0)
 print(f"{n_runs} runs, {moved} movers, {time.time() - t0:.0f} s: all equal")

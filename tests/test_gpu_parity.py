@@ -1149,6 +1149,54 @@ def test_transport_parity(wp, oracle, nx, nz, ny, px, py):
     blk.close()
 
 
+@pytest.mark.parametrize("nx,nz,ny,periodic", [(3, 4, 2, True), (4, 5, 3, False), (1, 66, 1, False), (4, 2, 4, "open")])
+def test_transport_law_1_parity(wp, oracle, nx, nz, ny, periodic):
+    """pmcx_set_transport_law(1): the reference's r < 1 branch by thinning of its picks -- movers
+    arrive once, particles that stay emit the other copies (outbox entries with the "stays" bit, new
+    ids for every copy) -- against the oracle's, weights spread over two decades between cells so
+    that ratios from 0.01 to 100 occur; periodic, closed and open lateral boundaries, a column taller
+    than a wavefront; a coagulation step on the mixed populations."""
+    n_cells, n_part, n_spec, n_class = nx * nz * ny, 500, 2, 2
+    blk, cells, info = parity.setup_pair(wp, oracle, n_cells, n_part, n_spec, n_class, 19, K_BROWN,
+                                         cap=8192, n_source=2)
+    r = np.random.RandomState(6)
+    mag = info["mag"] * 10 ** r.uniform(-1, 1, (n_cells, 1))
+    blk.set_weights(mag)
+    for c, oc in enumerate(cells):
+        oc.mag[:] = mag[c]
+    ph, pv, cv = _transport_probs(n_cells, n_class, nz, 5, scale=0.05)
+    next_id = np.array([oc.next_id for oc in cells], dtype=np.int64)
+    lateral = periodic == "open"
+    px = py = (periodic is True)
+    if lateral:
+        blk.set_transport_lateral(True)
+    blk.set_transport_law(1)
+    oracle.set_transport_law(1)
+    stayed = 0
+    try:
+        for step in range(3):
+            n0 = blk.aero_state_total_particles().copy()
+            nm, na = blk.transport(nx, nz, ny, ph, pv, cv, 19, step, px, py)
+            st, onm, ona = oracle.transport(cells, nx, nz, ny, ph, pv, cv, 19, 0, step, next_id, px, py, lateral=lateral)
+            assert st == int(np.bitwise_or.reduce(blk.coag_counters()[2]))
+            assert np.array_equal(nm, onm) and np.array_equal(na, ona), step
+            ok, msg = parity.compare_state(blk, cells)
+            assert ok, f"step {step}: {msg}"
+            assert np.array_equal(blk.get_next_id(), next_id)
+            assert np.array_equal(blk.aero_state_total_particles(), n0 - nm + na)
+            stayed += int(na.sum()) - int(nm.sum())
+            ns, nc, s2 = blk.mc_coag(K_BROWN, 600.0, 19, step)
+            for c, oc in enumerate(cells):
+                assert oc.mc_coag(K_BROWN, 600.0, 19, oc.cell_id, step) == (int(s2[c]), int(ns[c]), int(nc[c]))
+    finally:
+        oracle.set_transport_law(0)
+    ids = blk.download_cells()["id"]
+    assert len(np.unique(ids)) == len(ids)
+    if not lateral:
+        assert stayed > 50            # copies from particles that stayed outnumber the losses at r > 1
+    blk.close()
+
+
 @pytest.mark.parametrize("n_class,all_columns,do_vertmix", [(2, True, 1), (1, False, 1), (2, True, 0)])
 def test_transport_probs_built_on_the_device(wp, oracle, n_class, all_columns, do_vertmix):
     """wrf_pmc_trans_driver's probability half (wrf_pmc_trans.F90:95-156) on the device from
@@ -1451,6 +1499,14 @@ def test_transport_slabs_match_whole_domain(wp):
         b.close()
 
 
+def test_transport_blocks_cut_in_x_and_y_law_1(wp):
+    """The exchange with pmcx_set_transport_law(1): an emitter's copies cross a cut as records with
+    the "stays" mark and arrive under new ids, as inside one block."""
+    for periodic, shape in ((True, (8, 6, 2, 2)), (False, (9, 4, 3, 1))):
+        total_moved, _ = blocks_cut_in_x_and_y(wp, periodic, shape, law=1, cap_factor=6.0)
+        assert total_moved > 2000
+
+
 @pytest.mark.parametrize("periodic,shape", [(True, (8, 6, 2, 2)), (False, (8, 6, 2, 2)), (True, (4, 6, 4, 2)),
                                             (False, (9, 4, 3, 1)), (True, (6, 3, 2, 1))])
 def test_transport_blocks_cut_in_x_and_y(wp, periodic, shape):
@@ -1460,7 +1516,7 @@ def test_transport_blocks_cut_in_x_and_y(wp, periodic, shape):
 
 
 def blocks_cut_in_x_and_y(wp, periodic, shape, nz=3, n_class=2, n_spec=2, n_part=400, seed=17, prob=0.08,
-                          ideal=0.45, n_steps=3, cap_factor=2.56):
+                          ideal=0.45, n_steps=3, cap_factor=2.56, law=0):
     """The transport exchange with both cut directions (the reference decomposes in x and y,
     wrf_pmc_trans_aero.F90:148-273): the domain as 2 x 2 blocks, each with a ghost row and a ghost
     column on every side, movers exported / imported through the four sides (what RCCL would carry
@@ -1486,6 +1542,7 @@ def blocks_cut_in_x_and_y(wp, periodic, shape, nz=3, n_class=2, n_spec=2, n_part
     whole.set_next_id((np.arange(n, dtype=np.int64) << 32) + (1 << 20))
     whole.set_n_part_ideal(np.full((n, n_class), ideal * n_part / n_class))
     whole.generate_lognormal(n_part, modes, seed=3)
+    whole.set_transport_law(law)
     if not periodic:
         whole.set_transport_lateral(True)
     dn = whole.download_cells()
@@ -1502,6 +1559,7 @@ def blocks_cut_in_x_and_y(wp, periodic, shape, nz=3, n_class=2, n_spec=2, n_part
             blk = wp.CellBlock(nloc, cap, n_spec, n_class=n_class, n_source=2, n_comp_max=kc,
                                cell_id_base=((gj0 * nz) * nx + gi0) % (1 << 32))
             blk.set_transport_cuts(True, nxl, gi0, nx)
+            blk.set_transport_law(law)
             if not periodic:
                 blk.set_transport_lateral(True, gj0, ny)
             blk.set_aero_data(dens); blk.set_env(280.0, 9e4)

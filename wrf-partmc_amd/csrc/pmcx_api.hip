@@ -617,6 +617,14 @@ int pmcx_set_weight_preparation(pmcx_ctx *ctx, int32_t on, int32_t allow_doublin
     ctx->st.prep_halving = allow_halving ? 1 : 0;
     return PMCX_OK;
 }
+int pmcx_set_transport_law(pmcx_ctx *ctx, int32_t law)
+{
+    if (!ctx || (law != 0 && law != 1)) return fail(ctx, PMCX_EINVAL, "pmcx_set_transport_law: law is 0 or 1");
+    if (law == 1 && ctx->cfg.n_class > 64)
+        return fail(ctx, PMCX_EINVAL, "pmcx_set_transport_law: law 1 takes at most 64 weight classes");
+    ctx->st.trans_law = law;
+    return PMCX_OK;
+}
 int pmcx_set_next_id(pmcx_ctx *ctx, const int64_t *next_id)
 {
     if (!ctx || !next_id) return fail(ctx, PMCX_EINVAL, "pmcx_set_next_id: null argument");

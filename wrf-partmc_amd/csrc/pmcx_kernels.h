@@ -109,6 +109,7 @@ struct DeviceState {
     // the coagulations of the last mc_coag in event order, merged by k_comp_merge behind the sampler
     int32_t n_comp_max;
     // aero_state_prepare_weight_for_add in every add from a distribution (pmcx_set_weight_preparation)
+    int32_t trans_law;    // 0: movers carry 1 + geometric copies when r < 1; 1: movers arrive once, emitters send the rest
     int32_t prep_on, prep_doubling, prep_halving;
     int32_t *prep_resume; // [1 + 5 n_cells]: count, then {cell, position, n_emit, n_dil_in, n_dil_out} (k_scenario_update)
     uint64_t *comp_src;  // [n_cells][cap]

@@ -3759,6 +3759,8 @@ __global__ __launch_bounds__(256) void k_dry_deposition(DeviceState st, DepArgs 
 //   k_trans_remove  one wavefront per source cell: the cell's live count, and the
 //                   tombstones of the movers that no gather of this block reads
 
+constexpr int TRANS_LAW_MAX_CLASS = 64; // (the emitters' interval per class lives in static LDS)
+constexpr int TRANS_STAYS = (int)0x80000000u; // outbox entry: the source particle stays (an emitter's copy)
 constexpr int TRANS_MAX_COPIES = 4096; // (a guard, not a law: P(G > 4096) is 2e-18 at r = 0.01, 1.7 % of the mean at r = 0.001)
 
 // open lateral boundaries: is local row j the domain's first or last row?
@@ -3795,6 +3797,9 @@ struct TransGrid {
                          // the grid is too small or too tall for the code to be unambiguous)
 };
 
+// EMIT: law 1 (pmcx_set_transport_law) -- its own instance, so that the emitters' code and registers
+// (82 against 45) are not the default law's to carry (1.73 -> 1.99 ms when they were)
+template <bool EMIT>
 __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid tg, uint64_t seed,
                                                      uint32_t step)
 {
@@ -3906,6 +3911,24 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
         lds_sync();
     }
     for (int x = lane; x < C * ND; x += 64) t_cnt[x] = 0;
+    // law 1 (pmcx_set_transport_law): behind the movers' intervals one more, the emitters' -- a
+    // particle that stays and sends copies towards the destinations with r < 1, rate
+    // mu_d = p_d (1 - r_d) / r_d each (the non-removing picks of the reference's Poisson sampler,
+    // wrf_pmc_trans_aero.F90:2236-2266); width 1 - exp(-sum mu)
+    __shared__ double s_mu_sum[TRANS_LAW_MAX_CLASS], s_act_hi[TRANS_LAW_MAX_CLASS];
+    if (lane < C && lane < TRANS_LAW_MAX_CLASS) {
+        const int cl = lane, nt = t_n[cl];
+        double sum_mu = 0.0, a_hi = nt > 0 ? t_hi[cl * ND + nt - 1] : 0.0;
+        if (EMIT && nt > 0) {
+            for (int d = 0; d < nt; d++) {
+                const double r = t_ratio[cl * ND + d];
+                if (r < 1.0) sum_mu = sum_mu + (t_hi[cl * ND + d] - t_lo[cl * ND + d]) * (1.0 - r) / r;
+            }
+            a_hi = a_hi + (1.0 - det_exp(-sum_mu));
+            if (a_hi > 1.0) a_hi = 1.0;
+        }
+        s_mu_sum[cl] = sum_mu; s_act_hi[cl] = a_hi;
+    }
     lds_sync();
 
     const int n_hi = st.n_hi[c];
@@ -3931,7 +3954,7 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
         return (int)q;
     };
     // (one class: the stay-or-go threshold is the same for every particle of the cell)
-    const double hi_last0 = t_n[0] > 0 ? t_hi[t_n[0] - 1] : 0.0;
+    const double hi_last0 = s_act_hi[0];
     __shared__ __align__(16) uint32_t s_words[256];
     __shared__ uint32_t s_qent[128], s_qrank[128]; // particles the prefix cannot tell for: slot | prefix << 16 | class << 24, rank
     // The destination uniform of the particle of rank r starts with an 8-bit prefix: byte r & 15 of
@@ -3953,18 +3976,27 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
         return (int)q;
     };
     int queued = 0; // entries in the queue (uniform)
+    bool out_full = false; // law 1: the outbox ran out of entries (uniform)
     // the first `take` queued particles: the rest of their uniform, destination, copies, outbox
     auto evaluate = [&](int take) {
         const uint32_t ent = lane < take ? s_qent[lane] : 0u, rank = lane < take ? s_qrank[lane] : 0u;
         const int s = (int)(ent & 0xFFFFu), cl = (int)(ent >> 24);
         bool moves = false;
         int dest = 0, copies = 0, dslot = 0;
+        int n_emit = 0;   // law 1: copies this lane's particle sends while it stays
         if (lane < take) {
             uint32_t w[4];
             rng_block(seed, cell_id, step, rank, SITE_TRANS, 1, w);
             const double u = ((double)((ent >> 16) & 0xFFu) + (double)w[0] * 0x1.0p-32) * 0x1.0p-8;
             const int nt = t_n[cl];
-            if (u < t_hi[cl * ND + nt - 1]) {
+            if (EMIT && nt > 0 && !(u < t_hi[cl * ND + nt - 1]) && u < s_act_hi[cl]) {
+                // an emitter: a zero-truncated Poisson(sum mu) number of copies
+                const double sum_mu = s_mu_sum[cl], u2 = u53(w[2], w[3]), e0 = det_exp(-sum_mu);
+                double term = e0 * sum_mu / (1.0 - e0), cdf = term;
+                n_emit = 1;
+                while (u2 >= cdf && n_emit < TRANS_MAX_COPIES) { n_emit++; term = term * sum_mu / (double)n_emit; cdf = cdf + term; }
+            }
+            if (nt > 0 && u < t_hi[cl * ND + nt - 1]) {
                 // the first threshold above u, looked for from the top: the probabilities are in
                 // ascending order, the last few destinations hold most of the mass
                 int d = nt - 1;
@@ -3974,10 +4006,10 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
                 if (r != 1.0) {
                     const double u2 = u53(w[2], w[3]);
                     if (r > 1.0) copies = (u2 < 1.0 / r) ? 1 : 0;
-                    else {
+                    else if (!EMIT) {
                         copies = 1 + (int)(det_log(1.0 - u2) / det_log(1.0 - r));
                         if (copies > TRANS_MAX_COPIES) copies = TRANS_MAX_COPIES;
-                    }
+                    } // (law 1: a mover arrives once; the other 1 / r - 1 come from the emitters)
                 }
                 dslot = cl * ND + d;
                 dest = t_dest[dslot];
@@ -3985,13 +4017,46 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
                 moves = true;
             }
         }
-        const uint64_t mm = __ballot(moves);
-        if (moves) box[n_out + (uint32_t)__popcll(mm & lt)] = make_int2(s | (copies << 16), dest);
+        if (!EMIT) {
+            const uint64_t mm = __ballot(moves);
+            if (moves) box[n_out + (uint32_t)__popcll(mm & lt)] = make_int2(s | (copies << 16), dest);
+            n_out += (uint32_t)__popcll(mm);
+        } else {
+            // entries of the chunk in rank order: a mover's one, an emitter's one per copy (each dealt
+            // to a destination with r < 1 in proportion mu, its uniform from the particle's own blocks)
+            const uint32_t ne = moves ? 1u : (uint32_t)n_emit;
+            const uint32_t inc = wave_incl_scan_u32(ne, lane);
+            const uint32_t first = n_out + inc - ne;
+            if (moves && first < (uint32_t)st.cap) box[first] = make_int2(s | (copies << 16), dest);
+            for (int q = 0; q < n_emit; q++) {
+                uint32_t v[4];
+                rng_block(seed, cell_id, step, rank, SITE_TRANS, 2u + (uint32_t)(q >> 1), v);
+                const double xq = u53(v[2 * (q & 1)], v[2 * (q & 1) + 1]) * s_mu_sum[cl];
+                const int nt = t_n[cl];
+                double cm = 0.0;
+                int d = -1, last = -1;
+                for (int y = 0; y < nt; y++) {
+                    const double r = t_ratio[cl * ND + y];
+                    if (!(r < 1.0)) continue;
+                    cm = cm + (t_hi[cl * ND + y] - t_lo[cl * ND + y]) * (1.0 - r) / r;
+                    last = y;
+                    if (xq < cm) { d = y; break; }
+                }
+                if (d < 0) d = last;
+                if (first + (uint32_t)q < (uint32_t)st.cap) { // (an outbox holds cap entries: beyond, flagged below)
+                    box[first + (uint32_t)q] = make_int2(s | (1 << 16) | TRANS_STAYS, t_dest[cl * ND + d]);
+                    bits |= t_bit[cl * ND + d];
+                    atomicAdd(&t_cnt[cl * ND + d], 1);
+                }
+            }
+            if (moves && !(first < (uint32_t)st.cap)) moves = false; // (dropped with the rest: it stays)
+            n_out += (uint32_t)__shfl(inc, 63, 64);
+            if (n_out > (uint32_t)st.cap) { n_out = (uint32_t)st.cap; out_full = true; }
+        }
         // (a mover's sort key says "gone" from here on; its record lives until the gather of its
         // destination, or k_trans_remove, has dealt with it)
         if (moves && keyed) st.gkey[cb + s] = (uint16_t)0xFFFFu;
         if (moves && copies > 0) atomicAdd(&t_cnt[dslot], copies);
-        n_out += (uint32_t)__popcll(mm);
         // what is left moves to the front of the queue
         lds_sync();
         const int rest = queued - take;
@@ -4036,7 +4101,7 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
             const uint32_t idx = (rank - 16u * B0) & 1023u;
             const uint32_t p8 = (s_words[idx >> 2] >> (8u * (idx & 3u))) & 0xFFu;
             // (one class: no table look-up for the particles that stay, almost all of them)
-            const bool need = cl >= 0 && (double)p8 * 0x1.0p-8 < (C == 1 ? hi_last0 : (t_n[cl] > 0 ? t_hi[cl * ND + t_n[cl] - 1] : 0.0));
+            const bool need = cl >= 0 && (double)p8 * 0x1.0p-8 < (C == 1 ? hi_last0 : cl < TRANS_LAW_MAX_CLASS ? s_act_hi[cl] : (t_n[cl] > 0 ? t_hi[cl * ND + t_n[cl] - 1] : 0.0));
             const uint64_t mneed = __ballot(need);
             if (need) {
                 const int pos = queued + __popcll(mneed & lt);
@@ -4060,7 +4125,10 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
             atomicAdd(&tg.n_exp[dcell], t_cnt[x]);
         }
     for (int d = 32; d >= 1; d >>= 1) bits |= __shfl_xor(bits, d, 64);
-    if (lane == 0) { tg.n_out[c] = (int32_t)n_out; tg.dest_mask[c] = bits; }
+    if (lane == 0) {
+        tg.n_out[c] = (int32_t)n_out; tg.dest_mask[c] = bits;
+        if (out_full) atomicOr(&st.status[c], ST_CAP_OVERFLOW);
+    }
 }
 
 // The transport probabilities of one step, built where the particles are (SURVEY 8 f2,
@@ -4770,12 +4838,13 @@ __global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid t
     // move the first `take` queued arrivals (records, keys, ids), in queue order
     auto emit = [&](int take) {
         const int sc = lane < take ? s_qsc[lane] : 0, x = lane < take ? s_qx[lane] : 0;
-        const int copies = lane < take ? (x >> 16) : 0, from = x & 0xFFFF;
+        const int copies = lane < take ? ((x >> 16) & 0x7FFF) : 0, from = x & 0xFFFF;
+        const bool stays = x < 0; // (an emitter's copy: the source keeps its particle, every copy a new id)
         const int64_t sb = (int64_t)sc * st.cap;
         // slots and new ids of this entry's copies: prefix sums over the chunk
         const uint32_t inc = wave_incl_scan_u32((uint32_t)copies, lane);
         const uint32_t first = (uint32_t)at + inc - (uint32_t)copies;
-        const uint32_t n_new = copies > 0 ? (uint32_t)(copies - 1) : 0u;
+        const uint32_t n_new = copies > 0 ? (uint32_t)(stays ? copies : copies - 1) : 0u;
         const uint32_t inc_new = wave_incl_scan_u32(n_new, lane);
         const int64_t id0 = nid + (int64_t)(inc_new - n_new);
         if (copies > 0) {
@@ -4787,7 +4856,7 @@ __global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid t
             const uint16_t kd = key_of(st, hv.vtot, wc); // (from the record: the source's keys may not hold)
             // the mover's tombstone, into the line just read (k_trans_remove leaves these alone:
             // a store to a line nobody has read costs a read-modify-write in memory)
-            st.hot[sb + from].vtot = -1.0;
+            if (!stays) st.hot[sb + from].vtot = -1.0;
             for (int g = 0; g < copies; g++) {
                 const int dst = (int)first + g;
                 if (dst >= st.cap) { status |= ST_CAP_OVERFLOW; break; }
@@ -4800,7 +4869,7 @@ __global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid t
                 st.gkey[cb + dst] = kd;
                 if (st.n_class > 1) st.wclass[cb + dst] = wc;
                 Cold c2 = cv;
-                if (g != copies - 1) c2.id = id0 + g;
+                if (stays || g != copies - 1) c2.id = id0 + g;
                 st.cold[cb + dst] = c2;
                 comp_copy(st, cb + dst, sb + from);
             }
@@ -4876,7 +4945,7 @@ __global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid t
             const int2 en = nen;
             const int esc = nsc;
             if (f0 + 64 < total) nen = fetch(f0 + 64 + lane, nsc); // requested before this chunk's work
-            const bool mine = en.y == c && (en.x >> 16) > 0;
+            const bool mine = en.y == c && ((en.x >> 16) & 0x7FFF) > 0;
             const uint64_t mm = __ballot(mine);
             if (mine) {
                 const int pos = queued + __popcll(mm & ((1ull << lane) - 1ull));
@@ -4911,10 +4980,15 @@ __global__ __launch_bounds__(64) void k_trans_remove(DeviceState st, TransGrid t
     // keys were seen to by k_trans_decide.
     const int nx = tg.nx, nz = tg.nz, ny = tg.ny;
     if (ghost_col(st, c % nx, nx)) return; // (a ghost column's cells are emptied by k_halo_clear)
-    for (int e = lane; e < n_out; e += 64) {
-        const int2 en = box[e];
+    int n_movers = 0;
+    for (int e0 = 0; e0 < n_out; e0 += 64) {
+        const int e = e0 + lane;
+        const int2 en = e < n_out ? box[e] : make_int2(TRANS_STAYS, -1);
+        const bool stays = en.x < 0; // (an emitter's copy, law 1: its particle is not going anywhere)
+        n_movers += __popcll(__ballot(!stays));
+        if (stays) continue;
         const int dest = en.y;
-        bool gathered = (en.x >> 16) > 0 && dest >= tg.c_first && dest < tg.c_first + (int)gridDim.x &&
+        bool gathered = ((en.x >> 16) & 0x7FFF) > 0 && dest >= tg.c_first && dest < tg.c_first + (int)gridDim.x &&
                         !ghost_col(st, dest % nx, nx); // (to a ghost column: packed for the neighbouring rank)
         if (gathered && st.trans_lateral) {
             const int di = dest % nx, dj = dest / (nx * nz);
@@ -4924,8 +4998,11 @@ __global__ __launch_bounds__(64) void k_trans_remove(DeviceState st, TransGrid t
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wave_sync();
-    const int n_live = st.n_part[c] - n_out;
-    if (lane == 0) st.n_part[c] = n_live;
+    const int n_live = st.n_part[c] - n_movers;
+    if (lane == 0) {
+        st.n_part[c] = n_live;
+        tg.n_out[c] = n_movers; // (what the caller reads as n_moved: the particles that left, not the entries)
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __threadfence_block();
     wave_sync();
@@ -5020,8 +5097,8 @@ __global__ __launch_bounds__(64) void k_halo_pack(DeviceState st, TransGrid tg, 
             unsigned char *rec = recs + (size_t)(offsets[r] + idx) * rec_bytes;
             const int from = en.x & 0xFFFF;
             int32_t *h = (int32_t *)rec;
-            h[0] = r; h[1] = didx; h[2] = en.x >> 16;
-            h[3] = st.wclass[cb + from]; h[4] = idx; h[5] = 0;
+            h[0] = r; h[1] = didx; h[2] = (en.x >> 16) & 0x7FFF;
+            h[3] = st.wclass[cb + from]; h[4] = idx; h[5] = en.x < 0 ? 1 : 0; // (the source particle stays: law 1)
             double *d = (double *)(rec + 24);
             d[0] = st.hot[cb + from].vtot; d[1] = st.hot[cb + from].mass;
             d[2] = st.hot[cb + from].lct; d[3] = st.hot[cb + from].gct;
@@ -5079,7 +5156,7 @@ __global__ __launch_bounds__(64) void k_halo_unpack(DeviceState st, TransGrid tg
             st.comp_src[cb + slot] = ((const uint64_t *)cm)[0];
             for (int q = 0; q < st.n_comp_max; q++) st.comp_time[(cb + slot) * st.n_comp_max + q] = cm[1 + q];
         }
-        box[slot] = make_int2(slot | (copies << 16), dest);
+        box[slot] = make_int2(slot | (copies << 16) | ((ok && h[5] == 1) ? TRANS_STAYS : 0), dest);
         if (copies > 0) atomicAdd(&tg.n_exp[dest], copies);
     }
     if (lane == 0) {
@@ -5709,9 +5786,14 @@ hipError_t launch_transport_begin(const DeviceState &st, int nx, int nz, int ny,
     const TransGrid tg = make_grid(nx, nz, ny, periodic_x, periodic_y, prob_h, prob_v, cell_volume,
                                    outbox, n_out, n_arr, n_exp, dest_mask, 0);
     const size_t lds = transport_lds_bytes(st, nz);
-    allow_lds(k_trans_decide, lds);
     (void)hipMemsetAsync(n_exp, 0, sizeof(int32_t) * (size_t)st.n_cells, s);
-    hipLaunchKernelGGL(k_trans_decide, dim3(st.n_cells), dim3(64), lds, s, st, tg, seed, step);
+    if (st.trans_law == 1) {
+        allow_lds(k_trans_decide<true>, lds);
+        hipLaunchKernelGGL(k_trans_decide<true>, dim3(st.n_cells), dim3(64), lds, s, st, tg, seed, step);
+    } else {
+        allow_lds(k_trans_decide<false>, lds);
+        hipLaunchKernelGGL(k_trans_decide<false>, dim3(st.n_cells), dim3(64), lds, s, st, tg, seed, step);
+    }
     return hipGetLastError();
 }
 // room, gather, remove on the rows [row_first, row_first + n_rows); ghost rows emptied

@@ -118,6 +118,11 @@ module pmcx_c
        type(c_ptr), value :: ctx
        integer(c_int32_t), value :: on, allow_doubling, allow_halving
      end function pmcx_set_weight_preparation
+     integer(c_int) function pmcx_set_transport_law(ctx, law) bind(c, name="pmcx_set_transport_law")
+       import :: c_ptr, c_int, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: law
+     end function pmcx_set_transport_law
      integer(c_int) function pmcx_set_cell_id_base(ctx, cell_id_base) bind(c, name="pmcx_set_cell_id_base")
        import :: c_ptr, c_int, c_int32_t
        type(c_ptr), value :: ctx

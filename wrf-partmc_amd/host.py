@@ -24,7 +24,7 @@ COAG_KERNEL_TYPE_BROWN_SEDI = 101
 EXPORTED_SYMBOLS = [
     "pmcx_config_default", "pmcx_create", "pmcx_destroy", "pmcx_last_error", "pmcx_synchronize",
     "pmcx_set_aero_data", "pmcx_set_env", "pmcx_set_weights", "pmcx_get_weights",
-    "pmcx_set_n_part_ideal", "pmcx_set_weight_preparation", "pmcx_set_next_id", "pmcx_get_next_id", "pmcx_upload_cells",
+    "pmcx_set_n_part_ideal", "pmcx_set_weight_preparation", "pmcx_set_transport_law", "pmcx_set_next_id", "pmcx_get_next_id", "pmcx_upload_cells",
     "pmcx_get_n_part", "pmcx_download_cells", "pmcx_upload_components", "pmcx_download_components", "pmcx_update_kernel_bounds",
     "pmcx_set_kernel_bounds_margin", "pmcx_mc_coag",
     "pmcx_get_coag_counters", "pmcx_get_coag_totals", "pmcx_accumulate_totals",
@@ -210,6 +210,7 @@ def load_library():
     L.pmcx_mc_coag.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_uint64, C.c_uint32]
     L.pmcx_rebalance.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_uint32]
     L.pmcx_set_weight_preparation.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+    L.pmcx_set_transport_law.argtypes = [C.c_void_p, C.c_int32]
     L.pmcx_set_kernel_bounds_margin.argtypes = [C.c_void_p, C.c_int32]
     L.pmcx_condense.argtypes = [C.c_void_p, C.c_double, C.c_int32]
     L.pmcx_transport.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
@@ -406,6 +407,11 @@ class CellBlock:
         """aero_state_prepare_weight_for_add in front of every add from a distribution (emission,
         background, sea salt, the refill of an emptied boundary cell): pmcx.h.  Off by default."""
         self._ck(self._lib.pmcx_set_weight_preparation(self._h, int(on), int(allow_doubling), int(allow_halving)))
+
+    def set_transport_law(self, law):
+        """0: a mover towards a smaller weight carries 1 + geometric copies; 1: the reference's law --
+        movers arrive once, particles that stay emit the other copies (pmcx.h)."""
+        self._ck(self._lib.pmcx_set_transport_law(self._h, int(law)))
 
     def set_next_id(self, next_id):
         a = np.broadcast_to(np.asarray(next_id, dtype=np.int64), (self.cfg.n_cells,)).copy()
