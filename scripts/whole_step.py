@@ -35,6 +35,7 @@ ap.add_argument("--given-probs", action="store_true",
                 help="hand the transport fixed probabilities instead of building them from WRF-shaped "
                      "fields on the device every step (transport_probs + transport_preweight)")
 ap.add_argument("--trace", type=int, default=0, help="every TRACE steps: cells thinned by the preweight, weight and population spread (stderr)")
+ap.add_argument("--law", type=int, default=0, help="pmcx_set_transport_law: 0 movers with geometric copies, 1 movers and emitters")
 ap.add_argument("--prep", action="store_true", help="the adds' weight preparation on (pmcx_set_weight_preparation), as the Fortran drivers run")
 ap.add_argument("--sync-stages", action="store_true", help="every stage call waits for the device (the default before round 3)")
 a = ap.parse_args()
@@ -56,6 +57,7 @@ blk.set_weights(np.full((n, 1), 1e10 / N))
 blk.set_n_part_ideal(np.full((n, 1), float(N)))
 if a.prep:
     blk.set_weight_preparation(True, True, True)
+blk.set_transport_law(a.law)
 blk.set_next_id((np.arange(n, dtype=np.int64) << 32) + (1 << 24))
 blk.generate_lognormal(N, idealised_modes(1, 1), seed=0)
 blk.synchronize()      # (no pmcx_update_kernel_bounds: mc_coag keeps each cell's bounds current)

@@ -1850,6 +1850,39 @@ def test_transport_follows_the_sampling_law(wp):
     assert v0 > 1.5 * (horiz + var_dn_ref)             # (and it is not the reference's: stated, not hidden)
 
 
+def test_transport_law_1_has_the_reference_variance(wp):
+    """pmcx_set_transport_law(1) on the HIP path, without the oracle: coming down a level where
+    particles stand for half as much (r = 1/2) the arrivals of a cell have mean n p / r AND variance
+    n p / r -- the reference's Poisson picks (wrf_pmc_trans_aero.F90:2236-2266) -- where law 0 has
+    n p (2 - r - p) / r^2 (test_transport_follows_the_sampling_law); movers stay binomial."""
+    nx, nz, ny, n_part = 64, 2, 32, 2000
+    n_cells = nx * nz * ny
+    lev = (np.arange(n_cells) // nx) % nz
+    vol = np.where(lev == 0, 1.0, 2.0)
+    p_dn = 0.03
+    ph = np.zeros((n_cells, 1, 4)); pv = np.zeros((n_cells, 1, nz))
+    pv[lev == 1, 0, 0] = p_dn
+    from wrf_partmc_amd.data import idealised_modes
+    with wp.CellBlock(n_cells, 4096, 1) as blk:
+        blk.set_aero_data([1500.0]); blk.set_env(280.0, 9e4)
+        blk.set_weights(np.full((n_cells, 1), 1e7))
+        blk.set_next_id((np.arange(n_cells, dtype=np.int64) << 32) + (1 << 24))
+        blk.generate_lognormal(n_part, idealised_modes(1), seed=4)
+        blk.set_transport_law(1)
+        nm, na = blk.transport(nx, nz, ny, ph, pv, vol, seed=4, step=0)
+        n_after = blk.aero_state_total_particles()
+        ids = blk.download_cells()["id"]
+    assert np.array_equal(n_after, n_part - nm + na) and len(np.unique(ids)) == len(ids)
+    n1 = int((lev == 1).sum())
+    movers, arrivals = nm[lev == 1].astype(float), na[lev == 0].astype(float)
+    assert abs(movers.sum() - n1 * n_part * p_dn) < 5 * np.sqrt(n1 * n_part * p_dn)
+    assert abs(movers.var(ddof=1) / (n_part * p_dn * (1 - p_dn)) - 1) < 0.15
+    mean_ref = n_part * p_dn / 0.5
+    assert abs(arrivals.mean() - mean_ref) < 5 * np.sqrt(mean_ref / n1)
+    assert abs(arrivals.var(ddof=1) / mean_ref - 1) < 0.15, (arrivals.var(ddof=1), mean_ref)     # the reference's n p / r
+    assert arrivals.var(ddof=1) < 0.6 * n_part * p_dn * (2 - 0.5 - p_dn) / 0.25                  # not law 0's
+
+
 def test_transport_copies_at_a_small_weight_ratio(wp):
     """r = 1/20 (a particle of a heavy-weight cell arriving where particles stand for a twentieth):
     1 + geometric copies, twenty on average.  The count has a guard of 4096, not the 16 it had

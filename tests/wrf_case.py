@@ -289,8 +289,12 @@ class Case:
             next_id = np.array([oc.next_id for oc in cells], dtype=np.int64)
             oracle.transport_preweight(cells, nx, nz, ny, ph, pv, cv, self.n_ideal, seed, 0, wrf_step,
                                        self.periodic, self.periodic)
-            st, nm, na = oracle.transport(cells, nx, nz, ny, ph, pv, cv, seed, 0, wrf_step, next_id,
-                                          self.periodic, self.periodic, lateral=not self.periodic)
+            oracle.set_transport_law(1)          # (the driver's choice: wrf_pmc_trans_driver_pmcx)
+            try:
+                st, nm, na = oracle.transport(cells, nx, nz, ny, ph, pv, cv, seed, 0, wrf_step, next_id,
+                                              self.periodic, self.periodic, lateral=not self.periodic)
+            finally:
+                oracle.set_transport_law(0)
             assert st == 0
             for c, oc in enumerate(cells):
                 oc.next_id = int(next_id[c])

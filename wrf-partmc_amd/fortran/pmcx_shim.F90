@@ -1389,7 +1389,10 @@ contains
        end do
        end do
        end do
-       ! trans_aero (wrf_pmc_trans_aero.F90:40-971)
+       ! trans_aero (wrf_pmc_trans_aero.F90:40-971); the sampling in the form that has the reference's
+       ! variance where weights differ (movers arrive once, particles that stay send the other
+       ! copies: pmcx_set_transport_law, :2236-2300)
+       call pmcx_die(pmcx_set_transport_law(ctx, 1), 'pmcx_set_transport_law')
        call pmcx_die(pmcx_set_transport_lateral(ctx, merge(0, 1, ideal), 0, 0), 'pmcx_set_transport_lateral')
        call pmcx_die(pmcx_transport_preweight(ctx, nx, nz, ny, merge(1, 0, ideal), merge(1, 0, ideal), &
             c_null_ptr, c_null_ptr, cell_volume, int(grid%random_seed, c_int64_t), step, expected, n_rem), &
