@@ -16,7 +16,7 @@ from tests.test_gpu_parity import (  # noqa: F401
     test_mc_coag_parity, test_mc_coag_dense_events, test_rebalance_parity,
     test_results_independent_of_partition, test_split_off_draw, test_tombstones_and_lazy_compaction,
     test_wide_distribution_beyond_lds_window, test_scenario_update_parity, test_weight_preparation_parity,
-    test_seasalt_emissions_parity, test_transport_parity, test_transport_preweight_parity,
+    test_seasalt_emissions_parity, test_transport_parity, test_transport_law_1_parity, test_transport_preweight_parity,
     test_open_lateral_boundaries, test_transport_makes_room_among_tombstones,
     test_transport_slabs_match_whole_domain, test_transport_blocks_cut_in_x_and_y, test_dry_deposition_parity)
 from tests.test_gpu_timestep import test_partmc_timestep_loop  # noqa: F401
