@@ -546,6 +546,7 @@ int pmcx_dry_deposition(pmcx_ctx *ctx, double dt, uint64_t seed, uint32_t step,
  *                    an emitter draws a zero-truncated Poisson(sum mu) number of copies and deals
  *                    them to the r < 1 destinations in proportion mu, every copy under a new id.
  *                    Mean n p / r, variance n p / r: the reference's.  At most 64 weight classes.
+ *                    (Where sum p + 1 - exp(-sum mu) would exceed 1 the emitters' interval is cut at 1.)
  * Applies to pmcx_transport and pmcx_transport_begin ... _finish. */
 int pmcx_set_transport_law(pmcx_ctx *ctx, int32_t law);
 
