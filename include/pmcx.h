@@ -537,9 +537,10 @@ int pmcx_dry_deposition(pmcx_ctx *ctx, double dt, uint64_t seed, uint32_t step,
 /* How a particle that goes where particles stand for less (r = weight there / weight here < 1) turns
  * into 1 / r arrivals.  The reference (wrf_pmc_trans_aero.F90:2236-2300) draws Poisson(n p / r) picks
  * with replacement; every pick adds a copy and removes the picked particle with probability r.
- *   law 0 (default)  a mover carries 1 + geometric copies (mean 1 / r): the reference's mean, its
- *                    variance of the arrivals times (2 - r - p) / r
- *   law 1            the reference's law by Poisson thinning of its picks: the removing picks are
+ *   law 0            a mover carries 1 + geometric copies (mean 1 / r): the reference's mean, its
+ *                    variance of the arrivals times (2 - r - p) / r (the library's law until the
+ *                    end of round 3; the default with more than 64 weight classes)
+ *   law 1 (default)  the reference's law by Poisson thinning of its picks: the removing picks are
  *                    the movers, each arriving ONCE with its id; the non-removing picks, rate
  *                    mu_d = p_d (1 - r_d) / r_d, are copies from particles that STAY -- behind the
  *                    movers' intervals the placing uniform has one more of width 1 - exp(-sum mu):

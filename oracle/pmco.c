@@ -1256,7 +1256,7 @@ void pmco_diagnostics_ext(const pmco_cell *c, int i_water, double *species_mass,
 
 typedef struct { int dest; double lo, hi, ratio; } trans_dest;
 
-/* PROTOTYPE (oracle only, off by default): the r < 1 branch in the reference's own
+/* Law 1 (the default; pmcx_set_transport_law): the r < 1 branch in the reference's own
  * law, by Poisson thinning of its picks (wrf_pmc_trans_aero.F90:2244-2300: Poisson(n p / r) picks
  * with replacement, each adds a copy and removes the picked particle with probability r).  The
  * removing picks (rate p) are the movers -- a mover towards r < 1 arrives ONCE, id kept; the
@@ -1265,7 +1265,7 @@ typedef struct { int dest; double lo, hi, ratio; } trans_dest;
  * which draws a zero-truncated Poisson(sum mu) number of copies and deals them to the r < 1
  * destinations in proportion mu, every copy under a new id.  Mean n p / r as law 0, variance
  * n p / r as the reference's. */
-static int g_trans_law = 0;
+static int g_trans_law = 1;     /* the default, as the library's */
 void pmco_set_transport_law(int law) { g_trans_law = law; }
 
 /* destination table of (cell c, class cl): returns the number of entries */

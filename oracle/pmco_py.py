@@ -477,9 +477,12 @@ def transport_preweight(cells, nx, nz, ny, prob_h, prob_v, cell_volume, n_ideal,
     return ex, nr
 
 
-def set_transport_law(law):
-    """0: the library's transport law (default); 1: the prototype of the reference's r < 1 law
-    (movers and emitters, pmco.c) -- oracle only."""
+DEFAULT_TRANSPORT_LAW = 1
+
+
+def set_transport_law(law=DEFAULT_TRANSPORT_LAW):
+    """1 (default): the reference's r < 1 law -- movers arrive once, particles that stay emit the
+    other copies; 0: a mover carries 1 + geometric copies (pmcx_set_transport_law, pmco.c)."""
     lib().pmco_set_transport_law(int(law))
 
 

@@ -95,5 +95,5 @@ for run in range(n_runs):
         assert ok, (run, step, "after mc_coag", msg)
         moved += int(nm.sum())
     blk.close()
-    oracle.set_transport_law(0)
+    oracle.set_transport_law()
 print(f"{n_runs} runs, {moved} movers, {time.time() - t0:.0f} s: all equal")

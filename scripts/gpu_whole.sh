@@ -14,7 +14,7 @@ python3 - <<PY > $R/gpurun_out/whole_per_call_$tag.txt
 import csv, collections
 d = collections.defaultdict(list)
 for r in csv.DictReader(open("$t")):
-    n = r["Kernel_Name"].split("(")[0].replace("pmcx::", "").replace("void ", "")
+    n = r["Kernel_Name"].split("(")[0].replace("pmcx::", "").replace("void ", "").split("<")[0]
     d[n].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 for n in ("k_trans_decide", "k_trans_gather", "k_trans_remove", "k_dry_deposition", "k_scenario_update", "k_bin_sort", "k_kernel_bounds"):
     if n in d:

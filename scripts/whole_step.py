@@ -35,7 +35,7 @@ ap.add_argument("--given-probs", action="store_true",
                 help="hand the transport fixed probabilities instead of building them from WRF-shaped "
                      "fields on the device every step (transport_probs + transport_preweight)")
 ap.add_argument("--trace", type=int, default=0, help="every TRACE steps: cells thinned by the preweight, weight and population spread (stderr)")
-ap.add_argument("--law", type=int, default=0, help="pmcx_set_transport_law: 0 movers with geometric copies, 1 movers and emitters")
+ap.add_argument("--law", type=int, default=1, help="pmcx_set_transport_law: 0 movers with geometric copies, 1 movers and emitters")
 ap.add_argument("--prep", action="store_true", help="the adds' weight preparation on (pmcx_set_weight_preparation), as the Fortran drivers run")
 ap.add_argument("--sync-stages", action="store_true", help="every stage call waits for the device (the default before round 3)")
 a = ap.parse_args()

@@ -1189,7 +1189,7 @@ def test_transport_law_1_parity(wp, oracle, nx, nz, ny, periodic):
             for c, oc in enumerate(cells):
                 assert oc.mc_coag(K_BROWN, 600.0, 19, oc.cell_id, step) == (int(s2[c]), int(ns[c]), int(nc[c]))
     finally:
-        oracle.set_transport_law(0)
+        oracle.set_transport_law()
     ids = blk.download_cells()["id"]
     assert len(np.unique(ids)) == len(ids)
     if not lateral:
@@ -1813,6 +1813,7 @@ def test_transport_follows_the_sampling_law(wp):
         blk.set_weights(np.full((n_cells, 1), 1e7))
         blk.set_next_id((np.arange(n_cells, dtype=np.int64) << 32) + (1 << 24))
         blk.generate_lognormal(n_part, idealised_modes(1), seed=4)
+        blk.set_transport_law(0)             # (law 1: test_transport_law_1_has_the_reference_variance)
         nm, na = blk.transport(nx, nz, ny, ph, pv, vol, seed=4, step=0)
         n_after = blk.aero_state_total_particles()
     assert np.array_equal(n_after, n_part - nm + na)
@@ -1901,6 +1902,7 @@ def test_transport_copies_at_a_small_weight_ratio(wp):
         blk.set_weights(np.full((n_cells, 1), 1e7))
         blk.set_next_id((np.arange(n_cells, dtype=np.int64) << 32) + (1 << 24))
         blk.generate_lognormal(n_part, idealised_modes(1), seed=6)
+        blk.set_transport_law(0)             # (the law with copies per mover)
         nm, na = blk.transport(nx, nz, ny, ph, pv, vol, seed=6, step=0)
         assert not np.bitwise_or.reduce(blk.coag_counters()[2])
         ids = blk.download_cells()["id"]

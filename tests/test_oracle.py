@@ -698,7 +698,7 @@ def test_prototype_of_the_reference_transport_law_for_small_ratios(oracle, ratio
                 assert len(np.unique(ids)) == len(ids)
                 got[law].append((na[1], nm[0]))
     finally:
-        oracle.set_transport_law(0)
+        oracle.set_transport_law()
     g0, g1 = np.array(got[0], float), np.array(got[1], float)
     mean_add = n_part * p / ratio
     for g in (g0, g1):                                         # both laws: the reference's means

@@ -294,7 +294,7 @@ class Case:
                 st, nm, na = oracle.transport(cells, nx, nz, ny, ph, pv, cv, seed, 0, wrf_step, next_id,
                                               self.periodic, self.periodic, lateral=not self.periodic)
             finally:
-                oracle.set_transport_law(0)
+                oracle.set_transport_law()
             assert st == 0
             for c, oc in enumerate(cells):
                 oc.next_id = int(next_id[c])
