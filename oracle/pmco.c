@@ -1241,7 +1241,8 @@ void pmco_diagnostics_ext(const pmco_cell *c, int i_water, double *species_mass,
  * leaves its cell.  With r = weight_to' / weight_from:
  *   r == 1: one copy arrives                                   (:2254-2257)
  *   r  > 1: it arrives with probability 1/r                    (:2267-2273)
- *   r  < 1: G >= 1 copies arrive, P(G = g) = r (1-r)^(g-1), capped at 4096 (a guard: 16 until round 3, which cost 18 % of the arrivals at r = 0.1);
+ *   r  < 1 (law 0; law 1, the default, is described at g_trans_law below):
+ *           G >= 1 copies arrive, P(G = g) = r (1-r)^(g-1), capped at 4096 (a guard: 16 until round 3, which cost 18 % of the arrivals at r = 0.1);
  *           the last keeps the id, the others get new ids      (:2258-2266,2279-2283)
  *           [the reference reaches the same mean 1/r with repeated picks]
  * The placing uniform of the particle of rank i (among the cell's live particles) is 32 bits:

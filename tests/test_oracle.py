@@ -669,7 +669,7 @@ def test_weight_preparation_of_an_add(oracle):
 
 @pytest.mark.parametrize("ratio", [0.4, 0.1])
 def test_prototype_of_the_reference_transport_law_for_small_ratios(oracle, ratio):
-    """DESIGN.md 11.4, oracle only (pmco_set_transport_law(1)): the r < 1 branch by Poisson thinning
+    """Law 1 of the transport (the default): the r < 1 branch by Poisson thinning
     of the reference's picks -- movers arrive once, particles that stay emit the other copies.
     Against the transcription of the reference's pick loop: the same mean of arrivals and removals
     AND the same variance of the arrivals (n p / r), where the library's law (0) has
