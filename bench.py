@@ -14,7 +14,9 @@ total work is fixed as N grows ("strong").
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.
+The first form starts its own ranks when N > 1 and no launcher set WORLD_SIZE: a child
+`python -m torch.distributed.run` of this file, started before this process touches the GPU;
+rank 0's line and the children's exit code are passed on.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -54,19 +56,17 @@ def level_profile(levels):
 
 
 def algorithmic_bytes(name, n_spec, n_class, n_source, particles, candidates, events):
-    """Algorithmic HBM bytes of one launch (DESIGN.md 'Kernels and rooflines',
-    per-unit figures from SURVEY.md 8(d))."""
+    """Algorithmic HBM bytes of one launch: SURVEY.md 8(d)'s per-unit figures, nothing added."""
     meta = 28  # id 8 + create times 16 + class 4
     if name == "bin_sort":
-        return particles * (8 + 4 + (4 if n_class > 1 else 0))
+        return particles * (8 + 4)
     if name == "coag_sample":
-        # per candidate: 2 x (vtot + mass); per event: species 2R+1W, sources, metadata, caches
-        per_ev = 3 * 8 * n_spec + 3 * 4 * n_source + 3 * meta + 2 * 16
+        # SURVEY 8(d): per candidate pair 2 x (cached volume 8 + cached density 8) = 32 B; per
+        # accepted event read 2 x n_spec x 8 + write n_spec x 8, 2 x 28 B of metadata read and
+        # 28 B written: 24 n_spec + 84 (108 B with one species); the source histogram's counts
+        # (4 B per source, 2 read + 1 written) where the run carries sources
+        per_ev = 3 * 8 * n_spec + 3 * 4 * n_source + 3 * meta
         return candidates * 32 + events * per_ev
-    if name == "compact":
-        return 0  # only cells past the tombstone threshold move data
-    if name == "rebalance":
-        return particles * 4 if n_class > 1 else 0
     if name == "condense":
         # read the species (+ class), write water volume and the two caches
         return particles * (8 * n_spec + 4 + 8 + 16)
@@ -274,6 +274,48 @@ def bench_modes(n_spec):
     return idealised_modes(n_spec, 1)
 
 
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` without a launcher: one rank per GPU as children of this process
+    (`python -m torch.distributed.run` of this file with the same arguments), started BEFORE this
+    process has made any GPU call -- a fresh child, never an exec of a process that holds the GPU.
+    The children write to this process's stdout / stderr (rank 0 prints the line); returns their
+    exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this pool
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def rehearse_launch(args, rank, world):
+    """--rehearse-launch: the launch path alone, for a box without a GPU (tests/test_dist_gloo.py) --
+    rendezvous over gloo, the column partition, the barrier and the sum / max aggregation, one line
+    from rank 0.  No step runs and nothing is measured: `value` is null."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    c0, c1 = partition_columns(args.nx * args.ny, world, rank)
+    local = dict(elapsed=0.0, cells=(c1 - c0) * args.levels, ranks=1)
+    if world > 1:
+        dist.barrier()
+    agg = aggregate(local, dist if world > 1 else None)
+    if rank == 0:
+        print(json.dumps({"metric": "coagulation_events_per_sec", "value": None, "unit": "events/s",
+                          "n_gpus": world, "steps": 0, "warmup": 0, "rehearsal": "launch path only, no GPU",
+                          "cells": int(agg["cells"]), "ranks_joined": int(agg["ranks"])}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -314,7 +356,11 @@ def main():
     ap.add_argument("--workload", choices=["domain", "config3"], default="domain",
                     help="domain: BASELINE configs[4] (default). config3: 1000 cells x 10^4, "
                          "20 species, condensation sub-step + coagulation (BASELINE configs[2])")
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="no GPU needed: launch, rendezvous (gloo), partition and aggregation only; value null")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))       # (nothing has touched the GPU yet)
     args.cap = (args.particles + 63) // 64 * 64
     config3 = args.workload == "config3"
     if config3:
@@ -325,8 +371,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
-                         "with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher set WORLD_SIZE={world}: one rank per GPU")
+    if args.rehearse_launch:
+        return rehearse_launch(args, rank, world)
     # CPU baseline first, on rank 0 at N=1 only, before this process touches the GPU
     # (the worker pool forks; a forked child must not inherit a live HIP runtime)
     cpu_line, cpu_counts = None, None
@@ -548,14 +595,20 @@ def main():
                 "requests_per_launch": traffic / 64.0,
                 "source": "FETCH_SIZE + WRITE_SIZE (roofline.traffic_source) over 64 B; "
                           "peak from scripts/gather_probe.hip"}
-        # secondary rooflines of the other kernels (same accounting)
+        # The other kernels of the step.  Only a kernel whose launch streams the whole population
+        # gets a bandwidth figure (condense); inside the timed region bin_sort, compact and rebalance
+        # run on the few listed cells that need them, so bytes of the whole domain over their
+        # duration would be a meaningless number: their time is reported, nothing else (the
+        # sort of every cell is measured under resort_every_step).
         others = {}
         for k in KERNELS:
             if k == dom or agg["n_" + k] == 0:
                 continue
-            a = algorithmic_bytes(k, args.n_spec, 1, 0, **per_launch)
             ms = kern_ms[k] / max(1.0, agg["n_" + k] / world)
-            others[k] = {"achieved": a / (ms * 1e-3) / 1e9 if ms > 0 else 0.0, "avg_launch_ms": ms}
+            others[k] = {"avg_launch_ms": ms}
+            if k == "condense":
+                a = algorithmic_bytes(k, args.n_spec, 1, 0, **per_launch)
+                others[k]["achieved"] = a / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         line["roofline_other_kernels"] = others
         line["sort"] = ("lists persist between mc_coag calls (aero_state%valid_sort, "
                         "wrf_pmc_trans_aero.F90:2094): bin_sort only runs for cells whose "

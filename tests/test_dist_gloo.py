@@ -142,3 +142,26 @@ def test_four_neighbour_exchange_of_a_grid_of_ranks(tmp_path, grid, periodic):
     path = str(tmp_path / "ok.json")
     mp.spawn(_grid_worker, args=(px * py, _free_port(), grid, periodic, path), nprocs=px * py, join=True)
     assert json.load(open(path)) == [1] * (px * py)
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it (no WORLD_SIZE): bench.py starts one
+    child rank per GPU itself, before it touches a GPU, and passes on rank 0's single line and the
+    children's exit code.  Here without a GPU (--rehearse-launch: rendezvous over gloo, partition,
+    barrier, aggregation); the same command with the real step runs in tests/test_gpu_fullsize.py."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-launch",
+                        "--nx", "3", "--ny", "2", "--levels", "4"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks_joined"] == 2 and line["cells"] == 24
+    # a launcher that disagrees with --gpus is an error, not a silent single-rank run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-launch"],
+                        env=env2, capture_output=True, text=True, timeout=600)
+    assert r2.returncode != 0 and "WORLD_SIZE=1" in r2.stderr

@@ -183,3 +183,30 @@ def test_transport_driver_on_the_full_domain(wp, oracle):
     ns_, nc_, st = blk.mc_coag(K_BROWN, DEL_T, SEED, 0)
     assert not st.any() and nc_.min() > 0
     blk.close()
+
+
+def test_bench_starts_its_own_ranks_on_the_gpu():
+    """`python bench.py --gpus 2` with no launcher (no WORLD_SIZE in the environment): bench.py starts
+    its two ranks itself -- children, before it touches the GPU -- and passes on rank 0's ONE line.
+    Two ranks share this box's GPU over gloo; the events of the two column blocks must be those of
+    the same domain on one rank (RNG keyed by the global cell id)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    common = ["--steps", "2", "--warmup", "1", "--nx", "6", "--ny", "4", "--levels", "5", "--particles", "2000",
+              "--no-cpu-baseline", "--resort-steps", "0"]
+    lines = {}
+    for n in (1, 2):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--backend", "gloo"]
+                           + common, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        js = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(js) == 1, r.stdout
+        lines[n] = json.loads(js[0])
+    assert lines[2]["n_gpus"] == 2 and lines[1]["n_gpus"] == 1
+    assert lines[2]["events_per_step"] == lines[1]["events_per_step"] > 0
+    assert lines[2]["status_or"] == 0
