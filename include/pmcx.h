@@ -62,8 +62,14 @@ enum {
     PMCX_ST_KMAX_EXCEEDED = 4,
     PMCX_ST_OUT_OF_GRID = 8,
     PMCX_ST_CAP_OVERFLOW = 16,
-    PMCX_ST_KMAX_RANGE = 32   /* a particle was created in a bin above the range the cell's
+    PMCX_ST_KMAX_RANGE = 32,  /* a particle was created in a bin above the range the cell's
                                  kernel bounds cover (pmcx_set_kernel_bounds_margin)        */
+    PMCX_ST_OUTBOX_OVERFLOW = 64, /* transport, law 1: the SOURCE cell's list of entries to send
+                                 (cap of them: one per mover, one per destination an emitter
+                                 sends copies to) ran out; the first particle whose entries did
+                                 not fit and every later one of the cell stayed and sent nothing */
+    PMCX_ST_TRANS_COPIES = 128 /* transport, law 1: an emitter's copy count met the guard of 4096
+                                 (a weight ratio below about 1e-3 between neighbours)        */
 };
 
 typedef struct pmcx_ctx pmcx_ctx;
@@ -539,15 +545,19 @@ int pmcx_dry_deposition(pmcx_ctx *ctx, double dt, uint64_t seed, uint32_t step,
  * with replacement; every pick adds a copy and removes the picked particle with probability r.
  *   law 0            a mover carries 1 + geometric copies (mean 1 / r): the reference's mean, its
  *                    variance of the arrivals times (2 - r - p) / r (the library's law until the
- *                    end of round 3; the default with more than 64 weight classes)
+ *                    end of round 3)
  *   law 1 (default)  the reference's law by Poisson thinning of its picks: the removing picks are
  *                    the movers, each arriving ONCE with its id; the non-removing picks, rate
  *                    mu_d = p_d (1 - r_d) / r_d, are copies from particles that STAY -- behind the
  *                    movers' intervals the placing uniform has one more of width 1 - exp(-sum mu):
  *                    an emitter draws a zero-truncated Poisson(sum mu) number of copies and deals
  *                    them to the r < 1 destinations in proportion mu, every copy under a new id.
- *                    Mean n p / r, variance n p / r: the reference's.  At most 64 weight classes.
- *                    (Where sum p + 1 - exp(-sum mu) would exceed 1 the emitters' interval is cut at 1.)
+ *                    Mean n p / r, variance n p / r: the reference's.  Where the two do not fit
+ *                    side by side (sum p + 1 - exp(-sum mu) > 1: from r of about 0.4 at sum p = 0.5)
+ *                    the emitters' interval is [exp(-sum mu), 1) and overlaps the movers': a
+ *                    particle in the overlap sends its copies AND moves (the reference picks a
+ *                    particle without removal before the pick that removes it), so the mean stays
+ *                    n p / r at every ratio.  Above sum mu = 32 the count is the plain Poisson's.
  * Applies to pmcx_transport and pmcx_transport_begin ... _finish. */
 int pmcx_set_transport_law(pmcx_ctx *ctx, int32_t law);
 

@@ -1262,10 +1262,36 @@ typedef struct { int dest; double lo, hi, ratio; } trans_dest;
  * with replacement, each adds a copy and removes the picked particle with probability r).  The
  * removing picks (rate p) are the movers -- a mover towards r < 1 arrives ONCE, id kept; the
  * non-removing picks (rate mu = p (1 - r) / r) are copies from particles that STAY: behind the
- * movers' intervals the placing uniform has one more, of width 1 - exp(-sum mu) -- an emitter,
+ * movers' intervals the placing uniform has one more, of width w = 1 - exp(-sum mu) -- an emitter,
  * which draws a zero-truncated Poisson(sum mu) number of copies and deals them to the r < 1
- * destinations in proportion mu, every copy under a new id.  Mean n p / r as law 0, variance
- * n p / r as the reference's. */
+ * destinations in proportion mu, every copy under a new id.  Where the two do not fit side by side
+ * (sum p + w > 1) the emitters' interval is [1 - w, 1) and overlaps the movers': a particle in the
+ * overlap sends its copies and moves -- the reference, too, can pick a particle without removal
+ * before the pick that removes it -- so P(moves to d) = p_d and E[copies to d] = mu_d at every
+ * ratio.  Mean n p / r as law 0, variance n p / r as the reference's. */
+#define PMCO_TRANS_BOTH_BLOCK (1u << 20)   /* block of the copy count of a particle that moves and emits */
+#define PMCO_TRANS_EMIT_WALK_MAX 32.0      /* above this sum of rates the zero-truncation is below 2^-46 */
+static int emit_count(double sum_mu, double u2, int *clamped)
+{
+    int n;
+    if (sum_mu > PMCO_TRANS_EMIT_WALK_MAX) {
+        n = pmco_poisson(sum_mu, u2);
+        if (n < 1) n = 1;
+    } else {
+        const double e = pmco_exp(-sum_mu);
+        double term = e * sum_mu / (1.0 - e), cdf = term;   /* P(K = 1) of the zero-truncated Poisson */
+        n = 1;
+        while (u2 >= cdf && n < PMCO_TRANS_MAX_COPIES) {
+            n++;
+            term = term * sum_mu / (double)n;
+            const double next = cdf + term;
+            if (next == cdf) break;
+            cdf = next;
+        }
+    }
+    if (n > PMCO_TRANS_MAX_COPIES) { *clamped = 1; n = PMCO_TRANS_MAX_COPIES; }
+    return n;
+}
 static int g_trans_law = 1;     /* the default, as the library's */
 void pmco_set_transport_law(int law) { g_trans_law = law; }
 
@@ -1355,7 +1381,7 @@ int pmco_transport(pmco_cell *cells, int n_cells, int nx, int nz, int ny, int pe
         const int n = *s->n_part;
         size_t box_cap = (size_t)(n > 0 ? n : 1);
         box[c] = (entry *)malloc(sizeof(entry) * box_cap);
-        int n_movers = 0;
+        int n_movers = 0, closed = 0;
         for (int cl = 0; cl < C; cl++)
             ntab[cl] = trans_table(cells, c, cl, nx, nz, ny, periodic_x, periodic_y, prob_h, prob_v,
                                    cell_volume, C, tab + (size_t)cl * (4 + 128));
@@ -1371,26 +1397,58 @@ int pmco_transport(pmco_cell *cells, int n_cells, int nx, int nz, int ny, int pe
             uint32_t w[4];
             pmco_rng_block(seed, cell_id_base + (uint32_t)c, step, (uint32_t)i >> 4, PMCO_SITE_TRANS, 0, w);
             const uint32_t p8 = (w[(i & 15) >> 2] >> (8 * (i & 3))) & 0xFFu;
-            /* law 1: the emitters' interval behind the movers' */
+            /* law 1: the emitters' interval behind the movers', or -- where the two do not fit side by
+             * side -- at the top of the unit interval, overlapping them */
             const double s_hi = t[ntab[cl] - 1].hi;
-            double sum_mu = 0.0, a_hi = s_hi;
+            double sum_mu = 0.0, a_lo = s_hi, a_hi = s_hi;
             if (g_trans_law == 1) {
                 for (int d = 0; d < ntab[cl]; d++)
                     if (t[d].ratio < 1.0) sum_mu = sum_mu + (t[d].hi - t[d].lo) * (1.0 - t[d].ratio) / t[d].ratio;
-                a_hi = s_hi + (1.0 - pmco_exp(-sum_mu));
-                if (a_hi > 1.0) a_hi = 1.0;
+                const double w_emit = 1.0 - pmco_exp(-sum_mu);
+                a_hi = a_lo + w_emit;
+                if (a_hi > 1.0) { a_hi = 1.0; a_lo = 1.0 - w_emit; }
             }
             if (!((double)p8 * 0x1.0p-8 < a_hi)) continue;      /* stays */
             pmco_rng_block(seed, cell_id_base + (uint32_t)c, step, (uint32_t)i, PMCO_SITE_TRANS, 1, w);
             const double u = ((double)p8 + (double)w[0] * 0x1.0p-32) * 0x1.0p-8;
-            if (!(u < a_hi)) continue;      /* stays */
-            if (!(u < s_hi)) {              /* law 1: an emitter -- it stays and sends copies */
-                const double u2 = pmco_u53(w[2], w[3]);
-                const double e = pmco_exp(-sum_mu);
-                double term = e * sum_mu / (1.0 - e), cdf = term;   /* P(K = 1) of the zero-truncated Poisson */
-                int K = 1;
-                while (u2 >= cdf && K < PMCO_TRANS_MAX_COPIES) { K++; term = term * sum_mu / (double)K; cdf = cdf + term; }
-                for (int q = 0; q < K; q++) {
+            const int moves = u < s_hi;
+            const int emits = g_trans_law == 1 && !(u < a_lo) && u < a_hi;
+            if (!moves && !emits) continue;      /* stays */
+            /* the particle's entries: a mover's one, then an emitter's -- one per destination that
+             * takes copies, in table order, with its count */
+            entry ent[1 + 4 + 128];
+            int n_ent = 0, n_emit = 0;
+            if (emits) {                    /* it sends copies (and stays, unless it also moves) */
+                double u2 = pmco_u53(w[2], w[3]);
+                if (moves) {
+                    uint32_t v[4];
+                    pmco_rng_block(seed, cell_id_base + (uint32_t)c, step, (uint32_t)i, PMCO_SITE_TRANS, PMCO_TRANS_BOTH_BLOCK, v);
+                    u2 = pmco_u53(v[0], v[1]);
+                }
+                int clamped = 0;
+                n_emit = emit_count(sum_mu, u2, &clamped);
+                if (clamped) status |= PMCO_ST_TRANS_COPIES;
+            }
+            if (moves) {
+                int d = 0;
+                while (!(u < t[d].hi)) d++;
+                const double r = t[d].ratio;
+                int copies = 1;
+                if (r != 1.0) {
+                    const double u2 = pmco_u53(w[2], w[3]);
+                    if (r > 1.0) copies = (u2 < 1.0 / r) ? 1 : 0;
+                    else if (g_trans_law == 0) {
+                        copies = 1 + (int)(pmco_log(1.0 - u2) / pmco_log(1.0 - r));
+                        if (copies > PMCO_TRANS_MAX_COPIES) copies = PMCO_TRANS_MAX_COPIES;
+                    }   /* (law 1: a mover arrives once; the other 1 / r - 1 come from the emitters) */
+                }
+                ent[n_ent].slot = i; ent[n_ent].dest = t[d].dest; ent[n_ent].copies = copies; ent[n_ent].stays = 0;
+                n_ent++;
+            }
+            if (n_emit > 0) {
+                int deal[4 + 128];
+                for (int y = 0; y < ntab[cl]; y++) deal[y] = 0;
+                for (int q = 0; q < n_emit; q++) {
                     uint32_t v[4];
                     pmco_rng_block(seed, cell_id_base + (uint32_t)c, step, (uint32_t)i, PMCO_SITE_TRANS, 2u + (uint32_t)(q >> 1), v);
                     const double x = pmco_u53(v[2 * (q & 1)], v[2 * (q & 1) + 1]) * sum_mu;
@@ -1403,32 +1461,27 @@ int pmco_transport(pmco_cell *cells, int n_cells, int nx, int nz, int ny, int pe
                         if (x < cm) { d = y; break; }
                     }
                     if (d < 0) d = last;
-                    if (nbox[c] >= s->cap) { status |= PMCO_ST_CAP_OVERFLOW; continue; }   /* an outbox holds cap entries */
-                    if ((size_t)nbox[c] == box_cap) { box_cap *= 2; box[c] = (entry *)realloc(box[c], sizeof(entry) * box_cap); }
-                    box[c][nbox[c]].slot = i; box[c][nbox[c]].dest = t[d].dest; box[c][nbox[c]].copies = 1;
-                    box[c][nbox[c]].stays = 1;
-                    nbox[c]++;
+                    deal[d]++;
                 }
+                for (int y = 0; y < ntab[cl]; y++)
+                    if (deal[y] > 0) {
+                        ent[n_ent].slot = i; ent[n_ent].dest = t[y].dest; ent[n_ent].copies = deal[y]; ent[n_ent].stays = 1;
+                        n_ent++;
+                    }
+            }
+            /* an outbox holds cap entries (law 1; law 0 has one per mover and cannot run out): the first
+             * particle whose entries do not fit closes it -- they and every later particle's are
+             * dropped, a mover among them stays */
+            if (g_trans_law == 1 && (closed || nbox[c] + n_ent > s->cap)) {
+                closed = 1;
+                status |= PMCO_ST_OUTBOX_OVERFLOW;
                 continue;
             }
-            int d = 0;
-            while (!(u < t[d].hi)) d++;
-            const double r = t[d].ratio;
-            int copies = 1;
-            if (r != 1.0) {
-                const double u2 = pmco_u53(w[2], w[3]);
-                if (r > 1.0) copies = (u2 < 1.0 / r) ? 1 : 0;
-                else if (g_trans_law == 0) {
-                    copies = 1 + (int)(pmco_log(1.0 - u2) / pmco_log(1.0 - r));
-                    if (copies > PMCO_TRANS_MAX_COPIES) copies = PMCO_TRANS_MAX_COPIES;
-                }   /* (law 1: a mover arrives once; the other 1 / r - 1 come from the emitters) */
+            for (int e = 0; e < n_ent; e++) {
+                if ((size_t)nbox[c] == box_cap) { box_cap *= 2; box[c] = (entry *)realloc(box[c], sizeof(entry) * box_cap); }
+                box[c][nbox[c]++] = ent[e];
             }
-            if (nbox[c] >= s->cap) { status |= PMCO_ST_CAP_OVERFLOW; continue; }   /* (law 1 only: the mover stays) */
-            if ((size_t)nbox[c] == box_cap) { box_cap *= 2; box[c] = (entry *)realloc(box[c], sizeof(entry) * box_cap); }
-            box[c][nbox[c]].slot = i; box[c][nbox[c]].dest = t[d].dest; box[c][nbox[c]].copies = copies;
-            box[c][nbox[c]].stays = 0;
-            nbox[c]++;
-            n_movers++;
+            if (moves) n_movers++;
         }
         n_moved[c] = n_movers;
     }

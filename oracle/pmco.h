@@ -53,7 +53,9 @@ enum {
     PMCO_ST_APPEND_OVERFLOW = 2, /* list-append log full: step stopped early  */
     PMCO_ST_KMAX_EXCEEDED = 4,   /* some K/K_max > 1 (bound too tight)        */
     PMCO_ST_OUT_OF_GRID = 8,     /* a particle volume fell outside the bins   */
-    PMCO_ST_CAP_OVERFLOW = 16    /* rebalance doubling exceeded capacity      */
+    PMCO_ST_CAP_OVERFLOW = 16,   /* rebalance doubling exceeded capacity      */
+    PMCO_ST_OUTBOX_OVERFLOW = 64, /* transport, law 1: a source cell's outbox (cap entries) ran out */
+    PMCO_ST_TRANS_COPIES = 128   /* transport, law 1: an emitter's copy count met the guard */
 };
 
 typedef struct {

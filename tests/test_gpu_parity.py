@@ -1197,6 +1197,88 @@ def test_transport_law_1_parity(wp, oracle, nx, nz, ny, periodic):
     blk.close()
 
 
+@pytest.mark.parametrize("scale,decades,cap,want_bits", [(0.45, 1.0, 16384, 0), (0.3, 1.7, 16384, 0), (0.45, 1.0, 640, 64 | 16)])
+def test_transport_law_1_parity_where_movers_and_emitters_overlap(wp, oracle, scale, decades, cap, want_bits):
+    """Law 1 with large probabilities to leave and weight ratios down to a few per cent: sum p +
+    1 - exp(-sum mu) exceeds 1 in many (cell, class) pairs, the emitters' interval overlaps the
+    movers', particles send copies AND move (an outbox entry marked "keep": the gather of the mover's
+    destination leaves its record to the gathers of its copies, k_trans_remove writes the tombstone),
+    an emitter's copies travel as one entry per destination with a count.  Device = oracle bit for
+    bit, status words included; the last case has so few slots that outboxes close and cells fill."""
+    nx, nz, ny = 4, 5, 3
+    n_cells, n_part, n_spec, n_class = nx * nz * ny, 400, 2, 2
+    blk, cells, info = parity.setup_pair(wp, oracle, n_cells, n_part, n_spec, n_class, 23, K_BROWN,
+                                         cap=cap, n_source=2)
+    r = np.random.RandomState(8)
+    mag = info["mag"] * 10 ** r.uniform(-decades, decades, (n_cells, 1))
+    blk.set_weights(mag)
+    for c, oc in enumerate(cells):
+        oc.mag[:] = mag[c]
+    ph, pv, cv = _transport_probs(n_cells, n_class, nz, 7, scale=scale)
+    next_id = np.array([oc.next_id for oc in cells], dtype=np.int64)
+    blk.set_transport_law(1)
+    oracle.set_transport_law(1)
+    both, bits = 0, 0
+    try:
+        for step in range(2):
+            n0 = blk.aero_state_total_particles().copy()
+            nm, na = blk.transport(nx, nz, ny, ph, pv, cv, 23, step, True, True)
+            st, onm, ona = oracle.transport(cells, nx, nz, ny, ph, pv, cv, 23, 0, step, next_id, True, True)
+            dev_st = int(np.bitwise_or.reduce(blk.coag_counters()[2]))
+            assert st == dev_st, (st, dev_st)
+            bits |= st
+            assert np.array_equal(nm, onm) and np.array_equal(na, ona), step
+            ok, msg = parity.compare_state(blk, cells)
+            assert ok, f"step {step}: {msg}"
+            assert np.array_equal(blk.get_next_id(), next_id)
+            if not st:
+                assert np.array_equal(blk.aero_state_total_particles(), n0 - nm + na)
+            both += int(na.sum()) - int(nm.sum())
+            if st:
+                break
+    finally:
+        oracle.set_transport_law()
+    assert bits == want_bits or (want_bits and (bits & want_bits)), bits
+    if not want_bits:
+        ids = blk.download_cells()["id"]
+        assert len(np.unique(ids)) == len(ids)
+        assert both > 1000       # the copies outnumber the losses at r > 1 by far
+    blk.close()
+
+
+@pytest.mark.parametrize("p_dn,r", [(0.4, 0.25), (0.3, 0.1), (0.6, 1.0 / 32)])
+def test_transport_law_1_mean_where_movers_and_emitters_overlap(wp, p_dn, r):
+    """pmcx_set_transport_law(1) on the HIP path alone, where sum p + 1 - exp(-sum mu) > 1: arrivals
+    keep the mean n p / r of the reference's Poisson(n p / r) picks (wrf_pmc_trans_aero.F90:2236-2241),
+    movers n p; the variance stays of the order n p / r.  Until round 4 the emitters' interval was cut
+    at 1 and the mean fell short -- 0.89 of it at (0.4, 0.25), 0.77 at (0.3, 0.1)."""
+    nx, nz, ny, n_part = 32, 2, 16, 400
+    n_cells = nx * nz * ny
+    lev = (np.arange(n_cells) // nx) % nz
+    vol = np.where(lev == 0, 1.0, 1.0 / r)     # coming down a level: weight ratio r
+    ph = np.zeros((n_cells, 1, 4)); pv = np.zeros((n_cells, 1, nz))
+    pv[lev == 1, 0, 0] = p_dn
+    from wrf_partmc_amd.data import idealised_modes
+    cap = int(n_part * (1 + 1.4 * p_dn / r)) // 64 * 64 + 128
+    with wp.CellBlock(n_cells, cap, 1) as blk:
+        blk.set_aero_data([1500.0]); blk.set_env(280.0, 9e4)
+        blk.set_weights(np.full((n_cells, 1), 1e7))
+        blk.set_next_id((np.arange(n_cells, dtype=np.int64) << 32) + (1 << 24))
+        blk.generate_lognormal(n_part, idealised_modes(1), seed=9)
+        blk.set_transport_law(1)
+        nm, na = blk.transport(nx, nz, ny, ph, pv, vol, seed=9, step=0)
+        assert not np.bitwise_or.reduce(blk.coag_counters()[2])
+        n_after = blk.aero_state_total_particles()
+        ids = blk.download_cells()["id"]
+    assert np.array_equal(n_after, n_part - nm + na) and len(np.unique(ids)) == len(ids)
+    n1 = int((lev == 1).sum())
+    movers, arrivals = nm[lev == 1].astype(float), na[lev == 0].astype(float)
+    assert abs(movers.sum() - n1 * n_part * p_dn) < 5 * np.sqrt(n1 * n_part * p_dn * (1 - p_dn))
+    mean_ref = n_part * p_dn / r
+    assert abs(arrivals.mean() / mean_ref - 1) < 5 * np.sqrt(1.0 / (mean_ref * n1)) + 1e-3, arrivals.mean() / mean_ref
+    assert 0.5 * mean_ref < arrivals.var(ddof=1) < 1.5 * mean_ref, (arrivals.var(ddof=1), mean_ref)
+
+
 @pytest.mark.parametrize("n_class,all_columns,do_vertmix", [(2, True, 1), (1, False, 1), (2, True, 0)])
 def test_transport_probs_built_on_the_device(wp, oracle, n_class, all_columns, do_vertmix):
     """wrf_pmc_trans_driver's probability half (wrf_pmc_trans.F90:95-156) on the device from

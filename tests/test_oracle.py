@@ -710,6 +710,74 @@ def test_prototype_of_the_reference_transport_law_for_small_ratios(oracle, ratio
     assert v0 > (1.5 if ratio == 0.4 else 8.0) * v_ref, (v0, v_ref)           # law 0: (2 - r - p) / r times it
 
 
+@pytest.mark.parametrize("p,ratio", [(0.4, 0.25), (0.3, 0.1), (0.6, 0.03)])
+def test_transport_law_1_keeps_the_mean_where_movers_and_emitters_overlap(oracle, p, ratio):
+    """Law 1 where sum p + 1 - exp(-sum mu) > 1 (a large probability to leave and a small weight
+    ratio; from r of about 0.4 at p = 0.5): the emitters' interval lies at the top of the unit interval
+    and overlaps the movers' -- a particle in the overlap sends its copies and moves.  Arrivals keep
+    the mean n p / r of the reference's Poisson(n p / r) picks (wrf_pmc_trans_aero.F90:2236-2241; until
+    round 4 the interval was cut at 1 and the mean fell short: 0.89 of it at (0.4, 0.25), 0.77 at
+    (0.3, 0.1)), removals the mean n p; against the transcription of the reference's pick loop; no
+    status bit, every id once."""
+    n_part, trials = 1000, 30
+    dens = np.array([1500.0]); ve, _ = oracle.make_bin_tables(80, 1e-10, 1e-2)
+    rng = np.random.RandomState(3)
+    ref = np.array([_reference_sequential_sample(rng, n_part, p, ratio) for _ in range(200)])
+    got = []
+    for t in range(trials):
+        cells = []
+        for c in range(2):
+            oc = oracle.Cell(1, 1, 0, int(n_part * (1 + 1.3 * p / ratio)) + n_part, dens, ve)
+            oc.mag[:] = 1e6 if c == 0 else 1e6 * ratio
+            oc.generate([dict(frac=1, gm_radius=3e-8, gsd_log10=0.2, vol_frac=[1.0])], n_part, t, c, first_id=c << 32)
+            cells.append(oc)
+        ph = np.zeros((2, 1, 4)); ph[0, 0, 1] = p
+        next_id = np.array([1 << 40, 2 << 40], dtype=np.int64)
+        st, nm, na = oracle.transport(cells, 2, 1, 1, ph, np.zeros((2, 1, 1)), np.ones(2), 500 + t, 0, 0, next_id,
+                                      False, False)
+        assert st == 0 and int(cells[0].n_part[0]) == n_part - nm[0] and int(cells[1].n_part[0]) == n_part + na[1]
+        ids = np.concatenate([oc.id[:int(oc.n_part[0])] for oc in cells])
+        assert len(np.unique(ids)) == len(ids)
+        got.append((na[1], nm[0]))
+    got = np.array(got, float)
+    mean_add = n_part * p / ratio
+    assert abs(got[:, 0].mean() / mean_add - 1) < 4 * math.sqrt(1.0 / (mean_add * trials)) + 0.005, got[:, 0].mean() / mean_add
+    assert abs(got[:, 0].mean() - ref[:, 0].mean()) < 0.01 * mean_add
+    assert abs(got[:, 1].mean() - n_part * p) < 4 * math.sqrt(n_part * p * (1 - p) / trials) + 0.01 * n_part * p
+    # the variance stays of the reference's order (Poisson picks: n p / r), nowhere near law 0's
+    assert got[:, 0].var(ddof=1) < 2.0 * mean_add
+
+
+def test_transport_emitter_count_at_large_rates(oracle):
+    """The copy count of an emitter for sum mu from small to beyond what exp(-sum mu) can represent
+    (the zero-truncated walk's first term underflows near 745: the plain Poisson count takes over
+    above 32, where the truncation is below 2^-46): arrivals keep the mean n p / r at r = 1e-3, and a
+    ratio that asks for more than the guard of 4096 copies per emitter raises its own status bit
+    instead of running every emitter to the guard."""
+    dens = np.array([1500.0]); ve, _ = oracle.make_bin_tables(80, 1e-10, 1e-2)
+    for ratio, p, n_part, want_bit in ((1e-3, 0.5, 40, 0), (5e-5, 0.5, 8, 128)):
+        tot, exp = 0.0, 0.0
+        bits = 0
+        for t in range(6):
+            cells = []
+            for c in range(2):
+                oc = oracle.Cell(1, 1, 0, 60000, dens, ve)
+                oc.mag[:] = 1e6 if c == 0 else 1e6 * ratio
+                oc.generate([dict(frac=1, gm_radius=3e-8, gsd_log10=0.2, vol_frac=[1.0])], n_part, t, c, first_id=c << 32)
+                cells.append(oc)
+            ph = np.zeros((2, 1, 4)); ph[0, 0, 1] = p
+            next_id = np.array([1 << 40, 2 << 40], dtype=np.int64)
+            st, nm, na = oracle.transport(cells, 2, 1, 1, ph, np.zeros((2, 1, 1)), np.ones(2), 900 + t, 0, 0, next_id,
+                                          False, False)
+            bits |= st
+            tot += na[1]; exp += n_part * p / ratio
+        assert bits == want_bit, bits
+        if not want_bit:
+            assert abs(tot / exp - 1) < 4 * math.sqrt(1.0 / exp) + 0.01, tot / exp
+        else:
+            assert tot <= 6 * n_part * (4096 + 1)
+
+
 def test_dry_deposition_velocity(oracle):
     """Zhang (2001) deposition velocity (wrf_pmc_dep_aero.F90:265-420): equal to an independent
     numpy transcription to rounding, U-shaped in diameter, settling-dominated for coarse

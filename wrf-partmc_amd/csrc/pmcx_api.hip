@@ -329,7 +329,7 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
     st.n_dbin = cfg->n_dbin; st.i_water = cfg->i_water;
     st.max_events = cfg->max_events; st.max_appends = cfg->max_appends;
     st.n_comp_max = cfg->n_comp_max;
-    st.trans_law = cfg->n_class <= 64 ? 1 : 0; // (pmcx_set_transport_law; law 1 keeps a class's interval in static LDS)
+    st.trans_law = 1; // (pmcx_set_transport_law)
     st.compact_den = cfg->compact_den ? (int32_t)cfg->compact_den : 2;
     st.pcap = cfg->cap + cfg->cap / 8 + 16 * cfg->n_class * cfg->n_bin;
     st.cell_id_base = cfg->cell_id_base;
@@ -621,8 +621,6 @@ int pmcx_set_weight_preparation(pmcx_ctx *ctx, int32_t on, int32_t allow_doublin
 int pmcx_set_transport_law(pmcx_ctx *ctx, int32_t law)
 {
     if (!ctx || (law != 0 && law != 1)) return fail(ctx, PMCX_EINVAL, "pmcx_set_transport_law: law is 0 or 1");
-    if (law == 1 && ctx->cfg.n_class > 64)
-        return fail(ctx, PMCX_EINVAL, "pmcx_set_transport_law: law 1 takes at most 64 weight classes");
     ctx->st.trans_law = law;
     return PMCX_OK;
 }

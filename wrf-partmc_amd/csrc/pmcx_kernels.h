@@ -12,7 +12,9 @@ enum : int {
     ST_KMAX_EXCEEDED = 4,
     ST_OUT_OF_GRID = 8,
     ST_CAP_OVERFLOW = 16,
-    ST_KMAX_RANGE = 32
+    ST_KMAX_RANGE = 32,
+    ST_OUTBOX_OVERFLOW = 64,  // transport, law 1: a source cell's outbox (cap entries) ran out
+    ST_TRANS_COPIES = 128     // transport, law 1: an emitter's copy count met the guard (4096)
 };
 
 // What the pair sampler reads and writes of a particle -- the cached total volume and mass a

@@ -3759,9 +3759,40 @@ __global__ __launch_bounds__(256) void k_dry_deposition(DeviceState st, DepArgs 
 //   k_trans_remove  one wavefront per source cell: the cell's live count, and the
 //                   tombstones of the movers that no gather of this block reads
 
-constexpr int TRANS_LAW_MAX_CLASS = 64; // (the emitters' interval per class lives in static LDS)
-constexpr int TRANS_STAYS = (int)0x80000000u; // outbox entry: the source particle stays (an emitter's copy)
-constexpr int TRANS_MAX_COPIES = 4096; // (a guard, not a law: P(G > 4096) is 2e-18 at r = 0.01, 1.7 % of the mean at r = 0.001)
+constexpr int TRANS_STAYS = (int)0x80000000u; // outbox entry: the source particle stays (an emitter's copies)
+// outbox entry of a mover that also emits (law 1, where the two intervals overlap): its record is
+// read by the gathers of its copies' destinations too, so the gather of its own destination leaves
+// it alone and k_trans_remove writes the tombstone
+constexpr int TRANS_KEEP = 0x40000000;
+constexpr int TRANS_COPIES_MASK = 0x3FFF;
+constexpr int TRANS_MAX_COPIES = 4096; // (a guard, not a law: P(G > 4096) is 2e-18 at r = 0.01, 1.7 % of the mean at r = 0.001; law 1: flagged ST_TRANS_COPIES)
+constexpr uint32_t TRANS_BOTH_BLOCK = 1u << 20; // law 1: block of the copy count of a particle that moves AND emits
+constexpr double TRANS_EMIT_WALK_MAX = 32.0;    // law 1: above this sum of rates the zero-truncation is below 2^-46: plain Poisson
+
+// law 1: the number of copies an emitter sends, a zero-truncated Poisson(sum_mu) from one uniform
+// (the walk's first term exp(-sum_mu) sum_mu / (1 - exp(-sum_mu)) underflows for large rates, where the
+// truncation no longer matters: the plain count, at least one)
+__device__ inline int emit_count(double sum_mu, double u2, bool &clamped)
+{
+    int n;
+    if (sum_mu > TRANS_EMIT_WALK_MAX) {
+        n = poisson(sum_mu, u2);
+        if (n < 1) n = 1;
+    } else {
+        const double e0 = det_exp(-sum_mu);
+        double term = e0 * sum_mu / (1.0 - e0), cdf = term;
+        n = 1;
+        while (u2 >= cdf && n < TRANS_MAX_COPIES) {
+            n++;
+            term = term * sum_mu / (double)n;
+            const double next = cdf + term;
+            if (next == cdf) break;   // (the sum has stopped short of a uniform within rounding of 1)
+            cdf = next;
+        }
+    }
+    if (n > TRANS_MAX_COPIES) { clamped = true; n = TRANS_MAX_COPIES; }
+    return n;
+}
 
 // open lateral boundaries: is local row j the domain's first or last row?
 __device__ __forceinline__ bool lateral_row(const DeviceState &st, int j, int ny)
@@ -3819,6 +3850,11 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
     // wavefront's requests, the next trip's keys among them)
     uint64_t *t_bit = (uint64_t *)(smem + ((((size_t)((unsigned char *)(t_n + C) - smem)) + 7) & ~(size_t)7)); // [C][ND] dest_mask bit
     int *t_cnt = (int *)(t_bit + C * ND);    // [C][ND] copies sent to each destination
+    // law 1, per class: the sum of the emitters' rates, their interval [s_act_lo, s_act_hi) of the placing uniform
+    double *s_mu_sum = (double *)(smem + ((((size_t)((unsigned char *)(t_cnt + C * ND) - smem)) + 7) & ~(size_t)7));
+    double *s_act_lo = s_mu_sum + C, *s_act_hi = s_act_lo + C;
+    // law 1: a lane's copies per destination while it deals them ([64][ND], an emitter of several copies)
+    uint16_t *s_deal = (uint16_t *)(s_act_hi + C);
     for (int x = lane; x < C * ND; x += 64) t_cnt[x] = 0;
     const int i = c % nx, k = (c / nx) % nz, j = c / (nx * nz);
     const bool mask_ok = ND <= 64 && (nx >= 3 || !tg.periodic_x) && (ny >= 3 || !tg.periodic_y);
@@ -3912,22 +3948,26 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
     }
     for (int x = lane; x < C * ND; x += 64) t_cnt[x] = 0;
     // law 1 (pmcx_set_transport_law): behind the movers' intervals one more, the emitters' -- a
-    // particle that stays and sends copies towards the destinations with r < 1, rate
+    // particle that sends copies towards the destinations with r < 1, rate
     // mu_d = p_d (1 - r_d) / r_d each (the non-removing picks of the reference's Poisson sampler,
-    // wrf_pmc_trans_aero.F90:2236-2266); width 1 - exp(-sum mu)
-    __shared__ double s_mu_sum[TRANS_LAW_MAX_CLASS], s_act_hi[TRANS_LAW_MAX_CLASS];
-    if (lane < C && lane < TRANS_LAW_MAX_CLASS) {
-        const int cl = lane, nt = t_n[cl];
-        double sum_mu = 0.0, a_hi = nt > 0 ? t_hi[cl * ND + nt - 1] : 0.0;
+    // wrf_pmc_trans_aero.F90:2236-2266); width w = 1 - exp(-sum mu).  Where the two do not fit side
+    // by side (sum p + w > 1: a large probability to leave and a small weight ratio) the emitters'
+    // interval is [1 - w, 1) and overlaps the movers': a particle in the overlap moves AND emits, as
+    // a particle of the reference can be picked without removal before the pick that removes it.
+    // Either way P(moves to d) = p_d and E[copies to d] = mu_d: arrivals n p_d / r_d in the mean.
+    for (int cl = lane; cl < C; cl += 64) {
+        const int nt = t_n[cl];
+        double sum_mu = 0.0, a_lo = nt > 0 ? t_hi[cl * ND + nt - 1] : 0.0, a_hi = a_lo;
         if (EMIT && nt > 0) {
             for (int d = 0; d < nt; d++) {
                 const double r = t_ratio[cl * ND + d];
                 if (r < 1.0) sum_mu = sum_mu + (t_hi[cl * ND + d] - t_lo[cl * ND + d]) * (1.0 - r) / r;
             }
-            a_hi = a_hi + (1.0 - det_exp(-sum_mu));
-            if (a_hi > 1.0) a_hi = 1.0;
+            const double w_emit = 1.0 - det_exp(-sum_mu);
+            a_hi = a_lo + w_emit;
+            if (a_hi > 1.0) { a_hi = 1.0; a_lo = 1.0 - w_emit; }
         }
-        s_mu_sum[cl] = sum_mu; s_act_hi[cl] = a_hi;
+        s_mu_sum[cl] = sum_mu; s_act_lo[cl] = a_lo; s_act_hi[cl] = a_hi;
     }
     lds_sync();
 
@@ -3977,24 +4017,32 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
     };
     int queued = 0; // entries in the queue (uniform)
     bool out_full = false; // law 1: the outbox ran out of entries (uniform)
+    bool copies_clamped = false; // law 1: an emitter's count met the guard
     // the first `take` queued particles: the rest of their uniform, destination, copies, outbox
     auto evaluate = [&](int take) {
         const uint32_t ent = lane < take ? s_qent[lane] : 0u, rank = lane < take ? s_qrank[lane] : 0u;
         const int s = (int)(ent & 0xFFFFu), cl = (int)(ent >> 24);
         bool moves = false;
         int dest = 0, copies = 0, dslot = 0;
-        int n_emit = 0;   // law 1: copies this lane's particle sends while it stays
+        int n_emit = 0;   // law 1: copies this lane's particle sends (while it stays, or before it goes)
         if (lane < take) {
             uint32_t w[4];
             rng_block(seed, cell_id, step, rank, SITE_TRANS, 1, w);
             const double u = ((double)((ent >> 16) & 0xFFu) + (double)w[0] * 0x1.0p-32) * 0x1.0p-8;
             const int nt = t_n[cl];
-            if (EMIT && nt > 0 && !(u < t_hi[cl * ND + nt - 1]) && u < s_act_hi[cl]) {
-                // an emitter: a zero-truncated Poisson(sum mu) number of copies
-                const double sum_mu = s_mu_sum[cl], u2 = u53(w[2], w[3]), e0 = det_exp(-sum_mu);
-                double term = e0 * sum_mu / (1.0 - e0), cdf = term;
-                n_emit = 1;
-                while (u2 >= cdf && n_emit < TRANS_MAX_COPIES) { n_emit++; term = term * sum_mu / (double)n_emit; cdf = cdf + term; }
+            if (EMIT && nt > 0 && !(u < s_act_lo[cl]) && u < s_act_hi[cl]) {
+                // an emitter: a zero-truncated Poisson(sum mu) number of copies; one that also moves
+                // (the overlap) takes the count's uniform from a block of its own -- the mover's
+                // copies have the first one's
+                double u2 = u53(w[2], w[3]);
+                if (u < t_hi[cl * ND + nt - 1]) {
+                    uint32_t v[4];
+                    rng_block(seed, cell_id, step, rank, SITE_TRANS, TRANS_BOTH_BLOCK, v);
+                    u2 = u53(v[0], v[1]);
+                }
+                bool clamped = false;
+                n_emit = emit_count(s_mu_sum[cl], u2, clamped);
+                if (clamped) copies_clamped = true;
             }
             if (nt > 0 && u < t_hi[cl * ND + nt - 1]) {
                 // the first threshold above u, looked for from the top: the probabilities are in
@@ -4022,17 +4070,20 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
             if (moves) box[n_out + (uint32_t)__popcll(mm & lt)] = make_int2(s | (copies << 16), dest);
             n_out += (uint32_t)__popcll(mm);
         } else {
-            // entries of the chunk in rank order: a mover's one, an emitter's one per copy (each dealt
-            // to a destination with r < 1 in proportion mu, its uniform from the particle's own blocks)
-            const uint32_t ne = moves ? 1u : (uint32_t)n_emit;
-            const uint32_t inc = wave_incl_scan_u32(ne, lane);
-            const uint32_t first = n_out + inc - ne;
-            if (moves && first < (uint32_t)st.cap) box[first] = make_int2(s | (copies << 16), dest);
+            // entries of the chunk in rank order: a mover's one, then an emitter's -- every copy dealt to
+            // a destination with r < 1 in proportion mu (its uniform from the particle's own blocks),
+            // one entry per destination that takes any, in table order, with its count: what a
+            // destination gathers from the cell is the same sequence of records, under the same new
+            // ids, as one entry per copy in the order dealt would give it
+            const int nt = t_n[cl];
+            uint16_t *deal = s_deal + lane * ND;
+            int d_one = -1;      // the destination of a single copy
+            uint32_t n_dst = 0;  // destinations that take copies
+            if (n_emit > 1) for (int y = 0; y < nt; y++) deal[y] = 0;
             for (int q = 0; q < n_emit; q++) {
                 uint32_t v[4];
                 rng_block(seed, cell_id, step, rank, SITE_TRANS, 2u + (uint32_t)(q >> 1), v);
                 const double xq = u53(v[2 * (q & 1)], v[2 * (q & 1) + 1]) * s_mu_sum[cl];
-                const int nt = t_n[cl];
                 double cm = 0.0;
                 int d = -1, last = -1;
                 for (int y = 0; y < nt; y++) {
@@ -4043,15 +4094,34 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
                     if (xq < cm) { d = y; break; }
                 }
                 if (d < 0) d = last;
-                if (first + (uint32_t)q < (uint32_t)st.cap) { // (an outbox holds cap entries: beyond, flagged below)
-                    box[first + (uint32_t)q] = make_int2(s | (1 << 16) | TRANS_STAYS, t_dest[cl * ND + d]);
-                    bits |= t_bit[cl * ND + d];
-                    atomicAdd(&t_cnt[cl * ND + d], 1);
+                if (n_emit == 1) { d_one = d; n_dst = 1; }
+                else { if (deal[d] == 0) n_dst++; deal[d] = (uint16_t)(deal[d] + 1); }
+            }
+            const uint32_t ne = (moves ? 1u : 0u) + n_dst;
+            const uint32_t inc = wave_incl_scan_u32(ne, lane);
+            const uint32_t first = n_out + inc - ne;
+            // (an outbox holds cap entries: the first particle whose entries do not fit closes it -- its
+            // entries and every later particle's are dropped, a mover among them stays -- and is flagged)
+            const bool fits = !out_full && first + ne <= (uint32_t)st.cap;
+            if (moves && fits) box[first] = make_int2(s | (copies << 16) | (n_emit > 0 ? TRANS_KEEP : 0), dest);
+            if (n_emit > 0 && fits) {
+                uint32_t at = first + (moves ? 1u : 0u);
+                for (int y = (n_emit == 1 ? d_one : 0); y < (n_emit == 1 ? d_one + 1 : nt); y++) {
+                    const int k_y = n_emit == 1 ? 1 : (int)deal[y];
+                    if (k_y == 0) continue;
+                    box[at++] = make_int2(s | (k_y << 16) | TRANS_STAYS, t_dest[cl * ND + y]);
+                    bits |= t_bit[cl * ND + y];
+                    atomicAdd(&t_cnt[cl * ND + y], k_y);
                 }
             }
-            if (moves && !(first < (uint32_t)st.cap)) moves = false; // (dropped with the rest: it stays)
-            n_out += (uint32_t)__shfl(inc, 63, 64);
-            if (n_out > (uint32_t)st.cap) { n_out = (uint32_t)st.cap; out_full = true; }
+            if (!fits) moves = false;
+            const uint64_t nofit = __ballot(ne > 0 && !fits);
+            if (nofit) { // (uniform)
+                if (!out_full) n_out = (uint32_t)__shfl((int)first, __builtin_ctzll(nofit), 64);
+                out_full = true;
+            } else {
+                n_out += (uint32_t)__shfl(inc, 63, 64);
+            }
         }
         // (a mover's sort key says "gone" from here on; its record lives until the gather of its
         // destination, or k_trans_remove, has dealt with it)
@@ -4101,7 +4171,7 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
             const uint32_t idx = (rank - 16u * B0) & 1023u;
             const uint32_t p8 = (s_words[idx >> 2] >> (8u * (idx & 3u))) & 0xFFu;
             // (one class: no table look-up for the particles that stay, almost all of them)
-            const bool need = cl >= 0 && (double)p8 * 0x1.0p-8 < (C == 1 ? hi_last0 : cl < TRANS_LAW_MAX_CLASS ? s_act_hi[cl] : (t_n[cl] > 0 ? t_hi[cl * ND + t_n[cl] - 1] : 0.0));
+            const bool need = cl >= 0 && (double)p8 * 0x1.0p-8 < (C == 1 ? hi_last0 : s_act_hi[cl]);
             const uint64_t mneed = __ballot(need);
             if (need) {
                 const int pos = queued + __popcll(mneed & lt);
@@ -4125,9 +4195,10 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
             atomicAdd(&tg.n_exp[dcell], t_cnt[x]);
         }
     for (int d = 32; d >= 1; d >>= 1) bits |= __shfl_xor(bits, d, 64);
+    if (__ballot(copies_clamped) != 0 && lane == 0) atomicOr(&st.status[c], ST_TRANS_COPIES);
     if (lane == 0) {
         tg.n_out[c] = (int32_t)n_out; tg.dest_mask[c] = bits;
-        if (out_full) atomicOr(&st.status[c], ST_CAP_OVERFLOW);
+        if (out_full) atomicOr(&st.status[c], ST_OUTBOX_OVERFLOW);
     }
 }
 
@@ -4838,8 +4909,9 @@ __global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid t
     // move the first `take` queued arrivals (records, keys, ids), in queue order
     auto emit = [&](int take) {
         const int sc = lane < take ? s_qsc[lane] : 0, x = lane < take ? s_qx[lane] : 0;
-        const int copies = lane < take ? ((x >> 16) & 0x7FFF) : 0, from = x & 0xFFFF;
-        const bool stays = x < 0; // (an emitter's copy: the source keeps its particle, every copy a new id)
+        const int copies = lane < take ? ((x >> 16) & TRANS_COPIES_MASK) : 0, from = x & 0xFFFF;
+        const bool stays = x < 0; // (an emitter's copies: the source keeps its particle, every copy a new id)
+        const bool keep = (x & TRANS_KEEP) != 0; // (a mover that also emits: k_trans_remove leaves its tombstone)
         const int64_t sb = (int64_t)sc * st.cap;
         // slots and new ids of this entry's copies: prefix sums over the chunk
         const uint32_t inc = wave_incl_scan_u32((uint32_t)copies, lane);
@@ -4856,7 +4928,7 @@ __global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid t
             const uint16_t kd = key_of(st, hv.vtot, wc); // (from the record: the source's keys may not hold)
             // the mover's tombstone, into the line just read (k_trans_remove leaves these alone:
             // a store to a line nobody has read costs a read-modify-write in memory)
-            if (!stays) st.hot[sb + from].vtot = -1.0;
+            if (!stays && !keep) st.hot[sb + from].vtot = -1.0;
             for (int g = 0; g < copies; g++) {
                 const int dst = (int)first + g;
                 if (dst >= st.cap) { status |= ST_CAP_OVERFLOW; break; }
@@ -4945,7 +5017,7 @@ __global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid t
             const int2 en = nen;
             const int esc = nsc;
             if (f0 + 64 < total) nen = fetch(f0 + 64 + lane, nsc); // requested before this chunk's work
-            const bool mine = en.y == c && ((en.x >> 16) & 0x7FFF) > 0;
+            const bool mine = en.y == c && ((en.x >> 16) & TRANS_COPIES_MASK) > 0;
             const uint64_t mm = __ballot(mine);
             if (mine) {
                 const int pos = queued + __popcll(mm & ((1ull << lane) - 1ull));
@@ -4988,7 +5060,8 @@ __global__ __launch_bounds__(64) void k_trans_remove(DeviceState st, TransGrid t
         n_movers += __popcll(__ballot(!stays));
         if (stays) continue;
         const int dest = en.y;
-        bool gathered = ((en.x >> 16) & 0x7FFF) > 0 && dest >= tg.c_first && dest < tg.c_first + (int)gridDim.x &&
+        bool gathered = (en.x & TRANS_KEEP) == 0 &&  // (a mover that also emits: its gather left the record alone)
+                        ((en.x >> 16) & TRANS_COPIES_MASK) > 0 && dest >= tg.c_first && dest < tg.c_first + (int)gridDim.x &&
                         !ghost_col(st, dest % nx, nx); // (to a ghost column: packed for the neighbouring rank)
         if (gathered && st.trans_lateral) {
             const int di = dest % nx, dj = dest / (nx * nz);
@@ -5097,7 +5170,7 @@ __global__ __launch_bounds__(64) void k_halo_pack(DeviceState st, TransGrid tg, 
             unsigned char *rec = recs + (size_t)(offsets[r] + idx) * rec_bytes;
             const int from = en.x & 0xFFFF;
             int32_t *h = (int32_t *)rec;
-            h[0] = r; h[1] = didx; h[2] = (en.x >> 16) & 0x7FFF;
+            h[0] = r; h[1] = didx; h[2] = (en.x >> 16) & TRANS_COPIES_MASK;
             h[3] = st.wclass[cb + from]; h[4] = idx; h[5] = en.x < 0 ? 1 : 0; // (the source particle stays: law 1)
             double *d = (double *)(rec + 24);
             d[0] = st.hot[cb + from].vtot; d[1] = st.hot[cb + from].mass;
@@ -5763,7 +5836,9 @@ hipError_t launch_gas_update(const GasScenarioDev &g, double *mix_rat, const dou
 size_t transport_lds_bytes(const DeviceState &st, int nz)
 {
     const size_t nd = (size_t)(4 + nz), C = (size_t)st.n_class;
-    return (sizeof(double) * 4 + sizeof(int) * 3 + sizeof(uint64_t)) * C * nd + sizeof(int) * C + 24;
+    // (+ law 1: three doubles per class, a lane's copies per destination while it deals them)
+    return (sizeof(double) * 4 + sizeof(int) * 3 + sizeof(uint64_t)) * C * nd + sizeof(int) * C + 24 +
+           3 * sizeof(double) * C + 8 + sizeof(uint16_t) * 64 * nd;
 }
 static TransGrid make_grid(int nx, int nz, int ny, int periodic_x, int periodic_y,
                            const double *prob_h, const double *prob_v, const double *cell_volume,

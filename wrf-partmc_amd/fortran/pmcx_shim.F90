@@ -1389,10 +1389,9 @@ contains
        end do
        end do
        end do
-       ! trans_aero (wrf_pmc_trans_aero.F90:40-971); the sampling in the form that has the reference's
-       ! variance where weights differ (movers arrive once, particles that stay send the other
-       ! copies: pmcx_set_transport_law, :2236-2300)
-       call pmcx_die(pmcx_set_transport_law(ctx, 1), 'pmcx_set_transport_law')
+       ! trans_aero (wrf_pmc_trans_aero.F90:40-971); the sampling is the context's default law, the one
+       ! that has the reference's variance where weights differ (movers arrive once, emitters send
+       ! the other copies: pmcx_set_transport_law, :2236-2300), for any number of weight classes
        call pmcx_die(pmcx_set_transport_lateral(ctx, merge(0, 1, ideal), 0, 0), 'pmcx_set_transport_lateral')
        call pmcx_die(pmcx_transport_preweight(ctx, nx, nz, ny, merge(1, 0, ideal), merge(1, 0, ideal), &
             c_null_ptr, c_null_ptr, cell_volume, int(grid%random_seed, c_int64_t), step, expected, n_rem), &
@@ -1513,6 +1512,10 @@ contains
       call pmcx_die(pmcx_get_coag_counters(ctx, ns, nc, st), 'pmcx_get_coag_counters')
       if (any(iand(st, 16) /= 0)) call pmcx_die(5, 'wrf_pmc_trans_driver_pmcx (a cell ran out of particle slots ' &
            // trim(where) // ': pmcx_shim_set_headroom)')
+      if (any(iand(st, 64) /= 0)) call pmcx_die(5, 'wrf_pmc_trans_driver_pmcx (a source cell sends to more (particle, ' &
+           // 'destination) pairs than it has slots ' // trim(where) // ': pmcx_shim_set_headroom)')
+      if (any(iand(st, 128) /= 0)) call pmcx_die(5, 'wrf_pmc_trans_driver_pmcx (weights of neighbouring cells differ by ' &
+           // 'more than three decades ' // trim(where) // ': an emitter met the guard of 4096 copies)')
       deallocate(ns, nc, st)
     end subroutine check_transport_status
 
