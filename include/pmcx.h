@@ -78,8 +78,8 @@ typedef struct {
     int32_t struct_size;  /* sizeof(pmcx_config), for ABI checking            */
     int32_t device;       /* HIP device ordinal                               */
     int32_t n_cells;      /* cells owned by this context (this GPU's block)   */
-    int32_t cap;          /* particle capacity per cell; cap + cap/8 +
-                           * 16 n_class n_bin <= 65535 (16-bit list offsets)   */
+    int32_t cap;          /* particle capacity per cell, <= 65280 (16-bit list
+                           * entries), whatever the number of weight classes  */
     int32_t n_spec;       /* aero_data_n_spec                                 */
     int32_t n_class;      /* weight classes (n_group is 1, driver:1706)       */
     int32_t n_source;     /* width of the per-particle source histogram       */
@@ -643,9 +643,35 @@ int pmcx_scenario_update_gas_state(pmcx_ctx *ctx, double dt, double elapsed_time
  * scenario updates called on their own honour it too. */
 int pmcx_set_loop_cells(pmcx_ctx *ctx, const int32_t *in_loop);
 
-/* The largest cap a configuration admits: list entries and offsets are 16-bit, so
- * cap + cap/8 + 16 n_class n_bin <= 65535 (and cap <= 65280); a multiple of 64.  0 if none. */
+/* The largest cap a configuration admits: 65280 (slots are 16-bit list entries; a multiple of 64),
+ * whatever n_class -- until round 4 the room laid out behind every group, empty ones included, tied it
+ * to 16 n_class n_bin (12 742 slots with 40 classes x 80 bins).  0: n_class n_bin beyond 65535. */
 int32_t pmcx_max_cap(const pmcx_config *cfg);
+
+/* Growing particle arrays.  PartMC's aero_particle_array grows when a particle is added to a full one
+ * (behind aero_state_add_particle, wrf_pmc_trans_aero.F90:777-804, 2284); a block here has cap slots
+ * per cell.  pmcx_grow re-pitches every per-slot array to new_cap slots per cell (rounded up to 64, at
+ * most 65280; a smaller or equal one: nothing happens): particles, lists, sort keys, component lists
+ * and an open transport's outboxes keep their places -- no result depends on cap -- and the old
+ * arrays are freed; the block and its larger copy must both fit in device memory while it grows
+ * (PMCX_ENOMEM otherwise, the block unchanged).  Synchronises.
+ *
+ * pmcx_set_auto_grow(on, fill, factor): the library grows the block by itself --
+ *   * pmcx_transport / pmcx_transport_finish: every cell's arrivals are counted by its sources
+ *     before anything is written to it; if some cell would not hold its particles plus its arrivals
+ *     the block grows first, to factor x what that cell needs (exact: no arrival is ever dropped
+ *     for want of slots below 65280 per cell);
+ *   * pmcx_timestep, pmcx_boundary_resample, pmcx_transport: when the fullest cell uses more than
+ *     fill x cap slots at the start of the call, to factor x that (room for the step's emissions,
+ *     background, sea salt and refill: a margin, not a count -- what still does not fit raises
+ *     PMCX_ST_CAP_OVERFLOW as ever);
+ *   * pmcx_transport_import: a neighbouring rank's cell larger than a ghost cell here.
+ * Each check reads one number back from the device (the call waits for the stream there).  Off by
+ * default; the Fortran shim switches it on (fill 0.75, factor 1.5).
+ * pmcx_get_growth: the present cap and how many times the block has grown. */
+int pmcx_grow(pmcx_ctx *ctx, int32_t new_cap);
+int pmcx_set_auto_grow(pmcx_ctx *ctx, int32_t on, double fill, double factor);
+int pmcx_get_growth(pmcx_ctx *ctx, int32_t *cap, int32_t *n_grown);
 
 /* Global id of local cell 0 (the RNG key, pmcx_config.cell_id_base) of an existing context:
  * what a per-cell caller changes between cells instead of rebuilding the context. */
@@ -703,9 +729,12 @@ int pmcx_get_diag_grid(pmcx_ctx *ctx, double *d_edge /*[n_dbin+1]*/,
 int pmcx_get_kmax(pmcx_ctx *ctx, int32_t cell, double *kmax /*[n_bin*n_bin]*/);
 /* cached per-particle totals: vtot, mass [cap] of one cell */
 int pmcx_get_caches(pmcx_ctx *ctx, int32_t cell, double *vtot, double *mass);
-/* aero_sorted of one cell: the slot lists perm[pcap], pcap = cap + cap/8 +
- * 16 n_class n_bin; list lengths gcnt[n_class*n_bin]; list starts
- * goff[n_class*n_bin + 1] (each list has free entries behind it).  The lists
+/* aero_sorted of one cell: the slot lists perm[pcap], pcap = min(65535, cap + cap/8 +
+ * min(16 G, 8192)), G = n_class n_bin; list lengths gcnt[G]; list starts goff[G + 1].  Each list has
+ * free entries behind it -- 16 + n/8, behind the empty groups 16, while perm has the room; with tens of
+ * weight classes or a cell near 65 280 slots the room shrinks, first behind the empty groups, by a
+ * fixed ladder (16 + n/8 | 4, | 1, | 0, 4 + n/8 | 0, n/8 | 0, none): a merged particle that finds no
+ * room in its new group's list goes to the table of appends (max_appends), as ever.  The lists
  * persist between mc_coag calls like aero_state%valid_sort
  * (wrf_pmc_trans_aero.F90:2094): pmcx_sort_only sorts only the cells whose
  * population was changed by anything other than mc_coag since their last sort. */

@@ -357,12 +357,30 @@ typedef struct { int32_t pn, po, rem_o, cc, pn_is_1; } coag_event;
 static void compact_stable(pmco_cell *c, const unsigned char *dead, int n_old,
                               int n_dead);
 
-/* room left behind a group of n entries when the lists are laid out */
-int pmco_sort_slack(int n) { return 16 + (n >> 3); }
+/* Room left behind a group of n entries when the lists are laid out: 16 + n/8 behind every group,
+ * the empty ones too, while perm has the entries for that (level 0: up to 512 groups and a cap that
+ * leaves the device's offsets 16 bits).  With tens of weight classes (registry.partmc_trans:2-41: 40
+ * classes x 80 bins, nearly all groups empty) or a cell near 65 280 slots perm holds less and the room
+ * shrinks, first behind the empty groups, by the first level of a fixed ladder that fits:
+ *   level 0: 16 + n/8 | 16   1: 16 + n/8 | 4   2: 16 + n/8 | 1   3: 16 + n/8 | 0
+ *         4:  4 + n/8 | 0    5: n/8 | 0        6: 0 | 0        (populated | empty) */
+int pmco_sort_slack(int n, int level)
+{
+    if (n == 0) return level == 0 ? 16 : level == 1 ? 4 : level == 2 ? 1 : 0;
+    return (level <= 3 ? 16 : level == 4 ? 4 : 0) + (level <= 5 ? (n >> 3) : 0);
+}
+int pmco_sort_level(int N, int S3, int P, int G, int pcap)
+{
+    static const int base[7] = {16, 16, 16, 16, 4, 0, 0}, empty[7] = {16, 4, 1, 0, 0, 0, 0};
+    for (int l = 0; l < 6; l++)
+        if ((int64_t)N + S3 + (int64_t)base[l] * P + (int64_t)empty[l] * (G - P) <= pcap) return l;
+    return 6;
+}
 
 /* aero_state_sort [upstream; wrf_pmc_init.F90:1279, trans_aero:801]: groups
  * g = class*n_bin + bin, every list in ascending slot order, laid out one
- * after the other in perm with pmco_sort_slack() free entries behind each. */
+ * after the other in perm with pmco_sort_slack() free entries behind each (by the level of the
+ * ladder that fits pcap). */
 void pmco_sort(pmco_cell *c, int *status)
 {
     const int B = c->n_bin, G = B * c->n_class, n = *c->n_part;
@@ -374,13 +392,15 @@ void pmco_sort(pmco_cell *c, int *status)
         key[i] = c->wclass[i] * B + pmco_bin_of(c->v_edge, B, v);
         c->gcnt[key[i]]++;
     }
-    int32_t o = 0;
+    int32_t o = 0, S3 = 0, P = 0;
+    for (int g = 0; g < G; g++) { S3 += c->gcnt[g] >> 3; P += c->gcnt[g] > 0; }
+    const int level = pmco_sort_level(n, S3, P, G, c->pcap);
     for (int g = 0; g < G; g++) {
         c->goff[g] = o;
-        o += c->gcnt[g] + pmco_sort_slack(c->gcnt[g]);
+        o += c->gcnt[g] + pmco_sort_slack(c->gcnt[g], level);
         c->gcnt[g] = 0;
     }
-    c->goff[G] = o; /* <= n + n/8 + 16 G <= pcap */
+    c->goff[G] = o; /* <= pcap */
     for (int i = 0; i < n; i++) c->perm[c->goff[key[i]] + c->gcnt[key[i]]++] = i;
     free(key);
     *c->sort_valid = 1;

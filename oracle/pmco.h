@@ -83,7 +83,7 @@ typedef struct {
     /* aero_state%aero_sorted + %valid_sort (wrf_pmc_trans_aero.F90:2094-2122):
      * kept between calls; every routine that adds, removes or resizes
      * particles other than mc_coag clears sort_valid */
-    int32_t pcap;          /* entries of perm: >= cap + cap/8 + 16 n_class n_bin */
+    int32_t pcap;          /* entries of perm: min(65535, cap + cap/8 + min(16 G, 8192)) */
     int32_t *sort_valid;   /* [1]                                            */
     int32_t *perm;         /* [pcap] slot lists, group after group           */
     int32_t *gcnt;         /* [n_class*n_bin] list lengths                   */
@@ -141,7 +141,10 @@ void pmco_refresh_caches(pmco_cell *c);
 
 /* aero_state_sort: lists in ascending slot order, pmco_sort_slack(n) free
  * entries behind a list of n.  Sets sort_valid. */
-int pmco_sort_slack(int n);
+int pmco_sort_slack(int n, int level);
+/* the first level of the ladder whose layout fits pcap entries: N particles, S3 = sum n_g / 8, P
+ * populated groups of G */
+int pmco_sort_level(int N, int S3, int P, int G, int pcap);
 void pmco_sort(pmco_cell *c, int *status);
 
 /* One mc_coag call on one cell.  Returns the status bits.  Sorts first unless

@@ -193,7 +193,8 @@ class Cell:
         # aero_sorted: kept between calls while sort_valid (set it to 0 after
         # editing the particle arrays by hand)
         G = n_class * self.n_bin
-        self.pcap = cap + cap // 8 + 16 * G
+        # (16-bit offsets on the device: the lists' layout adapts to what perm holds, pmco_sort)
+        self.pcap = min(65535, cap + cap // 8 + min(16 * G, 8192))
         self.sort_valid = np.zeros(1, dtype=np.int32)
         self.perm = np.zeros(self.pcap, dtype=np.int32)
         self.gcnt = np.zeros(G, dtype=np.int32)
@@ -403,6 +404,22 @@ def seasalt_modes(sea_salt_opt, wind_speed):
     sc, na = C.c_double(), C.c_double()
     m = f(sea_salt_opt, wind_speed, _p(fl, _dp), _p(gm, _dp), _p(gs, _dp), C.byref(sc), C.byref(na))
     return fl[:m], gm[:m], gs[:m], sc.value, na.value
+
+
+def sort_slack(n, level):
+    """Room behind a list of n entries at a level of the layout's ladder (pmco_sort_slack)."""
+    f = lib().pmco_sort_slack
+    f.restype = C.c_int
+    f.argtypes = [C.c_int, C.c_int]
+    return f(int(n), int(level))
+
+
+def sort_level(n_part, s3, populated, n_groups, pcap):
+    """The level of the ladder a cell's lists are laid out at (pmco_sort_level)."""
+    f = lib().pmco_sort_level
+    f.restype = C.c_int
+    f.argtypes = [C.c_int] * 5
+    return f(int(n_part), int(s3), int(populated), int(n_groups), int(pcap))
 
 
 def sort(cell):

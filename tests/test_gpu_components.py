@@ -114,3 +114,71 @@ def test_column_file_carries_the_lists(wp, oracle, tmp_path, carried):
     for k in ("comp_len", "comp_source", "comp_time"):
         assert np.array_equal(cm2[k], cm[k]), k
     blk.close(); b2.close()
+
+
+def test_column_file_against_the_oracle(wp, oracle, tmp_path, carried):
+    """f3 held to the ORACLE, not to the device's own download: three cells through coagulating steps and a
+    rebalance on both sides, the device writes its column (output_column: the layout of
+    output_column_to_file_new, wrf_pmc_driver.F90:1292-1658), and the file -- walked by
+    tests/cdf5_walker.py, a reader written from the format grammar that shares no code with the writer --
+    must hold what the oracle's cells hold, variable by variable: part_start_index / n_parts, masses =
+    vol x density, classes (1-based), ids, create times, number concentrations, the weights per level,
+    next_id, and aero_component_* (lengths = the untruncated sums of the source histogram, the first
+    n_comp_max entries of every list the oracle's, in its order)."""
+    from tests.cdf5_walker import walk
+    K = carried
+    n_cells, n_part, n_spec, n_class = 3, 900, 2, 2
+    blk, cells, info = parity.setup_pair(wp, oracle, n_cells, n_part, n_spec, n_class, 27, 4, cap=2048, n_source=3,
+                                         num_conc_scale=20.0)
+    ideal = np.full(n_class, n_part / n_class)
+    for step in range(3):
+        ns, nc, st = blk.mc_coag(4, 3000.0, 27, step)
+        for c, oc in enumerate(cells):
+            assert oc.mc_coag(4, 3000.0, 27, oc.cell_id, step) == (int(st[c]), int(ns[c]), int(nc[c]))
+        blk.aero_state_rebalance(True, True, 27, step)
+        for oc in cells:
+            _, oc.next_id = oc.rebalance(ideal, True, True, 27, oc.cell_id, step, oc.next_id)
+    path = blk.output_column(str(tmp_path / "col"), 4, 5, 6, 0, n_cells, ["SO4", "BC"], time=180.0, del_t=60.0)
+    dims, gatts, v = walk(path)
+    n = [int(oc.n_part[0]) for oc in cells]
+    po = np.concatenate([[0], np.cumsum(n)])
+    assert dims["number_levels"] == n_cells and dims["aero_particle"] == po[-1] and dims["aero_species"] == n_spec
+    assert dims["aero_weight_class"] == n_class and dims["aero_source"] == 3
+    assert v["time"][2][()] == 180.0 and v["timestep"][2][()] == 60.0 and v["timestep_index"][2][()] == 6
+    assert v["n_parts"][2].tolist() == n and v["part_start_index"][2].tolist() == (po[:-1] + 1).tolist()
+    dens = info["dens"]
+    cat = lambda f: np.concatenate([f(oc)[:k] for oc, k in zip(cells, n)])
+    mass = np.concatenate([oc.vol[:, :k] for oc, k in zip(cells, n)], axis=1) * dens[:, None]
+    assert v["aero_particle_mass"][0] == ["aero_species", "aero_particle"]
+    np.testing.assert_array_equal(v["aero_particle_mass"][2], mass)
+    np.testing.assert_array_equal(v["aero_particle_weight_class"][2], cat(lambda oc: oc.wclass) + 1)
+    assert (v["aero_particle_weight_group"][2] == 1).all()
+    np.testing.assert_array_equal(v["aero_id"][2], cat(lambda oc: oc.id))
+    np.testing.assert_array_equal(v["aero_least_create_time"][2], cat(lambda oc: oc.lct))
+    np.testing.assert_array_equal(v["aero_greatest_create_time"][2], cat(lambda oc: oc.gct))
+    np.testing.assert_array_equal(v["aero_num_conc"][2],
+                                  np.concatenate([oc.mag[oc.wclass[:k]] for oc, k in zip(cells, n)]))
+    assert v["weight_magnitude"][0] == ["aero_weight_class", "aero_weight_group", "number_levels"]
+    np.testing.assert_array_equal(v["weight_magnitude"][2][:, 0, :], np.array([oc.mag for oc in cells]).T)
+    assert (v["weight_type"][2] == 1).all() and (v["weight_exponent"][2] == 0).all()
+    assert v["next_id"][2][()] == max(oc.next_id for oc in cells)
+    # component(:): lengths, start indices, owners; the entries the device carries against the oracle's lists
+    tot = np.concatenate([oc.n_orig[:, :k].sum(0) for oc, k in zip(cells, n)])
+    ln, start = v["aero_component_len"][2], v["aero_component_start_ind"][2]
+    np.testing.assert_array_equal(ln, tot)
+    np.testing.assert_array_equal(start, np.concatenate([[1], 1 + np.cumsum(tot)[:-1]]))
+    assert dims["aero_components"] == tot.sum() and (tot > 1).sum() > 100
+    np.testing.assert_array_equal(v["aero_component_particle_num"][2], np.repeat(np.arange(1, po[-1] + 1), tot))
+    src, tim = v["aero_component_source_num"][2], v["aero_component_create_time"][2]
+    o_n = cat(lambda oc: oc.comp_n); o_src = np.concatenate([oc.comp_src[:k] for oc, k in zip(cells, n)])
+    o_tim = np.concatenate([oc.comp_time[:k] for oc, k in zip(cells, n)])
+    checked = 0
+    for i in range(int(po[-1])):
+        k = int(min(o_n[i], K))
+        assert o_n[i] == min(tot[i], K)
+        a = int(start[i]) - 1
+        assert np.array_equal(src[a:a + k], o_src[i, :k] + 1), i
+        assert np.array_equal(tim[a:a + k], o_tim[i, :k]), i
+        checked += k > 1
+    assert checked > 100
+    blk.close()

@@ -570,10 +570,13 @@ def test_column_file_output_and_restart(wp, oracle, tmp_path):
 
 
 def test_maximum_capacity_cell(wp, oracle):
-    """The largest cell the sampler's 16-bit list offsets allow: cap + cap/8 + 16 G <= 65535."""
+    """The largest cell the 16-bit list entries allow: 65 280 slots (until round 4 the room laid out
+    behind every group held it to cap + cap/8 + 16 G <= 65535: 57 088 with one class).  A full cell's
+    lists have no room behind them at all (the last level of the layout's ladder): every particle that
+    changes its bin goes through the table of appends."""
     with pytest.raises(wp.PmcxError):
-        wp.CellBlock(1, 57152, 1)
-    blk, cells = _ragged_pair(wp, oracle, [57088, 40000], n_spec=1, cap=57088, conc=2e10,
+        wp.CellBlock(1, 65344, 1)
+    blk, cells = _ragged_pair(wp, oracle, [65280, 40000], n_spec=1, cap=65280, conc=2e10,
                               max_events=8192, max_appends=4096)
     ns, nc, st = blk.mc_coag(K_BROWN, 300.0, 4, 0)
     for c, oc in enumerate(cells):
@@ -837,7 +840,8 @@ def test_scenario_update_parity(wp, oracle):
     blk.close()
 
 
-@pytest.mark.parametrize("n_class,flags", [(1, (True, True)), (2, (True, True)), (2, (False, True)), (2, (True, False))])
+@pytest.mark.parametrize("n_class,flags", [(1, (True, True)), (2, (True, True)), (2, (False, True)), (2, (True, False)),
+                                           (10, (True, True)), (40, (True, True))])
 def test_weight_preparation_parity(wp, oracle, n_class, flags):
     """pmcx_set_weight_preparation: aero_state_prepare_weight_for_add in front of every mode's sample
     (the allow_doubling / allow_halving the reference hands to scenario_update_aero_state, the sea-salt
@@ -845,6 +849,9 @@ def test_weight_preparation_parity(wp, oracle, n_class, flags):
     and far above their populations -- thinned to the ideal count, left alone, multiplied by copies --
     through emission + dilution + background, sea salt and the boundary refill, against the oracle."""
     n_cells, n_part, n_spec = 6, 600, 2
+    # (tens of classes, most of them empty: away from elapsed_time 0, where the add into an EMPTY class --
+    # the formula's own corner, DESIGN 3.4 -- collapses that class's weight)
+    t0 = 0.0 if n_class <= 2 else 3600.0
     blk, cells, info = parity.setup_pair(wp, oracle, n_cells, n_part, n_spec, n_class, 12, K_BROWN,
                                          cap=8192, n_source=3)
     mag = info["mag"]
@@ -865,11 +872,11 @@ def test_weight_preparation_parity(wp, oracle, n_class, flags):
     dil = np.array([1e-3, 0.0, 4e-3, 2e-3, 1e-3, 0.0])
     mag0 = blk.get_weights()
     for step in range(3):
-        ne, ni, no = blk.scenario_update_aero_state(60.0, 60.0 * step, 12, step, em, em_rate, dil, bg, bg_conc)
+        ne, ni, no = blk.scenario_update_aero_state(60.0, t0 + 60.0 * step, 12, step, em, em_rate, dil, bg, bg_conc)
         for c, oc in enumerate(cells):
             oe = [dict(m, num_conc=em_rate[c, k]) for k, m in enumerate(em)]
             ob = [dict(m, num_conc=bg_conc[c, k]) for k, m in enumerate(bg)]
-            st, oc.next_id, one, oni, ono = oc.scenario_update(60.0, 60.0 * step, 12, oc.cell_id, step, oe, dil[c], ob,
+            st, oc.next_id, one, oni, ono = oc.scenario_update(60.0, t0 + 60.0 * step, 12, oc.cell_id, step, oe, dil[c], ob,
                                                                oc.next_id)
             assert st == 0 and (one, oni, ono) == (int(ne[c]), int(ni[c]), int(no[c])), (step, c)
         ok, msg = parity.compare_state(blk, cells)
@@ -895,7 +902,7 @@ def test_weight_preparation_parity(wp, oracle, n_class, flags):
             assert oc.mc_coag(K_BROWN, 600.0, 12, oc.cell_id, step) == (int(st[c]), int(ns[c]), int(nc[c]))
     magn = blk.get_weights()
     cnt = np.array([[int((oc.wclass[:int(oc.n_part[0])] == q).sum()) for q in range(n_class)] for oc in cells])
-    if flags == (True, True):
+    if flags == (True, True) and n_class <= 2:   # (with tens of classes a class's ideal count is a handful)
         # every class the adds touched has come into [ideal / 2, 2 ideal] (the in-tree top-up of a
         # boundary cell and the coagulation in between work without the preparation: some slack) ...
         assert ((cnt[:, 0] > 0.4 * n_ideal[:, 0]) & (cnt[:, 0] < 2.3 * n_ideal[:, 0] + 30)).all(), (cnt, n_ideal)
@@ -1197,7 +1204,7 @@ def test_transport_law_1_parity(wp, oracle, nx, nz, ny, periodic):
     blk.close()
 
 
-@pytest.mark.parametrize("scale,decades,cap,want_bits", [(0.45, 1.0, 16384, 0), (0.3, 1.7, 16384, 0), (0.45, 1.0, 640, 64 | 16)])
+@pytest.mark.parametrize("scale,decades,cap,want_bits", [(0.45, 1.0, 16384, 0), (0.3, 1.3, 49152, 0), (0.45, 1.0, 640, 64 | 16)])
 def test_transport_law_1_parity_where_movers_and_emitters_overlap(wp, oracle, scale, decades, cap, want_bits):
     """Law 1 with large probabilities to leave and weight ratios down to a few per cent: sum p +
     1 - exp(-sum mu) exceeds 1 in many (cell, class) pairs, the emitters' interval overlaps the

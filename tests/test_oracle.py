@@ -1195,3 +1195,32 @@ def test_boundary_resample_law(oracle):
     nid = dst.boundary_copy_from(src, 1 << 41)
     assert int(dst.n_part[0]) == 333 and nid == (1 << 41) + 333 and dst.mag[0] == 7e6
     assert np.array_equal(dst.vtot[:333], src.vtot[:333]) and np.array_equal(dst.id[:333], (1 << 41) + np.arange(333))
+
+
+def test_independent_cdf5_walker_reads_the_assembled_column(tmp_path):
+    """tests/cdf5_walker.py (a reader written from the format grammar, no code shared with ncio.py) on
+    the file tests/golden/make_cdf5_column.py assembles: every dimension and variable comes back with
+    the values that script states.  The -m gpu test test_column_file_against_the_oracle walks the
+    DEVICE-written column with it."""
+    from tests.cdf5_walker import walk
+    here = os.path.dirname(os.path.abspath(__file__))
+    text = open(os.path.join(here, "golden", "cdf5_column.hex")).read()
+    raw = bytes.fromhex("".join(ln.split("#")[0] for ln in text.splitlines()).replace(" ", ""))
+    fx = str(tmp_path / "fixture.nc")
+    open(fx, "wb").write(raw)
+    dims, gatts, v = walk(fx)
+    assert dims == dict(aero_species=2, aero_source=2, number_levels=2, aero_particle=3, aero_components=5,
+                        aero_weight_group=1, aero_weight_class=1, gas_species=1)
+    assert gatts["title"].startswith("PartMC version") and len(v) == 29
+    assert v["time"][2][()] == 7200.0 and v["timestep_index"][2][()] == 120
+    assert v["aero_species"][1]["names"] == "SO4,BC" and v["aero_source"][1]["names"] == "traffic,sea"
+    assert v["part_start_index"][2].tolist() == [1, 3] and v["n_parts"][2].tolist() == [2, 1]
+    assert v["aero_particle_mass"][0] == ["aero_species", "aero_particle"]
+    np.testing.assert_array_equal(v["aero_particle_mass"][2],
+                                  np.array([[1e-21, 2.5e-21, 4e-22], [0.0, 5e-22, 6e-22]]) * np.array([[1800.0], [1700.0]]))
+    assert v["aero_id"][2].tolist() == [7, (3 << 32) + 11, (1 << 40) + 2] and v["next_id"][2][()] == (1 << 40) + 3
+    assert v["aero_component_len"][2].tolist() == [1, 3, 1] and v["aero_component_start_ind"][2].tolist() == [1, 2, 5]
+    assert v["aero_component_source_num"][2].tolist() == [1, 2, 1, 1, 2]
+    assert v["aero_component_create_time"][2].tolist() == [0.0, 86400.25, 12.5, 3600.0, 300.0]
+    assert v["weight_magnitude"][2].reshape(-1).tolist() == [2.5e7, 1.25e7]
+    assert v["gas_mixing_ratio"][2].reshape(-1).tolist() == [41.5, 38.25]

@@ -101,6 +101,11 @@ struct pmcx_ctx {
     bool prof = false;
     // pmcx_set_async: the per-step stage calls return without waiting for the device
     bool async_stages = false;
+    // pmcx_set_auto_grow: the block's slots per cell grow like PartMC's aero_particle_array
+    bool auto_grow = false;
+    double grow_fill = 0.75, grow_factor = 1.5;
+    int32_t *d_need = nullptr;  // [2] max n_part + n_exp, max n_hi
+    int32_t n_grown = 0;        // times the block has grown
     // pmcx_timestep: the status word of the step is started once and its stages add their bits
     bool hold_status = false;
     int32_t *h_flags = nullptr; // page-locked: [0] pmcx_transport_probs' sub-step clamp, read at the next synchronisation
@@ -249,6 +254,9 @@ void prof_drain(pmcx_ctx *ctx)
 
 extern "C" {
 
+static int grow_if_needed(pmcx_ctx *ctx, const int32_t *n_exp);
+
+
 void pmcx_config_default(pmcx_config *cfg)
 {
     memset(cfg, 0, sizeof *cfg);
@@ -298,12 +306,6 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
         return fail(nullptr, PMCX_EINVAL,
                     "pmcx_create: n_comp_max = %d needs 0 <= n_comp_max <= 8 and 1 <= n_source <= 255",
                     cfg->n_comp_max);
-    // list offsets are 16-bit in the sampler's LDS: lists + the room behind them must fit
-    if ((int64_t)cfg->cap + cfg->cap / 8 + 16 * (int64_t)cfg->n_class * cfg->n_bin > 65535)
-        return fail(nullptr, PMCX_EINVAL,
-                    "pmcx_create: cap + cap/8 + 16 n_class n_bin = %lld exceeds 65535",
-                    (long long)((int64_t)cfg->cap + cfg->cap / 8 + 16 * (int64_t)cfg->n_class * cfg->n_bin));
-
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1 || cfg->device >= n_dev)
         return fail(nullptr, PMCX_EDEVICE, "no HIP device %d (found %d): this library has no CPU path",
@@ -331,7 +333,7 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
     st.n_comp_max = cfg->n_comp_max;
     st.trans_law = 1; // (pmcx_set_transport_law)
     st.compact_den = cfg->compact_den ? (int32_t)cfg->compact_den : 2;
-    st.pcap = cfg->cap + cfg->cap / 8 + 16 * cfg->n_class * cfg->n_bin;
+    st.pcap = sort_pcap(cfg->cap, cfg->n_class * cfg->n_bin);
     st.cell_id_base = cfg->cell_id_base;
     st.const_k = cfg->const_k; st.additive_beta = cfg->additive_beta;
     st.rho_min = 0; st.rho_max = 0;
@@ -491,6 +493,126 @@ int pmcx_set_async(pmcx_ctx *ctx, int32_t on)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->async_stages = on != 0;
     return PMCX_OK;
+}
+
+// ---- growing particle arrays (PartMC's aero_particle_array grows; a block's slabs are re-pitched) ----
+
+// One per-slot array of the block re-pitched from old_row to new_row elements per row: the new
+// allocation first (so that a failed one leaves the block as it was), the copy and the swap later.
+namespace {
+struct Regrid {
+    void **slot;        // where the context keeps the pointer
+    size_t elem, rows, old_row, new_row;
+    void *fresh;
+};
+}
+
+int pmcx_grow(pmcx_ctx *ctx, int32_t new_cap)
+{
+    if (!ctx) return PMCX_EINVAL;
+    pmcx_config &cf = ctx->cfg;
+    DeviceState &st = ctx->st;
+    new_cap = (new_cap + 63) & ~63;
+    if (new_cap <= cf.cap) return PMCX_OK;
+    if (new_cap > 65280)
+        return fail(ctx, PMCX_EINVAL, "pmcx_grow: %d slots per cell asked for, a cell holds at most 65280 "
+                                      "(16-bit list entries)", new_cap);
+    if (ctx->halo_nx != 0 && ctx->d_halo)
+        ; // (between pmcx_transport_begin and _finish: the outboxes are re-pitched with the rest)
+    HIP_TRY(ctx, hipSetDevice(cf.device));
+    const size_t nc = (size_t)cf.n_cells, oc = (size_t)cf.cap, nw = (size_t)new_cap;
+    const size_t G = (size_t)cf.n_class * cf.n_bin;
+    const size_t old_pcap = (size_t)st.pcap, new_pcap = (size_t)sort_pcap(new_cap, (int32_t)G);
+    std::vector<Regrid> jobs;
+    auto add = [&](void **slot, size_t elem, size_t rows, size_t old_row, size_t new_row) {
+        if (*slot) jobs.push_back(Regrid{slot, elem, rows, old_row, new_row, nullptr});
+    };
+    add((void **)&st.vol, sizeof(double), nc, oc * cf.n_spec, nw * cf.n_spec);
+    add((void **)&st.hot, sizeof(Hot), nc, oc, nw);
+    add((void **)&st.wclass, sizeof(int32_t), nc, oc, nw);
+    add((void **)&st.cold, sizeof(Cold), nc, oc, nw);
+    if (cf.n_source > 1) add((void **)&st.n_orig, sizeof(int32_t), nc * (size_t)(cf.n_source - 1), oc, nw);
+    add((void **)&st.perm, sizeof(uint16_t), nc, old_pcap, new_pcap);
+    add((void **)&st.gkey, sizeof(uint16_t), nc, oc, nw);
+    if (cf.n_comp_max > 0) {
+        add((void **)&st.comp_src, sizeof(uint64_t), nc, oc, nw);
+        add((void **)&st.comp_time, sizeof(double), nc, oc * (size_t)cf.n_comp_max, nw * (size_t)cf.n_comp_max);
+    }
+    add((void **)&ctx->d_outbox, sizeof(int64_t), nc, oc, nw);
+    int64_t more = 0;
+    for (Regrid &j : jobs) {
+        const size_t bytes = j.elem * j.rows * j.new_row;
+        if (hipMalloc(&j.fresh, bytes) != hipSuccess) {
+            for (Regrid &k : jobs) if (k.fresh) (void)hipFree(k.fresh);
+            return fail(ctx, PMCX_ENOMEM, "pmcx_grow: no memory for %d slots per cell (%d now): the block and its "
+                                          "larger copy must both fit while it grows", new_cap, cf.cap);
+        }
+        more += (int64_t)bytes - (int64_t)(j.elem * j.rows * j.old_row);
+    }
+    for (Regrid &j : jobs)
+        HIP_TRY(ctx, hipMemcpy2DAsync(j.fresh, j.elem * j.new_row, *j.slot, j.elem * j.old_row, j.elem * j.old_row,
+                                      j.rows, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (Regrid &j : jobs) {
+        for (void *&a : ctx->allocs) if (a == *j.slot) a = j.fresh;
+        (void)hipFree(*j.slot);
+        *j.slot = j.fresh;
+    }
+    ctx->bytes += more;
+    const int old_cap = cf.cap;
+    cf.cap = new_cap; st.cap = new_cap; st.pcap = (int32_t)new_pcap;
+    HIP_TRY(ctx, launch_grow_tail(st, old_cap, ctx->stream));
+    // (what was staged for the old pitch is rebuilt on use)
+    ctx->n_grown++;
+    return PMCX_OK;
+}
+
+int pmcx_set_auto_grow(pmcx_ctx *ctx, int32_t on, double fill, double factor)
+{
+    if (!ctx || (on && (!(fill > 0.0) || !(fill <= 1.0) || !(factor > 1.0) || !(factor <= 8.0))))
+        return fail(ctx, PMCX_EINVAL, "pmcx_set_auto_grow: 0 < fill <= 1 < factor <= 8");
+    if (on && !ctx->d_need) {
+        int rc = dev_alloc(ctx, &ctx->d_need, (size_t)2);
+        if (rc) return rc;
+    }
+    ctx->auto_grow = on != 0;
+    if (on) { ctx->grow_fill = fill; ctx->grow_factor = factor; }
+    return PMCX_OK;
+}
+
+int pmcx_get_growth(pmcx_ctx *ctx, int32_t *cap, int32_t *n_grown)
+{
+    if (!ctx) return PMCX_EINVAL;
+    if (cap) *cap = ctx->cfg.cap;
+    if (n_grown) *n_grown = ctx->n_grown;
+    return PMCX_OK;
+}
+
+// pmcx_set_auto_grow: the fullest cell -- what it holds (n_exp null) or is about to hold after the
+// arrivals its neighbours have counted for it (n_exp) -- read back (the call waits for the device
+// here), and the block grown when that is beyond fill x cap: to factor x that, at least to what is
+// needed, at most to 65 280.  What cannot fit even then is left to the kernels' status bit.
+static int grow_if_needed(pmcx_ctx *ctx, const int32_t *n_exp)
+{
+    if (!ctx->auto_grow) return PMCX_OK;
+    HIP_TRY(ctx, launch_need_max(ctx->st, n_exp, ctx->d_need, ctx->stream));
+    int32_t h[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_need, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // arrivals find room among a cell's dead slots (k_trans_room compacts): what counts is the live count
+    const int need = n_exp ? h[0] : h[1];
+    const int cap = ctx->cfg.cap;
+    const bool must = need > cap, should = (double)need > ctx->grow_fill * (double)cap;
+    if (!must && !should) return PMCX_OK;
+    double want = ctx->grow_factor * (double)(n_exp && !must ? cap : need);
+    if (want < (double)need) want = (double)need;
+    if (want > 65280.0) want = 65280.0;
+    int32_t new_cap = ((int32_t)want + 63) & ~63;
+    if (new_cap > 65280) new_cap = 65280;
+    if (new_cap <= cap) return PMCX_OK;
+    const int rc = pmcx_grow(ctx, new_cap);
+    if (rc == PMCX_ENOMEM && !must) { ctx->err.clear(); return PMCX_OK; } // (growing ahead of need is optional)
+    return rc;
 }
 
 int pmcx_memory_bytes(pmcx_ctx *ctx, int64_t *bytes)
@@ -1444,11 +1566,27 @@ int pmcx_transport(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int32_t pe
     }
     HIP_TRY(ctx, hipMemcpyAsync(d_cv, cell_volume, bc, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->st.status, 0, sizeof(int32_t) * nc, ctx->stream));
-    {
+    if (!ctx->auto_grow) {
         ProfScope ps(ctx, "transport");
         HIP_TRY(ctx, launch_transport(ctx->st, nx, nz, ny, periodic_x, periodic_y, d_ph, d_pv, d_cv,
                                       ctx->d_outbox, ctx->d_n_out, ctx->d_n_arr, ctx->d_n_exp,
                                       ctx->d_dest_mask, seed, step, ctx->stream));
+    } else {
+        // pmcx_set_auto_grow: the arrivals every cell is about to take are counted by its sources
+        // before anything is written to it -- a cell that would not hold them gets its slots first
+        {
+            ProfScope ps(ctx, "transport");
+            HIP_TRY(ctx, launch_transport_begin(ctx->st, nx, nz, ny, periodic_x, periodic_y, d_ph, d_pv, d_cv,
+                                                ctx->d_outbox, ctx->d_n_out, ctx->d_n_arr, ctx->d_n_exp,
+                                                ctx->d_dest_mask, seed, step, ctx->stream));
+        }
+        // (the cell volumes live in the staging area, which growing does not touch)
+        rc = grow_if_needed(ctx, ctx->d_n_exp);
+        if (rc) return rc;
+        ProfScope ps(ctx, "transport");
+        HIP_TRY(ctx, launch_transport_finish(ctx->st, nx, nz, ny, periodic_x, periodic_y, d_cv, ctx->d_outbox,
+                                             ctx->d_n_out, ctx->d_n_arr, ctx->d_n_exp, ctx->d_dest_mask, 0, ny,
+                                             ctx->stream));
     }
     if (n_moved) HIP_TRY(ctx, hipMemcpyAsync(n_moved, ctx->d_n_out, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));
     if (n_arrived) HIP_TRY(ctx, hipMemcpyAsync(n_arrived, ctx->d_n_arr, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));
@@ -1570,6 +1708,7 @@ int pmcx_boundary_resample(pmcx_ctx *ctx, int32_t n_list, const int32_t *cell, c
         return fail(ctx, PMCX_EINVAL, "pmcx_boundary_resample: bad argument");
     if (!ctx->aero_data_set) return fail(ctx, PMCX_ESTATE, "pmcx_set_aero_data must come first");
     if (n_list == 0) return PMCX_OK;
+    if (int grc = grow_if_needed(ctx, nullptr)) return grc; // (pmcx_set_auto_grow: room for the refill)
     const size_t nc = (size_t)ctx->cfg.n_cells;
     const int M = background->n_mode;
     if (M < 1 || M > 64 || !background->num_conc) return fail(ctx, PMCX_EINVAL, "pmcx_boundary_resample: bad background");
@@ -2000,6 +2139,11 @@ int pmcx_transport_import(pmcx_ctx *ctx, int32_t side, const void *dev_buf, int6
                                     hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         int64_t total = 0;
+        int32_t most = 0;
+        for (int r = 0; r < row; r++) most = h_counts[r] > most ? h_counts[r] : most;
+        // (a neighbouring rank whose block has grown may send a cell more than a ghost cell here holds)
+        if (most > ctx->cfg.cap && most <= 65280 && ctx->auto_grow)
+            if (int grc = pmcx_grow(ctx, most)) return grc;
         for (int r = 0; r < row; r++) {
             if (h_counts[r] < 0 || h_counts[r] > ctx->cfg.cap)
                 return fail(ctx, PMCX_EINVAL, "pmcx_transport_import: cell %d of the buffer claims %d "
@@ -2032,6 +2176,7 @@ int pmcx_transport_finish(pmcx_ctx *ctx, int32_t *n_moved, int32_t *n_arrived)
     if (!ctx || !ctx->halo_nx) return fail(ctx, PMCX_EINVAL, "pmcx_transport_finish: no pmcx_transport_begin");
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     const size_t nc = (size_t)ctx->cfg.n_cells;
+    if (int grc = grow_if_needed(ctx, ctx->d_n_exp)) return grc; // (pmcx_set_auto_grow: before anything is gathered)
     {
         ProfScope ps(ctx, "transport");
         HIP_TRY(ctx, launch_transport_finish(ctx->st, ctx->halo_nx, ctx->halo_nz, ctx->halo_ny, ctx->halo_px,
@@ -2288,15 +2433,10 @@ int pmcx_set_loop_cells(pmcx_ctx *ctx, const int32_t *in_loop)
 
 int32_t pmcx_max_cap(const pmcx_config *cfg)
 {
-    if (!cfg || cfg->n_class < 1 || cfg->n_bin < 1) return 0;
-    // cap + cap / 8 + 16 n_class n_bin <= 65535, cap <= 65280, cap a multiple of 64
-    const int64_t room = 65535 - 16 * (int64_t)cfg->n_class * cfg->n_bin;
-    if (room < 72) return 0;
-    int64_t cap = room * 8 / 9;
-    if (cap > 65280) cap = 65280;
-    cap &= ~(int64_t)63;
-    while (cap >= 64 && cap + cap / 8 > room) cap -= 64;
-    return cap >= 64 ? (int32_t)cap : 0;
+    if (!cfg || cfg->n_class < 1 || cfg->n_bin < 1 || (int64_t)cfg->n_class * cfg->n_bin > 65535) return 0;
+    // slots are 16-bit list entries (0xFFFF marks none), cap a multiple of 64: whatever the number of
+    // weight classes -- the lists' layout adapts to the room perm has (pmcx.h, pmcx_get_sort)
+    return 65280;
 }
 
 int pmcx_timestep(pmcx_ctx *ctx, const pmcx_step_flags *f)
@@ -2320,6 +2460,10 @@ int pmcx_timestep(pmcx_ctx *ctx, const pmcx_step_flags *f)
     // one status word for the step: every stage adds its bits (each of them, called by itself,
     // would start a new one and wipe what mc_coag reported)
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    // pmcx_set_auto_grow: room for this step's emissions, background and sea salt (the fullest cell
+    // beyond its fill mark: the block grows before the step, as PartMC's particle arrays grow on use)
+    rc = grow_if_needed(ctx, nullptr);
+    if (rc) return rc;
     HIP_TRY(ctx, hipMemsetAsync(ctx->st.status, 0, sizeof(int32_t) * (size_t)ctx->cfg.n_cells, ctx->stream));
     struct Hold { pmcx_ctx *c; Hold(pmcx_ctx *x) : c(x) { c->hold_status = true; } ~Hold() { c->hold_status = false; } } hold(ctx);
     if (chem_step && f->do_coagulation) {                                        // driver:189-198

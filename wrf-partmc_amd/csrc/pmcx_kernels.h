@@ -34,12 +34,21 @@ struct __attribute__((aligned(16))) Cold {
 
 constexpr int EVLOG_CAP = 256; // entries of a cell's event log (two per coagulation at most)
 
+// entries of perm per cell: min(65535, cap + cap/8 + min(16 G, 8192)) -- offsets into it are 16 bits in
+// the samplers' LDS; the lists' layout adapts to what it holds (sort_slack_level, pmcx_kernels.hip)
+inline int32_t sort_pcap(int32_t cap, int32_t G)
+{
+    const int64_t extra = 16 * (int64_t)G < 8192 ? 16 * (int64_t)G : 8192;
+    const int64_t want = (int64_t)cap + cap / 8 + extra;
+    return (int32_t)(want < 65535 ? want : 65535);
+}
+
 // Plain view of everything a kernel needs; passed by value.
 struct DeviceState {
     int32_t n_cells, cap, n_spec, n_class, n_source, n_bin, n_dbin, i_water;
     int32_t max_events, max_appends;
     int32_t compact_den; // holes are closed once more than 1/compact_den of a cell's slots are dead
-    int32_t pcap; // entries of perm per cell: cap + cap/8 + 16 n_class n_bin
+    int32_t pcap; // entries of perm per cell: sort_pcap(cap, n_class n_bin)
     uint32_t cell_id_base;
     double const_k, additive_beta;
     double rho_min, rho_max;
@@ -260,6 +269,10 @@ hipError_t launch_dry_deposition(const DeviceState &st, double dt, uint64_t seed
 hipError_t launch_condense(const DeviceState &st, const double *kappa, const double *rel_humid,
                            double del_t, int n_sub, hipStream_t s);
 hipError_t launch_totals(const DeviceState &st, int64_t *out4, hipStream_t s);
+// out2[0] = max over cells of n_part + n_exp (n_exp may be null), out2[1] = max n_hi
+hipError_t launch_need_max(const DeviceState &st, const int32_t *n_exp, int32_t *out2, hipStream_t s);
+// the slots [old_cap, new_cap) of every cell of a block that has just grown: dead
+hipError_t launch_grow_tail(const DeviceState &st, int old_cap, hipStream_t s);
 hipError_t launch_test_math(int op, int64_t n, const double *a, const double *b, const double *c3,
                             const double *c4, int ktype, double temp, double pressure,
                             double const_k, double additive_beta, double *out, hipStream_t s);

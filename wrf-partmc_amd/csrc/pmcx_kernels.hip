@@ -525,15 +525,41 @@ __global__ __launch_bounds__(512) void k_kernel_bounds(DeviceState st, int ktype
 // append in place; a cell whose lists still hold (sort_valid, the reference's
 // aero_state%valid_sort, wrf_pmc_trans_aero.F90:2094) is skipped.
 
-// free entries left behind a list of n when the lists are laid out (oracle: pmco_sort_slack)
-__device__ __forceinline__ uint32_t sort_slack(uint32_t n) { return 16u + (n >> 3); }
+// Free entries left behind a list of n when the lists are laid out (oracle: pmco_sort_slack): 16 + n/8
+// behind every group, the empty ones too, while the cell's perm has the entries for that (level 0:
+// every block of up to 512 groups whose cap leaves the offsets 16 bits).  With tens of weight
+// classes (registry.partmc_trans:2-41: 40 classes x 80 bins = 3200 groups, nearly all empty) or a
+// cell near 65 280 slots perm holds less -- pcap = min(65535, cap + cap/8 + min(16 G, 8192)) -- and
+// the room shrinks, first behind the empty groups, by the first level of a fixed ladder that fits
+// the cell's N particles, P populated groups and S3 = sum n_g / 8:
+//   level   populated       empty
+//     0     16 + n/8         16
+//     1     16 + n/8          4
+//     2     16 + n/8          1
+//     3     16 + n/8          0
+//     4      4 + n/8          0
+//     5          n/8          0
+//     6          0            0       (N <= cap <= pcap: always fits)
+// An entry that finds no room goes to the table of appends (max_appends), as before.
+__host__ __device__ inline uint32_t sort_slack_level(uint32_t n, int level)
+{
+    if (n == 0) return level == 0 ? 16u : level == 1 ? 4u : level == 2 ? 1u : 0u;
+    return (level <= 3 ? 16u : level == 4 ? 4u : 0u) + (level <= 5 ? (n >> 3) : 0u);
+}
+__host__ __device__ inline int sort_layout_level(uint32_t N, uint32_t S3, uint32_t P, uint32_t G, uint32_t pcap)
+{
+    const uint32_t base[7] = {16u, 16u, 16u, 16u, 4u, 0u, 0u}, empty[7] = {16u, 4u, 1u, 0u, 0u, 0u, 0u};
+    for (int l = 0; l < 6; l++)
+        if ((uint64_t)N + S3 + (uint64_t)base[l] * P + (uint64_t)empty[l] * (G - P) <= pcap) return l;
+    return 6;
+}
 
 // exclusive scan in place over an LDS u32 array of length n
 __device__ __forceinline__ void block_excl_scan_u32(uint32_t *a, int n, uint32_t *wsum)
 {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int per = (n + 255) / 256;
-    const int j0 = t * per, j1 = min(n, j0 + per);
+    const int per = (n + (int)blockDim.x - 1) / (int)blockDim.x;
+    const int j0 = min(n, t * per), j1 = min(n, j0 + per);
     uint32_t s = 0;
     for (int j = j0; j < j1; j++) s += a[j];
     const uint32_t inc = wave_incl_scan_u32(s, lane);
@@ -587,7 +613,11 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st, const int32_t 
 {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint32_t wsum[4];
+    __shared__ uint32_t s_lay[4]; // the layout's totals: particles, sum n_g / 8, populated groups; its level
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // wavefronts of the workgroup (4; 2 or 1 where the per-wavefront tables of 4 would not fit in
+    // LDS: tens of weight classes), each with a contiguous share of the slots
+    const int NW = (int)blockDim.x >> 6, NT = (int)blockDim.x;
     const int B = st.n_bin, C = st.n_class, G = B * C;
     const int n_work = list ? *count : st.n_cells;
   for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
@@ -597,21 +627,22 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st, const int32_t 
     const int64_t cb = (int64_t)c * st.cap;
 
     const size_t o_tab = (sizeof(double) * (size_t)(B + 1) + 15) & ~(size_t)15;
-    const size_t o_key = (o_tab + (sizeof(uint64_t) * 4 + sizeof(uint32_t) * 5) * (size_t)G + 15) & ~(size_t)15;
+    const size_t o_key = (o_tab + (sizeof(uint64_t) * NW + sizeof(uint32_t) * (NW + 1)) * (size_t)G + 15) & ~(size_t)15;
     double *edge = (double *)smem;                    // [B+1]
-    uint64_t *pmask = (uint64_t *)(smem + o_tab);     // [4][G] lanes of the chunk holding group g
-    uint32_t *hist = (uint32_t *)(pmask + 4 * (size_t)G); // [4][G] per-wave counts -> cursors
-    uint32_t *tot = hist + 4 * (size_t)G;             // [G] totals -> offsets
+    uint64_t *pmask = (uint64_t *)(smem + o_tab);     // [NW][G] lanes of the chunk holding group g
+    uint32_t *hist = (uint32_t *)(pmask + NW * (size_t)G); // [NW][G] per-wave counts -> cursors
+    uint32_t *tot = hist + NW * (size_t)G;            // [G] totals -> offsets
     uint16_t *key = (uint16_t *)(smem + o_key);       // [cap] group of slot (16-byte aligned)
 
-    for (int j = t; j <= B; j += 256) edge[j] = st.v_edge[j];
-    for (int j = t; j < 4 * G; j += 256) { hist[j] = 0; pmask[j] = 0; }
+    for (int j = t; j <= B; j += NT) edge[j] = st.v_edge[j];
+    for (int j = t; j < NW * G; j += NT) { hist[j] = 0; pmask[j] = 0; }
+    if (t < 4) s_lay[t] = 0;
     const bool keyed = st.key_valid[c] != 0; // (the whole workgroup: the slots' keys still hold)
     uint16_t *gk = st.gkey + cb;
     __syncthreads();
 
     // this wave's slots: a contiguous range whose length is a multiple of 64
-    const int per = (((n + 3) >> 2) + 63) & ~63;
+    const int per = (((n + NW - 1) / NW) + 63) & ~63;
     const int lo = min(n, wave * per), hi = min(n, lo + per);
     const Hot *vt = st.hot + cb; // .vtot = cached total volume
     const int32_t *wc = st.wclass + cb;
@@ -643,8 +674,7 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st, const int32_t 
             // (the log is read by all threads at once -- one entry each, EVLOG_CAP <= 256 -- and
             // applied from LDS by one: a later entry of the same slot must win)
             __shared__ uint32_t s_log[EVLOG_CAP];
-            const uint32_t mine = t < nl ? st.evlog[(int64_t)c * EVLOG_CAP + t] : 0u;
-            if (t < nl) s_log[t] = mine;
+            for (int j = t; j < nl; j += NT) s_log[j] = st.evlog[(int64_t)c * EVLOG_CAP + j];
             __syncthreads();
             if (t == 0)
                 for (int j = 0; j < nl; j++) {
@@ -652,8 +682,8 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st, const int32_t 
                     if ((int)(e & 0xFFFFu) < n) key[e & 0xFFFFu] = (uint16_t)(e >> 16);
                 }
             __syncthreads();
-            if (t < nl) {
-                const uint32_t sl = mine & 0xFFFFu;
+            for (int j = t; j < nl; j += NT) {
+                const uint32_t sl = s_log[j] & 0xFFFFu;
                 if ((int)sl < n) gk[sl] = key[sl];
             }
         }
@@ -695,23 +725,34 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st, const int32_t 
 
     int32_t *gcnt_g = st.gcnt + (int64_t)c * G;
     int32_t *goff_g = st.goff + (int64_t)c * (G + 1);
-    for (int g = t; g < G; g += 256) {
-        const uint32_t h0 = hist[g], h1 = hist[G + g], h2 = hist[2 * G + g], h3 = hist[3 * G + g];
-        hist[g] = 0; hist[G + g] = h0; hist[2 * G + g] = h0 + h1; hist[3 * G + g] = h0 + h1 + h2;
-        const uint32_t s = h0 + h1 + h2 + h3;
-        tot[g] = s + sort_slack(s); // the list and the room behind it
-        gcnt_g[g] = (int32_t)s;
+    {
+        uint32_t lN = 0, lS3 = 0, lP = 0;
+        for (int g = t; g < G; g += NT) {
+            uint32_t s = 0;
+            for (int q = 0; q < NW; q++) { const uint32_t h = hist[q * G + g]; hist[q * G + g] = s; s += h; }
+            tot[g] = s;
+            gcnt_g[g] = (int32_t)s;
+            lN += s; lS3 += s >> 3; lP += s > 0;
+        }
+        // (the layout's level: one of a fixed ladder, by the cell's totals -- sort_slack_level)
+        for (int d = 32; d >= 1; d >>= 1) {
+            lN += __shfl_xor(lN, d, 64); lS3 += __shfl_xor(lS3, d, 64); lP += __shfl_xor(lP, d, 64);
+        }
+        if (lane == 0) { atomicAdd(&s_lay[0], lN); atomicAdd(&s_lay[1], lS3); atomicAdd(&s_lay[2], lP); }
     }
     __syncthreads();
+    const int level = sort_layout_level(s_lay[0], s_lay[1], s_lay[2], (uint32_t)G, (uint32_t)st.pcap);
+    for (int g = t; g < G; g += NT) tot[g] = tot[g] + sort_slack_level(tot[g], level); // the list and the room behind it
+    __syncthreads();
     block_excl_scan_u32(tot, G, wsum);
-    for (int g = t; g < G; g += 256) {
+    for (int g = t; g < G; g += NT) {
         const uint32_t o = tot[g];
         goff_g[g] = (int32_t)o;
         if (g == G - 1) {
             const uint32_t s = (uint32_t)gcnt_g[g];
-            goff_g[G] = (int32_t)(o + s + sort_slack(s));
+            goff_g[G] = (int32_t)(o + s + sort_slack_level(s, level));
         }
-        hist[g] += o; hist[G + g] += o; hist[2 * G + g] += o; hist[3 * G + g] += o;
+        for (int q = 0; q < NW; q++) hist[q * G + g] += o;
     }
     __syncthreads();
 
@@ -5453,12 +5494,23 @@ __global__ void k_test_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
 
 // ------------------------------------------------------------------ launchers
 
-size_t bin_sort_lds_bytes(const DeviceState &st)
+static size_t bin_sort_lds_for(const DeviceState &st, int nw)
 {
     const size_t B = st.n_bin, G = (size_t)st.n_bin * st.n_class;
     const size_t o_tab = (sizeof(double) * (B + 1) + 15) & ~(size_t)15;
-    const size_t o_key = (o_tab + (sizeof(uint64_t) * 4 + sizeof(uint32_t) * 5) * G + 15) & ~(size_t)15;
+    const size_t o_key = (o_tab + (sizeof(uint64_t) * nw + sizeof(uint32_t) * (nw + 1)) * G + 15) & ~(size_t)15;
     return o_key + sizeof(uint16_t) * (((size_t)st.cap + 7) & ~(size_t)7);
+}
+// wavefronts per workgroup of k_bin_sort: four, fewer where their tables would not fit in LDS
+int bin_sort_waves(const DeviceState &st)
+{
+    int nw = 4;
+    while (nw > 1 && bin_sort_lds_for(st, nw) > (size_t)150 * 1024) nw >>= 1;
+    return nw;
+}
+size_t bin_sort_lds_bytes(const DeviceState &st)
+{
+    return bin_sort_lds_for(st, bin_sort_waves(st));
 }
 static size_t sampler_lds_for(const DeviceState &st, int lanes)
 {
@@ -5642,7 +5694,7 @@ hipError_t launch_bin_sort(const DeviceState &st, hipStream_t s)
 {
     allow_lds(k_bin_sort, bin_sort_lds_bytes(st));
     list_cells(st, LIST_SORT, 0, 0, 0, st.n_cells, s);
-    hipLaunchKernelGGL(k_bin_sort, dim3(st.n_cells < 16384 ? st.n_cells : 16384), dim3(256),
+    hipLaunchKernelGGL(k_bin_sort, dim3(st.n_cells < 16384 ? st.n_cells : 16384), dim3(64 * bin_sort_waves(st)),
                        bin_sort_lds_bytes(st), s, st, (const int32_t *)(st.work_list + 1),
                        (const int32_t *)st.work_list);
     return hipGetLastError();
@@ -6043,6 +6095,45 @@ hipError_t launch_condense(const DeviceState &st, const double *kappa, const dou
 {
     hipLaunchKernelGGL(k_condense, grid2(st.cap, st.n_cells), dim3(256), 0, s, st, kappa,
                        rel_humid, del_t, n_sub);
+    return hipGetLastError();
+}
+// pmcx_grow / pmcx_set_auto_grow: what the fullest cell holds, or is about to
+__global__ __launch_bounds__(256) void k_need_max(DeviceState st, const int32_t *n_exp, int32_t *out)
+{
+    int need = 0, hi = 0;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < st.n_cells; c += gridDim.x * blockDim.x) {
+        const int a = st.n_part[c] + (n_exp ? n_exp[c] : 0), b = st.n_hi[c];
+        need = a > need ? a : need;
+        hi = b > hi ? b : hi;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int a = __shfl_xor(need, d, 64), b = __shfl_xor(hi, d, 64);
+        need = a > need ? a : need;
+        hi = b > hi ? b : hi;
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMax(&out[0], need); atomicMax(&out[1], hi); }
+}
+hipError_t launch_need_max(const DeviceState &st, const int32_t *n_exp, int32_t *out2, hipStream_t s)
+{
+    (void)hipMemsetAsync(out2, 0, 2 * sizeof(int32_t), s);
+    int g = (st.n_cells + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(k_need_max, dim3(g), dim3(256), 0, s, st, n_exp, out2);
+    return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void k_grow_tail(DeviceState st, int old_cap)
+{
+    for (int c = blockIdx.x; c < st.n_cells; c += gridDim.x) {
+        const int64_t cb = (int64_t)c * st.cap;
+        for (int i = old_cap + threadIdx.x; i < st.cap; i += blockDim.x) {
+            st.hot[cb + i].vtot = -1.0;
+            st.gkey[cb + i] = (uint16_t)0xFFFFu;
+        }
+    }
+}
+hipError_t launch_grow_tail(const DeviceState &st, int old_cap, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_grow_tail, dim3(st.n_cells < 32768 ? st.n_cells : 32768), dim3(256), 0, s, st, old_cap);
     return hipGetLastError();
 }
 hipError_t launch_totals(const DeviceState &st, int64_t *out4, hipStream_t s)

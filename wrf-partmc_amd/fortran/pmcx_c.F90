@@ -72,6 +72,22 @@ module pmcx_c
        import :: pmcx_config, c_int32_t
        type(pmcx_config), intent(in) :: cfg
      end function pmcx_max_cap
+     integer(c_int) function pmcx_grow(ctx, new_cap) bind(c, name="pmcx_grow")
+       import :: c_ptr, c_int, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: new_cap
+     end function pmcx_grow
+     integer(c_int) function pmcx_set_auto_grow(ctx, on, fill, factor) bind(c, name="pmcx_set_auto_grow")
+       import :: c_ptr, c_int, c_int32_t, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: on
+       real(c_double), value :: fill, factor
+     end function pmcx_set_auto_grow
+     integer(c_int) function pmcx_get_growth(ctx, cap, n_grown) bind(c, name="pmcx_get_growth")
+       import :: c_ptr, c_int, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), intent(out) :: cap, n_grown
+     end function pmcx_get_growth
      integer(c_int) function pmcx_memory_bytes(ctx, bytes) bind(c, name="pmcx_memory_bytes")
        import :: c_ptr, c_int, c_int64_t
        type(c_ptr), value :: ctx

@@ -50,7 +50,7 @@ module pmcx_shim
   ! brings aero_states / gas_states up to date when the Fortran side needs them (output, restart)
   public :: partmc_timestep_pmcx, wrf_pmc_trans_driver_pmcx, partmc_sync_host_pmcx, &
        partmc_process_pmcx, pmcx_shim_is_resident
-  public :: pmcx_shim_set_components, pmcx_shim_set_headroom
+  public :: pmcx_shim_set_components, pmcx_shim_set_headroom, pmcx_shim_set_auto_grow, pmcx_shim_growth
   public :: pmcx_shim_init, pmcx_shim_finalize, pmcx_set_rng, mc_coag_pmcx, &
        partmc_coag_cells_pmcx, aero_state_rebalance_cells_pmcx, aero_state_rebalance_pmcx, &
        pmcx_config
@@ -73,6 +73,7 @@ module pmcx_shim
   logical, save :: have_ctx = .false.
   integer, save :: want_comp_max = 8           ! entries of component(:) carried per particle
   real(kind=dp), save :: headroom = 3.0d0      ! particle slots of a cell / its ideal count (pmcx_shim_set_headroom)
+  logical, save :: auto_grow = .true.          ! the block grows when a cell runs short of slots (pmcx_shim_set_auto_grow)
   ! per-step staging arrays in page-locked memory (pmcx_host_alloc): an upload from them is one
   ! DMA that overlaps the device's work; they grow as needed and live until pmcx_shim_finalize
   integer, parameter :: N_PIN = 24
@@ -155,6 +156,24 @@ contains
     headroom = max(1.0d0, factor)
   end subroutine pmcx_shim_set_headroom
 
+  !> Whether the block grows by itself when a cell runs short of slots (default .true.: PartMC's
+  !> particle arrays grow on use).  .false.: a full cell stops the run with its message, as until
+  !> round 4.  Takes effect at the next upload that builds a context.
+  subroutine pmcx_shim_set_auto_grow(on)
+    logical, intent(in) :: on
+    auto_grow = on
+  end subroutine pmcx_shim_set_auto_grow
+
+  !> Slots per cell now, and how many times the block has grown since it was made.
+  subroutine pmcx_shim_growth(cap, n_grown)
+    integer, intent(out) :: cap, n_grown
+    integer(c_int32_t) :: c_, n_
+    cap = 0; n_grown = 0
+    if (.not. have_ctx) return
+    call pmcx_die(pmcx_get_growth(ctx, c_, n_), 'pmcx_get_growth')
+    cap = c_; n_grown = n_
+  end subroutine pmcx_shim_growth
+
   subroutine pmcx_shim_init(n_cells, cap, aero_data, n_class, n_source, device)
     integer, intent(in) :: n_cells, cap, n_class, n_source, device
     type(aero_data_t), intent(in) :: aero_data
@@ -172,6 +191,10 @@ contains
     cfg%cell_id_base = cell_id_base
     call pmcx_die(pmcx_create(cfg, ctx), 'pmcx_create')
     have_ctx = .true.
+    ! PartMC's particle arrays grow on use (behind aero_state_add_particle, wrf_pmc_trans_aero.F90:777-804):
+    ! the block grows by itself -- before a transport gathers arrivals a cell would not hold, and
+    ! when the fullest cell passes 3/4 of its slots at the start of a step (pmcx_set_auto_grow)
+    if (auto_grow) call pmcx_die(pmcx_set_auto_grow(ctx, 1, 0.75d0, 1.5d0), 'pmcx_set_auto_grow')
     call pmcx_die(pmcx_set_aero_data(ctx, aero_data%density, c_null_ptr, c_null_ptr), &
          'pmcx_set_aero_data')
   end subroutine pmcx_shim_init
@@ -260,8 +283,8 @@ contains
           have_ideal = .false.
        end if
     end do
-    ! list entries and offsets are 16-bit on the device: cap + cap/8 + 16 n_class n_bin <= 65535
-    ! (pmcx_max_cap; about 57 000 slots with 80 bins and one class)
+    ! list entries are 16-bit on the device: at most 65 280 slots per cell, whatever the number of
+    ! weight classes (pmcx_max_cap)
     block
       type(pmcx_config) :: probe
       call pmcx_config_default(probe)
@@ -273,6 +296,13 @@ contains
        write(0,'(a,i0,a,i0,a)') 'pmcx_shim: a cell needs ', cap_needed, ' particle slots (its particles, or the &
             &headroom times its n_part_ideal); the device holds at most ', cap_max, ' per cell (16-bit list entries)'
        call pmcx_die(1, 'pmcx_upload_states')
+    end if
+    if (have_ctx) then   ! (the block may have grown since it was made)
+       block
+         integer(c_int32_t) :: cap_now, n_grown
+         call pmcx_die(pmcx_get_growth(ctx, cap_now, n_grown), 'pmcx_get_growth')
+         cfg%cap = cap_now
+       end block
     end if
     if (.not. have_ctx .or. cfg%n_cells /= n_cells .or. cfg%cap < cap_needed &
          .or. cfg%n_spec /= n_spec .or. cfg%n_class /= n_class .or. cfg%n_source /= n_source &

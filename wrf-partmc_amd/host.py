@@ -44,6 +44,7 @@ EXPORTED_SYMBOLS = [
     "pmcx_set_transport_lateral", "pmcx_boundary_copy", "pmcx_boundary_resample",
     "pmcx_transport_preweight_begin", "pmcx_transport_preweight_finish",
     "pmcx_get_sampler_info", "pmcx_step_flags_default", "pmcx_set_loop_cells", "pmcx_max_cap", "pmcx_set_aero_scenario_modes",
+    "pmcx_grow", "pmcx_set_auto_grow", "pmcx_get_growth",
 ]
 
 
@@ -60,6 +61,11 @@ class PmcxTransFields(C.Structure):
                 ("dx", C.c_double), ("dy", C.c_double)] + \
                [(n, C.c_void_p) for n in ("alt", "xkhh", "u_flux", "v_flux", "w_flux", "z", "z_at_w",
                                           "exch_h")]
+
+
+def sort_pcap(cap, n_groups):
+    """Entries of a cell's slot lists (pmcx_get_sort): min(65535, cap + cap/8 + min(16 G, 8192))."""
+    return min(65535, cap + cap // 8 + min(16 * n_groups, 8192))
 
 
 class PmcxError(RuntimeError):
@@ -248,6 +254,9 @@ def load_library():
     L.pmcx_step_flags_default.argtypes = [C.POINTER(PmcxStepFlags)]
     L.pmcx_set_loop_cells.argtypes = [C.c_void_p, C.c_void_p]
     L.pmcx_set_aero_scenario_modes.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    L.pmcx_grow.argtypes = [C.c_void_p, C.c_int32]
+    L.pmcx_set_auto_grow.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_double]
+    L.pmcx_get_growth.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.pmcx_max_cap.restype = C.c_int32
     L.pmcx_max_cap.argtypes = [C.POINTER(PmcxConfig)]
     L.pmcx_set_sampler_variant.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
@@ -1190,6 +1199,25 @@ class CellBlock:
     def max_cap(self):
         return int(self._lib.pmcx_max_cap(C.byref(self.cfg)))
 
+    def grow(self, new_cap):
+        """More slots per cell (PartMC's aero_particle_array grows; pmcx_grow): every particle, list
+        and key keeps its place, no result depends on cap.  Returns the new cap."""
+        self._ck(self._lib.pmcx_grow(self._h, int(new_cap)))
+        return self.growth()[0]
+
+    def set_auto_grow(self, on=True, fill=0.75, factor=1.5):
+        """The library grows the block by itself (pmcx_set_auto_grow): exactly, before a transport
+        gathers arrivals that would not fit; by a margin, when the fullest cell passes fill x cap at the
+        start of pmcx_timestep / the boundary refill."""
+        self._ck(self._lib.pmcx_set_auto_grow(self._h, int(bool(on)), float(fill), float(factor)))
+
+    def growth(self):
+        """(cap, times grown); keeps this object's cfg.cap current."""
+        cap, n = C.c_int32(), C.c_int32()
+        self._ck(self._lib.pmcx_get_growth(self._h, C.byref(cap), C.byref(n)))
+        self.cfg.cap = cap.value
+        return cap.value, n.value
+
     def partmc_timestep(self, elapsed_time, dt, partmc_chem_dt, do_coagulation=True,
                         allow_doubling=True, allow_halving=True,
                         kernel_type=COAG_KERNEL_TYPE_BROWN, random_seed=0, height=None,
@@ -1279,6 +1307,7 @@ class CellBlock:
         return k
 
     def caches(self, cell):
+        self.growth()       # (the block may have grown: cfg.cap current)
         v, m = np.zeros(self.cfg.cap), np.zeros(self.cfg.cap)
         self._ck(self._lib.pmcx_get_caches(self._h, cell, _ptr(v), _ptr(m)))
         return v, m
@@ -1307,6 +1336,7 @@ class CellBlock:
 
     def get_keys(self, cell):
         """(gkey [cap], key_valid, evlog [n_log]) of one cell."""
+        self.growth()
         k = np.zeros(self.cfg.cap, dtype=np.uint16)
         v, n = C.c_int32(), C.c_int32()
         lg = np.zeros(256, dtype=np.uint32)
@@ -1315,7 +1345,8 @@ class CellBlock:
 
     def get_sort(self, cell):
         G = self.cfg.n_class * self.cfg.n_bin
-        pcap = self.cfg.cap + self.cfg.cap // 8 + 16 * G
+        self.growth()
+        pcap = sort_pcap(self.cfg.cap, G)
         perm = np.zeros(pcap, dtype=np.uint32)
         gcnt, goff = np.zeros(G, dtype=np.int32), np.zeros(G + 1, dtype=np.int32)
         self._ck(self._lib.pmcx_get_sort(self._h, cell, _ptr(perm), _ptr(gcnt), _ptr(goff)))
