@@ -79,7 +79,7 @@ def test_lists_layout_at_its_reduced_levels(wp, oracle, n_class, cap, n_part):
     blk.close()
 
 
-@pytest.mark.parametrize("n_class,n_spec,lanes", [(10, 2, 0), (40, 2, 0), (40, 1, 64), (10, 1, 16), (10, 2, 8)])
+@pytest.mark.parametrize("n_class,n_spec,lanes", [(10, 2, 0), (40, 2, 0), (40, 1, 64), (10, 1, 16), (10, 2, 16)])
 def test_mc_coag_parity_many_classes(wp, oracle, n_class, n_spec, lanes):
     """mc_coag with 10 and 40 weight classes whose weights differ by one and a half decades (weighted
     removal, the merged particle's class the one that stands for fewer), particles born into empty

@@ -99,3 +99,64 @@ def test_wrf_steps_through_the_two_drivers(tmp_path, wp, oracle, periodic):
         out = ~case.inside
         assert np.array_equal(np.array([fc["gas"] for fc in final])[out], case.gas0[out])
         assert not np.array_equal(np.array([fc["gas"] for fc in final])[case.inside], case.gas0[case.inside])
+
+
+@pytest.mark.parametrize("periodic", [True, False])
+def test_a_rank_of_a_cut_domain_through_the_two_drivers(tmp_path, wp, periodic):
+    """WRF's only production mode is its patch decomposition (namelist.input.cares_bw_full:57-58; the
+    exchanges of interface/wrf_pmc_trans_aero.F90:148-273 volumes, :381-473 weights, :543-675 movers,
+    :1261-1343 the preweight's halo).  Four processes share this GPU, each rank (a, b) of a 2 x 2
+    decomposition: it holds its patch's aero_states only, calls partmc_timestep_pmcx and
+    wrf_pmc_trans_driver_pmcx with the patch's bounds as WRF would, and reaches its neighbours through
+    the callback it gave pmcx_shim_set_neighbours (here files in a directory: the stand-in for
+    MPI_Sendrecv).  Seven WRF steps through the two drivers only -- coagulation, emissions, sea salt,
+    preweight, transport, refill of the open boundaries, deposition, rebalance -- and every particle,
+    list, weight, gas and per-step count of every rank equals the single-rank run of the same case
+    (itself held to the oracle by test_wrf_steps_through_the_two_drivers)."""
+    _build()
+    case = wrf_case.Case(nx=4, nz=3, ny=4, periodic=periodic, seed=33 if periodic else 29)
+    with wp.CellBlock(1, 64, case.n_spec, n_class=case.n_class) as blk:
+        v_edge, _ = blk.bin_tables()
+        max_events, max_appends = blk.cfg.max_events, blk.cfg.max_appends
+    from oracle import pmco_py as oracle          # (only to lay the case's particles out: Case.make_cells)
+    cells = case.make_cells(oracle, v_edge, 2048, max_events, max_appends)
+    fstate, ffields = tmp_path / "state.bin", tmp_path / "fields.bin"
+    fstate.write_bytes(case.state_bytes(cells))
+    ffields.write_bytes(case.fields_bytes())
+    wrap = "1" if periodic else "0"
+    whole = tmp_path / "whole.bin"
+    run = subprocess.run([EXE, str(fstate), str(ffields), str(whole), wrap], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    w_steps, w_final = case.parse_output(whole.read_bytes())
+    xdir = tmp_path / "xchg"
+    xdir.mkdir()
+    px = py = 2
+    procs = []
+    for b in range(py):
+        for a in range(px):
+            out = tmp_path / f"rank_{a}_{b}.bin"
+            procs.append((a, b, out, subprocess.Popen([EXE, str(fstate), str(ffields), str(out), wrap, str(px), str(py),
+                                                       str(a), str(b), str(xdir)], stdout=subprocess.PIPE,
+                                                      stderr=subprocess.PIPE, text=True)))
+    for a, b, out, pr in procs:
+        so, se = pr.communicate(timeout=900)
+        assert pr.returncode == 0, (a, b, so[-1500:], se[-3000:])
+    rx, ry, nz = case.nx // px, case.ny // py, case.nz
+    moved = 0
+    for a, b, out, pr in procs:
+        steps, final = case.parse_output(out.read_bytes(), n_cells=rx * nz * ry)
+        gcell = [((b * ry + j) * nz + k) * case.nx + a * rx + i for j in range(ry) for k in range(nz) for i in range(rx)]
+        for s in range(case.n_steps):
+            assert np.array_equal(steps[s]["n_parts"], w_steps[s]["n_parts"][gcell]), (a, b, s)
+            for key in ("temp", "pres", "rh", "height", "cell_volume", "inv_density"):
+                assert np.array_equal(steps[s][key], w_steps[s][key][gcell]), (a, b, s, key)
+        moved += sum(st["n_moved"] for st in steps)
+        for q, g in enumerate(gcell):
+            fc, wc = final[q], w_final[g]
+            assert fc["n"] == wc["n"], (a, b, q)
+            for key in ("vol", "id", "wclass", "n_orig", "ct", "mag"):
+                assert np.array_equal(fc[key], wc[key]), (a, b, q, key)
+            assert np.array_equal(fc["gas"].view(np.uint64), wc["gas"].view(np.uint64)), (a, b, q)
+            for la, lb in zip(fc["comp"], wc["comp"]):
+                assert np.array_equal(la, lb), (a, b, q)
+    assert moved == sum(st["n_moved"] for st in w_steps) > 5 * case.n_cells

@@ -124,7 +124,7 @@ def test_a_step_that_fills_cells_grows_the_block(wp, oracle):
     small = _small_twin(wp, big, 768)
     small.set_env(info["temp"], info["pres"], np.full(n_cells, 0.5))
     small.set_auto_grow(True, 0.75, 1.5)
-    ideal = np.full((n_cells, n_class), 4.0 * n_part / n_class)      # (no halving: the cells fill up)
+    ideal = np.full((n_cells, n_class), 1.9 * n_part / n_class)      # (neither doubling nor halving: the cells fill up)
     small.set_n_part_ideal(ideal)
     mag = info["mag"]
     em = [dict(gm_radius=2e-8, gsd_log10=0.2, vol_frac=[0.5, 0.5], wclass=0, source=1),

@@ -188,8 +188,9 @@ class Case:
         return buf
 
     # ---- the driver's output ------------------------------------------------------------
-    def parse_output(self, out):
-        n, off = self.n_cells, 0
+    def parse_output(self, out, n_cells=None):
+        """n_cells: the cells the dump holds (a rank of a cut domain writes its patch's only)."""
+        n, off = (self.n_cells if n_cells is None else n_cells), 0
         steps = []
         for s in range(self.n_steps):
             env = np.frombuffer(out, "<f8", 7 * n, off).reshape(7, n); off += 8 * 7 * n

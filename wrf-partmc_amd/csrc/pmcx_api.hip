@@ -12,6 +12,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -104,7 +105,7 @@ struct pmcx_ctx {
     // pmcx_set_auto_grow: the block's slots per cell grow like PartMC's aero_particle_array
     bool auto_grow = false;
     double grow_fill = 0.75, grow_factor = 1.5;
-    int32_t *d_need = nullptr;  // [2] max n_part + n_exp, max n_hi
+    int32_t *d_need = nullptr;  // [3] max n_part + n_exp, max n_hi, the status words or-ed
     int32_t n_grown = 0;        // times the block has grown
     // pmcx_timestep: the status word of the step is started once and its stages add their bits
     bool hold_status = false;
@@ -549,9 +550,12 @@ int pmcx_grow(pmcx_ctx *ctx, int32_t new_cap)
         }
         more += (int64_t)bytes - (int64_t)(j.elem * j.rows * j.old_row);
     }
-    for (Regrid &j : jobs)
+    for (Regrid &j : jobs) {
+        // (zeroed like a fresh block's arrays: with one weight class nobody ever writes wclass)
+        HIP_TRY(ctx, hipMemsetAsync(j.fresh, 0, j.elem * j.rows * j.new_row, ctx->stream));
         HIP_TRY(ctx, hipMemcpy2DAsync(j.fresh, j.elem * j.new_row, *j.slot, j.elem * j.old_row, j.elem * j.old_row,
                                       j.rows, hipMemcpyDeviceToDevice, ctx->stream));
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (Regrid &j : jobs) {
         for (void *&a : ctx->allocs) if (a == *j.slot) a = j.fresh;
@@ -572,7 +576,7 @@ int pmcx_set_auto_grow(pmcx_ctx *ctx, int32_t on, double fill, double factor)
     if (!ctx || (on && (!(fill > 0.0) || !(fill <= 1.0) || !(factor > 1.0) || !(factor <= 8.0))))
         return fail(ctx, PMCX_EINVAL, "pmcx_set_auto_grow: 0 < fill <= 1 < factor <= 8");
     if (on && !ctx->d_need) {
-        int rc = dev_alloc(ctx, &ctx->d_need, (size_t)2);
+        int rc = dev_alloc(ctx, &ctx->d_need, (size_t)4);
         if (rc) return rc;
     }
     ctx->auto_grow = on != 0;
@@ -596,7 +600,7 @@ static int grow_if_needed(pmcx_ctx *ctx, const int32_t *n_exp)
 {
     if (!ctx->auto_grow) return PMCX_OK;
     HIP_TRY(ctx, launch_need_max(ctx->st, n_exp, ctx->d_need, ctx->stream));
-    int32_t h[2] = {0, 0};
+    int32_t h[3] = {0, 0, 0};
     HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_need, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     // arrivals find room among a cell's dead slots (k_trans_room compacts): what counts is the live count
@@ -613,6 +617,28 @@ static int grow_if_needed(pmcx_ctx *ctx, const int32_t *n_exp)
     const int rc = pmcx_grow(ctx, new_cap);
     if (rc == PMCX_ENOMEM && !must) { ctx->err.clear(); return PMCX_OK; } // (growing ahead of need is optional)
     return rc;
+}
+
+// pmcx_set_auto_grow, law 1 of the transport: a source cell's outbox holds cap entries (one per mover, one
+// per destination an emitter sends copies to).  Where k_trans_decide ran out of them the decision is
+// taken back (the movers' sort keys restored), the block grown and the decision taken again: it is
+// addressed by (seed, cell, step, rank), so the second time gives the first time's movers and the rest.
+static int decide_with_room(pmcx_ctx *ctx, const std::function<hipError_t()> &begin)
+{
+    for (int round = 0;; round++) {
+        HIP_TRY(ctx, begin());
+        if (!ctx->auto_grow || ctx->st.trans_law != 1) return PMCX_OK;
+        HIP_TRY(ctx, launch_need_max(ctx->st, nullptr, ctx->d_need, ctx->stream));
+        int32_t h[3] = {0, 0, 0};
+        HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_need, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (!(h[2] & ST_OUTBOX_OVERFLOW) || ctx->cfg.cap >= 65280 || round >= 12) return PMCX_OK;
+        double want = ctx->grow_factor * (double)ctx->cfg.cap;
+        if (want > 65280.0) want = 65280.0;
+        const int rc = pmcx_grow(ctx, (int32_t)want);
+        if (rc) return rc;
+        HIP_TRY(ctx, launch_transport_undo(ctx->st, ctx->d_outbox, ctx->d_n_out, ctx->stream));
+    }
 }
 
 int pmcx_memory_bytes(pmcx_ctx *ctx, int64_t *bytes)
@@ -1576,9 +1602,12 @@ int pmcx_transport(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int32_t pe
         // before anything is written to it -- a cell that would not hold them gets its slots first
         {
             ProfScope ps(ctx, "transport");
-            HIP_TRY(ctx, launch_transport_begin(ctx->st, nx, nz, ny, periodic_x, periodic_y, d_ph, d_pv, d_cv,
-                                                ctx->d_outbox, ctx->d_n_out, ctx->d_n_arr, ctx->d_n_exp,
-                                                ctx->d_dest_mask, seed, step, ctx->stream));
+            rc = decide_with_room(ctx, [&]() {
+                return launch_transport_begin(ctx->st, nx, nz, ny, periodic_x, periodic_y, d_ph, d_pv, d_cv,
+                                              ctx->d_outbox, ctx->d_n_out, ctx->d_n_arr, ctx->d_n_exp,
+                                              ctx->d_dest_mask, seed, step, ctx->stream);
+            });
+            if (rc) return rc;
         }
         // (the cell volumes live in the staging area, which growing does not touch)
         rc = grow_if_needed(ctx, ctx->d_n_exp);
@@ -2054,9 +2083,12 @@ int pmcx_transport_begin(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, int3
     ctx->halo_nx = nx; ctx->halo_nz = nz; ctx->halo_ny = ny; ctx->halo_px = periodic_x;
     ctx->halo_total[0] = ctx->halo_total[1] = ctx->halo_total[2] = ctx->halo_total[3] = -1;
     ProfScope ps(ctx, "transport");
-    HIP_TRY(ctx, launch_transport_begin(ctx->st, nx, nz, ny, periodic_x, 0, d_ph, d_pv, d_cv,
-                                        ctx->d_outbox, ctx->d_n_out, ctx->d_n_arr, ctx->d_n_exp,
-                                        ctx->d_dest_mask, seed, step, ctx->stream));
+    rc = decide_with_room(ctx, [&]() {
+        return launch_transport_begin(ctx->st, nx, nz, ny, periodic_x, 0, d_ph, d_pv, d_cv,
+                                      ctx->d_outbox, ctx->d_n_out, ctx->d_n_arr, ctx->d_n_exp,
+                                      ctx->d_dest_mask, seed, step, ctx->stream);
+    });
+    if (rc) return rc;
     // the probabilities live in the staging area, which another call may reallocate: they
     // have been consumed once the stream is idle
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

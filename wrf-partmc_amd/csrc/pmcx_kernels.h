@@ -269,8 +269,12 @@ hipError_t launch_dry_deposition(const DeviceState &st, double dt, uint64_t seed
 hipError_t launch_condense(const DeviceState &st, const double *kappa, const double *rel_humid,
                            double del_t, int n_sub, hipStream_t s);
 hipError_t launch_totals(const DeviceState &st, int64_t *out4, hipStream_t s);
-// out2[0] = max over cells of n_part + n_exp (n_exp may be null), out2[1] = max n_hi
-hipError_t launch_need_max(const DeviceState &st, const int32_t *n_exp, int32_t *out2, hipStream_t s);
+// out3[0] = max over cells of n_part + n_exp (n_exp may be null), out3[1] = max n_hi, out3[2] = the
+// cells' status words or-ed
+hipError_t launch_need_max(const DeviceState &st, const int32_t *n_exp, int32_t *out3, hipStream_t s);
+// a k_trans_decide whose outboxes ran out (ST_OUTBOX_OVERFLOW) taken back: the movers' sort keys restored,
+// the bit cleared -- so that the decision can be taken again with more room
+hipError_t launch_transport_undo(const DeviceState &st, void *outbox, const int32_t *n_out, hipStream_t s);
 // the slots [old_cap, new_cap) of every cell of a block that has just grown: dead
 hipError_t launch_grow_tail(const DeviceState &st, int old_cap, hipStream_t s);
 hipError_t launch_test_math(int op, int64_t n, const double *a, const double *b, const double *c3,

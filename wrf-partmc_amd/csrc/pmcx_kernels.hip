@@ -2064,6 +2064,22 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                 }
                 u_acc = u53(w[2], w[3]);
                 if (n_app == 0) { // every entry sits in perm
+#if defined(PMCX_PROTO_NOPERM)
+                    // TIMING BUILD, WRONG RESULTS (scripts/gpu_proto.sh): a list position taken as the
+                    // record's own place -- what records laid out in bin order would give the sampler:
+                    // no list entry to load, one dependent round trip a sample less
+                    p1 = min((eA >> 16) + (uint32_t)i1, (uint32_t)st.cap - 1u);
+                    p2 = min((eB >> 16) + (uint32_t)i2, (uint32_t)st.cap - 1u);
+                    last1 = min((eA >> 16) + (uint32_t)nA - 1u, (uint32_t)st.cap - 1u);
+                    last2 = min((eB >> 16) + (uint32_t)nB - 1u, (uint32_t)st.cap - 1u);
+                    last1b = last1;
+#elif defined(PMCX_PROTO_NOLAST)
+                    // TIMING BUILD, WRONG RESULTS: the lists' ends not requested with the pair (what an
+                    // event that fills its hole a pass later would save)
+                    p1 = perm[(eA >> 16) + i1];
+                    p2 = perm[(eB >> 16) + i2];
+                    last1 = p1; last2 = p2; last1b = p1;
+#else
                     p1 = perm[(eA >> 16) + i1];
                     p2 = perm[(eB >> 16) + i2];
                     last1 = perm[(eA >> 16) + nA - 1];
@@ -2071,6 +2087,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                     // (what the list's end will hold once one of the pair is gone: asked for
                     // here, with the others, an event does not wait for memory half-way)
                     if (same) last1b = perm[(eA >> 16) + nA - 2];
+#endif
                 } else {
                     p1 = list_get(gA, eA, i1, n_app);
                     p2 = list_get(gB, eB, i2, n_app);
@@ -2118,6 +2135,9 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                     acc = t_u < lo;
                 }
             }
+#if defined(PMCX_PROTO_ACCEPT)
+            need64 = false;   // (TIMING BUILD: wrong picks give volumes the fp64 kernel was never meant for)
+#endif
             if (need64) {
                 EnvDerived env;
                 env.gasfreepath = envs[0 * 64 + lane]; env.inv_gfp = envs[1 * 64 + lane];
@@ -2131,6 +2151,12 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                 if (kf > k_max) status |= ST_KMAX_EXCEEDED;
                 acc = t_u < kf;
             }
+#if defined(PMCX_PROTO_ACCEPT)
+            // TIMING BUILD, WRONG RESULTS: the accept decision from the uniform alone at the benchmark's
+            // rate (0.785 of the candidates), so that builds that pick other records run the same
+            // number of events
+            acc = u_acc < 0.785;
+#endif
             s_ev = s;
             s++;
             ns_rem--;
@@ -2161,9 +2187,16 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                 const int io = big1 ? i2 : i1;
                 const int b_old = big1 ? b1 : b2, b_o = big1 ? b2 : b1;
                 const uint32_t e_o = big1 ? eB : eA;
+#if defined(PMCX_PROTO_ACCEPT)
+                // (the merged particle moves up a bin in three events of ten, whatever was picked)
+                const int b_new = min(b_old + ((__double_as_longlong(u_acc) & 1023) < 307 ? 1 : 0), B - 2);
+                const bool move = b_new != b_old;
+                const bool in_grid = true;
+#else
                 const int b_new = bin_index(edge, B, vn, st);
                 const bool move = b_new != b_old;
                 const bool in_grid = !(vn < edge[0] || vn >= edge[B]);
+#endif
                 // (the new bin and the one behind it inside the window: their entries are in LDS)
                 bool ok = n_ev < st.max_events && in_grid &&
                           (!move || ((unsigned)(b_new - blo) < (unsigned)(SW - 1) && b_new + 1 < B));
@@ -6100,22 +6133,45 @@ hipError_t launch_condense(const DeviceState &st, const double *kappa, const dou
 // pmcx_grow / pmcx_set_auto_grow: what the fullest cell holds, or is about to
 __global__ __launch_bounds__(256) void k_need_max(DeviceState st, const int32_t *n_exp, int32_t *out)
 {
-    int need = 0, hi = 0;
+    int need = 0, hi = 0, bits = 0;
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < st.n_cells; c += gridDim.x * blockDim.x) {
         const int a = st.n_part[c] + (n_exp ? n_exp[c] : 0), b = st.n_hi[c];
         need = a > need ? a : need;
         hi = b > hi ? b : hi;
+        bits |= st.status[c];
     }
     for (int d = 32; d >= 1; d >>= 1) {
         const int a = __shfl_xor(need, d, 64), b = __shfl_xor(hi, d, 64);
         need = a > need ? a : need;
         hi = b > hi ? b : hi;
+        bits |= __shfl_xor(bits, d, 64);
     }
-    if ((threadIdx.x & 63) == 0) { atomicMax(&out[0], need); atomicMax(&out[1], hi); }
+    if ((threadIdx.x & 63) == 0) { atomicMax(&out[0], need); atomicMax(&out[1], hi); atomicOr(&out[2], bits); }
+}
+__global__ __launch_bounds__(64) void k_trans_undo(DeviceState st, const int2 *outbox, const int32_t *n_out)
+{
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const int64_t cb = (int64_t)c * st.cap;
+    if (st.key_valid[c]) {
+        const int n = n_out[c];
+        for (int e = lane; e < n; e += 64) {
+            const int2 en = outbox[cb + e];
+            if (en.x < 0) continue;                       // (an emitter's entry: its particle never left)
+            const int sl = en.x & 0xFFFF;
+            const int cl = st.n_class > 1 ? st.wclass[cb + sl] : 0;
+            st.gkey[cb + sl] = key_of(st, st.hot[cb + sl].vtot, cl);
+        }
+    }
+    if (lane == 0) atomicAnd(&st.status[c], ~(int)ST_OUTBOX_OVERFLOW);
+}
+hipError_t launch_transport_undo(const DeviceState &st, void *outbox, const int32_t *n_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_trans_undo, dim3(st.n_cells), dim3(64), 0, s, st, (const int2 *)outbox, n_out);
+    return hipGetLastError();
 }
 hipError_t launch_need_max(const DeviceState &st, const int32_t *n_exp, int32_t *out2, hipStream_t s)
 {
-    (void)hipMemsetAsync(out2, 0, 2 * sizeof(int32_t), s);
+    (void)hipMemsetAsync(out2, 0, 3 * sizeof(int32_t), s);
     int g = (st.n_cells + 255) / 256;
     if (g > 1024) g = 1024;
     hipLaunchKernelGGL(k_need_max, dim3(g), dim3(256), 0, s, st, n_exp, out2);

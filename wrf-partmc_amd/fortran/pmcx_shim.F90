@@ -51,6 +51,7 @@ module pmcx_shim
   public :: partmc_timestep_pmcx, wrf_pmc_trans_driver_pmcx, partmc_sync_host_pmcx, &
        partmc_process_pmcx, pmcx_shim_is_resident
   public :: pmcx_shim_set_components, pmcx_shim_set_headroom, pmcx_shim_set_auto_grow, pmcx_shim_growth
+  public :: pmcx_shim_set_neighbours, pmcx_shift_t
   public :: pmcx_shim_init, pmcx_shim_finalize, pmcx_set_rng, mc_coag_pmcx, &
        partmc_coag_cells_pmcx, aero_state_rebalance_cells_pmcx, aero_state_rebalance_pmcx, &
        pmcx_config
@@ -74,6 +75,32 @@ module pmcx_shim
   integer, save :: want_comp_max = 8           ! entries of component(:) carried per particle
   real(kind=dp), save :: headroom = 3.0d0      ! particle slots of a cell / its ideal count (pmcx_shim_set_headroom)
   logical, save :: auto_grow = .true.          ! the block grows when a cell runs short of slots (pmcx_shim_set_auto_grow)
+
+  ! ---- a rank of WRF's patch decomposition (pmcx_shim_set_neighbours) ----
+  !> How a rank reaches its neighbours: WRF supplies MPI_Sendrecv, a test a stand-in.  Send the n_send
+  !> bytes at `send` to the neighbour on side dir (0 south, 1 north, 2 west, 3 east) and receive n_recv
+  !> bytes into `recv` from the neighbour on the OPPOSITE side -- what it sent in the same direction
+  !> (one shift of a halo exchange: MPI_Sendrecv(send, ..., dest = neighbour(dir), recv, ..., source =
+  !> neighbour(opposite))).  n_send = 0 / n_recv = 0: no neighbour there, nothing travels.  Host memory.
+  abstract interface
+     subroutine pmcx_shift_t(dir, send, n_send, recv, n_recv)
+       import :: c_ptr, c_int64_t
+       integer, intent(in) :: dir
+       type(c_ptr), value :: send, recv
+       integer(c_int64_t), value :: n_send, n_recv
+     end subroutine pmcx_shift_t
+  end interface
+  procedure(pmcx_shift_t), pointer, save :: shift_proc => null()
+  logical, save :: has_nbr(0:3) = .false.      ! a neighbouring rank on side 0 south, 1 north, 2 west, 3 east
+  logical, save :: in_padded = .false.         ! the drivers are running on the patch + its ghost ring
+  integer, save :: real_is = 0, real_ie = 0, real_js = 0, real_je = 0   ! the patch inside the padded block
+  integer, save :: pad_gnx = 0, pad_gny = 0    ! the domain's columns and rows (ids of a cell's particles)
+  integer, save :: pad_nxb = 0, pad_nz = 0, pad_nyb = 0, pad_is0 = 0, pad_js0 = 0   ! the padded block: its shape, the
+                                               ! (1-based, global) column and row of its first cell
+  type(env_state_t), allocatable, save :: p_env(:,:,:)
+  type(scenario_t), allocatable, save :: p_scn(:,:,:)
+  type(aero_state_t), allocatable, save :: p_aero(:,:,:)
+  type(gas_state_t), allocatable, save :: p_gas(:,:,:)
   ! per-step staging arrays in page-locked memory (pmcx_host_alloc): an upload from them is one
   ! DMA that overlaps the device's work; they grow as needed and live until pmcx_shim_finalize
   integer, parameter :: N_PIN = 24
@@ -163,6 +190,97 @@ contains
     logical, intent(in) :: on
     auto_grow = on
   end subroutine pmcx_shim_set_auto_grow
+
+  !> This rank holds a patch of a domain cut across ranks (WRF's decomposition in x and y,
+  !> WRFV3/test/em_real/namelist.input.cares_bw_full:57-58; the exchanges of interface/
+  !> wrf_pmc_trans_aero.F90:148-273, 381-473, 543-675, 1261-1343): `shift` moves bytes between
+  !> neighbouring ranks, has_* say on which sides a neighbour exists (across a periodic edge of the
+  !> domain counts; the domain's open edge does not).  From then on partmc_timestep_pmcx and
+  !> wrf_pmc_trans_driver_pmcx -- called with the patch's bounds, as the reference's drivers are --
+  !> keep a resident block of the patch plus one ghost row and column on every side, and the transport
+  !> driver exchanges the preweight's terms, the boundary strips' weights and the movers with the four
+  !> neighbours: the result on the patch is the whole domain's, bit for bit.  Call before the first step.
+  subroutine pmcx_shim_set_neighbours(shift, has_south, has_north, has_west, has_east)
+    procedure(pmcx_shift_t) :: shift
+    logical, intent(in) :: has_south, has_north, has_west, has_east
+    shift_proc => shift
+    has_nbr = [has_south, has_north, has_west, has_east]
+  end subroutine pmcx_shim_set_neighbours
+
+  !> v modulo 2**32 as the 32-bit pattern C reads as uint32_t
+  integer(c_int32_t) function u32(v)
+    integer(kind=8), intent(in) :: v
+    integer(kind=8) :: w
+    w = modulo(v, 4294967296_8)
+    if (w >= 2147483648_8) w = w - 4294967296_8
+    u32 = int(w, c_int32_t)
+  end function u32
+
+  !> The padded arrays of a rank of a cut domain: the patch plus one ghost row and column on every side.
+  !> A ghost cell holds no particles; its weights, ideal counts, scenario and gases are copies of the
+  !> nearest cell of the patch (weights: until the exchange brings its owner's), its meteorology comes
+  !> from grid%'s halo like any cell's.  Built on the first call; later calls keep p_env (the old
+  !> heights) and only note the patch's bounds.
+  subroutine pad_states(grid, scenario, env_states, aero_states, gas_states, is, ie, js, je, ks, ke, gnx, gny)
+    type(domain), intent(in) :: grid
+    integer, intent(in) :: is, ie, js, je, ks, ke, gnx, gny
+    type(scenario_t), intent(in) :: scenario(is:ie, ks:ke, js:je)
+    type(env_state_t), intent(in) :: env_states(is:ie, ks:ke, js:je)
+    type(aero_state_t), intent(in) :: aero_states(is:ie, ks:ke, js:je)
+    type(gas_state_t), intent(in) :: gas_states(is:ie, ks:ke, js:je)
+    integer :: i, j, k, i0, j0
+    real_is = is; real_ie = ie; real_js = js; real_je = je
+    pad_gnx = gnx; pad_gny = gny
+    pad_nxb = ie - is + 3; pad_nz = ke - ks + 1; pad_nyb = je - js + 3; pad_is0 = is - 1; pad_js0 = js - 1
+    if (allocated(p_env)) return
+    allocate(p_env(is-1:ie+1, ks:ke, js-1:je+1), p_scn(is-1:ie+1, ks:ke, js-1:je+1), &
+         p_aero(is-1:ie+1, ks:ke, js-1:je+1), p_gas(is-1:ie+1, ks:ke, js-1:je+1))
+    do j = js - 1, je + 1
+    do k = ks, ke
+    do i = is - 1, ie + 1
+       i0 = min(max(i, is), ie); j0 = min(max(j, js), je)
+       p_env(i,k,j) = env_states(i0,k,j0)
+       p_scn(i,k,j) = scenario(i0,k,j0)
+       p_gas(i,k,j) = gas_states(i0,k,j0)
+       if (i == i0 .and. j == j0) then
+          p_aero(i,k,j) = aero_states(i,k,j)
+       else
+          p_aero(i,k,j)%awa = aero_states(i0,k,j0)%awa
+          if (allocated(aero_states(i0,k,j0)%n_part_ideal)) p_aero(i,k,j)%n_part_ideal = aero_states(i0,k,j0)%n_part_ideal
+          p_aero(i,k,j)%apa%n_part = 0
+          allocate(p_aero(i,k,j)%apa%particle(0))
+       end if
+    end do
+    end do
+    end do
+  end subroutine pad_states
+
+  !> The block of 2**32 ids a cell's new particles come from: its number within the rank's block or --
+  !> a rank of a cut domain -- within the whole domain, so that ids do not depend on the decomposition.
+  integer function id_block_of(c)
+    integer, intent(in) :: c
+    integer :: i, k, j, gi, gj
+    if (.not. in_padded) then
+       id_block_of = c - 1
+       return
+    end if
+    i = mod(c - 1, pad_nxb); k = mod((c - 1) / pad_nxb, pad_nz); j = (c - 1) / (pad_nxb * pad_nz)
+    gi = modulo(pad_is0 + i - 1, pad_gnx); gj = modulo(pad_js0 + j - 1, pad_gny)
+    id_block_of = (gj * pad_nz + k) * pad_gnx + gi
+  end function id_block_of
+
+  !> what every side sends goes to its neighbour; recv(s) takes what the neighbour on side s sent
+  !> towards this rank (n_recv(s) bytes, known to both)
+  subroutine swap4(send, n_send, recv, n_recv)
+    type(c_ptr), intent(in) :: send(0:3), recv(0:3)
+    integer(c_int64_t), intent(in) :: n_send(0:3), n_recv(0:3)
+    integer :: dir, opp
+    do dir = 0, 3
+       opp = ieor(dir, 1)
+       call shift_proc(dir, send(dir), merge(n_send(dir), 0_c_int64_t, has_nbr(dir)), &
+            recv(opp), merge(n_recv(opp), 0_c_int64_t, has_nbr(opp)))
+    end do
+  end subroutine swap4
 
   !> Slots per cell now, and how many times the block has grown since it was made.
   subroutine pmcx_shim_growth(cap, n_grown)
@@ -362,10 +480,10 @@ contains
       allocate(nid(n_cells))
       id_block_base = next_id
       do c = 1, n_cells
-         nid(c) = next_id + int(c - 1, 8) * ID_BLOCK
+         nid(c) = next_id + int(id_block_of(c), 8) * ID_BLOCK
       end do
       call pmcx_die(pmcx_set_next_id(ctx, nid), 'pmcx_set_next_id')
-      next_id = next_id + int(n_cells, 8) * ID_BLOCK
+      next_id = next_id + int(merge(pad_gnx * pad_gny * pad_nz, n_cells, in_padded), 8) * ID_BLOCK
     end block
     call pmcx_die(pmcx_upload_cells(ctx, 0, n_cells, part_offset, vol, wclass, id, lct, gct, &
          p_norig), 'pmcx_upload_cells')
@@ -473,7 +591,7 @@ contains
       allocate(nid(n_cells))
       call pmcx_die(pmcx_get_next_id(ctx, nid), 'pmcx_get_next_id')
       do c = 1, n_cells
-         if (nid(c) > id_block_base + int(c, 8) * ID_BLOCK) &
+         if (nid(c) > id_block_base + int(id_block_of(c) + 1, 8) * ID_BLOCK) &
               call pmcx_die(5, 'pmcx_download_states (a cell created more than 2**32 particle ids)')
       end do
     end block
@@ -900,6 +1018,9 @@ contains
     integer(c_int32_t), intent(out) :: inside(nx, nz, ny)
     integer :: i, j, gi, gj
     inside = 1
+    if (in_padded) then       ! the ghost ring of a rank's block: not this rank's cells
+       inside(1,:,:) = 0; inside(nx,:,:) = 0; inside(:,:,1) = 0; inside(:,:,ny) = 0
+    end if
     if (config_flags%periodic_x .and. config_flags%periodic_y) return
     do j = 1, ny
        do i = 1, nx
@@ -1113,7 +1234,7 @@ contains
   !> chemistry steps, scenario_update_gas_state, scenario_update_aero_state, seasalt_emissions,
   !> aero_state_rebalance, over the cells of the reference's loop nest.  MOSAIC (driver:232-245) is
   !> not part of the library: grid%do_mosaic must be off.
-  subroutine partmc_timestep_pmcx(grid, config_flags, scenario, env_states, &
+  recursive subroutine partmc_timestep_pmcx(grid, config_flags, scenario, env_states, &
        aero_data, aero_states, gas_data, gas_states, pmc_is, pmc_ie, pmc_js, &
        pmc_je, pmc_ks, pmc_ke, global_nx, global_ny, global_nz)
     integer, intent(in) :: pmc_is, pmc_ie, pmc_js, pmc_je, pmc_ks, pmc_ke
@@ -1138,6 +1259,17 @@ contains
     logical :: changed
     integer :: m
 
+    ! a rank of a cut domain (pmcx_shim_set_neighbours): the same routine on the patch plus its ghost ring
+    if (associated(shift_proc) .and. .not. in_padded) then
+       call pad_states(grid, scenario, env_states, aero_states, gas_states, pmc_is, pmc_ie, pmc_js, pmc_je, &
+            pmc_ks, pmc_ke, global_nx, global_ny)
+       in_padded = .true.
+       call partmc_timestep_pmcx(grid, config_flags, p_scn, p_env, aero_data, p_aero, gas_data, p_gas, &
+            pmc_is - 1, pmc_ie + 1, pmc_js - 1, pmc_je + 1, pmc_ks, pmc_ke, global_nx, global_ny, global_nz)
+       in_padded = .false.
+       env_states = p_env(pmc_is:pmc_ie, pmc_ks:pmc_ke, pmc_js:pmc_je)
+       return
+    end if
     if (grid%do_mosaic) then
        write(0,'(a)') 'partmc_timestep_pmcx: grid%do_mosaic is on; MOSAIC is not part of libpmcx &
             &(run it on host states between partmc_sync_host_pmcx and a new upload, or switch it off)'
@@ -1173,6 +1305,13 @@ contains
             int(headroom * grid%num_particles))
        resident = .true.
        res_nx = nx; res_nz = nz; res_ny = ny
+       if (in_padded) then
+          ! the block's place in the domain: a row of it is shorter than a row of the domain, so the
+          ! global id of a cell -- the key of every random draw -- is formed from both
+          call pmcx_die(pmcx_set_cell_id_base(ctx, u32(int((pmc_js - 1) * nz, 8) * global_nx + (pmc_is - 1))), &
+               'pmcx_set_cell_id_base')
+          call pmcx_die(pmcx_set_transport_cuts(ctx, 1, nx, pmc_is - 1, global_nx), 'pmcx_set_transport_cuts')
+       end if
     else if (nx /= res_nx .or. nz /= res_nz .or. ny /= res_ny) then
        call pmcx_die(4, 'partmc_timestep_pmcx (the resident block has another shape)')
     end if
@@ -1333,7 +1472,7 @@ contains
   !> compute_diffusion_probs, compute_vertical_probs, normalize_probs), then trans_aero:
   !> trans_aero_preweight, the sampling, the rebalance of the interior cells, the refill of the
   !> lateral boundary cells (wrf_pmc_trans_aero.F90:40-971); then dry deposition on the lowest level.
-  subroutine wrf_pmc_trans_driver_pmcx(grid, config_flags, env_states, scenario, &
+  recursive subroutine wrf_pmc_trans_driver_pmcx(grid, config_flags, env_states, scenario, &
        aero_data, aero_states, gas_states, pmc_is, pmc_ie, pmc_js, pmc_je, &
        pmc_ks, pmc_ke, global_nx, global_ny, global_nz)
     integer, intent(in) :: pmc_is, pmc_ie, pmc_js, pmc_je, pmc_ks, pmc_ke
@@ -1359,8 +1498,22 @@ contains
     integer(c_int32_t), allocatable, target :: from_c(:), to_c(:), res_c(:), &
          thr(:), cls(:,:), src(:,:), n_add(:), n_rm(:), st(:), ns(:), nc(:)
     type(pmcx_aero_dist_t) :: bgd
+    integer :: r_is, r_ie, r_js, r_je       ! this rank's cells (the patch inside a padded block)
 
     if (.not. resident) call pmcx_die(4, 'wrf_pmc_trans_driver_pmcx (partmc_timestep_pmcx comes first: nothing is resident)')
+    ! a rank of a cut domain (pmcx_shim_set_neighbours): the same routine on the patch plus its ghost ring
+    if (associated(shift_proc) .and. .not. in_padded) then
+       in_padded = .true.
+       call wrf_pmc_trans_driver_pmcx(grid, config_flags, p_env, p_scn, aero_data, p_aero, p_gas, &
+            pmc_is - 1, pmc_ie + 1, pmc_js - 1, pmc_je + 1, pmc_ks, pmc_ke, global_nx, global_ny, global_nz)
+       in_padded = .false.
+       env_states = p_env(pmc_is:pmc_ie, pmc_ks:pmc_ke, pmc_js:pmc_je)
+       return
+    end if
+    r_is = pmc_is; r_ie = pmc_ie; r_js = pmc_js; r_je = pmc_je
+    if (in_padded) then
+       r_is = real_is; r_ie = real_ie; r_js = real_js; r_je = real_je
+    end if
     nx = pmc_ie - pmc_is + 1; nz = pmc_ke - pmc_ks + 1; ny = pmc_je - pmc_js + 1
     n_cells = nx * nz * ny
     n_class = cfg%n_class
@@ -1400,7 +1553,7 @@ contains
        ! (the stage calls below only enqueue, pmcx_set_async: what they report -- normalize_probs'
        ! assertions, the movers, cells out of slots, the deposited -- is looked at once, behind the
        ! pmcx_synchronize at the end of this routine)
-       call pmcx_die(pmcx_set_async(ctx, 1), 'pmcx_set_async')
+       if (.not. in_padded) call pmcx_die(pmcx_set_async(ctx, 1), 'pmcx_set_async')   ! (a cut domain's calls wait for their exchanges)
        call c_f_pointer(pinned(9, 4_c_int64_t * n_cells), bad, [n_cells])
        call pmcx_die(pmcx_transport_probs(ctx, f, c_null_ptr, c_null_ptr, c_null_ptr, c_loc(bad), &
             c_null_ptr), 'pmcx_transport_probs')
@@ -1422,6 +1575,11 @@ contains
        ! trans_aero (wrf_pmc_trans_aero.F90:40-971); the sampling is the context's default law, the one
        ! that has the reference's variance where weights differ (movers arrive once, emitters send
        ! the other copies: pmcx_set_transport_law, :2236-2300), for any number of weight classes
+       if (in_padded) then
+          call pmcx_die(pmcx_set_transport_lateral(ctx, merge(0, 1, ideal), pmc_js - 1, global_ny), &
+               'pmcx_set_transport_lateral')
+          call transport_cut()                      ! trans_aero:148-273, 294, 381-473, 519-801, 1261-1343
+       else
        call pmcx_die(pmcx_set_transport_lateral(ctx, merge(0, 1, ideal), 0, 0), 'pmcx_set_transport_lateral')
        call pmcx_die(pmcx_transport_preweight(ctx, nx, nz, ny, merge(1, 0, ideal), merge(1, 0, ideal), &
             c_null_ptr, c_null_ptr, cell_volume, int(grid%random_seed, c_int64_t), step, expected, n_rem), &
@@ -1429,6 +1587,7 @@ contains
        call pmcx_die(pmcx_transport(ctx, nx, nz, ny, merge(1, 0, ideal), merge(1, 0, ideal), c_null_ptr, &
             c_null_ptr, cell_volume, int(grid%random_seed, c_int64_t), step, n_moved, n_arrived), &
             'pmcx_transport')                                                     ! trans_aero:519-801
+       end if
        ! aero_state_rebalance + aero_state_sort of the interior cells (trans_aero:798-801): its draws
        ! are keyed apart from those of partmc_timestep's rebalance in the same WRF step
        call pmcx_die(pmcx_rebalance(ctx, merge(1, 0, grid%allow_doubling), merge(1, 0, grid%allow_halving), &
@@ -1443,10 +1602,12 @@ contains
           ! where the wind has turned or the background has moved to its next time level)
           allocate(from_c(n_cells), to_c(n_cells), res_c(n_cells), thr(n_cells))
           n_copy = 0; n_res = 0
-          if (pmc_is == 1) call side(1, 0, 1, 0, .true.)                          ! west,  u_2(i,k,j) < 0: outflow
-          if (pmc_ie == global_nx) call side(global_nx, 0, -1, 0, .false.)        ! east,  u_2(i+1,k,j) > 0
-          if (pmc_js == 1) call side(0, 1, 0, 1, .true.)                          ! south, v_2(i,k,j) < 0
-          if (pmc_je == global_ny) call side(0, global_ny, 0, -1, .false.)        ! north, v_2(i,k,j+1) > 0
+          ! (a rank of a cut domain sees to the boundary cells it holds; a patch on a lateral boundary is
+          ! at least two cells wide, as WRF's are: a boundary cell's inner neighbour is this rank's too)
+          if (r_is == 1) call side(1, 0, 1, 0, .true.)                            ! west,  u_2(i,k,j) < 0: outflow
+          if (r_ie == global_nx) call side(global_nx, 0, -1, 0, .false.)          ! east,  u_2(i+1,k,j) > 0
+          if (r_js == 1) call side(0, 1, 0, 1, .true.)                            ! south, v_2(i,k,j) < 0
+          if (r_je == global_ny) call side(0, global_ny, 0, -1, .false.)          ! north, v_2(i,k,j+1) > 0
           if (n_copy > 0) call pmcx_die(pmcx_boundary_copy(ctx, n_copy, from_c, to_c), 'pmcx_boundary_copy')
           if (n_res > 0) then
              nm = 0
@@ -1495,8 +1656,8 @@ contains
        call c_f_pointer(pinned(23, 4_c_int64_t * n_cells), unreal, [n_cells])
        surface = 0; ra = 1d0; ust = 1d0; alpha_c = 1d0; biga_c = 1d0; height = 1d0; rrho = 1d0
        zr = 2.0
-       do j = max(pmc_js, 2), min(pmc_je, global_ny - 1)
-          do i = max(pmc_is, 2), min(pmc_ie, global_nx - 1)
+       do j = max(r_js, 2), min(r_je, global_ny - 1)
+          do i = max(r_is, 2), min(r_ie, global_nx - 1)
              c = ((j - pmc_js) * nz + 0) * nx + (i - pmc_is) + 1
              surface(c) = 1
              ust(c) = real(grid%ust(i,j), dp)
@@ -1516,6 +1677,7 @@ contains
     call pmcx_die(pmcx_set_async(ctx, 0), 'pmcx_set_async')
     if (grid%do_transport) then
        ! normalize_probs' assertions (wrf_pmc_trans.F90:713,746,759,771)
+       if (in_padded) call clear_ghost_flags(bad)      ! (a ghost cell's fields are its owner's business)
        if (any(bad /= 0)) call pmcx_die(5, 'wrf_pmc_trans_driver_pmcx (normalize_probs: a probability is negative, above one, or their sum is)')
        last_n_moved = sum(int(n_moved, 8))
        ! (open boundaries: the transport's word was looked at before the refill started a new one;
@@ -1534,6 +1696,119 @@ contains
     end if
 
   contains
+
+    !> flags of the block's ghost ring cleared
+    subroutine clear_ghost_flags(flag)
+      integer(c_int32_t), intent(inout) :: flag(nx, nz, ny)
+      flag(1,:,:) = 0; flag(nx,:,:) = 0; flag(:,:,1) = 0; flag(:,:,ny) = 0
+    end subroutine clear_ghost_flags
+
+    !> trans_aero for a rank of a cut domain: the block is the patch plus a ghost ring, and what crosses a
+    !> cut travels through shift_proc -- the preweight's ready terms of the four boundary strips
+    !> (wrf_pmc_trans_aero.F90:1261-1343), the strips' scaled weights for the neighbours' ghost strips
+    !> (:381-473), the movers (:543-675).  Sides: 0 south, 1 north, 2 west, 3 east.
+    subroutine transport_cut()
+      integer, parameter :: i8 = c_int64_t
+      real(c_double), allocatable, target :: edge(:), got_rows(:,:), got_cols(:,:), mag(:), strip(:,:), gst(:,:)
+      integer(c_int64_t) :: nb_s(0:3), nb_r(0:3), sz_s(0:3), sz_r(0:3)
+      integer(c_int64_t), target :: n_out(0:3), n_in(0:3)
+      type(c_ptr) :: ps(0:3), pr(0:3), dbuf
+      integer(c_int8_t), allocatable, target :: hs0(:), hs1(:), hs2(:), hs3(:), hr0(:), hr1(:), hr2(:), hr3(:)
+      integer :: sd, row_n, col_n, ii, jj, kk2, q2
+      integer(c_int64_t) :: seed64
+      seed64 = int(grid%random_seed, c_int64_t)
+      row_n = nx * nz * n_class; col_n = ny * nz * n_class
+      ! ---- preweight: the ready terms of the boundary strips, rows first then columns
+      allocate(edge(2 * row_n + 2 * col_n), got_rows(row_n, 0:1), got_cols(col_n, 0:1))
+      call pmcx_die(pmcx_transport_preweight_begin(ctx, nx, nz, ny, merge(1, 0, ideal), merge(1, 0, ideal), &
+           pmc_js - 1, global_ny, c_null_ptr, c_null_ptr, cell_volume, edge), 'pmcx_transport_preweight_begin')
+      ps = [c_loc(edge(1)), c_loc(edge(row_n + 1)), c_loc(edge(2 * row_n + 1)), c_loc(edge(2 * row_n + col_n + 1))]
+      pr = [c_loc(got_rows(1, 0)), c_loc(got_rows(1, 1)), c_loc(got_cols(1, 0)), c_loc(got_cols(1, 1))]
+      nb_s = [int(row_n, i8), int(row_n, i8), int(col_n, i8), int(col_n, i8)] * 8_i8
+      call swap4(ps, nb_s, pr, nb_s)
+      call pmcx_die(pmcx_transport_preweight_x_terms(ctx, merge(pr(2), c_null_ptr, has_nbr(2)), &
+           merge(pr(3), c_null_ptr, has_nbr(3)), merge(1, 0, has_nbr(2) .and. r_is == 1), &
+           merge(1, 0, has_nbr(3) .and. r_ie == global_nx)), 'pmcx_transport_preweight_x_terms')
+      call pmcx_die(pmcx_transport_preweight_finish(ctx, merge(pr(0), c_null_ptr, has_nbr(0)), &
+           merge(pr(1), c_null_ptr, has_nbr(1)), merge(1, 0, has_nbr(0) .and. r_js == 1), &
+           merge(1, 0, has_nbr(1) .and. r_je == global_ny), seed64, step, expected, n_rem), &
+           'pmcx_transport_preweight_finish')                                     ! trans_aero:294
+      ! ---- the ghost strips stand for the neighbours' boundary strips: their weights follow the scaling there
+      allocate(mag(n_class * n_cells), strip(max(row_n, col_n), 0:3), gst(max(row_n, col_n), 0:3))
+      call pmcx_die(pmcx_get_weights(ctx, mag), 'pmcx_get_weights')
+      do sd = 0, 3
+         q2 = 0
+         do jj = 1, ny
+         do kk2 = 1, nz
+         do ii = 1, nx
+            if ((sd == 0 .and. jj == 2) .or. (sd == 1 .and. jj == ny - 1) .or. &
+                 (sd == 2 .and. ii == 2) .or. (sd == 3 .and. ii == nx - 1)) then
+               c = ((jj - 1) * nz + (kk2 - 1)) * nx + ii
+               strip(q2 + 1 : q2 + n_class, sd) = mag((c - 1) * n_class + 1 : c * n_class)
+               q2 = q2 + n_class
+            end if
+         end do
+         end do
+         end do
+      end do
+      ps = [c_loc(strip(1, 0)), c_loc(strip(1, 1)), c_loc(strip(1, 2)), c_loc(strip(1, 3))]
+      pr = [c_loc(gst(1, 0)), c_loc(gst(1, 1)), c_loc(gst(1, 2)), c_loc(gst(1, 3))]
+      call swap4(ps, nb_s, pr, nb_s)
+      do sd = 0, 3
+         if (.not. has_nbr(sd)) cycle
+         q2 = 0
+         do jj = 1, ny
+         do kk2 = 1, nz
+         do ii = 1, nx
+            if ((sd == 0 .and. jj == 1) .or. (sd == 1 .and. jj == ny) .or. &
+                 (sd == 2 .and. ii == 1) .or. (sd == 3 .and. ii == nx)) then
+               c = ((jj - 1) * nz + (kk2 - 1)) * nx + ii
+               mag((c - 1) * n_class + 1 : c * n_class) = gst(q2 + 1 : q2 + n_class, sd)
+               q2 = q2 + n_class
+            end if
+         end do
+         end do
+         end do
+      end do
+      call pmcx_die(pmcx_set_weights(ctx, mag), 'pmcx_set_weights')
+      ! ---- the sampling: every cell draws its movers, the boundary strips' leave through the four sides
+      call pmcx_die(pmcx_transport_begin(ctx, nx, nz, ny, 0, c_null_ptr, c_null_ptr, cell_volume, seed64, step), &
+           'pmcx_transport_begin')                                                ! trans_aero:519-675
+      do sd = 0, 3
+         call pmcx_die(pmcx_transport_export_size(ctx, sd, n_out(sd)), 'pmcx_transport_export_size')
+      end do
+      allocate(hs0(max(n_out(0), 1_i8)), hs1(max(n_out(1), 1_i8)), hs2(max(n_out(2), 1_i8)), hs3(max(n_out(3), 1_i8)))
+      ps = [c_loc(hs0), c_loc(hs1), c_loc(hs2), c_loc(hs3)]
+      do sd = 0, 3
+         if (n_out(sd) == 0 .or. .not. has_nbr(sd)) cycle
+         call pmcx_die(pmcx_device_alloc(ctx, n_out(sd), dbuf), 'pmcx_device_alloc')
+         call pmcx_die(pmcx_transport_export(ctx, sd, dbuf), 'pmcx_transport_export')
+         call pmcx_die(pmcx_device_copy(ctx, ps(sd), dbuf, n_out(sd), 2), 'pmcx_device_copy')
+         call pmcx_die(pmcx_device_free(ctx, dbuf), 'pmcx_device_free')
+      end do
+      ! the sizes first, then the records
+      n_in = 0
+      sz_s = 8_i8
+      call swap4([c_loc(n_out(0)), c_loc(n_out(1)), c_loc(n_out(2)), c_loc(n_out(3))], sz_s, &
+           [c_loc(n_in(0)), c_loc(n_in(1)), c_loc(n_in(2)), c_loc(n_in(3))], sz_s)
+      allocate(hr0(max(n_in(0), 1_i8)), hr1(max(n_in(1), 1_i8)), hr2(max(n_in(2), 1_i8)), hr3(max(n_in(3), 1_i8)))
+      pr = [c_loc(hr0), c_loc(hr1), c_loc(hr2), c_loc(hr3)]
+      nb_r = n_in
+      where (.not. has_nbr) nb_r = 0
+      call swap4(ps, n_out, pr, nb_r)
+      do sd = 0, 3
+         if (.not. has_nbr(sd) .or. nb_r(sd) == 0) then
+            call pmcx_die(pmcx_transport_import(ctx, sd, c_null_ptr, 0_i8), 'pmcx_transport_import')
+         else
+            call pmcx_die(pmcx_device_alloc(ctx, nb_r(sd), dbuf), 'pmcx_device_alloc')
+            call pmcx_die(pmcx_device_copy(ctx, dbuf, pr(sd), nb_r(sd), 1), 'pmcx_device_copy')
+            call pmcx_die(pmcx_transport_import(ctx, sd, dbuf, nb_r(sd)), 'pmcx_transport_import')
+            call pmcx_die(pmcx_device_free(ctx, dbuf), 'pmcx_device_free')
+         end if
+      end do
+      call pmcx_die(pmcx_transport_finish(ctx, n_moved, n_arrived), 'pmcx_transport_finish')   ! trans_aero:677-801
+      call clear_ghost_flags(n_moved)
+    end subroutine transport_cut
 
     !> the cells' status after the transport: no cell may have run out of slots
     subroutine check_transport_status(where)
@@ -1569,11 +1844,11 @@ contains
       logical :: change_bc, outflow, turned
       real :: v2, v1
       if (i_b > 0) then
-         a = max(pmc_js, 2); b = min(pmc_je, global_ny - 1)
-         i0 = i_b; j0 = pmc_js
+         a = max(r_js, 2); b = min(r_je, global_ny - 1)
+         i0 = i_b; j0 = r_js
       else
-         a = max(pmc_is, 2); b = min(pmc_ie, global_nx - 1)
-         i0 = pmc_is; j0 = j_b
+         a = max(r_is, 2); b = min(r_ie, global_nx - 1)
+         i0 = r_is; j0 = j_b
       end if
       ! the background moves to its next time level in this step (decided at the side's first cell,
       ! as the reference does: trans_aero:811-822)
@@ -1638,13 +1913,28 @@ contains
 
   !> Brings the host's aero_states / gas_states up to date with the resident block (what
   !> partmc_before_solve_io needs at output and restart times, wrf_pmc_driver.F90:300-386).
-  subroutine partmc_sync_host_pmcx(aero_states, gas_states, pmc_is, pmc_ie, pmc_js, pmc_je, pmc_ks, pmc_ke)
+  recursive subroutine partmc_sync_host_pmcx(aero_states, gas_states, pmc_is, pmc_ie, pmc_js, pmc_je, pmc_ks, pmc_ke)
     integer, intent(in) :: pmc_is, pmc_ie, pmc_js, pmc_je, pmc_ks, pmc_ke
     type(aero_state_t), dimension(pmc_is:pmc_ie,pmc_ks:pmc_ke,pmc_js:pmc_je), intent(inout) :: aero_states
     type(gas_state_t), dimension(pmc_is:pmc_ie,pmc_ks:pmc_ke,pmc_js:pmc_je), intent(inout) :: gas_states
     integer :: n_cells, n_gas, c, i, j, k
     real(c_double), allocatable :: mix(:,:)
     if (.not. resident) return
+    ! a rank of a cut domain: the block is the patch plus its ghost ring (which holds nothing between steps)
+    if (associated(shift_proc) .and. .not. in_padded) then
+       in_padded = .true.
+       call partmc_sync_host_pmcx(p_aero, p_gas, pmc_is - 1, pmc_ie + 1, pmc_js - 1, pmc_je + 1, pmc_ks, pmc_ke)
+       in_padded = .false.
+       do j = pmc_js, pmc_je
+       do k = pmc_ks, pmc_ke
+       do i = pmc_is, pmc_ie
+          aero_states(i,k,j) = p_aero(i,k,j)
+          gas_states(i,k,j) = p_gas(i,k,j)
+       end do
+       end do
+       end do
+       return
+    end if
     n_cells = (pmc_ie - pmc_is + 1) * (pmc_ke - pmc_ks + 1) * (pmc_je - pmc_js + 1)
     if (n_cells /= cfg%n_cells) call pmcx_die(1, 'partmc_sync_host_pmcx (array shape /= resident block)')
     call download_states_n(n_cells, aero_states)
@@ -1674,6 +1964,37 @@ contains
     integer(c_int32_t), intent(out), target, optional :: n_parts(:)
     type(c_ptr) :: p1, p2, p3, p4
     if (.not. have_ctx) call pmcx_die(4, 'partmc_process_pmcx (no resident block)')
+    ! a rank of a cut domain: arrays over the patch's cells are filled from the block's (patch + ghost ring)
+    if (associated(shift_proc) .and. size(tot_num_conc) /= cfg%n_cells .and. &
+         size(tot_num_conc) == (real_ie - real_is + 1) * pad_nz * (real_je - real_js + 1)) then
+       block
+         real(kind=dp), allocatable, target :: tn(:), tm(:), nd(:,:), md(:,:), sm(:,:), sn(:,:), pm(:,:)
+         integer(c_int32_t), allocatable, target :: np(:)
+         integer :: nb, c, i, j, k, q, ns_src
+         nb = cfg%n_cells
+         ns_src = max(cfg%n_source, 1)
+         allocate(tn(nb), tm(nb), nd(cfg%n_dbin, nb), md(cfg%n_dbin, nb), sm(cfg%n_spec, nb), sn(ns_src, nb), &
+              pm(3, nb), np(nb))
+         call pmcx_die(pmcx_diagnostics(ctx, c_loc(tn), c_loc(tm), c_loc(nd), c_loc(md)), 'pmcx_diagnostics')
+         call pmcx_die(pmcx_diagnostics_ext(ctx, c_loc(sm), c_loc(sn), c_loc(pm), c_loc(np)), 'pmcx_diagnostics_ext')
+         q = 0
+         do j = real_js, real_je
+         do k = 1, pad_nz
+         do i = real_is, real_ie
+            q = q + 1
+            c = ((j - pad_js0) * pad_nz + (k - 1)) * pad_nxb + (i - pad_is0) + 1
+            tot_num_conc(q) = tn(c); tot_mass_conc(q) = tm(c)
+            num_dist(:, q) = nd(:, c); mass_dist(:, q) = md(:, c)
+            if (present(species_mass_conc)) species_mass_conc(:, q) = sm(:, c)
+            if (present(num_conc_by_source)) num_conc_by_source(:, q) = sn(1:size(num_conc_by_source, 1), c)
+            if (present(pm_mass_conc)) pm_mass_conc(:, q) = pm(:, c)
+            if (present(n_parts)) n_parts(q) = np(c)
+         end do
+         end do
+         end do
+       end block
+       return
+    end if
     if (size(tot_num_conc) /= cfg%n_cells .or. size(num_dist, 1) /= cfg%n_dbin) &
          call pmcx_die(1, 'partmc_process_pmcx (array shapes)')
     call pmcx_die(pmcx_diagnostics(ctx, c_loc(tot_num_conc), c_loc(tot_mass_conc), c_loc(num_dist), &

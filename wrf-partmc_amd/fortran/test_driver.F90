@@ -8,7 +8,14 @@
 ! and output are raw binary files so that a test can hold the result to the CPU oracle running the
 ! same loop, bit for bit.
 !
-! usage: test_driver <state.bin> <fields.bin> <out.bin>
+! usage: test_driver <state.bin> <fields.bin> <out.bin> [wrap [px py a b exchange_dir]]
+!   wrap = 1: the halo cells of grid%'s fields are filled by periodic wrap after reading (what WRF's
+!             periodic halo exchange leaves there); 0: by the nearest cell of the domain
+!   px py a b exchange_dir: this process is rank (a, b) of a px x py decomposition of the domain (WRF's
+!             patches: columns a nx/px + 1 .. (a + 1) nx/px, rows likewise); it reads the whole case,
+!             keeps its patch, hands the two drivers the patch's bounds exactly as WRF would, and reaches
+!             its neighbours through files in exchange_dir (the stand-in for MPI_Sendrecv:
+!             pmcx_shim_set_neighbours).  out.bin then holds this rank's cells only.
 ! state.bin : int32 nx, nz, ny, n_part, n_spec, n_class, n_source, n_gas, n_steps, periodic,
 !             sea_salt_opt, i_na, i_cl (1-based), n_time_e, n_mode_e, n_time_b, n_mode_b, vertmix;
 !             int64 seed; float64 dt, chem_dt, dx, dy, num_particles; float64 density(n_spec);
@@ -27,13 +34,93 @@
 !             int64 n_samp, n_coag, n_moved, n_deposited;
 !             then per cell: float64 mag(n_class), gas(n_gas), int32 n_part, the particles as
 !             test_shim writes them
+module rank_exchange
+  ! The file-backed stand-in for MPI_Sendrecv between the ranks of a cut domain: a message is a file
+  ! <dir>/m<sequence>_<direction>_<from>_<to>.bin, written whole and then announced by an empty .ok
+  ! file; the receiver polls for the announcement, reads and deletes both.
+  use iso_c_binding
+  implicit none
+  character(len=512), save :: xdir = ''
+  integer, save :: px = 1, py = 1, ra = 0, rb = 0, seq = 0
+  logical, save :: periodic_dom = .false.
+contains
+  integer function neighbour(side)          ! rank on side 0 south, 1 north, 2 west, 3 east; -1: none
+    integer, intent(in) :: side
+    integer :: a, b
+    a = ra; b = rb
+    select case (side)
+    case (0); b = b - 1
+    case (1); b = b + 1
+    case (2); a = a - 1
+    case (3); a = a + 1
+    end select
+    neighbour = -1
+    if (periodic_dom) then
+       a = modulo(a, px); b = modulo(b, py)
+    else if (a < 0 .or. a >= px .or. b < 0 .or. b >= py) then
+       return
+    end if
+    if (a == ra .and. b == rb) return      ! (one rank across that direction: no cut)
+    neighbour = b * px + a
+  end function neighbour
+
+  subroutine file_shift(dir, send, n_send, recv, n_recv)
+    integer, intent(in) :: dir
+    type(c_ptr), value :: send, recv
+    integer(c_int64_t), value :: n_send, n_recv
+    integer(c_int8_t), pointer :: bs(:), br(:)
+    character(len=700) :: name
+    integer :: u, me, to, from, tries
+    logical :: there
+    seq = seq + 1
+    me = rb * px + ra
+    to = neighbour(dir); from = neighbour(ieor(dir, 1))
+    if (n_send > 0 .and. to >= 0) then
+       call c_f_pointer(send, bs, [n_send])
+       write(name, '(a,a,i8.8,a,i1,a,i3.3,a,i3.3)') trim(xdir), '/m', seq, '_', dir, '_', me, '_', to
+       open(newunit=u, file=trim(name) // '.bin', access='stream', form='unformatted', status='replace')
+       write(u) bs
+       close(u)
+       open(newunit=u, file=trim(name) // '.ok', status='replace')
+       close(u)
+    end if
+    if (n_recv > 0 .and. from >= 0) then
+       call c_f_pointer(recv, br, [n_recv])
+       write(name, '(a,a,i8.8,a,i1,a,i3.3,a,i3.3)') trim(xdir), '/m', seq, '_', dir, '_', from, '_', me
+       tries = 0
+       do
+          inquire(file=trim(name) // '.ok', exist=there)
+          if (there) exit
+          tries = tries + 1
+          if (tries > 600000) then
+             write(0, '(a,a)') 'rank_exchange: no message ', trim(name)
+             stop 3
+          end if
+          call execute_command_line('sleep 0.002')
+       end do
+       open(newunit=u, file=trim(name) // '.bin', access='stream', form='unformatted', status='old')
+       read(u) br
+       close(u, status='delete')
+       open(newunit=u, file=trim(name) // '.ok', status='old')
+       close(u, status='delete')
+    end if
+  end subroutine file_shift
+end module rank_exchange
+
 program test_driver
   use iso_c_binding
   use pmc_mock
   use wrf_mock
   use pmcx_shim
+  use rank_exchange
   implicit none
-  character(len=512) :: fstate, ffields, fout
+  character(len=512) :: fstate, ffields, fout, arg
+  integer :: wrap, is, ie, js, je, hal
+  logical :: ranked
+  type(env_state_t), allocatable :: env_p(:,:,:)
+  type(aero_state_t), allocatable :: aero_p(:,:,:)
+  type(scenario_t), allocatable :: scn_p(:,:,:)
+  type(gas_state_t), allocatable :: gas_p(:,:,:)
   integer :: nx, nz, ny, n_part, n_spec, n_class, n_source, n_gas, n_steps, periodic, sea_salt_opt, &
        i_na, i_cl, n_time_e, n_mode_e, n_time_b, n_mode_b, vertmix
   integer(kind=8) :: seed
@@ -55,6 +142,18 @@ program test_driver
   call get_command_argument(1, fstate)
   call get_command_argument(2, ffields)
   call get_command_argument(3, fout)
+  wrap = 0; ranked = .false.
+  if (command_argument_count() >= 4) then
+     call get_command_argument(4, arg); read(arg, *) wrap
+  end if
+  if (command_argument_count() >= 9) then
+     ranked = .true.
+     call get_command_argument(5, arg); read(arg, *) px
+     call get_command_argument(6, arg); read(arg, *) py
+     call get_command_argument(7, arg); read(arg, *) ra
+     call get_command_argument(8, arg); read(arg, *) rb
+     call get_command_argument(9, xdir)
+  end if
   open(newunit=u, file=trim(fstate), access='stream', form='unformatted', status='old')
   read(u) nx, nz, ny, n_part, n_spec, n_class, n_source, n_gas, n_steps, periodic, sea_salt_opt, &
        i_na, i_cl, n_time_e, n_mode_e, n_time_b, n_mode_b, vertmix
@@ -147,7 +246,27 @@ program test_driver
   end do
   close(u)
 
-  call wrf_mock_allocate(grid, nx, nz, ny, n_class)
+  ! this process's patch (the whole domain unless it is a rank of a cut one)
+  is = 1; ie = nx; js = 1; je = ny; hal = 1
+  if (ranked) then
+     if (mod(nx, px) /= 0 .or. mod(ny, py) /= 0) stop 'test_driver: px, py must divide nx, ny'
+     is = ra * (nx / px) + 1; ie = (ra + 1) * (nx / px); js = rb * (ny / py) + 1; je = (rb + 1) * (ny / py)
+     hal = 3
+     periodic_dom = periodic /= 0
+     call pmcx_shim_set_neighbours(file_shift, neighbour(0) >= 0, neighbour(1) >= 0, neighbour(2) >= 0, &
+          neighbour(3) >= 0)
+  end if
+  allocate(env_p(is:ie, nz, js:je), aero_p(is:ie, nz, js:je), scn_p(is:ie, nz, js:je), gas_p(is:ie, nz, js:je))
+  do j = js, je
+  do k = 1, nz
+  do i = is, ie
+     env_p(i,k,j) = env_states(i,k,j); aero_p(i,k,j) = aero_states(i,k,j)
+     scn_p(i,k,j) = scenario(i,k,j); gas_p(i,k,j) = gas_states(i,k,j)
+  end do
+  end do
+  end do
+  n_cells = (ie - is + 1) * nz * (je - js + 1)
+  call wrf_mock_allocate(grid, nx, nz, ny, n_class, hal)
   grid%dt = real(dt); grid%dx = real(dx); grid%dy = real(dy); grid%rdx = 1.0 / grid%dx; grid%rdy = 1.0 / grid%dy
   grid%partmc_chem_dt = real(chem_dt); grid%num_particles = real(num_particles)
   grid%random_seed = int(seed); grid%partmc_seasalt_param = sea_salt_opt
@@ -160,22 +279,27 @@ program test_driver
   open(newunit=uo, file=trim(fout), access='stream', form='unformatted', status='replace')
   do step = 1, n_steps
      call read_fields()
-     call partmc_timestep_pmcx(grid, config_flags, scenario, env_states, aero_data, aero_states, &
-          gas_data, gas_states, 1, nx, 1, ny, 1, nz, nx, ny, nz)
-     call wrf_pmc_trans_driver_pmcx(grid, config_flags, env_states, scenario, aero_data, aero_states, &
-          gas_states, 1, nx, 1, ny, 1, nz, nx, ny, nz)
-     write(uo) env_states%temp, env_states%pressure, env_states%rel_humid, env_states%height, &
-          env_states%cell_volume, env_states%inverse_density
-     write(uo) last_aer_res
+     call partmc_timestep_pmcx(grid, config_flags, scn_p, env_p, aero_data, aero_p, &
+          gas_data, gas_p, is, ie, js, je, 1, nz, nx, ny, nz)
+     call wrf_pmc_trans_driver_pmcx(grid, config_flags, env_p, scn_p, aero_data, aero_p, &
+          gas_p, is, ie, js, je, 1, nz, nx, ny, nz)
+     write(uo) env_p%temp, env_p%pressure, env_p%rel_humid, env_p%height, &
+          env_p%cell_volume, env_p%inverse_density
+     if (ranked) then          ! (the block's resistances: this rank's cells of them)
+        write(uo) (((last_aer_res(((j - js + 1) * nz + (k - 1)) * (ie - is + 3) + (i - is + 1) + 1), i = is, ie), k = 1, nz), j = js, je)
+     else
+        write(uo) last_aer_res
+     end if
      call partmc_process_pmcx(tn, tm, nd, md, n_parts=n_parts)
      write(uo) n_parts
      write(uo) last_n_samp, last_n_coag, last_n_moved, last_n_deposited
   end do
   close(uf)
-  call partmc_sync_host_pmcx(aero_states, gas_states, 1, nx, 1, ny, 1, nz)
-  do j = 1, ny
+  call partmc_sync_host_pmcx(aero_p, gas_p, is, ie, js, je, 1, nz)
+  do j = js, je
   do k = 1, nz
-  do i = 1, nx
+  do i = is, ie
+     aero_states(i,k,j) = aero_p(i,k,j); gas_states(i,k,j) = gas_p(i,k,j)
      do s = 1, n_class
         write(uo) aero_states(i,k,j)%awa%weight(1, s)%magnitude
      end do
@@ -231,13 +355,98 @@ contains
     end do
   end subroutine read_dist
 
+  ! the file holds every array with one halo cell (0 : n + 1; the staggered ones 0 : n + 2); a rank of a
+  ! cut domain keeps more halo, filled like the first: by periodic wrap or from the nearest cell
   subroutine read_fields()
+    real, allocatable :: a3(:,:,:), b3(:,:,:), f4(:,:,:,:), a2(:,:)
+    integer, allocatable :: i2(:,:)
+    integer :: q
     read(uf) grid%time_since_sim_start
-    read(uf) grid%p, grid%pb, grid%t_2, grid%moist, grid%alt, grid%z, grid%z_at_w, grid%xkhh, grid%exch_h
-    read(uf) grid%u_2, grid%v_2, grid%u_1, grid%v_1
-    read(uf) grid%u_flux, grid%v_flux, grid%w_flux
-    read(uf) grid%xland, grid%u10, grid%v10, grid%msftx, grid%msfty, grid%ust, grid%rmol, grid%znt
-    read(uf) grid%ivgtyp
+    allocate(a3(0:nx+1, nz+1, 0:ny+1), b3(0:nx+2, nz+1, 0:ny+2), f4(0:nx+2, nz+1, 0:ny+2, n_class + 1), &
+         a2(0:nx+1, 0:ny+1), i2(0:nx+1, 0:ny+1))
+    read(uf) a3; call put3(grid%p, a3, 0)
+    read(uf) a3; call put3(grid%pb, a3, 0)
+    read(uf) a3; call put3(grid%t_2, a3, 0)
+    read(uf) a3; call put3(grid%moist(:,:,:,1), a3, 0)
+    read(uf) a3; call put3(grid%alt, a3, 0)
+    read(uf) a3; call put3(grid%z, a3, 0)
+    read(uf) a3; call put3(grid%z_at_w, a3, 0)
+    read(uf) a3; call put3(grid%xkhh, a3, 0)
+    read(uf) a3; call put3(grid%exch_h, a3, 0)
+    read(uf) b3; call put3(grid%u_2, b3, 1)
+    read(uf) b3; call put3(grid%v_2, b3, 1)
+    read(uf) b3; call put3(grid%u_1, b3, 1)
+    read(uf) b3; call put3(grid%v_1, b3, 1)
+    read(uf) f4
+    do q = 1, n_class + 1
+       call put3(grid%u_flux(:,:,:,q), f4(:,:,:,q), 1)
+    end do
+    read(uf) f4
+    do q = 1, n_class + 1
+       call put3(grid%v_flux(:,:,:,q), f4(:,:,:,q), 1)
+    end do
+    read(uf) f4
+    do q = 1, n_class + 1
+       call put3(grid%w_flux(:,:,:,q), f4(:,:,:,q), 1)
+    end do
+    read(uf) a2; call put2(grid%xland, a2)
+    read(uf) a2; call put2(grid%u10, a2)
+    read(uf) a2; call put2(grid%v10, a2)
+    read(uf) a2; call put2(grid%msftx, a2)
+    read(uf) a2; call put2(grid%msfty, a2)
+    read(uf) a2; call put2(grid%ust, a2)
+    read(uf) a2; call put2(grid%rmol, a2)
+    read(uf) a2; call put2(grid%znt, a2)
+    read(uf) i2
+    call puti(grid%ivgtyp, i2)
   end subroutine read_fields
+
+  ! source index of a halo cell: itself inside the file's range unless wrap asks for the periodic image
+  integer function src_index(g, n, stag)
+    integer, intent(in) :: g, n, stag
+    if (wrap /= 0) then
+       if (g >= 1 .and. g <= n + stag) then
+          src_index = g
+       else
+          src_index = modulo(g - 1, n) + 1
+       end if
+    else
+       src_index = min(max(g, 0), n + 1 + stag)
+    end if
+  end function src_index
+
+  subroutine put3(dst, src, stag)
+    real, intent(inout) :: dst(1-hal:, :, 1-hal:)
+    real, intent(in) :: src(0:, :, 0:)
+    integer, intent(in) :: stag
+    integer :: gi, gj
+    do gj = lbound(dst, 3), ubound(dst, 3)
+       do gi = lbound(dst, 1), ubound(dst, 1)
+          dst(gi, :, gj) = src(src_index(gi, nx, stag), :, src_index(gj, ny, stag))
+       end do
+    end do
+  end subroutine put3
+
+  subroutine put2(dst, src)
+    real, intent(inout) :: dst(1-hal:, 1-hal:)
+    real, intent(in) :: src(0:, 0:)
+    integer :: gi, gj
+    do gj = lbound(dst, 2), ubound(dst, 2)
+       do gi = lbound(dst, 1), ubound(dst, 1)
+          dst(gi, gj) = src(src_index(gi, nx, 0), src_index(gj, ny, 0))
+       end do
+    end do
+  end subroutine put2
+
+  subroutine puti(dst, src)
+    integer, intent(inout) :: dst(1-hal:, 1-hal:)
+    integer, intent(in) :: src(0:, 0:)
+    integer :: gi, gj
+    do gj = lbound(dst, 2), ubound(dst, 2)
+       do gi = lbound(dst, 1), ubound(dst, 1)
+          dst(gi, gj) = src(src_index(gi, nx, 0), src_index(gj, ny, 0))
+       end do
+    end do
+  end subroutine puti
 
 end program test_driver

@@ -60,21 +60,26 @@ module wrf_mock
 
 contains
 
-  !> Allocate the fields of a grid of nx x nz x ny cells (one halo cell in x and y, nz + 1 levels,
-  !> n_class + 1 flux scalars).
-  subroutine wrf_mock_allocate(grid, nx, nz, ny, n_class)
+  !> Allocate the fields of a grid of nx x nz x ny cells (halo cells in x and y -- one unless `halo` says
+  !> more: a rank of a cut domain reads two beyond its patch --, nz + 1 levels, n_class + 1 flux scalars).
+  subroutine wrf_mock_allocate(grid, nx, nz, ny, n_class, halo)
     type(domain), intent(inout) :: grid
     integer, intent(in) :: nx, nz, ny, n_class
-    allocate(grid%p(0:nx+1, nz+1, 0:ny+1), grid%pb(0:nx+1, nz+1, 0:ny+1), grid%t_2(0:nx+1, nz+1, 0:ny+1), &
-         grid%alt(0:nx+1, nz+1, 0:ny+1), grid%z(0:nx+1, nz+1, 0:ny+1), grid%z_at_w(0:nx+1, nz+1, 0:ny+1), &
-         grid%moist(0:nx+1, nz+1, 0:ny+1, 1), grid%xkhh(0:nx+1, nz+1, 0:ny+1), &
-         grid%exch_h(0:nx+1, nz+1, 0:ny+1), grid%u_2(0:nx+2, nz+1, 0:ny+2), grid%v_2(0:nx+2, nz+1, 0:ny+2), &
-         grid%u_1(0:nx+2, nz+1, 0:ny+2), grid%v_1(0:nx+2, nz+1, 0:ny+2))
-     allocate(grid%u_flux(0:nx+2, nz+1, 0:ny+2, n_class + 1), grid%v_flux(0:nx+2, nz+1, 0:ny+2, n_class + 1), &
-         grid%w_flux(0:nx+2, nz+1, 0:ny+2, n_class + 1))
-     allocate(grid%xland(0:nx+1, 0:ny+1), grid%u10(0:nx+1, 0:ny+1), grid%v10(0:nx+1, 0:ny+1), &
-         grid%msftx(0:nx+1, 0:ny+1), grid%msfty(0:nx+1, 0:ny+1), grid%ust(0:nx+1, 0:ny+1), &
-         grid%rmol(0:nx+1, 0:ny+1), grid%znt(0:nx+1, 0:ny+1), grid%ivgtyp(0:nx+1, 0:ny+1))
+    integer, intent(in), optional :: halo
+    integer :: l, hx, hy, hx2, hy2
+    l = 0
+    if (present(halo)) l = 1 - max(halo, 1)
+    hx = nx + 1 - l; hy = ny + 1 - l; hx2 = hx + 1; hy2 = hy + 1
+    allocate(grid%p(l:hx, nz+1, l:hy), grid%pb(l:hx, nz+1, l:hy), grid%t_2(l:hx, nz+1, l:hy), &
+         grid%alt(l:hx, nz+1, l:hy), grid%z(l:hx, nz+1, l:hy), grid%z_at_w(l:hx, nz+1, l:hy), &
+         grid%moist(l:hx, nz+1, l:hy, 1), grid%xkhh(l:hx, nz+1, l:hy), &
+         grid%exch_h(l:hx, nz+1, l:hy), grid%u_2(l:hx2, nz+1, l:hy2), grid%v_2(l:hx2, nz+1, l:hy2), &
+         grid%u_1(l:hx2, nz+1, l:hy2), grid%v_1(l:hx2, nz+1, l:hy2))
+     allocate(grid%u_flux(l:hx2, nz+1, l:hy2, n_class + 1), grid%v_flux(l:hx2, nz+1, l:hy2, n_class + 1), &
+         grid%w_flux(l:hx2, nz+1, l:hy2, n_class + 1))
+     allocate(grid%xland(l:hx, l:hy), grid%u10(l:hx, l:hy), grid%v10(l:hx, l:hy), &
+         grid%msftx(l:hx, l:hy), grid%msfty(l:hx, l:hy), grid%ust(l:hx, l:hy), &
+         grid%rmol(l:hx, l:hy), grid%znt(l:hx, l:hy), grid%ivgtyp(l:hx, l:hy))
      grid%p = 0.0; grid%pb = 1.0e5; grid%t_2 = 0.0; grid%alt = 0.85; grid%z = 0.0; grid%z_at_w = 0.0
      grid%moist = 0.0; grid%xkhh = 0.0; grid%exch_h = 0.0
      grid%u_2 = 0.0; grid%v_2 = 0.0; grid%u_1 = 0.0; grid%v_1 = 0.0
