@@ -356,6 +356,10 @@ def main():
     ap.add_argument("--workload", choices=["domain", "config3"], default="domain",
                     help="domain: BASELINE configs[4] (default). config3: 1000 cells x 10^4, "
                          "20 species, condensation sub-step + coagulation (BASELINE configs[2])")
+    ap.add_argument("--n-class", type=int, default=1,
+                    help="weight classes (WRFV3/Registry/registry.partmc_trans:2-41 carries 40): the idealised mode "
+                         "split evenly over them, class c standing for (1 + c / 2) times class 0's number "
+                         "(a side measurement: no CPU leg, the cells take the lanes-per-cell sampler)")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="no GPU needed: launch, rendezvous (gloo), partition and aggregation only; value null")
     args = ap.parse_args()
@@ -365,6 +369,8 @@ def main():
     config3 = args.workload == "config3"
     if config3:
         args.nx, args.ny, args.levels, args.n_spec = 10, 10, 10, 20
+        args.no_cpu_baseline = True
+    if args.n_class > 1:
         args.no_cpu_baseline = True
 
     rank = int(os.environ.get("RANK", "0"))
@@ -402,7 +408,7 @@ def main():
     first_cell, n_cells = c0 * args.levels, (c1 - c0) * args.levels
     n_cells_total = n_cols * args.levels
 
-    blk = wp.CellBlock(n_cells, args.cap, args.n_spec, n_class=1, n_source=0, device=device,
+    blk = wp.CellBlock(n_cells, args.cap, args.n_spec, n_class=args.n_class, n_source=0, device=device,
                        cell_id_base=first_cell, max_events=args.max_events,
                        max_appends=args.max_appends, i_water=(19 if config3 else -1))
     if args.sampler_lanes or args.sampler_stamps or args.sampler_wpb:
@@ -418,13 +424,20 @@ def main():
     else:
         blk.set_aero_data(bench_density(args.n_spec))
         blk.set_env(temp[lev], pres[lev], np.full(n_cells, 0.5))
-    blk.set_weights(np.full((n_cells, 1), args.num_conc / args.particles))
-    blk.set_n_part_ideal(np.full((n_cells, 1), float(args.particles)))
+    Cn = args.n_class
+    # (class c stands for (1 + c / 2) times class 0's number; the classes hold equal shares of the particles)
+    w_cls = 1.0 + 0.5 * np.arange(Cn)
+    mag0 = args.num_conc / (args.particles / Cn * w_cls.sum())
+    blk.set_weights(np.tile(mag0 * w_cls, (n_cells, 1)))
+    blk.set_n_part_ideal(np.full((n_cells, Cn), float(args.particles) / Cn))
     blk.set_next_id((first_cell + np.arange(n_cells, dtype=np.int64) << 32) + (1 << 24))
     if config3:
         from wrf_partmc_amd.data import scm_init_modes
         modes3, _ = scm_init_modes()      # em_scm_xy bimodal IC, OC:SO4:NH4 composition
         blk.generate_lognormal(args.particles, modes3, seed=args.seed)
+    elif Cn > 1:
+        base = bench_modes(args.n_spec)[0]
+        blk.generate_lognormal(args.particles, [dict(base, frac=1.0 / Cn, wclass=c) for c in range(Cn)], seed=args.seed)
     else:
         blk.generate_lognormal(args.particles, bench_modes(args.n_spec), seed=args.seed)
     blk.update_kernel_bounds(args.kernel)
@@ -470,7 +483,7 @@ def main():
                        for g in cpu_counts if first_cell <= g < first_cell + n_cells}
     sampler_left = blk.sampler_info()     # cells the sampler's split-off draw left to its second launch (last step)
     samp, coag, parts_after, status = blk.read_accumulated(reset=True)
-    parts = parts_after + coag    # one class: particles entering a step = survivors + events
+    parts = parts_after + coag    # one class: particles entering a step = survivors + events (several: an upper bound)
     for k in KERNELS:
         prof_main[k] = blk.profile_get(k)
     if args.sampler_stamps and rank == 0:   # diagnostic build of the sampler
@@ -530,7 +543,7 @@ def main():
         per_launch = dict(particles=agg["particle_steps"] / world / args.steps,
                           candidates=agg["n_samp"] / world / args.steps,
                           events=agg["n_coag"] / world / args.steps)
-        alg = algorithmic_bytes(dom, args.n_spec, 1, 0, **per_launch)
+        alg = algorithmic_bytes(dom, args.n_spec, args.n_class, 0, **per_launch)
         avg_ms = kern_ms[dom] / launches
         achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         # HBM bytes per launch from the PMC passes (profiles/pmc_traffic.json, scripts/gpu_pmc_shape.sh):
@@ -540,7 +553,7 @@ def main():
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         full_default = (args.workload == "domain" and (args.nx, args.ny, args.levels) == (100, 100, 30)
-                        and args.particles == 10000 and args.n_spec == 1 and world == 1)
+                        and args.particles == 10000 and args.n_spec == 1 and world == 1 and args.n_class == 1)
         if full_default and dom == "coag_sample" and os.path.exists(tpath):
             try:
                 shapes = json.load(open(tpath)).get("shapes", {})
@@ -564,7 +577,8 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": (f"{args.nx}x{args.ny}x{args.levels} cells x {args.particles} "
                                     f"particles/cell, Brownian mc_coag del_t={args.del_t:g}s + rebalance, "
-                                    f"n_spec={args.n_spec}, cell-column blocks over {world} GPU(s)"
+                                    f"n_spec={args.n_spec}" + (f", n_class={args.n_class}" if args.n_class > 1 else "")
+                                    + f", cell-column blocks over {world} GPU(s)"
                                     + (", condensation sub-step (extension) before coagulation, "
                                        "em_scm_xy species table and bimodal IC" if config3 else "")),
                        "cells": n_cells_total, "particles_per_cell": args.particles,

@@ -3,7 +3,10 @@
 tests/test_gpu_driver.py -- WRF steps through partmc_timestep_pmcx and wrf_pmc_trans_driver_pmcx,
 the oracle through the same loop, every particle, component list, weight and gas compared bit for
 bit -- with grid shape, particle count, number of steps, boundaries, sea-salt option and seed at
-random.   python scripts/fuzz_driver.py [n_runs] [seed] [max_steps]"""
+random.   python scripts/fuzz_driver.py [n_runs] [seed] [max_steps] [headroom] [auto_grow]
+headroom: slots per cell / ideal count the Fortran side STARTS with (default: the shim's 3; the oracle
+keeps three times the ideal count, the results do not depend on it); auto_grow 0: the block does not
+grow (a full cell stops the run, as until round 4)."""
 import os
 import pathlib
 import sys
@@ -21,6 +24,10 @@ from tests import test_gpu_driver as drv, wrf_case  # noqa: E402
 n_runs = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
 max_steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+if len(sys.argv) > 4:
+    os.environ["PMCX_TEST_HEADROOM"] = sys.argv[4]
+if len(sys.argv) > 5:
+    os.environ["PMCX_TEST_AUTO_GROW"] = sys.argv[5]
 assert os.path.exists(drv.EXE), "build wrf-partmc_amd/fortran first (make)"
 t0 = time.time()
 full = 0
@@ -45,4 +52,5 @@ for run in range(n_runs):
             continue
     print(f"   moved {sum(s['n_moved'] for s in steps)} coagulated {sum(s['n_coag'] for s in steps)} "
           f"deposited {sum(s['n_deposited'] for s in steps)} particles {sum(f['n'] for f in final)}", flush=True)
-print(f"{n_runs} runs ({full} stopped by a full cell), {time.time() - t0:.0f} s: all equal")
+print(f"{n_runs} runs ({full} stopped by a full cell), {time.time() - t0:.0f} s: all equal"
+      + (f" (headroom {sys.argv[4]})" if len(sys.argv) > 4 else ""))

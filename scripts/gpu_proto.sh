@@ -7,5 +7,7 @@
 #   proto_accept_nolast   + the lists' ends not requested with the pair
 # usage (on the GPU box): bash scripts/gpu_proto.sh <tag>
 tag=${1:-proto}
-REPS=${REPS:-3} bash scripts/gpu_ab.sh $tag
+# (one timed step behind one warm-up step of a fresh population: the wrong picks of a timing build make its
+# populations drift away from the benchmark's within a few steps)
+REPS=${REPS:-4} bash scripts/gpu_ab.sh $tag --steps 1 --warmup 1
 cp gpurun_out/ab_$tag.txt gpurun_out/proto_$tag.txt

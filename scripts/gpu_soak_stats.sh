@@ -1,10 +1,10 @@
 #!/bin/bash
 # per-kernel statistics of a longer coupled run (populations and weights have drifted apart)
-tag=${1:-soak}; steps=${2:-90}
+tag=${1:-soak}; steps=${2:-90}; shift 2 2>/dev/null
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_soak_$tag -- python3 $R/scripts/whole_step.py --steps $steps > $R/gpurun_out/soak_prof_$tag.log 2>&1 || { tail -5 $R/gpurun_out/soak_prof_$tag.log; exit 1; }
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_soak_$tag -- python3 $R/scripts/whole_step.py --steps $steps "$@" > $R/gpurun_out/soak_prof_$tag.log 2>&1 || { tail -5 $R/gpurun_out/soak_prof_$tag.log; exit 1; }
 f=$(find $R/gpurun_out/prof_soak_$tag -name '*kernel_stats.csv' | head -1)
 cp "$f" $R/gpurun_out/soak_kernel_stats_$tag.csv
 t=$(find $R/gpurun_out/prof_soak_$tag -name '*kernel_trace.csv' | head -1)

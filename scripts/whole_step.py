@@ -38,13 +38,15 @@ ap.add_argument("--trace", type=int, default=0, help="every TRACE steps: cells t
 ap.add_argument("--law", type=int, default=1, help="pmcx_set_transport_law: 0 movers with geometric copies, 1 movers and emitters")
 ap.add_argument("--prep", action="store_true", help="the adds' weight preparation on (pmcx_set_weight_preparation), as the Fortran drivers run")
 ap.add_argument("--sync-stages", action="store_true", help="every stage call waits for the device (the default before round 3)")
+ap.add_argument("--cap-factor", type=float, default=2.2, help="slots per cell / ideal count (the Fortran shim's default headroom is 3)")
+ap.add_argument("--auto-grow", action="store_true", help="pmcx_set_auto_grow(0.75, 1.5): the block grows like PartMC's particle arrays")
 a = ap.parse_args()
 
 nx, ny, nz, N = a.nx, a.ny, a.levels, a.particles
 n = nx * ny * nz
 # slots: the rebalance lets a cell grow to twice its ideal count before it halves it
 # (aero_state_rebalance), and a step's arrivals come on top
-cap = (int(N * 2.2) + 63) // 64 * 64
+cap = (int(N * a.cap_factor) + 63) // 64 * 64
 blk = wp.CellBlock(n, cap, 1, n_class=1, n_source=2, max_events=1024, max_appends=128)
 blk.set_aero_data([1770.0])
 # transport's cell order: c = (j * nz + k) * nx + i
@@ -58,6 +60,8 @@ blk.set_n_part_ideal(np.full((n, 1), float(N)))
 if a.prep:
     blk.set_weight_preparation(True, True, True)
 blk.set_transport_law(a.law)
+if a.auto_grow:
+    blk.set_auto_grow(True, 0.75, 1.5)
 blk.set_next_id((np.arange(n, dtype=np.int64) << 32) + (1 << 24))
 blk.generate_lognormal(N, idealised_modes(1, 1), seed=0)
 blk.synchronize()      # (no pmcx_update_kernel_bounds: mc_coag keeps each cell's bounds current)

@@ -1096,8 +1096,11 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
                                 same ? (double)nA * ((double)nA - 1.0) / 2.0
                                      : (double)nA * (double)nB;
                             const double mean = k_max * del_t * n_possible;
-                            ns = (uint32_t)poisson(mean, poisson_uniform(seed, cell_id, step, (uint32_t)gA,
-                                                                         (uint32_t)gB));
+                            // (u < 1 - mean - 4e-15 implies u < det_exp(-mean): a count of zero, as poisson()
+                            // says, without the exponential -- nearly every slot of a sweep, and with tens of
+                            // weight classes there are thousands of them a cell)
+                            const double u_slot = poisson_uniform(seed, cell_id, step, (uint32_t)gA, (uint32_t)gB);
+                            if (!(u_slot < (1.0 - mean) - 4e-15)) ns = (uint32_t)poisson(mean, u_slot);
                         }
                         r = ns;
                     }
@@ -2188,8 +2191,8 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                 const int b_old = big1 ? b1 : b2, b_o = big1 ? b2 : b1;
                 const uint32_t e_o = big1 ? eB : eA;
 #if defined(PMCX_PROTO_ACCEPT)
-                // (the merged particle moves up a bin in three events of ten, whatever was picked)
-                const int b_new = min(b_old + ((__double_as_longlong(u_acc) & 1023) < 307 ? 1 : 0), B - 2);
+                // (the merged particle moves up a bin in one event of seven, whatever was picked)
+                const int b_new = min(b_old + ((__double_as_longlong(u_acc) & 1023) < 146 ? 1 : 0), B - 2);
                 const bool move = b_new != b_old;
                 const bool in_grid = true;
 #else
@@ -2974,12 +2977,37 @@ __global__ __launch_bounds__(64) void k_rebalance(DeviceState st, int allow_doub
     const double *n_ideal = st.n_ideal + (int64_t)c * st.n_class;
     int status = 0;
     apply_event_log(st, c, lane);
+    // particles per class, class q in lane q (up to 64 classes): the lengths of the cell's lists while they
+    // hold (what mc_coag leaves), else ONE pass with a ballot per class -- not a pass per class and
+    // doubling, which with ten classes was 247 ms of a 535-ms step at the full domain
+    const bool counted = st.n_class > 1 && st.n_class <= 64;
+    int cls_cnt = 0;
+    if (counted) {
+        if (st.sort_valid[c]) {
+            if (lane < st.n_class) {
+                const int32_t *g = st.gcnt + ((int64_t)c * st.n_class + lane) * st.n_bin;
+                for (int b = 0; b < st.n_bin; b++) cls_cnt += g[b];
+            }
+        } else {
+            const int n_hi0 = st.n_hi[c];
+            for (int i0 = 0; i0 < n_hi0; i0 += 64) {
+                const int wc = i0 + lane < n_hi0 ? live_class_c(st, cb, i0 + lane) : -1;
+                for (int q = 0; q < st.n_class; q++) {
+                    const int k = __popcll(__ballot(wc == q));
+                    if (lane == q) cls_cnt += k;
+                }
+            }
+        }
+    }
     for (int cl = 0; cl < st.n_class; cl++) {
+        int ncl_kept = counted ? __shfl(cls_cnt, cl, 64) : 0;
         for (uint32_t iter = 0; iter < 32; iter++) {
             int n_hi = st.n_hi[c];
             const int n_live = st.n_part[c];
             int ncl = n_live; // one class: every live particle belongs to it
-            if (st.n_class > 1) {
+            if (counted) {
+                ncl = ncl_kept;
+            } else if (st.n_class > 1) {
                 uint32_t cnt = 0;
                 for (int i = lane; i < n_hi; i += 64) cnt += (live_class_c(st, cb, i) == cl);
                 ncl = (int)wave_sum_u64(cnt);
@@ -3015,6 +3043,7 @@ __global__ __launch_bounds__(64) void k_rebalance(DeviceState st, int allow_doub
                     mag[cl] = mag[cl] / 2.0;
                     st.sort_valid[c] = 0;
                 }
+                ncl_kept = 2 * ncl;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __threadfence_block();
                 wave_sync();
@@ -3044,6 +3073,7 @@ __global__ __launch_bounds__(64) void k_rebalance(DeviceState st, int allow_doub
                     mag[cl] = mag[cl] * 2.0;
                     st.sort_valid[c] = 0;
                 }
+                ncl_kept = ncl - (int)nd;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __threadfence_block();
                 wave_sync();

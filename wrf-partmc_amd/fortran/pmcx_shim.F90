@@ -1282,6 +1282,20 @@ contains
     ! Update the meteorology (driver:120-135)
     call wrf_to_partmc_pmcx(grid, nx, nz, ny, pmc_is, pmc_ks, pmc_js, env_states, old_height)
     elapsed_time = real(real_time_since_sim_start(grid), kind=dp)
+    if (in_padded .and. .not. (config_flags%periodic_x .and. config_flags%periodic_y)) then
+       ! a ghost cell beyond the domain's open edge stands for nothing (no rank owns it, nothing is sent
+       ! there): whatever grid%'s halo holds there, it gets the meteorology of the nearest cell of the domain
+       do j = pmc_js, pmc_je
+       do k = pmc_ks, pmc_ke
+       do i = pmc_is, pmc_ie
+          if (i >= 1 .and. i <= global_nx .and. j >= 1 .and. j <= global_ny) cycle
+          env_states(i,k,j) = env_states(min(max(i, 1), global_nx), k, min(max(j, 1), global_ny))
+          old_height(((j - pmc_js) * nz + (k - pmc_ks)) * nx + (i - pmc_is) + 1) = &
+               old_height(((min(max(j, 1), global_ny) - pmc_js) * nz + (k - pmc_ks)) * nx + (min(max(i, 1), global_nx) - pmc_is) + 1)
+       end do
+       end do
+       end do
+    end if
     c = 0
     do j = pmc_js, pmc_je
     do k = pmc_ks, pmc_ke

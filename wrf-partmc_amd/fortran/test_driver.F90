@@ -142,6 +142,18 @@ program test_driver
   call get_command_argument(1, fstate)
   call get_command_argument(2, ffields)
   call get_command_argument(3, fout)
+  ! (environment, for scripts/fuzz_driver.py: PMCX_TEST_HEADROOM = slots per cell / ideal count the block
+  ! starts with; PMCX_TEST_AUTO_GROW = 0: a full cell stops the run as until round 4)
+  call get_environment_variable('PMCX_TEST_HEADROOM', arg, status=i)
+  if (i == 0 .and. len_trim(arg) > 0) then
+     read(arg, *) t_lo
+     call pmcx_shim_set_headroom(t_lo)
+  end if
+  call get_environment_variable('PMCX_TEST_AUTO_GROW', arg, status=i)
+  if (i == 0 .and. len_trim(arg) > 0) then
+     read(arg, *) j
+     call pmcx_shim_set_auto_grow(j /= 0)
+  end if
   wrap = 0; ranked = .false.
   if (command_argument_count() >= 4) then
      call get_command_argument(4, arg); read(arg, *) wrap
@@ -336,8 +348,10 @@ program test_driver
   end do
   end do
   close(uo)
+  call pmcx_shim_growth(i, j)
   call pmcx_shim_finalize()
-  print '(a,i0,a,i0,a)', 'test_driver ok: ', n_cells, ' cells, ', n_steps, ' WRF steps'
+  print '(a,i0,a,i0,a,i0,a,i0,a)', 'test_driver ok: ', n_cells, ' cells, ', n_steps, ' WRF steps; ', i, &
+       ' slots a cell, the block grew ', j, ' times'
 
 contains
 
