@@ -661,10 +661,15 @@ int32_t pmcx_max_cap(const pmcx_config *cfg);
  *     before anything is written to it; if some cell would not hold its particles plus its arrivals
  *     the block grows first, to factor x what that cell needs (exact: no arrival is ever dropped
  *     for want of slots below 65280 per cell);
- *   * pmcx_timestep, pmcx_boundary_resample, pmcx_transport: when the fullest cell uses more than
- *     fill x cap slots at the start of the call, to factor x that (room for the step's emissions,
- *     background, sea salt and refill: a margin, not a count -- what still does not fit raises
- *     PMCX_ST_CAP_OVERFLOW as ever);
+ *   * pmcx_timestep, pmcx_boundary_resample: at the start of the call, (i) when the fullest cell uses
+ *     more than fill x cap slots, to factor x that, and (ii) when some cell's slots in use plus the sum
+ *     of its classes' ideal counts (pmcx_set_n_part_ideal: what a doubling, or the weight preparation
+ *     of an add, can bring a cell in one call) exceed cap, to 1.25 x that -- room for the step's
+ *     refill and doubling: a margin, not a count;
+ *   * pmcx_scenario_update_aero_state, pmcx_seasalt_emissions (also inside pmcx_timestep): before the
+ *     adds, an upper bound of what they can bring a cell to -- per mode the Poisson mean of its sample
+ *     + 6 sigma + 12, with the weight preparation on also the classes' ideal counts -- against cap; to
+ *     1.25 x that (what still does not fit -- one sample in 10^9 -- raises PMCX_ST_CAP_OVERFLOW as ever);
  *   * pmcx_transport_import: a neighbouring rank's cell larger than a ghost cell here.
  * Each check reads one number back from the device (the call waits for the stream there).  Off by
  * default; the Fortran shim switches it on (fill 0.75, factor 1.5).

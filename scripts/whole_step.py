@@ -145,6 +145,10 @@ for step in range(a.steps):
     else:
         nm, na = blk.transport(nx, nz, ny, prob_h, prob_v, cell_volume, seed=0, step=step)
         host["transport"] += time.perf_counter() - ts
+    if a.trace and step % a.trace == 0:
+        blk.synchronize()
+        print(f"step {step}: {int(nm.sum())} movers, {int(na.sum())} arrivals ({na.sum() / max(nm.sum(), 1):.2f} per mover), "
+              f"most into one cell {int(na.max())}", file=sys.stderr)
     tc = time.perf_counter()
     if step == 0:
         blk.synchronize()

@@ -256,6 +256,8 @@ void prof_drain(pmcx_ctx *ctx)
 extern "C" {
 
 static int grow_if_needed(pmcx_ctx *ctx, const int32_t *n_exp);
+static int grow_for_adds(pmcx_ctx *ctx, double dt, const GenSpecDev *em, const double *em_conc, const double *dil,
+                         const GenSpecDev *bg, const double *bg_conc, const double *height, const double *old_height);
 
 
 void pmcx_config_default(pmcx_config *cfg)
@@ -603,12 +605,18 @@ static int grow_if_needed(pmcx_ctx *ctx, const int32_t *n_exp)
     int32_t h[3] = {0, 0, 0};
     HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_need, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    // arrivals find room among a cell's dead slots (k_trans_room compacts): what counts is the live count
-    const int need = n_exp ? h[0] : h[1];
+    // With the arrivals counted (transport): exact -- they find room among a cell's dead slots (k_trans_room
+    // compacts), what counts is the live count plus the arrivals.  Without: a margin -- the fullest cell's
+    // slots in use against fill x cap, and its slots in use plus its classes' ideal counts (what a
+    // doubling or the weight preparation of an add can bring in one call; n_ideal set) against cap.
     const int cap = ctx->cfg.cap;
-    const bool must = need > cap, should = (double)need > ctx->grow_fill * (double)cap;
+    int need = n_exp ? h[0] : h[1];
+    bool must = need > cap;
+    const bool should = (double)need > ctx->grow_fill * (double)cap;
+    if (!n_exp && ctx->n_ideal_set && h[0] > cap) { must = true; need = h[0] > need ? h[0] : need; }
     if (!must && !should) return PMCX_OK;
     double want = ctx->grow_factor * (double)(n_exp && !must ? cap : need);
+    if (!n_exp && must) want = 1.25 * (double)need > ctx->grow_factor * (double)h[1] ? 1.25 * (double)need : ctx->grow_factor * (double)h[1];
     if (want < (double)need) want = (double)need;
     if (want > 65280.0) want = 65280.0;
     int32_t new_cap = ((int32_t)want + 63) & ~63;
@@ -617,6 +625,24 @@ static int grow_if_needed(pmcx_ctx *ctx, const int32_t *n_exp)
     const int rc = pmcx_grow(ctx, new_cap);
     if (rc == PMCX_ENOMEM && !must) { ctx->err.clear(); return PMCX_OK; } // (growing ahead of need is optional)
     return rc;
+}
+
+// pmcx_set_auto_grow: room for a scenario update's adds (emission, background, sea salt) -- an upper bound
+// from the Poisson means of the samples (mean + 6 sigma + 12 a mode) and, with the weight preparation on,
+// the classes' ideal counts; the block grows to 1.25 x the fullest cell's bound
+static int grow_for_adds(pmcx_ctx *ctx, double dt, const GenSpecDev *em, const double *em_conc, const double *dil,
+                         const GenSpecDev *bg, const double *bg_conc, const double *height, const double *old_height)
+{
+    HIP_TRY(ctx, launch_adds_bound(ctx->st, dt, em, em_conc, dil, bg, bg_conc, height, old_height, ctx->d_need,
+                                   ctx->stream));
+    int32_t need = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&need, ctx->d_need, sizeof need, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (need <= ctx->cfg.cap) return PMCX_OK;
+    double want = 1.25 * (double)need;
+    if (want > 65280.0) want = 65280.0;
+    if ((int32_t)want <= ctx->cfg.cap) return PMCX_OK;
+    return pmcx_grow(ctx, (int32_t)want);
 }
 
 // pmcx_set_auto_grow, law 1 of the transport: a source cell's outbox holds cap entries (one per mover, one
@@ -1391,6 +1417,11 @@ int pmcx_scenario_update_aero_state(pmcx_ctx *ctx, double dt, double elapsed_tim
     }
     if (e == hipSuccess) { e = tmp_malloc(ctx, (void **)&d_cnt, sizeof(int32_t) * 3 * nc); if (e == hipSuccess) tmp.push_back(d_cnt); }
     if (e == hipSuccess && !ctx->hold_status) e = hipMemsetAsync(ctx->st.status, 0, sizeof(int32_t) * nc, ctx->stream);
+    if (e == hipSuccess && ctx->auto_grow) { // room for what the adds can bring (an upper bound; the call waits here)
+        rc = grow_for_adds(ctx, dt, emission ? &ge : nullptr, ce, d_dil, background ? &gb : nullptr, cbg, d_h,
+                           d_h ? d_h + nc : nullptr);
+        if (rc) { cleanup(); return rc; }
+    }
     if (e == hipSuccess) {
         ProfScope ps(ctx, "scenario");
         e = launch_scenario_update(ctx->st, dt, elapsed_time, seed, step, emission ? &ge : nullptr, ce,
@@ -1494,6 +1525,10 @@ int pmcx_seasalt_emissions(pmcx_ctx *ctx, double dt, double elapsed_time, uint64
     hipError_t e = tmp_malloc(ctx, (void **)&d_cnt, sizeof(int32_t) * nc);
     if (e == hipSuccess) tmp.push_back(d_cnt);
     if (e == hipSuccess && !ctx->hold_status) e = hipMemsetAsync(ctx->st.status, 0, sizeof(int32_t) * nc, ctx->stream);
+    if (e == hipSuccess && ctx->auto_grow) {
+        rc = grow_for_adds(ctx, dt, &ge, ce, nullptr, nullptr, nullptr, nullptr, nullptr);
+        if (rc) { cleanup(); return rc; }
+    }
     if (e == hipSuccess) {
         ProfScope ps(ctx, "scenario");
         e = launch_scenario_update(ctx->st, dt, elapsed_time, seed, step, &ge, ce, nullptr, nullptr, nullptr,

@@ -275,6 +275,12 @@ hipError_t launch_need_max(const DeviceState &st, const int32_t *n_exp, int32_t 
 // a k_trans_decide whose outboxes ran out (ST_OUTBOX_OVERFLOW) taken back: the movers' sort keys restored,
 // the bit cleared -- so that the decision can be taken again with more room
 hipError_t launch_transport_undo(const DeviceState &st, void *outbox, const int32_t *n_out, hipStream_t s);
+// out[0] = max over the cells of an upper bound of the slots a scenario update (launch_scenario_update
+// with the same arguments) can bring a cell to: its slots in use, its classes' ideal counts (what the
+// weight preparation of an add can copy), and per mode the Poisson mean of the sample + 6 sigma + 12
+hipError_t launch_adds_bound(const DeviceState &st, double dt, const GenSpecDev *em, const double *em_conc,
+                             const double *dilution_rate, const GenSpecDev *bg, const double *bg_conc,
+                             const double *height, const double *old_height, int32_t *out, hipStream_t s);
 // the slots [old_cap, new_cap) of every cell of a block that has just grown: dead
 hipError_t launch_grow_tail(const DeviceState &st, int old_cap, hipStream_t s);
 hipError_t launch_test_math(int op, int64_t n, const double *a, const double *b, const double *c3,

@@ -3876,7 +3876,9 @@ constexpr double TRANS_EMIT_WALK_MAX = 32.0;    // law 1: above this sum of rate
 // law 1: the number of copies an emitter sends, a zero-truncated Poisson(sum_mu) from one uniform
 // (the walk's first term exp(-sum_mu) sum_mu / (1 - exp(-sum_mu)) underflows for large rates, where the
 // truncation no longer matters: the plain count, at least one)
-__device__ inline int emit_count(double sum_mu, double u2, bool &clamped)
+// (not inlined, like deal_copies below: the emitters are a few particles in a hundred, and their code and
+// registers in k_trans_decide's straight path cost every particle -- 1.80 -> 2.3 ms at 1.2e9 particles)
+__device__ __attribute__((noinline)) int emit_count(double sum_mu, double u2, bool &clamped)
 {
     int n;
     if (sum_mu > TRANS_EMIT_WALK_MAX) {
@@ -3896,6 +3898,35 @@ __device__ inline int emit_count(double sum_mu, double u2, bool &clamped)
     }
     if (n > TRANS_MAX_COPIES) { clamped = true; n = TRANS_MAX_COPIES; }
     return n;
+}
+
+// law 1: an emitter's n_emit copies dealt to the r < 1 destinations of its class in proportion to their
+// rates (mucum: the running sums in table order, -1 where r >= 1; the uniform of copy q from the particle's
+// blocks 2 + q / 2).  One copy: returns its destination.  Several: deal[y] counts them per destination,
+// n_dst = how many destinations take any.
+__device__ __attribute__((noinline)) int deal_copies(uint64_t seed, uint32_t cell_id, uint32_t step, uint32_t rank,
+                                                     int n_emit, double sum_mu, const double *mucum, int nt,
+                                                     uint16_t *deal, uint32_t &n_dst)
+{
+    int d_one = -1;
+    n_dst = 0;
+    if (n_emit > 1) for (int y = 0; y < nt; y++) deal[y] = 0;
+    for (int q = 0; q < n_emit; q++) {
+        uint32_t v[4];
+        rng_block(seed, cell_id, step, rank, SITE_TRANS, 2u + (uint32_t)(q >> 1), v);
+        const double xq = u53(v[2 * (q & 1)], v[2 * (q & 1) + 1]) * sum_mu;
+        int d = -1, last = -1;
+        for (int y = 0; y < nt; y++) {
+            const double cm = mucum[y];   // (the sum the oracle forms term by term, same order)
+            if (cm < 0.0) continue;
+            last = y;
+            if (xq < cm) { d = y; break; }
+        }
+        if (d < 0) d = last;
+        if (n_emit == 1) { d_one = d; n_dst = 1; }
+        else { if (deal[d] == 0) n_dst++; deal[d] = (uint16_t)(deal[d] + 1); }
+    }
+    return d_one;
 }
 
 // open lateral boundaries: is local row j the domain's first or last row?
@@ -3934,8 +3965,13 @@ struct TransGrid {
 
 // EMIT: law 1 (pmcx_set_transport_law) -- its own instance, so that the emitters' code and registers
 // (82 against 45) are not the default law's to carry (1.73 -> 1.99 ms when they were)
+#ifndef PMCX_DECIDE_WAVES
+#define PMCX_DECIDE_WAVES 6
+#endif
+// (six wavefronts a SIMD: the kernel streams keys and waits for them -- at 88 registers, five wavefronts,
+// the law-1 instance ran 2.3 ms where round 3's 82 registers gave 1.8)
 template <bool EMIT>
-__global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid tg, uint64_t seed,
+__global__ __launch_bounds__(64, PMCX_DECIDE_WAVES) void k_trans_decide(DeviceState st, TransGrid tg, uint64_t seed,
                                                      uint32_t step)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -3957,8 +3993,11 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
     // law 1, per class: the sum of the emitters' rates, their interval [s_act_lo, s_act_hi) of the placing uniform
     double *s_mu_sum = (double *)(smem + ((((size_t)((unsigned char *)(t_cnt + C * ND) - smem)) + 7) & ~(size_t)7));
     double *s_act_lo = s_mu_sum + C, *s_act_hi = s_act_lo + C;
+    // law 1: the running sum of the rates over a class's r < 1 destinations in table order (-1: r >= 1):
+    // what a copy's uniform is compared with when it is dealt (formed once per cell, not per copy)
+    double *t_mucum = s_act_hi + C;          // [C][ND]
     // law 1: a lane's copies per destination while it deals them ([64][ND], an emitter of several copies)
-    uint16_t *s_deal = (uint16_t *)(s_act_hi + C);
+    uint16_t *s_deal = (uint16_t *)(t_mucum + C * ND);
     for (int x = lane; x < C * ND; x += 64) t_cnt[x] = 0;
     const int i = c % nx, k = (c / nx) % nz, j = c / (nx * nz);
     const bool mask_ok = ND <= 64 && (nx >= 3 || !tg.periodic_x) && (ny >= 3 || !tg.periodic_y);
@@ -4066,6 +4105,7 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
             for (int d = 0; d < nt; d++) {
                 const double r = t_ratio[cl * ND + d];
                 if (r < 1.0) sum_mu = sum_mu + (t_hi[cl * ND + d] - t_lo[cl * ND + d]) * (1.0 - r) / r;
+                t_mucum[cl * ND + d] = r < 1.0 ? sum_mu : -1.0;
             }
             const double w_emit = 1.0 - det_exp(-sum_mu);
             a_hi = a_lo + w_emit;
@@ -4181,26 +4221,10 @@ __global__ __launch_bounds__(64) void k_trans_decide(DeviceState st, TransGrid t
             // ids, as one entry per copy in the order dealt would give it
             const int nt = t_n[cl];
             uint16_t *deal = s_deal + lane * ND;
-            int d_one = -1;      // the destination of a single copy
             uint32_t n_dst = 0;  // destinations that take copies
-            if (n_emit > 1) for (int y = 0; y < nt; y++) deal[y] = 0;
-            for (int q = 0; q < n_emit; q++) {
-                uint32_t v[4];
-                rng_block(seed, cell_id, step, rank, SITE_TRANS, 2u + (uint32_t)(q >> 1), v);
-                const double xq = u53(v[2 * (q & 1)], v[2 * (q & 1) + 1]) * s_mu_sum[cl];
-                double cm = 0.0;
-                int d = -1, last = -1;
-                for (int y = 0; y < nt; y++) {
-                    const double r = t_ratio[cl * ND + y];
-                    if (!(r < 1.0)) continue;
-                    cm = cm + (t_hi[cl * ND + y] - t_lo[cl * ND + y]) * (1.0 - r) / r;
-                    last = y;
-                    if (xq < cm) { d = y; break; }
-                }
-                if (d < 0) d = last;
-                if (n_emit == 1) { d_one = d; n_dst = 1; }
-                else { if (deal[d] == 0) n_dst++; deal[d] = (uint16_t)(deal[d] + 1); }
-            }
+            int d_one = -1;      // the destination of a single copy
+            if (n_emit > 0)
+                d_one = deal_copies(seed, cell_id, step, rank, n_emit, s_mu_sum[cl], t_mucum + cl * ND, nt, deal, n_dst);
             const uint32_t ne = (moves ? 1u : 0u) + n_dst;
             const uint32_t inc = wave_incl_scan_u32(ne, lane);
             const uint32_t first = n_out + inc - ne;
@@ -5937,6 +5961,57 @@ hipError_t launch_scenario_update(const DeviceState &st, double dt, double creat
                            old_height);
     return hipGetLastError();
 }
+// pmcx_set_auto_grow: how many slots the adds of a scenario update can need (an upper bound)
+__global__ __launch_bounds__(256) void k_adds_bound(DeviceState st, double dt, AeroDistDev emission,
+                                                    const double *dilution_rate, AeroDistDev background,
+                                                    const double *height, const double *old_height, int32_t *out)
+{
+    int need = 0;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < st.n_cells; c += gridDim.x * blockDim.x) {
+        if (!in_loop(st, c)) continue;
+        const double *mag = st.mag + (int64_t)c * st.n_class;
+        double b = (double)st.n_hi[c];
+        if (st.prep_on)
+            for (int q = 0; q < st.n_class; q++) b += st.n_ideal[(int64_t)c * st.n_class + q];
+        auto upper = [](double mean) { return mean > 0.0 ? mean + 6.0 * sqrt(mean) + 12.0 : 0.0; };
+        for (int m = 0; m < emission.n_mode; m++) {
+            const double nc = emission.num_conc[(int64_t)c * emission.n_mode + m];
+            const int cl = emission.mode_class ? emission.mode_class[emission.mo(c) + m] : 0;
+            if (nc > 0.0 && cl >= 0 && cl < st.n_class && mag[cl] > 0.0) b += upper(nc * dt / mag[cl]);
+        }
+        const double rate = dilution_rate ? dilution_rate[c] : 0.0;
+        const bool grew = height && height[c] > old_height[c] && old_height[c] > 0.0;
+        if ((rate > 0.0 || grew) && background.n_mode > 0) {
+            double p_keep = exp(-rate * dt);
+            if (grew) p_keep = p_keep * old_height[c] / height[c];
+            const double p_loss = 1.0 - p_keep + 1e-12;
+            for (int m = 0; m < background.n_mode; m++) {
+                const double nc = background.num_conc[(int64_t)c * background.n_mode + m];
+                const int cl = background.mode_class ? background.mode_class[background.mo(c) + m] : 0;
+                if (nc > 0.0 && cl >= 0 && cl < st.n_class && mag[cl] > 0.0) b += upper(nc * p_loss / mag[cl]);
+            }
+        }
+        const int bi = b < 1.0e9 ? (int)b + 1 : 1000000000;
+        need = bi > need ? bi : need;
+    }
+    for (int d = 32; d >= 1; d >>= 1) { const int a = __shfl_xor(need, d, 64); need = a > need ? a : need; }
+    if ((threadIdx.x & 63) == 0) atomicMax(&out[0], need);
+}
+hipError_t launch_adds_bound(const DeviceState &st, double dt, const GenSpecDev *em, const double *em_conc,
+                             const double *dilution_rate, const GenSpecDev *bg, const double *bg_conc,
+                             const double *height, const double *old_height, int32_t *out, hipStream_t s)
+{
+    AeroDistDev e{0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0}, b = e;
+    if (em) e = AeroDistDev{em->n_mode, em_conc, em->ln_gm_radius, em->ln_gsd, em->vol_frac,
+                            em->mode_class, em->mode_source, em->per_cell};
+    if (bg) b = AeroDistDev{bg->n_mode, bg_conc, bg->ln_gm_radius, bg->ln_gsd, bg->vol_frac,
+                            bg->mode_class, bg->mode_source, bg->per_cell};
+    (void)hipMemsetAsync(out, 0, sizeof(int32_t), s);
+    int g = (st.n_cells + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(k_adds_bound, dim3(g), dim3(256), 0, s, st, dt, e, dilution_rate, b, height, old_height, out);
+    return hipGetLastError();
+}
 hipError_t launch_gas_update(const GasScenarioDev &g, double *mix_rat, const double *temp,
                              const double *pressure, const double *height, const double *old_height,
                              int n_cells, double dt, double elapsed_time, hipStream_t s,
@@ -5952,7 +6027,7 @@ size_t transport_lds_bytes(const DeviceState &st, int nz)
 {
     const size_t nd = (size_t)(4 + nz), C = (size_t)st.n_class;
     // (+ law 1: three doubles per class, a lane's copies per destination while it deals them)
-    return (sizeof(double) * 4 + sizeof(int) * 3 + sizeof(uint64_t)) * C * nd + sizeof(int) * C + 24 +
+    return (sizeof(double) * 5 + sizeof(int) * 3 + sizeof(uint64_t)) * C * nd + sizeof(int) * C + 24 +
            3 * sizeof(double) * C + 8 + sizeof(uint16_t) * 64 * nd;
 }
 static TransGrid make_grid(int nx, int nz, int ny, int periodic_x, int periodic_y,
@@ -6165,7 +6240,15 @@ __global__ __launch_bounds__(256) void k_need_max(DeviceState st, const int32_t 
 {
     int need = 0, hi = 0, bits = 0;
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < st.n_cells; c += gridDim.x * blockDim.x) {
-        const int a = st.n_part[c] + (n_exp ? n_exp[c] : 0), b = st.n_hi[c];
+        int a = st.n_part[c] + (n_exp ? n_exp[c] : 0);
+        const int b = st.n_hi[c];
+        if (!n_exp && st.n_ideal) {
+            // (no arrivals counted: the slots in use plus the classes' ideal counts -- what a doubling, or
+            // the weight preparation of an add, can bring a cell in one call)
+            double s = 0.0;
+            for (int q = 0; q < st.n_class; q++) s += st.n_ideal[(int64_t)c * st.n_class + q];
+            a = b + (s < 65536.0 ? (int)s + 1 : 65536);
+        }
         need = a > need ? a : need;
         hi = b > hi ? b : hi;
         bits |= st.status[c];
