@@ -24,7 +24,7 @@ for run in range(n_runs):
     periodic = bool(rng.randint(2))
     nx, ny = (int(rng.randint(1, 6)), int(rng.randint(1, 6))) if periodic else (int(rng.randint(3, 7)), int(rng.randint(3, 7)))
     nz = int(rng.choice([1, 2, 5, 30, 61]))
-    n_class, n_spec = int(rng.choice([1, 2, 3])), int(rng.choice([1, 2]))
+    n_class, n_spec = int(rng.choice([1, 2, 3, 3, 12])), int(rng.choice([1, 2]))
     n_part = int(rng.choice([40, 200, 600]))
     n = nx * nz * ny
     if n * n_part > 400000:
@@ -37,7 +37,8 @@ for run in range(n_runs):
     blk, cells, info = parity.setup_pair(wp, oracle, n, n_part, n_spec, n_class, seed, 4, cap=int(np.ceil(n_part * 3.0 / 64) * 64),
                                          n_source=2, num_conc_scale=float(10 ** rng.uniform(0, 1.5)))
     # weights spread by up to 10x between cells, some cells empty
-    mag = info["mag"] * 10 ** rng.uniform(-0.5, 0.5, (n, 1))
+    spread = float(rng.choice([0.5, 0.5, 1.2]))       # (1.2: ratios down to 4e-3 -- movers and emitters overlap)
+    mag = info["mag"] * 10 ** rng.uniform(-spread, spread, (n, 1))
     blk.set_weights(mag)
     for c, oc in enumerate(cells):
         oc.mag[:] = mag[c]

@@ -101,6 +101,21 @@ def test_wrf_steps_through_the_two_drivers(tmp_path, wp, oracle, periodic):
         assert not np.array_equal(np.array([fc["gas"] for fc in final])[case.inside], case.gas0[case.inside])
 
 
+@pytest.mark.parametrize("n_class,periodic", [(10, False), (40, True)])
+def test_wrf_steps_with_tens_of_weight_classes(tmp_path, wp, oracle, n_class, periodic):
+    """The same seven WRF steps with 10 and 40 weight classes (WRFV3/Registry/registry.partmc_trans:2-41 carries
+    40; the real case names one per initial-condition mode, boundary mode and emission source x 2,
+    wrf_pmc_init.F90:781-786, 941-943, 1057-1059): the initial particles in two of them, emissions and the
+    background bringing others to life, sea salt into five, the rest empty throughout -- per-class fluxes,
+    probabilities, preweight, weights and rebalance through the two Fortran drivers against the oracle."""
+    _build()
+    case = wrf_case.Case(periodic=periodic, seed=61 + n_class, n_class=n_class, sea_salt_opt=2)
+    steps, final = run_case(case, tmp_path, wp, oracle)
+    used = set(int(q) for fc in final for q in np.unique(fc["wclass"]))
+    assert len(used) >= 5, used          # classes beyond the initial two came to life
+    assert sum(st["n_moved"] for st in steps) > 5 * case.n_cells and sum(st["n_coag"] for st in steps) > 0
+
+
 @pytest.mark.parametrize("periodic", [True, False])
 def test_a_rank_of_a_cut_domain_through_the_two_drivers(tmp_path, wp, periodic):
     """WRF's only production mode is its patch decomposition (namelist.input.cares_bw_full:57-58; the

@@ -19,11 +19,11 @@ class Case:
     condition), gases, sea salt over the ocean columns, transport from WRF-shaped fields, dry
     deposition on the lowest level."""
 
-    def __init__(self, nx=4, nz=3, ny=4, n_part=300, n_steps=7, periodic=False, seed=91, sea_salt_opt=1):
+    def __init__(self, nx=4, nz=3, ny=4, n_part=300, n_steps=7, periodic=False, seed=91, sea_salt_opt=1, n_class=2):
         self.nx, self.nz, self.ny, self.n_part, self.n_steps = nx, nz, ny, n_part, n_steps
         self.periodic, self.seed, self.sea_salt_opt = periodic, seed, sea_salt_opt
         self.n_cells = nx * nz * ny
-        self.n_spec, self.n_class, self.n_source, self.n_gas = 3, 2, 3, 5
+        self.n_spec, self.n_class, self.n_source, self.n_gas = 3, n_class, 3, 5
         self.i_na, self.i_cl = 2, 3                         # 1-based species of the sea-salt source
         self.dt, self.chem_dt, self.dx, self.dy = 20.0, 60.0, 3000.0, 3000.0
         self.vertmix = 1
@@ -31,7 +31,10 @@ class Case:
         self.density = np.array([1770.0, 1900.0, 1900.0])
         r = self.r = np.random.RandomState(seed)
         n = self.n_cells
-        self.n_ideal = np.tile(np.array([0.55, 0.5]) * n_part, (n, 1))
+        # (more than two classes -- the registry carries 40, registry.partmc_trans:2-41: the initial particles sit
+        # in the first two, emissions, background and sea salt bring others to life, most stay empty)
+        ideal = np.array([0.55, 0.5] + [0.12] * (n_class - 2))[:n_class] if n_class >= 2 else np.array([1.05])
+        self.n_ideal = np.tile(ideal * n_part, (n, 1))
         self.num_conc0 = 3.0e9
         self.mag = (self.num_conc0 / n_part) * np.tile(1.0 + 0.5 * np.arange(self.n_class), (n, 1))
         self.gas0 = r.uniform(0.0, 60.0, (n, self.n_gas))
@@ -59,7 +62,8 @@ class Case:
                         vf = r.uniform(0.1, 1.0, self.n_spec); vf /= vf.sum()
                         ms.append(dict(num_conc=conc_scale[m] * r.uniform(0.6, 1.4),
                                        gm_radius=radii[m] * r.uniform(0.8, 1.25), gsd_log10=r.uniform(0.12, 0.3),
-                                       vol_frac=vf, wclass=m % self.n_class, source=(m + t) % self.n_source))
+                                       vol_frac=vf, wclass=(m % self.n_class if self.n_class <= 2 else (4 * m + 1) % self.n_class),
+                                       source=(m + t) % self.n_source))
                     out.append(ms)
                 return out
             # emission: number flux per m^2 and s such that a few particles per step appear
@@ -275,7 +279,8 @@ class Case:
                     wind = float(np.sqrt(F32(u10 * u10 + v10 * v10)))
                     st, oc.next_id, _ = oc.seasalt_emissions(self.dt, t, seed, c, wrf_step, self.sea_salt_opt, wind,
                                                              float(height[c]), self.i_na - 1, self.i_cl - 1,
-                                                             [0, 1, 0, 0, 0], [0, 1, 2, 0, 0], oc.next_id)
+                                                             [m if m < self.n_class else 0 for m in range(5)], [0, 1, 2, 0, 0],
+                                                             oc.next_id)
                     assert st == 0
                 st, oc.next_id = oc.rebalance(self.n_ideal[c], True, True, seed, c, wrf_step, oc.next_id)
                 assert st == 0
