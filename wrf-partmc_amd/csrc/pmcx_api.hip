@@ -256,8 +256,9 @@ void prof_drain(pmcx_ctx *ctx)
 extern "C" {
 
 static int grow_if_needed(pmcx_ctx *ctx, const int32_t *n_exp);
-static int grow_for_adds(pmcx_ctx *ctx, double dt, const GenSpecDev *em, const double *em_conc, const double *dil,
-                         const GenSpecDev *bg, const double *bg_conc, const double *height, const double *old_height);
+static int grow_for_adds(pmcx_ctx *ctx, double dt, double elapsed_time, const GenSpecDev *em, const double *em_conc,
+                         const double *dil, const GenSpecDev *bg, const double *bg_conc, const double *height,
+                         const double *old_height);
 
 
 void pmcx_config_default(pmcx_config *cfg)
@@ -630,11 +631,12 @@ static int grow_if_needed(pmcx_ctx *ctx, const int32_t *n_exp)
 // pmcx_set_auto_grow: room for a scenario update's adds (emission, background, sea salt) -- an upper bound
 // from the Poisson means of the samples (mean + 6 sigma + 12 a mode) and, with the weight preparation on,
 // the classes' ideal counts; the block grows to 1.25 x the fullest cell's bound
-static int grow_for_adds(pmcx_ctx *ctx, double dt, const GenSpecDev *em, const double *em_conc, const double *dil,
-                         const GenSpecDev *bg, const double *bg_conc, const double *height, const double *old_height)
+static int grow_for_adds(pmcx_ctx *ctx, double dt, double elapsed_time, const GenSpecDev *em, const double *em_conc,
+                         const double *dil, const GenSpecDev *bg, const double *bg_conc, const double *height,
+                         const double *old_height)
 {
-    HIP_TRY(ctx, launch_adds_bound(ctx->st, dt, em, em_conc, dil, bg, bg_conc, height, old_height, ctx->d_need,
-                                   ctx->stream));
+    HIP_TRY(ctx, launch_adds_bound(ctx->st, dt, elapsed_time, em, em_conc, dil, bg, bg_conc, height, old_height,
+                                   ctx->d_need, ctx->stream));
     int32_t need = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&need, ctx->d_need, sizeof need, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1418,7 +1420,7 @@ int pmcx_scenario_update_aero_state(pmcx_ctx *ctx, double dt, double elapsed_tim
     if (e == hipSuccess) { e = tmp_malloc(ctx, (void **)&d_cnt, sizeof(int32_t) * 3 * nc); if (e == hipSuccess) tmp.push_back(d_cnt); }
     if (e == hipSuccess && !ctx->hold_status) e = hipMemsetAsync(ctx->st.status, 0, sizeof(int32_t) * nc, ctx->stream);
     if (e == hipSuccess && ctx->auto_grow) { // room for what the adds can bring (an upper bound; the call waits here)
-        rc = grow_for_adds(ctx, dt, emission ? &ge : nullptr, ce, d_dil, background ? &gb : nullptr, cbg, d_h,
+        rc = grow_for_adds(ctx, dt, elapsed_time, emission ? &ge : nullptr, ce, d_dil, background ? &gb : nullptr, cbg, d_h,
                            d_h ? d_h + nc : nullptr);
         if (rc) { cleanup(); return rc; }
     }
@@ -1526,7 +1528,7 @@ int pmcx_seasalt_emissions(pmcx_ctx *ctx, double dt, double elapsed_time, uint64
     if (e == hipSuccess) tmp.push_back(d_cnt);
     if (e == hipSuccess && !ctx->hold_status) e = hipMemsetAsync(ctx->st.status, 0, sizeof(int32_t) * nc, ctx->stream);
     if (e == hipSuccess && ctx->auto_grow) {
-        rc = grow_for_adds(ctx, dt, &ge, ce, nullptr, nullptr, nullptr, nullptr, nullptr);
+        rc = grow_for_adds(ctx, dt, elapsed_time, &ge, ce, nullptr, nullptr, nullptr, nullptr, nullptr);
         if (rc) { cleanup(); return rc; }
     }
     if (e == hipSuccess) {

@@ -278,9 +278,10 @@ hipError_t launch_transport_undo(const DeviceState &st, void *outbox, const int3
 // out[0] = max over the cells of an upper bound of the slots a scenario update (launch_scenario_update
 // with the same arguments) can bring a cell to: its slots in use, its classes' ideal counts (what the
 // weight preparation of an add can copy), and per mode the Poisson mean of the sample + 6 sigma + 12
-hipError_t launch_adds_bound(const DeviceState &st, double dt, const GenSpecDev *em, const double *em_conc,
-                             const double *dilution_rate, const GenSpecDev *bg, const double *bg_conc,
-                             const double *height, const double *old_height, int32_t *out, hipStream_t s);
+hipError_t launch_adds_bound(const DeviceState &st, double dt, double elapsed_time, const GenSpecDev *em,
+                             const double *em_conc, const double *dilution_rate, const GenSpecDev *bg,
+                             const double *bg_conc, const double *height, const double *old_height, int32_t *out,
+                             hipStream_t s);
 // the slots [old_cap, new_cap) of every cell of a block that has just grown: dead
 hipError_t launch_grow_tail(const DeviceState &st, int old_cap, hipStream_t s);
 hipError_t launch_test_math(int op, int64_t n, const double *a, const double *b, const double *c3,

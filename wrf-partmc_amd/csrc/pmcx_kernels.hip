@@ -5962,11 +5962,15 @@ hipError_t launch_scenario_update(const DeviceState &st, double dt, double creat
     return hipGetLastError();
 }
 // pmcx_set_auto_grow: how many slots the adds of a scenario update can need (an upper bound)
-__global__ __launch_bounds__(256) void k_adds_bound(DeviceState st, double dt, AeroDistDev emission,
+__global__ __launch_bounds__(256) void k_adds_bound(DeviceState st, double dt, double elapsed_time, AeroDistDev emission,
                                                     const double *dilution_rate, AeroDistDev background,
                                                     const double *height, const double *old_height, int32_t *out)
 {
     int need = 0;
+    // With the weight preparation on a mode's sample is drawn at the weight the preparation leaves: a class
+    // scaled to (n + mean cf) / ideal of its weight takes mean ideal / (n + mean cf) <= ideal / cf particles --
+    // ideal x dt at elapsed_time 0 into an empty class, the formula's own corner
+    const double cf = fmax(1.0, fmin(3600.0, elapsed_time)) / dt;
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < st.n_cells; c += gridDim.x * blockDim.x) {
         if (!in_loop(st, c)) continue;
         const double *mag = st.mag + (int64_t)c * st.n_class;
@@ -5974,10 +5978,15 @@ __global__ __launch_bounds__(256) void k_adds_bound(DeviceState st, double dt, A
         if (st.prep_on)
             for (int q = 0; q < st.n_class; q++) b += st.n_ideal[(int64_t)c * st.n_class + q];
         auto upper = [](double mean) { return mean > 0.0 ? mean + 6.0 * sqrt(mean) + 12.0 : 0.0; };
+        auto prepared = [&](double mean, int cl) { // the larger of the sample at the present and at the prepared weight
+            if (!st.prep_on) return mean;
+            const double at_ideal = st.n_ideal[(int64_t)c * st.n_class + cl] / cf;
+            return mean > at_ideal ? mean : at_ideal;
+        };
         for (int m = 0; m < emission.n_mode; m++) {
             const double nc = emission.num_conc[(int64_t)c * emission.n_mode + m];
             const int cl = emission.mode_class ? emission.mode_class[emission.mo(c) + m] : 0;
-            if (nc > 0.0 && cl >= 0 && cl < st.n_class && mag[cl] > 0.0) b += upper(nc * dt / mag[cl]);
+            if (nc > 0.0 && cl >= 0 && cl < st.n_class && mag[cl] > 0.0) b += upper(prepared(nc * dt / mag[cl], cl));
         }
         const double rate = dilution_rate ? dilution_rate[c] : 0.0;
         const bool grew = height && height[c] > old_height[c] && old_height[c] > 0.0;
@@ -5988,7 +5997,7 @@ __global__ __launch_bounds__(256) void k_adds_bound(DeviceState st, double dt, A
             for (int m = 0; m < background.n_mode; m++) {
                 const double nc = background.num_conc[(int64_t)c * background.n_mode + m];
                 const int cl = background.mode_class ? background.mode_class[background.mo(c) + m] : 0;
-                if (nc > 0.0 && cl >= 0 && cl < st.n_class && mag[cl] > 0.0) b += upper(nc * p_loss / mag[cl]);
+                if (nc > 0.0 && cl >= 0 && cl < st.n_class && mag[cl] > 0.0) b += upper(prepared(nc * p_loss / mag[cl], cl));
             }
         }
         const int bi = b < 1.0e9 ? (int)b + 1 : 1000000000;
@@ -5997,9 +6006,10 @@ __global__ __launch_bounds__(256) void k_adds_bound(DeviceState st, double dt, A
     for (int d = 32; d >= 1; d >>= 1) { const int a = __shfl_xor(need, d, 64); need = a > need ? a : need; }
     if ((threadIdx.x & 63) == 0) atomicMax(&out[0], need);
 }
-hipError_t launch_adds_bound(const DeviceState &st, double dt, const GenSpecDev *em, const double *em_conc,
-                             const double *dilution_rate, const GenSpecDev *bg, const double *bg_conc,
-                             const double *height, const double *old_height, int32_t *out, hipStream_t s)
+hipError_t launch_adds_bound(const DeviceState &st, double dt, double elapsed_time, const GenSpecDev *em,
+                             const double *em_conc, const double *dilution_rate, const GenSpecDev *bg,
+                             const double *bg_conc, const double *height, const double *old_height, int32_t *out,
+                             hipStream_t s)
 {
     AeroDistDev e{0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0}, b = e;
     if (em) e = AeroDistDev{em->n_mode, em_conc, em->ln_gm_radius, em->ln_gsd, em->vol_frac,
@@ -6009,7 +6019,8 @@ hipError_t launch_adds_bound(const DeviceState &st, double dt, const GenSpecDev 
     (void)hipMemsetAsync(out, 0, sizeof(int32_t), s);
     int g = (st.n_cells + 255) / 256;
     if (g > 1024) g = 1024;
-    hipLaunchKernelGGL(k_adds_bound, dim3(g), dim3(256), 0, s, st, dt, e, dilution_rate, b, height, old_height, out);
+    hipLaunchKernelGGL(k_adds_bound, dim3(g), dim3(256), 0, s, st, dt, elapsed_time, e, dilution_rate, b, height,
+                       old_height, out);
     return hipGetLastError();
 }
 hipError_t launch_gas_update(const GasScenarioDev &g, double *mix_rat, const double *temp,
