@@ -751,8 +751,9 @@ int pmcx_invalidate_sort(pmcx_ctx *ctx);
  * domain size, so that tests can hold every variant to the oracle at small sizes.  lanes: 0
  * automatic; 1 lane per cell (the full domain's kernel: with one class, one species and the
  * Brownian kernel its draw runs ahead of the sweep as a phase of its own); 3 lane per cell
- * without that; 2 its two-wavefront form (a rank's share at N = 4, 8); 8, 16, 64 lanes per cell
- * (small blocks).  wavefronts_per_group: 0
+ * without that; 2 its two-wavefront form (a rank's share at N = 4, 8); 4 lane per cell with the 256 cells
+ * of a workgroup grouped every round by what they do next (k_coag_grp; one class, one species, Brownian);
+ * 8, 16, 64 lanes per cell (small blocks).  wavefronts_per_group: 0
  * automatic, 1, 2 or 4 (the 8/16/64 kernels; with lanes = 1: 1, 2 cap the wavefronts a SIMD
  * holds).  stamps: 1 = the instantiation that records
  * cycles per stage (pmcx_profile_phase_cycles).  Results do not depend on any of them. */

@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 K_BROWN, K_SEDI, K_ADD, K_CONST, K_ZERO, K_BS = 4, 1, 2, 3, 5, 101
 
 
-@pytest.fixture(autouse=True, params=["dispatch", "lane-per-cell", "lane-per-cell-split", "lane-per-cell-one-phase"])
+@pytest.fixture(autouse=True, params=["dispatch", "lane-per-cell", "lane-per-cell-split", "lane-per-cell-one-phase",
+                                      "lane-per-cell-grouped"])
 def sampler_variant(request, monkeypatch, wp):
     """Every test of this module runs four times: with the library's own choice of sampler (the
     lanes-per-cell kernels at these cell counts), with the lane-per-cell kernel forced (the one
@@ -22,7 +23,7 @@ def sampler_variant(request, monkeypatch, wp):
     two-wavefront form (evaluator + drawer, what a rank's share of the domain runs at N = 8) and
     with the lane-per-cell kernel drawing as it sweeps, so that all are held to the oracle."""
     variant = {"lane-per-cell": (1, 0, 0), "lane-per-cell-split": (2, 0, 0),
-               "lane-per-cell-one-phase": (3, 0, 0)}.get(request.param)
+               "lane-per-cell-one-phase": (3, 0, 0), "lane-per-cell-grouped": (4, 0, 0)}.get(request.param)
     from wrf_partmc_amd import host
     monkeypatch.setattr(host, "SAMPLER_VARIANT", variant)   # -> pmcx_set_sampler_variant
     return request.param

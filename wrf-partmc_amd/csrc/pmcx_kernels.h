@@ -113,7 +113,8 @@ struct DeviceState {
     // the lane-per-cell sampler with its draw split off (k_coag_lane<.., PRE>): a cell's list of the
     // slots whose count could be non-zero, where an unfinished cell stands, the cells to finish
     uint4 *pre;        // [n_cells][128] {uniform, bound, slot, -} (nullptr: not allocated)
-    int32_t *resume;   // [n_cells][2] slot settled last (-1: none), entries in the overflow table
+    int32_t *resume;   // [n_cells][4] where a kernel left a cell to the one launched behind it: slot settled last
+                       // (-1: none), entries in the overflow table, samples of that slot still to evaluate, the next one's index
     int32_t *work2;    // [1 + n_cells] count, cells
     // particle%component(:) (interface/wrf_pmc_driver.F90:1421-1437), the first n_comp_max of a
     // particle's list (0: not carried): source ids a byte each (0xFF past the end), create times;

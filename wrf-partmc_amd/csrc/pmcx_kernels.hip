@@ -1647,8 +1647,8 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
     if (resuming && live) {
         // where the first launch left the cell (a slot boundary): what it counted so far, the slot
         // it settled last, the entries it had put in the table past the groups' rooms
-        const int32_t pos = st.resume[2 * (int64_t)c];
-        n_app = st.resume[2 * (int64_t)c + 1];
+        const int32_t pos = st.resume[4 * (int64_t)c];
+        n_app = st.resume[4 * (int64_t)c + 1];
         n_ev = st.n_events[c]; tot_coag = st.n_coag[c]; tot_samp = (uint64_t)(uint32_t)st.n_samp[c];
         if (pos >= 0) { b1 = pos & 0xFF; b2 = (pos >> 8) & 0xFF; c1 = (pos >> 16) & 0xFF; c2 = (pos >> 24) & 0xFF; }
     }
@@ -1688,6 +1688,13 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
         n1 = n2 = nmin = fmax = factor = magl[lane];
         cc = 0; rc1 = rc2 = 0;
         cf_up = (float)(fmax * del_t) * 1.000001f;
+        if (resuming && live && b1 >= 0) {
+            // left in the middle of a slot (k_coag_grp hands a cell over in front of an event its
+            // straight-line code does not cover): the samples still to evaluate, the next one's index
+            ns_rem = (uint32_t)st.resume[4 * (int64_t)c + 2];
+            s = (uint32_t)st.resume[4 * (int64_t)c + 3];
+            if (ns_rem) k_max = (double)st.kmax[(int64_t)c * st.kmax_stride + b1 * B + b2] * fmax;
+        }
     }
 
     // The slot the lane would draw next from where it stands, with the lists as they are now:
@@ -2417,8 +2424,9 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
         if (n_lg >= 0) st.n_log[c] = n_lg;
         else if (n_lg == -2) st.key_valid[c] = 0;
         if (PRE && unfinished) { // where the cell stands, for the launch behind this one
-            st.resume[2 * (int64_t)c] = b1 < 0 ? -1 : (b1 | (b2 << 8));
-            st.resume[2 * (int64_t)c + 1] = n_app;
+            st.resume[4 * (int64_t)c] = b1 < 0 ? -1 : (b1 | (b2 << 8));
+            st.resume[4 * (int64_t)c + 1] = n_app;
+            st.resume[4 * (int64_t)c + 2] = 0; st.resume[4 * (int64_t)c + 3] = 0;   // (left at a slot boundary)
             resume_count[1 + atomicAdd(resume_count, 1)] = c;
         }
         st.n_events[c] = n_ev;
@@ -2442,6 +2450,459 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
 #undef O_last_app
 #undef O_app_slot
 #undef O_app_prev
+}
+
+// ------------------------------ coag sampler, lane per cell, the cells of a workgroup grouped by what they do next
+//
+// k_coag_grp (one class, one species, Brownian: the benchmark's and the reference's configuration).  In
+// k_coag_lane a lane IS a cell for the whole sweep, and the 64 cells of a wavefront are in different states
+// -- settling slots, counting, evaluating a sample, coagulating -- so every pass runs every stage for the
+// few lanes that need it: 1 700 instructions a pass, the draw alone half of a wavefront's cycles at a sixth
+// of its lanes' use.  Here a workgroup of 256 threads owns 256 cells whose whole sweep state
+// lives in LDS, and every round the cells are sorted by what they need: those holding samples are
+// evaluated 64 to a wavefront by code that only evaluates (and coagulates), those holding none draw 64 to
+// a wavefront by code that only draws -- every lane of a chunk busy with the same stage.  Per cell the
+// sequence of operations is k_coag_lane's, and the oracle's.  Only the straight path is here: a cell whose
+// population reaches beyond the window, or whose next event needs the general code (no room behind the new
+// bin's list, a full event log, a volume outside the grid), is handed -- where it stands, in the middle of
+// a slot if need be -- to k_coag_lane, launched behind this kernel over the cells listed (st.resume).
+constexpr int GRP_NC = 256;                  // cells (threads) of a workgroup
+constexpr int GRP_SW = 32;                   // bins of a cell's window (its list state in LDS)
+#ifndef PMCX_GRP_NTRY
+#define PMCX_GRP_NTRY 8
+#endif
+#ifndef PMCX_GRP_ROUNDS
+#define PMCX_GRP_ROUNDS 3
+#endif
+constexpr uint32_t GRP_DONE = 1u, GRP_HAND = 2u;
+
+__host__ __device__ inline size_t grp_lds_bytes(int B)
+{
+    size_t o = ((size_t)(B + 1) * sizeof(double) + 15) & ~(size_t)15;       // sort-grid edges
+    o += sizeof(double) * (POISSON_RCP_N + 2);                             // 1/n of the Poisson walk
+    o += sizeof(double) * 2 * GRP_NC + sizeof(uint64_t) * 4 * GRP_NC;      // k_max, weight; the cached block and bounds
+    o += sizeof(uint32_t) * (size_t)GRP_SW * GRP_NC;                       // count | offset << 16 of the window's bins
+    o += sizeof(uint32_t) * 18 * GRP_NC;                                   // position, samples, ..., counters (18 words)
+    o += sizeof(uint16_t) * 2 * GRP_NC + sizeof(uint32_t) * 8;             // the two queues, the wavefronts' counts
+    return (o + 15) & ~(size_t)15;
+}
+
+__global__ __launch_bounds__(GRP_NC, 2) void k_coag_grp(DeviceState st, double del_t, uint64_t seed, uint32_t step,
+                                                        int32_t *resume_count)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int NC = GRP_NC, SW = GRP_SW, NTRY = PMCX_GRP_NTRY;
+    constexpr uint32_t TAG_NONE = 0xFFFFFFFFu;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int B = st.n_bin, NS = st.n_source;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    double *edge = (double *)smem;
+    double *rcp = (double *)(smem + (((size_t)(B + 1) * sizeof(double) + 15) & ~(size_t)15));
+    double *s_kmax = rcp + (POISSON_RCP_N + 2), *s_mag = s_kmax + NC;
+    uint64_t *s_wq01 = (uint64_t *)(s_mag + NC), *s_wq23 = s_wq01 + NC, *s_kq01 = s_wq23 + NC, *s_kq23 = s_kq01 + NC;
+    uint32_t *ent = (uint32_t *)(s_kq23 + NC);                       // [SW][NC]
+    uint32_t *s_pos = ent + (size_t)SW * NC;                         // (b1 + 1) | (b2 + 1) << 8 | blo << 16
+    uint32_t *s_flag = s_pos + NC, *s_ns = s_flag + NC, *s_s = s_ns + NC, *s_wmask = s_s + NC, *s_tag = s_wmask + NC;
+    float *s_env = (float *)(s_tag + NC);                            // [5][NC]
+    int32_t *s_rng = (int32_t *)(s_env + 5 * NC), *s_nev = s_rng + NC, *s_ncoag = s_nev + NC, *s_samp = s_ncoag + NC,
+            *s_status = s_samp + NC, *s_nlg = s_status + NC, *s_lo = s_nlg + NC;   // (s_lo: spare)
+    uint16_t *qD = (uint16_t *)(s_lo + NC), *qE = qD + NC;
+    uint32_t *s_cnt = (uint32_t *)(qE + NC);                         // [8]
+
+    for (int j = t; j <= B; j += NC) edge[j] = st.v_edge[j];
+    for (int j = t; j <= POISSON_RCP_N; j += NC) rcp[j] = g_poisson_rcp[j];
+#ifdef PMCX_GRP_STAMPS
+    uint64_t t_last = __builtin_amdgcn_s_memtime(), t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define GSTAMP(k) { const uint64_t t_now = __builtin_amdgcn_s_memtime(); t_acc[k] += t_now - t_last; t_last = t_now; }
+#else
+#define GSTAMP(k)
+#endif
+
+    // ---- set-up: thread t owns cell blockIdx.x * NC + t for this part and for the write-back
+    const int cidx = blockIdx.x * NC + t;
+    const bool live = cidx < st.n_cells && in_loop(st, cidx);
+    const int c_own = cidx < st.n_cells ? cidx : st.n_cells - 1;
+    if (cidx < st.n_cells && !live) { st.n_samp[cidx] = 0; st.n_coag[cidx] = 0; st.n_events[cidx] = 0; }
+    int blo_own = 0;
+    {
+        const int32_t *gc = st.gcnt + (int64_t)c_own * B;
+        const int32_t *go = st.goff + (int64_t)c_own * (B + 1);
+        uint64_t m0 = 0, m1 = 0;
+        int blo = B;
+        for (int b0 = 0; b0 < B; b0 += 8) {
+            int32_t n8[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) n8[k] = gc[min(b0 + k, B - 1)];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int b = b0 + k;
+                const bool has = b < B && n8[k] > 0;
+                const uint64_t bit = has ? 1ull << (b & 63) : 0ull;
+                if (b < 64) m0 |= bit; else m1 |= bit;
+                blo = (has && b < blo) ? b : blo;
+            }
+        }
+        if (blo > B - SW) blo = (B - SW > 0) ? B - SW : 0;
+        uint32_t e[SW];
+#pragma unroll
+        for (int k = 0; k < SW; k++) {
+            const int b = min(blo + k, B - 1);
+            e[k] = (uint32_t)gc[b] | ((uint32_t)go[b] << 16);
+        }
+#pragma unroll
+        for (int k = 0; k < SW; k++) ent[k * NC + t] = (blo + k < B) ? e[k] : 0u;
+        uint64_t w64;
+        if (blo == 0) w64 = m0;
+        else if (blo < 64) w64 = (m0 >> blo) | (m1 << (64 - blo));
+        else w64 = m1 >> (blo - 64);
+        bool far = (w64 >> 32) != 0 || (blo < 64 && (m1 >> blo) != 0);
+        if (blo > 0 && blo < 64 && (m0 & ((1ull << blo) - 1ull))) far = true;
+        if (blo >= 64 && (m0 || (m1 & ((1ull << (blo - 64)) - 1ull)))) far = true;
+        blo_own = blo;
+        uint32_t fl = live ? 0u : GRP_DONE;
+        if (live && far) fl = GRP_DONE | GRP_HAND;       // (a population beyond the window: the other kernel, from the start)
+        s_flag[t] = fl;
+        s_wmask[t] = (uint32_t)w64;
+        s_pos[t] = ((uint32_t)blo << 16);
+        s_ns[t] = 0; s_s[t] = 0; s_tag[t] = TAG_NONE; s_kmax[t] = 0.0;
+        s_wq01[t] = 0; s_wq23[t] = 0; s_kq01[t] = 0; s_kq23[t] = 0;
+        s_mag[t] = st.mag[c_own];
+        const EnvDerived ed = env_derive(st.temp[c_own], st.pressure[c_own]);
+        s_env[0 * NC + t] = (float)ed.gasfreepath; s_env[1 * NC + t] = (float)ed.inv_gfp;
+        s_env[2 * NC + t] = (float)ed.c_diff; s_env[3 * NC + t] = (float)ed.c_speed;
+        s_env[4 * NC + t] = (float)ed.c_inv_speed;
+        s_rng[t] = st.kmax_rng[4 * (int64_t)c_own + 1];
+        s_nev[t] = 0; s_ncoag[t] = 0; s_samp[t] = 0; s_status[t] = 0;
+        s_nlg[t] = st.key_valid[c_own] != 0 ? st.n_log[c_own] : -1;
+    }
+    __syncthreads();
+    GSTAMP(0)
+
+    const KernelParams kp{st.const_k, st.additive_beta};
+
+    // ---- the draw: the cell settles slots until one has samples (or the sweep is over), a few rounds of
+    // ---- NTRY tries with the fetch of the next block in between
+    auto draw = [&](int k, bool valid) {
+        const int c = min(blockIdx.x * NC + k, st.n_cells - 1);
+        const uint32_t cell_id = cell_gid(st, c);
+        const uint32_t pos = s_pos[k];
+        int b1 = (int)(pos & 255u) - 1, b2 = (int)((pos >> 8) & 255u) - 1;
+        const int blo = (int)(pos >> 16);
+        const uint32_t wmask = s_wmask[k];
+        uint32_t blk_tag = s_tag[k];
+        uint64_t wq01 = s_wq01[k], wq23 = s_wq23[k], kq01 = s_kq01[k], kq23 = s_kq23[k];
+        const double fmax = s_mag[k];
+        const float cf_up = (float)(fmax * del_t) * 1.000001f;
+        bool dr = valid, done = false, pending = false;
+        double p_mean = 0, p_u = 0, k_max = 0;
+        for (int r = 0; r < PMCX_GRP_ROUNDS; r++) {
+            if (__ballot(dr) == 0) break;
+            uint32_t want = TAG_NONE;
+            bool active = dr;
+#pragma unroll
+            for (int q = 0; q < NTRY; q++) {
+                if (active) {
+                    const int p1_ = b1 - blo, p2_ = b2 - blo;
+                    const bool rowok = b1 >= 0 && ((wmask >> p1_) & 1u);
+                    const uint32_t m = (rowok && p2_ < 31) ? (wmask & (~0u << (p2_ + 1))) : 0u;
+                    const uint32_t mr = b1 < 0 ? wmask : (p1_ < 31 ? (wmask & (~0u << (p1_ + 1))) : 0u);
+                    const int nb1 = m ? b1 : blo + __builtin_ctz(mr | 0x80000000u);
+                    const int nb2 = m ? blo + __builtin_ctz(m) : nb1;
+                    if (!m && !mr) { done = true; active = false; }
+                    else {
+                        const uint32_t tag = ((uint32_t)nb1 << 16) | ((uint32_t)nb2 & ~3u);
+                        if (tag != blk_tag) { want = tag; active = false; }
+                        else {
+                            b1 = nb1; b2 = nb2;
+                            const uint32_t dA = ent[(nb1 - blo) * NC + k], dB = ent[(nb2 - blo) * NC + k];
+                            const uint32_t hB_ = (uint32_t)nb2, sh_ = (hB_ & 1u) * 32u;
+                            const uint32_t wu_ = (uint32_t)(((hB_ & 2u) ? wq23 : wq01) >> sh_);
+                            const float kf_ = __uint_as_float((uint32_t)(((hB_ & 2u) ? kq23 : kq01) >> sh_));
+                            const uint32_t nAu = dA & 0xFFFFu, nBu = dB & 0xFFFFu;
+                            const uint32_t np_ = nb1 == nb2 ? (nAu * (nAu - 1u)) >> 1 : nAu * nBu;
+                            const float mean_up = (kf_ * cf_up) * ((float)np_ * 1.00001f);
+                            const float u_up = (float)((wu_ >> 8) + 1u) * 0x1.0p-24f;
+                            bool zero = u_up < (1.0f - mean_up) - 1e-6f;
+                            if (!zero) {
+                                const double nA_ = (double)nAu, nB_ = (double)nBu;
+                                k_max = (double)kf_ * fmax;
+                                const double n_possible_ = (nb1 == nb2) ? nA_ * (nA_ - 1.0) / 2.0 : nA_ * nB_;
+                                const double mean_ = k_max * del_t * n_possible_;
+                                const double u_ = (double)wu_ * 0x1.0p-32;
+                                zero = u_ < (1.0 - mean_) - 4e-15;
+                                if (!zero) { pending = true; p_mean = mean_; p_u = u_; active = false; }
+                            }
+                        }
+                    }
+                }
+            }
+            if (want != TAG_NONE) { // the block the sweep moves into: one Philox block, four bounds
+                uint32_t w[4];
+                rng_block(seed, cell_id, step, want, SITE_POISSON, 0, w);
+                wq01 = (uint64_t)w[0] | ((uint64_t)w[1] << 32); wq23 = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+                const int hA = (int)(want >> 16), hBq = (int)(want & 0xFFFFu);
+                const float *row = st.kmax + (int64_t)c * st.kmax_stride + hA * B;
+                const float kq0 = row[min(hBq, B - 1)], kq1 = row[min(hBq + 1, B - 1)];
+                const float kq2 = row[min(hBq + 2, B - 1)], kq3 = row[min(hBq + 3, B - 1)];
+                kq01 = (uint64_t)__float_as_uint(kq0) | ((uint64_t)__float_as_uint(kq1) << 32);
+                kq23 = (uint64_t)__float_as_uint(kq2) | ((uint64_t)__float_as_uint(kq3) << 32);
+                blk_tag = want;
+            }
+            dr = dr && !done && !pending;
+        }
+        if (valid) {
+            if (pending) {
+                const uint32_t ns = (uint32_t)poisson(p_mean, p_u, rcp);
+                s_ns[k] = ns; s_s[k] = 0; s_kmax[k] = k_max;
+                s_samp[k] = (int32_t)((uint32_t)s_samp[k] + ns);
+            }
+            if (done) s_flag[k] = s_flag[k] | GRP_DONE;
+            s_pos[k] = (uint32_t)(b1 + 1) | ((uint32_t)(b2 + 1) << 8) | ((uint32_t)blo << 16);
+            s_tag[k] = blk_tag; s_wq01[k] = wq01; s_wq23[k] = wq23; s_kq01[k] = kq01; s_kq23[k] = kq23;
+        }
+    };
+
+    // ---- one sample of the cell's slot: the pair, its records, kernel and accept, the coagulation
+    auto eval = [&](int k, bool valid) {
+        const int c = min(blockIdx.x * NC + k, st.n_cells - 1);
+        const int64_t cb = (int64_t)c * st.cap;
+        const uint32_t cell_id = cell_gid(st, c);
+        uint16_t *perm = st.perm + (int64_t)c * st.pcap;
+        Hot *hot = st.hot + cb;
+        Cold *cold = st.cold + cb;
+        const uint32_t pos = s_pos[k];
+        const int b1 = (int)(pos & 255u) - 1, b2 = (int)((pos >> 8) & 255u) - 1, blo = (int)(pos >> 16);
+        uint32_t ns_rem = valid ? s_ns[k] : 0u, s = s_s[k];
+        const double k_max = s_kmax[k], factor = s_mag[k];
+        uint32_t wmask = s_wmask[k];
+        int n_ev = s_nev[k], n_lg = s_nlg[k], status = 0, tot_coag = s_ncoag[k];
+        const bool same = b1 == b2;
+        bool evalid = false, acc = false, hand = false;
+        int i1 = 0, i2 = 0;
+        uint32_t p1 = 0, p2 = 0, last1 = 0, last2 = 0, last1b = 0, eA = 0, eB = 0;
+        double u_acc = 0;
+        if (ns_rem > 0) {
+            eA = ent[(b1 - blo) * NC + k];
+            eB = same ? eA : ent[(b2 - blo) * NC + k];
+            const int nA = (int)(eA & 0xFFFFu), nB = (int)(eB & 0xFFFFu);
+            if (nA < 1 || nB < 1 || (same && nA < 2)) {
+                ns_rem = 0; // a list ran out: the slot ends
+            } else {
+                uint32_t w[4];
+                rng_block(seed, cell_id, step, ((uint32_t)b1 << 16) | (uint32_t)b2, SITE_CAND, s, w);
+                i1 = (int)index_of(w[0], (uint32_t)nA);
+                if (same) {
+                    i2 = (int)index_of(w[1], (uint32_t)(nA - 1));
+                    if (i2 >= i1) i2++;
+                } else {
+                    i2 = (int)index_of(w[1], (uint32_t)nB);
+                }
+                u_acc = u53(w[2], w[3]);
+                p1 = perm[(eA >> 16) + i1];
+                p2 = perm[(eB >> 16) + i2];
+                last1 = perm[(eA >> 16) + nA - 1];
+                last2 = perm[(eB >> 16) + nB - 1];
+                if (same) last1b = perm[(eA >> 16) + nA - 2];
+                evalid = true;
+            }
+        }
+        double v1 = 0, v2 = 0, m1 = 0, m2 = 0, lct1 = 0, lct2 = 0, gct1 = 0, gct2 = 0;
+        int32_t no1 = 0, no2 = 0;
+        if (evalid) {
+            const double2 a1 = *(const double2 *)&hot[p1].vtot, a2 = *(const double2 *)&hot[p2].vtot;
+            const double2 t1 = *(const double2 *)&hot[p1].lct, t2 = *(const double2 *)&hot[p2].lct;
+            v1 = a1.x; m1 = a1.y; v2 = a2.x; m2 = a2.y;
+            lct1 = t1.x; gct1 = t1.y; lct2 = t2.x; gct2 = t2.y;
+            if (NS > 0) { no1 = cold[p1].n_orig0; no2 = cold[p2].n_orig0; }
+        }
+        if (evalid) {
+            const double t_u = u_acc * k_max;
+            bool need64 = true;
+            {
+                EnvF32 ef;
+                ef.gasfreepath = s_env[0 * NC + k]; ef.inv_gfp = s_env[1 * NC + k];
+                ef.c_diff = s_env[2 * NC + k]; ef.c_speed = s_env[3 * NC + k]; ef.c_inv_speed = s_env[4 * NC + k];
+                bool ok;
+                const float k32 = brown_screen_f32(v1, m1, v2, m2, ef, ok);
+                const double kf32 = (double)k32 * factor;
+                const double lo = kf32 * (1.0 - (double)BROWN_SCREEN_MARGIN);
+                const double hi = kf32 * (1.0 + (double)BROWN_SCREEN_MARGIN);
+                if (ok && k32 > 1.0e-30f && hi <= k_max && (t_u < lo || !(t_u < hi))) {
+                    need64 = false;
+                    acc = t_u < lo;
+                }
+            }
+            if (need64) { // (some lane within a thousandth of the accept line: a few chunks in a hundred)
+                const EnvDerived env = env_derive(st.temp[c], st.pressure[c]);
+                const PartProps qa = props_for(KERNEL_BROWN, v1, m1, env);
+                const PartProps qb = props_for(KERNEL_BROWN, v2, m2, env);
+                const double kk = kernel_pair(KERNEL_BROWN, v1, v2, qa, qb, kp);
+                const double kf = kk * factor;
+                if (kf > k_max) status |= ST_KMAX_EXCEEDED;
+                acc = t_u < kf;
+            }
+        }
+        if (evalid && acc) {
+            const double vn = v1 + v2, mn = m1 + m2;
+            const bool big1 = (v1 >= v2);
+            const uint32_t pn = big1 ? p1 : p2, po = big1 ? p2 : p1;
+            int in = big1 ? i1 : i2;
+            const int io = big1 ? i2 : i1;
+            const int b_old = big1 ? b1 : b2, b_o = big1 ? b2 : b1;
+            const uint32_t e_o = big1 ? eB : eA;
+            const int b_new = bin_index(edge, B, vn, st);
+            const bool move = b_new != b_old;
+            const bool in_grid = !(vn < edge[0] || vn >= edge[B]);
+            bool ok = n_ev < st.max_events && in_grid &&
+                      (!move || ((unsigned)(b_new - blo) < (unsigned)(SW - 1) && b_new + 1 < B));
+            uint32_t en = 0;
+            if (ok && move) {
+                en = ent[(b_new - blo) * NC + k];
+                const uint32_t nxt = ent[(b_new + 1 - blo) * NC + k];
+                ok = (int)(en >> 16) + (int)(en & 0xFFFFu) < (int)(nxt >> 16);
+            }
+            if (!ok) {
+                hand = true;          // the general event: the other kernel, from this very sample
+            } else {
+                auto cnt_set = [&](int b, uint32_t e, int n) {
+                    ent[(b - blo) * NC + k] = (e & 0xFFFF0000u) | (uint32_t)n;
+                    if (n == 0) wmask &= ~(1u << (b - blo));
+                    else wmask |= 1u << (b - blo);
+                };
+                auto log_key = [&](uint32_t slot, uint32_t key) {
+                    if (n_lg >= 0) {
+                        if (n_lg < EVLOG_CAP) st.evlog[(int64_t)c * EVLOG_CAP + n_lg++] = slot | (key << 16);
+                        else n_lg = -2;
+                    }
+                };
+                if (b_new > s_rng[k]) status |= ST_KMAX_RANGE; // no bound was computed there
+                n_ev++;
+                if (st.mlog)
+                    st.mlog[(int64_t)c * st.max_events + n_ev - 1] = (uint64_t)pn | ((uint64_t)po << 16) | ((uint64_t)big1 << 32);
+                // swap-with-last removal of the other particle
+                const int last_o = (int)(e_o & 0xFFFFu) - 1;
+                if (io != last_o) perm[(e_o >> 16) + io] = big1 ? last2 : last1;
+                cnt_set(b_o, e_o, last_o);
+                if (same && in == last_o) in = io;
+                if (move) {
+                    uint32_t e = big1 ? eA : eB;
+                    uint32_t lastv = big1 ? last1 : last2;
+                    if (same) { // (the list as the removal above left it)
+                        e = (e_o & 0xFFFF0000u) | (uint32_t)last_o;
+                        lastv = (io == last_o - 1) ? last1 : last1b;
+                    }
+                    const int last = (int)(e & 0xFFFFu) - 1;
+                    if (in != last) perm[(e >> 16) + in] = lastv;
+                    cnt_set(b_old, e, last);
+                    const int n = (int)(en & 0xFFFFu);
+                    perm[(en >> 16) + n] = pn;
+                    cnt_set(b_new, en, n + 1);
+                    log_key(pn, (uint32_t)b_new);
+                }
+                log_key(po, 0xFFFFu);
+                *(double2 *)&hot[pn].vtot = make_double2(vn, mn);
+                {
+                    const double lo_n = big1 ? lct1 : lct2, lo_o = big1 ? lct2 : lct1;
+                    const double go_n = big1 ? gct1 : gct2, go_o = big1 ? gct2 : gct1;
+                    if (lo_o < lo_n || go_o > go_n)
+                        *(double2 *)&hot[pn].lct = make_double2(lo_o < lo_n ? lo_o : lo_n, go_o > go_n ? go_o : go_n);
+                    if (NS > 0) cold[pn].n_orig0 = (int32_t)((uint32_t)no1 + (uint32_t)no2);
+                }
+                for (int sp = 1; sp < NS; sp++) {
+                    int32_t *a = &norig(st, cb, sp, pn);
+                    *a = (int32_t)((uint32_t)*a + (uint32_t)norig(st, cb, sp, po));
+                }
+                hot[po].vtot = -1.0; // tombstone: in the record just read
+                tot_coag++;
+            }
+        }
+        if (valid) {
+            if (hand) {
+                s_flag[k] = s_flag[k] | GRP_DONE | GRP_HAND;     // (s, ns_rem as they stand: this sample is the other kernel's)
+            } else if (evalid) {
+                s++; ns_rem--;
+            }
+            s_ns[k] = hand ? ns_rem : ns_rem; s_s[k] = s;
+            s_wmask[k] = wmask; s_nev[k] = n_ev; s_nlg[k] = n_lg; s_ncoag[k] = tot_coag;
+            if (status) s_status[k] = s_status[k] | status;
+        }
+    };
+
+    // ---- rounds: the workgroup's cells sorted by what they do next, 64 of a kind to a wavefront
+    while (true) {
+        const uint32_t fl = s_flag[t], nsv = s_ns[t];
+        const bool wE = !(fl & GRP_DONE) && nsv > 0, wD = !(fl & GRP_DONE) && nsv == 0;
+        const uint64_t mE = __ballot(wE), mD = __ballot(wD);
+        if (lane == 0) { s_cnt[wave] = (uint32_t)__popcll(mD); s_cnt[4 + wave] = (uint32_t)__popcll(mE); }
+        __syncthreads();
+        int baseD = 0, baseE = 0, nD = 0, nE = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            if (w < wave) { baseD += (int)s_cnt[w]; baseE += (int)s_cnt[4 + w]; }
+            nD += (int)s_cnt[w]; nE += (int)s_cnt[4 + w];
+        }
+        if (wD) qD[baseD + __popcll(mD & lt)] = (uint16_t)t;
+        if (wE) qE[baseE + __popcll(mE & lt)] = (uint16_t)t;
+        __syncthreads();
+        GSTAMP(1)
+        if (nD + nE == 0) break;
+        const int chE = (nE + 63) >> 6, chD = (nD + 63) >> 6;
+        for (int ch = wave; ch < chE + chD; ch += 4) {
+            if (ch < chE) {
+                const int idx = ch * 64 + lane;
+                eval(idx < nE ? (int)qE[idx] : 0, idx < nE);
+                GSTAMP(2)
+#ifdef PMCX_GRP_STAMPS
+                t_acc[6]++;
+#endif
+            } else {
+                const int idx = (ch - chE) * 64 + lane;
+                draw(idx < nD ? (int)qD[idx] : 0, idx < nD);
+                GSTAMP(3)
+#ifdef PMCX_GRP_STAMPS
+                t_acc[7]++;
+#endif
+            }
+        }
+        __syncthreads();
+        GSTAMP(4)
+#ifdef PMCX_GRP_STAMPS
+        t_acc[10]++;
+#endif
+    }
+
+    // ---- write-back (thread t: its own cell)
+    if (live) {
+        const int c = cidx;
+        const uint32_t fl = s_flag[t];
+        int32_t *gc = st.gcnt + (int64_t)c * B;
+        for (int k = 0; k < SW && blo_own + k < B; k++) gc[blo_own + k] = (int32_t)(ent[k * NC + t] & 0xFFFFu);
+        const int n_lg = s_nlg[t];
+        if (n_lg >= 0) st.n_log[c] = n_lg;
+        else if (n_lg == -2) st.key_valid[c] = 0;
+        st.n_samp[c] = s_samp[t];
+        st.n_events[c] = s_nev[t];
+        st.n_part[c] = st.n_part[c] - s_ncoag[t];
+        st.n_coag[c] = s_ncoag[t];
+        if (s_status[t]) atomicOr(&st.status[c], s_status[t]);
+        if (fl & GRP_HAND) { // where the cell stands, for the kernel launched behind this one
+            const uint32_t pos = s_pos[t];
+            const int b1 = (int)(pos & 255u) - 1, b2 = (int)((pos >> 8) & 255u) - 1;
+            st.resume[4 * (int64_t)c] = b1 < 0 ? -1 : (b1 | (b2 << 8));
+            st.resume[4 * (int64_t)c + 1] = 0;
+            st.resume[4 * (int64_t)c + 2] = (int32_t)s_ns[t];
+            st.resume[4 * (int64_t)c + 3] = (int32_t)s_s[t];
+            resume_count[1 + atomicAdd(resume_count, 1)] = c;
+        }
+    }
+#ifdef PMCX_GRP_STAMPS
+    GSTAMP(5)
+    if (lane == 0) {
+        for (int k = 0; k < 11; k++) atomicAdd(&g_seq_stamps[k], (unsigned long long)t_acc[k]);
+        atomicAdd(&g_seq_stamps[11], 1ull);
+    }
+#endif
+#undef GSTAMP
 }
 
 hipError_t seq_stamps_read(uint64_t out[12], bool reset)
@@ -5622,6 +6083,7 @@ int sampler_lanes(const DeviceState &st, int ktype)
     const int fl = st.force_lanes;
     const bool seq_fits = seq_lds_bytes(st.n_bin, st.n_class) + SEQ_SHARED_BYTES <= 64 * 1024;
     if (fl == 1) return pre_available(st, ktype) ? 1 : (seq_fits ? 3 : 64);
+    if (fl == 4) return pre_available(st, ktype) ? 4 : (seq_fits ? 3 : 64);   // (k_coag_grp: the configuration PRE runs on)
     if ((fl == 2 || fl == 3) && seq_fits) return fl;
     if (fl == 8 || fl == 16 || fl == 64) return fl;
     // One lane per cell with the draw split off wherever a wavefront's own chain is the floor --
@@ -5788,7 +6250,8 @@ hipError_t launch_bin_sort(const DeviceState &st, hipStream_t s)
 }
 bool coag_sample_splits_draw(const DeviceState &st, int ktype)
 {
-    return sampler_lanes(st, ktype) == 1;
+    const int L = sampler_lanes(st, ktype);
+    return L == 1 || L == 4;      // (the forms that leave cells to a second launch: pmcx_get_sampler_info counts them)
 }
 static hipError_t launch_coag_sample_only(const DeviceState &st, int ktype, double del_t, uint64_t seed,
                                           uint32_t step, hipStream_t s)
@@ -5808,6 +6271,17 @@ static hipError_t launch_coag_sample_only(const DeviceState &st, int ktype, doub
         else
             hipLaunchKernelGGL((k_coag_lane<false, false, 0, true>), grid, block, lds, s, st, ktype,
                                del_t, seed, step, st.seq_ovf, (const int32_t *)nullptr, (int32_t *)nullptr);
+        return hipGetLastError();
+    }
+    if (L == 4) { // the cells of a workgroup grouped by what they do next; what it hands over: the one-phase kernel
+        (void)hipMemsetAsync(st.work2, 0, sizeof(int32_t), s);
+        const size_t lds_g = grp_lds_bytes(st.n_bin);
+        allow_lds(k_coag_grp, lds_g);
+        hipLaunchKernelGGL(k_coag_grp, dim3((st.n_cells + GRP_NC - 1) / GRP_NC), dim3(GRP_NC), lds_g, s, st, del_t, seed,
+                           step, st.work2);
+        hipLaunchKernelGGL((k_coag_lane<false, true, KERNEL_BROWN>), dim3((st.n_cells + 63) / 64), dim3(64),
+                           seq_lds_bytes(st.n_bin, st.n_class), s, st, ktype, del_t, seed, step, st.seq_ovf,
+                           (const int32_t *)(st.work2 + 1), st.work2);
         return hipGetLastError();
     }
     if (L == 1 || L == 3) {
