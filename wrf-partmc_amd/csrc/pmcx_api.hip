@@ -399,13 +399,15 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
     A_(st.gkey, nc * cap); A_(st.key_valid, nc); A_(st.evlog, nc * (size_t)EVLOG_CAP); A_(st.n_log, nc);
     A_(st.seq_ovf, nc * (2 * G + 2 * (size_t)cfg->max_appends));
     A_(st.n_events, nc); A_(st.n_samp, nc); A_(st.n_coag, nc); A_(st.status, nc);
-    if (cfg->n_spec == 1 && cfg->n_class == 1) { // the sampler's split-off draw (2 KB per cell)
+    if (cfg->n_class == 1) { // the sampler's split-off draw (2 KB per cell)
         A_(st.pre, nc * 128); A_(st.resume, nc * 4); A_(st.work2, nc + 1);
     }
     if (cfg->n_comp_max > 0) { // particle%component(:): 8 (1 + n_comp_max) bytes per slot
         A_(st.comp_src, nc * cap); A_(st.comp_time, nc * cap * (size_t)cfg->n_comp_max);
-        A_(st.mlog, nc * (size_t)cfg->max_events);
     }
+    // the coagulations of a call in event order, a word each: what k_vol_merge (species volumes) and
+    // k_comp_merge (component lists) apply behind the sampler
+    if (cfg->n_comp_max > 0 || cfg->n_spec > 1) A_(st.mlog, nc * (size_t)cfg->max_events);
     A_(ctx->d_totals, (size_t)4);
     A_(ctx->d_acc, (size_t)4);
     A_(ctx->d_diag, nc * (size_t)(2 + 2 * nd));

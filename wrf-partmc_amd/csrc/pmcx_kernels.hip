@@ -1224,20 +1224,11 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
         n_ev++;
         if (st.mlog && lead)
             st.mlog[(int64_t)c * st.max_events + n_ev - 1] = (uint64_t)pn | ((uint64_t)po << 16) | ((uint64_t)pn_is_1 << 32);
-        // Species volumes, source histogram, create times and class of the merged
-        // particle [aero_particle_coagulate]: loads go out now and are consumed after
-        // the list updates below; lanes of the group split the species.
-        // (with one species the plane is not kept current, see spec_vol: nothing to merge)
-        const int S = st.n_spec > 1 ? st.n_spec : 0, NS = st.n_source;
-        double mv_a[3] = {0, 0, 0}, mv_b[3] = {0, 0, 0}; // up to 3 species per lane at L = 8
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const int sp = gl + k * L;
-            if (sp < S) {
-                mv_a[k] = ld_f64(&st.vol[(cb + pn) * S + sp]);
-                mv_b[k] = ld_f64(&st.vol[(cb + po) * S + sp]);
-            }
-        }
+        // Source histogram, create times and class of the merged particle
+        // [aero_particle_coagulate]: loads go out now and are consumed after the list
+        // updates below.  (The species volumes are summed behind the sampler, from the log:
+        // k_vol_merge.)
+        const int NS = st.n_source;
         double lo_n = 0, lo_o = 0, go_n = 0, go_o = 0;
         if (lead) {
             lo_n = ld_f64(&st.hot[cb + pn].lct); lo_o = ld_f64(&st.hot[cb + po].lct);
@@ -1260,15 +1251,6 @@ __global__ __launch_bounds__(256, 3) void k_coag_sample(DeviceState st, int ktyp
             if (C > 1) st_u32((uint32_t *)&st.wclass[cb + pn], (uint32_t)cc);
         }
         {
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const int sp = gl + k * L;
-                if (sp < S) st_f64(&st.vol[(cb + pn) * S + sp], mv_a[k] + mv_b[k]);
-            }
-            for (int sp = gl + 3 * L; sp < S; sp += L) { // more than 3*L species: plain loop
-                double *a = &st.vol[(cb + pn) * S + sp];
-                st_f64(a, ld_f64(a) + ld_f64(&st.vol[(cb + po) * S + sp]));
-            }
             for (int sp = gl; sp < NS; sp += L) {
                 uint32_t *a = (uint32_t *)&norig(st, cb, sp, pn);
                 st_u32(a, ld_u32(a) + ld_u32((uint32_t *)&norig(st, cb, sp, po)));
@@ -1367,9 +1349,12 @@ __host__ __device__ inline size_t seq_lds_bytes(int B, int C, int W = SEQ_W)
 // and accept | unused | coagulation), [8] write-back, [9] draws, [10] passes, [11] wavefronts
 __device__ unsigned long long g_seq_stamps[12];
 
-// SIMPLE: one species and one weight class known at compile time (the idealised reference
-// initial condition, wrf_pmc_init.F90:1766-1770): the species loop, the weighted-removal
-// draws and the class bookkeeping fold away, which is worth registers in the hot loop.
+// SIMPLE: one weight class known at compile time (the idealised reference initial condition,
+// wrf_pmc_init.F90:1766-1770): the weighted-removal draws and the class bookkeeping fold away,
+// which is worth registers in the hot loop.  (No sampler touches the species volumes: a pair is
+// evaluated from the cached total volume and mass, an event logs its two slots and k_vol_merge
+// sums the species behind the sampler in event order -- what the oracle does, pmco.c "apply the
+// event log".)
 // KT: the coagulation kernel when known at compile time (COAG_KERNEL_TYPE_BROWN, the one the
 // reference selects, wrf_pmc_driver.F90:192), 0 = chosen at run time.
 
@@ -1453,7 +1438,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 2 : PMCX_LANE_WAVES)
 void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint32_t step,
                 uint16_t *ovf_mem, const int32_t *resume_list, int32_t *resume_count)
 {
-    static_assert(!PRE || (SIMPLE && !SPLIT && KT == KERNEL_BROWN), "PRE: one class, one species, Brownian");
+    static_assert(!PRE || (SIMPLE && !SPLIT && KT == KERNEL_BROWN), "PRE: one class, Brownian");
     // the second launch: only the cells the first one listed (nothing listed: nothing to do)
     if (!PRE && resume_list && (int)blockIdx.x * 64 >= *resume_count) return;
     uint64_t t_last = 0, t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1476,7 +1461,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
     if (cidx < st.n_cells && !live && role_e) { st.n_samp[cidx] = 0; st.n_coag[cidx] = 0; st.n_events[cidx] = 0; }
     const int ktype = KT ? KT : ktype_rt;
     const int B = st.n_bin, C = SIMPLE ? 1 : st.n_class, G = B * C;
-    const int S = SIMPLE ? 1 : st.n_spec, NS = st.n_source;
+    const int NS = st.n_source;
     const int64_t cb = (int64_t)c * st.cap;
     const uint32_t cell_id = cell_gid(st, c);
 
@@ -1869,7 +1854,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
         int gA = 0, gB = 0;
         bool same = false;
         double v1 = 0, v2 = 0, m1 = 0, m2 = 0;
-        double vol1 = 0, vol2 = 0, lct1 = 0, lct2 = 0, gct1 = 0, gct2 = 0; // first species, times
+        double lct1 = 0, lct2 = 0, gct1 = 0, gct2 = 0; // create times
         int32_t no1 = 0, no2 = 0;               // first source
 
         // ---- drawing lanes (no samples in hand): settle slots inside the cached block, fetch the
@@ -2117,9 +2102,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
             const double2 t1 = *(const double2 *)&hot[p1].lct, t2 = *(const double2 *)&hot[p2].lct;
             v1 = a1.x; m1 = a1.y; v2 = a2.x; m2 = a2.y;
             lct1 = t1.x; gct1 = t1.y; lct2 = t2.x; gct2 = t2.y;
-            // (with one species the volume of that species IS the cached total: both are sums
-            // of the same terms)
-            if (S > 1) { vol1 = st.vol[(cb + p1) * S]; vol2 = st.vol[(cb + p2) * S]; }
+            // (the species volumes are summed behind the sampler, from the log: k_vol_merge)
             if (NS > 0) { no1 = cold[p1].n_orig0; no2 = cold[p2].n_orig0; }
         }
         STAMP(4)
@@ -2345,21 +2328,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                 }
                 if (rem_o) PMCX_LOG(po, 0xFFFFu)
                 *(double2 *)&hot[pn].vtot = make_double2(vn, mn);
-                // species volumes, source histogram, create times, class [aero_particle_coagulate]
-                if (S > 1) st.vol[(cb + pn) * S] = (pn_is_1 ? vol1 : vol2) + (pn_is_1 ? vol2 : vol1);
-                for (int s0 = 1; s0 < S; s0 += 4) { // four species' loads in flight
-                    double a[4], b[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        if (s0 + k < S) {
-                            a[k] = st.vol[(cb + pn) * S + (s0 + k)];
-                            b[k] = st.vol[(cb + po) * S + (s0 + k)];
-                        }
-#pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        if (s0 + k < S)
-                            st.vol[(cb + pn) * S + (s0 + k)] = a[k] + b[k];
-                }
+                // source histogram, create times, class [aero_particle_coagulate]
                 for (int sp = 1; sp < NS; sp++) {
                     int32_t *a = &norig(st, cb, sp, pn);
                     *a = (int32_t)((uint32_t)*a + (uint32_t)norig(st, cb, sp, po));
@@ -2913,6 +2882,79 @@ hipError_t seq_stamps_read(uint64_t out[12], bool reset)
         e = hipMemcpyToSymbol(HIP_SYMBOL(g_seq_stamps), z, sizeof(z));
     }
     return e;
+}
+
+// ------------------------------------------------------------- species volumes
+//
+// aero_particle_coagulate's vol(:) = vol1(:) + vol2(:) [upstream, uncited; the container:
+// interface/wrf_pmc_driver.F90:1419-1466].  No sampler reads a species volume (pairs are evaluated
+// from the cached totals), so the sums are made here, behind the sampler, from the slots it logged
+// (DeviceState::mlog) -- in event order wherever that matters: a wavefront per cell, 64 events at
+// a time, each given the level 1 + the highest level among the earlier events that wrote a slot it
+// reads (a particle that coagulated twice) and no level below that of an earlier event that read the
+// slot it writes, the events of a level summed together, lanes over
+// (event, species): 160 contiguous bytes per particle at the reference's 20 species, every load of
+// a level in flight before its first store.  Same sums in the same order as a sampler that adds the
+// species at the event (which it did until round 4: a lane per cell walking 20 species through five
+// dependent round trips was three quarters of the sampler's time at 20 species).
+__global__ __launch_bounds__(256) void k_vol_merge(DeviceState st)
+{
+    __shared__ uint32_t s_ev[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int S = st.n_spec;
+    for (int c = blockIdx.x * 4 + wave; c < st.n_cells; c += gridDim.x * 4) {
+        if (!in_loop(st, c)) continue;
+        const int n_ev = min(st.n_events[c], st.max_events);
+        const uint64_t *lg = st.mlog + (int64_t)c * st.max_events;
+        double *vol = st.vol + (int64_t)c * st.cap * S;
+        for (int e0 = 0; e0 < n_ev; e0 += 64) {
+            const int ne = min(64, n_ev - e0);
+            uint32_t pn = 0xFFFFFFFFu, po = 0xFFFFFFFEu;
+            if (lane < ne) {
+                const uint64_t ev = lg[e0 + lane];
+                pn = (uint32_t)(ev & 0xFFFFu); po = (uint32_t)((ev >> 16) & 0xFFFFu);
+            }
+            int level = 0, top = 0;
+            for (int i = 0; i + 1 < ne; i++) { // (uniform) event i's level is final when the loop reaches it
+                const uint32_t pi = (uint32_t)__builtin_amdgcn_readlane((int)pn, i);
+                const uint32_t qi = (uint32_t)__builtin_amdgcn_readlane((int)po, i);
+                const int li = __builtin_amdgcn_readlane(level, i);
+                if (lane > i && (pi == pn || pi == po)) level = max(level, li + 1);
+                // (event i reads a slot this one writes -- its other particle, kept by the weighted removal:
+                // not before it; the same level will do, a level's loads go out in event order before its stores)
+                if (lane > i && qi == pn) level = max(level, li);
+            }
+            top = level;
+            for (int d = 32; d >= 1; d >>= 1) top = max(top, __shfl_xor(top, d, 64));
+            for (int lv = 0; lv <= top; lv++) {
+                // the events of this level, side by side in LDS: pn | po << 16
+                const uint64_t m = __ballot(lane < ne && level == lv);
+                if (lane < ne && level == lv) s_ev[wave][__popcll(m & ((1ull << lane) - 1ull))] = pn | (po << 16);
+                const int items = (int)__popcll(m) * S;
+                __threadfence_block(); // (one wavefront: the LDS words; the stores of the level before this one)
+                for (int it0 = 0; it0 < items; it0 += 256) {
+                    double a[4], b[4];
+                    int64_t dst[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int it = it0 + u * 64 + lane;
+                        dst[u] = -1;
+                        if (it < items) {
+                            const int k = it / S, sp = it - k * S;
+                            const uint32_t w = s_ev[wave][k];
+                            dst[u] = (int64_t)(w & 0xFFFFu) * S + sp;
+                            a[u] = vol[dst[u]];
+                            b[u] = vol[(int64_t)(w >> 16) * S + sp];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (dst[u] >= 0) vol[dst[u]] = a[u] + b[u];
+                }
+                __threadfence_block();
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------- components
@@ -6075,7 +6117,7 @@ size_t sampler_lds_bytes_per_cell(const DeviceState &st)
 // (tests hold every form to the oracle at small sizes).
 static bool pre_available(const DeviceState &st, int ktype)
 {
-    return st.n_spec == 1 && st.n_class == 1 && ktype == KERNEL_BROWN && (st.n_bin & 3) == 0 && st.pre != nullptr &&
+    return st.n_class == 1 && ktype == KERNEL_BROWN && (st.n_bin & 3) == 0 && st.pre != nullptr &&
            seq_lds_bytes(st.n_bin, st.n_class, 32) <= 64 * 1024;
 }
 int sampler_lanes(const DeviceState &st, int ktype)
@@ -6261,7 +6303,7 @@ static hipError_t launch_coag_sample_only(const DeviceState &st, int ktype, doub
     if (L == 2) { // lane per cell, two wavefronts (evaluator, drawer) per 64 cells
         const dim3 grid((st.n_cells + 63) / 64), block(128);
         const size_t lds = seq_lds_bytes(st.n_bin, st.n_class) + SEQ_SHARED_BYTES;
-        const bool simple = st.n_spec == 1 && st.n_class == 1;
+        const bool simple = st.n_class == 1;
         if (simple && ktype == KERNEL_BROWN)
             hipLaunchKernelGGL((k_coag_lane<false, true, KERNEL_BROWN, true>), grid, block, lds, s, st,
                                ktype, del_t, seed, step, st.seq_ovf, (const int32_t *)nullptr, (int32_t *)nullptr);
@@ -6291,7 +6333,7 @@ static hipError_t launch_coag_sample_only(const DeviceState &st, int ktype, doub
         // (diagnostic: wavefronts_per_group = n caps the wavefronts a SIMD holds at n by padding LDS)
         if ((st.force_wpb == 1 || st.force_wpb == 2) && lds < (size_t)160 * 1024 / (4 * st.force_wpb) - 1024)
             lds = (size_t)160 * 1024 / (4 * st.force_wpb) - 1024;
-        const bool simple = st.n_spec == 1 && st.n_class == 1;
+        const bool simple = st.n_class == 1;
         const int32_t *no_list = nullptr;
         int32_t *no_count = nullptr;
 #define PMCX_LAUNCH_LANE(STAMPS_, SIMPLE_, KT_)                                                     \
@@ -6347,7 +6389,12 @@ hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, ui
                               uint32_t step, hipStream_t s)
 {
     const hipError_t e = launch_coag_sample_only(st, ktype, del_t, seed, step, s);
-    if (e != hipSuccess || !st.n_comp_max) return e;
+    if (e != hipSuccess) return e;
+    if (st.n_spec > 1) {
+        const int n_wg = (st.n_cells + 3) / 4;
+        hipLaunchKernelGGL(k_vol_merge, dim3(n_wg < 16384 ? n_wg : 16384), dim3(256), 0, s, st);
+    }
+    if (!st.n_comp_max) return hipGetLastError();
     hipLaunchKernelGGL(k_comp_merge, dim3((st.n_cells + 63) / 64), dim3(64), 0, s, st);
     return hipGetLastError();
 }
