@@ -14,16 +14,19 @@ K_BROWN, K_SEDI, K_ADD, K_CONST, K_ZERO, K_BS = 4, 1, 2, 3, 5, 101
 
 
 @pytest.fixture(autouse=True, params=["dispatch", "lane-per-cell", "lane-per-cell-split", "lane-per-cell-one-phase",
-                                      "lane-per-cell-grouped"])
+                                      "lane-per-cell-grouped", "lanes-per-cell"])
 def sampler_variant(request, monkeypatch, wp):
-    """Every test of this module runs four times: with the library's own choice of sampler (the
-    lanes-per-cell kernels at these cell counts), with the lane-per-cell kernel forced (the one
+    """Every test of this module runs six times: with the library's own choice of sampler (the
+    lanes-per-cell kernels at these cell counts with one weight class; with several, the screen and the
+    sweep of its list, k_coag_screen + k_coag_lane<LISTED>), with the lane-per-cell kernel forced (the one
     the full-size domain runs: with one class, one species and the Brownian kernel its draw runs
     ahead of the sweep, and the kernel without that finishes what it leaves), with its
     two-wavefront form (evaluator + drawer, what a rank's share of the domain runs at N = 8) and
-    with the lane-per-cell kernel drawing as it sweeps, so that all are held to the oracle."""
+    with the lane-per-cell kernel drawing as it sweeps, with the cells of a workgroup grouped by state, and
+    with 64 lanes per cell (k_coag_sample, whatever the class count), so that all are held to the oracle."""
     variant = {"lane-per-cell": (1, 0, 0), "lane-per-cell-split": (2, 0, 0),
-               "lane-per-cell-one-phase": (3, 0, 0), "lane-per-cell-grouped": (4, 0, 0)}.get(request.param)
+               "lane-per-cell-one-phase": (3, 0, 0), "lane-per-cell-grouped": (4, 0, 0),
+               "lanes-per-cell": (64, 0, 0)}.get(request.param)
     from wrf_partmc_amd import host
     monkeypatch.setattr(host, "SAMPLER_VARIANT", variant)   # -> pmcx_set_sampler_variant
     return request.param

@@ -399,8 +399,11 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
     A_(st.gkey, nc * cap); A_(st.key_valid, nc); A_(st.evlog, nc * (size_t)EVLOG_CAP); A_(st.n_log, nc);
     A_(st.seq_ovf, nc * (2 * G + 2 * (size_t)cfg->max_appends));
     A_(st.n_events, nc); A_(st.n_samp, nc); A_(st.n_coag, nc); A_(st.status, nc);
+    A_(st.resume, nc * 4); A_(st.work2, nc + 1);
     if (cfg->n_class == 1) { // the sampler's split-off draw (2 KB per cell)
-        A_(st.pre, nc * 128); A_(st.resume, nc * 4); A_(st.work2, nc + 1);
+        A_(st.pre, nc * 128);
+    } else {                 // several classes: the list of possible slots (4 KB per cell), the lengths it was made for
+        A_(st.slist, nc * (size_t)SLIST_CAP); A_(st.gnb, nc * G); A_(st.work3, nc + 1);
     }
     if (cfg->n_comp_max > 0) { // particle%component(:): 8 (1 + n_comp_max) bytes per slot
         A_(st.comp_src, nc * cap); A_(st.comp_time, nc * cap * (size_t)cfg->n_comp_max);
@@ -1157,10 +1160,10 @@ int pmcx_set_transport_lateral(pmcx_ctx *ctx, int32_t on, int32_t j_global0, int
 int pmcx_set_sampler_variant(pmcx_ctx *ctx, int32_t lanes, int32_t wavefronts_per_group, int32_t stamps)
 {
     if (!ctx) return PMCX_EINVAL;
-    if (!(lanes == 0 || lanes == 1 || lanes == 2 || lanes == 3 || lanes == 4 || lanes == 8 || lanes == 16 || lanes == 64) ||
+    if (!(lanes == 0 || lanes == 1 || lanes == 2 || lanes == 3 || lanes == 4 || lanes == 5 || lanes == 8 || lanes == 16 || lanes == 64) ||
         !(wavefronts_per_group == 0 || wavefronts_per_group == 1 || wavefronts_per_group == 2 ||
           wavefronts_per_group == 4) || (stamps != 0 && stamps != 1))
-        return fail(ctx, PMCX_EINVAL, "pmcx_set_sampler_variant: lanes in {0,1,2,3,4,8,16,64}, "
+        return fail(ctx, PMCX_EINVAL, "pmcx_set_sampler_variant: lanes in {0,1,2,3,4,5,8,16,64}, "
                                       "wavefronts_per_group in {0,1,2,4}, stamps in {0,1}");
     ctx->st.force_lanes = lanes;
     ctx->st.force_wpb = wavefronts_per_group;

@@ -32,6 +32,11 @@ struct __attribute__((aligned(16))) Cold {
     int32_t pad;
 };
 
+#ifndef PMCX_SLIST_CAP
+#define PMCX_SLIST_CAP 512
+#endif
+constexpr int SLIST_CAP = PMCX_SLIST_CAP;  // entries of a cell's list of possible slots (the last one ends it)
+constexpr uint32_t SL_END = 0xFFFFFFFFu, SL_FULL = 0xFFFFFFFEu; // end of the sweep / list full: the next round goes on
 constexpr int EVLOG_CAP = 256; // entries of a cell's event log (two per coagulation at most)
 
 // entries of perm per cell: min(65535, cap + cap/8 + min(16 G, 8192)) -- offsets into it are 16 bits in
@@ -116,6 +121,13 @@ struct DeviceState {
     int32_t *resume;   // [n_cells][4] where a kernel left a cell to the one launched behind it: slot settled last
                        // (-1: none), entries in the overflow table, samples of that slot still to evaluate, the next one's index
     int32_t *work2;    // [1 + n_cells] count, cells
+    // several weight classes: the pair sampler's slots (pairs of groups) number n_class^2 n_bin^2 / 2 and
+    // nearly all draw a count of zero; k_coag_screen, a wavefront per cell, tests them all side by side
+    // and lists the few that might not (k_coag_lane<.., LISTED> then sweeps the list, a lane per cell)
+    uint2 *slist;      // [n_cells][SLIST_CAP] {group A << 16 | group B, the slot's uniform}, SL_END / SL_FULL behind the last
+    uint16_t *gnb;     // [n_cells][n_class n_bin] the length each group was tested with (0: not walked): the list
+                       // describes the cell while no group is longer
+    int32_t *work3;    // [1 + n_cells] count, cells (the rounds alternate between work2 and work3)
     // particle%component(:) (interface/wrf_pmc_driver.F90:1421-1437), the first n_comp_max of a
     // particle's list (0: not carried): source ids a byte each (0xFF past the end), create times;
     // the coagulations of the last mc_coag in event order, merged by k_comp_merge behind the sampler

@@ -1348,6 +1348,10 @@ __host__ __device__ inline size_t seq_lds_bytes(int B, int C, int W = SEQ_W)
 // exact counts | pair picked and list entries requested | particle records requested | kernel
 // and accept | unused | coagulation), [8] write-back, [9] draws, [10] passes, [11] wavefronts
 __device__ unsigned long long g_seq_stamps[12];
+#if defined(PMCX_DEBUG_LIST)
+// DEBUG BUILD: what the sweep of cell PMCX_DEBUG_LIST took from its list {slot, count | n_A << 16, n_B | round marker}
+__device__ uint32_t g_dbg[1 + 3 * 20000];
+#endif
 
 // SIMPLE: one weight class known at compile time (the idealised reference initial condition,
 // wrf_pmc_init.F90:1766-1770): the weighted-removal draws and the class bookkeeping fold away,
@@ -1433,12 +1437,14 @@ constexpr uint32_t PRE_END = 0xFFFFu, PRE_MORE = 0xFFFEu; // slot ids: end of th
 
 // SW: bins of the cell's window with list state in LDS (SEQ_W; 32 -- the whole window word -- in the
 // form with the draw split off, which runs where LDS does not limit the wavefronts a SIMD holds)
-template <bool STAMPS, bool SIMPLE, int KT, bool SPLIT = false, bool PRE = false, int SW = PRE ? 32 : SEQ_W>
+template <bool STAMPS, bool SIMPLE, int KT, bool SPLIT = false, bool PRE = false, int SW = PRE ? 32 : SEQ_W,
+          bool LISTED = false>
 __global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 2 : PMCX_LANE_WAVES)
 void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint32_t step,
-                uint16_t *ovf_mem, const int32_t *resume_list, int32_t *resume_count)
+                uint16_t *ovf_mem, const int32_t *resume_list, int32_t *resume_count, int32_t *next_list = nullptr)
 {
     static_assert(!PRE || (SIMPLE && !SPLIT && KT == KERNEL_BROWN), "PRE: one class, Brownian");
+    static_assert(!LISTED || (!SIMPLE && !SPLIT && !PRE && !STAMPS), "LISTED: several classes, one wavefront");
     // the second launch: only the cells the first one listed (nothing listed: nothing to do)
     if (!PRE && resume_list && (int)blockIdx.x * 64 >= *resume_count) return;
     uint64_t t_last = 0, t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1468,6 +1474,8 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
     double *edge = (double *)smem;
     double *rcp = (double *)(smem + (((size_t)(B + 1) * sizeof(double) + 15) & ~(size_t)15));
     double *envs = rcp + (POISSON_RCP_N + 2);
+    // (LISTED: the weights, the masks of non-empty bins and the windows of list state are not kept --
+    // tens of classes -- and never addressed: list lengths and offsets come from memory)
     double *magl = envs + SEQ_ENV * 64;                   // [C][64] weight magnitudes
     uint64_t *mask = (uint64_t *)(magl + (size_t)C * 64); // [C*2][64]
     uint32_t *ent = (uint32_t *)(mask + 2 * (size_t)C * 64); // [C*SW][64]
@@ -1495,6 +1503,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
     // (the list lengths are requested eight at a time, the window's entries all at once: one
     // request per wait made the set-up 180 memory round trips, 8 % of the kernel)
     int blo = B;
+    if (!LISTED)
     for (int cl = 0; cl < C; cl++) {
         uint64_t m0 = 0, m1 = 0;
         for (int b0 = 0; b0 < B; b0 += 8) {
@@ -1513,6 +1522,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
         MASK(cl * 2) = m0; MASK(cl * 2 + 1) = m1;
     }
     if (blo > B - SW) blo = (B - SW > 0) ? B - SW : 0;
+    if (!LISTED)
     for (int cl = 0; cl < C; cl++) {
         uint32_t e[SW];
 #pragma unroll
@@ -1524,7 +1534,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
         for (int k = 0; k < SW; k++)
             ent[(cl * SW + k) * 64 + lane] = (blo + k < B) ? e[k] : 0u;
     }
-    for (int cl = 0; cl < C; cl++) magl[cl * 64 + lane] = st.mag[(int64_t)c * C + cl];
+    if (!LISTED) for (int cl = 0; cl < C; cl++) magl[cl * 64 + lane] = st.mag[(int64_t)c * C + cl];
     {
         const EnvDerived e = env_derive(st.temp[c], st.pressure[c]);
         envs[0 * 64 + lane] = e.gasfreepath; envs[1 * 64 + lane] = e.inv_gfp;
@@ -1541,7 +1551,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
     const KernelParams kp{st.const_k, st.additive_beta};
 
     // ---- list state: packed entry = count | offset << 16 ----
-    auto in_win = [&](int b) -> bool { return (unsigned)(b - blo) < (unsigned)SW; };
+    auto in_win = [&](int b) -> bool { return !LISTED && (unsigned)(b - blo) < (unsigned)SW; };
     auto ent_get = [&](int cl, int b) -> uint32_t {
         if (in_win(b)) return ent[(cl * SW + (b - blo)) * 64 + lane];
         const int g = cl * B + b;
@@ -1576,6 +1586,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                 far = true;
             }
         }
+        if (LISTED) return;
         if (n == 0) MASKC(cl * 2 + (b >> 6)) &= ~(1ull << (b & 63));
         else if (n == 1) MASKC(cl * 2 + (b >> 6)) |= 1ull << (b & 63);
     };
@@ -1635,7 +1646,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
         const int32_t pos = st.resume[4 * (int64_t)c];
         n_app = st.resume[4 * (int64_t)c + 1];
         n_ev = st.n_events[c]; tot_coag = st.n_coag[c]; tot_samp = (uint64_t)(uint32_t)st.n_samp[c];
-        if (pos >= 0) { b1 = pos & 0xFF; b2 = (pos >> 8) & 0xFF; c1 = (pos >> 16) & 0xFF; c2 = (pos >> 24) & 0xFF; }
+        if (pos != -1) { b1 = pos & 0xFF; b2 = (pos >> 8) & 0xFF; c1 = (pos >> 16) & 0xFF; c2 = (pos >> 24) & 0xFF; }
     }
     if (SIMPLE) {
         // bins blo .. blo + 63 of the 128-bit mask (m1 : m0), shifted down by blo
@@ -1731,6 +1742,16 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
     bool unfinished = false;
     bool need_pre = false;           // the lane is to walk its slots (again) from where it stands
     uint64_t arr0 = 0, arr1 = 0;     // merged particles each bin of the window has taken (5 bits a bin)
+    // ---- LISTED (several classes): the slots whose count could be non-zero come from the cell's list,
+    // ---- made by k_coag_screen for as long as no group outgrows the length it was tested with
+    const uint2 *sl = nullptr;
+    uint2 la = make_uint2(SL_END, 0u);   // the entry in hand
+    int lk = 0;
+    if (LISTED) {
+        sl = st.slist + (int64_t)c * SLIST_CAP;
+        if (!done) la = sl[0];
+        wide = true;                     // (list lengths and offsets from memory)
+    }
     if (PRE) {
         pre = st.pre + (int64_t)c * PRE_CAP;
         if (live && far) { unfinished = true; done = true; }  // (beyond the 32 bins of the window word: the other kernel)
@@ -1918,6 +1939,49 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
             if (!done && !need_pre && pk >= pk_pair + 2) {
                 ea = pre[pk]; eb = pre[pk + 1];
                 pk_pair = pk;
+            }
+        } else if (LISTED) {
+            // the next slot from the cell's list: its exact count with the lists as they are now
+            if (dr) {
+                if (pre_stop || la.x == SL_FULL) {
+                    // a group outgrew the length the list was made for (the slots it left out may draw
+                    // samples now), or the list ran full: the next round lists what lies behind the slot
+                    // settled last
+                    unfinished = true; done = true;
+                } else if (la.x == SL_END) {
+                    done = true;
+                } else {
+                    const int hA = (int)(la.x >> 16), hB = (int)(la.x & 0xFFFFu);
+                    c1 = hA / B; b1 = hA - c1 * B; c2 = hB / B; b2 = hB - c2 * B;
+                    if (c1 != rc1 || c2 != rc2) {
+                        n1 = st.mag[(int64_t)c * C + c1]; n2 = st.mag[(int64_t)c * C + c2];
+                        cc = (n1 < n2) ? c1 : c2;
+                        nmin = (n1 < n2) ? n1 : n2;
+                        fmax = (n1 < n2) ? n2 : n1;
+                        factor = n1 * n2 / nmin;
+                        rc1 = c1; rc2 = c2;
+                    }
+                    const uint32_t dA = ent_get(c1, b1), dB = hA == hB ? dA : ent_get(c2, b2);
+                    const double nA_ = (double)(dA & 0xFFFFu), nB_ = (double)(dB & 0xFFFFu);
+                    k_max = (double)st.kmax[(int64_t)c * st.kmax_stride + b1 * B + b2] * fmax;
+                    const double n_possible_ = (hA == hB) ? nA_ * (nA_ - 1.0) / 2.0 : nA_ * nB_;
+                    const double mean_ = k_max * del_t * n_possible_;
+                    const double u_ = (double)la.y * 0x1.0p-32;
+                    // (a list that ran out gives n_possible <= 0: no sample, as the sweep has it)
+                    if (!(u_ < (1.0 - mean_) - 4e-15)) { pending = true; p_mean = mean_; p_u = u_; }
+#if defined(PMCX_DEBUG_LIST)
+                    if (c == PMCX_DEBUG_LIST) {
+                        const uint32_t k_ = atomicAdd(&g_dbg[0], 1u);
+                        if (k_ < 20000u) {
+                            g_dbg[1 + 3 * k_] = la.x;
+                            g_dbg[2 + 3 * k_] = (pending ? 1u : 0u) | ((dA & 0xFFFFu) << 16);
+                            g_dbg[3 + 3 * k_] = (dB & 0xFFFFu) | ((uint32_t)lk << 16);
+                        }
+                    }
+#endif
+                    lk++;
+                    la = sl[lk];
+                }
             }
         } else
         for (int r = 0; r < NROUND; r++) {
@@ -2325,6 +2389,8 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                     cnt_set(cc, b_new, en, n + 1);
                     PMCX_LOG(pn, g_new)
                     if (PRE) ev_bnew = b_new;
+                    // (LISTED: the list holds while no group is longer than the screen allowed for)
+                    if (LISTED && n + 1 > (int)st.gnb[(int64_t)c * G + g_new]) pre_stop = true;
                 }
                 if (rem_o) PMCX_LOG(po, 0xFFFFu)
                 *(double2 *)&hot[pn].vtot = make_double2(vn, mn);
@@ -2382,10 +2448,17 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
         st.n_samp[c] = tot_samp > 0x7FFFFFFFull ? 0x7FFFFFFF : (int32_t)tot_samp;
     if (live && !role_e && status) atomicOr(&st.status[c], status);
     if (live && role_e) {
+        if (!LISTED)
         for (int cl = 0; cl < C; cl++)
             for (int k = 0; k < SW && blo + k < B; k++)
                 gcnt_g[cl * B + blo + k] = (int32_t)(ent[(cl * SW + k) * 64 + lane] & 0xFFFFu);
-        if (n_app) {
+        if (LISTED && unfinished) { // where the cell stands (a slot boundary), for the next round
+            st.resume[4 * (int64_t)c] = b1 < 0 ? -1 : (b1 | (b2 << 8) | (c1 << 16) | (c2 << 24));
+            st.resume[4 * (int64_t)c + 1] = n_app;
+            st.resume[4 * (int64_t)c + 2] = 0; st.resume[4 * (int64_t)c + 3] = 0;
+            next_list[1 + atomicAdd(next_list, 1)] = c;
+        }
+        if (n_app && !unfinished) { // (a cell handed to another launch: judged where its sweep ends)
             bool ovf = false;
             for (int g = 0; g < G; g++) ovf |= O_ovf_n(g) != 0;
             if (ovf) st.sort_valid[c] = 0;
@@ -2882,6 +2955,146 @@ hipError_t seq_stamps_read(uint64_t out[12], bool reset)
         e = hipMemcpyToSymbol(HIP_SYMBOL(g_seq_stamps), z, sizeof(z));
     }
     return e;
+}
+
+// ------------------------------------- coag sampler, several weight classes: the screen
+//
+// With C weight classes the sweep visits C (C + 1) / 2 class pairs times the bin pairs of each
+// (WRFV3/Registry/registry.partmc_trans:2-41 carries 40 classes: 5 * 10^6 slots a cell), the events stay
+// what they were, and nearly every slot draws a count of zero -- but each needs its own uniform to
+// say so.  A lane walking its cell's slots one Philox block after the other (the forms above) takes
+// 67 ms at 10 classes and 1.8 s at 40 for the 75 000 cells it does in 1.2 ms with one class.  Hence, as in
+// the one-class form with the draw split off (PRE), but with the whole wavefront on one cell: the
+// slots of a class pair are laid side by side over the lanes, four partner bins (one Philox block) to
+// a lane, tested against 1 - mean with every list SCR_M entries longer than it is now, and the few
+// that fail are listed in sweep order {slot, uniform}.  k_coag_lane<.., LISTED> then sweeps that
+// list, a lane per cell, taking each entry's exact count from the lists as they are when it reaches
+// it: every count is the oracle's.  Walked: per class the bins from its first populated one up to two
+// above the cell's last (a merged particle joins the class of one of its parents, at or above that
+// parent's bin); gnb holds the length each group was tested with, and the sweep stops at the first
+// arrival that exceeds one (or when the list ran full): the next round screens what lies behind the
+// slot it settled last, with the lists as they are then (launch_coag_listed).
+#ifndef PMCX_SCR_M
+#define PMCX_SCR_M 12
+#endif
+constexpr int SCR_M = PMCX_SCR_M;
+
+__host__ __device__ inline size_t screen_lds_per_wave(int G, int C)
+{
+    return (((size_t)2 * G + 15) & ~(size_t)15) + (((size_t)10 * C + 15) & ~(size_t)15);
+}
+
+__global__ __launch_bounds__(256) void k_coag_screen(DeviceState st, double del_t, uint64_t seed, uint32_t step,
+                                                     const int32_t *list, const int32_t *count)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int B = st.n_bin, C = st.n_class, G = B * C;
+    unsigned char *mine = smem + (size_t)wave * screen_lds_per_wave(G, C);
+    uint16_t *nup = (uint16_t *)mine;                                        // [G] the length a group is tested with
+    double *mg = (double *)(mine + (((size_t)2 * G + 15) & ~(size_t)15));    // [C] weights
+    int16_t *lo = (int16_t *)(mg + C);                                       // [C] first populated bin (B: none)
+    const int n_work = list ? *count : st.n_cells;
+    for (int wk = blockIdx.x * 4 + wave; wk < n_work; wk += gridDim.x * 4) {
+        const int c = list ? list[wk] : wk;
+        if (!in_loop(st, c)) continue;
+        // settled so far: everything up to and including the slot (sc1, sc2, sb1, sb2); sc1 < 0: nothing
+        int sc1 = -1, sc2 = 0, sb1 = 0, sb2 = 0;
+        if (list) {
+            const int32_t pos = st.resume[4 * (int64_t)c];
+            if (pos != -1) { sb1 = pos & 0xFF; sb2 = (pos >> 8) & 0xFF; sc1 = (pos >> 16) & 0xFF; sc2 = (pos >> 24) & 0xFF; }
+        }
+        const int32_t *gc = st.gcnt + (int64_t)c * G;
+        uint16_t *nb_g = st.gnb + (int64_t)c * G;
+        uint2 *sl = st.slist + (int64_t)c * SLIST_CAP;
+        const float *kmx = st.kmax + (int64_t)c * st.kmax_stride;
+        const uint32_t cell_id = cell_gid(st, c);
+        int hi = -1;
+        for (int g = lane; g < G; g += 64) {
+            const int n = gc[g];
+            nup[g] = (uint16_t)n;
+            if (n > 0) hi = max(hi, g % B);
+        }
+        for (int d = 32; d >= 1; d >>= 1) hi = max(hi, __shfl_xor(hi, d, 64));
+        __threadfence_block();
+        for (int cl = lane; cl < C; cl += 64) {
+            int l = B;
+            for (int b = B - 1; b >= 0; b--) if (nup[cl * B + b]) l = b;
+            lo[cl] = (int16_t)l;
+            mg[cl] = st.mag[(int64_t)c * C + cl];
+        }
+        __threadfence_block();
+        // (the cell's bounds cover the populated range of the call's start and bounds_margin >= 2 bins above it)
+        const int hi2 = min(min(B - 1, hi + 2), st.kmax_rng[4 * (int64_t)c + 1]);
+        for (int g = lane; g < G; g += 64) {
+            const int cl = g / B, b = g - cl * B, l = lo[cl];
+            const bool walk = l < B && b >= l && b <= hi2;
+            const uint32_t v = walk ? min(65535u, (uint32_t)nup[g] + (uint32_t)SCR_M) : 0u;
+            nup[g] = (uint16_t)v;
+            nb_g[g] = (uint16_t)v;
+        }
+        __threadfence_block();
+
+        int npre = 0;
+        bool full = false;
+        for (int c1 = max(sc1, 0); c1 < C && !full && hi >= 0; c1++) {
+            const int l1 = lo[c1];
+            if (l1 >= B) continue;
+            const double n1 = mg[c1];
+            for (int c2 = (c1 == sc1 ? sc2 : 0); c2 <= c1 && !full; c2++) {
+                const int l2 = lo[c2];
+                if (l2 >= B) continue;
+                const double n2 = mg[c2];
+                const double fmax = (n1 < n2) ? n2 : n1;
+                const bool at_start = (c1 == sc1 && c2 == sc2);
+                // rows l1 .. hi2 of class c1, the blocks of four partner bins from l2's up to hi2's
+                const int q0 = l2 >> 2, nblk = (hi2 >> 2) - q0 + 1, items = (hi2 - l1 + 1) * nblk;
+                for (int t0 = 0; t0 < items && !full; t0 += 64) {
+                    const int t = t0 + lane;
+                    const int r = t / nblk, q = t - r * nblk;
+                    const int b1 = l1 + r, q4 = (q0 + q) << 2;
+                    bool act = t < items;
+                    if (c1 == c2 && q4 + 3 < b1) act = false;                                  // (partners below the row's bin)
+                    if (at_start && (b1 < sb1 || (b1 == sb1 && q4 + 3 <= sb2))) act = false;  // (settled already)
+                    uint32_t pm = 0;
+                    uint32_t w[4] = {0, 0, 0, 0};
+                    const uint32_t gA = (uint32_t)(c1 * B + b1), gB0 = (uint32_t)(c2 * B + q4);
+                    if (act) {
+                        rng_block(seed, cell_id, step, (gA << 16) | gB0, SITE_POISSON, 0, w);
+                        const float4 kf4 = *(const float4 *)(kmx + b1 * B + q4);
+                        const float kfa[4] = {kf4.x, kf4.y, kf4.z, kf4.w};
+                        const double nA_up = (double)nup[gA];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int b2 = q4 + k;
+                            const bool ok = b2 >= l2 && b2 <= hi2 && (c1 != c2 || b2 >= b1) &&
+                                            !(at_start && b1 == sb1 && b2 <= sb2);
+                            const double nB_up = (double)nup[gB0 + (ok ? k : 0)];
+                            const double np_up = (c1 == c2 && b2 == b1) ? nA_up * (nA_up - 1.0) / 2.0 : nA_up * nB_up;
+                            const double mean_up = ((double)kfa[k] * fmax) * del_t * np_up; // (the sweep's expression)
+                            const double u_ = (double)w[k] * 0x1.0p-32;
+                            if (ok && !(u_ < (1.0 - mean_up) - 4e-15)) pm |= 1u << k;
+                        }
+                    }
+                    uint64_t anyp = __ballot(pm != 0);
+                    while (anyp) {
+                        const int l = __builtin_ctzll(anyp);
+                        anyp &= anyp - 1;
+                        const int cnt = __popc((uint32_t)__builtin_amdgcn_readlane((int)pm, l));
+                        if (npre + cnt > SLIST_CAP - 1) { full = true; break; } // (the next round goes on behind the last entry)
+                        if (lane == l) {
+                            int o = npre;
+#pragma unroll
+                            for (int k = 0; k < 4; k++)
+                                if ((pm >> k) & 1u) sl[o++] = make_uint2((gA << 16) | (gB0 + (uint32_t)k), w[k]);
+                        }
+                        npre += cnt;
+                    }
+                }
+            }
+        }
+        if (lane == 0) sl[npre] = make_uint2(full ? SL_FULL : SL_END, 0u);
+    }
 }
 
 // ------------------------------------------------------------- species volumes
@@ -6120,10 +6333,17 @@ static bool pre_available(const DeviceState &st, int ktype)
     return st.n_class == 1 && ktype == KERNEL_BROWN && (st.n_bin & 3) == 0 && st.pre != nullptr &&
            seq_lds_bytes(st.n_bin, st.n_class, 32) <= 64 * 1024;
 }
+// several classes: the screen and the sweep of its list (k_coag_screen, k_coag_lane<.., LISTED>)
+static bool listed_available(const DeviceState &st)
+{
+    return st.n_class > 1 && st.n_class <= 255 && st.n_bin <= 255 && (st.n_bin & 3) == 0 && st.slist != nullptr &&
+           st.n_class * st.n_bin < 65535 && 4 * screen_lds_per_wave(st.n_class * st.n_bin, st.n_class) <= (size_t)150 * 1024;
+}
 int sampler_lanes(const DeviceState &st, int ktype)
 {
     const int fl = st.force_lanes;
     const bool seq_fits = seq_lds_bytes(st.n_bin, st.n_class) + SEQ_SHARED_BYTES <= 64 * 1024;
+    if ((fl == 0 || fl == 5) && listed_available(st)) return 5;
     if (fl == 1) return pre_available(st, ktype) ? 1 : (seq_fits ? 3 : 64);
     if (fl == 4) return pre_available(st, ktype) ? 4 : (seq_fits ? 3 : 64);   // (k_coag_grp: the configuration PRE runs on)
     if ((fl == 2 || fl == 3) && seq_fits) return fl;
@@ -6295,6 +6515,45 @@ bool coag_sample_splits_draw(const DeviceState &st, int ktype)
     const int L = sampler_lanes(st, ktype);
     return L == 1 || L == 4;      // (the forms that leave cells to a second launch: pmcx_get_sampler_info counts them)
 }
+// Several classes: rounds of (screen, sweep of the list) until no cell is left -- a cell is left when its
+// list ran full or a group outgrew the length the list was made for; every round settles at least one
+// slot with samples or SLIST_CAP - 1 listed ones, so the loop ends.  Two rounds are launched blind (the
+// second finds its work list empty nearly always and returns at once), then the count is looked at.
+static hipError_t launch_coag_listed(const DeviceState &st, int ktype, double del_t, uint64_t seed, uint32_t step,
+                                     hipStream_t s)
+{
+    const int G = st.n_class * st.n_bin;
+    const size_t lds_s = 4 * screen_lds_per_wave(G, st.n_class);
+    allow_lds(k_coag_screen, lds_s);
+    const size_t lds_l = seq_lds_bytes(st.n_bin, 0, 0);
+    const int n_wg = (st.n_cells + 3) / 4;
+    const dim3 grid_s(n_wg < 16384 ? n_wg : 16384), grid_l((st.n_cells + 63) / 64);
+    int32_t *in = nullptr, *out = st.work2;
+    for (int round = 0; round < 1000; round++) {
+        (void)hipMemsetAsync(out, 0, sizeof(int32_t), s);
+        const int32_t *il = in ? in + 1 : nullptr;
+        hipLaunchKernelGGL(k_coag_screen, grid_s, dim3(256), lds_s, s, st, del_t, seed, step, il, (const int32_t *)in);
+        if (ktype == KERNEL_BROWN)
+            hipLaunchKernelGGL((k_coag_lane<false, false, KERNEL_BROWN, false, false, SEQ_W, true>), grid_l, dim3(64), lds_l, s,
+                               st, ktype, del_t, seed, step, st.seq_ovf, il, in, out);
+        else
+            hipLaunchKernelGGL((k_coag_lane<false, false, 0, false, false, SEQ_W, true>), grid_l, dim3(64), lds_l, s,
+                               st, ktype, del_t, seed, step, st.seq_ovf, il, in, out);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        if (round & 1) {
+            int32_t left = 0;
+            e = hipMemcpyAsync(&left, out, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) return e;
+            if (left == 0) return hipSuccess;
+        }
+        in = out;
+        out = (out == st.work2) ? st.work3 : st.work2;
+    }
+    return hipErrorLaunchFailure; // (not reached: every round settles slots)
+}
+
 static hipError_t launch_coag_sample_only(const DeviceState &st, int ktype, double del_t, uint64_t seed,
                                           uint32_t step, hipStream_t s)
 {
@@ -6315,6 +6574,7 @@ static hipError_t launch_coag_sample_only(const DeviceState &st, int ktype, doub
                                del_t, seed, step, st.seq_ovf, (const int32_t *)nullptr, (int32_t *)nullptr);
         return hipGetLastError();
     }
+    if (L == 5) return launch_coag_listed(st, ktype, del_t, seed, step, s);
     if (L == 4) { // the cells of a workgroup grouped by what they do next; what it hands over: the one-phase kernel
         (void)hipMemsetAsync(st.work2, 0, sizeof(int32_t), s);
         const size_t lds_g = grp_lds_bytes(st.n_bin);
@@ -6385,6 +6645,14 @@ static hipError_t launch_coag_sample_only(const DeviceState &st, int ktype, doub
 #undef PMCX_LAUNCH_SAMPLER
     return hipGetLastError();
 }
+#if defined(PMCX_DEBUG_LIST)
+extern "C" int pmcx_debug_read(uint32_t *out, int n, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), (size_t)n * sizeof(uint32_t));
+    if (e == hipSuccess && reset) { uint32_t z = 0; e = hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &z, sizeof(z)); }
+    return (int)e;
+}
+#endif
 hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, uint64_t seed,
                               uint32_t step, hipStream_t s)
 {
