@@ -33,7 +33,7 @@ struct __attribute__((aligned(16))) Cold {
 };
 
 #ifndef PMCX_SLIST_CAP
-#define PMCX_SLIST_CAP 512
+#define PMCX_SLIST_CAP 2048
 #endif
 constexpr int SLIST_CAP = PMCX_SLIST_CAP;  // entries of a cell's list of possible slots (the last one ends it)
 constexpr uint32_t SL_END = 0xFFFFFFFFu, SL_FULL = 0xFFFFFFFEu; // end of the sweep / list full: the next round goes on

@@ -2966,7 +2966,7 @@ hipError_t seq_stamps_read(uint64_t out[12], bool reset)
 // 67 ms at 10 classes and 1.8 s at 40 for the 75 000 cells it does in 1.2 ms with one class.  Hence, as in
 // the one-class form with the draw split off (PRE), but with the whole wavefront on one cell: the
 // slots of a class pair are laid side by side over the lanes, four partner bins (one Philox block) to
-// a lane, tested against 1 - mean with every list SCR_M entries longer than it is now, and the few
+// a lane, tested against 1 - mean with every list a few entries longer than it is now, and the few
 // that fail are listed in sweep order {slot, uniform}.  k_coag_lane<.., LISTED> then sweeps that
 // list, a lane per cell, taking each entry's exact count from the lists as they are when it reaches
 // it: every count is the oracle's.  Walked: per class the bins from its first populated one up to two
@@ -2974,10 +2974,21 @@ hipError_t seq_stamps_read(uint64_t out[12], bool reset)
 // parent's bin); gnb holds the length each group was tested with, and the sweep stops at the first
 // arrival that exceeds one (or when the list ran full): the next round screens what lies behind the
 // slot it settled last, with the lists as they are then (launch_coag_listed).
+// the length a group is tested with: n + max(SCR_M, n >> SCR_SHIFT) for a populated one, SCR_E for an
+// empty one that could take a merged particle.  Measured at 75 000 cells (ms per mc_coag, 2 / 10 / 40
+// classes; profiles/r4_classes.txt): 12, -, 12 with 512 entries a list: 3.2 / 10.2 / 90.9 (14 rounds at 40
+// classes, every list full); with 2048 entries: 3.2 / 9.1 / 76.9; 4, -, 2: 4.3 / 7.6 / 54.8; 2, 2, 1: 3.0 /
+// 7.9 / 55.6; 3, 3, 3: 2.9 / 7.7 / 56.5 (2.5 rounds at 40 classes)
 #ifndef PMCX_SCR_M
-#define PMCX_SCR_M 12
+#define PMCX_SCR_M 3
 #endif
-constexpr int SCR_M = PMCX_SCR_M;
+#ifndef PMCX_SCR_SHIFT
+#define PMCX_SCR_SHIFT 3
+#endif
+#ifndef PMCX_SCR_E
+#define PMCX_SCR_E 3
+#endif
+constexpr int SCR_M = PMCX_SCR_M, SCR_SHIFT = PMCX_SCR_SHIFT, SCR_E = PMCX_SCR_E;
 
 __host__ __device__ inline size_t screen_lds_per_wave(int G, int C)
 {
@@ -3029,7 +3040,8 @@ __global__ __launch_bounds__(256) void k_coag_screen(DeviceState st, double del_
         for (int g = lane; g < G; g += 64) {
             const int cl = g / B, b = g - cl * B, l = lo[cl];
             const bool walk = l < B && b >= l && b <= hi2;
-            const uint32_t v = walk ? min(65535u, (uint32_t)nup[g] + (uint32_t)SCR_M) : 0u;
+            const uint32_t n = nup[g];
+            const uint32_t v = !walk ? 0u : (n == 0u ? (uint32_t)SCR_E : min(65535u, n + max((uint32_t)SCR_M, n >> SCR_SHIFT)));
             nup[g] = (uint16_t)v;
             nb_g[g] = (uint16_t)v;
         }
