@@ -359,7 +359,7 @@ def main():
     ap.add_argument("--n-class", type=int, default=1,
                     help="weight classes (WRFV3/Registry/registry.partmc_trans:2-41 carries 40): the idealised mode "
                          "split evenly over them, class c standing for (1 + c / 2) times class 0's number "
-                         "(a side measurement: no CPU leg, the cells take the lanes-per-cell sampler)")
+                         "(a side measurement: no CPU leg; the screen + list-sweep form of the sampler, DESIGN.md 5.3)")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="no GPU needed: launch, rendezvous (gloo), partition and aggregation only; value null")
     args = ap.parse_args()

@@ -749,11 +749,15 @@ int pmcx_sort_only(pmcx_ctx *ctx);
 int pmcx_invalidate_sort(pmcx_ctx *ctx);
 /* Diagnostic: pin the pair sampler's launch shape instead of the library's own choice by
  * domain size, so that tests can hold every variant to the oracle at small sizes.  lanes: 0
- * automatic; 1 lane per cell (the full domain's kernel: with one class, one species and the
- * Brownian kernel its draw runs ahead of the sweep as a phase of its own); 3 lane per cell
+ * automatic (with several weight classes: 5); 1 lane per cell (the full domain's kernel: with one
+ * class and the Brownian kernel its draw runs ahead of the sweep as a phase of its own); 3 lane per cell
  * without that; 2 its two-wavefront form (a rank's share at N = 4, 8); 4 lane per cell with the 256 cells
- * of a workgroup grouped every round by what they do next (k_coag_grp; one class, one species, Brownian);
- * 8, 16, 64 lanes per cell (small blocks).  wavefronts_per_group: 0
+ * of a workgroup grouped every round by what they do next (k_coag_grp; one class, Brownian);
+ * 5 several classes: a wavefront per cell screens the slots of all class pairs, a lane per cell sweeps
+ * the list of those that may draw samples, in rounds until no cell is left (one host synchronisation per
+ * mc_coag); 8, 16, 64 lanes per cell (small blocks).  A form that does not apply to the configuration
+ * falls back to the library's choice.  No form touches the species volumes: they are summed behind the
+ * sampler from the events' log (any species count runs the same forms).  wavefronts_per_group: 0
  * automatic, 1, 2 or 4 (the 8/16/64 kernels; with lanes = 1: 1, 2 cap the wavefronts a SIMD
  * holds).  stamps: 1 = the instantiation that records
  * cycles per stage (pmcx_profile_phase_cycles).  Results do not depend on any of them. */

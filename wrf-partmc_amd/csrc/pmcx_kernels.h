@@ -124,7 +124,7 @@ struct DeviceState {
     // several weight classes: the pair sampler's slots (pairs of groups) number n_class^2 n_bin^2 / 2 and
     // nearly all draw a count of zero; k_coag_screen, a wavefront per cell, tests them all side by side
     // and lists the few that might not (k_coag_lane<.., LISTED> then sweeps the list, a lane per cell)
-    uint2 *slist;      // [n_cells][SLIST_CAP] {group A << 16 | group B, the slot's uniform}, SL_END / SL_FULL behind the last
+    uint2 *slist;      // [n_cells][SLIST_CAP] {c1 << 24 | b1 << 16 | c2 << 8 | b2, the slot's uniform}, SL_END / SL_FULL behind the last
     uint16_t *gnb;     // [n_cells][n_class n_bin] the length each group was tested with (0: not walked): the list
                        // describes the cell while no group is longer
     int32_t *work3;    // [1 + n_cells] count, cells (the rounds alternate between work2 and work3)

@@ -1348,10 +1348,6 @@ __host__ __device__ inline size_t seq_lds_bytes(int B, int C, int W = SEQ_W)
 // exact counts | pair picked and list entries requested | particle records requested | kernel
 // and accept | unused | coagulation), [8] write-back, [9] draws, [10] passes, [11] wavefronts
 __device__ unsigned long long g_seq_stamps[12];
-#if defined(PMCX_DEBUG_LIST)
-// DEBUG BUILD: what the sweep of cell PMCX_DEBUG_LIST took from its list {slot, count | n_A << 16, n_B | round marker}
-__device__ uint32_t g_dbg[1 + 3 * 20000];
-#endif
 
 // SIMPLE: one weight class known at compile time (the idealised reference initial condition,
 // wrf_pmc_init.F90:1766-1770): the weighted-removal draws and the class bookkeeping fold away,
@@ -1745,11 +1741,12 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
     // ---- LISTED (several classes): the slots whose count could be non-zero come from the cell's list,
     // ---- made by k_coag_screen for as long as no group outgrows the length it was tested with
     const uint2 *sl = nullptr;
-    uint2 la = make_uint2(SL_END, 0u);   // the entry in hand
+    uint2 lq[4];                         // the four entries in hand
     int lk = 0;
     if (LISTED) {
         sl = st.slist + (int64_t)c * SLIST_CAP;
-        if (!done) la = sl[0];
+#pragma unroll
+        for (int k = 0; k < 4; k++) lq[k] = done ? make_uint2(SL_END, 0u) : sl[k];
         wide = true;                     // (list lengths and offsets from memory)
     }
     if (PRE) {
@@ -1941,46 +1938,61 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                 pk_pair = pk;
             }
         } else if (LISTED) {
-            // the next slot from the cell's list: its exact count with the lists as they are now
+            // The next slots from the cell's list, up to four a pass: the list lengths, the bounds and the
+            // weights of all four are requested together, then each entry's exact count is taken in order
+            // with the lists as they are now, up to the first that holds samples (nothing changes the
+            // lists in between: entries that draw none cost a quarter of a pass each).
             if (dr) {
-                if (pre_stop || la.x == SL_FULL) {
+                if (pre_stop) {
                     // a group outgrew the length the list was made for (the slots it left out may draw
-                    // samples now), or the list ran full: the next round lists what lies behind the slot
-                    // settled last
+                    // samples now): the next round lists what lies behind the slot settled last
                     unfinished = true; done = true;
-                } else if (la.x == SL_END) {
-                    done = true;
                 } else {
-                    const int hA = (int)(la.x >> 16), hB = (int)(la.x & 0xFFFFu);
-                    c1 = hA / B; b1 = hA - c1 * B; c2 = hB / B; b2 = hB - c2 * B;
-                    if (c1 != rc1 || c2 != rc2) {
-                        n1 = st.mag[(int64_t)c * C + c1]; n2 = st.mag[(int64_t)c * C + c2];
-                        cc = (n1 < n2) ? c1 : c2;
-                        nmin = (n1 < n2) ? n1 : n2;
-                        fmax = (n1 < n2) ? n2 : n1;
-                        factor = n1 * n2 / nmin;
-                        rc1 = c1; rc2 = c2;
+                    uint32_t cA[4], cB[4];
+                    float kf[4];
+                    double wa[4], wb[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t x = lq[k].x < SL_FULL ? lq[k].x : 0u; // c1 << 24 | b1 << 16 | c2 << 8 | b2
+                        const int e1 = (int)(x >> 24), d1 = (int)((x >> 16) & 0xFFu), e2 = (int)((x >> 8) & 0xFFu), d2 = (int)(x & 0xFFu);
+                        cA[k] = (uint32_t)gcnt_g[e1 * B + d1];
+                        cB[k] = (uint32_t)gcnt_g[e2 * B + d2];
+                        kf[k] = st.kmax[(int64_t)c * st.kmax_stride + d1 * B + d2];
+                        wa[k] = st.mag[(int64_t)c * C + e1];
+                        wb[k] = st.mag[(int64_t)c * C + e2];
                     }
-                    const uint32_t dA = ent_get(c1, b1), dB = hA == hB ? dA : ent_get(c2, b2);
-                    const double nA_ = (double)(dA & 0xFFFFu), nB_ = (double)(dB & 0xFFFFu);
-                    k_max = (double)st.kmax[(int64_t)c * st.kmax_stride + b1 * B + b2] * fmax;
-                    const double n_possible_ = (hA == hB) ? nA_ * (nA_ - 1.0) / 2.0 : nA_ * nB_;
-                    const double mean_ = k_max * del_t * n_possible_;
-                    const double u_ = (double)la.y * 0x1.0p-32;
-                    // (a list that ran out gives n_possible <= 0: no sample, as the sweep has it)
-                    if (!(u_ < (1.0 - mean_) - 4e-15)) { pending = true; p_mean = mean_; p_u = u_; }
-#if defined(PMCX_DEBUG_LIST)
-                    if (c == PMCX_DEBUG_LIST) {
-                        const uint32_t k_ = atomicAdd(&g_dbg[0], 1u);
-                        if (k_ < 20000u) {
-                            g_dbg[1 + 3 * k_] = la.x;
-                            g_dbg[2 + 3 * k_] = (pending ? 1u : 0u) | ((dA & 0xFFFFu) << 16);
-                            g_dbg[3 + 3 * k_] = (dB & 0xFFFFu) | ((uint32_t)lk << 16);
+                    int used = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (!pending && !done) {
+                            const uint32_t x = lq[k].x;
+                            if (x == SL_END) {
+                                done = true;
+                            } else if (x == SL_FULL) {   // the list ran full: the next round goes on from here
+                                unfinished = true; done = true;
+                            } else {
+                                c1 = (int)(x >> 24); b1 = (int)((x >> 16) & 0xFFu); c2 = (int)((x >> 8) & 0xFFu); b2 = (int)(x & 0xFFu);
+                                n1 = wa[k]; n2 = wb[k];
+                                cc = (n1 < n2) ? c1 : c2;
+                                nmin = (n1 < n2) ? n1 : n2;
+                                fmax = (n1 < n2) ? n2 : n1;
+                                const double nA_ = (double)(cA[k] & 0xFFFFu), nB_ = (double)(cB[k] & 0xFFFFu);
+                                k_max = (double)kf[k] * fmax;
+                                const double n_possible_ = (c1 == c2 && b1 == b2) ? nA_ * (nA_ - 1.0) / 2.0 : nA_ * nB_;
+                                const double mean_ = k_max * del_t * n_possible_;
+                                const double u_ = (double)lq[k].y * 0x1.0p-32;
+                                // (a list that ran out gives n_possible <= 0: no sample, as the sweep has it)
+                                if (!(u_ < (1.0 - mean_) - 4e-15)) { pending = true; p_mean = mean_; p_u = u_; }
+                                used++;
+                            }
                         }
                     }
-#endif
-                    lk++;
-                    la = sl[lk];
+                    if (pending) factor = n1 * n2 / nmin;
+                    lk += used;
+                    if (!done) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) lq[k] = sl[min(lk + k, SLIST_CAP - 1)];
+                    }
                 }
             }
         } else
@@ -3098,7 +3110,8 @@ __global__ __launch_bounds__(256) void k_coag_screen(DeviceState st, double del_
                             int o = npre;
 #pragma unroll
                             for (int k = 0; k < 4; k++)
-                                if ((pm >> k) & 1u) sl[o++] = make_uint2((gA << 16) | (gB0 + (uint32_t)k), w[k]);
+                                if ((pm >> k) & 1u)
+                                    sl[o++] = make_uint2(((uint32_t)c1 << 24) | ((uint32_t)b1 << 16) | ((uint32_t)c2 << 8) | (uint32_t)(q4 + k), w[k]);
                         }
                         npre += cnt;
                     }
@@ -6657,14 +6670,6 @@ static hipError_t launch_coag_sample_only(const DeviceState &st, int ktype, doub
 #undef PMCX_LAUNCH_SAMPLER
     return hipGetLastError();
 }
-#if defined(PMCX_DEBUG_LIST)
-extern "C" int pmcx_debug_read(uint32_t *out, int n, int reset)
-{
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), (size_t)n * sizeof(uint32_t));
-    if (e == hipSuccess && reset) { uint32_t z = 0; e = hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &z, sizeof(z)); }
-    return (int)e;
-}
-#endif
 hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, uint64_t seed,
                               uint32_t step, hipStream_t s)
 {
