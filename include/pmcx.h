@@ -759,7 +759,7 @@ int pmcx_invalidate_sort(pmcx_ctx *ctx);
  * falls back to the library's choice.  No form touches the species volumes: they are summed behind the
  * sampler from the events' log (any species count runs the same forms).  wavefronts_per_group: 0
  * automatic, 1, 2 or 4 (the 8/16/64 kernels; with lanes = 1: 1, 2 cap the wavefronts a SIMD
- * holds).  stamps: 1 = the instantiation that records
+ * holds; with lanes = 5: 1, 2 cut a cell's list to 64, 256 entries, i.e. many rounds).  stamps: 1 = the instantiation that records
  * cycles per stage (pmcx_profile_phase_cycles).  Results do not depend on any of them. */
 int pmcx_set_sampler_variant(pmcx_ctx *ctx, int32_t lanes, int32_t wavefronts_per_group, int32_t stamps);
 

@@ -79,19 +79,23 @@ def test_lists_layout_at_its_reduced_levels(wp, oracle, n_class, cap, n_part):
     blk.close()
 
 
-@pytest.mark.parametrize("n_class,n_spec,lanes", [(10, 2, 0), (40, 2, 0), (40, 1, 64), (10, 1, 16), (10, 2, 16)])
+@pytest.mark.parametrize("n_class,n_spec,lanes", [(10, 2, 0), (40, 2, 0), (40, 1, 64), (10, 1, 16), (10, 2, 16),
+                                                  (40, 2, (5, 1)), (10, 1, (5, 1)), (3, 2, (5, 2))])
 def test_mc_coag_parity_many_classes(wp, oracle, n_class, n_spec, lanes):
     """mc_coag with 10 and 40 weight classes whose weights differ by one and a half decades (weighted
     removal, the merged particle's class the one that stands for fewer), particles born into empty
     groups whose lists have an entry of room or none (the table of appends), three steps with the
-    rebalance in between; counters and every particle against the oracle."""
+    rebalance in between; counters and every particle against the oracle.  lanes 0: the library's
+    choice (the screen and the sweep of its list); (5, 1), (5, 2): the same with a cell's list cut to 64 /
+    256 entries -- tens of rounds, each going on behind the slot the last one settled; 16, 64: the
+    lanes-per-cell kernels."""
     n_cells, n_part = 5, 3000
     modes, num = class_modes(n_spec, n_class)
     from wrf_partmc_amd import host
     old = host.SAMPLER_VARIANT
     try:
         if lanes:
-            host.SAMPLER_VARIANT = (lanes, 0, 0)
+            host.SAMPLER_VARIANT = (lanes[0], lanes[1], 0) if isinstance(lanes, tuple) else (lanes, 0, 0)
         blk, cells, info = parity.setup_pair(wp, oracle, n_cells, n_part, n_spec, n_class, 21, K_BROWN, cap=4 * n_part,
                                              modes=modes, num_conc=num, num_conc_scale=15.0, max_appends=4096, max_events=16384)
     finally:

@@ -3061,6 +3061,8 @@ __global__ __launch_bounds__(256) void k_coag_screen(DeviceState st, double del_
 
         int npre = 0;
         bool full = false;
+        // (diagnostic, pmcx_set_sampler_variant(5, 1 | 2, 0): lists of 64 / 256 entries, so that tests run many rounds)
+        const int cap_l = st.force_lanes == 5 && st.force_wpb == 1 ? 64 : (st.force_lanes == 5 && st.force_wpb == 2 ? 256 : SLIST_CAP);
         for (int c1 = max(sc1, 0); c1 < C && !full && hi >= 0; c1++) {
             const int l1 = lo[c1];
             if (l1 >= B) continue;
@@ -3105,7 +3107,7 @@ __global__ __launch_bounds__(256) void k_coag_screen(DeviceState st, double del_
                         const int l = __builtin_ctzll(anyp);
                         anyp &= anyp - 1;
                         const int cnt = __popc((uint32_t)__builtin_amdgcn_readlane((int)pm, l));
-                        if (npre + cnt > SLIST_CAP - 1) { full = true; break; } // (the next round goes on behind the last entry)
+                        if (npre + cnt > cap_l - 1) { full = true; break; } // (the next round goes on behind the last entry)
                         if (lane == l) {
                             int o = npre;
 #pragma unroll
