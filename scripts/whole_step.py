@@ -39,6 +39,8 @@ ap.add_argument("--law", type=int, default=1, help="pmcx_set_transport_law: 0 mo
 ap.add_argument("--prep", action="store_true", help="the adds' weight preparation on (pmcx_set_weight_preparation), as the Fortran drivers run")
 ap.add_argument("--sync-stages", action="store_true", help="every stage call waits for the device (the default before round 3)")
 ap.add_argument("--cap-factor", type=float, default=2.2, help="slots per cell / ideal count (the Fortran shim's default headroom is 3)")
+ap.add_argument("--n-class", type=int, default=1, help="weight classes (class c stands for 1 + c / 2 times class 0's number, equal shares)")
+ap.add_argument("--n-spec", type=int, default=1, help="species (the first carries the volume)")
 ap.add_argument("--auto-grow", action="store_true", help="pmcx_set_auto_grow(0.75, 1.5): the block grows like PartMC's particle arrays")
 a = ap.parse_args()
 
@@ -47,23 +49,25 @@ n = nx * ny * nz
 # slots: the rebalance lets a cell grow to twice its ideal count before it halves it
 # (aero_state_rebalance), and a step's arrivals come on top
 cap = (int(N * a.cap_factor) + 63) // 64 * 64
-blk = wp.CellBlock(n, cap, 1, n_class=1, n_source=2, max_events=1024, max_appends=128)
-blk.set_aero_data([1770.0])
+C, S = a.n_class, a.n_spec
+blk = wp.CellBlock(n, cap, S, n_class=C, n_source=2, max_events=1024, max_appends=128 if C == 1 else 1024)
+blk.set_aero_data([1770.0] + [1000.0 + 40.0 * s_ for s_ in range(1, S)])
 # transport's cell order: c = (j * nz + k) * nx + i
 k = (np.arange(n) // nx) % nz
 z = np.linspace(50.0, 12000.0, nz)
 temp = 288.15 - 6.5e-3 * z
 pres = 101325.0 * (temp / 288.15) ** 5.2559
 blk.set_env(temp[k], pres[k], np.full(n, 0.5))
-blk.set_weights(np.full((n, 1), 1e10 / N))
-blk.set_n_part_ideal(np.full((n, 1), float(N)))
+w_cls = 1.0 + 0.5 * np.arange(C)
+blk.set_weights(np.tile(1e10 / (N / C * w_cls.sum()) * w_cls, (n, 1)))
+blk.set_n_part_ideal(np.full((n, C), float(N) / C))
 if a.prep:
     blk.set_weight_preparation(True, True, True)
 blk.set_transport_law(a.law)
 if a.auto_grow:
     blk.set_auto_grow(True, 0.75, 1.5)
 blk.set_next_id((np.arange(n, dtype=np.int64) << 32) + (1 << 24))
-blk.generate_lognormal(N, idealised_modes(1, 1), seed=0)
+blk.generate_lognormal(N, [dict(idealised_modes(S, 1)[0], frac=1.0 / C, wclass=c_, source=0) for c_ in range(C)], seed=0)
 blk.synchronize()      # (no pmcx_update_kernel_bounds: mc_coag keeps each cell's bounds current)
 
 # per-step inputs and results live in page-locked host memory (pmcx_host_alloc), as the Fortran
@@ -81,14 +85,14 @@ def pinned(a):
 
 
 rng = np.random.RandomState(1)
-prob_h = np.full((n, 1, 4), 0.01) * rng.uniform(0.9, 1.1, (n, 1, 4))     # Courant-like numbers
-prob_v = np.zeros((n, 1, nz))
+prob_h = np.full((n, C, 4), 0.01) * rng.uniform(0.9, 1.1, (n, C, 4))     # Courant-like numbers
+prob_v = np.zeros((n, C, nz))
 for kk in range(nz):                                                      # to the level above/below
     m = k == kk
     if kk + 1 < nz:
-        prob_v[m, 0, kk + 1] = 0.004
+        prob_v[m, :, kk + 1] = 0.004
     if kk > 0:
-        prob_v[m, 0, kk - 1] = 0.004
+        prob_v[m, :, kk - 1] = 0.004
 cell_volume = np.full(n, 1.0e9)
 surface = (k == 0).astype(np.int32)
 ustar = np.full(n, 0.35)
@@ -96,7 +100,7 @@ ra = np.broadcast_to(aerodynamic_resistance(0.0, 0.1, 0.35), (n,))
 alpha, big_a = zhang_surface_parameters(np.full(n, 7))                    # grassland
 height = np.full(n, 50.0)
 rrho = 1.0 / (pres[k] / (287.0 * temp[k]))
-emission = [dict(num_conc=None, gm_radius=3e-8, gsd_log10=0.2, vol_frac=[1.0], wclass=0, source=1)]
+emission = [dict(num_conc=None, gm_radius=3e-8, gsd_log10=0.2, vol_frac=[1.0] + [0.0] * (S - 1), wclass=0, source=1)]
 emit_rate = np.where(surface[:, None] == 1, 2.0e5, 0.0)                   # m^-3 s^-1 at the ground
 
 fields = None
@@ -104,7 +108,9 @@ if not a.given_probs:
     # WRF-shaped single-precision fields (tests/trans_fields.py); fluxes scaled to the cells'
     # mixing ratios so that a few particles in a thousand leave through a face per step
     from tests import trans_fields
-    fields = trans_fields.make_fields(nx, nz, ny, 1, seed=3, k_scale=6.0, flux_scale=0.004 * 1e10)
+    fields = trans_fields.make_fields(nx, nz, ny, C, seed=3, k_scale=6.0, flux_scale=0.004 * 1e10)
+    for key in ("u_flux", "v_flux", "w_flux"):     # (a class's flux in proportion to the number it stands for)
+        fields[key] = fields[key] * (w_cls / w_cls.sum()).reshape((C,) + (1,) * (fields[key].ndim - 1))
 
 cell_volume, surface, ustar, ra, alpha, big_a, height, rrho, emit_rate = (
     pinned(np.ascontiguousarray(x)) for x in (cell_volume, surface, ustar, ra, alpha, big_a, height, rrho, emit_rate))

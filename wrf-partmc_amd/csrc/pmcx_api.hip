@@ -404,6 +404,7 @@ int pmcx_create(const pmcx_config *cfg, pmcx_ctx **out)
         A_(st.pre, nc * 128);
     } else {                 // several classes: the list of possible slots (4 KB per cell), the lengths it was made for
         A_(st.slist, nc * (size_t)SLIST_CAP); A_(st.gnb, nc * G); A_(st.work3, nc + 1);
+        A_(st.cls_cnt, nc * (size_t)cfg->n_class);
     }
     if (cfg->n_comp_max > 0) { // particle%component(:): 8 (1 + n_comp_max) bytes per slot
         A_(st.comp_src, nc * cap); A_(st.comp_time, nc * cap * (size_t)cfg->n_comp_max);

@@ -261,6 +261,81 @@ __device__ __forceinline__ void apply_event_log(const DeviceState &st, int c, in
     wave_sync();
 }
 
+
+// Live particles of every weight class of cell c (several classes), into cls[0 .. n_class) in LDS, by one
+// wavefront: the lists' lengths while they hold; else ONE pass over the slots' keys, eight to a 16-byte
+// load (class = key / n_bin), or over the records where the keys do not hold -- counted with LDS atomics
+// (a handful of addresses a few lanes share: eight copies of each counter, a lane adds to copy lane & 7; cls
+// holds 8 n_class ints, the sums end up in its first n_class).  Until round 4 the transport's probabilities, the
+// preweight and the rebalance each walked the cell once PER CLASS or issued a ballot per class and chunk
+// with one load in flight: 8 + 21 + 10 ms of a coupled step at ten classes and 122 880 cells.
+__device__ __forceinline__ void wave_class_counts(const DeviceState &st, int c, int lane, int *cls)
+{
+    const int C = st.n_class, B = st.n_bin;
+    for (int q = lane; q < 8 * C; q += 64) cls[q] = 0;
+    lds_sync();
+    int *mine = cls + (lane & 7) * C;   // (this lane's copy of the counters)
+    if (st.sort_valid[c]) {
+        const int32_t *g = st.gcnt + (int64_t)c * C * B;
+        for (int x = lane; x < C * B; x += 64) {
+            const int n = g[x];
+            if (n) atomicAdd(&mine[x / B], n);
+        }
+    } else {
+        const int64_t cb = (int64_t)c * st.cap;
+        const int n_hi = st.n_hi[c];
+        if (st.key_valid[c] != 0 && (st.cap & 7) == 0) {
+            const uint32_t mdiv = (1u << 24) / (uint32_t)B + 1u;  // key / B = key * mdiv >> 24 (keys < 65 535, B <= 255)
+            const uint4 *k4 = (const uint4 *)(st.gkey + cb);
+            const int n8 = (n_hi + 7) >> 3;
+            for (int j0 = 0; j0 < n8; j0 += 128) {
+                uint4 v[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) v[u] = j0 + u * 64 + lane < n8 ? k4[j0 + u * 64 + lane] : make_uint4(~0u, ~0u, ~0u, ~0u);
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const uint32_t w4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                    const int i0 = (j0 + u * 64 + lane) * 8;
+#pragma unroll
+                    for (int h = 0; h < 8; h++) {
+                        const uint32_t key = (w4[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
+                        if (key != 0xFFFFu && i0 + h < n_hi) atomicAdd(&mine[(key * mdiv) >> 24], 1);
+                    }
+                }
+            }
+        } else {
+            for (int i0 = 0; i0 < n_hi; i0 += 256) {
+                int wc[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) wc[u] = i0 + u * 64 + lane < n_hi ? live_class_c(st, cb, i0 + u * 64 + lane) : -1;
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (wc[u] >= 0) atomicAdd(&mine[wc[u]], 1);
+            }
+        }
+    }
+    lds_sync();
+    for (int q = lane; q < C; q += 64) {
+        int t = 0;
+        for (int r = 0; r < 8; r++) t += cls[r * C + q];
+        cls[q] = t;    // (copy 0's place: read before it is written, by the same lane)
+    }
+    lds_sync();
+}
+
+// the same for every cell, into cls_cnt [n_cells][n_class] (the transport's probabilities and preweight)
+__global__ __launch_bounds__(256) void k_class_counts(DeviceState st, int32_t *cls_cnt)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, C = st.n_class;
+    int *cls = (int *)smem + (size_t)wave * 8 * C;
+    for (int c = blockIdx.x * 4 + wave; c < st.n_cells; c += gridDim.x * 4) {
+        apply_event_log(st, c, lane);
+        wave_class_counts(st, c, lane, cls);
+        for (int q = lane; q < C; q += 64) cls_cnt[(int64_t)c * C + q] = cls[q];
+        lds_sync();
+    }
+}
+
 // sort key of a live particle: its group class * n_bin + bin
 __device__ __forceinline__ uint16_t key_of(const DeviceState &st, double vtot, int cl)
 {
@@ -3723,27 +3798,11 @@ __global__ __launch_bounds__(64) void k_rebalance(DeviceState st, int allow_doub
     // particles per class, class q in lane q (up to 64 classes): the lengths of the cell's lists while they
     // hold (what mc_coag leaves), else ONE pass with a ballot per class -- not a pass per class and
     // doubling, which with ten classes was 247 ms of a 535-ms step at the full domain
-    const bool counted = st.n_class > 1 && st.n_class <= 64;
-    int cls_cnt = 0;
-    if (counted) {
-        if (st.sort_valid[c]) {
-            if (lane < st.n_class) {
-                const int32_t *g = st.gcnt + ((int64_t)c * st.n_class + lane) * st.n_bin;
-                for (int b = 0; b < st.n_bin; b++) cls_cnt += g[b];
-            }
-        } else {
-            const int n_hi0 = st.n_hi[c];
-            for (int i0 = 0; i0 < n_hi0; i0 += 64) {
-                const int wc = i0 + lane < n_hi0 ? live_class_c(st, cb, i0 + lane) : -1;
-                for (int q = 0; q < st.n_class; q++) {
-                    const int k = __popcll(__ballot(wc == q));
-                    if (lane == q) cls_cnt += k;
-                }
-            }
-        }
-    }
+    const bool counted = st.n_class > 1;
+    __shared__ int s_cls[8 * 256];
+    if (counted) wave_class_counts(st, c, lane, s_cls);
     for (int cl = 0; cl < st.n_class; cl++) {
-        int ncl_kept = counted ? __shfl(cls_cnt, cl, 64) : 0;
+        int ncl_kept = counted ? s_cls[cl] : 0;
         for (uint32_t iter = 0; iter < 32; iter++) {
             int n_hi = st.n_hi[c];
             const int n_live = st.n_part[c];
@@ -4721,26 +4780,29 @@ __global__ __launch_bounds__(64, PMCX_DECIDE_WAVES) void k_trans_decide(DeviceSt
     const int lane = threadIdx.x, c = blockIdx.x;
     const int C = st.n_class, nx = tg.nx, nz = tg.nz, ny = tg.ny;
     const int ND = 4 + nz;
-    double *t_lo = (double *)smem;           // [C][ND]
-    double *t_hi = t_lo + C * ND;
-    double *t_ratio = t_hi + C * ND;
-    double *t_p = t_ratio + C * ND;          // scratch: probabilities before sorting
-    int *t_dest = (int *)(t_p + C * ND);     // [C][ND]
-    int *t_tmpd = t_dest + C * ND;           // scratch: destinations before sorting
-    int *t_n = t_tmpd + C * ND;              // [C]
-    // (formed from smem and an offset: through an integer the pointer would lose its address space
-    // and every access of the mover's path become a FLAT one, whose wait is for all the
-    // wavefront's requests, the next trip's keys among them)
-    uint64_t *t_bit = (uint64_t *)(smem + ((((size_t)((unsigned char *)(t_n + C) - smem)) + 7) & ~(size_t)7)); // [C][ND] dest_mask bit
-    int *t_cnt = (int *)(t_bit + C * ND);    // [C][ND] copies sent to each destination
-    // law 1, per class: the sum of the emitters' rates, their interval [s_act_lo, s_act_hi) of the placing uniform
-    double *s_mu_sum = (double *)(smem + ((((size_t)((unsigned char *)(t_cnt + C * ND) - smem)) + 7) & ~(size_t)7));
-    double *s_act_lo = s_mu_sum + C, *s_act_hi = s_act_lo + C;
+    // The tables of a class cost 33 bytes per destination (60 until round 4: with ten weight classes six
+    // wavefronts shared a CU's LDS where twenty-four stream keys with one): the thresholds' lower ends
+    // are the upper ends in front of them, the destination's bit of the mask is kept as its index, the
+    // scratch of the sort is one class's.  (Pointers formed from smem and offsets: through an integer a
+    // pointer would lose its address space and every access of the mover's path become a FLAT one, whose
+    // wait is for all the wavefront's requests, the next trip's keys among them.)
+    double *t_hi = (double *)smem;           // [C][ND] cumulative thresholds (their upper ends)
+    double *t_ratio = t_hi + C * ND;         // [C][ND]
     // law 1: the running sum of the rates over a class's r < 1 destinations in table order (-1: r >= 1):
     // what a copy's uniform is compared with when it is dealt (formed once per cell, not per copy)
-    double *t_mucum = s_act_hi + C;          // [C][ND]
+    double *t_mucum = t_ratio + C * ND;      // [C][ND]
+    double *t_p = t_mucum + C * ND;          // [ND] scratch: a class's probabilities before sorting
+    // law 1, per class: the sum of the emitters' rates, their interval [s_act_lo, s_act_hi) of the placing uniform
+    double *s_mu_sum = t_p + ND;
+    double *s_act_lo = s_mu_sum + C, *s_act_hi = s_act_lo + C;
+    int *t_dest = (int *)(s_act_hi + C);     // [C][ND]
+    int *t_cnt = t_dest + C * ND;            // [C][ND] copies sent to each destination
+    int *t_tmpd = t_cnt + C * ND;            // [ND] scratch: a class's destinations before sorting
+    int *t_n = t_tmpd + ND;                  // [C]
     // law 1: a lane's copies per destination while it deals them ([64][ND], an emitter of several copies)
-    uint16_t *s_deal = (uint16_t *)(t_mucum + C * ND);
+    uint16_t *s_deal = (uint16_t *)(t_n + C);
+    uint8_t *t_bit = (uint8_t *)(s_deal + 64 * ND); // [C][ND] the destination's bit of dest_mask (255: every bit)
+    auto bit_of = [](uint8_t b) -> uint64_t { return b == 255u ? ~0ull : 1ull << b; };
     for (int x = lane; x < C * ND; x += 64) t_cnt[x] = 0;
     const int i = c % nx, k = (c / nx) % nz, j = c / (nx * nz);
     const bool mask_ok = ND <= 64 && (nx >= 3 || !tg.periodic_x) && (ny >= 3 || !tg.periodic_y);
@@ -4755,8 +4817,8 @@ __global__ __launch_bounds__(64, PMCX_DECIDE_WAVES) void k_trans_decide(DeviceSt
     // one); its weight ratio and its bit of the destination mask are its own lane's work; only
     // the cumulative thresholds are taken in sequence (their sums depend on the order).
     for (int cl = 0; cl < C; cl++) {
-        double *p = t_p + cl * ND;
-        int *dc = t_tmpd + cl * ND;
+        double *p = t_p;
+        int *dc = t_tmpd;
         int *ord = t_cnt + cl * ND; // rank -> element (t_cnt is cleared again below)
         const bool bx = lateral_col(st, i, nx), by = lateral_row(st, j, ny);
         const bool lateral_cell = st.trans_lateral && (bx || by);
@@ -4808,28 +4870,16 @@ __global__ __launch_bounds__(64, PMCX_DECIDE_WAVES) void k_trans_decide(DeviceSt
             t_ratio[cl * ND + r] = (st.mag[(int64_t)dca * C + cl] / factor) / mag_from;
             // where the destination lies, as the gather of that cell will look for it
             const int di_ = dca % nx, dk_ = (dca / nx) % nz, dj_ = dca / (nx * nz);
-            uint64_t bit = ~0ull;
+            uint8_t bit = 255u;
             if (mask_ok) {
-                if (di_ == i && dj_ == j) bit = 1ull << (4 + dk_);
-                else if (dj_ == j) bit = (di_ == (i + 1) % nx) ? 1ull : 2ull;
-                else bit = (dj_ == (j + 1) % ny) ? 4ull : 8ull;
+                if (di_ == i && dj_ == j) bit = (uint8_t)(4 + dk_);
+                else if (dj_ == j) bit = (di_ == (i + 1) % nx) ? 0u : 1u;
+                else bit = (dj_ == (j + 1) % ny) ? 2u : 3u;
             }
             t_bit[cl * ND + r] = bit;
+            t_hi[cl * ND + r] = p[a];   // (the probability, in table order: summed below, a lane per class)
         }
-        if (lane == 0) {
-            double rem = 1.0, cum = 0.0;
-            for (int r = 0; r < n; r++) {
-                const double pa = p[ord[r]];
-                t_lo[cl * ND + r] = cum;
-                if (rem >= 1e-8) {
-                    cum = cum + pa;
-                    if (cum > 1.0) cum = 1.0;
-                    rem = rem - pa;
-                }
-                t_hi[cl * ND + r] = cum;
-            }
-            t_n[cl] = n;
-        }
+        if (lane == 0) t_n[cl] = n;
         lds_sync();
     }
     for (int x = lane; x < C * ND; x += 64) t_cnt[x] = 0;
@@ -4843,13 +4893,27 @@ __global__ __launch_bounds__(64, PMCX_DECIDE_WAVES) void k_trans_decide(DeviceSt
     // Either way P(moves to d) = p_d and E[copies to d] = mu_d: arrivals n p_d / r_d in the mean.
     for (int cl = lane; cl < C; cl += 64) {
         const int nt = t_n[cl];
-        double sum_mu = 0.0, a_lo = nt > 0 ? t_hi[cl * ND + nt - 1] : 0.0, a_hi = a_lo;
-        if (EMIT && nt > 0) {
+        // the cumulative thresholds, taken in sequence (their sums depend on the order)
+        double sum_mu = 0.0;
+        {
+            double rem = 1.0, cum = 0.0;
             for (int d = 0; d < nt; d++) {
-                const double r = t_ratio[cl * ND + d];
-                if (r < 1.0) sum_mu = sum_mu + (t_hi[cl * ND + d] - t_lo[cl * ND + d]) * (1.0 - r) / r;
-                t_mucum[cl * ND + d] = r < 1.0 ? sum_mu : -1.0;
+                const double pa = t_hi[cl * ND + d], lo = cum;
+                if (rem >= 1e-8) {
+                    cum = cum + pa;
+                    if (cum > 1.0) cum = 1.0;
+                    rem = rem - pa;
+                }
+                t_hi[cl * ND + d] = cum;
+                if (EMIT) {
+                    const double r = t_ratio[cl * ND + d];
+                    if (r < 1.0) sum_mu = sum_mu + (cum - lo) * (1.0 - r) / r;
+                    t_mucum[cl * ND + d] = r < 1.0 ? sum_mu : -1.0;
+                }
             }
+        }
+        double a_lo = nt > 0 ? t_hi[cl * ND + nt - 1] : 0.0, a_hi = a_lo;
+        if (EMIT && nt > 0) {
             const double w_emit = 1.0 - det_exp(-sum_mu);
             a_hi = a_lo + w_emit;
             if (a_hi > 1.0) { a_hi = 1.0; a_lo = 1.0 - w_emit; }
@@ -4948,7 +5012,7 @@ __global__ __launch_bounds__(64, PMCX_DECIDE_WAVES) void k_trans_decide(DeviceSt
                 }
                 dslot = cl * ND + d;
                 dest = t_dest[dslot];
-                bits |= t_bit[dslot];
+                bits |= bit_of(t_bit[dslot]);
                 moves = true;
             }
         }
@@ -4981,7 +5045,7 @@ __global__ __launch_bounds__(64, PMCX_DECIDE_WAVES) void k_trans_decide(DeviceSt
                     const int k_y = n_emit == 1 ? 1 : (int)deal[y];
                     if (k_y == 0) continue;
                     box[at++] = make_int2(s | (k_y << 16) | TRANS_STAYS, t_dest[cl * ND + y]);
-                    bits |= t_bit[cl * ND + y];
+                    bits |= bit_of(t_bit[cl * ND + y]);
                     atomicAdd(&t_cnt[cl * ND + y], k_y);
                 }
             }
@@ -5133,26 +5197,8 @@ __global__ __launch_bounds__(256) void k_trans_probs(DeviceState st, TransFields
     for (int k = wave; k < nz; k += 4) {
         const int c = (int)cell_of(k);
         if (C == 1) { if (lane == 0) cnt[k] = st.n_part[c]; continue; }
-        apply_event_log(st, c, lane);
-        const int64_t cb = (int64_t)c * st.cap;
-        const int n_hi = st.n_hi[c];
-        const bool keyed = st.key_valid[c] != 0;
-        for (int s0 = 0; s0 < n_hi; s0 += 64) {
-            const int sl = s0 + lane;
-            int cl = -1;
-            if (sl < n_hi) {
-                if (keyed) {
-                    const uint32_t kq = st.gkey[cb + sl];
-                    cl = kq == 0xFFFFu ? -1 : (int)(kq / (uint32_t)st.n_bin);
-                } else {
-                    cl = live_class(st, cb, sl);
-                }
-            }
-            for (int q = 0; q < C; q++) {
-                const int n = __popcll(__ballot(cl == q));
-                if (lane == 0) cnt[k * C + q] += n;
-            }
-        }
+        // (several classes: counted by k_class_counts, launched in front of this kernel)
+        for (int q = lane; q < C; q += 64) cnt[k * C + q] = st.cls_cnt[(int64_t)c * C + q];
     }
     __syncthreads();
 
@@ -5517,7 +5563,7 @@ __global__ __launch_bounds__(64) void k_boundary_resample(DeviceState st, const 
 // trans_aero_preweight (interface/wrf_pmc_trans_aero.F90:1103-1423): the number concentration
 // every (cell, class) is expected to hold after the transport, and a larger weight where that
 // is more than twice the ideal particle count.
-//   k_preweight_old    one wavefront per cell: particles per class x magnitude
+//   k_preweight_old    a thread per (cell, class): particles per class (k_class_counts) x magnitude
 //   k_preweight_new    one thread per (cell, class): compute_fluxes (:1428-1627) turned into a
 //                      gather that adds its terms in the order the reference's scatter applies them
 //                      to that cell -- sources in (j, k, i) order, the cell's own losses at its place
@@ -5546,29 +5592,13 @@ struct PreweightArgs {
 
 __global__ __launch_bounds__(64) void k_preweight_old(DeviceState st, PreweightArgs a)
 {
-    const int lane = threadIdx.x, c = blockIdx.x, C = st.n_class;
-    const int64_t cb = (int64_t)c * st.cap;
-    apply_event_log(st, c, lane);
-    const int n_hi = st.n_hi[c];
-    const bool keyed = st.key_valid[c] != 0;
-    for (int cl = 0; cl < C; cl++) {
-        int n = st.n_part[c];
-        if (C > 1) {
-            uint32_t cnt = 0;
-            for (int i = lane; i < n_hi; i += 64) {
-                int wc;
-                if (keyed) {
-                    const uint32_t kq = st.gkey[cb + i];
-                    wc = kq == 0xFFFFu ? -1 : (int)(kq / (uint32_t)st.n_bin);
-                } else {
-                    wc = live_class(st, cb, i);
-                }
-                cnt += (wc == cl);
-            }
-            n = (int)wave_sum_u64(cnt);
-        }
-        if (lane == 0) a.old[(int64_t)c * C + cl] = (double)n * st.mag[(int64_t)c * C + cl];
-    }
+    // (a thread per (cell, class); several classes: counted by k_class_counts, launched in front)
+    const int C = st.n_class;
+    const int64_t x = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (x >= (int64_t)st.n_cells * C) return;
+    const int c = (int)(x / C);
+    const int n = C > 1 ? st.cls_cnt[x] : st.n_part[c];
+    a.old[x] = (double)n * st.mag[x];
 }
 
 // which moves a source cell makes: bit d of the result = towards i-1, i+1, j-1, j+1; bit 4 = levels
@@ -6324,6 +6354,15 @@ __global__ void k_test_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
 
 // ------------------------------------------------------------------ launchers
 
+// particles per class of every cell into st.cls_cnt (several classes)
+static void launch_class_counts(const DeviceState &st, hipStream_t s)
+{
+    if (st.n_class <= 1 || !st.cls_cnt) return;
+    const int n_wg = (st.n_cells + 3) / 4;
+    hipLaunchKernelGGL(k_class_counts, dim3(n_wg < 32768 ? n_wg : 32768), dim3(256), 4 * 8 * sizeof(int) * (size_t)st.n_class, s,
+                       st, st.cls_cnt);
+}
+
 static size_t bin_sort_lds_for(const DeviceState &st, int nw)
 {
     const size_t B = st.n_bin, G = (size_t)st.n_bin * st.n_class;
@@ -6846,8 +6885,8 @@ size_t transport_lds_bytes(const DeviceState &st, int nz)
 {
     const size_t nd = (size_t)(4 + nz), C = (size_t)st.n_class;
     // (+ law 1: three doubles per class, a lane's copies per destination while it deals them)
-    return (sizeof(double) * 5 + sizeof(int) * 3 + sizeof(uint64_t)) * C * nd + sizeof(int) * C + 24 +
-           3 * sizeof(double) * C + 8 + sizeof(uint16_t) * 64 * nd;
+    return sizeof(double) * (3 * C * nd + nd + 3 * C) + sizeof(int) * (2 * C * nd + nd + C) +
+           sizeof(uint16_t) * 64 * nd + C * nd + 16;
 }
 static TransGrid make_grid(int nx, int nz, int ny, int periodic_x, int periodic_y,
                            const double *prob_h, const double *prob_v, const double *cell_volume,
@@ -6944,7 +6983,8 @@ hipError_t launch_preweight_slab_begin(const DeviceState &st, int nx, int nz, in
     a.nx = nx; a.nz = nz; a.ny = ny; a.ideal = ideal; a.prob_h = prob_h; a.prob_v = prob_v;
     a.cell_volume = cell_volume; a.old = old; a.slab = 1; a.j_global0 = j_global0; a.global_ny = global_ny;
     a.edge_out = edge_out;
-    hipLaunchKernelGGL(k_preweight_old, dim3(st.n_cells), dim3(64), 0, s, st, a);
+    launch_class_counts(st, s);
+    hipLaunchKernelGGL(k_preweight_old, dim3((unsigned)(((int64_t)st.n_cells * st.n_class + 63) / 64)), dim3(64), 0, s, st, a);
     const int64_t n = 2 * (int64_t)nx * nz * st.n_class + (st.trans_cut_x ? 2 * (int64_t)ny * nz * st.n_class : 0);
     hipLaunchKernelGGL(k_preweight_edge, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, a);
     return hipGetLastError();
@@ -6976,7 +7016,8 @@ hipError_t launch_transport_preweight(const DeviceState &st, int nx, int nz, int
     PreweightArgs a{};
     a.nx = nx; a.nz = nz; a.ny = ny; a.ideal = ideal; a.prob_h = prob_h; a.prob_v = prob_v;
     a.cell_volume = cell_volume; a.old = old; a.expect = expect; a.n_removed = n_removed;
-    hipLaunchKernelGGL(k_preweight_old, dim3(st.n_cells), dim3(64), 0, s, st, a);
+    launch_class_counts(st, s);
+    hipLaunchKernelGGL(k_preweight_old, dim3((unsigned)(((int64_t)st.n_cells * st.n_class + 63) / 64)), dim3(64), 0, s, st, a);
     const int64_t n = (int64_t)st.n_cells * st.n_class;
     hipLaunchKernelGGL(k_preweight_new, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, a);
     hipLaunchKernelGGL(k_preweight_scale, dim3(st.n_cells), dim3(64), 0, s, st, a, seed, step);
@@ -6989,6 +7030,7 @@ size_t trans_probs_lds_bytes(const DeviceState &st, int nz)
 }
 hipError_t launch_transport_probs(const DeviceState &st, const TransFieldsArgs &a, hipStream_t s)
 {
+    launch_class_counts(st, s);
     TransFieldsDev f{};
     f.nx = a.nx; f.nz = a.nz; f.ny = a.ny; f.do_vertmix = a.do_vertmix; f.all_columns = a.all_columns;
     f.i_offset = a.i_offset; f.j_offset = a.j_offset; f.global_nx = a.global_nx; f.global_ny = a.global_ny;
