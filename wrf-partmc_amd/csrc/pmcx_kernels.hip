@@ -683,8 +683,11 @@ __global__ __launch_bounds__(256) void k_list_cells(DeviceState st, int what, in
     if (need) scratch[1 + base + (int)__popcll(m & ((1ull << lane) - 1ull))] = c;
 }
 
+// stage: the cell's keys are copied to LDS (2 bytes a slot of `cap`) and both passes read them there; 0: they
+// are read from memory twice (tens of weight classes: the per-wavefront tables take the room -- with ten
+// classes and cap = 22 016 one workgroup filled a CU's LDS where three fit without the copy)
 __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st, const int32_t *list,
-                                                  const int32_t *count)
+                                                  const int32_t *count, int stage)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint32_t wsum[4];
@@ -731,6 +734,30 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st, const int32_t 
         // pass 1, keys kept: 2 bytes per slot instead of its 32-byte record.  The slots the pair
         // sampler re-binned or removed since the keys were written are in the cell's event log,
         // applied in order (a slot may appear more than once) and written back to the keys.
+        if (!stage) {
+            // the log's entries go to the keys in memory: of several for one slot the last one
+            const int nl = min(st.n_log[c], EVLOG_CAP);
+            __shared__ uint32_t s_log2[EVLOG_CAP];
+            if (nl > 0) {
+                for (int j = t; j < nl; j += NT) s_log2[j] = st.evlog[(int64_t)c * EVLOG_CAP + j];
+                __syncthreads();
+                for (int j = t; j < nl; j += NT) {
+                    const uint32_t e = s_log2[j], sl = e & 0xFFFFu;
+                    bool last = (int)sl < n;
+                    for (int q = j + 1; q < nl && last; q++) last = (s_log2[q] & 0xFFFFu) != sl;
+                    if (last) gk[sl] = (uint16_t)(e >> 16);
+                }
+                __threadfence_block();
+                __syncthreads();
+            }
+            for (int i0 = lo; i0 < hi; i0 += 256) {
+                uint32_t g4[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) g4[u] = i0 + u * 64 + lane < hi ? (uint32_t)gk[i0 + u * 64 + lane] : 0xFFFFu;
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (g4[u] != 0xFFFFu) atomicAdd(&myhist[g4[u]], 1u);
+            }
+        } else {
         if ((st.cap & 7) == 0) {
             // eight keys per lane and request: the wave's whole range is in flight at once.  The
             // range starts at a multiple of 64 slots and the cell's keys at a multiple of 8: both
@@ -766,6 +793,7 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st, const int32_t 
             const uint32_t g = key[i];
             if (g != 0xFFFFu) atomicAdd(&myhist[g], 1u);
         }
+        }
     } else {
     // pass 1: keys + per-wave histogram (LDS atomics: counting is order-independent).
     // Four loads are issued before the first use so a wave keeps 2 KiB in flight.
@@ -784,11 +812,11 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st, const int32_t 
                     oog |= (v[u] < v_lo) | (v[u] >= v_hi);
                     uint32_t g = (uint32_t)bin_index(edge, B, v[u], st);
                     if (C > 1) g += (uint32_t)wc[i] * (uint32_t)B;
-                    key[i] = (uint16_t)g;
+                    if (stage) key[i] = (uint16_t)g;
                     gk[i] = (uint16_t)g;
                     atomicAdd(&myhist[g], 1u);
                 } else {
-                    key[i] = 0xFFFFu; // tombstone
+                    if (stage) key[i] = 0xFFFFu; // tombstone
                     gk[i] = (uint16_t)0xFFFFu;
                 }
             }
@@ -796,6 +824,7 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st, const int32_t 
     }
     }
     if (oog) atomicOr(&st.status[c], ST_OUT_OF_GRID);
+    if (!stage) __threadfence_block(); // (the keys written to memory are read again below, by other lanes)
     __syncthreads();
 
     int32_t *gcnt_g = st.gcnt + (int64_t)c * G;
@@ -838,9 +867,16 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st, const int32_t 
     uint16_t *perm = st.perm + (int64_t)c * st.pcap;
     uint64_t *mymask = pmask + (size_t)wave * G;
     if (t == 0) { st.sort_valid[c] = 1; st.key_valid[c] = 1; st.n_log[c] = 0; }
+    uint32_t k_next = (!stage && lo + lane < hi) ? (uint32_t)gk[lo + lane] : 0xFFFFu; // (requested a chunk ahead)
     for (int i0 = lo; i0 < hi; i0 += 64) {
         const int i = i0 + lane;
-        const uint32_t gk = i < hi ? key[i] : 0xFFFFu;
+        uint32_t gk;
+        if (stage) {
+            gk = i < hi ? key[i] : 0xFFFFu;
+        } else {
+            gk = k_next;
+            k_next = i + 64 < hi ? (uint32_t)(st.gkey + cb)[i + 64] : 0xFFFFu;
+        }
         const bool valid = gk != 0xFFFFu;
         if (valid) atomicOr((unsigned long long *)&mymask[gk], 1ull << lane);
         lds_sync();
@@ -5833,9 +5869,6 @@ __global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid t
             for (int g = 0; g < copies; g++) {
                 const int dst = (int)first + g;
                 if (dst >= st.cap) { status |= ST_CAP_OVERFLOW; break; }
-                if (S > 1)
-                    for (int sp = 0; sp < S; sp++)
-                        st.vol[(cb + dst) * S + sp] = st.vol[(sb + from) * S + sp];
                 for (int sp = 1; sp < NS; sp++)
                     norig(st, cb, sp, dst) = norig(st, sb, sp, from);
                 st.hot[cb + dst] = hv;
@@ -5845,6 +5878,32 @@ __global__ __launch_bounds__(64) void k_trans_gather(DeviceState st, TransGrid t
                 if (stays || g != copies - 1) c2.id = id0 + g;
                 st.cold[cb + dst] = c2;
                 comp_copy(st, cb + dst, sb + from);
+            }
+        }
+        if (S > 1) {
+            // the species volumes of the chunk's arrivals, lanes over (arrival, species): n_spec x 8 contiguous
+            // bytes per record, four requests a lane in flight (a lane copying its own arrival's species one
+            // after the other was twenty dependent round trips a chunk at the reference's 20 species)
+            const int64_t srow = sb + from;
+            const int fits = copies > 0 ? max(0, min(copies, st.cap - (int)first)) : 0;
+            const int s_lo = (int)(uint32_t)srow, s_hi = (int)(uint32_t)((uint64_t)srow >> 32);
+            for (int it0 = 0; it0 < 64 * S; it0 += 256) {
+                double v[4];
+                int64_t d0[4];
+                int n4[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int it = it0 + u * 64 + lane;
+                    const int e = min(it / S, 63), sp = it - (it / S) * S;
+                    const int64_t src = (int64_t)(((uint64_t)(uint32_t)__shfl(s_hi, e, 64) << 32) | (uint32_t)__shfl(s_lo, e, 64));
+                    const int df = __shfl((int)first, e, 64), nc = __shfl(fits, e, 64);
+                    n4[u] = it < 64 * S ? nc : 0;
+                    d0[u] = (cb + df) * S + sp;
+                    v[u] = n4[u] > 0 ? st.vol[src * S + sp] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    for (int g = 0; g < n4[u]; g++) st.vol[d0[u] + (int64_t)g * S] = v[u];
             }
         }
         at += (int)__shfl(inc, 63, 64);
@@ -6363,23 +6422,28 @@ static void launch_class_counts(const DeviceState &st, hipStream_t s)
                        st, st.cls_cnt);
 }
 
-static size_t bin_sort_lds_for(const DeviceState &st, int nw)
+static size_t bin_sort_lds_for(const DeviceState &st, int nw, bool stage)
 {
     const size_t B = st.n_bin, G = (size_t)st.n_bin * st.n_class;
     const size_t o_tab = (sizeof(double) * (B + 1) + 15) & ~(size_t)15;
     const size_t o_key = (o_tab + (sizeof(uint64_t) * nw + sizeof(uint32_t) * (nw + 1)) * G + 15) & ~(size_t)15;
-    return o_key + sizeof(uint16_t) * (((size_t)st.cap + 7) & ~(size_t)7);
+    return o_key + (stage ? sizeof(uint16_t) * (((size_t)st.cap + 7) & ~(size_t)7) : 0);
+}
+// the keys' copy in LDS while three workgroups still share a CU with it
+static bool bin_sort_stage(const DeviceState &st)
+{
+    return bin_sort_lds_for(st, 4, true) <= (size_t)53 * 1024;
 }
 // wavefronts per workgroup of k_bin_sort: four, fewer where their tables would not fit in LDS
 int bin_sort_waves(const DeviceState &st)
 {
     int nw = 4;
-    while (nw > 1 && bin_sort_lds_for(st, nw) > (size_t)150 * 1024) nw >>= 1;
+    while (nw > 1 && bin_sort_lds_for(st, nw, bin_sort_stage(st)) > (size_t)150 * 1024) nw >>= 1;
     return nw;
 }
 size_t bin_sort_lds_bytes(const DeviceState &st)
 {
-    return bin_sort_lds_for(st, bin_sort_waves(st));
+    return bin_sort_lds_for(st, bin_sort_waves(st), bin_sort_stage(st));
 }
 static size_t sampler_lds_for(const DeviceState &st, int lanes)
 {
@@ -6573,7 +6637,7 @@ hipError_t launch_bin_sort(const DeviceState &st, hipStream_t s)
     list_cells(st, LIST_SORT, 0, 0, 0, st.n_cells, s);
     hipLaunchKernelGGL(k_bin_sort, dim3(st.n_cells < 16384 ? st.n_cells : 16384), dim3(64 * bin_sort_waves(st)),
                        bin_sort_lds_bytes(st), s, st, (const int32_t *)(st.work_list + 1),
-                       (const int32_t *)st.work_list);
+                       (const int32_t *)st.work_list, bin_sort_stage(st) ? 1 : 0);
     return hipGetLastError();
 }
 bool coag_sample_splits_draw(const DeviceState &st, int ktype)
