@@ -1990,6 +1990,8 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
         // ---- next block when the sweep leaves it, settle on -- NROUND rounds a pass ----
         bool pending = false;            // a slot whose count needs the exact Poisson
         double p_mean = 0, p_u = 0;
+        uint32_t pe_A = 0, pe_B = 0;     // LISTED: the drawn slot's list entries (count | offset << 16)
+        bool have_ent = false;
         bool dr = role_d && own && !done && ns_rem == 0;
         if (STAMPS && dr) t_acc[9]++;
         // the slot's mean and uniform from the cached block; ZERO = true: its count is surely zero
@@ -2059,7 +2061,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                     // samples now): the next round lists what lies behind the slot settled last
                     unfinished = true; done = true;
                 } else {
-                    uint32_t cA[4], cB[4];
+                    uint32_t cA[4], cB[4], oA[4], oB[4];
                     float kf[4];
                     double wa[4], wb[4];
 #pragma unroll
@@ -2068,6 +2070,8 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                         const int e1 = (int)(x >> 24), d1 = (int)((x >> 16) & 0xFFu), e2 = (int)((x >> 8) & 0xFFu), d2 = (int)(x & 0xFFu);
                         cA[k] = (uint32_t)gcnt_g[e1 * B + d1];
                         cB[k] = (uint32_t)gcnt_g[e2 * B + d2];
+                        oA[k] = (uint32_t)goff_g[e1 * B + d1];   // (for the first sample of the entry that holds some)
+                        oB[k] = (uint32_t)goff_g[e2 * B + d2];
                         kf[k] = st.kmax[(int64_t)c * st.kmax_stride + d1 * B + d2];
                         wa[k] = st.mag[(int64_t)c * C + e1];
                         wb[k] = st.mag[(int64_t)c * C + e2];
@@ -2093,7 +2097,11 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
                                 const double mean_ = k_max * del_t * n_possible_;
                                 const double u_ = (double)lq[k].y * 0x1.0p-32;
                                 // (a list that ran out gives n_possible <= 0: no sample, as the sweep has it)
-                                if (!(u_ < (1.0 - mean_) - 4e-15)) { pending = true; p_mean = mean_; p_u = u_; }
+                                if (!(u_ < (1.0 - mean_) - 4e-15)) {
+                                    pending = true; p_mean = mean_; p_u = u_;
+                                    pe_A = (cA[k] & 0xFFFFu) | (oA[k] << 16); pe_B = (cB[k] & 0xFFFFu) | (oB[k] << 16);
+                                    have_ent = true;
+                                }
                                 used++;
                             }
                         }
@@ -2227,10 +2235,14 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
             if (SIMPLE && !any_wide) {
                 eA = ent[(b1 - blo) * 64 + lane];
                 eB = same ? eA : ent[(b2 - blo) * 64 + lane];
+            } else if (LISTED && have_ent) {
+                // (the slot was drawn in this pass: its lists' lengths and offsets came with its entry)
+                eA = pe_A; eB = same ? eA : pe_B;
             } else {
                 eA = ent_get(c1, b1);
                 eB = same ? eA : ent_get(c2, b2);
             }
+            have_ent = false;
             const int nA = (int)(eA & 0xFFFFu), nB = (int)(eB & 0xFFFFu);
             if (nA < 1 || nB < 1 || (same && nA < 2)) {
                 ns_rem = 0; // a list ran out: the slot ends (the lane draws in the next pass)
