@@ -1514,7 +1514,7 @@ __device__ unsigned long long g_seq_stamps[12];
 // window word) lives in LDS between passes; in a pass a lane is worked on by exactly one of the
 // two (the evaluator while it holds samples, else the drawer), one barrier per pass: per lane
 // the sequence of operations, and every result, is the single wavefront's.
-// PRE (one class, one species, Brownian: the benchmark's and the reference's configuration): the
+// PRE (one class, Brownian: the benchmark's configuration, any species count): the
 // draw is split off the sweep.  Phase 0, every lane busy: the lane walks ALL slots of its cell in
 // sweep order, four to a Philox block as the sweep would, and keeps the few whose count could be
 // non-zero -- tested with both lists PRE_M entries longer than they are now, which bounds their
@@ -2631,7 +2631,7 @@ void k_coag_lane(DeviceState st, int ktype_rt, double del_t, uint64_t seed, uint
 
 // ------------------------------ coag sampler, lane per cell, the cells of a workgroup grouped by what they do next
 //
-// k_coag_grp (one class, one species, Brownian: the benchmark's and the reference's configuration).  In
+// k_coag_grp (one class, Brownian: the benchmark's configuration, any species count).  In
 // k_coag_lane a lane IS a cell for the whole sweep, and the 64 cells of a wavefront are in different states
 // -- settling slots, counting, evaluating a sample, coagulating -- so every pass runs every stage for the
 // few lanes that need it: 1 700 instructions a pass, the draw alone half of a wavefront's cycles at a sixth
@@ -6467,7 +6467,7 @@ size_t sampler_lds_bytes_per_cell(const DeviceState &st)
     return sampler_lds_for(st, 64); // upper bound over the lane variants
 }
 // The sampler's form.  1: one lane per cell with the draw split off the sweep (k_coag_lane<.., PRE>;
-// one class, one species, Brownian); 3: one lane per cell, drawing as it sweeps; 2: that in its
+// one class, Brownian); 3: one lane per cell, drawing as it sweeps; 2: that in its
 // two-wavefront form; 8, 16, 64: lanes per cell (k_coag_sample).  pmcx_set_sampler_variant overrides
 // (tests hold every form to the oracle at small sizes).
 static bool pre_available(const DeviceState &st, int ktype)
