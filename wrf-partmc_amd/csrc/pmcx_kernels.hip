@@ -750,6 +750,21 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st, const int32_t 
                 __threadfence_block();
                 __syncthreads();
             }
+            if ((st.cap & 7) == 0) {
+                // eight keys per lane and request (the range starts at a multiple of 64 slots, the cell's keys
+                // at a multiple of 8; keys past hi, below cap, ride along and are not counted)
+                const uint4 *g4 = (const uint4 *)(gk + lo);
+                const int n8 = (hi - lo + 7) >> 3;
+                for (int j = lane; j < n8; j += 64) {
+                    const uint4 v = g4[j];
+                    const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int h = 0; h < 8; h++) {
+                        const uint32_t g = (w4[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
+                        if (g != 0xFFFFu && lo + j * 8 + h < hi) atomicAdd(&myhist[g], 1u);
+                    }
+                }
+            } else
             for (int i0 = lo; i0 < hi; i0 += 256) {
                 uint32_t g4[4];
 #pragma unroll
@@ -867,12 +882,27 @@ __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st, const int32_t 
     uint16_t *perm = st.perm + (int64_t)c * st.pcap;
     uint64_t *mymask = pmask + (size_t)wave * G;
     if (t == 0) { st.sort_valid[c] = 1; st.key_valid[c] = 1; st.n_log[c] = 0; }
-    uint32_t k_next = (!stage && lo + lane < hi) ? (uint32_t)gk[lo + lane] : 0xFFFFu; // (requested a chunk ahead)
+    // without the whole copy: 512 keys at a time through a small LDS buffer of the wavefront's own (two
+    // halves: the block being scattered, the next one's request in flight meanwhile), eight keys a lane
+    const bool rolling = !stage && (st.cap & 7) == 0;
+    uint16_t *roll = key + (size_t)wave * 1024;
+    const uint4 *gk4 = (const uint4 *)(st.gkey + cb);
+    uint4 nxt = make_uint4(~0u, ~0u, ~0u, ~0u);
+    if (rolling && lo + lane * 8 < hi) nxt = gk4[(lo >> 3) + lane];
+    uint32_t k_next = (!stage && !rolling && lo + lane < hi) ? (uint32_t)gk[lo + lane] : 0xFFFFu; // (requested a chunk ahead)
     for (int i0 = lo; i0 < hi; i0 += 64) {
         const int i = i0 + lane;
         uint32_t gk;
         if (stage) {
             gk = i < hi ? key[i] : 0xFFFFu;
+        } else if (rolling) {
+            const int rel = i0 - lo, half = (rel >> 9) & 1;
+            if ((rel & 511) == 0) {   // (uniform) a new block: what was requested goes to LDS, the next block is requested
+                ((uint4 *)(roll + half * 512))[lane] = nxt;
+                nxt = (i0 + 512 + lane * 8 < hi) ? gk4[((i0 + 512) >> 3) + lane] : make_uint4(~0u, ~0u, ~0u, ~0u);
+                lds_sync();
+            }
+            gk = i < hi ? (uint32_t)roll[half * 512 + (rel & 511) + lane] : 0xFFFFu;
         } else {
             gk = k_next;
             k_next = i + 64 < hi ? (uint32_t)(st.gkey + cb)[i + 64] : 0xFFFFu;
@@ -6439,7 +6469,8 @@ static size_t bin_sort_lds_for(const DeviceState &st, int nw, bool stage)
     const size_t B = st.n_bin, G = (size_t)st.n_bin * st.n_class;
     const size_t o_tab = (sizeof(double) * (B + 1) + 15) & ~(size_t)15;
     const size_t o_key = (o_tab + (sizeof(uint64_t) * nw + sizeof(uint32_t) * (nw + 1)) * G + 15) & ~(size_t)15;
-    return o_key + (stage ? sizeof(uint16_t) * (((size_t)st.cap + 7) & ~(size_t)7) : 0);
+    // (without the copy: two halves of 512 keys per wavefront)
+    return o_key + (stage ? sizeof(uint16_t) * (((size_t)st.cap + 7) & ~(size_t)7) : sizeof(uint16_t) * 1024 * (size_t)nw);
 }
 // the keys' copy in LDS while three workgroups still share a CU with it
 static bool bin_sort_stage(const DeviceState &st)
