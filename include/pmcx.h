@@ -764,7 +764,9 @@ int pmcx_invalidate_sort(pmcx_ctx *ctx);
 int pmcx_set_sampler_variant(pmcx_ctx *ctx, int32_t lanes, int32_t wavefronts_per_group, int32_t stamps);
 
 /* Inspection: out[0] = cells the lane-per-cell sampler's split-off draw left to its second launch in
- * the last pmcx_mc_coag (-1: that form did not run); out[1..3] reserved (0).  Synchronises. */
+ * the last pmcx_mc_coag (-1: that form did not run); out[1] = the form it ran in (pmcx_set_sampler_variant's
+ * numbering: 5 with several weight classes); out[2] = with form 5 the rounds it launched (the last one
+ * found no cell left); out[3] reserved (0).  Synchronises. */
 int pmcx_get_sampler_info(pmcx_ctx *ctx, int32_t out[4]);
 
 /* The lists only: the library keeps, per slot, the sort key (group, or "tombstone") it was

@@ -103,8 +103,13 @@ def test_mc_coag_parity_many_classes(wp, oracle, n_class, n_spec, lanes):
     _weights(blk, cells, n_cells, n_class, info["mag"][0, 0])
     ideal = np.full(n_class, n_part / n_class)
     events = 0
+    rounds = []
     for step in range(3):
         ns, nc, st = blk.mc_coag(K_BROWN, 900.0, 21, step)
+        form, n_rounds = blk.sampler_form()
+        # (the library's choice with several classes is the screen + list sweep; a cut list means many rounds)
+        assert form == (lanes[0] if isinstance(lanes, tuple) else (lanes or 5)), form
+        rounds.append(n_rounds)
         for c, oc in enumerate(cells):
             assert oc.mc_coag(K_BROWN, 900.0, 21, oc.cell_id, step) == (int(st[c]), int(ns[c]), int(nc[c])), (step, c)
         assert not np.bitwise_or.reduce(st)
@@ -118,6 +123,8 @@ def test_mc_coag_parity_many_classes(wp, oracle, n_class, n_spec, lanes):
         assert ok, f"step {step} after the rebalance: {msg}"
         assert np.array_equal(blk.get_weights(), np.array([oc.mag for oc in cells]))
     assert events > 60 * n_cells
+    if isinstance(lanes, tuple) and lanes[1] == 1:
+        assert max(rounds) >= 6, rounds       # (64-entry lists: the sweep went on round after round)
     blk.close()
 
 

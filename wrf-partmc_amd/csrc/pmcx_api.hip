@@ -94,6 +94,7 @@ struct pmcx_ctx {
     // distributions kept between calls (a dist passed with gm_radius == NULL refers to them)
     struct ResidentModes { GenSpecDev g{}; void *dd = nullptr, *di = nullptr; } res_modes[2];
     bool sampler_pre_ran = false; // the last pmcx_mc_coag ran the sampler with its draw split off
+    int sampler_form = 0;         // ... in this form (pmcx_set_sampler_variant's numbering)
     int bounds_kernel = 0; // kernel type the kmax tables are valid for (0 = none)
     int bounds_margin = 8;     // bins above a cell's populated range its bounds cover (< 0: whole tables)
     bool bounds_dirty = true;  // something other than mc_coag changed a population since the last check
@@ -1175,7 +1176,7 @@ int pmcx_set_sampler_variant(pmcx_ctx *ctx, int32_t lanes, int32_t wavefronts_pe
 int pmcx_get_sampler_info(pmcx_ctx *ctx, int32_t out[4])
 {
     if (!ctx || !out) return fail(ctx, PMCX_EINVAL, "pmcx_get_sampler_info: null argument");
-    out[0] = -1; out[1] = out[2] = out[3] = 0;
+    out[0] = -1; out[1] = ctx->sampler_form; out[2] = ctx->sampler_form == 5 ? coag_listed_rounds() : 0; out[3] = 0;
     if (!ctx->st.work2 || !ctx->sampler_pre_ran) return PMCX_OK;
     return copy_cells_d2h(ctx, out, ctx->st.work2, sizeof(int32_t));
 }
@@ -1235,6 +1236,7 @@ int pmcx_mc_coag(pmcx_ctx *ctx, int32_t kernel_type, double del_t, uint64_t seed
         ProfScope ps(ctx, "coag_sample");
         HIP_TRY(ctx, launch_coag_sample(ctx->st, kernel_type, del_t, seed, step, ctx->stream));
         ctx->sampler_pre_ran = coag_sample_splits_draw(ctx->st, kernel_type);
+        ctx->sampler_form = coag_sample_form(ctx->st, kernel_type);
     }
     {
         // close holes in the cells where more than 1/compact_den of the slots are tombstones

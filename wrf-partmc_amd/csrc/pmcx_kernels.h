@@ -189,6 +189,8 @@ hipError_t launch_bin_sort(const DeviceState &st, hipStream_t s);
 hipError_t launch_coag_sample(const DeviceState &st, int ktype, double del_t, uint64_t seed,
                               uint32_t step, hipStream_t s);
 bool coag_sample_splits_draw(const DeviceState &st, int ktype); // the form launch_coag_sample picks
+int coag_sample_form(const DeviceState &st, int ktype);  // the form's number (pmcx_set_sampler_variant's lanes)
+int coag_listed_rounds();                                // form 5: rounds launched by the last call (the last one empty)
 hipError_t seq_stamps_read(uint64_t out[12], bool reset); // diagnostic (pmcx_set_sampler_variant, stamps = 1)
 hipError_t launch_comp_upload(const DeviceState &st, int cell_first, int n_up, const int64_t *part_offset,
                               const int32_t *len, const int32_t *source, const double *time, hipStream_t s);

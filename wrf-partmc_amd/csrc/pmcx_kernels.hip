@@ -6719,6 +6719,9 @@ bool coag_sample_splits_draw(const DeviceState &st, int ktype)
 // list ran full or a group outgrew the length the list was made for; every round settles at least one
 // slot with samples or SLIST_CAP - 1 listed ones, so the loop ends.  Two rounds are launched blind (the
 // second finds its work list empty nearly always and returns at once), then the count is looked at.
+static int g_listed_rounds = 0; // rounds the last call took (pmcx_get_sampler_info)
+int coag_listed_rounds() { return g_listed_rounds; }
+int coag_sample_form(const DeviceState &st, int ktype) { return sampler_lanes(st, ktype); }
 static hipError_t launch_coag_listed(const DeviceState &st, int ktype, double del_t, uint64_t seed, uint32_t step,
                                      hipStream_t s)
 {
@@ -6746,7 +6749,7 @@ static hipError_t launch_coag_listed(const DeviceState &st, int ktype, double de
             e = hipMemcpyAsync(&left, out, sizeof(int32_t), hipMemcpyDeviceToHost, s);
             if (e == hipSuccess) e = hipStreamSynchronize(s);
             if (e != hipSuccess) return e;
-            if (left == 0) return hipSuccess;
+            if (left == 0) { g_listed_rounds = round + 1; return hipSuccess; }
         }
         in = out;
         out = (out == st.work2) ? st.work3 : st.work2;

@@ -1330,6 +1330,13 @@ class CellBlock:
         self._ck(self._lib.pmcx_get_sampler_info(self._h, out))
         return int(out[0])
 
+    def sampler_form(self):
+        """(form, rounds) of the last mc_coag: pmcx_set_sampler_variant's numbering (5: several weight
+        classes, the screen and the sweep of its list) and, for form 5, the rounds it launched."""
+        out = (C.c_int32 * 4)()
+        self._ck(self._lib.pmcx_get_sampler_info(self._h, out))
+        return int(out[1]), int(out[2])
+
     def invalidate_lists(self):
         """The lists of every cell are to be rebuilt, from sort keys that still hold."""
         self._ck(self._lib.pmcx_invalidate_lists(self._h))
