@@ -95,6 +95,7 @@ struct pmcx_ctx {
     struct ResidentModes { GenSpecDev g{}; void *dd = nullptr, *di = nullptr; } res_modes[2];
     bool sampler_pre_ran = false; // the last pmcx_mc_coag ran the sampler with its draw split off
     int sampler_form = 0;         // ... in this form (pmcx_set_sampler_variant's numbering)
+    bool cls_fresh = false;       // st.cls_cnt holds the populations as they are (set by pmcx_transport_probs, see HIP_TRY)
     int bounds_kernel = 0; // kernel type the kmax tables are valid for (0 = none)
     int bounds_margin = 8;     // bins above a cell's populated range its bounds cover (< 0: whole tables)
     bool bounds_dirty = true;  // something other than mc_coag changed a population since the last check
@@ -114,6 +115,8 @@ struct pmcx_ctx {
     std::map<std::string, ProfEntry> profile;
     std::vector<hipEvent_t> event_pool;
 };
+static inline void counts_stale(pmcx_ctx *ctx) { if (ctx) ctx->cls_fresh = false; }
+
 
 namespace {
 
@@ -128,8 +131,12 @@ int fail(pmcx_ctx *ctx, int code, const char *fmt, ...)
     return code;
 }
 
+// (any device call of any entry point voids the per-class counts pmcx_transport_probs left for the
+// preweight that follows it at once: whatever came in between may have changed a population)
+static inline void counts_stale(std::nullptr_t) {}
 #define HIP_TRY(ctx, expr)                                                                  \
     do {                                                                                    \
+        counts_stale(ctx);                                                                  \
         hipError_t e_ = (expr);                                                             \
         if (e_ != hipSuccess)                                                               \
             return fail(ctx, e_ == hipErrorOutOfMemory ? PMCX_ENOMEM : PMCX_EDEVICE,        \
@@ -1741,6 +1748,7 @@ int pmcx_transport_probs(pmcx_ctx *ctx, const pmcx_trans_fields *f, double *prob
                                       "sub-steps (z(2) - z(1) too small or exch_h too large; bit 16 of bad[]): "
                                       "the probabilities were not built");
     ctx->probs_nx = nx; ctx->probs_ny = ny;
+    ctx->cls_fresh = cf.n_class > 1;
     return PMCX_OK;
 }
 
@@ -1841,6 +1849,7 @@ int pmcx_transport_preweight(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, 
 {
     if (!ctx || !cell_volume || (!prob_h) != (!prob_v))
         return fail(ctx, PMCX_EINVAL, "pmcx_transport_preweight: null argument");
+    const bool counted = ctx->cls_fresh; // (pmcx_transport_probs was the call in front of this one)
     const bool built = !prob_h;
     if (built && (ctx->probs_nx != nx || ctx->probs_nz != nz || ctx->probs_ny != ny))
         return fail(ctx, PMCX_ESTATE, "pmcx_transport_preweight: no probabilities were built for this grid");
@@ -1872,6 +1881,7 @@ int pmcx_transport_preweight(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_t ny, 
     HIP_TRY(ctx, hipMemsetAsync(d_nr, 0, sizeof(int32_t) * nc, ctx->stream));
     {
         ProfScope ps(ctx, "transport_preweight");
+        ctx->st.cls_fresh = counted ? 1 : 0;
         HIP_TRY(ctx, launch_transport_preweight(ctx->st, nx, nz, ny, periodic_x && periodic_y, d_ph, d_pv,
                                                 d_cv, ctx->d_preweight, ctx->d_preweight + nc * C, d_nr,
                                                 seed, step, ctx->stream));
@@ -1897,6 +1907,7 @@ int pmcx_transport_preweight_begin(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_
 {
     if (!ctx || !cell_volume || !edge_terms || (!prob_h) != (!prob_v))
         return fail(ctx, PMCX_EINVAL, "pmcx_transport_preweight_begin: null argument");
+    const bool counted = ctx->cls_fresh; // (pmcx_transport_probs was the call in front of this one)
     const pmcx_config &cf = ctx->cfg;
     if (nx < 1 || nz < 1 || ny < 3 || nz > 128 || (int64_t)nx * nz * ny != cf.n_cells || global_ny < ny - 2)
         return fail(ctx, PMCX_EINVAL, "pmcx_transport_preweight_begin: nx*nz*ny must equal n_cells, ny >= 3 "
@@ -1936,6 +1947,7 @@ int pmcx_transport_preweight_begin(pmcx_ctx *ctx, int32_t nx, int32_t nz, int32_
     const int ideal = periodic_x && periodic_y;
     {
         ProfScope ps(ctx, "transport_preweight");
+        ctx->st.cls_fresh = counted ? 1 : 0;
         HIP_TRY(ctx, launch_preweight_slab_begin(ctx->st, nx, nz, ny, ideal, j_global0, global_ny, ctx->d_prob_h,
                                                  ctx->d_prob_v, ctx->d_halo_cv, ctx->d_preweight, ctx->d_pw_edge,
                                                  ctx->stream));

@@ -129,6 +129,7 @@ struct DeviceState {
                        // describes the cell while no group is longer
     int32_t *work3;    // [1 + n_cells] count, cells (the rounds alternate between work2 and work3)
     int32_t *cls_cnt;  // [n_cells][n_class] live particles per class (k_class_counts: the transport's probabilities and preweight)
+    int32_t cls_fresh; // 1: cls_cnt holds the populations as they are (the preweight right behind the probabilities)
     // particle%component(:) (interface/wrf_pmc_driver.F90:1421-1437), the first n_comp_max of a
     // particle's list (0: not carried): source ids a byte each (0xFF past the end), create times;
     // the coagulations of the last mc_coag in event order, merged by k_comp_merge behind the sampler

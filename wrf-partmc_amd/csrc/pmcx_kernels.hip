@@ -6483,9 +6483,10 @@ __global__ void k_test_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
 // ------------------------------------------------------------------ launchers
 
 // particles per class of every cell into st.cls_cnt (several classes)
-static void launch_class_counts(const DeviceState &st, hipStream_t s)
+static void launch_class_counts(const DeviceState &st, hipStream_t s, bool reuse = false)
 {
     if (st.n_class <= 1 || !st.cls_cnt) return;
+    if (reuse && st.cls_fresh) return; // (counted by the call in front of this one, nothing since)
     const int n_wg = (st.n_cells + 3) / 4;
     hipLaunchKernelGGL(k_class_counts, dim3(n_wg < 32768 ? n_wg : 32768), dim3(256), 4 * 8 * sizeof(int) * (size_t)st.n_class, s,
                        st, st.cls_cnt);
@@ -7120,7 +7121,7 @@ hipError_t launch_preweight_slab_begin(const DeviceState &st, int nx, int nz, in
     a.nx = nx; a.nz = nz; a.ny = ny; a.ideal = ideal; a.prob_h = prob_h; a.prob_v = prob_v;
     a.cell_volume = cell_volume; a.old = old; a.slab = 1; a.j_global0 = j_global0; a.global_ny = global_ny;
     a.edge_out = edge_out;
-    launch_class_counts(st, s);
+    launch_class_counts(st, s, true);
     hipLaunchKernelGGL(k_preweight_old, dim3((unsigned)(((int64_t)st.n_cells * st.n_class + 63) / 64)), dim3(64), 0, s, st, a);
     const int64_t n = 2 * (int64_t)nx * nz * st.n_class + (st.trans_cut_x ? 2 * (int64_t)ny * nz * st.n_class : 0);
     hipLaunchKernelGGL(k_preweight_edge, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, a);
@@ -7153,7 +7154,7 @@ hipError_t launch_transport_preweight(const DeviceState &st, int nx, int nz, int
     PreweightArgs a{};
     a.nx = nx; a.nz = nz; a.ny = ny; a.ideal = ideal; a.prob_h = prob_h; a.prob_v = prob_v;
     a.cell_volume = cell_volume; a.old = old; a.expect = expect; a.n_removed = n_removed;
-    launch_class_counts(st, s);
+    launch_class_counts(st, s, true);
     hipLaunchKernelGGL(k_preweight_old, dim3((unsigned)(((int64_t)st.n_cells * st.n_class + 63) / 64)), dim3(64), 0, s, st, a);
     const int64_t n = (int64_t)st.n_cells * st.n_class;
     hipLaunchKernelGGL(k_preweight_new, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, st, a);
