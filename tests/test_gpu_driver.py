@@ -120,6 +120,18 @@ def test_wrf_steps_with_tens_of_weight_classes(tmp_path, wp, oracle, n_class, pe
     assert sum(st["n_moved"] for st in steps) > 5 * case.n_cells and sum(st["n_coag"] for st in steps) > 0
 
 
+def test_wrf_steps_in_the_reference_shape(tmp_path, wp, oracle):
+    """Seven WRF steps with the reference's 20 species (WRFV3/test/em_scm_xy/aero_data.dat:2-21) and ten weight
+    classes through the two Fortran drivers: the species sums behind the pair sampler (k_vol_merge), the screen
+    and the sweep of its list, the per-class counts, transport records of 20 species -- every particle, list,
+    weight and gas against the oracle loop."""
+    _build()
+    case = wrf_case.Case(periodic=False, seed=77, n_class=10, n_spec=20, sea_salt_opt=2)
+    steps, final = run_case(case, tmp_path, wp, oracle, oracle_room=12.0)
+    assert sum(st["n_moved"] for st in steps) > 5 * case.n_cells and sum(st["n_coag"] for st in steps) > 0
+    assert all(fc["vol"].shape[0] == 20 for fc in final)
+
+
 @pytest.mark.parametrize("periodic", [True, False])
 def test_a_rank_of_a_cut_domain_through_the_two_drivers(tmp_path, wp, periodic):
     """WRF's only production mode is its patch decomposition (namelist.input.cares_bw_full:57-58; the

@@ -19,16 +19,20 @@ class Case:
     condition), gases, sea salt over the ocean columns, transport from WRF-shaped fields, dry
     deposition on the lowest level."""
 
-    def __init__(self, nx=4, nz=3, ny=4, n_part=300, n_steps=7, periodic=False, seed=91, sea_salt_opt=1, n_class=2):
+    def __init__(self, nx=4, nz=3, ny=4, n_part=300, n_steps=7, periodic=False, seed=91, sea_salt_opt=1, n_class=2,
+                 n_spec=3):
         self.nx, self.nz, self.ny, self.n_part, self.n_steps = nx, nz, ny, n_part, n_steps
         self.periodic, self.seed, self.sea_salt_opt = periodic, seed, sea_salt_opt
         self.n_cells = nx * nz * ny
-        self.n_spec, self.n_class, self.n_source, self.n_gas = 3, n_class, 3, 5
+        self.n_spec, self.n_class, self.n_source, self.n_gas = n_spec, n_class, 3, 5
         self.i_na, self.i_cl = 2, 3                         # 1-based species of the sea-salt source
         self.dt, self.chem_dt, self.dx, self.dy = 20.0, 60.0, 3000.0, 3000.0
         self.vertmix = 1
         self.num_particles = float(n_part)
-        self.density = np.array([1770.0, 1900.0, 1900.0])
+        # (more than three species: the densities of WRFV3/test/em_scm_xy/aero_data.dat:2-21 behind the first three)
+        scm = [1770.0, 1770.0, 1900.0, 1770.0, 1800.0, 1400.0, 1400.0, 1400.0, 1400.0, 1000.0, 1400.0, 1400.0, 1400.0,
+               2600.0, 1900.0, 2600.0, 2600.0, 1000.0, 1700.0, 1000.0]
+        self.density = np.array(([1770.0, 1900.0, 1900.0] + scm[3:] + [1500.0] * n_spec)[:n_spec])
         r = self.r = np.random.RandomState(seed)
         n = self.n_cells
         # (more than two classes -- the registry carries 40, registry.partmc_trans:2-41: the initial particles sit
