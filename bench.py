@@ -360,12 +360,15 @@ def main():
                     help="weight classes (WRFV3/Registry/registry.partmc_trans:2-41 carries 40): the idealised mode "
                          "split evenly over them, class c standing for (1 + c / 2) times class 0's number "
                          "(a side measurement: no CPU leg; the screen + list-sweep form of the sampler, DESIGN.md 5.3)")
+    ap.add_argument("--cap-factor", type=float, default=1.0,
+                    help="slots per cell / particles per cell (1: the headline's; the Fortran shim's default headroom is 3; "
+                         "with tens of classes the lists' layout needs the room, DESIGN.md 4)")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="no GPU needed: launch, rendezvous (gloo), partition and aggregation only; value null")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))       # (nothing has touched the GPU yet)
-    args.cap = (args.particles + 63) // 64 * 64
+    args.cap = (int(args.particles * args.cap_factor) + 63) // 64 * 64
     config3 = args.workload == "config3"
     if config3:
         args.nx, args.ny, args.levels, args.n_spec = 10, 10, 10, 20
