@@ -711,8 +711,9 @@ __global__ __launch_bounds__(256) void k_list_cells(DeviceState st, int what, in
 }
 
 // stage: the cell's keys are copied to LDS (2 bytes a slot of `cap`) and both passes read them there; 0: they
-// are read from memory twice (tens of weight classes: the per-wavefront tables take the room -- with ten
-// classes and cap = 22 016 one workgroup filled a CU's LDS where three fit without the copy)
+// are read from memory twice, the second time 512 at a time through a small buffer of the wavefront's own
+// (the default: with ten classes and cap = 22 016 the copy left one workgroup a CU where three fit
+// without it, and with one class the form without the copy is the faster one too)
 __global__ __launch_bounds__(256) void k_bin_sort(DeviceState st, const int32_t *list,
                                                   const int32_t *count, int stage)
 {
@@ -6500,10 +6501,13 @@ static size_t bin_sort_lds_for(const DeviceState &st, int nw, bool stage)
     // (without the copy: two halves of 512 keys per wavefront)
     return o_key + (stage ? sizeof(uint16_t) * (((size_t)st.cap + 7) & ~(size_t)7) : sizeof(uint16_t) * 1024 * (size_t)nw);
 }
-// the keys' copy in LDS while three workgroups still share a CU with it
+// The keys' whole copy in LDS only where they cannot be taken eight to a request (cap not a multiple of
+// 8); else 512 at a time through the wavefront's rolling buffer: with one class too that is the faster
+// form (scripts/gpu_ab_sort.sh: 6.4 -> 5.7 ms per launch in the coupled step, a chemistry step 13.7 ->
+// 12.8 ms: four workgroups a CU instead of three, no second pass through 44 KB of LDS)
 static bool bin_sort_stage(const DeviceState &st)
 {
-    return bin_sort_lds_for(st, 4, true) <= (size_t)53 * 1024;
+    return (st.cap & 7) != 0 && bin_sort_lds_for(st, 4, true) <= (size_t)150 * 1024;
 }
 // wavefronts per workgroup of k_bin_sort: four, fewer where their tables would not fit in LDS
 int bin_sort_waves(const DeviceState &st)
