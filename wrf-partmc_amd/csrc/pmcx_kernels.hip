@@ -6501,13 +6501,15 @@ static size_t bin_sort_lds_for(const DeviceState &st, int nw, bool stage)
     // (without the copy: two halves of 512 keys per wavefront)
     return o_key + (stage ? sizeof(uint16_t) * (((size_t)st.cap + 7) & ~(size_t)7) : sizeof(uint16_t) * 1024 * (size_t)nw);
 }
-// The keys' whole copy in LDS only where they cannot be taken eight to a request (cap not a multiple of
-// 8); else 512 at a time through the wavefront's rolling buffer: with one class too that is the faster
-// form (scripts/gpu_ab_sort.sh: 6.4 -> 5.7 ms per launch in the coupled step, a chemistry step 13.7 ->
-// 12.8 ms: four workgroups a CU instead of three, no second pass through 44 KB of LDS)
+// The keys' whole copy in LDS while five workgroups share a CU with it (30 KB: the headline's cap = 10 048
+// with one class, 9.85 ms for 3*10^9 slots against 10.0 without the copy), or where the keys cannot be
+// taken eight to a request (cap not a multiple of 8); else 512 at a time through the wavefront's rolling
+// buffer -- the coupled step's cap = 22 016 with one class: 6.4 -> 5.7 ms per launch, a chemistry step
+// 13.7 -> 12.8 ms (scripts/gpu_ab_sort.sh); ten classes: 15.7 -> 9.6 ms
 static bool bin_sort_stage(const DeviceState &st)
 {
-    return (st.cap & 7) != 0 && bin_sort_lds_for(st, 4, true) <= (size_t)150 * 1024;
+    const size_t with_copy = bin_sort_lds_for(st, 4, true);
+    return with_copy <= (size_t)30 * 1024 || ((st.cap & 7) != 0 && with_copy <= (size_t)150 * 1024);
 }
 // wavefronts per workgroup of k_bin_sort: four, fewer where their tables would not fit in LDS
 int bin_sort_waves(const DeviceState &st)
