@@ -21,10 +21,13 @@ events = 0
 for run in range(n_runs):
     kernel = int(rng.choice([4, 4, 4, 1, 101, 2, 3]))
     n_class = int(rng.choice([1, 1, 2, 3, 10, 40]))
-    n_spec = int(rng.choice([1, 1, 2, 5]))
+    n_spec = int(rng.choice([1, 1, 2, 5, 20]))
     n_cells = int(rng.choice([1, 3, 64, 65, 130]))
     n_part = int(rng.choice([50, 300, 1000, 2500]))
-    variant = [None, (1, 0, 0), (2, 0, 0), (3, 0, 0), (8, 0, 0), (16, 0, 0), (64, 0, 0)][rng.randint(7)]
+    # (None: the library's choice -- with several classes the screen + list sweep; (5, 1), (5, 2): that with a
+    # cell's list cut to 64 / 256 entries: many rounds; (4, 0, 0): the cells of a workgroup grouped by state)
+    variant = [None, (1, 0, 0), (2, 0, 0), (3, 0, 0), (8, 0, 0), (16, 0, 0), (64, 0, 0), None, (5, 1, 0), (5, 2, 0),
+               (4, 0, 0)][rng.randint(11)]
     if n_class >= 10 and variant is not None and variant[0] in (8, 16):
         variant = (64, 0, 0)      # (the list state of eight or four such cells does not fit a workgroup's LDS)
     kc = int(rng.choice([0, 0, 2, 8]))
