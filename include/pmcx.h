@@ -241,9 +241,12 @@ int pmcx_set_kernel_bounds_margin(pmcx_ctx *ctx, int32_t margin);
 
 /*
  * mc_coag on every cell (wrf_pmc_driver.F90:192-194).  Asynchronous on the
- * context's stream.  seed = grid%random_seed (wrf_pmc_init.F90:131); step =
- * chemistry-step index; together with the global cell id they key the
- * counter-based RNG.
+ * context's stream with one weight class; with several the call waits for the
+ * device once or more (its pair sampler works in rounds and reads back whether a
+ * cell is left).  seed = grid%random_seed (wrf_pmc_init.F90:131);
+ * step = chemistry-step index; together with the global cell id they key the
+ * counter-based RNG.  The species volumes of coagulated particles are summed
+ * behind the sampler, in event order, from the log of its events (n_spec > 1).
  */
 int pmcx_mc_coag(pmcx_ctx *ctx, int32_t kernel_type, double del_t, uint64_t seed,
                  uint32_t step);
